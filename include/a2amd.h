@@ -1,0 +1,201 @@
+/*
+ * a2amd.h - C ABI of the MI355X voice-render backend ("liba2amd.so")
+ *
+ * This is the drop-in boundary for ONE path of Audiality 2: the per-voice
+ * unit-generator render loop.  The host (the unmodified Audiality 2 engine:
+ * A2S VM, event scheduler, voice tree) keeps running on the CPU and forwards
+ * the four callbacks of its unit plugin surface to this library, which records
+ * them per fragment and evaluates all recorded unit chains on the GPU.
+ *
+ * Every entry point below names the reference interface it stands in for
+ * (path:line under the reference tree).  Plain C types only: no torch, no HIP
+ * types (a hipStream_t / device pointer travels as void*).
+ *
+ *   reference callback / call site                       entry point here
+ *   --------------------------------------------------   -----------------------
+ *   A2_unitdesc.OpenState   include/a2_units.h:159       a2amd_open
+ *   A2_unitdesc.CloseState  include/a2_units.h:160       a2amd_close
+ *   A2_unitdesc.Initialize  include/a2_units.h:132       a2amd_unit_init
+ *        (called from a2_AddUnit, src/core.c:290)
+ *   A2_unitdesc.Deinitialize include/a2_units.h:142      a2amd_unit_deinit
+ *        (called from a2_DestroyUnit, src/core.c:318)
+ *   A2_crdesc.write         include/a2_units.h:115       a2amd_unit_write
+ *        (called from a2_VoiceControl, src/core.c:143)
+ *   A2_unit.Process         include/a2_units.h:176       a2amd_unit_process
+ *        (called from a2_VoiceProcess, src/core.c:1875)
+ *   a2_inline_Process[Add]  src/core.c:1763-1776         a2amd_unit_process + a2amd_inline_end
+ *   a2_GetWave/A2_wave      include/a2_waves.h:88-103    a2amd_wave_upload / a2amd_wave_drop
+ *   a2_AudioCallback fragment loop src/core.c:1964-1973  a2amd_fragment
+ *   a2_ProcessMaster        src/core.c:1900-1907         a2amd_render (master bus -> caller)
+ *
+ * Numeric formats are the reference's: audio 8:24 int32, control values 16:16,
+ * ramp durations 24:8 frames, sub-sample start 0..255.
+ *
+ * Threading: like the reference's unit callbacks, all calls for one context
+ * come from one thread (the engine context of one A2 state).
+ */
+#ifndef A2AMD_H
+#define A2AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A2AMD_MAXFRAG      64   /* A2_MAXFRAG, include/audiality2.h.cmake:50 */
+#define A2AMD_MAXCHANNELS   8   /* A2_MAXCHANNELS, include/audiality2.h.cmake:56 */
+#define A2AMD_MIPLEVELS    10   /* A2_MIPLEVELS, include/a2_waves.h:33 */
+#define A2AMD_WAVEPRE       1   /* A2_WAVEPRE,  include/a2_waves.h:60 */
+#define A2AMD_WAVEPOST    131   /* A2_WAVEPOST, include/a2_waves.h:63-64 */
+#define A2AMD_MAXCHAIN      8   /* max units in one voice's chain (ours) */
+
+typedef struct a2amd_ctx a2amd_ctx;
+
+/* Error codes (negative returns).  0 = OK. */
+typedef enum a2amd_errors {
+	A2AMD_OK = 0,
+	A2AMD_ENODEVICE   = -1,  /* no HIP device / HIP runtime failure       */
+	A2AMD_EINVAL      = -2,  /* bad argument                               */
+	A2AMD_ENOMEM      = -3,
+	A2AMD_EUNSUPPORTED= -4,  /* chain / mode outside the hot-path scope    */
+	A2AMD_ESTATE      = -5,  /* call out of sequence                       */
+	A2AMD_EHIP        = -6   /* a HIP call failed; see a2amd_last_error()  */
+} a2amd_errors;
+
+/* Unit kinds on the hot path. */
+typedef enum a2amd_unitkind {
+	A2AMD_WTOSC = 0,     /* src/units/wtosc.c    regs: w p a phase            */
+	A2AMD_PANMIX,        /* src/units/panmix.c   regs: vol pan                */
+	A2AMD_FILTER12,      /* src/units/filter12.c regs: cutoff q lp bp hp      */
+	A2AMD_FBDELAY,       /* src/units/fbdelay.c  regs: fbdelay ldelay rdelay drygain fbgain lgain rgain */
+	A2AMD_INLINE,        /* src/units/inline.c + src/core.c:1763-1776         */
+	A2AMD_XINSERT,       /* src/units/xinsert.c:145-161 (bypass only)         */
+	A2AMD_NKINDS
+} a2amd_unitkind;
+
+/* A2_unitflags bit the units care about (include/a2_units.h:72). */
+#define A2AMD_PROCADD 0x00000001u
+
+/* A2_wavetypes (include/a2_waves.h:79-85) and A2_LOOPED (:112). */
+#define A2AMD_WOFF     0
+#define A2AMD_WNOISE   1
+#define A2AMD_WWAVE    2
+#define A2AMD_WMIPWAVE 3
+#define A2AMD_LOOPED   0x00000100u
+
+typedef struct a2amd_config {
+	uint32_t struct_size;   /* sizeof(a2amd_config), for ABI growth          */
+	int32_t  samplerate;    /* A2_config.samplerate                           */
+	int32_t  basepitch;     /* A2_config.basepitch (16:16), audiality2.c:398  */
+	int32_t  channels;      /* master bus channels, 1..8                      */
+	int32_t  device;        /* HIP device ordinal                             */
+	uint32_t max_batch;     /* max fragments recorded between renders (>=1)   */
+	void    *stream;        /* hipStream_t to launch on; NULL = own stream    */
+} a2amd_config;
+
+/* Mirror of A2_wave (include/a2_waves.h:88-103); data[] point at the first pad
+ * sample (i.e. the reference's w->d.wave.data[i], which has A2_WAVEPRE samples
+ * before and A2_WAVEPOST after the size[i] payload samples). */
+typedef struct a2amd_wavedesc {
+	int32_t  type;                      /* A2AMD_W*                           */
+	uint32_t flags;                     /* A2AMD_LOOPED ...                   */
+	uint32_t period;
+	uint32_t size[A2AMD_MIPLEVELS];     /* payload samples per level          */
+	const int16_t *data[A2AMD_MIPLEVELS];
+} a2amd_wavedesc;
+
+/* ---- state ---------------------------------------------------------------*/
+int  a2amd_open(const a2amd_config *cfg, a2amd_ctx **out);
+void a2amd_close(a2amd_ctx *ctx);
+const char *a2amd_last_error(const a2amd_ctx *ctx);   /* ctx may be NULL */
+const char *a2amd_version(void);
+
+/* The 64x{base,coeff} table of a2_P2I (src/pitch.c:57-96).  a2amd_open builds
+ * it with the host's powf exactly as the reference does; a host that wants the
+ * engine's own table bit-for-bit may overwrite it (128 uint32). */
+int  a2amd_set_pitch_table(a2amd_ctx *ctx, const uint32_t *tab128);
+int  a2amd_get_pitch_table(const a2amd_ctx *ctx, uint32_t *tab128);
+
+/* ---- waves ---------------------------------------------------------------*/
+/* Upload all mip levels incl. pads.  'key' is whatever identifies the wave on
+ * the host (the A2_wave pointer); returns a wave id >= 0 to be used as the
+ * value of a wtosc 'w' write.  Re-uploading an existing key refreshes it. */
+int  a2amd_wave_upload(a2amd_ctx *ctx, uint64_t key, const a2amd_wavedesc *w);
+/* Host wave was unloaded (size[0] == 0, src/waves.c:717-723): oscillators
+ * still pointing at it fall silent like wtosc_check_unloaded (wtosc.c:168). */
+int  a2amd_wave_drop(a2amd_ctx *ctx, uint64_t key);
+
+/* ---- fragment clock --------------------------------------------------------*/
+/* Begin the next fragment of 'frames' (1..64) sample frames; all following
+ * init/write/process calls belong to it (src/core.c:1964-1973). */
+int  a2amd_fragment(a2amd_ctx *ctx, unsigned frames);
+
+/* ---- unit callbacks --------------------------------------------------------*/
+/*
+ * Initialize.  'voice_key' identifies the owning voice (the A2_vmstate pointer
+ * handed to Initialize); consecutive inits with the same key form that voice's
+ * chain in order (a2_PopulateVoice, src/core.c:350-420).  'wired_out' != 0 when
+ * the unit's outputs are the voice's output bus (A2_IO_WIREOUT, core.c:240-243)
+ * rather than the scratch bus.  'transpose' = vms->r[R_TRANSPOSE],
+ * 'wakefrac' = vms->waketime & 0xff (wtosc.c:400-407).
+ * Returns a unit id >= 0.
+ */
+int  a2amd_unit_init(a2amd_ctx *ctx, uint64_t voice_key, int kind,
+		unsigned flags, int ninputs, int noutputs, int wired_out,
+		int transpose, unsigned wakefrac);
+int  a2amd_unit_deinit(a2amd_ctx *ctx, int unit);
+
+/* Control register write; 'reg' indexes the unit's register table in the
+ * reference's order.  For wtosc reg 0 ('w') 'value' is a wave id from
+ * a2amd_wave_upload() (or -1 for no wave) instead of a 16:16 handle.
+ * 'transpose' = current vms->r[R_TRANSPOSE] (read by wtosc 'p' and filter12
+ * 'cutoff', wtosc.c:489, filter12.c:144). */
+int  a2amd_unit_write(a2amd_ctx *ctx, int unit, int reg, int value,
+		unsigned start, unsigned duration, int transpose);
+
+/* Process [offset, offset+frames) of the current fragment.  'noisestate'
+ * points at the engine-global RNG word (A2_state.noisestate, internals.h:682)
+ * or NULL; a wtosc in noise mode consumes draws from it in call order exactly
+ * like wtosc_noise (wtosc.c:129-152), so VM RAND instructions interleave
+ * correctly. */
+int  a2amd_unit_process(a2amd_ctx *ctx, int unit, unsigned offset,
+		unsigned frames, uint32_t *noisestate);
+/* Closes the window opened by a2amd_unit_process() on an A2AMD_INLINE unit,
+ * i.e. the return of a2_ProcessSubvoices (src/core.c:1769,1775). */
+int  a2amd_inline_end(a2amd_ctx *ctx, int unit);
+
+/* ---- render ----------------------------------------------------------------*/
+#define A2AMD_RENDER_SUBTREES 1u  /* everything below the root voice's bus   */
+#define A2AMD_RENDER_ROOT     2u  /* root voice chain -> master bus           */
+#define A2AMD_RENDER_ALL      3u
+/*
+ * Evaluate the recorded fragments on the GPU.  With A2AMD_RENDER_ALL the
+ * master bus of every recorded fragment is written, planar, to
+ * out[c][0..total_frames) (host pointers; a2_ProcessMaster) and the recording
+ * restarts.  Multi-GPU: run SUBTREES, reduce a2amd_rootbus() across ranks
+ * (int32 sum is order independent), then ROOT on the rank that owns the root
+ * chain.  Returns the number of frames rendered or a negative error.
+ */
+int  a2amd_render(a2amd_ctx *ctx, unsigned phases, int32_t *const *out,
+		unsigned out_capacity_frames);
+/* Device pointer + size (bytes) of the root voice's inline bus partials for
+ * the fragments of the current batch: int32 [batch][channels][64]. */
+int  a2amd_rootbus(a2amd_ctx *ctx, void **devptr, uint64_t *bytes);
+
+/* ---- introspection (tests, bench) --------------------------------------*/
+typedef struct a2amd_stats {
+	uint64_t fragments;        /* fragments rendered so far                 */
+	uint64_t voice_fragments;  /* sum over fragments of voices processed    */
+	uint64_t records;          /* command records shipped                   */
+	uint64_t launches;         /* kernel launches                           */
+	double   last_kernel_ms;   /* HIP-event time of the last batch's kernels */
+	double   last_leaf_ms;     /* ... of the leaf-voice kernel alone        */
+	uint32_t live_units, live_voices, live_waves, reserved;
+} a2amd_stats;
+int  a2amd_get_stats(const a2amd_ctx *ctx, a2amd_stats *st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* A2AMD_H */
