@@ -1,0 +1,42 @@
+"""Build recipes: liba2amd.so (hipcc, gfx950) and the test oracle (gcc)."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_lib(force=False):
+    csrc = os.path.join(HERE, "csrc")
+    srcs = [os.path.join(csrc, "a2amd_host.cpp"), os.path.join(csrc, "a2amd_kernels.hip")]
+    deps = srcs + [os.path.join(csrc, "a2amd_device.h"), os.path.join(ROOT, "include", "a2amd.h")]
+    out = os.path.join(HERE, "liba2amd.so")
+    if force or _newer(out, deps):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-Wno-unused-value", "-o", out] + srcs
+        subprocess.run(cmd, check=True)
+    return out
+
+
+def build_oracle(force=False):
+    """Test infrastructure: the CPU restatement and, when the reference tree
+    is present, the compiled reference + its harness (oracle/_ref)."""
+    odir = os.path.join(ROOT, "oracle")
+    targets = ["restate"]
+    if os.path.exists("/root/reference/src/core.c") and shutil.which("cmake"):
+        targets += ["ref", "tools"]
+    subprocess.run(["make", "-s", "-C", odir] + (["-B"] if force else []) + targets, check=True)
+    return os.path.join(odir, "liba2oracle.so")
+
+
+def build_all(force=False):
+    return build_lib(force), build_oracle(force)

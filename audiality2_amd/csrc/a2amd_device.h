@@ -1,0 +1,110 @@
+// a2amd_device.h - data layout shared by the host recorder and the HIP kernels.
+//
+// Everything the kernels touch lives in a handful of flat device arrays; the
+// host owns the *structure* (which units form a voice, where a voice's output
+// lands), the device owns the *signal state* (phases, rampers, filter and
+// delay memories) and only ever changes it by executing command records.
+#pragma once
+#include <stdint.h>
+
+#define A2D_MAXCHAIN   8      // units per voice (A2AMD_MAXCHAIN)
+#define A2D_USTATE    24      // int32 words of device state per unit
+#define A2D_MAXCH      8
+#define A2D_FRAG      64
+#define A2D_MIPS      10
+#define A2D_FBD_BUFSIZE 131072          // fbdelay.c:27
+#define A2D_MAXPHINC  512               // a2_waves.h:57
+#define A2D_WTOSC_MAXLENGTH (0x01000000 - 1 - 131)   // wtosc.c:55
+
+// unit kinds: numerically equal to a2amd_unitkind
+enum { A2D_WTOSC = 0, A2D_PANMIX, A2D_FILTER12, A2D_FBDELAY, A2D_INLINE, A2D_XINSERT };
+
+// wtosc Process variants (the reference swaps u->Process, wtosc.c:433-483)
+enum { A2D_OSC_OFF = 0, A2D_OSC_NOISE, A2D_OSC_WAVE, A2D_OSC_MIPWAVE };
+
+// packed static description of a unit instance (host owned)
+//   bits 0-3 kind, 4 add (A2_PROCADD), 8-11 ninputs, 12-15 noutputs, 16 wired out
+#define A2D_DESC(kind, add, nin, nout, wired) \
+	((uint32_t)(kind) | ((uint32_t)(add) << 4) | ((uint32_t)(nin) << 8) | \
+	 ((uint32_t)(nout) << 12) | ((uint32_t)(wired) << 16))
+#define A2D_KIND(d)  ((d) & 15u)
+#define A2D_ADD(d)   (((d) >> 4) & 1u)
+#define A2D_NIN(d)   (((d) >> 8) & 15u)
+#define A2D_NOUT(d)  (((d) >> 12) & 15u)
+#define A2D_WIRED(d) (((d) >> 16) & 1u)
+
+// device unit state word indices ------------------------------------------
+// ramper = 4 consecutive words {value, target, delta, timer} (a2_dsp.h:105)
+enum {	// wtosc (A2_wtosc, wtosc.c:66-80)
+	OW_MODE = 0, OW_WAVE, OW_DPHASE, OW_PHASE_LO, OW_PHASE_HI, OW_NOISE,
+	OW_PRAMPING, OW_P = 7, OW_A = 11, OW_SEED = 15 };
+enum {	// panmix (A2_panmix, panmix.c:35-40)
+	PW_VOL = 0, PW_PAN = 4 };
+enum {	// filter12 (A2_filter12, filter12.c:36-56); the cutoff ramper and the
+	// float coefficient maths stay on the host, which ships f1 values
+	FW_Q = 0, FW_LP = 4, FW_BP, FW_HP, FW_F1, FW_D1A, FW_D1B, FW_D2A, FW_D2B,
+	FW_F1NEXT, FW_RAMP };
+enum {	// fbdelay (A2_fbdelay, fbdelay.c:41-60)
+	DW_FBDELAY = 0, DW_LDELAY, DW_RDELAY, DW_DRYGAIN, DW_FBGAIN, DW_LGAIN,
+	DW_RGAIN, DW_BUFPOS, DW_BUFIDX };
+
+// mirror of A2_wave for the device: offsets index the int16 wave pool and point
+// at the first PAYLOAD sample of a level (i.e. data[level] + A2_WAVEPRE)
+struct A2DWave {
+	int32_t  type;
+	uint32_t flags;
+	uint32_t period;
+	uint32_t size[A2D_MIPS];
+	uint32_t off[A2D_MIPS];
+	uint32_t pad;
+};
+
+// one voice = one unit chain (host owned)
+struct A2DVoice {
+	int32_t nunits;
+	int32_t unit[A2D_MAXCHAIN];	// indices into udesc[] / ustate[]
+	int32_t out_off, out_nch;	// bus the wired outputs add into (int32 offset into busmem)
+	int32_t own_off, own_nch;	// bus our 'inline' unit collects children in, or -1
+	int32_t pad[3];
+};
+
+// command record, 16 bytes
+struct A2DRec {
+	uint32_t head;		// frag:16 | op:8 | unit:4 | reg:4
+	int32_t  value;
+	uint32_t dur;		// SEG: offset | frames << 16
+	uint32_t start;
+};
+enum { R_SEG = 1, R_WRITE, R_INIT, R_KILL, R_F1SET, R_F1RAMP, R_NOISESEED, R_NOP };
+#define A2D_HEAD(frag, op, unit, reg) \
+	((uint32_t)(frag) | ((uint32_t)(op) << 16) | ((uint32_t)(unit) << 24) | ((uint32_t)(reg) << 28))
+#define A2D_RFRAG(h) ((h) & 0xffffu)
+#define A2D_ROP(h)   (((h) >> 16) & 0xffu)
+#define A2D_RUNIT(h) (((h) >> 24) & 15u)
+#define A2D_RREG(h)  (((h) >> 28) & 15u)
+
+struct A2DRun { int32_t first, count; };
+
+#define A2D_MAXBATCH 256
+#define A2D_MAXVPW   32       // voices one wavefront may walk per fragment
+
+struct A2DParams {
+	const A2DVoice *voices;
+	const uint32_t *udesc;
+	int32_t        *ustate;		// [unit][A2D_USTATE]
+	int32_t        *vactive;	// [voice slot]
+	const A2DRun   *runs;		// [voice slot], this batch
+	const A2DRec   *recs;
+	const A2DWave  *waves;
+	const int16_t  *wavepool;
+	int32_t        *busmem;
+	int32_t        *fbdmem;		// [bufidx][2][A2D_FBD_BUFSIZE]
+	const uint32_t *ptab;		// 64 x {base, coeff}, pitch.c:70-96
+	int32_t         nfrags;
+	int32_t         samplerate;
+	uint8_t         fragframes[A2D_MAXBATCH];
+};
+
+// launchers implemented in a2amd_kernels.hip (stream = hipStream_t)
+// dparams / dlist are device pointers; 'vpw' voices of the list per wavefront
+int a2d_launch_voices(const A2DParams *dparams, const int *dlist, int nlist, int vpw, void *stream);

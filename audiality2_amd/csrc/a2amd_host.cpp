@@ -1,0 +1,1149 @@
+// a2amd_host.cpp - host half of liba2amd.so: the C ABI of include/a2amd.h.
+//
+// Records what the Audiality 2 engine asks of its units during a batch of
+// fragments (per voice, in call order), keeps the little host-side state the
+// reference itself computes with libm or draws from the engine-global RNG
+// (filter12's cutoff -> coefficient, the noise oscillators' draw counts), and
+// at a2amd_render() ships the records and launches the kernels:
+//
+//   leaf voices (no 'inline' unit)            one launch, all in parallel
+//   voices with an 'inline' unit, by nesting  one launch per depth, deepest first
+//
+// which is the reference's depth-first voice walk (src/core.c:1883-1896) turned
+// inside out: children only ever ADD into the bus their parent's inline unit
+// collects (core.c:479-480, inline.c:32-33), so all children of all parents can
+// run first and each parent picks the sum up where its inline unit sits.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <vector>
+
+#include "../../include/a2amd.h"
+#include "a2amd_device.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+// ---- host copies of the few reference formulas the host must evaluate ----
+struct Ramp { int value, target, delta, timer; };
+
+inline int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+inline int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+inline int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+
+// a2_InitRamper / a2_PrepareRamper / a2_RunRamper / a2_SetRamper, a2_dsp.h:121-170
+void ramp_init(Ramp &r, int v) { r.value = r.target = (int)((unsigned)v << 8); r.delta = r.timer = 0; }
+void ramp_prepare(Ramp &r, int frames)
+{
+	if(!r.timer) {
+		r.value = r.target;
+		r.delta = 0;
+	} else if(frames <= (r.timer >> 8)) {
+		r.delta = (int)((((int64_t)wsub(r.target, r.value)) * 256) / r.timer);
+		r.timer = wsub(r.timer, frames << 8);
+	} else {
+		r.delta = wsub(r.target, r.value) / frames;
+		r.timer = 0;
+	}
+}
+void ramp_run(Ramp &r, int frames) { r.value = wadd(r.value, wmul(r.delta, frames)); }
+void ramp_set(Ramp &r, int target, int start, int duration)
+{
+	r.target = (int)((unsigned)target << 8);
+	r.timer = wadd(duration, start);
+	if(r.timer < 256)
+		r.value = r.target;
+	else
+		r.value = wadd(r.value, wmul(r.delta, start) >> 8);
+}
+
+// a2_pitch_open, pitch.c:70-96
+void build_pitch_table(uint32_t *tab)
+{
+	unsigned b = 0x80000000u;
+	for(unsigned i = 0; i < 64; ++i) {
+		unsigned b2 = (unsigned)((double)0x80000000u * powf(2.0f, (i + 1) * (1.0f / 64)) + 0.5f);
+		tab[2 * i] = b;
+		tab[2 * i + 1] = (b2 - b + 128) >> 8;
+		b = b2;
+	}
+}
+
+// a2_P2I, pitch.c:57-67
+unsigned p2i(const uint32_t *tab, int pitch)
+{
+	int n = pitch & 0xffff, oct = pitch >> 16;
+	unsigned dph = tab[2 * (n >> 10) + 1] * (unsigned)(n & 0x3ff);
+	dph >>= 2;
+	dph += tab[2 * (n >> 10)];
+	return dph >> ((unsigned)(7 - oct) & 31u);
+}
+
+// f12_pitch2coeff, filter12.c:65-72 -- float/double libm maths: host only
+int f12_coeff(const uint32_t *tab, int cutoff_value, int samplerate)
+{
+	float f = p2i(tab, cutoff_value >> 8) * (261.626f / 16777216.0f);
+	if(f > (samplerate >> 2))
+		return 362 << 16;
+	return (int)(512.0f * 65536.0f * sin(M_PI * f / samplerate));
+}
+
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if(e_ != hipSuccess) \
+	return (c)->fail(A2AMD_EHIP, "%s: %s", #call, hipGetErrorString(e_)); } while(0)
+
+template<class T> struct DevBuf {
+	T *d = nullptr;
+	size_t cap = 0;
+};
+
+struct HUnit {
+	bool live = false;
+	int kind = 0;
+	unsigned flags = 0;
+	int nin = 0, nout = 0, wired = 0;
+	int voice = -1, chainpos = 0;
+	// wtosc shadow: enough of A2_wtosc to count noise draws on the host
+	int mode = A2D_OSC_OFF, wave = -1;
+	bool shadow_ok = true;
+	Ramp p = {0, 0, 0, 0};
+	unsigned dphase = 0;
+	uint64_t phase = 0;
+	int p_ramping = 0;
+	// filter12 shadow: the cutoff ramper never leaves the host
+	Ramp cutoff = {0, 0, 0, 0};
+	// fbdelay: delay line pair index
+	int fbdbuf = -1;
+};
+
+struct HVoice {
+	bool live = false, dying = false;
+	uint64_t key = 0;
+	int nunits = 0, nlive = 0;
+	int unit[A2D_MAXCHAIN];
+	bool resolved = false, started = false;
+	int depth = 0;
+	int inline_pos = -1;		// chain position of the inline unit, if any
+	int out_off = 0, out_nch = 0;
+	int own_off = -1, own_nch = 0;
+	int win_off = -1, win_frames = 0;
+	std::vector<A2DRec> recs;	// this batch, fragment order
+	int touched = -1;		// fragment tag of the last touch
+	size_t frag_mark = 0;		// recs.size() when that fragment was first touched
+};
+
+struct HWave {
+	bool live = false;
+	uint64_t key = 0;
+	A2DWave dw;
+};
+
+} // namespace
+
+struct a2amd_ctx {
+	a2amd_config cfg;
+	char err[256];
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+	uint32_t ptab[128];
+
+	std::vector<HUnit> units;
+	std::vector<int> free_units, deferred_free_units;
+	std::vector<HVoice> voices;
+	std::vector<int> free_voices, deferred_free_voices;
+	std::vector<HWave> waves;
+	int building = -1;
+	std::vector<int> stack;			// open inline windows (unit ids)
+	std::vector<int> touched_list;
+	int n_started_live = 0;			// voices the engine is walking
+	int n_noise = 0, n_cutoff_ramps = 0;
+
+	// fragment clock
+	bool frag_open = false;
+	int cur_frag = 0, nfrags = 0;
+	unsigned fragframes[A2D_MAXBATCH];
+	bool uploaded = false;
+
+	// host mirrors of host-owned device tables
+	std::vector<A2DVoice> mvoices;
+	std::vector<uint32_t> mudesc;
+	std::vector<A2DWave> mwaves;
+	bool voices_dirty = true, udesc_dirty = true, waves_dirty = true, lists_dirty = true, ptab_dirty = true;
+	std::vector<int> list_all;		// leaf list followed by per-depth lists
+	int n_leaf = 0;
+	std::vector<std::pair<int,int>> depth_ranges;	// (first, count) per depth, index = depth
+
+	// bus memory allocator (units of int32)
+	size_t bus_stride_frames;
+	size_t bus_used = 0;
+	std::map<int, std::vector<int>> bus_free;	// nch -> offsets
+	std::vector<std::pair<int,int>> deferred_bus_free;
+
+	// fbdelay buffers
+	int fbd_count = 0;
+	std::vector<int> fbd_free, fbd_deferred_free, fbd_to_zero;
+
+	// wave pool (int16 samples)
+	size_t wavepool_used = 0;
+
+	DevBuf<A2DVoice> d_voices;
+	DevBuf<uint32_t> d_udesc;
+	DevBuf<int32_t> d_ustate;	// cap in units
+	DevBuf<int32_t> d_vactive;
+	DevBuf<A2DRun> d_runs;
+	DevBuf<A2DRec> d_recs;
+	DevBuf<A2DWave> d_waves;
+	DevBuf<int16_t> d_wavepool;
+	DevBuf<int32_t> d_busmem;
+	DevBuf<int32_t> d_fbdmem;	// cap in buffer pairs
+	DevBuf<int> d_list;
+	uint32_t *d_ptab = nullptr;
+	A2DParams *d_params = nullptr;
+	int32_t *h_master = nullptr;	// pinned
+	size_t h_master_cap = 0;
+
+	a2amd_stats stats;
+
+	int fail(int code, const char *fmt, ...)
+	{
+		va_list ap;
+		va_start(ap, fmt);
+		vsnprintf(err, sizeof(err), fmt, ap);
+		va_end(ap);
+		snprintf(g_err, sizeof(g_err), "%s", err);
+		return code;
+	}
+};
+
+namespace {
+
+// grow a device array; keep = preserve old contents (device-owned data)
+template<class T>
+int grow(a2amd_ctx *c, DevBuf<T> &b, size_t need, size_t elem_mult, bool keep)
+{
+	if(need <= b.cap)
+		return 0;
+	size_t ncap = std::max(need, b.cap ? b.cap * 2 : (size_t)1024);
+	T *nd = nullptr;
+	HIPCHK(c, hipMalloc((void **)&nd, ncap * elem_mult * sizeof(T)));
+	if(keep && b.d && b.cap) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		HIPCHK(c, hipMemcpy(nd, b.d, b.cap * elem_mult * sizeof(T), hipMemcpyDeviceToDevice));
+	}
+	if(keep)
+		HIPCHK(c, hipMemset((char *)nd + b.cap * elem_mult * sizeof(T), 0,
+				(ncap - b.cap) * elem_mult * sizeof(T)));
+	if(b.d) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		HIPCHK(c, hipFree(b.d));
+	}
+	b.d = nd;
+	b.cap = ncap;
+	return 0;
+}
+
+int rec_tag(const a2amd_ctx *c) { return c->frag_open ? c->cur_frag : c->nfrags; }
+
+void touch(a2amd_ctx *c, int vi)
+{
+	HVoice &v = c->voices[vi];
+	int tag = rec_tag(c);
+	if(v.touched != tag) {
+		v.touched = tag;
+		v.frag_mark = v.recs.size();
+		c->touched_list.push_back(vi);
+	}
+}
+
+void push_rec(a2amd_ctx *c, int vi, int op, int unit, int reg, int value, unsigned dur, unsigned start)
+{
+	touch(c, vi);
+	A2DRec r;
+	r.head = A2D_HEAD(rec_tag(c), op, unit, reg);
+	r.value = value;
+	r.dur = dur;
+	r.start = start;
+	c->voices[vi].recs.push_back(r);
+}
+
+int bus_alloc(a2amd_ctx *c, int nch)
+{
+	auto &fl = c->bus_free[nch];
+	if(!fl.empty()) {
+		int off = fl.back();
+		fl.pop_back();
+		return off;
+	}
+	size_t off = c->bus_used;
+	c->bus_used += c->bus_stride_frames * (size_t)nch;
+	return (int)off;
+}
+
+// the engine-visible walk found no work for the VMs: close the fragment
+int close_fragment(a2amd_ctx *c)
+{
+	if(!c->frag_open)
+		return 0;
+	const int f = c->cur_frag;
+	const unsigned nframes = c->fragframes[f];
+	int touched_started = 0;
+	for(int vi : c->touched_list) {
+		HVoice &v = c->voices[vi];
+		if(v.touched != f)
+			continue;	// touched ahead of a later fragment
+		if(v.started && !v.dying)
+			++touched_started;
+		size_t n = v.recs.size() - v.frag_mark;
+		if(n == 1) {
+			const A2DRec &r = v.recs.back();
+			if(A2D_ROP(r.head) == R_SEG && r.dur == (nframes << 16))
+				v.recs.pop_back();	// the default: one full window
+		}
+	}
+	c->touched_list.clear();
+	if(touched_started != c->n_started_live) {
+		// a live voice got no Process call this fragment: say so, or
+		// the kernel would apply the default
+		for(size_t vi = 0; vi < c->voices.size(); ++vi) {
+			HVoice &v = c->voices[vi];
+			if(v.live && v.started && !v.dying && v.touched != f) {
+				A2DRec r = { A2D_HEAD(f, R_NOP, 0, 0), 0, 0, 0 };
+				v.recs.push_back(r);
+				v.touched = f;
+			}
+		}
+	}
+	c->frag_open = false;
+	return 0;
+}
+
+void resolve_out(a2amd_ctx *c, HVoice &v)
+{
+	if(v.resolved)
+		return;
+	v.depth = (int)c->stack.size();
+	if(c->stack.empty()) {
+		v.out_off = 0;
+		v.out_nch = c->cfg.channels;
+	} else {
+		const HUnit &il = c->units[c->stack.back()];
+		const HVoice &pv = c->voices[il.voice];
+		if(il.wired) {
+			v.out_off = pv.out_off;
+			v.out_nch = pv.out_nch;
+		} else {
+			v.out_off = pv.own_off;
+			v.out_nch = pv.own_nch;
+		}
+	}
+	v.resolved = true;
+	c->voices_dirty = true;
+	c->lists_dirty = true;
+}
+
+void sync_voice_mirror(a2amd_ctx *c, int vi)
+{
+	const HVoice &v = c->voices[vi];
+	if(c->mvoices.size() <= (size_t)vi)
+		c->mvoices.resize(vi + 1);
+	A2DVoice &m = c->mvoices[vi];
+	memset(&m, 0, sizeof(m));
+	m.nunits = v.nunits;
+	for(int i = 0; i < v.nunits; ++i)
+		m.unit[i] = v.unit[i];
+	m.out_off = v.out_off;
+	m.out_nch = v.out_nch;
+	m.own_off = v.own_off;
+	m.own_nch = v.own_nch;
+}
+
+int upload(a2amd_ctx *c)
+{
+	const size_t nv = c->voices.size(), nu = c->units.size();
+	// capacities
+	if(int r = grow(c, c->d_voices, nv, 1, false)) return r;
+	if(int r = grow(c, c->d_udesc, nu, 1, false)) return r;
+	if(int r = grow(c, c->d_ustate, nu, A2D_USTATE, true)) return r;
+	if(int r = grow(c, c->d_vactive, nv, 1, true)) return r;
+	if(int r = grow(c, c->d_runs, nv, 1, false)) return r;
+	if(int r = grow(c, c->d_busmem, c->bus_used, 1, false)) return r;
+	if(c->fbd_count)
+		if(int r = grow(c, c->d_fbdmem, c->fbd_count, 2 * (size_t)A2D_FBD_BUFSIZE, true)) return r;
+
+	if(c->voices_dirty && nv) {
+		for(size_t vi = 0; vi < nv; ++vi)
+			sync_voice_mirror(c, (int)vi);
+		HIPCHK(c, hipMemcpyAsync(c->d_voices.d, c->mvoices.data(), nv * sizeof(A2DVoice),
+				hipMemcpyHostToDevice, c->stream));
+		c->voices_dirty = false;
+	}
+	if(c->udesc_dirty && nu) {
+		HIPCHK(c, hipMemcpyAsync(c->d_udesc.d, c->mudesc.data(), nu * sizeof(uint32_t),
+				hipMemcpyHostToDevice, c->stream));
+		c->udesc_dirty = false;
+	}
+	if(c->waves_dirty && !c->mwaves.empty()) {
+		if(int r = grow(c, c->d_waves, c->mwaves.size(), 1, false)) return r;
+		HIPCHK(c, hipMemcpyAsync(c->d_waves.d, c->mwaves.data(), c->mwaves.size() * sizeof(A2DWave),
+				hipMemcpyHostToDevice, c->stream));
+		c->waves_dirty = false;
+	}
+	if(c->ptab_dirty) {
+		HIPCHK(c, hipMemcpyAsync(c->d_ptab, c->ptab, sizeof(c->ptab), hipMemcpyHostToDevice, c->stream));
+		c->ptab_dirty = false;
+	}
+	for(int b : c->fbd_to_zero)
+		HIPCHK(c, hipMemsetAsync(c->d_fbdmem.d + (size_t)b * 2 * A2D_FBD_BUFSIZE, 0,
+				2 * (size_t)A2D_FBD_BUFSIZE * sizeof(int32_t), c->stream));
+	c->fbd_to_zero.clear();
+
+	// records: one contiguous run per voice
+	std::vector<A2DRun> runs(nv);
+	std::vector<A2DRec> recs;
+	for(size_t vi = 0; vi < nv; ++vi) {
+		HVoice &v = c->voices[vi];
+		runs[vi].first = (int)recs.size();
+		runs[vi].count = (int)v.recs.size();
+		recs.insert(recs.end(), v.recs.begin(), v.recs.end());
+	}
+	if(int r = grow(c, c->d_recs, recs.size() + 1, 1, false)) return r;
+	if(nv)
+		HIPCHK(c, hipMemcpyAsync(c->d_runs.d, runs.data(), nv * sizeof(A2DRun), hipMemcpyHostToDevice, c->stream));
+	if(!recs.empty())
+		HIPCHK(c, hipMemcpyAsync(c->d_recs.d, recs.data(), recs.size() * sizeof(A2DRec),
+				hipMemcpyHostToDevice, c->stream));
+	c->stats.records += recs.size();
+
+	// launch lists: leaves (sorted by output bus so one wavefront can sum
+	// several voices before touching the bus), then inline voices by depth
+	if(c->lists_dirty) {
+		std::vector<int> leaf;
+		std::map<int, std::vector<int>> bydepth;
+		int maxdepth = -1;
+		for(size_t vi = 0; vi < nv; ++vi) {
+			const HVoice &v = c->voices[vi];
+			if(!v.live || !v.resolved)
+				continue;
+			if(v.inline_pos >= 0) {
+				bydepth[v.depth].push_back((int)vi);
+				maxdepth = std::max(maxdepth, v.depth);
+			} else
+				leaf.push_back((int)vi);
+		}
+		std::stable_sort(leaf.begin(), leaf.end(), [&](int a, int b) {
+			return c->voices[a].out_off < c->voices[b].out_off; });
+		c->list_all = leaf;
+		c->n_leaf = (int)leaf.size();
+		c->depth_ranges.assign(maxdepth + 1, std::make_pair(0, 0));
+		for(int d = 0; d <= maxdepth; ++d) {
+			auto &l = bydepth[d];
+			c->depth_ranges[d] = std::make_pair((int)c->list_all.size(), (int)l.size());
+			c->list_all.insert(c->list_all.end(), l.begin(), l.end());
+		}
+		if(int r = grow(c, c->d_list, c->list_all.size() + 1, 1, false)) return r;
+		if(!c->list_all.empty())
+			HIPCHK(c, hipMemcpyAsync(c->d_list.d, c->list_all.data(), c->list_all.size() * sizeof(int),
+					hipMemcpyHostToDevice, c->stream));
+		c->lists_dirty = false;
+	}
+
+	A2DParams p;
+	memset(&p, 0, sizeof(p));
+	p.voices = c->d_voices.d;
+	p.udesc = c->d_udesc.d;
+	p.ustate = c->d_ustate.d;
+	p.vactive = c->d_vactive.d;
+	p.runs = c->d_runs.d;
+	p.recs = c->d_recs.d;
+	p.waves = c->d_waves.d;
+	p.wavepool = c->d_wavepool.d;
+	p.busmem = c->d_busmem.d;
+	p.fbdmem = c->d_fbdmem.d;
+	p.ptab = c->d_ptab;
+	p.nfrags = c->nfrags;
+	p.samplerate = c->cfg.samplerate;
+	for(int f = 0; f < c->nfrags; ++f)
+		p.fragframes[f] = (uint8_t)c->fragframes[f];
+	HIPCHK(c, hipMemcpyAsync(c->d_params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
+	// pageable sources above: make sure they are consumed before they die
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	c->uploaded = true;
+	return 0;
+}
+
+int pick_vpw(int n)
+{
+	int v = n / 4096;
+	return std::min(std::max(v, 1), (int)A2D_MAXVPW);
+}
+
+void end_batch(a2amd_ctx *c)
+{
+	// Records made after the last fragment of the batch was closed belong to
+	// the first fragment of the next batch: carry them over.
+	const int done = c->nfrags;
+	c->touched_list.clear();
+	for(size_t vi = 0; vi < c->voices.size(); ++vi) {
+		HVoice &v = c->voices[vi];
+		size_t keep = 0;
+		for(size_t i = 0; i < v.recs.size(); ++i)
+			if((int)A2D_RFRAG(v.recs[i].head) >= done) {
+				A2DRec r = v.recs[i];
+				r.head = (r.head & 0xffff0000u) | (uint32_t)((int)A2D_RFRAG(r.head) - done);
+				v.recs[keep++] = r;
+			}
+		v.recs.resize(keep);
+		v.frag_mark = 0;
+		if(keep) {
+			v.touched = 0;
+			c->touched_list.push_back((int)vi);
+		} else
+			v.touched = -1;
+	}
+	for(int vi : c->deferred_free_voices) {
+		c->voices[vi] = HVoice();
+		c->free_voices.push_back(vi);
+	}
+	c->deferred_free_voices.clear();
+	for(int ui : c->deferred_free_units)
+		c->free_units.push_back(ui);
+	c->deferred_free_units.clear();
+	for(auto &b : c->deferred_bus_free)
+		c->bus_free[b.second].push_back(b.first);
+	c->deferred_bus_free.clear();
+	for(int b : c->fbd_deferred_free)
+		c->fbd_free.push_back(b);
+	c->fbd_deferred_free.clear();
+	c->nfrags = 0;
+	c->cur_frag = 0;
+	c->frag_open = false;
+	c->uploaded = false;
+}
+
+} // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+const char *a2amd_version(void) { return "a2amd 0.1 (gfx950)"; }
+
+const char *a2amd_last_error(const a2amd_ctx *c) { return c ? c->err : g_err; }
+
+int a2amd_open(const a2amd_config *cfg, a2amd_ctx **out)
+{
+	if(!cfg || !out || cfg->channels < 1 || cfg->channels > A2D_MAXCH || cfg->samplerate <= 0) {
+		snprintf(g_err, sizeof(g_err), "a2amd_open: bad configuration");
+		return A2AMD_EINVAL;
+	}
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if(e != hipSuccess || ndev <= 0 || cfg->device >= ndev) {
+		snprintf(g_err, sizeof(g_err), "a2amd_open: no usable HIP device (%s, %d devices, want #%d); "
+				"this library has no CPU fallback", hipGetErrorString(e), ndev, cfg->device);
+		return A2AMD_ENODEVICE;
+	}
+	a2amd_ctx *c = new a2amd_ctx();
+	c->cfg = *cfg;
+	c->err[0] = 0;
+	if(!c->cfg.max_batch)
+		c->cfg.max_batch = 1;
+	if(c->cfg.max_batch > A2D_MAXBATCH)
+		c->cfg.max_batch = A2D_MAXBATCH;
+	memset(&c->stats, 0, sizeof(c->stats));
+	build_pitch_table(c->ptab);
+	c->bus_stride_frames = (size_t)c->cfg.max_batch * A2D_FRAG;
+	c->bus_used = c->bus_stride_frames * (size_t)c->cfg.channels;	// master bus at offset 0
+#define OPENCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
+	snprintf(g_err, sizeof(g_err), "a2amd_open: %s: %s", #call, hipGetErrorString(e_)); \
+	delete c; return A2AMD_EHIP; } } while(0)
+	OPENCHK(hipSetDevice(cfg->device));
+	if(cfg->stream)
+		c->stream = (hipStream_t)cfg->stream;
+	else {
+		OPENCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+		c->own_stream = true;
+	}
+	OPENCHK(hipEventCreate(&c->ev0));
+	OPENCHK(hipEventCreate(&c->ev1));
+	OPENCHK(hipEventCreate(&c->ev2));
+	OPENCHK(hipMalloc((void **)&c->d_ptab, sizeof(c->ptab)));
+	OPENCHK(hipMalloc((void **)&c->d_params, sizeof(A2DParams)));
+	OPENCHK(hipMalloc((void **)&c->d_wavepool.d, (size_t)(8u << 20) * sizeof(int16_t)));
+	c->d_wavepool.cap = 8u << 20;
+#undef OPENCHK
+	*out = c;
+	return A2AMD_OK;
+}
+
+void a2amd_close(a2amd_ctx *c)
+{
+	if(!c)
+		return;
+	hipStreamSynchronize(c->stream);
+	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d);
+	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
+	hipFree(c->d_waves.d); hipFree(c->d_wavepool.d); hipFree(c->d_busmem.d);
+	hipFree(c->d_fbdmem.d); hipFree(c->d_list.d); hipFree(c->d_ptab); hipFree(c->d_params);
+	if(c->h_master)
+		hipHostFree(c->h_master);
+	hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipEventDestroy(c->ev2);
+	if(c->own_stream)
+		hipStreamDestroy(c->stream);
+	delete c;
+}
+
+int a2amd_set_pitch_table(a2amd_ctx *c, const uint32_t *t)
+{
+	memcpy(c->ptab, t, sizeof(c->ptab));
+	c->ptab_dirty = true;
+	return A2AMD_OK;
+}
+
+int a2amd_get_pitch_table(const a2amd_ctx *c, uint32_t *t)
+{
+	memcpy(t, c->ptab, sizeof(c->ptab));
+	return A2AMD_OK;
+}
+
+// ---- waves ------------------------------------------------------------------
+int a2amd_wave_upload(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w)
+{
+	if(!w)
+		return c->fail(A2AMD_EINVAL, "wave_upload: null descriptor");
+	int id = -1;
+	for(size_t i = 0; i < c->waves.size(); ++i)
+		if(c->waves[i].live && c->waves[i].key == key)
+			id = (int)i;
+	if(id < 0) {
+		id = (int)c->waves.size();
+		c->waves.push_back(HWave());
+		c->mwaves.push_back(A2DWave());
+	}
+	HWave &hw = c->waves[id];
+	hw.live = true;
+	hw.key = key;
+	memset(&hw.dw, 0, sizeof(hw.dw));
+	hw.dw.type = w->type;
+	hw.dw.flags = w->flags;
+	hw.dw.period = w->period;
+	int levels = w->type == A2AMD_WMIPWAVE ? A2D_MIPS : w->type == A2AMD_WWAVE ? 1 : 0;
+	size_t total = 0;
+	for(int l = 0; l < levels; ++l)
+		total += A2AMD_WAVEPRE + (size_t)w->size[l] + A2AMD_WAVEPOST;
+	total = (total + 7) & ~(size_t)7;
+	if(c->wavepool_used + total > c->d_wavepool.cap)
+		if(int r = grow(c, c->d_wavepool, c->wavepool_used + total, 1, true)) return r;
+	size_t pos = c->wavepool_used;
+	for(int l = 0; l < levels; ++l) {
+		size_t n = A2AMD_WAVEPRE + (size_t)w->size[l] + A2AMD_WAVEPOST;
+		HIPCHK(c, hipMemcpy(c->d_wavepool.d + pos, w->data[l], n * sizeof(int16_t), hipMemcpyHostToDevice));
+		hw.dw.size[l] = w->size[l];
+		hw.dw.off[l] = (uint32_t)(pos + A2AMD_WAVEPRE);
+		pos += n;
+	}
+	c->wavepool_used += total;
+	c->mwaves[id] = hw.dw;
+	c->waves_dirty = true;
+	++c->stats.live_waves;
+	return id;
+}
+
+int a2amd_wave_drop(a2amd_ctx *c, uint64_t key)
+{
+	for(size_t i = 0; i < c->waves.size(); ++i)
+		if(c->waves[i].live && c->waves[i].key == key) {
+			c->waves[i].live = false;
+			c->waves[i].dw.size[0] = 0;	// "unloaded", waves.c:717-723
+			c->mwaves[i] = c->waves[i].dw;
+			c->waves_dirty = true;
+			--c->stats.live_waves;
+			return A2AMD_OK;
+		}
+	return c->fail(A2AMD_EINVAL, "wave_drop: unknown key");
+}
+
+// ---- fragment clock -----------------------------------------------------------
+int a2amd_fragment(a2amd_ctx *c, unsigned frames)
+{
+	if(!frames || frames > A2D_FRAG)
+		return c->fail(A2AMD_EINVAL, "fragment of %u frames", frames);
+	if(!c->stack.empty())
+		return c->fail(A2AMD_ESTATE, "fragment inside an inline window");
+	if(c->uploaded)
+		return c->fail(A2AMD_ESTATE, "batch already uploaded; finish the render first");
+	close_fragment(c);
+	if(c->nfrags >= (int)c->cfg.max_batch)
+		return c->fail(A2AMD_ESTATE, "more than max_batch=%u fragments without a render", c->cfg.max_batch);
+	c->cur_frag = c->nfrags++;
+	c->fragframes[c->cur_frag] = frames;
+	c->frag_open = true;
+	c->building = -1;
+	return A2AMD_OK;
+}
+
+int a2amd_fragment_repeat(a2amd_ctx *c, unsigned frames, unsigned count)
+{
+	if(c->n_noise || c->n_cutoff_ramps)
+		return c->fail(A2AMD_EUNSUPPORTED, "fragment_repeat with %d noise oscillators / %d cutoff ramps "
+				"in flight", c->n_noise, c->n_cutoff_ramps);
+	for(unsigned i = 0; i < count; ++i) {
+		if(int r = a2amd_fragment(c, frames))
+			return r;
+		// every live voice gets the default window: nothing to record, but
+		// tell close_fragment() that nobody was skipped
+		c->frag_open = false;
+	}
+	return A2AMD_OK;
+}
+
+// ---- units ----------------------------------------------------------------------
+int a2amd_unit_init(a2amd_ctx *c, uint64_t key, int kind, unsigned flags, int nin, int nout,
+		int wired, int transpose, unsigned wakefrac)
+{
+	(void)wakefrac;		// only shifts the phase of an oscillator that has a wave (none at init)
+	if(kind < 0 || kind >= A2AMD_NKINDS)
+		return c->fail(A2AMD_EINVAL, "unit kind %d", kind);
+	if(nin < 0 || nin > A2D_MAXCH || nout < 0 || nout > A2D_MAXCH)
+		return c->fail(A2AMD_EINVAL, "bad channel counts %d->%d", nin, nout);
+	const bool add = (flags & A2AMD_PROCADD) != 0;
+	switch(kind) {
+	  case A2AMD_WTOSC:
+		if(nout != 1) return c->fail(A2AMD_EINVAL, "wtosc has 1 output");
+		break;
+	  case A2AMD_PANMIX:
+	  case A2AMD_FBDELAY:
+		if(nin < 1 || nin > 2 || nout < 1 || nout > 2)
+			return c->fail(A2AMD_EINVAL, "unit kind %d with %d->%d channels", kind, nin, nout);
+		break;
+	  case A2AMD_FILTER12:
+		if(nin != nout || nin < 1 || nin > 2)
+			return c->fail(A2AMD_EINVAL, "filter12 %d->%d", nin, nout);
+		break;
+	  case A2AMD_XINSERT:
+		if(nin != nout || nin < 1)
+			return c->fail(A2AMD_EINVAL, "xinsert %d->%d", nin, nout);
+		break;
+	  case A2AMD_INLINE:
+		if(nout < 1)
+			return c->fail(A2AMD_EINVAL, "inline needs outputs");
+		break;
+	}
+	if(wired && !add && kind != A2AMD_INLINE)
+		return c->fail(A2AMD_EUNSUPPORTED, "replacing-mode unit wired to the voice output bus");
+
+	// voice under construction? (a2_PopulateVoice, core.c:350-420)
+	int vi = c->building;
+	if(vi < 0 || c->voices[vi].key != key) {
+		if(!c->free_voices.empty()) {
+			vi = c->free_voices.back();
+			c->free_voices.pop_back();
+		} else {
+			vi = (int)c->voices.size();
+			c->voices.push_back(HVoice());
+		}
+		HVoice &v = c->voices[vi];
+		v = HVoice();
+		v.live = true;
+		v.key = key;
+		c->building = vi;
+		c->voices_dirty = true;
+		++c->stats.live_voices;
+	}
+	HVoice &v = c->voices[vi];
+	if(v.nunits >= A2D_MAXCHAIN)
+		return c->fail(A2AMD_EUNSUPPORTED, "voice chain longer than %d units", A2D_MAXCHAIN);
+	if(kind == A2AMD_INLINE && v.inline_pos >= 0)
+		return c->fail(A2AMD_EUNSUPPORTED, "two inline units in one voice");
+
+	int ui;
+	if(!c->free_units.empty()) {
+		ui = c->free_units.back();
+		c->free_units.pop_back();
+	} else {
+		ui = (int)c->units.size();
+		c->units.push_back(HUnit());
+		c->mudesc.push_back(0);
+	}
+	HUnit &u = c->units[ui];
+	u = HUnit();
+	u.live = true;
+	u.kind = kind;
+	u.flags = flags;
+	u.nin = nin;
+	u.nout = nout;
+	u.wired = wired ? 1 : 0;
+	u.voice = vi;
+	u.chainpos = v.nunits;
+	v.unit[v.nunits++] = ui;
+	++v.nlive;
+	c->mudesc[ui] = A2D_DESC(kind, add ? 1 : 0, nin, nout, wired ? 1 : 0);
+	c->udesc_dirty = true;
+	c->voices_dirty = true;
+	++c->stats.live_units;
+
+	int initval = 0;
+	switch(kind) {
+	  case A2AMD_WTOSC:	// wtosc_Initialize, wtosc.c:390-423
+		initval = transpose + c->cfg.basepitch;
+		ramp_init(u.p, initval);
+		u.dphase = p2i(c->ptab, u.p.value >> 8);
+		u.phase = 0;
+		u.p_ramping = 0;
+		u.mode = A2D_OSC_OFF;
+		u.wave = -1;
+		u.shadow_ok = true;
+		break;
+	  case A2AMD_FILTER12:	// f12_Initialize -> f12_CutOff(u, 0, 0, 0), filter12.c:141-147,203
+		ramp_init(u.cutoff, 0);
+		ramp_set(u.cutoff, transpose, 0, 0);
+		initval = f12_coeff(c->ptab, u.cutoff.value, c->cfg.samplerate);
+		break;
+	  case A2AMD_FBDELAY:	// two zeroed delay lines, fbdelay.c:180-181
+		if(!c->fbd_free.empty()) {
+			u.fbdbuf = c->fbd_free.back();
+			c->fbd_free.pop_back();
+		} else
+			u.fbdbuf = c->fbd_count++;
+		c->fbd_to_zero.push_back(u.fbdbuf);
+		initval = u.fbdbuf;
+		break;
+	  case A2AMD_INLINE:
+		v.inline_pos = u.chainpos;
+		if(!wired) {
+			v.own_nch = nout;
+			v.own_off = bus_alloc(c, nout);
+		}
+		break;
+	  default:
+		break;
+	}
+	push_rec(c, vi, R_INIT, u.chainpos, 0, initval, 0, 0);
+	return ui;
+}
+
+int a2amd_unit_deinit(a2amd_ctx *c, int ui)
+{
+	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live)
+		return c->fail(A2AMD_EINVAL, "deinit of dead unit %d", ui);
+	HUnit &u = c->units[ui];
+	HVoice &v = c->voices[u.voice];
+	if(c->building == u.voice)
+		c->building = -1;
+	if(u.kind == A2AMD_WTOSC && u.mode == A2D_OSC_NOISE)
+		--c->n_noise;
+	if(u.kind == A2AMD_FILTER12 && u.cutoff.timer)
+		--c->n_cutoff_ramps;
+	if(u.fbdbuf >= 0)
+		c->fbd_deferred_free.push_back(u.fbdbuf);
+	u.live = false;
+	c->deferred_free_units.push_back(ui);
+	--c->stats.live_units;
+	if(--v.nlive == 0) {
+		// a2_VoiceFree (core.c:532-591) took the whole chain down
+		push_rec(c, u.voice, R_KILL, 0, 0, 0, 0, 0);
+		if(v.started)
+			--c->n_started_live;
+		v.dying = true;
+		v.live = false;
+		if(v.own_off >= 0)
+			c->deferred_bus_free.push_back(std::make_pair(v.own_off, v.own_nch));
+		c->deferred_free_voices.push_back(u.voice);
+		c->lists_dirty = true;
+		--c->stats.live_voices;
+	}
+	return A2AMD_OK;
+}
+
+int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, unsigned dur, int transpose)
+{
+	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live)
+		return c->fail(A2AMD_EINVAL, "write to dead unit %d", ui);
+	HUnit &u = c->units[ui];
+	c->building = -1;
+	start &= 255;		// a2_VoiceControl, core.c:148
+	switch(u.kind) {
+	  case A2AMD_WTOSC:
+		switch(reg) {
+		  case 0: {	// wtosc_Wave, wtosc.c:433-483
+			int wt = A2AMD_WOFF, id = -1;
+			if(value >= 0 && value < (int)c->waves.size() && c->waves[value].live) {
+				id = value;
+				wt = c->waves[id].dw.type;
+				if((wt == A2AMD_WWAVE || wt == A2AMD_WMIPWAVE) &&
+						c->waves[id].dw.size[0] > (unsigned)A2D_WTOSC_MAXLENGTH)
+					wt = A2AMD_WOFF;
+			}
+			int nmode = wt == A2AMD_WNOISE ? A2D_OSC_NOISE : wt == A2AMD_WWAVE ? A2D_OSC_WAVE :
+					wt == A2AMD_WMIPWAVE ? A2D_OSC_MIPWAVE : A2D_OSC_OFF;
+			if(nmode == A2D_OSC_NOISE && !u.shadow_ok)
+				return c->fail(A2AMD_EUNSUPPORTED, "oscillator switched to noise after playing a "
+						"wavetable: its phase lives on the GPU");
+			if(u.mode == A2D_OSC_NOISE && nmode != A2D_OSC_NOISE)
+				--c->n_noise;
+			if(u.mode != A2D_OSC_NOISE && nmode == A2D_OSC_NOISE)
+				++c->n_noise;
+			u.mode = nmode;
+			u.wave = nmode == A2D_OSC_OFF ? -1 : id;
+			value = id;
+			break;
+		  }
+		  case 1:	// wtosc_Pitch, wtosc.c:486-492
+			value = value + transpose + c->cfg.basepitch;
+			ramp_set(u.p, value, (int)start, (int)dur);
+			if(!dur)
+				u.p_ramping = 1;
+			break;
+		  case 2:
+			break;
+		  case 3:	// wtosc_Phase -> wtosc_set_phase, wtosc.c:369-378
+			if(u.wave < 0)
+				u.phase = 0;
+			else {
+				int ph = (int)((unsigned)value + ((start * (u.dphase >> 8)) >> 8));
+				u.phase = (uint64_t)(((int64_t)ph * (int64_t)c->waves[u.wave].dw.period) * 256);
+			}
+			break;
+		  default:
+			return c->fail(A2AMD_EINVAL, "wtosc register %d", reg);
+		}
+		break;
+	  case A2AMD_PANMIX:
+		if(reg < 0 || reg > 1)
+			return c->fail(A2AMD_EINVAL, "panmix register %d", reg);
+		break;
+	  case A2AMD_FILTER12:
+		switch(reg) {
+		  case 0: {	// f12_CutOff, filter12.c:141-147: stays on the host
+			bool was = u.cutoff.timer != 0;
+			ramp_set(u.cutoff, value + transpose, (int)start, (int)dur);
+			bool is = u.cutoff.timer != 0;
+			c->n_cutoff_ramps += (int)is - (int)was;
+			if(dur < 256)
+				push_rec(c, u.voice, R_F1SET, u.chainpos, 0,
+						f12_coeff(c->ptab, u.cutoff.value, c->cfg.samplerate), 0, 0);
+			return A2AMD_OK;
+		  }
+		  case 1:	// f12_Q, filter12.c:149-162
+			value = value < 512 ? 32768 : (65536 << 8) / value;
+			break;
+		  case 2: case 3: case 4:
+			break;
+		  default:
+			return c->fail(A2AMD_EINVAL, "filter12 register %d", reg);
+		}
+		break;
+	  case A2AMD_FBDELAY:
+		if(reg < 0 || reg > 6)
+			return c->fail(A2AMD_EINVAL, "fbdelay register %d", reg);
+		break;
+	  default:
+		return c->fail(A2AMD_EINVAL, "unit kind %d has no registers", u.kind);
+	}
+	push_rec(c, u.voice, R_WRITE, u.chainpos, reg, value, dur, start);
+	return A2AMD_OK;
+}
+
+int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, uint32_t *noisestate)
+{
+	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live)
+		return c->fail(A2AMD_EINVAL, "process of dead unit %d", ui);
+	if(!c->frag_open || !frames || offset + frames > c->fragframes[c->cur_frag])
+		return c->fail(A2AMD_ESTATE, "process [%u,+%u) outside the open fragment", offset, frames);
+	HUnit &u = c->units[ui];
+	const int vi = u.voice;
+	HVoice &v = c->voices[vi];
+	c->building = -1;
+	if(!v.resolved)
+		resolve_out(c, v);
+	if(!v.started) {
+		v.started = true;
+		++c->n_started_live;
+	}
+	touch(c, vi);
+	if(u.chainpos == 0) {
+		v.win_off = (int)offset;
+		v.win_frames = (int)frames;
+	} else if(v.win_off != (int)offset || v.win_frames != (int)frames)
+		return c->fail(A2AMD_ESTATE, "units of one voice processed over different windows");
+
+	switch(u.kind) {
+	  case A2AMD_WTOSC:
+		if(u.mode == A2D_OSC_NOISE) {
+			// Count the draws wtosc_noise (wtosc.c:129-152) makes over this
+			// window and hand the engine-global RNG back advanced, so VM
+			// RAND instructions and other voices interleave as they do in
+			// the reference; the kernel regenerates the same draws from
+			// the seed recorded here.
+			if(!noisestate)
+				return c->fail(A2AMD_EINVAL, "noise oscillator needs the engine's noise state");
+			push_rec(c, vi, R_NOISESEED, u.chainpos, 0, (int)*noisestate, 0, 0);
+			ramp_prepare(u.p, (int)frames);
+			if(!(u.dphase && (!u.p.timer && !u.p_ramping))) {	// wtosc_run_pitch
+				unsigned lastv = (unsigned)u.p.value;
+				ramp_run(u.p, (int)frames);
+				u.p_ramping = u.p.delta;
+				u.dphase = p2i(c->ptab, (int)((lastv + (unsigned)u.p.value) >> 9));
+			}
+			uint64_t end = u.phase + (uint64_t)frames * u.dphase;
+			uint64_t draws = u.dphase >= (1u << 23) ? frames : (end >> 23) - (u.phase >> 23);
+			uint32_t st = *noisestate;
+			for(uint64_t i = 0; i < draws; ++i)
+				st = st * 1566083941u + 1u;
+			*noisestate = st;
+			u.phase = end;
+		} else if(u.mode == A2D_OSC_OFF) {
+			if(u.shadow_ok) {	// wtosc_Off, wtosc.c:108-126
+				ramp_prepare(u.p, (int)frames);
+				ramp_run(u.p, (int)frames);
+			}
+		} else
+			u.shadow_ok = false;
+		break;
+	  case A2AMD_FILTER12: {	// the head of f12_process, filter12.c:86-96
+		bool was = u.cutoff.timer != 0;
+		ramp_prepare(u.cutoff, (int)frames);
+		if(u.cutoff.delta) {
+			ramp_run(u.cutoff, (int)frames);
+			push_rec(c, vi, R_F1RAMP, u.chainpos, 0,
+					f12_coeff(c->ptab, u.cutoff.value, c->cfg.samplerate), 0, 0);
+		}
+		c->n_cutoff_ramps += (int)(u.cutoff.timer != 0) - (int)was;
+		break;
+	  }
+	  case A2AMD_INLINE:
+		c->stack.push_back(ui);
+		break;
+	  default:
+		break;
+	}
+	if(u.chainpos == v.nunits - 1)
+		push_rec(c, vi, R_SEG, 0, 0, 0, offset | (frames << 16), 0);
+	return A2AMD_OK;
+}
+
+int a2amd_inline_end(a2amd_ctx *c, int ui)
+{
+	if(c->stack.empty() || c->stack.back() != ui)
+		return c->fail(A2AMD_ESTATE, "inline_end(%d) does not match the open window", ui);
+	c->stack.pop_back();
+	return A2AMD_OK;
+}
+
+// ---- render -------------------------------------------------------------------------
+int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned cap)
+{
+	if(!c->stack.empty())
+		return c->fail(A2AMD_ESTATE, "render inside an inline window");
+	close_fragment(c);
+	unsigned total = 0;
+	for(int f = 0; f < c->nfrags; ++f)
+		total += c->fragframes[f];
+	if(!c->nfrags) {
+		if(!(phases & A2AMD_RENDER_KEEP))
+			;	// nothing recorded: records made outside any fragment wait for the next batch
+		return 0;
+	}
+	if(phases & A2AMD_RENDER_UPLOAD)
+		if(int r = upload(c))
+			return r;
+	if((phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT)) && !c->uploaded)
+		return c->fail(A2AMD_ESTATE, "render phases out of order: upload first");
+
+	if(phases & A2AMD_RENDER_SUBTREES) {
+		HIPCHK(c, hipMemsetAsync(c->d_busmem.d, 0, c->bus_used * sizeof(int32_t), c->stream));
+		HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+		if(c->n_leaf) {
+			if(a2d_launch_voices(c->d_params, c->d_list.d, c->n_leaf, pick_vpw(c->n_leaf), c->stream))
+				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+			++c->stats.launches;
+		}
+		HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+		for(int d = (int)c->depth_ranges.size() - 1; d >= 1; --d) {
+			auto rg = c->depth_ranges[d];
+			if(!rg.second)
+				continue;
+			if(a2d_launch_voices(c->d_params, c->d_list.d + rg.first, rg.second, 1, c->stream))
+				return c->fail(A2AMD_EHIP, "bus launch failed: %s", hipGetErrorString(hipGetLastError()));
+			++c->stats.launches;
+		}
+	}
+	if(phases & A2AMD_RENDER_ROOT) {
+		if(!c->depth_ranges.empty() && c->depth_ranges[0].second) {
+			auto rg = c->depth_ranges[0];
+			if(a2d_launch_voices(c->d_params, c->d_list.d + rg.first, rg.second, 1, c->stream))
+				return c->fail(A2AMD_EHIP, "root launch failed: %s", hipGetErrorString(hipGetLastError()));
+			++c->stats.launches;
+		}
+		HIPCHK(c, hipEventRecord(c->ev2, c->stream));
+		c->stats.fragments += c->nfrags;
+		c->stats.voice_fragments += (uint64_t)c->nfrags * (uint64_t)c->list_all.size();
+	}
+	if(phases & A2AMD_RENDER_READBACK) {
+		const int nch = c->cfg.channels;
+		size_t n = (size_t)c->nfrags * nch * A2D_FRAG;
+		if(!out)
+			return c->fail(A2AMD_EINVAL, "readback without output buffers");
+		if(total > cap)
+			return c->fail(A2AMD_EINVAL, "output capacity %u < %u frames", cap, total);
+		if(n > c->h_master_cap) {
+			if(c->h_master)
+				HIPCHK(c, hipHostFree(c->h_master));
+			HIPCHK(c, hipHostMalloc((void **)&c->h_master, n * sizeof(int32_t), hipHostMallocDefault));
+			c->h_master_cap = n;
+		}
+		HIPCHK(c, hipMemcpyAsync(c->h_master, c->d_busmem.d, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		unsigned pos = 0;
+		for(int f = 0; f < c->nfrags; ++f) {
+			for(int ch = 0; ch < nch; ++ch)
+				memcpy(out[ch] + pos, c->h_master + ((size_t)f * nch + ch) * A2D_FRAG,
+						c->fragframes[f] * sizeof(int32_t));
+			pos += c->fragframes[f];
+		}
+		float ms = 0;
+		if(hipEventElapsedTime(&ms, c->ev0, c->ev2) == hipSuccess)
+			c->stats.last_kernel_ms = ms;
+		if(hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess)
+			c->stats.last_leaf_ms = ms;
+	}
+	if(!(phases & A2AMD_RENDER_KEEP) && (phases & (A2AMD_RENDER_READBACK | A2AMD_RENDER_ROOT)))
+		end_batch(c);
+	return (int)total;
+}
+
+int a2amd_rootbus(a2amd_ctx *c, void **devptr, uint64_t *bytes)
+{
+	// the root voice is the depth-0 voice with an inline unit (a2_rootdriver,
+	// audiality2.c:271-291)
+	for(size_t vi = 0; vi < c->voices.size(); ++vi) {
+		const HVoice &v = c->voices[vi];
+		if(v.live && v.resolved && v.depth == 0 && v.own_off >= 0) {
+			if(!c->d_busmem.d)
+				return c->fail(A2AMD_ESTATE, "no batch uploaded yet");
+			*devptr = c->d_busmem.d + v.own_off;
+			*bytes = (uint64_t)c->nfrags * v.own_nch * A2D_FRAG * sizeof(int32_t);
+			return A2AMD_OK;
+		}
+	}
+	return c->fail(A2AMD_ESTATE, "no root voice with an inline bus");
+}
+
+int a2amd_get_stats(const a2amd_ctx *c, a2amd_stats *st)
+{
+	*st = c->stats;
+	return A2AMD_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,870 @@
+// a2amd_kernels.hip - HIP kernels of the MI355X voice-render backend (gfx950).
+//
+// k_voices: the general kernel.  One wavefront renders whole voices; the 64
+// lanes are the 64 sample frames of a fragment.  That orientation makes every
+// per-voice parameter wave-uniform, turns the wavetable gather into 64
+// near-consecutive reads, and makes the voice -> bus mix-down a plain per-lane
+// add (wrap-around int32 adds commute, so any order is bit exact).  Units that
+// are recurrences in time (filter12, fbdelay with short delays, noise) fall
+// back to a few lanes running the sample loop.
+//
+// Arithmetic follows the reference bit for bit (see DESIGN.md "Arithmetic"):
+// int32/int64 fixed point, wrap-around via unsigned ops, arithmetic >> on
+// signed values, shift counts masked to 5 bits like x86.
+#include <hip/hip_runtime.h>
+#include "a2amd_device.h"
+
+#define DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------
+// fixed point helpers
+// ---------------------------------------------------------------------------
+DEV int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+DEV int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+DEV int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+DEV int wshl(int a, int n) { return (int)((unsigned)a << n); }
+DEV int mul64s(int a, int b, int sh) { return (int)(((int64_t)a * (int64_t)b) >> sh); }
+
+struct Ramp { int value, target, delta, timer; };
+
+DEV Ramp ramp_load(const int *w) { Ramp r = { w[0], w[1], w[2], w[3] }; return r; }
+DEV void ramp_store(int *w, const Ramp &r) { w[0] = r.value; w[1] = r.target; w[2] = r.delta; w[3] = r.timer; }
+
+// a2_InitRamper, a2_dsp.h:121-125
+DEV void ramp_init(Ramp &r, int v) { r.value = r.target = wshl(v, 8); r.delta = r.timer = 0; }
+
+// a2_PrepareRamper, a2_dsp.h:128-149
+DEV void ramp_prepare(Ramp &r, int frames)
+{
+	if(!r.timer) {
+		r.value = r.target;
+		r.delta = 0;
+	} else if(frames <= (r.timer >> 8)) {
+		int64_t d = (int64_t)wsub(r.target, r.value);
+		r.delta = (int)((d * 256) / r.timer);
+		r.timer = wsub(r.timer, frames << 8);
+	} else {
+		r.delta = wsub(r.target, r.value) / frames;
+		r.timer = 0;
+	}
+}
+
+// a2_RunRamper, a2_dsp.h:152-155
+DEV void ramp_run(Ramp &r, int frames) { r.value = wadd(r.value, wmul(r.delta, frames)); }
+
+// a2_SetRamper, a2_dsp.h:161-170
+DEV void ramp_set(Ramp &r, int target, int start, int duration)
+{
+	r.target = wshl(target, 8);
+	r.timer = wadd(duration, start);
+	if(r.timer < 256)
+		r.value = r.target;
+	else
+		r.value = wadd(r.value, wmul(r.delta, start) >> 8);
+}
+
+// a2_P2I, pitch.c:57-67 (shift count mod 32 as on the reference's x86 targets)
+DEV unsigned p2i(const uint32_t *tab, int pitch)
+{
+	int n = pitch & 0xffff;
+	int oct = pitch >> 16;
+	unsigned base = tab[2 * (n >> 10)], coeff = tab[2 * (n >> 10) + 1];
+	unsigned dph = coeff * (unsigned)(n & 0x3ff);
+	dph >>= 2;
+	dph += base;
+	return dph >> ((unsigned)(7 - oct) & 31u);
+}
+
+// a2_Noise, a2_dsp.h:37-42
+DEV int noise_next(unsigned &st)
+{
+	st = st * 1566083941u + 1u;
+	return (int)((st * (st >> 16)) >> 16);
+}
+
+// a2_Hermite, a2_dsp.h:64-74; d = first payload sample, ph 24:8
+DEV int hermite(const int16_t *d, unsigned ph)
+{
+	int i = (int)(ph >> 8);
+	int x = (int)(ph & 0xff) << 7;
+	int dm = d[i - 1], d0 = d[i], d1 = d[i + 1], d2 = d[i + 2];
+	int c = (d1 - dm) >> 1;
+	int a = (3 * (d0 - d1) + d2 - dm) >> 1;
+	int b = dm - d0 + c - a;
+	a = wmul(a, x) >> 15;
+	a = wmul(wadd(a, b), x) >> 15;
+	return d0 + (wmul(wadd(a, c), x) >> 15);
+}
+
+// wtosc_Inter, A2_HIFI build (config.h:108), wtosc.c:28-33
+DEV int inter(const int16_t *d, unsigned ph, unsigned dph)
+{
+	return hermite(d, ph) + hermite(d, ph + (dph >> 1));
+}
+
+// ---------------------------------------------------------------------------
+// per-wavefront working set in LDS
+// ---------------------------------------------------------------------------
+struct WaveLDS {
+	int scratch[A2D_MAXCH][A2D_FRAG];	// the voice's scratch bus (core.c:365-395)
+	int otile[A2D_MAXCH][A2D_FRAG];		// pending adds into the output bus
+	int us[A2D_MAXCHAIN][A2D_USTATE];	// unit states of the current voice
+	int cursor[A2D_MAXVPW];			// next unread record of each of our voices
+};
+
+struct Ctx {
+	const A2DParams *p;
+	WaveLDS *l;
+	int lane;
+	int frag;		// fragment index inside the batch
+	int own_off, own_nch;
+	unsigned omask;		// channels of otile that hold data
+};
+
+DEV void lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// write one output sample of unit 'desc' on channel ch, frame = lane
+DEV void emit(Ctx &c, uint32_t desc, int ch, int val)
+{
+	if(A2D_WIRED(desc)) {
+		c.l->otile[ch][c.lane] = wadd(c.l->otile[ch][c.lane], val);
+	} else if(A2D_ADD(desc)) {
+		c.l->scratch[ch][c.lane] = wadd(c.l->scratch[ch][c.lane], val);
+	} else {
+		c.l->scratch[ch][c.lane] = val;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// wtosc
+// ---------------------------------------------------------------------------
+struct Osc {
+	int mode, wave;
+	unsigned dphase;
+	uint64_t phase;
+	int noise, p_ramping;
+	Ramp p, a;
+	unsigned seed;
+};
+
+DEV Osc osc_load(const int *w)
+{
+	Osc o;
+	o.mode = w[OW_MODE]; o.wave = w[OW_WAVE]; o.dphase = (unsigned)w[OW_DPHASE];
+	o.phase = (uint64_t)(unsigned)w[OW_PHASE_LO] | ((uint64_t)(unsigned)w[OW_PHASE_HI] << 32);
+	o.noise = w[OW_NOISE]; o.p_ramping = w[OW_PRAMPING];
+	o.p = ramp_load(w + OW_P); o.a = ramp_load(w + OW_A);
+	o.seed = (unsigned)w[OW_SEED];
+	return o;
+}
+
+DEV void osc_store(int *w, const Osc &o)
+{
+	w[OW_MODE] = o.mode; w[OW_WAVE] = o.wave; w[OW_DPHASE] = (int)o.dphase;
+	w[OW_PHASE_LO] = (int)(unsigned)o.phase; w[OW_PHASE_HI] = (int)(unsigned)(o.phase >> 32);
+	w[OW_NOISE] = o.noise; w[OW_PRAMPING] = o.p_ramping;
+	ramp_store(w + OW_P, o.p); ramp_store(w + OW_A, o.a);
+	w[OW_SEED] = (int)o.seed;
+}
+
+// wtosc_run_pitch, wtosc.c:89-105
+DEV void osc_run_pitch(const A2DParams &p, Osc &o, int frames)
+{
+	ramp_prepare(o.p, frames);
+	if(o.dphase && (!o.p.timer && !o.p_ramping))
+		return;
+	unsigned lastv = (unsigned)o.p.value;
+	ramp_run(o.p, frames);
+	o.p_ramping = o.p.delta;
+	o.dphase = p2i(p.ptab, (int)((lastv + (unsigned)o.p.value) >> 9));
+}
+
+// wtosc_set_phase, wtosc.c:369-378
+DEV void osc_set_phase(const A2DParams &p, Osc &o, int ph, unsigned sst)
+{
+	if(o.wave < 0) {
+		o.phase = 0;
+		return;
+	}
+	unsigned period = p.waves[o.wave].period;
+	ph = (int)((unsigned)ph + ((sst * (o.dphase >> 8)) >> 8));
+	o.phase = (uint64_t)(((int64_t)ph * (int64_t)period) * 256);
+}
+
+// wtosc_Wave, wtosc.c:433-483 ('value' is already a device wave id)
+DEV void osc_set_wave(const A2DParams &p, Osc &o, int id)
+{
+	int wt = 0;
+	o.wave = id;
+	if(id >= 0) {
+		wt = p.waves[id].type;
+		if((wt == 2 || wt == 3) && p.waves[id].size[0] > (unsigned)A2D_WTOSC_MAXLENGTH)
+			wt = 0;
+	}
+	switch(wt) {
+	  default: o.wave = -1; o.mode = A2D_OSC_OFF; break;
+	  case 1: o.mode = A2D_OSC_NOISE; break;
+	  case 2: o.mode = A2D_OSC_WAVE; break;
+	  case 3: o.mode = A2D_OSC_MIPWAVE; break;
+	}
+}
+
+// The sample loop of wtosc_do_fragment (wtosc.c:200-236) with the optional
+// per-sample loop/end test, evaluated for all frames of the window at once:
+//   ph_k = ph0 + k*dph  (mod wsize<<24 when looped), a_k = a0 + k*delta.
+// Returns the phase the sequential loop would have returned.
+DEV uint64_t osc_window(Ctx &c, uint32_t desc, Osc &o, const int16_t *d,
+		int offset, int frames, uint64_t ph, unsigned dph, int looped, unsigned wsize)
+{
+	int k = c.lane - offset;
+	bool in = (k >= 0) && (k < frames);
+	int kk = in ? k : 0;
+	uint64_t phk = ph + (uint64_t)kk * dph;
+	int ndone = frames;
+	if(wsize) {
+		if(looped) {
+			phk %= (uint64_t)wsize << 24;
+		} else {
+			// first frame whose phase is past the end stops the loop
+			bool over = in && ((phk >> 24) >= wsize);
+			unsigned long long m = __ballot(over);
+			if(m)
+				ndone = (int)__ffsll((long long)m) - 1 - offset;
+		}
+	}
+	if(in) {
+		int val = 0;
+		if(k < ndone) {
+			int ak = wadd(o.a.value, wmul(o.a.delta, k));
+			int v = inter(d, (unsigned)(phk >> 16), dph >> 16);
+			val = mul64s(v, ak, 17);
+			emit(c, desc, 0, val);
+		} else if(!A2D_ADD(desc)) {
+			emit(c, desc, 0, 0);
+		}
+	}
+	// state after the loop
+	ramp_run(o.a, ndone);
+	if(wsize && looped) {
+		if(frames > 0) {
+			uint64_t last = (ph + (uint64_t)(frames - 1) * dph) % ((uint64_t)wsize << 24);
+			return last + dph;
+		}
+		return ph;
+	}
+	return ph + (uint64_t)ndone * dph;
+}
+
+DEV void osc_zero(Ctx &c, uint32_t desc, int offset, int frames)
+{
+	int k = c.lane - offset;
+	if(!A2D_ADD(desc) && k >= 0 && k < frames)
+		emit(c, desc, 0, 0);
+}
+
+// wtosc_wavetable, wtosc.c:239-286
+DEV void osc_mipwave(Ctx &c, uint32_t desc, Osc &o, int offset, int frames)
+{
+	const A2DParams &p = *c.p;
+	const A2DWave &w = p.waves[o.wave];
+	if(!w.size[0]) {		// wtosc_check_unloaded, wtosc.c:168-183
+		o.wave = -1;
+		o.mode = A2D_OSC_OFF;
+		return;
+	}
+	osc_run_pitch(p, o, frames);
+	unsigned dph = ((o.dphase + 255) >> 8) * w.period;
+	ramp_prepare(o.a, frames);
+	unsigned mm = 0;
+	for(; (dph > (A2D_MAXPHINC << 8)) && (mm < A2D_MIPS - 1); ++mm)
+		dph >>= 1;
+	uint64_t ph = o.phase >> mm;
+	dph = (unsigned)(((uint64_t)o.dphase * w.period) >> mm);
+	if(w.flags & 0x100u) {
+		ph %= (uint64_t)w.size[mm] << 24;
+	} else if((ph >> 24) > (uint64_t)(w.size[mm] + 1)) {
+		osc_zero(c, desc, offset, frames);
+		return;
+	}
+	if(dph > (A2D_MAXPHINC << 16)) {
+		osc_zero(c, desc, offset, frames);
+		ph += (uint64_t)dph * (unsigned)frames;
+		o.phase = ph << mm;
+		ramp_run(o.a, frames);
+	} else {
+		o.phase = osc_window(c, desc, o, p.wavepool + w.off[mm], offset, frames,
+				ph, dph, 0, 0) << mm;
+	}
+}
+
+// wtosc_wavetable_no_mip, wtosc.c:301-358
+DEV void osc_wave(Ctx &c, uint32_t desc, Osc &o, int offset, int frames)
+{
+	const A2DParams &p = *c.p;
+	const A2DWave &w = p.waves[o.wave];
+	if(!w.size[0]) {
+		o.wave = -1;
+		o.mode = A2D_OSC_OFF;
+		return;
+	}
+	const int16_t *d = p.wavepool + w.off[0];
+	osc_run_pitch(p, o, frames);
+	uint64_t dph = (uint64_t)o.dphase * w.period;
+	ramp_prepare(o.a, frames);
+	if(dph >> 32) {
+		osc_zero(c, desc, offset, frames);
+		o.phase += dph * (unsigned)frames;
+		ramp_run(o.a, frames);
+	} else if(dph > (A2D_MAXPHINC << 16)) {
+		o.phase = osc_window(c, desc, o, d, offset, frames, o.phase, (unsigned)dph,
+				(w.flags & 0x100u) ? 1 : 0, w.size[0]);
+	} else {
+		if(w.flags & 0x100u) {
+			// wtosc.c:340 uses a 32 bit "size << 24"; a zero modulus
+			// traps in the reference, we leave the phase alone.
+			unsigned m = w.size[0] << 24;
+			if(m)
+				o.phase %= m;
+		} else if((o.phase >> 24) > (uint64_t)(w.size[0] + 1)) {
+			osc_zero(c, desc, offset, frames);
+			return;
+		}
+		o.phase = osc_window(c, desc, o, d, offset, frames, o.phase, (unsigned)dph, 0, 0);
+	}
+}
+
+// wtosc_noise, wtosc.c:129-152.  Frame k draws a new sample iff dphase >= 2^23
+// or bit 23.. of the phase change between k and k+1; the draw index of a frame
+// is a prefix count, the RNG a uniform loop of at most 'frames' steps.
+DEV void osc_noise(Ctx &c, uint32_t desc, Osc &o, int offset, int frames)
+{
+	const A2DParams &p = *c.p;
+	osc_run_pitch(p, o, frames);
+	ramp_prepare(o.a, frames);
+	int k = c.lane - offset;
+	bool in = (k >= 0) && (k < frames);
+	uint64_t phk = o.phase + (uint64_t)(in ? k : 0) * o.dphase;
+	uint64_t nph = phk + o.dphase;
+	bool draw = in && ((o.dphase >= (1u << 23)) || ((nph ^ phk) >> 23));
+	unsigned long long m = __ballot(draw);
+	// draws up to and including my frame
+	unsigned long long below = (c.lane >= 63) ? ~0ull : ((2ull << c.lane) - 1ull);
+	int mine = __popcll(m & below);
+	int total = __popcll(m);
+	int held = o.noise, myval = o.noise;
+	unsigned st = o.seed;
+	for(int j = 1; j <= total; ++j) {
+		held = noise_next(st) - 32767;
+		if(j == mine)
+			myval = held;
+	}
+	o.seed = st;
+	o.noise = held;
+	if(in) {
+		int ak = wadd(o.a.value, wmul(o.a.delta, k));
+		emit(c, desc, 0, wmul(myval, ak >> 10) >> 6);
+	}
+	o.phase += (uint64_t)(unsigned)frames * o.dphase;
+	ramp_run(o.a, frames);
+}
+
+DEV void osc_process(Ctx &c, uint32_t desc, int *w, int offset, int frames)
+{
+	Osc o = osc_load(w);
+	switch(o.mode) {
+	  case A2D_OSC_OFF:	// wtosc_Off[Add], wtosc.c:108-126
+		ramp_prepare(o.p, frames);
+		ramp_prepare(o.a, frames);
+		ramp_run(o.p, frames);
+		ramp_run(o.a, frames);
+		osc_zero(c, desc, offset, frames);
+		break;
+	  case A2D_OSC_NOISE: osc_noise(c, desc, o, offset, frames); break;
+	  case A2D_OSC_WAVE: osc_wave(c, desc, o, offset, frames); break;
+	  case A2D_OSC_MIPWAVE: osc_mipwave(c, desc, o, offset, frames); break;
+	}
+	lds_sync();
+	if(c.lane == 0)
+		osc_store(w, o);
+}
+
+// ---------------------------------------------------------------------------
+// panmix, panmix.c:49-249
+// ---------------------------------------------------------------------------
+DEV void panmix_process(Ctx &c, uint32_t desc, int *w, int offset, int frames)
+{
+	Ramp vol = ramp_load(w + PW_VOL), pan = ramp_load(w + PW_PAN);
+	int nin = A2D_NIN(desc), nout = A2D_NOUT(desc);
+	int k = c.lane - offset;
+	bool in = (k >= 0) && (k < frames);
+	if(nin == 1 && nout == 1) {		// panmix_process11
+		ramp_prepare(vol, frames);
+		if(in) {
+			int vk = wadd(vol.value, wmul(vol.delta, k));
+			emit(c, desc, 0, mul64s(c.l->scratch[0][c.lane], vk, 24));
+		}
+		ramp_run(vol, frames);
+	} else {
+		// clamp variant is chosen before the rampers are prepared,
+		// panmix.c:117-135 / :171-189 / :231-249
+		bool clamp = pan.target > 0xffffff || pan.target < -0xffffff ||
+				pan.value > 0xffffff || pan.value < -0xffffff;
+		ramp_prepare(vol, frames);
+		ramp_prepare(pan, frames);
+		if(in) {
+			int vk = wadd(vol.value, wmul(vol.delta, k));
+			int pk = wadd(pan.value, wmul(pan.delta, k));
+			int vp = mul64s(pk, vk, 24);
+			int v0 = wsub(vk, vp), v1 = wadd(vk, vp);
+			if(clamp) {
+				int lim = wshl(vk, 1);
+				if(v0 > lim) v0 = lim;
+				if(v1 > lim) v1 = lim;
+			}
+			int i0 = c.l->scratch[0][c.lane];
+			if(nin == 1) {		// panmix_process12
+				emit(c, desc, 0, mul64s(i0, v0, 24));
+				emit(c, desc, 1, mul64s(i0, v1, 24));
+			} else {
+				int i1 = c.l->scratch[1][c.lane];
+				if(nout == 1) {	// panmix_process21
+					int64_t s = (int64_t)i0 * v0 + (int64_t)i1 * v1;
+					emit(c, desc, 0, (int)(s >> 25));
+				} else {	// panmix_process22
+					emit(c, desc, 0, mul64s(i0, v0, 24));
+					emit(c, desc, 1, mul64s(i1, v1, 24));
+				}
+			}
+		}
+		ramp_run(vol, frames);
+		ramp_run(pan, frames);
+	}
+	lds_sync();
+	if(c.lane == 0) {
+		ramp_store(w + PW_VOL, vol);
+		ramp_store(w + PW_PAN, pan);
+	}
+}
+
+// ---------------------------------------------------------------------------
+// filter12, filter12.c:74-119: a recurrence in time; lane ch runs channel ch
+// ---------------------------------------------------------------------------
+DEV void f12_process(Ctx &c, uint32_t desc, int *w, int offset, int frames)
+{
+	Ramp q = ramp_load(w + FW_Q);
+	int lp = w[FW_LP], bp = w[FW_BP], hp = w[FW_HP];
+	int f0 = w[FW_F1], df = 0, f1 = f0;
+	int channels = A2D_NIN(desc);
+	ramp_prepare(q, frames);
+	if(w[FW_RAMP]) {		// host ran the cutoff ramper + f12_pitch2coeff
+		f1 = w[FW_F1NEXT];
+		df = wadd(wsub(f1, f0), frames >> 1) / frames;
+	}
+	if(c.lane < channels) {
+		int ch = c.lane;
+		int d1 = w[FW_D1A + ch], d2 = w[FW_D2A + ch];
+		int qv = q.value;
+		for(int s = offset; s < offset + frames; ++s) {
+			int f = f0 >> 12;
+			int qq = qv >> 12;
+			int d1s = d1 >> 4;
+			int l = wadd(d2, wmul(f, d1s) >> 8);
+			int h = wsub(wsub(c.l->scratch[ch][s] >> 5, l), wmul(qq, d1s) >> 8);
+			int b = wadd(wmul(f, h >> 4) >> 8, d1);
+			int fout = wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3;
+			if(A2D_WIRED(desc))
+				c.l->otile[ch][s] = wadd(c.l->otile[ch][s], fout);
+			else if(A2D_ADD(desc))
+				c.l->scratch[ch][s] = wadd(c.l->scratch[ch][s], fout);
+			else
+				c.l->scratch[ch][s] = fout;
+			d1 = b;
+			d2 = l;
+			f0 = wadd(f0, df);
+			qv = wadd(qv, q.delta);
+		}
+		w[FW_D1A + ch] = d1;
+		w[FW_D2A + ch] = d2;
+	}
+	ramp_run(q, frames);
+	lds_sync();
+	if(c.lane == 0) {
+		ramp_store(w + FW_Q, q);
+		w[FW_F1] = f1;
+		w[FW_RAMP] = 0;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// fbdelay, fbdelay.c:69-126
+// ---------------------------------------------------------------------------
+DEV void fbd_process(Ctx &c, uint32_t desc, int *w, int offset, int frames)
+{
+	const int M = A2D_FBD_BUFSIZE - 1;
+	int fbdelay = w[DW_FBDELAY], ldelay = w[DW_LDELAY], rdelay = w[DW_RDELAY];
+	int drygain = w[DW_DRYGAIN], fbgain = w[DW_FBGAIN], lgain = w[DW_LGAIN], rgain = w[DW_RGAIN];
+	int bufpos = w[DW_BUFPOS];
+	int *b0 = c.p->fbdmem + (size_t)w[DW_BUFIDX] * 2 * A2D_FBD_BUFSIZE;
+	int *b1 = b0 + A2D_FBD_BUFSIZE;
+	int stereoin = A2D_NIN(desc) == 2, stereoout = A2D_NOUT(desc) == 2;
+	int in1ch = stereoin ? 1 : 0;
+	// All taps reach back at least a whole window: no frame of this window
+	// reads what another frame of it writes, so the frames are independent.
+	bool par = fbdelay >= frames && ldelay >= frames && rdelay >= frames &&
+			fbdelay < A2D_FBD_BUFSIZE - 64 && ldelay < A2D_FBD_BUFSIZE - 64 &&
+			rdelay < A2D_FBD_BUFSIZE - 64;
+	if(par) {
+		int k = c.lane - offset;
+		if(k >= 0 && k < frames) {
+			int pos = wadd(bufpos, k);
+			int i0 = c.l->scratch[0][c.lane], i1 = c.l->scratch[in1ch][c.lane];
+			int o0 = mul64s(b1[(pos - fbdelay) & M], fbgain, 16);
+			int o1 = mul64s(b0[(pos - fbdelay) & M], fbgain, 16);
+			int t0 = b0[(pos - ldelay) & M], t1 = b1[(pos - rdelay) & M];
+			b0[pos & M] = wadd(i0, o0);
+			b1[pos & M] = wadd(i1, o1);
+			o0 = wadd(o0, mul64s(t0, lgain, 16));
+			o1 = wadd(o1, mul64s(t1, rgain, 16));
+			o0 = wadd(o0, mul64s(i0, drygain, 16));
+			o1 = wadd(o1, mul64s(i1, drygain, 16));
+			if(stereoout) {
+				emit(c, desc, 0, o0);
+				emit(c, desc, 1, o1);
+			} else
+				emit(c, desc, 0, wadd(o0, o1) >> 1);
+		}
+	} else if(c.lane == 0) {
+		for(int s = offset; s < offset + frames; ++s) {
+			int pos = wadd(bufpos, s - offset);
+			int i0 = c.l->scratch[0][s], i1 = c.l->scratch[in1ch][s];
+			int o0 = mul64s(b1[(pos - fbdelay) & M], fbgain, 16);
+			int o1 = mul64s(b0[(pos - fbdelay) & M], fbgain, 16);
+			b0[pos & M] = wadd(i0, o0);
+			b1[pos & M] = wadd(i1, o1);
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+			o0 = wadd(o0, mul64s(b0[(pos - ldelay) & M], lgain, 16));
+			o1 = wadd(o1, mul64s(b1[(pos - rdelay) & M], rgain, 16));
+			o0 = wadd(o0, mul64s(i0, drygain, 16));
+			o1 = wadd(o1, mul64s(i1, drygain, 16));
+			int *t0, *t1;
+			if(A2D_WIRED(desc)) { t0 = &c.l->otile[0][s]; t1 = &c.l->otile[1][s]; }
+			else { t0 = &c.l->scratch[0][s]; t1 = &c.l->scratch[1][s]; }
+			bool acc = A2D_WIRED(desc) || A2D_ADD(desc);
+			if(stereoout) {
+				*t0 = acc ? wadd(*t0, o0) : o0;
+				*t1 = acc ? wadd(*t1, o1) : o1;
+			} else {
+				int m = wadd(o0, o1) >> 1;
+				*t0 = acc ? wadd(*t0, m) : m;
+			}
+		}
+	}
+	// delay-line stores of this window must be visible to the lanes that read
+	// them in a later window
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+	lds_sync();
+	if(c.lane == 0)
+		w[DW_BUFPOS] = wadd(bufpos, frames);
+}
+
+// ---------------------------------------------------------------------------
+// inline (core.c:1763-1776) and xinsert bypass (xinsert.c:145-161)
+// ---------------------------------------------------------------------------
+DEV void inline_process(Ctx &c, uint32_t desc, int offset, int frames)
+{
+	// The children of this voice were rendered by earlier launches and
+	// summed into our own bus; this is the point of the chain where their
+	// signal enters.  Replacing mode = take it, adding mode = add it.  An
+	// inline whose outputs are wired needs nothing: the children already
+	// added straight into the bus beyond us.
+	if(A2D_WIRED(desc) || c.own_off < 0)
+		return;
+	int k = c.lane - offset;
+	if(k < 0 || k >= frames)
+		return;
+	const int *src = c.p->busmem + c.own_off + (size_t)c.frag * c.own_nch * A2D_FRAG;
+	int nout = A2D_NOUT(desc);
+	for(int ch = 0; ch < nout; ++ch) {
+		int v = src[ch * A2D_FRAG + c.lane];
+		if(A2D_ADD(desc))
+			v = wadd(v, c.l->scratch[ch][c.lane]);
+		c.l->scratch[ch][c.lane] = v;
+	}
+}
+
+DEV void xinsert_process(Ctx &c, uint32_t desc, int offset, int frames)
+{
+	int k = c.lane - offset;
+	if(k < 0 || k >= frames)
+		return;
+	int n = A2D_NIN(desc);
+	if(A2D_WIRED(desc)) {
+		for(int ch = 0; ch < n; ++ch)
+			c.l->otile[ch][c.lane] = wadd(c.l->otile[ch][c.lane], c.l->scratch[ch][c.lane]);
+	} else if(A2D_ADD(desc)) {
+		// in == out on the scratch bus: out += in doubles the signal
+		for(int ch = 0; ch < n; ++ch)
+			c.l->scratch[ch][c.lane] = wshl(c.l->scratch[ch][c.lane], 1);
+	}
+}
+
+// ---------------------------------------------------------------------------
+// control writes and unit init (uniform; lane 0 commits)
+// ---------------------------------------------------------------------------
+DEV void unit_init(const A2DParams &p, uint32_t desc, int *w, const A2DRec &r)
+{
+	for(int i = 0; i < A2D_USTATE; ++i)
+		w[i] = 0;
+	switch(A2D_KIND(desc)) {
+	  case A2D_WTOSC: {	// wtosc_Initialize, wtosc.c:390-423; value = transpose + basepitch
+		Osc o = osc_load(w);
+		o.wave = -1;
+		o.mode = A2D_OSC_OFF;
+		ramp_init(o.a, 0);
+		ramp_init(o.p, r.value);
+		o.dphase = p2i(p.ptab, o.p.value >> 8);
+		osc_store(w, o);
+		break;
+	  }
+	  case A2D_PANMIX: {	// panmix_Initialize, panmix.c:252-284
+		Ramp vol, pan;
+		ramp_init(vol, 65536);
+		ramp_init(pan, 0);
+		ramp_store(w + PW_VOL, vol);
+		ramp_store(w + PW_PAN, pan);
+		break;
+	  }
+	  case A2D_FILTER12: {	// f12_Initialize, filter12.c:180-221; value = f1 from the host
+		Ramp q;
+		ramp_init(q, 0);
+		ramp_set(q, 32768, 0, 0);	// f12_Q(u, 0, 0, 0)
+		ramp_store(w + FW_Q, q);
+		w[FW_LP] = 65536 >> 8;
+		w[FW_F1] = r.value;
+		break;
+	  }
+	  case A2D_FBDELAY: {	// fbdelay_Initialize, fbdelay.c:170-220; value = buffer index
+		int sr = p.samplerate;
+		w[DW_FBDELAY] = (int)((int64_t)(400 << 16) * sr / 65536000);
+		w[DW_LDELAY] = (int)((int64_t)(280 << 16) * sr / 65536000);
+		w[DW_RDELAY] = (int)((int64_t)(320 << 16) * sr / 65536000);
+		w[DW_DRYGAIN] = 65536;
+		w[DW_FBGAIN] = 16384;
+		w[DW_LGAIN] = 32768;
+		w[DW_RGAIN] = 32768;
+		w[DW_BUFIDX] = r.value;
+		break;
+	  }
+	  default: break;
+	}
+}
+
+DEV void unit_write(const A2DParams &p, uint32_t desc, int *w, const A2DRec &r)
+{
+	int reg = A2D_RREG(r.head), v = r.value;
+	int start = (int)r.start, dur = (int)r.dur;
+	switch(A2D_KIND(desc)) {
+	  case A2D_WTOSC: {
+		Osc o = osc_load(w);
+		switch(reg) {
+		  case 0: osc_set_wave(p, o, v); break;
+		  case 1:	// wtosc_Pitch, wtosc.c:486-492 (host added transpose + basepitch)
+			ramp_set(o.p, v, start, dur);
+			if(!dur)
+				o.p_ramping = 1;
+			break;
+		  case 2: ramp_set(o.a, v, start, dur); break;
+		  case 3: osc_set_phase(p, o, v, (unsigned)start); break;
+		}
+		osc_store(w, o);
+		break;
+	  }
+	  case A2D_PANMIX: {
+		Ramp rr = ramp_load(w + (reg ? PW_PAN : PW_VOL));
+		ramp_set(rr, v, start, dur);
+		ramp_store(w + (reg ? PW_PAN : PW_VOL), rr);
+		break;
+	  }
+	  case A2D_FILTER12:
+		switch(reg) {
+		  case 1: {	// f12_Q, filter12.c:149-162 (host did the 1/v)
+			Ramp q = ramp_load(w + FW_Q);
+			ramp_set(q, v, start, dur);
+			ramp_store(w + FW_Q, q);
+			break;
+		  }
+		  case 2: w[FW_LP] = v >> 8; break;
+		  case 3: w[FW_BP] = v >> 8; break;
+		  case 4: w[FW_HP] = v >> 8; break;
+		}
+		break;
+	  case A2D_FBDELAY:	// fbdelay.c:231-267
+		if(reg < 3)
+			w[DW_FBDELAY + reg] = (int)((int64_t)v * p.samplerate / 65536000);
+		else if(reg < 7)
+			w[DW_FBDELAY + reg] = v;
+		break;
+	  default: break;
+	}
+}
+
+// add the pending output tile into the bus it belongs to and clear it
+DEV void flush_otile(Ctx &c, int out_off, int out_nch)
+{
+	if(out_off < 0)
+		return;
+	lds_sync();
+	int *dst = c.p->busmem + out_off + (size_t)c.frag * out_nch * A2D_FRAG;
+	for(int ch = 0; ch < out_nch; ++ch) {
+		int v = c.l->otile[ch][c.lane];
+		if(v)
+			atomicAdd(&dst[ch * A2D_FRAG + c.lane], v);
+		c.l->otile[ch][c.lane] = 0;
+	}
+}
+
+DEV void process_window(Ctx &c, const A2DVoice &v, int offset, int frames)
+{
+	for(int u = 0; u < v.nunits; ++u) {
+		uint32_t desc = c.p->udesc[v.unit[u]];
+		int *w = c.l->us[u];
+		switch(A2D_KIND(desc)) {
+		  case A2D_WTOSC: osc_process(c, desc, w, offset, frames); break;
+		  case A2D_PANMIX: panmix_process(c, desc, w, offset, frames); break;
+		  case A2D_FILTER12: f12_process(c, desc, w, offset, frames); break;
+		  case A2D_FBDELAY: fbd_process(c, desc, w, offset, frames); break;
+		  case A2D_INLINE: inline_process(c, desc, offset, frames); break;
+		  case A2D_XINSERT: xinsert_process(c, desc, offset, frames); break;
+		}
+		lds_sync();
+	}
+}
+
+#define WAVES_PER_BLOCK 4
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
+void k_voices(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw)
+{
+	__shared__ WaveLDS lds[WAVES_PER_BLOCK];
+	const A2DParams &p = *pp;
+	const int wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	const int gw = blockIdx.x * WAVES_PER_BLOCK + wv;
+	const int first = gw * vpw;
+	if(first >= nlist)
+		return;
+	const int last = min(first + vpw, nlist);
+	Ctx c;
+	c.p = pp;
+	c.l = &lds[wv];
+	c.lane = lane;
+	c.omask = 0;
+	for(int ch = 0; ch < A2D_MAXCH; ++ch) {
+		c.l->otile[ch][lane] = 0;
+		c.l->scratch[ch][lane] = 0;
+	}
+	if(lane < A2D_MAXVPW)
+		c.l->cursor[lane] = 0;
+	lds_sync();
+
+	for(int f = 0; f < p.nfrags; ++f) {
+		const int nframes = p.fragframes[f];
+		int cur_off = -1, cur_nch = 0;
+		c.frag = f;
+		for(int vi = first; vi < last; ++vi) {
+			const int slot = list[vi];
+			const A2DVoice v = p.voices[slot];
+			const A2DRun run = p.runs[slot];
+			if(v.out_off != cur_off) {
+				flush_otile(c, cur_off, cur_nch);
+				cur_off = v.out_off;
+				cur_nch = v.out_nch;
+			}
+			c.own_off = v.own_off;
+			c.own_nch = v.own_nch;
+			// unit states -> LDS
+			for(int u = 0; u < v.nunits; ++u)
+				if(lane < A2D_USTATE)
+					c.l->us[u][lane] = p.ustate[(size_t)v.unit[u] * A2D_USTATE + lane];
+			lds_sync();
+			int active = p.vactive[slot];
+
+			// records of this fragment: the run is sorted by fragment;
+			// skip what earlier fragments consumed
+			int r0 = run.first + c.l->cursor[vi - first], r1 = run.first + run.count;
+			bool explicit_ = (r0 < r1) && ((int)A2D_RFRAG(p.recs[r0].head) == f);
+			if(!explicit_) {
+				// no records: the engine called Process(0, frames)
+				// once on every unit (core.c:1875-1876)
+				if(active)
+					process_window(c, v, 0, nframes);
+			} else {
+				for(; r0 < r1 && (int)A2D_RFRAG(p.recs[r0].head) == f; ++r0) {
+					const A2DRec r = p.recs[r0];
+					const int u = A2D_RUNIT(r.head);
+					switch(A2D_ROP(r.head)) {
+					  case R_SEG:
+						if(active)
+							process_window(c, v, r.dur & 0xffff, r.dur >> 16);
+						break;
+					  case R_INIT:
+						if(lane == 0)
+							unit_init(p, p.udesc[v.unit[u]], c.l->us[u], r);
+						active = 1;
+						break;
+					  case R_WRITE:
+						if(lane == 0)
+							unit_write(p, p.udesc[v.unit[u]], c.l->us[u], r);
+						break;
+					  case R_F1SET:
+						if(lane == 0) {
+							c.l->us[u][FW_F1] = r.value;
+							c.l->us[u][FW_RAMP] = 0;
+						}
+						break;
+					  case R_F1RAMP:
+						if(lane == 0) {
+							c.l->us[u][FW_F1NEXT] = r.value;
+							c.l->us[u][FW_RAMP] = 1;
+						}
+						break;
+					  case R_NOISESEED:
+						if(lane == 0)
+							c.l->us[u][OW_SEED] = r.value;
+						break;
+					  case R_KILL:
+						active = 0;
+						break;
+					}
+					lds_sync();
+				}
+			}
+			// unit states -> memory
+			lds_sync();
+			for(int u = 0; u < v.nunits; ++u)
+				if(lane < A2D_USTATE)
+					p.ustate[(size_t)v.unit[u] * A2D_USTATE + lane] = c.l->us[u][lane];
+			if(lane == 0) {
+				p.vactive[slot] = active;
+				c.l->cursor[vi - first] = r0 - run.first;
+			}
+			lds_sync();
+		}
+		flush_otile(c, cur_off, cur_nch);
+	}
+}
+
+int a2d_launch_voices(const A2DParams *dparams, const int *dlist, int nlist, int vpw, void *stream)
+{
+	if(nlist <= 0)
+		return 0;
+	if(vpw < 1)
+		vpw = 1;
+	if(vpw > A2D_MAXVPW)
+		vpw = A2D_MAXVPW;
+	int nwaves = (nlist + vpw - 1) / vpw;
+	int nblocks = (nwaves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+	hipLaunchKernelGGL(k_voices, dim3(nblocks), dim3(64 * WAVES_PER_BLOCK), 0,
+			(hipStream_t)stream, dparams, dlist, nlist, vpw);
+	return (int)hipGetLastError();
+}

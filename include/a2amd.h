@@ -166,22 +166,37 @@ int  a2amd_unit_process(a2amd_ctx *ctx, int unit, unsigned offset,
 int  a2amd_inline_end(a2amd_ctx *ctx, int unit);
 
 /* ---- render ----------------------------------------------------------------*/
-#define A2AMD_RENDER_SUBTREES 1u  /* everything below the root voice's bus   */
-#define A2AMD_RENDER_ROOT     2u  /* root voice chain -> master bus           */
-#define A2AMD_RENDER_ALL      3u
+#define A2AMD_RENDER_SUBTREES 1u  /* kernels: everything below the root voice */
+#define A2AMD_RENDER_ROOT     2u  /* kernels: root voice chain -> master bus  */
+#define A2AMD_RENDER_UPLOAD   4u  /* ship the recorded commands to the GPU    */
+#define A2AMD_RENDER_READBACK 8u  /* master bus -> out[], wait for the GPU    */
+#define A2AMD_RENDER_KEEP    16u  /* keep the recording (re-run it next call) */
+#define A2AMD_RENDER_ALL     15u
 /*
  * Evaluate the recorded fragments on the GPU.  With A2AMD_RENDER_ALL the
  * master bus of every recorded fragment is written, planar, to
  * out[c][0..total_frames) (host pointers; a2_ProcessMaster) and the recording
- * restarts.  Multi-GPU: run SUBTREES, reduce a2amd_rootbus() across ranks
- * (int32 sum is order independent), then ROOT on the rank that owns the root
- * chain.  Returns the number of frames rendered or a negative error.
+ * restarts.  The phases may be issued by separate calls, in the order UPLOAD,
+ * SUBTREES, ROOT, READBACK; out may be NULL unless READBACK is requested.
+ * Multi-GPU: run UPLOAD|SUBTREES, reduce a2amd_rootbus() across ranks (int32
+ * sum is order independent), then ROOT|READBACK on the rank that owns the root
+ * chain.  With KEEP the recording and its uploaded form survive the call, so
+ * the next SUBTREES|ROOT renders the NEXT batch of audio from the same command
+ * stream (what an engine whose VMs all sleep would record again).
+ * Returns the number of frames in the batch or a negative error.
  */
 int  a2amd_render(a2amd_ctx *ctx, unsigned phases, int32_t *const *out,
 		unsigned out_capacity_frames);
 /* Device pointer + size (bytes) of the root voice's inline bus partials for
  * the fragments of the current batch: int32 [batch][channels][64]. */
 int  a2amd_rootbus(a2amd_ctx *ctx, void **devptr, uint64_t *bytes);
+
+/* Begin 'count' further fragments of 'frames' frames in which the engine's
+ * voice walk finds every VM asleep: each live voice gets exactly one
+ * Process(0, frames) per unit and nothing else happens (src/core.c:1852-1878
+ * with no wake-ups).  Fails with A2AMD_EUNSUPPORTED while a noise oscillator
+ * or a ramping filter cutoff needs per-call host work. */
+int  a2amd_fragment_repeat(a2amd_ctx *ctx, unsigned frames, unsigned count);
 
 /* ---- introspection (tests, bench) --------------------------------------*/
 typedef struct a2amd_stats {

@@ -1,0 +1,60 @@
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ORACLE_SO = os.path.join(ROOT, "oracle", "liba2oracle.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def fnv1a_fragments(pcm, frag=64):
+    """FNV-1a 64 of every `frag`-frame fragment (bytes of ch0, then ch1, ...),
+    vectorised over fragments."""
+    nfr = pcm.shape[1] // frag
+    blk = np.ascontiguousarray(
+        pcm[:, :nfr * frag].reshape(pcm.shape[0], nfr, frag).transpose(1, 0, 2)).view(np.uint8)
+    blk = blk.reshape(nfr, -1)
+    h = np.full(nfr, 0xCBF29CE484222325, dtype=np.uint64)
+    prime = np.uint64(0x100000001B3)
+    with np.errstate(over="ignore"):
+        for i in range(blk.shape[1]):
+            h = (h ^ blk[:, i].astype(np.uint64)) * prime
+    return h
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    """The CPU oracle (test infrastructure): built on demand with gcc."""
+    if not os.path.exists(ORACLE_SO):
+        from audiality2_amd import build
+        build.build_oracle()
+    return ctypes.CDLL(ORACLE_SO)
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    import audiality2_amd
+    return audiality2_amd.load_library()
+
+
+def make_oracle(oracle_lib, samplerate=48000, basepitch=None, channels=2):
+    from audiality2_amd import synth
+    from audiality2_amd.replay import Backend
+    if basepitch is None:
+        basepitch = synth.basepitch_for(samplerate)
+    return Backend(oracle_lib, "a2o_", samplerate, basepitch, channels)
+
+
+def make_gpu(samplerate=48000, basepitch=None, channels=2, max_batch=64):
+    import audiality2_amd
+    return audiality2_amd.open_backend(samplerate, basepitch, channels, max_batch=max_batch)

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Regenerate the golden fixtures from the COMPILED REFERENCE.
+
+Runs only where /root/reference is mounted (the build container): builds
+oracle/_ref with oracle/Makefile, then for every case below lets the
+unmodified reference engine render a script while oracle/_ref/ref_tools logs
+the calls it makes through the unit plugin surface.  Committed per case:
+
+  <case>.trace.gz   the call trace (input of every backend)
+  <case>.hash.npy   FNV-1a 64 of the reference's output, one per 64-frame
+                    fragment, channel 0 then channel 1
+  <case>.head.npy   the first 4096 output frames [channels, 4096], for eyeballs
+
+plus reference dumps used to pin the stand-alone pieces of the oracle:
+  p2i_probe.npy     (pitch, a2_P2I(pitch)) pairs           src/pitch.c:57
+  builtin_waves.npz the engine's 24 built-in waves, all mip levels incl. pads
+                    (src/waves.c:629-708)
+"""
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from audiality2_amd.replay import read_pcm  # noqa: E402
+
+REF = "/root/reference"
+TOOLS = os.path.join(ROOT, "oracle", "_ref", "ref_tools")
+A2S = os.path.join(ROOT, "tests", "a2s")
+
+# name, script, program, frames, args
+CASES = [
+    ("sustain", f"{A2S}/sustain.a2s", "Main", 9600, ["4", "0.05"]),
+    ("filter", f"{A2S}/filter.a2s", "Main", 48000, ["4", "0.02"]),
+    ("delaybus", f"{A2S}/delaybus.a2s", "Main", 48000, ["2", "4", "0.05"]),
+    ("scripted", f"{A2S}/scripted.a2s", "Main", 48000, ["0.2"]),
+    ("k2intro", f"{REF}/benchmark/k2intro.a2s", "Song", 6 * 48000, []),
+]
+
+
+def fnv1a_fragments(pcm, frag=64):
+    """FNV-1a 64 per fragment over the little-endian bytes of ch0 then ch1..."""
+    nfr = pcm.shape[1] // frag
+    out = np.zeros(nfr, dtype=np.uint64)
+    prime = np.uint64(0x100000001B3)
+    for f in range(nfr):
+        h = np.uint64(0xCBF29CE484222325)
+        blk = np.ascontiguousarray(pcm[:, f * frag:(f + 1) * frag]).view(np.uint8).reshape(-1)
+        with np.errstate(over="ignore"):
+            for b in blk:
+                h = (h ^ np.uint64(b)) * prime
+        out[f] = h
+    return out
+
+
+def main():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
+    tmp = "/tmp/a2amd_goldens"
+    os.makedirs(tmp, exist_ok=True)
+    for name, script, prog, frames, args in CASES:
+        tr, pcm = f"{tmp}/{name}.trace", f"{tmp}/{name}.pcm"
+        subprocess.run([TOOLS, "trace", script, prog, str(frames), "64", "48000", "2", tr, pcm] + args,
+                       check=True, cwd=os.path.dirname(script))
+        with open(tr, "rb") as f, gzip.GzipFile(f"{HERE}/{name}.trace.gz", "wb", 9, mtime=0) as g:
+            g.write(f.read())
+        audio = read_pcm(pcm, 2, 64)
+        np.save(f"{HERE}/{name}.hash.npy", fnv1a_fragments(audio))
+        np.save(f"{HERE}/{name}.head.npy", audio[:, :4096])
+        print(name, audio.shape, "peak", int(np.abs(audio).max()))
+    subprocess.run([TOOLS, "dump", tmp], check=True)
+    np.save(f"{HERE}/p2i_probe.npy", np.fromfile(f"{tmp}/p2i_probe.bin", dtype="<i4").reshape(-1, 2))
+    raw = np.fromfile(f"{tmp}/builtin_waves.bin", dtype="<i2")
+    pos, waves = 0, {}
+    for k in range(24):
+        hdr = raw[pos:pos + 26].view("<i4")
+        pos += 26
+        sizes = hdr[3:13]
+        n = int(sum(1 + int(s) + 131 for s in sizes))
+        waves[f"w{k}_hdr"] = hdr.copy()
+        waves[f"w{k}_data"] = raw[pos:pos + n].copy()
+        pos += n
+    np.savez_compressed(f"{HERE}/builtin_waves.npz", **waves)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

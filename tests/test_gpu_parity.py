@@ -1,0 +1,137 @@
+"""Parity of the HIP path (through the C ABI of liba2amd.so) with the CPU
+oracle and with the fixtures captured from the compiled reference.
+Bit-exact: everything on this path is integer arithmetic."""
+import os
+
+import numpy as np
+import pytest
+
+from audiality2_amd import synth
+from audiality2_amd.replay import Trace, replay
+from conftest import GOLDEN, fnv1a_fragments, make_gpu, make_oracle
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["sustain", "filter", "delaybus", "scripted", "k2intro"]
+
+
+def first_diff(a, b):
+    d = np.nonzero(a != b)
+    if not len(d[0]):
+        return None
+    i = int(np.argmin(d[1]))
+    return int(d[0][i]), int(d[1][i]), int(a[d[0][i], d[1][i]]), int(b[d[0][i], d[1][i]])
+
+
+@pytest.mark.parametrize("batch", [1, 64])
+@pytest.mark.parametrize("name", CASES)
+def test_reference_traces_on_gpu(oracle_lib, name, batch):
+    """The reference's own call traces (k2intro.a2s and our test scripts),
+    rendered on the GPU, hash-equal to the audio the reference produced."""
+    if name == "k2intro" and batch == 1:
+        pytest.skip("covered by the batched run; one launch set per fragment is slow over 4500 fragments")
+    tr = Trace(os.path.join(GOLDEN, f"{name}.trace.gz"))
+    cfg = tr.config
+    gpu = make_gpu(cfg["samplerate"], cfg["basepitch"], cfg["channels"], max_batch=batch)
+    out = replay(tr, gpu, batch=batch, check_noise=True)
+    gpu.close()
+    want = np.load(os.path.join(GOLDEN, f"{name}.hash.npy"))
+    got = fnv1a_fragments(out)
+    bad = np.nonzero(got != want)[0]
+    if len(bad):
+        ora = make_oracle(oracle_lib, cfg["samplerate"], cfg["basepitch"], cfg["channels"])
+        ref = replay(tr, ora, batch=64)
+        pytest.fail(f"{name}: {len(bad)} fragments differ, first {bad[:4]}; "
+                    f"first sample diff (ch, frame, gpu, oracle) = {first_diff(out, ref)}")
+
+
+@pytest.mark.parametrize("chain,n", [("osc-pan", 1024), ("osc-filter-pan", 512), ("osc2-pan", 300)])
+def test_scenes_match_oracle(oracle_lib, chain, n):
+    """BASELINE config shapes at oracle-friendly sizes, 24 fragments."""
+    outs = []
+    for be in (make_gpu(max_batch=8), make_oracle(oracle_lib)):
+        sc = synth.Scene(be)
+        sc.root()
+        sc.add_voices(n, chain=chain)
+        outs.append(sc.run(24, batch=8))
+        be.close()
+    assert first_diff(outs[0], outs[1]) is None
+
+
+def test_groups_with_delays_match_oracle(oracle_lib):
+    """Config 4 shape: 2-oscillator leaves under inline->fbdelay->fbdelay groups,
+    long and short (< one fragment) delay taps."""
+    outs = []
+    for be in (make_gpu(max_batch=16), make_oracle(oracle_lib)):
+        sc = synth.Scene(be)
+        sc.root()
+        g1 = sc.add_group()
+        g2 = sc.add_group(fb=(1.2, 0.5, 137.9), gains=(0.2, 0.3, 0.3))
+        sc.add_voices(40, chain="osc2-pan", group=g1, total=128)
+        sc.add_voices(40, chain="osc2-pan", group=g2, total=128)
+        sc.add_voices(48, chain="osc-filter-pan", total=128)
+        outs.append(sc.run(150, batch=16))
+        be.close()
+    assert first_diff(outs[0], outs[1]) is None
+
+
+def test_partial_fragments_and_voice_death(oracle_lib):
+    outs = []
+    for be in (make_gpu(max_batch=4), make_oracle(oracle_lib)):
+        sc = synth.Scene(be)
+        sc.root()
+        sc.add_voices(70)
+        a = sc.run(5, batch=4, frames=37)
+        for units in sc.leaves[:30]:
+            for u in units:
+                be.unit_deinit(u)
+        sc.leaves = sc.leaves[30:]
+        b = sc.run(6, batch=4, frames=64)
+        sc.add_voices(10, chain="osc-filter-pan")
+        c = sc.run(3, batch=4, frames=1)
+        outs.append(np.concatenate([a, b, c], axis=1))
+        be.close()
+    assert first_diff(outs[0], outs[1]) is None
+
+
+def test_fragment_repeat_equals_explicit_walk(oracle_lib):
+    """a2amd_fragment_repeat (all VMs asleep) == issuing every Process call."""
+    gpu = make_gpu(max_batch=32)
+    sc = synth.Scene(gpu)
+    sc.root()
+    sc.add_voices(256)
+    first = sc.run(1, batch=1)
+    rc = gpu.lib.a2amd_fragment_repeat(gpu.ctx, 64, 31)
+    assert rc == 0, gpu._err(gpu.ctx)
+    rest = gpu.render(31 * 64)
+    gpu.close()
+    ora = make_oracle(oracle_lib)
+    so = synth.Scene(ora)
+    so.root()
+    so.add_voices(256)
+    want = so.run(32, batch=32)
+    ora.close()
+    assert first_diff(np.concatenate([first, rest], axis=1), want) is None
+
+
+def test_linearity_at_full_size():
+    """Size-independent property at BASELINE size (16384 voices, config 3
+    shape would take the oracle minutes): the bus is a wrap-around sum, so the
+    render of voices A+B equals render(A) + render(B) mod 2^32 on the root's
+    inline bus; the root chain is identity at vol 1, pan 0."""
+    def render(sel):
+        gpu = make_gpu(max_batch=4)
+        sc = synth.Scene(gpu)
+        sc.root()
+        sc.nvoices = sel[0]
+        sc.add_voices(sel[1] - sel[0], chain="osc-filter-pan", total=16384)
+        out = sc.run(1, batch=1)
+        assert gpu.lib.a2amd_fragment_repeat(gpu.ctx, 64, 3) == 0
+        out = np.concatenate([out, gpu.render(3 * 64)], axis=1)
+        gpu.close()
+        return out
+    whole = render((0, 16384))
+    parts = render((0, 9000)).astype(np.int64) + render((9000, 16384)).astype(np.int64)
+    parts = ((parts + 2**31) % 2**32 - 2**31).astype(np.int32)
+    assert whole.any()
+    assert first_diff(whole, parts) is None

@@ -1,0 +1,57 @@
+"""The C-ABI library: loads without a GPU, exports every symbol the header
+declares, and refuses to open (rather than fall back to the CPU) when there is
+no HIP device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "a2amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(a2amd_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    syms = declared_symbols()
+    for need in ("a2amd_open", "a2amd_unit_init", "a2amd_unit_write", "a2amd_unit_process",
+                 "a2amd_unit_deinit", "a2amd_inline_end", "a2amd_wave_upload", "a2amd_render",
+                 "a2amd_fragment", "a2amd_rootbus"):
+        assert need in syms
+
+
+def test_library_exports_every_declared_symbol(gpu_lib):
+    for s in declared_symbols():
+        assert hasattr(gpu_lib, s), f"liba2amd.so lacks {s}"
+
+
+def test_oracle_mirrors_the_call_protocol(oracle_lib):
+    for s in declared_symbols():
+        o = s.replace("a2amd_", "a2o_")
+        if s in ("a2amd_version", "a2amd_rootbus", "a2amd_get_stats", "a2amd_fragment_repeat"):
+            continue
+        assert hasattr(oracle_lib, o), f"oracle lacks {o}"
+
+
+def test_open_fails_loudly_without_gpu(gpu_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from audiality2_amd.replay import Backend
+    with pytest.raises(RuntimeError, match="no usable HIP device|a2amd_open"):
+        Backend(gpu_lib, "a2amd_", 48000, -492789, 2)
+
+
+def test_product_does_not_link_the_oracle():
+    """Nothing under audiality2_amd/ may reference oracle/ (it is the checker)."""
+    pkg = os.path.join(ROOT, "audiality2_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h", ".c")) and fn != "build.py":
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "a2o_" not in text.replace('"a2o_*"', "") or fn == "replay.py", fn
+                assert "liba2oracle" not in text, fn

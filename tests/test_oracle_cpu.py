@@ -1,0 +1,115 @@
+"""The CPU oracle against fixtures generated from the compiled reference
+(tests/golden/make_goldens.py).  Runs without a GPU."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from audiality2_amd import synth
+from audiality2_amd.replay import Trace, replay
+from conftest import GOLDEN, fnv1a_fragments, make_oracle
+
+CASES = ["sustain", "filter", "delaybus", "scripted", "k2intro"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_trace_replay_matches_reference(oracle_lib, name):
+    """Feeding the reference's own call trace to the restatement reproduces the
+    audio the reference rendered, bit for bit, and the engine-global noise RNG
+    stays in step after every oscillator call."""
+    tr = Trace(os.path.join(GOLDEN, f"{name}.trace.gz"))
+    be = make_oracle(oracle_lib, tr.config["samplerate"], tr.config["basepitch"], tr.config["channels"])
+    out = replay(tr, be, batch=64, check_noise=True)
+    be.close()
+    want = np.load(os.path.join(GOLDEN, f"{name}.hash.npy"))
+    head = np.load(os.path.join(GOLDEN, f"{name}.head.npy"))
+    assert out.shape[1] == len(want) * 64
+    assert np.array_equal(out[:, :head.shape[1]], head)
+    got = fnv1a_fragments(out)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, f"first differing fragment {bad[:5]}"
+
+
+def test_replay_batching_is_transparent(oracle_lib):
+    tr = Trace(os.path.join(GOLDEN, "scripted.trace.gz"))
+    outs = []
+    for batch in (1, 7, 64):
+        be = make_oracle(oracle_lib, tr.config["samplerate"], tr.config["basepitch"])
+        outs.append(replay(tr, be, batch=batch, max_fragments=200))
+        be.close()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_p2i_matches_reference(oracle_lib):
+    """a2_P2I over one full octave plus 20000 random pitches in +-128 octaves."""
+    probe = np.load(os.path.join(GOLDEN, "p2i_probe.npy"))
+    tab = (ctypes.c_uint32 * 128)()
+    oracle_lib.a2o_build_pitch_table(tab)
+    oracle_lib.a2o_p2i.restype = ctypes.c_uint
+    oracle_lib.a2o_p2i.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int]
+    for pitch, want in probe[::7]:
+        assert oracle_lib.a2o_p2i(tab, int(pitch)) == (int(want) & 0xFFFFFFFF)
+
+
+def test_builtin_waves_match_reference(oracle_lib):
+    """a2_InitWaves + mip/pad preparation, all 24 waves, every level and pad.
+    pulse1[20] is uninitialised stack memory in the reference (waves.c:640-647);
+    the dump's value is fed back in."""
+    z = np.load(os.path.join(GOLDEN, "builtin_waves.npz"))
+    buf = np.zeros(2048, dtype=np.int16)
+    dst = np.zeros(8192, dtype=np.int16)
+    sizes = (ctypes.c_uint32 * 10)()
+    offs = (ctypes.c_uint32 * 10)()
+    oracle_lib.a2o_wave_pyramid.restype = ctypes.c_uint
+    p16 = ctypes.POINTER(ctypes.c_int16)
+    for k in range(24):
+        hdr, data = z[f"w{k}_hdr"], z[f"w{k}_data"]
+        assert hdr[0] == synth.WMIPWAVE and hdr[1] & synth.LOOPED and hdr[2] == 2048
+        hole = int(data[1 + 20]) if k == 0 else 0
+        assert oracle_lib.a2o_builtin_wave(k, buf.ctypes.data_as(p16), hole) == 0
+        n = oracle_lib.a2o_wave_pyramid(buf.ctypes.data_as(p16), 2048, 1, 10, dst.ctypes.data_as(p16), sizes, offs)
+        assert n == len(data)
+        assert list(sizes) == [int(s) for s in hdr[3:13]]
+        assert np.array_equal(dst[:n], data), f"wave {k}"
+
+
+def test_host_wave_preparation_matches_oracle(oracle_lib):
+    """synth.wave_pyramid (host-side data preparation used by bench/tests) vs
+    the restated a2_render_mipmaps, looped and one-shot, odd lengths."""
+    rng = np.random.default_rng(3)
+    oracle_lib.a2o_wave_pyramid.restype = ctypes.c_uint
+    p16 = ctypes.POINTER(ctypes.c_int16)
+    for length, looped in [(2048, True), (1000, True), (777, False), (5, True), (1, False)]:
+        src = rng.integers(-32768, 32767, length).astype(np.int16)
+        sizes, data = synth.wave_pyramid(src, looped)
+        dst = np.zeros(length * 2 + 10 * 140, dtype=np.int16)
+        sz = (ctypes.c_uint32 * 10)()
+        off = (ctypes.c_uint32 * 10)()
+        n = oracle_lib.a2o_wave_pyramid(src.ctypes.data_as(p16), length, int(looped), 10,
+                                        dst.ctypes.data_as(p16), sz, off)
+        assert list(sz) == sizes
+        assert np.array_equal(np.concatenate(data), dst[:n])
+
+
+def test_basepitch_formula():
+    assert synth.basepitch_for(48000) == -492789      # value the reference reports (trace CONFIG)
+
+
+def test_scene_edge_cases(oracle_lib):
+    """Empty tree, partial fragments, voices dying: the oracle stays sane."""
+    be = make_oracle(oracle_lib)
+    sc = synth.Scene(be)
+    sc.root()
+    out = sc.run(3, batch=2, frames=17)
+    assert out.shape == (2, 51) and not out.any()
+    sc.add_voices(3)
+    out = sc.run(2, batch=8, frames=64)
+    assert out.any()
+    for units in sc.leaves:
+        for u in units:
+            be.unit_deinit(u)
+    sc.leaves = []
+    out = sc.run(2, batch=8, frames=33)
+    assert not out.any()
+    be.close()
