@@ -432,7 +432,9 @@ int upload(a2amd_ctx *c)
 		int maxdepth = -1;
 		for(size_t vi = 0; vi < nv; ++vi) {
 			const HVoice &v = c->voices[vi];
-			if(!v.live || !v.resolved)
+			// voices that died during this batch still render up to their
+			// R_KILL record
+			if(!(v.live || v.dying) || !v.resolved)
 				continue;
 			if(v.inline_pos >= 0) {
 				bydepth[v.depth].push_back((int)vi);
@@ -496,10 +498,13 @@ void end_batch(a2amd_ctx *c)
 	for(size_t vi = 0; vi < c->voices.size(); ++vi) {
 		HVoice &v = c->voices[vi];
 		size_t keep = 0;
+		// (a voice that was set up but not walked yet keeps everything)
+		const bool unborn = v.live && !v.resolved;
 		for(size_t i = 0; i < v.recs.size(); ++i)
-			if((int)A2D_RFRAG(v.recs[i].head) >= done) {
+			if(unborn || (int)A2D_RFRAG(v.recs[i].head) >= done) {
 				A2DRec r = v.recs[i];
-				r.head = (r.head & 0xffff0000u) | (uint32_t)((int)A2D_RFRAG(r.head) - done);
+				int f = (int)A2D_RFRAG(r.head) - done;
+				r.head = (r.head & 0xffff0000u) | (uint32_t)(f < 0 ? 0 : f);
 				v.recs[keep++] = r;
 			}
 		v.recs.resize(keep);
@@ -513,6 +518,8 @@ void end_batch(a2amd_ctx *c)
 	for(int vi : c->deferred_free_voices) {
 		c->voices[vi] = HVoice();
 		c->free_voices.push_back(vi);
+		c->lists_dirty = true;
+		c->voices_dirty = true;
 	}
 	c->deferred_free_voices.clear();
 	for(int ui : c->deferred_free_units)

@@ -163,7 +163,7 @@ class Backend:
     def inline_end(self, unit):
         return self._chk(self._inline_end(self.ctx, unit), "inline_end")
 
-    def render(self, capacity_frames, phases=3):
+    def render(self, capacity_frames, phases=15):
         out = np.zeros((self.channels, max(capacity_frames, 1)), dtype=np.int32)
         ptrs = (C.POINTER(C.c_int32) * self.channels)()
         for c in range(self.channels):
