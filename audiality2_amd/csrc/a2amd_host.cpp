@@ -155,6 +155,9 @@ struct a2amd_ctx {
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+	bool profiling = false;
+	std::vector<hipEvent_t> ev_pool;	// triples: before leaf, after leaf, after root
+	size_t ev_used = 0;
 	uint32_t ptab[128];
 
 	std::vector<HUnit> units;
@@ -585,6 +588,9 @@ int a2amd_open(const a2amd_config *cfg, a2amd_ctx **out)
 	OPENCHK(hipEventCreate(&c->ev0));
 	OPENCHK(hipEventCreate(&c->ev1));
 	OPENCHK(hipEventCreate(&c->ev2));
+	c->ev_pool.push_back(c->ev0);
+	c->ev_pool.push_back(c->ev1);
+	c->ev_pool.push_back(c->ev2);
 	OPENCHK(hipMalloc((void **)&c->d_ptab, sizeof(c->ptab)));
 	OPENCHK(hipMalloc((void **)&c->d_params, sizeof(A2DParams)));
 	OPENCHK(hipMalloc((void **)&c->d_wavepool.d, (size_t)(8u << 20) * sizeof(int16_t)));
@@ -605,7 +611,8 @@ void a2amd_close(a2amd_ctx *c)
 	hipFree(c->d_fbdmem.d); hipFree(c->d_list.d); hipFree(c->d_ptab); hipFree(c->d_params);
 	if(c->h_master)
 		hipHostFree(c->h_master);
-	hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); hipEventDestroy(c->ev2);
+	for(hipEvent_t e : c->ev_pool)
+		hipEventDestroy(e);
 	if(c->own_stream)
 		hipStreamDestroy(c->stream);
 	delete c;
@@ -1068,6 +1075,18 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 	if((phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT)) && !c->uploaded)
 		return c->fail(A2AMD_ESTATE, "render phases out of order: upload first");
 
+	if((phases & A2AMD_RENDER_SUBTREES) && c->profiling) {
+		if(c->ev_used + 3 > c->ev_pool.size())
+			for(int i = 0; i < 3; ++i) {
+				hipEvent_t e;
+				HIPCHK(c, hipEventCreate(&e));
+				c->ev_pool.push_back(e);
+			}
+		c->ev0 = c->ev_pool[c->ev_used];
+		c->ev1 = c->ev_pool[c->ev_used + 1];
+		c->ev2 = c->ev_pool[c->ev_used + 2];
+		c->ev_used += 3;
+	}
 	if(phases & A2AMD_RENDER_SUBTREES) {
 		HIPCHK(c, hipMemsetAsync(c->d_busmem.d, 0, c->bus_used * sizeof(int32_t), c->stream));
 		HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -1147,9 +1166,42 @@ int a2amd_rootbus(a2amd_ctx *c, void **devptr, uint64_t *bytes)
 	return c->fail(A2AMD_ESTATE, "no root voice with an inline bus");
 }
 
-int a2amd_get_stats(const a2amd_ctx *c, a2amd_stats *st)
+static int drain_events(a2amd_ctx *c)
 {
+	if(!c->ev_used)
+		return 0;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	for(size_t i = 0; i + 2 < c->ev_used + 0 && i + 2 < c->ev_pool.size(); i += 3) {
+		float a = 0, b = 0;
+		if(hipEventElapsedTime(&a, c->ev_pool[i], c->ev_pool[i + 1]) == hipSuccess &&
+				hipEventElapsedTime(&b, c->ev_pool[i], c->ev_pool[i + 2]) == hipSuccess) {
+			c->stats.timed_leaf_ms += a;
+			c->stats.timed_all_ms += b;
+			++c->stats.timed_batches;
+		}
+	}
+	c->ev_used = 0;
+	return 0;
+}
+
+int a2amd_get_stats(a2amd_ctx *c, a2amd_stats *st)
+{
+	if(c->profiling)
+		if(int r = drain_events(c))
+			return r;
 	*st = c->stats;
+	return A2AMD_OK;
+}
+
+int a2amd_set_profiling(a2amd_ctx *c, int on)
+{
+	if(int r = drain_events(c))
+		return r;
+	if(on) {
+		c->stats.timed_leaf_ms = c->stats.timed_all_ms = 0;
+		c->stats.timed_batches = 0;
+	}
+	c->profiling = on != 0;
 	return A2AMD_OK;
 }
 

@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py - voice-samples/sec of the MI355X voice-render path.
+
+Workload (BASELINE.json configs[1]): 1 024 sustained voices, wtosc -> panmix,
+48 kHz, fragment = 64 frames, stereo, per GPU.  One "step" = one batch of
+--batch fragments (default 64 = 4096 frames = 85 ms of audio) rendered for all
+voices: upload happened before the timed region (the command stream of
+sustained voices is empty and identical for every batch, so the same uploaded
+batch is re-run; each run renders the NEXT 85 ms of audio).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns
+its own voice subtrees (weak scaling: --voices per GPU); per step each rank
+renders its subtrees into its partial of the root voice's inline bus, the
+partials are summed with ONE RCCL reduce (int32, wrap-around sum => exact in
+any order), and rank 0 runs the root chain (panmix must see the sum,
+SURVEY.md 8e).
+
+Prints one JSON line (rank 0).  Extra objects: "roofline" (the dominant kernel
+against the HBM roofline, timed with HIP events on the launch stream inside
+the timed region) and "cpu_baseline" (the compiled reference, or the C port,
+timed on this host's cores on a bounded sample of the same workload).
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_VOICE_SAMPLE = {          # algorithmic HBM bytes
+    "osc-pan": 504.0 / 64.0,        # 7.9 B: (152+96 B state) x2 + 8 B bus share per fragment
+    "osc-filter-pan": 792.0 / 64.0,  # 12.4 B with filter12's 144 B state
+    "osc2-pan": (504.0 + 2 * 152.0) / 64.0,
+}
+HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("fragments", ctypes.c_uint64), ("voice_fragments", ctypes.c_uint64),
+                ("records", ctypes.c_uint64), ("launches", ctypes.c_uint64),
+                ("last_kernel_ms", ctypes.c_double), ("last_leaf_ms", ctypes.c_double),
+                ("live_units", ctypes.c_uint32), ("live_voices", ctypes.c_uint32),
+                ("live_waves", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("timed_leaf_ms", ctypes.c_double), ("timed_all_ms", ctypes.c_double),
+                ("timed_batches", ctypes.c_uint64)]
+
+
+def cpu_baseline(voices, chain, oracle_fragments=600):
+    """Reference (oracle/_ref/ref_bench) if it travelled, else the C port."""
+    program = {"osc-pan": "OscPan", "osc-filter-pan": "OscFilterPan"}.get(chain)
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+    script = os.path.join(ROOT, "tests", "a2s", "bench.a2s")
+    ncores = os.cpu_count() or 1
+    if program and os.path.exists(exe):
+        frags = 7500 if chain == "osc-pan" else 4000      # ~4 s of one core
+        res = {}
+        for threads in sorted({1, min(ncores, 16)}):
+            try:
+                out = subprocess.run([exe, script, program, str(voices), str(frags), str(threads)],
+                                     capture_output=True, text=True, timeout=180, check=True).stdout
+                res[threads] = json.loads(out.strip().splitlines()[-1])
+            except Exception as e:  # noqa: BLE001
+                res[threads] = {"error": str(e)}
+        ok = {t: r for t, r in res.items() if "voice_samples_per_s" in r}
+        if ok:
+            best = max(ok, key=lambda t: ok[t]["voice_samples_per_s"])
+            return {"value": ok[best]["voice_samples_per_s"], "unit": "voice-samples/s", "cores": best,
+                    "kind": "reference",
+                    "single_thread_value": ok.get(1, {}).get("voice_samples_per_s"),
+                    "host_cores": ncores,
+                    "sample": f"{voices} voices {chain}, {frags} fragments of 64 frames "
+                              f"({frags * 64 / 48000:.1f} s of audio), reference engine via a2_Run(64), "
+                              f"{best} thread(s) = {best} independent engine states"}
+    # the C restatement, driven through the same call protocol
+    from audiality2_amd import synth
+    from audiality2_amd.replay import Backend
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liba2oracle.so"))
+    be = Backend(lib, "a2o_", 48000, synth.basepitch_for(48000), 2)
+    sc = synth.Scene(be)
+    sc.root()
+    sc.add_voices(voices, chain=chain)
+    sc.run(1, batch=1)
+    lib.a2o_fragment_repeat.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
+    t0 = time.perf_counter()
+    done = 0
+    while done < oracle_fragments:
+        n = min(64, oracle_fragments - done)
+        assert lib.a2o_fragment_repeat(be.ctx, 64, n) == 0
+        be.render(n * 64)
+        done += n
+    dt = time.perf_counter() - t0
+    be.close()
+    return {"value": voices * 64.0 * oracle_fragments / dt, "unit": "voice-samples/s", "cores": 1,
+            "kind": "port", "host_cores": ncores,
+            "sample": f"{voices} voices {chain}, {oracle_fragments} fragments of 64 frames, "
+                      f"C restatement (oracle/a2o.c), 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--voices", type=int, default=1024, help="voices per GPU")
+    ap.add_argument("--chain", default="osc-pan", choices=sorted(BYTES_PER_VOICE_SAMPLE))
+    ap.add_argument("--batch", type=int, default=64, help="fragments per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import audiality2_amd
+    from audiality2_amd import synth
+    from audiality2_amd.replay import Backend
+
+    B = args.batch
+    stream = torch.cuda.current_stream().cuda_stream
+    be = audiality2_amd.open_backend(48000, None, 2, device=local_rank, max_batch=B, stream=stream)
+    lib = be.lib
+    lib.a2amd_fragment_repeat.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
+    lib.a2amd_get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
+    lib.a2amd_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.a2amd_rootbus.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
+
+    # ---- build the voice tree; every rank plays different voices -----------
+    sc = synth.Scene(be)
+    sc.root()
+    sc.nvoices = rank * args.voices
+    sc.add_voices(args.voices, chain=args.chain, total=args.voices * world)
+
+    def repeat(n):
+        rc = lib.a2amd_fragment_repeat(be.ctx, 64, n)
+        if rc:
+            raise RuntimeError(be._err(be.ctx))
+
+    # first batch: the explicit engine walk (voice inits + control writes)
+    sc.walk(64)
+    repeat(B - 1)
+    first = be.render(B * 64)
+
+    parity = None
+    if rank == 0 and world == 1 and not args.no_parity:
+        olib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liba2oracle.so"))
+        ob = Backend(olib, "a2o_", 48000, synth.basepitch_for(48000), 2)
+        so = synth.Scene(ob)
+        so.root()
+        so.add_voices(args.voices, chain=args.chain, total=args.voices)
+        nchk = min(B, 8)
+        want = so.run(nchk, batch=nchk)
+        ob.close()
+        parity = bool(np.array_equal(first[:, :nchk * 64], want))
+        if not parity:
+            raise SystemExit("bench.py: GPU render differs from the CPU oracle; refusing to report a number")
+
+    # ---- steady state: record once, upload once, re-run ----------------------
+    UP, SUB, ROOTP, RB, KEEP = 4, 1, 2, 8, 16
+    repeat(B)
+    be.render(0, phases=UP | KEEP)
+
+    rootbus = None
+    if world > 1:
+        ptr, nbytes = ctypes.c_void_p(), ctypes.c_uint64()
+        if lib.a2amd_rootbus(be.ctx, ctypes.byref(ptr), ctypes.byref(nbytes)):
+            raise RuntimeError(be._err(be.ctx))
+
+        class _Wrap:
+            __cuda_array_interface__ = {"shape": (nbytes.value // 4,), "typestr": "<i4",
+                                        "data": (ptr.value, False), "version": 2}
+        rootbus = torch.as_tensor(_Wrap(), device=torch.device("cuda", local_rank))
+
+    def step():
+        if world == 1:
+            be.render(0, phases=SUB | ROOTP | KEEP)
+        else:
+            be.render(0, phases=SUB | KEEP)
+            dist.reduce(rootbus, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                be.render(0, phases=ROOTP | KEEP)
+
+    for _ in range(args.warmup):
+        step()
+    lib.a2amd_set_profiling(be.ctx, 1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    st = Stats()
+    lib.a2amd_get_stats(be.ctx, ctypes.byref(st))
+    lib.a2amd_set_profiling(be.ctx, 0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    last = be.render(B * 64, phases=RB) if (world == 1 or rank == 0) else None
+    if world > 1 and rank != 0:
+        be.render(0, phases=ROOTP)      # close the batch on the other ranks
+
+    if rank == 0:
+        vs_per_step = float(args.voices) * world * B * 64
+        value = vs_per_step * args.steps / dt
+        leaf_ms = st.timed_leaf_ms / max(st.timed_batches, 1)
+        bpvs = BYTES_PER_VOICE_SAMPLE[args.chain]
+        achieved = bpvs * args.voices * B * 64 / (leaf_ms * 1e-3) / 1e9 if leaf_ms > 0 else None
+        line = {
+            "metric": "voice-samples/sec (max realtime voices @48kHz reported alongside)",
+            "value": value, "unit": "voice-samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"{args.voices} voices/GPU, {args.chain} (wtosc->panmix = BASELINE "
+                                   f"configs[1]), 48 kHz, fragment=64, stereo",
+                       "voices_per_gpu": args.voices, "chain": args.chain, "fragments_per_step": B,
+                       "samplerate": 48000, "sharding": "voice subtrees per GPU + 1 RCCL int32 reduce "
+                       "of the root bus per step" if world > 1 else "single GPU"},
+            "realtime_factor": value / (args.voices * world * 48000.0),
+            "max_realtime_voices_at_this_rate": int(value / 48000.0),
+            "parity_vs_oracle": parity,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                         "kernel": "k_voices (leaf launch)", "avg_launch_ms": leaf_ms,
+                         "launches_timed": int(st.timed_batches),
+                         "algorithmic_bytes_per_voice_sample": bpvs,
+                         "all_kernels_ms_per_step": st.timed_all_ms / max(st.timed_batches, 1)},
+            "output_check": {"peak": int(np.abs(last).max()), "nonzero": bool(last.any())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.voices, args.chain)
+        print(json.dumps(line))
+    be.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -207,8 +207,17 @@ typedef struct a2amd_stats {
 	double   last_kernel_ms;   /* HIP-event time of the last batch's kernels */
 	double   last_leaf_ms;     /* ... of the leaf-voice kernel alone        */
 	uint32_t live_units, live_voices, live_waves, reserved;
+	/* with a2amd_set_profiling(ctx, 1): HIP-event times, summed over every
+	 * batch rendered since profiling was switched on */
+	double   timed_leaf_ms;    /* the leaf-voice kernel                     */
+	double   timed_all_ms;     /* all kernels of a batch                    */
+	uint64_t timed_batches;
 } a2amd_stats;
-int  a2amd_get_stats(const a2amd_ctx *ctx, a2amd_stats *st);
+/* Waits for the stream when profiling is on (event times are read back). */
+int  a2amd_get_stats(a2amd_ctx *ctx, a2amd_stats *st);
+/* Bracket every batch's kernels with HIP events on the launch stream; the sums
+ * appear in a2amd_stats.  Switching it on resets the sums. */
+int  a2amd_set_profiling(a2amd_ctx *ctx, int on);
 
 #ifdef __cplusplus
 }

@@ -323,6 +323,12 @@ struct a2o_ctx
 	int		stack[256];
 	int		sp;
 
+	/* call pattern of the last explicitly walked fragment (for
+	 * a2o_fragment_repeat): unit ids, or -1 - unit for an inline_end */
+	int		*pattern;
+	int		npattern, cap_pattern;
+	int		replaying;
+
 	/* fragment clock + master bus (A2_state.master) */
 	int		frag_open;
 	unsigned	frag_frames;
@@ -375,6 +381,7 @@ void a2o_close(a2o_ctx *c)
 		free(c->units[i].rbuf);
 	}
 	free(c->units);
+	free(c->pattern);
 	for(i = 0; i < c->nvoices; ++i)
 		free(c->voices[i]);
 	free(c->voices);
@@ -497,7 +504,49 @@ int a2o_fragment(a2o_ctx *c, unsigned frames)
 	c->frag_frames = frames;
 	c->frag_open = 1;
 	c->building = NULL;
+	if(!c->replaying)
+		c->npattern = 0;
 	return A2AMD_OK;
+}
+
+static void pattern_add(a2o_ctx *c, int code)
+{
+	if(c->replaying)
+		return;
+	if(c->npattern == c->cap_pattern)
+	{
+		int nc = c->cap_pattern ? c->cap_pattern * 2 : 4096;
+		int *np = (int *)realloc(c->pattern, nc * sizeof(int));
+		if(!np)
+			return;
+		c->pattern = np;
+		c->cap_pattern = nc;
+	}
+	c->pattern[c->npattern++] = code;
+}
+
+/*
+ * 'count' more fragments in which the engine's voice walk finds every VM
+ * asleep: the Process calls of the last walked fragment again, each over the
+ * full fragment (core.c:1852-1878 with no wake-ups).  No noise oscillators.
+ */
+int a2o_fragment_repeat(a2o_ctx *c, unsigned frames, unsigned count)
+{
+	unsigned n;
+	int i, r = A2AMD_OK;
+	c->replaying = 1;
+	for(n = 0; n < count && !r; ++n)
+	{
+		if((r = a2o_fragment(c, frames)))
+			break;
+		for(i = 0; i < c->npattern && !r; ++i)
+			if(c->pattern[i] >= 0)
+				r = a2o_unit_process(c, c->pattern[i], 0, frames, NULL);
+			else
+				r = a2o_inline_end(c, -1 - c->pattern[i]);
+	}
+	c->replaying = 0;
+	return r;
 }
 
 int a2o_render(a2o_ctx *c, unsigned phases, int32_t *const *out, unsigned cap)
@@ -1237,6 +1286,8 @@ int a2o_unit_process(a2o_ctx *c, int id, unsigned offset, unsigned frames,
 		return fail(c, A2AMD_ESTATE, "process [%u,+%u) outside fragment",
 				offset, frames);
 	c->building = NULL;
+	if(!offset)
+		pattern_add(c, id);
 	v = u->voice;
 	resolve_out(c, v);
 	for(ch = 0; ch < MAXCH; ++ch)
@@ -1317,5 +1368,6 @@ int a2o_inline_end(a2o_ctx *c, int id)
 	if(!c->sp || c->stack[c->sp - 1] != id)
 		return fail(c, A2AMD_ESTATE, "inline_end(%d) does not match", id);
 	--c->sp;
+	pattern_add(c, -1 - id);
 	return A2AMD_OK;
 }

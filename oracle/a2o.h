@@ -35,6 +35,7 @@ int  a2o_get_pitch_table(const a2o_ctx *ctx, uint32_t *tab128);
 int  a2o_wave_upload(a2o_ctx *ctx, uint64_t key, const a2amd_wavedesc *w);
 int  a2o_wave_drop(a2o_ctx *ctx, uint64_t key);
 int  a2o_fragment(a2o_ctx *ctx, unsigned frames);
+int  a2o_fragment_repeat(a2o_ctx *ctx, unsigned frames, unsigned count);
 int  a2o_unit_init(a2o_ctx *ctx, uint64_t voice_key, int kind, unsigned flags,
 		int ninputs, int noutputs, int wired_out, int transpose,
 		unsigned wakefrac);

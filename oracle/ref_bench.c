@@ -1,0 +1,122 @@
+/*
+ * ref_bench.c - times the COMPILED REFERENCE (oracle/_ref/libaudiality2.so) on
+ * a sustained-voice workload, one engine state per thread.
+ *
+ * TEST / MEASUREMENT INFRASTRUCTURE ONLY: this is the "cpu_baseline" leg of
+ * bench.py (kind "reference").  No wrappers, no tracing: the reference's own
+ * units render.  The reference is single-threaded per engine state; T threads
+ * means T independent master states with voices/T voices each, the only
+ * thread-safe arrangement (include/audiality2.h.cmake:163-166).
+ *
+ * usage: ref_bench <script.a2s> <program> <voices> <fragments> <threads>
+ * prints: one JSON line {voice_samples_per_s, seconds, voices, fragments, threads, active_voices}
+ */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "audiality2.h"
+#include "a2_drivers.h"
+#include "a2_properties.h"
+
+typedef struct JOB
+{
+	const char	*script, *program;
+	int		voices, fragments;
+	double		seconds;
+	int		active;
+	int		ok;
+} JOB;
+
+static double now(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+static void *run(void *arg)
+{
+	JOB *j = (JOB *)arg;
+	A2_driver *drv;
+	A2_config *cfg;
+	A2_interface *i;
+	A2_handle bank, prog;
+	int args[2], f, av = 0;
+	double t0;
+	if(!(drv = a2_NewDriver(A2_AUDIODRIVER, "buffer")))
+		return NULL;
+	if(!(cfg = a2_OpenConfig(48000, 64, 2, A2_AUTOCLOSE)))
+		return NULL;
+	a2_AddDriver(cfg, drv);
+	if(!(i = a2_Open(cfg)))
+		return NULL;
+	if((bank = a2_Load(i, j->script, 0)) < 0)
+		return NULL;
+	if((prog = a2_Get(i, bank, j->program)) < 0)
+		return NULL;
+	args[0] = (j->voices / 4) << 16;
+	args[1] = (int)(65536.0 * 4.0 / (j->voices > 4 ? j->voices : 4));
+	a2_TimestampReset(i);
+	if(a2_Starta(i, a2_RootVoice(i), prog, 2, args) < 0)
+		return NULL;
+	/* warm-up: instantiates the voices */
+	for(f = 0; f < j->voices / 4 * 2 / 64 + 16; ++f)
+		a2_Run(i, 64);
+	t0 = now();
+	for(f = 0; f < j->fragments; ++f)
+		a2_Run(i, 64);
+	j->seconds = now() - t0;
+	a2_GetStateProperty(i, A2_PACTIVEVOICES, &av);
+	j->active = av;
+	j->ok = 1;
+	a2_Close(i);
+	return NULL;
+}
+
+int main(int argc, const char *argv[])
+{
+	int voices, fragments, threads, t, active = 0;
+	double worst = 0;
+	JOB *jobs;
+	pthread_t *th;
+	if(argc < 6)
+	{
+		fprintf(stderr, "usage: ref_bench <a2s> <program> <voices> "
+				"<fragments> <threads>\n");
+		return 1;
+	}
+	voices = atoi(argv[3]);
+	fragments = atoi(argv[4]);
+	threads = atoi(argv[5]);
+	if(threads < 1)
+		threads = 1;
+	jobs = calloc(threads, sizeof(JOB));
+	th = calloc(threads, sizeof(pthread_t));
+	for(t = 0; t < threads; ++t)
+	{
+		jobs[t].script = argv[1];
+		jobs[t].program = argv[2];
+		jobs[t].voices = voices / threads;
+		jobs[t].fragments = fragments;
+		pthread_create(&th[t], NULL, run, &jobs[t]);
+	}
+	for(t = 0; t < threads; ++t)
+	{
+		pthread_join(th[t], NULL);
+		if(!jobs[t].ok)
+		{
+			fprintf(stderr, "ref_bench: thread %d failed\n", t);
+			return 1;
+		}
+		if(jobs[t].seconds > worst)
+			worst = jobs[t].seconds;
+		active += jobs[t].active;
+	}
+	printf("{\"voice_samples_per_s\": %.6g, \"seconds\": %.6f, \"voices\": %d, "
+			"\"fragments\": %d, \"threads\": %d, \"active_voices\": %d}\n",
+			(double)(voices / threads) * threads * 64.0 * fragments / worst,
+			worst, (voices / threads) * threads, fragments, threads, active);
+	return 0;
+}
