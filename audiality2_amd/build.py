@@ -17,8 +17,10 @@ def _newer(target, sources):
 
 def build_lib(force=False):
     csrc = os.path.join(HERE, "csrc")
-    srcs = [os.path.join(csrc, "a2amd_host.cpp"), os.path.join(csrc, "a2amd_kernels.hip")]
-    deps = srcs + [os.path.join(csrc, "a2amd_device.h"), os.path.join(ROOT, "include", "a2amd.h")]
+    srcs = [os.path.join(csrc, "a2amd_host.cpp"), os.path.join(csrc, "a2amd_kernels.hip"),
+            os.path.join(csrc, "a2amd_fast.hip")]
+    deps = srcs + [os.path.join(csrc, "a2amd_device.h"), os.path.join(csrc, "a2amd_dsp.h"),
+                   os.path.join(ROOT, "include", "a2amd.h")]
     out = os.path.join(HERE, "liba2amd.so")
     if force or _newer(out, deps):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

@@ -102,9 +102,14 @@ struct A2DParams {
 	const uint32_t *ptab;		// 64 x {base, coeff}, pitch.c:70-96
 	int32_t         nfrags;
 	int32_t         samplerate;
+	int32_t         debug;		// A2AMD_DEBUG ablation bits (perf experiments only)
 	uint8_t         fragframes[A2D_MAXBATCH];
 };
 
 // launchers implemented in a2amd_kernels.hip (stream = hipStream_t)
 // dparams / dlist are device pointers; 'vpw' voices of the list per wavefront
 int a2d_launch_voices(const A2DParams *dparams, const int *dlist, int nlist, int vpw, void *stream);
+// hp = host copy of *dparams (device pointers passed as direct kernel arguments)
+int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
+		int vpw, void *stream);
+int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, void *stream);

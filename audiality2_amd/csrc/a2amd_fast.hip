@@ -1,0 +1,538 @@
+// a2amd_fast.hip - specialised kernels for voices that are "quiet" in a batch
+// (no command records: every fragment is the engine's default
+// Process(0, frames) on each unit).  They read and write the same device state
+// as the general kernel (a2amd_kernels.hip), so a voice can move between the
+// two from one batch to the next; results are bit-identical by construction
+// and by test (tests/test_gpu_parity.py runs both).
+//
+//   k_leaf_oscpan   wtosc (mip-mapped wave) -> panmix 1->2, the BASELINE
+//                   config 2 voice.  A wavefront owns up to 64 voices.  Lane =
+//                   sample frame while rendering, so everything per voice is
+//                   wave-uniform: the voice state is parked one voice per lane
+//                   in 22 VGPRs and pulled into SGPRs with v_readlane when its
+//                   turn comes, and rampers, pitch table lookup, mip selection
+//                   and phase wrap run on the scalar unit while the vector
+//                   unit does the two Hermite taps, the amplitude and the pan
+//                   multiplies.  Wave data is fetched as three aligned dwords
+//                   per frame (five int16 cover both taps) from addresses that
+//                   are consecutive across lanes.  The voices of a wavefront
+//                   are summed in registers and reach the bus with one atomic
+//                   per (wavefront, fragment, channel, frame).
+//   k_bus_driver    inline -> panmix 2->2 -> xinsert: the engine's root and
+//                   group voices (audiality2.c:271-302).  One workgroup per
+//                   voice; the fragments of the batch are independent once the
+//                   two rampers have been stepped through them, so thread 0
+//                   steps the rampers and the wavefronts then split the
+//                   fragments.
+#include <hip/hip_runtime.h>
+#include "a2amd_device.h"
+#include "a2amd_dsp.h"
+
+#define FAST_WPB   4		// wavefronts per workgroup
+#define FAST_FCH   8		// fragments whose bus sums stay in registers at a time
+
+DEV int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
+DEV int rdl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// park a wave-uniform value back in lane 'sel' of a per-lane register
+#define WRL(reg, val) reg = me ? (val) : reg
+
+// a2_Hermite (a2_dsp.h:64-74) on four already fetched samples.  The operands of
+// the three products are below 2^20 and 2^15 in magnitude, so the 24 bit
+// multiplier returns the same low 32 bits as the reference's int multiply
+// (including its wrap-around) at full rate.
+DEV int hermite4(int dm, int d0, int d1, int d2, int frac)
+{
+	int x = frac << 7;
+	int c = (d1 - dm) >> 1;
+	int a = (3 * (d0 - d1) + d2 - dm) >> 1;
+	int b = dm - d0 + c - a;
+	a = __mul24(a, x) >> 15;
+	a = __mul24(a + b, x) >> 15;
+	return d0 + (__mul24(a + c, x) >> 15);
+}
+
+// Both taps of wtosc_Inter (wtosc.c:28-33) from the three dwords that hold
+// d[i-1 .. i+3] (+1 spare), 'odd' = the window starts in the upper half of w0.
+// The second tap is at most one sample further (dph16 <= 512 << 8).
+DEV int inter_from_dwords(uint32_t w0, uint32_t w1, uint32_t w2, unsigned odd, unsigned ph, unsigned dph16)
+{
+	unsigned ph2 = ph + (dph16 >> 1);
+	bool up = (ph2 >> 8) != (ph >> 8);
+	uint32_t x0 = odd ? __builtin_amdgcn_alignbit(w1, w0, 16) : w0;	// dm | d0 << 16
+	uint32_t x1 = odd ? __builtin_amdgcn_alignbit(w2, w1, 16) : w1;	// d1 | d2 << 16
+	int dm = (int16_t)(x0 & 0xffff), d0 = (int)x0 >> 16;
+	int d1 = (int16_t)(x1 & 0xffff), d2 = (int)x1 >> 16;
+	int d3 = odd ? ((int)w2 >> 16) : (int)(int16_t)(w2 & 0xffff);
+	int h0 = hermite4(dm, d0, d1, d2, (int)(ph & 0xff));
+	int s0 = up ? d0 : dm, s1 = up ? d1 : d0, s2 = up ? d2 : d1, s3 = up ? d3 : d2;
+	return h0 + hermite4(s0, s1, s2, s3, (int)(ph2 & 0xff));
+}
+
+// wtosc_Inter at 24:8 phase ph from wave data d (first payload sample): the
+// five samples d[i-1 .. i+3] serve both taps and come in as three aligned dwords.
+DEV int inter_dwords(const int16_t *d, unsigned ph, unsigned dph16)
+{
+	const int16_t *q = d + ((int)(ph >> 8) - 1);
+	unsigned odd = (unsigned)(((uintptr_t)q) >> 1) & 1u;
+	const uint32_t *a = (const uint32_t *)(q - odd);
+	return inter_from_dwords(a[0], a[1], a[2], odd, ph, dph16);
+}
+
+// ---- cold paths: kept out of line so the hot loop stays small -------------
+// (all operands are wave-uniform; results go back to SGPRs via readfirstlane)
+__device__ __attribute__((noinline)) int cold_ramp_delta(int target, int value, int timer, int frames,
+		int *newtimer)
+{
+	// the two ramping branches of a2_PrepareRamper, a2_dsp.h:134-148
+	if(frames <= (timer >> 8)) {
+		*newtimer = wsub(timer, frames << 8);
+		return (int)((((int64_t)wsub(target, value)) * 256) / timer);
+	}
+	*newtimer = 0;
+	return wsub(target, value) / frames;
+}
+
+__device__ __attribute__((noinline)) uint64_t cold_umod64(uint64_t a, uint64_t m)
+{
+	return a % m;
+}
+
+// ph %= (uint64_t)size << 24 (wtosc.c:260-263) for wave-uniform operands.  The
+// low 24 bits pass through, so this is a 32 bit modulo of the sample index; the
+// built-in waves and their mip levels have power-of-two sizes (a mask).
+DEV uint64_t wrap_phase(uint64_t ph, unsigned size)
+{
+	if(ph >> 56) {		// never in practice: index beyond 32 bits
+		uint64_t r = cold_umod64(ph, (uint64_t)size << 24);
+		return (uint64_t)(unsigned)rfl((int)(unsigned)r) | ((uint64_t)(unsigned)rfl((int)(unsigned)(r >> 32)) << 32);
+	}
+	unsigned hi = (unsigned)(ph >> 24);
+	if(hi >= size) {
+		if(!(size & (size - 1)))
+			hi &= size - 1;
+		else
+			hi = (unsigned)rfl((int)(hi % size));
+		ph = ((uint64_t)hi << 24) | (ph & 0xffffffu);
+	}
+	return ph;
+}
+
+// a2_PrepareRamper with a scalar fast path for the finished ramp
+DEV void ramp_prepare_s(Ramp &r, int frames)
+{
+	if(r.timer == 0) {
+		r.value = r.target;
+		r.delta = 0;
+	} else {
+		int nt;
+		int d = cold_ramp_delta(r.target, r.value, r.timer, frames, &nt);
+		r.delta = rfl(d);
+		r.timer = rfl(nt);
+	}
+}
+
+struct OscS {		// A2_wtosc, wave-uniform copy
+	int mode, wave;
+	unsigned dphase;
+	uint64_t phase;
+	int p_ramping;
+	Ramp p, a;
+};
+
+struct FastPtrs {
+	const int16_t *wavepool;
+	const A2DWave *waves;
+	const uint32_t *ptab;
+	int dbg;
+};
+
+// One default fragment of wtosc (mip wave) -> panmix 1->2 adding into the
+// voice's output bus: wtosc_wavetable (wtosc.c:239-286) + panmix_process12
+// (panmix.c:78-135) fused per frame; frame = lane.  Everything named o.*, vol,
+// pan lives in SGPRs.
+DEV void oscpan_fragment(const FastPtrs &g, OscS &o, Ramp &vol, Ramp &pan,
+		int nframes, int lane, int &acc0, int &acc1)
+{
+	int x = 0;		// the sample wtosc leaves in the scratch buffer
+	const bool in = lane < nframes;
+	if(o.mode == A2D_OSC_MIPWAVE) {
+		const A2DWave *w = g.waves + o.wave;
+		const unsigned size0 = w->size[0], period = w->period, flags = w->flags;
+		if(!size0) {		// wtosc_check_unloaded, wtosc.c:168-183
+			o.wave = -1;
+			o.mode = A2D_OSC_OFF;
+		} else {
+			// wtosc_run_pitch, wtosc.c:89-105
+			ramp_prepare_s(o.p, nframes);
+			if(!(o.dphase && (!o.p.timer && !o.p_ramping))) {
+				unsigned lastv = (unsigned)o.p.value;
+				ramp_run(o.p, nframes);
+				o.p_ramping = o.p.delta;
+				o.dphase = (unsigned)rfl((int)p2i(g.ptab, (int)((lastv + (unsigned)o.p.value) >> 9)));
+			}
+			unsigned dph = ((o.dphase + 255) >> 8) * period;
+			ramp_prepare_s(o.a, nframes);
+			unsigned mm = 0;
+			for(; (dph > (A2D_MAXPHINC << 8)) && (mm < A2D_MIPS - 1); ++mm)
+				dph >>= 1;
+			uint64_t ph = o.phase >> mm;
+			dph = (unsigned)(((uint64_t)o.dphase * period) >> mm);
+			const unsigned sizem = w->size[mm];
+			bool play = true;
+			if(flags & 0x100u) {
+				ph = wrap_phase(ph, sizem);
+			} else if((ph >> 24) > (uint64_t)(sizem + 1))
+				play = false;	// all played: silence, state untouched
+			if(play) {
+				if(dph <= (A2D_MAXPHINC << 16)) {
+					const int16_t *d = g.wavepool + w->off[mm];
+					if(in) {
+						uint64_t phk = ph + (uint64_t)(unsigned)lane * dph;
+						int ak = wadd(o.a.value, wmul(o.a.delta, lane));
+						int v = inter_dwords(d, (unsigned)(phk >> 16), dph >> 16);
+						x = mul64s(v, ak, 17);
+					}
+				}
+				ph += (uint64_t)dph * (unsigned)nframes;
+				o.phase = ph << mm;
+				ramp_run(o.a, nframes);
+			}
+		}
+	} else {		// wtosc_Off, wtosc.c:108-126
+		ramp_prepare_s(o.p, nframes);
+		ramp_prepare_s(o.a, nframes);
+		ramp_run(o.p, nframes);
+		ramp_run(o.a, nframes);
+	}
+	// panmix_Process12Add, panmix.c:117-125
+	const bool clamp = pan.target > 0xffffff || pan.target < -0xffffff ||
+			pan.value > 0xffffff || pan.value < -0xffffff;
+	ramp_prepare_s(vol, nframes);
+	ramp_prepare_s(pan, nframes);
+	if(in) {
+		int vk = wadd(vol.value, wmul(vol.delta, lane));
+		int pk = wadd(pan.value, wmul(pan.delta, lane));
+		int vp = mul64s(pk, vk, 24);
+		int v0 = wsub(vk, vp), v1 = wadd(vk, vp);
+		if(clamp) {
+			int lim = wshl(vk, 1);
+			if(v0 > lim) v0 = lim;
+			if(v1 > lim) v1 = lim;
+		}
+		acc0 = wadd(acc0, mul64s(x, v0, 24));
+		acc1 = wadd(acc1, mul64s(x, v1, 24));
+	}
+	ramp_run(vol, nframes);
+	ramp_run(pan, nframes);
+}
+
+// frames of fragment f from the per-lane table (f is wave-uniform)
+DEV int frames_of(const int (&ffr)[A2D_MAXBATCH / 64], int f)
+{
+	int r = 0;
+#pragma unroll
+	for(int k = 0; k < A2D_MAXBATCH / 64; ++k)
+		if((f >> 6) == k)
+			r = rdl(ffr[k], f & 63);
+	return r;
+}
+
+// add the register sums of a chunk of fragments into the bus and clear them
+DEV void flush_acc(int *busmem, int off, int nch, int f0, int nf, int lane, int dbg,
+		int (&acc0)[FAST_FCH], int (&acc1)[FAST_FCH])
+{
+#pragma unroll
+	for(int j = 0; j < FAST_FCH; ++j) {
+		if(j < nf && off >= 0 && !(dbg & 1)) {
+			int *dst = busmem + off + (size_t)(f0 + j) * nch * A2D_FRAG;
+			if(acc0[j])
+				atomicAdd(&dst[lane], acc0[j]);
+			if(acc1[j])
+				atomicAdd(&dst[A2D_FRAG + lane], acc1[j]);
+		}
+		acc0[j] = 0;
+		acc1[j] = 0;
+	}
+}
+
+// state words of one wtosc->panmix voice, kept one voice per lane in VGPRs
+enum { SV_MODE = 0, SV_WAVE, SV_DPHASE, SV_PHLO, SV_PHHI, SV_PRAMP, SV_P = 6, SV_A = 10,
+	SV_VOL = 14, SV_PAN = 18, SV_NWORDS = 22 };
+
+__global__ __launch_bounds__(64 * FAST_WPB)
+void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
+		const A2DVoice *__restrict__ voices, int *__restrict__ ustate,
+		const int16_t *__restrict__ wavepool, const A2DWave *__restrict__ waves,
+		const uint32_t *__restrict__ ptab, int *__restrict__ busmem)
+{
+	const A2DParams &p = *pp;
+	const int wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	const int first = (blockIdx.x * FAST_WPB + wv) * vpw;
+	if(first >= nlist)
+		return;
+	const int nv = min(vpw, nlist - first);
+	const int nfrags = p.nfrags;
+	const int dbg = p.debug;
+	FastPtrs g = { wavepool, waves, ptab, dbg };
+
+	// fragment lengths: lane l of ffr[k] holds fragment 64*k + l (byte loads are
+	// vector memory operations; do them once, not per fragment)
+	int ffr[A2D_MAXBATCH / 64];
+#pragma unroll
+	for(int k = 0; k < A2D_MAXBATCH / 64; ++k)
+		ffr[k] = (k * 64 + lane < nfrags) ? p.fragframes[k * 64 + lane] : 0;
+
+	// lane v keeps voice v: its unit ids, output bus and the 22 state words
+	int sv[SV_NWORDS];
+	int u0 = 0, u1 = 0, my_off = -1, my_nch = 2;
+	if(lane < nv) {
+		const A2DVoice &vc = voices[list[first + lane]];
+		u0 = vc.unit[0];
+		u1 = vc.unit[1];
+		my_off = vc.out_off;
+		my_nch = vc.out_nch;
+		const int *w0 = ustate + (size_t)u0 * A2D_USTATE;
+		const int *w1 = ustate + (size_t)u1 * A2D_USTATE;
+		sv[SV_MODE] = w0[OW_MODE]; sv[SV_WAVE] = w0[OW_WAVE]; sv[SV_DPHASE] = w0[OW_DPHASE];
+		sv[SV_PHLO] = w0[OW_PHASE_LO]; sv[SV_PHHI] = w0[OW_PHASE_HI]; sv[SV_PRAMP] = w0[OW_PRAMPING];
+#pragma unroll
+		for(int k = 0; k < 4; ++k) {
+			sv[SV_P + k] = w0[OW_P + k];
+			sv[SV_A + k] = w0[OW_A + k];
+			sv[SV_VOL + k] = w1[PW_VOL + k];
+			sv[SV_PAN + k] = w1[PW_PAN + k];
+		}
+	} else {
+#pragma unroll
+		for(int k = 0; k < SV_NWORDS; ++k)
+			sv[k] = 0;
+	}
+
+	for(int f0 = 0; f0 < nfrags; f0 += FAST_FCH) {
+		const int nf = min((int)FAST_FCH, nfrags - f0);
+		int acc0[FAST_FCH], acc1[FAST_FCH];
+#pragma unroll
+		for(int j = 0; j < FAST_FCH; ++j)
+			acc0[j] = acc1[j] = 0;
+		int nfr[FAST_FCH];	// frames of the chunk's fragments (SGPRs)
+#pragma unroll
+		for(int j = 0; j < FAST_FCH; ++j)
+			nfr[j] = frames_of(ffr, min(f0 + j, nfrags - 1));
+		int cur_off = rdl(my_off, 0), cur_nch = rdl(my_nch, 0);
+		for(int v = 0; v < nv; ++v) {
+			const int voff = rdl(my_off, v);
+			if(voff != cur_off) {
+				flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+				cur_off = voff;
+				cur_nch = rdl(my_nch, v);
+			}
+			OscS o;
+			Ramp vol, pan;
+			o.mode = rdl(sv[SV_MODE], v);
+			o.wave = rdl(sv[SV_WAVE], v);
+			o.dphase = (unsigned)rdl(sv[SV_DPHASE], v);
+			o.phase = (uint64_t)(unsigned)rdl(sv[SV_PHLO], v) |
+					((uint64_t)(unsigned)rdl(sv[SV_PHHI], v) << 32);
+			o.p_ramping = rdl(sv[SV_PRAMP], v);
+			o.p.value = rdl(sv[SV_P], v); o.p.target = rdl(sv[SV_P + 1], v);
+			o.p.delta = rdl(sv[SV_P + 2], v); o.p.timer = rdl(sv[SV_P + 3], v);
+			o.a.value = rdl(sv[SV_A], v); o.a.target = rdl(sv[SV_A + 1], v);
+			o.a.delta = rdl(sv[SV_A + 2], v); o.a.timer = rdl(sv[SV_A + 3], v);
+			vol.value = rdl(sv[SV_VOL], v); vol.target = rdl(sv[SV_VOL + 1], v);
+			vol.delta = rdl(sv[SV_VOL + 2], v); vol.timer = rdl(sv[SV_VOL + 3], v);
+			pan.value = rdl(sv[SV_PAN], v); pan.target = rdl(sv[SV_PAN + 1], v);
+			pan.delta = rdl(sv[SV_PAN + 2], v); pan.timer = rdl(sv[SV_PAN + 3], v);
+			const bool me = lane == v;
+
+			// Settled voice: every ramper has arrived (a2_PrepareRamper would
+			// change nothing) and the pitch is constant, so over the whole
+			// chunk only the phase moves: mip level, increment, amplitude and
+			// the two pan gains are computed once, on the scalar unit.
+			bool settled = nf == FAST_FCH && o.mode == A2D_OSC_MIPWAVE && o.dphase && !o.p_ramping &&
+					!(o.p.timer | o.p.delta | o.a.timer | o.a.delta | vol.timer | vol.delta |
+					  pan.timer | pan.delta) &&
+					o.p.value == o.p.target && o.a.value == o.a.target &&
+					vol.value == vol.target && pan.value == pan.target;
+			unsigned mm = 0, dph = 0, sizem = 0, doff = 0;
+			if(settled) {
+				const A2DWave *w = waves + o.wave;
+				const unsigned period = w->period;
+				dph = ((o.dphase + 255) >> 8) * period;
+				for(; (dph > (A2D_MAXPHINC << 8)) && (mm < A2D_MIPS - 1); ++mm)
+					dph >>= 1;
+				dph = (unsigned)(((uint64_t)o.dphase * period) >> mm);
+				sizem = w->size[mm];
+				doff = w->off[mm];
+				settled = w->size[0] && (w->flags & 0x100u) && dph <= (A2D_MAXPHINC << 16);
+			}
+			if(settled) {
+				// panmix_process12 gains, constant over the chunk (panmix.c:89-104)
+				const bool clamp = pan.value > 0xffffff || pan.value < -0xffffff;
+				const int vp = mul64s(pan.value, vol.value, 24);
+				int v0 = wsub(vol.value, vp), v1 = wadd(vol.value, vp);
+				if(clamp) {
+					int lim = wshl(vol.value, 1);
+					if(v0 > lim) v0 = lim;
+					if(v1 > lim) v1 = lim;
+				}
+				const int amp = o.a.value;
+				const unsigned dph16 = dph >> 16;
+				// scalar pass: the phase each fragment starts from
+				uint64_t ph = o.phase >> mm;
+				uint64_t phs[FAST_FCH];
+#pragma unroll
+				for(int j = 0; j < FAST_FCH; ++j) {
+					ph = wrap_phase(ph, sizem);
+					phs[j] = ph;
+					ph += (uint64_t)dph * (unsigned)nfr[j];
+				}
+				// vector pass, branch free: all wave data loads of the chunk can
+				// be in flight together (lanes past a short fragment read inside
+				// the A2_WAVEPOST pad and are masked at the sum)
+				const uint64_t lanedph = (uint64_t)(unsigned)lane * dph;
+				const uint32_t *wp32 = (const uint32_t *)wavepool;	// pool base is dword aligned
+				uint32_t w0[FAST_FCH], w1[FAST_FCH], w2[FAST_FCH];
+				unsigned ph16[FAST_FCH], odd[FAST_FCH];
+#pragma unroll
+				for(int j = 0; j < FAST_FCH; ++j) {
+					ph16[j] = (unsigned)((phs[j] + lanedph) >> 16);
+					unsigned e = doff + (ph16[j] >> 8) - 1u;	// int16 index of d[i-1]
+					odd[j] = e & 1u;
+					const uint32_t *ap = wp32 + (e >> 1);
+					w0[j] = ap[0]; w1[j] = ap[1]; w2[j] = ap[2];
+				}
+#pragma unroll
+				for(int j = 0; j < FAST_FCH; ++j) {
+					int sm = (dbg & 2) ? (int)ph16[j] :
+							inter_from_dwords(w0[j], w1[j], w2[j], odd[j], ph16[j], dph16);
+					int x = mul64s(sm, amp, 17);
+					x = (lane < nfr[j]) ? x : 0;
+					acc0[j] = wadd(acc0[j], mul64s(x, v0, 24));
+					acc1[j] = wadd(acc1[j], mul64s(x, v1, 24));
+				}
+				o.phase = ph << mm;
+				WRL(sv[SV_PHLO], (int)(unsigned)o.phase);
+				WRL(sv[SV_PHHI], (int)(unsigned)(o.phase >> 32));
+			} else {
+				// anything still moving: the full per-fragment logic
+				for(int j = 0; j < nf; ++j) {
+					int o0 = 0, o1 = 0;
+					oscpan_fragment(g, o, vol, pan, frames_of(ffr, f0 + j), lane, o0, o1);
+#pragma unroll
+					for(int jj = 0; jj < FAST_FCH; ++jj)
+						if(jj == j) {
+							acc0[jj] = wadd(acc0[jj], o0);
+							acc1[jj] = wadd(acc1[jj], o1);
+						}
+				}
+				WRL(sv[SV_MODE], o.mode);
+				WRL(sv[SV_WAVE], o.wave);
+				WRL(sv[SV_DPHASE], (int)o.dphase);
+				WRL(sv[SV_PHLO], (int)(unsigned)o.phase);
+				WRL(sv[SV_PHHI], (int)(unsigned)(o.phase >> 32));
+				WRL(sv[SV_PRAMP], o.p_ramping);
+				WRL(sv[SV_P], o.p.value); WRL(sv[SV_P + 1], o.p.target);
+				WRL(sv[SV_P + 2], o.p.delta); WRL(sv[SV_P + 3], o.p.timer);
+				WRL(sv[SV_A], o.a.value); WRL(sv[SV_A + 1], o.a.target);
+				WRL(sv[SV_A + 2], o.a.delta); WRL(sv[SV_A + 3], o.a.timer);
+				WRL(sv[SV_VOL], vol.value); WRL(sv[SV_VOL + 1], vol.target);
+				WRL(sv[SV_VOL + 2], vol.delta); WRL(sv[SV_VOL + 3], vol.timer);
+				WRL(sv[SV_PAN], pan.value); WRL(sv[SV_PAN + 1], pan.target);
+				WRL(sv[SV_PAN + 2], pan.delta); WRL(sv[SV_PAN + 3], pan.timer);
+			}
+		}
+		flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+	}
+
+	// unit states -> memory
+	if(lane < nv) {
+		int *w0 = ustate + (size_t)u0 * A2D_USTATE;
+		int *w1 = ustate + (size_t)u1 * A2D_USTATE;
+		w0[OW_MODE] = sv[SV_MODE]; w0[OW_WAVE] = sv[SV_WAVE]; w0[OW_DPHASE] = sv[SV_DPHASE];
+		w0[OW_PHASE_LO] = sv[SV_PHLO]; w0[OW_PHASE_HI] = sv[SV_PHHI]; w0[OW_PRAMPING] = sv[SV_PRAMP];
+#pragma unroll
+		for(int k = 0; k < 4; ++k) {
+			w0[OW_P + k] = sv[SV_P + k];
+			w0[OW_A + k] = sv[SV_A + k];
+			w1[PW_VOL + k] = sv[SV_VOL + k];
+			w1[PW_PAN + k] = sv[SV_PAN + k];
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// inline -> panmix 2->2 -> xinsert (add, wired): root / group driver voices
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist)
+{
+	__shared__ int fr[A2D_MAXBATCH][5];	// per fragment: vol, dvol, pan, dpan, clamp
+	const A2DParams &p = *pp;
+	if((int)blockIdx.x >= nlist)
+		return;
+	const A2DVoice &vc = p.voices[list[blockIdx.x]];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	if(threadIdx.x == 0) {
+		// step the two rampers of panmix_process22 (panmix.c:192-249)
+		// through the batch
+		int *w = p.ustate + (size_t)vc.unit[1] * A2D_USTATE;
+		Ramp vol = ramp_load(w + PW_VOL), pan = ramp_load(w + PW_PAN);
+		for(int f = 0; f < p.nfrags; ++f) {
+			const int n = p.fragframes[f];
+			fr[f][4] = pan.target > 0xffffff || pan.target < -0xffffff ||
+					pan.value > 0xffffff || pan.value < -0xffffff;
+			ramp_prepare(vol, n);
+			ramp_prepare(pan, n);
+			fr[f][0] = vol.value; fr[f][1] = vol.delta;
+			fr[f][2] = pan.value; fr[f][3] = pan.delta;
+			ramp_run(vol, n);
+			ramp_run(pan, n);
+		}
+		ramp_store(w + PW_VOL, vol);
+		ramp_store(w + PW_PAN, pan);
+	}
+	__syncthreads();
+	for(int f = wv; f < p.nfrags; f += 4) {
+		if(lane >= p.fragframes[f])
+			continue;
+		const int *src = p.busmem + vc.own_off + (size_t)f * vc.own_nch * A2D_FRAG;
+		int *dst = p.busmem + vc.out_off + (size_t)f * vc.out_nch * A2D_FRAG;
+		int i0 = src[lane], i1 = src[A2D_FRAG + lane];
+		int vk = wadd(fr[f][0], wmul(fr[f][1], lane));
+		int pk = wadd(fr[f][2], wmul(fr[f][3], lane));
+		int vp = mul64s(pk, vk, 24);
+		int v0 = wsub(vk, vp), v1 = wadd(vk, vp);
+		if(fr[f][4]) {
+			int lim = wshl(vk, 1);
+			if(v0 > lim) v0 = lim;
+			if(v1 > lim) v1 = lim;
+		}
+		int o0 = mul64s(i0, v0, 24), o1 = mul64s(i1, v1, 24);
+		if(o0)
+			atomicAdd(&dst[lane], o0);
+		if(o1)
+			atomicAdd(&dst[A2D_FRAG + lane], o1);
+	}
+}
+
+int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
+		int vpw, void *stream)
+{
+	if(nlist <= 0)
+		return 0;
+	vpw = vpw < 1 ? 1 : (vpw > 64 ? 64 : vpw);
+	int nwaves = (nlist + vpw - 1) / vpw;
+	int nblocks = (nwaves + FAST_WPB - 1) / FAST_WPB;
+	hipLaunchKernelGGL(k_leaf_oscpan, dim3(nblocks), dim3(64 * FAST_WPB), 0, (hipStream_t)stream,
+			dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
+	return (int)hipGetLastError();
+}
+
+int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, void *stream)
+{
+	if(nlist <= 0)
+		return 0;
+	hipLaunchKernelGGL(k_bus_driver, dim3(nlist), dim3(256), 0, (hipStream_t)stream, dparams, dlist, nlist);
+	return (int)hipGetLastError();
+}

@@ -141,6 +141,8 @@ struct HVoice {
 	size_t frag_mark = 0;		// recs.size() when that fragment was first touched
 };
 
+struct DepthRange { int fast_first = 0, fast_count = 0, gen_first = 0, gen_count = 0; };
+
 struct HWave {
 	bool live = false;
 	uint64_t key = 0;
@@ -184,7 +186,9 @@ struct a2amd_ctx {
 	bool voices_dirty = true, udesc_dirty = true, waves_dirty = true, lists_dirty = true, ptab_dirty = true;
 	std::vector<int> list_all;		// leaf list followed by per-depth lists
 	int n_leaf = 0;
-	std::vector<std::pair<int,int>> depth_ranges;	// (first, count) per depth, index = depth
+	int n_fast_leaf = 0;			// list_all = [fast leaves | general leaves | per depth ...]
+	std::vector<DepthRange> depth_ranges;	// index = depth
+	bool no_fast = false;			// A2AMD_NO_FAST=1: general kernel only (debugging)
 
 	// bus memory allocator (units of int32)
 	size_t bus_stride_frames;
@@ -212,6 +216,7 @@ struct a2amd_ctx {
 	DevBuf<int> d_list;
 	uint32_t *d_ptab = nullptr;
 	A2DParams *d_params = nullptr;
+	A2DParams hparams;
 	int32_t *h_master = nullptr;	// pinned
 	size_t h_master_cap = 0;
 
@@ -370,6 +375,30 @@ void sync_voice_mirror(a2amd_ctx *c, int vi)
 	m.own_nch = v.own_nch;
 }
 
+// wtosc (mip-mapped wave playing) -> panmix 1->2 adding into the output bus
+bool is_oscpan_chain(const a2amd_ctx *c, const HVoice &v)
+{
+	if(v.nunits != 2 || v.out_nch < 2)
+		return false;
+	const HUnit &o = c->units[v.unit[0]], &pm = c->units[v.unit[1]];
+	return o.kind == A2AMD_WTOSC && !(o.flags & A2AMD_PROCADD) && !o.wired &&
+			(o.mode == A2D_OSC_MIPWAVE || o.mode == A2D_OSC_OFF) &&
+			pm.kind == A2AMD_PANMIX && pm.nin == 1 && pm.nout == 2 && pm.wired &&
+			(pm.flags & A2AMD_PROCADD);
+}
+
+// inline 0 2; panmix 2 2; xinsert 2 >  (a2_rootdriver / a2_groupdriver)
+bool is_driver_chain(const a2amd_ctx *c, const HVoice &v)
+{
+	if(v.nunits != 3 || v.own_nch != 2 || v.out_nch < 2 || v.own_off < 0)
+		return false;
+	const HUnit &il = c->units[v.unit[0]], &pm = c->units[v.unit[1]], &xi = c->units[v.unit[2]];
+	return il.kind == A2AMD_INLINE && !(il.flags & A2AMD_PROCADD) && !il.wired && il.nout == 2 &&
+			pm.kind == A2AMD_PANMIX && pm.nin == 2 && pm.nout == 2 && !pm.wired &&
+			!(pm.flags & A2AMD_PROCADD) &&
+			xi.kind == A2AMD_XINSERT && xi.nin == 2 && xi.wired && (xi.flags & A2AMD_PROCADD);
+}
+
 int upload(a2amd_ctx *c)
 {
 	const size_t nv = c->voices.size(), nu = c->units.size();
@@ -427,11 +456,13 @@ int upload(a2amd_ctx *c)
 				hipMemcpyHostToDevice, c->stream));
 	c->stats.records += recs.size();
 
-	// launch lists: leaves (sorted by output bus so one wavefront can sum
-	// several voices before touching the bus), then inline voices by depth
-	if(c->lists_dirty) {
-		std::vector<int> leaf;
-		std::map<int, std::vector<int>> bydepth;
+	// Launch lists, rebuilt per batch because "quiet" is a per-batch property:
+	//   leaves: [fast wtosc->panmix | general]   (each sorted by output bus so a
+	//           wavefront can sum several voices before touching the bus)
+	//   voices with an inline unit, per nesting depth: [fast driver chain | general]
+	{
+		std::vector<int> fast_leaf, gen_leaf;
+		std::map<int, std::pair<std::vector<int>, std::vector<int>>> bydepth;
 		int maxdepth = -1;
 		for(size_t vi = 0; vi < nv; ++vi) {
 			const HVoice &v = c->voices[vi];
@@ -439,21 +470,31 @@ int upload(a2amd_ctx *c)
 			// R_KILL record
 			if(!(v.live || v.dying) || !v.resolved)
 				continue;
+			const bool quiet = v.live && !v.dying && v.started && v.recs.empty() && !c->no_fast;
 			if(v.inline_pos >= 0) {
-				bydepth[v.depth].push_back((int)vi);
+				auto &d = bydepth[v.depth];
+				(quiet && is_driver_chain(c, v) ? d.first : d.second).push_back((int)vi);
 				maxdepth = std::max(maxdepth, v.depth);
 			} else
-				leaf.push_back((int)vi);
+				(quiet && is_oscpan_chain(c, v) ? fast_leaf : gen_leaf).push_back((int)vi);
 		}
-		std::stable_sort(leaf.begin(), leaf.end(), [&](int a, int b) {
-			return c->voices[a].out_off < c->voices[b].out_off; });
-		c->list_all = leaf;
-		c->n_leaf = (int)leaf.size();
-		c->depth_ranges.assign(maxdepth + 1, std::make_pair(0, 0));
+		auto by_bus = [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; };
+		std::stable_sort(fast_leaf.begin(), fast_leaf.end(), by_bus);
+		std::stable_sort(gen_leaf.begin(), gen_leaf.end(), by_bus);
+		c->list_all = fast_leaf;
+		c->n_fast_leaf = (int)fast_leaf.size();
+		c->list_all.insert(c->list_all.end(), gen_leaf.begin(), gen_leaf.end());
+		c->n_leaf = (int)gen_leaf.size();
+		c->depth_ranges.assign(maxdepth + 1, DepthRange());
 		for(int d = 0; d <= maxdepth; ++d) {
 			auto &l = bydepth[d];
-			c->depth_ranges[d] = std::make_pair((int)c->list_all.size(), (int)l.size());
-			c->list_all.insert(c->list_all.end(), l.begin(), l.end());
+			DepthRange &r = c->depth_ranges[d];
+			r.fast_first = (int)c->list_all.size();
+			r.fast_count = (int)l.first.size();
+			c->list_all.insert(c->list_all.end(), l.first.begin(), l.first.end());
+			r.gen_first = (int)c->list_all.size();
+			r.gen_count = (int)l.second.size();
+			c->list_all.insert(c->list_all.end(), l.second.begin(), l.second.end());
 		}
 		if(int r = grow(c, c->d_list, c->list_all.size() + 1, 1, false)) return r;
 		if(!c->list_all.empty())
@@ -477,12 +518,40 @@ int upload(a2amd_ctx *c)
 	p.ptab = c->d_ptab;
 	p.nfrags = c->nfrags;
 	p.samplerate = c->cfg.samplerate;
+	p.debug = getenv("A2AMD_DEBUG") ? atoi(getenv("A2AMD_DEBUG")) : 0;
 	for(int f = 0; f < c->nfrags; ++f)
 		p.fragframes[f] = (uint8_t)c->fragframes[f];
+	c->hparams = p;
 	HIPCHK(c, hipMemcpyAsync(c->d_params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
 	// pageable sources above: make sure they are consumed before they die
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	c->uploaded = true;
+	return 0;
+}
+
+int pick_fast_vpw(int n)
+{
+	// enough wavefronts to fill 256 CUs x 4 SIMDs several times over, then
+	// more voices per wavefront (fewer, fatter bus updates)
+	if(getenv("A2AMD_VPW"))
+		return std::min(std::max(atoi(getenv("A2AMD_VPW")), 1), 64);
+	int v = (n + 4095) / 4096;
+	return std::min(std::max(v, 1), 64);
+}
+
+int launch_depth(a2amd_ctx *c, int d)
+{
+	const DepthRange &r = c->depth_ranges[d];
+	if(r.fast_count) {
+		if(a2d_launch_bus_driver(c->d_params, c->d_list.d + r.fast_first, r.fast_count, c->stream))
+			return c->fail(A2AMD_EHIP, "bus driver launch failed: %s", hipGetErrorString(hipGetLastError()));
+		++c->stats.launches;
+	}
+	if(r.gen_count) {
+		if(a2d_launch_voices(c->d_params, c->d_list.d + r.gen_first, r.gen_count, 1, c->stream))
+			return c->fail(A2AMD_EHIP, "bus launch failed: %s", hipGetErrorString(hipGetLastError()));
+		++c->stats.launches;
+	}
 	return 0;
 }
 
@@ -573,6 +642,7 @@ int a2amd_open(const a2amd_config *cfg, a2amd_ctx **out)
 		c->cfg.max_batch = A2D_MAXBATCH;
 	memset(&c->stats, 0, sizeof(c->stats));
 	build_pitch_table(c->ptab);
+	c->no_fast = getenv("A2AMD_NO_FAST") && atoi(getenv("A2AMD_NO_FAST"));
 	c->bus_stride_frames = (size_t)c->cfg.max_batch * A2D_FRAG;
 	c->bus_used = c->bus_stride_frames * (size_t)c->cfg.channels;	// master bus at offset 0
 #define OPENCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
@@ -1090,28 +1160,27 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 	if(phases & A2AMD_RENDER_SUBTREES) {
 		HIPCHK(c, hipMemsetAsync(c->d_busmem.d, 0, c->bus_used * sizeof(int32_t), c->stream));
 		HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+		if(c->n_fast_leaf) {
+			if(a2d_launch_leaf_oscpan(c->d_params, c->hparams, c->d_list.d, c->n_fast_leaf,
+					pick_fast_vpw(c->n_fast_leaf), c->stream))
+				return c->fail(A2AMD_EHIP, "fast leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+			++c->stats.launches;
+		}
 		if(c->n_leaf) {
-			if(a2d_launch_voices(c->d_params, c->d_list.d, c->n_leaf, pick_vpw(c->n_leaf), c->stream))
+			if(a2d_launch_voices(c->d_params, c->d_list.d + c->n_fast_leaf, c->n_leaf,
+					pick_vpw(c->n_leaf), c->stream))
 				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
 		HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-		for(int d = (int)c->depth_ranges.size() - 1; d >= 1; --d) {
-			auto rg = c->depth_ranges[d];
-			if(!rg.second)
-				continue;
-			if(a2d_launch_voices(c->d_params, c->d_list.d + rg.first, rg.second, 1, c->stream))
-				return c->fail(A2AMD_EHIP, "bus launch failed: %s", hipGetErrorString(hipGetLastError()));
-			++c->stats.launches;
-		}
+		for(int d = (int)c->depth_ranges.size() - 1; d >= 1; --d)
+			if(int r = launch_depth(c, d))
+				return r;
 	}
 	if(phases & A2AMD_RENDER_ROOT) {
-		if(!c->depth_ranges.empty() && c->depth_ranges[0].second) {
-			auto rg = c->depth_ranges[0];
-			if(a2d_launch_voices(c->d_params, c->d_list.d + rg.first, rg.second, 1, c->stream))
-				return c->fail(A2AMD_EHIP, "root launch failed: %s", hipGetErrorString(hipGetLastError()));
-			++c->stats.launches;
-		}
+		if(!c->depth_ranges.empty())
+			if(int r = launch_depth(c, 0))
+				return r;
 		HIPCHK(c, hipEventRecord(c->ev2, c->stream));
 		c->stats.fragments += c->nfrags;
 		c->stats.voice_fragments += (uint64_t)c->nfrags * (uint64_t)c->list_all.size();
