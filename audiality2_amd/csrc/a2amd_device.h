@@ -104,12 +104,15 @@ struct A2DParams {
 	int32_t         samplerate;
 	int32_t         debug;		// A2AMD_DEBUG ablation bits (perf experiments only)
 	uint8_t         fragframes[A2D_MAXBATCH];
+	uint16_t        fragstart[A2D_MAXBATCH];	// frames before each fragment
 };
 
 // launchers implemented in a2amd_kernels.hip (stream = hipStream_t)
 // dparams / dlist are device pointers; 'vpw' voices of the list per wavefront
 int a2d_launch_voices(const A2DParams *dparams, const int *dlist, int nlist, int vpw, void *stream);
 // hp = host copy of *dparams (device pointers passed as direct kernel arguments)
+// ysplit > 1 cuts the batch into time slices rendered by different wavefronts
+// (needs the staging copy 'ustage' of the unit state array)
 int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
-		int vpw, void *stream);
-int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, void *stream);
+		int vpw, int ysplit, int *ustage, void *stream);
+int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, int nfrags, void *stream);

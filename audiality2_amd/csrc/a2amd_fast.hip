@@ -259,11 +259,14 @@ DEV void flush_acc(int *busmem, int off, int nch, int f0, int nf, int lane, int 
 enum { SV_MODE = 0, SV_WAVE, SV_DPHASE, SV_PHLO, SV_PHHI, SV_PRAMP, SV_P = 6, SV_A = 10,
 	SV_VOL = 14, SV_PAN = 18, SV_NWORDS = 22 };
 
+// Extra per-lane words derived once per launch from a voice's state
+enum { DV_SETTLED = 0, DV_MM, DV_DPH, DV_SIZEM, DV_DOFF, DV_V0, DV_V1, DV_NWORDS };
+
 __global__ __launch_bounds__(64 * FAST_WPB)
 void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
-		const A2DVoice *__restrict__ voices, int *__restrict__ ustate,
-		const int16_t *__restrict__ wavepool, const A2DWave *__restrict__ waves,
-		const uint32_t *__restrict__ ptab, int *__restrict__ busmem)
+		int ysplit, const A2DVoice *__restrict__ voices, const int *ustate,
+		int *ustage, const int16_t *__restrict__ wavepool,
+		const A2DWave *__restrict__ waves, const uint32_t *__restrict__ ptab, int *__restrict__ busmem)
 {
 	const A2DParams &p = *pp;
 	const int wv = threadIdx.x >> 6;
@@ -276,16 +279,34 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	const int dbg = p.debug;
 	FastPtrs g = { wavepool, waves, ptab, dbg };
 
-	// fragment lengths: lane l of ffr[k] holds fragment 64*k + l (byte loads are
-	// vector memory operations; do them once, not per fragment)
-	int ffr[A2D_MAXBATCH / 64];
-#pragma unroll
-	for(int k = 0; k < A2D_MAXBATCH / 64; ++k)
-		ffr[k] = (k * 64 + lane < nfrags) ? p.fragframes[k * 64 + lane] : 0;
+	// this wavefront's slice of the batch, in chunks of FAST_FCH fragments
+	const int nchunks = (nfrags + FAST_FCH - 1) / FAST_FCH;
+	const int per = (nchunks + ysplit - 1) / ysplit;
+	const int slice = blockIdx.y;
+	const int c_lo = slice * per, c_hi = min(nchunks, c_lo + per);
+	const bool last_slice = c_hi >= nchunks;
+	if(c_lo >= nchunks)
+		return;
 
-	// lane v keeps voice v: its unit ids, output bus and the 22 state words
-	int sv[SV_NWORDS];
+	// fragment lengths and their prefix sums: lane l of ffr[k] / fst[k] holds
+	// fragment 64*k + l (byte loads are vector memory operations: once, here)
+	int ffr[A2D_MAXBATCH / 64], fst[A2D_MAXBATCH / 64];
+#pragma unroll
+	for(int k = 0; k < A2D_MAXBATCH / 64; ++k) {
+		ffr[k] = (k * 64 + lane < nfrags) ? p.fragframes[k * 64 + lane] : 0;
+		fst[k] = (k * 64 + lane < nfrags) ? p.fragstart[k * 64 + lane] : 0;
+	}
+
+	// lane v keeps voice v: its unit ids, output bus, the 22 state words and
+	// what follows from them for a settled voice
+	int sv[SV_NWORDS], dv[DV_NWORDS];
 	int u0 = 0, u1 = 0, my_off = -1, my_nch = 2;
+#pragma unroll
+	for(int k = 0; k < SV_NWORDS; ++k)
+		sv[k] = 0;
+#pragma unroll
+	for(int k = 0; k < DV_NWORDS; ++k)
+		dv[k] = 0;
 	if(lane < nv) {
 		const A2DVoice &vc = voices[list[first + lane]];
 		u0 = vc.unit[0];
@@ -303,13 +324,46 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 			sv[SV_VOL + k] = w1[PW_VOL + k];
 			sv[SV_PAN + k] = w1[PW_PAN + k];
 		}
-	} else {
-#pragma unroll
-		for(int k = 0; k < SV_NWORDS; ++k)
-			sv[k] = 0;
+		// Settled voice: every ramper has arrived (a2_PrepareRamper would
+		// change nothing) and the pitch is constant, so over the whole batch
+		// only the phase moves; mip level, increment and the two pan gains
+		// are fixed.  Anything else takes the per-fragment path.
+		bool settled = sv[SV_MODE] == A2D_OSC_MIPWAVE && sv[SV_DPHASE] && !sv[SV_PRAMP] &&
+				!(sv[SV_P + 3] | sv[SV_P + 2] | sv[SV_A + 3] | sv[SV_A + 2] |
+				  sv[SV_VOL + 3] | sv[SV_VOL + 2] | sv[SV_PAN + 3] | sv[SV_PAN + 2]) &&
+				sv[SV_P] == sv[SV_P + 1] && sv[SV_A] == sv[SV_A + 1] &&
+				sv[SV_VOL] == sv[SV_VOL + 1] && sv[SV_PAN] == sv[SV_PAN + 1];
+		if(settled) {
+			const A2DWave *w = waves + sv[SV_WAVE];
+			const unsigned period = w->period, dphase = (unsigned)sv[SV_DPHASE];
+			unsigned dph = ((dphase + 255) >> 8) * period, mm = 0;	// wtosc.c:250-258
+			for(; (dph > (A2D_MAXPHINC << 8)) && (mm < A2D_MIPS - 1); ++mm)
+				dph >>= 1;
+			dph = (unsigned)(((uint64_t)dphase * period) >> mm);
+			settled = w->size[0] && (w->flags & 0x100u) && dph <= (A2D_MAXPHINC << 16);
+			dv[DV_MM] = (int)mm;
+			dv[DV_DPH] = (int)dph;
+			dv[DV_SIZEM] = (int)w->size[mm];
+			dv[DV_DOFF] = (int)w->off[mm];
+			// panmix_process12 gains (panmix.c:89-104)
+			const int vol = sv[SV_VOL], pan = sv[SV_PAN];
+			const int vp = mul64s(pan, vol, 24);
+			int v0 = wsub(vol, vp), v1 = wadd(vol, vp);
+			if(pan > 0xffffff || pan < -0xffffff) {
+				int lim = wshl(vol, 1);
+				if(v0 > lim) v0 = lim;
+				if(v1 > lim) v1 = lim;
+			}
+			dv[DV_V0] = v0;
+			dv[DV_V1] = v1;
+		}
+		dv[DV_SETTLED] = settled ? 1 : 0;
 	}
+	const unsigned long long unsettled_mask = __ballot(lane < nv && !dv[DV_SETTLED]);
 
-	for(int f0 = 0; f0 < nfrags; f0 += FAST_FCH) {
+	// ---- settled voices: this slice's chunks ---------------------------------
+	for(int c = c_lo; c < c_hi; ++c) {
+		const int f0 = c * FAST_FCH;
 		const int nf = min((int)FAST_FCH, nfrags - f0);
 		int acc0[FAST_FCH], acc1[FAST_FCH];
 #pragma unroll
@@ -318,104 +372,106 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 		int nfr[FAST_FCH];	// frames of the chunk's fragments (SGPRs)
 #pragma unroll
 		for(int j = 0; j < FAST_FCH; ++j)
-			nfr[j] = frames_of(ffr, min(f0 + j, nfrags - 1));
+			nfr[j] = (j < nf) ? frames_of(ffr, f0 + j) : 0;
+		const unsigned before = (unsigned)frames_of(fst, f0);
 		int cur_off = rdl(my_off, 0), cur_nch = rdl(my_nch, 0);
 		for(int v = 0; v < nv; ++v) {
+			if(!rdl(dv[DV_SETTLED], v))
+				continue;
 			const int voff = rdl(my_off, v);
 			if(voff != cur_off) {
 				flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
 				cur_off = voff;
 				cur_nch = rdl(my_nch, v);
 			}
-			OscS o;
-			Ramp vol, pan;
-			o.mode = rdl(sv[SV_MODE], v);
-			o.wave = rdl(sv[SV_WAVE], v);
-			o.dphase = (unsigned)rdl(sv[SV_DPHASE], v);
-			o.phase = (uint64_t)(unsigned)rdl(sv[SV_PHLO], v) |
+			const unsigned mm = (unsigned)rdl(dv[DV_MM], v), dph = (unsigned)rdl(dv[DV_DPH], v);
+			const unsigned sizem = (unsigned)rdl(dv[DV_SIZEM], v), doff = (unsigned)rdl(dv[DV_DOFF], v);
+			const int v0 = rdl(dv[DV_V0], v), v1 = rdl(dv[DV_V1], v), amp = rdl(sv[SV_A], v);
+			const uint64_t phase = (uint64_t)(unsigned)rdl(sv[SV_PHLO], v) |
 					((uint64_t)(unsigned)rdl(sv[SV_PHHI], v) << 32);
-			o.p_ramping = rdl(sv[SV_PRAMP], v);
-			o.p.value = rdl(sv[SV_P], v); o.p.target = rdl(sv[SV_P + 1], v);
-			o.p.delta = rdl(sv[SV_P + 2], v); o.p.timer = rdl(sv[SV_P + 3], v);
-			o.a.value = rdl(sv[SV_A], v); o.a.target = rdl(sv[SV_A + 1], v);
-			o.a.delta = rdl(sv[SV_A + 2], v); o.a.timer = rdl(sv[SV_A + 3], v);
-			vol.value = rdl(sv[SV_VOL], v); vol.target = rdl(sv[SV_VOL + 1], v);
-			vol.delta = rdl(sv[SV_VOL + 2], v); vol.timer = rdl(sv[SV_VOL + 3], v);
-			pan.value = rdl(sv[SV_PAN], v); pan.target = rdl(sv[SV_PAN + 1], v);
-			pan.delta = rdl(sv[SV_PAN + 2], v); pan.timer = rdl(sv[SV_PAN + 3], v);
-			const bool me = lane == v;
-
-			// Settled voice: every ramper has arrived (a2_PrepareRamper would
-			// change nothing) and the pitch is constant, so over the whole
-			// chunk only the phase moves: mip level, increment, amplitude and
-			// the two pan gains are computed once, on the scalar unit.
-			bool settled = nf == FAST_FCH && o.mode == A2D_OSC_MIPWAVE && o.dphase && !o.p_ramping &&
-					!(o.p.timer | o.p.delta | o.a.timer | o.a.delta | vol.timer | vol.delta |
-					  pan.timer | pan.delta) &&
-					o.p.value == o.p.target && o.a.value == o.a.target &&
-					vol.value == vol.target && pan.value == pan.target;
-			unsigned mm = 0, dph = 0, sizem = 0, doff = 0;
-			if(settled) {
-				const A2DWave *w = waves + o.wave;
-				const unsigned period = w->period;
-				dph = ((o.dphase + 255) >> 8) * period;
-				for(; (dph > (A2D_MAXPHINC << 8)) && (mm < A2D_MIPS - 1); ++mm)
-					dph >>= 1;
-				dph = (unsigned)(((uint64_t)o.dphase * period) >> mm);
-				sizem = w->size[mm];
-				doff = w->off[mm];
-				settled = w->size[0] && (w->flags & 0x100u) && dph <= (A2D_MAXPHINC << 16);
+			const unsigned dph16 = dph >> 16;
+			// The phase fragment f starts from is ((phase >> mm) + frames_before(f) * dph)
+			// mod (size << 24): the reference's "ph %= size << 24; ...; ph += frames * dph"
+			// per fragment (wtosc.c:259-285) is addition mod size << 24.
+			uint64_t ph = (phase >> mm) + (uint64_t)before * dph;
+			uint64_t phs[FAST_FCH];
+#pragma unroll
+			for(int j = 0; j < FAST_FCH; ++j) {
+				ph = wrap_phase(ph, sizem);
+				phs[j] = ph;
+				ph += (uint64_t)dph * (unsigned)nfr[j];
 			}
-			if(settled) {
-				// panmix_process12 gains, constant over the chunk (panmix.c:89-104)
-				const bool clamp = pan.value > 0xffffff || pan.value < -0xffffff;
-				const int vp = mul64s(pan.value, vol.value, 24);
-				int v0 = wsub(vol.value, vp), v1 = wadd(vol.value, vp);
-				if(clamp) {
-					int lim = wshl(vol.value, 1);
-					if(v0 > lim) v0 = lim;
-					if(v1 > lim) v1 = lim;
-				}
-				const int amp = o.a.value;
-				const unsigned dph16 = dph >> 16;
-				// scalar pass: the phase each fragment starts from
-				uint64_t ph = o.phase >> mm;
-				uint64_t phs[FAST_FCH];
+			// vector pass, branch free: all wave data loads of the chunk can be
+			// in flight together (lanes past a short fragment read inside the
+			// A2_WAVEPOST pad and are masked at the sum)
+			const uint64_t lanedph = (uint64_t)(unsigned)lane * dph;
+			const uint32_t *wp32 = (const uint32_t *)wavepool;	// pool base is dword aligned
+			uint32_t w0[FAST_FCH], w1[FAST_FCH], w2[FAST_FCH];
+			unsigned ph16[FAST_FCH], odd[FAST_FCH];
 #pragma unroll
-				for(int j = 0; j < FAST_FCH; ++j) {
-					ph = wrap_phase(ph, sizem);
-					phs[j] = ph;
-					ph += (uint64_t)dph * (unsigned)nfr[j];
-				}
-				// vector pass, branch free: all wave data loads of the chunk can
-				// be in flight together (lanes past a short fragment read inside
-				// the A2_WAVEPOST pad and are masked at the sum)
-				const uint64_t lanedph = (uint64_t)(unsigned)lane * dph;
-				const uint32_t *wp32 = (const uint32_t *)wavepool;	// pool base is dword aligned
-				uint32_t w0[FAST_FCH], w1[FAST_FCH], w2[FAST_FCH];
-				unsigned ph16[FAST_FCH], odd[FAST_FCH];
+			for(int j = 0; j < FAST_FCH; ++j) {
+				ph16[j] = (unsigned)((phs[j] + lanedph) >> 16);
+				unsigned e = doff + (ph16[j] >> 8) - 1u;	// int16 index of d[i-1]
+				odd[j] = e & 1u;
+				const uint32_t *ap = wp32 + (e >> 1);
+				w0[j] = ap[0]; w1[j] = ap[1]; w2[j] = ap[2];
+			}
 #pragma unroll
-				for(int j = 0; j < FAST_FCH; ++j) {
-					ph16[j] = (unsigned)((phs[j] + lanedph) >> 16);
-					unsigned e = doff + (ph16[j] >> 8) - 1u;	// int16 index of d[i-1]
-					odd[j] = e & 1u;
-					const uint32_t *ap = wp32 + (e >> 1);
-					w0[j] = ap[0]; w1[j] = ap[1]; w2[j] = ap[2];
-				}
+			for(int j = 0; j < FAST_FCH; ++j) {
+				int sm = (dbg & 2) ? (int)ph16[j] :
+						inter_from_dwords(w0[j], w1[j], w2[j], odd[j], ph16[j], dph16);
+				int x = mul64s(sm, amp, 17);
+				x = (lane < nfr[j]) ? x : 0;
+				acc0[j] = wadd(acc0[j], mul64s(x, v0, 24));
+				acc1[j] = wadd(acc1[j], mul64s(x, v1, 24));
+			}
+			if(last_slice && c == c_hi - 1) {
+				// what the oscillator is left with after the batch: the
+				// unwrapped end of the last fragment (wtosc.c:284)
+				const bool me = lane == v;
+				const uint64_t endph = ph << mm;
+				WRL(sv[SV_PHLO], (int)(unsigned)endph);
+				WRL(sv[SV_PHHI], (int)(unsigned)(endph >> 32));
+			}
+		}
+		flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+	}
+
+	// ---- voices with something still moving: slice 0 walks the whole batch ----
+	if(slice == 0 && unsettled_mask) {
+		for(int f0 = 0; f0 < nfrags; f0 += FAST_FCH) {
+			const int nf = min((int)FAST_FCH, nfrags - f0);
+			int acc0[FAST_FCH], acc1[FAST_FCH];
 #pragma unroll
-				for(int j = 0; j < FAST_FCH; ++j) {
-					int sm = (dbg & 2) ? (int)ph16[j] :
-							inter_from_dwords(w0[j], w1[j], w2[j], odd[j], ph16[j], dph16);
-					int x = mul64s(sm, amp, 17);
-					x = (lane < nfr[j]) ? x : 0;
-					acc0[j] = wadd(acc0[j], mul64s(x, v0, 24));
-					acc1[j] = wadd(acc1[j], mul64s(x, v1, 24));
+			for(int j = 0; j < FAST_FCH; ++j)
+				acc0[j] = acc1[j] = 0;
+			int cur_off = rdl(my_off, 0), cur_nch = rdl(my_nch, 0);
+			for(int v = 0; v < nv; ++v) {
+				if(!((unsettled_mask >> v) & 1ull))
+					continue;
+				const int voff = rdl(my_off, v);
+				if(voff != cur_off) {
+					flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+					cur_off = voff;
+					cur_nch = rdl(my_nch, v);
 				}
-				o.phase = ph << mm;
-				WRL(sv[SV_PHLO], (int)(unsigned)o.phase);
-				WRL(sv[SV_PHHI], (int)(unsigned)(o.phase >> 32));
-			} else {
-				// anything still moving: the full per-fragment logic
+				OscS o;
+				Ramp vol, pan;
+				o.mode = rdl(sv[SV_MODE], v);
+				o.wave = rdl(sv[SV_WAVE], v);
+				o.dphase = (unsigned)rdl(sv[SV_DPHASE], v);
+				o.phase = (uint64_t)(unsigned)rdl(sv[SV_PHLO], v) |
+						((uint64_t)(unsigned)rdl(sv[SV_PHHI], v) << 32);
+				o.p_ramping = rdl(sv[SV_PRAMP], v);
+				o.p.value = rdl(sv[SV_P], v); o.p.target = rdl(sv[SV_P + 1], v);
+				o.p.delta = rdl(sv[SV_P + 2], v); o.p.timer = rdl(sv[SV_P + 3], v);
+				o.a.value = rdl(sv[SV_A], v); o.a.target = rdl(sv[SV_A + 1], v);
+				o.a.delta = rdl(sv[SV_A + 2], v); o.a.timer = rdl(sv[SV_A + 3], v);
+				vol.value = rdl(sv[SV_VOL], v); vol.target = rdl(sv[SV_VOL + 1], v);
+				vol.delta = rdl(sv[SV_VOL + 2], v); vol.timer = rdl(sv[SV_VOL + 3], v);
+				pan.value = rdl(sv[SV_PAN], v); pan.target = rdl(sv[SV_PAN + 1], v);
+				pan.delta = rdl(sv[SV_PAN + 2], v); pan.timer = rdl(sv[SV_PAN + 3], v);
+				const bool me = lane == v;
 				for(int j = 0; j < nf; ++j) {
 					int o0 = 0, o1 = 0;
 					oscpan_fragment(g, o, vol, pan, frames_of(ffr, f0 + j), lane, o0, o1);
@@ -441,14 +497,18 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 				WRL(sv[SV_PAN], pan.value); WRL(sv[SV_PAN + 1], pan.target);
 				WRL(sv[SV_PAN + 2], pan.delta); WRL(sv[SV_PAN + 3], pan.timer);
 			}
+			flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
 		}
-		flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
 	}
 
-	// unit states -> memory
-	if(lane < nv) {
-		int *w0 = ustate + (size_t)u0 * A2D_USTATE;
-		int *w1 = ustate + (size_t)u1 * A2D_USTATE;
+	// State out.  With one slice it goes straight back; with several the other
+	// slices are still reading the old state, so it is staged and committed by
+	// k_commit_oscpan afterwards.  The last slice owns the settled voices (their
+	// end phase), slice 0 the others.
+	const bool settled_l = dv[DV_SETTLED] != 0;
+	if(lane < nv && ((settled_l && last_slice) || (!settled_l && slice == 0))) {
+		int *w0 = ustage + (size_t)u0 * A2D_USTATE;
+		int *w1 = ustage + (size_t)u1 * A2D_USTATE;
 		w0[OW_MODE] = sv[SV_MODE]; w0[OW_WAVE] = sv[SV_WAVE]; w0[OW_DPHASE] = sv[SV_DPHASE];
 		w0[OW_PHASE_LO] = sv[SV_PHLO]; w0[OW_PHASE_HI] = sv[SV_PHHI]; w0[OW_PRAMPING] = sv[SV_PRAMP];
 #pragma unroll
@@ -461,6 +521,25 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	}
 }
 
+// staged state of the fast leaf voices -> the unit state array
+__global__ void k_commit_oscpan(const int *__restrict__ list, int nlist, const A2DVoice *__restrict__ voices,
+		int *__restrict__ ustate, const int *__restrict__ ustage)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= nlist * 16)
+		return;
+	const A2DVoice &vc = voices[list[i >> 4]];
+	const int k = i & 15;
+	// the words k_leaf_oscpan stages: wtosc 0..6 (+ p, a = 7..14), panmix 0..7
+	size_t a = (size_t)vc.unit[0] * A2D_USTATE + k;
+	if(k != OW_NOISE && k < 15)
+		ustate[a] = ustage[a];
+	if(k < 8) {
+		size_t b = (size_t)vc.unit[1] * A2D_USTATE + k;
+		ustate[b] = ustage[b];
+	}
+}
+
 // ---------------------------------------------------------------------------
 // inline -> panmix 2->2 -> xinsert (add, wired): root / group driver voices
 // ---------------------------------------------------------------------------
@@ -469,41 +548,52 @@ void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list
 {
 	__shared__ int fr[A2D_MAXBATCH][5];	// per fragment: vol, dvol, pan, dpan, clamp
 	const A2DParams &p = *pp;
-	if((int)blockIdx.x >= nlist)
-		return;
 	const A2DVoice &vc = p.voices[list[blockIdx.x]];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	if(threadIdx.x == 0) {
-		// step the two rampers of panmix_process22 (panmix.c:192-249)
-		// through the batch
-		int *w = p.ustate + (size_t)vc.unit[1] * A2D_USTATE;
-		Ramp vol = ramp_load(w + PW_VOL), pan = ramp_load(w + PW_PAN);
-		for(int f = 0; f < p.nfrags; ++f) {
-			const int n = p.fragframes[f];
-			fr[f][4] = pan.target > 0xffffff || pan.target < -0xffffff ||
-					pan.value > 0xffffff || pan.value < -0xffffff;
-			ramp_prepare(vol, n);
-			ramp_prepare(pan, n);
-			fr[f][0] = vol.value; fr[f][1] = vol.delta;
-			fr[f][2] = pan.value; fr[f][3] = pan.delta;
-			ramp_run(vol, n);
-			ramp_run(pan, n);
+	int *w = p.ustate + (size_t)vc.unit[1] * A2D_USTATE;
+	Ramp vol = ramp_load(w + PW_VOL), pan = ramp_load(w + PW_PAN);
+	// Both rampers at rest (the usual case): the gains are the same for every
+	// fragment, the fragments are independent and the workgroups of this voice
+	// (blockIdx.y) split them.  Otherwise workgroup 0 steps the rampers through
+	// the batch first and renders it alone.
+	const bool settled = !(vol.timer | vol.delta | pan.timer | pan.delta) &&
+			vol.value == vol.target && pan.value == pan.target;
+	int fbeg = blockIdx.y * 4 + wv, fstep = gridDim.y * 4;
+	if(!settled) {
+		if(blockIdx.y)
+			return;
+		fbeg = wv;
+		fstep = 4;
+		if(threadIdx.x == 0) {
+			// panmix_process22's rampers (panmix.c:192-249)
+			for(int f = 0; f < p.nfrags; ++f) {
+				const int n = p.fragframes[f];
+				fr[f][4] = pan.target > 0xffffff || pan.target < -0xffffff ||
+						pan.value > 0xffffff || pan.value < -0xffffff;
+				ramp_prepare(vol, n);
+				ramp_prepare(pan, n);
+				fr[f][0] = vol.value; fr[f][1] = vol.delta;
+				fr[f][2] = pan.value; fr[f][3] = pan.delta;
+				ramp_run(vol, n);
+				ramp_run(pan, n);
+			}
+			ramp_store(w + PW_VOL, vol);
+			ramp_store(w + PW_PAN, pan);
 		}
-		ramp_store(w + PW_VOL, vol);
-		ramp_store(w + PW_PAN, pan);
+		__syncthreads();
 	}
-	__syncthreads();
-	for(int f = wv; f < p.nfrags; f += 4) {
+	const bool sclamp = pan.value > 0xffffff || pan.value < -0xffffff;
+	for(int f = fbeg; f < p.nfrags; f += fstep) {
 		if(lane >= p.fragframes[f])
 			continue;
 		const int *src = p.busmem + vc.own_off + (size_t)f * vc.own_nch * A2D_FRAG;
 		int *dst = p.busmem + vc.out_off + (size_t)f * vc.out_nch * A2D_FRAG;
 		int i0 = src[lane], i1 = src[A2D_FRAG + lane];
-		int vk = wadd(fr[f][0], wmul(fr[f][1], lane));
-		int pk = wadd(fr[f][2], wmul(fr[f][3], lane));
+		int vk = settled ? vol.value : wadd(fr[f][0], wmul(fr[f][1], lane));
+		int pk = settled ? pan.value : wadd(fr[f][2], wmul(fr[f][3], lane));
 		int vp = mul64s(pk, vk, 24);
 		int v0 = wsub(vk, vp), v1 = wadd(vk, vp);
-		if(fr[f][4]) {
+		if(settled ? sclamp : (fr[f][4] != 0)) {
 			int lim = wshl(vk, 1);
 			if(v0 > lim) v0 = lim;
 			if(v1 > lim) v1 = lim;
@@ -517,22 +607,30 @@ void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list
 }
 
 int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
-		int vpw, void *stream)
+		int vpw, int ysplit, int *ustage, void *stream)
 {
 	if(nlist <= 0)
 		return 0;
 	vpw = vpw < 1 ? 1 : (vpw > 64 ? 64 : vpw);
+	if(ysplit < 1 || !ustage)
+		ysplit = 1;
 	int nwaves = (nlist + vpw - 1) / vpw;
 	int nblocks = (nwaves + FAST_WPB - 1) / FAST_WPB;
-	hipLaunchKernelGGL(k_leaf_oscpan, dim3(nblocks), dim3(64 * FAST_WPB), 0, (hipStream_t)stream,
-			dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
+	hipLaunchKernelGGL(k_leaf_oscpan, dim3(nblocks, ysplit), dim3(64 * FAST_WPB), 0, (hipStream_t)stream,
+			dparams, dlist, nlist, vpw, ysplit, hp.voices, (const int *)hp.ustate,
+			ysplit > 1 ? ustage : hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
+	if(ysplit > 1)
+		hipLaunchKernelGGL(k_commit_oscpan, dim3((nlist * 16 + 255) / 256), dim3(256), 0,
+				(hipStream_t)stream, dlist, nlist, hp.voices, hp.ustate, (const int *)ustage);
 	return (int)hipGetLastError();
 }
 
-int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, void *stream)
+int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, int nfrags, void *stream)
 {
 	if(nlist <= 0)
 		return 0;
-	hipLaunchKernelGGL(k_bus_driver, dim3(nlist), dim3(256), 0, (hipStream_t)stream, dparams, dlist, nlist);
+	// grid.y: workgroups per voice, 4 fragments in flight each
+	hipLaunchKernelGGL(k_bus_driver, dim3(nlist, nfrags >= 16 ? 16 : (nfrags + 3) / 4), dim3(256), 0,
+			(hipStream_t)stream, dparams, dlist, nlist);
 	return (int)hipGetLastError();
 }

@@ -206,6 +206,7 @@ struct a2amd_ctx {
 	DevBuf<A2DVoice> d_voices;
 	DevBuf<uint32_t> d_udesc;
 	DevBuf<int32_t> d_ustate;	// cap in units
+	DevBuf<int32_t> d_ustage;	// staging copy for time-sliced kernels
 	DevBuf<int32_t> d_vactive;
 	DevBuf<A2DRun> d_runs;
 	DevBuf<A2DRec> d_recs;
@@ -217,6 +218,8 @@ struct a2amd_ctx {
 	uint32_t *d_ptab = nullptr;
 	A2DParams *d_params = nullptr;
 	A2DParams hparams;
+	hipGraph_t graph[2] = {nullptr, nullptr};	// [0] = GRAPH_STEPS runs of the batch, [1] = one
+	hipGraphExec_t gexec[2] = {nullptr, nullptr};
 	int32_t *h_master = nullptr;	// pinned
 	size_t h_master_cap = 0;
 
@@ -234,6 +237,8 @@ struct a2amd_ctx {
 };
 
 namespace {
+
+void drop_graphs(a2amd_ctx *c);
 
 // grow a device array; keep = preserve old contents (device-owned data)
 template<class T>
@@ -401,11 +406,13 @@ bool is_driver_chain(const a2amd_ctx *c, const HVoice &v)
 
 int upload(a2amd_ctx *c)
 {
+	drop_graphs(c);
 	const size_t nv = c->voices.size(), nu = c->units.size();
 	// capacities
 	if(int r = grow(c, c->d_voices, nv, 1, false)) return r;
 	if(int r = grow(c, c->d_udesc, nu, 1, false)) return r;
 	if(int r = grow(c, c->d_ustate, nu, A2D_USTATE, true)) return r;
+	if(int r = grow(c, c->d_ustage, c->d_ustate.cap, A2D_USTATE, false)) return r;
 	if(int r = grow(c, c->d_vactive, nv, 1, true)) return r;
 	if(int r = grow(c, c->d_runs, nv, 1, false)) return r;
 	if(int r = grow(c, c->d_busmem, c->bus_used, 1, false)) return r;
@@ -519,14 +526,33 @@ int upload(a2amd_ctx *c)
 	p.nfrags = c->nfrags;
 	p.samplerate = c->cfg.samplerate;
 	p.debug = getenv("A2AMD_DEBUG") ? atoi(getenv("A2AMD_DEBUG")) : 0;
-	for(int f = 0; f < c->nfrags; ++f)
+	for(int f = 0, acc = 0; f < c->nfrags; ++f) {
 		p.fragframes[f] = (uint8_t)c->fragframes[f];
+		p.fragstart[f] = (uint16_t)acc;
+		acc += (int)c->fragframes[f];
+	}
 	c->hparams = p;
 	HIPCHK(c, hipMemcpyAsync(c->d_params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
 	// pageable sources above: make sure they are consumed before they die
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	c->uploaded = true;
 	return 0;
+}
+
+// Shape of the fast leaf launch, from sweeps on MI355X (DESIGN.md "Launch
+// shape"): cut the batch into as many time slices as it has 8-fragment chunks
+// (up to 8), then give a wavefront enough voices that about 4096 wavefronts
+// (one resident round of 256 CUs x 16) share the work; at least 4 voices, so
+// that their sum reaches the bus in one atomic instead of four, at most 32.
+void pick_fast_shape(int n, int nfrags, int *vpw, int *ysplit)
+{
+	const int nchunks = (nfrags + 7) / 8;
+	int y = getenv("A2AMD_YSPLIT") ? atoi(getenv("A2AMD_YSPLIT")) : 8;
+	y = std::min(std::max(y, 1), nchunks);
+	int v = getenv("A2AMD_VPW") ? atoi(getenv("A2AMD_VPW")) :
+			std::min(std::max((int)(((long long)n * y + 4095) / 4096), 4), 32);
+	*vpw = std::min(std::max(v, 1), 64);
+	*ysplit = y;
 }
 
 int pick_fast_vpw(int n)
@@ -543,7 +569,7 @@ int launch_depth(a2amd_ctx *c, int d)
 {
 	const DepthRange &r = c->depth_ranges[d];
 	if(r.fast_count) {
-		if(a2d_launch_bus_driver(c->d_params, c->d_list.d + r.fast_first, r.fast_count, c->stream))
+		if(a2d_launch_bus_driver(c->d_params, c->d_list.d + r.fast_first, r.fast_count, c->nfrags, c->stream))
 			return c->fail(A2AMD_EHIP, "bus driver launch failed: %s", hipGetErrorString(hipGetLastError()));
 		++c->stats.launches;
 	}
@@ -563,6 +589,7 @@ int pick_vpw(int n)
 
 void end_batch(a2amd_ctx *c)
 {
+	drop_graphs(c);
 	// Records made after the last fragment of the batch was closed belong to
 	// the first fragment of the next batch: carry them over.
 	const int done = c->nfrags;
@@ -607,6 +634,80 @@ void end_batch(a2amd_ctx *c)
 	c->cur_frag = 0;
 	c->frag_open = false;
 	c->uploaded = false;
+}
+
+
+// the kernels of one batch, in stream order; e* may be null
+int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2)
+{
+	if(phases & A2AMD_RENDER_SUBTREES) {
+		HIPCHK(c, hipMemsetAsync(c->d_busmem.d, 0, c->bus_used * sizeof(int32_t), c->stream));
+		if(e0)
+			HIPCHK(c, hipEventRecord(e0, c->stream));
+		if(c->n_fast_leaf) {
+			int vpw, ysplit;
+			pick_fast_shape(c->n_fast_leaf, c->nfrags, &vpw, &ysplit);
+			if(a2d_launch_leaf_oscpan(c->d_params, c->hparams, c->d_list.d, c->n_fast_leaf,
+					vpw, ysplit, c->d_ustage.d, c->stream))
+				return c->fail(A2AMD_EHIP, "fast leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+			++c->stats.launches;
+		}
+		if(c->n_leaf) {
+			if(a2d_launch_voices(c->d_params, c->d_list.d + c->n_fast_leaf, c->n_leaf,
+					pick_vpw(c->n_leaf), c->stream))
+				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+			++c->stats.launches;
+		}
+		if(e1)
+			HIPCHK(c, hipEventRecord(e1, c->stream));
+		for(int d = (int)c->depth_ranges.size() - 1; d >= 1; --d)
+			if(int r = launch_depth(c, d))
+				return r;
+	}
+	if(phases & A2AMD_RENDER_ROOT) {
+		if(!c->depth_ranges.empty())
+			if(int r = launch_depth(c, 0))
+				return r;
+		if(e2)
+			HIPCHK(c, hipEventRecord(e2, c->stream));
+		c->stats.fragments += c->nfrags;
+		c->stats.voice_fragments += (uint64_t)c->nfrags * (uint64_t)c->list_all.size();
+	}
+	return 0;
+}
+
+void drop_graphs(a2amd_ctx *c)
+{
+	for(int i = 0; i < 2; ++i) {
+		if(c->gexec[i]) {
+			hipGraphExecDestroy(c->gexec[i]);
+			c->gexec[i] = nullptr;
+		}
+		if(c->graph[i]) {
+			hipGraphDestroy(c->graph[i]);
+			c->graph[i] = nullptr;
+		}
+	}
+}
+
+// capture 'steps' consecutive runs of the uploaded batch into one graph
+int build_graph(a2amd_ctx *c, int slot, int steps)
+{
+	hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+	if(e != hipSuccess)
+		return c->fail(A2AMD_EHIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+	int r = 0;
+	for(int i = 0; i < steps && !r; ++i)
+		r = issue_kernels(c, A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT, nullptr, nullptr, nullptr);
+	e = hipStreamEndCapture(c->stream, &c->graph[slot]);
+	if(r)
+		return r;
+	if(e != hipSuccess)
+		return c->fail(A2AMD_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+	e = hipGraphInstantiate(&c->gexec[slot], c->graph[slot], nullptr, nullptr, 0);
+	if(e != hipSuccess)
+		return c->fail(A2AMD_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+	return 0;
 }
 
 } // namespace
@@ -675,7 +776,8 @@ void a2amd_close(a2amd_ctx *c)
 	if(!c)
 		return;
 	hipStreamSynchronize(c->stream);
-	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d);
+	drop_graphs(c);
+	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
 	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
 	hipFree(c->d_waves.d); hipFree(c->d_wavepool.d); hipFree(c->d_busmem.d);
 	hipFree(c->d_fbdmem.d); hipFree(c->d_list.d); hipFree(c->d_ptab); hipFree(c->d_params);
@@ -1157,34 +1259,9 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		c->ev2 = c->ev_pool[c->ev_used + 2];
 		c->ev_used += 3;
 	}
-	if(phases & A2AMD_RENDER_SUBTREES) {
-		HIPCHK(c, hipMemsetAsync(c->d_busmem.d, 0, c->bus_used * sizeof(int32_t), c->stream));
-		HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-		if(c->n_fast_leaf) {
-			if(a2d_launch_leaf_oscpan(c->d_params, c->hparams, c->d_list.d, c->n_fast_leaf,
-					pick_fast_vpw(c->n_fast_leaf), c->stream))
-				return c->fail(A2AMD_EHIP, "fast leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
-			++c->stats.launches;
-		}
-		if(c->n_leaf) {
-			if(a2d_launch_voices(c->d_params, c->d_list.d + c->n_fast_leaf, c->n_leaf,
-					pick_vpw(c->n_leaf), c->stream))
-				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
-			++c->stats.launches;
-		}
-		HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-		for(int d = (int)c->depth_ranges.size() - 1; d >= 1; --d)
-			if(int r = launch_depth(c, d))
-				return r;
-	}
-	if(phases & A2AMD_RENDER_ROOT) {
-		if(!c->depth_ranges.empty())
-			if(int r = launch_depth(c, 0))
-				return r;
-		HIPCHK(c, hipEventRecord(c->ev2, c->stream));
-		c->stats.fragments += c->nfrags;
-		c->stats.voice_fragments += (uint64_t)c->nfrags * (uint64_t)c->list_all.size();
-	}
+	if(phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT))
+		if(int r = issue_kernels(c, phases, c->ev0, c->ev1, c->ev2))
+			return r;
 	if(phases & A2AMD_RENDER_READBACK) {
 		const int nch = c->cfg.channels;
 		size_t n = (size_t)c->nfrags * nch * A2D_FRAG;
@@ -1216,6 +1293,53 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 	if(!(phases & A2AMD_RENDER_KEEP) && (phases & (A2AMD_RENDER_READBACK | A2AMD_RENDER_ROOT)))
 		end_batch(c);
 	return (int)total;
+}
+
+int a2amd_replay(a2amd_ctx *c, unsigned steps)
+{
+	const int GRAPH_STEPS = 8;
+	if(!c->uploaded || !c->nfrags)
+		return c->fail(A2AMD_ESTATE, "replay without an uploaded batch");
+	for(int vi = 0; vi < (int)c->voices.size(); ++vi)
+		if(!c->voices[vi].recs.empty())
+			return c->fail(A2AMD_ESTATE, "replay of a batch that carries command records");
+	bool graphs = c->stream != nullptr && !c->profiling && !getenv("A2AMD_NO_GRAPH");
+	if(graphs && !c->gexec[0]) {
+		if(build_graph(c, 0, GRAPH_STEPS) || build_graph(c, 1, 1)) {
+			drop_graphs(c);
+			graphs = false;
+		}
+	}
+	while(steps) {
+		if(graphs && steps >= (unsigned)GRAPH_STEPS) {
+			HIPCHK(c, hipGraphLaunch(c->gexec[0], c->stream));
+			steps -= GRAPH_STEPS;
+			c->stats.fragments += (uint64_t)c->nfrags * GRAPH_STEPS;
+			c->stats.voice_fragments += (uint64_t)c->nfrags * c->list_all.size() * GRAPH_STEPS;
+		} else if(graphs) {
+			HIPCHK(c, hipGraphLaunch(c->gexec[1], c->stream));
+			--steps;
+			c->stats.fragments += c->nfrags;
+			c->stats.voice_fragments += (uint64_t)c->nfrags * c->list_all.size();
+		} else {
+			if(c->profiling) {
+				if(c->ev_used + 3 > c->ev_pool.size())
+					for(int i = 0; i < 3; ++i) {
+						hipEvent_t e;
+						HIPCHK(c, hipEventCreate(&e));
+						c->ev_pool.push_back(e);
+					}
+				c->ev0 = c->ev_pool[c->ev_used];
+				c->ev1 = c->ev_pool[c->ev_used + 1];
+				c->ev2 = c->ev_pool[c->ev_used + 2];
+				c->ev_used += 3;
+			}
+			if(int r = issue_kernels(c, A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT, c->ev0, c->ev1, c->ev2))
+				return r;
+			--steps;
+		}
+	}
+	return A2AMD_OK;
 }
 
 int a2amd_rootbus(a2amd_ctx *c, void **devptr, uint64_t *bytes)

@@ -132,13 +132,20 @@ def main():
     from audiality2_amd.replay import Backend
 
     B = args.batch
-    stream = torch.cuda.current_stream().cuda_stream
-    be = audiality2_amd.open_backend(48000, None, 2, device=local_rank, max_batch=B, stream=stream)
+    # N=1: the library launches on its own stream and replays the steady-state
+    # step from a hipGraph.  N>1: everything (kernels and the RCCL reduce) is
+    # ordered on one torch stream.
+    tstream = torch.cuda.Stream(device=local_rank) if world > 1 else None
+    if tstream is not None:
+        torch.cuda.set_stream(tstream)
+    be = audiality2_amd.open_backend(48000, None, 2, device=local_rank, max_batch=B,
+                                     stream=tstream.cuda_stream if tstream is not None else None)
     lib = be.lib
     lib.a2amd_fragment_repeat.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
     lib.a2amd_get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
     lib.a2amd_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.a2amd_rootbus.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
+    lib.a2amd_replay.argtypes = [ctypes.c_void_p, ctypes.c_uint]
 
     # ---- build the voice tree; every rank plays different voices -----------
     sc = synth.Scene(be)
@@ -186,35 +193,40 @@ def main():
                                         "data": (ptr.value, False), "version": 2}
         rootbus = torch.as_tensor(_Wrap(), device=torch.device("cuda", local_rank))
 
-    def step():
+    def run(nsteps):
         if world == 1:
-            be.render(0, phases=SUB | ROOTP | KEEP)
-        else:
+            if lib.a2amd_replay(be.ctx, nsteps):
+                raise RuntimeError(be._err(be.ctx))
+            return
+        for _ in range(nsteps):
             be.render(0, phases=SUB | KEEP)
             dist.reduce(rootbus, dst=0, op=dist.ReduceOp.SUM)
             if rank == 0:
                 be.render(0, phases=ROOTP | KEEP)
 
-    for _ in range(args.warmup):
-        step()
-    lib.a2amd_set_profiling(be.ctx, 1)
+    run(args.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    st = Stats()
-    lib.a2amd_get_stats(be.ctx, ctypes.byref(st))
-    lib.a2amd_set_profiling(be.ctx, 0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # kernel durations: the same step, every launch bracketed by HIP events on
+    # the launch stream (profiling disables the graph replay)
+    nprof = min(args.steps, 64)
+    lib.a2amd_set_profiling(be.ctx, 1)
+    run(nprof)
+    st = Stats()
+    lib.a2amd_get_stats(be.ctx, ctypes.byref(st))
+    lib.a2amd_set_profiling(be.ctx, 0)
     last = be.render(B * 64, phases=RB) if (world == 1 or rank == 0) else None
     if world > 1 and rank != 0:
         be.render(0, phases=ROOTP)      # close the batch on the other ranks
@@ -240,7 +252,10 @@ def main():
             "parity_vs_oracle": parity,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
-                         "kernel": "k_voices (leaf launch)", "avg_launch_ms": leaf_ms,
+                         "kernel": "k_leaf_oscpan" if args.chain == "osc-pan" else "k_voices (leaf launch)",
+                         "avg_launch_ms": leaf_ms,
+                         "timing": "HIP events on the launch stream around every launch, separate pass of "
+                                   f"{nprof} steps right after the timed region (graph replay off)",
                          "launches_timed": int(st.timed_batches),
                          "algorithmic_bytes_per_voice_sample": bpvs,
                          "all_kernels_ms_per_step": st.timed_all_ms / max(st.timed_batches, 1)},

@@ -187,6 +187,11 @@ int  a2amd_inline_end(a2amd_ctx *ctx, int unit);
  */
 int  a2amd_render(a2amd_ctx *ctx, unsigned phases, int32_t *const *out,
 		unsigned out_capacity_frames);
+/* Re-run the uploaded, record-free batch 'steps' more times (each run renders
+ * the next batch of audio; see A2AMD_RENDER_KEEP).  The launch sequence is
+ * captured once into a hipGraph and replayed, 8 runs per graph launch, unless
+ * profiling is on (then every run is bracketed with events instead). */
+int  a2amd_replay(a2amd_ctx *ctx, unsigned steps);
 /* Device pointer + size (bytes) of the root voice's inline bus partials for
  * the fragments of the current batch: int32 [batch][channels][64]. */
 int  a2amd_rootbus(a2amd_ctx *ctx, void **devptr, uint64_t *bytes);
