@@ -29,6 +29,17 @@ def build_lib(force=False):
     return out
 
 
+def build_units(force=False):
+    """The drop-in unit descriptors (plain C) on top of liba2amd.so."""
+    src = os.path.join(HERE, "csrc", "a2amd_units.c")
+    deps = [src, os.path.join(ROOT, "include", "a2amd.h"), os.path.join(ROOT, "include", "a2amd_plugin.h")]
+    out = os.path.join(HERE, "liba2amd_units.so")
+    if force or _newer(out, deps):
+        subprocess.run(["gcc", "-O2", "-Wall", "-fPIC", "-shared", "-o", out, src,
+                        "-L" + HERE, "-la2amd", "-ldl", "-Wl,-rpath,$ORIGIN"], check=True)
+    return out
+
+
 def build_oracle(force=False):
     """Test infrastructure: the CPU restatement and, when the reference tree
     is present, the compiled reference + its harness (oracle/_ref)."""
@@ -41,4 +52,6 @@ def build_oracle(force=False):
 
 
 def build_all(force=False):
-    return build_lib(force), build_oracle(force)
+    lib = build_lib(force)
+    build_units(force)
+    return lib, build_oracle(force)

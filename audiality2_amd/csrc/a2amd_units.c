@@ -1,0 +1,439 @@
+/*
+ * a2amd_units.c - drop-in voice units for Audiality 2 backed by liba2amd.so.
+ *
+ * Builds into liba2amd_units.so.  Loaded ahead of libaudiality2 (LD_PRELOAD,
+ * or simply earlier on the link line) its unit descriptors take the place of
+ * the engine's built-in wtosc / panmix / filter12 / fbdelay (and wrap inline /
+ * xinsert): the engine's unit table (src/audiality2.c:183-207) refers to the
+ * descriptors by symbol, and ELF symbol interposition binds it to ours.  The
+ * engine itself - A2S compiler, VM, event scheduler, voice tree, API - runs
+ * unchanged on the CPU and keeps calling Initialize / write / Process /
+ * Deinitialize exactly as before (include/a2_units.h:115-176); here those calls
+ * are forwarded to the GPU backend (include/a2amd.h), which renders all voices
+ * of a fragment together.
+ *
+ * Where the audio re-enters the engine: the root voice is
+ * "inline; panmix; xinsert >" (a2_rootdriver, audiality2.c:271-291).  Every
+ * time the engine processes a window of the root voice, its inline unit walks
+ * the whole voice tree (our units record), then its panmix is called: at that
+ * point everything that feeds this window has been recorded, so the GPU renders
+ * it and the result is written where the engine expects the root panmix to have
+ * left it - the input buffers of the root xinsert.  The engine's own xinsert
+ * then moves it to the master bus and feeds any sink/insert clients (a2play's
+ * silence detector, a2_Render's stream) with real audio.
+ *
+ * One engine window of the root voice = one fragment of the backend; offsets of
+ * all other voices are rebased to the start of that window.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/a2amd.h"
+#include "../../include/a2amd_plugin.h"
+
+/* engine API we call back into (public: a2_waves.h:183, a2_properties.h:106) */
+extern A2P_wave *a2_GetWave(void *iface, int handle);
+extern int a2_GetStateProperty(void *iface, int prop, int *v);
+extern int a2_SetStateProperty(void *iface, int prop, int v);
+
+#define MAXSTATES 16
+#define MAXWAVES  4096
+
+typedef struct HOSTSTATE
+{
+	A2P_config	*cfg;
+	a2amd_ctx	*ctx;
+	int		refs;
+	int		depth;		/* open inline windows */
+	unsigned	base;		/* engine offset of the current root window */
+	A2P_vmstate	*root_vms;	/* the root voice (first voice of a state) */
+	A2P_vmstate	*chain_vms;	/* voice whose chain is being populated */
+	A2P_unit	*chain_last;
+	A2P_wave	*wave_ptr[MAXWAVES];
+	int		wave_id[MAXWAVES];
+	int		nwaves;
+	int32_t		out[A2AMD_MAXCHANNELS][A2AMD_MAXFRAG];
+} HOSTSTATE;
+
+static HOSTSTATE states[MAXSTATES];
+
+/* our per-instance data lives at the tail of the engine's 384 byte block */
+typedef struct XTRA
+{
+	HOSTSTATE	*hs;
+	A2P_vmstate	*vms;
+	int		uid;		/* backend unit id, -1 = not forwarded */
+	int		kind;
+	int		follow;		/* backend id of a trailing xinsert to process along */
+	int		is_root;
+	A2P_process_cb	orig_process;
+} XTRA;
+
+static inline XTRA *xtra(A2P_unit *u)
+{
+	return (XTRA *)((char *)u + A2P_BLOCK_SIZE - sizeof(XTRA));
+}
+
+static void die(HOSTSTATE *hs, const char *what, int rc)
+{
+	fprintf(stderr, "a2amd units: %s failed (%d): %s\n", what, rc,
+			a2amd_last_error(hs ? hs->ctx : NULL));
+	abort();	/* there is no CPU fallback to continue on */
+}
+
+static const A2P_unitdesc *orig_desc(const char *sym)
+{
+	const A2P_unitdesc *d = (const A2P_unitdesc *)dlsym(RTLD_NEXT, sym);
+	if(!d)
+	{
+		fprintf(stderr, "a2amd units: the engine has no %s to wrap\n", sym);
+		abort();
+	}
+	return d;
+}
+
+/* ---- state open / close (A2_unitdesc.OpenState / CloseState) -------------*/
+static int amd_open(A2P_config *cfg, void **statedata)
+{
+	int i, f = -1;
+	for(i = 0; i < MAXSTATES; ++i)
+		if(states[i].refs && states[i].cfg == cfg)
+		{
+			++states[i].refs;
+			*statedata = &states[i];
+			return 0;
+		}
+		else if(!states[i].refs && f < 0)
+			f = i;
+	if(f < 0)
+		return 1;
+	memset(&states[f], 0, sizeof(HOSTSTATE));
+	states[f].cfg = cfg;
+	states[f].refs = 1;
+	*statedata = &states[f];
+	return 0;
+}
+
+static void amd_close(void *statedata)
+{
+	HOSTSTATE *hs = (HOSTSTATE *)statedata;
+	if(hs && !--hs->refs && hs->ctx)
+	{
+		a2amd_close(hs->ctx);
+		hs->ctx = NULL;
+	}
+}
+
+/* the backend is opened on first use: A2_config.basepitch is only valid once
+ * a2_Open() has returned (audiality2.c:398) */
+static a2amd_ctx *ctx_of(HOSTSTATE *hs)
+{
+	if(!hs->ctx)
+	{
+		a2amd_config c;
+		int rc;
+		memset(&c, 0, sizeof(c));
+		c.struct_size = sizeof(c);
+		c.samplerate = hs->cfg->samplerate;
+		c.basepitch = hs->cfg->basepitch;
+		c.channels = hs->cfg->channels;
+		c.device = getenv("A2AMD_DEVICE") ? atoi(getenv("A2AMD_DEVICE")) : 0;
+		c.max_batch = 1;
+		if((rc = a2amd_open(&c, &hs->ctx)))
+			die(NULL, "a2amd_open", rc);
+	}
+	return hs->ctx;
+}
+
+/* ---- Initialize / Deinitialize ---------------------------------------------*/
+static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned flags, int forward)
+{
+	HOSTSTATE *hs = (HOSTSTATE *)sd;
+	XTRA *x = xtra(u);
+	a2amd_ctx *ctx = ctx_of(hs);
+	int wired = u->outputs != u->inputs;
+	unsigned lflags = flags;
+	memset(x, 0, sizeof(*x));
+	x->hs = hs;
+	x->vms = vms;
+	x->kind = kind;
+	x->uid = -1;
+	x->follow = -1;
+	if(!hs->root_vms)
+		hs->root_vms = vms;
+	x->is_root = vms == hs->root_vms;
+	if(hs->chain_vms != vms)
+	{
+		hs->chain_vms = vms;
+		hs->chain_last = NULL;
+	}
+	if(x->is_root && kind == A2AMD_PANMIX)
+	{
+		/* the root panmix is where the audio returns to the engine: for
+		 * the backend it feeds the master bus directly */
+		wired = 1;
+		lflags |= A2AMD_PROCADD;
+	}
+	if(x->is_root && kind == A2AMD_XINSERT)
+		forward = 0;	/* stays with the engine */
+	if(forward)
+	{
+		x->uid = a2amd_unit_init(ctx, (uint64_t)(uintptr_t)vms, kind, lflags, u->ninputs,
+				u->noutputs, wired, vms->r[A2P_R_TRANSPOSE], vms->waketime & 0xff);
+		if(x->uid < 0)
+		{
+			fprintf(stderr, "a2amd units: cannot instantiate unit kind %d: %s\n", kind,
+					a2amd_last_error(ctx));
+			return 1;	/* the engine reports A2_VOICEINIT and drops the voice */
+		}
+		if(kind == A2AMD_XINSERT && hs->chain_last)
+			xtra(hs->chain_last)->follow = x->uid;
+	}
+	hs->chain_last = u;
+	return 0;
+}
+
+static void amd_deinit(A2P_unit *u)
+{
+	XTRA *x = xtra(u);
+	int rc;
+	if(x->hs->chain_last == u)
+		x->hs->chain_last = NULL;
+	if(x->uid >= 0 && (rc = a2amd_unit_deinit(x->hs->ctx, x->uid)))
+		die(x->hs, "a2amd_unit_deinit", rc);
+}
+
+/* ---- Process ---------------------------------------------------------------------*/
+static void forward_process(XTRA *x, unsigned offset, unsigned frames)
+{
+	HOSTSTATE *hs = x->hs;
+	uint32_t noise = 0, before = 0;
+	int rc, v = 0;
+	if(x->kind == A2AMD_WTOSC)
+	{
+		/* the engine-global RNG the noise oscillators share with the VM's
+		 * RAND instructions (internals.h:682), through the public property */
+		a2_GetStateProperty(hs->cfg->interface, A2P_PNOISESEED, &v);
+		noise = before = (uint32_t)v;
+	}
+	if((rc = a2amd_unit_process(hs->ctx, x->uid, offset - hs->base, frames,
+			x->kind == A2AMD_WTOSC ? &noise : NULL)))
+		die(hs, "a2amd_unit_process", rc);
+	if(noise != before)
+		a2_SetStateProperty(hs->cfg->interface, A2P_PNOISESEED, (int)noise);
+	if(x->follow >= 0 && (rc = a2amd_unit_process(hs->ctx, x->follow, offset - hs->base, frames, NULL)))
+		die(hs, "a2amd_unit_process (xinsert)", rc);
+}
+
+static void amd_process(A2P_unit *u, unsigned offset, unsigned frames)
+{
+	XTRA *x = xtra(u);
+	HOSTSTATE *hs = x->hs;
+	forward_process(x, offset, frames);
+	if(x->is_root && x->kind == A2AMD_PANMIX)
+	{
+		/* end of a root window: render it and hand the result to the engine */
+		int32_t *outp[A2AMD_MAXCHANNELS];
+		int c, n;
+		for(c = 0; c < A2AMD_MAXCHANNELS; ++c)
+			outp[c] = hs->out[c];
+		n = a2amd_render(hs->ctx, A2AMD_RENDER_ALL, outp, A2AMD_MAXFRAG);
+		if(n != (int)frames)
+			die(hs, "a2amd_render", n);
+		for(c = 0; c < u->noutputs; ++c)
+			memcpy(u->outputs[c] + offset, hs->out[c], frames * sizeof(int32_t));
+	}
+}
+
+static void amd_inline_process(A2P_unit *u, unsigned offset, unsigned frames)
+{
+	XTRA *x = xtra(u);
+	HOSTSTATE *hs = x->hs;
+	int rc;
+	if(!hs->depth)
+	{
+		/* a window of the root voice opens a backend fragment */
+		if((rc = a2amd_fragment(hs->ctx, frames)))
+			die(hs, "a2amd_fragment", rc);
+		hs->base = offset;
+	}
+	forward_process(x, offset, frames);
+	++hs->depth;
+	x->orig_process(u, offset, frames);	/* the engine walks the subvoices */
+	--hs->depth;
+	if((rc = a2amd_inline_end(hs->ctx, x->uid)))
+		die(hs, "a2amd_inline_end", rc);
+}
+
+/* ---- control register writes --------------------------------------------------*/
+static int wave_id_of(HOSTSTATE *hs, A2P_wave *w)
+{
+	a2amd_wavedesc d;
+	int i, id, levels;
+	if(!w)
+		return -1;
+	for(i = 0; i < hs->nwaves; ++i)
+		if(hs->wave_ptr[i] == w)
+			return hs->wave_id[i];
+	if(hs->nwaves >= MAXWAVES)
+		return -1;
+	memset(&d, 0, sizeof(d));
+	d.type = w->type;
+	d.flags = w->flags;
+	d.period = w->period;
+	levels = w->type == A2AMD_WMIPWAVE ? A2AMD_MIPLEVELS : w->type == A2AMD_WWAVE ? 1 : 0;
+	for(i = 0; i < levels; ++i)
+	{
+		d.size[i] = w->size[i];
+		d.data[i] = w->data[i];
+	}
+	id = a2amd_wave_upload(ctx_of(hs), (uint64_t)(uintptr_t)w, &d);
+	if(id < 0)
+		die(hs, "a2amd_wave_upload", id);
+	hs->wave_ptr[hs->nwaves] = w;
+	hs->wave_id[hs->nwaves++] = id;
+	return id;
+}
+
+static void amd_write(A2P_unit *u, int reg, int v, unsigned start, unsigned dur)
+{
+	XTRA *x = xtra(u);
+	int rc;
+	if(x->kind == A2AMD_WTOSC && reg == 0)		/* wtosc_Wave, wtosc.c:433-440 */
+		v = wave_id_of(x->hs, a2_GetWave(x->hs->cfg->interface, v >> 16));
+	if((rc = a2amd_unit_write(x->hs->ctx, x->uid, reg, v, start, dur, x->vms->r[A2P_R_TRANSPOSE])))
+		die(x->hs, "a2amd_unit_write", rc);
+}
+
+#define WR(n) static void wr##n(A2P_unit *u, int v, unsigned s, unsigned d) { amd_write(u, n, v, s, d); }
+WR(0) WR(1) WR(2) WR(3) WR(4) WR(5) WR(6)
+
+/* ---- the replaced units -----------------------------------------------------------*/
+#define OWN_UNIT(K, name, regvals) \
+static int name##_init(A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned f) \
+{ \
+	static const int defaults[] = regvals; \
+	unsigned i; \
+	int rc = amd_init(K, u, vms, sd, f, 1); \
+	if(rc) \
+		return rc; \
+	for(i = 0; i < sizeof(defaults) / sizeof(defaults[0]); ++i) \
+		u->registers[i] = defaults[i];	/* the VM reads these back */ \
+	u->Process = amd_process; \
+	return 0; \
+}
+#define ARR(...) { __VA_ARGS__ }
+/* register defaults: wtosc.c:409-413, panmix.c:262-263, filter12.c:191-195,
+ * fbdelay.c:183-194 */
+OWN_UNIT(A2AMD_WTOSC, wtosc, ARR(0, 0, 0, 0))
+OWN_UNIT(A2AMD_PANMIX, panmix, ARR(65536, 0))
+OWN_UNIT(A2AMD_FILTER12, filter12, ARR(0, 0, 65536, 0, 0))
+OWN_UNIT(A2AMD_FBDELAY, fbdelay, ARR(400 << 16, 280 << 16, 320 << 16, 65536, 16384, 32768, 32768))
+
+static const A2P_crdesc wtosc_regs[] = { { "w", wr0 }, { "p", wr1 }, { "a", wr2 }, { "phase", wr3 },
+		{ NULL, NULL } };
+static const A2P_crdesc panmix_regs[] = { { "vol", wr0 }, { "pan", wr1 }, { NULL, NULL } };
+static const A2P_constdesc panmix_consts[] = { { "CENTER", 0 }, { "LEFT", -65536 }, { "RIGHT", 65536 },
+		{ NULL, 0 } };
+static const A2P_crdesc filter12_regs[] = { { "cutoff", wr0 }, { "q", wr1 }, { "lp", wr2 }, { "bp", wr3 },
+		{ "hp", wr4 }, { NULL, NULL } };
+static const A2P_crdesc fbdelay_regs[] = { { "fbdelay", wr0 }, { "ldelay", wr1 }, { "rdelay", wr2 },
+		{ "drygain", wr3 }, { "fbgain", wr4 }, { "lgain", wr5 }, { "rgain", wr6 }, { NULL, NULL } };
+
+const A2P_unitdesc a2_wtosc_unitdesc = { "wtosc", 0, wtosc_regs, NULL, NULL, 0, 0, 1, 1,
+	A2P_BLOCK_SIZE, wtosc_init, amd_deinit, amd_open, amd_close };
+const A2P_unitdesc a2_panmix_unitdesc = { "panmix", 0, panmix_regs, NULL, panmix_consts, 1, 2, 1, 2,
+	A2P_BLOCK_SIZE, panmix_init, amd_deinit, amd_open, amd_close };
+const A2P_unitdesc a2_filter12_unitdesc = { "filter12", A2P_MATCHIO, filter12_regs, NULL, NULL, 1, 2, 1, 2,
+	A2P_BLOCK_SIZE, filter12_init, amd_deinit, amd_open, amd_close };
+const A2P_unitdesc a2_fbdelay_unitdesc = { "fbdelay", 0, fbdelay_regs, NULL, NULL, 1, 2, 1, 2,
+	A2P_BLOCK_SIZE, fbdelay_init, amd_deinit, amd_open, amd_close };
+
+/* ---- the wrapped engine-internal units ------------------------------------------------
+ * inline and xinsert need engine internals (the voice behind a vmstate, the
+ * xinsert client list), so the engine's own instances keep doing that part:
+ * their Initialize runs first inside the same instance block, ours adds the
+ * backend bookkeeping.  Both use two state pointers: ours for the backend, the
+ * original's for itself. */
+typedef struct WRAPSTATE { HOSTSTATE *hs; void *orig_sd; } WRAPSTATE;
+
+static int wrap_open(const char *sym, A2P_config *cfg, void **statedata)
+{
+	const A2P_unitdesc *od = orig_desc(sym);
+	WRAPSTATE *ws = (WRAPSTATE *)calloc(1, sizeof(WRAPSTATE));
+	void *hs = NULL;
+	int rc;
+	if(!ws)
+		return 1;
+	if((rc = amd_open(cfg, &hs)))
+		return rc;
+	ws->hs = (HOSTSTATE *)hs;
+	if(od->OpenState && (rc = od->OpenState(cfg, &ws->orig_sd)))
+		return rc;
+	*statedata = ws;
+	return 0;
+}
+
+static void wrap_close(const char *sym, void *statedata)
+{
+	const A2P_unitdesc *od = orig_desc(sym);
+	WRAPSTATE *ws = (WRAPSTATE *)statedata;
+	if(od->CloseState)
+		od->CloseState(ws->orig_sd);
+	amd_close(ws->hs);
+	free(ws);
+}
+
+static int inl_open(A2P_config *cfg, void **sd) { return wrap_open("a2_inline_unitdesc", cfg, sd); }
+static void inl_close(void *sd) { wrap_close("a2_inline_unitdesc", sd); }
+static int xi_open(A2P_config *cfg, void **sd) { return wrap_open("a2_xinsert_unitdesc", cfg, sd); }
+static void xi_close(void *sd) { wrap_close("a2_xinsert_unitdesc", sd); }
+
+static int inl_init(A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned flags)
+{
+	WRAPSTATE *ws = (WRAPSTATE *)sd;
+	int rc = orig_desc("a2_inline_unitdesc")->Initialize(u, vms, ws->orig_sd, flags);
+	if(rc)
+		return rc;
+	if((rc = amd_init(A2AMD_INLINE, u, vms, ws->hs, flags, 1)))
+		return rc;
+	xtra(u)->orig_process = u->Process;
+	u->Process = amd_inline_process;
+	return 0;
+}
+
+static void inl_deinit(A2P_unit *u)
+{
+	const A2P_unitdesc *od = orig_desc("a2_inline_unitdesc");
+	amd_deinit(u);
+	if(od->Deinitialize)
+		od->Deinitialize(u);
+}
+
+static int xi_init(A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned flags)
+{
+	WRAPSTATE *ws = (WRAPSTATE *)sd;
+	/* The engine's xinsert keeps its own Process (its client API swaps it at
+	 * will, xinsert.c:164-193): on a non-root voice it merely shuffles the
+	 * engine's unused CPU buffers, while the backend gets the bypass behaviour
+	 * from the unit ahead of it in the chain (XTRA.follow). */
+	int rc = orig_desc("a2_xinsert_unitdesc")->Initialize(u, vms, ws->orig_sd, flags);
+	if(rc)
+		return rc;
+	return amd_init(A2AMD_XINSERT, u, vms, ws->hs, flags, 1);
+}
+
+static void xi_deinit(A2P_unit *u)
+{
+	const A2P_unitdesc *od = orig_desc("a2_xinsert_unitdesc");
+	amd_deinit(u);
+	if(od->Deinitialize)
+		od->Deinitialize(u);
+}
+
+const A2P_unitdesc a2_inline_unitdesc = { "inline", 0, NULL, NULL, NULL, 0, 0, 1, A2AMD_MAXCHANNELS,
+	A2P_BLOCK_SIZE, inl_init, inl_deinit, inl_open, inl_close };
+const A2P_unitdesc a2_xinsert_unitdesc = { "xinsert", A2P_MATCHIO | A2P_XINSERT, NULL, NULL, NULL,
+	1, A2AMD_MAXCHANNELS, 1, A2AMD_MAXCHANNELS, A2P_BLOCK_SIZE, xi_init, xi_deinit, xi_open, xi_close };

@@ -1,0 +1,128 @@
+/*
+ * a2amd_plugin.h - the Audiality 2 unit plugin ABI as seen by the drop-in units
+ * (liba2amd_units.so).
+ *
+ * The drop-in replaces the engine's built-in wtosc / panmix / filter12 /
+ * fbdelay units (and wraps inline / xinsert) by exporting unit descriptors under
+ * the very symbol names the engine's unit table refers to
+ * (src/audiality2.c:183-207).  To be loadable into an unmodified libaudiality2
+ * it must agree with the reference on the layout of the handful of public
+ * structs that cross the plugin boundary; they are declared here, member for
+ * member, with the reference location of each.  Nothing else of the reference
+ * is needed to build the drop-in.  tests/test_plugin_abi.py compiles a
+ * translation unit that includes both this file and the reference's own headers
+ * and static-asserts that sizes and offsets match (runs where the reference
+ * tree is mounted).
+ *
+ * Exported objects (all `const A2P_unitdesc`, C linkage):
+ *   a2_wtosc_unitdesc     replaces src/units/wtosc.c:516-536
+ *   a2_panmix_unitdesc    replaces src/units/panmix.c:313-333
+ *   a2_filter12_unitdesc  replaces src/units/filter12.c:241-261
+ *   a2_fbdelay_unitdesc   replaces src/units/fbdelay.c:289-309
+ *   a2_inline_unitdesc    wraps    src/units/inline.c:50-69
+ *   a2_xinsert_unitdesc   wraps    src/units/xinsert.c:232-252
+ * Imported from the engine at load time (public API, include/a2_waves.h:183,
+ * include/a2_properties.h:106-107): a2_GetWave, a2_GetStateProperty,
+ * a2_SetStateProperty.
+ */
+#ifndef A2AMD_PLUGIN_H
+#define A2AMD_PLUGIN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct A2P_unit A2P_unit;
+typedef struct A2P_unitdesc A2P_unitdesc;
+
+/* A2_vmstate, include/a2_vm.h:62-69 */
+typedef struct A2P_vmstate
+{
+	unsigned	waketime;
+	uint8_t		state;
+	uint8_t		func;
+	uint16_t	pc;
+	int		r[64];		/* A2_REGISTERS */
+} A2P_vmstate;
+#define A2P_R_TRANSPOSE 1		/* R_TRANSPOSE, include/a2_vm.h:54 */
+
+/* A2_config, include/a2_drivers.h:46-63 */
+typedef struct A2P_config
+{
+	void	*interface;
+	void	*drivers;
+	int	samplerate;
+	int	buffer;
+	int	channels;
+	int	flags;
+	int	poolsize;
+	int	blockpool;
+	int	voicepool;
+	int	eventpool;
+	int	basepitch;
+} A2P_config;
+
+/* A2_wave, include/a2_waves.h:88-103 */
+typedef struct A2P_wave
+{
+	int		type;		/* A2_wavetypes */
+	unsigned	flags;
+	unsigned	period;
+	int16_t		*data[10];	/* A2_MIPLEVELS */
+	unsigned	size[10];
+} A2P_wave;
+
+/* callback types, include/a2_units.h:115,132,142,159-160,176 */
+typedef void (*A2P_write_cb)(A2P_unit *u, int value, unsigned start, unsigned duration);
+typedef int  (*A2P_uinit_cb)(A2P_unit *u, A2P_vmstate *vms, void *statedata, unsigned flags);
+typedef void (*A2P_udeinit_cb)(A2P_unit *u);
+typedef int  (*A2P_udopen_cb)(A2P_config *cfg, void **statedata);
+typedef void (*A2P_udclose_cb)(void *statedata);
+typedef void (*A2P_process_cb)(A2P_unit *u, unsigned offset, unsigned frames);
+
+/* A2_crdesc / A2_constdesc, include/a2_units.h:196-221 */
+typedef struct A2P_crdesc { const char *name; A2P_write_cb write; } A2P_crdesc;
+typedef struct A2P_constdesc { const char *name; int value; } A2P_constdesc;
+
+/* A2_unitdesc, include/a2_units.h:225-251 */
+struct A2P_unitdesc
+{
+	const char		*name;
+	unsigned		flags;		/* A2_MATCHIO 0x10000, A2_XINSERT 0x20000 */
+	const A2P_crdesc	*registers;
+	const void		*coutputs;
+	const A2P_constdesc	*constants;
+	uint8_t			mininputs, maxinputs, minoutputs, maxoutputs;
+	unsigned		instancesize;
+	A2P_uinit_cb		Initialize;
+	A2P_udeinit_cb		Deinitialize;
+	A2P_udopen_cb		OpenState;
+	A2P_udclose_cb		CloseState;
+};
+
+/* A2_unit, include/a2_units.h:282-310 */
+struct A2P_unit
+{
+	A2P_unit		*next;
+	const A2P_unitdesc	*descriptor;
+	uint16_t		ninputs, noutputs;
+	int32_t			**inputs, **outputs;
+	int			*registers;
+	void			*coutputs;
+	A2P_process_cb		Process;
+};
+
+#define A2P_BLOCK_SIZE	384		/* A2_BLOCK_SIZE, include/audiality2.h.cmake:53 */
+#define A2P_PNOISESEED	0x0002000a	/* A2_PNOISESEED, include/a2_properties.h:71 */
+#define A2P_MATCHIO	0x00010000
+#define A2P_XINSERT	0x00020000
+
+extern const A2P_unitdesc a2_wtosc_unitdesc, a2_panmix_unitdesc, a2_filter12_unitdesc,
+		a2_fbdelay_unitdesc, a2_inline_unitdesc, a2_xinsert_unitdesc;
+
+#ifdef __cplusplus
+}
+#endif
+#endif

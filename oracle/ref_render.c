@@ -1,0 +1,74 @@
+/*
+ * ref_render.c - renders an A2S program offline through the COMPILED REFERENCE
+ * engine (oracle/_ref/libaudiality2.so) and writes the driver buffers.
+ *
+ * TEST INFRASTRUCTURE.  No wrappers, nothing interposed by this program: run
+ * as is, the reference's own units render (= what ref_tools captured in the
+ * golden fixtures); run with LD_PRELOAD=audiality2_amd/liba2amd_units.so the
+ * same engine renders through the GPU drop-in units.  tests/test_dropin.py
+ * compares the two.
+ *
+ * usage: ref_render <file.a2s> <program> <frames> <buffer> <rate> <channels> <out.pcm> [args...]
+ * output: per a2_Run() call, <channels> planar int32 blocks of <buffer> frames
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include "audiality2.h"
+#include "a2_drivers.h"
+#include "a2_vm.h"
+
+int main(int argc, const char *argv[])
+{
+	int frames, buffer, rate, channels, nargs, pargs[A2_MAXARGS], k, done = 0, c;
+	A2_config *cfg;
+	A2_driver *drv;
+	A2_interface *i;
+	A2_handle bank, prog;
+	FILE *pcm;
+	if(argc < 8)
+	{
+		fprintf(stderr, "usage: ref_render <a2s> <program> <frames> <buffer> "
+				"<rate> <channels> <out.pcm> [args...]\n");
+		return 1;
+	}
+	frames = atoi(argv[3]);
+	buffer = atoi(argv[4]);
+	rate = atoi(argv[5]);
+	channels = atoi(argv[6]);
+	nargs = argc - 8 > A2_MAXARGS ? A2_MAXARGS : argc - 8;
+	for(k = 0; k < nargs; ++k)
+		pargs[k] = (int)(atof(argv[8 + k]) * 65536.0);
+	if(!(pcm = fopen(argv[7], "wb")))
+		return 1;
+	if(!(drv = a2_NewDriver(A2_AUDIODRIVER, "buffer")))
+		return 1;
+	if(!(cfg = a2_OpenConfig(rate, buffer, channels, A2_AUTOCLOSE)))
+		return 1;
+	a2_AddDriver(cfg, drv);
+	if(!(i = a2_Open(cfg)))
+	{
+		fprintf(stderr, "a2_Open failed: %s\n", a2_ErrorString(a2_LastError()));
+		return 1;
+	}
+	if((bank = a2_Load(i, argv[1], 0)) < 0 || (prog = a2_Get(i, bank, argv[2])) < 0)
+	{
+		fprintf(stderr, "cannot load %s / %s\n", argv[1], argv[2]);
+		return 1;
+	}
+	a2_TimestampReset(i);
+	if(a2_Starta(i, a2_RootVoice(i), prog, nargs, pargs) < 0)
+		return 1;
+	while(done < frames)
+	{
+		int n = frames - done < buffer ? frames - done : buffer;
+		if(a2_Run(i, n) < 0)
+			return 1;
+		a2_PumpMessages(i);
+		for(c = 0; c < channels; ++c)
+			fwrite(((A2_audiodriver *)drv)->buffers[c], 4, n, pcm);
+		done += n;
+	}
+	fclose(pcm);
+	a2_Close(i);
+	return 0;
+}

@@ -1,0 +1,63 @@
+"""End to end through the reference's own engine: the unmodified compiled
+reference (oracle/_ref) loads the drop-in units (liba2amd_units.so) by symbol
+interposition, runs its A2S compiler, VM and voice tree on the CPU, and every
+unit callback lands on the GPU backend.  The audio a2_Run() hands back must be
+the audio the reference renders with its own units."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from audiality2_amd.replay import read_pcm
+from conftest import GOLDEN, ROOT, fnv1a_fragments
+
+REF_RENDER = os.path.join(ROOT, "oracle", "_ref", "ref_render")
+UNITS_SO = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
+A2S = os.path.join(ROOT, "tests", "a2s")
+
+# name, program args, frames (as in tests/golden/make_goldens.py)
+CASES = [("sustain", ["4", "0.05"], 9600), ("filter", ["4", "0.02"], 48000),
+         ("delaybus", ["2", "4", "0.05"], 48000), ("scripted", ["0.2"], 48000)]
+
+
+def need_ref():
+    if not (os.path.exists(REF_RENDER) and os.path.exists(UNITS_SO)):
+        pytest.skip("oracle/_ref (compiled reference) or liba2amd_units.so not built")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,args,frames", CASES)
+def test_engine_with_dropin_units_matches_reference(tmp_path, name, args, frames):
+    need_ref()
+    out = tmp_path / f"{name}.pcm"
+    env = dict(os.environ, LD_PRELOAD=UNITS_SO)
+    subprocess.run([REF_RENDER, f"{A2S}/{name}.a2s", "Main", str(frames), "64", "48000", "2", str(out)] + args,
+                   check=True, env=env, cwd=A2S, timeout=600)
+    audio = read_pcm(out, 2, 64)
+    want = np.load(os.path.join(GOLDEN, f"{name}.hash.npy"))
+    got = fnv1a_fragments(audio)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, f"{len(bad)} fragments differ from the reference render, first {bad[:5]}"
+
+
+def test_reference_render_is_reproducible(tmp_path):
+    """The harness itself (no drop-in) reproduces the golden fixture: the
+    fixtures are what the reference renders, run to run."""
+    need_ref()
+    out = tmp_path / "s.pcm"
+    subprocess.run([REF_RENDER, f"{A2S}/sustain.a2s", "Main", "9600", "64", "48000", "2", str(out), "4", "0.05"],
+                   check=True, cwd=A2S, timeout=120)
+    audio = read_pcm(out, 2, 64)
+    assert np.array_equal(fnv1a_fragments(audio), np.load(os.path.join(GOLDEN, "sustain.hash.npy")))
+
+
+def test_dropin_refuses_to_run_without_gpu(tmp_path):
+    import torch
+    need_ref()
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([REF_RENDER, f"{A2S}/sustain.a2s", "Main", "640", "64", "48000", "2",
+                        str(tmp_path / "x.pcm"), "1", "0.05"],
+                       env=dict(os.environ, LD_PRELOAD=UNITS_SO), cwd=A2S, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr

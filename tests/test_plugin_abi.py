@@ -1,0 +1,61 @@
+"""include/a2amd_plugin.h must lay the plugin-boundary structs out exactly like
+the reference's public headers.  Compiles a C file that includes both and
+static-asserts sizes and offsets (only where the reference tree is mounted)."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+REF = "/root/reference"
+REFINC = os.path.join(ROOT, "oracle", "_ref", "include")
+
+SRC = r'''
+#include <stddef.h>
+#include "audiality2.h"
+#include "a2_units.h"
+#include "a2_waves.h"
+#include "a2_drivers.h"
+#include "a2_properties.h"
+#include "a2amd_plugin.h"
+#define SAME(A, B, m) _Static_assert(offsetof(A, m) == offsetof(B, m), #m)
+#define SIZE(A, B) _Static_assert(sizeof(A) == sizeof(B), #A)
+SIZE(A2_unit, A2P_unit); SAME(A2_unit, A2P_unit, next); SAME(A2_unit, A2P_unit, descriptor);
+SAME(A2_unit, A2P_unit, ninputs); SAME(A2_unit, A2P_unit, noutputs); SAME(A2_unit, A2P_unit, inputs);
+SAME(A2_unit, A2P_unit, outputs); SAME(A2_unit, A2P_unit, registers); SAME(A2_unit, A2P_unit, coutputs);
+SAME(A2_unit, A2P_unit, Process);
+SIZE(A2_unitdesc, A2P_unitdesc); SAME(A2_unitdesc, A2P_unitdesc, name); SAME(A2_unitdesc, A2P_unitdesc, flags);
+SAME(A2_unitdesc, A2P_unitdesc, registers); SAME(A2_unitdesc, A2P_unitdesc, coutputs);
+SAME(A2_unitdesc, A2P_unitdesc, constants); SAME(A2_unitdesc, A2P_unitdesc, mininputs);
+SAME(A2_unitdesc, A2P_unitdesc, maxoutputs); SAME(A2_unitdesc, A2P_unitdesc, instancesize);
+SAME(A2_unitdesc, A2P_unitdesc, Initialize); SAME(A2_unitdesc, A2P_unitdesc, Deinitialize);
+SAME(A2_unitdesc, A2P_unitdesc, OpenState); SAME(A2_unitdesc, A2P_unitdesc, CloseState);
+SIZE(A2_vmstate, A2P_vmstate); SAME(A2_vmstate, A2P_vmstate, waketime); SAME(A2_vmstate, A2P_vmstate, r);
+SIZE(A2_config, A2P_config); SAME(A2_config, A2P_config, interface); SAME(A2_config, A2P_config, samplerate);
+SAME(A2_config, A2P_config, channels); SAME(A2_config, A2P_config, basepitch);
+_Static_assert(sizeof(A2_wave) == sizeof(A2P_wave), "A2_wave");
+_Static_assert(offsetof(A2_wave, d.wave.data) == offsetof(A2P_wave, data), "data");
+_Static_assert(offsetof(A2_wave, d.wave.size) == offsetof(A2P_wave, size), "size");
+_Static_assert(offsetof(A2_wave, period) == offsetof(A2P_wave, period), "period");
+_Static_assert(A2_BLOCK_SIZE == A2P_BLOCK_SIZE, "block");
+_Static_assert(A2_PNOISESEED == A2P_PNOISESEED, "noiseseed");
+_Static_assert(R_TRANSPOSE == A2P_R_TRANSPOSE, "transpose");
+_Static_assert(A2_MATCHIO == A2P_MATCHIO && A2_XINSERT == A2P_XINSERT, "flags");
+_Static_assert(A2_MAXFRAG == 64 && A2_MAXCHANNELS == 8 && A2_MIPLEVELS == 10, "limits");
+_Static_assert(A2_WAVEPRE == 1 && A2_WAVEPOST == 131, "pads");
+int main(void) { return 0; }
+'''
+
+
+def test_plugin_structs_match_reference_headers(tmp_path):
+    if not (os.path.isdir(REF) and os.path.exists(os.path.join(REFINC, "audiality2.h"))):
+        pytest.skip("reference tree / generated header not available here")
+    src = tmp_path / "abi.c"
+    src.write_text(SRC)
+    # the plugin header declares the a2_*_unitdesc symbols with its own type;
+    # keep the two declarations apart
+    subprocess.run(["gcc", "-std=gnu11", "-fsyntax-only", f"-I{REFINC}", f"-I{REF}/include",
+                    f"-I{ROOT}/include", "-Da2_wtosc_unitdesc=p_wtosc", "-Da2_panmix_unitdesc=p_panmix",
+                    "-Da2_filter12_unitdesc=p_f12", "-Da2_fbdelay_unitdesc=p_fbd",
+                    "-Da2_inline_unitdesc=p_inl", "-Da2_xinsert_unitdesc=p_xi", str(src)], check=True)
