@@ -146,14 +146,13 @@ struct FastPtrs {
 	int dbg;
 };
 
-// One default fragment of wtosc (mip wave) -> panmix 1->2 adding into the
-// voice's output bus: wtosc_wavetable (wtosc.c:239-286) + panmix_process12
-// (panmix.c:78-135) fused per frame; frame = lane.  Everything named o.*, vol,
-// pan lives in SGPRs.
-DEV void oscpan_fragment(const FastPtrs &g, OscS &o, Ramp &vol, Ramp &pan,
-		int nframes, int lane, int &acc0, int &acc1)
+// One default fragment of wtosc, scalar control + vector frames (frame = lane):
+// wtosc_wavetable (wtosc.c:239-286) / wtosc_Off (:108-126).  Returns the sample
+// the oscillator leaves in the scratch buffer for this lane.  Everything named
+// o.* lives in SGPRs.
+DEV int osc_fragment_s(const FastPtrs &g, OscS &o, int nframes, int lane)
 {
-	int x = 0;		// the sample wtosc leaves in the scratch buffer
+	int x = 0;
 	const bool in = lane < nframes;
 	if(o.mode == A2D_OSC_MIPWAVE) {
 		const A2DWave *w = g.waves + o.wave;
@@ -204,12 +203,18 @@ DEV void oscpan_fragment(const FastPtrs &g, OscS &o, Ramp &vol, Ramp &pan,
 		ramp_run(o.p, nframes);
 		ramp_run(o.a, nframes);
 	}
-	// panmix_Process12Add, panmix.c:117-125
+	return x;
+}
+
+// One default fragment of panmix 1->2 adding into the voice's output bus
+// (panmix_Process12Add / panmix_process12, panmix.c:78-125) for input x.
+DEV void pan_fragment_s(Ramp &vol, Ramp &pan, int x, int nframes, int lane, int &acc0, int &acc1)
+{
 	const bool clamp = pan.target > 0xffffff || pan.target < -0xffffff ||
 			pan.value > 0xffffff || pan.value < -0xffffff;
 	ramp_prepare_s(vol, nframes);
 	ramp_prepare_s(pan, nframes);
-	if(in) {
+	if(lane < nframes) {
 		int vk = wadd(vol.value, wmul(vol.delta, lane));
 		int pk = wadd(pan.value, wmul(pan.delta, lane));
 		int vp = mul64s(pk, vk, 24);
@@ -224,6 +229,13 @@ DEV void oscpan_fragment(const FastPtrs &g, OscS &o, Ramp &vol, Ramp &pan,
 	}
 	ramp_run(vol, nframes);
 	ramp_run(pan, nframes);
+}
+
+DEV void oscpan_fragment(const FastPtrs &g, OscS &o, Ramp &vol, Ramp &pan,
+		int nframes, int lane, int &acc0, int &acc1)
+{
+	int x = osc_fragment_s(g, o, nframes, lane);
+	pan_fragment_s(vol, pan, x, nframes, lane, acc0, acc1);
 }
 
 // frames of fragment f from the per-lane table (f is wave-uniform)
@@ -541,6 +553,298 @@ __global__ void k_commit_oscpan(const int *__restrict__ list, int nlist, const A
 }
 
 // ---------------------------------------------------------------------------
+// wtosc -> filter12 (1 ch) -> panmix 1->2: the BASELINE config 3 voice
+// ---------------------------------------------------------------------------
+// The oscillator and the pan stage are independent per frame (lane = frame);
+// the filter is a recurrence in time (lane = voice).  A wavefront owns up to 64
+// voices, lane v holding ALL state of voice v, and walks the fragments in order:
+//   A  for each voice (state -> SGPRs by readlane): oscillator frames -> row v
+//      of a [voices][64+1] LDS tile
+//   B  every lane runs f12_process (filter12.c:74-119) along its own row, the
+//      filter memories d1/d2 and the q ramper staying in its registers
+//   C  for each voice: row v * pan gains, summed over the voices in registers,
+//      one atomic per (fragment, channel, frame) into the bus
+// The +1 row pitch makes both the row accesses (A, C) and the column accesses
+// (B: lane v reads tile[v][s]) bank-conflict free.
+#define FILT_MAXV   64
+#define FILT_PITCH  65
+enum { FV_Q = 0, FV_LP = 4, FV_BP, FV_HP, FV_F1, FV_D1, FV_D2, FV_NWORDS };
+
+__global__ __launch_bounds__(64 * FAST_WPB)
+void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
+		const A2DVoice *__restrict__ voices, int *ustate, const int16_t *__restrict__ wavepool,
+		const A2DWave *__restrict__ waves, const uint32_t *__restrict__ ptab, int *__restrict__ busmem)
+{
+	extern __shared__ __attribute__((aligned(16))) int tiles[];
+	const A2DParams &p = *pp;
+	const int wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	const int first = (blockIdx.x * FAST_WPB + wv) * vpw;
+	if(first >= nlist)
+		return;
+	const int nv = min(vpw, nlist - first);
+	const int nfrags = p.nfrags;
+	const int dbg = p.debug;
+	FastPtrs g = { wavepool, waves, ptab, dbg };
+	int *tile = tiles + wv * vpw * FILT_PITCH;
+
+	int ffr[A2D_MAXBATCH / 64], fst[A2D_MAXBATCH / 64];
+#pragma unroll
+	for(int k = 0; k < A2D_MAXBATCH / 64; ++k) {
+		ffr[k] = (k * 64 + lane < nfrags) ? p.fragframes[k * 64 + lane] : 0;
+		fst[k] = (k * 64 + lane < nfrags) ? p.fragstart[k * 64 + lane] : 0;
+	}
+
+	int sv[SV_NWORDS], dv[DV_NWORDS], fv[FV_NWORDS];
+	int u0 = 0, u1 = 0, u2 = 0, my_off = -1, my_nch = 2;
+#pragma unroll
+	for(int k = 0; k < SV_NWORDS; ++k)
+		sv[k] = 0;
+#pragma unroll
+	for(int k = 0; k < DV_NWORDS; ++k)
+		dv[k] = 0;
+#pragma unroll
+	for(int k = 0; k < FV_NWORDS; ++k)
+		fv[k] = 0;
+	if(lane < nv) {
+		const A2DVoice &vc = voices[list[first + lane]];
+		u0 = vc.unit[0];
+		u1 = vc.unit[1];
+		u2 = vc.unit[2];
+		my_off = vc.out_off;
+		my_nch = vc.out_nch;
+		const int *w0 = ustate + (size_t)u0 * A2D_USTATE;
+		const int *w1 = ustate + (size_t)u1 * A2D_USTATE;
+		const int *w2 = ustate + (size_t)u2 * A2D_USTATE;
+		sv[SV_MODE] = w0[OW_MODE]; sv[SV_WAVE] = w0[OW_WAVE]; sv[SV_DPHASE] = w0[OW_DPHASE];
+		sv[SV_PHLO] = w0[OW_PHASE_LO]; sv[SV_PHHI] = w0[OW_PHASE_HI]; sv[SV_PRAMP] = w0[OW_PRAMPING];
+#pragma unroll
+		for(int k = 0; k < 4; ++k) {
+			sv[SV_P + k] = w0[OW_P + k];
+			sv[SV_A + k] = w0[OW_A + k];
+			sv[SV_VOL + k] = w2[PW_VOL + k];
+			sv[SV_PAN + k] = w2[PW_PAN + k];
+			fv[FV_Q + k] = w1[FW_Q + k];
+		}
+		fv[FV_LP] = w1[FW_LP]; fv[FV_BP] = w1[FW_BP]; fv[FV_HP] = w1[FW_HP];
+		fv[FV_F1] = w1[FW_F1]; fv[FV_D1] = w1[FW_D1A]; fv[FV_D2] = w1[FW_D2A];
+		bool settled = sv[SV_MODE] == A2D_OSC_MIPWAVE && sv[SV_DPHASE] && !sv[SV_PRAMP] &&
+				!(sv[SV_P + 3] | sv[SV_P + 2] | sv[SV_A + 3] | sv[SV_A + 2] |
+				  sv[SV_VOL + 3] | sv[SV_VOL + 2] | sv[SV_PAN + 3] | sv[SV_PAN + 2]) &&
+				sv[SV_P] == sv[SV_P + 1] && sv[SV_A] == sv[SV_A + 1] &&
+				sv[SV_VOL] == sv[SV_VOL + 1] && sv[SV_PAN] == sv[SV_PAN + 1];
+		if(settled) {
+			const A2DWave *w = waves + sv[SV_WAVE];
+			const unsigned period = w->period, dphase = (unsigned)sv[SV_DPHASE];
+			unsigned dph = ((dphase + 255) >> 8) * period, mm = 0;
+			for(; (dph > (A2D_MAXPHINC << 8)) && (mm < A2D_MIPS - 1); ++mm)
+				dph >>= 1;
+			dph = (unsigned)(((uint64_t)dphase * period) >> mm);
+			settled = w->size[0] && (w->flags & 0x100u) && dph <= (A2D_MAXPHINC << 16);
+			dv[DV_MM] = (int)mm;
+			dv[DV_DPH] = (int)dph;
+			dv[DV_SIZEM] = (int)w->size[mm];
+			dv[DV_DOFF] = (int)w->off[mm];
+			const int vol = sv[SV_VOL], pan = sv[SV_PAN];
+			const int vp = mul64s(pan, vol, 24);
+			int v0 = wsub(vol, vp), v1 = wadd(vol, vp);
+			if(pan > 0xffffff || pan < -0xffffff) {
+				int lim = wshl(vol, 1);
+				if(v0 > lim) v0 = lim;
+				if(v1 > lim) v1 = lim;
+			}
+			dv[DV_V0] = v0;
+			dv[DV_V1] = v1;
+		}
+		dv[DV_SETTLED] = settled ? 1 : 0;
+	}
+	const uint32_t *wp32 = (const uint32_t *)wavepool;
+	unsigned total = 0;	// frames rendered so far
+
+	for(int f = 0; f < nfrags; ++f) {
+		const int n = frames_of(ffr, f);
+		// ---- A: oscillators, frame = lane ----
+		for(int v = 0; v < nv; ++v) {
+			int x;
+			// four settled voices at a time: their wave data loads overlap
+			if(v + 3 < nv && (rdl(dv[DV_SETTLED], v) & rdl(dv[DV_SETTLED], v + 1) &
+					rdl(dv[DV_SETTLED], v + 2) & rdl(dv[DV_SETTLED], v + 3))) {
+				uint32_t q0[4], q1[4], q2[4];
+				unsigned qph[4], qodd[4], qd16[4];
+				int qamp[4];
+#pragma unroll
+				for(int k = 0; k < 4; ++k) {
+					const int vk = v + k;
+					const unsigned mm = (unsigned)rdl(dv[DV_MM], vk), dph = (unsigned)rdl(dv[DV_DPH], vk);
+					const unsigned sizem = (unsigned)rdl(dv[DV_SIZEM], vk), doff = (unsigned)rdl(dv[DV_DOFF], vk);
+					const uint64_t phase = (uint64_t)(unsigned)rdl(sv[SV_PHLO], vk) |
+							((uint64_t)(unsigned)rdl(sv[SV_PHHI], vk) << 32);
+					uint64_t ph = wrap_phase((phase >> mm) + (uint64_t)total * dph, sizem);
+					qph[k] = (unsigned)((ph + (uint64_t)(unsigned)lane * dph) >> 16);
+					unsigned e = doff + (qph[k] >> 8) - 1u;
+					qodd[k] = e & 1u;
+					const uint32_t *ap = wp32 + (e >> 1);
+					q0[k] = ap[0]; q1[k] = ap[1]; q2[k] = ap[2];
+					qd16[k] = dph >> 16;
+					qamp[k] = rdl(sv[SV_A], vk);
+				}
+#pragma unroll
+				for(int k = 0; k < 4; ++k) {
+					int sm = inter_from_dwords(q0[k], q1[k], q2[k], qodd[k], qph[k], qd16[k]);
+					int xk = mul64s(sm, qamp[k], 17);
+					tile[(v + k) * FILT_PITCH + lane] = (lane < n) ? xk : 0;
+				}
+				v += 3;
+				continue;
+			}
+			if(rdl(dv[DV_SETTLED], v)) {
+				const unsigned mm = (unsigned)rdl(dv[DV_MM], v), dph = (unsigned)rdl(dv[DV_DPH], v);
+				const unsigned sizem = (unsigned)rdl(dv[DV_SIZEM], v), doff = (unsigned)rdl(dv[DV_DOFF], v);
+				const int amp = rdl(sv[SV_A], v);
+				const uint64_t phase = (uint64_t)(unsigned)rdl(sv[SV_PHLO], v) |
+						((uint64_t)(unsigned)rdl(sv[SV_PHHI], v) << 32);
+				// start of fragment f = ((phase >> mm) + frames_before * dph) mod (size << 24)
+				uint64_t ph = wrap_phase((phase >> mm) + (uint64_t)total * dph, sizem);
+				unsigned ph16 = (unsigned)((ph + (uint64_t)(unsigned)lane * dph) >> 16);
+				unsigned e = doff + (ph16 >> 8) - 1u;
+				const uint32_t *ap = wp32 + (e >> 1);
+				int sm = inter_from_dwords(ap[0], ap[1], ap[2], e & 1u, ph16, dph >> 16);
+				x = mul64s(sm, amp, 17);
+			} else {
+				OscS o;
+				o.mode = rdl(sv[SV_MODE], v);
+				o.wave = rdl(sv[SV_WAVE], v);
+				o.dphase = (unsigned)rdl(sv[SV_DPHASE], v);
+				o.phase = (uint64_t)(unsigned)rdl(sv[SV_PHLO], v) |
+						((uint64_t)(unsigned)rdl(sv[SV_PHHI], v) << 32);
+				o.p_ramping = rdl(sv[SV_PRAMP], v);
+				o.p.value = rdl(sv[SV_P], v); o.p.target = rdl(sv[SV_P + 1], v);
+				o.p.delta = rdl(sv[SV_P + 2], v); o.p.timer = rdl(sv[SV_P + 3], v);
+				o.a.value = rdl(sv[SV_A], v); o.a.target = rdl(sv[SV_A + 1], v);
+				o.a.delta = rdl(sv[SV_A + 2], v); o.a.timer = rdl(sv[SV_A + 3], v);
+				x = osc_fragment_s(g, o, n, lane);
+				const bool me = lane == v;
+				WRL(sv[SV_MODE], o.mode);
+				WRL(sv[SV_WAVE], o.wave);
+				WRL(sv[SV_DPHASE], (int)o.dphase);
+				WRL(sv[SV_PHLO], (int)(unsigned)o.phase);
+				WRL(sv[SV_PHHI], (int)(unsigned)(o.phase >> 32));
+				WRL(sv[SV_PRAMP], o.p_ramping);
+				WRL(sv[SV_P], o.p.value); WRL(sv[SV_P + 1], o.p.target);
+				WRL(sv[SV_P + 2], o.p.delta); WRL(sv[SV_P + 3], o.p.timer);
+				WRL(sv[SV_A], o.a.value); WRL(sv[SV_A + 1], o.a.target);
+				WRL(sv[SV_A + 2], o.a.delta); WRL(sv[SV_A + 3], o.a.timer);
+			}
+			tile[v * FILT_PITCH + lane] = (lane < n) ? x : 0;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		// ---- B: filter12, voice = lane (f12_process, filter12.c:74-119; no
+		// cutoff ramp in a quiet voice: df = 0) ----
+		if(lane < nv) {
+			Ramp q = { fv[FV_Q], fv[FV_Q + 1], fv[FV_Q + 2], fv[FV_Q + 3] };
+			ramp_prepare(q, n);
+			const int ff = fv[FV_F1] >> 12, lp = fv[FV_LP], bp = fv[FV_BP], hp = fv[FV_HP];
+			int d1 = fv[FV_D1], d2 = fv[FV_D2], qv = q.value;
+			int *row = tile + lane * FILT_PITCH;
+			for(int s = 0; s < n; ++s) {
+				int qq = qv >> 12;
+				int d1s = d1 >> 4;
+				int l = wadd(d2, wmul(ff, d1s) >> 8);
+				int h = wsub(wsub(row[s] >> 5, l), wmul(qq, d1s) >> 8);
+				int b = wadd(wmul(ff, h >> 4) >> 8, d1);
+				row[s] = wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3;
+				d1 = b;
+				d2 = l;
+				qv = wadd(qv, q.delta);
+			}
+			ramp_run(q, n);
+			fv[FV_Q] = q.value; fv[FV_Q + 1] = q.target; fv[FV_Q + 2] = q.delta; fv[FV_Q + 3] = q.timer;
+			fv[FV_D1] = d1;
+			fv[FV_D2] = d2;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		// ---- C: pan + mix-down, frame = lane ----
+		int acc0 = 0, acc1 = 0;
+		int cur_off = rdl(my_off, 0), cur_nch = rdl(my_nch, 0);
+		for(int v = 0; v < nv; ++v) {
+			const int voff = rdl(my_off, v);
+			if(voff != cur_off) {
+				int *dst = busmem + cur_off + (size_t)f * cur_nch * A2D_FRAG;
+				if(acc0) atomicAdd(&dst[lane], acc0);
+				if(acc1) atomicAdd(&dst[A2D_FRAG + lane], acc1);
+				acc0 = acc1 = 0;
+				cur_off = voff;
+				cur_nch = rdl(my_nch, v);
+			}
+			const int y = tile[v * FILT_PITCH + lane];
+			if(rdl(dv[DV_SETTLED], v)) {
+				const int v0 = rdl(dv[DV_V0], v), v1 = rdl(dv[DV_V1], v);
+				if(lane < n) {
+					acc0 = wadd(acc0, mul64s(y, v0, 24));
+					acc1 = wadd(acc1, mul64s(y, v1, 24));
+				}
+			} else {
+				Ramp vol, pan;
+				vol.value = rdl(sv[SV_VOL], v); vol.target = rdl(sv[SV_VOL + 1], v);
+				vol.delta = rdl(sv[SV_VOL + 2], v); vol.timer = rdl(sv[SV_VOL + 3], v);
+				pan.value = rdl(sv[SV_PAN], v); pan.target = rdl(sv[SV_PAN + 1], v);
+				pan.delta = rdl(sv[SV_PAN + 2], v); pan.timer = rdl(sv[SV_PAN + 3], v);
+				pan_fragment_s(vol, pan, y, n, lane, acc0, acc1);
+				const bool me = lane == v;
+				WRL(sv[SV_VOL], vol.value); WRL(sv[SV_VOL + 1], vol.target);
+				WRL(sv[SV_VOL + 2], vol.delta); WRL(sv[SV_VOL + 3], vol.timer);
+				WRL(sv[SV_PAN], pan.value); WRL(sv[SV_PAN + 1], pan.target);
+				WRL(sv[SV_PAN + 2], pan.delta); WRL(sv[SV_PAN + 3], pan.timer);
+			}
+		}
+		if(cur_off >= 0 && !(dbg & 1)) {
+			int *dst = busmem + cur_off + (size_t)f * cur_nch * A2D_FRAG;
+			if(acc0) atomicAdd(&dst[lane], acc0);
+			if(acc1) atomicAdd(&dst[A2D_FRAG + lane], acc1);
+		}
+		total += (unsigned)n;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
+
+	if(lane < nv) {
+		if(dv[DV_SETTLED]) {
+			// the unwrapped end of the last fragment (wtosc.c:284)
+			const unsigned mm = (unsigned)dv[DV_MM], dph = (unsigned)dv[DV_DPH];
+			const unsigned nlast = (unsigned)frames_of(ffr, nfrags - 1);
+			const uint64_t phase = (uint64_t)(unsigned)sv[SV_PHLO] | ((uint64_t)(unsigned)sv[SV_PHHI] << 32);
+			uint64_t ph = (phase >> mm) + (uint64_t)(total - nlast) * dph;
+			const unsigned size = (unsigned)dv[DV_SIZEM];
+			unsigned hi = (unsigned)(ph >> 24);		// wrap_phase, per lane
+			if(ph >> 56)
+				ph %= (uint64_t)size << 24;
+			else if(hi >= size)
+				ph = ((uint64_t)(hi % size) << 24) | (ph & 0xffffffu);
+			ph = (ph + (uint64_t)dph * nlast) << mm;
+			sv[SV_PHLO] = (int)(unsigned)ph;
+			sv[SV_PHHI] = (int)(unsigned)(ph >> 32);
+		}
+		int *w0 = ustate + (size_t)u0 * A2D_USTATE;
+		int *w1 = ustate + (size_t)u1 * A2D_USTATE;
+		int *w2 = ustate + (size_t)u2 * A2D_USTATE;
+		w0[OW_MODE] = sv[SV_MODE]; w0[OW_WAVE] = sv[SV_WAVE]; w0[OW_DPHASE] = sv[SV_DPHASE];
+		w0[OW_PHASE_LO] = sv[SV_PHLO]; w0[OW_PHASE_HI] = sv[SV_PHHI]; w0[OW_PRAMPING] = sv[SV_PRAMP];
+#pragma unroll
+		for(int k = 0; k < 4; ++k) {
+			w0[OW_P + k] = sv[SV_P + k];
+			w0[OW_A + k] = sv[SV_A + k];
+			w2[PW_VOL + k] = sv[SV_VOL + k];
+			w2[PW_PAN + k] = sv[SV_PAN + k];
+			w1[FW_Q + k] = fv[FV_Q + k];
+		}
+		w1[FW_D1A] = fv[FV_D1];
+		w1[FW_D2A] = fv[FV_D2];
+	}
+}
+
+// ---------------------------------------------------------------------------
 // inline -> panmix 2->2 -> xinsert (add, wired): root / group driver voices
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
@@ -622,6 +926,20 @@ int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const 
 	if(ysplit > 1)
 		hipLaunchKernelGGL(k_commit_oscpan, dim3((nlist * 16 + 255) / 256), dim3(256), 0,
 				(hipStream_t)stream, dlist, nlist, hp.voices, hp.ustate, (const int *)ustage);
+	return (int)hipGetLastError();
+}
+
+int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
+		int vpw, void *stream)
+{
+	if(nlist <= 0)
+		return 0;
+	vpw = vpw < 1 ? 1 : (vpw > FILT_MAXV ? FILT_MAXV : vpw);
+	int nwaves = (nlist + vpw - 1) / vpw;
+	int nblocks = (nwaves + FAST_WPB - 1) / FAST_WPB;
+	size_t lds = (size_t)FAST_WPB * vpw * FILT_PITCH * sizeof(int);
+	hipLaunchKernelGGL(k_leaf_oscfiltpan, dim3(nblocks), dim3(64 * FAST_WPB), lds, (hipStream_t)stream,
+			dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
 	return (int)hipGetLastError();
 }
 

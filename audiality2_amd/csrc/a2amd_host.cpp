@@ -186,7 +186,7 @@ struct a2amd_ctx {
 	bool voices_dirty = true, udesc_dirty = true, waves_dirty = true, lists_dirty = true, ptab_dirty = true;
 	std::vector<int> list_all;		// leaf list followed by per-depth lists
 	int n_leaf = 0;
-	int n_fast_leaf = 0;			// list_all = [fast leaves | general leaves | per depth ...]
+	int n_fast_leaf = 0, n_filt_leaf = 0;	// list_all = [wtosc-panmix | wtosc-filter12-panmix | general leaves | per depth ...]
 	std::vector<DepthRange> depth_ranges;	// index = depth
 	bool no_fast = false;			// A2AMD_NO_FAST=1: general kernel only (debugging)
 
@@ -392,6 +392,20 @@ bool is_oscpan_chain(const a2amd_ctx *c, const HVoice &v)
 			(pm.flags & A2AMD_PROCADD);
 }
 
+// wtosc -> filter12 (1 channel, replacing) -> panmix 1->2 adding into the output bus
+bool is_oscfiltpan_chain(const a2amd_ctx *c, const HVoice &v)
+{
+	if(v.nunits != 3 || v.out_nch < 2)
+		return false;
+	const HUnit &o = c->units[v.unit[0]], &f = c->units[v.unit[1]], &pm = c->units[v.unit[2]];
+	return o.kind == A2AMD_WTOSC && !(o.flags & A2AMD_PROCADD) && !o.wired &&
+			(o.mode == A2D_OSC_MIPWAVE || o.mode == A2D_OSC_OFF) &&
+			f.kind == A2AMD_FILTER12 && f.nin == 1 && !f.wired && !(f.flags & A2AMD_PROCADD) &&
+			f.cutoff.timer == 0 && f.cutoff.delta == 0 &&
+			pm.kind == A2AMD_PANMIX && pm.nin == 1 && pm.nout == 2 && pm.wired &&
+			(pm.flags & A2AMD_PROCADD);
+}
+
 // inline 0 2; panmix 2 2; xinsert 2 >  (a2_rootdriver / a2_groupdriver)
 bool is_driver_chain(const a2amd_ctx *c, const HVoice &v)
 {
@@ -468,7 +482,7 @@ int upload(a2amd_ctx *c)
 	//           wavefront can sum several voices before touching the bus)
 	//   voices with an inline unit, per nesting depth: [fast driver chain | general]
 	{
-		std::vector<int> fast_leaf, gen_leaf;
+		std::vector<int> fast_leaf, filt_leaf, gen_leaf;
 		std::map<int, std::pair<std::vector<int>, std::vector<int>>> bydepth;
 		int maxdepth = -1;
 		for(size_t vi = 0; vi < nv; ++vi) {
@@ -483,13 +497,17 @@ int upload(a2amd_ctx *c)
 				(quiet && is_driver_chain(c, v) ? d.first : d.second).push_back((int)vi);
 				maxdepth = std::max(maxdepth, v.depth);
 			} else
-				(quiet && is_oscpan_chain(c, v) ? fast_leaf : gen_leaf).push_back((int)vi);
+				(quiet && is_oscpan_chain(c, v) ? fast_leaf :
+				 quiet && is_oscfiltpan_chain(c, v) ? filt_leaf : gen_leaf).push_back((int)vi);
 		}
 		auto by_bus = [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; };
 		std::stable_sort(fast_leaf.begin(), fast_leaf.end(), by_bus);
 		std::stable_sort(gen_leaf.begin(), gen_leaf.end(), by_bus);
+		std::stable_sort(filt_leaf.begin(), filt_leaf.end(), by_bus);
 		c->list_all = fast_leaf;
 		c->n_fast_leaf = (int)fast_leaf.size();
+		c->list_all.insert(c->list_all.end(), filt_leaf.begin(), filt_leaf.end());
+		c->n_filt_leaf = (int)filt_leaf.size();
 		c->list_all.insert(c->list_all.end(), gen_leaf.begin(), gen_leaf.end());
 		c->n_leaf = (int)gen_leaf.size();
 		c->depth_ranges.assign(maxdepth + 1, DepthRange());
@@ -652,8 +670,16 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 				return c->fail(A2AMD_EHIP, "fast leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
+		if(c->n_filt_leaf) {
+			int vpw = getenv("A2AMD_FVPW") ? atoi(getenv("A2AMD_FVPW")) :
+					std::min(std::max((c->n_filt_leaf + 2047) / 2048, 1), 32);
+			if(a2d_launch_leaf_oscfiltpan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf,
+					c->n_filt_leaf, vpw, c->stream))
+				return c->fail(A2AMD_EHIP, "filter leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+			++c->stats.launches;
+		}
 		if(c->n_leaf) {
-			if(a2d_launch_voices(c->d_params, c->d_list.d + c->n_fast_leaf, c->n_leaf,
+			if(a2d_launch_voices(c->d_params, c->d_list.d + c->n_fast_leaf + c->n_filt_leaf, c->n_leaf,
 					pick_vpw(c->n_leaf), c->stream))
 				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;

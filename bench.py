@@ -252,7 +252,8 @@ def main():
             "parity_vs_oracle": parity,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
-                         "kernel": "k_leaf_oscpan" if args.chain == "osc-pan" else "k_voices (leaf launch)",
+                         "kernel": {"osc-pan": "k_leaf_oscpan", "osc-filter-pan": "k_leaf_oscfiltpan"}.get(
+                             args.chain, "k_voices (leaf launch)"),
                          "avg_launch_ms": leaf_ms,
                          "timing": "HIP events on the launch stream around every launch, separate pass of "
                                    f"{nprof} steps right after the timed region (graph replay off)",
