@@ -313,13 +313,16 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	// what follows from them for a settled voice
 	int sv[SV_NWORDS], dv[DV_NWORDS];
 	int u0 = 0, u1 = 0, my_off = -1, my_nch = 2;
+	bool mine = false;	// this lane's voice is ours to render (no records this batch)
 #pragma unroll
 	for(int k = 0; k < SV_NWORDS; ++k)
 		sv[k] = 0;
 #pragma unroll
 	for(int k = 0; k < DV_NWORDS; ++k)
 		dv[k] = 0;
-	if(lane < nv) {
+	if(lane < nv)
+		mine = p.runs[list[first + lane]].count == 0;
+	if(mine) {
 		const A2DVoice &vc = voices[list[first + lane]];
 		u0 = vc.unit[0];
 		u1 = vc.unit[1];
@@ -371,7 +374,7 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 		}
 		dv[DV_SETTLED] = settled ? 1 : 0;
 	}
-	const unsigned long long unsettled_mask = __ballot(lane < nv && !dv[DV_SETTLED]);
+	const unsigned long long unsettled_mask = __ballot(mine && !dv[DV_SETTLED]);
 
 	// ---- settled voices: this slice's chunks ---------------------------------
 	for(int c = c_lo; c < c_hi; ++c) {
@@ -518,7 +521,7 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	// k_commit_oscpan afterwards.  The last slice owns the settled voices (their
 	// end phase), slice 0 the others.
 	const bool settled_l = dv[DV_SETTLED] != 0;
-	if(lane < nv && ((settled_l && last_slice) || (!settled_l && slice == 0))) {
+	if(mine && ((settled_l && last_slice) || (!settled_l && slice == 0))) {
 		int *w0 = ustage + (size_t)u0 * A2D_USTATE;
 		int *w1 = ustage + (size_t)u1 * A2D_USTATE;
 		w0[OW_MODE] = sv[SV_MODE]; w0[OW_WAVE] = sv[SV_WAVE]; w0[OW_DPHASE] = sv[SV_DPHASE];
@@ -535,11 +538,13 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 
 // staged state of the fast leaf voices -> the unit state array
 __global__ void k_commit_oscpan(const int *__restrict__ list, int nlist, const A2DVoice *__restrict__ voices,
-		int *__restrict__ ustate, const int *__restrict__ ustage)
+		const A2DRun *__restrict__ runs, int *__restrict__ ustate, const int *__restrict__ ustage)
 {
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if(i >= nlist * 16)
 		return;
+	if(runs[list[i >> 4]].count)
+		return;		// not rendered by k_leaf_oscpan this batch: nothing staged
 	const A2DVoice &vc = voices[list[i >> 4]];
 	const int k = i & 15;
 	// the words k_leaf_oscpan stages: wtosc 0..6 (+ p, a = 7..14), panmix 0..7
@@ -597,6 +602,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 
 	int sv[SV_NWORDS], dv[DV_NWORDS], fv[FV_NWORDS];
 	int u0 = 0, u1 = 0, u2 = 0, my_off = -1, my_nch = 2;
+	bool mine = false;	// this lane's voice is ours to render (no records this batch)
 #pragma unroll
 	for(int k = 0; k < SV_NWORDS; ++k)
 		sv[k] = 0;
@@ -606,7 +612,10 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 #pragma unroll
 	for(int k = 0; k < FV_NWORDS; ++k)
 		fv[k] = 0;
-	if(lane < nv) {
+	if(lane < nv)
+		mine = p.runs[list[first + lane]].count == 0;
+	const unsigned long long mine_mask = __ballot(mine);
+	if(mine) {
 		const A2DVoice &vc = voices[list[first + lane]];
 		u0 = vc.unit[0];
 		u1 = vc.unit[1];
@@ -666,6 +675,10 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		// ---- A: oscillators, frame = lane ----
 		for(int v = 0; v < nv; ++v) {
 			int x;
+			if(!((mine_mask >> v) & 1ull)) {
+				tile[v * FILT_PITCH + lane] = 0;
+				continue;
+			}
 			// four settled voices at a time: their wave data loads overlap
 			if(v + 3 < nv && (rdl(dv[DV_SETTLED], v) & rdl(dv[DV_SETTLED], v + 1) &
 					rdl(dv[DV_SETTLED], v + 2) & rdl(dv[DV_SETTLED], v + 3))) {
@@ -741,7 +754,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		__builtin_amdgcn_wave_barrier();
 		// ---- B: filter12, voice = lane (f12_process, filter12.c:74-119; no
 		// cutoff ramp in a quiet voice: df = 0) ----
-		if(lane < nv) {
+		if(mine) {
 			Ramp q = { fv[FV_Q], fv[FV_Q + 1], fv[FV_Q + 2], fv[FV_Q + 3] };
 			ramp_prepare(q, n);
 			const int ff = fv[FV_F1] >> 12, lp = fv[FV_LP], bp = fv[FV_BP], hp = fv[FV_HP];
@@ -769,11 +782,15 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		int acc0 = 0, acc1 = 0;
 		int cur_off = rdl(my_off, 0), cur_nch = rdl(my_nch, 0);
 		for(int v = 0; v < nv; ++v) {
+			if(!((mine_mask >> v) & 1ull))
+				continue;
 			const int voff = rdl(my_off, v);
 			if(voff != cur_off) {
-				int *dst = busmem + cur_off + (size_t)f * cur_nch * A2D_FRAG;
-				if(acc0) atomicAdd(&dst[lane], acc0);
-				if(acc1) atomicAdd(&dst[A2D_FRAG + lane], acc1);
+				if(cur_off >= 0) {
+					int *dst = busmem + cur_off + (size_t)f * cur_nch * A2D_FRAG;
+					if(acc0) atomicAdd(&dst[lane], acc0);
+					if(acc1) atomicAdd(&dst[A2D_FRAG + lane], acc1);
+				}
 				acc0 = acc1 = 0;
 				cur_off = voff;
 				cur_nch = rdl(my_nch, v);
@@ -809,7 +826,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		__builtin_amdgcn_wave_barrier();
 	}
 
-	if(lane < nv) {
+	if(mine) {
 		if(dv[DV_SETTLED]) {
 			// the unwrapped end of the last fragment (wtosc.c:284)
 			const unsigned mm = (unsigned)dv[DV_MM], dph = (unsigned)dv[DV_DPH];
@@ -852,6 +869,8 @@ void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list
 {
 	__shared__ int fr[A2D_MAXBATCH][5];	// per fragment: vol, dvol, pan, dpan, clamp
 	const A2DParams &p = *pp;
+	if(p.runs[list[blockIdx.x]].count)
+		return;		// carries records this batch: the general kernel renders it
 	const A2DVoice &vc = p.voices[list[blockIdx.x]];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	int *w = p.ustate + (size_t)vc.unit[1] * A2D_USTATE;
@@ -925,7 +944,24 @@ int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const 
 			ysplit > 1 ? ustage : hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
 	if(ysplit > 1)
 		hipLaunchKernelGGL(k_commit_oscpan, dim3((nlist * 16 + 255) / 256), dim3(256), 0,
-				(hipStream_t)stream, dlist, nlist, hp.voices, hp.ustate, (const int *)ustage);
+				(hipStream_t)stream, dlist, nlist, hp.voices, hp.runs, hp.ustate, (const int *)ustage);
+	return (int)hipGetLastError();
+}
+
+__global__ void k_scatter_runs(const int *__restrict__ idx, const A2DRun *__restrict__ val, int n,
+		A2DRun *__restrict__ runs)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if(i < n)
+		runs[idx[i]] = val[i];
+}
+
+int a2d_launch_scatter_runs(const int *didx, const A2DRun *dval, int n, A2DRun *druns, void *stream)
+{
+	if(n <= 0)
+		return 0;
+	hipLaunchKernelGGL(k_scatter_runs, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+			didx, dval, n, druns);
 	return (int)hipGetLastError();
 }
 

@@ -137,11 +137,14 @@ struct HVoice {
 	int own_off = -1, own_nch = 0;
 	int win_off = -1, win_frames = 0;
 	std::vector<A2DRec> recs;	// this batch, fragment order
-	int touched = -1;		// fragment tag of the last touch
+	long long touched = -1;		// serial of the fragment of the last touch
 	size_t frag_mark = 0;		// recs.size() when that fragment was first touched
+	int cls = 0;			// launch class (CLS_*), set when the lists are rebuilt
+	bool listed_recs = false;	// already in a2amd_ctx::with_recs
 };
 
-struct DepthRange { int fast_first = 0, fast_count = 0, gen_first = 0, gen_count = 0; };
+struct DepthRange { int fast_first = 0, fast_count = 0, gen_first = 0, gen_count = 0, dyn_first = 0, dyn_count = 0; };
+enum { CLS_GENERIC = 0, CLS_OSCPAN, CLS_OSCFILTPAN, CLS_BUSDRIVER, CLS_BUSGENERIC };
 
 struct HWave {
 	bool live = false;
@@ -170,6 +173,10 @@ struct a2amd_ctx {
 	int building = -1;
 	std::vector<int> stack;			// open inline windows (unit ids)
 	std::vector<int> touched_list;
+	std::vector<int> with_recs, prev_with_recs;	// voices carrying records this / last batch
+	std::vector<int> dirty_voices;		// voice mirror entries to re-upload
+	long long serial_base = 0;		// fragments rendered before this batch
+	int n_leaf_dyn = 0, static_len = 0;
 	int n_started_live = 0;			// voices the engine is walking
 	int n_noise = 0, n_cutoff_ramps = 0;
 
@@ -188,7 +195,7 @@ struct a2amd_ctx {
 	int n_leaf = 0;
 	int n_fast_leaf = 0, n_filt_leaf = 0;	// list_all = [wtosc-panmix | wtosc-filter12-panmix | general leaves | per depth ...]
 	std::vector<DepthRange> depth_ranges;	// index = depth
-	bool no_fast = false;			// A2AMD_NO_FAST=1: general kernel only (debugging)
+	int no_fast = 0;			// A2AMD_NO_FAST bit mask: 1 wtosc-panmix, 2 wtosc-filter12-panmix, 4 driver chains -> general kernel (debugging / A-B tests)
 
 	// bus memory allocator (units of int32)
 	size_t bus_stride_frames;
@@ -215,6 +222,7 @@ struct a2amd_ctx {
 	DevBuf<int32_t> d_busmem;
 	DevBuf<int32_t> d_fbdmem;	// cap in buffer pairs
 	DevBuf<int> d_list;
+	DevBuf<int> d_scatter;	// idx[k] then A2DRun[k] for k_scatter_runs
 	uint32_t *d_ptab = nullptr;
 	A2DParams *d_params = nullptr;
 	A2DParams hparams;
@@ -270,9 +278,9 @@ int rec_tag(const a2amd_ctx *c) { return c->frag_open ? c->cur_frag : c->nfrags;
 void touch(a2amd_ctx *c, int vi)
 {
 	HVoice &v = c->voices[vi];
-	int tag = rec_tag(c);
-	if(v.touched != tag) {
-		v.touched = tag;
+	const long long serial = c->serial_base + rec_tag(c);
+	if(v.touched != serial) {
+		v.touched = serial;
 		v.frag_mark = v.recs.size();
 		c->touched_list.push_back(vi);
 	}
@@ -286,7 +294,12 @@ void push_rec(a2amd_ctx *c, int vi, int op, int unit, int reg, int value, unsign
 	r.value = value;
 	r.dur = dur;
 	r.start = start;
-	c->voices[vi].recs.push_back(r);
+	HVoice &v = c->voices[vi];
+	if(!v.listed_recs) {
+		v.listed_recs = true;
+		c->with_recs.push_back(vi);
+	}
+	v.recs.push_back(r);
 }
 
 int bus_alloc(a2amd_ctx *c, int nch)
@@ -312,7 +325,7 @@ int close_fragment(a2amd_ctx *c)
 	int touched_started = 0;
 	for(int vi : c->touched_list) {
 		HVoice &v = c->voices[vi];
-		if(v.touched != f)
+		if(v.touched != c->serial_base + f)
 			continue;	// touched ahead of a later fragment
 		if(v.started && !v.dying)
 			++touched_started;
@@ -329,10 +342,14 @@ int close_fragment(a2amd_ctx *c)
 		// the kernel would apply the default
 		for(size_t vi = 0; vi < c->voices.size(); ++vi) {
 			HVoice &v = c->voices[vi];
-			if(v.live && v.started && !v.dying && v.touched != f) {
+			if(v.live && v.started && !v.dying && v.touched != c->serial_base + f) {
 				A2DRec r = { A2D_HEAD(f, R_NOP, 0, 0), 0, 0, 0 };
+				if(!v.listed_recs) {
+					v.listed_recs = true;
+					c->with_recs.push_back((int)vi);
+				}
 				v.recs.push_back(r);
-				v.touched = f;
+				v.touched = c->serial_base + f;
 			}
 		}
 	}
@@ -361,6 +378,7 @@ void resolve_out(a2amd_ctx *c, HVoice &v)
 	}
 	v.resolved = true;
 	c->voices_dirty = true;
+	c->dirty_voices.push_back((int)(&v - c->voices.data()));
 	c->lists_dirty = true;
 }
 
@@ -428,16 +446,26 @@ int upload(a2amd_ctx *c)
 	if(int r = grow(c, c->d_ustate, nu, A2D_USTATE, true)) return r;
 	if(int r = grow(c, c->d_ustage, c->d_ustate.cap, A2D_USTATE, false)) return r;
 	if(int r = grow(c, c->d_vactive, nv, 1, true)) return r;
-	if(int r = grow(c, c->d_runs, nv, 1, false)) return r;
+	if(int r = grow(c, c->d_runs, nv, 1, true)) return r;
 	if(int r = grow(c, c->d_busmem, c->bus_used, 1, false)) return r;
 	if(c->fbd_count)
 		if(int r = grow(c, c->d_fbdmem, c->fbd_count, 2 * (size_t)A2D_FBD_BUFSIZE, true)) return r;
 
 	if(c->voices_dirty && nv) {
-		for(size_t vi = 0; vi < nv; ++vi)
-			sync_voice_mirror(c, (int)vi);
-		HIPCHK(c, hipMemcpyAsync(c->d_voices.d, c->mvoices.data(), nv * sizeof(A2DVoice),
-				hipMemcpyHostToDevice, c->stream));
+		// re-upload the span of voice table entries that changed
+		if(c->mvoices.size() < nv)
+			c->mvoices.resize(nv);
+		int lo = (int)nv, hi = -1;
+		for(int vi : c->dirty_voices)
+			if(vi < (int)nv) {
+				sync_voice_mirror(c, vi);
+				lo = std::min(lo, vi);
+				hi = std::max(hi, vi);
+			}
+		c->dirty_voices.clear();
+		if(hi >= lo)
+			HIPCHK(c, hipMemcpyAsync(c->d_voices.d + lo, c->mvoices.data() + lo,
+					(size_t)(hi - lo + 1) * sizeof(A2DVoice), hipMemcpyHostToDevice, c->stream));
 		c->voices_dirty = false;
 	}
 	if(c->udesc_dirty && nu) {
@@ -460,45 +488,77 @@ int upload(a2amd_ctx *c)
 				2 * (size_t)A2D_FBD_BUFSIZE * sizeof(int32_t), c->stream));
 	c->fbd_to_zero.clear();
 
-	// records: one contiguous run per voice
-	std::vector<A2DRun> runs(nv);
+	// Records: one contiguous run per voice that has any.  The device keeps a
+	// dense runs[slot] table (zero = quiet voice); only the entries that change
+	// are written, by a scatter kernel: this batch's runs, and zeros for the
+	// voices that carried records last batch but not now.
 	std::vector<A2DRec> recs;
-	for(size_t vi = 0; vi < nv; ++vi) {
+	std::vector<int> sc_idx;
+	std::vector<A2DRun> sc_val;
+	std::vector<int> now;
+	for(int vi : c->with_recs) {
 		HVoice &v = c->voices[vi];
-		runs[vi].first = (int)recs.size();
-		runs[vi].count = (int)v.recs.size();
+		if(v.recs.empty()) {
+			v.listed_recs = false;
+			continue;
+		}
+		A2DRun r = { (int)recs.size(), (int)v.recs.size() };
 		recs.insert(recs.end(), v.recs.begin(), v.recs.end());
+		sc_idx.push_back(vi);
+		sc_val.push_back(r);
+		now.push_back(vi);
 	}
+	c->with_recs = now;
+	for(int vi : c->prev_with_recs)
+		if(vi < (int)nv && c->voices[vi].recs.empty()) {
+			A2DRun z = { 0, 0 };
+			sc_idx.push_back(vi);
+			sc_val.push_back(z);
+		}
+	c->prev_with_recs.clear();
 	if(int r = grow(c, c->d_recs, recs.size() + 1, 1, false)) return r;
-	if(nv)
-		HIPCHK(c, hipMemcpyAsync(c->d_runs.d, runs.data(), nv * sizeof(A2DRun), hipMemcpyHostToDevice, c->stream));
 	if(!recs.empty())
 		HIPCHK(c, hipMemcpyAsync(c->d_recs.d, recs.data(), recs.size() * sizeof(A2DRec),
 				hipMemcpyHostToDevice, c->stream));
+	if(!sc_idx.empty()) {
+		const size_t k = sc_idx.size();
+		if(int r = grow(c, c->d_scatter, 3 * k, 1, false)) return r;
+		HIPCHK(c, hipMemcpyAsync(c->d_scatter.d, sc_idx.data(), k * sizeof(int), hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipMemcpyAsync(c->d_scatter.d + k, sc_val.data(), k * sizeof(A2DRun), hipMemcpyHostToDevice, c->stream));
+		if(a2d_launch_scatter_runs(c->d_scatter.d, (const A2DRun *)(c->d_scatter.d + k), (int)k, c->d_runs.d, c->stream))
+			return c->fail(A2AMD_EHIP, "scatter launch failed");
+	}
 	c->stats.records += recs.size();
 
-	// Launch lists, rebuilt per batch because "quiet" is a per-batch property:
-	//   leaves: [fast wtosc->panmix | general]   (each sorted by output bus so a
-	//           wavefront can sum several voices before touching the bus)
-	//   voices with an inline unit, per nesting depth: [fast driver chain | general]
-	{
+	// Launch lists.  Static part, rebuilt when the voice tree changes: every
+	// listed voice by class -
+	//   leaves: [wtosc-panmix | wtosc-filter12-panmix | general]  (each sorted by
+	//           output bus so a wavefront can sum several voices before touching it)
+	//   voices with an inline unit, per nesting depth: [driver chain | general]
+	// The fast kernels skip a voice whose runs[] entry is non-zero; those voices
+	// form the dynamic part (this batch's exceptions) and go to the general kernel.
+	if(c->lists_dirty) {
 		std::vector<int> fast_leaf, filt_leaf, gen_leaf;
 		std::map<int, std::pair<std::vector<int>, std::vector<int>>> bydepth;
 		int maxdepth = -1;
 		for(size_t vi = 0; vi < nv; ++vi) {
-			const HVoice &v = c->voices[vi];
+			HVoice &v = c->voices[vi];
 			// voices that died during this batch still render up to their
 			// R_KILL record
-			if(!(v.live || v.dying) || !v.resolved)
+			if(!(v.live || v.dying) || !v.resolved) {
+				v.cls = -1;
 				continue;
-			const bool quiet = v.live && !v.dying && v.started && v.recs.empty() && !c->no_fast;
+			}
 			if(v.inline_pos >= 0) {
 				auto &d = bydepth[v.depth];
-				(quiet && is_driver_chain(c, v) ? d.first : d.second).push_back((int)vi);
+				v.cls = !(c->no_fast & 4) && is_driver_chain(c, v) ? CLS_BUSDRIVER : CLS_BUSGENERIC;
+				(v.cls == CLS_BUSDRIVER ? d.first : d.second).push_back((int)vi);
 				maxdepth = std::max(maxdepth, v.depth);
-			} else
-				(quiet && is_oscpan_chain(c, v) ? fast_leaf :
-				 quiet && is_oscfiltpan_chain(c, v) ? filt_leaf : gen_leaf).push_back((int)vi);
+			} else {
+				v.cls = !(c->no_fast & 1) && is_oscpan_chain(c, v) ? CLS_OSCPAN :
+						!(c->no_fast & 2) && is_oscfiltpan_chain(c, v) ? CLS_OSCFILTPAN : CLS_GENERIC;
+				(v.cls == CLS_OSCPAN ? fast_leaf : v.cls == CLS_OSCFILTPAN ? filt_leaf : gen_leaf).push_back((int)vi);
+			}
 		}
 		auto by_bus = [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; };
 		std::stable_sort(fast_leaf.begin(), fast_leaf.end(), by_bus);
@@ -521,11 +581,43 @@ int upload(a2amd_ctx *c)
 			r.gen_count = (int)l.second.size();
 			c->list_all.insert(c->list_all.end(), l.second.begin(), l.second.end());
 		}
-		if(int r = grow(c, c->d_list, c->list_all.size() + 1, 1, false)) return r;
+		c->static_len = (int)c->list_all.size();
+		if(int r = grow(c, c->d_list, 2 * c->list_all.size() + 64, 1, false)) return r;
 		if(!c->list_all.empty())
 			HIPCHK(c, hipMemcpyAsync(c->d_list.d, c->list_all.data(), c->list_all.size() * sizeof(int),
 					hipMemcpyHostToDevice, c->stream));
 		c->lists_dirty = false;
+	}
+	{
+		// this batch's exceptions, behind the static lists
+		std::vector<int> dyn_leaf;
+		std::vector<std::vector<int>> dyn_bus(c->depth_ranges.size());
+		for(int vi : c->with_recs) {
+			const HVoice &v = c->voices[vi];
+			if(v.cls == CLS_OSCPAN || v.cls == CLS_OSCFILTPAN)
+				dyn_leaf.push_back(vi);
+			else if(v.cls == CLS_BUSDRIVER && v.depth < (int)dyn_bus.size())
+				dyn_bus[v.depth].push_back(vi);
+		}
+		std::stable_sort(dyn_leaf.begin(), dyn_leaf.end(),
+				[&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; });
+		std::vector<int> dyn = dyn_leaf;
+		c->n_leaf_dyn = (int)dyn_leaf.size();
+		for(size_t d = 0; d < dyn_bus.size(); ++d) {
+			c->depth_ranges[d].dyn_first = c->static_len + (int)dyn.size();
+			c->depth_ranges[d].dyn_count = (int)dyn_bus[d].size();
+			dyn.insert(dyn.end(), dyn_bus[d].begin(), dyn_bus[d].end());
+		}
+		if((size_t)c->static_len + dyn.size() > c->d_list.cap) {
+			// rare: more exceptions than listed voices; re-upload everything
+			if(int r = grow(c, c->d_list, c->static_len + 2 * dyn.size() + 64, 1, false)) return r;
+			if(c->static_len)
+				HIPCHK(c, hipMemcpyAsync(c->d_list.d, c->list_all.data(), c->static_len * sizeof(int),
+						hipMemcpyHostToDevice, c->stream));
+		}
+		if(!dyn.empty())
+			HIPCHK(c, hipMemcpyAsync(c->d_list.d + c->static_len, dyn.data(), dyn.size() * sizeof(int),
+					hipMemcpyHostToDevice, c->stream));
 	}
 
 	A2DParams p;
@@ -596,6 +688,11 @@ int launch_depth(a2amd_ctx *c, int d)
 			return c->fail(A2AMD_EHIP, "bus launch failed: %s", hipGetErrorString(hipGetLastError()));
 		++c->stats.launches;
 	}
+	if(r.dyn_count) {
+		if(a2d_launch_voices(c->d_params, c->d_list.d + r.dyn_first, r.dyn_count, 1, c->stream))
+			return c->fail(A2AMD_EHIP, "bus launch failed: %s", hipGetErrorString(hipGetLastError()));
+		++c->stats.launches;
+	}
 	return 0;
 }
 
@@ -611,9 +708,13 @@ void end_batch(a2amd_ctx *c)
 	// Records made after the last fragment of the batch was closed belong to
 	// the first fragment of the next batch: carry them over.
 	const int done = c->nfrags;
+	c->serial_base += done;
 	c->touched_list.clear();
-	for(size_t vi = 0; vi < c->voices.size(); ++vi) {
+	std::vector<int> carry;
+	c->prev_with_recs.clear();
+	for(int vi : c->with_recs) {
 		HVoice &v = c->voices[vi];
+		c->prev_with_recs.push_back(vi);
 		size_t keep = 0;
 		// (a voice that was set up but not walked yet keeps everything)
 		const bool unborn = v.live && !v.resolved;
@@ -627,16 +728,19 @@ void end_batch(a2amd_ctx *c)
 		v.recs.resize(keep);
 		v.frag_mark = 0;
 		if(keep) {
-			v.touched = 0;
-			c->touched_list.push_back((int)vi);
-		} else
+			v.touched = c->serial_base;
+			c->touched_list.push_back(vi);
+			carry.push_back(vi);
+		} else {
 			v.touched = -1;
+			v.listed_recs = false;
+		}
 	}
+	c->with_recs = carry;
 	for(int vi : c->deferred_free_voices) {
 		c->voices[vi] = HVoice();
 		c->free_voices.push_back(vi);
 		c->lists_dirty = true;
-		c->voices_dirty = true;
 	}
 	c->deferred_free_voices.clear();
 	for(int ui : c->deferred_free_units)
@@ -653,7 +757,6 @@ void end_batch(a2amd_ctx *c)
 	c->frag_open = false;
 	c->uploaded = false;
 }
-
 
 // the kernels of one batch, in stream order; e* may be null
 int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2)
@@ -681,6 +784,12 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		if(c->n_leaf) {
 			if(a2d_launch_voices(c->d_params, c->d_list.d + c->n_fast_leaf + c->n_filt_leaf, c->n_leaf,
 					pick_vpw(c->n_leaf), c->stream))
+				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+			++c->stats.launches;
+		}
+		if(c->n_leaf_dyn) {
+			if(a2d_launch_voices(c->d_params, c->d_list.d + c->static_len, c->n_leaf_dyn,
+					pick_vpw(c->n_leaf_dyn), c->stream))
 				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
@@ -769,7 +878,7 @@ int a2amd_open(const a2amd_config *cfg, a2amd_ctx **out)
 		c->cfg.max_batch = A2D_MAXBATCH;
 	memset(&c->stats, 0, sizeof(c->stats));
 	build_pitch_table(c->ptab);
-	c->no_fast = getenv("A2AMD_NO_FAST") && atoi(getenv("A2AMD_NO_FAST"));
+	c->no_fast = getenv("A2AMD_NO_FAST") ? atoi(getenv("A2AMD_NO_FAST")) : 0;
 	c->bus_stride_frames = (size_t)c->cfg.max_batch * A2D_FRAG;
 	c->bus_used = c->bus_stride_frames * (size_t)c->cfg.channels;	// master bus at offset 0
 #define OPENCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
@@ -806,7 +915,7 @@ void a2amd_close(a2amd_ctx *c)
 	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
 	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
 	hipFree(c->d_waves.d); hipFree(c->d_wavepool.d); hipFree(c->d_busmem.d);
-	hipFree(c->d_fbdmem.d); hipFree(c->d_list.d); hipFree(c->d_ptab); hipFree(c->d_params);
+	hipFree(c->d_fbdmem.d); hipFree(c->d_list.d); hipFree(c->d_scatter.d); hipFree(c->d_ptab); hipFree(c->d_params);
 	if(c->h_master)
 		hipHostFree(c->h_master);
 	for(hipEvent_t e : c->ev_pool)
@@ -1003,6 +1112,7 @@ int a2amd_unit_init(a2amd_ctx *c, uint64_t key, int kind, unsigned flags, int ni
 	c->mudesc[ui] = A2D_DESC(kind, add ? 1 : 0, nin, nout, wired ? 1 : 0);
 	c->udesc_dirty = true;
 	c->voices_dirty = true;
+	c->dirty_voices.push_back(vi);
 	++c->stats.live_units;
 
 	int initval = 0;

@@ -123,19 +123,24 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # A2AMD_BENCH_FORCE_DIST=1: take the multi-rank code path (torch stream,
+    # phase-split render, RCCL reduce of the root bus) even with one rank
+    multi = world > 1 or os.environ.get("A2AMD_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
     import audiality2_amd
-    from audiality2_amd import synth
+    from audiality2_amd import shard, synth
     from audiality2_amd.replay import Backend
 
     B = args.batch
     # N=1: the library launches on its own stream and replays the steady-state
     # step from a hipGraph.  N>1: everything (kernels and the RCCL reduce) is
     # ordered on one torch stream.
-    tstream = torch.cuda.Stream(device=local_rank) if world > 1 else None
+    tstream = torch.cuda.Stream(device=local_rank) if multi else None
     if tstream is not None:
         torch.cuda.set_stream(tstream)
     be = audiality2_amd.open_backend(48000, None, 2, device=local_rank, max_batch=B,
@@ -150,7 +155,7 @@ def main():
     # ---- build the voice tree; every rank plays different voices -----------
     sc = synth.Scene(be)
     sc.root()
-    sc.nvoices = rank * args.voices
+    sc.nvoices = shard.voice_range(rank, args.voices)[0]
     sc.add_voices(args.voices, chain=args.chain, total=args.voices * world)
 
     def repeat(n):
@@ -183,38 +188,35 @@ def main():
     be.render(0, phases=UP | KEEP)
 
     rootbus = None
-    if world > 1:
+    if multi:
         ptr, nbytes = ctypes.c_void_p(), ctypes.c_uint64()
         if lib.a2amd_rootbus(be.ctx, ctypes.byref(ptr), ctypes.byref(nbytes)):
             raise RuntimeError(be._err(be.ctx))
 
-        class _Wrap:
-            __cuda_array_interface__ = {"shape": (nbytes.value // 4,), "typestr": "<i4",
-                                        "data": (ptr.value, False), "version": 2}
-        rootbus = torch.as_tensor(_Wrap(), device=torch.device("cuda", local_rank))
+        rootbus = shard.wrap_device_bus(ptr.value, nbytes.value, torch.device("cuda", local_rank))
 
     def run(nsteps):
-        if world == 1:
+        if not multi:
             if lib.a2amd_replay(be.ctx, nsteps):
                 raise RuntimeError(be._err(be.ctx))
             return
         for _ in range(nsteps):
             be.render(0, phases=SUB | KEEP)
-            dist.reduce(rootbus, dst=0, op=dist.ReduceOp.SUM)
+            shard.reduce_root_bus(rootbus, dst=0)
             if rank == 0:
                 be.render(0, phases=ROOTP | KEEP)
 
     run(args.warmup)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -227,8 +229,8 @@ def main():
     st = Stats()
     lib.a2amd_get_stats(be.ctx, ctypes.byref(st))
     lib.a2amd_set_profiling(be.ctx, 0)
-    last = be.render(B * 64, phases=RB) if (world == 1 or rank == 0) else None
-    if world > 1 and rank != 0:
+    last = be.render(B * 64, phases=RB) if rank == 0 else None
+    if rank != 0:
         be.render(0, phases=ROOTP)      # close the batch on the other ranks
 
     if rank == 0:
@@ -246,7 +248,7 @@ def main():
                                    f"configs[1]), 48 kHz, fragment=64, stereo",
                        "voices_per_gpu": args.voices, "chain": args.chain, "fragments_per_step": B,
                        "samplerate": 48000, "sharding": "voice subtrees per GPU + 1 RCCL int32 reduce "
-                       "of the root bus per step" if world > 1 else "single GPU"},
+                       "of the root bus per step" if multi else "single GPU"},
             "realtime_factor": value / (args.voices * world * 48000.0),
             "max_realtime_voices_at_this_rate": int(value / 48000.0),
             "parity_vs_oracle": parity,
@@ -266,7 +268,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.voices, args.chain)
         print(json.dumps(line))
     be.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -114,6 +114,38 @@ def test_fragment_repeat_equals_explicit_walk(oracle_lib):
     assert first_diff(np.concatenate([first, rest], axis=1), want) is None
 
 
+def test_mixed_quiet_and_active_voices_across_batches(oracle_lib):
+    """Voices move between the fast kernels (quiet, settled), their per-fragment
+    path (ramps in flight) and the general kernel (records this batch) from one
+    64-fragment batch to the next; time-sliced launches must not disturb the
+    state of voices they skip."""
+    outs = []
+    for be in (make_gpu(max_batch=64), make_oracle(oracle_lib)):
+        sc = synth.Scene(be)
+        sc.root()
+        sc.add_voices(150, chain="osc-pan", total=256)
+        sc.add_voices(106, chain="osc-filter-pan", total=256)
+        rng = np.random.default_rng(11)
+        chunks = []
+        for batch in range(4):
+            for f in range(64):
+                if f in (0, 5, 33) and batch > 0:
+                    for k in rng.choice(256, 40, replace=False):
+                        units = sc.leaves[k]
+                        dur = int(rng.choice([0, 3000, 40000, 900000]))
+                        be.unit_write(units[0], 1, synth.fix(float(rng.uniform(-2, 2))), 17, dur)   # p
+                        be.unit_write(units[0], 2, synth.fix(float(rng.uniform(0, .05))), 0, dur)   # a
+                        be.unit_write(units[-1], 1, synth.fix(float(rng.uniform(-1.5, 1.5))), 200, dur)  # pan
+                        if len(units) == 3:
+                            be.unit_write(units[1], 1, synth.fix(float(rng.uniform(1, 9))), 0, dur)  # q
+                            be.unit_write(units[1], 0, synth.fix(float(rng.uniform(0, 4))), 0, dur)  # cutoff
+                sc.walk(64)
+            chunks.append(be.render(64 * 64))
+        outs.append(np.concatenate(chunks, axis=1))
+        be.close()
+    assert first_diff(outs[0], outs[1]) is None
+
+
 def test_linearity_at_full_size():
     """Size-independent property at BASELINE size (16384 voices, config 3
     shape would take the oracle minutes): the bus is a wrap-around sum, so the
