@@ -930,7 +930,7 @@ void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list
 }
 
 int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
-		int vpw, int ysplit, int *ustage, void *stream)
+		int vpw, int ysplit, int *ustage, void *stream, void *event_after_main)
 {
 	if(nlist <= 0)
 		return 0;
@@ -942,6 +942,8 @@ int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const 
 	hipLaunchKernelGGL(k_leaf_oscpan, dim3(nblocks, ysplit), dim3(64 * FAST_WPB), 0, (hipStream_t)stream,
 			dparams, dlist, nlist, vpw, ysplit, hp.voices, (const int *)hp.ustate,
 			ysplit > 1 ? ustage : hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
+	if(event_after_main)
+		hipEventRecord((hipEvent_t)event_after_main, (hipStream_t)stream);
 	if(ysplit > 1)
 		hipLaunchKernelGGL(k_commit_oscpan, dim3((nlist * 16 + 255) / 256), dim3(256), 0,
 				(hipStream_t)stream, dlist, nlist, hp.voices, hp.runs, hp.ustate, (const int *)ustage);

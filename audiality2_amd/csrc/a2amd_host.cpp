@@ -768,8 +768,11 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		if(c->n_fast_leaf) {
 			int vpw, ysplit;
 			pick_fast_shape(c->n_fast_leaf, c->nfrags, &vpw, &ysplit);
+			// e1 right behind the main kernel when it is the only leaf kernel
+			// of the batch: "leaf" time is then that kernel alone
+			const bool solo = !c->n_filt_leaf && !c->n_leaf && !c->n_leaf_dyn;
 			if(a2d_launch_leaf_oscpan(c->d_params, c->hparams, c->d_list.d, c->n_fast_leaf,
-					vpw, ysplit, c->d_ustage.d, c->stream))
+					vpw, ysplit, c->d_ustage.d, c->stream, solo ? (void *)e1 : nullptr))
 				return c->fail(A2AMD_EHIP, "fast leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
@@ -793,7 +796,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
-		if(e1)
+		if(e1 && !(c->n_fast_leaf && !c->n_filt_leaf && !c->n_leaf && !c->n_leaf_dyn))
 			HIPCHK(c, hipEventRecord(e1, c->stream));
 		for(int d = (int)c->depth_ranges.size() - 1; d >= 1; --d)
 			if(int r = launch_depth(c, d))
