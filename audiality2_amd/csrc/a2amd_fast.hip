@@ -51,31 +51,29 @@ DEV int hermite4(int dm, int d0, int d1, int d2, int frac)
 	return d0 + (__mul24(a + c, x) >> 15);
 }
 
-// Both taps of wtosc_Inter (wtosc.c:28-33) from the three dwords that hold
-// d[i-1 .. i+3] (+1 spare), 'odd' = the window starts in the upper half of w0.
-// The second tap is at most one sample further (dph16 <= 512 << 8).
-DEV int inter_from_dwords(uint32_t w0, uint32_t w1, uint32_t w2, unsigned odd, unsigned ph, unsigned dph16)
+// Four consecutive int16 samples as two dwords from a 2-byte aligned address
+// (gfx950 global loads take any byte alignment in the HSA configuration).
+struct __attribute__((packed, aligned(2))) Quad16 { uint32_t lo, hi; };
+
+// Both taps of wtosc_Inter (wtosc.c:28-33): window A = d[i-1 .. i+2] for the tap
+// at ph, window B = d[i'-1 .. i'+2] for the tap at ph + (dph16 >> 1), i' being i
+// or i + 1 (dph16 <= 512 << 8).  Each window is one 8 byte load.
+DEV int inter_quads(const Quad16 qa, const Quad16 qb, unsigned ph, unsigned ph2)
 {
-	unsigned ph2 = ph + (dph16 >> 1);
-	bool up = (ph2 >> 8) != (ph >> 8);
-	uint32_t x0 = odd ? __builtin_amdgcn_alignbit(w1, w0, 16) : w0;	// dm | d0 << 16
-	uint32_t x1 = odd ? __builtin_amdgcn_alignbit(w2, w1, 16) : w1;	// d1 | d2 << 16
-	int dm = (int16_t)(x0 & 0xffff), d0 = (int)x0 >> 16;
-	int d1 = (int16_t)(x1 & 0xffff), d2 = (int)x1 >> 16;
-	int d3 = odd ? ((int)w2 >> 16) : (int)(int16_t)(w2 & 0xffff);
-	int h0 = hermite4(dm, d0, d1, d2, (int)(ph & 0xff));
-	int s0 = up ? d0 : dm, s1 = up ? d1 : d0, s2 = up ? d2 : d1, s3 = up ? d3 : d2;
-	return h0 + hermite4(s0, s1, s2, s3, (int)(ph2 & 0xff));
+	int h0 = hermite4((int16_t)(qa.lo & 0xffff), (int)qa.lo >> 16, (int16_t)(qa.hi & 0xffff), (int)qa.hi >> 16,
+			(int)(ph & 0xff));
+	int h1 = hermite4((int16_t)(qb.lo & 0xffff), (int)qb.lo >> 16, (int16_t)(qb.hi & 0xffff), (int)qb.hi >> 16,
+			(int)(ph2 & 0xff));
+	return h0 + h1;
 }
 
-// wtosc_Inter at 24:8 phase ph from wave data d (first payload sample): the
-// five samples d[i-1 .. i+3] serve both taps and come in as three aligned dwords.
+// wtosc_Inter at 24:8 phase ph from wave data d (first payload sample)
 DEV int inter_dwords(const int16_t *d, unsigned ph, unsigned dph16)
 {
-	const int16_t *q = d + ((int)(ph >> 8) - 1);
-	unsigned odd = (unsigned)(((uintptr_t)q) >> 1) & 1u;
-	const uint32_t *a = (const uint32_t *)(q - odd);
-	return inter_from_dwords(a[0], a[1], a[2], odd, ph, dph16);
+	const unsigned ph2 = ph + (dph16 >> 1);
+	const Quad16 qa = *(const Quad16 *)(d + (int)(ph >> 8) - 1);
+	const Quad16 qb = *(const Quad16 *)(d + (int)(ph2 >> 8) - 1);
+	return inter_quads(qa, qb, ph, ph2);
 }
 
 // ---- cold paths: kept out of line so the hot loop stays small -------------
@@ -420,21 +418,19 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 			// in flight together (lanes past a short fragment read inside the
 			// A2_WAVEPOST pad and are masked at the sum)
 			const uint64_t lanedph = (uint64_t)(unsigned)lane * dph;
-			const uint32_t *wp32 = (const uint32_t *)wavepool;	// pool base is dword aligned
-			uint32_t w0[FAST_FCH], w1[FAST_FCH], w2[FAST_FCH];
-			unsigned ph16[FAST_FCH], odd[FAST_FCH];
+			const int16_t *dbase = wavepool + doff;
+			Quad16 qa[FAST_FCH], qb[FAST_FCH];
+			unsigned ph16[FAST_FCH], ph2[FAST_FCH];
 #pragma unroll
 			for(int j = 0; j < FAST_FCH; ++j) {
 				ph16[j] = (unsigned)((phs[j] + lanedph) >> 16);
-				unsigned e = doff + (ph16[j] >> 8) - 1u;	// int16 index of d[i-1]
-				odd[j] = e & 1u;
-				const uint32_t *ap = wp32 + (e >> 1);
-				w0[j] = ap[0]; w1[j] = ap[1]; w2[j] = ap[2];
+				ph2[j] = ph16[j] + (dph16 >> 1);
+				qa[j] = *(const Quad16 *)(dbase + (int)(ph16[j] >> 8) - 1);
+				qb[j] = *(const Quad16 *)(dbase + (int)(ph2[j] >> 8) - 1);
 			}
 #pragma unroll
 			for(int j = 0; j < FAST_FCH; ++j) {
-				int sm = (dbg & 2) ? (int)ph16[j] :
-						inter_from_dwords(w0[j], w1[j], w2[j], odd[j], ph16[j], dph16);
+				int sm = (dbg & 2) ? (int)ph16[j] : inter_quads(qa[j], qb[j], ph16[j], ph2[j]);
 				int x = mul64s(sm, amp, 17);
 				x = (lane < nfr[j]) ? x : 0;
 				acc0[j] = wadd(acc0[j], mul64s(x, v0, 24));
@@ -667,7 +663,6 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		}
 		dv[DV_SETTLED] = settled ? 1 : 0;
 	}
-	const uint32_t *wp32 = (const uint32_t *)wavepool;
 	unsigned total = 0;	// frames rendered so far
 
 	for(int f = 0; f < nfrags; ++f) {
@@ -682,8 +677,8 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 			// four settled voices at a time: their wave data loads overlap
 			if(v + 3 < nv && (rdl(dv[DV_SETTLED], v) & rdl(dv[DV_SETTLED], v + 1) &
 					rdl(dv[DV_SETTLED], v + 2) & rdl(dv[DV_SETTLED], v + 3))) {
-				uint32_t q0[4], q1[4], q2[4];
-				unsigned qph[4], qodd[4], qd16[4];
+				Quad16 qa[4], qb[4];
+				unsigned qph[4], qph2[4];
 				int qamp[4];
 #pragma unroll
 				for(int k = 0; k < 4; ++k) {
@@ -694,16 +689,15 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 							((uint64_t)(unsigned)rdl(sv[SV_PHHI], vk) << 32);
 					uint64_t ph = wrap_phase((phase >> mm) + (uint64_t)total * dph, sizem);
 					qph[k] = (unsigned)((ph + (uint64_t)(unsigned)lane * dph) >> 16);
-					unsigned e = doff + (qph[k] >> 8) - 1u;
-					qodd[k] = e & 1u;
-					const uint32_t *ap = wp32 + (e >> 1);
-					q0[k] = ap[0]; q1[k] = ap[1]; q2[k] = ap[2];
-					qd16[k] = dph >> 16;
+					qph2[k] = qph[k] + (dph >> 17);
+					const int16_t *dbase = wavepool + doff;
+					qa[k] = *(const Quad16 *)(dbase + (int)(qph[k] >> 8) - 1);
+					qb[k] = *(const Quad16 *)(dbase + (int)(qph2[k] >> 8) - 1);
 					qamp[k] = rdl(sv[SV_A], vk);
 				}
 #pragma unroll
 				for(int k = 0; k < 4; ++k) {
-					int sm = inter_from_dwords(q0[k], q1[k], q2[k], qodd[k], qph[k], qd16[k]);
+					int sm = inter_quads(qa[k], qb[k], qph[k], qph2[k]);
 					int xk = mul64s(sm, qamp[k], 17);
 					tile[(v + k) * FILT_PITCH + lane] = (lane < n) ? xk : 0;
 				}
@@ -719,9 +713,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 				// start of fragment f = ((phase >> mm) + frames_before * dph) mod (size << 24)
 				uint64_t ph = wrap_phase((phase >> mm) + (uint64_t)total * dph, sizem);
 				unsigned ph16 = (unsigned)((ph + (uint64_t)(unsigned)lane * dph) >> 16);
-				unsigned e = doff + (ph16 >> 8) - 1u;
-				const uint32_t *ap = wp32 + (e >> 1);
-				int sm = inter_from_dwords(ap[0], ap[1], ap[2], e & 1u, ph16, dph >> 16);
+				int sm = inter_dwords(wavepool + doff, ph16, dph >> 16);
 				x = mul64s(sm, amp, 17);
 			} else {
 				OscS o;

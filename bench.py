@@ -237,6 +237,12 @@ def main():
         vs_per_step = float(args.voices) * world * B * 64
         value = vs_per_step * args.steps / dt
         leaf_ms = st.timed_leaf_ms / max(st.timed_batches, 1)
+        traffic = None      # HBM bytes per launch from PMC counters (profiles/README.md), if collected
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f).get(f"{args.chain}/{args.voices}/{B}", {}).get("hbm_bytes_per_launch")
+        except OSError:
+            pass
         bpvs = BYTES_PER_VOICE_SAMPLE[args.chain]
         achieved = bpvs * args.voices * B * 64 / (leaf_ms * 1e-3) / 1e9 if leaf_ms > 0 else None
         line = {
@@ -253,7 +259,8 @@ def main():
             "max_realtime_voices_at_this_rate": int(value / 48000.0),
             "parity_vs_oracle": parity,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bpvs * args.voices * B * 64,
                          "kernel": {"osc-pan": "k_leaf_oscpan", "osc-filter-pan": "k_leaf_oscfiltpan"}.get(
                              args.chain, "k_voices (leaf launch)"),
                          "avg_launch_ms": leaf_ms,
