@@ -120,3 +120,5 @@ int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, co
 		int vpw, void *stream);
 // runs[idx[i]] = val[i] for the few voices whose record run changed this batch
 int a2d_launch_scatter_runs(const int *didx, const A2DRun *dval, int n, A2DRun *druns, void *stream);
+int a2d_launch_leaf_osc2pan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
+		int vpw, int ysplit, int *ustage, void *stream);

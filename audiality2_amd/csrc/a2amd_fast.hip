@@ -248,11 +248,12 @@ DEV int frames_of(const int (&ffr)[A2D_MAXBATCH / 64], int f)
 }
 
 // add the register sums of a chunk of fragments into the bus and clear them
+template<int N>
 DEV void flush_acc(int *busmem, int off, int nch, int f0, int nf, int lane, int dbg,
-		int (&acc0)[FAST_FCH], int (&acc1)[FAST_FCH])
+		int (&acc0)[N], int (&acc1)[N])
 {
 #pragma unroll
-	for(int j = 0; j < FAST_FCH; ++j) {
+	for(int j = 0; j < N; ++j) {
 		if(j < nf && off >= 0 && !(dbg & 1)) {
 			int *dst = busmem + off + (size_t)(f0 + j) * nch * A2D_FRAG;
 			if(acc0[j])
@@ -532,24 +533,300 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	}
 }
 
-// staged state of the fast leaf voices -> the unit state array
-__global__ void k_commit_oscpan(const int *__restrict__ list, int nlist, const A2DVoice *__restrict__ voices,
-		const A2DRun *__restrict__ runs, int *__restrict__ ustate, const int *__restrict__ ustage)
+// staged state of the fast leaf voices (nosc oscillators + panmix) -> the unit
+// state array
+__global__ void k_commit_oscpan(const int *__restrict__ list, int nlist, int nosc,
+		const A2DVoice *__restrict__ voices, const A2DRun *__restrict__ runs, int *__restrict__ ustate,
+		const int *__restrict__ ustage)
 {
+	const int per = (nosc + 1) * 16;
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if(i >= nlist * 16)
+	if(i >= nlist * per)
 		return;
-	if(runs[list[i >> 4]].count)
-		return;		// not rendered by k_leaf_oscpan this batch: nothing staged
-	const A2DVoice &vc = voices[list[i >> 4]];
-	const int k = i & 15;
-	// the words k_leaf_oscpan stages: wtosc 0..6 (+ p, a = 7..14), panmix 0..7
-	size_t a = (size_t)vc.unit[0] * A2D_USTATE + k;
-	if(k != OW_NOISE && k < 15)
+	const int slot = list[i / per];
+	if(runs[slot].count)
+		return;		// not rendered by the fast kernel this batch: nothing staged
+	const A2DVoice &vc = voices[slot];
+	const int u = (i % per) >> 4, k = i & 15;
+	// the words the kernels stage: wtosc 0..14 except the noise sample, panmix 0..7
+	if(u < nosc ? (k != OW_NOISE && k < 15) : (k < 8)) {
+		size_t a = (size_t)vc.unit[u] * A2D_USTATE + k;
 		ustate[a] = ustage[a];
-	if(k < 8) {
-		size_t b = (size_t)vc.unit[1] * A2D_USTATE + k;
-		ustate[b] = ustage[b];
+	}
+}
+
+// ---------------------------------------------------------------------------
+// wtosc + wtosc -> panmix 1->2: two oscillators summed in the scratch buffer
+// (the second one adding, compiler.c:3125), the BASELINE config 4 leaf
+// ---------------------------------------------------------------------------
+// Same plan as k_leaf_oscpan with the oscillator state doubled; 4 fragments per
+// register chunk keep the 16 window loads of a chunk within the register budget.
+#define OSC2_FCH 4
+enum { OV_MODE = 0, OV_WAVE, OV_DPHASE, OV_PHLO, OV_PHHI, OV_PRAMP, OV_P = 6, OV_A = 10, OV_NWORDS = 14 };
+enum { OD_MM = 0, OD_DPH, OD_SIZEM, OD_DOFF, OD_NWORDS };
+
+DEV void osc_from_lanes(OscS &o, const int (&so)[OV_NWORDS], int v)
+{
+	o.mode = rdl(so[OV_MODE], v);
+	o.wave = rdl(so[OV_WAVE], v);
+	o.dphase = (unsigned)rdl(so[OV_DPHASE], v);
+	o.phase = (uint64_t)(unsigned)rdl(so[OV_PHLO], v) | ((uint64_t)(unsigned)rdl(so[OV_PHHI], v) << 32);
+	o.p_ramping = rdl(so[OV_PRAMP], v);
+	o.p.value = rdl(so[OV_P], v); o.p.target = rdl(so[OV_P + 1], v);
+	o.p.delta = rdl(so[OV_P + 2], v); o.p.timer = rdl(so[OV_P + 3], v);
+	o.a.value = rdl(so[OV_A], v); o.a.target = rdl(so[OV_A + 1], v);
+	o.a.delta = rdl(so[OV_A + 2], v); o.a.timer = rdl(so[OV_A + 3], v);
+}
+
+DEV void osc_to_lanes(int (&so)[OV_NWORDS], const OscS &o, bool me)
+{
+	WRL(so[OV_MODE], o.mode);
+	WRL(so[OV_WAVE], o.wave);
+	WRL(so[OV_DPHASE], (int)o.dphase);
+	WRL(so[OV_PHLO], (int)(unsigned)o.phase);
+	WRL(so[OV_PHHI], (int)(unsigned)(o.phase >> 32));
+	WRL(so[OV_PRAMP], o.p_ramping);
+	WRL(so[OV_P], o.p.value); WRL(so[OV_P + 1], o.p.target);
+	WRL(so[OV_P + 2], o.p.delta); WRL(so[OV_P + 3], o.p.timer);
+	WRL(so[OV_A], o.a.value); WRL(so[OV_A + 1], o.a.target);
+	WRL(so[OV_A + 2], o.a.delta); WRL(so[OV_A + 3], o.a.timer);
+}
+
+__global__ __launch_bounds__(64 * FAST_WPB)
+void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
+		int ysplit, const A2DVoice *__restrict__ voices, const int *ustate, int *ustage,
+		const int16_t *__restrict__ wavepool, const A2DWave *__restrict__ waves,
+		const uint32_t *__restrict__ ptab, int *__restrict__ busmem)
+{
+	const A2DParams &p = *pp;
+	const int wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	const int first = (blockIdx.x * FAST_WPB + wv) * vpw;
+	if(first >= nlist)
+		return;
+	const int nv = min(vpw, nlist - first);
+	const int nfrags = p.nfrags;
+	const int dbg = p.debug;
+	FastPtrs g = { wavepool, waves, ptab, dbg };
+
+	const int nchunks = (nfrags + OSC2_FCH - 1) / OSC2_FCH;
+	const int per = (nchunks + ysplit - 1) / ysplit;
+	const int slice = blockIdx.y;
+	const int c_lo = slice * per, c_hi = min(nchunks, c_lo + per);
+	const bool last_slice = c_hi >= nchunks;
+	if(c_lo >= nchunks)
+		return;
+
+	int ffr[A2D_MAXBATCH / 64], fst[A2D_MAXBATCH / 64];
+#pragma unroll
+	for(int k = 0; k < A2D_MAXBATCH / 64; ++k) {
+		ffr[k] = (k * 64 + lane < nfrags) ? p.fragframes[k * 64 + lane] : 0;
+		fst[k] = (k * 64 + lane < nfrags) ? p.fragstart[k * 64 + lane] : 0;
+	}
+
+	int so[2][OV_NWORDS], sp[8], od[2][OD_NWORDS], v0l = 0, v1l = 0, settled_l = 0;
+	int uu[3] = { 0, 0, 0 }, my_off = -1, my_nch = 2;
+	bool mine = false;
+#pragma unroll
+	for(int o = 0; o < 2; ++o) {
+#pragma unroll
+		for(int k = 0; k < OV_NWORDS; ++k)
+			so[o][k] = 0;
+#pragma unroll
+		for(int k = 0; k < OD_NWORDS; ++k)
+			od[o][k] = 0;
+	}
+#pragma unroll
+	for(int k = 0; k < 8; ++k)
+		sp[k] = 0;
+	if(lane < nv)
+		mine = p.runs[list[first + lane]].count == 0;
+	if(mine) {
+		const A2DVoice &vc = voices[list[first + lane]];
+		my_off = vc.out_off;
+		my_nch = vc.out_nch;
+		bool settled = true;
+#pragma unroll
+		for(int o = 0; o < 2; ++o) {
+			uu[o] = vc.unit[o];
+			const int *w = ustate + (size_t)uu[o] * A2D_USTATE;
+			so[o][OV_MODE] = w[OW_MODE]; so[o][OV_WAVE] = w[OW_WAVE]; so[o][OV_DPHASE] = w[OW_DPHASE];
+			so[o][OV_PHLO] = w[OW_PHASE_LO]; so[o][OV_PHHI] = w[OW_PHASE_HI]; so[o][OV_PRAMP] = w[OW_PRAMPING];
+#pragma unroll
+			for(int k = 0; k < 4; ++k) {
+				so[o][OV_P + k] = w[OW_P + k];
+				so[o][OV_A + k] = w[OW_A + k];
+			}
+			settled = settled && so[o][OV_MODE] == A2D_OSC_MIPWAVE && so[o][OV_DPHASE] && !so[o][OV_PRAMP] &&
+					!(so[o][OV_P + 3] | so[o][OV_P + 2] | so[o][OV_A + 3] | so[o][OV_A + 2]) &&
+					so[o][OV_P] == so[o][OV_P + 1] && so[o][OV_A] == so[o][OV_A + 1];
+		}
+		uu[2] = vc.unit[2];
+		const int *wp = ustate + (size_t)uu[2] * A2D_USTATE;
+#pragma unroll
+		for(int k = 0; k < 8; ++k)
+			sp[k] = wp[k];		// vol ramper, pan ramper
+		settled = settled && !(sp[3] | sp[2] | sp[7] | sp[6]) && sp[0] == sp[1] && sp[4] == sp[5];
+		if(settled) {
+#pragma unroll
+			for(int o = 0; o < 2; ++o) {
+				const A2DWave *w = waves + so[o][OV_WAVE];
+				const unsigned period = w->period, dphase = (unsigned)so[o][OV_DPHASE];
+				unsigned dph = ((dphase + 255) >> 8) * period, mm = 0;	// wtosc.c:250-258
+				for(; (dph > (A2D_MAXPHINC << 8)) && (mm < A2D_MIPS - 1); ++mm)
+					dph >>= 1;
+				dph = (unsigned)(((uint64_t)dphase * period) >> mm);
+				settled = settled && w->size[0] && (w->flags & 0x100u) && dph <= (A2D_MAXPHINC << 16);
+				od[o][OD_MM] = (int)mm;
+				od[o][OD_DPH] = (int)dph;
+				od[o][OD_SIZEM] = (int)w->size[mm];
+				od[o][OD_DOFF] = (int)w->off[mm];
+			}
+			const int vol = sp[0], pan = sp[4];	// panmix_process12 gains (panmix.c:89-104)
+			const int vp = mul64s(pan, vol, 24);
+			v0l = wsub(vol, vp);
+			v1l = wadd(vol, vp);
+			if(pan > 0xffffff || pan < -0xffffff) {
+				int lim = wshl(vol, 1);
+				if(v0l > lim) v0l = lim;
+				if(v1l > lim) v1l = lim;
+			}
+		}
+		settled_l = settled ? 1 : 0;
+	}
+	const unsigned long long unsettled_mask = __ballot(mine && !settled_l);
+
+	// ---- settled voices: this slice's chunks ----
+	for(int c = c_lo; c < c_hi; ++c) {
+		const int f0 = c * OSC2_FCH;
+		const int nf = min((int)OSC2_FCH, nfrags - f0);
+		int acc0[OSC2_FCH], acc1[OSC2_FCH], nfr[OSC2_FCH];
+#pragma unroll
+		for(int j = 0; j < OSC2_FCH; ++j) {
+			acc0[j] = acc1[j] = 0;
+			nfr[j] = (j < nf) ? frames_of(ffr, f0 + j) : 0;
+		}
+		const unsigned before = (unsigned)frames_of(fst, f0);
+		int cur_off = rdl(my_off, 0), cur_nch = rdl(my_nch, 0);
+		for(int v = 0; v < nv; ++v) {
+			if(!rdl(settled_l, v))
+				continue;
+			const int voff = rdl(my_off, v);
+			if(voff != cur_off) {
+				flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+				cur_off = voff;
+				cur_nch = rdl(my_nch, v);
+			}
+			const int v0 = rdl(v0l, v), v1 = rdl(v1l, v);
+			Quad16 qa[2][OSC2_FCH], qb[2][OSC2_FCH];
+			unsigned ph16[2][OSC2_FCH], ph2[2][OSC2_FCH];
+			int amp[2];
+			uint64_t endph[2];
+#pragma unroll
+			for(int o = 0; o < 2; ++o) {
+				const unsigned mm = (unsigned)rdl(od[o][OD_MM], v), dph = (unsigned)rdl(od[o][OD_DPH], v);
+				const unsigned sizem = (unsigned)rdl(od[o][OD_SIZEM], v), doff = (unsigned)rdl(od[o][OD_DOFF], v);
+				amp[o] = rdl(so[o][OV_A], v);
+				const uint64_t phase = (uint64_t)(unsigned)rdl(so[o][OV_PHLO], v) |
+						((uint64_t)(unsigned)rdl(so[o][OV_PHHI], v) << 32);
+				uint64_t ph = (phase >> mm) + (uint64_t)before * dph;
+				const uint64_t lanedph = (uint64_t)(unsigned)lane * dph;
+				const int16_t *dbase = wavepool + doff;
+#pragma unroll
+				for(int j = 0; j < OSC2_FCH; ++j) {
+					ph = wrap_phase(ph, sizem);
+					ph16[o][j] = (unsigned)((ph + lanedph) >> 16);
+					ph2[o][j] = ph16[o][j] + (dph >> 17);
+					qa[o][j] = *(const Quad16 *)(dbase + (int)(ph16[o][j] >> 8) - 1);
+					qb[o][j] = *(const Quad16 *)(dbase + (int)(ph2[o][j] >> 8) - 1);
+					ph += (uint64_t)dph * (unsigned)nfr[j];
+				}
+				endph[o] = ph << mm;
+			}
+#pragma unroll
+			for(int j = 0; j < OSC2_FCH; ++j) {
+				// the second oscillator adds into the scratch buffer (wrap-around)
+				int x = wadd(mul64s(inter_quads(qa[0][j], qb[0][j], ph16[0][j], ph2[0][j]), amp[0], 17),
+						mul64s(inter_quads(qa[1][j], qb[1][j], ph16[1][j], ph2[1][j]), amp[1], 17));
+				x = (lane < nfr[j]) ? x : 0;
+				acc0[j] = wadd(acc0[j], mul64s(x, v0, 24));
+				acc1[j] = wadd(acc1[j], mul64s(x, v1, 24));
+			}
+			if(last_slice && c == c_hi - 1) {
+				const bool me = lane == v;
+#pragma unroll
+				for(int o = 0; o < 2; ++o) {
+					WRL(so[o][OV_PHLO], (int)(unsigned)endph[o]);
+					WRL(so[o][OV_PHHI], (int)(unsigned)(endph[o] >> 32));
+				}
+			}
+		}
+		flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+	}
+
+	// ---- voices with something still moving: slice 0 walks the whole batch ----
+	if(slice == 0 && unsettled_mask) {
+		for(int f0 = 0; f0 < nfrags; f0 += OSC2_FCH) {
+			const int nf = min((int)OSC2_FCH, nfrags - f0);
+			int acc0[OSC2_FCH], acc1[OSC2_FCH];
+#pragma unroll
+			for(int j = 0; j < OSC2_FCH; ++j)
+				acc0[j] = acc1[j] = 0;
+			int cur_off = rdl(my_off, 0), cur_nch = rdl(my_nch, 0);
+			for(int v = 0; v < nv; ++v) {
+				if(!((unsettled_mask >> v) & 1ull))
+					continue;
+				const int voff = rdl(my_off, v);
+				if(voff != cur_off) {
+					flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+					cur_off = voff;
+					cur_nch = rdl(my_nch, v);
+				}
+				OscS oa, ob;
+				Ramp vol, pan;
+				osc_from_lanes(oa, so[0], v);
+				osc_from_lanes(ob, so[1], v);
+				vol.value = rdl(sp[0], v); vol.target = rdl(sp[1], v); vol.delta = rdl(sp[2], v); vol.timer = rdl(sp[3], v);
+				pan.value = rdl(sp[4], v); pan.target = rdl(sp[5], v); pan.delta = rdl(sp[6], v); pan.timer = rdl(sp[7], v);
+				const bool me = lane == v;
+				for(int j = 0; j < nf; ++j) {
+					const int n = frames_of(ffr, f0 + j);
+					int o0 = 0, o1 = 0;
+					int x = osc_fragment_s(g, oa, n, lane);
+					x = wadd(x, osc_fragment_s(g, ob, n, lane));
+					pan_fragment_s(vol, pan, x, n, lane, o0, o1);
+#pragma unroll
+					for(int jj = 0; jj < OSC2_FCH; ++jj)
+						if(jj == j) {
+							acc0[jj] = wadd(acc0[jj], o0);
+							acc1[jj] = wadd(acc1[jj], o1);
+						}
+				}
+				osc_to_lanes(so[0], oa, me);
+				osc_to_lanes(so[1], ob, me);
+				WRL(sp[0], vol.value); WRL(sp[1], vol.target); WRL(sp[2], vol.delta); WRL(sp[3], vol.timer);
+				WRL(sp[4], pan.value); WRL(sp[5], pan.target); WRL(sp[6], pan.delta); WRL(sp[7], pan.timer);
+			}
+			flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+		}
+	}
+
+	if(mine && ((settled_l && last_slice) || (!settled_l && slice == 0))) {
+#pragma unroll
+		for(int o = 0; o < 2; ++o) {
+			int *w = ustage + (size_t)uu[o] * A2D_USTATE;
+			w[OW_MODE] = so[o][OV_MODE]; w[OW_WAVE] = so[o][OV_WAVE]; w[OW_DPHASE] = so[o][OV_DPHASE];
+			w[OW_PHASE_LO] = so[o][OV_PHLO]; w[OW_PHASE_HI] = so[o][OV_PHHI]; w[OW_PRAMPING] = so[o][OV_PRAMP];
+#pragma unroll
+			for(int k = 0; k < 4; ++k) {
+				w[OW_P + k] = so[o][OV_P + k];
+				w[OW_A + k] = so[o][OV_A + k];
+			}
+		}
+		int *wp = ustage + (size_t)uu[2] * A2D_USTATE;
+#pragma unroll
+		for(int k = 0; k < 8; ++k)
+			wp[k] = sp[k];
 	}
 }
 
@@ -937,8 +1214,27 @@ int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const 
 	if(event_after_main)
 		hipEventRecord((hipEvent_t)event_after_main, (hipStream_t)stream);
 	if(ysplit > 1)
-		hipLaunchKernelGGL(k_commit_oscpan, dim3((nlist * 16 + 255) / 256), dim3(256), 0,
-				(hipStream_t)stream, dlist, nlist, hp.voices, hp.runs, hp.ustate, (const int *)ustage);
+		hipLaunchKernelGGL(k_commit_oscpan, dim3((nlist * 32 + 255) / 256), dim3(256), 0,
+				(hipStream_t)stream, dlist, nlist, 1, hp.voices, hp.runs, hp.ustate, (const int *)ustage);
+	return (int)hipGetLastError();
+}
+
+int a2d_launch_leaf_osc2pan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
+		int vpw, int ysplit, int *ustage, void *stream)
+{
+	if(nlist <= 0)
+		return 0;
+	vpw = vpw < 1 ? 1 : (vpw > 64 ? 64 : vpw);
+	if(ysplit < 1 || !ustage)
+		ysplit = 1;
+	int nwaves = (nlist + vpw - 1) / vpw;
+	int nblocks = (nwaves + FAST_WPB - 1) / FAST_WPB;
+	hipLaunchKernelGGL(k_leaf_osc2pan, dim3(nblocks, ysplit), dim3(64 * FAST_WPB), 0, (hipStream_t)stream,
+			dparams, dlist, nlist, vpw, ysplit, hp.voices, (const int *)hp.ustate,
+			ysplit > 1 ? ustage : hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
+	if(ysplit > 1)
+		hipLaunchKernelGGL(k_commit_oscpan, dim3((nlist * 48 + 255) / 256), dim3(256), 0,
+				(hipStream_t)stream, dlist, nlist, 2, hp.voices, hp.runs, hp.ustate, (const int *)ustage);
 	return (int)hipGetLastError();
 }
 

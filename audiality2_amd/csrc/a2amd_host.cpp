@@ -144,7 +144,7 @@ struct HVoice {
 };
 
 struct DepthRange { int fast_first = 0, fast_count = 0, gen_first = 0, gen_count = 0, dyn_first = 0, dyn_count = 0; };
-enum { CLS_GENERIC = 0, CLS_OSCPAN, CLS_OSCFILTPAN, CLS_BUSDRIVER, CLS_BUSGENERIC };
+enum { CLS_GENERIC = 0, CLS_OSCPAN, CLS_OSCFILTPAN, CLS_BUSDRIVER, CLS_BUSGENERIC, CLS_OSC2PAN };
 
 struct HWave {
 	bool live = false;
@@ -193,7 +193,7 @@ struct a2amd_ctx {
 	bool voices_dirty = true, udesc_dirty = true, waves_dirty = true, lists_dirty = true, ptab_dirty = true;
 	std::vector<int> list_all;		// leaf list followed by per-depth lists
 	int n_leaf = 0;
-	int n_fast_leaf = 0, n_filt_leaf = 0;	// list_all = [wtosc-panmix | wtosc-filter12-panmix | general leaves | per depth ...]
+	int n_fast_leaf = 0, n_osc2_leaf = 0, n_filt_leaf = 0;	// list_all = [wtosc-panmix | wtosc-filter12-panmix | general leaves | per depth ...]
 	std::vector<DepthRange> depth_ranges;	// index = depth
 	int no_fast = 0;			// A2AMD_NO_FAST bit mask: 1 wtosc-panmix, 2 wtosc-filter12-panmix, 4 driver chains -> general kernel (debugging / A-B tests)
 
@@ -410,6 +410,20 @@ bool is_oscpan_chain(const a2amd_ctx *c, const HVoice &v)
 			(pm.flags & A2AMD_PROCADD);
 }
 
+// wtosc (replacing) + wtosc (adding) -> panmix 1->2 adding into the output bus
+bool is_osc2pan_chain(const a2amd_ctx *c, const HVoice &v)
+{
+	if(v.nunits != 3 || v.out_nch < 2)
+		return false;
+	const HUnit &a = c->units[v.unit[0]], &b = c->units[v.unit[1]], &pm = c->units[v.unit[2]];
+	return a.kind == A2AMD_WTOSC && !(a.flags & A2AMD_PROCADD) && !a.wired &&
+			(a.mode == A2D_OSC_MIPWAVE || a.mode == A2D_OSC_OFF) &&
+			b.kind == A2AMD_WTOSC && (b.flags & A2AMD_PROCADD) && !b.wired &&
+			(b.mode == A2D_OSC_MIPWAVE || b.mode == A2D_OSC_OFF) &&
+			pm.kind == A2AMD_PANMIX && pm.nin == 1 && pm.nout == 2 && pm.wired &&
+			(pm.flags & A2AMD_PROCADD);
+}
+
 // wtosc -> filter12 (1 channel, replacing) -> panmix 1->2 adding into the output bus
 bool is_oscfiltpan_chain(const a2amd_ctx *c, const HVoice &v)
 {
@@ -538,7 +552,7 @@ int upload(a2amd_ctx *c)
 	// The fast kernels skip a voice whose runs[] entry is non-zero; those voices
 	// form the dynamic part (this batch's exceptions) and go to the general kernel.
 	if(c->lists_dirty) {
-		std::vector<int> fast_leaf, filt_leaf, gen_leaf;
+		std::vector<int> fast_leaf, osc2_leaf, filt_leaf, gen_leaf;
 		std::map<int, std::pair<std::vector<int>, std::vector<int>>> bydepth;
 		int maxdepth = -1;
 		for(size_t vi = 0; vi < nv; ++vi) {
@@ -556,16 +570,21 @@ int upload(a2amd_ctx *c)
 				maxdepth = std::max(maxdepth, v.depth);
 			} else {
 				v.cls = !(c->no_fast & 1) && is_oscpan_chain(c, v) ? CLS_OSCPAN :
+						!(c->no_fast & 8) && is_osc2pan_chain(c, v) ? CLS_OSC2PAN :
 						!(c->no_fast & 2) && is_oscfiltpan_chain(c, v) ? CLS_OSCFILTPAN : CLS_GENERIC;
-				(v.cls == CLS_OSCPAN ? fast_leaf : v.cls == CLS_OSCFILTPAN ? filt_leaf : gen_leaf).push_back((int)vi);
+				(v.cls == CLS_OSCPAN ? fast_leaf : v.cls == CLS_OSC2PAN ? osc2_leaf :
+				 v.cls == CLS_OSCFILTPAN ? filt_leaf : gen_leaf).push_back((int)vi);
 			}
 		}
 		auto by_bus = [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; };
 		std::stable_sort(fast_leaf.begin(), fast_leaf.end(), by_bus);
 		std::stable_sort(gen_leaf.begin(), gen_leaf.end(), by_bus);
 		std::stable_sort(filt_leaf.begin(), filt_leaf.end(), by_bus);
+		std::stable_sort(osc2_leaf.begin(), osc2_leaf.end(), by_bus);
 		c->list_all = fast_leaf;
 		c->n_fast_leaf = (int)fast_leaf.size();
+		c->list_all.insert(c->list_all.end(), osc2_leaf.begin(), osc2_leaf.end());
+		c->n_osc2_leaf = (int)osc2_leaf.size();
 		c->list_all.insert(c->list_all.end(), filt_leaf.begin(), filt_leaf.end());
 		c->n_filt_leaf = (int)filt_leaf.size();
 		c->list_all.insert(c->list_all.end(), gen_leaf.begin(), gen_leaf.end());
@@ -594,7 +613,7 @@ int upload(a2amd_ctx *c)
 		std::vector<std::vector<int>> dyn_bus(c->depth_ranges.size());
 		for(int vi : c->with_recs) {
 			const HVoice &v = c->voices[vi];
-			if(v.cls == CLS_OSCPAN || v.cls == CLS_OSCFILTPAN)
+			if(v.cls == CLS_OSCPAN || v.cls == CLS_OSCFILTPAN || v.cls == CLS_OSC2PAN)
 				dyn_leaf.push_back(vi);
 			else if(v.cls == CLS_BUSDRIVER && v.depth < (int)dyn_bus.size())
 				dyn_bus[v.depth].push_back(vi);
@@ -657,7 +676,7 @@ int upload(a2amd_ctx *c)
 void pick_fast_shape(int n, int nfrags, int *vpw, int *ysplit)
 {
 	const int nchunks = (nfrags + 7) / 8;
-	int y = getenv("A2AMD_YSPLIT") ? atoi(getenv("A2AMD_YSPLIT")) : 8;
+	int y = getenv("A2AMD_YSPLIT") ? atoi(getenv("A2AMD_YSPLIT")) : 32;
 	y = std::min(std::max(y, 1), nchunks);
 	int v = getenv("A2AMD_VPW") ? atoi(getenv("A2AMD_VPW")) :
 			std::min(std::max((int)(((long long)n * y + 4095) / 4096), 4), 32);
@@ -770,22 +789,30 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			pick_fast_shape(c->n_fast_leaf, c->nfrags, &vpw, &ysplit);
 			// e1 right behind the main kernel when it is the only leaf kernel
 			// of the batch: "leaf" time is then that kernel alone
-			const bool solo = !c->n_filt_leaf && !c->n_leaf && !c->n_leaf_dyn;
+			const bool solo = !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_leaf && !c->n_leaf_dyn;
 			if(a2d_launch_leaf_oscpan(c->d_params, c->hparams, c->d_list.d, c->n_fast_leaf,
 					vpw, ysplit, c->d_ustage.d, c->stream, solo ? (void *)e1 : nullptr))
 				return c->fail(A2AMD_EHIP, "fast leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
+		if(c->n_osc2_leaf) {
+			int vpw, ysplit;
+			pick_fast_shape(c->n_osc2_leaf, c->nfrags * 2, &vpw, &ysplit);	// 4-fragment chunks
+			if(a2d_launch_leaf_osc2pan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf, c->n_osc2_leaf,
+					vpw, ysplit, c->d_ustage.d, c->stream))
+				return c->fail(A2AMD_EHIP, "2-osc leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+			++c->stats.launches;
+		}
 		if(c->n_filt_leaf) {
 			int vpw = getenv("A2AMD_FVPW") ? atoi(getenv("A2AMD_FVPW")) :
 					std::min(std::max((c->n_filt_leaf + 2047) / 2048, 1), 32);
-			if(a2d_launch_leaf_oscfiltpan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf,
+			if(a2d_launch_leaf_oscfiltpan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf,
 					c->n_filt_leaf, vpw, c->stream))
 				return c->fail(A2AMD_EHIP, "filter leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
 		if(c->n_leaf) {
-			if(a2d_launch_voices(c->d_params, c->d_list.d + c->n_fast_leaf + c->n_filt_leaf, c->n_leaf,
+			if(a2d_launch_voices(c->d_params, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf, c->n_leaf,
 					pick_vpw(c->n_leaf), c->stream))
 				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
@@ -796,7 +823,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
-		if(e1 && !(c->n_fast_leaf && !c->n_filt_leaf && !c->n_leaf && !c->n_leaf_dyn))
+		if(e1 && !(c->n_fast_leaf && !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_leaf && !c->n_leaf_dyn))
 			HIPCHK(c, hipEventRecord(e1, c->stream));
 		for(int d = (int)c->depth_ranges.size() - 1; d >= 1; --d)
 			if(int r = launch_depth(c, d))

@@ -3,10 +3,11 @@
 
 Workload (BASELINE.json configs[1]): 1 024 sustained voices, wtosc -> panmix,
 48 kHz, fragment = 64 frames, stereo, per GPU.  One "step" = one batch of
---batch fragments (default 64 = 4096 frames = 85 ms of audio) rendered for all
-voices: upload happened before the timed region (the command stream of
-sustained voices is empty and identical for every batch, so the same uploaded
-batch is re-run; each run renders the NEXT 85 ms of audio).
+--batch fragments (default 256 = 16384 frames = 341 ms of audio, an offline
+a2_Run() buffer) rendered for all voices: upload happened before the timed
+region (the command stream of sustained voices is empty and identical for every
+batch, so the same uploaded batch is re-run; each run renders the NEXT 341 ms
+of audio).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns
 its own voice subtrees (weak scaling: --voices per GPU); per step each rank
@@ -109,7 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--voices", type=int, default=1024, help="voices per GPU")
     ap.add_argument("--chain", default="osc-pan", choices=sorted(BYTES_PER_VOICE_SAMPLE))
-    ap.add_argument("--batch", type=int, default=64, help="fragments per step")
+    ap.add_argument("--batch", type=int, default=256, help="fragments per step (256 = 341 ms of audio)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -261,7 +262,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bpvs * args.voices * B * 64,
-                         "kernel": {"osc-pan": "k_leaf_oscpan", "osc-filter-pan": "k_leaf_oscfiltpan"}.get(
+                         "kernel": {"osc-pan": "k_leaf_oscpan", "osc-filter-pan": "k_leaf_oscfiltpan", "osc2-pan": "k_leaf_osc2pan"}.get(
                              args.chain, "k_voices (leaf launch)"),
                          "avg_launch_ms": leaf_ms,
                          "timing": "HIP events on the launch stream around every launch, separate pass of "

@@ -41,6 +41,26 @@ def test_engine_with_dropin_units_matches_reference(tmp_path, name, args, frames
     assert len(bad) == 0, f"{len(bad)} fragments differ from the reference render, first {bad[:5]}"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels,buffer", [(1, 64), (2, 37), (1, 50)])
+def test_dropin_mono_root_and_odd_buffers(tmp_path, channels, buffer):
+    """a2_Render-style 1-channel states use the mono root driver (panmix 2->1,
+    audiality2.c:282-291); buffers that are not multiples of 64 give partial
+    fragments.  Compared with the same binary without the drop-in."""
+    need_ref()
+    outs = []
+    for pre in (None, UNITS_SO):
+        out = tmp_path / f"o{int(pre is not None)}.pcm"
+        env = dict(os.environ)
+        if pre:
+            env["LD_PRELOAD"] = pre
+        subprocess.run([REF_RENDER, f"{A2S}/scripted.a2s", "Main", str(buffer * 300), str(buffer), "48000",
+                        str(channels), str(out), "0.2"], check=True, env=env, cwd=A2S, timeout=600)
+        outs.append(np.fromfile(out, dtype="<i4"))
+    assert outs[0].any()
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_reference_render_is_reproducible(tmp_path):
     """The harness itself (no drop-in) reproduces the golden fixture: the
     fixtures are what the reference renders, run to run."""
