@@ -226,8 +226,10 @@ struct a2amd_ctx {
 	uint32_t *d_ptab = nullptr;
 	A2DParams *d_params = nullptr;
 	A2DParams hparams;
-	hipGraph_t graph[2] = {nullptr, nullptr};	// [0] = GRAPH_STEPS runs of the batch, [1] = one
-	hipGraphExec_t gexec[2] = {nullptr, nullptr};
+	// [0] = GRAPH_STEPS whole runs of the batch, [1] = one run, [2] = its SUBTREES
+	// phase alone, [3] = its ROOT phase alone (multi-GPU steps)
+	hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
+	hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
 	int32_t *h_master = nullptr;	// pinned
 	size_t h_master_cap = 0;
 
@@ -843,7 +845,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 
 void drop_graphs(a2amd_ctx *c)
 {
-	for(int i = 0; i < 2; ++i) {
+	for(int i = 0; i < 4; ++i) {
 		if(c->gexec[i]) {
 			hipGraphExecDestroy(c->gexec[i]);
 			c->gexec[i] = nullptr;
@@ -856,14 +858,14 @@ void drop_graphs(a2amd_ctx *c)
 }
 
 // capture 'steps' consecutive runs of the uploaded batch into one graph
-int build_graph(a2amd_ctx *c, int slot, int steps)
+int build_graph(a2amd_ctx *c, int slot, int steps, unsigned phases = A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT)
 {
 	hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
 	if(e != hipSuccess)
 		return c->fail(A2AMD_EHIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
 	int r = 0;
 	for(int i = 0; i < steps && !r; ++i)
-		r = issue_kernels(c, A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT, nullptr, nullptr, nullptr);
+		r = issue_kernels(c, phases, nullptr, nullptr, nullptr);
 	e = hipStreamEndCapture(c->stream, &c->graph[slot]);
 	if(r)
 		return r;
@@ -1425,8 +1427,26 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		c->ev2 = c->ev_pool[c->ev_used + 2];
 		c->ev_used += 3;
 	}
+	// Re-running a kept, record-free batch phase by phase (multi-GPU steps): one
+	// graph launch per phase instead of 3-5 separate commands.
+	const unsigned kphases = phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT);
+	if((phases & A2AMD_RENDER_KEEP) && kphases && kphases == (phases & ~A2AMD_RENDER_KEEP) &&
+			c->uploaded && !c->profiling && c->stream && c->with_recs.empty() && !getenv("A2AMD_NO_GRAPH")) {
+		const int slot = kphases == A2AMD_RENDER_SUBTREES ? 2 : kphases == A2AMD_RENDER_ROOT ? 3 : 1;
+		if(c->gexec[slot] || !build_graph(c, slot, 1, kphases)) {
+			HIPCHK(c, hipGraphLaunch(c->gexec[slot], c->stream));
+			if(kphases & A2AMD_RENDER_ROOT) {
+				c->stats.fragments += c->nfrags;
+				c->stats.voice_fragments += (uint64_t)c->nfrags * c->list_all.size();
+			}
+			return (int)total;
+		}
+	}
+	// Events only when profiling (each one from the pool, used once until read):
+	// re-recording an event the GPU has not reached yet makes the runtime wait.
 	if(phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT))
-		if(int r = issue_kernels(c, phases, c->ev0, c->ev1, c->ev2))
+		if(int r = c->profiling ? issue_kernels(c, phases, c->ev0, c->ev1, c->ev2) :
+				issue_kernels(c, phases, nullptr, nullptr, nullptr))
 			return r;
 	if(phases & A2AMD_RENDER_READBACK) {
 		const int nch = c->cfg.channels;
@@ -1451,9 +1471,9 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 			pos += c->fragframes[f];
 		}
 		float ms = 0;
-		if(hipEventElapsedTime(&ms, c->ev0, c->ev2) == hipSuccess)
+		if(c->profiling && hipEventElapsedTime(&ms, c->ev0, c->ev2) == hipSuccess)
 			c->stats.last_kernel_ms = ms;
-		if(hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess)
+		if(c->profiling && hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess)
 			c->stats.last_leaf_ms = ms;
 	}
 	if(!(phases & A2AMD_RENDER_KEEP) && (phases & (A2AMD_RENDER_READBACK | A2AMD_RENDER_ROOT)))
@@ -1500,7 +1520,9 @@ int a2amd_replay(a2amd_ctx *c, unsigned steps)
 				c->ev2 = c->ev_pool[c->ev_used + 2];
 				c->ev_used += 3;
 			}
-			if(int r = issue_kernels(c, A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT, c->ev0, c->ev1, c->ev2))
+			if(int r = c->profiling ?
+					issue_kernels(c, A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT, c->ev0, c->ev1, c->ev2) :
+					issue_kernels(c, A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT, nullptr, nullptr, nullptr))
 				return r;
 			--steps;
 		}

@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--voices", type=int, default=1024, help="voices per GPU")
     ap.add_argument("--chain", default="osc-pan", choices=sorted(BYTES_PER_VOICE_SAMPLE))
     ap.add_argument("--batch", type=int, default=256, help="fragments per step (256 = 341 ms of audio)")
+    ap.add_argument("--groups", type=int, default=0,
+                    help="put the voices under this many inline->fbdelay->fbdelay group voices (config 4 shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -157,7 +159,13 @@ def main():
     sc = synth.Scene(be)
     sc.root()
     sc.nvoices = shard.voice_range(rank, args.voices)[0]
-    sc.add_voices(args.voices, chain=args.chain, total=args.voices * world)
+    if args.groups:
+        per = args.voices // args.groups
+        for gi in range(args.groups):
+            grp = sc.add_group()
+            sc.add_voices(per, chain=args.chain, group=grp, total=args.voices * world)
+    else:
+        sc.add_voices(args.voices, chain=args.chain, total=args.voices * world)
 
     def repeat(n):
         rc = lib.a2amd_fragment_repeat(be.ctx, 64, n)
@@ -175,7 +183,11 @@ def main():
         ob = Backend(olib, "a2o_", 48000, synth.basepitch_for(48000), 2)
         so = synth.Scene(ob)
         so.root()
-        so.add_voices(args.voices, chain=args.chain, total=args.voices)
+        if args.groups:
+            for gi in range(args.groups):
+                so.add_voices(args.voices // args.groups, chain=args.chain, group=so.add_group(), total=args.voices)
+        else:
+            so.add_voices(args.voices, chain=args.chain, total=args.voices)
         nchk = min(B, 8)
         want = so.run(nchk, batch=nchk)
         ob.close()
@@ -207,16 +219,28 @@ def main():
             if rank == 0:
                 be.render(0, phases=ROOTP | KEEP)
 
+    # barrier = a (pre-warmed) 1-element all-reduce every rank must join, with the
+    # device idle on both sides; dist.barrier() itself costs tens of ms on first use
+    token = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", local_rank)) if multi else None
+
+    def fence():
+        torch.cuda.synchronize()
+        if multi:
+            dist.all_reduce(token)
+            torch.cuda.synchronize()
+
+    fence()                 # first use builds the RCCL communicator: keep it out of the timing
     run(args.warmup)
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
+    fence()
+    import gc
+    gc.collect()
+    gc.disable()            # a full collection mid-loop costs tens of ms of host time
     t0 = time.perf_counter()
     run(args.steps)
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
+    fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     if multi:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -253,7 +277,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{args.voices} voices/GPU, {args.chain} (wtosc->panmix = BASELINE "
                                    f"configs[1]), 48 kHz, fragment=64, stereo",
-                       "voices_per_gpu": args.voices, "chain": args.chain, "fragments_per_step": B,
+                       "voices_per_gpu": args.voices, "chain": args.chain, "groups": args.groups,
+                       "fragments_per_step": B,
                        "samplerate": 48000, "sharding": "voice subtrees per GPU + 1 RCCL int32 reduce "
                        "of the root bus per step" if multi else "single GPU"},
             "realtime_factor": value / (args.voices * world * 48000.0),
