@@ -3,9 +3,9 @@
 A trace is the ordered list of calls the Audiality 2 engine made through its
 unit plugin surface (Initialize / write / Process / Deinitialize, see
 include/a2amd.h) while rendering a script, captured from the unmodified
-reference by oracle/ref_tools.c.  Replaying it against a backend that speaks
-the a2amd call protocol ("a2amd_*" = the GPU library, "a2o_*" = the CPU oracle
-used by the tests) must reproduce the audio the reference rendered.
+reference (see tests/golden/).  Replaying it against a library that exports the
+call protocol of include/a2amd.h under some symbol prefix ("a2amd_" = the GPU
+library) must reproduce the audio the reference rendered.
 
 Format (little endian): int32 records of 8 words {op,a,b,c,d,e,f,g}; a WAVE
 record is followed by uint32 size[10] and the int16 payload of every level

@@ -113,3 +113,14 @@ def test_scene_edge_cases(oracle_lib):
     out = sc.run(2, batch=8, frames=33)
     assert not out.any()
     be.close()
+
+
+def test_bench_parity_golden_matches_oracle(oracle_lib):
+    """bench.py gates its number on tests/golden/bench_default_first8.hash.npy
+    (data only); the file must be what the oracle renders for that workload."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mbg", os.path.join(GOLDEN, "make_bench_golden.py"))
+    mbg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mbg)
+    want = np.load(os.path.join(GOLDEN, "bench_default_first8.hash.npy"))
+    assert np.array_equal(fnv1a_fragments(mbg.render()), want)
