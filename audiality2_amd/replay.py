@@ -13,6 +13,7 @@ record is followed by uint32 size[10] and the int16 payload of every level
 """
 import ctypes as C
 import gzip
+import lzma
 
 import numpy as np
 
@@ -26,7 +27,7 @@ class Trace:
     """Parsed trace: .config dict, .records (list of tuples), .waves."""
 
     def __init__(self, path):
-        opener = gzip.open if str(path).endswith(".gz") else open
+        opener = gzip.open if str(path).endswith(".gz") else lzma.open if str(path).endswith(".xz") else open
         with opener(path, "rb") as f:
             raw = f.read()
         words = np.frombuffer(raw[: len(raw) // 4 * 4], dtype="<i4")

@@ -6,7 +6,7 @@ oracle/_ref with oracle/Makefile, then for every case below lets the
 unmodified reference engine render a script while oracle/_ref/ref_tools logs
 the calls it makes through the unit plugin surface.  Committed per case:
 
-  <case>.trace.gz   the call trace (input of every backend)
+  <case>.trace.xz   the call trace (input of every backend)
   <case>.hash.npy   FNV-1a 64 of the reference's output, one per 64-frame
                     fragment, channel 0 then channel 1
   <case>.head.npy   the first 4096 output frames [channels, 4096], for eyeballs
@@ -16,7 +16,7 @@ plus reference dumps used to pin the stand-alone pieces of the oracle:
   builtin_waves.npz the engine's 24 built-in waves, all mip levels incl. pads
                     (src/waves.c:629-708)
 """
-import gzip
+import lzma
 import os
 import subprocess
 import sys
@@ -38,7 +38,13 @@ CASES = [
     ("filter", f"{A2S}/filter.a2s", "Main", 48000, ["4", "0.02"]),
     ("delaybus", f"{A2S}/delaybus.a2s", "Main", 48000, ["2", "4", "0.05"]),
     ("scripted", f"{A2S}/scripted.a2s", "Main", 48000, ["0.2"]),
+    # the reference's own benchmark songs (benchmark/RESULTS): all five use only
+    # units on the hot path
     ("k2intro", f"{REF}/benchmark/k2intro.a2s", "Song", 6 * 48000, []),
+    ("k2epilogue", f"{REF}/benchmark/k2epilogue.a2s", "Song", 5 * 48000, []),
+    ("k2loader", f"{REF}/benchmark/k2loader.a2s", "Song", 5 * 48000, []),
+    ("k2trance", f"{REF}/benchmark/k2trance.a2s", "Song", 5 * 48000, []),
+    ("pulsetronic", f"{REF}/benchmark/pulsetronic.a2s", "Song", 5 * 48000, []),
 ]
 
 
@@ -65,7 +71,7 @@ def main():
         tr, pcm = f"{tmp}/{name}.trace", f"{tmp}/{name}.pcm"
         subprocess.run([TOOLS, "trace", script, prog, str(frames), "64", "48000", "2", tr, pcm] + args,
                        check=True, cwd=os.path.dirname(script))
-        with open(tr, "rb") as f, gzip.GzipFile(f"{HERE}/{name}.trace.gz", "wb", 9, mtime=0) as g:
+        with open(tr, "rb") as f, lzma.open(f"{HERE}/{name}.trace.xz", "wb", preset=9 | lzma.PRESET_EXTREME) as g:
             g.write(f.read())
         audio = read_pcm(pcm, 2, 64)
         np.save(f"{HERE}/{name}.hash.npy", fnv1a_fragments(audio))

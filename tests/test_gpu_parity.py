@@ -12,7 +12,7 @@ from conftest import GOLDEN, fnv1a_fragments, make_gpu, make_oracle
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["sustain", "filter", "delaybus", "scripted", "k2intro"]
+CASES = ["sustain", "filter", "delaybus", "scripted", "k2intro", "k2epilogue", "k2loader", "k2trance", "pulsetronic"]
 
 
 def first_diff(a, b):
@@ -28,9 +28,9 @@ def first_diff(a, b):
 def test_reference_traces_on_gpu(oracle_lib, name, batch):
     """The reference's own call traces (k2intro.a2s and our test scripts),
     rendered on the GPU, hash-equal to the audio the reference produced."""
-    if name == "k2intro" and batch == 1:
+    if name in ("k2intro", "k2epilogue", "k2loader", "k2trance", "pulsetronic") and batch == 1:
         pytest.skip("covered by the batched run; one launch set per fragment is slow over 4500 fragments")
-    tr = Trace(os.path.join(GOLDEN, f"{name}.trace.gz"))
+    tr = Trace(os.path.join(GOLDEN, f"{name}.trace.xz"))
     cfg = tr.config
     gpu = make_gpu(cfg["samplerate"], cfg["basepitch"], cfg["channels"], max_batch=batch)
     out = replay(tr, gpu, batch=batch, check_noise=True)

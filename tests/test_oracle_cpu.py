@@ -10,7 +10,7 @@ from audiality2_amd import synth
 from audiality2_amd.replay import Trace, replay
 from conftest import GOLDEN, fnv1a_fragments, make_oracle
 
-CASES = ["sustain", "filter", "delaybus", "scripted", "k2intro"]
+CASES = ["sustain", "filter", "delaybus", "scripted", "k2intro", "k2epilogue", "k2loader", "k2trance", "pulsetronic"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -18,7 +18,7 @@ def test_trace_replay_matches_reference(oracle_lib, name):
     """Feeding the reference's own call trace to the restatement reproduces the
     audio the reference rendered, bit for bit, and the engine-global noise RNG
     stays in step after every oscillator call."""
-    tr = Trace(os.path.join(GOLDEN, f"{name}.trace.gz"))
+    tr = Trace(os.path.join(GOLDEN, f"{name}.trace.xz"))
     be = make_oracle(oracle_lib, tr.config["samplerate"], tr.config["basepitch"], tr.config["channels"])
     out = replay(tr, be, batch=64, check_noise=True)
     be.close()
@@ -32,7 +32,7 @@ def test_trace_replay_matches_reference(oracle_lib, name):
 
 
 def test_replay_batching_is_transparent(oracle_lib):
-    tr = Trace(os.path.join(GOLDEN, "scripted.trace.gz"))
+    tr = Trace(os.path.join(GOLDEN, "scripted.trace.xz"))
     outs = []
     for batch in (1, 7, 64):
         be = make_oracle(oracle_lib, tr.config["samplerate"], tr.config["basepitch"])
