@@ -115,6 +115,7 @@ struct HUnit {
 	// wtosc shadow: enough of A2_wtosc to count noise draws on the host
 	int mode = A2D_OSC_OFF, wave = -1;
 	bool shadow_ok = true;
+	unsigned shadow_epoch = 0;	// == ctx epoch while every Process call came through unit_process
 	Ramp p = {0, 0, 0, 0};
 	unsigned dphase = 0;
 	uint64_t phase = 0;
@@ -179,6 +180,7 @@ struct a2amd_ctx {
 	int n_leaf_dyn = 0, static_len = 0;
 	int n_started_live = 0;			// voices the engine is walking
 	int n_noise = 0, n_cutoff_ramps = 0;
+	unsigned shadow_epoch = 0;
 
 	// fragment clock
 	bool frag_open = false;
@@ -1051,6 +1053,8 @@ int a2amd_fragment_repeat(a2amd_ctx *c, unsigned frames, unsigned count)
 	if(c->n_noise || c->n_cutoff_ramps)
 		return c->fail(A2AMD_EUNSUPPORTED, "fragment_repeat with %d noise oscillators / %d cutoff ramps "
 				"in flight", c->n_noise, c->n_cutoff_ramps);
+	if(count)
+		++c->shadow_epoch;	// oscillator phases advance without the host seeing it
 	for(unsigned i = 0; i < count; ++i) {
 		if(int r = a2amd_fragment(c, frames))
 			return r;
@@ -1158,6 +1162,7 @@ int a2amd_unit_init(a2amd_ctx *c, uint64_t key, int kind, unsigned flags, int ni
 		u.mode = A2D_OSC_OFF;
 		u.wave = -1;
 		u.shadow_ok = true;
+		u.shadow_epoch = c->shadow_epoch;
 		break;
 	  case A2AMD_FILTER12:	// f12_Initialize -> f12_CutOff(u, 0, 0, 0), filter12.c:141-147,203
 		ramp_init(u.cutoff, 0);
@@ -1241,9 +1246,9 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 			}
 			int nmode = wt == A2AMD_WNOISE ? A2D_OSC_NOISE : wt == A2AMD_WWAVE ? A2D_OSC_WAVE :
 					wt == A2AMD_WMIPWAVE ? A2D_OSC_MIPWAVE : A2D_OSC_OFF;
-			if(nmode == A2D_OSC_NOISE && !u.shadow_ok)
-				return c->fail(A2AMD_EUNSUPPORTED, "oscillator switched to noise after playing a "
-						"wavetable: its phase lives on the GPU");
+			if(nmode == A2D_OSC_NOISE && !(u.shadow_ok && u.shadow_epoch == c->shadow_epoch))
+				return c->fail(A2AMD_EUNSUPPORTED, "oscillator switched to noise after rendering through "
+						"fragment_repeat/replay: its phase was not shadowed on the host");
 			if(u.mode == A2D_OSC_NOISE && nmode != A2D_OSC_NOISE)
 				--c->n_noise;
 			if(u.mode != A2D_OSC_NOISE && nmode == A2D_OSC_NOISE)
@@ -1309,6 +1314,74 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 	return A2AMD_OK;
 }
 
+
+// ---- wtosc phase shadow ------------------------------------------------------------
+// The engine-global noise generator is shared by every noise oscillator and by
+// the VM's RAND instructions (wtosc.c:136, a2_Noise()), so the host has to hand
+// it back advanced by the right number of draws after each Process call of a
+// noise oscillator; that count depends on the oscillator's phase.  Scripts do
+// switch an oscillator from a wavetable to noise (benchmark/k2epilogue.a2s), so
+// the phase is shadowed in wavetable mode too: the closed form of what the
+// kernels compute sample by sample.  Pitch and phase only - no audio.
+static void shadow_run_pitch(a2amd_ctx *c, HUnit &u, unsigned frames)
+{
+	ramp_prepare(u.p, (int)frames);		// wtosc_run_pitch, wtosc.c:88-106
+	if(u.dphase && (!u.p.timer && !u.p_ramping))
+		return;
+	unsigned lastv = (unsigned)u.p.value;
+	ramp_run(u.p, (int)frames);
+	u.p_ramping = u.p.delta;
+	u.dphase = p2i(c->ptab, (int)((lastv + (unsigned)u.p.value) >> 9));
+}
+
+static void shadow_wave(a2amd_ctx *c, HUnit &u, unsigned frames)
+{
+	const A2DWave &w = c->waves[u.wave].dw;
+	const bool looped = (w.flags & 0x100u) != 0;	// A2_LOOPED
+	if(!w.size[0]) {	// wtosc_check_unloaded, wtosc.c:168-183
+		u.wave = -1;
+		u.mode = A2D_OSC_OFF;
+		return;
+	}
+	shadow_run_pitch(c, u, frames);
+	if(u.mode == A2D_OSC_MIPWAVE) {		// wtosc_wavetable, wtosc.c:239-286
+		unsigned dph = ((u.dphase + 255) >> 8) * w.period;
+		unsigned mm = 0;
+		for(; (dph > (A2D_MAXPHINC << 8)) && (mm < A2D_MIPS - 1); ++mm)
+			dph >>= 1;
+		uint64_t ph = u.phase >> mm;
+		dph = (unsigned)(((uint64_t)u.dphase * w.period) >> mm);
+		if(looped)
+			ph %= (uint64_t)w.size[mm] << 24;
+		else if((ph >> 24) > (uint64_t)(w.size[mm] + 1))
+			return;		// all played
+		u.phase = (ph + (uint64_t)dph * frames) << mm;
+		return;
+	}
+	// wtosc_wavetable_no_mip, wtosc.c:301-358
+	const uint64_t dph = (uint64_t)u.dphase * w.period;
+	if(dph >> 32) {
+		u.phase += dph * frames;
+	} else if(dph > (A2D_MAXPHINC << 16)) {
+		// per-sample loop/end test of wtosc_do_fragment, wtosc.c:207-226
+		const uint64_t m = (uint64_t)w.size[0] << 24;
+		if(looped) {
+			u.phase = (u.phase + (uint64_t)(frames - 1) * dph) % m + dph;
+		} else if(u.phase < m) {
+			uint64_t steps = (m - u.phase + dph - 1) / dph;
+			u.phase += (steps < frames ? steps : frames) * dph;
+		}
+	} else {
+		if(looped) {
+			unsigned m = w.size[0] << 24;	// 32 bit in the reference, wtosc.c:340
+			if(m)
+				u.phase %= m;
+		} else if((u.phase >> 24) > (uint64_t)(w.size[0] + 1))
+			return;
+		u.phase += dph * frames;
+	}
+}
+
 int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, uint32_t *noisestate)
 {
 	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live)
@@ -1343,13 +1416,7 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 			if(!noisestate)
 				return c->fail(A2AMD_EINVAL, "noise oscillator needs the engine's noise state");
 			push_rec(c, vi, R_NOISESEED, u.chainpos, 0, (int)*noisestate, 0, 0);
-			ramp_prepare(u.p, (int)frames);
-			if(!(u.dphase && (!u.p.timer && !u.p_ramping))) {	// wtosc_run_pitch
-				unsigned lastv = (unsigned)u.p.value;
-				ramp_run(u.p, (int)frames);
-				u.p_ramping = u.p.delta;
-				u.dphase = p2i(c->ptab, (int)((lastv + (unsigned)u.p.value) >> 9));
-			}
+			shadow_run_pitch(c, u, frames);
 			uint64_t end = u.phase + (uint64_t)frames * u.dphase;
 			uint64_t draws = u.dphase >= (1u << 23) ? frames : (end >> 23) - (u.phase >> 23);
 			uint32_t st = *noisestate;
@@ -1357,11 +1424,12 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 				st = st * 1566083941u + 1u;
 			*noisestate = st;
 			u.phase = end;
-		} else if(u.mode == A2D_OSC_OFF) {
-			if(u.shadow_ok) {	// wtosc_Off, wtosc.c:108-126
+		} else if(u.shadow_ok && u.shadow_epoch == c->shadow_epoch) {
+			if(u.mode == A2D_OSC_OFF) {	// wtosc_Off, wtosc.c:108-126
 				ramp_prepare(u.p, (int)frames);
 				ramp_run(u.p, (int)frames);
-			}
+			} else
+				shadow_wave(c, u, frames);
 		} else
 			u.shadow_ok = false;
 		break;
@@ -1409,6 +1477,8 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 			;	// nothing recorded: records made outside any fragment wait for the next batch
 		return 0;
 	}
+	if(phases & A2AMD_RENDER_KEEP)
+		++c->shadow_epoch;	// a kept batch runs again: phases move on without host calls
 	if(phases & A2AMD_RENDER_UPLOAD)
 		if(int r = upload(c))
 			return r;
@@ -1489,6 +1559,7 @@ int a2amd_replay(a2amd_ctx *c, unsigned steps)
 	for(int vi = 0; vi < (int)c->voices.size(); ++vi)
 		if(!c->voices[vi].recs.empty())
 			return c->fail(A2AMD_ESTATE, "replay of a batch that carries command records");
+	++c->shadow_epoch;
 	bool graphs = c->stream != nullptr && !c->profiling && !getenv("A2AMD_NO_GRAPH");
 	if(graphs && !c->gexec[0]) {
 		if(build_graph(c, 0, GRAPH_STEPS) || build_graph(c, 1, 1)) {

@@ -200,7 +200,12 @@ int  a2amd_rootbus(a2amd_ctx *ctx, void **devptr, uint64_t *bytes);
  * voice walk finds every VM asleep: each live voice gets exactly one
  * Process(0, frames) per unit and nothing else happens (src/core.c:1852-1878
  * with no wake-ups).  Fails with A2AMD_EUNSUPPORTED while a noise oscillator
- * or a ramping filter cutoff needs per-call host work. */
+ * or a ramping filter cutoff needs per-call host work.  Fragments rendered
+ * this way (and by A2AMD_RENDER_KEEP / a2amd_replay re-runs) advance the
+ * oscillators without a2amd_unit_process calls, so the host loses track of
+ * their phase: an oscillator alive across such a stretch can afterwards not be
+ * switched from a wavetable to noise (A2AMD_EUNSUPPORTED) - the engine-driven
+ * path, where every Process call arrives, has no such restriction. */
 int  a2amd_fragment_repeat(a2amd_ctx *ctx, unsigned frames, unsigned count);
 
 /* ---- introspection (tests, bench) --------------------------------------*/

@@ -23,11 +23,11 @@ def first_diff(a, b):
     return int(d[0][i]), int(d[1][i]), int(a[d[0][i], d[1][i]]), int(b[d[0][i], d[1][i]])
 
 
-@pytest.mark.parametrize("batch", [1, 64])
+@pytest.mark.parametrize("batch", [1, 7, 64])
 @pytest.mark.parametrize("name", CASES)
 def test_reference_traces_on_gpu(oracle_lib, name, batch):
-    """The reference's own call traces (k2intro.a2s and our test scripts),
-    rendered on the GPU, hash-equal to the audio the reference produced."""
+    """The reference's own call traces (its five benchmark songs and our test scripts),
+    rendered on the GPU in batches of 1, 7 and 64 fragments, hash-equal to the audio the reference produced."""
     if name in ("k2intro", "k2epilogue", "k2loader", "k2trance", "pulsetronic") and batch == 1:
         pytest.skip("covered by the batched run; one launch set per fragment is slow over 4500 fragments")
     tr = Trace(os.path.join(GOLDEN, f"{name}.trace.xz"))
