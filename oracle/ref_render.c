@@ -42,7 +42,15 @@ int main(int argc, const char *argv[])
 		return 1;
 	if(!(drv = a2_NewDriver(A2_AUDIODRIVER, "buffer")))
 		return 1;
-	if(!(cfg = a2_OpenConfig(rate, buffer, channels, A2_AUTOCLOSE)))
+	/*
+	 * A2REF_REALTIME=1: open the master state with the A2_REALTIME flag, so
+	 * that API calls travel through the message FIFOs (interface.c:932-975).
+	 * Needed for scripts that render waves at load time: a2_RenderWave ends
+	 * with a2_Release() on the master interface, which the direct-call
+	 * variant used by offline states does not implement (interface.c:496-505).
+	 */
+	if(!(cfg = a2_OpenConfig(rate, buffer, channels, A2_AUTOCLOSE |
+			(getenv("A2REF_REALTIME") ? A2_REALTIME : 0))))
 		return 1;
 	a2_AddDriver(cfg, drv);
 	if(!(i = a2_Open(cfg)))

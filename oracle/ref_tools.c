@@ -45,6 +45,7 @@ enum { K_WTOSC = 0, K_PANMIX, K_FILTER12, K_FBDELAY, K_INLINE, K_XINSERT,
 		K_COUNT };
 
 static FILE *tracef;
+static int trace_muted;		/* set while a2_Load() renders waves in a substate */
 static A2_interface *g_iface;
 static int next_uid, next_voice;
 static A2_vmstate *last_init_vms;
@@ -53,7 +54,7 @@ static int chain_open;
 static void rec(int op, int a, int b, int c, int d, int e, int f, int g)
 {
 	int32_t r[8] = { op, a, b, c, d, e, f, g };
-	if(tracef)
+	if(tracef && !trace_muted)
 		fwrite(r, sizeof(r), 1, tracef);
 }
 
@@ -65,7 +66,7 @@ static int nwaves;
 static int wave_id(A2_wave *w)
 {
 	int i, levels;
-	if(!w)
+	if(!w || trace_muted)
 		return -1;
 	for(i = 0; i < nwaves; ++i)
 		if(wave_ptr[i] == w)
@@ -389,7 +390,15 @@ static int do_trace(int argc, const char *argv[])
 	}
 	if(!(drv = a2_NewDriver(A2_AUDIODRIVER, "buffer")))
 		return 1;
-	if(!(cfg = a2_OpenConfig(rate, buffer, channels, A2_AUTOCLOSE)))
+	/*
+	 * A2REF_REALTIME=1: open the master state with the A2_REALTIME flag, so
+	 * that API calls travel through the message FIFOs (interface.c:932-975).
+	 * Needed for scripts that render waves at load time: a2_RenderWave ends
+	 * with a2_Release() on the master interface, which the direct-call
+	 * variant used by offline states does not implement (interface.c:496-505).
+	 */
+	if(!(cfg = a2_OpenConfig(rate, buffer, channels, A2_AUTOCLOSE |
+			(getenv("A2REF_REALTIME") ? A2_REALTIME : 0))))
 		return 1;
 	a2_AddDriver(cfg, drv);
 	if(!(g_iface = a2_Open(cfg)))
@@ -400,7 +409,17 @@ static int do_trace(int argc, const char *argv[])
 	}
 	rec(T_CONFIG, cfg->samplerate, cfg->basepitch, cfg->channels, buffer,
 			(int)noise_state(), 0, 0);
-	if((bank = a2_Load(g_iface, script, 0)) < 0)
+	/*
+	 * A script may render waves while it is compiled (a2_RenderWave in an
+	 * offline substate, compiler.c:3334-3370): those unit calls belong to
+	 * another engine state with its own fragments and noise generator, and
+	 * are not part of this state's trace.  The waves they produce are
+	 * logged (T_WAVE) when an oscillator first plays them.
+	 */
+	trace_muted = 1;
+	bank = a2_Load(g_iface, script, 0);
+	trace_muted = 0;
+	if(bank < 0)
 	{
 		fprintf(stderr, "cannot load %s: %s\n", script,
 				a2_ErrorString(-bank));

@@ -38,6 +38,9 @@ CASES = [
     ("filter", f"{A2S}/filter.a2s", "Main", 48000, ["4", "0.02"]),
     ("delaybus", f"{A2S}/delaybus.a2s", "Main", 48000, ["2", "4", "0.05"]),
     ("scripted", f"{A2S}/scripted.a2s", "Main", 48000, ["0.2"]),
+    # corner cases of every unit; renders its own waves at load time, which the
+    # reference only manages on an A2_REALTIME master state (see ref_tools.c)
+    ("edge", f"{A2S}/edge.a2s", "Main", 4 * 48000, ["0.2"]),
     # the reference's own benchmark songs (benchmark/RESULTS): all five use only
     # units on the hot path
     ("k2intro", f"{REF}/benchmark/k2intro.a2s", "Song", 6 * 48000, []),
@@ -46,6 +49,8 @@ CASES = [
     ("k2trance", f"{REF}/benchmark/k2trance.a2s", "Song", 5 * 48000, []),
     ("pulsetronic", f"{REF}/benchmark/pulsetronic.a2s", "Song", 5 * 48000, []),
 ]
+
+REALTIME_CASES = {"edge"}
 
 
 def fnv1a_fragments(pcm, frag=64):
@@ -69,8 +74,11 @@ def main():
     os.makedirs(tmp, exist_ok=True)
     for name, script, prog, frames, args in CASES:
         tr, pcm = f"{tmp}/{name}.trace", f"{tmp}/{name}.pcm"
+        env = dict(os.environ)
+        if name in REALTIME_CASES:
+            env["A2REF_REALTIME"] = "1"
         subprocess.run([TOOLS, "trace", script, prog, str(frames), "64", "48000", "2", tr, pcm] + args,
-                       check=True, cwd=os.path.dirname(script))
+                       check=True, cwd=os.path.dirname(script), env=env)
         with open(tr, "rb") as f, lzma.open(f"{HERE}/{name}.trace.xz", "wb", preset=9 | lzma.PRESET_EXTREME) as g:
             g.write(f.read())
         audio = read_pcm(pcm, 2, 64)

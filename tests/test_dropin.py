@@ -18,7 +18,11 @@ A2S = os.path.join(ROOT, "tests", "a2s")
 
 # name, program args, frames (as in tests/golden/make_goldens.py)
 CASES = [("sustain", ["4", "0.05"], 9600), ("filter", ["4", "0.02"], 48000),
-         ("delaybus", ["2", "4", "0.05"], 48000), ("scripted", ["0.2"], 48000)]
+         ("delaybus", ["2", "4", "0.05"], 48000), ("scripted", ["0.2"], 48000),
+         # renders three waves in offline substates while the script loads: those
+         # states get GPU contexts of their own next to the master state's
+         ("edge", ["0.2"], 4 * 48000)]
+REALTIME_CASES = {"edge"}      # see tests/golden/make_goldens.py
 
 
 def need_ref():
@@ -32,6 +36,8 @@ def test_engine_with_dropin_units_matches_reference(tmp_path, name, args, frames
     need_ref()
     out = tmp_path / f"{name}.pcm"
     env = dict(os.environ, LD_PRELOAD=UNITS_SO)
+    if name in REALTIME_CASES:
+        env["A2REF_REALTIME"] = "1"
     subprocess.run([REF_RENDER, f"{A2S}/{name}.a2s", "Main", str(frames), "64", "48000", "2", str(out)] + args,
                    check=True, env=env, cwd=A2S, timeout=600)
     audio = read_pcm(out, 2, 64)
