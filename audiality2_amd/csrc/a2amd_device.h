@@ -17,7 +17,9 @@
 #define A2D_WTOSC_MAXLENGTH (0x01000000 - 1 - 131)   // wtosc.c:55
 
 // unit kinds: numerically equal to a2amd_unitkind
-enum { A2D_WTOSC = 0, A2D_PANMIX, A2D_FILTER12, A2D_FBDELAY, A2D_INLINE, A2D_XINSERT };
+enum { A2D_WTOSC = 0, A2D_PANMIX, A2D_FILTER12, A2D_FBDELAY, A2D_INLINE, A2D_XINSERT,
+	A2D_FM1, A2D_FM2, A2D_FM3, A2D_FM4, A2D_FM3P, A2D_FM4P, A2D_FM2R, A2D_FM4R };
+#define A2D_IS_FM(k) ((k) >= A2D_FM1 && (k) <= A2D_FM4R)
 
 // wtosc Process variants (the reference swaps u->Process, wtosc.c:433-483)
 enum { A2D_OSC_OFF = 0, A2D_OSC_NOISE, A2D_OSC_WAVE, A2D_OSC_MIPWAVE };
@@ -47,6 +49,13 @@ enum {	// filter12 (A2_filter12, filter12.c:36-56); the cutoff ramper and the
 enum {	// fbdelay (A2_fbdelay, fbdelay.c:41-60)
 	DW_FBDELAY = 0, DW_LDELAY, DW_RDELAY, DW_DRYGAIN, DW_FBGAIN, DW_LGAIN,
 	DW_RGAIN, DW_BUFPOS, DW_BUFIDX };
+
+enum {	// fm (A2_fm, fm.c:95-105): the operators live in a pool of their own
+	// (fmstate[slot][A2D_FMSTATE]); the unit's state words only name the slot
+	MW_SLOT = 0 };
+enum {	// one operator (A2_fmosc, fm.c:84-93), A2D_FMSTATE / 4 words
+	FO_A = 0, FO_FB = 4, FO_P = 8, FO_LASTPITCH = 12, FO_PHASE, FO_DPHASE, FO_LAST, FO_WORDS };
+#define A2D_FMSTATE 64
 
 // mirror of A2_wave for the device: offsets index the int16 wave pool and point
 // at the first PAYLOAD sample of a level (i.e. data[level] + A2_WAVEPRE)
@@ -100,6 +109,8 @@ struct A2DParams {
 	int32_t        *busmem;
 	int32_t        *fbdmem;		// [bufidx][2][A2D_FBD_BUFSIZE]
 	const uint32_t *ptab;		// 64 x {base, coeff}, pitch.c:70-96
+	int32_t        *fmstate;	// [fm slot][A2D_FMSTATE]
+	const uint32_t *fmsine;		// 2048 x {s[i], s[i+1]-s[i]} packed 16:16, fm.c:493-501
 	int32_t         nfrags;
 	int32_t         samplerate;
 	int32_t         debug;		// A2AMD_DEBUG ablation bits (perf experiments only)

@@ -124,6 +124,8 @@ struct HUnit {
 	Ramp cutoff = {0, 0, 0, 0};
 	// fbdelay: delay line pair index
 	int fbdbuf = -1;
+	// fm: slot in the operator state pool
+	int fmslot = -1;
 };
 
 struct HVoice {
@@ -208,6 +210,9 @@ struct a2amd_ctx {
 	// fbdelay buffers
 	int fbd_count = 0;
 	std::vector<int> fbd_free, fbd_deferred_free, fbd_to_zero;
+	// fm operator state pool
+	int fm_count = 0;
+	std::vector<int> fm_free, fm_deferred_free;
 
 	// wave pool (int16 samples)
 	size_t wavepool_used = 0;
@@ -223,6 +228,8 @@ struct a2amd_ctx {
 	DevBuf<int16_t> d_wavepool;
 	DevBuf<int32_t> d_busmem;
 	DevBuf<int32_t> d_fbdmem;	// cap in buffer pairs
+	DevBuf<int32_t> d_fmstate;	// cap in slots of A2D_FMSTATE words
+	uint32_t *d_fmsine = nullptr;
 	DevBuf<int> d_list;
 	DevBuf<int> d_scatter;	// idx[k] then A2DRun[k] for k_scatter_runs
 	uint32_t *d_ptab = nullptr;
@@ -468,6 +475,22 @@ int upload(a2amd_ctx *c)
 	if(int r = grow(c, c->d_busmem, c->bus_used, 1, false)) return r;
 	if(c->fbd_count)
 		if(int r = grow(c, c->d_fbdmem, c->fbd_count, 2 * (size_t)A2D_FBD_BUFSIZE, true)) return r;
+	if(c->fm_count) {
+		if(int r = grow(c, c->d_fmstate, c->fm_count, A2D_FMSTATE, true)) return r;
+		if(!c->d_fmsine) {
+			// fm_OpenState, fm.c:493-501: one period of sine and one pad
+			// sample, computed here with the reference's own expression
+			// (libm on the host) and shipped as {s[i], s[i+1] - s[i]} pairs
+			int16_t sine[2049];
+			uint32_t pairs[2048];
+			for(int k = 0; k < 2049; ++k)
+				sine[k] = (int16_t)(sin(k * 2.0f * M_PI / 2048) * 32767.0f);
+			for(int k = 0; k < 2048; ++k)
+				pairs[k] = (uint32_t)(uint16_t)sine[k] | ((uint32_t)(sine[k + 1] - sine[k]) << 16);
+			HIPCHK(c, hipMalloc((void **)&c->d_fmsine, sizeof(pairs)));
+			HIPCHK(c, hipMemcpy(c->d_fmsine, pairs, sizeof(pairs), hipMemcpyHostToDevice));
+		}
+	}
 
 	if(c->voices_dirty && nv) {
 		// re-upload the span of voice table entries that changed
@@ -656,6 +679,8 @@ int upload(a2amd_ctx *c)
 	p.busmem = c->d_busmem.d;
 	p.fbdmem = c->d_fbdmem.d;
 	p.ptab = c->d_ptab;
+	p.fmstate = c->d_fmstate.d;
+	p.fmsine = c->d_fmsine;
 	p.nfrags = c->nfrags;
 	p.samplerate = c->cfg.samplerate;
 	p.debug = getenv("A2AMD_DEBUG") ? atoi(getenv("A2AMD_DEBUG")) : 0;
@@ -775,6 +800,9 @@ void end_batch(a2amd_ctx *c)
 	for(int b : c->fbd_deferred_free)
 		c->fbd_free.push_back(b);
 	c->fbd_deferred_free.clear();
+	for(int b : c->fm_deferred_free)
+		c->fm_free.push_back(b);
+	c->fm_deferred_free.clear();
 	c->nfrags = 0;
 	c->cur_frag = 0;
 	c->frag_open = false;
@@ -949,7 +977,7 @@ void a2amd_close(a2amd_ctx *c)
 	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
 	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
 	hipFree(c->d_waves.d); hipFree(c->d_wavepool.d); hipFree(c->d_busmem.d);
-	hipFree(c->d_fbdmem.d); hipFree(c->d_list.d); hipFree(c->d_scatter.d); hipFree(c->d_ptab); hipFree(c->d_params);
+	hipFree(c->d_fbdmem.d); hipFree(c->d_fmstate.d); hipFree(c->d_fmsine); hipFree(c->d_list.d); hipFree(c->d_scatter.d); hipFree(c->d_ptab); hipFree(c->d_params);
 	if(c->h_master)
 		hipHostFree(c->h_master);
 	for(hipEvent_t e : c->ev_pool)
@@ -1069,7 +1097,6 @@ int a2amd_fragment_repeat(a2amd_ctx *c, unsigned frames, unsigned count)
 int a2amd_unit_init(a2amd_ctx *c, uint64_t key, int kind, unsigned flags, int nin, int nout,
 		int wired, int transpose, unsigned wakefrac)
 {
-	(void)wakefrac;		// only shifts the phase of an oscillator that has a wave (none at init)
 	if(kind < 0 || kind >= A2AMD_NKINDS)
 		return c->fail(A2AMD_EINVAL, "unit kind %d", kind);
 	if(nin < 0 || nin > A2D_MAXCH || nout < 0 || nout > A2D_MAXCH)
@@ -1095,6 +1122,10 @@ int a2amd_unit_init(a2amd_ctx *c, uint64_t key, int kind, unsigned flags, int ni
 	  case A2AMD_INLINE:
 		if(nout < 1)
 			return c->fail(A2AMD_EINVAL, "inline needs outputs");
+		break;
+	  default:	// fm1..fm4r, fm.c:532-834: no inputs, one output
+		if(nin != 0 || nout != 1)
+			return c->fail(A2AMD_EINVAL, "fm unit with %d->%d channels", nin, nout);
 		break;
 	}
 	if(wired && !add && kind != A2AMD_INLINE)
@@ -1188,7 +1219,18 @@ int a2amd_unit_init(a2amd_ctx *c, uint64_t key, int kind, unsigned flags, int ni
 	  default:
 		break;
 	}
-	push_rec(c, vi, R_INIT, u.chainpos, 0, initval, 0, 0);
+	unsigned initdur = 0, initstart = 0;
+	if(kind >= A2AMD_FM1 && kind <= A2AMD_FM4R) {	// fm_Initialize, fm.c:338-400
+		if(!c->fm_free.empty()) {
+			u.fmslot = c->fm_free.back();
+			c->fm_free.pop_back();
+		} else
+			u.fmslot = c->fm_count++;
+		initval = transpose + c->cfg.basepitch;
+		initdur = (unsigned)u.fmslot;
+		initstart = wakefrac & 0xffu;	// vms->waketime & 0xff: sub-sample start time
+	}
+	push_rec(c, vi, R_INIT, u.chainpos, 0, initval, initdur, initstart);
 	return ui;
 }
 
@@ -1206,6 +1248,8 @@ int a2amd_unit_deinit(a2amd_ctx *c, int ui)
 		--c->n_cutoff_ramps;
 	if(u.fbdbuf >= 0)
 		c->fbd_deferred_free.push_back(u.fbdbuf);
+	if(u.fmslot >= 0)
+		c->fm_deferred_free.push_back(u.fmslot);
 	u.live = false;
 	c->deferred_free_units.push_back(ui);
 	--c->stats.live_units;
@@ -1307,8 +1351,17 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 		if(reg < 0 || reg > 6)
 			return c->fail(A2AMD_EINVAL, "fbdelay register %d", reg);
 		break;
-	  default:
+	  case A2AMD_INLINE:
+	  case A2AMD_XINSERT:
 		return c->fail(A2AMD_EINVAL, "unit kind %d has no registers", u.kind);
+	  default: {	// fm.c:403-483: phase | p a fb | p1 a1 fb1 | ...
+		static const int nops[8] = { 1, 2, 3, 4, 3, 4, 2, 4 };
+		if(reg < 0 || reg > 3 * nops[u.kind - A2AMD_FM1])
+			return c->fail(A2AMD_EINVAL, "fm register %d", reg);
+		if(reg == 1)	// fm_Pitch: operator 0 is the absolute one
+			value = value + transpose + c->cfg.basepitch;
+		break;
+	  }
 	}
 	push_rec(c, u.voice, R_WRITE, u.chainpos, reg, value, dur, start);
 	return A2AMD_OK;

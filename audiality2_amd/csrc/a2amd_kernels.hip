@@ -15,6 +15,7 @@
 #include "a2amd_device.h"
 
 #include "a2amd_dsp.h"
+#include "a2amd_fm.h"
 
 // ---------------------------------------------------------------------------
 // per-wavefront working set in LDS
@@ -29,6 +30,7 @@ struct WaveLDS {
 struct Ctx {
 	const A2DParams *p;
 	WaveLDS *l;
+	const uint32_t *sine;	// fm sine table in LDS (when the context has fm units)
 	int lane;
 	int frag;		// fragment index inside the batch
 	int own_off, own_nch;
@@ -523,6 +525,48 @@ DEV void xinsert_process(Ctx &c, uint32_t desc, int offset, int frames)
 }
 
 // ---------------------------------------------------------------------------
+// fm1..fm4r, fm.c:194-322: a recurrence in time (operator feedback); lane 0
+// runs the window with the operators in registers
+// ---------------------------------------------------------------------------
+template<int NOPS, int OSBITS, int PAR>
+static __device__ __attribute__((noinline)) void fm_run(int *fw, const uint32_t *ptab, const uint32_t *sine,
+		int *dst, int frames, bool acc)
+{
+	FmOp op[NOPS];
+#pragma unroll
+	for(int i = 0; i < NOPS; ++i)
+		fmop_load(op[i], fw + i * FO_WORDS);
+	fm_window<NOPS, OSBITS, PAR>(op, ptab, sine, frames, [&](int s, int v) {
+		dst[s] = acc ? wadd(dst[s], v) : v;
+	});
+#pragma unroll
+	for(int i = 0; i < NOPS; ++i)
+		fmop_store(fw + i * FO_WORDS, op[i]);
+}
+
+DEV void fm_process(Ctx &c, uint32_t desc, int *w, int offset, int frames)
+{
+	if(c.lane == 0) {
+		int *fw = c.p->fmstate + (size_t)w[MW_SLOT] * A2D_FMSTATE;
+		const bool wired = A2D_WIRED(desc);
+		int *dst = (wired ? c.l->otile[0] : c.l->scratch[0]) + offset;
+		const bool acc = wired || A2D_ADD(desc);
+		const uint32_t *pt = c.p->ptab;
+		switch(A2D_KIND(desc)) {
+		  case A2D_FM1: fm_run<1, 0, 0>(fw, pt, c.sine, dst, frames, acc); break;
+		  case A2D_FM2: fm_run<2, 1, 0>(fw, pt, c.sine, dst, frames, acc); break;
+		  case A2D_FM3: fm_run<3, 2, 0>(fw, pt, c.sine, dst, frames, acc); break;
+		  case A2D_FM4: fm_run<4, 2, 0>(fw, pt, c.sine, dst, frames, acc); break;
+		  case A2D_FM3P: fm_run<3, 2, 1>(fw, pt, c.sine, dst, frames, acc); break;
+		  case A2D_FM4P: fm_run<4, 2, 1>(fw, pt, c.sine, dst, frames, acc); break;
+		  case A2D_FM2R: fm_run<2, 1, 2>(fw, pt, c.sine, dst, frames, acc); break;
+		  case A2D_FM4R: fm_run<4, 2, 2>(fw, pt, c.sine, dst, frames, acc); break;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+	}
+}
+
+// ---------------------------------------------------------------------------
 // control writes and unit init (uniform; lane 0 commits)
 // ---------------------------------------------------------------------------
 DEV void unit_init(const A2DParams &p, uint32_t desc, int *w, const A2DRec &r)
@@ -569,7 +613,14 @@ DEV void unit_init(const A2DParams &p, uint32_t desc, int *w, const A2DRec &r)
 		w[DW_BUFIDX] = r.value;
 		break;
 	  }
-	  default: break;
+	  case A2D_INLINE: case A2D_XINSERT:
+		break;
+	  default:	// fm: value = transpose + basepitch, start = wake fraction, dur = pool slot
+		w[MW_SLOT] = (int)r.dur;
+		fm_init_words(p.ptab, p.fmstate + (size_t)r.dur * A2D_FMSTATE, fm_nops(A2D_KIND(desc)),
+				r.value, r.start & 0xffu);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+		break;
 	}
 }
 
@@ -618,7 +669,13 @@ DEV void unit_write(const A2DParams &p, uint32_t desc, int *w, const A2DRec &r)
 		else if(reg < 7)
 			w[DW_FBDELAY + reg] = v;
 		break;
-	  default: break;
+	  case A2D_INLINE: case A2D_XINSERT:
+		break;
+	  default:	// fm.c:403-483
+		fm_write_words(p.fmstate + (size_t)w[MW_SLOT] * A2D_FMSTATE, fm_nops(A2D_KIND(desc)),
+				reg, v, start, dur);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+		break;
 	}
 }
 
@@ -649,6 +706,7 @@ DEV void process_window(Ctx &c, const A2DVoice &v, int offset, int frames)
 		  case A2D_FBDELAY: fbd_process(c, desc, w, offset, frames); break;
 		  case A2D_INLINE: inline_process(c, desc, offset, frames); break;
 		  case A2D_XINSERT: xinsert_process(c, desc, offset, frames); break;
+		  default: fm_process(c, desc, w, offset, frames); break;
 		}
 		lds_sync();
 	}
@@ -660,7 +718,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK)
 void k_voices(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw)
 {
 	__shared__ WaveLDS lds[WAVES_PER_BLOCK];
+	__shared__ uint32_t fmsine[2048];
 	const A2DParams &p = *pp;
+	if(p.fmstate) {		// the context has fm units
+		for(int i = threadIdx.x; i < 2048; i += 64 * WAVES_PER_BLOCK)
+			fmsine[i] = p.fmsine[i];
+		__syncthreads();
+	}
 	const int wv = threadIdx.x >> 6;
 	const int lane = threadIdx.x & 63;
 	const int gw = blockIdx.x * WAVES_PER_BLOCK + wv;
@@ -672,6 +736,7 @@ void k_voices(const A2DParams *__restrict__ pp, const int *__restrict__ list, in
 	c.p = pp;
 	c.l = &lds[wv];
 	c.lane = lane;
+	c.sine = fmsine;
 	c.omask = 0;
 	for(int ch = 0; ch < A2D_MAXCH; ++ch) {
 		c.l->otile[ch][lane] = 0;

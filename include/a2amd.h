@@ -71,6 +71,17 @@ typedef enum a2amd_unitkind {
 	A2AMD_FBDELAY,       /* src/units/fbdelay.c  regs: fbdelay ldelay rdelay drygain fbgain lgain rgain */
 	A2AMD_INLINE,        /* src/units/inline.c + src/core.c:1763-1776         */
 	A2AMD_XINSERT,       /* src/units/xinsert.c:145-161 (bypass only)         */
+	/* the FM oscillators of src/units/fm.c.  regs, in
+	 * order: phase, then p a fb / p1 a1 fb1 / p2 a2 fb2 / p3 a3 fb3 for as
+	 * many operators as the unit has (fm.c:54-79). */
+	A2AMD_FM1,           /* fm.c:532-552  o0 ->                               */
+	A2AMD_FM2,           /* fm.c:579-599  o1 -> o0 ->                         */
+	A2AMD_FM3,           /* fm.c:631-651  o2 -> o1 -> o0 ->                   */
+	A2AMD_FM4,           /* fm.c:688-708  o3 -> o2 -> o1 -> o0 ->             */
+	A2AMD_FM3P,          /* fm.c:719-739  (o1 + o2) -> o0 ->                  */
+	A2AMD_FM4P,          /* fm.c:752-772  (o1 + o2 + o3) -> o0 ->             */
+	A2AMD_FM2R,          /* fm.c:783-803  o0 * o1 (ring modulator)            */
+	A2AMD_FM4R,          /* fm.c:814-834  (o2 -> o0) * (o3 -> o1)             */
 	A2AMD_NKINDS
 } a2amd_unitkind;
 

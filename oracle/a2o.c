@@ -292,6 +292,15 @@ typedef struct a2o_unit
 	int		drygain, fbgain, lgain, rgain;
 	int32_t		*lbuf, *rbuf;
 	int		bufpos;
+	/* fm (A2_fm / A2_fmosc, fm.c:81-105) */
+	int		nops;
+	struct a2o_fmosc
+	{
+		ramper		a, fb, p;
+		int		last_pitch;
+		unsigned	phase, dphase;
+		int		last;
+	} op[4];
 } a2o_unit;
 
 typedef struct a2o_voice
@@ -595,6 +604,44 @@ static void wtosc_set_phase(a2o_ctx *c, a2o_unit *o, int ph, unsigned sst)
 	o->phase = (uint64_t)((int64_t)ph * w->period << 8);
 }
 
+/* ---- fm.c: structure tables, sine table, phase -----------------------------*/
+
+/* operators / oversampling bits / structure (0 chain, 1 parallel modulators,
+ * 2 ring modulator) per unit kind.  fm.c only includes fm.h -> a2_units.h, never
+ * config.h, so A2_HIFI (config.h:108) is NOT defined where fm.c:36-52 picks the
+ * oversampling: the unit is built with the "standard" factors 1/2/4/4, and
+ * fm3p/fm4p/fm4r use fm3's, fm2r fm2's (fm.c:280-322). */
+static const struct { int nops, osbits, parallel; } fm_shape[8] = {
+	{ 1, 0, 0 }, { 2, 1, 0 }, { 3, 2, 0 }, { 4, 2, 0 },	/* fm1..fm4 */
+	{ 3, 2, 1 }, { 4, 2, 1 },				/* fm3p fm4p */
+	{ 2, 1, 2 }, { 4, 2, 2 }				/* fm2r fm4r */
+};
+#define IS_FM(k)	((k) >= A2AMD_FM1 && (k) <= A2AMD_FM4R)
+
+/* fm_OpenState, fm.c:493-501: one period of sine + 1 pad sample */
+static int16_t fm_sine[2049];
+static int fm_sine_ready;
+static void fm_build_sine(void)
+{
+	int s;
+	if(fm_sine_ready)
+		return;
+	for(s = 0; s < 2049; ++s)
+		fm_sine[s] = (int16_t)(sin(s * 2.0f * M_PI / 2048) * 32767.0f);
+	fm_sine_ready = 1;
+}
+
+/* fm_set_phase, fm.c:327-335 */
+static void fm_set_phase(a2o_unit *fm, int ph, unsigned sst)
+{
+	int i;
+	for(i = 0; i < fm->nops; ++i)
+	{
+		int ssph = (int)((unsigned)ph + (sst * (fm->op[i].dphase >> 8) >> 8));
+		fm->op[i].phase = (unsigned)((int)((unsigned)ssph * 2048u) >> 8);
+	}
+}
+
 static void f12_set_q(a2o_unit *f, int v, int start, int dur);
 static void f12_set_cutoff(a2o_ctx *c, a2o_unit *f, int v, int transpose,
 		int start, int dur);
@@ -722,6 +769,24 @@ int a2o_unit_init(a2o_ctx *c, uint64_t key, int kind, unsigned flags,
 		break;
 	  case A2AMD_INLINE:	/* a2i_Initialize, inline.c:26-39 */
 	  case A2AMD_XINSERT:	/* xi_Initialize, xinsert.c:196-212 */
+		break;
+	  default:		/* fm_Initialize, fm.c:338-400 */
+		if(nin != 0 || nout != 1)
+			return fail(c, A2AMD_EINVAL, "fm %d->%d", nin, nout);
+		fm_build_sine();
+		u->nops = fm_shape[kind - A2AMD_FM1].nops;
+		for(i = 0; i < u->nops; ++i)
+		{
+			ramp_init(&u->op[i].a, 0);
+			ramp_init(&u->op[i].fb, 0);
+			ramp_init(&u->op[i].p, transpose + c->cfg.basepitch);
+			u->op[i].last_pitch = 0;
+			u->op[i].last = 0;
+		}
+		u->op[0].dphase = a2o_p2i(c->ptab, u->op[0].p.value >> 8);
+		for(i = 1; i < u->nops; ++i)
+			u->op[i].dphase = u->op[0].dphase;
+		fm_set_phase(u, 0, wakefrac & 0xff);
 		break;
 	}
 	return id;
@@ -861,8 +926,29 @@ int a2o_unit_write(a2o_ctx *c, int id, int reg, int value, unsigned start,
 		}
 		break;
 	  default:
-		return fail(c, A2AMD_EINVAL, "unit kind %d has no registers",
-				u->kind);
+		if(!IS_FM(u->kind))
+			return fail(c, A2AMD_EINVAL, "unit kind %d has no registers",
+					u->kind);
+		/* fm.c:403-483: phase | p a fb | p1 a1 fb1 | ... */
+		if(reg < 0 || reg > 3 * u->nops)
+			return fail(c, A2AMD_EINVAL, "fm reg %d", reg);
+		if(reg == 0)
+			fm_set_phase(u, value, start);
+		else
+		{
+			struct a2o_fmosc *o = &u->op[(reg - 1) / 3];
+			switch((reg - 1) % 3)
+			{
+			  case 0:	/* fm_Pitch: only op0 is absolute */
+				if(reg == 1)
+					value += transpose + c->cfg.basepitch;
+				ramp_set(&o->p, value, start, dur);
+				break;
+			  case 1: ramp_set(&o->a, value, start, dur); break;
+			  case 2: ramp_set(&o->fb, value, start, dur); break;
+			}
+		}
+		break;
 	}
 	return A2AMD_OK;
 }
@@ -1255,6 +1341,114 @@ static void fbdelay_process(a2o_unit *fbd, int32_t **in, int32_t **out,
  * the innermost inline window open when the voice first processes, or the
  * master bus (A2_state.master) when none is.
  */
+
+/* ---- fm.c ----------------------------------------------------------------*/
+
+/* a2_Lerp, a2_dsp.h:50-55 */
+static int lerp16(const int16_t *d, unsigned ph)
+{
+	int i = (int)(ph >> 8);
+	int x = (int)(ph & 0xff);
+	return (d[i] * (256 - x) + d[i + 1] * x) >> 8;
+}
+
+/* fm_osc, fm.c:111-123 */
+static int32_t fm_osc(struct a2o_fmosc *o, int mod)
+{
+	int fb = (int)((int64_t)o->last * o->fb.value >> 17);
+	unsigned ph = (o->phase + (unsigned)mod + (unsigned)fb) >> (24 - 8 - 11);
+	o->last = lerp16(fm_sine, ph & ((2048u << 8) - 1));
+	return (int32_t)((int64_t)o->last * o->a.value >> 16);
+}
+
+/* fm_run_pitch, fm.c:126-141: the ramper only ever runs half a window */
+static void fm_run_pitch(a2o_ctx *c, struct a2o_fmosc *o, unsigned frames,
+		int detune)
+{
+	int newpitch;
+	ramp_prepare(&o->p, (int)frames);
+	ramp_run(&o->p, (int)(frames >> 1));
+	newpitch = (int)((unsigned)o->p.value + (unsigned)detune) >> 8;
+	if(newpitch != o->last_pitch)
+	{
+		o->dphase = a2o_p2i(c->ptab, newpitch);
+		o->last_pitch = newpitch;
+	}
+}
+
+/* fm_sample, fm.c:151-165 */
+static int fm_sample(a2o_unit *fm, int osbits, int parallel)
+{
+	int i, v = 0;
+	for(i = fm->nops - 1; i >= 0; --i)
+	{
+		if(i && parallel)
+			v = (int)((unsigned)v + (unsigned)fm_osc(&fm->op[i], 0));
+		else
+			v = fm_osc(&fm->op[i], v);
+		fm->op[i].phase += fm->op[i].dphase >> osbits;
+	}
+	return v;
+}
+
+/* fm_sample_rm, fm.c:172-192 */
+static int fm_sample_rm(a2o_unit *fm, int osbits)
+{
+	int i, v[2];
+	if(fm->nops == 2)
+		for(i = 0; i < 2; ++i)
+		{
+			v[i] = fm_osc(&fm->op[i], 0);
+			fm->op[i].phase += fm->op[i].dphase >> osbits;
+		}
+	else
+		for(i = 0; i < 2; ++i)
+		{
+			v[i] = fm_osc(&fm->op[i], fm_osc(&fm->op[i + 2], 0));
+			fm->op[i].phase += fm->op[i].dphase >> osbits;
+			fm->op[i + 2].phase += fm->op[i + 2].dphase >> osbits;
+		}
+	return (int)((int64_t)v[0] * v[1] >> 23);
+}
+
+/* fm_process, fm.c:194-233 */
+static void fm_process(a2o_ctx *c, a2o_unit *fm, int32_t *out, unsigned offset,
+		unsigned frames, int add)
+{
+	const int osbits = fm_shape[fm->kind - A2AMD_FM1].osbits;
+	const int parallel = fm_shape[fm->kind - A2AMD_FM1].parallel;
+	const unsigned oversample = 1u << osbits;
+	unsigned s, os, end = offset + frames;
+	int i, detune = 0;
+	for(i = 0; i < fm->nops; ++i)
+	{
+		ramp_prepare(&fm->op[i].a, (int)frames);
+		ramp_prepare(&fm->op[i].fb, (int)frames);
+		fm_run_pitch(c, &fm->op[i], frames, detune);
+		detune = fm->op[0].p.value;
+	}
+	for(s = offset; s < end; ++s)
+	{
+		unsigned vsum = 0;
+		for(os = 0; os < oversample; ++os)
+			if(parallel == 2)
+				vsum += (unsigned)fm_sample_rm(fm, osbits);
+			else
+				vsum += (unsigned)fm_sample(fm, osbits, parallel);
+		for(i = 0; i < fm->nops; ++i)
+		{
+			ramp_run(&fm->op[i].a, 1);
+			ramp_run(&fm->op[i].fb, 1);
+			/* "Fix the rounding error buildup!" */
+			fm->op[i].phase += fm->op[i].dphase & (oversample - 1);
+		}
+		if(add)
+			out[s] += (int)vsum >> osbits;
+		else
+			out[s] = (int)vsum >> osbits;
+	}
+}
+
 static void resolve_out(a2o_ctx *c, a2o_voice *v)
 {
 	int ch;
@@ -1358,6 +1552,9 @@ int a2o_unit_process(a2o_ctx *c, int id, unsigned offset, unsigned frames,
 				for(s = offset; s < offset + frames; ++s)
 					out[ch][s] = in[ch][s];
 		}
+		break;
+	  default:		/* fm*_Process[Add], fm.c:235-322 */
+		fm_process(c, u, out[0], offset, frames, add);
 		break;
 	}
 	return A2AMD_OK;

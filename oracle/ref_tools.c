@@ -42,7 +42,8 @@
 enum { T_FRAGMENT = 1, T_INIT, T_DEINIT, T_WRITE, T_PROCESS, T_INLINE_END,
 		T_WAVE, T_CONFIG };
 enum { K_WTOSC = 0, K_PANMIX, K_FILTER12, K_FBDELAY, K_INLINE, K_XINSERT,
-		K_COUNT };
+		K_FM1, K_FM2, K_FM3, K_FM4, K_FM3P, K_FM4P, K_FM2R, K_FM4R,
+		K_COUNT };	/* = a2amd_unitkind, include/a2amd.h */
 
 static FILE *tracef;
 static int trace_muted;		/* set while a2_Load() renders waves in a substate */
@@ -114,7 +115,10 @@ static inline XTRA *xtra(A2_unit *u)
 static const A2_unitdesc *orig[K_COUNT];
 static const char *orig_sym[K_COUNT] = {
 	"a2_wtosc_unitdesc", "a2_panmix_unitdesc", "a2_filter12_unitdesc",
-	"a2_fbdelay_unitdesc", "a2_inline_unitdesc", "a2_xinsert_unitdesc"
+	"a2_fbdelay_unitdesc", "a2_inline_unitdesc", "a2_xinsert_unitdesc",
+	"a2_fm1_unitdesc", "a2_fm2_unitdesc", "a2_fm3_unitdesc",
+	"a2_fm4_unitdesc", "a2_fm3p_unitdesc", "a2_fm4p_unitdesc",
+	"a2_fm2r_unitdesc", "a2_fm4r_unitdesc"
 };
 
 static const A2_unitdesc *get_orig(int k)
@@ -185,7 +189,7 @@ static void tr_write(A2_unit *u, int reg, int v, unsigned start, unsigned dur)
 
 #define WR(n) static void tr_write##n(A2_unit *u, int v, unsigned s, unsigned d) \
 	{ tr_write(u, n, v, s, d); }
-WR(0) WR(1) WR(2) WR(3) WR(4) WR(5) WR(6)
+WR(0) WR(1) WR(2) WR(3) WR(4) WR(5) WR(6) WR(7) WR(8) WR(9) WR(10) WR(11) WR(12)
 
 static A2_errors tr_init(int kind, A2_unit *u, A2_vmstate *vms, void *sd,
 		unsigned flags)
@@ -249,6 +253,14 @@ KIND_FUNCS(K_FILTER12, filter12)
 KIND_FUNCS(K_FBDELAY, fbdelay)
 KIND_FUNCS(K_INLINE, inl)
 KIND_FUNCS(K_XINSERT, xins)
+KIND_FUNCS(K_FM1, fm1)
+KIND_FUNCS(K_FM2, fm2)
+KIND_FUNCS(K_FM3, fm3)
+KIND_FUNCS(K_FM4, fm4)
+KIND_FUNCS(K_FM3P, fm3p)
+KIND_FUNCS(K_FM4P, fm4p)
+KIND_FUNCS(K_FM2R, fm2r)
+KIND_FUNCS(K_FM4R, fm4r)
 
 static const A2_crdesc wtosc_regs[] = {
 	{ "w", tr_write0 }, { "p", tr_write1 }, { "a", tr_write2 },
@@ -265,6 +277,16 @@ static const A2_crdesc fbdelay_regs[] = {
 	{ "fbdelay", tr_write0 }, { "ldelay", tr_write1 }, { "rdelay", tr_write2 },
 	{ "drygain", tr_write3 }, { "fbgain", tr_write4 }, { "lgain", tr_write5 },
 	{ "rgain", tr_write6 }, { NULL, NULL } };
+
+/* fm.c:509-530,562-577,603-629,654-686: a prefix of one list */
+#define FM_REGS(n) static const A2_crdesc fm##n##_regs[] = { \
+	{ "phase", tr_write0 }, { "p", tr_write1 }, { "a", tr_write2 }, \
+	{ "fb", tr_write3 }, { n > 1 ? "p1" : NULL, n > 1 ? tr_write4 : NULL }, \
+	{ "a1", tr_write5 }, { "fb1", tr_write6 }, \
+	{ n > 2 ? "p2" : NULL, n > 2 ? tr_write7 : NULL }, { "a2", tr_write8 }, \
+	{ "fb2", tr_write9 }, { n > 3 ? "p3" : NULL, n > 3 ? tr_write10 : NULL }, \
+	{ "a3", tr_write11 }, { "fb3", tr_write12 }, { NULL, NULL } };
+FM_REGS(1) FM_REGS(2) FM_REGS(3) FM_REGS(4)
 
 /* The interposing descriptors.  Same names / limits as the originals
  * (wtosc.c:516, panmix.c:313, filter12.c:241, fbdelay.c:289, inline.c:50,
@@ -286,6 +308,16 @@ const A2_unitdesc a2_inline_unitdesc = { "inline", 0, NULL, NULL, NULL,
 const A2_unitdesc a2_xinsert_unitdesc = { "xinsert", A2_MATCHIO | A2_XINSERT,
 	NULL, NULL, NULL, 1, A2_MAXCHANNELS, 1, A2_MAXCHANNELS, BLOCKSIZE,
 	xins_init, xins_deinit, xins_open, xins_close };
+
+/* fm.c:532,579,631,688,719,752,783,814; fm_Initialize reads the structure off
+ * the descriptor's name (fm.c:346-350), so the names are load-bearing */
+#define FM_DESC(sym, nm, regs) const A2_unitdesc a2_##sym##_unitdesc = { nm, 0, \
+	regs, NULL, NULL, 0, 0, 1, 1, BLOCKSIZE, sym##_init, sym##_deinit, \
+	sym##_open, sym##_close };
+FM_DESC(fm1, "fm1", fm1_regs) FM_DESC(fm2, "fm2", fm2_regs)
+FM_DESC(fm3, "fm3", fm3_regs) FM_DESC(fm4, "fm4", fm4_regs)
+FM_DESC(fm3p, "fm3p", fm3_regs) FM_DESC(fm4p, "fm4p", fm4_regs)
+FM_DESC(fm2r, "fm2r", fm2_regs) FM_DESC(fm4r, "fm4r", fm4_regs)
 
 /* ---------------------------------------------------------------------- */
 

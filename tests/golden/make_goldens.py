@@ -41,6 +41,10 @@ CASES = [
     # corner cases of every unit; renders its own waves at load time, which the
     # reference only manages on an A2_REALTIME master state (see ref_tools.c)
     ("edge", f"{A2S}/edge.a2s", "Main", 4 * 48000, ["0.2"]),
+    # the FM oscillator units
+    ("fm", f"{A2S}/fm.a2s", "Main", 3 * 48000, ["0.15"]),
+    ("fmtest3", f"{REF}/benchmark/fmtest3.a2s", "Song", 5 * 48000, []),
+    ("fmtest4", f"{REF}/benchmark/fmtest4.a2s", "Song", 5 * 48000, []),
     # the reference's own benchmark songs (benchmark/RESULTS): all five use only
     # units on the hot path
     ("k2intro", f"{REF}/benchmark/k2intro.a2s", "Song", 6 * 48000, []),
