@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include "a2amd_device.h"
 #include "a2amd_dsp.h"
+#include "a2amd_fm.h"
 
 #define FAST_WPB   4		// wavefronts per workgroup
 #define FAST_FCH   8		// fragments whose bus sums stay in registers at a time
@@ -1267,6 +1268,355 @@ int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, co
 	hipLaunchKernelGGL(k_leaf_oscfiltpan, dim3(nblocks), dim3(64 * FAST_WPB), lds, (hipStream_t)stream,
 			dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
 	return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// fmN -> panmix 1->2 leaf voices (fm.c + panmix.c)
+// ---------------------------------------------------------------------------
+// An FM voice is a recurrence in time (operator feedback), so here a lane is a
+// voice for the oscillator part: every lane runs fm_process (fm.c:194-233) over
+// the fragment with its operators in registers, the sine table in LDS, and
+// writes its 64 samples into its row of a [voices][64+1] LDS tile.  The mix-down
+// then runs frame = lane as in the other leaf kernels: row v * pan gains, summed
+// over the voices of the wavefront in registers, one atomic per (fragment,
+// channel, frame) into the bus.  One launch per unit kind present (the host
+// groups the list by kind), so the operator count / oversampling / structure
+// are compile-time constants of the body.
+enum { PV_VOL = 0, PV_PAN = 4, PV_NWORDS = 8 };
+
+// frames [off, off + len) of panmix 1->2 adding into the voice's output bus
+// (panmix_Process12Add, panmix.c:78-125) for input x, frame = lane
+DEV void pan_window_s(Ramp &vol, Ramp &pan, int x, int off, int len, int lane, int &acc0, int &acc1)
+{
+	const bool clamp = pan.target > 0xffffff || pan.target < -0xffffff ||
+			pan.value > 0xffffff || pan.value < -0xffffff;
+	ramp_prepare_s(vol, len);
+	ramp_prepare_s(pan, len);
+	const int k = lane - off;
+	if(k >= 0 && k < len) {
+		int vk = wadd(vol.value, wmul(vol.delta, k));
+		int pk = wadd(pan.value, wmul(pan.delta, k));
+		int vp = mul64s(pk, vk, 24);
+		int v0 = wsub(vk, vp), v1 = wadd(vk, vp);
+		if(clamp) {
+			int lim = wshl(vk, 1);
+			if(v0 > lim) v0 = lim;
+			if(v1 > lim) v1 = lim;
+		}
+		acc0 = wadd(acc0, mul64s(x, v0, 24));
+		acc1 = wadd(acc1, mul64s(x, v1, 24));
+	}
+	ramp_run(vol, len);
+	ramp_run(pan, len);
+}
+
+// Unlike the wavetable leaf kernels this one also executes the voices' command
+// records (control writes, sub-fragment windows, births and deaths): FM voices
+// in real scripts are enveloped by the VM every few milliseconds, and sending
+// each such voice-fragment through the general kernel (one lane per voice)
+// would cost more than the rest of the batch.  The oscillator stage is frame
+// synchronous - all lanes step through the fragment's frames together - and a
+// lane whose window ended consumes its own records up to the next window
+// (divergent, rare); the mix-down stage walks the same records for the panmix
+// unit, voice by voice, on the scalar unit.
+template<int NOPS, int OSBITS, int PAR>
+DEV void fmpan_body(const A2DParams &p, const int *__restrict__ list, int first, int nv, int lane,
+		int *tile, const uint32_t *sine, const A2DVoice *__restrict__ voices, int *ustate,
+		int *fmstate, const uint32_t *__restrict__ ptab, int *__restrict__ busmem)
+{
+	const int nfrags = p.nfrags;
+	const int dbg = p.debug;
+	const A2DRec *__restrict__ recs = p.recs;
+	int ffr[A2D_MAXBATCH / 64];
+#pragma unroll
+	for(int k = 0; k < A2D_MAXBATCH / 64; ++k)
+		ffr[k] = (k * 64 + lane < nfrags) ? p.fragframes[k * 64 + lane] : 0;
+
+	int pv[PV_NWORDS];
+#pragma unroll
+	for(int k = 0; k < PV_NWORDS; ++k)
+		pv[k] = 0;
+	FmOp op[NOPS];
+#pragma unroll
+	for(int i = 0; i < NOPS; ++i) {
+		op[i].a = op[i].fb = op[i].p = Ramp{ 0, 0, 0, 0 };
+		op[i].last_pitch = op[i].last = 0;
+		op[i].phase = op[i].dphase = 0;
+	}
+	unsigned step[NOPS], fix[NOPS];
+#pragma unroll
+	for(int i = 0; i < NOPS; ++i)
+		step[i] = fix[i] = 0;
+	int slot = -1, u0 = 0, u1 = 0, my_off = -1, my_nch = 2, v0 = 0, v1 = 0, settled = 0;
+	int run_first = 0, run_count = 0, fmslot = -1;
+	int actB = 0;		// the voice is alive (vactive), as seen by the oscillator stage
+	if(lane < nv)
+		slot = list[first + lane];
+	const bool mine = slot >= 0;
+	const unsigned long long mine_mask = __ballot(mine);
+	if(mine) {
+		const A2DVoice &vc = voices[slot];
+		u0 = vc.unit[0];
+		u1 = vc.unit[1];
+		my_off = vc.out_off;
+		my_nch = vc.out_nch;
+		const A2DRun run = p.runs[slot];
+		run_first = run.first;
+		run_count = run.count;
+		actB = p.vactive[slot];
+	}
+	bool touched = mine && actB;	// the state in our registers is the voice's and goes back to memory
+	if(touched) {
+		fmslot = ustate[(size_t)u0 * A2D_USTATE + MW_SLOT];
+		const int *fw = fmstate + (size_t)fmslot * A2D_FMSTATE;
+#pragma unroll
+		for(int i = 0; i < NOPS; ++i)
+			fmop_load(op[i], fw + i * FO_WORDS);
+		const int *w1 = ustate + (size_t)u1 * A2D_USTATE;
+#pragma unroll
+		for(int k = 0; k < 4; ++k) {
+			pv[PV_VOL + k] = w1[PW_VOL + k];
+			pv[PV_PAN + k] = w1[PW_PAN + k];
+		}
+		settled = !run_count && !(pv[PV_VOL + 3] | pv[PV_VOL + 2] | pv[PV_PAN + 3] | pv[PV_PAN + 2]) &&
+				pv[PV_VOL] == pv[PV_VOL + 1] && pv[PV_PAN] == pv[PV_PAN + 1];
+		if(settled) {
+			const int vol = pv[PV_VOL], pan = pv[PV_PAN];
+			const int vp = mul64s(pan, vol, 24);
+			v0 = wsub(vol, vp);
+			v1 = wadd(vol, vp);
+			if(pan > 0xffffff || pan < -0xffffff) {
+				int lim = wshl(vol, 1);
+				if(v0 > lim) v0 = lim;
+				if(v1 > lim) v1 = lim;
+			}
+		}
+	}
+	int curB = 0, curC = 0, actC = actB;	// record cursors / liveness of the two stages
+	int *row = tile + lane * FILT_PITCH;
+	// wave-uniform facts about the voices as bit masks: tests on the scalar unit
+	const unsigned long long settled_mask = __ballot(settled != 0);
+	const int prev_off = __shfl_up(my_off, 1);
+	const unsigned long long newbus_mask = __ballot(mine && lane > 0 && my_off != prev_off);
+
+	for(int f = 0; f < nfrags; ++f) {
+		const int n = frames_of(ffr, f);
+		// ---- oscillators, voice = lane, all lanes in step ----
+		int wstart = A2D_FRAG, wend = 0;	// no window open
+		bool pending = mine && curB < run_count && (int)A2D_RFRAG(recs[run_first + curB].head) == f;
+		if(mine && !pending && actB) {
+			// no records: the engine called Process(0, frames) (core.c:1875-1876)
+			wstart = 0;
+			wend = n;
+			fm_prepare<NOPS, OSBITS>(op, ptab, n, step, fix);
+		}
+		const unsigned long long recs_mask = __ballot(pending);	// voices with records in this fragment
+		if(!recs_mask) {
+			// nobody in this wavefront has records in this fragment: plain loop
+			if(wend)
+				for(int s = 0; s < n; ++s)
+					row[s] = fm_frame<NOPS, OSBITS, PAR>(op, step, fix, sine);
+		} else
+		for(int s = 0; s <= n; ++s) {
+			if(pending && s >= wend) {
+				// records up to and including the next window (at s == n:
+				// whatever follows the last window of the fragment)
+				for(;;) {
+					if(curB >= run_count) {
+						pending = false;
+						break;
+					}
+					const A2DRec r = recs[run_first + curB];
+					if((int)A2D_RFRAG(r.head) != f) {
+						pending = false;
+						break;
+					}
+					++curB;
+					const int rop = (int)A2D_ROP(r.head), unit = (int)A2D_RUNIT(r.head);
+					if(rop == R_SEG) {
+						if(actB) {
+							wstart = (int)(r.dur & 0xffffu);
+							wend = wstart + (int)(r.dur >> 16);
+							fm_prepare<NOPS, OSBITS>(op, ptab, (int)(r.dur >> 16), step, fix);
+							break;
+						}
+					} else if(rop == R_INIT) {
+						if(unit == 0) {	// value = transpose + basepitch, start = wake fraction, dur = pool slot
+							fm_init_ops<NOPS>(op, ptab, r.value, r.start & 0xffu);
+							fmslot = (int)r.dur;
+							touched = true;
+						}
+						actB = 1;
+					} else if(rop == R_WRITE) {
+						if(unit == 0)
+							fm_write_ops<NOPS>(op, (int)A2D_RREG(r.head), r.value, (int)r.start, (int)r.dur);
+					} else if(rop == R_KILL)
+						actB = 0;
+				}
+			}
+			if(s >= wstart && s < wend)
+				row[s] = fm_frame<NOPS, OSBITS, PAR>(op, step, fix, sine);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		// ---- pan + mix-down, frame = lane, voice by voice ----
+		int acc0 = 0, acc1 = 0;
+		int cur_off = rdl(my_off, 0), cur_nch = rdl(my_nch, 0);
+		for(int v = 0; v < nv; ++v) {
+			if(!((mine_mask >> v) & 1ull))
+				continue;
+			if((newbus_mask >> v) & 1ull) {
+				if(cur_off >= 0 && !(dbg & 1)) {
+					int *dst = busmem + cur_off + (size_t)f * cur_nch * A2D_FRAG;
+					if(acc0) atomicAdd(&dst[lane], acc0);
+					if(acc1) atomicAdd(&dst[A2D_FRAG + lane], acc1);
+				}
+				acc0 = acc1 = 0;
+				cur_off = rdl(my_off, v);
+				cur_nch = rdl(my_nch, v);
+			}
+			const int y = tile[v * FILT_PITCH + lane];
+			const bool recs_now = (recs_mask >> v) & 1ull;
+			if(!recs_now && ((settled_mask >> v) & 1ull)) {
+				const int g0 = rdl(v0, v), g1 = rdl(v1, v);
+				if(lane < n) {
+					acc0 = wadd(acc0, mul64s(y, g0, 24));
+					acc1 = wadd(acc1, mul64s(y, g1, 24));
+				}
+				continue;
+			}
+			const int rc = rdl(run_count, v), rf = rdl(run_first, v);
+			int cc = rdl(curC, v);
+			int act = rdl(actC, v);
+			if(!recs_now && !act)
+				continue;
+			Ramp vol, pan;
+			vol.value = rdl(pv[PV_VOL], v); vol.target = rdl(pv[PV_VOL + 1], v);
+			vol.delta = rdl(pv[PV_VOL + 2], v); vol.timer = rdl(pv[PV_VOL + 3], v);
+			pan.value = rdl(pv[PV_PAN], v); pan.target = rdl(pv[PV_PAN + 1], v);
+			pan.delta = rdl(pv[PV_PAN + 2], v); pan.timer = rdl(pv[PV_PAN + 3], v);
+			if(!recs_now)
+				pan_window_s(vol, pan, y, 0, n, lane, acc0, acc1);
+			else
+				for(; cc < rc; ++cc) {
+					const A2DRec r = recs[rf + cc];
+					if((int)A2D_RFRAG(r.head) != f)
+						break;
+					const int rop = (int)A2D_ROP(r.head), unit = (int)A2D_RUNIT(r.head);
+					if(rop == R_SEG) {
+						if(act)
+							pan_window_s(vol, pan, y, (int)(r.dur & 0xffffu), (int)(r.dur >> 16),
+									lane, acc0, acc1);
+					} else if(rop == R_INIT) {
+						if(unit == 1) {	// panmix_Initialize, panmix.c:252-284
+							ramp_init(vol, 65536);
+							ramp_init(pan, 0);
+						}
+						act = 1;
+					} else if(rop == R_WRITE) {
+						if(unit == 1) {
+							if(A2D_RREG(r.head))
+								ramp_set(pan, r.value, (int)r.start, (int)r.dur);
+							else
+								ramp_set(vol, r.value, (int)r.start, (int)r.dur);
+						}
+					} else if(rop == R_KILL)
+						act = 0;
+				}
+			const bool me = lane == v;
+			WRL(pv[PV_VOL], vol.value); WRL(pv[PV_VOL + 1], vol.target);
+			WRL(pv[PV_VOL + 2], vol.delta); WRL(pv[PV_VOL + 3], vol.timer);
+			WRL(pv[PV_PAN], pan.value); WRL(pv[PV_PAN + 1], pan.target);
+			WRL(pv[PV_PAN + 2], pan.delta); WRL(pv[PV_PAN + 3], pan.timer);
+			WRL(curC, cc);
+			WRL(actC, act);
+		}
+		if(cur_off >= 0 && !(dbg & 1)) {
+			int *dst = busmem + cur_off + (size_t)f * cur_nch * A2D_FRAG;
+			if(acc0) atomicAdd(&dst[lane], acc0);
+			if(acc1) atomicAdd(&dst[A2D_FRAG + lane], acc1);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
+
+	if(mine)
+		p.vactive[slot] = actB;
+	if(touched) {
+		int *fw = fmstate + (size_t)fmslot * A2D_FMSTATE;
+#pragma unroll
+		for(int i = 0; i < NOPS; ++i)
+			fmop_store(fw + i * FO_WORDS, op[i]);
+		ustate[(size_t)u0 * A2D_USTATE + MW_SLOT] = fmslot;
+		int *w1 = ustate + (size_t)u1 * A2D_USTATE;
+#pragma unroll
+		for(int k = 0; k < 4; ++k) {
+			w1[PW_VOL + k] = pv[PV_VOL + k];
+			w1[PW_PAN + k] = pv[PV_PAN + k];
+		}
+	}
+}
+
+// one instantiation per unit kind: each gets the registers it needs (fm1 a
+// third of fm4's), and with them its own occupancy
+template<int NOPS, int OSBITS, int PAR>
+__global__ __launch_bounds__(64 * FAST_WPB)
+void k_leaf_fmpan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
+		const A2DVoice *__restrict__ voices, int *ustate,
+		int *fmstate, const uint32_t *__restrict__ fmsine, const uint32_t *__restrict__ ptab,
+		int *__restrict__ busmem)
+{
+	extern __shared__ __attribute__((aligned(16))) int tiles[];
+	__shared__ uint32_t sine[2048];		// static: a constant LDS address folds into ds_read's offset
+	for(int i = threadIdx.x; i < 2048; i += 64 * FAST_WPB)
+		sine[i] = fmsine[i];
+	__syncthreads();
+	const int wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	const int first = (blockIdx.x * FAST_WPB + wv) * vpw;
+	if(first >= nlist)
+		return;
+	fmpan_body<NOPS, OSBITS, PAR>(*pp, list, first, min(vpw, nlist - first), lane,
+			tiles + wv * vpw * FILT_PITCH, sine, voices, ustate, fmstate, ptab, busmem);
+}
+
+template<int NOPS, int OSBITS, int PAR>
+static int launch_fmpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
+		int vpw, hipStream_t stream)
+{
+	const int nwaves = (nlist + vpw - 1) / vpw;
+	const int nblocks = (nwaves + FAST_WPB - 1) / FAST_WPB;
+	const size_t lds = (size_t)FAST_WPB * vpw * FILT_PITCH * sizeof(int);
+	static bool attr_set = false;
+	if(!attr_set) {
+		(void)hipFuncSetAttribute((const void *)k_leaf_fmpan<NOPS, OSBITS, PAR>,
+				hipFuncAttributeMaxDynamicSharedMemorySize,
+				FAST_WPB * FILT_MAXV * FILT_PITCH * (int)sizeof(int));
+		attr_set = true;
+	}
+	hipLaunchKernelGGL((k_leaf_fmpan<NOPS, OSBITS, PAR>), dim3(nblocks), dim3(64 * FAST_WPB), lds, stream,
+			dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.fmstate, hp.fmsine, hp.ptab, hp.busmem);
+	return (int)hipGetLastError();
+}
+
+int a2d_launch_leaf_fmpan(const A2DParams *dparams, const A2DParams &hp, int kind, const int *dlist, int nlist,
+		int vpw, void *stream)
+{
+	if(nlist <= 0)
+		return 0;
+	vpw = min(max(vpw, 1), FILT_MAXV);
+	hipStream_t st = (hipStream_t)stream;
+	switch(kind) {
+	  case A2D_FM1: return launch_fmpan<1, 0, 0>(dparams, hp, dlist, nlist, vpw, st);
+	  case A2D_FM2: return launch_fmpan<2, 1, 0>(dparams, hp, dlist, nlist, vpw, st);
+	  case A2D_FM3: return launch_fmpan<3, 2, 0>(dparams, hp, dlist, nlist, vpw, st);
+	  case A2D_FM4: return launch_fmpan<4, 2, 0>(dparams, hp, dlist, nlist, vpw, st);
+	  case A2D_FM3P: return launch_fmpan<3, 2, 1>(dparams, hp, dlist, nlist, vpw, st);
+	  case A2D_FM4P: return launch_fmpan<4, 2, 1>(dparams, hp, dlist, nlist, vpw, st);
+	  case A2D_FM2R: return launch_fmpan<2, 1, 2>(dparams, hp, dlist, nlist, vpw, st);
+	  case A2D_FM4R: return launch_fmpan<4, 2, 2>(dparams, hp, dlist, nlist, vpw, st);
+	}
+	return -1;
 }
 
 int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, int nfrags, void *stream)

@@ -90,6 +90,22 @@ DEV void fm_run_pitch(const uint32_t *ptab, FmOp &o, int frames, int detune)
 	}
 }
 
+// 24 bit multiply(-add) the compiler cannot strength-"reduce" back into the
+// quarter-rate 32 bit v_mul_lo_u32
+DEV int fm_mul24(int a, int b)
+{
+	int r;
+	asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+
+DEV int fm_mad24(int a, int b, int c)
+{
+	int r;
+	asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
+
 struct FmGain { int ah, al, fbh, fbl; };
 
 DEV void fm_gain(FmGain &g, const FmOp &o)
@@ -106,14 +122,14 @@ DEV int fm_osc(FmOp &o, const FmGain &g, int mod, const uint32_t *sine)
 	const uint32_t e = sine[(ph >> 13) & 2047u];
 	const int x = (int)((ph >> 5) & 255u);
 	o.last = (int)(int16_t)(e & 0xffffu) + (__mul24((int)e >> 16, x) >> 8);
-	return __mul24(o.last, g.ah) + (__mul24(o.last, g.al) >> 16);
+	return fm_mad24(o.last, g.ah, fm_mul24(o.last, g.al) >> 16);
 }
 
-// One window of fm_process (fm.c:194-233) for one voice.  PAR: 0 chain,
-// 1 parallel modulators, 2 ring modulator.  emit(s, value) receives frame s of
-// the window (0-based).
-template<int NOPS, int OSBITS, int PAR, typename Emit>
-DEV void fm_window(FmOp (&op)[NOPS], const uint32_t *ptab, const uint32_t *sine, int frames, Emit emit)
+// fm_process (fm.c:194-233) in two pieces: the head of a window (rampers
+// prepared for 'frames' frames, pitches run, per-subsample phase steps derived)
+// and one output frame.  PAR: 0 chain, 1 parallel modulators, 2 ring modulator.
+template<int NOPS, int OSBITS>
+DEV void fm_prepare(FmOp (&op)[NOPS], const uint32_t *ptab, int frames, unsigned (&step)[NOPS], unsigned (&fix)[NOPS])
 {
 	int detune = 0;
 #pragma unroll
@@ -123,53 +139,111 @@ DEV void fm_window(FmOp (&op)[NOPS], const uint32_t *ptab, const uint32_t *sine,
 		fm_run_pitch(ptab, op[i], frames, detune);
 		detune = op[0].p.value;
 	}
-	unsigned step[NOPS], fix[NOPS];
 #pragma unroll
 	for(int i = 0; i < NOPS; ++i) {
 		step[i] = op[i].dphase >> OSBITS;
 		fix[i] = op[i].dphase & ((1u << OSBITS) - 1u);	// "Fix the rounding error buildup!"
 	}
-	for(int s = 0; s < frames; ++s) {
-		FmGain g[NOPS];
+}
+
+template<int NOPS, int OSBITS, int PAR>
+DEV int fm_frame(FmOp (&op)[NOPS], const unsigned (&step)[NOPS], const unsigned (&fix)[NOPS], const uint32_t *sine)
+{
+	FmGain g[NOPS];
+#pragma unroll
+	for(int i = 0; i < NOPS; ++i)
+		fm_gain(g[i], op[i]);
+	int vsum = 0;
+#pragma unroll 1
+	for(int os = 0; os < (1 << OSBITS); ++os) {
+		int v;
+		if(PAR == 2) {			// fm_sample_rm, fm.c:172-192
+			int v0, v1;
+			if(NOPS == 2) {
+				v0 = fm_osc(op[0], g[0], 0, sine);
+				v1 = fm_osc(op[1], g[1], 0, sine);
+			} else {
+				v0 = fm_osc(op[0], g[0], fm_osc(op[NOPS > 2 ? 2 : 0], g[NOPS > 2 ? 2 : 0], 0, sine), sine);
+				v1 = fm_osc(op[1], g[1], fm_osc(op[NOPS > 3 ? 3 : 0], g[NOPS > 3 ? 3 : 0], 0, sine), sine);
+			}
+			v = mul64s(v0, v1, 23);
+		} else {			// fm_sample, fm.c:151-165
+			v = 0;
+#pragma unroll
+			for(int i = NOPS - 1; i >= 0; --i) {
+				if(i && PAR == 1)
+					v = wadd(v, fm_osc(op[i], g[i], 0, sine));
+				else
+					v = fm_osc(op[i], g[i], v, sine);
+			}
+		}
 #pragma unroll
 		for(int i = 0; i < NOPS; ++i)
-			fm_gain(g[i], op[i]);
-		int vsum = 0;
-#pragma unroll 1
-		for(int os = 0; os < (1 << OSBITS); ++os) {
-			int v;
-			if(PAR == 2) {			// fm_sample_rm, fm.c:172-192
-				int v0, v1;
-				if(NOPS == 2) {
-					v0 = fm_osc(op[0], g[0], 0, sine);
-					v1 = fm_osc(op[1], g[1], 0, sine);
-				} else {
-					v0 = fm_osc(op[0], g[0], fm_osc(op[NOPS > 2 ? 2 : 0], g[NOPS > 2 ? 2 : 0], 0, sine), sine);
-					v1 = fm_osc(op[1], g[1], fm_osc(op[NOPS > 3 ? 3 : 0], g[NOPS > 3 ? 3 : 0], 0, sine), sine);
-				}
-				v = mul64s(v0, v1, 23);
-			} else {			// fm_sample, fm.c:151-165
-				v = 0;
+			op[i].phase += step[i];
+		vsum = wadd(vsum, v);
+	}
 #pragma unroll
-				for(int i = NOPS - 1; i >= 0; --i) {
-					if(i && PAR == 1)
-						v = wadd(v, fm_osc(op[i], g[i], 0, sine));
-					else
-						v = fm_osc(op[i], g[i], v, sine);
-				}
-			}
+	for(int i = 0; i < NOPS; ++i) {
+		op[i].a.value = wadd(op[i].a.value, op[i].a.delta);
+		op[i].fb.value = wadd(op[i].fb.value, op[i].fb.delta);
+		op[i].phase += fix[i];
+	}
+	return vsum >> OSBITS;
+}
+
+// One whole window for one voice; emit(s, value) receives frame s (0-based).
+template<int NOPS, int OSBITS, int PAR, typename Emit>
+DEV void fm_window(FmOp (&op)[NOPS], const uint32_t *ptab, const uint32_t *sine, int frames, Emit emit)
+{
+	unsigned step[NOPS], fix[NOPS];
+	fm_prepare<NOPS, OSBITS>(op, ptab, frames, step, fix);
+	for(int s = 0; s < frames; ++s)
+		emit(s, fm_frame<NOPS, OSBITS, PAR>(op, step, fix, sine));
+}
+
+// fm_Initialize (fm.c:338-400) and the write callbacks (fm.c:403-483) on
+// operators held in registers (the register index is a compile-time constant
+// in every arm: no dynamic indexing of the operator array)
+template<int NOPS>
+DEV void fm_set_phase_ops(FmOp (&op)[NOPS], int ph, unsigned sst)
+{
 #pragma unroll
-			for(int i = 0; i < NOPS; ++i)
-				op[i].phase += step[i];
-			vsum = wadd(vsum, v);
-		}
+	for(int i = 0; i < NOPS; ++i) {
+		const int ssph = (int)((unsigned)ph + ((sst * (op[i].dphase >> 8)) >> 8));
+		op[i].phase = (unsigned)((int)((unsigned)ssph * 2048u) >> 8);
+	}
+}
+
+template<int NOPS>
+DEV void fm_init_ops(FmOp (&op)[NOPS], const uint32_t *ptab, int pitch, unsigned sst)
+{
+	Ramp p;
+	ramp_init(p, pitch);
+	const unsigned dphase = p2i(ptab, p.value >> 8);
 #pragma unroll
-		for(int i = 0; i < NOPS; ++i) {
-			op[i].a.value = wadd(op[i].a.value, op[i].a.delta);
-			op[i].fb.value = wadd(op[i].fb.value, op[i].fb.delta);
-			op[i].phase += fix[i];
-		}
-		emit(s, vsum >> OSBITS);
+	for(int i = 0; i < NOPS; ++i) {
+		ramp_init(op[i].a, 0);
+		ramp_init(op[i].fb, 0);
+		op[i].p = p;
+		op[i].last_pitch = 0;
+		op[i].last = 0;
+		op[i].dphase = dphase;
+	}
+	fm_set_phase_ops<NOPS>(op, 0, sst);
+}
+
+template<int NOPS>
+DEV void fm_write_ops(FmOp (&op)[NOPS], int reg, int v, int start, int dur)
+{
+	if(reg == 0) {
+		fm_set_phase_ops<NOPS>(op, v, (unsigned)start);
+		return;
+	}
+#pragma unroll
+	for(int i = 0; i < NOPS; ++i) {
+		if(reg == 1 + 3 * i) ramp_set(op[i].p, v, start, dur);
+		if(reg == 2 + 3 * i) ramp_set(op[i].a, v, start, dur);
+		if(reg == 3 + 3 * i) ramp_set(op[i].fb, v, start, dur);
 	}
 }
 

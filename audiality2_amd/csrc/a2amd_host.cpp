@@ -147,7 +147,7 @@ struct HVoice {
 };
 
 struct DepthRange { int fast_first = 0, fast_count = 0, gen_first = 0, gen_count = 0, dyn_first = 0, dyn_count = 0; };
-enum { CLS_GENERIC = 0, CLS_OSCPAN, CLS_OSCFILTPAN, CLS_BUSDRIVER, CLS_BUSGENERIC, CLS_OSC2PAN };
+enum { CLS_GENERIC = 0, CLS_OSCPAN, CLS_OSCFILTPAN, CLS_BUSDRIVER, CLS_BUSGENERIC, CLS_OSC2PAN, CLS_FMPAN };
 
 struct HWave {
 	bool live = false;
@@ -197,7 +197,9 @@ struct a2amd_ctx {
 	bool voices_dirty = true, udesc_dirty = true, waves_dirty = true, lists_dirty = true, ptab_dirty = true;
 	std::vector<int> list_all;		// leaf list followed by per-depth lists
 	int n_leaf = 0;
-	int n_fast_leaf = 0, n_osc2_leaf = 0, n_filt_leaf = 0;	// list_all = [wtosc-panmix | wtosc-filter12-panmix | general leaves | per depth ...]
+	int n_fast_leaf = 0, n_osc2_leaf = 0, n_filt_leaf = 0;	// list_all = [wtosc-panmix | 2 x wtosc-panmix | wtosc-filter12-panmix | fm-panmix | general leaves | per depth ...]
+	int n_fm_leaf = 0, fm_kind_count[8] = { 0 };		// fm-panmix: grouped by unit kind (fm1..fm4r), one launch each
+	int n_list_pads = 0;
 	std::vector<DepthRange> depth_ranges;	// index = depth
 	int no_fast = 0;			// A2AMD_NO_FAST bit mask: 1 wtosc-panmix, 2 wtosc-filter12-panmix, 4 driver chains -> general kernel (debugging / A-B tests)
 
@@ -449,6 +451,17 @@ bool is_oscfiltpan_chain(const a2amd_ctx *c, const HVoice &v)
 			(pm.flags & A2AMD_PROCADD);
 }
 
+// fmN -> panmix 1->2 adding into the output bus
+bool is_fmpan_chain(const a2amd_ctx *c, const HVoice &v)
+{
+	if(v.nunits != 2 || v.out_nch < 2)
+		return false;
+	const HUnit &o = c->units[v.unit[0]], &pm = c->units[v.unit[1]];
+	return o.kind >= A2AMD_FM1 && o.kind <= A2AMD_FM4R && !(o.flags & A2AMD_PROCADD) && !o.wired &&
+			pm.kind == A2AMD_PANMIX && pm.nin == 1 && pm.nout == 2 && pm.wired &&
+			(pm.flags & A2AMD_PROCADD);
+}
+
 // inline 0 2; panmix 2 2; xinsert 2 >  (a2_rootdriver / a2_groupdriver)
 bool is_driver_chain(const a2amd_ctx *c, const HVoice &v)
 {
@@ -579,7 +592,7 @@ int upload(a2amd_ctx *c)
 	// The fast kernels skip a voice whose runs[] entry is non-zero; those voices
 	// form the dynamic part (this batch's exceptions) and go to the general kernel.
 	if(c->lists_dirty) {
-		std::vector<int> fast_leaf, osc2_leaf, filt_leaf, gen_leaf;
+		std::vector<int> fast_leaf, osc2_leaf, filt_leaf, fm_leaf, gen_leaf;
 		std::map<int, std::pair<std::vector<int>, std::vector<int>>> bydepth;
 		int maxdepth = -1;
 		for(size_t vi = 0; vi < nv; ++vi) {
@@ -598,9 +611,10 @@ int upload(a2amd_ctx *c)
 			} else {
 				v.cls = !(c->no_fast & 1) && is_oscpan_chain(c, v) ? CLS_OSCPAN :
 						!(c->no_fast & 8) && is_osc2pan_chain(c, v) ? CLS_OSC2PAN :
-						!(c->no_fast & 2) && is_oscfiltpan_chain(c, v) ? CLS_OSCFILTPAN : CLS_GENERIC;
+						!(c->no_fast & 2) && is_oscfiltpan_chain(c, v) ? CLS_OSCFILTPAN :
+						!(c->no_fast & 16) && is_fmpan_chain(c, v) ? CLS_FMPAN : CLS_GENERIC;
 				(v.cls == CLS_OSCPAN ? fast_leaf : v.cls == CLS_OSC2PAN ? osc2_leaf :
-				 v.cls == CLS_OSCFILTPAN ? filt_leaf : gen_leaf).push_back((int)vi);
+				 v.cls == CLS_OSCFILTPAN ? filt_leaf : v.cls == CLS_FMPAN ? fm_leaf : gen_leaf).push_back((int)vi);
 			}
 		}
 		auto by_bus = [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; };
@@ -614,6 +628,19 @@ int upload(a2amd_ctx *c)
 		c->n_osc2_leaf = (int)osc2_leaf.size();
 		c->list_all.insert(c->list_all.end(), filt_leaf.begin(), filt_leaf.end());
 		c->n_filt_leaf = (int)filt_leaf.size();
+		{
+			// fm voices, grouped by unit kind: one launch per kind present
+			std::stable_sort(fm_leaf.begin(), fm_leaf.end(), [&](int a, int b) {
+				const int ka = c->units[c->voices[a].unit[0]].kind, kb = c->units[c->voices[b].unit[0]].kind;
+				return ka != kb ? ka < kb : c->voices[a].out_off < c->voices[b].out_off;
+			});
+			for(int k = 0; k < 8; ++k)
+				c->fm_kind_count[k] = 0;
+			for(int vi : fm_leaf)
+				++c->fm_kind_count[c->units[c->voices[vi].unit[0]].kind - A2AMD_FM1];
+			c->list_all.insert(c->list_all.end(), fm_leaf.begin(), fm_leaf.end());
+			c->n_fm_leaf = (int)fm_leaf.size();
+		}
 		c->list_all.insert(c->list_all.end(), gen_leaf.begin(), gen_leaf.end());
 		c->n_leaf = (int)gen_leaf.size();
 		c->depth_ranges.assign(maxdepth + 1, DepthRange());
@@ -640,6 +667,7 @@ int upload(a2amd_ctx *c)
 		std::vector<std::vector<int>> dyn_bus(c->depth_ranges.size());
 		for(int vi : c->with_recs) {
 			const HVoice &v = c->voices[vi];
+			// (fm-panmix voices execute their own records in k_leaf_fmpan)
 			if(v.cls == CLS_OSCPAN || v.cls == CLS_OSCFILTPAN || v.cls == CLS_OSC2PAN)
 				dyn_leaf.push_back(vi);
 			else if(v.cls == CLS_BUSDRIVER && v.depth < (int)dyn_bus.size())
@@ -821,7 +849,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			pick_fast_shape(c->n_fast_leaf, c->nfrags, &vpw, &ysplit);
 			// e1 right behind the main kernel when it is the only leaf kernel
 			// of the batch: "leaf" time is then that kernel alone
-			const bool solo = !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_leaf && !c->n_leaf_dyn;
+			const bool solo = !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn;
 			if(a2d_launch_leaf_oscpan(c->d_params, c->hparams, c->d_list.d, c->n_fast_leaf,
 					vpw, ysplit, c->d_ustage.d, c->stream, solo ? (void *)e1 : nullptr))
 				return c->fail(A2AMD_EHIP, "fast leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -843,8 +871,24 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 				return c->fail(A2AMD_EHIP, "filter leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
+		for(int k = 0, at = c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf; k < 8; at += c->fm_kind_count[k++]) {
+			const int n = c->fm_kind_count[k];
+			if(!n)
+				continue;
+			// Few voices: spread them over many wavefronts (a voice is a serial
+			// recurrence, a launch takes as long as its longest lane); many:
+			// fill the lanes.  Sweep on MI355X: one wavefront per SIMD with all
+			// 64 lanes busy beats two with 32 from 65 536 voices up
+			// (profiles/r01_fm_sweep.jsonl).
+			int vpw = getenv("A2AMD_FMVPW") ? atoi(getenv("A2AMD_FMVPW")) : (n + 1023) / 1024;
+			vpw = std::min(std::max(vpw, 1), 64);
+			if(a2d_launch_leaf_fmpan(c->d_params, c->hparams, A2AMD_FM1 + k, c->d_list.d + at, n, vpw, c->stream))
+				return c->fail(A2AMD_EHIP, "fm leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+			++c->stats.launches;
+		}
 		if(c->n_leaf) {
-			if(a2d_launch_voices(c->d_params, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf, c->n_leaf,
+			if(a2d_launch_voices(c->d_params, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf +
+					c->n_fm_leaf, c->n_leaf,
 					pick_vpw(c->n_leaf), c->stream))
 				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
@@ -855,7 +899,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
-		if(e1 && !(c->n_fast_leaf && !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_leaf && !c->n_leaf_dyn))
+		if(e1 && !(c->n_fast_leaf && !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn))
 			HIPCHK(c, hipEventRecord(e1, c->stream));
 		for(int d = (int)c->depth_ranges.size() - 1; d >= 1; --d)
 			if(int r = launch_depth(c, d))
@@ -868,7 +912,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		if(e2)
 			HIPCHK(c, hipEventRecord(e2, c->stream));
 		c->stats.fragments += c->nfrags;
-		c->stats.voice_fragments += (uint64_t)c->nfrags * (uint64_t)c->list_all.size();
+		c->stats.voice_fragments += (uint64_t)c->nfrags * (uint64_t)(c->list_all.size() - c->n_list_pads);
 	}
 	return 0;
 }
@@ -1560,7 +1604,7 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 			HIPCHK(c, hipGraphLaunch(c->gexec[slot], c->stream));
 			if(kphases & A2AMD_RENDER_ROOT) {
 				c->stats.fragments += c->nfrags;
-				c->stats.voice_fragments += (uint64_t)c->nfrags * c->list_all.size();
+				c->stats.voice_fragments += (uint64_t)c->nfrags * (c->list_all.size() - c->n_list_pads);
 			}
 			return (int)total;
 		}
@@ -1625,12 +1669,12 @@ int a2amd_replay(a2amd_ctx *c, unsigned steps)
 			HIPCHK(c, hipGraphLaunch(c->gexec[0], c->stream));
 			steps -= GRAPH_STEPS;
 			c->stats.fragments += (uint64_t)c->nfrags * GRAPH_STEPS;
-			c->stats.voice_fragments += (uint64_t)c->nfrags * c->list_all.size() * GRAPH_STEPS;
+			c->stats.voice_fragments += (uint64_t)c->nfrags * (c->list_all.size() - c->n_list_pads) * GRAPH_STEPS;
 		} else if(graphs) {
 			HIPCHK(c, hipGraphLaunch(c->gexec[1], c->stream));
 			--steps;
 			c->stats.fragments += c->nfrags;
-			c->stats.voice_fragments += (uint64_t)c->nfrags * c->list_all.size();
+			c->stats.voice_fragments += (uint64_t)c->nfrags * (c->list_all.size() - c->n_list_pads);
 		} else {
 			if(c->profiling) {
 				if(c->ev_used + 3 > c->ev_pool.size())

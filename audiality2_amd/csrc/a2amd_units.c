@@ -308,7 +308,7 @@ static void amd_write(A2P_unit *u, int reg, int v, unsigned start, unsigned dur)
 }
 
 #define WR(n) static void wr##n(A2P_unit *u, int v, unsigned s, unsigned d) { amd_write(u, n, v, s, d); }
-WR(0) WR(1) WR(2) WR(3) WR(4) WR(5) WR(6)
+WR(0) WR(1) WR(2) WR(3) WR(4) WR(5) WR(6) WR(7) WR(8) WR(9) WR(10) WR(11) WR(12)
 
 /* ---- the replaced units -----------------------------------------------------------*/
 #define OWN_UNIT(K, name, regvals) \
@@ -350,6 +350,31 @@ const A2P_unitdesc a2_filter12_unitdesc = { "filter12", A2P_MATCHIO, filter12_re
 	A2P_BLOCK_SIZE, filter12_init, amd_deinit, amd_open, amd_close };
 const A2P_unitdesc a2_fbdelay_unitdesc = { "fbdelay", 0, fbdelay_regs, NULL, NULL, 1, 2, 1, 2,
 	A2P_BLOCK_SIZE, fbdelay_init, amd_deinit, amd_open, amd_close };
+
+/* ---- the FM oscillators, fm.c:509-834 ----------------------------------------------
+ * Eight descriptors over one register list (phase, then p a fb per operator,
+ * fm.c:54-79), all registers initially 0 (fm.c:373-376). */
+OWN_UNIT(A2AMD_FM1, fm1, ARR(0, 0, 0, 0))
+OWN_UNIT(A2AMD_FM2, fm2, ARR(0, 0, 0, 0, 0, 0, 0))
+OWN_UNIT(A2AMD_FM3, fm3, ARR(0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
+OWN_UNIT(A2AMD_FM4, fm4, ARR(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
+OWN_UNIT(A2AMD_FM3P, fm3p, ARR(0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
+OWN_UNIT(A2AMD_FM4P, fm4p, ARR(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
+OWN_UNIT(A2AMD_FM2R, fm2r, ARR(0, 0, 0, 0, 0, 0, 0))
+OWN_UNIT(A2AMD_FM4R, fm4r, ARR(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
+
+#define FM_REGS(n) static const A2P_crdesc fm##n##_regs[] = { { "phase", wr0 }, \
+	{ "p", wr1 }, { "a", wr2 }, { "fb", wr3 }, \
+	{ n > 1 ? "p1" : NULL, n > 1 ? wr4 : NULL }, { "a1", wr5 }, { "fb1", wr6 }, \
+	{ n > 2 ? "p2" : NULL, n > 2 ? wr7 : NULL }, { "a2", wr8 }, { "fb2", wr9 }, \
+	{ n > 3 ? "p3" : NULL, n > 3 ? wr10 : NULL }, { "a3", wr11 }, { "fb3", wr12 }, { NULL, NULL } };
+FM_REGS(1) FM_REGS(2) FM_REGS(3) FM_REGS(4)
+
+#define FM_DESC(sym, nm, regs) const A2P_unitdesc a2_##sym##_unitdesc = { nm, 0, regs, NULL, NULL, \
+	0, 0, 1, 1, A2P_BLOCK_SIZE, sym##_init, amd_deinit, amd_open, amd_close };
+FM_DESC(fm1, "fm1", fm1_regs) FM_DESC(fm2, "fm2", fm2_regs) FM_DESC(fm3, "fm3", fm3_regs)
+FM_DESC(fm4, "fm4", fm4_regs) FM_DESC(fm3p, "fm3p", fm3_regs) FM_DESC(fm4p, "fm4p", fm4_regs)
+FM_DESC(fm2r, "fm2r", fm2_regs) FM_DESC(fm4r, "fm4r", fm4_regs)
 
 /* ---- the wrapped engine-internal units ------------------------------------------------
  * inline and xinsert need engine internals (the voice behind a vmstate, the

@@ -12,6 +12,9 @@ import numpy as np
 from .replay import WAVEPOST, WAVEPRE, MIPLEVELS
 
 K_WTOSC, K_PANMIX, K_FILTER12, K_FBDELAY, K_INLINE, K_XINSERT = range(6)
+# the FM oscillators (a2amd_unitkind): name -> (kind, operators)
+FM_KINDS = {"fm1": (6, 1), "fm2": (7, 2), "fm3": (8, 3), "fm4": (9, 4),
+            "fm3p": (10, 3), "fm4p": (11, 4), "fm2r": (12, 2), "fm4r": (13, 4)}
 PROCADD = 1
 WOFF, WNOISE, WWAVE, WMIPWAVE = range(4)
 LOOPED = 0x100
@@ -157,6 +160,31 @@ class Scene:
                          be.unit_init(key, K_WTOSC, PROCADD, 0, 1, 0),
                          be.unit_init(key, K_PANMIX, PROCADD, 1, 2, 1)]
                 oscs, pan = units[:2], units[2]
+            elif chain.endswith("-pan") and (chain[:-4] in FM_KINDS or chain == "fmmix-pan"):
+                # fmN; panmix.  "fmmix" cycles through the eight units.
+                name = sorted(FM_KINDS)[k % 8] if chain == "fmmix-pan" else chain[:-4]
+                kind, nops = FM_KINDS[name]
+                units = [be.unit_init(key, kind, 0, 0, 1, 0, wakefrac=(k * 37) & 255),
+                         be.unit_init(key, K_PANMIX, PROCADD, 1, 2, 1)]
+                oscs, pan = [], units[1]
+                fm = units[0]
+                ring = name.endswith("r")
+                be.unit_write(fm, 1, p)                                   # p
+                # a (ramping in every fourth voice), fb
+                be.unit_write(fm, 2, fix(1.0) if ring else amp)
+                if k % 4 == 0:
+                    be.unit_write(fm, 2, (fix(1.0) if ring else amp) // 2, 0, 3000 << 8)
+                be.unit_write(fm, 3, fix((k % 5) / 8.0))
+                ratios = (1.0 + (k % 3) * 0.5, 2.01, (k % 7) * 0.5 + 0.5)
+                depths = (0.5 + (k % 4) * 0.25, 0.7, 0.4)
+                fbs = ((k % 3) / 4.0, 0.2, (k % 2) * 0.5)
+                for j in range(1, nops):
+                    be.unit_write(fm, 1 + 3 * j, fix(ratios[j - 1]))      # pN (relative)
+                    be.unit_write(fm, 2 + 3 * j, amp if (ring and j == 1) else fix(depths[j - 1]))
+                    be.unit_write(fm, 3 + 3 * j, fix(fbs[j - 1]))
+                if k % 8 == 3:
+                    be.unit_write(fm, 1, p + fix(0.5), 0, 1500 << 8)      # pitch glide
+                be.unit_write(fm, 0, (k * 2654435761) % 65536)            # phase
             else:
                 raise ValueError(chain)
             for j, o in enumerate(oscs):

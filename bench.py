@@ -38,6 +38,9 @@ BYTES_PER_VOICE_SAMPLE = {          # algorithmic HBM bytes
     "osc-pan": 504.0 / 64.0,        # 7.9 B: (152+96 B state) x2 + 8 B bus share per fragment
     "osc-filter-pan": 792.0 / 64.0,  # 12.4 B with filter12's 144 B state
     "osc2-pan": (504.0 + 2 * 152.0) / 64.0,
+    # fm units: 64 B of operator state per operator + panmix, read + written, + bus share
+    **{f"{k}-pan": ((64.0 * n + 96.0) * 2 + 8.0) / 64.0 for k, n in
+       (("fm1", 1), ("fm2", 2), ("fm3", 3), ("fm4", 4), ("fm3p", 3), ("fm4p", 4), ("fm2r", 2), ("fm4r", 4))},
 }
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s
 
@@ -66,12 +69,13 @@ def fnv1a_fragments(pcm, frag=64):
 
 def cpu_baseline(voices, chain, oracle_fragments=600):
     """Reference (oracle/_ref/ref_bench) if it travelled, else the C port."""
-    program = {"osc-pan": "OscPan", "osc-filter-pan": "OscFilterPan"}.get(chain)
+    program = {"osc-pan": "OscPan", "osc-filter-pan": "OscFilterPan", "fm1-pan": "Fm1Pan", "fm2-pan": "Fm2Pan",
+               "fm4-pan": "Fm4Pan"}.get(chain)
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
     script = os.path.join(ROOT, "tests", "a2s", "bench.a2s")
     ncores = os.cpu_count() or 1
     if program and os.path.exists(exe):
-        frags = 7500 if chain == "osc-pan" else 4000      # ~4 s of one core
+        frags = {"osc-pan": 7500, "fm4-pan": 1000, "fm2-pan": 2500}.get(chain, 4000)   # a few seconds of one core
         res = {}
         for threads in sorted({1, min(ncores, 16)}):
             try:
@@ -293,7 +297,7 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bpvs * args.voices * B * 64,
                          "kernel": {"osc-pan": "k_leaf_oscpan", "osc-filter-pan": "k_leaf_oscfiltpan", "osc2-pan": "k_leaf_osc2pan"}.get(
-                             args.chain, "k_voices (leaf launch)"),
+                             args.chain, "k_leaf_fmpan" if args.chain.startswith("fm") else "k_voices (leaf launch)"),
                          "avg_launch_ms": leaf_ms,
                          "timing": "HIP events on the launch stream around every launch, separate pass of "
                                    f"{nprof} steps right after the timed region (graph replay off)",

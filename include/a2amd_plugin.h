@@ -19,6 +19,8 @@
  *   a2_panmix_unitdesc    replaces src/units/panmix.c:313-333
  *   a2_filter12_unitdesc  replaces src/units/filter12.c:241-261
  *   a2_fbdelay_unitdesc   replaces src/units/fbdelay.c:289-309
+ *   a2_fm1/fm2/fm3/fm4/fm3p/fm4p/fm2r/fm4r_unitdesc
+ *                         replace  src/units/fm.c:532,579,631,688,719,752,783,814
  *   a2_inline_unitdesc    wraps    src/units/inline.c:50-69
  *   a2_xinsert_unitdesc   wraps    src/units/xinsert.c:232-252
  * Imported from the engine at load time (public API, include/a2_waves.h:183,
@@ -120,7 +122,9 @@ struct A2P_unit
 #define A2P_XINSERT	0x00020000
 
 extern const A2P_unitdesc a2_wtosc_unitdesc, a2_panmix_unitdesc, a2_filter12_unitdesc,
-		a2_fbdelay_unitdesc, a2_inline_unitdesc, a2_xinsert_unitdesc;
+		a2_fbdelay_unitdesc, a2_inline_unitdesc, a2_xinsert_unitdesc,
+		a2_fm1_unitdesc, a2_fm2_unitdesc, a2_fm3_unitdesc, a2_fm4_unitdesc,
+		a2_fm3p_unitdesc, a2_fm4p_unitdesc, a2_fm2r_unitdesc, a2_fm4r_unitdesc;
 
 #ifdef __cplusplus
 }

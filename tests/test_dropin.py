@@ -21,7 +21,9 @@ CASES = [("sustain", ["4", "0.05"], 9600), ("filter", ["4", "0.02"], 48000),
          ("delaybus", ["2", "4", "0.05"], 48000), ("scripted", ["0.2"], 48000),
          # renders three waves in offline substates while the script loads: those
          # states get GPU contexts of their own next to the master state's
-         ("edge", ["0.2"], 4 * 48000)]
+         ("edge", ["0.2"], 4 * 48000),
+         # the FM oscillator units
+         ("fm", ["0.15"], 3 * 48000)]
 REALTIME_CASES = {"edge"}      # see tests/golden/make_goldens.py
 
 

@@ -45,7 +45,8 @@ def test_reference_traces_on_gpu(oracle_lib, name, batch):
                     f"first sample diff (ch, frame, gpu, oracle) = {first_diff(out, ref)}")
 
 
-@pytest.mark.parametrize("chain,n", [("osc-pan", 1024), ("osc-filter-pan", 512), ("osc2-pan", 300)])
+@pytest.mark.parametrize("chain,n", [("osc-pan", 1024), ("osc-filter-pan", 512), ("osc2-pan", 300),
+                                     ("fmmix-pan", 333), ("fm4-pan", 70), ("fm1-pan", 5000)])
 def test_scenes_match_oracle(oracle_lib, chain, n):
     """BASELINE config shapes at oracle-friendly sizes, 24 fragments."""
     outs = []
@@ -54,6 +55,23 @@ def test_scenes_match_oracle(oracle_lib, chain, n):
         sc.root()
         sc.add_voices(n, chain=chain)
         outs.append(sc.run(24, batch=8))
+        be.close()
+    assert first_diff(outs[0], outs[1]) is None
+
+
+@pytest.mark.parametrize("vpw", [1, 7, 64])
+def test_fm_leaf_kernel_wavefront_shapes(oracle_lib, monkeypatch, vpw):
+    """The fm->panmix leaf kernel gives each wavefront `vpw` voices of one unit
+    kind (the host pads the kind groups); any shape renders the same audio."""
+    monkeypatch.setenv("A2AMD_FMVPW", str(vpw))
+    outs = []
+    for be in (make_gpu(max_batch=8), make_oracle(oracle_lib)):
+        sc = synth.Scene(be)
+        sc.root()
+        sc.add_voices(203, chain="fmmix-pan")
+        g = sc.add_group()
+        sc.add_voices(41, chain="fm3p-pan", group=g)
+        outs.append(sc.run(19, batch=8, frames=64))
         be.close()
     assert first_diff(outs[0], outs[1]) is None
 
