@@ -164,6 +164,82 @@ def test_mixed_quiet_and_active_voices_across_batches(oracle_lib):
     assert first_diff(outs[0], outs[1]) is None
 
 
+def _fm_script(be, nvoices=190, batches=3, bfrags=16, seed=5):
+    """FM voices the way a script drives them: control writes between
+    sub-fragment windows, ramps of all lengths, phase resets, voices born in the
+    middle of a fragment and voices dying, every few fragments per voice."""
+    rng = np.random.default_rng(seed)
+    sc = synth.Scene(be)
+    sc.root()
+    sc.add_voices(nvoices, chain="fmmix-pan")
+    nops = [synth.FM_KINDS[sorted(synth.FM_KINDS)[k % 8]][1] for k in range(nvoices)]
+    born = [0] * nvoices
+    chunks = []
+    frag = 0
+    for _ in range(batches):
+        for _ in range(bfrags):
+            frag += 1
+            busy = set(int(k) for k in rng.choice(len(sc.leaves), len(sc.leaves) // 5, replace=False))
+            be.fragment(64)
+            be.unit_process(sc.rootv[0], 0, 64)
+            # a voice is born in the middle of this fragment now and then
+            newborn = None
+            if frag % 5 == 2:
+                n0 = len(sc.leaves)
+                sc.add_voices(1, chain="fm4r-pan" if frag % 2 else "fm2-pan", total=nvoices)
+                newborn = (sc.leaves[n0], int(rng.integers(1, 63)))
+                nops.append(4 if frag % 2 else 2)
+            for k, units in enumerate(sc.leaves):
+                fm, pan = units
+                if newborn and units is newborn[0]:
+                    be.unit_process(fm, newborn[1], 64 - newborn[1])
+                    be.unit_process(pan, newborn[1], 64 - newborn[1])
+                    continue
+                if k not in busy:
+                    be.unit_process(fm, 0, 64)
+                    be.unit_process(pan, 0, 64)
+                    continue
+                cut = sorted(set(int(c) for c in rng.integers(1, 64, int(rng.integers(1, 4)))))
+                at = 0
+                for c in cut + [64]:
+                    dur = int(rng.choice([0, 100, 3000, 70000, 2000000]))
+                    reg = int(rng.integers(0, 1 + 3 * nops[k]))
+                    val = synth.fix(float(rng.uniform(-1, 3))) if reg % 3 == 1 else synth.fix(float(rng.uniform(0, 1.5)))
+                    if reg == 0:
+                        val = int(rng.integers(0, 65536))
+                    be.unit_write(fm, reg, val, int(rng.integers(0, 256)), dur)
+                    if rng.random() < 0.4:
+                        be.unit_write(pan, int(rng.integers(0, 2)), synth.fix(float(rng.uniform(-1.5, 1.5))), 0, dur)
+                    be.unit_process(fm, at, c - at)
+                    be.unit_process(pan, at, c - at)
+                    at = c
+            be.inline_end(sc.rootv[0])
+            be.unit_process(sc.rootv[1], 0, 64)
+            be.unit_process(sc.rootv[2], 0, 64)
+            # ... and one dies
+            if frag % 4 == 3 and len(sc.leaves) > 8:
+                k = int(rng.integers(0, len(sc.leaves)))
+                for u in sc.leaves[k]:
+                    be.unit_deinit(u)
+                del sc.leaves[k]
+                del nops[k]
+        chunks.append(be.render(bfrags * 64))
+    return np.concatenate(chunks, axis=1)
+
+
+@pytest.mark.parametrize("vpw", [1, 64])
+def test_fm_leaf_kernel_executes_records(oracle_lib, monkeypatch, vpw):
+    monkeypatch.setenv("A2AMD_FMVPW", str(vpw))
+    gpu = make_gpu(max_batch=16)
+    got = _fm_script(gpu)
+    gpu.close()
+    ora = make_oracle(oracle_lib)
+    want = _fm_script(ora)
+    ora.close()
+    assert want.any()
+    assert first_diff(got, want) is None
+
+
 def test_linearity_at_full_size():
     """Size-independent property at BASELINE size (16384 voices, config 3
     shape would take the oracle minutes): the bus is a wrap-around sum, so the
