@@ -18,18 +18,19 @@
 
 // unit kinds: numerically equal to a2amd_unitkind
 enum { A2D_WTOSC = 0, A2D_PANMIX, A2D_FILTER12, A2D_FBDELAY, A2D_INLINE, A2D_XINSERT,
-	A2D_FM1, A2D_FM2, A2D_FM3, A2D_FM4, A2D_FM3P, A2D_FM4P, A2D_FM2R, A2D_FM4R };
+	A2D_FM1, A2D_FM2, A2D_FM3, A2D_FM4, A2D_FM3P, A2D_FM4P, A2D_FM2R, A2D_FM4R,
+	A2D_DC, A2D_WAVESHAPER, A2D_DCBLOCK, A2D_LIMITER };
 #define A2D_IS_FM(k) ((k) >= A2D_FM1 && (k) <= A2D_FM4R)
 
 // wtosc Process variants (the reference swaps u->Process, wtosc.c:433-483)
 enum { A2D_OSC_OFF = 0, A2D_OSC_NOISE, A2D_OSC_WAVE, A2D_OSC_MIPWAVE };
 
 // packed static description of a unit instance (host owned)
-//   bits 0-3 kind, 4 add (A2_PROCADD), 8-11 ninputs, 12-15 noutputs, 16 wired out
+//   bits 4 add (A2_PROCADD), 8-11 ninputs, 12-15 noutputs, 16 wired out, 24-31 kind
 #define A2D_DESC(kind, add, nin, nout, wired) \
-	((uint32_t)(kind) | ((uint32_t)(add) << 4) | ((uint32_t)(nin) << 8) | \
+	(((uint32_t)(kind) << 24) | ((uint32_t)(add) << 4) | ((uint32_t)(nin) << 8) | \
 	 ((uint32_t)(nout) << 12) | ((uint32_t)(wired) << 16))
-#define A2D_KIND(d)  ((d) & 15u)
+#define A2D_KIND(d)  ((d) >> 24)
 #define A2D_ADD(d)   (((d) >> 4) & 1u)
 #define A2D_NIN(d)   (((d) >> 8) & 15u)
 #define A2D_NOUT(d)  (((d) >> 12) & 15u)
@@ -50,6 +51,14 @@ enum {	// fbdelay (A2_fbdelay, fbdelay.c:41-60)
 	DW_FBDELAY = 0, DW_LDELAY, DW_RDELAY, DW_DRYGAIN, DW_FBGAIN, DW_LGAIN,
 	DW_RGAIN, DW_BUFPOS, DW_BUFIDX };
 
+enum {	// dc (A2_dc, dc.c:42-47)
+	CW_VALUE = 0, CW_MODE = 4 };
+enum {	// waveshaper (A2_waveshaper, waveshaper.c:44-48)
+	SW_AMOUNT = 0 };
+enum {	// dcblock (A2_dcblock, dcblock.c:33-49); the host ships f1
+	BW_F1 = 0, BW_D1A, BW_D1B, BW_D2A, BW_D2B };
+enum {	// limiter (A2_limiter, limiter.c:35-42); release / threshold computed by the host
+	LW_RELEASE = 0, LW_THRESHOLD, LW_PEAK };
 enum {	// fm (A2_fm, fm.c:95-105): the operators live in a pool of their own
 	// (fmstate[slot][A2D_FMSTATE]); the unit's state words only name the slot
 	MW_SLOT = 0 };

@@ -98,6 +98,15 @@ int f12_coeff(const uint32_t *tab, int cutoff_value, int samplerate)
 	return (int)(512.0f * 65536.0f * sin(M_PI * f / samplerate));
 }
 
+// dcb_pitch2coeff, dcblock.c:57-64: the same maths from a 16:16 pitch
+int dcb_coeff(const uint32_t *tab, int cutoff, int samplerate)
+{
+	float f = p2i(tab, cutoff) * (261.626f / 16777216.0f);
+	if(f > (samplerate >> 2))
+		return 362 << 16;
+	return (int)(512.0f * 65536.0f * sin(M_PI * f / samplerate));
+}
+
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if(e_ != hipSuccess) \
 	return (c)->fail(A2AMD_EHIP, "%s: %s", #call, hipGetErrorString(e_)); } while(0)
 
@@ -1167,6 +1176,16 @@ int a2amd_unit_init(a2amd_ctx *c, uint64_t key, int kind, unsigned flags, int ni
 		if(nout < 1)
 			return c->fail(A2AMD_EINVAL, "inline needs outputs");
 		break;
+	  case A2AMD_DC:	// dc.c:262-281: a source with one or two outputs
+		if(nin != 0 || nout < 1 || nout > 2)
+			return c->fail(A2AMD_EINVAL, "dc %d->%d", nin, nout);
+		break;
+	  case A2AMD_WAVESHAPER:
+	  case A2AMD_DCBLOCK:
+	  case A2AMD_LIMITER:	// A2_MATCHIO, one or two channels
+		if(nin != nout || nin < 1 || nin > 2)
+			return c->fail(A2AMD_EINVAL, "unit kind %d with %d->%d channels", kind, nin, nout);
+		break;
 	  default:	// fm1..fm4r, fm.c:532-834: no inputs, one output
 		if(nin != 0 || nout != 1)
 			return c->fail(A2AMD_EINVAL, "fm unit with %d->%d channels", nin, nout);
@@ -1264,6 +1283,10 @@ int a2amd_unit_init(a2amd_ctx *c, uint64_t key, int kind, unsigned flags, int ni
 		break;
 	}
 	unsigned initdur = 0, initstart = 0;
+	if(kind == A2AMD_DCBLOCK)	// dcb_Initialize, dcblock.c:131-132: cutoff -5.0 (8.18 Hz)
+		initval = dcb_coeff(c->ptab, (int)((unsigned)(-5 * 65536) + (unsigned)transpose), c->cfg.samplerate);
+	if(kind == A2AMD_LIMITER)	// limiter_Initialize, limiter.c:176-181
+		initval = ((64 << 16) << 8) / c->cfg.samplerate;
 	if(kind >= A2AMD_FM1 && kind <= A2AMD_FM4R) {	// fm_Initialize, fm.c:338-400
 		if(!c->fm_free.empty()) {
 			u.fmslot = c->fm_free.back();
@@ -1398,6 +1421,28 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 	  case A2AMD_INLINE:
 	  case A2AMD_XINSERT:
 		return c->fail(A2AMD_EINVAL, "unit kind %d has no registers", u.kind);
+	  case A2AMD_DC:
+		if(reg < 0 || reg > 1)
+			return c->fail(A2AMD_EINVAL, "dc register %d", reg);
+		break;
+	  case A2AMD_WAVESHAPER:
+		if(reg != 0)
+			return c->fail(A2AMD_EINVAL, "waveshaper register %d", reg);
+		break;
+	  case A2AMD_DCBLOCK:	// dcb_CutOff, dcblock.c:112-117: float/libm, host only
+		if(reg != 0)
+			return c->fail(A2AMD_EINVAL, "dcblock register %d", reg);
+		value = dcb_coeff(c->ptab, (int)((unsigned)value + (unsigned)transpose), c->cfg.samplerate);
+		break;
+	  case A2AMD_LIMITER:	// limiter_Release / limiter_Threshold, limiter.c:201-213
+		if(reg == 0)
+			value = (int)((unsigned)value << 8) / c->cfg.samplerate;
+		else if(reg == 1) {
+			unsigned t = (unsigned)value << 8;
+			value = (int)(t < 256 ? 256u : t);
+		} else
+			return c->fail(A2AMD_EINVAL, "limiter register %d", reg);
+		break;
 	  default: {	// fm.c:403-483: phase | p a fb | p1 a1 fb1 | ...
 		static const int nops[8] = { 1, 2, 3, 4, 3, 4, 2, 4 };
 		if(reg < 0 || reg > 3 * nops[u.kind - A2AMD_FM1])

@@ -525,6 +525,151 @@ DEV void xinsert_process(Ctx &c, uint32_t desc, int offset, int frames)
 }
 
 // ---------------------------------------------------------------------------
+// dc, dc.c:56-134: a generator; every frame is a closed form of the window
+// ---------------------------------------------------------------------------
+DEV void dc_process(Ctx &c, uint32_t desc, int *w, int offset, int frames)
+{
+	Ramp v = ramp_load(w + CW_VALUE);
+	const int nout = A2D_NOUT(desc);
+	const int k = c.lane - offset;
+	const bool in = (k >= 0) && (k < frames);
+	int val;
+	if(w[CW_MODE] == 0) {		// A2DCRM_STEP
+		// [0, e2): value; e2: the half-way "transient" sample; then target
+		int e2 = 0;
+		const int value = v.value;
+		bool trans;
+		if(v.timer >= 256) {
+			if((unsigned)(v.timer >> 8) >= (unsigned)frames) {
+				e2 = frames;
+				v.timer = wsub(v.timer, frames << 8);
+			} else {
+				e2 = v.timer >> 8;
+				v.timer &= 0xff;
+			}
+		}
+		trans = (v.timer < 256) && (e2 < frames);
+		const int tv = wadd(wmul(v.value >> 4, v.timer), wmul(v.target >> 4, 256 - v.timer)) >> 4;
+		if(trans) {
+			v.timer = 0;
+			v.value = v.target;
+		}
+		val = k < e2 ? value : (k == e2 && trans) ? tv : v.target;
+	} else {			// A2DCRM_LINEAR
+		ramp_prepare(v, frames);
+		val = wadd(v.value, wmul(v.delta, k));
+		ramp_run(v, frames);
+	}
+	if(in)
+		for(int o = 0; o < nout; ++o)
+			emit(c, desc, o, val);
+	lds_sync();
+	if(c.lane == 0)
+		ramp_store(w + CW_VALUE, v);
+}
+
+// ---------------------------------------------------------------------------
+// waveshaper, waveshaper.c:57-112 (fixed point branch): stateless per frame
+// ---------------------------------------------------------------------------
+DEV void waveshaper_process(Ctx &c, uint32_t desc, int *w, int offset, int frames)
+{
+	Ramp am = ramp_load(w + SW_AMOUNT);
+	const int channels = A2D_NIN(desc);
+	const int k = c.lane - offset;
+	ramp_prepare(am, frames);
+	if(k >= 0 && k < frames) {
+		const int a = wadd(am.value, wmul(am.delta, k));
+		const int a3p1 = wadd(wadd(wshl(a, 1), a), 1 << 24);
+		const int asqr = (int)(((int64_t)(a >> 4) * (int64_t)(a >> 4)) >> 24);
+		for(int ch = 0; ch < channels; ++ch) {
+			const int v = c.l->scratch[ch][c.lane];
+			const int vsqr = (int)(((int64_t)v * (int64_t)v) >> 22);
+			int64_t vout = (int64_t)v * (int64_t)a3p1;
+			const int64_t sqrsub = (int64_t)a * (int64_t)vsqr;
+			vout = v >= 0 ? vout - sqrsub : vout + sqrsub;
+			vout /= (((int64_t)asqr * (int64_t)vsqr) >> 16) + (1 << 24);
+			emit(c, desc, ch, (int)vout);
+		}
+	}
+	ramp_run(am, frames);
+	lds_sync();
+	if(c.lane == 0)
+		ramp_store(w + SW_AMOUNT, am);
+}
+
+// ---------------------------------------------------------------------------
+// dcblock, dcblock.c:66-95: a recurrence in time; lane ch runs channel ch
+// ---------------------------------------------------------------------------
+DEV void dcb_process(Ctx &c, uint32_t desc, int *w, int offset, int frames)
+{
+	const int channels = A2D_NIN(desc);
+	if(c.lane < channels) {
+		const int ch = c.lane;
+		const int f = w[BW_F1] >> 12;
+		int d1v = w[BW_D1A + ch], d2v = w[BW_D2A + ch];
+		for(int s = offset; s < offset + frames; ++s) {
+			const int d1 = d1v >> 4;
+			const int l = wadd(d2v, wmul(f, d1) >> 8);
+			const int h = wsub(wsub(c.l->scratch[ch][s] >> 5, l), wshl(d1, 4));
+			const int b = wadd(wmul(f, h >> 4) >> 8, d1v);
+			const int fout = wshl(h, 5);
+			if(A2D_WIRED(desc))
+				c.l->otile[ch][s] = wadd(c.l->otile[ch][s], fout);
+			else if(A2D_ADD(desc))
+				c.l->scratch[ch][s] = wadd(c.l->scratch[ch][s], fout);
+			else
+				c.l->scratch[ch][s] = fout;
+			d1v = b;
+			d2v = l;
+		}
+		w[BW_D1A + ch] = d1v;
+		w[BW_D2A + ch] = d2v;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// limiter, limiter.c:51-158: the peak follower is a recurrence over both
+// channels; lane 0 runs it
+// ---------------------------------------------------------------------------
+DEV int iabs_w(int x) { return x < 0 ? (int)(0u - (unsigned)x) : x; }
+
+DEV void limiter_process(Ctx &c, uint32_t desc, int *w, int offset, int frames)
+{
+	const int channels = A2D_NIN(desc);
+	if(c.lane == 0) {
+		const unsigned release = (unsigned)w[LW_RELEASE], threshold = (unsigned)w[LW_THRESHOLD];
+		unsigned peak = (unsigned)w[LW_PEAK];
+		const bool wired = A2D_WIRED(desc), acc = wired || A2D_ADD(desc);
+		for(int s = offset; s < offset + frames; ++s) {
+			const int i0 = c.l->scratch[0][s], i1 = channels == 2 ? c.l->scratch[1][s] : 0;
+			unsigned p;
+			if(channels == 1)
+				p = (unsigned)iabs_w(i0);
+			else {
+				const int lp = iabs_w(i0), rp = iabs_w(i1);
+				p = (unsigned)(lp > rp ? lp : rp);
+				p = p + ((p - (unsigned)iabs_w(wsub(lp, rp))) >> 1);
+			}
+			if(p > peak)
+				peak = p;
+			else {
+				peak -= release;
+				if(peak < threshold)
+					peak = threshold;
+				p = peak;
+			}
+			const int gain = (int)((32767LL << 16) / (long long)((p + 511u) >> 9));
+			for(int ch = 0; ch < channels; ++ch) {
+				const int r = mul64s(ch ? i1 : i0, gain, 16);
+				int *t = wired ? &c.l->otile[ch][s] : &c.l->scratch[ch][s];
+				*t = acc ? wadd(*t, r) : r;
+			}
+		}
+		w[LW_PEAK] = (int)peak;
+	}
+}
+
+// ---------------------------------------------------------------------------
 // fm1..fm4r, fm.c:194-322: a recurrence in time (operator feedback); lane 0
 // runs the window with the operators in registers
 // ---------------------------------------------------------------------------
@@ -615,6 +760,27 @@ DEV void unit_init(const A2DParams &p, uint32_t desc, int *w, const A2DRec &r)
 	  }
 	  case A2D_INLINE: case A2D_XINSERT:
 		break;
+	  case A2D_DC: {	// dc_Initialize, dc.c:160-188
+		Ramp v;
+		ramp_init(v, 0);
+		ramp_store(w + CW_VALUE, v);
+		w[CW_MODE] = 1;		// A2DCRM_LINEAR
+		break;
+	  }
+	  case A2D_WAVESHAPER: {	// waveshaper_Initialize, waveshaper.c:131-156
+		Ramp v;
+		ramp_init(v, 0);
+		ramp_store(w + SW_AMOUNT, v);
+		break;
+	  }
+	  case A2D_DCBLOCK:	// dcb_Initialize, dcblock.c:119-153; value = f1 from the host
+		w[BW_F1] = r.value;
+		break;
+	  case A2D_LIMITER:	// limiter_Initialize, limiter.c:168-198; value = release from the host
+		w[LW_RELEASE] = r.value;
+		w[LW_THRESHOLD] = (1 << 16) << 8;
+		w[LW_PEAK] = 32768 << 8;
+		break;
 	  default:	// fm: value = transpose + basepitch, start = wake fraction, dur = pool slot
 		w[MW_SLOT] = (int)r.dur;
 		fm_init_words(p.ptab, p.fmstate + (size_t)r.dur * A2D_FMSTATE, fm_nops(A2D_KIND(desc)),
@@ -671,6 +837,34 @@ DEV void unit_write(const A2DParams &p, uint32_t desc, int *w, const A2DRec &r)
 		break;
 	  case A2D_INLINE: case A2D_XINSERT:
 		break;
+	  case A2D_DC:
+		if(reg == 0) {		// dc_Value, dc.c:191-215
+			Ramp rr = ramp_load(w + CW_VALUE);
+			if(w[CW_MODE] == 0) {
+				rr.target = wshl(v, 8);
+				rr.timer = (int)((unsigned)dur >> 1) - start;
+				if(rr.timer <= 0) {
+					rr.value = rr.target;
+					rr.timer = 0;
+				}
+			} else
+				ramp_set(rr, v, start, dur);
+			ramp_store(w + CW_VALUE, rr);
+		} else			// dc_Mode, dc.c:218-238
+			w[CW_MODE] = (v >> 16) == 1 ? 1 : 0;
+		break;
+	  case A2D_WAVESHAPER: {	// waveshaper_Amount, waveshaper.c:159-162
+		Ramp rr = ramp_load(w + SW_AMOUNT);
+		ramp_set(rr, v, start, dur);
+		ramp_store(w + SW_AMOUNT, rr);
+		break;
+	  }
+	  case A2D_DCBLOCK:	// dcb_CutOff, dcblock.c:112-117 (the host did pitch -> coefficient)
+		w[BW_F1] = v;
+		break;
+	  case A2D_LIMITER:	// limiter.c:201-213 (the host did the scaling)
+		w[reg ? LW_THRESHOLD : LW_RELEASE] = v;
+		break;
 	  default:	// fm.c:403-483
 		fm_write_words(p.fmstate + (size_t)w[MW_SLOT] * A2D_FMSTATE, fm_nops(A2D_KIND(desc)),
 				reg, v, start, dur);
@@ -706,6 +900,10 @@ DEV void process_window(Ctx &c, const A2DVoice &v, int offset, int frames)
 		  case A2D_FBDELAY: fbd_process(c, desc, w, offset, frames); break;
 		  case A2D_INLINE: inline_process(c, desc, offset, frames); break;
 		  case A2D_XINSERT: xinsert_process(c, desc, offset, frames); break;
+		  case A2D_DC: dc_process(c, desc, w, offset, frames); break;
+		  case A2D_WAVESHAPER: waveshaper_process(c, desc, w, offset, frames); break;
+		  case A2D_DCBLOCK: dcb_process(c, desc, w, offset, frames); break;
+		  case A2D_LIMITER: limiter_process(c, desc, w, offset, frames); break;
 		  default: fm_process(c, desc, w, offset, frames); break;
 		}
 		lds_sync();

@@ -376,6 +376,27 @@ FM_DESC(fm1, "fm1", fm1_regs) FM_DESC(fm2, "fm2", fm2_regs) FM_DESC(fm3, "fm3", 
 FM_DESC(fm4, "fm4", fm4_regs) FM_DESC(fm3p, "fm3p", fm3_regs) FM_DESC(fm4p, "fm4p", fm4_regs)
 FM_DESC(fm2r, "fm2r", fm2_regs) FM_DESC(fm4r, "fm4r", fm4_regs)
 
+/* ---- the small units: dc.c:241-281, waveshaper.c:165-193, dcblock.c:162-190,
+ * limiter.c:222-250; register defaults dc.c:170-171, waveshaper.c:139,
+ * dcblock.c:131, limiter.c:176-177 ----------------------------------------------------*/
+OWN_UNIT(A2AMD_DC, dc, ARR(0, 1 << 16))
+OWN_UNIT(A2AMD_WAVESHAPER, wshaper, ARR(0))
+OWN_UNIT(A2AMD_DCBLOCK, dcblock, ARR(-5 * 65536))
+OWN_UNIT(A2AMD_LIMITER, limiter, ARR(64 << 16, 1 << 16))
+static const A2P_crdesc dc_regs[] = { { "value", wr0 }, { "mode", wr1 }, { NULL, NULL } };
+static const A2P_constdesc dc_consts[] = { { "STEP", 0 }, { "LINEAR", 1 << 16 }, { NULL, 0 } };
+static const A2P_crdesc ws_regs[] = { { "amount", wr0 }, { NULL, NULL } };
+static const A2P_crdesc dcb_regs[] = { { "cutoff", wr0 }, { NULL, NULL } };
+static const A2P_crdesc lim_regs[] = { { "release", wr0 }, { "threshold", wr1 }, { NULL, NULL } };
+const A2P_unitdesc a2_dc_unitdesc = { "dc", 0, dc_regs, NULL, dc_consts, 0, 0, 1, 2,
+	A2P_BLOCK_SIZE, dc_init, amd_deinit, amd_open, amd_close };
+const A2P_unitdesc a2_waveshaper_unitdesc = { "waveshaper", A2P_MATCHIO, ws_regs, NULL, NULL, 1, 2, 1, 2,
+	A2P_BLOCK_SIZE, wshaper_init, amd_deinit, amd_open, amd_close };
+const A2P_unitdesc a2_dcblock_unitdesc = { "dcblock", A2P_MATCHIO, dcb_regs, NULL, NULL, 1, 2, 1, 2,
+	A2P_BLOCK_SIZE, dcblock_init, amd_deinit, amd_open, amd_close };
+const A2P_unitdesc a2_limiter_unitdesc = { "limiter", A2P_MATCHIO, lim_regs, NULL, NULL, 1, 2, 1, 2,
+	A2P_BLOCK_SIZE, limiter_init, amd_deinit, amd_open, amd_close };
+
 /* ---- the wrapped engine-internal units ------------------------------------------------
  * inline and xinsert need engine internals (the voice behind a vmstate, the
  * xinsert client list), so the engine's own instances keep doing that part:

@@ -82,6 +82,11 @@ typedef enum a2amd_unitkind {
 	A2AMD_FM4P,          /* fm.c:752-772  (o1 + o2 + o3) -> o0 ->             */
 	A2AMD_FM2R,          /* fm.c:783-803  o0 * o1 (ring modulator)            */
 	A2AMD_FM4R,          /* fm.c:814-834  (o2 -> o0) * (o3 -> o1)             */
+	/* the small units (env is not built) */
+	A2AMD_DC,            /* src/units/dc.c         regs: value mode  (STEP=0, LINEAR=1<<16) */
+	A2AMD_WAVESHAPER,    /* src/units/waveshaper.c regs: amount                        */
+	A2AMD_DCBLOCK,       /* src/units/dcblock.c    regs: cutoff                        */
+	A2AMD_LIMITER,       /* src/units/limiter.c    regs: release threshold             */
 	A2AMD_NKINDS
 } a2amd_unitkind;
 

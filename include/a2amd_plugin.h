@@ -21,6 +21,8 @@
  *   a2_fbdelay_unitdesc   replaces src/units/fbdelay.c:289-309
  *   a2_fm1/fm2/fm3/fm4/fm3p/fm4p/fm2r/fm4r_unitdesc
  *                         replace  src/units/fm.c:532,579,631,688,719,752,783,814
+ *   a2_dc_unitdesc, a2_waveshaper_unitdesc, a2_dcblock_unitdesc, a2_limiter_unitdesc
+ *                         replace  src/units/dc.c:262, waveshaper.c:172, dcblock.c:168, limiter.c:228
  *   a2_inline_unitdesc    wraps    src/units/inline.c:50-69
  *   a2_xinsert_unitdesc   wraps    src/units/xinsert.c:232-252
  * Imported from the engine at load time (public API, include/a2_waves.h:183,
@@ -124,7 +126,8 @@ struct A2P_unit
 extern const A2P_unitdesc a2_wtosc_unitdesc, a2_panmix_unitdesc, a2_filter12_unitdesc,
 		a2_fbdelay_unitdesc, a2_inline_unitdesc, a2_xinsert_unitdesc,
 		a2_fm1_unitdesc, a2_fm2_unitdesc, a2_fm3_unitdesc, a2_fm4_unitdesc,
-		a2_fm3p_unitdesc, a2_fm4p_unitdesc, a2_fm2r_unitdesc, a2_fm4r_unitdesc;
+		a2_fm3p_unitdesc, a2_fm4p_unitdesc, a2_fm2r_unitdesc, a2_fm4r_unitdesc,
+		a2_dc_unitdesc, a2_waveshaper_unitdesc, a2_dcblock_unitdesc, a2_limiter_unitdesc;
 
 #ifdef __cplusplus
 }

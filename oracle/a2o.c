@@ -148,6 +148,15 @@ int a2o_f12_coeff(const uint32_t *tab, int cutoff_value, int samplerate)
 	return (int)(512.0f * 65536.0f * sin(M_PI * f / samplerate));
 }
 
+/* dcb_pitch2coeff, dcblock.c:57-64: as filter12's, from a 16:16 pitch */
+int a2o_dcb_coeff(const uint32_t *tab, int cutoff, int samplerate)
+{
+	float f = a2o_p2i(tab, cutoff) * (MIDDLEC / 16777216.0f);
+	if(f > (samplerate >> 2))
+		return 362 << 16;
+	return (int)(512.0f * 65536.0f * sin(M_PI * f / samplerate));
+}
+
 /* ------------------------------------------------------------------------
  * src/waves.c: padding, mip maps, built-in waves
  * ----------------------------------------------------------------------*/
@@ -292,6 +301,13 @@ typedef struct a2o_unit
 	int		drygain, fbgain, lgain, rgain;
 	int32_t		*lbuf, *rbuf;
 	int		bufpos;
+	/* dc (A2_dc, dc.c:42-47): ramper 'a' is reused as the value ramper */
+	int		dcmode;
+	/* waveshaper (A2_waveshaper, waveshaper.c:44-48): 'a' = amount */
+	/* dcblock (A2_dcblock, dcblock.c:33-49): f1, d1[], d2[] as filter12's */
+	/* limiter (A2_limiter, limiter.c:35-42) */
+	unsigned	threshold, peak;
+	int		release;
 	/* fm (A2_fm / A2_fmosc, fm.c:81-105) */
 	int		nops;
 	struct a2o_fmosc
@@ -770,6 +786,30 @@ int a2o_unit_init(a2o_ctx *c, uint64_t key, int kind, unsigned flags,
 	  case A2AMD_INLINE:	/* a2i_Initialize, inline.c:26-39 */
 	  case A2AMD_XINSERT:	/* xi_Initialize, xinsert.c:196-212 */
 		break;
+	  case A2AMD_DC:	/* dc_Initialize, dc.c:160-188 */
+		if(nin != 0 || nout < 1 || nout > 2)
+			return fail(c, A2AMD_EINVAL, "dc %d->%d", nin, nout);
+		ramp_init(&u->a, 0);
+		u->dcmode = 1;		/* A2DCRM_LINEAR */
+		break;
+	  case A2AMD_WAVESHAPER:	/* waveshaper_Initialize, waveshaper.c:131-156 */
+		if(nin != nout || nin < 1 || nin > 2)
+			return fail(c, A2AMD_EINVAL, "waveshaper %d->%d", nin, nout);
+		ramp_init(&u->a, 0);
+		break;
+	  case A2AMD_DCBLOCK:	/* dcb_Initialize, dcblock.c:119-153: cutoff -5.0 */
+		if(nin != nout || nin < 1 || nin > 2)
+			return fail(c, A2AMD_EINVAL, "dcblock %d->%d", nin, nout);
+		u->f1 = a2o_dcb_coeff(c->ptab, (int)((unsigned)(-5 << 16) + (unsigned)transpose),
+				c->cfg.samplerate);
+		break;
+	  case A2AMD_LIMITER:	/* limiter_Initialize, limiter.c:168-198 */
+		if(nin != nout || nin < 1 || nin > 2)
+			return fail(c, A2AMD_EINVAL, "limiter %d->%d", nin, nout);
+		u->release = ((64 << 16) << 8) / c->cfg.samplerate;
+		u->threshold = (unsigned)((1 << 16) << 8);
+		u->peak = 32768u << 8;
+		break;
 	  default:		/* fm_Initialize, fm.c:338-400 */
 		if(nin != 0 || nout != 1)
 			return fail(c, A2AMD_EINVAL, "fm %d->%d", nin, nout);
@@ -924,6 +964,50 @@ int a2o_unit_write(a2o_ctx *c, int id, int reg, int value, unsigned start,
 		  default:
 			return fail(c, A2AMD_EINVAL, "fbdelay reg %d", reg);
 		}
+		break;
+	  case A2AMD_DC:
+		if(reg == 0)	/* dc_Value, dc.c:191-215 */
+		{
+			if(u->dcmode == 0)	/* A2DCRM_STEP */
+			{
+				u->a.target = (int)((unsigned)value << 8);
+				u->a.timer = (int)(dur >> 1) - (int)start;
+				if(u->a.timer <= 0)
+				{
+					u->a.value = u->a.target;
+					u->a.timer = 0;
+				}
+			}
+			else
+				ramp_set(&u->a, value, start, dur);
+		}
+		else if(reg == 1)	/* dc_Mode, dc.c:218-238: anything but LINEAR is STEP */
+			u->dcmode = (value >> 16) == 1 ? 1 : 0;
+		else
+			return fail(c, A2AMD_EINVAL, "dc reg %d", reg);
+		break;
+	  case A2AMD_WAVESHAPER:	/* waveshaper_Amount, waveshaper.c:159-162 */
+		if(reg != 0)
+			return fail(c, A2AMD_EINVAL, "waveshaper reg %d", reg);
+		ramp_set(&u->a, value, start, dur);
+		break;
+	  case A2AMD_DCBLOCK:	/* dcb_CutOff, dcblock.c:112-117 */
+		if(reg != 0)
+			return fail(c, A2AMD_EINVAL, "dcblock reg %d", reg);
+		u->f1 = a2o_dcb_coeff(c->ptab, (int)((unsigned)value + (unsigned)transpose),
+				c->cfg.samplerate);
+		break;
+	  case A2AMD_LIMITER:	/* limiter.c:201-213 */
+		if(reg == 0)
+			u->release = (int)((unsigned)value << 8) / c->cfg.samplerate;
+		else if(reg == 1)
+		{
+			u->threshold = (unsigned)value << 8;
+			if(u->threshold < 256)
+				u->threshold = 256;
+		}
+		else
+			return fail(c, A2AMD_EINVAL, "limiter reg %d", reg);
 		break;
 	  default:
 		if(!IS_FM(u->kind))
@@ -1342,6 +1426,158 @@ static void fbdelay_process(a2o_unit *fbd, int32_t **in, int32_t **out,
  * master bus (A2_state.master) when none is.
  */
 
+/* ---- dc.c, waveshaper.c, dcblock.c, limiter.c -------------------------------*/
+
+/* dc_process, dc.c:56-134 */
+static void dc_process(a2o_unit *dc, int32_t **out, unsigned offset,
+		unsigned frames, int outputs, int add)
+{
+	ramper *v = &dc->a;
+	unsigned s, end = offset + frames;
+	int o;
+#define DC_PUT(x) for(o = 0; o < outputs; ++o) { if(add) out[o][s] += (x); else out[o][s] = (x); }
+	if(dc->dcmode == 0)	/* A2DCRM_STEP */
+	{
+		s = offset;
+		if(v->timer >= 256)
+		{
+			unsigned e2;
+			if((unsigned)(v->timer >> 8) >= frames)
+			{
+				e2 = end;
+				v->timer -= (int)(frames << 8);
+			}
+			else
+			{
+				e2 = s + (unsigned)(v->timer >> 8);
+				v->timer &= 0xff;
+			}
+			for( ; s < e2; ++s)
+				DC_PUT(v->value)
+		}
+		if((v->timer < 256) && (s < end))
+		{
+			int tv = ((v->value >> 4) * v->timer +
+					(v->target >> 4) * (256 - v->timer)) >> 4;
+			DC_PUT(tv)
+			++s;
+			v->timer = 0;
+			v->value = v->target;
+		}
+		for( ; s < end; ++s)
+			DC_PUT(v->target)
+	}
+	else			/* A2DCRM_LINEAR */
+	{
+		ramp_prepare(v, (int)frames);
+		for(s = offset; s < end; ++s)
+		{
+			DC_PUT(v->value)
+			ramp_run(v, 1);
+		}
+	}
+#undef DC_PUT
+}
+
+/* waveshaper_process, waveshaper.c:57-112 (the fixed point branch) */
+static void waveshaper_process(a2o_unit *ws, int32_t **in, int32_t **out,
+		unsigned offset, unsigned frames, int add, int channels)
+{
+	unsigned s, end = offset + frames;
+	int c;
+	ramp_prepare(&ws->a, (int)frames);
+	for(s = offset; s < end; ++s)
+	{
+		int32_t a = ws->a.value;
+		int32_t a3p1 = (int32_t)(((uint32_t)a << 1) + (uint32_t)a + (1u << 24));
+		int32_t asqr = (int32_t)((int64_t)(a >> 4) * (a >> 4) >> 24);
+		for(c = 0; c < channels; ++c)
+		{
+			int32_t v = in[c][s];
+			int32_t vsqr = (int32_t)((int64_t)v * v >> 22);
+			int64_t vout = (int64_t)v * a3p1;
+			int64_t sqrsub = (int64_t)a * vsqr;
+			if(v >= 0)
+				vout -= sqrsub;
+			else
+				vout += sqrsub;
+			vout /= ((int64_t)asqr * vsqr >> 16) + (1 << 24);
+			if(add)
+				out[c][s] += (int32_t)vout;
+			else
+				out[c][s] = (int32_t)vout;
+		}
+		ramp_run(&ws->a, 1);
+	}
+}
+
+/* dcb_process, dcblock.c:66-95 */
+static void dcb_process(a2o_unit *dcb, int32_t **in, int32_t **out,
+		unsigned offset, unsigned frames, int add, int channels)
+{
+	unsigned s, end = offset + frames;
+	int c, f = dcb->f1 >> 12;
+	for(s = offset; s < end; ++s)
+		for(c = 0; c < channels; ++c)
+		{
+			int d1 = dcb->d1[c] >> 4;
+			int l = dcb->d2[c] + (f * d1 >> 8);
+			int h = (in[c][s] >> 5) - l - (int)((unsigned)d1 << 4);
+			int b = (f * (h >> 4) >> 8) + dcb->d1[c];
+			int fout = (int)((unsigned)h << 5);
+			if(add)
+				out[c][s] += fout;
+			else
+				out[c][s] = fout;
+			dcb->d1[c] = b;
+			dcb->d2[c] = l;
+		}
+}
+
+static int iabs(int x)
+{
+	return x < 0 ? (int)(0u - (unsigned)x) : x;	/* abs(), INT_MIN stays */
+}
+
+/* limiter_process11 / limiter_process22, limiter.c:51-158 */
+static void limiter_process(a2o_unit *lim, int32_t **in, int32_t **out,
+		unsigned offset, unsigned frames, int add, int channels)
+{
+	unsigned s, end = offset + frames;
+	int c;
+	for(s = offset; s < end; ++s)
+	{
+		int gain;
+		unsigned p;
+		if(channels == 1)
+			p = (unsigned)iabs(in[0][s]);
+		else
+		{
+			int lp = iabs(in[0][s]), rp = iabs(in[1][s]);
+			p = (unsigned)(lp > rp ? lp : rp);
+			p = p + ((p - (unsigned)iabs(lp - rp)) >> 1);
+		}
+		if(p > lim->peak)
+			lim->peak = p;
+		else
+		{
+			lim->peak -= (unsigned)lim->release;
+			if(lim->peak < lim->threshold)
+				lim->peak = lim->threshold;
+			p = lim->peak;
+		}
+		gain = (int)((32767LL << 16) / ((p + 511) >> 9));
+		for(c = 0; c < channels; ++c)
+		{
+			int32_t r = (int32_t)((int64_t)in[c][s] * gain >> 16);
+			if(add)
+				out[c][s] += r;
+			else
+				out[c][s] = r;
+		}
+	}
+}
+
 /* ---- fm.c ----------------------------------------------------------------*/
 
 /* a2_Lerp, a2_dsp.h:50-55 */
@@ -1552,6 +1788,18 @@ int a2o_unit_process(a2o_ctx *c, int id, unsigned offset, unsigned frames,
 				for(s = offset; s < offset + frames; ++s)
 					out[ch][s] = in[ch][s];
 		}
+		break;
+	  case A2AMD_DC:
+		dc_process(u, out, offset, frames, u->nout, add);
+		break;
+	  case A2AMD_WAVESHAPER:
+		waveshaper_process(u, in, out, offset, frames, add, u->nin);
+		break;
+	  case A2AMD_DCBLOCK:
+		dcb_process(u, in, out, offset, frames, add, u->nin);
+		break;
+	  case A2AMD_LIMITER:
+		limiter_process(u, in, out, offset, frames, add, u->nin);
 		break;
 	  default:		/* fm*_Process[Add], fm.c:235-322 */
 		fm_process(c, u, out[0], offset, frames, add);

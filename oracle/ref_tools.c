@@ -43,6 +43,7 @@ enum { T_FRAGMENT = 1, T_INIT, T_DEINIT, T_WRITE, T_PROCESS, T_INLINE_END,
 		T_WAVE, T_CONFIG };
 enum { K_WTOSC = 0, K_PANMIX, K_FILTER12, K_FBDELAY, K_INLINE, K_XINSERT,
 		K_FM1, K_FM2, K_FM3, K_FM4, K_FM3P, K_FM4P, K_FM2R, K_FM4R,
+		K_DC, K_WAVESHAPER, K_DCBLOCK, K_LIMITER,
 		K_COUNT };	/* = a2amd_unitkind, include/a2amd.h */
 
 static FILE *tracef;
@@ -118,7 +119,9 @@ static const char *orig_sym[K_COUNT] = {
 	"a2_fbdelay_unitdesc", "a2_inline_unitdesc", "a2_xinsert_unitdesc",
 	"a2_fm1_unitdesc", "a2_fm2_unitdesc", "a2_fm3_unitdesc",
 	"a2_fm4_unitdesc", "a2_fm3p_unitdesc", "a2_fm4p_unitdesc",
-	"a2_fm2r_unitdesc", "a2_fm4r_unitdesc"
+	"a2_fm2r_unitdesc", "a2_fm4r_unitdesc",
+	"a2_dc_unitdesc", "a2_waveshaper_unitdesc", "a2_dcblock_unitdesc",
+	"a2_limiter_unitdesc"
 };
 
 static const A2_unitdesc *get_orig(int k)
@@ -261,6 +264,10 @@ KIND_FUNCS(K_FM3P, fm3p)
 KIND_FUNCS(K_FM4P, fm4p)
 KIND_FUNCS(K_FM2R, fm2r)
 KIND_FUNCS(K_FM4R, fm4r)
+KIND_FUNCS(K_DC, dc)
+KIND_FUNCS(K_WAVESHAPER, wshaper)
+KIND_FUNCS(K_DCBLOCK, dcblock)
+KIND_FUNCS(K_LIMITER, limiter)
 
 static const A2_crdesc wtosc_regs[] = {
 	{ "w", tr_write0 }, { "p", tr_write1 }, { "a", tr_write2 },
@@ -318,6 +325,27 @@ FM_DESC(fm1, "fm1", fm1_regs) FM_DESC(fm2, "fm2", fm2_regs)
 FM_DESC(fm3, "fm3", fm3_regs) FM_DESC(fm4, "fm4", fm4_regs)
 FM_DESC(fm3p, "fm3p", fm3_regs) FM_DESC(fm4p, "fm4p", fm4_regs)
 FM_DESC(fm2r, "fm2r", fm2_regs) FM_DESC(fm4r, "fm4r", fm4_regs)
+
+/* dc.c:241-281, waveshaper.c:165-193, dcblock.c:162-190, limiter.c:222-250 */
+static const A2_crdesc dc_regs[] = {
+	{ "value", tr_write0 }, { "mode", tr_write1 }, { NULL, NULL } };
+static const A2_constdesc dc_consts[] = {
+	{ "STEP", 0 << 16 }, { "LINEAR", 1 << 16 }, { NULL, 0 } };
+static const A2_crdesc ws_regs[] = { { "amount", tr_write0 }, { NULL, NULL } };
+static const A2_crdesc dcb_regs[] = { { "cutoff", tr_write0 }, { NULL, NULL } };
+static const A2_crdesc lim_regs[] = {
+	{ "release", tr_write0 }, { "threshold", tr_write1 }, { NULL, NULL } };
+const A2_unitdesc a2_dc_unitdesc = { "dc", 0, dc_regs, NULL, dc_consts,
+	0, 0, 1, 2, BLOCKSIZE, dc_init, dc_deinit, dc_open, dc_close };
+const A2_unitdesc a2_waveshaper_unitdesc = { "waveshaper", A2_MATCHIO, ws_regs,
+	NULL, NULL, 1, 2, 1, 2, BLOCKSIZE, wshaper_init, wshaper_deinit,
+	wshaper_open, wshaper_close };
+const A2_unitdesc a2_dcblock_unitdesc = { "dcblock", A2_MATCHIO, dcb_regs,
+	NULL, NULL, 1, 2, 1, 2, BLOCKSIZE, dcblock_init, dcblock_deinit,
+	dcblock_open, dcblock_close };
+const A2_unitdesc a2_limiter_unitdesc = { "limiter", A2_MATCHIO, lim_regs,
+	NULL, NULL, 1, 2, 1, 2, BLOCKSIZE, limiter_init, limiter_deinit,
+	limiter_open, limiter_close };
 
 /* ---------------------------------------------------------------------- */
 

@@ -45,6 +45,10 @@ CASES = [
     ("fm", f"{A2S}/fm.a2s", "Main", 3 * 48000, ["0.15"]),
     ("fmtest3", f"{REF}/benchmark/fmtest3.a2s", "Song", 5 * 48000, []),
     ("fmtest4", f"{REF}/benchmark/fmtest4.a2s", "Song", 5 * 48000, []),
+    # dc, waveshaper, dcblock, limiter
+    ("fx", f"{A2S}/fx.a2s", "Main", 3 * 48000, ["0.1"]),
+    ("dctest", f"{REF}/benchmark/dctest.a2s", "Song", 5 * 48000, []),
+    ("wstest", f"{REF}/benchmark/wstest.a2s", "Song", 5 * 48000, []),
     # the reference's own benchmark songs (benchmark/RESULTS): all five use only
     # units on the hot path
     ("k2intro", f"{REF}/benchmark/k2intro.a2s", "Song", 6 * 48000, []),

@@ -23,7 +23,9 @@ CASES = [("sustain", ["4", "0.05"], 9600), ("filter", ["4", "0.02"], 48000),
          # states get GPU contexts of their own next to the master state's
          ("edge", ["0.2"], 4 * 48000),
          # the FM oscillator units
-         ("fm", ["0.15"], 3 * 48000)]
+         ("fm", ["0.15"], 3 * 48000),
+         # dc, waveshaper, dcblock, limiter
+         ("fx", ["0.1"], 3 * 48000)]
 REALTIME_CASES = {"edge"}      # see tests/golden/make_goldens.py
 
 
