@@ -145,6 +145,8 @@ struct HVoice {
 	bool resolved = false, started = false;
 	int depth = 0;
 	int inline_pos = -1;		// chain position of the inline unit, if any
+	int win_done = 0;		// units of the chain that have processed the window in progress
+	std::vector<A2DRec> deferred;	// writes waiting behind that window's SEG record
 	int out_off = 0, out_nch = 0;
 	int own_off = -1, own_nch = 0;
 	int win_off = -1, win_frames = 0;
@@ -321,7 +323,21 @@ void push_rec(a2amd_ctx *c, int vi, int op, int unit, int reg, int value, unsign
 		v.listed_recs = true;
 		c->with_recs.push_back(vi);
 	}
+	// A write that reaches a unit which has already rendered the window the
+	// voice is in (a control wire from a unit further down the chain, e.g. the
+	// engine's env, env.c:135) takes effect after that window: the device
+	// executes a window as one SEG record, so the write waits behind it.
+	if(op != R_SEG && op != R_INIT && op != R_KILL && unit < v.win_done) {
+		v.deferred.push_back(r);
+		return;
+	}
 	v.recs.push_back(r);
+	if(op == R_SEG) {
+		v.win_done = 0;
+		for(A2DRec &d : v.deferred)
+			v.recs.push_back(d);
+		v.deferred.clear();
+	}
 }
 
 int bus_alloc(a2amd_ctx *c, int nch)
@@ -1592,6 +1608,7 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 	  default:
 		break;
 	}
+	v.win_done = u.chainpos + 1;
 	if(u.chainpos == v.nunits - 1)
 		push_rec(c, vi, R_SEG, 0, 0, 0, offset | (frames << 16), 0);
 	return A2AMD_OK;

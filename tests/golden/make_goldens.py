@@ -49,6 +49,8 @@ CASES = [
     ("fx", f"{A2S}/fx.a2s", "Main", 3 * 48000, ["0.1"]),
     ("dctest", f"{REF}/benchmark/dctest.a2s", "Song", 5 * 48000, []),
     ("wstest", f"{REF}/benchmark/wstest.a2s", "Song", 5 * 48000, []),
+    # the engine's own env unit (stays on the CPU) wired to replaced units
+    ("envwire", f"{A2S}/envwire.a2s", "Main", 2 * 48000, ["0.2"]),
     # the reference's own benchmark songs (benchmark/RESULTS): all five use only
     # units on the hot path
     ("k2intro", f"{REF}/benchmark/k2intro.a2s", "Song", 6 * 48000, []),

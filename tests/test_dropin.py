@@ -25,7 +25,9 @@ CASES = [("sustain", ["4", "0.05"], 9600), ("filter", ["4", "0.02"], 48000),
          # the FM oscillator units
          ("fm", ["0.15"], 3 * 48000),
          # dc, waveshaper, dcblock, limiter
-         ("fx", ["0.1"], 3 * 48000)]
+         ("fx", ["0.1"], 3 * 48000),
+         # the engine's env unit on the CPU driving GPU units through control wires
+         ("envwire", ["0.2"], 2 * 48000)]
 REALTIME_CASES = {"edge"}      # see tests/golden/make_goldens.py
 
 

@@ -12,7 +12,7 @@ from conftest import GOLDEN, fnv1a_fragments, make_gpu, make_oracle
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["sustain", "filter", "delaybus", "scripted", "edge", "fm", "fmtest3", "fmtest4", "fx", "dctest", "wstest", "k2intro", "k2epilogue", "k2loader", "k2trance", "pulsetronic"]
+CASES = ["sustain", "filter", "delaybus", "scripted", "edge", "fm", "fmtest3", "fmtest4", "fx", "dctest", "wstest", "envwire", "k2intro", "k2epilogue", "k2loader", "k2trance", "pulsetronic"]
 
 
 def first_diff(a, b):

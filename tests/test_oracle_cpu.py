@@ -10,7 +10,7 @@ from audiality2_amd import synth
 from audiality2_amd.replay import Trace, replay
 from conftest import GOLDEN, fnv1a_fragments, make_oracle
 
-CASES = ["sustain", "filter", "delaybus", "scripted", "edge", "fm", "fmtest3", "fmtest4", "fx", "dctest", "wstest", "k2intro", "k2epilogue", "k2loader", "k2trance", "pulsetronic"]
+CASES = ["sustain", "filter", "delaybus", "scripted", "edge", "fm", "fmtest3", "fmtest4", "fx", "dctest", "wstest", "envwire", "k2intro", "k2epilogue", "k2loader", "k2trance", "pulsetronic"]
 
 
 @pytest.mark.parametrize("name", CASES)
