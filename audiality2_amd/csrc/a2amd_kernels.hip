@@ -183,9 +183,14 @@ DEV void osc_mipwave(Ctx &c, uint32_t desc, Osc &o, int offset, int frames)
 {
 	const A2DParams &p = *c.p;
 	const A2DWave &w = p.waves[o.wave];
-	if(!w.size[0]) {		// wtosc_check_unloaded, wtosc.c:168-183
+	if(!w.size[0]) {
+		// wtosc_check_unloaded, wtosc.c:168-183.  The reference leaves the
+		// output buffer untouched in this window (the voice replays what
+		// another voice left in the shared scratch bus); we render silence,
+		// as in every following window.
 		o.wave = -1;
 		o.mode = A2D_OSC_OFF;
+		osc_zero(c, desc, offset, frames);
 		return;
 	}
 	osc_run_pitch(p, o, frames);
@@ -221,6 +226,7 @@ DEV void osc_wave(Ctx &c, uint32_t desc, Osc &o, int offset, int frames)
 	if(!w.size[0]) {
 		o.wave = -1;
 		o.mode = A2D_OSC_OFF;
+		osc_zero(c, desc, offset, frames);
 		return;
 	}
 	const int16_t *d = p.wavepool + w.off[0];

@@ -69,6 +69,7 @@ typedef struct XTRA
 	int		follow;		/* backend id of a trailing xinsert to process along */
 	int		is_root;
 	A2P_process_cb	orig_process;
+	A2P_wave	*wave;		/* wtosc: the wave it plays (engine object), or NULL */
 } XTRA;
 
 static inline XTRA *xtra(A2P_unit *u)
@@ -206,11 +207,38 @@ static void amd_deinit(A2P_unit *u)
 }
 
 /* ---- Process ---------------------------------------------------------------------*/
+/* A wave released by the application keeps its A2_wave for one more engine
+ * cycle with size[0] = 0 ("unloaded", waves.c:711-718); the engine's wtosc looks
+ * at that at the top of every Process call (wtosc.c:168-183) and so do we: the
+ * device copy is dropped, every oscillator playing it goes silent. */
+static void check_unloaded(XTRA *x)
+{
+	HOSTSTATE *hs = x->hs;
+	A2P_wave *w = x->wave;
+	int i, rc;
+	if(!w || (w->type != A2AMD_WWAVE && w->type != A2AMD_WMIPWAVE) || w->size[0])
+		return;
+	x->wave = NULL;
+	for(i = 0; i < hs->nwaves; ++i)
+		if(hs->wave_ptr[i] == w)
+		{
+			if((rc = a2amd_wave_drop(hs->ctx, (uint64_t)(uintptr_t)w)))
+				die(hs, "a2amd_wave_drop", rc);
+			/* forget the address: malloc may hand it out again */
+			hs->wave_ptr[i] = hs->wave_ptr[hs->nwaves - 1];
+			hs->wave_id[i] = hs->wave_id[hs->nwaves - 1];
+			--hs->nwaves;
+			break;
+		}
+}
+
 static void forward_process(XTRA *x, unsigned offset, unsigned frames)
 {
 	HOSTSTATE *hs = x->hs;
 	uint32_t noise = 0, before = 0;
 	int rc, v = 0;
+	if(x->kind == A2AMD_WTOSC)
+		check_unloaded(x);
 	if(x->kind == A2AMD_WTOSC)
 	{
 		/* the engine-global RNG the noise oscillators share with the VM's
@@ -302,7 +330,10 @@ static void amd_write(A2P_unit *u, int reg, int v, unsigned start, unsigned dur)
 	XTRA *x = xtra(u);
 	int rc;
 	if(x->kind == A2AMD_WTOSC && reg == 0)		/* wtosc_Wave, wtosc.c:433-440 */
-		v = wave_id_of(x->hs, a2_GetWave(x->hs->cfg->interface, v >> 16));
+	{
+		x->wave = a2_GetWave(x->hs->cfg->interface, v >> 16);
+		v = wave_id_of(x->hs, x->wave);
+	}
 	if((rc = a2amd_unit_write(x->hs->ctx, x->uid, reg, v, start, dur, x->vms->r[A2P_R_TRANSPOSE])))
 		die(x->hs, "a2amd_unit_write", rc);
 }

@@ -17,7 +17,7 @@ import lzma
 
 import numpy as np
 
-T_FRAGMENT, T_INIT, T_DEINIT, T_WRITE, T_PROCESS, T_INLINE_END, T_WAVE, T_CONFIG = range(1, 9)
+T_FRAGMENT, T_INIT, T_DEINIT, T_WRITE, T_PROCESS, T_INLINE_END, T_WAVE, T_CONFIG, T_WAVEDROP = range(1, 10)
 MIPLEVELS = 10
 WAVEPRE = 1
 WAVEPOST = 131
@@ -209,6 +209,14 @@ def replay(trace, backend, batch=64, check_noise=True, max_fragments=None):
             w = trace.waves[r[1]]
             wmap[r[1]] = backend.wave_upload(0x1000 + r[1], w["type"], w["flags"], w["period"],
                                              w["sizes"], w["data"])
+        elif op == T_WAVEDROP:
+            # the wave was released between two a2_Run() calls: what was
+            # recorded so far plays it to the end
+            if pending:
+                outs.append(backend.render(pending))
+                pending = 0
+            backend.wave_drop(0x1000 + r[1])
+            wmap.pop(r[1], None)
         elif op == T_INIT:
             _, uid, voice, kind, flags, io, transpose, wakefrac = r
             umap[uid] = backend.unit_init(voice, kind, flags & 0xFFFFFFFF, io & 0xFF,

@@ -1117,12 +1117,21 @@ static uint64_t wtosc_do_fragment(a2o_unit *o, const int16_t *d, int32_t *out,
 }
 
 /* wtosc_check_unloaded, wtosc.c:168-183 */
-static int wtosc_check_unloaded(a2o_unit *o, a2o_wave *w)
+/* wtosc_check_unloaded, wtosc.c:168-183.  DELIBERATE DEVIATION: the reference
+ * returns from Process without touching its output buffer in the window in
+ * which it notices, so the voice plays whatever the previously rendered voice
+ * left in the scratch bus they share (core.c:365-395) for that one window.
+ * That depends on the traversal order of unrelated voices; here (and on the
+ * GPU) the window is silent, as every following one is (wtosc_Off). */
+static int wtosc_check_unloaded(a2o_unit *o, a2o_wave *w, int32_t *out,
+		unsigned offset, unsigned frames, int add)
 {
 	if(w->size[0])
 		return 0;
 	o->wave = -1;
 	o->mode = OSC_OFF;
+	if(!add)
+		memset(out + offset, 0, frames * sizeof(int32_t));
 	return 1;
 }
 
@@ -1133,7 +1142,7 @@ static void wtosc_wavetable(a2o_ctx *c, a2o_unit *o, int32_t *out,
 	unsigned mm, dph;
 	uint64_t ph;
 	a2o_wave *w = osc_wave(c, o);
-	if(wtosc_check_unloaded(o, w))
+	if(wtosc_check_unloaded(o, w, out, offset, frames, add))
 		return;
 	wtosc_run_pitch(c, o, frames);
 	dph = ((o->dphase + 255) >> 8) * w->period;
@@ -1172,7 +1181,7 @@ static void wtosc_wavetable_no_mip(a2o_ctx *c, a2o_unit *o, int32_t *out,
 	uint64_t dph;
 	a2o_wave *w = osc_wave(c, o);
 	const int16_t *d;
-	if(wtosc_check_unloaded(o, w))
+	if(wtosc_check_unloaded(o, w, out, offset, frames, add))
 		return;
 	d = w->data[0] + WAVEPRE;
 	wtosc_run_pitch(c, o, frames);

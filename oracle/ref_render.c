@@ -17,13 +17,31 @@
 #include "a2_drivers.h"
 #include "a2_vm.h"
 
+
+/*
+ * A2REF_UPLOAD=<frames>: upload a wave through the API before the program
+ * starts (a2_UploadWave, waves.c:559), hand its handle to the program as one
+ * more argument, and release it again after <frames> frames while voices are
+ * still playing it - the "wave unloaded under a running oscillator" case of
+ * wtosc_check_unloaded (wtosc.c:168-183, waves.c:717-723).
+ */
+static A2_handle upload_test_wave(A2_interface *i)
+{
+	static int16_t data[3000];
+	int k;
+	for(k = 0; k < 3000; ++k)
+		data[k] = (int16_t)(((k * 7919) % 4001 - 2000) * 6 + (k % 300 - 150) * 40);
+	return a2_UploadWave(i, A2_WMIPWAVE, 0, A2_LOOPED, A2_I16, data, sizeof(data));
+}
+
 int main(int argc, const char *argv[])
 {
 	int frames, buffer, rate, channels, nargs, pargs[A2_MAXARGS], k, done = 0, c;
 	A2_config *cfg;
 	A2_driver *drv;
 	A2_interface *i;
-	A2_handle bank, prog;
+	A2_handle bank, prog, upwave = -1;
+	int release_at = 0;
 	FILE *pcm;
 	if(argc < 8)
 	{
@@ -63,12 +81,29 @@ int main(int argc, const char *argv[])
 		fprintf(stderr, "cannot load %s / %s\n", argv[1], argv[2]);
 		return 1;
 	}
+	if(getenv("A2REF_UPLOAD"))
+	{
+		release_at = atoi(getenv("A2REF_UPLOAD"));
+		if((upwave = upload_test_wave(i)) < 0 || nargs >= A2_MAXARGS)
+			return 1;
+		pargs[nargs++] = upwave << 16;
+	}
 	a2_TimestampReset(i);
 	if(a2_Starta(i, a2_RootVoice(i), prog, nargs, pargs) < 0)
 		return 1;
 	while(done < frames)
 	{
 		int n = frames - done < buffer ? frames - done : buffer;
+		if(upwave >= 0 && done >= release_at)
+		{
+			if(a2_Release(i, upwave))
+			{
+				/* offline states cannot release (interface.c:496-505) */
+				fprintf(stderr, "a2_Release failed: use A2REF_REALTIME=1\n");
+				return 1;
+			}
+			upwave = -1;
+		}
 		if(a2_Run(i, n) < 0)
 			return 1;
 		a2_PumpMessages(i);

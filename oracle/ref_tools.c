@@ -40,7 +40,7 @@
 #include "a2_drivers.h"
 
 enum { T_FRAGMENT = 1, T_INIT, T_DEINIT, T_WRITE, T_PROCESS, T_INLINE_END,
-		T_WAVE, T_CONFIG };
+		T_WAVE, T_CONFIG, T_WAVEDROP };
 enum { K_WTOSC = 0, K_PANMIX, K_FILTER12, K_FBDELAY, K_INLINE, K_XINSERT,
 		K_FM1, K_FM2, K_FM3, K_FM4, K_FM3P, K_FM4P, K_FM2R, K_FM4R,
 		K_DC, K_WAVESHAPER, K_DCBLOCK, K_LIMITER,
@@ -426,6 +426,24 @@ static int do_dump(const char *dir)
 	return 0;
 }
 
+
+/*
+ * A2REF_UPLOAD=<frames>: upload a wave through the API before the program
+ * starts (a2_UploadWave, waves.c:559), hand its handle to the program as one
+ * more argument, and release it again after <frames> frames while voices are
+ * still playing it - the "wave unloaded under a running oscillator" case of
+ * wtosc_check_unloaded (wtosc.c:168-183, waves.c:717-723).  The trace gets a
+ * T_WAVEDROP record at that point (between two a2_Run() calls).
+ */
+static A2_handle upload_test_wave(A2_interface *i)
+{
+	static int16_t data[3000];
+	int k;
+	for(k = 0; k < 3000; ++k)
+		data[k] = (int16_t)(((k * 7919) % 4001 - 2000) * 6 + (k % 300 - 150) * 40);
+	return a2_UploadWave(i, A2_WMIPWAVE, 0, A2_LOOPED, A2_I16, data, sizeof(data));
+}
+
 static int do_trace(int argc, const char *argv[])
 {
 	const char *script = argv[2], *program = argv[3];
@@ -435,7 +453,9 @@ static int do_trace(int argc, const char *argv[])
 	int nargs = argc - 10, pargs[A2_MAXARGS], k, done = 0, c;
 	A2_config *cfg;
 	A2_driver *drv;
-	A2_handle bank, prog, vh;
+	A2_handle bank, prog, vh, upwave = -1;
+	A2_wave *upwave_ptr = NULL;
+	int release_at = 0;
 	FILE *pcm;
 
 	if(nargs > A2_MAXARGS)
@@ -490,6 +510,14 @@ static int do_trace(int argc, const char *argv[])
 		fprintf(stderr, "no program %s\n", program);
 		return 1;
 	}
+	if(getenv("A2REF_UPLOAD"))
+	{
+		release_at = atoi(getenv("A2REF_UPLOAD"));
+		if((upwave = upload_test_wave(g_iface)) < 0 || nargs >= A2_MAXARGS)
+			return 1;
+		upwave_ptr = a2_GetWave(g_iface, upwave);
+		pargs[nargs++] = upwave << 16;
+	}
 	a2_TimestampReset(g_iface);
 	vh = a2_Starta(g_iface, a2_RootVoice(g_iface), prog, nargs, pargs);
 	if(vh < 0)
@@ -501,6 +529,23 @@ static int do_trace(int argc, const char *argv[])
 	{
 		int n = frames - done < buffer ? frames - done : buffer;
 		int left = n;
+		if(upwave >= 0 && done >= release_at)
+		{
+			int k;
+			for(k = 0; k < nwaves; ++k)
+				if(wave_ptr[k] == upwave_ptr)
+				{
+					rec(T_WAVEDROP, k, 0, 0, 0, 0, 0, 0);
+					wave_ptr[k] = NULL;	/* the address may be reused */
+				}
+			if(a2_Release(g_iface, upwave))
+			{
+				/* offline states cannot release (interface.c:496-505) */
+				fprintf(stderr, "a2_Release failed: use A2REF_REALTIME=1\n");
+				return 1;
+			}
+			upwave = -1;
+		}
 		/* a2_AudioCallback cuts the buffer into fragments of <= 64
 		 * frames (core.c:1964-1973); log the same cuts. */
 		while(left)

@@ -58,3 +58,19 @@ def make_oracle(oracle_lib, samplerate=48000, basepitch=None, channels=2):
 def make_gpu(samplerate=48000, basepitch=None, channels=2, max_batch=64):
     import audiality2_amd
     return audiality2_amd.open_backend(samplerate, basepitch, channels, max_batch=max_batch)
+
+
+# Fragments of a fixture in which we knowingly differ from the reference.
+#   unload/313: the fragment in which the oscillators notice that their wave
+#   was released.  The reference's wtosc returns without writing its output
+#   there (wtosc.c:168-183), so each voice replays what the previously rendered
+#   voice left in the shared scratch bus for that one window; oracle and GPU
+#   render silence.  Everything before and after is exact.
+KNOWN_DEVIATIONS = {"unload": [313]}
+
+
+def differing_fragments(name, got, want):
+    """Indices where the per-fragment hashes differ, minus the documented ones."""
+    import numpy as np
+    bad = np.nonzero(got != want)[0]
+    return np.array([b for b in bad if b not in KNOWN_DEVIATIONS.get(name, [])], dtype=int)

@@ -51,16 +51,22 @@ CASES = [
     ("wstest", f"{REF}/benchmark/wstest.a2s", "Song", 5 * 48000, []),
     # the engine's own env unit (stays on the CPU) wired to replaced units
     ("envwire", f"{A2S}/envwire.a2s", "Main", 2 * 48000, ["0.2"]),
+    # a wave uploaded by the application and released under running oscillators (A2REF_UPLOAD)
+    ("unload", f"{A2S}/unload.a2s", "Main", 48000, ["0.1"]),
     # the reference's own benchmark songs (benchmark/RESULTS): all five use only
     # units on the hot path
     ("k2intro", f"{REF}/benchmark/k2intro.a2s", "Song", 6 * 48000, []),
+    # BASELINE configs[0] is quoted at 44.1 kHz (benchmark.sh: a2play -dbuffer -r44100): base pitch,
+    # filter coefficients and delay lengths all depend on the rate
+    ("k2intro44", f"{REF}/benchmark/k2intro.a2s", "Song", 3 * 44100 // 64 * 64, []),
     ("k2epilogue", f"{REF}/benchmark/k2epilogue.a2s", "Song", 5 * 48000, []),
     ("k2loader", f"{REF}/benchmark/k2loader.a2s", "Song", 5 * 48000, []),
     ("k2trance", f"{REF}/benchmark/k2trance.a2s", "Song", 5 * 48000, []),
     ("pulsetronic", f"{REF}/benchmark/pulsetronic.a2s", "Song", 5 * 48000, []),
 ]
 
-REALTIME_CASES = {"edge"}
+REALTIME_CASES = {"edge", "unload"}
+UPLOAD_CASES = {"unload": "20000"}       # release the uploaded wave after this many frames
 
 
 def fnv1a_fragments(pcm, frag=64):
@@ -87,7 +93,10 @@ def main():
         env = dict(os.environ)
         if name in REALTIME_CASES:
             env["A2REF_REALTIME"] = "1"
-        subprocess.run([TOOLS, "trace", script, prog, str(frames), "64", "48000", "2", tr, pcm] + args,
+        if name in UPLOAD_CASES:
+            env["A2REF_UPLOAD"] = UPLOAD_CASES[name]
+        rate = "44100" if name.endswith("44") else "48000"
+        subprocess.run([TOOLS, "trace", script, prog, str(frames), "64", rate, "2", tr, pcm] + args,
                        check=True, cwd=os.path.dirname(script), env=env)
         with open(tr, "rb") as f, lzma.open(f"{HERE}/{name}.trace.xz", "wb", preset=9 | lzma.PRESET_EXTREME) as g:
             g.write(f.read())

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from audiality2_amd.replay import read_pcm
-from conftest import GOLDEN, ROOT, fnv1a_fragments
+from conftest import GOLDEN, ROOT, differing_fragments, fnv1a_fragments
 
 REF_RENDER = os.path.join(ROOT, "oracle", "_ref", "ref_render")
 UNITS_SO = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
@@ -27,8 +27,11 @@ CASES = [("sustain", ["4", "0.05"], 9600), ("filter", ["4", "0.02"], 48000),
          # dc, waveshaper, dcblock, limiter
          ("fx", ["0.1"], 3 * 48000),
          # the engine's env unit on the CPU driving GPU units through control wires
-         ("envwire", ["0.2"], 2 * 48000)]
-REALTIME_CASES = {"edge"}      # see tests/golden/make_goldens.py
+         ("envwire", ["0.2"], 2 * 48000),
+         # the application releases a wave under running oscillators
+         ("unload", ["0.1"], 48000)]
+REALTIME_CASES = {"edge", "unload"}      # see tests/golden/make_goldens.py
+UPLOAD_CASES = {"unload": "20000"}
 
 
 def need_ref():
@@ -44,12 +47,14 @@ def test_engine_with_dropin_units_matches_reference(tmp_path, name, args, frames
     env = dict(os.environ, LD_PRELOAD=UNITS_SO)
     if name in REALTIME_CASES:
         env["A2REF_REALTIME"] = "1"
+    if name in UPLOAD_CASES:
+        env["A2REF_UPLOAD"] = UPLOAD_CASES[name]
     subprocess.run([REF_RENDER, f"{A2S}/{name}.a2s", "Main", str(frames), "64", "48000", "2", str(out)] + args,
                    check=True, env=env, cwd=A2S, timeout=600)
     audio = read_pcm(out, 2, 64)
     want = np.load(os.path.join(GOLDEN, f"{name}.hash.npy"))
     got = fnv1a_fragments(audio)
-    bad = np.nonzero(got != want)[0]
+    bad = differing_fragments(name, got, want)
     assert len(bad) == 0, f"{len(bad)} fragments differ from the reference render, first {bad[:5]}"
 
 

@@ -8,9 +8,9 @@ import pytest
 
 from audiality2_amd import synth
 from audiality2_amd.replay import Trace, replay
-from conftest import GOLDEN, fnv1a_fragments, make_oracle
+from conftest import GOLDEN, differing_fragments, fnv1a_fragments, make_oracle
 
-CASES = ["sustain", "filter", "delaybus", "scripted", "edge", "fm", "fmtest3", "fmtest4", "fx", "dctest", "wstest", "envwire", "k2intro", "k2epilogue", "k2loader", "k2trance", "pulsetronic"]
+CASES = ["sustain", "filter", "delaybus", "scripted", "edge", "fm", "fmtest3", "fmtest4", "fx", "dctest", "wstest", "envwire", "unload", "k2intro", "k2intro44", "k2epilogue", "k2loader", "k2trance", "pulsetronic"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -27,7 +27,7 @@ def test_trace_replay_matches_reference(oracle_lib, name):
     assert out.shape[1] == len(want) * 64
     assert np.array_equal(out[:, :head.shape[1]], head)
     got = fnv1a_fragments(out)
-    bad = np.nonzero(got != want)[0]
+    bad = differing_fragments(name, got, want)
     assert len(bad) == 0, f"first differing fragment {bad[:5]}"
 
 
