@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc counter_collection CSVs per kernel (mean per launch).
+
+    python tools/pmc_summary.py <dir-with-rocprof-output> [label]
+
+Prints one line per (kernel, counter); FETCH_SIZE / WRITE_SIZE (KB) are also
+turned into HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 - the
+gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE
+reports half of wide coalesced reads).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def short(name):
+    m = re.match(r"(?:void )?([A-Za-z0-9_]+)", name)
+    return m.group(1) if m else name
+
+
+def main():
+    root = sys.argv[1]
+    label = sys.argv[2] if len(sys.argv) > 2 else ""
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    launches = collections.Counter()
+    for fn in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        with open(fn, newline="") as f:
+            seen = set()
+            for row in csv.DictReader(f):
+                k = short(row.get("Kernel_Name", ""))
+                c = row.get("Counter_Name", "")
+                try:
+                    v = float(row.get("Counter_Value", "0"))
+                except ValueError:
+                    continue
+                acc[(k, c)][0] += v
+                did = (k, c, row.get("Dispatch_Id"))
+                if did not in seen:
+                    seen.add(did)
+                    acc[(k, c)][1] += 1
+    out = {}
+    for (k, c), (tot, n) in sorted(acc.items()):
+        mean = tot / max(n, 1)
+        out.setdefault(k, {})[c] = mean
+        print(f"{label:>28s} {k:24s} {c:24s} {mean:16.6g} per launch ({n} launches)")
+    for k, d in out.items():
+        if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
+            hbm = (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0
+            d["hbm_bytes_per_launch"] = hbm
+            print(f"{label:>28s} {k:24s} {'-> HBM bytes/launch':24s} {hbm:16.6g}")
+    print("JSON " + json.dumps({label: out}))
+
+
+if __name__ == "__main__":
+    main()
