@@ -246,7 +246,18 @@ struct a2amd_ctx {
 	DevBuf<int> d_list;
 	DevBuf<int> d_scatter;	// idx[k] then A2DRun[k] for k_scatter_runs
 	uint32_t *d_ptab = nullptr;
-	A2DParams *d_params = nullptr;
+	A2DParams *d_params = nullptr;	// = start of the device blob of the uploaded batch
+	// Everything a batch ships - parameter block, records, run-table updates,
+	// this batch's exception lists - is assembled in ONE pinned staging buffer
+	// and sent with one asynchronous copy (no host sync at upload; two staging
+	// buffers alternate, each guarded by an event).
+	DevBuf<char> d_blob;
+	char *h_blob[2] = { nullptr, nullptr };
+	size_t h_blob_cap[2] = { 0, 0 };
+	hipEvent_t blob_ev[2] = { nullptr, nullptr };
+	bool blob_busy[2] = { false, false };
+	int blob_i = 0;
+	const int *d_dyn = nullptr;	// this batch's exception lists inside the blob
 	A2DParams hparams;
 	// [0] = GRAPH_STEPS whole runs of the batch, [1] = one run, [2] = its SUBTREES
 	// phase alone, [3] = its ROOT phase alone (multi-GPU steps)
@@ -595,18 +606,6 @@ int upload(a2amd_ctx *c)
 			sc_val.push_back(z);
 		}
 	c->prev_with_recs.clear();
-	if(int r = grow(c, c->d_recs, recs.size() + 1, 1, false)) return r;
-	if(!recs.empty())
-		HIPCHK(c, hipMemcpyAsync(c->d_recs.d, recs.data(), recs.size() * sizeof(A2DRec),
-				hipMemcpyHostToDevice, c->stream));
-	if(!sc_idx.empty()) {
-		const size_t k = sc_idx.size();
-		if(int r = grow(c, c->d_scatter, 3 * k, 1, false)) return r;
-		HIPCHK(c, hipMemcpyAsync(c->d_scatter.d, sc_idx.data(), k * sizeof(int), hipMemcpyHostToDevice, c->stream));
-		HIPCHK(c, hipMemcpyAsync(c->d_scatter.d + k, sc_val.data(), k * sizeof(A2DRun), hipMemcpyHostToDevice, c->stream));
-		if(a2d_launch_scatter_runs(c->d_scatter.d, (const A2DRun *)(c->d_scatter.d + k), (int)k, c->d_runs.d, c->stream))
-			return c->fail(A2AMD_EHIP, "scatter launch failed");
-	}
 	c->stats.records += recs.size();
 
 	// Launch lists.  Static part, rebuilt when the voice tree changes: every
@@ -680,14 +679,15 @@ int upload(a2amd_ctx *c)
 			c->list_all.insert(c->list_all.end(), l.second.begin(), l.second.end());
 		}
 		c->static_len = (int)c->list_all.size();
-		if(int r = grow(c, c->d_list, 2 * c->list_all.size() + 64, 1, false)) return r;
+		if(int r = grow(c, c->d_list, c->list_all.size() + 64, 1, false)) return r;
 		if(!c->list_all.empty())
 			HIPCHK(c, hipMemcpyAsync(c->d_list.d, c->list_all.data(), c->list_all.size() * sizeof(int),
 					hipMemcpyHostToDevice, c->stream));
 		c->lists_dirty = false;
 	}
+	std::vector<int> dyn_all;
 	{
-		// this batch's exceptions, behind the static lists
+		// this batch's exceptions (shipped in the blob)
 		std::vector<int> dyn_leaf;
 		std::vector<std::vector<int>> dyn_bus(c->depth_ranges.size());
 		for(int vi : c->with_recs) {
@@ -703,20 +703,11 @@ int upload(a2amd_ctx *c)
 		std::vector<int> dyn = dyn_leaf;
 		c->n_leaf_dyn = (int)dyn_leaf.size();
 		for(size_t d = 0; d < dyn_bus.size(); ++d) {
-			c->depth_ranges[d].dyn_first = c->static_len + (int)dyn.size();
+			c->depth_ranges[d].dyn_first = (int)dyn.size();
 			c->depth_ranges[d].dyn_count = (int)dyn_bus[d].size();
 			dyn.insert(dyn.end(), dyn_bus[d].begin(), dyn_bus[d].end());
 		}
-		if((size_t)c->static_len + dyn.size() > c->d_list.cap) {
-			// rare: more exceptions than listed voices; re-upload everything
-			if(int r = grow(c, c->d_list, c->static_len + 2 * dyn.size() + 64, 1, false)) return r;
-			if(c->static_len)
-				HIPCHK(c, hipMemcpyAsync(c->d_list.d, c->list_all.data(), c->static_len * sizeof(int),
-						hipMemcpyHostToDevice, c->stream));
-		}
-		if(!dyn.empty())
-			HIPCHK(c, hipMemcpyAsync(c->d_list.d + c->static_len, dyn.data(), dyn.size() * sizeof(int),
-					hipMemcpyHostToDevice, c->stream));
+		dyn_all.swap(dyn);
 	}
 
 	A2DParams p;
@@ -726,7 +717,6 @@ int upload(a2amd_ctx *c)
 	p.ustate = c->d_ustate.d;
 	p.vactive = c->d_vactive.d;
 	p.runs = c->d_runs.d;
-	p.recs = c->d_recs.d;
 	p.waves = c->d_waves.d;
 	p.wavepool = c->d_wavepool.d;
 	p.busmem = c->d_busmem.d;
@@ -742,10 +732,51 @@ int upload(a2amd_ctx *c)
 		p.fragstart[f] = (uint16_t)acc;
 		acc += (int)c->fragframes[f];
 	}
+
+	// the blob: [params | records | scatter indices | scatter runs | exception lists]
+	auto up256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	const size_t nsc = sc_idx.size();
+	const size_t o_recs = up256(sizeof(A2DParams));
+	const size_t o_idx = o_recs + up256((recs.size() + 1) * sizeof(A2DRec));
+	const size_t o_val = o_idx + up256(nsc * sizeof(int));
+	const size_t o_dyn = o_val + up256(nsc * sizeof(A2DRun));
+	const size_t total = o_dyn + up256(dyn_all.size() * sizeof(int));
+	if(int r = grow(c, c->d_blob, total, 1, false)) return r;
+	const int bi = c->blob_i;
+	c->blob_i ^= 1;
+	if(c->blob_busy[bi]) {		// the copy that last read this staging buffer must have run
+		HIPCHK(c, hipEventSynchronize(c->blob_ev[bi]));
+		c->blob_busy[bi] = false;
+	}
+	if(total > c->h_blob_cap[bi]) {
+		if(c->h_blob[bi])
+			HIPCHK(c, hipHostFree(c->h_blob[bi]));
+		c->h_blob_cap[bi] = std::max(total * 2, (size_t)65536);
+		HIPCHK(c, hipHostMalloc((void **)&c->h_blob[bi], c->h_blob_cap[bi], hipHostMallocDefault));
+	}
+	if(!c->blob_ev[bi])
+		HIPCHK(c, hipEventCreateWithFlags(&c->blob_ev[bi], hipEventDisableTiming));
+	char *hb = c->h_blob[bi];
+	p.recs = (const A2DRec *)(c->d_blob.d + o_recs);
 	c->hparams = p;
-	HIPCHK(c, hipMemcpyAsync(c->d_params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
-	// pageable sources above: make sure they are consumed before they die
-	HIPCHK(c, hipStreamSynchronize(c->stream));
+	memcpy(hb, &p, sizeof(p));
+	if(!recs.empty())
+		memcpy(hb + o_recs, recs.data(), recs.size() * sizeof(A2DRec));
+	if(nsc) {
+		memcpy(hb + o_idx, sc_idx.data(), nsc * sizeof(int));
+		memcpy(hb + o_val, sc_val.data(), nsc * sizeof(A2DRun));
+	}
+	if(!dyn_all.empty())
+		memcpy(hb + o_dyn, dyn_all.data(), dyn_all.size() * sizeof(int));
+	HIPCHK(c, hipMemcpyAsync(c->d_blob.d, hb, total, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipEventRecord(c->blob_ev[bi], c->stream));
+	c->blob_busy[bi] = true;
+	c->d_params = (A2DParams *)c->d_blob.d;
+	c->d_dyn = (const int *)(c->d_blob.d + o_dyn);
+	if(nsc)
+		if(a2d_launch_scatter_runs((const int *)(c->d_blob.d + o_idx), (const A2DRun *)(c->d_blob.d + o_val),
+				(int)nsc, c->d_runs.d, c->stream))
+			return c->fail(A2AMD_EHIP, "scatter launch failed");
 	c->uploaded = true;
 	return 0;
 }
@@ -790,7 +821,7 @@ int launch_depth(a2amd_ctx *c, int d)
 		++c->stats.launches;
 	}
 	if(r.dyn_count) {
-		if(a2d_launch_voices(c->d_params, c->d_list.d + r.dyn_first, r.dyn_count, 1, c->stream))
+		if(a2d_launch_voices(c->d_params, c->d_dyn + r.dyn_first, r.dyn_count, 1, c->stream))
 			return c->fail(A2AMD_EHIP, "bus launch failed: %s", hipGetErrorString(hipGetLastError()));
 		++c->stats.launches;
 	}
@@ -919,7 +950,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			++c->stats.launches;
 		}
 		if(c->n_leaf_dyn) {
-			if(a2d_launch_voices(c->d_params, c->d_list.d + c->static_len, c->n_leaf_dyn,
+			if(a2d_launch_voices(c->d_params, c->d_dyn, c->n_leaf_dyn,
 					pick_vpw(c->n_leaf_dyn), c->stream))
 				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
@@ -1029,7 +1060,6 @@ int a2amd_open(const a2amd_config *cfg, a2amd_ctx **out)
 	c->ev_pool.push_back(c->ev1);
 	c->ev_pool.push_back(c->ev2);
 	OPENCHK(hipMalloc((void **)&c->d_ptab, sizeof(c->ptab)));
-	OPENCHK(hipMalloc((void **)&c->d_params, sizeof(A2DParams)));
 	OPENCHK(hipMalloc((void **)&c->d_wavepool.d, (size_t)(8u << 20) * sizeof(int16_t)));
 	c->d_wavepool.cap = 8u << 20;
 #undef OPENCHK
@@ -1046,7 +1076,8 @@ void a2amd_close(a2amd_ctx *c)
 	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
 	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
 	hipFree(c->d_waves.d); hipFree(c->d_wavepool.d); hipFree(c->d_busmem.d);
-	hipFree(c->d_fbdmem.d); hipFree(c->d_fmstate.d); hipFree(c->d_fmsine); hipFree(c->d_list.d); hipFree(c->d_scatter.d); hipFree(c->d_ptab); hipFree(c->d_params);
+	hipFree(c->d_fbdmem.d); hipFree(c->d_fmstate.d); hipFree(c->d_fmsine); hipFree(c->d_list.d); hipFree(c->d_scatter.d); hipFree(c->d_ptab); hipFree(c->d_blob.d);
+	for(int k = 0; k < 2; ++k) { if(c->h_blob[k]) hipHostFree(c->h_blob[k]); if(c->blob_ev[k]) hipEventDestroy(c->blob_ev[k]); }
 	if(c->h_master)
 		hipHostFree(c->h_master);
 	for(hipEvent_t e : c->ev_pool)
@@ -1623,8 +1654,20 @@ int a2amd_inline_end(a2amd_ctx *c, int ui)
 }
 
 // ---- render -------------------------------------------------------------------------
+static double now_us()
+{
+	timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+static double g_t[4], g_n;
+struct TimingDump { ~TimingDump() { if(getenv("A2AMD_HOSTTIMING") && g_n) fprintf(stderr,
+	"a2amd host timing per render: upload %.1f us, issue %.1f us, readback %.1f us (%g renders)\n",
+	g_t[0] / g_n, g_t[1] / g_n, g_t[2] / g_n, g_n); } } g_timing_dump;
+
 int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned cap)
 {
+	double t0 = now_us();
 	if(!c->stack.empty())
 		return c->fail(A2AMD_ESTATE, "render inside an inline window");
 	close_fragment(c);
@@ -1641,6 +1684,8 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 	if(phases & A2AMD_RENDER_UPLOAD)
 		if(int r = upload(c))
 			return r;
+	double t1 = now_us();
+	g_t[0] += t1 - t0;
 	if((phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT)) && !c->uploaded)
 		return c->fail(A2AMD_ESTATE, "render phases out of order: upload first");
 
@@ -1677,6 +1722,9 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		if(int r = c->profiling ? issue_kernels(c, phases, c->ev0, c->ev1, c->ev2) :
 				issue_kernels(c, phases, nullptr, nullptr, nullptr))
 			return r;
+	double t2 = now_us();
+	g_t[1] += t2 - t1;
+	g_n += 1;
 	if(phases & A2AMD_RENDER_READBACK) {
 		const int nch = c->cfg.channels;
 		size_t n = (size_t)c->nfrags * nch * A2D_FRAG;
@@ -1692,6 +1740,7 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		}
 		HIPCHK(c, hipMemcpyAsync(c->h_master, c->d_busmem.d, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
+		g_t[2] += now_us() - t2;
 		unsigned pos = 0;
 		for(int f = 0; f < c->nfrags; ++f) {
 			for(int ch = 0; ch < nch; ++ch)
