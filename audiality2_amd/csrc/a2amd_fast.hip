@@ -1030,16 +1030,21 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 			const int ff = fv[FV_F1] >> 12, lp = fv[FV_LP], bp = fv[FV_BP], hp = fv[FV_HP];
 			int d1 = fv[FV_D1], d2 = fv[FV_D2], qv = q.value;
 			int *row = tile + lane * FILT_PITCH;
+			// the next input is fetched a sample ahead: with few voices a lane's
+			// recurrence is the critical path and the LDS latency would sit on it
+			int xin = row[0];
 			for(int s = 0; s < n; ++s) {
+				const int xnext = row[s + 1];	// (row pitch 65: in bounds)
 				int qq = qv >> 12;
 				int d1s = d1 >> 4;
 				int l = wadd(d2, wmul(ff, d1s) >> 8);
-				int h = wsub(wsub(row[s] >> 5, l), wmul(qq, d1s) >> 8);
+				int h = wsub(wsub(xin >> 5, l), wmul(qq, d1s) >> 8);
 				int b = wadd(wmul(ff, h >> 4) >> 8, d1);
 				row[s] = wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3;
 				d1 = b;
 				d2 = l;
 				qv = wadd(qv, q.delta);
+				xin = xnext;
 			}
 			ramp_run(q, n);
 			fv[FV_Q] = q.value; fv[FV_Q + 1] = q.target; fv[FV_Q + 2] = q.delta; fv[FV_Q + 3] = q.timer;

@@ -69,7 +69,7 @@ def fnv1a_fragments(pcm, frag=64):
 
 def cpu_baseline(voices, chain, oracle_fragments=600):
     """Reference (oracle/_ref/ref_bench) if it travelled, else the C port."""
-    program = {"osc-pan": "OscPan", "osc-filter-pan": "OscFilterPan", "fm1-pan": "Fm1Pan", "fm2-pan": "Fm2Pan",
+    program = {"osc-pan": "OscPan", "osc-filter-pan": "OscFilterPan", "osc2-pan": "Osc2Pan", "fm1-pan": "Fm1Pan", "fm2-pan": "Fm2Pan",
                "fm4-pan": "Fm4Pan"}.get(chain)
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
     script = os.path.join(ROOT, "tests", "a2s", "bench.a2s")
