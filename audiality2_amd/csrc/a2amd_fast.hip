@@ -25,6 +25,8 @@
 //                   steps the rampers and the wavefronts then split the
 //                   fragments.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <stdlib.h>
 #include "a2amd_device.h"
 #include "a2amd_dsp.h"
 #include "a2amd_fm.h"
@@ -1591,12 +1593,13 @@ static int launch_fmpan(const A2DParams *dparams, const A2DParams &hp, const int
 {
 	const int nwaves = (nlist + vpw - 1) / vpw;
 	const int nblocks = (nwaves + FAST_WPB - 1) / FAST_WPB;
-	const size_t lds = (size_t)FAST_WPB * vpw * FILT_PITCH * sizeof(int);
+	size_t lds = (size_t)FAST_WPB * vpw * FILT_PITCH * sizeof(int);
+	if(getenv("A2AMD_FMLDS"))
+		lds = std::max(lds, (size_t)atoi(getenv("A2AMD_FMLDS")));
 	static bool attr_set = false;
 	if(!attr_set) {
 		(void)hipFuncSetAttribute((const void *)k_leaf_fmpan<NOPS, OSBITS, PAR>,
-				hipFuncAttributeMaxDynamicSharedMemorySize,
-				FAST_WPB * FILT_MAXV * FILT_PITCH * (int)sizeof(int));
+				hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 		attr_set = true;
 	}
 	hipLaunchKernelGGL((k_leaf_fmpan<NOPS, OSBITS, PAR>), dim3(nblocks), dim3(64 * FAST_WPB), lds, stream,

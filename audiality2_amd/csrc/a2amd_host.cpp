@@ -931,12 +931,15 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			const int n = c->fm_kind_count[k];
 			if(!n)
 				continue;
-			// Few voices: spread them over many wavefronts (a voice is a serial
-			// recurrence, a launch takes as long as its longest lane); many:
-			// fill the lanes.  Sweep on MI355X: one wavefront per SIMD with all
-			// 64 lanes busy beats two with 32 from 65 536 voices up
-			// (profiles/r01_fm_sweep.jsonl).
-			int vpw = getenv("A2AMD_FMVPW") ? atoi(getenv("A2AMD_FMVPW")) : (n + 1023) / 1024;
+			// A voice is a serial recurrence, so a launch takes as long as its
+			// longest lane and few voices would like many wavefronts - but a
+			// wavefront with fewer than 16 busy lanes runs its lane(s) up to 2x
+			// slower on MI355X (sweep over voices x lanes-per-wavefront,
+			// profiles/r01_fm_vpw_sweep.txt: fm4, 1 024 voices: 29.1 / 32.3 / 33.2 /
+			// 14.5 / 15.1 / 16.8 ms for 1 / 4 / 8 / 16 / 32 / 64 voices per
+			// wavefront).  So: 16 per wavefront until that fills one wavefront per
+			// SIMD (16 384 voices), then more lanes.
+			int vpw = getenv("A2AMD_FMVPW") ? atoi(getenv("A2AMD_FMVPW")) : std::max(16, (n + 1023) / 1024);
 			vpw = std::min(std::max(vpw, 1), 64);
 			if(a2d_launch_leaf_fmpan(c->d_params, c->hparams, A2AMD_FM1 + k, c->d_list.d + at, n, vpw, c->stream))
 				return c->fail(A2AMD_EHIP, "fm leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
