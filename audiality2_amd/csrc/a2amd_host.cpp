@@ -920,8 +920,13 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			++c->stats.launches;
 		}
 		if(c->n_filt_leaf) {
+			// sweep (MI355X, ms per 256 fragments): 1 024 voices best at 1 voice per
+			// wavefront (1.11), 4 096 at 4 (1.36), 16 384 at 8 (2.37): one wavefront
+			// per SIMD while that is possible, then two
+			const int nf = c->n_filt_leaf;
 			int vpw = getenv("A2AMD_FVPW") ? atoi(getenv("A2AMD_FVPW")) :
-					std::min(std::max((c->n_filt_leaf + 2047) / 2048, 1), 32);
+					nf <= 16384 ? std::min(std::max((nf + 1023) / 1024, 1), 8) :
+					std::min(std::max((nf + 2047) / 2048, 1), 32);
 			if(a2d_launch_leaf_oscfiltpan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf,
 					c->n_filt_leaf, vpw, c->stream))
 				return c->fail(A2AMD_EHIP, "filter leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
