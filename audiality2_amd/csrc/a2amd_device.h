@@ -145,3 +145,7 @@ int a2d_launch_leaf_osc2pan(const A2DParams *dparams, const A2DParams &hp, const
 // fm -> panmix leaf voices of ONE unit kind (a2amd_unitkind A2AMD_FM1..FM4R)
 int a2d_launch_leaf_fmpan(const A2DParams *dparams, const A2DParams &hp, int kind, const int *dlist, int nlist,
 		int vpw, void *stream);
+// ... or of all eight kinds in one launch (small voice counts); the list is
+// grouped by kind in a2amd_unitkind order, count8[k] voices each
+int a2d_launch_leaf_fmpan_all(const A2DParams *dparams, const A2DParams &hp, const int *dlist,
+		const int *count8, int vpw, void *stream);

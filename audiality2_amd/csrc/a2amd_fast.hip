@@ -1593,9 +1593,7 @@ static int launch_fmpan(const A2DParams *dparams, const A2DParams &hp, const int
 {
 	const int nwaves = (nlist + vpw - 1) / vpw;
 	const int nblocks = (nwaves + FAST_WPB - 1) / FAST_WPB;
-	size_t lds = (size_t)FAST_WPB * vpw * FILT_PITCH * sizeof(int);
-	if(getenv("A2AMD_FMLDS"))
-		lds = std::max(lds, (size_t)atoi(getenv("A2AMD_FMLDS")));
+	const size_t lds = (size_t)FAST_WPB * vpw * FILT_PITCH * sizeof(int);
 	static bool attr_set = false;
 	if(!attr_set) {
 		(void)hipFuncSetAttribute((const void *)k_leaf_fmpan<NOPS, OSBITS, PAR>,
@@ -1604,6 +1602,82 @@ static int launch_fmpan(const A2DParams *dparams, const A2DParams &hp, const int
 	}
 	hipLaunchKernelGGL((k_leaf_fmpan<NOPS, OSBITS, PAR>), dim3(nblocks), dim3(64 * FAST_WPB), lds, stream,
 			dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.fmstate, hp.fmsine, hp.ptab, hp.busmem);
+	return (int)hipGetLastError();
+}
+
+// All kinds in one launch, for small voice counts: eight per-kind launches on
+// one stream run one after the other although they are independent, and with a
+// few dozen voices each of them is a single dependent chain (tens of
+// microseconds per fragment).  Wavefronts look their kind up in the segment
+// table; the register budget is that of the largest body.
+struct FmSegs { int count[8]; };	// voices per kind, fm1 fm2 fm3 fm4 fm3p fm4p fm2r fm4r; list grouped in that order
+
+__global__ __launch_bounds__(64 * FAST_WPB)
+void k_leaf_fmpan_all(const A2DParams *__restrict__ pp, const int *__restrict__ list, FmSegs segs, int vpw,
+		const A2DVoice *__restrict__ voices, int *ustate,
+		int *fmstate, const uint32_t *__restrict__ fmsine, const uint32_t *__restrict__ ptab,
+		int *__restrict__ busmem)
+{
+	extern __shared__ __attribute__((aligned(16))) int tiles[];
+	__shared__ uint32_t sine[2048];
+	for(int i = threadIdx.x; i < 2048; i += 64 * FAST_WPB)
+		sine[i] = fmsine[i];
+	__syncthreads();
+	const int wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	int gw = blockIdx.x * FAST_WPB + wv;	// wavefront index; which kind's range is it in?
+	int kind = -1, first = 0, nv = 0, at = 0;
+#pragma unroll
+	for(int k = 0; k < 8; ++k) {
+		const int nw = (segs.count[k] + vpw - 1) / vpw;
+		if(kind < 0 && gw < nw) {
+			kind = k;
+			first = at + gw * vpw;
+			nv = min(vpw, segs.count[k] - gw * vpw);
+		}
+		gw -= nw;
+		at += segs.count[k];
+	}
+	if(kind < 0)
+		return;
+	int *tile = tiles + wv * vpw * FILT_PITCH;
+#define FMPAN(N, OS, PAR) fmpan_body<N, OS, PAR>(*pp, list, first, nv, lane, tile, sine, voices, ustate, \
+		fmstate, ptab, busmem)
+	switch(rfl(kind)) {
+	  case 0: FMPAN(1, 0, 0); break;
+	  case 1: FMPAN(2, 1, 0); break;
+	  case 2: FMPAN(3, 2, 0); break;
+	  case 3: FMPAN(4, 2, 0); break;
+	  case 4: FMPAN(3, 2, 1); break;
+	  case 5: FMPAN(4, 2, 1); break;
+	  case 6: FMPAN(2, 1, 2); break;
+	  case 7: FMPAN(4, 2, 2); break;
+	}
+#undef FMPAN
+}
+
+int a2d_launch_leaf_fmpan_all(const A2DParams *dparams, const A2DParams &hp, const int *dlist,
+		const int *count8, int vpw, void *stream)
+{
+	FmSegs segs;
+	int nwaves = 0;
+	vpw = min(max(vpw, 1), FILT_MAXV);
+	for(int k = 0; k < 8; ++k) {
+		segs.count[k] = count8[k];
+		nwaves += (count8[k] + vpw - 1) / vpw;
+	}
+	if(!nwaves)
+		return 0;
+	const int nblocks = (nwaves + FAST_WPB - 1) / FAST_WPB;
+	const size_t lds = (size_t)FAST_WPB * vpw * FILT_PITCH * sizeof(int);
+	static bool attr_set = false;
+	if(!attr_set) {
+		(void)hipFuncSetAttribute((const void *)k_leaf_fmpan_all, hipFuncAttributeMaxDynamicSharedMemorySize,
+				150 * 1024);
+		attr_set = true;
+	}
+	hipLaunchKernelGGL(k_leaf_fmpan_all, dim3(nblocks), dim3(64 * FAST_WPB), lds, (hipStream_t)stream,
+			dparams, dlist, segs, vpw, hp.voices, hp.ustate, hp.fmstate, hp.fmsine, hp.ptab, hp.busmem);
 	return (int)hipGetLastError();
 }
 

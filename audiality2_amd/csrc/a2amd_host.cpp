@@ -932,6 +932,18 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 				return c->fail(A2AMD_EHIP, "filter leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
+		int fm_kinds = 0;
+		for(int k = 0; k < 8; ++k)
+			fm_kinds += c->fm_kind_count[k] != 0;
+		if(fm_kinds > 1 && c->n_fm_leaf <= 16384 && !getenv("A2AMD_FMVPW")) {
+			// several kinds, few voices: one launch for all of them (the
+			// per-kind launches below would run back to back, each as long
+			// as a voice's serial chain)
+			if(a2d_launch_leaf_fmpan_all(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf +
+					c->n_filt_leaf, c->fm_kind_count, 16, c->stream))
+				return c->fail(A2AMD_EHIP, "fm leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+			++c->stats.launches;
+		} else
 		for(int k = 0, at = c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf; k < 8; at += c->fm_kind_count[k++]) {
 			const int n = c->fm_kind_count[k];
 			if(!n)
