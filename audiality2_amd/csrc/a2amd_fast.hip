@@ -1357,8 +1357,16 @@ DEV void fmpan_body(const A2DParams &p, const int *__restrict__ list, int first,
 	int slot = -1, u0 = 0, u1 = 0, my_off = -1, my_nch = 2, v0 = 0, v1 = 0, settled = 0;
 	int run_first = 0, run_count = 0, fmslot = -1;
 	int actB = 0;		// the voice is alive (vactive), as seen by the oscillator stage
+	// A wavefront with fewer than 16 busy lanes runs a lane's serial chain only
+	// about half as fast on MI355X (measured: fm4, 64 voices in 64 one-lane
+	// wavefronts 34.0 ms per 16 384 frames, the same with 15 idle lanes put to
+	// work on copies 14.5 ms; profiles/r01_fm_vpw_sweep.txt).  So lanes nv..15
+	// shadow the wavefront's voices: same inputs, same arithmetic, no stores.
+	const bool writer = lane < nv;
 	if(lane < nv)
 		slot = list[first + lane];
+	else if(lane < 16 && !(p.debug & 4))
+		slot = list[first + lane % nv];
 	const bool mine = slot >= 0;
 	const unsigned long long mine_mask = __ballot(mine);
 	if(mine) {
@@ -1420,9 +1428,18 @@ DEV void fmpan_body(const A2DParams &p, const int *__restrict__ list, int first,
 		const unsigned long long recs_mask = __ballot(pending);	// voices with records in this fragment
 		if(!recs_mask) {
 			// nobody in this wavefront has records in this fragment: plain loop
-			if(wend)
-				for(int s = 0; s < n; ++s)
-					row[s] = fm_frame<NOPS, OSBITS, PAR>(op, step, fix, sine);
+			if(wend) {
+				if(nv >= 16) {		// no shadow lanes in this wavefront
+					for(int s = 0; s < n; ++s)
+						row[s] = fm_frame<NOPS, OSBITS, PAR>(op, step, fix, sine);
+				} else {
+					for(int s = 0; s < n; ++s) {
+						const int y_ = fm_frame<NOPS, OSBITS, PAR>(op, step, fix, sine);
+						if(writer)
+							row[s] = y_;
+					}
+				}
+			}
 		} else
 		for(int s = 0; s <= n; ++s) {
 			if(pending && s >= wend) {
@@ -1461,8 +1478,11 @@ DEV void fmpan_body(const A2DParams &p, const int *__restrict__ list, int first,
 						actB = 0;
 				}
 			}
-			if(s >= wstart && s < wend)
-				row[s] = fm_frame<NOPS, OSBITS, PAR>(op, step, fix, sine);
+			if(s >= wstart && s < wend) {
+				const int y_ = fm_frame<NOPS, OSBITS, PAR>(op, step, fix, sine);
+				if(writer)
+					row[s] = y_;
+			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
@@ -1547,9 +1567,9 @@ DEV void fmpan_body(const A2DParams &p, const int *__restrict__ list, int first,
 		__builtin_amdgcn_wave_barrier();
 	}
 
-	if(mine)
+	if(mine && writer)
 		p.vactive[slot] = actB;
-	if(touched) {
+	if(touched && writer) {
 		int *fw = fmstate + (size_t)fmslot * A2D_FMSTATE;
 #pragma unroll
 		for(int i = 0; i < NOPS; ++i)

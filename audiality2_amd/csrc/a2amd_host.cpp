@@ -940,7 +940,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			// per-kind launches below would run back to back, each as long
 			// as a voice's serial chain)
 			if(a2d_launch_leaf_fmpan_all(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf +
-					c->n_filt_leaf, c->fm_kind_count, 16, c->stream))
+					c->n_filt_leaf, c->fm_kind_count, (c->n_fm_leaf + 1023) / 1024, c->stream))
 				return c->fail(A2AMD_EHIP, "fm leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		} else
@@ -948,15 +948,12 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			const int n = c->fm_kind_count[k];
 			if(!n)
 				continue;
-			// A voice is a serial recurrence, so a launch takes as long as its
-			// longest lane and few voices would like many wavefronts - but a
-			// wavefront with fewer than 16 busy lanes runs its lane(s) up to 2x
-			// slower on MI355X (sweep over voices x lanes-per-wavefront,
-			// profiles/r01_fm_vpw_sweep.txt: fm4, 1 024 voices: 29.1 / 32.3 / 33.2 /
-			// 14.5 / 15.1 / 16.8 ms for 1 / 4 / 8 / 16 / 32 / 64 voices per
-			// wavefront).  So: 16 per wavefront until that fills one wavefront per
-			// SIMD (16 384 voices), then more lanes.
-			int vpw = getenv("A2AMD_FMVPW") ? atoi(getenv("A2AMD_FMVPW")) : std::max(16, (n + 1023) / 1024);
+			// A voice is a serial recurrence: a launch takes as long as its longest
+			// lane, so few voices are spread over many wavefronts (idle lanes of a
+			// wavefront shadow its voices, see fmpan_body) until there is one
+			// wavefront per SIMD (1 024), then the lanes fill up
+			// (profiles/r01_fm_vpw_sweep.txt).
+			int vpw = getenv("A2AMD_FMVPW") ? atoi(getenv("A2AMD_FMVPW")) : (n + 1023) / 1024;
 			vpw = std::min(std::max(vpw, 1), 64);
 			if(a2d_launch_leaf_fmpan(c->d_params, c->hparams, A2AMD_FM1 + k, c->d_list.d + at, n, vpw, c->stream))
 				return c->fail(A2AMD_EHIP, "fm leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
