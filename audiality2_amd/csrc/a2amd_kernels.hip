@@ -681,37 +681,44 @@ DEV void limiter_process(Ctx &c, uint32_t desc, int *w, int offset, int frames)
 // ---------------------------------------------------------------------------
 template<int NOPS, int OSBITS, int PAR>
 static __device__ __attribute__((noinline)) void fm_run(int *fw, const uint32_t *ptab, const uint32_t *sine,
-		int *dst, int frames, bool acc)
+		int *dst, int frames, bool acc, bool writer)
 {
 	FmOp op[NOPS];
 #pragma unroll
 	for(int i = 0; i < NOPS; ++i)
 		fmop_load(op[i], fw + i * FO_WORDS);
 	fm_window<NOPS, OSBITS, PAR>(op, ptab, sine, frames, [&](int s, int v) {
-		dst[s] = acc ? wadd(dst[s], v) : v;
+		const int nv = acc ? wadd(dst[s], v) : v;
+		if(writer)
+			dst[s] = nv;
 	});
+	if(writer) {
 #pragma unroll
-	for(int i = 0; i < NOPS; ++i)
-		fmop_store(fw + i * FO_WORDS, op[i]);
+		for(int i = 0; i < NOPS; ++i)
+			fmop_store(fw + i * FO_WORDS, op[i]);
+	}
 }
 
 DEV void fm_process(Ctx &c, uint32_t desc, int *w, int offset, int frames)
 {
-	if(c.lane == 0) {
+	// lanes 1..15 shadow lane 0 (same data, no stores): a wavefront with fewer
+	// than 16 busy lanes runs this chain at half speed (see fmpan_body)
+	if(c.lane < 16) {
+		const bool writer = c.lane == 0;
 		int *fw = c.p->fmstate + (size_t)w[MW_SLOT] * A2D_FMSTATE;
 		const bool wired = A2D_WIRED(desc);
 		int *dst = (wired ? c.l->otile[0] : c.l->scratch[0]) + offset;
 		const bool acc = wired || A2D_ADD(desc);
 		const uint32_t *pt = c.p->ptab;
 		switch(A2D_KIND(desc)) {
-		  case A2D_FM1: fm_run<1, 0, 0>(fw, pt, c.sine, dst, frames, acc); break;
-		  case A2D_FM2: fm_run<2, 1, 0>(fw, pt, c.sine, dst, frames, acc); break;
-		  case A2D_FM3: fm_run<3, 2, 0>(fw, pt, c.sine, dst, frames, acc); break;
-		  case A2D_FM4: fm_run<4, 2, 0>(fw, pt, c.sine, dst, frames, acc); break;
-		  case A2D_FM3P: fm_run<3, 2, 1>(fw, pt, c.sine, dst, frames, acc); break;
-		  case A2D_FM4P: fm_run<4, 2, 1>(fw, pt, c.sine, dst, frames, acc); break;
-		  case A2D_FM2R: fm_run<2, 1, 2>(fw, pt, c.sine, dst, frames, acc); break;
-		  case A2D_FM4R: fm_run<4, 2, 2>(fw, pt, c.sine, dst, frames, acc); break;
+		  case A2D_FM1: fm_run<1, 0, 0>(fw, pt, c.sine, dst, frames, acc, writer); break;
+		  case A2D_FM2: fm_run<2, 1, 0>(fw, pt, c.sine, dst, frames, acc, writer); break;
+		  case A2D_FM3: fm_run<3, 2, 0>(fw, pt, c.sine, dst, frames, acc, writer); break;
+		  case A2D_FM4: fm_run<4, 2, 0>(fw, pt, c.sine, dst, frames, acc, writer); break;
+		  case A2D_FM3P: fm_run<3, 2, 1>(fw, pt, c.sine, dst, frames, acc, writer); break;
+		  case A2D_FM4P: fm_run<4, 2, 1>(fw, pt, c.sine, dst, frames, acc, writer); break;
+		  case A2D_FM2R: fm_run<2, 1, 2>(fw, pt, c.sine, dst, frames, acc, writer); break;
+		  case A2D_FM4R: fm_run<4, 2, 2>(fw, pt, c.sine, dst, frames, acc, writer); break;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 	}
