@@ -164,6 +164,7 @@ struct HWave {
 	bool live = false;
 	uint64_t key = 0;
 	A2DWave dw;
+	size_t pool_off = 0, pool_len = 0;	// its region of the device wave pool (int16 units)
 };
 
 } // namespace
@@ -229,6 +230,7 @@ struct a2amd_ctx {
 
 	// wave pool (int16 samples)
 	size_t wavepool_used = 0;
+	std::vector<std::pair<size_t, size_t>> wavepool_free;	// (offset, length) of dropped waves' regions
 
 	DevBuf<A2DVoice> d_voices;
 	DevBuf<uint32_t> d_udesc;
@@ -1130,6 +1132,10 @@ int a2amd_wave_upload(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w)
 		id = (int)c->waves.size();
 		c->waves.push_back(HWave());
 		c->mwaves.push_back(A2DWave());
+	} else {
+		// same key again: the old data is replaced
+		c->wavepool_free.push_back(std::make_pair(c->waves[id].pool_off, c->waves[id].pool_len));
+		--c->stats.live_waves;
 	}
 	HWave &hw = c->waves[id];
 	hw.live = true;
@@ -1143,9 +1149,27 @@ int a2amd_wave_upload(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w)
 	for(int l = 0; l < levels; ++l)
 		total += A2AMD_WAVEPRE + (size_t)w->size[l] + A2AMD_WAVEPOST;
 	total = (total + 7) & ~(size_t)7;
-	if(c->wavepool_used + total > c->d_wavepool.cap)
-		if(int r = grow(c, c->d_wavepool, c->wavepool_used + total, 1, true)) return r;
-	size_t pos = c->wavepool_used;
+	// a region a dropped wave left behind (first fit), else the end of the pool
+	size_t pos = (size_t)-1;
+	for(size_t k = 0; k < c->wavepool_free.size() && total; ++k)
+		if(c->wavepool_free[k].second >= total) {
+			pos = c->wavepool_free[k].first;
+			c->wavepool_free[k].first += total;
+			c->wavepool_free[k].second -= total;
+			if(!c->wavepool_free[k].second)
+				c->wavepool_free.erase(c->wavepool_free.begin() + k);
+			// work in flight may still read the old contents
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			break;
+		}
+	if(pos == (size_t)-1) {
+		if(c->wavepool_used + total > c->d_wavepool.cap)
+			if(int r = grow(c, c->d_wavepool, c->wavepool_used + total, 1, true)) return r;
+		pos = c->wavepool_used;
+		c->wavepool_used += total;
+	}
+	hw.pool_off = pos;
+	hw.pool_len = total;
 	for(int l = 0; l < levels; ++l) {
 		size_t n = A2AMD_WAVEPRE + (size_t)w->size[l] + A2AMD_WAVEPOST;
 		HIPCHK(c, hipMemcpy(c->d_wavepool.d + pos, w->data[l], n * sizeof(int16_t), hipMemcpyHostToDevice));
@@ -1153,7 +1177,6 @@ int a2amd_wave_upload(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w)
 		hw.dw.off[l] = (uint32_t)(pos + A2AMD_WAVEPRE);
 		pos += n;
 	}
-	c->wavepool_used += total;
 	c->mwaves[id] = hw.dw;
 	c->waves_dirty = true;
 	++c->stats.live_waves;
@@ -1166,6 +1189,9 @@ int a2amd_wave_drop(a2amd_ctx *c, uint64_t key)
 		if(c->waves[i].live && c->waves[i].key == key) {
 			c->waves[i].live = false;
 			c->waves[i].dw.size[0] = 0;	// "unloaded", waves.c:717-723
+			if(c->waves[i].pool_len)
+				c->wavepool_free.push_back(std::make_pair(c->waves[i].pool_off, c->waves[i].pool_len));
+			c->waves[i].pool_len = 0;
 			c->mwaves[i] = c->waves[i].dw;
 			c->waves_dirty = true;
 			--c->stats.live_waves;

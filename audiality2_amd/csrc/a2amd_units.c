@@ -306,7 +306,7 @@ static int wave_id_of(HOSTSTATE *hs, A2P_wave *w)
 		if(hs->wave_ptr[i] == w)
 			return hs->wave_id[i];
 	if(hs->nwaves >= MAXWAVES)
-		return -1;
+		die(hs, "more waves in use than the drop-in's registry holds", -MAXWAVES);
 	memset(&d, 0, sizeof(d));
 	d.type = w->type;
 	d.flags = w->flags;

@@ -244,6 +244,54 @@ def test_fm_leaf_kernel_executes_records(oracle_lib, monkeypatch, vpw):
     assert first_diff(got, want) is None
 
 
+def test_wave_drop_and_pool_reuse(oracle_lib):
+    """Waves come and go (a2_UploadWave / a2_Release while oscillators play
+    them): a dropped wave silences its oscillators, its region of the device
+    pool is handed to the next upload, re-uploading a key replaces the data."""
+    from audiality2_amd.replay import MIPLEVELS
+    rng = np.random.default_rng(9)
+
+    def run(be):
+        sc = synth.Scene(be, nwaves=2)
+        sc.root()
+        chunks = []
+
+        def up(key, n):
+            w = (rng.integers(-20000, 20000, n)).astype(np.int16)
+            sizes, data = synth.wave_pyramid(w)
+            return be.wave_upload(key, synth.WMIPWAVE, synth.LOOPED, n, sizes + [0] * (MIPLEVELS - len(sizes)), data)
+
+        def voices(wid, n):
+            first = len(sc.leaves)
+            sc.add_voices(n, chain="osc-pan", total=64)
+            for units in sc.leaves[first:]:
+                be.unit_write(units[0], 0, wid)
+            return first
+
+        a = up(0x900, 1500)
+        voices(a, 6)
+        chunks.append(sc.run(3, batch=2))
+        be.wave_drop(0x900)                      # oscillators on it fall silent
+        chunks.append(sc.run(2, batch=2))
+        b = up(0x901, 1500)                      # fits the region wave a left
+        voices(b, 5)
+        chunks.append(sc.run(3, batch=4))
+        c = up(0x901, 700)                       # same key again: replaced
+        voices(c, 4)
+        chunks.append(sc.run(3, batch=1))
+        return np.concatenate(chunks, axis=1)
+
+    rng = np.random.default_rng(9)
+    gpu = make_gpu(max_batch=4)
+    got = run(gpu)
+    gpu.close()
+    rng = np.random.default_rng(9)
+    ora = make_oracle(oracle_lib)
+    want = run(ora)
+    ora.close()
+    assert want.any() and first_diff(got, want) is None
+
+
 def test_linearity_at_full_size():
     """Size-independent property at BASELINE size (16384 voices, config 3
     shape would take the oracle minutes): the bus is a wrap-around sum, so the
