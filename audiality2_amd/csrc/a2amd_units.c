@@ -70,6 +70,7 @@ typedef struct XTRA
 	int		is_root;
 	A2P_process_cb	orig_process;
 	A2P_wave	*wave;		/* wtosc: the wave it plays (engine object), or NULL */
+	int		chain_checked;	/* the units behind us in the voice have been looked at */
 } XTRA;
 
 static inline XTRA *xtra(A2P_unit *u)
@@ -151,6 +152,7 @@ static a2amd_ctx *ctx_of(HOSTSTATE *hs)
 /* ---- Initialize / Deinitialize ---------------------------------------------*/
 static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned flags, int forward)
 {
+
 	HOSTSTATE *hs = (HOSTSTATE *)sd;
 	XTRA *x = xtra(u);
 	a2amd_ctx *ctx = ctx_of(hs);
@@ -179,6 +181,16 @@ static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned 
 	}
 	if(x->is_root && kind == A2AMD_XINSERT)
 		forward = 0;	/* stays with the engine */
+	if(forward && !hs->chain_last && kind != A2AMD_INLINE &&
+			(u->ninputs || ((flags & A2AMD_PROCADD) && !wired)))
+	{
+		/* the first replaced unit of a voice consumes (or adds to) a signal:
+		 * something in front of it produced that on the CPU */
+		fprintf(stderr, "a2amd units: '%s' is the first GPU-rendered unit of its voice but takes its "
+				"input from a unit that is not replaced: mixed CPU/GPU chains are not "
+				"supported (no CPU fallback)\n", u->descriptor->name);
+		return 1;	/* A2_VOICEINIT for this voice */
+	}
 	if(forward)
 	{
 		x->uid = a2amd_unit_init(ctx, (uint64_t)(uintptr_t)vms, kind, lflags, u->ninputs,
@@ -232,6 +244,42 @@ static void check_unloaded(XTRA *x)
 		}
 }
 
+/* Units of the engine (or of the application, a2_RegisterUnit) that are NOT
+ * replaced render on the CPU into buffers the GPU never sees.  One with audio
+ * ports in the middle of a replaced chain would silently process silence, so
+ * it is refused, loudly, the first time the chain runs.  (Units without audio
+ * ports - the engine's env - are fine: they only write control registers.) */
+static int is_ours(const A2P_unitdesc *d)
+{
+	static const A2P_unitdesc *const ours[] = {
+		&a2_wtosc_unitdesc, &a2_panmix_unitdesc, &a2_filter12_unitdesc, &a2_fbdelay_unitdesc,
+		&a2_inline_unitdesc, &a2_xinsert_unitdesc, &a2_fm1_unitdesc, &a2_fm2_unitdesc,
+		&a2_fm3_unitdesc, &a2_fm4_unitdesc, &a2_fm3p_unitdesc, &a2_fm4p_unitdesc,
+		&a2_fm2r_unitdesc, &a2_fm4r_unitdesc, &a2_dc_unitdesc, &a2_waveshaper_unitdesc,
+		&a2_dcblock_unitdesc, &a2_limiter_unitdesc };
+	unsigned i;
+	for(i = 0; i < sizeof(ours) / sizeof(ours[0]); ++i)
+		if(d == ours[i])
+			return 1;
+	return 0;
+}
+
+static void check_chain_behind(A2P_unit *u)
+{
+	const A2P_unit *n;
+
+	for(n = u->next; n && !is_ours(n->descriptor); n = n->next)
+		if(n->descriptor->maxinputs || n->descriptor->maxoutputs)	/* (the unit's own counts are
+				not meaningful for a port-less unit: the engine still hands env one) */
+		{
+			fprintf(stderr, "a2amd units: unit '%s' (%u in, %u out) sits behind a GPU-rendered '%s' in "
+					"one voice but is not replaced: mixed CPU/GPU chains are not supported "
+					"(no CPU fallback)\n", n->descriptor->name, n->ninputs, n->noutputs,
+					u->descriptor->name);
+			abort();
+		}
+}
+
 static void forward_process(XTRA *x, unsigned offset, unsigned frames)
 {
 	HOSTSTATE *hs = x->hs;
@@ -259,6 +307,12 @@ static void amd_process(A2P_unit *u, unsigned offset, unsigned frames)
 {
 	XTRA *x = xtra(u);
 	HOSTSTATE *hs = x->hs;
+
+	if(!x->chain_checked)
+	{
+		x->chain_checked = 1;
+		check_chain_behind(u);
+	}
 	forward_process(x, offset, frames);
 	if(x->is_root && x->kind == A2AMD_PANMIX)
 	{
@@ -277,6 +331,7 @@ static void amd_process(A2P_unit *u, unsigned offset, unsigned frames)
 
 static void amd_inline_process(A2P_unit *u, unsigned offset, unsigned frames)
 {
+
 	XTRA *x = xtra(u);
 	HOSTSTATE *hs = x->hs;
 	int rc;

@@ -98,3 +98,18 @@ def test_dropin_refuses_to_run_without_gpu(tmp_path):
                         str(tmp_path / "x.pcm"), "1", "0.05"],
                        env=dict(os.environ, LD_PRELOAD=UNITS_SO), cwd=A2S, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_dropin_refuses_mixed_chains(tmp_path):
+    """A CPU unit with audio ports inside a GPU-rendered chain would process
+    silence: the drop-in aborts with a message instead (no silent fallback); a
+    voice that *starts* in a CPU unit is refused at instantiation."""
+    need_ref()
+    env = dict(os.environ, LD_PRELOAD=UNITS_SO)
+    r = subprocess.run([REF_RENDER, f"{A2S}/mixed.a2s", "Main", "640", "64", "48000", "2", str(tmp_path / "m.pcm"), "0.1"],
+                       env=env, cwd=A2S, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "mixed CPU/GPU chains are not supported" in r.stderr, r.stderr[-500:]
+    r = subprocess.run([REF_RENDER, f"{A2S}/mixedhead.a2s", "Main", "640", "64", "48000", "2", str(tmp_path / "h.pcm"), "0.1"],
+                       env=env, cwd=A2S, capture_output=True, text=True, timeout=120)
+    assert "takes its input from a unit that is not replaced" in r.stderr, r.stderr[-500:]
