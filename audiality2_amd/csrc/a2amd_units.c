@@ -67,6 +67,7 @@ typedef struct XTRA
 	int		uid;		/* backend unit id, -1 = not forwarded */
 	int		kind;
 	int		follow;		/* backend id of a trailing xinsert to process along */
+	A2P_unit	*follow_unit;	/* ... and the engine's instance of it */
 	int		is_root;
 	A2P_process_cb	orig_process;
 	A2P_wave	*wave;		/* wtosc: the wave it plays (engine object), or NULL */
@@ -202,7 +203,10 @@ static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned 
 			return 1;	/* the engine reports A2_VOICEINIT and drops the voice */
 		}
 		if(kind == A2AMD_XINSERT && hs->chain_last)
+		{
 			xtra(hs->chain_last)->follow = x->uid;
+			xtra(hs->chain_last)->follow_unit = u;
+		}
 	}
 	hs->chain_last = u;
 	return 0;
@@ -299,8 +303,22 @@ static void forward_process(XTRA *x, unsigned offset, unsigned frames)
 		die(hs, "a2amd_unit_process", rc);
 	if(noise != before)
 		a2_SetStateProperty(hs->cfg->interface, A2P_PNOISESEED, (int)noise);
-	if(x->follow >= 0 && (rc = a2amd_unit_process(hs->ctx, x->follow, offset - hs->base, frames, NULL)))
-		die(hs, "a2amd_unit_process (xinsert)", rc);
+	if(x->follow >= 0)
+	{
+		/* an xinsert on a voice other than the root is rendered on the GPU as
+		 * the bypass it is without clients (xinsert.c:145-161); a client
+		 * (a2_XinsertAddClient, a2_SinkCallback, streams ...) would be handed
+		 * the engine's unused CPU buffers */
+		if(((A2P_xinsert *)x->follow_unit)->clients)
+		{
+			fprintf(stderr, "a2amd units: an xinsert client was attached to a voice other than the root "
+					"voice: its audio is on the GPU, the client would see silence "
+					"(unsupported, no CPU fallback)\n");
+			abort();
+		}
+		if((rc = a2amd_unit_process(hs->ctx, x->follow, offset - hs->base, frames, NULL)))
+			die(hs, "a2amd_unit_process (xinsert)", rc);
+	}
 }
 
 static void amd_process(A2P_unit *u, unsigned offset, unsigned frames)

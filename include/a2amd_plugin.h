@@ -118,6 +118,16 @@ struct A2P_unit
 	A2P_process_cb		Process;
 };
 
+/* Head of A2_xinsert, src/units/xinsert.h:60-68 (engine-internal, shared by
+ * xinsert / xsink / xsource): the drop-in only looks at 'clients', to refuse a
+ * stream or callback client on a voice whose audio is not on the CPU. */
+typedef struct A2P_xinsert
+{
+	A2P_unit	header;
+	void		*state;
+	void		*clients;
+} A2P_xinsert;
+
 #define A2P_BLOCK_SIZE	384		/* A2_BLOCK_SIZE, include/audiality2.h.cmake:53 */
 #define A2P_PNOISESEED	0x0002000a	/* A2_PNOISESEED, include/a2_properties.h:71 */
 #define A2P_MATCHIO	0x00010000

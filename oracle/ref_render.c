@@ -34,13 +34,30 @@ static A2_handle upload_test_wave(A2_interface *i)
 	return a2_UploadWave(i, A2_WMIPWAVE, 0, A2_LOOPED, A2_I16, data, sizeof(data));
 }
 
+/* A2REF_SINK=1: attach a sink callback (a2_SinkCallback, audiality2.h.cmake:512)
+ * to the voice the program runs on - which then needs an xinsert or xsink unit -
+ * and report the peak it saw. */
+static int sink_peak;
+static A2_errors sink_cb(int32_t **buffers, unsigned nbuffers, unsigned frames, void *userdata)
+{
+	unsigned c, s;
+	for(c = 0; c < nbuffers; ++c)
+		for(s = 0; s < frames; ++s)
+		{
+			int v = buffers[c][s] < 0 ? -buffers[c][s] : buffers[c][s];
+			if(v > sink_peak)
+				sink_peak = v;
+		}
+	return A2_OK;
+}
+
 int main(int argc, const char *argv[])
 {
 	int frames, buffer, rate, channels, nargs, pargs[A2_MAXARGS], k, done = 0, c;
 	A2_config *cfg;
 	A2_driver *drv;
 	A2_interface *i;
-	A2_handle bank, prog, upwave = -1;
+	A2_handle bank, prog, upwave = -1, vh;
 	int release_at = 0;
 	FILE *pcm;
 	if(argc < 8)
@@ -89,8 +106,13 @@ int main(int argc, const char *argv[])
 		pargs[nargs++] = upwave << 16;
 	}
 	a2_TimestampReset(i);
-	if(a2_Starta(i, a2_RootVoice(i), prog, nargs, pargs) < 0)
+	if((vh = a2_Starta(i, a2_RootVoice(i), prog, nargs, pargs)) < 0)
 		return 1;
+	if(getenv("A2REF_SINK") && a2_SinkCallback(i, vh, sink_cb, NULL) < 0)
+	{
+		fprintf(stderr, "a2_SinkCallback failed: %s\n", a2_ErrorString(a2_LastError()));
+		return 1;
+	}
 	while(done < frames)
 	{
 		int n = frames - done < buffer ? frames - done : buffer;
@@ -112,6 +134,8 @@ int main(int argc, const char *argv[])
 		done += n;
 	}
 	fclose(pcm);
+	if(getenv("A2REF_SINK"))
+		printf("sink peak %d\n", sink_peak);
 	a2_Close(i);
 	return 0;
 }

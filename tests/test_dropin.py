@@ -113,3 +113,17 @@ def test_dropin_refuses_mixed_chains(tmp_path):
     r = subprocess.run([REF_RENDER, f"{A2S}/mixedhead.a2s", "Main", "640", "64", "48000", "2", str(tmp_path / "h.pcm"), "0.1"],
                        env=env, cwd=A2S, capture_output=True, text=True, timeout=120)
     assert "takes its input from a unit that is not replaced" in r.stderr, r.stderr[-500:]
+    # a sink client on a voice other than the root (a group's xinsert): fine on
+    # the CPU, refused by the drop-in - the client would be handed silence
+    cmd = [REF_RENDER, f"{A2S}/sinkgroup.a2s", "Main", "640", "64", "48000", "2", str(tmp_path / "s.pcm"), "0.1"]
+    r = subprocess.run(cmd, env=dict(os.environ, A2REF_SINK="1"), cwd=A2S, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "sink peak" in r.stdout and "sink peak 0" not in r.stdout
+    r = subprocess.run(cmd, env=dict(env, A2REF_SINK="1"), cwd=A2S, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "xinsert client was attached to a voice other than the root" in r.stderr, r.stderr[-500:]
+    # ... while without a client the same script renders like the reference
+    outs = []
+    for e in (dict(os.environ), env):
+        out = tmp_path / f"g{len(outs)}.pcm"
+        subprocess.run(cmd[:7] + [str(out)] + cmd[8:], env=e, cwd=A2S, check=True, timeout=120)
+        outs.append(np.fromfile(out, dtype="<i4"))
+    assert outs[0].any() and np.array_equal(outs[0], outs[1])

@@ -18,6 +18,15 @@ SRC = r'''
 #include "a2_waves.h"
 #include "a2_drivers.h"
 #include "a2_properties.h"
+#include "xinsert.h"            /* engine-internal: src/units/xinsert.h */
+/* the plugin header declares the a2_*_unitdesc symbols with its own type; keep
+ * the two sets of declarations apart */
+#define a2_wtosc_unitdesc p_wtosc
+#define a2_panmix_unitdesc p_panmix
+#define a2_filter12_unitdesc p_f12
+#define a2_fbdelay_unitdesc p_fbd
+#define a2_inline_unitdesc p_inl
+#define a2_xinsert_unitdesc p_xi
 #include "a2amd_plugin.h"
 #define SAME(A, B, m) _Static_assert(offsetof(A, m) == offsetof(B, m), #m)
 #define SIZE(A, B) _Static_assert(sizeof(A) == sizeof(B), #A)
@@ -25,6 +34,7 @@ SIZE(A2_unit, A2P_unit); SAME(A2_unit, A2P_unit, next); SAME(A2_unit, A2P_unit, 
 SAME(A2_unit, A2P_unit, ninputs); SAME(A2_unit, A2P_unit, noutputs); SAME(A2_unit, A2P_unit, inputs);
 SAME(A2_unit, A2P_unit, outputs); SAME(A2_unit, A2P_unit, registers); SAME(A2_unit, A2P_unit, coutputs);
 SAME(A2_unit, A2P_unit, Process);
+SAME(A2_xinsert, A2P_xinsert, state); SAME(A2_xinsert, A2P_xinsert, clients);
 SIZE(A2_unitdesc, A2P_unitdesc); SAME(A2_unitdesc, A2P_unitdesc, name); SAME(A2_unitdesc, A2P_unitdesc, flags);
 SAME(A2_unitdesc, A2P_unitdesc, registers); SAME(A2_unitdesc, A2P_unitdesc, coutputs);
 SAME(A2_unitdesc, A2P_unitdesc, constants); SAME(A2_unitdesc, A2P_unitdesc, mininputs);
@@ -53,9 +63,5 @@ def test_plugin_structs_match_reference_headers(tmp_path):
         pytest.skip("reference tree / generated header not available here")
     src = tmp_path / "abi.c"
     src.write_text(SRC)
-    # the plugin header declares the a2_*_unitdesc symbols with its own type;
-    # keep the two declarations apart
-    subprocess.run(["gcc", "-std=gnu11", "-fsyntax-only", f"-I{REFINC}", f"-I{REF}/include",
-                    f"-I{ROOT}/include", "-Da2_wtosc_unitdesc=p_wtosc", "-Da2_panmix_unitdesc=p_panmix",
-                    "-Da2_filter12_unitdesc=p_f12", "-Da2_fbdelay_unitdesc=p_fbd",
-                    "-Da2_inline_unitdesc=p_inl", "-Da2_xinsert_unitdesc=p_xi", str(src)], check=True)
+    subprocess.run(["gcc", "-std=gnu11", "-fsyntax-only", f"-I{REFINC}", f"-I{REF}/include", f"-I{REF}/src", f"-I{REF}/src/units",
+                    f"-I{ROOT}/include", str(src)], check=True)
