@@ -153,6 +153,10 @@ struct HVoice {
 	std::vector<A2DRec> recs;	// this batch, fragment order
 	long long touched = -1;		// serial of the fragment of the last touch
 	size_t frag_mark = 0;		// recs.size() when that fragment was first touched
+	long long walked = -1;		// serial of the last fragment the engine made a Process call in
+	long long default_seg = -1;	// serial of the fragment whose only event so far is the default
+					// window (one Process(0, frames) per unit): no record is made
+					// for it unless something else follows in that fragment
 	int cls = 0;			// launch class (CLS_*), set when the lists are rebuilt
 	bool listed_recs = false;	// already in a2amd_ctx::with_recs
 };
@@ -187,12 +191,12 @@ struct a2amd_ctx {
 	std::vector<HWave> waves;
 	int building = -1;
 	std::vector<int> stack;			// open inline windows (unit ids)
-	std::vector<int> touched_list;
 	std::vector<int> with_recs, prev_with_recs;	// voices carrying records this / last batch
 	std::vector<int> dirty_voices;		// voice mirror entries to re-upload
 	long long serial_base = 0;		// fragments rendered before this batch
 	int n_leaf_dyn = 0, static_len = 0;
 	int n_started_live = 0;			// voices the engine is walking
+	int walked_started = 0;			// ... of which it has walked this many in the open fragment
 	int n_noise = 0, n_cutoff_ramps = 0;
 	unsigned shadow_epoch = 0;
 
@@ -319,13 +323,26 @@ void touch(a2amd_ctx *c, int vi)
 	if(v.touched != serial) {
 		v.touched = serial;
 		v.frag_mark = v.recs.size();
-		c->touched_list.push_back(vi);
 	}
 }
 
 void push_rec(a2amd_ctx *c, int vi, int op, int unit, int reg, int value, unsigned dur, unsigned start)
 {
 	touch(c, vi);
+	{
+		HVoice &dv = c->voices[vi];
+		if(dv.default_seg == c->serial_base + rec_tag(c)) {
+			// the default window of this fragment was left unrecorded; now
+			// something follows it, so it has to be spelled out first
+			dv.default_seg = -1;
+			A2DRec seg = { A2D_HEAD(rec_tag(c), R_SEG, 0, 0), 0, (unsigned)c->fragframes[rec_tag(c)] << 16, 0 };
+			if(!dv.listed_recs) {
+				dv.listed_recs = true;
+				c->with_recs.push_back(vi);
+			}
+			dv.recs.push_back(seg);
+		}
+	}
 	A2DRec r;
 	r.head = A2D_HEAD(rec_tag(c), op, unit, reg);
 	r.value = value;
@@ -373,27 +390,14 @@ int close_fragment(a2amd_ctx *c)
 		return 0;
 	const int f = c->cur_frag;
 	const unsigned nframes = c->fragframes[f];
-	int touched_started = 0;
-	for(int vi : c->touched_list) {
-		HVoice &v = c->voices[vi];
-		if(v.touched != c->serial_base + f)
-			continue;	// touched ahead of a later fragment
-		if(v.started && !v.dying)
-			++touched_started;
-		size_t n = v.recs.size() - v.frag_mark;
-		if(n == 1) {
-			const A2DRec &r = v.recs.back();
-			if(A2D_ROP(r.head) == R_SEG && r.dur == (nframes << 16))
-				v.recs.pop_back();	// the default: one full window
-		}
-	}
-	c->touched_list.clear();
-	if(touched_started != c->n_started_live) {
+	(void)nframes;
+	if(c->walked_started != c->n_started_live) {
 		// a live voice got no Process call this fragment: say so, or
 		// the kernel would apply the default
 		for(size_t vi = 0; vi < c->voices.size(); ++vi) {
 			HVoice &v = c->voices[vi];
-			if(v.live && v.started && !v.dying && v.touched != c->serial_base + f) {
+			if(v.live && v.started && !v.dying && v.walked != c->serial_base + f &&
+					v.touched != c->serial_base + f) {
 				A2DRec r = { A2D_HEAD(f, R_NOP, 0, 0), 0, 0, 0 };
 				if(!v.listed_recs) {
 					v.listed_recs = true;
@@ -517,7 +521,8 @@ int upload(a2amd_ctx *c)
 	drop_graphs(c);
 	const size_t nv = c->voices.size(), nu = c->units.size();
 	// capacities
-	if(int r = grow(c, c->d_voices, nv, 1, false)) return r;
+	// (kept: only the entries that changed are re-sent below)
+	if(int r = grow(c, c->d_voices, nv, 1, true)) return r;
 	if(int r = grow(c, c->d_udesc, nu, 1, false)) return r;
 	if(int r = grow(c, c->d_ustate, nu, A2D_USTATE, true)) return r;
 	if(int r = grow(c, c->d_ustage, c->d_ustate.cap, A2D_USTATE, false)) return r;
@@ -843,7 +848,6 @@ void end_batch(a2amd_ctx *c)
 	// the first fragment of the next batch: carry them over.
 	const int done = c->nfrags;
 	c->serial_base += done;
-	c->touched_list.clear();
 	std::vector<int> carry;
 	c->prev_with_recs.clear();
 	for(int vi : c->with_recs) {
@@ -863,7 +867,6 @@ void end_batch(a2amd_ctx *c)
 		v.frag_mark = 0;
 		if(keep) {
 			v.touched = c->serial_base;
-			c->touched_list.push_back(vi);
 			carry.push_back(vi);
 		} else {
 			v.touched = -1;
@@ -1215,6 +1218,7 @@ int a2amd_fragment(a2amd_ctx *c, unsigned frames)
 	c->cur_frag = c->nfrags++;
 	c->fragframes[c->cur_frag] = frames;
 	c->frag_open = true;
+	c->walked_started = 0;
 	c->building = -1;
 	return A2AMD_OK;
 }
@@ -1413,8 +1417,11 @@ int a2amd_unit_deinit(a2amd_ctx *c, int ui)
 	if(--v.nlive == 0) {
 		// a2_VoiceFree (core.c:532-591) took the whole chain down
 		push_rec(c, u.voice, R_KILL, 0, 0, 0, 0, 0);
-		if(v.started)
+		if(v.started) {
 			--c->n_started_live;
+			if(c->frag_open && v.walked == c->serial_base + c->cur_frag)
+				--c->walked_started;
+		}
 		v.dying = true;
 		v.live = false;
 		if(v.own_off >= 0)
@@ -1583,9 +1590,13 @@ static void shadow_wave(a2amd_ctx *c, HUnit &u, unsigned frames)
 			dph >>= 1;
 		uint64_t ph = u.phase >> mm;
 		dph = (unsigned)(((uint64_t)u.dphase * w.period) >> mm);
-		if(looped)
-			ph %= (uint64_t)w.size[mm] << 24;
-		else if((ph >> 24) > (uint64_t)(w.size[mm] + 1))
+		if(looped) {
+			const uint64_t m = (uint64_t)w.size[mm] << 24;
+			if(!(m & (m - 1)))
+				ph &= m - 1;	// built-in waves: power-of-two levels
+			else
+				ph %= m;
+		} else if((ph >> 24) > (uint64_t)(w.size[mm] + 1))
 			return;		// all played
 		u.phase = (ph + (uint64_t)dph * frames) << mm;
 		return;
@@ -1631,6 +1642,10 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 		++c->n_started_live;
 	}
 	touch(c, vi);
+	if(v.walked != c->serial_base + c->cur_frag) {
+		v.walked = c->serial_base + c->cur_frag;
+		++c->walked_started;
+	}
 	if(u.chainpos == 0) {
 		v.win_off = (int)offset;
 		v.win_frames = (int)frames;
@@ -1683,8 +1698,19 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 		break;
 	}
 	v.win_done = u.chainpos + 1;
-	if(u.chainpos == v.nunits - 1)
-		push_rec(c, vi, R_SEG, 0, 0, 0, offset | (frames << 16), 0);
+	if(u.chainpos == v.nunits - 1) {
+		// The common case at scale - the voice's VM slept through the fragment,
+		// the engine made one full-window Process call per unit, nothing else
+		// happened to the voice - costs no record: the kernels apply that
+		// default to every voice without records (push_rec spells it out if
+		// something does follow in this fragment).
+		if(offset == 0 && frames == c->fragframes[c->cur_frag] && v.recs.size() == v.frag_mark &&
+				v.deferred.empty()) {
+			v.default_seg = c->serial_base + c->cur_frag;
+			v.win_done = 0;
+		} else
+			push_rec(c, vi, R_SEG, 0, 0, 0, offset | (frames << 16), 0);
+	}
 	return A2AMD_OK;
 }
 

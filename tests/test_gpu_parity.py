@@ -292,6 +292,24 @@ def test_wave_drop_and_pool_reuse(oracle_lib):
     assert want.any() and first_diff(got, want) is None
 
 
+def test_voice_table_grows_between_batches(oracle_lib):
+    """Voices keep arriving after the first render until the device tables have
+    to be reallocated (first capacity: 1024 voices / units): the entries of the
+    voices that did not change must survive the move (regression: an engine
+    spawning 1 024 voices over several fragments faulted on the GPU)."""
+    outs = []
+    for be in (make_gpu(max_batch=4), make_oracle(oracle_lib)):
+        sc = synth.Scene(be)
+        sc.root()
+        chunks = []
+        for step in range(6):
+            sc.add_voices(300, chain="osc-pan" if step % 2 else "osc-filter-pan", total=2048)
+            chunks.append(sc.run(2, batch=2))
+        outs.append(np.concatenate(chunks, axis=1))
+        be.close()
+    assert first_diff(outs[0], outs[1]) is None
+
+
 def test_linearity_at_full_size():
     """Size-independent property at BASELINE size (16384 voices, config 3
     shape would take the oracle minutes): the bus is a wrap-around sum, so the

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""The whole stack at scale: the unmodified reference engine (compiler, VM,
+voice walk: one thread) rendering N sustained voices per 64-frame fragment, with
+its own units and with the drop-in GPU units (LD_PRELOAD).  This is the number
+an application linking the drop-in gets; the engine's per-voice walk and the
+per-unit callbacks stay on that one CPU thread.
+
+    python tools/engine_in_loop.py
+
+Uses oracle/_ref/ref_bench (compiled reference + timing harness) and
+tests/a2s/bench.a2s.  One JSON line per (program, voices).
+"""
+import json
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+U = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
+A2S = os.path.join(ROOT, "tests", "a2s")
+
+
+def run(program, voices, frags, preload):
+    env = dict(os.environ)
+    if preload:
+        env["LD_PRELOAD"] = U
+    out = subprocess.run([B, "bench.a2s", program, str(voices), str(frags), "1"], env=env, cwd=A2S,
+                         capture_output=True, text=True, check=True, timeout=900).stdout
+    return json.loads(out.strip().splitlines()[-1])
+
+
+def main():
+    for program, cpu_frags in (("OscPan", 300), ("OscFilterPan", 200), ("Osc2Pan", 200), ("Fm1Pan", 300),
+                               ("Fm2Pan", 150), ("Fm4Pan", 60)):
+        for voices in (1024, 4096, 16384):
+            c = run(program, voices, max(cpu_frags * 1024 // voices, 20), False)
+            g = run(program, voices, 300, True)
+            frag_us = g["seconds"] / g["fragments"] * 1e6
+            print(json.dumps({"program": program, "voices": voices,
+                              "cpu_reference_vs_per_s": c["voice_samples_per_s"],
+                              "engine_plus_dropin_vs_per_s": g["voice_samples_per_s"],
+                              "speedup": round(g["voice_samples_per_s"] / c["voice_samples_per_s"], 2),
+                              "dropin_us_per_fragment": round(frag_us, 1),
+                              "realtime_at_48k": frag_us < 1333.3}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
