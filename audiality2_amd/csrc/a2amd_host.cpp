@@ -116,21 +116,23 @@ template<class T> struct DevBuf {
 };
 
 struct HUnit {
+	// --- what a Process call of a wtosc / any unit reads and writes: one cache line ---
 	bool live = false;
+	bool shadow_ok = true;
 	int kind = 0;
-	unsigned flags = 0;
-	int nin = 0, nout = 0, wired = 0;
 	int voice = -1, chainpos = 0;
 	// wtosc shadow: enough of A2_wtosc to count noise draws on the host
 	int mode = A2D_OSC_OFF, wave = -1;
-	bool shadow_ok = true;
 	unsigned shadow_epoch = 0;	// == ctx epoch while every Process call came through unit_process
-	Ramp p = {0, 0, 0, 0};
 	unsigned dphase = 0;
-	uint64_t phase = 0;
 	int p_ramping = 0;
+	uint64_t phase = 0;
+	Ramp p = {0, 0, 0, 0};
+	// --- second line ---
 	// filter12 shadow: the cutoff ramper never leaves the host
 	Ramp cutoff = {0, 0, 0, 0};
+	unsigned flags = 0;
+	int nin = 0, nout = 0, wired = 0;
 	// fbdelay: delay line pair index
 	int fbdbuf = -1;
 	// fm: slot in the operator state pool
@@ -138,27 +140,31 @@ struct HUnit {
 };
 
 struct HVoice {
+	// --- touched by every Process call of the voice: kept within one cache line ---
 	bool live = false, dying = false;
-	uint64_t key = 0;
-	int nunits = 0, nlive = 0;
-	int unit[A2D_MAXCHAIN];
 	bool resolved = false, started = false;
-	int depth = 0;
-	int inline_pos = -1;		// chain position of the inline unit, if any
-	int win_done = 0;		// units of the chain that have processed the window in progress
-	std::vector<A2DRec> deferred;	// writes waiting behind that window's SEG record
-	int out_off = 0, out_nch = 0;
-	int own_off = -1, own_nch = 0;
+	bool listed_recs = false;	// already in a2amd_ctx::with_recs
+	int nunits = 0;
 	int win_off = -1, win_frames = 0;
-	std::vector<A2DRec> recs;	// this batch, fragment order
+	int win_done = 0;		// units of the chain that have processed the window in progress
 	long long touched = -1;		// serial of the fragment of the last touch
-	size_t frag_mark = 0;		// recs.size() when that fragment was first touched
 	long long walked = -1;		// serial of the last fragment the engine made a Process call in
 	long long default_seg = -1;	// serial of the fragment whose only event so far is the default
 					// window (one Process(0, frames) per unit): no record is made
 					// for it unless something else follows in that fragment
+	size_t frag_mark = 0;		// recs.size() when that fragment was first touched
+	// --- second line: the records ---
+	std::vector<A2DRec> recs;	// this batch, fragment order
+	std::vector<A2DRec> deferred;	// writes waiting behind the open window's SEG record
+	// --- structure (set up once) ---
+	uint64_t key = 0;
+	int nlive = 0;
+	int unit[A2D_MAXCHAIN];
+	int depth = 0;
+	int inline_pos = -1;		// chain position of the inline unit, if any
+	int out_off = 0, out_nch = 0;
+	int own_off = -1, own_nch = 0;
 	int cls = 0;			// launch class (CLS_*), set when the lists are rebuilt
-	bool listed_recs = false;	// already in a2amd_ctx::with_recs
 };
 
 struct DepthRange { int fast_first = 0, fast_count = 0, gen_first = 0, gen_count = 0, dyn_first = 0, dyn_count = 0; };

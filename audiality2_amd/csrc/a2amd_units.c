@@ -59,7 +59,11 @@ typedef struct HOSTSTATE
 
 static HOSTSTATE states[MAXSTATES];
 
-/* our per-instance data lives at the tail of the engine's 384 byte block */
+/* Our per-instance data lives in the engine's 384 byte instance block: right
+ * behind the A2_unit header (the cache line after the one the engine's dispatch
+ * loop has just touched) for the units that are entirely ours, at the tail of
+ * the block for the two wrapped engine units, whose own structs (A2_inline,
+ * A2_xinsert) start the block. */
 typedef struct XTRA
 {
 	HOSTSTATE	*hs;
@@ -74,9 +78,13 @@ typedef struct XTRA
 	int		chain_checked;	/* the units behind us in the voice have been looked at */
 } XTRA;
 
+_Static_assert(sizeof(A2P_unit) <= 64 && 64 + sizeof(XTRA) <= A2P_BLOCK_SIZE, "XTRA placement");
+
 static inline XTRA *xtra(A2P_unit *u)
 {
-	return (XTRA *)((char *)u + A2P_BLOCK_SIZE - sizeof(XTRA));
+	if(u->descriptor == &a2_inline_unitdesc || u->descriptor == &a2_xinsert_unitdesc)
+		return (XTRA *)((char *)u + A2P_BLOCK_SIZE - sizeof(XTRA));
+	return (XTRA *)((char *)u + 64);
 }
 
 static void die(HOSTSTATE *hs, const char *what, int rc)
