@@ -5,7 +5,8 @@ its own units and with the drop-in GPU units (LD_PRELOAD).  This is the number
 an application linking the drop-in gets; the engine's per-voice walk and the
 per-unit callbacks stay on that one CPU thread.
 
-    python tools/engine_in_loop.py
+    python tools/engine_in_loop.py            # one engine state, 1 024 ... 32 768 voices
+    python tools/engine_in_loop.py states     # 1 ... 16 engine states (threads) on one GPU
 
 Uses oracle/_ref/ref_bench (compiled reference + timing harness) and
 tests/a2s/bench.a2s.  One JSON line per (program, voices).
@@ -20,11 +21,11 @@ U = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
 A2S = os.path.join(ROOT, "tests", "a2s")
 
 
-def run(program, voices, frags, preload):
+def run(program, voices, frags, preload, threads=1):
     env = dict(os.environ)
     if preload:
         env["LD_PRELOAD"] = U
-    out = subprocess.run([B, "bench.a2s", program, str(voices), str(frags), "1"], env=env, cwd=A2S,
+    out = subprocess.run([B, "bench.a2s", program, str(voices), str(frags), str(threads)], env=env, cwd=A2S,
                          capture_output=True, text=True, check=True, timeout=900).stdout
     return json.loads(out.strip().splitlines()[-1])
 
@@ -44,5 +45,28 @@ def main():
                               "realtime_at_48k": frag_us < 1333.3}), flush=True)
 
 
+def states():
+    """T independent engine states (the only thread-safe arrangement,
+    audiality2.h.cmake:163-166), one host thread each, 16 384 voices per state,
+    all sharing one GPU through the drop-in (one backend context + stream per
+    state)."""
+    per = 16384
+    for program in ("OscPan", "OscFilterPan", "Fm4Pan"):
+        for t in (1, 2, 4, 8, 16):
+            c = run(program, per * t, 40 if program != "Fm4Pan" else 10, False, t)
+            g = run(program, per * t, 200, True, t)
+            frag_us = g["seconds"] / g["fragments"] * 1e6
+            print(json.dumps({"program": program, "states": t, "voices_total": per * t,
+                              "cpu_reference_vs_per_s": c["voice_samples_per_s"],
+                              "engine_plus_dropin_vs_per_s": g["voice_samples_per_s"],
+                              "speedup": round(g["voice_samples_per_s"] / c["voice_samples_per_s"], 2),
+                              "dropin_us_per_fragment": round(frag_us, 1),
+                              "realtime_at_48k": frag_us < 1333.3}), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    if sys.argv[1:] == ["states"]:
+        states()
+    else:
+        main()
