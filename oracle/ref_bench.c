@@ -27,6 +27,7 @@ typedef struct JOB
 	double		seconds;
 	int		active;
 	int		ok;
+	unsigned long long hash;	/* FNV-1a 64 of everything the state rendered while timed */
 } JOB;
 
 static double now(void)
@@ -64,9 +65,23 @@ static void *run(void *arg)
 	/* warm-up: instantiates the voices */
 	for(f = 0; f < j->voices / 4 * 2 / 64 + 16; ++f)
 		a2_Run(i, 64);
+	j->hash = 0xcbf29ce484222325ULL;
 	t0 = now();
 	for(f = 0; f < j->fragments; ++f)
+	{
 		a2_Run(i, 64);
+		if(getenv("A2REF_HASH"))	/* correctness runs only: costs time */
+		{
+			int c;
+			unsigned k;
+			for(c = 0; c < 2; ++c)
+			{
+				const unsigned char *b = (const unsigned char *)((A2_audiodriver *)drv)->buffers[c];
+				for(k = 0; k < 64 * 4; ++k)
+					j->hash = (j->hash ^ b[k]) * 0x100000001b3ULL;
+			}
+		}
+	}
 	j->seconds = now() - t0;
 	a2_GetStateProperty(i, A2_PACTIVEVOICES, &av);
 	j->active = av;
@@ -115,8 +130,16 @@ int main(int argc, const char *argv[])
 		active += jobs[t].active;
 	}
 	printf("{\"voice_samples_per_s\": %.6g, \"seconds\": %.6f, \"voices\": %d, "
-			"\"fragments\": %d, \"threads\": %d, \"active_voices\": %d}\n",
+			"\"fragments\": %d, \"threads\": %d, \"active_voices\": %d",
 			(double)(voices / threads) * threads * 64.0 * fragments / worst,
 			worst, (voices / threads) * threads, fragments, threads, active);
+	if(getenv("A2REF_HASH"))
+	{
+		printf(", \"hashes\": [");
+		for(t = 0; t < threads; ++t)
+			printf("%s\"%016llx\"", t ? ", " : "", jobs[t].hash);
+		printf("]");
+	}
+	printf("}\n");
 	return 0;
 }

@@ -127,3 +127,23 @@ def test_dropin_refuses_mixed_chains(tmp_path):
         subprocess.run(cmd[:7] + [str(out)] + cmd[8:], env=e, cwd=A2S, check=True, timeout=120)
         outs.append(np.fromfile(out, dtype="<i4"))
     assert outs[0].any() and np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_several_engine_states_share_the_gpu():
+    """Independent engine states on their own host threads (the reference's
+    only thread-safe arrangement) each get a backend context and a stream of
+    their own from the drop-in; every state's audio equals the CPU render."""
+    import json
+    bench = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+    need_ref()
+    res = []
+    for preload in (False, True):
+        env = dict(os.environ, A2REF_HASH="1")
+        if preload:
+            env["LD_PRELOAD"] = UNITS_SO
+        out = subprocess.run([bench, "bench.a2s", "OscFilterPan", str(6 * 520), "40", "6"], env=env, cwd=A2S,
+                             capture_output=True, text=True, check=True, timeout=600).stdout
+        res.append(json.loads(out.strip().splitlines()[-1]))
+    assert res[0]["active_voices"] == res[1]["active_voices"] > 6 * 500
+    assert len(res[0]["hashes"]) == 6 and res[0]["hashes"] == res[1]["hashes"]
