@@ -1046,6 +1046,17 @@ const char *a2amd_version(void) { return "a2amd 0.1 (gfx950)"; }
 
 const char *a2amd_last_error(const a2amd_ctx *c) { return c ? c->err : g_err; }
 
+int a2amd_device_count(void)
+{
+	int n = 0;
+	return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+// The current HIP device is per host thread; a context may be driven from a
+// thread other than the one that opened it, and contexts of one process may
+// live on different GPUs (one engine state per GPU).
+static inline void use_device(const a2amd_ctx *c) { (void)hipSetDevice(c->cfg.device); }
+
 int a2amd_open(const a2amd_config *cfg, a2amd_ctx **out)
 {
 	if(!cfg || !out || cfg->channels < 1 || cfg->channels > A2D_MAXCH || cfg->samplerate <= 0) {
@@ -1099,6 +1110,7 @@ void a2amd_close(a2amd_ctx *c)
 {
 	if(!c)
 		return;
+	use_device(c);
 	hipStreamSynchronize(c->stream);
 	drop_graphs(c);
 	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
@@ -1131,6 +1143,7 @@ int a2amd_get_pitch_table(const a2amd_ctx *c, uint32_t *t)
 // ---- waves ------------------------------------------------------------------
 int a2amd_wave_upload(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w)
 {
+	use_device(c);
 	if(!w)
 		return c->fail(A2AMD_EINVAL, "wave_upload: null descriptor");
 	int id = -1;
@@ -1742,6 +1755,7 @@ struct TimingDump { ~TimingDump() { if(getenv("A2AMD_HOSTTIMING") && g_n) fprint
 
 int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned cap)
 {
+	use_device(c);
 	double t0 = now_us();
 	if(!c->stack.empty())
 		return c->fail(A2AMD_ESTATE, "render inside an inline window");
@@ -1836,6 +1850,7 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 
 int a2amd_replay(a2amd_ctx *c, unsigned steps)
 {
+	use_device(c);
 	const int GRAPH_STEPS = 8;
 	if(!c->uploaded || !c->nfrags)
 		return c->fail(A2AMD_ESTATE, "replay without an uploaded batch");

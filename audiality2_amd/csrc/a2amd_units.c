@@ -150,7 +150,15 @@ static a2amd_ctx *ctx_of(HOSTSTATE *hs)
 		c.samplerate = hs->cfg->samplerate;
 		c.basepitch = hs->cfg->basepitch;
 		c.channels = hs->cfg->channels;
+		/* A2AMD_DEVICE=<n>: that HIP device; A2AMD_DEVICE=all: the engine
+		 * states of this process are dealt round robin over all devices
+		 * (independent states exchange nothing: no collective) */
 		c.device = getenv("A2AMD_DEVICE") ? atoi(getenv("A2AMD_DEVICE")) : 0;
+		if(getenv("A2AMD_DEVICE") && !strcmp(getenv("A2AMD_DEVICE"), "all"))
+		{
+			int n = a2amd_device_count();
+			c.device = n > 0 ? (int)(hs - states) % n : 0;
+		}
 		c.max_batch = 1;
 		if((rc = a2amd_open(&c, &hs->ctx)))
 			die(NULL, "a2amd_open", rc);

@@ -126,6 +126,8 @@ int  a2amd_open(const a2amd_config *cfg, a2amd_ctx **out);
 void a2amd_close(a2amd_ctx *ctx);
 const char *a2amd_last_error(const a2amd_ctx *ctx);   /* ctx may be NULL */
 const char *a2amd_version(void);
+/* Number of HIP devices a2amd_config.device may name (0 without a GPU). */
+int  a2amd_device_count(void);
 
 /* The 64x{base,coeff} table of a2_P2I (src/pitch.c:57-96).  a2amd_open builds
  * it with the host's powf exactly as the reference does; a host that wants the
