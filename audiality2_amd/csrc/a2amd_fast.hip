@@ -1614,11 +1614,15 @@ static int launch_fmpan(const A2DParams *dparams, const A2DParams &hp, const int
 	const int nwaves = (nlist + vpw - 1) / vpw;
 	const int nblocks = (nwaves + FAST_WPB - 1) / FAST_WPB;
 	const size_t lds = (size_t)FAST_WPB * vpw * FILT_PITCH * sizeof(int);
-	static bool attr_set = false;
-	if(!attr_set) {
+	// (the attribute belongs to the function on ONE device: contexts of one
+	// process may live on different GPUs)
+	static bool attr_set[64];
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	if(!attr_set[dev & 63]) {
 		(void)hipFuncSetAttribute((const void *)k_leaf_fmpan<NOPS, OSBITS, PAR>,
 				hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-		attr_set = true;
+		attr_set[dev & 63] = true;
 	}
 	hipLaunchKernelGGL((k_leaf_fmpan<NOPS, OSBITS, PAR>), dim3(nblocks), dim3(64 * FAST_WPB), lds, stream,
 			dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.fmstate, hp.fmsine, hp.ptab, hp.busmem);
@@ -1690,11 +1694,13 @@ int a2d_launch_leaf_fmpan_all(const A2DParams *dparams, const A2DParams &hp, con
 		return 0;
 	const int nblocks = (nwaves + FAST_WPB - 1) / FAST_WPB;
 	const size_t lds = (size_t)FAST_WPB * vpw * FILT_PITCH * sizeof(int);
-	static bool attr_set = false;
-	if(!attr_set) {
+	static bool attr_set[64];
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	if(!attr_set[dev & 63]) {
 		(void)hipFuncSetAttribute((const void *)k_leaf_fmpan_all, hipFuncAttributeMaxDynamicSharedMemorySize,
 				150 * 1024);
-		attr_set = true;
+		attr_set[dev & 63] = true;
 	}
 	hipLaunchKernelGGL(k_leaf_fmpan_all, dim3(nblocks), dim3(64 * FAST_WPB), lds, (hipStream_t)stream,
 			dparams, dlist, segs, vpw, hp.voices, hp.ustate, hp.fmstate, hp.fmsine, hp.ptab, hp.busmem);

@@ -223,6 +223,7 @@ struct a2amd_ctx {
 	int n_fm_leaf = 0, fm_kind_count[8] = { 0 };		// fm-panmix: grouped by unit kind (fm1..fm4r), one launch each
 	int n_list_pads = 0;
 	std::vector<DepthRange> depth_ranges;	// index = depth
+	bool hosttiming = false;		// A2AMD_HOSTTIMING
 	int no_fast = 0;			// A2AMD_NO_FAST bit mask: 1 wtosc-panmix, 2 wtosc-filter12-panmix, 4 driver chains -> general kernel (debugging / A-B tests)
 
 	// bus memory allocator (units of int32)
@@ -1080,6 +1081,7 @@ int a2amd_open(const a2amd_config *cfg, a2amd_ctx **out)
 	memset(&c->stats, 0, sizeof(c->stats));
 	build_pitch_table(c->ptab);
 	c->no_fast = getenv("A2AMD_NO_FAST") ? atoi(getenv("A2AMD_NO_FAST")) : 0;
+	c->hosttiming = getenv("A2AMD_HOSTTIMING") != nullptr;
 	c->bus_stride_frames = (size_t)c->cfg.max_batch * A2D_FRAG;
 	c->bus_used = c->bus_stride_frames * (size_t)c->cfg.channels;	// master bus at offset 0
 #define OPENCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
@@ -1756,7 +1758,8 @@ struct TimingDump { ~TimingDump() { if(getenv("A2AMD_HOSTTIMING") && g_n) fprint
 int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned cap)
 {
 	use_device(c);
-	double t0 = now_us();
+	const bool timing = c->hosttiming;	// (debug aid; the accumulators are process-wide and not thread safe)
+	double t0 = timing ? now_us() : 0;
 	if(!c->stack.empty())
 		return c->fail(A2AMD_ESTATE, "render inside an inline window");
 	close_fragment(c);
@@ -1773,8 +1776,9 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 	if(phases & A2AMD_RENDER_UPLOAD)
 		if(int r = upload(c))
 			return r;
-	double t1 = now_us();
-	g_t[0] += t1 - t0;
+	double t1 = timing ? now_us() : 0;
+	if(timing)
+		g_t[0] += t1 - t0;
 	if((phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT)) && !c->uploaded)
 		return c->fail(A2AMD_ESTATE, "render phases out of order: upload first");
 
@@ -1811,9 +1815,11 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		if(int r = c->profiling ? issue_kernels(c, phases, c->ev0, c->ev1, c->ev2) :
 				issue_kernels(c, phases, nullptr, nullptr, nullptr))
 			return r;
-	double t2 = now_us();
-	g_t[1] += t2 - t1;
-	g_n += 1;
+	double t2 = timing ? now_us() : 0;
+	if(timing) {
+		g_t[1] += t2 - t1;
+		g_n += 1;
+	}
 	if(phases & A2AMD_RENDER_READBACK) {
 		const int nch = c->cfg.channels;
 		size_t n = (size_t)c->nfrags * nch * A2D_FRAG;
@@ -1829,7 +1835,8 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		}
 		HIPCHK(c, hipMemcpyAsync(c->h_master, c->d_busmem.d, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
-		g_t[2] += now_us() - t2;
+		if(timing)
+			g_t[2] += now_us() - t2;
 		unsigned pos = 0;
 		for(int f = 0; f < c->nfrags; ++f) {
 			for(int ch = 0; ch < nch; ++ch)

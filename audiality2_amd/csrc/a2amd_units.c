@@ -304,18 +304,21 @@ static void forward_process(XTRA *x, unsigned offset, unsigned frames)
 {
 	HOSTSTATE *hs = x->hs;
 	uint32_t noise = 0, before = 0;
-	int rc, v = 0;
-	if(x->kind == A2AMD_WTOSC)
-		check_unloaded(x);
+	int rc, v = 0, is_noise = 0;
 	if(x->kind == A2AMD_WTOSC)
 	{
+		check_unloaded(x);
+		is_noise = x->wave && x->wave->type == A2AMD_WNOISE;
+	}
+	if(is_noise)
+	{
 		/* the engine-global RNG the noise oscillators share with the VM's
-		 * RAND instructions (internals.h:682), through the public property */
+		 * RAND instructions (internals.h:682), through the public property
+		 * (only oscillators that play the noise wave draw from it) */
 		a2_GetStateProperty(hs->cfg->interface, A2P_PNOISESEED, &v);
 		noise = before = (uint32_t)v;
 	}
-	if((rc = a2amd_unit_process(hs->ctx, x->uid, offset - hs->base, frames,
-			x->kind == A2AMD_WTOSC ? &noise : NULL)))
+	if((rc = a2amd_unit_process(hs->ctx, x->uid, offset - hs->base, frames, is_noise ? &noise : NULL)))
 		die(hs, "a2amd_unit_process", rc);
 	if(noise != before)
 		a2_SetStateProperty(hs->cfg->interface, A2P_PNOISESEED, (int)noise);
