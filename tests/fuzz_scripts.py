@@ -1,0 +1,155 @@
+"""Random A2S scripts for differential testing (tests/test_fuzz_dropin.py): voice
+programs over every replaced unit with random structures, parameters, ramps and
+timing, spawned by a random main program.  Deterministic per seed."""
+import random
+
+WAVES = ["sine", "saw", "triangle", "pulse10", "pulse30", "pulse50", "asine", "hsine", "qsine", "noise"]
+FMS = [("fm1", 1), ("fm2", 2), ("fm3", 3), ("fm4", 4), ("fm3p", 3), ("fm4p", 4), ("fm2r", 2), ("fm4r", 4)]
+
+
+def r(rng, lo, hi, nd=3):
+    return f"{rng.uniform(lo, hi):.{nd}f}".rstrip("0").rstrip(".") or "0"
+
+
+def pos(x):
+    """A2S lexes '-.5' after a name as a literal only in some places: always parenthesise negatives."""
+    return f"({x})" if x.startswith("-") else x
+
+
+def delay(rng):
+    return r(rng, 0.3, 35.0, 2)
+
+
+def osc_steps(rng, n, pre=""):
+    out = []
+    for _ in range(n):
+        k = rng.random()
+        if k < 0.3:
+            out.append(f"\t{pre}p (P + {pos(r(rng, -1.5, 1.5))}); d {delay(rng)}")
+        elif k < 0.55:
+            out.append(f"\t{pre}a (V * {r(rng, 0, 1.2)}); d {delay(rng)}")
+        elif k < 0.65:
+            out.append(f"\t@{pre}p (P + {pos(r(rng, -1, 2))}); {pre}phase {r(rng, 0, 1)}; d {delay(rng)}")
+        elif k < 0.8:
+            out.append(f"\t{pre}w {rng.choice(WAVES)}; d {delay(rng)}")
+        elif k < 0.9:
+            out.append(f"\t+{pre}p (rand .2 - .1); d {delay(rng)}")
+        else:
+            out.append(f"\td {delay(rng)}")
+    return out
+
+
+def pan_steps(rng, n):
+    return [f"\tpan {pos(r(rng, -1.6, 1.6))}; vol {r(rng, 0, 1.5)}; d {delay(rng)}" for _ in range(n)]
+
+
+def voice_program(rng, name):
+    kind = rng.randrange(12)
+    L = [f"{name}(P V)", "{"]
+    n = rng.randint(2, 7)
+    if kind == 0:
+        L += ["\tstruct { wtosc; panmix }", f"\tw {rng.choice(WAVES)}; @p P; @a V; pan {pos(r(rng, -1, 1))}; set"]
+        L += osc_steps(rng, n) + pan_steps(rng, rng.randint(0, 2))
+    elif kind == 1:
+        L += ["\tstruct { wtosc; filter12; panmix }",
+              f"\tw {rng.choice(WAVES[:9])}; @p P; @a V; cutoff (P + {r(rng, 0, 6)}); q {r(rng, 0.001, 30)}; "
+              f"lp {r(rng, 0, 1)}; bp {r(rng, 0, 1)}; hp {r(rng, 0, 1)}; set"]
+        for _ in range(n):
+            if rng.random() < 0.5:
+                L.append(f"\tcutoff (P + {pos(r(rng, -2, 9))}); d {delay(rng)}")
+            else:
+                L.append(f"\t@cutoff (P + {r(rng, 0, 5)}); q {r(rng, 0.3, 20)}; d {delay(rng)}")
+        L += osc_steps(rng, 2)
+    elif kind == 2:
+        L += ["\tstruct { wtosc A; wtosc B; panmix }",
+              f"\tA.w {rng.choice(WAVES)}; B.w {rng.choice(WAVES)}; A.p P; B.p (P + {pos(r(rng, -1, 1))}); "
+              f"A.a V; B.a (V * {r(rng, 0, 1)}); set"]
+        L += osc_steps(rng, n // 2 + 1, "A.") + osc_steps(rng, n // 2 + 1, "B.")
+    elif kind == 3:
+        fm, nops = rng.choice(FMS)
+        ring = fm.endswith("r")
+        init = [f"@p P; @a {'1' if ring else 'V'}; fb {r(rng, 0, 1.2)}"]
+        for j in range(1, nops):
+            init.append(f"@p{j} {r(rng, 0.25, 4)}; @a{j} {('V' if (ring and j == 1) else r(rng, 0, 2.5))}; fb{j} {r(rng, 0, 1)}")
+        L += [f"\tstruct {{ {fm}; panmix }}", "\t" + "; ".join(init) + f"; pan {pos(r(rng, -1, 1))}; set"]
+        for _ in range(n):
+            j = rng.randrange(nops)
+            sfx = "" if j == 0 else str(j)
+            k = rng.random()
+            if k < 0.35:
+                L.append(f"\ta{sfx} {r(rng, 0, 2) if j else '(V * ' + r(rng, 0, 1) + ')'}; d {delay(rng)}")
+            elif k < 0.6:
+                L.append(f"\tfb{sfx} {r(rng, 0, 1.5)}; d {delay(rng)}")
+            elif k < 0.85:
+                L.append(f"\tp{sfx} {('(P + ' + pos(r(rng, -1, 1)) + ')') if j == 0 else r(rng, 0.25, 4)}; d {delay(rng)}")
+            else:
+                L.append(f"\tphase {r(rng, 0, 1)}; d {delay(rng)}")
+    elif kind == 4:
+        L += ["\tstruct { wtosc; waveshaper; panmix }", f"\tw {rng.choice(WAVES[:9])}; @p P; @a V; amount {r(rng, 0, 8)}; set"]
+        L += [f"\tamount {r(rng, 0, 10)}; d {delay(rng)}" for _ in range(n)] + osc_steps(rng, 2)
+    elif kind == 5:
+        L += ["\tstruct { wtosc; dcblock; panmix }", f"\tw {rng.choice(['pulse10', 'pulse30', 'hsine', 'qsine'])}; @p P; @a V; set"]
+        L += [f"\tcutoff {pos(r(rng, -8, 3))}; d {delay(rng)}" for _ in range(n)] + osc_steps(rng, 2)
+    elif kind == 6:
+        L += ["\tstruct { wtosc; limiter; panmix }",
+              f"\tw {rng.choice(WAVES[:9])}; @p P; @a (V * {r(rng, 1, 20)}); threshold {r(rng, 0.02, 0.6)}; release {r(rng, 1, 120)}; set"]
+        L += [f"\ta (V * {r(rng, 0, 25)}); d {delay(rng)}" for _ in range(n)]
+    elif kind == 7:
+        L += ["\tstruct { dc; panmix }", f"\tvalue (V * {pos(r(rng, -1, 1))}); d {delay(rng)}"]
+        for _ in range(n):
+            if rng.random() < 0.3:
+                L.append(f"\tmode {rng.choice(['STEP', 'LINEAR'])}")
+            L.append(f"\tvalue (V * {pos(r(rng, -1, 1))}); d {delay(rng)}")
+        L.append("\tvalue 0; d 3")
+    elif kind == 8:
+        L += ["\tstruct { env E; wtosc; panmix; wire E.out a }", f"\tw {rng.choice(WAVES[:9])}; @p P; pan {pos(r(rng, -1, 1))}; set pan"]
+        L += [f"\tE.target (V * {r(rng, 0, 1)}); d {delay(rng)}" for _ in range(n)]
+        L.append("\tE.target 0; d 8")
+    elif kind == 9:
+        L += ["\tstruct { wtosc }", f"\tw {rng.choice(WAVES)}; @p P; @a V; d {delay(rng)}"] + osc_steps(rng, n)
+    elif kind == 10:
+        L += ["\tstruct { wtosc; panmix P1 1 2; filter12 2 2; panmix P2 2 > }",
+              f"\tw {rng.choice(WAVES[:9])}; @p P; @a V; P1.pan {pos(r(rng, -1, 1))}; cutoff (P + {r(rng, 0, 5)}); q {r(rng, 0.5, 9)}; set"]
+        L += [f"\tP2.pan {pos(r(rng, -1.8, 1.8))}; cutoff (P + {pos(r(rng, -1, 7))}); d {delay(rng)}" for _ in range(n)]
+    else:
+        L += ["\tstruct { wtosc; panmix 1 2; fbdelay 2 > }",
+              f"\tw {rng.choice(WAVES[:9])}; @p P; @a V; fbdelay {r(rng, 0.1, 30)}; ldelay {r(rng, 0.1, 40)}; "
+              f"rdelay {r(rng, 0.1, 40)}; fbgain {pos(r(rng, -0.6, 0.6))}; set"]
+        L += [f"\tldelay {r(rng, 0.05, 60)}; a (V * {r(rng, 0, 1)}); d {delay(rng)}" for _ in range(n)]
+    L += ["\ta 0; d 2" if kind in (0, 1, 4, 5, 9, 10, 11) else "\td 1", "}"]
+    return "\n".join(L)
+
+
+def bus_program(rng, name, children):
+    L = [f"{name}(P V)", "{"]
+    if rng.random() < 0.5:
+        L += ["\tstruct { inline 0 2; fbdelay D 2 2; panmix 2 > }",
+              f"\tD.fbdelay {r(rng, 1, 50)}; D.ldelay {r(rng, 1, 60)}; D.rdelay {r(rng, 1, 60)}; D.fbgain {r(rng, 0, 0.5)}; "
+              f"pan {pos(r(rng, -1, 1))}; set"]
+    else:
+        L += ["\tstruct { inline 0 2; panmix 2 2; xinsert 2 > }", f"\tvol {r(rng, 0.3, 1.2)}; pan {pos(r(rng, -1, 1))}; set"]
+    for _ in range(rng.randint(2, 5)):
+        L.append(f"\t{rng.choice(children)} (P + {pos(r(rng, -1, 1))}) (V * {r(rng, 0.3, 1)}); d {delay(rng)}")
+    L += [f"\tvol {r(rng, 0, 1)}; d {delay(rng)}", "\td 60", "}"]
+    return "\n".join(L)
+
+
+def make_script(seed):
+    rng = random.Random(seed)
+    nv = rng.randint(4, 8)
+    names = [f"V{i}" for i in range(nv)]
+    parts = [f'def title\t"fuzz{seed}"', 'def a2sversion\t"1.9"', ""]
+    parts += [voice_program(rng, n) + "\n" for n in names]
+    buses = [f"B{i}" for i in range(rng.randint(1, 2))]
+    parts += [bus_program(rng, b, names) + "\n" for b in buses]
+    main = ["export Main(V=.15)", "{", "\t!P 0", "\tfor {"]
+    for _ in range(rng.randint(6, 14)):
+        prog = rng.choice(names + buses)
+        main.append(f"\t\t{prog} (P + {pos(r(rng, -1.5, 1))}) V; d {delay(rng)}")
+    main += ["\t\t+P (rand 1 - .5)", "\t\tif P > 1 { P 0 }", "\t\tif P < -2 { P 0 }", "\t}", "}"]
+    return "\n".join(parts + main) + "\n"
+
+
+if __name__ == "__main__":
+    import sys
+    print(make_script(int(sys.argv[1]) if len(sys.argv) > 1 else 0))

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""One-off differential fuzz soak (see tests/test_fuzz_dropin.py): seeds A..B,
+reference engine with its own units vs with the drop-in.  Prints failures and a
+summary line.   python tools/fuzz_soak.py 24 400"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fuzz_scripts import make_script  # noqa: E402
+
+R = os.path.join(ROOT, "oracle", "_ref", "ref_render")
+U = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
+
+
+def main():
+    a, b = int(sys.argv[1]), int(sys.argv[2])
+    frames = int(sys.argv[3]) if len(sys.argv) > 3 else 96000
+    tmp = tempfile.mkdtemp(prefix="a2fuzz")
+    bad, errors, silent = [], [], 0
+    for seed in range(a, b):
+        sp = f"{tmp}/f.a2s"
+        open(sp, "w").write(make_script(seed))
+        outs = []
+        for pre in (False, True):
+            env = dict(os.environ)
+            if pre:
+                env["LD_PRELOAD"] = U
+            r = subprocess.run([R, sp, "Main", str(frames), "64", "48000", "2", f"{tmp}/o{int(pre)}.pcm", "0.15"],
+                               env=env, cwd=tmp, capture_output=True, text=True)
+            if r.returncode:
+                errors.append((seed, pre, r.stderr[-300:]))
+                break
+            outs.append(np.fromfile(f"{tmp}/o{int(pre)}.pcm", dtype="<i4"))
+        if len(outs) == 2:
+            if not outs[0].any():
+                silent += 1
+            d = np.nonzero(outs[0] != outs[1])[0]
+            if len(d):
+                bad.append((seed, int(len(d)), int(d[0])))
+                print("MISMATCH", seed, len(d), d[:3], flush=True)
+    for e in errors:
+        print("ERROR", e, flush=True)
+    print(json.dumps({"seeds": [a, b], "frames": frames, "mismatching_seeds": [x[0] for x in bad],
+                      "errors": len(errors), "silent": silent}))
+
+
+if __name__ == "__main__":
+    main()
