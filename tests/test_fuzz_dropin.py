@@ -14,7 +14,12 @@ from fuzz_scripts import make_script
 
 REF_RENDER = os.path.join(ROOT, "oracle", "_ref", "ref_render")
 UNITS_SO = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
-FRAMES = 72000          # 1.5 s
+SECONDS = 1.5
+
+
+def engine_config(seed):
+    """Sample rate, a2_Run() buffer size and master channels also vary with the seed."""
+    return (48000, 44100, 96000, 32000)[seed % 4], (64, 37, 256, 1024, 17)[seed % 5], (2, 2, 1)[seed % 3]
 
 
 @pytest.mark.gpu
@@ -30,11 +35,15 @@ def test_random_script_matches_reference(tmp_path, seed):
         env = dict(os.environ)
         if preload:
             env["LD_PRELOAD"] = UNITS_SO
-        r = subprocess.run([REF_RENDER, str(script), "Main", str(FRAMES), "64", "48000", "2", str(out), "0.15"],
+        rate, buffer, channels = engine_config(seed)
+        frames = int(SECONDS * rate) // buffer * buffer
+        r = subprocess.run([REF_RENDER, str(script), "Main", str(frames), str(buffer), str(rate), str(channels),
+                            str(out), "0.15"],
                            env=env, cwd=tmp_path, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (seed, preload, r.stderr[-800:])
         outs.append(np.fromfile(out, dtype="<i4"))
     assert outs[0].any(), f"seed {seed}: the reference rendered silence"
     bad = np.nonzero(outs[0] != outs[1])[0]
     assert len(bad) == 0, (f"seed {seed}: {len(bad)} samples differ, first at {bad[:3]} "
-                           f"(fragment {bad[0] // 128}); script: python tests/fuzz_scripts.py {seed}")
+                           f"; config (rate, buffer, channels) = {engine_config(seed)}; "
+                           f"script: python tests/fuzz_scripts.py {seed}")

@@ -31,7 +31,9 @@ def main():
             env = dict(os.environ)
             if pre:
                 env["LD_PRELOAD"] = U
-            r = subprocess.run([R, sp, "Main", str(frames), "64", "48000", "2", f"{tmp}/o{int(pre)}.pcm", "0.15"],
+            rate, buffer, channels = (48000, 44100, 96000, 32000)[seed % 4], (64, 37, 256, 1024, 17)[seed % 5], (2, 2, 1)[seed % 3]
+            n = frames * rate // 48000 // buffer * buffer
+            r = subprocess.run([R, sp, "Main", str(n), str(buffer), str(rate), str(channels), f"{tmp}/o{int(pre)}.pcm", "0.15"],
                                env=env, cwd=tmp, capture_output=True, text=True)
             if r.returncode:
                 errors.append((seed, pre, r.stderr[-300:]))
