@@ -310,6 +310,55 @@ def test_voice_table_grows_between_batches(oracle_lib):
     assert first_diff(outs[0], outs[1]) is None
 
 
+def _scene_fuzz(be, seed, nvoices, batches, bfrags):
+    """Thousands of voices of mixed classes; in every batch random voices get
+    control writes with random timing, some die, new ones arrive: every leaf
+    kernel sees quiet, ramping and record-carrying voices side by side."""
+    rng = np.random.default_rng(seed)
+    sc = synth.Scene(be)
+    sc.root()
+    chains = ["osc-pan", "osc-filter-pan", "osc2-pan", "fmmix-pan", "fm2-pan"]
+    g = sc.add_group()
+    for i, ch in enumerate(chains):
+        sc.add_voices(nvoices // len(chains), chain=ch, total=nvoices, group=g if i == 2 else None)
+    chunks = []
+    for b in range(batches):
+        for f in range(bfrags):
+            if rng.random() < 0.4:
+                pool = sc.leaves + g["leaves"]
+                for k in rng.choice(len(pool), min(len(pool), int(rng.integers(1, 60))), replace=False):
+                    units = pool[int(k)]
+                    dur = int(rng.choice([0, 200, 5000, 60000, 1500000]))
+                    start = int(rng.integers(0, 256))
+                    be.unit_write(units[-1], int(rng.integers(0, 2)), synth.fix(float(rng.uniform(-1.4, 1.4))), start, dur)
+                    be.unit_write(units[0], 2, synth.fix(float(rng.uniform(0, .02))), start, dur)
+                    if rng.random() < 0.5:
+                        be.unit_write(units[0], 1, synth.fix(float(rng.uniform(-2, 2))), start, dur)
+            sc.walk(64)
+        chunks.append(be.render(bfrags * 64))
+        # between batches: some voices die, some are born
+        for _ in range(int(rng.integers(0, 12))):
+            if len(sc.leaves) > 10:
+                k = int(rng.integers(0, len(sc.leaves)))
+                for u in sc.leaves[k]:
+                    be.unit_deinit(u)
+                del sc.leaves[k]
+        sc.add_voices(int(rng.integers(0, 15)), chain=str(rng.choice(chains)), total=nvoices)
+    return np.concatenate(chunks, axis=1)
+
+
+@pytest.mark.parametrize("seed,nvoices,bfrags", [(1, 3000, 16), (2, 800, 64), (3, 6000, 5), (4, 1500, 1)])
+def test_scene_fuzz_matches_oracle(oracle_lib, seed, nvoices, bfrags):
+    batches = 4 if bfrags > 1 else 12
+    gpu = make_gpu(max_batch=bfrags)
+    got = _scene_fuzz(gpu, seed, nvoices, batches, bfrags)
+    gpu.close()
+    ora = make_oracle(oracle_lib)
+    want = _scene_fuzz(ora, seed, nvoices, batches, bfrags)
+    ora.close()
+    assert want.any() and first_diff(got, want) is None
+
+
 def test_linearity_at_full_size():
     """Size-independent property at BASELINE size (16384 voices, config 3
     shape would take the oracle minutes): the bus is a wrap-around sum, so the
