@@ -134,16 +134,41 @@ def bus_program(rng, name, children):
     return "\n".join(L)
 
 
+def held_program(rng, name):
+    """A note that sustains until it is told to stop: `end` parks the VM, message 1
+    forces the release section (the idiom of the reference's test programs)."""
+    k = rng.randrange(3)
+    if k == 0:
+        st, setup = "wtosc; panmix", f"w {rng.choice(WAVES)}; @p P; a V; pan {pos(r(rng, -1, 1))}"
+    elif k == 1:
+        st, setup = "wtosc; filter12; panmix", f"w {rng.choice(WAVES[:9])}; @p P; a V; cutoff (P + {r(rng, 1, 5)}); q {r(rng, 1, 9)}"
+    else:
+        fm, nops = rng.choice(FMS[:4])
+        st = f"{fm}; panmix"
+        setup = "@p P; a V; fb " + r(rng, 0, 1) + "".join(f"; @p{j} {r(rng, .5, 3)}; a{j} {r(rng, 0, 2)}" for j in range(1, nops))
+    return "\n".join([f"{name}(P V)", "{", f"\tstruct {{ {st} }}", f"\t{setup}; d {delay(rng)}",
+                      f"\ta (V * {r(rng, .2, 1)}); d {delay(rng)}", "\tend",
+                      f".rel\ta 0; d {r(rng, 1, 40, 1)}", "\t1() { force rel }", "}"])
+
+
 def make_script(seed):
     rng = random.Random(seed)
     nv = rng.randint(4, 8)
     names = [f"V{i}" for i in range(nv)]
     parts = [f'def title\t"fuzz{seed}"', 'def a2sversion\t"1.9"', ""]
     parts += [voice_program(rng, n) + "\n" for n in names]
+    held = [f"H{i}" for i in range(2)]
+    parts += [held_program(rng, h) + "\n" for h in held]
     buses = [f"B{i}" for i in range(rng.randint(1, 2))]
     parts += [bus_program(rng, b, names) + "\n" for b in buses]
     main = ["export Main(V=.15)", "{", "\t!P 0", "\tfor {"]
     for _ in range(rng.randint(6, 14)):
+        if rng.random() < 0.25:
+            # an attached voice with an id: started, held, then released by message, killed or detached
+            vid = rng.randint(1, 6)
+            how = rng.choice([f"{vid}<1", f"kill {vid}", f"detach {vid}"])
+            main.append(f"\t\t{vid}:{rng.choice(held)} (P + {pos(r(rng, -1, 1))}) V; d {delay(rng)}; {how}; d {delay(rng)}")
+            continue
         prog = rng.choice(names + buses)
         main.append(f"\t\t{prog} (P + {pos(r(rng, -1.5, 1))}) V; d {delay(rng)}")
     main += ["\t\t+P (rand 1 - .5)", "\t\tif P > 1 { P 0 }", "\t\tif P < -2 { P 0 }", "\t}", "}"]
