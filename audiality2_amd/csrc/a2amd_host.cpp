@@ -600,6 +600,15 @@ int upload(a2amd_ctx *c)
 	std::vector<int> sc_idx;
 	std::vector<A2DRun> sc_val;
 	std::vector<int> now;
+	{
+		size_t total = 0;
+		for(int vi : c->with_recs)
+			total += c->voices[vi].recs.size();
+		recs.reserve(total);
+		sc_idx.reserve(c->with_recs.size() + c->prev_with_recs.size());
+		sc_val.reserve(c->with_recs.size() + c->prev_with_recs.size());
+		now.reserve(c->with_recs.size());
+	}
 	for(int vi : c->with_recs) {
 		HVoice &v = c->voices[vi];
 		if(v.recs.empty()) {
@@ -712,8 +721,10 @@ int upload(a2amd_ctx *c)
 			else if(v.cls == CLS_BUSDRIVER && v.depth < (int)dyn_bus.size())
 				dyn_bus[v.depth].push_back(vi);
 		}
-		std::stable_sort(dyn_leaf.begin(), dyn_leaf.end(),
-				[&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; });
+		// (the walk order usually has them grouped by bus already)
+		auto by_bus_dyn = [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; };
+		if(!std::is_sorted(dyn_leaf.begin(), dyn_leaf.end(), by_bus_dyn))
+			std::stable_sort(dyn_leaf.begin(), dyn_leaf.end(), by_bus_dyn);
 		std::vector<int> dyn = dyn_leaf;
 		c->n_leaf_dyn = (int)dyn_leaf.size();
 		for(size_t d = 0; d < dyn_bus.size(); ++d) {
