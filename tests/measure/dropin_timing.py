@@ -6,7 +6,7 @@ its own units and with the drop-in GPU units (BASELINE configs[0] style:
 Needs oracle/_ref (the compiled reference: it travels with the repo snapshot,
 the reference's own .a2s songs do not, so the scripts are tests/a2s/*).
 
-    python tools/dropin_timing.py [--seconds 30] [--buffer 64]
+    python tests/measure/dropin_timing.py [--seconds 30] [--buffer 64]
 """
 import argparse
 import json
@@ -14,7 +14,7 @@ import os
 import subprocess
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 R = os.path.join(ROOT, "oracle", "_ref", "ref_render")
 U = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
 A2S = os.path.join(ROOT, "tests", "a2s")

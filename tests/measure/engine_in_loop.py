@@ -5,8 +5,8 @@ its own units and with the drop-in GPU units (LD_PRELOAD).  This is the number
 an application linking the drop-in gets; the engine's per-voice walk and the
 per-unit callbacks stay on that one CPU thread.
 
-    python tools/engine_in_loop.py            # one engine state, 1 024 ... 32 768 voices
-    python tools/engine_in_loop.py states     # 1 ... 16 engine states (threads) on one GPU
+    python tests/measure/engine_in_loop.py            # one engine state, 1 024 ... 32 768 voices
+    python tests/measure/engine_in_loop.py states     # 1 ... 16 engine states (threads) on one GPU
 
 Uses oracle/_ref/ref_bench (compiled reference + timing harness) and
 tests/a2s/bench.a2s.  One JSON line per (program, voices).
@@ -15,7 +15,7 @@ import json
 import os
 import subprocess
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 B = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
 U = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
 A2S = os.path.join(ROOT, "tests", "a2s")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off differential fuzz soak (see tests/test_fuzz_dropin.py): seeds A..B,
 reference engine with its own units vs with the drop-in.  Prints failures and a
-summary line.   python tools/fuzz_soak.py 24 400"""
+summary line.   python tests/measure/fuzz_soak.py 24 400"""
 import json
 import os
 import subprocess
@@ -10,7 +10,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from fuzz_scripts import make_script  # noqa: E402
 

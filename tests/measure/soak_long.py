@@ -5,10 +5,10 @@ directory (the workload of its benchmark.sh), GPU vs the reference's own render.
 Two steps, because the reference exists only in the build container and the GPU
 only on the GPU box:
 
-  python tools/soak_long.py capture   # here: oracle/_ref/ref_tools renders every
+  python tests/measure/soak_long.py capture   # here: oracle/_ref/ref_tools renders every
                                       # song and logs the call traces into
                                       # soak_long/ (git-ignored, travels with gpurun)
-  python tools/soak_long.py replay    # GPU box: replay each trace through
+  python tests/measure/soak_long.py replay    # GPU box: replay each trace through
                                       # liba2amd.so, compare per-fragment hashes
 
 The replay prints one JSON line per song (fragments compared / differing).
@@ -22,7 +22,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 DIR = os.path.join(ROOT, "soak_long")

@@ -49,6 +49,6 @@ done
 python $REPO/tools/fm_scripted_timing.py --voices 16384 --chain fm4-pan > $OUT/fm_scripted.jsonl 2>/dev/null
 python $REPO/tools/fm_scripted_timing.py --voices 65536 --chain fm4-pan --batch 16 >> $OUT/fm_scripted.jsonl 2>/dev/null
 python $REPO/tools/fm_scripted_timing.py --voices 16384 --chain fm1-pan >> $OUT/fm_scripted.jsonl 2>/dev/null
-python $REPO/tools/dropin_timing.py > $OUT/dropin_timing.jsonl 2>/dev/null
+python $REPO/tests/measure/dropin_timing.py > $OUT/dropin_timing.jsonl 2>/dev/null
 python $REPO/tools/realtime_sweep.py --fragments 300 > $OUT/realtime_sweep.jsonl 2>/dev/null
 ls -la $OUT
