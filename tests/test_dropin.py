@@ -30,6 +30,9 @@ CASES = [("sustain", ["4", "0.05"], 9600), ("filter", ["4", "0.02"], 48000),
          ("envwire", ["0.2"], 2 * 48000),
          # the application releases a wave under running oscillators
          ("unload", ["0.1"], 48000)]
+# no fixture, compared with the reference run on the same box: 10 s of voice churn
+# (20 000 births and deaths, ~300 voices alive)
+LIVE_CASES = [("churn", ["0.05"], 10 * 48000)]
 REALTIME_CASES = {"edge", "unload"}      # see tests/golden/make_goldens.py
 UPLOAD_CASES = {"unload": "20000"}
 
@@ -147,3 +150,21 @@ def test_several_engine_states_share_the_gpu():
         res.append(json.loads(out.strip().splitlines()[-1]))
     assert res[0]["active_voices"] == res[1]["active_voices"] > 6 * 500
     assert len(res[0]["hashes"]) == 6 and res[0]["hashes"] == res[1]["hashes"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,args,frames", LIVE_CASES)
+def test_engine_with_dropin_units_matches_reference_run(tmp_path, name, args, frames):
+    need_ref()
+    outs = []
+    for preload in (False, True):
+        out = tmp_path / f"{name}{int(preload)}.pcm"
+        env = dict(os.environ)
+        if preload:
+            env["LD_PRELOAD"] = UNITS_SO
+        subprocess.run([REF_RENDER, f"{A2S}/{name}.a2s", "Main", str(frames), "64", "48000", "2", str(out)] + args,
+                       check=True, env=env, cwd=A2S, timeout=900)
+        outs.append(np.fromfile(out, dtype="<i4"))
+    assert outs[0].any()
+    bad = np.nonzero(outs[0] != outs[1])[0]
+    assert len(bad) == 0, f"{len(bad)} samples differ, first at frame {bad[0] // 2 if len(bad) else -1}"
