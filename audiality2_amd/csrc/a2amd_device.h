@@ -103,6 +103,11 @@ enum { R_SEG = 1, R_WRITE, R_INIT, R_KILL, R_F1SET, R_F1RAMP, R_NOISESEED, R_NOP
 
 struct A2DRun { int32_t first, count; };
 
+// xinsert state words: client slot + 1 (0 = no clients) and A2AMD_XIO_* mode bits
+enum { XW_SLOT = 0, XW_MODE = 1 };
+#define A2D_XIO_HALF ((size_t)A2D_MAXBATCH * 8 * A2D_FRAG)	// words per direction of a slot
+#define A2D_XIO_SLOT (2 * A2D_XIO_HALF)
+
 #define A2D_MAXBATCH 256
 #define A2D_MAXVPW   32       // voices one wavefront may walk per fragment
 
@@ -120,6 +125,7 @@ struct A2DParams {
 	const uint32_t *ptab;		// 64 x {base, coeff}, pitch.c:70-96
 	int32_t        *fmstate;	// [fm slot][A2D_FMSTATE]
 	const uint32_t *fmsine;		// 2048 x {s[i], s[i+1]-s[i]} packed 16:16, fm.c:493-501
+	int32_t *xio;			// xinsert client slots: [slot]{ tap[batch][ch][64], inject[batch][ch][64] }
 	int32_t         nfrags;
 	int32_t         samplerate;
 	int32_t         debug;		// A2AMD_DEBUG ablation bits (perf experiments only)

@@ -137,6 +137,9 @@ struct HUnit {
 	int fbdbuf = -1;
 	// fm: slot in the operator state pool
 	int fmslot = -1;
+	// xinsert: client slot (tap / inject buffers) and A2AMD_XIO_* mode
+	int xio = -1;
+	unsigned xio_mode = 0;
 };
 
 struct HVoice {
@@ -169,6 +172,15 @@ struct HVoice {
 
 struct DepthRange { int fast_first = 0, fast_count = 0, gen_first = 0, gen_count = 0, dyn_first = 0, dyn_count = 0; };
 enum { CLS_GENERIC = 0, CLS_OSCPAN, CLS_OSCFILTPAN, CLS_BUSDRIVER, CLS_BUSGENERIC, CLS_OSC2PAN, CLS_FMPAN };
+
+// host side of an xinsert client slot
+struct XioSlot {
+	int unit = -1;
+	int last_unit = -1;		// whose taps 'tap' holds (that unit may be gone by now)
+	std::vector<int32_t> tap, inj;	// [fragment][A2AMD_MAXCHANNELS][64]
+	bool inj_used = false;
+	bool tapped = false;		// had READ clients at some point of the batch being recorded
+};
 
 struct HWave {
 	bool live = false;
@@ -239,6 +251,10 @@ struct a2amd_ctx {
 	int fm_count = 0;
 	std::vector<int> fm_free, fm_deferred_free;
 
+	// xinsert client slots
+	std::vector<XioSlot> xio;
+	std::vector<int> xio_free, xio_deferred_free;
+
 	// wave pool (int16 samples)
 	size_t wavepool_used = 0;
 	std::vector<std::pair<size_t, size_t>> wavepool_free;	// (offset, length) of dropped waves' regions
@@ -255,6 +271,7 @@ struct a2amd_ctx {
 	DevBuf<int32_t> d_busmem;
 	DevBuf<int32_t> d_fbdmem;	// cap in buffer pairs
 	DevBuf<int32_t> d_fmstate;	// cap in slots of A2D_FMSTATE words
+	DevBuf<int32_t> d_xio;		// cap in slots of A2D_XIO_SLOT words
 	uint32_t *d_fmsine = nullptr;
 	DevBuf<int> d_list;
 	DevBuf<int> d_scatter;	// idx[k] then A2DRun[k] for k_scatter_runs
@@ -520,7 +537,8 @@ bool is_driver_chain(const a2amd_ctx *c, const HVoice &v)
 	return il.kind == A2AMD_INLINE && !(il.flags & A2AMD_PROCADD) && !il.wired && il.nout == 2 &&
 			pm.kind == A2AMD_PANMIX && pm.nin == 2 && pm.nout == 2 && !pm.wired &&
 			!(pm.flags & A2AMD_PROCADD) &&
-			xi.kind == A2AMD_XINSERT && xi.nin == 2 && xi.wired && (xi.flags & A2AMD_PROCADD);
+			xi.kind == A2AMD_XINSERT && xi.nin == 2 && xi.wired && (xi.flags & A2AMD_PROCADD) &&
+			!xi.xio_mode;	// (clients: the general kernel serves them)
 }
 
 int upload(a2amd_ctx *c)
@@ -538,6 +556,24 @@ int upload(a2amd_ctx *c)
 	if(int r = grow(c, c->d_busmem, c->bus_used, 1, false)) return r;
 	if(c->fbd_count)
 		if(int r = grow(c, c->d_fbdmem, c->fbd_count, 2 * (size_t)A2D_FBD_BUFSIZE, true)) return r;
+	if(!c->xio.empty()) {
+		if(int r = grow(c, c->d_xio, c->xio.size(), A2D_XIO_SLOT, true)) return r;
+		// what the WRITE clients produced for this batch's fragments
+		const size_t n = (size_t)c->nfrags * A2AMD_MAXCHANNELS * A2D_FRAG;
+		for(size_t k = 0; k < c->xio.size(); ++k) {
+			XioSlot &x = c->xio[k];
+			// (also when the clients left in the middle of the batch, and zeros
+			// over last batch's when they produced nothing)
+			if(x.unit < 0 || !(x.inj_used || (c->units[x.unit].xio_mode & A2AMD_XIO_INJECT)))
+				continue;
+			HIPCHK(c, hipMemcpyAsync(c->d_xio.d + k * A2D_XIO_SLOT + A2D_XIO_HALF, x.inj.data(),
+					n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			if(x.inj_used)
+				std::fill(x.inj.begin(), x.inj.begin() + n, 0);
+			x.inj_used = false;
+		}
+	}
 	if(c->fm_count) {
 		if(int r = grow(c, c->d_fmstate, c->fm_count, A2D_FMSTATE, true)) return r;
 		if(!c->d_fmsine) {
@@ -748,6 +784,7 @@ int upload(a2amd_ctx *c)
 	p.fbdmem = c->d_fbdmem.d;
 	p.ptab = c->d_ptab;
 	p.fmstate = c->d_fmstate.d;
+	p.xio = c->d_xio.d;
 	p.fmsine = c->d_fmsine;
 	p.nfrags = c->nfrags;
 	p.samplerate = c->cfg.samplerate;
@@ -910,6 +947,11 @@ void end_batch(a2amd_ctx *c)
 	for(int b : c->fm_deferred_free)
 		c->fm_free.push_back(b);
 	c->fm_deferred_free.clear();
+	for(int b : c->xio_deferred_free) {
+		c->xio[b].unit = -1;
+		c->xio_free.push_back(b);
+	}
+	c->xio_deferred_free.clear();
 	c->nfrags = 0;
 	c->cur_frag = 0;
 	c->frag_open = false;
@@ -1129,7 +1171,7 @@ void a2amd_close(a2amd_ctx *c)
 	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
 	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
 	hipFree(c->d_waves.d); hipFree(c->d_wavepool.d); hipFree(c->d_busmem.d);
-	hipFree(c->d_fbdmem.d); hipFree(c->d_fmstate.d); hipFree(c->d_fmsine); hipFree(c->d_list.d); hipFree(c->d_scatter.d); hipFree(c->d_ptab); hipFree(c->d_blob.d);
+	hipFree(c->d_fbdmem.d); hipFree(c->d_fmstate.d); hipFree(c->d_xio.d); hipFree(c->d_fmsine); hipFree(c->d_list.d); hipFree(c->d_scatter.d); hipFree(c->d_ptab); hipFree(c->d_blob.d);
 	for(int k = 0; k < 2; ++k) { if(c->h_blob[k]) hipHostFree(c->h_blob[k]); if(c->blob_ev[k]) hipEventDestroy(c->blob_ev[k]); }
 	if(c->h_master)
 		hipHostFree(c->h_master);
@@ -1443,6 +1485,8 @@ int a2amd_unit_deinit(a2amd_ctx *c, int ui)
 		c->fbd_deferred_free.push_back(u.fbdbuf);
 	if(u.fmslot >= 0)
 		c->fm_deferred_free.push_back(u.fmslot);
+	if(u.xio >= 0)		// (the slot serves the batch being recorded to its end)
+		c->xio_deferred_free.push_back(u.xio);
 	u.live = false;
 	c->deferred_free_units.push_back(ui);
 	--c->stats.live_units;
@@ -1746,6 +1790,71 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 	return A2AMD_OK;
 }
 
+int a2amd_unit_clients(a2amd_ctx *c, int ui, unsigned mode)
+{
+	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live || c->units[ui].kind != A2AMD_XINSERT)
+		return c->fail(A2AMD_EINVAL, "unit %d is not a live xinsert", ui);
+	if(mode & ~(unsigned)(A2AMD_XIO_TAP | A2AMD_XIO_INJECT))
+		return c->fail(A2AMD_EINVAL, "xinsert client mode %#x", mode);
+	HUnit &u = c->units[ui];
+	if(mode == u.xio_mode)
+		return A2AMD_OK;
+	if(mode && u.xio < 0) {
+		if(!c->xio_free.empty()) {
+			u.xio = c->xio_free.back();
+			c->xio_free.pop_back();
+		} else {
+			u.xio = (int)c->xio.size();
+			c->xio.emplace_back();
+		}
+		XioSlot &x = c->xio[u.xio];
+		x.unit = x.last_unit = ui;
+		x.tap.assign(A2D_XIO_HALF, 0);
+		x.inj.assign(A2D_XIO_HALF, 0);
+		x.inj_used = x.tapped = false;
+	}
+	if(mode & A2AMD_XIO_TAP)
+		c->xio[u.xio].tapped = true;
+	// (the device reads slot and mode from the unit's state words: two writes,
+	// in order with the voice's windows)
+	c->building = -1;
+	push_rec(c, u.voice, R_WRITE, u.chainpos, 0, mode ? u.xio + 1 : 0, 0, 0);
+	push_rec(c, u.voice, R_WRITE, u.chainpos, 1, (int)mode, 0, 0);
+	u.xio_mode = mode;
+	c->lists_dirty = true;		// a driver chain with clients is served by the general kernel
+	return A2AMD_OK;
+}
+
+int a2amd_unit_inject(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, const int32_t *const *bufs)
+{
+	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live || !(c->units[ui].xio_mode & A2AMD_XIO_INJECT))
+		return c->fail(A2AMD_EINVAL, "unit %d takes no client output", ui);
+	if(!c->frag_open || !frames || offset + frames > c->fragframes[c->cur_frag])
+		return c->fail(A2AMD_ESTATE, "inject [%u,+%u) outside the open fragment", offset, frames);
+	HUnit &u = c->units[ui];
+	XioSlot &x = c->xio[u.xio];
+	for(int ch = 0; ch < u.nin; ++ch) {
+		int32_t *d = x.inj.data() + ((size_t)c->cur_frag * A2AMD_MAXCHANNELS + ch) * A2D_FRAG + offset;
+		for(unsigned k = 0; k < frames; ++k)
+			d[k] = wadd(d[k], bufs[ch][k]);
+	}
+	x.inj_used = true;
+	return A2AMD_OK;
+}
+
+int a2amd_unit_tapped(a2amd_ctx *c, int ui, unsigned fragment, const int32_t **bufs)
+{
+	// (also for a unit that was deinitialised in the course of that batch)
+	if(ui < 0 || ui >= (int)c->units.size() || c->units[ui].xio < 0 || c->xio[c->units[ui].xio].last_unit != ui)
+		return c->fail(A2AMD_EINVAL, "unit %d has had no clients", ui);
+	if(fragment >= A2D_MAXBATCH)
+		return c->fail(A2AMD_EINVAL, "fragment %u", fragment);
+	const HUnit &u = c->units[ui];
+	for(int ch = 0; ch < u.nin; ++ch)
+		bufs[ch] = c->xio[u.xio].tap.data() + ((size_t)fragment * A2AMD_MAXCHANNELS + ch) * A2D_FRAG;
+	return u.nin;
+}
+
 int a2amd_inline_end(a2amd_ctx *c, int ui)
 {
 	if(c->stack.empty() || c->stack.back() != ui)
@@ -1845,6 +1954,16 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 			c->h_master_cap = n;
 		}
 		HIPCHK(c, hipMemcpyAsync(c->h_master, c->d_busmem.d, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+		for(size_t k = 0; k < c->xio.size(); ++k) {
+			// what the READ clients of xinsert units are to be handed
+			XioSlot &x = c->xio[k];
+			if(x.unit >= 0 && x.tapped) {
+				x.tapped = (c->units[x.unit].xio_mode & A2AMD_XIO_TAP) != 0;
+				HIPCHK(c, hipMemcpyAsync(x.tap.data(), c->d_xio.d + k * A2D_XIO_SLOT,
+						(size_t)c->nfrags * A2AMD_MAXCHANNELS * A2D_FRAG * sizeof(int32_t),
+						hipMemcpyDeviceToHost, c->stream));
+			}
+		}
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		if(timing)
 			g_t[2] += now_us() - t2;

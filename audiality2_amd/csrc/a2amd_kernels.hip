@@ -514,19 +514,38 @@ DEV void inline_process(Ctx &c, uint32_t desc, int offset, int frames)
 	}
 }
 
-DEV void xinsert_process(Ctx &c, uint32_t desc, int offset, int frames)
+DEV void xinsert_process(Ctx &c, uint32_t desc, const int *w, int offset, int frames)
 {
 	int k = c.lane - offset;
 	if(k < 0 || k >= frames)
 		return;
 	int n = A2D_NIN(desc);
-	if(A2D_WIRED(desc)) {
-		for(int ch = 0; ch < n; ++ch)
-			c.l->otile[ch][c.lane] = wadd(c.l->otile[ch][c.lane], c.l->scratch[ch][c.lane]);
-	} else if(A2D_ADD(desc)) {
-		// in == out on the scratch bus: out += in doubles the signal
-		for(int ch = 0; ch < n; ++ch)
-			c.l->scratch[ch][c.lane] = wshl(c.l->scratch[ch][c.lane], 1);
+	// clients (xinsert.c:60-142): READ-only ones are handed the input - it is
+	// left in the slot's tap half for the host; WRITE-only ones were run by
+	// the host, their summed output waits in the inject half
+	const int slot = w[XW_SLOT], mode = w[XW_MODE];
+	int *tap = nullptr;
+	const int *inj = nullptr;
+	if(slot) {
+		int32_t *base = c.p->xio + (size_t)(slot - 1) * A2D_XIO_SLOT + (size_t)c.frag * 8 * A2D_FRAG + c.lane;
+		if(mode & 1)
+			tap = base;
+		if(mode & 2)
+			inj = base + A2D_XIO_HALF;
+	}
+	for(int ch = 0; ch < n; ++ch) {
+		const int in = c.l->scratch[ch][c.lane];
+		const int add = inj ? inj[ch * A2D_FRAG] : 0;
+		if(tap)
+			tap[ch * A2D_FRAG] = in;
+		if(A2D_WIRED(desc))
+			c.l->otile[ch][c.lane] = wadd(c.l->otile[ch][c.lane], wadd(in, add));
+		else if(A2D_ADD(desc))
+			// in == out on the scratch bus: the client output lands in the
+			// input before "out += in" doubles it (xinsert.c:113-124)
+			c.l->scratch[ch][c.lane] = wshl(wadd(in, add), 1);
+		else if(inj)
+			c.l->scratch[ch][c.lane] = wadd(in, add);
 	}
 }
 
@@ -771,7 +790,10 @@ DEV void unit_init(const A2DParams &p, uint32_t desc, int *w, const A2DRec &r)
 		w[DW_BUFIDX] = r.value;
 		break;
 	  }
-	  case A2D_INLINE: case A2D_XINSERT:
+	  case A2D_INLINE:
+		break;
+	  case A2D_XINSERT:
+		w[XW_SLOT] = w[XW_MODE] = 0;
 		break;
 	  case A2D_DC: {	// dc_Initialize, dc.c:160-188
 		Ramp v;
@@ -848,7 +870,10 @@ DEV void unit_write(const A2DParams &p, uint32_t desc, int *w, const A2DRec &r)
 		else if(reg < 7)
 			w[DW_FBDELAY + reg] = v;
 		break;
-	  case A2D_INLINE: case A2D_XINSERT:
+	  case A2D_INLINE:
+		break;
+	  case A2D_XINSERT:	// a2amd_unit_clients: reg 0 = slot + 1, reg 1 = mode
+		w[reg ? XW_MODE : XW_SLOT] = v;
 		break;
 	  case A2D_DC:
 		if(reg == 0) {		// dc_Value, dc.c:191-215
@@ -912,7 +937,7 @@ DEV void process_window(Ctx &c, const A2DVoice &v, int offset, int frames)
 		  case A2D_FILTER12: f12_process(c, desc, w, offset, frames); break;
 		  case A2D_FBDELAY: fbd_process(c, desc, w, offset, frames); break;
 		  case A2D_INLINE: inline_process(c, desc, offset, frames); break;
-		  case A2D_XINSERT: xinsert_process(c, desc, offset, frames); break;
+		  case A2D_XINSERT: xinsert_process(c, desc, w, offset, frames); break;
 		  case A2D_DC: dc_process(c, desc, w, offset, frames); break;
 		  case A2D_WAVESHAPER: waveshaper_process(c, desc, w, offset, frames); break;
 		  case A2D_DCBLOCK: dcb_process(c, desc, w, offset, frames); break;

@@ -38,8 +38,24 @@ extern A2P_wave *a2_GetWave(void *iface, int handle);
 extern int a2_GetStateProperty(void *iface, int prop, int *v);
 extern int a2_SetStateProperty(void *iface, int prop, int v);
 
+/* engine-internal, present when the engine's symbols are visible (xinsert.c:57,
+ * xinsertapi.c:114) */
+extern int a2r_Error(void *st, int e, const char *info) __attribute__((weak));
+extern int a2_XinsertRemoveClient(A2P_xinsert_client *xic) __attribute__((weak));
+
 #define MAXSTATES 16
 #define MAXWAVES  4096
+#define MAXPEND   1024
+#define MAXZOMBIES 16
+
+/* a READ client's window, waiting for the audio of its fragment */
+typedef struct PENDING
+{
+	A2P_xinsert		*xi;
+	A2P_xinsert_client	*xic;
+	int			uid;
+	unsigned		offset, frames;
+} PENDING;
 
 typedef struct HOSTSTATE
 {
@@ -55,6 +71,10 @@ typedef struct HOSTSTATE
 	int		wave_id[MAXWAVES];
 	int		nwaves;
 	int32_t		out[A2AMD_MAXCHANNELS][A2AMD_MAXFRAG];
+	PENDING		pend[MAXPEND];
+	int		npend;
+	A2P_xinsert	*zombies[MAXZOMBIES];	/* client lists of xinserts that died owing windows */
+	int		nzombies;
 } HOSTSTATE;
 
 static HOSTSTATE states[MAXSTATES];
@@ -72,6 +92,7 @@ typedef struct XTRA
 	int		kind;
 	int		follow;		/* backend id of a trailing xinsert to process along */
 	A2P_unit	*follow_unit;	/* ... and the engine's instance of it */
+	unsigned	follow_mode;	/* A2AMD_XIO_*: what that xinsert's clients need */
 	int		is_root;
 	A2P_process_cb	orig_process;
 	A2P_wave	*wave;		/* wtosc: the wave it plays (engine object), or NULL */
@@ -300,6 +321,126 @@ static void check_chain_behind(A2P_unit *u)
 		}
 }
 
+static void client_error(A2P_xinsert *xi, int res, const char *info)
+{
+	if(a2r_Error)
+		a2r_Error(xi->state, res, info);
+	else
+		fprintf(stderr, "a2amd units: %s: error %d\n", info, res);
+}
+
+/* xi_process (src/units/xinsert.c:60-142) for an xinsert whose audio is on the
+ * GPU.  WRITE-only clients (a2_SourceCallback, a2_OpenSource) produce audio
+ * without looking at any: they run here, in the walk, and their sum travels
+ * with the batch.  READ-only clients (a2_SinkCallback, a2_OpenSink) are handed
+ * the unit's input, which exists once the fragment has been rendered: their
+ * windows are noted and served, in walk order, when the root window's audio
+ * comes back (deliver_pending).  An insert client (READ and WRITE) would need
+ * its voice's audio on the host in the middle of the GPU batch. */
+static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned frames)
+{
+	HOSTSTATE *hs = x->hs;
+	A2P_xinsert_client *xic;
+	A2P_unit *xu = &xi->header;
+	unsigned mode = 0;
+	int rc, i;
+	unsigned s;
+	for(xic = xi->clients; xic; xic = xic->next)
+		if((xic->flags & A2P_XI_READ) && (xic->flags & A2P_XI_WRITE))
+		{
+			fprintf(stderr, "a2amd units: an insert client (a2_InsertCallback) was attached to a voice "
+					"other than the root voice: its audio is on the GPU (sink and source "
+					"clients are served; inserts are unsupported, no CPU fallback)\n");
+			abort();
+		}
+		else
+			mode |= (xic->flags & A2P_XI_WRITE) ? A2AMD_XIO_INJECT : A2AMD_XIO_TAP;
+	if(mode != x->follow_mode)
+	{
+		if((rc = a2amd_unit_clients(hs->ctx, x->follow, mode)))
+			die(hs, "a2amd_unit_clients", rc);
+		x->follow_mode = mode;
+	}
+	if(mode & A2AMD_XIO_INJECT)
+	{
+		/* (the reference hands WRITE-only clients uninitialised stack arrays,
+		 * xinsert.c:66, and mixes all of them into the output, :113-118; ours
+		 * are cleared, so a client that fills only some channels - the source
+		 * streams do - adds silence to the others, not stack contents) */
+		int32_t sum[A2AMD_MAXCHANNELS][A2AMD_MAXFRAG], tmp[A2AMD_MAXCHANNELS][A2AMD_MAXFRAG];
+		int32_t *bufp[A2AMD_MAXCHANNELS];
+		const int32_t *sump[A2AMD_MAXCHANNELS];
+		memset(sum, 0, sizeof(sum));
+		for(xic = xi->clients; xic; xic = xic->next)
+		{
+			if(!(xic->flags & A2P_XI_WRITE))
+				continue;
+			memset(tmp, 0, sizeof(tmp));
+			for(i = 0; i < xu->ninputs; ++i)
+				bufp[i] = tmp[i];
+			if((rc = xic->callback(bufp, xu->ninputs, frames, xic->userdata)))
+				client_error(xi, rc, "xinsert client callback");
+			for(i = 0; i < xu->ninputs; ++i)
+				for(s = 0; s < frames; ++s)
+					sum[i][s] = (int32_t)((uint32_t)sum[i][s] + (uint32_t)tmp[i][s]);
+		}
+		for(i = 0; i < xu->ninputs; ++i)
+			sump[i] = sum[i];
+		if((rc = a2amd_unit_inject(hs->ctx, x->follow, offset - hs->base, frames, sump)))
+			die(hs, "a2amd_unit_inject", rc);
+	}
+	if(mode & A2AMD_XIO_TAP)
+		for(xic = xi->clients; xic; xic = xic->next)
+		{
+			PENDING *p;
+			if(xic->flags & A2P_XI_WRITE)
+				continue;
+			if(hs->npend >= MAXPEND)
+				die(hs, "more sink client windows in one fragment than the drop-in holds", -MAXPEND);
+			p = &hs->pend[hs->npend++];
+			p->xi = xi;
+			p->xic = xic;
+			p->uid = x->follow;
+			p->offset = offset - hs->base;
+			p->frames = frames;
+		}
+}
+
+/* The root window has been rendered: hand the READ clients their windows. */
+static void deliver_pending(HOSTSTATE *hs)
+{
+	int k, i, n, rc;
+	for(k = 0; k < hs->npend; ++k)
+	{
+		PENDING *p = &hs->pend[k];
+		const int32_t *bufs[A2AMD_MAXCHANNELS];
+		int32_t *bufp[A2AMD_MAXCHANNELS];
+		A2P_xinsert_client *c;
+		/* (the engine may have removed the client since; its unit, or the
+		 * stand-in xi_deinit left for it, is alive) */
+		for(c = p->xi->clients; c && c != p->xic; c = c->next)
+			;
+		if(!c)
+			continue;
+		if((n = a2amd_unit_tapped(hs->ctx, p->uid, 0, bufs)) < 0)
+			die(hs, "a2amd_unit_tapped", n);
+		for(i = 0; i < n; ++i)
+			bufp[i] = (int32_t *)bufs[i] + p->offset;
+		if((rc = c->callback(bufp, n, p->frames, c->userdata)))
+			client_error(p->xi, rc, "xinsert client callback");
+	}
+	hs->npend = 0;
+	for(k = 0; k < hs->nzombies; ++k)
+	{
+		/* what xi_Deinitialize (xinsert.c:204-211) would have done */
+		A2P_xinsert *z = hs->zombies[k];
+		while(z->clients)
+			a2_XinsertRemoveClient(z->clients);
+		free(z);
+	}
+	hs->nzombies = 0;
+}
+
 static void forward_process(XTRA *x, unsigned offset, unsigned frames)
 {
 	HOSTSTATE *hs = x->hs;
@@ -324,17 +465,10 @@ static void forward_process(XTRA *x, unsigned offset, unsigned frames)
 		a2_SetStateProperty(hs->cfg->interface, A2P_PNOISESEED, (int)noise);
 	if(x->follow >= 0)
 	{
-		/* an xinsert on a voice other than the root is rendered on the GPU as
-		 * the bypass it is without clients (xinsert.c:145-161); a client
-		 * (a2_XinsertAddClient, a2_SinkCallback, streams ...) would be handed
-		 * the engine's unused CPU buffers */
-		if(((A2P_xinsert *)x->follow_unit)->clients)
-		{
-			fprintf(stderr, "a2amd units: an xinsert client was attached to a voice other than the root "
-					"voice: its audio is on the GPU, the client would see silence "
-					"(unsupported, no CPU fallback)\n");
-			abort();
-		}
+		/* an xinsert on a voice other than the root is rendered on the GPU:
+		 * the bypass it is without clients (xinsert.c:145-161), or ... */
+		if(((A2P_xinsert *)x->follow_unit)->clients || x->follow_mode)
+			serve_clients(x, (A2P_xinsert *)x->follow_unit, offset, frames);
 		if((rc = a2amd_unit_process(hs->ctx, x->follow, offset - hs->base, frames, NULL)))
 			die(hs, "a2amd_unit_process (xinsert)", rc);
 	}
@@ -363,6 +497,8 @@ static void amd_process(A2P_unit *u, unsigned offset, unsigned frames)
 			die(hs, "a2amd_render", n);
 		for(c = 0; c < u->noutputs; ++c)
 			memcpy(u->outputs[c] + offset, hs->out[c], frames * sizeof(int32_t));
+		if(hs->npend || hs->nzombies)
+			deliver_pending(hs);
 	}
 }
 
@@ -581,22 +717,78 @@ static void inl_deinit(A2P_unit *u)
 		od->Deinitialize(u);
 }
 
+/* On a voice other than the root the engine's xi_Process* (xinsert.c:145-161,
+ * :60-142) would shuffle the engine's unused CPU buffers and hand THOSE to the
+ * clients: its Process is parked, also when the client API re-installs it. */
+static void xi_parked_process(A2P_unit *u, unsigned offset, unsigned frames)
+{
+	(void)u; (void)offset; (void)frames;
+}
+
+static void xi_parked_setprocess(A2P_unit *u)
+{
+	u->Process = xi_parked_process;
+}
+
 static int xi_init(A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned flags)
 {
 	WRAPSTATE *ws = (WRAPSTATE *)sd;
-	/* The engine's xinsert keeps its own Process (its client API swaps it at
-	 * will, xinsert.c:164-193): on a non-root voice it merely shuffles the
-	 * engine's unused CPU buffers, while the backend gets the bypass behaviour
-	 * from the unit ahead of it in the chain (XTRA.follow). */
+	/* The engine's xinsert keeps its own Process on the root voice (its client
+	 * API swaps it at will, xinsert.c:164-193; the root's audio is back on the
+	 * CPU when it runs).  Elsewhere the backend gets the unit's windows from the
+	 * unit ahead of it in the chain (XTRA.follow), which also serves the
+	 * clients (serve_clients). */
 	int rc = orig_desc("a2_xinsert_unitdesc")->Initialize(u, vms, ws->orig_sd, flags);
 	if(rc)
 		return rc;
-	return amd_init(A2AMD_XINSERT, u, vms, ws->hs, flags, 1);
+	if((rc = amd_init(A2AMD_XINSERT, u, vms, ws->hs, flags, 1)))
+		return rc;
+	if(!xtra(u)->is_root)
+	{
+		((A2P_xinsert *)u)->SetProcess = xi_parked_setprocess;
+		xi_parked_setprocess(u);
+	}
+	return 0;
 }
 
 static void xi_deinit(A2P_unit *u)
 {
 	const A2P_unitdesc *od = orig_desc("a2_xinsert_unitdesc");
+	HOSTSTATE *hs = xtra(u)->hs;
+	int k, n = 0;
+	/* Windows its READ clients are still owed: the voice dies in the middle of a
+	 * fragment that is not rendered yet.  xi_Deinitialize (xinsert.c:204-211)
+	 * would tell the clients they are removed now; instead the client list
+	 * moves to a stand-in A2_xinsert that lives until the fragment's audio is
+	 * back: the clients get those windows and are removed then
+	 * (deliver_pending), the way the engine does it. */
+	for(k = 0; k < hs->npend; ++k)
+		if((A2P_unit *)hs->pend[k].xi == u)
+			++n;
+	if(n && a2_XinsertRemoveClient && hs->nzombies < MAXZOMBIES)
+	{
+		A2P_xinsert *xi = (A2P_xinsert *)u, *z = (A2P_xinsert *)malloc(sizeof(A2P_xinsert));
+		A2P_xinsert_client *c;
+		if(!z)
+			die(hs, "out of memory", -1);
+		*z = *xi;
+		z->SetProcess = xi_parked_setprocess;
+		for(c = z->clients; c; c = c->next)
+			c->unit = z;
+		xi->clients = NULL;
+		for(k = 0; k < hs->npend; ++k)
+			if((A2P_unit *)hs->pend[k].xi == u)
+				hs->pend[k].xi = z;
+		hs->zombies[hs->nzombies++] = z;
+	}
+	else if(n)
+	{
+		/* (an engine that hides a2_XinsertRemoveClient: those windows are lost) */
+		for(n = k = 0; k < hs->npend; ++k)
+			if((A2P_unit *)hs->pend[k].xi != u)
+				hs->pend[n++] = hs->pend[k];
+		hs->npend = n;
+	}
 	amd_deinit(u);
 	if(od->Deinitialize)
 		od->Deinitialize(u);

@@ -105,6 +105,9 @@ class Backend:
         self._unit_write = fn("unit_write", i32, vp, i32, i32, i32, u32, u32, i32)
         self._unit_process = fn("unit_process", i32, vp, i32, u32, u32, C.POINTER(C.c_uint32))
         self._inline_end = fn("inline_end", i32, vp, i32)
+        self._unit_clients = fn("unit_clients", i32, vp, i32, u32)
+        self._unit_inject = fn("unit_inject", i32, vp, i32, u32, u32, C.POINTER(C.POINTER(C.c_int32)))
+        self._unit_tapped = fn("unit_tapped", i32, vp, i32, u32, C.POINTER(C.POINTER(C.c_int32)))
         self._render = fn("render", i32, vp, u32, C.POINTER(C.POINTER(C.c_int32)), u32)
         self._set_pt = fn("set_pitch_table", i32, vp, C.POINTER(C.c_uint32))
         self._get_pt = fn("get_pitch_table", i32, vp, C.POINTER(C.c_uint32))
@@ -163,6 +166,24 @@ class Backend:
 
     def inline_end(self, unit):
         return self._chk(self._inline_end(self.ctx, unit), "inline_end")
+
+    def unit_clients(self, unit, mode):
+        """mode: 1 = tap the unit's input for READ clients, 2 = take WRITE clients' output."""
+        return self._chk(self._unit_clients(self.ctx, unit, mode), "unit_clients")
+
+    def unit_inject(self, unit, offset, audio):
+        """audio: int32 [channels, frames] produced by the WRITE clients for this window."""
+        audio = np.ascontiguousarray(audio, dtype=np.int32)
+        ptrs = (C.POINTER(C.c_int32) * audio.shape[0])()
+        for c in range(audio.shape[0]):
+            ptrs[c] = audio[c].ctypes.data_as(C.POINTER(C.c_int32))
+        return self._chk(self._unit_inject(self.ctx, unit, offset, audio.shape[1], ptrs), "unit_inject")
+
+    def unit_tapped(self, unit, fragment):
+        """int32 [channels, 64]: what the unit's inputs carried in `fragment` of the last batch."""
+        ptrs = (C.POINTER(C.c_int32) * 8)()
+        n = self._chk(self._unit_tapped(self.ctx, unit, fragment, ptrs), "unit_tapped")
+        return np.stack([np.ctypeslib.as_array(ptrs[c], shape=(64,)).copy() for c in range(n)])
 
     def render(self, capacity_frames, phases=15):
         out = np.zeros((self.channels, max(capacity_frames, 1)), dtype=np.int32)

@@ -179,6 +179,27 @@ int  a2amd_unit_write(a2amd_ctx *ctx, int unit, int reg, int value,
  * correctly. */
 int  a2amd_unit_process(a2amd_ctx *ctx, int unit, unsigned offset,
 		unsigned frames, uint32_t *noisestate);
+/* Clients of an A2AMD_XINSERT unit (a2_XinsertAddClient, src/xinsertapi.c:72-111;
+ * served by xi_process, src/units/xinsert.c:60-142).  The client callbacks stay
+ * with the host; 'mode' says what the unit does for them from its next window
+ * on: A2AMD_XIO_TAP leaves every window's input where a2amd_unit_tapped() finds
+ * it after a READBACK render (what READ-only clients are handed),
+ * A2AMD_XIO_INJECT adds what a2amd_unit_inject() collected to the unit's output
+ * (what WRITE-only clients produced).  Insert clients (READ and WRITE) would
+ * need the audio on the host in the middle of a batch: not supported. */
+#define A2AMD_XIO_TAP     1u
+#define A2AMD_XIO_INJECT  2u
+int  a2amd_unit_clients(a2amd_ctx *ctx, int unit, unsigned mode);
+/* Add 'frames' frames per input channel (bufs[ch][0..frames)) to what the unit
+ * emits over [offset, offset+frames) of the open fragment - call it before the
+ * a2amd_unit_process() of that window. */
+int  a2amd_unit_inject(a2amd_ctx *ctx, int unit, unsigned offset, unsigned frames,
+		const int32_t *const *bufs);
+/* After a2amd_render(... READBACK): bufs[ch] = the 64 frames the unit's inputs
+ * carried in fragment 'fragment' of that batch, where it had READ clients
+ * (valid until the next render).  Returns the number of channels. */
+int  a2amd_unit_tapped(a2amd_ctx *ctx, int unit, unsigned fragment, const int32_t **bufs);
+
 /* Closes the window opened by a2amd_unit_process() on an A2AMD_INLINE unit,
  * i.e. the return of a2_ProcessSubvoices (src/core.c:1769,1775). */
 int  a2amd_inline_end(a2amd_ctx *ctx, int unit);

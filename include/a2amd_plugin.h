@@ -118,14 +118,36 @@ struct A2P_unit
 	A2P_process_cb		Process;
 };
 
-/* Head of A2_xinsert, src/units/xinsert.h:60-68 (engine-internal, shared by
- * xinsert / xsink / xsource): the drop-in only looks at 'clients', to refuse a
- * stream or callback client on a voice whose audio is not on the CPU. */
+/* A2_xinsert_client, src/units/xinsert.h:44-58, and the head of A2_xinsert,
+ * src/units/xinsert.h:60-68 (engine-internal, shared by xinsert / xsink /
+ * xsource).  On a voice other than the root the drop-in serves the clients of
+ * an xinsert itself (the engine's own xi_process would hand them the engine's
+ * unused CPU buffers): it walks 'clients' and calls 'callback' the way
+ * xi_run_callback (src/units/xinsert.c:44-58) does. */
+typedef int (*A2P_xinsert_cb)(int32_t **buffers, unsigned nbuffers, unsigned frames, void *userdata);
+#define A2P_XI_READ	0x00000100	/* A2_XI_READ,  src/units/xinsert.h:36 */
+#define A2P_XI_WRITE	0x00000200	/* A2_XI_WRITE, src/units/xinsert.h:37 */
+typedef struct A2P_xinsert_client
+{
+	struct A2P_xinsert_client *next;
+	struct A2P_xinsert	*unit;
+	A2P_xinsert_cb		callback;
+	void			*userdata;
+	void			*fifo;
+	int			channel;
+	int			voice;
+	int			handle;
+	int			stream;
+	unsigned		flags;
+	int			xflow;
+} A2P_xinsert_client;
+
 typedef struct A2P_xinsert
 {
-	A2P_unit	header;
-	void		*state;
-	void		*clients;
+	A2P_unit		header;
+	void			*state;
+	A2P_xinsert_client	*clients;
+	void (*SetProcess)(A2P_unit *u);	/* called when clients come and go, xinsertapi.c:108,135 */
 } A2P_xinsert;
 
 #define A2P_BLOCK_SIZE	384		/* A2_BLOCK_SIZE, include/audiality2.h.cmake:53 */

@@ -308,6 +308,12 @@ typedef struct a2o_unit
 	/* limiter (A2_limiter, limiter.c:35-42) */
 	unsigned	threshold, peak;
 	int		release;
+	/* xinsert clients (A2_xinsert.clients, xinsert.h:64): the callbacks stay
+	 * with the caller; what READ-only clients are handed is kept per fragment,
+	 * what WRITE-only clients produced for the coming window waits in inj */
+	unsigned	xio_mode;
+	int32_t		*tap;		/* [256 fragments][MAXCH][MAXFRAG] */
+	int32_t		inj[A2AMD_MAXCHANNELS][A2AMD_MAXFRAG];
 	/* fm (A2_fm / A2_fmosc, fm.c:81-105) */
 	int		nops;
 	struct a2o_fmosc
@@ -357,6 +363,7 @@ struct a2o_ctx
 	/* fragment clock + master bus (A2_state.master) */
 	int		frag_open;
 	unsigned	frag_frames;
+	int		batch_frags;	/* fragments begun since the last render */
 	int32_t		master[MAXCH][MAXFRAG];
 	int32_t		*outbuf[MAXCH];
 	unsigned	out_frames, out_cap;
@@ -404,6 +411,7 @@ void a2o_close(a2o_ctx *c)
 	{
 		free(c->units[i].lbuf);
 		free(c->units[i].rbuf);
+		free(c->units[i].tap);
 	}
 	free(c->units);
 	free(c->pattern);
@@ -528,6 +536,7 @@ int a2o_fragment(a2o_ctx *c, unsigned frames)
 	memset(c->master, 0, sizeof(c->master));	/* a2_ClearBus */
 	c->frag_frames = frames;
 	c->frag_open = 1;
+	++c->batch_frags;
 	c->building = NULL;
 	if(!c->replaying)
 		c->npattern = 0;
@@ -589,6 +598,7 @@ int a2o_render(a2o_ctx *c, unsigned phases, int32_t *const *out, unsigned cap)
 		memcpy(out[ch], c->outbuf[ch], c->out_frames * sizeof(int32_t));
 	n = (int)c->out_frames;
 	c->out_frames = 0;
+	c->batch_frags = 0;
 	c->building = NULL;
 	return n;
 }
@@ -724,9 +734,10 @@ int a2o_unit_init(a2o_ctx *c, uint64_t key, int kind, unsigned flags,
 			c->units = nu;
 			c->cap_units = nc;
 		}
-		++c->nunits;
+		c->units[c->nunits++].tap = NULL;
 	}
 	u = &c->units[id];
+	free(u->tap);		/* (left readable by a2o_unit_deinit) */
 	memset(u, 0, sizeof(*u));
 	u->live = 1;
 	u->kind = kind;
@@ -841,7 +852,7 @@ int a2o_unit_deinit(a2o_ctx *c, int id)
 	v = u->voice;
 	free(u->lbuf);		/* fbdelay_Deinitialize, fbdelay.c:222-228 */
 	free(u->rbuf);
-	u->lbuf = u->rbuf = NULL;
+	u->lbuf = u->rbuf = NULL;	/* (u->tap stays readable until the slot is reused) */
 	u->live = 0;
 	if(c->building == v)
 		c->building = NULL;
@@ -1712,6 +1723,103 @@ static void resolve_out(a2o_ctx *c, a2o_voice *v)
 	v->resolved = 1;
 }
 
+/*
+ * xi_process, xinsert.c:60-142, for READ-only and WRITE-only clients.  The
+ * client callbacks themselves are the application's: READ-only ones are
+ * handed the unit's inputs (:97-101) - kept here per fragment for
+ * a2o_unit_tapped(); the buffers the WRITE-only ones filled (:113-118) arrived
+ * through a2o_unit_inject() as their sum.  There are no insert clients
+ * (:104-111), so the input is bypassed into the output as well (:121-124).
+ */
+static int xi_process(a2o_ctx *c, a2o_unit *u, int32_t **in, int32_t **out,
+		unsigned o, unsigned f, int add)
+{
+	int32_t obufs[MAXCH][MAXFRAG];
+	int32_t *obufp[MAXCH];
+	unsigned s;
+	int i;
+	if(c->batch_frags > 256)
+		return fail(c, A2AMD_ESTATE, "more than 256 fragments in a batch "
+				"with xinsert clients");
+	for(i = 0; i < u->nin; ++i)
+	{
+		if(add || in[i] != out[i])
+			obufp[i] = out[i];
+		else
+			obufp[i] = obufs[i];
+		if(!add)
+			memset(obufp[i], 0, sizeof(int32_t) * MAXFRAG);
+	}
+	if(u->xio_mode & A2AMD_XIO_TAP)
+		for(i = 0; i < u->nin; ++i)
+			memcpy(u->tap + ((size_t)(c->batch_frags - 1) * MAXCH + i) * MAXFRAG + o,
+					in[i] + o, f * sizeof(int32_t));
+	if(u->xio_mode & A2AMD_XIO_INJECT)
+		for(i = 0; i < u->nin; ++i)
+			for(s = o; s < o + f; ++s)
+			{
+				obufp[i][s] += u->inj[i][s];
+				u->inj[i][s] = 0;
+			}
+	for(i = 0; i < u->nin; ++i)
+		for(s = o; s < o + f; ++s)
+			obufp[i][s] += in[i][s];
+	if(!add)
+		for(i = 0; i < u->nin; ++i)
+			if(obufp[i] != out[i])
+				for(s = o; s < o + f; ++s)
+					out[i][s] = obufp[i][s];
+	return A2AMD_OK;
+}
+
+/* a2_XinsertAddClient / a2_XinsertRemoveClient, xinsertapi.c:72-111, :114-157,
+ * as far as the unit is concerned: which kinds of client it has. */
+int a2o_unit_clients(a2o_ctx *c, int id, unsigned mode)
+{
+	a2o_unit *u = get_unit(c, id);
+	if(!u || u->kind != A2AMD_XINSERT)
+		return fail(c, A2AMD_EINVAL, "unit %d is not a live xinsert", id);
+	if(mode & ~(unsigned)(A2AMD_XIO_TAP | A2AMD_XIO_INJECT))
+		return fail(c, A2AMD_EINVAL, "xinsert client mode %#x", mode);
+	if(mode && !u->tap && !(u->tap = (int32_t *)calloc((size_t)256 * MAXCH * MAXFRAG, sizeof(int32_t))))
+		return A2AMD_ENOMEM;
+	if(!(mode & A2AMD_XIO_INJECT))
+		memset(u->inj, 0, sizeof(u->inj));
+	u->xio_mode = mode;
+	c->building = NULL;
+	return A2AMD_OK;
+}
+
+int a2o_unit_inject(a2o_ctx *c, int id, unsigned offset, unsigned frames,
+		const int32_t *const *bufs)
+{
+	a2o_unit *u = get_unit(c, id);
+	unsigned s;
+	int i;
+	if(!u || !(u->xio_mode & A2AMD_XIO_INJECT))
+		return fail(c, A2AMD_EINVAL, "unit %d takes no client output", id);
+	if(!c->frag_open || !frames || offset + frames > c->frag_frames)
+		return fail(c, A2AMD_ESTATE, "inject [%u,+%u) outside fragment", offset, frames);
+	for(i = 0; i < u->nin; ++i)
+		for(s = 0; s < frames; ++s)
+			u->inj[i][offset + s] += bufs[i][s];
+	return A2AMD_OK;
+}
+
+int a2o_unit_tapped(a2o_ctx *c, int id, unsigned fragment, const int32_t **bufs)
+{
+	/* (also for a unit that was deinitialised in the course of that batch) */
+	a2o_unit *u = id >= 0 && id < c->nunits ? &c->units[id] : NULL;
+	int i;
+	if(!u || !u->tap)
+		return fail(c, A2AMD_EINVAL, "unit %d has had no clients", id);
+	if(fragment >= 256)
+		return fail(c, A2AMD_EINVAL, "fragment %u", fragment);
+	for(i = 0; i < u->nin; ++i)
+		bufs[i] = u->tap + ((size_t)fragment * MAXCH + i) * MAXFRAG;
+	return u->nin;
+}
+
 int a2o_unit_process(a2o_ctx *c, int id, unsigned offset, unsigned frames,
 		uint32_t *nstate)
 {
@@ -1786,7 +1894,15 @@ int a2o_unit_process(a2o_ctx *c, int id, unsigned offset, unsigned frames,
 				memset(out[ch] + offset, 0, frames * sizeof(int32_t));
 		c->stack[c->sp++] = id;
 		break;
-	  case A2AMD_XINSERT:	/* xi_ProcessBypass[Add], xinsert.c:145-161 */
+	  case A2AMD_XINSERT:
+		if(u->xio_mode)
+		{
+			int r = xi_process(c, u, in, out, offset, frames, add);
+			if(r)
+				return r;
+			break;
+		}
+		/* xi_ProcessBypass[Add], xinsert.c:145-161 */
 		for(ch = 0; ch < u->nin; ++ch)
 		{
 			unsigned s;

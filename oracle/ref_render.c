@@ -38,16 +38,37 @@ static A2_handle upload_test_wave(A2_interface *i)
  * to the voice the program runs on - which then needs an xinsert or xsink unit -
  * and report the peak it saw. */
 static int sink_peak;
+static unsigned long long sink_hash = 0xCBF29CE484222325ull, sink_frames;
 static A2_errors sink_cb(int32_t **buffers, unsigned nbuffers, unsigned frames, void *userdata)
 {
-	unsigned c, s;
+	unsigned c, s, b;
 	for(c = 0; c < nbuffers; ++c)
 		for(s = 0; s < frames; ++s)
 		{
 			int v = buffers[c][s] < 0 ? -buffers[c][s] : buffers[c][s];
 			if(v > sink_peak)
 				sink_peak = v;
+			/* FNV-1a over everything the sink was handed, in the order it came */
+			for(b = 0; b < 4; ++b)
+				sink_hash = (sink_hash ^ (((unsigned)buffers[c][s] >> (8 * b)) & 255)) * 0x100000001B3ull;
 		}
+	sink_frames += frames;
+	return A2_OK;
+}
+
+/* A2REF_SOURCE=1: attach a source callback (a2_SourceCallback,
+ * audiality2.h.cmake:525) to the same voice: a deterministic sawtooth pair that
+ * does not care how the engine slices its windows. */
+static unsigned source_pos;
+static A2_errors source_cb(int32_t **buffers, unsigned nbuffers, unsigned frames, void *userdata)
+{
+	unsigned c, s;
+	if(!buffers)
+		return A2_OK;	/* removal notification */
+	for(c = 0; c < nbuffers; ++c)
+		for(s = 0; s < frames; ++s)
+			buffers[c][s] = (int)(((source_pos + s) * (c ? 77003u : 52361u)) & 0x3fffff) - 0x200000;
+	source_pos += frames;
 	return A2_OK;
 }
 
@@ -57,8 +78,11 @@ int main(int argc, const char *argv[])
 	A2_config *cfg;
 	A2_driver *drv;
 	A2_interface *i;
-	A2_handle bank, prog, upwave = -1, vh;
+	A2_handle bank, prog, upwave = -1, vh, srcstream = -1, sinkstream = -1;
+	unsigned long long stream_hash = 0xCBF29CE484222325ull, stream_frames = 0;
 	int release_at = 0;
+	/* A2REF_KILL=<frame>: a2_Kill() the voice the program runs on, timestamped */
+	int kill_at = getenv("A2REF_KILL") ? atoi(getenv("A2REF_KILL")) : -1;
 	FILE *pcm;
 	if(argc < 8)
 	{
@@ -85,7 +109,8 @@ int main(int argc, const char *argv[])
 	 * variant used by offline states does not implement (interface.c:496-505).
 	 */
 	if(!(cfg = a2_OpenConfig(rate, buffer, channels, A2_AUTOCLOSE |
-			(getenv("A2REF_REALTIME") ? A2_REALTIME : 0))))
+			(getenv("A2REF_REALTIME") ? A2_REALTIME : 0) |
+			(getenv("A2REF_KILL") ? A2_TIMESTAMP : 0))))
 		return 1;
 	a2_AddDriver(cfg, drv);
 	if(!(i = a2_Open(cfg)))
@@ -108,14 +133,56 @@ int main(int argc, const char *argv[])
 	a2_TimestampReset(i);
 	if((vh = a2_Starta(i, a2_RootVoice(i), prog, nargs, pargs)) < 0)
 		return 1;
+	if(getenv("A2REF_SOURCE") && a2_SourceCallback(i, vh, source_cb, NULL) < 0)
+	{
+		fprintf(stderr, "a2_SourceCallback failed: %s\n", a2_ErrorString(a2_LastError()));
+		return 1;
+	}
 	if(getenv("A2REF_SINK") && a2_SinkCallback(i, vh, sink_cb, NULL) < 0)
 	{
 		fprintf(stderr, "a2_SinkCallback failed: %s\n", a2_ErrorString(a2_LastError()));
 		return 1;
 	}
+	if(getenv("A2REF_INSERT") && a2_InsertCallback(i, vh, source_cb, NULL) < 0)
+		return 1;
+	/* A2REF_STREAMS=1: the buffered variants (a2_OpenSource / a2_OpenSink,
+	 * audiality2.h.cmake:561-577): a source stream feeding channel 1 of the
+	 * voice, written ahead of every a2_Run(), and a sink stream on channel 0,
+	 * drained after it. */
+	if(getenv("A2REF_STREAMS"))
+	{
+		if((srcstream = a2_OpenSource(i, vh, 1, 4 * buffer, 0)) < 0 ||
+				(sinkstream = a2_OpenSink(i, vh, 0, 4 * buffer, 0)) < 0)
+		{
+			fprintf(stderr, "cannot open streams: %s\n", a2_ErrorString(a2_LastError()));
+			return 1;
+		}
+	}
 	while(done < frames)
 	{
 		int n = frames - done < buffer ? frames - done : buffer;
+		if(kill_at >= 0 && done >= kill_at)
+		{
+			/* 0.7 ms into the coming buffer: the voice dies in the middle of a
+			 * fragment, with whatever clients it has */
+			a2_TimestampReset(i);
+			a2_TimestampBump(i, a2_ms2Timestamp(i, 0.7));
+			a2_Kill(i, vh);
+			kill_at = -1;
+			srcstream = -1;		/* (its reader is going away) */
+		}
+		if(srcstream >= 0)
+		{
+			int32_t sb[4096];
+			for(k = 0; k < n && k < 4096; ++k)
+				sb[k] = (int)(((done + k) * 40503u) & 0x3fffff) - 0x200000;
+			/* (A2_I24 = the engine's 8:24: the only format these streams take, xinsertapi.c:340) */
+			if((k = a2_Write(i, srcstream, A2_I24, sb, n * 4)))
+			{
+				fprintf(stderr, "a2_Write: %s\n", a2_ErrorString(k));
+				return 1;
+			}
+		}
 		if(upwave >= 0 && done >= release_at)
 		{
 			if(a2_Release(i, upwave))
@@ -129,13 +196,30 @@ int main(int argc, const char *argv[])
 		if(a2_Run(i, n) < 0)
 			return 1;
 		a2_PumpMessages(i);
+		if(sinkstream >= 0)
+		{
+			int32_t sb[4096];
+			int avail = a2_Available(i, sinkstream);
+			unsigned b;
+			if(avail > 4096)
+				avail = 4096;
+			if(avail > 0 && !a2_Read(i, sinkstream, A2_I24, sb, avail * 4))
+			{
+				for(k = 0; k < avail; ++k)
+					for(b = 0; b < 4; ++b)
+						stream_hash = (stream_hash ^ (((unsigned)sb[k] >> (8 * b)) & 255)) * 0x100000001B3ull;
+				stream_frames += avail;
+			}
+		}
 		for(c = 0; c < channels; ++c)
 			fwrite(((A2_audiodriver *)drv)->buffers[c], 4, n, pcm);
 		done += n;
 	}
 	fclose(pcm);
+	if(sinkstream >= 0)
+		printf("sink stream frames %llu hash %016llx\n", stream_frames, stream_hash);
 	if(getenv("A2REF_SINK"))
-		printf("sink peak %d\n", sink_peak);
+		printf("sink peak %d frames %llu hash %016llx\n", sink_peak, sink_frames, sink_hash);
 	a2_Close(i);
 	return 0;
 }

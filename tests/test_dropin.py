@@ -116,20 +116,53 @@ def test_dropin_refuses_mixed_chains(tmp_path):
     r = subprocess.run([REF_RENDER, f"{A2S}/mixedhead.a2s", "Main", "640", "64", "48000", "2", str(tmp_path / "h.pcm"), "0.1"],
                        env=env, cwd=A2S, capture_output=True, text=True, timeout=120)
     assert "takes its input from a unit that is not replaced" in r.stderr, r.stderr[-500:]
-    # a sink client on a voice other than the root (a group's xinsert): fine on
-    # the CPU, refused by the drop-in - the client would be handed silence
+    # an insert client (reads AND writes) on a voice other than the root would need
+    # that voice's audio on the host in the middle of the GPU batch: refused
     cmd = [REF_RENDER, f"{A2S}/sinkgroup.a2s", "Main", "640", "64", "48000", "2", str(tmp_path / "s.pcm"), "0.1"]
-    r = subprocess.run(cmd, env=dict(os.environ, A2REF_SINK="1"), cwd=A2S, capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0 and "sink peak" in r.stdout and "sink peak 0" not in r.stdout
-    r = subprocess.run(cmd, env=dict(env, A2REF_SINK="1"), cwd=A2S, capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and "xinsert client was attached to a voice other than the root" in r.stderr, r.stderr[-500:]
-    # ... while without a client the same script renders like the reference
-    outs = []
-    for e in (dict(os.environ), env):
-        out = tmp_path / f"g{len(outs)}.pcm"
-        subprocess.run(cmd[:7] + [str(out)] + cmd[8:], env=e, cwd=A2S, check=True, timeout=120)
-        outs.append(np.fromfile(out, dtype="<i4"))
-    assert outs[0].any() and np.array_equal(outs[0], outs[1])
+    r = subprocess.run(cmd, env=dict(env, A2REF_INSERT="1"), cwd=A2S, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "an insert client" in r.stderr, r.stderr[-500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("script,frames", [("sinkgroup", 9600), ("clients", 48000)])
+@pytest.mark.parametrize("clients", [(), ("SINK",), ("SOURCE",), ("SOURCE", "SINK"), ("STREAMS",), ("STREAMS", "SINK"),
+                                     # ... and the voice is killed 0.7 ms into a buffer: its clients are owed
+                                     # the windows of a fragment that is rendered after the voice is gone
+                                     ("SINK", "KILL"), ("SOURCE", "STREAMS", "SINK", "KILL")])
+def test_dropin_serves_sink_and_source_clients(tmp_path, script, frames, clients):
+    """a2_SinkCallback / a2_SourceCallback on a voice in the middle
+    of the graph (a group: inline; panmix; xinsert), and their buffered variants
+    a2_OpenSink / a2_OpenSource (STREAMS).  The sink is handed what it is handed
+    on the CPU (hash over everything it saw, in order), the source's audio is in
+    the output, the output is the reference's."""
+    need_ref()
+    res = []
+    for preload in (False, True):
+        out = tmp_path / f"c{int(preload)}.pcm"
+        env = dict(os.environ, **{f"A2REF_{c}": "1" for c in clients})
+        if "KILL" in clients:
+            env["A2REF_KILL"] = str(frames // 2)
+        if preload:
+            env["LD_PRELOAD"] = UNITS_SO
+        r = subprocess.run([REF_RENDER, f"{A2S}/{script}.a2s", "Main", str(frames), "64", "48000", "2", str(out), "0.1"],
+                           env=env, cwd=A2S, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-500:]
+        res.append(([ln for ln in r.stdout.splitlines() if ln.startswith("sink ")], np.fromfile(out, dtype="<i4")))
+    assert res[0][1].any()
+    assert len(res[0][0]) == len([c for c in clients if c in ("SINK", "STREAMS")])
+    if "KILL" in clients:
+        assert all(f" frames {frames // 2 + 33} " in ln for ln in res[0][0]), res[0][0]
+    assert not any(" frames 0 " in ln or "sink peak 0 " in ln for ln in res[0][0])
+    assert res[0][0] == res[1][0]
+    a, b = (r[1].reshape(-1, 2, 64) for r in res)          # [buffer, channel, frame]
+    if "STREAMS" in clients:
+        # A source stream fills only its own channel (1) of the buffers the engine
+        # hands it (a2_sourcestream_process, xinsertapi.c:287-318) and xi_process
+        # mixes ALL of them into the output (xinsert.c:113-118) - the others are
+        # uninitialised stack arrays (xinsert.c:66).  What the reference adds to
+        # channel 0 is whatever its stack held; the drop-in adds silence.
+        a, b = a[:, 1], b[:, 1]
+    assert np.array_equal(a, b)
 
 
 @pytest.mark.gpu

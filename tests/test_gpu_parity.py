@@ -380,3 +380,77 @@ def test_linearity_at_full_size():
     parts = ((parts + 2**31) % 2**32 - 2**31).astype(np.int32)
     assert whole.any()
     assert first_diff(whole, parts) is None
+
+
+def _clients_script(be, fragments=14, batch=5, seed=11):
+    """A group driver voice (inline; panmix 2->2; xinsert 2 > : a2_NewGroup's
+    shape) whose xinsert gets clients while it plays: READ-only ones (the input
+    is tapped, a2_SinkCallback), WRITE-only ones (their output is injected,
+    a2_SourceCallback), both, none again - with the group walked in split
+    windows in some fragments.  Returns (audio, {fragment: tapped input})."""
+    rng = np.random.default_rng(seed)
+    sc = synth.Scene(be, nwaves=4)
+    sc.root()
+    k = sc._key()
+    g = dict(units=[be.unit_init(k, synth.K_INLINE, 0, 0, 2, 0),
+                    be.unit_init(k, synth.K_PANMIX, 0, 2, 2, 0),
+                    be.unit_init(k, synth.K_XINSERT, synth.PROCADD, 2, 2, 1)], leaves=[])
+    sc.groups.append(g)
+    sc.add_voices(5, chain="osc-pan", group=g, total=64)
+    sc.add_voices(3, chain="osc-pan", total=64)
+    il, pm, xi = g["units"]
+    modes = {2: 1, 4: 3, 8: 2, 11: 0}
+    mode, chunks, taps, pending = 0, [], {}, []
+    for frag in range(fragments):
+        be.fragment(64)
+        be.unit_process(sc.rootv[0], 0, 64)
+        cuts = [0, 64] if frag % 3 else [0, 20, 47, 64]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            be.unit_process(il, a, b - a)
+            for units in g["leaves"]:
+                for u in units:
+                    be.unit_process(u, a, b - a)
+            be.inline_end(il)
+            if a == 20:
+                be.unit_write(pm, 0, synth.fix(float(rng.uniform(0.2, 1.0))), 0, 256 * 30)
+            be.unit_process(pm, a, b - a)
+            if frag in modes and a == 0:
+                mode = modes[frag]
+                be.unit_clients(xi, mode)
+            if mode & 2:
+                be.unit_inject(xi, a, rng.integers(-1 << 22, 1 << 22, (2, b - a)))
+                if frag % 2:        # a second WRITE client's output adds up
+                    be.unit_inject(xi, a, rng.integers(-1 << 20, 1 << 20, (2, b - a)))
+            be.unit_process(xi, a, b - a)
+        for units in sc.leaves:
+            for u in units:
+                be.unit_process(u, 0, 64)
+        be.inline_end(sc.rootv[0])
+        be.unit_process(sc.rootv[1], 0, 64)
+        be.unit_process(sc.rootv[2], 0, 64)
+        if mode & 1:
+            pending.append(frag)
+        if frag % batch == batch - 1 or frag == fragments - 1:
+            first = frag - frag % batch
+            chunks.append(be.render(batch * 64))
+            for f in pending:
+                taps[f] = be.unit_tapped(xi, f - first)
+            pending = []
+    return np.concatenate(chunks, axis=1), taps
+
+
+def test_xinsert_clients_tap_and_inject(oracle_lib):
+    """sink and source clients on an xinsert in the middle of the
+    graph (xi_process, src/units/xinsert.c:60-142): same audio, and the sink is
+    handed the same input, as on the CPU."""
+    gpu = make_gpu(max_batch=8)
+    got, gtaps = _clients_script(gpu)
+    gpu.close()
+    ora = make_oracle(oracle_lib)
+    want, wtaps = _clients_script(ora)
+    ora.close()
+    assert first_diff(got, want) is None
+    assert sorted(gtaps) == sorted(wtaps) == [2, 3, 4, 5, 6, 7]
+    for f in wtaps:
+        assert wtaps[f].any()
+        assert np.array_equal(gtaps[f], wtaps[f]), f"tapped input differs in fragment {f}"

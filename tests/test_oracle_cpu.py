@@ -124,3 +124,43 @@ def test_bench_parity_golden_matches_oracle(oracle_lib):
     spec.loader.exec_module(mbg)
     want = np.load(os.path.join(GOLDEN, "bench_default_first8.hash.npy"))
     assert np.array_equal(fnv1a_fragments(mbg.render()), want)
+
+
+def test_oracle_xinsert_clients(oracle_lib):
+    """xi_process (src/units/xinsert.c:60-142) in the oracle: what WRITE-only
+    clients produced is added to the unit's output, READ-only clients are
+    handed its input, with no clients it is the bypass."""
+    from audiality2_amd import synth
+    be = make_oracle(oracle_lib)
+    sc = synth.Scene(be, nwaves=1)
+    il, pm, xi = sc.root()
+    sc.add_voices(2, chain="osc-pan", total=64)
+    plain = sc.run(2, batch=2)
+    assert plain.any()
+    be.close()
+    be = make_oracle(oracle_lib)
+    sc = synth.Scene(be, nwaves=1)
+    il, pm, xi = sc.root()
+    sc.add_voices(2, chain="osc-pan", total=64)
+    be.unit_clients(xi, 3)
+    rng = np.random.default_rng(0)
+    x = rng.integers(-1 << 20, 1 << 20, (2, 128)).astype(np.int32)
+
+    def walk(frag):
+        be.fragment(64)
+        be.unit_process(il, 0, 64)
+        for units in sc.leaves:
+            for u in units:
+                be.unit_process(u, 0, 64)
+        be.inline_end(il)
+        be.unit_process(pm, 0, 64)
+        be.unit_inject(xi, 0, x[:, frag * 64:frag * 64 + 30])       # two windows' worth of client output
+        be.unit_inject(xi, 30, x[:, frag * 64 + 30:frag * 64 + 64])
+        be.unit_process(xi, 0, 30)
+        be.unit_process(xi, 30, 34)
+    walk(0)
+    walk(1)
+    out = be.render(128)
+    assert np.array_equal(out, plain + x)
+    assert np.array_equal(np.concatenate([be.unit_tapped(xi, 0), be.unit_tapped(xi, 1)], axis=1), plain)
+    be.close()

@@ -34,7 +34,11 @@ SIZE(A2_unit, A2P_unit); SAME(A2_unit, A2P_unit, next); SAME(A2_unit, A2P_unit, 
 SAME(A2_unit, A2P_unit, ninputs); SAME(A2_unit, A2P_unit, noutputs); SAME(A2_unit, A2P_unit, inputs);
 SAME(A2_unit, A2P_unit, outputs); SAME(A2_unit, A2P_unit, registers); SAME(A2_unit, A2P_unit, coutputs);
 SAME(A2_unit, A2P_unit, Process);
-SAME(A2_xinsert, A2P_xinsert, state); SAME(A2_xinsert, A2P_xinsert, clients);
+SAME(A2_xinsert, A2P_xinsert, state); SAME(A2_xinsert, A2P_xinsert, clients); SAME(A2_xinsert, A2P_xinsert, SetProcess);
+SIZE(A2_xinsert_client, A2P_xinsert_client); SAME(A2_xinsert_client, A2P_xinsert_client, next);
+SAME(A2_xinsert_client, A2P_xinsert_client, callback); SAME(A2_xinsert_client, A2P_xinsert_client, userdata);
+SAME(A2_xinsert_client, A2P_xinsert_client, flags);
+_Static_assert(A2_XI_READ == A2P_XI_READ && A2_XI_WRITE == A2P_XI_WRITE, "xiflags");
 SIZE(A2_unitdesc, A2P_unitdesc); SAME(A2_unitdesc, A2P_unitdesc, name); SAME(A2_unitdesc, A2P_unitdesc, flags);
 SAME(A2_unitdesc, A2P_unitdesc, registers); SAME(A2_unitdesc, A2P_unitdesc, coutputs);
 SAME(A2_unitdesc, A2P_unitdesc, constants); SAME(A2_unitdesc, A2P_unitdesc, mininputs);
