@@ -19,7 +19,7 @@
 // unit kinds: numerically equal to a2amd_unitkind
 enum { A2D_WTOSC = 0, A2D_PANMIX, A2D_FILTER12, A2D_FBDELAY, A2D_INLINE, A2D_XINSERT,
 	A2D_FM1, A2D_FM2, A2D_FM3, A2D_FM4, A2D_FM3P, A2D_FM4P, A2D_FM2R, A2D_FM4R,
-	A2D_DC, A2D_WAVESHAPER, A2D_DCBLOCK, A2D_LIMITER };
+	A2D_DC, A2D_WAVESHAPER, A2D_DCBLOCK, A2D_LIMITER, A2D_XSINK, A2D_XSOURCE };
 #define A2D_IS_FM(k) ((k) >= A2D_FM1 && (k) <= A2D_FM4R)
 
 // wtosc Process variants (the reference swaps u->Process, wtosc.c:433-483)

@@ -1340,6 +1340,14 @@ int a2amd_unit_init(a2amd_ctx *c, uint64_t key, int kind, unsigned flags, int ni
 		if(nin != nout || nin < 1)
 			return c->fail(A2AMD_EINVAL, "xinsert %d->%d", nin, nout);
 		break;
+	  case A2AMD_XSINK:
+		if(nin < 1 || nout != 0)
+			return c->fail(A2AMD_EINVAL, "xsink %d->%d", nin, nout);
+		break;
+	  case A2AMD_XSOURCE:
+		if(nin != 0 || nout < 1)
+			return c->fail(A2AMD_EINVAL, "xsource %d->%d", nin, nout);
+		break;
 	  case A2AMD_INLINE:
 		if(nout < 1)
 			return c->fail(A2AMD_EINVAL, "inline needs outputs");
@@ -1593,6 +1601,8 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 		break;
 	  case A2AMD_INLINE:
 	  case A2AMD_XINSERT:
+	  case A2AMD_XSINK:
+	  case A2AMD_XSOURCE:
 		return c->fail(A2AMD_EINVAL, "unit kind %d has no registers", u.kind);
 	  case A2AMD_DC:
 		if(reg < 0 || reg > 1)
@@ -1792,10 +1802,14 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 
 int a2amd_unit_clients(a2amd_ctx *c, int ui, unsigned mode)
 {
-	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live || c->units[ui].kind != A2AMD_XINSERT)
-		return c->fail(A2AMD_EINVAL, "unit %d is not a live xinsert", ui);
-	if(mode & ~(unsigned)(A2AMD_XIO_TAP | A2AMD_XIO_INJECT))
-		return c->fail(A2AMD_EINVAL, "xinsert client mode %#x", mode);
+	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live ||
+			(c->units[ui].kind != A2AMD_XINSERT && c->units[ui].kind != A2AMD_XSINK &&
+			 c->units[ui].kind != A2AMD_XSOURCE))
+		return c->fail(A2AMD_EINVAL, "unit %d is not a live xinsert / xsink / xsource", ui);
+	if((mode & ~(unsigned)(A2AMD_XIO_TAP | A2AMD_XIO_INJECT)) ||
+			(c->units[ui].kind == A2AMD_XSINK && (mode & A2AMD_XIO_INJECT)) ||
+			(c->units[ui].kind == A2AMD_XSOURCE && (mode & A2AMD_XIO_TAP)))
+		return c->fail(A2AMD_EINVAL, "client mode %#x on unit kind %d", mode, c->units[ui].kind);
 	HUnit &u = c->units[ui];
 	if(mode == u.xio_mode)
 		return A2AMD_OK;
@@ -1833,7 +1847,7 @@ int a2amd_unit_inject(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, co
 		return c->fail(A2AMD_ESTATE, "inject [%u,+%u) outside the open fragment", offset, frames);
 	HUnit &u = c->units[ui];
 	XioSlot &x = c->xio[u.xio];
-	for(int ch = 0; ch < u.nin; ++ch) {
+	for(int ch = 0; ch < u.nout; ++ch) {
 		int32_t *d = x.inj.data() + ((size_t)c->cur_frag * A2AMD_MAXCHANNELS + ch) * A2D_FRAG + offset;
 		for(unsigned k = 0; k < frames; ++k)
 			d[k] = wadd(d[k], bufs[ch][k]);

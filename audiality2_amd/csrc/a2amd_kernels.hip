@@ -549,6 +549,31 @@ DEV void xinsert_process(Ctx &c, uint32_t desc, const int *w, int offset, int fr
 	}
 }
 
+// xsink (xsink.c:27-46): every client is handed the inputs; no outputs
+DEV void xsink_process(Ctx &c, uint32_t desc, const int *w, int offset, int frames)
+{
+	int k = c.lane - offset;
+	if(k < 0 || k >= frames || !w[XW_SLOT] || !(w[XW_MODE] & 1))
+		return;
+	int32_t *tap = c.p->xio + (size_t)(w[XW_SLOT] - 1) * A2D_XIO_SLOT + (size_t)c.frag * 8 * A2D_FRAG + c.lane;
+	for(int ch = 0, n = A2D_NIN(desc); ch < n; ++ch)
+		tap[ch * A2D_FRAG] = c.l->scratch[ch][c.lane];
+}
+
+// xsource (xsource.c:43-137): the sum of what its clients produced, or silence
+DEV void xsource_process(Ctx &c, uint32_t desc, const int *w, int offset, int frames)
+{
+	int k = c.lane - offset;
+	if(k < 0 || k >= frames)
+		return;
+	const int32_t *inj = nullptr;
+	if(w[XW_SLOT] && (w[XW_MODE] & 2))
+		inj = c.p->xio + (size_t)(w[XW_SLOT] - 1) * A2D_XIO_SLOT + A2D_XIO_HALF +
+				(size_t)c.frag * 8 * A2D_FRAG + c.lane;
+	for(int ch = 0, n = A2D_NOUT(desc); ch < n; ++ch)
+		emit(c, desc, ch, inj ? inj[ch * A2D_FRAG] : 0);
+}
+
 // ---------------------------------------------------------------------------
 // dc, dc.c:56-134: a generator; every frame is a closed form of the window
 // ---------------------------------------------------------------------------
@@ -792,7 +817,7 @@ DEV void unit_init(const A2DParams &p, uint32_t desc, int *w, const A2DRec &r)
 	  }
 	  case A2D_INLINE:
 		break;
-	  case A2D_XINSERT:
+	  case A2D_XINSERT: case A2D_XSINK: case A2D_XSOURCE:
 		w[XW_SLOT] = w[XW_MODE] = 0;
 		break;
 	  case A2D_DC: {	// dc_Initialize, dc.c:160-188
@@ -872,7 +897,7 @@ DEV void unit_write(const A2DParams &p, uint32_t desc, int *w, const A2DRec &r)
 		break;
 	  case A2D_INLINE:
 		break;
-	  case A2D_XINSERT:	// a2amd_unit_clients: reg 0 = slot + 1, reg 1 = mode
+	  case A2D_XINSERT: case A2D_XSINK: case A2D_XSOURCE:	// a2amd_unit_clients: reg 0 = slot + 1, reg 1 = mode
 		w[reg ? XW_MODE : XW_SLOT] = v;
 		break;
 	  case A2D_DC:
@@ -938,6 +963,8 @@ DEV void process_window(Ctx &c, const A2DVoice &v, int offset, int frames)
 		  case A2D_FBDELAY: fbd_process(c, desc, w, offset, frames); break;
 		  case A2D_INLINE: inline_process(c, desc, offset, frames); break;
 		  case A2D_XINSERT: xinsert_process(c, desc, w, offset, frames); break;
+		  case A2D_XSINK: xsink_process(c, desc, w, offset, frames); break;
+		  case A2D_XSOURCE: xsource_process(c, desc, w, offset, frames); break;
 		  case A2D_DC: dc_process(c, desc, w, offset, frames); break;
 		  case A2D_WAVESHAPER: waveshaper_process(c, desc, w, offset, frames); break;
 		  case A2D_DCBLOCK: dcb_process(c, desc, w, offset, frames); break;

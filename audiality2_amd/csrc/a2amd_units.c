@@ -54,6 +54,7 @@ typedef struct PENDING
 	A2P_xinsert		*xi;
 	A2P_xinsert_client	*xic;
 	int			uid;
+	const char		*what;		/* for error reports */
 	unsigned		offset, frames;
 } PENDING;
 
@@ -90,9 +91,7 @@ typedef struct XTRA
 	A2P_vmstate	*vms;
 	int		uid;		/* backend unit id, -1 = not forwarded */
 	int		kind;
-	int		follow;		/* backend id of a trailing xinsert to process along */
-	A2P_unit	*follow_unit;	/* ... and the engine's instance of it */
-	unsigned	follow_mode;	/* A2AMD_XIO_*: what that xinsert's clients need */
+	unsigned	client_mode;	/* xinsert / xsink / xsource: A2AMD_XIO_*, what its clients need */
 	int		is_root;
 	A2P_process_cb	orig_process;
 	A2P_wave	*wave;		/* wtosc: the wave it plays (engine object), or NULL */
@@ -103,7 +102,8 @@ _Static_assert(sizeof(A2P_unit) <= 64 && 64 + sizeof(XTRA) <= A2P_BLOCK_SIZE, "X
 
 static inline XTRA *xtra(A2P_unit *u)
 {
-	if(u->descriptor == &a2_inline_unitdesc || u->descriptor == &a2_xinsert_unitdesc)
+	if(u->descriptor == &a2_inline_unitdesc || u->descriptor == &a2_xinsert_unitdesc ||
+			u->descriptor == &a2_xsink_unitdesc || u->descriptor == &a2_xsource_unitdesc)
 		return (XTRA *)((char *)u + A2P_BLOCK_SIZE - sizeof(XTRA));
 	return (XTRA *)((char *)u + 64);
 }
@@ -201,7 +201,6 @@ static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned 
 	x->vms = vms;
 	x->kind = kind;
 	x->uid = -1;
-	x->follow = -1;
 	if(!hs->root_vms)
 		hs->root_vms = vms;
 	x->is_root = vms == hs->root_vms;
@@ -238,11 +237,6 @@ static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned 
 			fprintf(stderr, "a2amd units: cannot instantiate unit kind %d: %s\n", kind,
 					a2amd_last_error(ctx));
 			return 1;	/* the engine reports A2_VOICEINIT and drops the voice */
-		}
-		if(kind == A2AMD_XINSERT && hs->chain_last)
-		{
-			xtra(hs->chain_last)->follow = x->uid;
-			xtra(hs->chain_last)->follow_unit = u;
 		}
 	}
 	hs->chain_last = u;
@@ -297,7 +291,7 @@ static int is_ours(const A2P_unitdesc *d)
 		&a2_inline_unitdesc, &a2_xinsert_unitdesc, &a2_fm1_unitdesc, &a2_fm2_unitdesc,
 		&a2_fm3_unitdesc, &a2_fm4_unitdesc, &a2_fm3p_unitdesc, &a2_fm4p_unitdesc,
 		&a2_fm2r_unitdesc, &a2_fm4r_unitdesc, &a2_dc_unitdesc, &a2_waveshaper_unitdesc,
-		&a2_dcblock_unitdesc, &a2_limiter_unitdesc };
+		&a2_dcblock_unitdesc, &a2_limiter_unitdesc, &a2_xsink_unitdesc, &a2_xsource_unitdesc };
 	unsigned i;
 	for(i = 0; i < sizeof(ours) / sizeof(ours[0]); ++i)
 		if(d == ours[i])
@@ -342,11 +336,20 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 	HOSTSTATE *hs = x->hs;
 	A2P_xinsert_client *xic;
 	A2P_unit *xu = &xi->header;
+	const int nch = x->kind == A2AMD_XSOURCE ? xu->noutputs : xu->ninputs;
+	const char *what = x->kind == A2AMD_XSOURCE ? "xsource client callback" :
+			x->kind == A2AMD_XSINK ? "xsink client callback" : "xinsert client callback";
 	unsigned mode = 0;
 	int rc, i;
 	unsigned s;
+	/* xsink hands every client its inputs (xsink.c:41-44), xsource adds up every
+	 * client's output (xsource.c:69-77); xinsert looks at the client's flags */
 	for(xic = xi->clients; xic; xic = xic->next)
-		if((xic->flags & A2P_XI_READ) && (xic->flags & A2P_XI_WRITE))
+		if(x->kind == A2AMD_XSINK)
+			mode |= A2AMD_XIO_TAP;
+		else if(x->kind == A2AMD_XSOURCE)
+			mode |= A2AMD_XIO_INJECT;
+		else if((xic->flags & A2P_XI_READ) && (xic->flags & A2P_XI_WRITE))
 		{
 			fprintf(stderr, "a2amd units: an insert client (a2_InsertCallback) was attached to a voice "
 					"other than the root voice: its audio is on the GPU (sink and source "
@@ -355,52 +358,54 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 		}
 		else
 			mode |= (xic->flags & A2P_XI_WRITE) ? A2AMD_XIO_INJECT : A2AMD_XIO_TAP;
-	if(mode != x->follow_mode)
+	if(mode != x->client_mode)
 	{
-		if((rc = a2amd_unit_clients(hs->ctx, x->follow, mode)))
+		if((rc = a2amd_unit_clients(hs->ctx, x->uid, mode)))
 			die(hs, "a2amd_unit_clients", rc);
-		x->follow_mode = mode;
+		x->client_mode = mode;
 	}
 	if(mode & A2AMD_XIO_INJECT)
 	{
 		/* (the reference hands WRITE-only clients uninitialised stack arrays,
-		 * xinsert.c:66, and mixes all of them into the output, :113-118; ours
-		 * are cleared, so a client that fills only some channels - the source
-		 * streams do - adds silence to the others, not stack contents) */
+		 * xinsert.c:66, xsource.c:50, and mixes all of them into the output,
+		 * xinsert.c:113-118; ours are cleared, so a client that fills only some
+		 * channels - the source streams do - adds silence to the others, not
+		 * stack contents) */
 		int32_t sum[A2AMD_MAXCHANNELS][A2AMD_MAXFRAG], tmp[A2AMD_MAXCHANNELS][A2AMD_MAXFRAG];
 		int32_t *bufp[A2AMD_MAXCHANNELS];
 		const int32_t *sump[A2AMD_MAXCHANNELS];
 		memset(sum, 0, sizeof(sum));
 		for(xic = xi->clients; xic; xic = xic->next)
 		{
-			if(!(xic->flags & A2P_XI_WRITE))
+			if(x->kind == A2AMD_XINSERT && !(xic->flags & A2P_XI_WRITE))
 				continue;
 			memset(tmp, 0, sizeof(tmp));
-			for(i = 0; i < xu->ninputs; ++i)
+			for(i = 0; i < nch; ++i)
 				bufp[i] = tmp[i];
-			if((rc = xic->callback(bufp, xu->ninputs, frames, xic->userdata)))
-				client_error(xi, rc, "xinsert client callback");
-			for(i = 0; i < xu->ninputs; ++i)
+			if((rc = xic->callback(bufp, nch, frames, xic->userdata)))
+				client_error(xi, rc, what);
+			for(i = 0; i < nch; ++i)
 				for(s = 0; s < frames; ++s)
 					sum[i][s] = (int32_t)((uint32_t)sum[i][s] + (uint32_t)tmp[i][s]);
 		}
-		for(i = 0; i < xu->ninputs; ++i)
+		for(i = 0; i < nch; ++i)
 			sump[i] = sum[i];
-		if((rc = a2amd_unit_inject(hs->ctx, x->follow, offset - hs->base, frames, sump)))
+		if((rc = a2amd_unit_inject(hs->ctx, x->uid, offset - hs->base, frames, sump)))
 			die(hs, "a2amd_unit_inject", rc);
 	}
 	if(mode & A2AMD_XIO_TAP)
 		for(xic = xi->clients; xic; xic = xic->next)
 		{
 			PENDING *p;
-			if(xic->flags & A2P_XI_WRITE)
+			if(x->kind == A2AMD_XINSERT && (xic->flags & A2P_XI_WRITE))
 				continue;
 			if(hs->npend >= MAXPEND)
 				die(hs, "more sink client windows in one fragment than the drop-in holds", -MAXPEND);
 			p = &hs->pend[hs->npend++];
 			p->xi = xi;
 			p->xic = xic;
-			p->uid = x->follow;
+			p->uid = x->uid;
+			p->what = what;
 			p->offset = offset - hs->base;
 			p->frames = frames;
 		}
@@ -427,7 +432,7 @@ static void deliver_pending(HOSTSTATE *hs)
 		for(i = 0; i < n; ++i)
 			bufp[i] = (int32_t *)bufs[i] + p->offset;
 		if((rc = c->callback(bufp, n, p->frames, c->userdata)))
-			client_error(p->xi, rc, "xinsert client callback");
+			client_error(p->xi, rc, p->what);
 	}
 	hs->npend = 0;
 	for(k = 0; k < hs->nzombies; ++k)
@@ -463,15 +468,6 @@ static void forward_process(XTRA *x, unsigned offset, unsigned frames)
 		die(hs, "a2amd_unit_process", rc);
 	if(noise != before)
 		a2_SetStateProperty(hs->cfg->interface, A2P_PNOISESEED, (int)noise);
-	if(x->follow >= 0)
-	{
-		/* an xinsert on a voice other than the root is rendered on the GPU:
-		 * the bypass it is without clients (xinsert.c:145-161), or ... */
-		if(((A2P_xinsert *)x->follow_unit)->clients || x->follow_mode)
-			serve_clients(x, (A2P_xinsert *)x->follow_unit, offset, frames);
-		if((rc = a2amd_unit_process(hs->ctx, x->follow, offset - hs->base, frames, NULL)))
-			die(hs, "a2amd_unit_process (xinsert)", rc);
-	}
 }
 
 static void amd_process(A2P_unit *u, unsigned offset, unsigned frames)
@@ -693,8 +689,6 @@ static void wrap_close(const char *sym, void *statedata)
 
 static int inl_open(A2P_config *cfg, void **sd) { return wrap_open("a2_inline_unitdesc", cfg, sd); }
 static void inl_close(void *sd) { wrap_close("a2_inline_unitdesc", sd); }
-static int xi_open(A2P_config *cfg, void **sd) { return wrap_open("a2_xinsert_unitdesc", cfg, sd); }
-static void xi_close(void *sd) { wrap_close("a2_xinsert_unitdesc", sd); }
 
 static int inl_init(A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned flags)
 {
@@ -717,43 +711,53 @@ static void inl_deinit(A2P_unit *u)
 		od->Deinitialize(u);
 }
 
-/* On a voice other than the root the engine's xi_Process* (xinsert.c:145-161,
- * :60-142) would shuffle the engine's unused CPU buffers and hand THOSE to the
- * clients: its Process is parked, also when the client API re-installs it. */
-static void xi_parked_process(A2P_unit *u, unsigned offset, unsigned frames)
+/* ---- xinsert, xsink, xsource (src/units/xinsert.c, xsink.c, xsource.c) ----------
+ * The engine's instances keep the A2_xinsert struct the client API works on
+ * (a2_XinsertAddClient / a2_XinsertRemoveClient, xinsertapi.c:72-157) and, on
+ * the root voice, their own Process (the root's audio is back on the CPU when
+ * it runs).  Elsewhere their Process would shuffle the engine's unused CPU
+ * buffers and hand THOSE to the clients, so ours is installed instead - also
+ * when the client API re-installs one (A2_xinsert.SetProcess). */
+static void amd_x_process(A2P_unit *u, unsigned offset, unsigned frames)
 {
-	(void)u; (void)offset; (void)frames;
+	XTRA *x = xtra(u);
+	HOSTSTATE *hs = x->hs;
+	int rc;
+	if(!x->chain_checked)
+	{
+		x->chain_checked = 1;
+		check_chain_behind(u);
+	}
+	if(((A2P_xinsert *)u)->clients || x->client_mode)
+		serve_clients(x, (A2P_xinsert *)u, offset, frames);
+	if((rc = a2amd_unit_process(hs->ctx, x->uid, offset - hs->base, frames, NULL)))
+		die(hs, "a2amd_unit_process", rc);
 }
 
-static void xi_parked_setprocess(A2P_unit *u)
+static void amd_x_setprocess(A2P_unit *u)
 {
-	u->Process = xi_parked_process;
+	u->Process = amd_x_process;
 }
 
-static int xi_init(A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned flags)
+static int x_init(const char *sym, int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned flags)
 {
 	WRAPSTATE *ws = (WRAPSTATE *)sd;
-	/* The engine's xinsert keeps its own Process on the root voice (its client
-	 * API swaps it at will, xinsert.c:164-193; the root's audio is back on the
-	 * CPU when it runs).  Elsewhere the backend gets the unit's windows from the
-	 * unit ahead of it in the chain (XTRA.follow), which also serves the
-	 * clients (serve_clients). */
-	int rc = orig_desc("a2_xinsert_unitdesc")->Initialize(u, vms, ws->orig_sd, flags);
+	int rc = orig_desc(sym)->Initialize(u, vms, ws->orig_sd, flags);
 	if(rc)
 		return rc;
-	if((rc = amd_init(A2AMD_XINSERT, u, vms, ws->hs, flags, 1)))
+	if((rc = amd_init(kind, u, vms, ws->hs, flags, 1)))
 		return rc;
-	if(!xtra(u)->is_root)
+	if(xtra(u)->uid >= 0)
 	{
-		((A2P_xinsert *)u)->SetProcess = xi_parked_setprocess;
-		xi_parked_setprocess(u);
+		((A2P_xinsert *)u)->SetProcess = amd_x_setprocess;
+		amd_x_setprocess(u);
 	}
 	return 0;
 }
 
-static void xi_deinit(A2P_unit *u)
+static void x_deinit(const char *sym, A2P_unit *u)
 {
-	const A2P_unitdesc *od = orig_desc("a2_xinsert_unitdesc");
+	const A2P_unitdesc *od = orig_desc(sym);
 	HOSTSTATE *hs = xtra(u)->hs;
 	int k, n = 0;
 	/* Windows its READ clients are still owed: the voice dies in the middle of a
@@ -772,7 +776,7 @@ static void xi_deinit(A2P_unit *u)
 		if(!z)
 			die(hs, "out of memory", -1);
 		*z = *xi;
-		z->SetProcess = xi_parked_setprocess;
+		z->SetProcess = amd_x_setprocess;
 		for(c = z->clients; c; c = c->next)
 			c->unit = z;
 		xi->clients = NULL;
@@ -794,7 +798,21 @@ static void xi_deinit(A2P_unit *u)
 		od->Deinitialize(u);
 }
 
+#define X_UNIT(KIND, name) \
+	static int name##_open(A2P_config *cfg, void **sd) { return wrap_open("a2_" #name "_unitdesc", cfg, sd); } \
+	static void name##_close(void *sd) { wrap_close("a2_" #name "_unitdesc", sd); } \
+	static int name##_init(A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned flags) \
+		{ return x_init("a2_" #name "_unitdesc", KIND, u, vms, sd, flags); } \
+	static void name##_deinit(A2P_unit *u) { x_deinit("a2_" #name "_unitdesc", u); }
+X_UNIT(A2AMD_XINSERT, xinsert)
+X_UNIT(A2AMD_XSINK, xsink)
+X_UNIT(A2AMD_XSOURCE, xsource)
+
 const A2P_unitdesc a2_inline_unitdesc = { "inline", 0, NULL, NULL, NULL, 0, 0, 1, A2AMD_MAXCHANNELS,
 	A2P_BLOCK_SIZE, inl_init, inl_deinit, inl_open, inl_close };
 const A2P_unitdesc a2_xinsert_unitdesc = { "xinsert", A2P_MATCHIO | A2P_XINSERT, NULL, NULL, NULL,
-	1, A2AMD_MAXCHANNELS, 1, A2AMD_MAXCHANNELS, A2P_BLOCK_SIZE, xi_init, xi_deinit, xi_open, xi_close };
+	1, A2AMD_MAXCHANNELS, 1, A2AMD_MAXCHANNELS, A2P_BLOCK_SIZE, xinsert_init, xinsert_deinit, xinsert_open, xinsert_close };
+const A2P_unitdesc a2_xsink_unitdesc = { "xsink", A2P_XINSERT, NULL, NULL, NULL,
+	1, A2AMD_MAXCHANNELS, 0, 0, A2P_BLOCK_SIZE, xsink_init, xsink_deinit, xsink_open, xsink_close };
+const A2P_unitdesc a2_xsource_unitdesc = { "xsource", A2P_XINSERT, NULL, NULL, NULL,
+	0, 0, 1, A2AMD_MAXCHANNELS, A2P_BLOCK_SIZE, xsource_init, xsource_deinit, xsource_open, xsource_close };

@@ -70,7 +70,7 @@ typedef enum a2amd_unitkind {
 	A2AMD_FILTER12,      /* src/units/filter12.c regs: cutoff q lp bp hp      */
 	A2AMD_FBDELAY,       /* src/units/fbdelay.c  regs: fbdelay ldelay rdelay drygain fbgain lgain rgain */
 	A2AMD_INLINE,        /* src/units/inline.c + src/core.c:1763-1776         */
-	A2AMD_XINSERT,       /* src/units/xinsert.c:145-161 (bypass only)         */
+	A2AMD_XINSERT,       /* src/units/xinsert.c (bypass; clients: a2amd_unit_clients) */
 	/* the FM oscillators of src/units/fm.c.  regs, in
 	 * order: phase, then p a fb / p1 a1 fb1 / p2 a2 fb2 / p3 a3 fb3 for as
 	 * many operators as the unit has (fm.c:54-79). */
@@ -87,6 +87,10 @@ typedef enum a2amd_unitkind {
 	A2AMD_WAVESHAPER,    /* src/units/waveshaper.c regs: amount                        */
 	A2AMD_DCBLOCK,       /* src/units/dcblock.c    regs: cutoff                        */
 	A2AMD_LIMITER,       /* src/units/limiter.c    regs: release threshold             */
+	/* the other two hosts of stream / callback clients
+	 * (a2amd_unit_clients): inputs only, outputs only */
+	A2AMD_XSINK,         /* src/units/xsink.c:27-46                                    */
+	A2AMD_XSOURCE,       /* src/units/xsource.c:27-137                                 */
 	A2AMD_NKINDS
 } a2amd_unitkind;
 
@@ -179,8 +183,10 @@ int  a2amd_unit_write(a2amd_ctx *ctx, int unit, int reg, int value,
  * correctly. */
 int  a2amd_unit_process(a2amd_ctx *ctx, int unit, unsigned offset,
 		unsigned frames, uint32_t *noisestate);
-/* Clients of an A2AMD_XINSERT unit (a2_XinsertAddClient, src/xinsertapi.c:72-111;
- * served by xi_process, src/units/xinsert.c:60-142).  The client callbacks stay
+/* Clients of an A2AMD_XINSERT / A2AMD_XSINK / A2AMD_XSOURCE unit
+ * (a2_XinsertAddClient, src/xinsertapi.c:72-111; served by xi_process,
+ * src/units/xinsert.c:60-142, xsink_Process, xsink.c:27-46, xsrc_process,
+ * xsource.c:43-78).  The client callbacks stay
  * with the host; 'mode' says what the unit does for them from its next window
  * on: A2AMD_XIO_TAP leaves every window's input where a2amd_unit_tapped() finds
  * it after a READBACK render (what READ-only clients are handed),

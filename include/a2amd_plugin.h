@@ -157,6 +157,7 @@ typedef struct A2P_xinsert
 
 extern const A2P_unitdesc a2_wtosc_unitdesc, a2_panmix_unitdesc, a2_filter12_unitdesc,
 		a2_fbdelay_unitdesc, a2_inline_unitdesc, a2_xinsert_unitdesc,
+		a2_xsink_unitdesc, a2_xsource_unitdesc,
 		a2_fm1_unitdesc, a2_fm2_unitdesc, a2_fm3_unitdesc, a2_fm4_unitdesc,
 		a2_fm3p_unitdesc, a2_fm4p_unitdesc, a2_fm2r_unitdesc, a2_fm4r_unitdesc,
 		a2_dc_unitdesc, a2_waveshaper_unitdesc, a2_dcblock_unitdesc, a2_limiter_unitdesc;

@@ -797,6 +797,14 @@ int a2o_unit_init(a2o_ctx *c, uint64_t key, int kind, unsigned flags,
 	  case A2AMD_INLINE:	/* a2i_Initialize, inline.c:26-39 */
 	  case A2AMD_XINSERT:	/* xi_Initialize, xinsert.c:196-212 */
 		break;
+	  case A2AMD_XSINK:	/* xsink_Initialize, xsink.c:56-71; 1..8 inputs, no outputs (:91-112) */
+		if(nin < 1 || nout != 0)
+			return fail(c, A2AMD_EINVAL, "xsink %d->%d", nin, nout);
+		break;
+	  case A2AMD_XSOURCE:	/* xsrc_Initialize, xsource.c:140-156; no inputs (:171-192) */
+		if(nin != 0 || nout < 1)
+			return fail(c, A2AMD_EINVAL, "xsource %d->%d", nin, nout);
+		break;
 	  case A2AMD_DC:	/* dc_Initialize, dc.c:160-188 */
 		if(nin != 0 || nout < 1 || nout > 2)
 			return fail(c, A2AMD_EINVAL, "dc %d->%d", nin, nout);
@@ -1777,10 +1785,12 @@ static int xi_process(a2o_ctx *c, a2o_unit *u, int32_t **in, int32_t **out,
 int a2o_unit_clients(a2o_ctx *c, int id, unsigned mode)
 {
 	a2o_unit *u = get_unit(c, id);
-	if(!u || u->kind != A2AMD_XINSERT)
-		return fail(c, A2AMD_EINVAL, "unit %d is not a live xinsert", id);
-	if(mode & ~(unsigned)(A2AMD_XIO_TAP | A2AMD_XIO_INJECT))
-		return fail(c, A2AMD_EINVAL, "xinsert client mode %#x", mode);
+	if(!u || (u->kind != A2AMD_XINSERT && u->kind != A2AMD_XSINK && u->kind != A2AMD_XSOURCE))
+		return fail(c, A2AMD_EINVAL, "unit %d is not a live xinsert / xsink / xsource", id);
+	if((mode & ~(unsigned)(A2AMD_XIO_TAP | A2AMD_XIO_INJECT)) ||
+			(u->kind == A2AMD_XSINK && (mode & A2AMD_XIO_INJECT)) ||
+			(u->kind == A2AMD_XSOURCE && (mode & A2AMD_XIO_TAP)))
+		return fail(c, A2AMD_EINVAL, "client mode %#x on unit kind %d", mode, u->kind);
 	if(mode && !u->tap && !(u->tap = (int32_t *)calloc((size_t)256 * MAXCH * MAXFRAG, sizeof(int32_t))))
 		return A2AMD_ENOMEM;
 	if(!(mode & A2AMD_XIO_INJECT))
@@ -1800,7 +1810,7 @@ int a2o_unit_inject(a2o_ctx *c, int id, unsigned offset, unsigned frames,
 		return fail(c, A2AMD_EINVAL, "unit %d takes no client output", id);
 	if(!c->frag_open || !frames || offset + frames > c->frag_frames)
 		return fail(c, A2AMD_ESTATE, "inject [%u,+%u) outside fragment", offset, frames);
-	for(i = 0; i < u->nin; ++i)
+	for(i = 0; i < u->nout; ++i)
 		for(s = 0; s < frames; ++s)
 			u->inj[i][offset + s] += bufs[i][s];
 	return A2AMD_OK;
@@ -1914,6 +1924,35 @@ int a2o_unit_process(a2o_ctx *c, int id, unsigned offset, unsigned frames,
 					out[ch][s] = in[ch][s];
 		}
 		break;
+	  case A2AMD_XSINK:	/* xsink_Process, xsink.c:27-46: every client gets the inputs */
+		if(u->xio_mode & A2AMD_XIO_TAP)
+		{
+			if(c->batch_frags > 256)
+				return fail(c, A2AMD_ESTATE, "more than 256 fragments in a "
+						"batch with xsink clients");
+			for(ch = 0; ch < u->nin; ++ch)
+				memcpy(u->tap + ((size_t)(c->batch_frags - 1) * MAXCH + ch) * MAXFRAG + offset,
+						in[ch] + offset, frames * sizeof(int32_t));
+		}
+		break;
+	  case A2AMD_XSOURCE:
+	  {
+		/* xsrc_ProcessAdd, xsource.c:84-87 via :43-78: out += every client's
+		 * buffers.  Replacing: one client writes the output itself
+		 * (xsrc_ProcessSingle, :90-103); none - silence (xsrc_ProcessNil,
+		 * :105-112).  (With several clients in replacing mode the reference
+		 * adds an uninitialised array per client, :56-59 with :74-75; here
+		 * they add up as in adding mode.) */
+		unsigned s;
+		for(ch = 0; ch < u->nout; ++ch)
+			for(s = offset; s < offset + frames; ++s)
+			{
+				int32_t x = (u->xio_mode & A2AMD_XIO_INJECT) ? u->inj[ch][s] : 0;
+				u->inj[ch][s] = 0;
+				out[ch][s] = add ? (int32_t)((uint32_t)out[ch][s] + (uint32_t)x) : x;
+			}
+		break;
+	  }
 	  case A2AMD_DC:
 		dc_process(u, out, offset, frames, u->nout, add);
 		break;

@@ -16,6 +16,7 @@
 #include "audiality2.h"
 #include "a2_drivers.h"
 #include "a2_vm.h"
+#include "a2_units.h"
 
 
 /*
@@ -72,6 +73,46 @@ static A2_errors source_cb(int32_t **buffers, unsigned nbuffers, unsigned frames
 	return A2_OK;
 }
 
+/* A2REF_FOREIGN=1: the application registers a unit of its own
+ * (a2_RegisterUnit, a2_units.h:327) before the script is compiled: "thru", 1-2
+ * channels, copies (or adds) its inputs to its outputs. */
+static void thru_process(A2_unit *u, unsigned offset, unsigned frames)
+{
+	unsigned c, s;
+	for(c = 0; c < u->noutputs; ++c)
+		for(s = offset; s < offset + frames; ++s)
+			u->outputs[c][s] = u->inputs[c][s];
+}
+static void thru_process_add(A2_unit *u, unsigned offset, unsigned frames)
+{
+	unsigned c, s;
+	for(c = 0; c < u->noutputs; ++c)
+		for(s = offset; s < offset + frames; ++s)
+			u->outputs[c][s] += u->inputs[c][s];
+}
+static A2_errors thru_init(A2_unit *u, A2_vmstate *vms, void *statedata, unsigned flags)
+{
+	u->Process = (flags & A2_PROCADD) ? thru_process_add : thru_process;
+	return A2_OK;
+}
+static const A2_unitdesc thru_unitdesc = { "thru", A2_MATCHIO, NULL, NULL, NULL, 1, 2, 1, 2,
+		sizeof(A2_unit), thru_init, NULL, NULL, NULL };
+/* ... and "tone", a source: no inputs, a fixed sawtooth on 1-2 outputs */
+static void tone_process(A2_unit *u, unsigned offset, unsigned frames)
+{
+	unsigned c, s;
+	for(c = 0; c < u->noutputs; ++c)
+		for(s = offset; s < offset + frames; ++s)
+			u->outputs[c][s] = (int)((s * 65536u) & 0x3fffff) - 0x200000;
+}
+static A2_errors tone_init(A2_unit *u, A2_vmstate *vms, void *statedata, unsigned flags)
+{
+	u->Process = tone_process;
+	return A2_OK;
+}
+static const A2_unitdesc tone_unitdesc = { "tone", 0, NULL, NULL, NULL, 0, 0, 1, 2,
+		sizeof(A2_unit), tone_init, NULL, NULL, NULL };
+
 int main(int argc, const char *argv[])
 {
 	int frames, buffer, rate, channels, nargs, pargs[A2_MAXARGS], k, done = 0, c;
@@ -118,6 +159,13 @@ int main(int argc, const char *argv[])
 		fprintf(stderr, "a2_Open failed: %s\n", a2_ErrorString(a2_LastError()));
 		return 1;
 	}
+	if(getenv("A2REF_FOREIGN") && ((k = a2_RegisterUnit(i, &thru_unitdesc)) < 0 ||
+			a2_Export(i, A2_ROOTBANK, k, NULL) || (k = a2_RegisterUnit(i, &tone_unitdesc)) < 0 ||
+			a2_Export(i, A2_ROOTBANK, k, NULL)))	/* (as a2_Open does for its own, audiality2.c:256-262) */
+	{
+		fprintf(stderr, "a2_RegisterUnit failed: %s\n", a2_ErrorString(a2_LastError()));
+		return 1;
+	}
 	if((bank = a2_Load(i, argv[1], 0)) < 0 || (prog = a2_Get(i, bank, argv[2])) < 0)
 	{
 		fprintf(stderr, "cannot load %s / %s\n", argv[1], argv[2]);
@@ -145,14 +193,17 @@ int main(int argc, const char *argv[])
 	}
 	if(getenv("A2REF_INSERT") && a2_InsertCallback(i, vh, source_cb, NULL) < 0)
 		return 1;
-	/* A2REF_STREAMS=1: the buffered variants (a2_OpenSource / a2_OpenSink,
-	 * audiality2.h.cmake:561-577): a source stream feeding channel 1 of the
-	 * voice, written ahead of every a2_Run(), and a sink stream on channel 0,
-	 * drained after it. */
-	if(getenv("A2REF_STREAMS"))
+	/* A2REF_SRCSTREAM=<channel> / A2REF_SINKSTREAM=<channel>: the buffered
+	 * variants (a2_OpenSource / a2_OpenSink, audiality2.h.cmake:561-577): a
+	 * source stream feeding that channel of the voice, written ahead of every
+	 * a2_Run(), and a sink stream, drained after it. */
 	{
-		if((srcstream = a2_OpenSource(i, vh, 1, 4 * buffer, 0)) < 0 ||
-				(sinkstream = a2_OpenSink(i, vh, 0, 4 * buffer, 0)) < 0)
+		/* A2REF_STREAMS=1 = A2REF_SRCSTREAM=1 A2REF_SINKSTREAM=0 (the channels) */
+		const char *both = getenv("A2REF_STREAMS");
+		const char *src = getenv("A2REF_SRCSTREAM") ? getenv("A2REF_SRCSTREAM") : both ? "1" : NULL;
+		const char *snk = getenv("A2REF_SINKSTREAM") ? getenv("A2REF_SINKSTREAM") : both ? "0" : NULL;
+		if((src && (srcstream = a2_OpenSource(i, vh, atoi(src), 4 * buffer, 0)) < 0) ||
+				(snk && (sinkstream = a2_OpenSink(i, vh, atoi(snk), 4 * buffer, 0)) < 0))
 		{
 			fprintf(stderr, "cannot open streams: %s\n", a2_ErrorString(a2_LastError()));
 			return 1;

@@ -109,7 +109,11 @@ def test_dropin_refuses_mixed_chains(tmp_path):
     silence: the drop-in aborts with a message instead (no silent fallback); a
     voice that *starts* in a CPU unit is refused at instantiation."""
     need_ref()
-    env = dict(os.environ, LD_PRELOAD=UNITS_SO)
+    env = dict(os.environ, LD_PRELOAD=UNITS_SO, A2REF_FOREIGN="1")
+    for script in ("mixed", "mixedhead"):   # (both fine on the CPU)
+        subprocess.run([REF_RENDER, f"{A2S}/{script}.a2s", "Main", "640", "64", "48000", "2", str(tmp_path / "c.pcm"), "0.1"],
+                       env=dict(os.environ, A2REF_FOREIGN="1"), cwd=A2S, check=True, timeout=120)
+        assert np.fromfile(tmp_path / "c.pcm", dtype="<i4").any()
     r = subprocess.run([REF_RENDER, f"{A2S}/mixed.a2s", "Main", "640", "64", "48000", "2", str(tmp_path / "m.pcm"), "0.1"],
                        env=env, cwd=A2S, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "mixed CPU/GPU chains are not supported" in r.stderr, r.stderr[-500:]
@@ -201,3 +205,31 @@ def test_engine_with_dropin_units_matches_reference_run(tmp_path, name, args, fr
     assert outs[0].any()
     bad = np.nonzero(outs[0] != outs[1])[0]
     assert len(bad) == 0, f"{len(bad)} samples differ, first at frame {bad[0] // 2 if len(bad) else -1}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("program,env", [
+    ("Player", {"A2REF_SOURCE": "1"}), ("Player", {"A2REF_SRCSTREAM": "0"}), ("Player2", {"A2REF_SOURCE": "1"}),
+    ("Player", {}), ("Capture", {"A2REF_SINK": "1"}), ("Capture", {"A2REF_SINKSTREAM": "0"}),
+    ("Monitor", {"A2REF_SINK": "1"}), ("Monitor", {"A2REF_SINKSTREAM": "1", "A2REF_SINK": "1"}),
+    ("Monitor", {"A2REF_SINK": "1", "A2REF_KILL": "4800"}), ("Player2", {"A2REF_SOURCE": "1", "A2REF_KILL": "4800"})])
+def test_dropin_xsource_and_xsink_voices(tmp_path, program, env):
+    """The voice shapes of the reference's own stream tests (test/streamtest.c,
+    test/streamstress.c): 'xsource; panmix' fed by the application through a
+    callback or a stream, 'inline; xsink' handing it what plays underneath."""
+    need_ref()
+    res = []
+    for preload in (False, True):
+        out = tmp_path / f"x{int(preload)}.pcm"
+        e = dict(os.environ, **env)
+        if preload:
+            e["LD_PRELOAD"] = UNITS_SO
+        r = subprocess.run([REF_RENDER, f"{A2S}/streams.a2s", program, "9600", "64", "48000", "2", str(out), "0.3"],
+                           env=e, cwd=A2S, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-500:]
+        res.append(([ln for ln in r.stdout.splitlines() if ln.startswith("sink ")], np.fromfile(out, dtype="<i4")))
+    sinks = len([k for k in env if "SINK" in k])
+    assert len(res[0][0]) == sinks and not any(" frames 0 " in ln for ln in res[0][0])
+    assert res[0][0] == res[1][0]
+    assert res[0][1].any() == (program != "Capture" and bool(env))
+    assert np.array_equal(res[0][1], res[1][1])

@@ -454,3 +454,73 @@ def test_xinsert_clients_tap_and_inject(oracle_lib):
     for f in wtaps:
         assert wtaps[f].any()
         assert np.array_equal(gtaps[f], wtaps[f]), f"tapped input differs in fragment {f}"
+
+
+def _xio_voices_script(be, fragments=9, batch=4, seed=3):
+    """'xsource; panmix' and 'wtosc; xsink; panmix' leaves (the voice shapes of
+    test/data/testprograms.a2s StreamVoice / CaptureVoice) plus an adding
+    xsource behind an oscillator, clients coming and going."""
+    K_XSINK, K_XSOURCE = 18, 19
+    rng = np.random.default_rng(seed)
+    sc = synth.Scene(be, nwaves=2)
+    sc.root()
+    sc.add_voices(2, chain="osc-pan", total=64)
+    ka, kb, kc = sc._key(), sc._key(), sc._key()
+    va = [be.unit_init(ka, K_XSOURCE, 0, 0, 1, 0), be.unit_init(ka, synth.K_PANMIX, synth.PROCADD, 1, 2, 1)]
+    vb = [be.unit_init(kb, synth.K_WTOSC, 0, 0, 1, 0), be.unit_init(kb, K_XSINK, 0, 1, 0, 0),
+          be.unit_init(kb, synth.K_PANMIX, synth.PROCADD, 1, 2, 1)]
+    vc = [be.unit_init(kc, synth.K_WTOSC, 0, 0, 1, 0), be.unit_init(kc, K_XSOURCE, synth.PROCADD, 0, 1, 0),
+          be.unit_init(kc, synth.K_PANMIX, synth.PROCADD, 1, 2, 1)]
+    for v in (vb, vc):
+        be.unit_write(v[0], 0, sc.wave_ids[0])
+        be.unit_write(v[0], 1, synth.fix(-0.3))
+        be.unit_write(v[0], 2, synth.fix(0.2))
+    chunks, taps, pending = [], {}, []
+    for frag in range(fragments):
+        be.fragment(64)
+        be.unit_process(sc.rootv[0], 0, 64)
+        for units in sc.leaves:
+            for u in units:
+                be.unit_process(u, 0, 64)
+        if frag == 1:
+            be.unit_clients(va[0], 2)
+            be.unit_clients(vb[1], 1)
+        if frag == 3:
+            be.unit_clients(vc[1], 2)
+        if frag == 6:
+            be.unit_clients(va[0], 0)
+            be.unit_clients(vb[1], 0)
+        cuts = [0, 64] if frag % 2 else [0, 13, 64]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if 1 <= frag < 6:
+                be.unit_inject(va[0], a, rng.integers(-1 << 22, 1 << 22, (1, b - a)))
+            if frag >= 3:
+                be.unit_inject(vc[1], a, rng.integers(-1 << 22, 1 << 22, (1, b - a)))
+            for v in (va, vb, vc):
+                for u in v:
+                    be.unit_process(u, a, b - a)
+        be.inline_end(sc.rootv[0])
+        be.unit_process(sc.rootv[1], 0, 64)
+        be.unit_process(sc.rootv[2], 0, 64)
+        if 1 <= frag < 6:
+            pending.append(frag)
+        if frag % batch == batch - 1 or frag == fragments - 1:
+            first = frag - frag % batch
+            chunks.append(be.render(batch * 64))
+            for f in pending:
+                taps[f] = be.unit_tapped(vb[1], f - first)
+            pending = []
+    return np.concatenate(chunks, axis=1), taps
+
+
+def test_xsource_and_xsink_units(oracle_lib):
+    gpu = make_gpu(max_batch=4)
+    got, gtaps = _xio_voices_script(gpu)
+    gpu.close()
+    ora = make_oracle(oracle_lib)
+    want, wtaps = _xio_voices_script(ora)
+    ora.close()
+    assert want.any() and first_diff(got, want) is None
+    assert sorted(gtaps) == sorted(wtaps) == [1, 2, 3, 4, 5]
+    for f in wtaps:
+        assert wtaps[f].any() and np.array_equal(gtaps[f], wtaps[f]), f"tapped input differs in fragment {f}"

@@ -27,6 +27,8 @@ SRC = r'''
 #define a2_fbdelay_unitdesc p_fbd
 #define a2_inline_unitdesc p_inl
 #define a2_xinsert_unitdesc p_xi
+#define a2_xsink_unitdesc p_xsink
+#define a2_xsource_unitdesc p_xsrc
 #include "a2amd_plugin.h"
 #define SAME(A, B, m) _Static_assert(offsetof(A, m) == offsetof(B, m), #m)
 #define SIZE(A, B) _Static_assert(sizeof(A) == sizeof(B), #A)
