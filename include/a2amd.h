@@ -24,6 +24,11 @@
  *   A2_unit.Process         include/a2_units.h:176       a2amd_unit_process
  *        (called from a2_VoiceProcess, src/core.c:1875)
  *   a2_inline_Process[Add]  src/core.c:1763-1776         a2amd_unit_process + a2amd_inline_end
+ *   a2_XinsertAddClient / a2_XinsertRemoveClient         a2amd_unit_clients
+ *        src/xinsertapi.c:72-157
+ *   xi_process, client loop src/units/xinsert.c:95-119   a2amd_unit_inject (WRITE clients' output)
+ *        xsrc_process       src/units/xsource.c:69-77    a2amd_unit_tapped (READ clients' input)
+ *        xsink_Process      src/units/xsink.c:41-44
  *   a2_GetWave/A2_wave      include/a2_waves.h:88-103    a2amd_wave_upload / a2amd_wave_drop
  *   a2_AudioCallback fragment loop src/core.c:1964-1973  a2amd_fragment
  *   a2_ProcessMaster        src/core.c:1900-1907         a2amd_render (master bus -> caller)
