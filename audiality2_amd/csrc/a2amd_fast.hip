@@ -49,9 +49,11 @@ DEV int hermite4(int dm, int d0, int d1, int d2, int frac)
 	int c = (d1 - dm) >> 1;
 	int a = (3 * (d0 - d1) + d2 - dm) >> 1;
 	int b = dm - d0 + c - a;
-	a = __mul24(a, x) >> 15;
-	a = __mul24(a + b, x) >> 15;
-	return d0 + (__mul24(a + c, x) >> 15);
+	// (spelled as the instruction: left to itself the compiler proves the 24 bit
+	// range for one of the three only and uses the slower 32 bit multiply)
+	a = fm_mul24(a, x) >> 15;
+	a = fm_mul24(a + b, x) >> 15;
+	return d0 + (fm_mul24(a + c, x) >> 15);
 }
 
 // Four consecutive int16 samples as two dwords from a 2-byte aligned address
