@@ -76,6 +76,13 @@ DEV int noise_next(unsigned &st)
 	return (int)((st * (st >> 16)) >> 16);
 }
 
+DEV int mul24(int a, int b)
+{
+	int r;
+	asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+
 // a2_Hermite, a2_dsp.h:64-74; d = first payload sample, ph 24:8
 DEV int hermite(const int16_t *d, unsigned ph)
 {
@@ -85,9 +92,12 @@ DEV int hermite(const int16_t *d, unsigned ph)
 	int c = (d1 - dm) >> 1;
 	int a = (3 * (d0 - d1) + d2 - dm) >> 1;
 	int b = dm - d0 + c - a;
-	a = wmul(a, x) >> 15;
-	a = wmul(wadd(a, b), x) >> 15;
-	return d0 + (wmul(wadd(a, c), x) >> 15);
+	// |a|, |a + b|, |a + c| < 2^20 and x < 2^15: the 24 bit multiplier gives the
+	// low 32 bits of the reference's int products (wrap-around included) at
+	// full rate; spelled as the instruction, the compiler does not prove it
+	a = mul24(a, x) >> 15;
+	a = mul24(wadd(a, b), x) >> 15;
+	return d0 + (mul24(wadd(a, c), x) >> 15);
 }
 
 // wtosc_Inter, A2_HIFI build (config.h:108), wtosc.c:28-33

@@ -45,6 +45,12 @@ int  a2o_unit_write(a2o_ctx *ctx, int unit, int reg, int value,
 int  a2o_unit_process(a2o_ctx *ctx, int unit, unsigned offset,
 		unsigned frames, uint32_t *noisestate);
 int  a2o_inline_end(a2o_ctx *ctx, int unit);
+/* clients of xinsert / xsink / xsource units (xinsert.c:60-142, xsink.c:27-46,
+ * xsource.c:43-137): as a2amd_unit_clients / _inject / _tapped */
+int  a2o_unit_clients(a2o_ctx *ctx, int unit, unsigned mode);
+int  a2o_unit_inject(a2o_ctx *ctx, int unit, unsigned offset, unsigned frames,
+		const int32_t *const *bufs);
+int  a2o_unit_tapped(a2o_ctx *ctx, int unit, unsigned fragment, const int32_t **bufs);
 int  a2o_render(a2o_ctx *ctx, unsigned phases, int32_t *const *out,
 		unsigned out_capacity_frames);
 

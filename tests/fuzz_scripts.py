@@ -161,7 +161,12 @@ def make_script(seed):
     parts += [held_program(rng, h) + "\n" for h in held]
     buses = [f"B{i}" for i in range(rng.randint(1, 2))]
     parts += [bus_program(rng, b, names) + "\n" for b in buses]
-    main = ["export Main(V=.15)", "{", "\t!P 0", "\tfor {"]
+    main = ["export Main(V=.15)", "{"]
+    if seed % 3 == 0:
+        # Main is a group (a2_NewGroup's driver shape): the test attaches a sink, and for
+        # every other such seed a source as well, to its xinsert (A2REF_SINK / A2REF_SOURCE)
+        main += ["\tstruct { inline 0 2; panmix 2 2; xinsert 2 > }", f"\tvol {r(rng, 0.4, 1)}; set"]
+    main += ["\t!P 0", "\tfor {"]
     for _ in range(rng.randint(6, 14)):
         if rng.random() < 0.25:
             # an attached voice with an id: started, held, then released by message, killed or detached

@@ -26,11 +26,15 @@ def main():
     for seed in range(a, b):
         sp = f"{tmp}/f.a2s"
         open(sp, "w").write(make_script(seed))
-        outs = []
+        outs, sinks = [], []
         for pre in (False, True):
             env = dict(os.environ)
             if pre:
                 env["LD_PRELOAD"] = U
+            if seed % 3 == 0:       # Main is a group with an xinsert (tests/fuzz_scripts.py): give it clients
+                env["A2REF_SINK"] = "1"
+                if seed % 6 == 0:
+                    env["A2REF_SOURCE"] = "1"
             rate, buffer, channels = (48000, 44100, 96000, 32000)[seed % 4], (64, 37, 256, 1024, 17)[seed % 5], (2, 2, 1)[seed % 3]
             n = frames * rate // 48000 // buffer * buffer
             r = subprocess.run([R, sp, "Main", str(n), str(buffer), str(rate), str(channels), f"{tmp}/o{int(pre)}.pcm", "0.15"],
@@ -39,6 +43,10 @@ def main():
                 errors.append((seed, pre, r.stderr[-300:]))
                 break
             outs.append(np.fromfile(f"{tmp}/o{int(pre)}.pcm", dtype="<i4"))
+            sinks.append([ln for ln in r.stdout.splitlines() if ln.startswith("sink ")])
+        if len(outs) == 2 and sinks[0] != sinks[1]:
+            bad.append((seed, -1, -1))
+            print("SINK MISMATCH", seed, sinks, flush=True)
         if len(outs) == 2:
             if not outs[0].any():
                 silent += 1

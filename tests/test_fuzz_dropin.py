@@ -29,12 +29,16 @@ def test_random_script_matches_reference(tmp_path, seed):
         pytest.skip("oracle/_ref (compiled reference) or liba2amd_units.so not built")
     script = tmp_path / f"fuzz{seed}.a2s"
     script.write_text(make_script(seed))
-    outs = []
+    outs, sinks = [], []
     for preload in (False, True):
         out = tmp_path / f"o{int(preload)}.pcm"
         env = dict(os.environ)
         if preload:
             env["LD_PRELOAD"] = UNITS_SO
+        if seed % 3 == 0:       # Main is a group with an xinsert: give it clients
+            env["A2REF_SINK"] = "1"
+            if seed % 6 == 0:
+                env["A2REF_SOURCE"] = "1"
         rate, buffer, channels = engine_config(seed)
         frames = int(SECONDS * rate) // buffer * buffer
         r = subprocess.run([REF_RENDER, str(script), "Main", str(frames), str(buffer), str(rate), str(channels),
@@ -42,6 +46,8 @@ def test_random_script_matches_reference(tmp_path, seed):
                            env=env, cwd=tmp_path, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (seed, preload, r.stderr[-800:])
         outs.append(np.fromfile(out, dtype="<i4"))
+        sinks.append([ln for ln in r.stdout.splitlines() if ln.startswith("sink ")])
+    assert sinks[0] == sinks[1] and len(sinks[0]) == (seed % 3 == 0), (seed, sinks)
     assert outs[0].any(), f"seed {seed}: the reference rendered silence"
     bad = np.nonzero(outs[0] != outs[1])[0]
     assert len(bad) == 0, (f"seed {seed}: {len(bad)} samples differ, first at {bad[:3]} "

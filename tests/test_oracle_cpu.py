@@ -164,3 +164,18 @@ def test_oracle_xinsert_clients(oracle_lib):
     assert np.array_equal(out, plain + x)
     assert np.array_equal(np.concatenate([be.unit_tapped(xi, 0), be.unit_tapped(xi, 1)], axis=1), plain)
     be.close()
+
+
+def test_oracle_xsource_and_xsink_units(oracle_lib):
+    """xsrc_process / xsink_Process in the oracle (xsource.c:43-137, xsink.c:27-46)
+    on the script the GPU test compares (tests/test_gpu_parity.py): what a source
+    client produced is what a 'xsource; panmix' voice plays, a sink on
+    'wtosc; xsink; panmix' is handed the oscillator."""
+    from test_gpu_parity import _xio_voices_script
+    be = make_oracle(oracle_lib)
+    audio, taps = _xio_voices_script(be)
+    be.close()
+    assert audio.any() and sorted(taps) == [1, 2, 3, 4, 5]
+    # the tapped oscillator: a triangle at constant pitch and amplitude, the same peak in every fragment
+    peaks = {int(np.abs(t).max()) for f, t in taps.items() if f != 3}
+    assert len(peaks) == 1 and peaks.pop() > 1 << 20
