@@ -216,6 +216,7 @@ struct a2amd_ctx {
 	int n_started_live = 0;			// voices the engine is walking
 	int walked_started = 0;			// ... of which it has walked this many in the open fragment
 	int n_noise = 0, n_cutoff_ramps = 0;
+	int n_clients = 0;			// units whose clients are served (a2amd_unit_clients mode != 0)
 	unsigned shadow_epoch = 0;
 
 	// fragment clock
@@ -319,16 +320,21 @@ int grow(a2amd_ctx *c, DevBuf<T> &b, size_t need, size_t elem_mult, bool keep)
 {
 	if(need <= b.cap)
 		return 0;
-	size_t ncap = std::max(need, b.cap ? b.cap * 2 : (size_t)1024);
+	// (big elements - the 1 MB client slots - start small)
+	size_t ncap = std::max(need, b.cap ? b.cap * 2 : (elem_mult >= 65536 ? (size_t)2 : (size_t)1024));
 	T *nd = nullptr;
 	HIPCHK(c, hipMalloc((void **)&nd, ncap * elem_mult * sizeof(T)));
 	if(keep && b.d && b.cap) {
 		HIPCHK(c, hipStreamSynchronize(c->stream));
-		HIPCHK(c, hipMemcpy(nd, b.d, b.cap * elem_mult * sizeof(T), hipMemcpyDeviceToDevice));
+		HIPCHK(c, hipMemcpyAsync(nd, b.d, b.cap * elem_mult * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
 	}
+	// (on the context's stream: a memset on the null stream is not ordered with
+	// what this stream does to the new buffer next)
 	if(keep)
-		HIPCHK(c, hipMemset((char *)nd + b.cap * elem_mult * sizeof(T), 0,
-				(ncap - b.cap) * elem_mult * sizeof(T)));
+		HIPCHK(c, hipMemsetAsync((char *)nd + b.cap * elem_mult * sizeof(T), 0,
+				(ncap - b.cap) * elem_mult * sizeof(T), c->stream));
+	if(keep)	// ... nor with the synchronous copies some callers make into it right away
+		HIPCHK(c, hipStreamSynchronize(c->stream));
 	if(b.d) {
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		HIPCHK(c, hipFree(b.d));
@@ -1302,6 +1308,9 @@ int a2amd_fragment_repeat(a2amd_ctx *c, unsigned frames, unsigned count)
 	if(c->n_noise || c->n_cutoff_ramps)
 		return c->fail(A2AMD_EUNSUPPORTED, "fragment_repeat with %d noise oscillators / %d cutoff ramps "
 				"in flight", c->n_noise, c->n_cutoff_ramps);
+	if(c->n_clients)
+		return c->fail(A2AMD_EUNSUPPORTED, "fragment_repeat with clients on %d xinsert / xsink / xsource "
+				"unit(s): their callbacks need every window", c->n_clients);
 	if(count)
 		++c->shadow_epoch;	// oscillator phases advance without the host seeing it
 	for(unsigned i = 0; i < count; ++i) {
@@ -1495,6 +1504,8 @@ int a2amd_unit_deinit(a2amd_ctx *c, int ui)
 		c->fm_deferred_free.push_back(u.fmslot);
 	if(u.xio >= 0)		// (the slot serves the batch being recorded to its end)
 		c->xio_deferred_free.push_back(u.xio);
+	if(u.xio_mode)
+		--c->n_clients;
 	u.live = false;
 	c->deferred_free_units.push_back(ui);
 	--c->stats.live_units;
@@ -1834,6 +1845,7 @@ int a2amd_unit_clients(a2amd_ctx *c, int ui, unsigned mode)
 	c->building = -1;
 	push_rec(c, u.voice, R_WRITE, u.chainpos, 0, mode ? u.xio + 1 : 0, 0, 0);
 	push_rec(c, u.voice, R_WRITE, u.chainpos, 1, (int)mode, 0, 0);
+	c->n_clients += (int)(mode != 0) - (int)(u.xio_mode != 0);
 	u.xio_mode = mode;
 	c->lists_dirty = true;		// a driver chain with clients is served by the general kernel
 	return A2AMD_OK;

@@ -249,8 +249,9 @@ int  a2amd_rootbus(a2amd_ctx *ctx, void **devptr, uint64_t *bytes);
 /* Begin 'count' further fragments of 'frames' frames in which the engine's
  * voice walk finds every VM asleep: each live voice gets exactly one
  * Process(0, frames) per unit and nothing else happens (src/core.c:1852-1878
- * with no wake-ups).  Fails with A2AMD_EUNSUPPORTED while a noise oscillator
- * or a ramping filter cutoff needs per-call host work.  Fragments rendered
+ * with no wake-ups).  Fails with A2AMD_EUNSUPPORTED while a noise oscillator,
+ * a ramping filter cutoff or a unit with clients (a2amd_unit_clients) needs
+ * per-call host work.  Fragments rendered
  * this way (and by A2AMD_RENDER_KEEP / a2amd_replay re-runs) advance the
  * oscillators without a2amd_unit_process calls, so the host loses track of
  * their phase: an oscillator alive across such a stretch can afterwards not be

@@ -568,6 +568,10 @@ int a2o_fragment_repeat(a2o_ctx *c, unsigned frames, unsigned count)
 {
 	unsigned n;
 	int i, r = A2AMD_OK;
+	for(i = 0; i < c->nunits; ++i)
+		if(c->units[i].live && c->units[i].xio_mode)
+			return fail(c, A2AMD_EUNSUPPORTED, "fragment_repeat with clients "
+					"on unit %d: their callbacks need every window", i);
 	c->replaying = 1;
 	for(n = 0; n < count && !r; ++n)
 	{

@@ -436,6 +436,10 @@ def _clients_script(be, fragments=14, batch=5, seed=11):
             for f in pending:
                 taps[f] = be.unit_tapped(xi, f - first)
             pending = []
+    # client callbacks need every window: no "everybody sleeps" fragments while there are clients
+    be.unit_clients(xi, 1)
+    assert getattr(be.lib, be.prefix + "fragment_repeat")(be.ctx, 64, 2) == -4       # A2AMD_EUNSUPPORTED
+    be.unit_clients(xi, 0)
     return np.concatenate(chunks, axis=1), taps
 
 
@@ -465,13 +469,16 @@ def _xio_voices_script(be, fragments=9, batch=4, seed=3):
     sc = synth.Scene(be, nwaves=2)
     sc.root()
     sc.add_voices(2, chain="osc-pan", total=64)
-    ka, kb, kc = sc._key(), sc._key(), sc._key()
+    ka, kb, kc, kd = sc._key(), sc._key(), sc._key(), sc._key()
     va = [be.unit_init(ka, K_XSOURCE, 0, 0, 1, 0), be.unit_init(ka, synth.K_PANMIX, synth.PROCADD, 1, 2, 1)]
     vb = [be.unit_init(kb, synth.K_WTOSC, 0, 0, 1, 0), be.unit_init(kb, K_XSINK, 0, 1, 0, 0),
           be.unit_init(kb, synth.K_PANMIX, synth.PROCADD, 1, 2, 1)]
     vc = [be.unit_init(kc, synth.K_WTOSC, 0, 0, 1, 0), be.unit_init(kc, K_XSOURCE, synth.PROCADD, 0, 1, 0),
           be.unit_init(kc, synth.K_PANMIX, synth.PROCADD, 1, 2, 1)]
-    for v in (vb, vc):
+    # ... and an xinsert in the middle of a chain (in place on the voice's scratch bus)
+    vd = [be.unit_init(kd, synth.K_WTOSC, 0, 0, 1, 0), be.unit_init(kd, synth.K_XINSERT, 0, 1, 1, 0),
+          be.unit_init(kd, synth.K_PANMIX, synth.PROCADD, 1, 2, 1)]
+    for v in (vb, vc, vd):
         be.unit_write(v[0], 0, sc.wave_ids[0])
         be.unit_write(v[0], 1, synth.fix(-0.3))
         be.unit_write(v[0], 2, synth.fix(0.2))
@@ -487,6 +494,10 @@ def _xio_voices_script(be, fragments=9, batch=4, seed=3):
             be.unit_clients(vb[1], 1)
         if frag == 3:
             be.unit_clients(vc[1], 2)
+        if frag == 2:
+            be.unit_clients(vd[1], 3)
+        if frag == 7:
+            be.unit_clients(vd[1], 1)
         if frag == 6:
             be.unit_clients(va[0], 0)
             be.unit_clients(vb[1], 0)
@@ -496,7 +507,9 @@ def _xio_voices_script(be, fragments=9, batch=4, seed=3):
                 be.unit_inject(va[0], a, rng.integers(-1 << 22, 1 << 22, (1, b - a)))
             if frag >= 3:
                 be.unit_inject(vc[1], a, rng.integers(-1 << 22, 1 << 22, (1, b - a)))
-            for v in (va, vb, vc):
+            if 2 <= frag < 7:
+                be.unit_inject(vd[1], a, rng.integers(-1 << 21, 1 << 21, (1, b - a)))
+            for v in (va, vb, vc, vd):
                 for u in v:
                     be.unit_process(u, a, b - a)
         be.inline_end(sc.rootv[0])
@@ -509,6 +522,8 @@ def _xio_voices_script(be, fragments=9, batch=4, seed=3):
             chunks.append(be.render(batch * 64))
             for f in pending:
                 taps[f] = be.unit_tapped(vb[1], f - first)
+            for f in range(max(first, 2), frag + 1):
+                taps[100 + f] = be.unit_tapped(vd[1], f - first)
             pending = []
     return np.concatenate(chunks, axis=1), taps
 
@@ -521,6 +536,6 @@ def test_xsource_and_xsink_units(oracle_lib):
     want, wtaps = _xio_voices_script(ora)
     ora.close()
     assert want.any() and first_diff(got, want) is None
-    assert sorted(gtaps) == sorted(wtaps) == [1, 2, 3, 4, 5]
+    assert sorted(gtaps) == sorted(wtaps) == [1, 2, 3, 4, 5] + [100 + f for f in range(2, 9)]
     for f in wtaps:
         assert wtaps[f].any() and np.array_equal(gtaps[f], wtaps[f]), f"tapped input differs in fragment {f}"
