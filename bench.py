@@ -308,10 +308,15 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.voices, args.chain)
-        print(json.dumps(line))
     be.close()
     if multi:
         dist.destroy_process_group()
+    # The contract line is the LAST thing on stdout: RCCL writes a version banner
+    # through C stdio, which sits in libc's buffer until it is flushed.
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
