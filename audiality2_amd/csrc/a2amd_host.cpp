@@ -1050,6 +1050,12 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 				return r;
 	}
 	if(phases & A2AMD_RENDER_ROOT) {
+		// The root chain adds into the master bus.  When its phase runs on its own
+		// (multi-GPU steps: several SUBTREES phases may have gone by since the
+		// last one, audiality2_amd/shard.py) the master bus is cleared here.
+		if(!(phases & A2AMD_RENDER_SUBTREES))
+			HIPCHK(c, hipMemsetAsync(c->d_busmem.d, 0,
+					(size_t)c->nfrags * c->cfg.channels * A2D_FRAG * sizeof(int32_t), c->stream));
 		if(!c->depth_ranges.empty())
 			if(int r = launch_depth(c, 0))
 				return r;
@@ -2077,6 +2083,19 @@ int a2amd_rootbus(a2amd_ctx *c, void **devptr, uint64_t *bytes)
 		}
 	}
 	return c->fail(A2AMD_ESTATE, "no root voice with an inline bus");
+}
+
+int a2amd_rootbus_copy(a2amd_ctx *c, void *stage, int to_stage)
+{
+	void *bus;
+	uint64_t bytes;
+	use_device(c);
+	if(int r = a2amd_rootbus(c, &bus, &bytes))
+		return r;
+	if(!stage)
+		return c->fail(A2AMD_EINVAL, "no staging buffer");
+	HIPCHK(c, hipMemcpyAsync(to_stage ? stage : bus, to_stage ? bus : stage, bytes, hipMemcpyDeviceToDevice, c->stream));
+	return A2AMD_OK;
 }
 
 static int drain_events(a2amd_ctx *c)

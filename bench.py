@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="fragments per step (256 = 341 ms of audio)")
     ap.add_argument("--groups", type=int, default=0,
                     help="put the voices under this many inline->fbdelay->fbdelay group voices (config 4 shape)")
+    ap.add_argument("--reduce-group", type=int, default=8,
+                    help="N>1: steps whose root-bus partials are summed by one collective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -217,16 +219,30 @@ def main():
 
         rootbus = shard.wrap_device_bus(ptr.value, nbytes.value, torch.device("cuda", local_rank))
 
+    # N>1: the root-bus sums of `--reduce-group` steps travel in one collective that
+    # overlaps the next group's subtree kernels (audiality2_amd/shard.py)
+    pipe = None
+    if multi:
+        lib.a2amd_rootbus_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        render = be._render                 # (the raw entry point: no output arrays in the step loop)
+
+        def phase(ph):
+            if render(be.ctx, ph | KEEP, None, 0) < 0:
+                raise RuntimeError(be._err(be.ctx))
+
+        def copy_fn(ptr, to_stage):
+            if lib.a2amd_rootbus_copy(be.ctx, ptr, to_stage):
+                raise RuntimeError(be._err(be.ctx))
+
+        pipe = shard.GroupedRootReduce(rootbus, lambda: phase(SUB), lambda: phase(ROOTP), rank,
+                                       group=args.reduce_group, copy_fn=copy_fn)
+
     def run(nsteps):
         if not multi:
             if lib.a2amd_replay(be.ctx, nsteps):
                 raise RuntimeError(be._err(be.ctx))
             return
-        for _ in range(nsteps):
-            be.render(0, phases=SUB | KEEP)
-            shard.reduce_root_bus(rootbus, dst=0)
-            if rank == 0:
-                be.render(0, phases=ROOTP | KEEP)
+        pipe.run(nsteps)
 
     # barrier = a (pre-warmed) 1-element all-reduce every rank must join, with the
     # device idle on both sides; dist.barrier() itself costs tens of ms on first use
@@ -256,10 +272,18 @@ def main():
         dt = float(t.item())
 
     # kernel durations: the same step, every launch bracketed by HIP events on
-    # the launch stream (profiling disables the graph replay)
+    # the launch stream (profiling disables the graph replay; N>1: one step at a
+    # time, so that every step's events pair up)
+    def run_serial(nsteps):
+        for _ in range(nsteps):
+            be.render(0, phases=SUB | KEEP)
+            shard.reduce_root_bus(rootbus, dst=0)
+            if rank == 0:
+                be.render(0, phases=ROOTP | KEEP)
+
     nprof = min(args.steps, 64)
     lib.a2amd_set_profiling(be.ctx, 1)
-    run(nprof)
+    (run_serial if multi else run)(nprof)
     st = Stats()
     lib.a2amd_get_stats(be.ctx, ctypes.byref(st))
     lib.a2amd_set_profiling(be.ctx, 0)

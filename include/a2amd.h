@@ -245,6 +245,11 @@ int  a2amd_replay(a2amd_ctx *ctx, unsigned steps);
 /* Device pointer + size (bytes) of the root voice's inline bus partials for
  * the fragments of the current batch: int32 [batch][channels][64]. */
 int  a2amd_rootbus(a2amd_ctx *ctx, void **devptr, uint64_t *bytes);
+/* Copy the root-bus partials of the current batch to (to_stage != 0) or from a
+ * device staging buffer of that size, on the context's stream: lets a host park
+ * several batches' partials and sum them across ranks with one collective
+ * (audiality2_amd/shard.py: GroupedRootReduce). */
+int  a2amd_rootbus_copy(a2amd_ctx *ctx, void *stage, int to_stage);
 
 /* Begin 'count' further fragments of 'frames' frames in which the engine's
  * voice walk finds every VM asleep: each live voice gets exactly one
