@@ -141,7 +141,7 @@ int a2d_launch_voices(const A2DParams *dparams, const int *dlist, int nlist, int
 // (needs the staging copy 'ustage' of the unit state array)
 int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
 		int vpw, int ysplit, int *ustage, void *stream, void *event_after_main);
-int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, int nfrags, void *stream);
+int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, int nfrags, int consume, void *stream);
 int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
 		int vpw, void *stream);
 // runs[idx[i]] = val[i] for the few voices whose record run changed this batch

@@ -1144,7 +1144,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 // inline -> panmix 2->2 -> xinsert (add, wired): root / group driver voices
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist)
+void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int consume)
 {
 	__shared__ int fr[A2D_MAXBATCH][5];	// per fragment: vol, dvol, pan, dpan, clamp
 	const A2DParams &p = *pp;
@@ -1188,9 +1188,15 @@ void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list
 	for(int f = fbeg; f < p.nfrags; f += fstep) {
 		if(lane >= p.fragframes[f])
 			continue;
-		const int *src = p.busmem + vc.own_off + (size_t)f * vc.own_nch * A2D_FRAG;
+		int *src = p.busmem + vc.own_off + (size_t)f * vc.own_nch * A2D_FRAG;
 		int *dst = p.busmem + vc.out_off + (size_t)f * vc.out_nch * A2D_FRAG;
 		int i0 = src[lane], i1 = src[A2D_FRAG + lane];
+		if(consume) {
+			// every bus of this batch is read here and nowhere else: leave it
+			// zeroed for the next batch (no memset between batches)
+			src[lane] = 0;
+			src[A2D_FRAG + lane] = 0;
+		}
 		int vk = settled ? vol.value : wadd(fr[f][0], wmul(fr[f][1], lane));
 		int pk = settled ? pan.value : wadd(fr[f][2], wmul(fr[f][3], lane));
 		int vp = mul64s(pk, vk, 24);
@@ -1201,6 +1207,12 @@ void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list
 			if(v1 > lim) v1 = lim;
 		}
 		int o0 = mul64s(i0, v0, 24), o1 = mul64s(i1, v1, 24);
+		if(consume && vc.out_off == 0) {
+			// ... and the master bus has one writer, the root: a plain store
+			dst[lane] = o0;
+			dst[A2D_FRAG + lane] = o1;
+			continue;
+		}
 		if(o0)
 			atomicAdd(&dst[lane], o0);
 		if(o1)
@@ -1729,12 +1741,12 @@ int a2d_launch_leaf_fmpan(const A2DParams *dparams, const A2DParams &hp, int kin
 	return -1;
 }
 
-int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, int nfrags, void *stream)
+int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, int nfrags, int consume, void *stream)
 {
 	if(nlist <= 0)
 		return 0;
 	// grid.y: workgroups per voice, 4 fragments in flight each
 	hipLaunchKernelGGL(k_bus_driver, dim3(nlist, nfrags >= 16 ? 16 : (nfrags + 3) / 4), dim3(256), 0,
-			(hipStream_t)stream, dparams, dlist, nlist);
+			(hipStream_t)stream, dparams, dlist, nlist, consume);
 	return (int)hipGetLastError();
 }

@@ -216,6 +216,12 @@ struct a2amd_ctx {
 	int n_started_live = 0;			// voices the engine is walking
 	int walked_started = 0;			// ... of which it has walked this many in the open fragment
 	int n_noise = 0, n_cutoff_ramps = 0;
+	// Self-cleaning buses: when every bus is read by k_bus_driver (its owner is a plain
+	// driver chain without records this batch), that kernel zeroes what it read and the
+	// root stores the master bus instead of adding to it - the batch needs no memset.
+	bool owners_all_driver = false;		// (static: set when the lists are rebuilt)
+	bool consume_ok = false;		// ... and none of them carries records this batch
+	bool bus_clean = false;			// bus memory behind the master bus is known to be zero
 	int n_clients = 0;			// units whose clients are served (a2amd_unit_clients mode != 0)
 	unsigned shadow_epoch = 0;
 
@@ -559,7 +565,12 @@ int upload(a2amd_ctx *c)
 	if(int r = grow(c, c->d_ustage, c->d_ustate.cap, A2D_USTATE, false)) return r;
 	if(int r = grow(c, c->d_vactive, nv, 1, true)) return r;
 	if(int r = grow(c, c->d_runs, nv, 1, true)) return r;
-	if(int r = grow(c, c->d_busmem, c->bus_used, 1, false)) return r;
+	{
+		const int32_t *before = c->d_busmem.d;
+		if(int r = grow(c, c->d_busmem, c->bus_used, 1, false)) return r;
+		if(c->d_busmem.d != before)
+			c->bus_clean = false;
+	}
 	if(c->fbd_count)
 		if(int r = grow(c, c->d_fbdmem, c->fbd_count, 2 * (size_t)A2D_FBD_BUFSIZE, true)) return r;
 	if(!c->xio.empty()) {
@@ -681,6 +692,7 @@ int upload(a2amd_ctx *c)
 	// The fast kernels skip a voice whose runs[] entry is non-zero; those voices
 	// form the dynamic part (this batch's exceptions) and go to the general kernel.
 	if(c->lists_dirty) {
+		bool owners_ok = !getenv("A2AMD_NO_SELFCLEAN"), root_driver = false;
 		std::vector<int> fast_leaf, osc2_leaf, filt_leaf, fm_leaf, gen_leaf;
 		std::map<int, std::pair<std::vector<int>, std::vector<int>>> bydepth;
 		int maxdepth = -1;
@@ -695,6 +707,11 @@ int upload(a2amd_ctx *c)
 			if(v.inline_pos >= 0) {
 				auto &d = bydepth[v.depth];
 				v.cls = !(c->no_fast & 4) && is_driver_chain(c, v) ? CLS_BUSDRIVER : CLS_BUSGENERIC;
+				// (the master bus at offset 0 is the root's alone)
+				if(v.cls != CLS_BUSDRIVER || (v.out_off == 0) != (v.depth == 0))
+					owners_ok = false;
+				else if(v.depth == 0)
+					root_driver = true;
 				(v.cls == CLS_BUSDRIVER ? d.first : d.second).push_back((int)vi);
 				maxdepth = std::max(maxdepth, v.depth);
 			} else {
@@ -702,6 +719,8 @@ int upload(a2amd_ctx *c)
 						!(c->no_fast & 8) && is_osc2pan_chain(c, v) ? CLS_OSC2PAN :
 						!(c->no_fast & 2) && is_oscfiltpan_chain(c, v) ? CLS_OSCFILTPAN :
 						!(c->no_fast & 16) && is_fmpan_chain(c, v) ? CLS_FMPAN : CLS_GENERIC;
+				if(v.out_off == 0)
+					owners_ok = false;	// adds straight into the master bus
 				(v.cls == CLS_OSCPAN ? fast_leaf : v.cls == CLS_OSC2PAN ? osc2_leaf :
 				 v.cls == CLS_OSCFILTPAN ? filt_leaf : v.cls == CLS_FMPAN ? fm_leaf : gen_leaf).push_back((int)vi);
 			}
@@ -749,6 +768,7 @@ int upload(a2amd_ctx *c)
 			HIPCHK(c, hipMemcpyAsync(c->d_list.d, c->list_all.data(), c->list_all.size() * sizeof(int),
 					hipMemcpyHostToDevice, c->stream));
 		c->lists_dirty = false;
+		c->owners_all_driver = owners_ok && root_driver;
 	}
 	std::vector<int> dyn_all;
 	{
@@ -775,6 +795,10 @@ int upload(a2amd_ctx *c)
 			dyn.insert(dyn.end(), dyn_bus[d].begin(), dyn_bus[d].end());
 		}
 		dyn_all.swap(dyn);
+		c->consume_ok = c->owners_all_driver;
+		for(const std::vector<int> &d : dyn_bus)
+			if(!d.empty())
+				c->consume_ok = false;	// a bus owner carries records: the general kernel renders it
 	}
 
 	A2DParams p;
@@ -875,11 +899,11 @@ int pick_fast_vpw(int n)
 	return std::min(std::max(v, 1), 64);
 }
 
-int launch_depth(a2amd_ctx *c, int d)
+int launch_depth(a2amd_ctx *c, int d, bool consume)
 {
 	const DepthRange &r = c->depth_ranges[d];
 	if(r.fast_count) {
-		if(a2d_launch_bus_driver(c->d_params, c->d_list.d + r.fast_first, r.fast_count, c->nfrags, c->stream))
+		if(a2d_launch_bus_driver(c->d_params, c->d_list.d + r.fast_first, r.fast_count, c->nfrags, consume, c->stream))
 			return c->fail(A2AMD_EHIP, "bus driver launch failed: %s", hipGetErrorString(hipGetLastError()));
 		++c->stats.launches;
 	}
@@ -967,8 +991,12 @@ void end_batch(a2amd_ctx *c)
 // the kernels of one batch, in stream order; e* may be null
 int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2)
 {
+	// (self-cleaning buses need both phases in one go: the root's bus is read in ROOT)
+	const bool consume = c->consume_ok && (phases & A2AMD_RENDER_SUBTREES) && (phases & A2AMD_RENDER_ROOT);
 	if(phases & A2AMD_RENDER_SUBTREES) {
-		HIPCHK(c, hipMemsetAsync(c->d_busmem.d, 0, c->bus_used * sizeof(int32_t), c->stream));
+		if(!(consume && c->bus_clean))
+			HIPCHK(c, hipMemsetAsync(c->d_busmem.d, 0, c->bus_used * sizeof(int32_t), c->stream));
+		c->bus_clean = consume;
 		if(e0)
 			HIPCHK(c, hipEventRecord(e0, c->stream));
 		if(c->n_fast_leaf) {
@@ -1046,7 +1074,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		if(e1 && !(c->n_fast_leaf && !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn))
 			HIPCHK(c, hipEventRecord(e1, c->stream));
 		for(int d = (int)c->depth_ranges.size() - 1; d >= 1; --d)
-			if(int r = launch_depth(c, d))
+			if(int r = launch_depth(c, d, consume))
 				return r;
 	}
 	if(phases & A2AMD_RENDER_ROOT) {
@@ -1057,7 +1085,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			HIPCHK(c, hipMemsetAsync(c->d_busmem.d, 0,
 					(size_t)c->nfrags * c->cfg.channels * A2D_FRAG * sizeof(int32_t), c->stream));
 		if(!c->depth_ranges.empty())
-			if(int r = launch_depth(c, 0))
+			if(int r = launch_depth(c, 0, consume))
 				return r;
 		if(e2)
 			HIPCHK(c, hipEventRecord(e2, c->stream));
@@ -1088,8 +1116,13 @@ int build_graph(a2amd_ctx *c, int slot, int steps, unsigned phases = A2AMD_RENDE
 	if(e != hipSuccess)
 		return c->fail(A2AMD_EHIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
 	int r = 0;
+	// (a captured run does not happen now: every graph starts from buses of
+	// unknown state, and what it leaves behind is noted when it is launched)
+	const bool clean = c->bus_clean;
+	c->bus_clean = false;
 	for(int i = 0; i < steps && !r; ++i)
 		r = issue_kernels(c, phases, nullptr, nullptr, nullptr);
+	c->bus_clean = clean;
 	e = hipStreamEndCapture(c->stream, &c->graph[slot]);
 	if(r)
 		return r;
@@ -1954,6 +1987,7 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		const int slot = kphases == A2AMD_RENDER_SUBTREES ? 2 : kphases == A2AMD_RENDER_ROOT ? 3 : 1;
 		if(c->gexec[slot] || !build_graph(c, slot, 1, kphases)) {
 			HIPCHK(c, hipGraphLaunch(c->gexec[slot], c->stream));
+			c->bus_clean = c->consume_ok && slot == 1;
 			if(kphases & A2AMD_RENDER_ROOT) {
 				c->stats.fragments += c->nfrags;
 				c->stats.voice_fragments += (uint64_t)c->nfrags * (c->list_all.size() - c->n_list_pads);
@@ -2037,11 +2071,13 @@ int a2amd_replay(a2amd_ctx *c, unsigned steps)
 	while(steps) {
 		if(graphs && steps >= (unsigned)GRAPH_STEPS) {
 			HIPCHK(c, hipGraphLaunch(c->gexec[0], c->stream));
+			c->bus_clean = c->consume_ok;
 			steps -= GRAPH_STEPS;
 			c->stats.fragments += (uint64_t)c->nfrags * GRAPH_STEPS;
 			c->stats.voice_fragments += (uint64_t)c->nfrags * (c->list_all.size() - c->n_list_pads) * GRAPH_STEPS;
 		} else if(graphs) {
 			HIPCHK(c, hipGraphLaunch(c->gexec[1], c->stream));
+			c->bus_clean = c->consume_ok;
 			--steps;
 			c->stats.fragments += c->nfrags;
 			c->stats.voice_fragments += (uint64_t)c->nfrags * (c->list_all.size() - c->n_list_pads);
