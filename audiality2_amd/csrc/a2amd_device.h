@@ -139,15 +139,21 @@ int a2d_launch_voices(const A2DParams *dparams, const int *dlist, int nlist, int
 // hp = host copy of *dparams (device pointers passed as direct kernel arguments)
 // ysplit > 1 cuts the batch into time slices rendered by different wavefronts
 // (needs the staging copy 'ustage' of the unit state array)
+// a state commit a time-sliced leaf kernel left to be done (ustage -> ustate for its
+// voices): rides along with the next driver-chain launch instead of one of its own
+struct A2DCommit { const int *list; int nlist, nosc; const int *ustage; };
+struct A2DCommitSet { A2DCommit c[2]; int n; };
 int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
-		int vpw, int ysplit, int *ustage, void *stream, void *event_after_main);
-int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, int nfrags, int consume, void *stream);
+		int vpw, int ysplit, int *ustage, void *stream, void *event_after_main, A2DCommit *defer);
+int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, int nfrags, int consume,
+		const A2DCommitSet *commits, void *stream);
+int a2d_launch_commit(const A2DParams &hp, const A2DCommit &cm, void *stream);
 int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
 		int vpw, void *stream);
 // runs[idx[i]] = val[i] for the few voices whose record run changed this batch
 int a2d_launch_scatter_runs(const int *didx, const A2DRun *dval, int n, A2DRun *druns, void *stream);
 int a2d_launch_leaf_osc2pan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
-		int vpw, int ysplit, int *ustage, void *stream);
+		int vpw, int ysplit, int *ustage, void *stream, A2DCommit *defer);
 // fm -> panmix leaf voices of ONE unit kind (a2amd_unitkind A2AMD_FM1..FM4R)
 int a2d_launch_leaf_fmpan(const A2DParams *dparams, const A2DParams &hp, int kind, const int *dlist, int nlist,
 		int vpw, void *stream);

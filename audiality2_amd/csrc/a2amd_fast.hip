@@ -540,24 +540,32 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 
 // staged state of the fast leaf voices (nosc oscillators + panmix) -> the unit
 // state array
-__global__ void k_commit_oscpan(const int *__restrict__ list, int nlist, int nosc,
-		const A2DVoice *__restrict__ voices, const A2DRun *__restrict__ runs, int *__restrict__ ustate,
-		const int *__restrict__ ustage)
+DEV void commit_block(const A2DCommit &cm, int block, const A2DVoice *__restrict__ voices,
+		const A2DRun *__restrict__ runs, int *__restrict__ ustate)
 {
-	const int per = (nosc + 1) * 16;
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if(i >= nlist * per)
+	const int per = (cm.nosc + 1) * 16;
+	int i = block * 256 + threadIdx.x;
+	if(i >= cm.nlist * per)
 		return;
-	const int slot = list[i / per];
+	const int slot = cm.list[i / per];
 	if(runs[slot].count)
 		return;		// not rendered by the fast kernel this batch: nothing staged
 	const A2DVoice &vc = voices[slot];
 	const int u = (i % per) >> 4, k = i & 15;
 	// the words the kernels stage: wtosc 0..14 except the noise sample, panmix 0..7
-	if(u < nosc ? (k != OW_NOISE && k < 15) : (k < 8)) {
+	if(u < cm.nosc ? (k != OW_NOISE && k < 15) : (k < 8)) {
 		size_t a = (size_t)vc.unit[u] * A2D_USTATE + k;
-		ustate[a] = ustage[a];
+		ustate[a] = cm.ustage[a];
 	}
+}
+
+DEV int commit_blocks(const A2DCommit &cm) { return (cm.nlist * (cm.nosc + 1) * 16 + 255) / 256; }
+
+__global__ __launch_bounds__(256)
+void k_commit_oscpan(A2DCommit cm, const A2DVoice *__restrict__ voices, const A2DRun *__restrict__ runs,
+		int *__restrict__ ustate)
+{
+	commit_block(cm, blockIdx.x, voices, runs, ustate);
 }
 
 // ---------------------------------------------------------------------------
@@ -1144,10 +1152,27 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 // inline -> panmix 2->2 -> xinsert (add, wired): root / group driver voices
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int consume)
+void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int consume,
+		A2DCommitSet commits)
 {
 	__shared__ int fr[A2D_MAXBATCH][5];	// per fragment: vol, dvol, pan, dpan, clamp
 	const A2DParams &p = *pp;
+	if((int)blockIdx.x >= nlist) {
+		// workgroups past the voices: state commits the leaf kernels left behind
+		// (different voices than the ones rendered here)
+		if(blockIdx.y)
+			return;
+		int b = (int)blockIdx.x - nlist;
+		for(int k = 0; k < commits.n; ++k) {
+			const int nb = commit_blocks(commits.c[k]);
+			if(b < nb) {
+				commit_block(commits.c[k], b, p.voices, p.runs, p.ustate);
+				return;
+			}
+			b -= nb;
+		}
+		return;
+	}
 	if(p.runs[list[blockIdx.x]].count)
 		return;		// carries records this batch: the general kernel renders it
 	const A2DVoice &vc = p.voices[list[blockIdx.x]];
@@ -1221,7 +1246,7 @@ void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list
 }
 
 int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
-		int vpw, int ysplit, int *ustage, void *stream, void *event_after_main)
+		int vpw, int ysplit, int *ustage, void *stream, void *event_after_main, A2DCommit *defer)
 {
 	if(nlist <= 0)
 		return 0;
@@ -1235,14 +1260,19 @@ int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const 
 			ysplit > 1 ? ustage : hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
 	if(event_after_main)
 		hipEventRecord((hipEvent_t)event_after_main, (hipStream_t)stream);
-	if(ysplit > 1)
-		hipLaunchKernelGGL(k_commit_oscpan, dim3((nlist * 32 + 255) / 256), dim3(256), 0,
-				(hipStream_t)stream, dlist, nlist, 1, hp.voices, hp.runs, hp.ustate, (const int *)ustage);
+	if(ysplit > 1) {
+		A2DCommit cm = { dlist, nlist, 1, ustage };
+		if(defer)
+			*defer = cm;
+		else
+			a2d_launch_commit(hp, cm, stream);
+	} else if(defer)
+		defer->nlist = 0;
 	return (int)hipGetLastError();
 }
 
 int a2d_launch_leaf_osc2pan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
-		int vpw, int ysplit, int *ustage, void *stream)
+		int vpw, int ysplit, int *ustage, void *stream, A2DCommit *defer)
 {
 	if(nlist <= 0)
 		return 0;
@@ -1254,9 +1284,14 @@ int a2d_launch_leaf_osc2pan(const A2DParams *dparams, const A2DParams &hp, const
 	hipLaunchKernelGGL(k_leaf_osc2pan, dim3(nblocks, ysplit), dim3(64 * FAST_WPB), 0, (hipStream_t)stream,
 			dparams, dlist, nlist, vpw, ysplit, hp.voices, (const int *)hp.ustate,
 			ysplit > 1 ? ustage : hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
-	if(ysplit > 1)
-		hipLaunchKernelGGL(k_commit_oscpan, dim3((nlist * 48 + 255) / 256), dim3(256), 0,
-				(hipStream_t)stream, dlist, nlist, 2, hp.voices, hp.runs, hp.ustate, (const int *)ustage);
+	if(ysplit > 1) {
+		A2DCommit cm = { dlist, nlist, 2, ustage };
+		if(defer)
+			*defer = cm;
+		else
+			a2d_launch_commit(hp, cm, stream);
+	} else if(defer)
+		defer->nlist = 0;
 	return (int)hipGetLastError();
 }
 
@@ -1741,12 +1776,31 @@ int a2d_launch_leaf_fmpan(const A2DParams *dparams, const A2DParams &hp, int kin
 	return -1;
 }
 
-int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, int nfrags, int consume, void *stream)
+int a2d_launch_commit(const A2DParams &hp, const A2DCommit &cm, void *stream)
+{
+	if(cm.nlist <= 0)
+		return 0;
+	hipLaunchKernelGGL(k_commit_oscpan, dim3((cm.nlist * (cm.nosc + 1) * 16 + 255) / 256), dim3(256), 0,
+			(hipStream_t)stream, cm, hp.voices, hp.runs, hp.ustate);
+	return (int)hipGetLastError();
+}
+
+int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, int nfrags, int consume,
+		const A2DCommitSet *commits, void *stream)
 {
 	if(nlist <= 0)
 		return 0;
+	A2DCommitSet cs;
+	cs.n = 0;
+	int extra = 0;
+	if(commits)
+		for(int k = 0; k < commits->n; ++k)
+			if(commits->c[k].nlist > 0) {
+				cs.c[cs.n++] = commits->c[k];
+				extra += (commits->c[k].nlist * (commits->c[k].nosc + 1) * 16 + 255) / 256;
+			}
 	// grid.y: workgroups per voice, 4 fragments in flight each
-	hipLaunchKernelGGL(k_bus_driver, dim3(nlist, nfrags >= 16 ? 16 : (nfrags + 3) / 4), dim3(256), 0,
-			(hipStream_t)stream, dparams, dlist, nlist, consume);
+	hipLaunchKernelGGL(k_bus_driver, dim3(nlist + extra, nfrags >= 16 ? 16 : (nfrags + 3) / 4), dim3(256), 0,
+			(hipStream_t)stream, dparams, dlist, nlist, consume, cs);
 	return (int)hipGetLastError();
 }

@@ -899,12 +899,15 @@ int pick_fast_vpw(int n)
 	return std::min(std::max(v, 1), 64);
 }
 
-int launch_depth(a2amd_ctx *c, int d, bool consume)
+int launch_depth(a2amd_ctx *c, int d, bool consume, A2DCommitSet *pend)
 {
 	const DepthRange &r = c->depth_ranges[d];
 	if(r.fast_count) {
-		if(a2d_launch_bus_driver(c->d_params, c->d_list.d + r.fast_first, r.fast_count, c->nfrags, consume, c->stream))
+		// (state commits the time-sliced leaf kernels left behind ride along)
+		if(a2d_launch_bus_driver(c->d_params, c->d_list.d + r.fast_first, r.fast_count, c->nfrags, consume,
+				pend, c->stream))
 			return c->fail(A2AMD_EHIP, "bus driver launch failed: %s", hipGetErrorString(hipGetLastError()));
+		pend->n = 0;
 		++c->stats.launches;
 	}
 	if(r.gen_count) {
@@ -993,6 +996,14 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 {
 	// (self-cleaning buses need both phases in one go: the root's bus is read in ROOT)
 	const bool consume = c->consume_ok && (phases & A2AMD_RENDER_SUBTREES) && (phases & A2AMD_RENDER_ROOT);
+	A2DCommitSet pend;
+	pend.n = 0;
+	pend.c[0].nlist = pend.c[1].nlist = 0;
+	auto flush_commits = [&]() {
+		for(int k = 0; k < pend.n; ++k)
+			a2d_launch_commit(c->hparams, pend.c[k], c->stream);
+		pend.n = 0;
+	};
 	if(phases & A2AMD_RENDER_SUBTREES) {
 		if(!(consume && c->bus_clean))
 			HIPCHK(c, hipMemsetAsync(c->d_busmem.d, 0, c->bus_used * sizeof(int32_t), c->stream));
@@ -1006,16 +1017,20 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			// of the batch: "leaf" time is then that kernel alone
 			const bool solo = !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn;
 			if(a2d_launch_leaf_oscpan(c->d_params, c->hparams, c->d_list.d, c->n_fast_leaf,
-					vpw, ysplit, c->d_ustage.d, c->stream, solo ? (void *)e1 : nullptr))
+					vpw, ysplit, c->d_ustage.d, c->stream, solo ? (void *)e1 : nullptr, &pend.c[pend.n]))
 				return c->fail(A2AMD_EHIP, "fast leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+			if(pend.c[pend.n].nlist)
+				++pend.n;
 			++c->stats.launches;
 		}
 		if(c->n_osc2_leaf) {
 			int vpw, ysplit;
 			pick_fast_shape(c->n_osc2_leaf, c->nfrags * 2, &vpw, &ysplit);	// 4-fragment chunks
 			if(a2d_launch_leaf_osc2pan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf, c->n_osc2_leaf,
-					vpw, ysplit, c->d_ustage.d, c->stream))
+					vpw, ysplit, c->d_ustage.d, c->stream, &pend.c[pend.n]))
 				return c->fail(A2AMD_EHIP, "2-osc leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+			if(pend.c[pend.n].nlist)
+				++pend.n;
 			++c->stats.launches;
 		}
 		if(c->n_filt_leaf) {
@@ -1074,8 +1089,11 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		if(e1 && !(c->n_fast_leaf && !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn))
 			HIPCHK(c, hipEventRecord(e1, c->stream));
 		for(int d = (int)c->depth_ranges.size() - 1; d >= 1; --d)
-			if(int r = launch_depth(c, d, consume))
+			if(int r = launch_depth(c, d, consume, &pend))
 				return r;
+		// (the ROOT phase may run elsewhere, or later: nothing stays pending across calls)
+		if(!(phases & A2AMD_RENDER_ROOT))
+			flush_commits();
 	}
 	if(phases & A2AMD_RENDER_ROOT) {
 		// The root chain adds into the master bus.  When its phase runs on its own
@@ -1085,8 +1103,9 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			HIPCHK(c, hipMemsetAsync(c->d_busmem.d, 0,
 					(size_t)c->nfrags * c->cfg.channels * A2D_FRAG * sizeof(int32_t), c->stream));
 		if(!c->depth_ranges.empty())
-			if(int r = launch_depth(c, 0, consume))
+			if(int r = launch_depth(c, 0, consume, &pend))
 				return r;
+		flush_commits();
 		if(e2)
 			HIPCHK(c, hipEventRecord(e2, c->stream));
 		c->stats.fragments += c->nfrags;
