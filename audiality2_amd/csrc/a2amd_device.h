@@ -108,6 +108,9 @@ enum { XW_SLOT = 0, XW_MODE = 1 };
 #define A2D_XIO_HALF ((size_t)A2D_MAXBATCH * 8 * A2D_FRAG)	// words per direction of a slot
 #define A2D_XIO_SLOT (2 * A2D_XIO_HALF)
 
+#ifndef A2D_FAST_FCH
+#define A2D_FAST_FCH 8	// k_leaf_oscpan: fragments per chunk (the host sizes the time slices by it)
+#endif
 #define A2D_MAXBATCH 256
 #define A2D_MAXVPW   32       // voices one wavefront may walk per fragment
 

@@ -32,7 +32,7 @@
 #include "a2amd_fm.h"
 
 #define FAST_WPB   4		// wavefronts per workgroup
-#define FAST_FCH   8		// fragments whose bus sums stay in registers at a time
+#define FAST_FCH   A2D_FAST_FCH	// fragments whose bus sums stay in registers at a time
 
 DEV int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
 DEV int rdl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }

@@ -880,7 +880,7 @@ int upload(a2amd_ctx *c)
 // that their sum reaches the bus in one atomic instead of four, at most 32.
 void pick_fast_shape(int n, int nfrags, int *vpw, int *ysplit)
 {
-	const int nchunks = (nfrags + 7) / 8;
+	const int nchunks = (nfrags + A2D_FAST_FCH - 1) / A2D_FAST_FCH;
 	int y = getenv("A2AMD_YSPLIT") ? atoi(getenv("A2AMD_YSPLIT")) : 32;
 	y = std::min(std::max(y, 1), nchunks);
 	int v = getenv("A2AMD_VPW") ? atoi(getenv("A2AMD_VPW")) :
@@ -1025,7 +1025,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		}
 		if(c->n_osc2_leaf) {
 			int vpw, ysplit;
-			pick_fast_shape(c->n_osc2_leaf, c->nfrags * 2, &vpw, &ysplit);	// 4-fragment chunks
+			pick_fast_shape(c->n_osc2_leaf, c->nfrags * A2D_FAST_FCH / 4, &vpw, &ysplit);	// (its chunks are 4 fragments)
 			if(a2d_launch_leaf_osc2pan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf, c->n_osc2_leaf,
 					vpw, ysplit, c->d_ustage.d, c->stream, &pend.c[pend.n]))
 				return c->fail(A2AMD_EHIP, "2-osc leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
