@@ -379,6 +379,7 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 		dv[DV_SETTLED] = settled ? 1 : 0;
 	}
 	const unsigned long long unsettled_mask = __ballot(mine && !dv[DV_SETTLED]);
+	const unsigned long long settled_mask = __ballot(mine && dv[DV_SETTLED]);
 
 	// ---- settled voices: this slice's chunks ---------------------------------
 	for(int c = c_lo; c < c_hi; ++c) {
@@ -393,9 +394,20 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 		for(int j = 0; j < FAST_FCH; ++j)
 			nfr[j] = (j < nf) ? frames_of(ffr, f0 + j) : 0;
 		const unsigned before = (unsigned)frames_of(fst, f0);
+		// frames from the start of the chunk to each of its fragments (SGPRs)
+		unsigned pre[FAST_FCH];
+		pre[0] = 0;
+#pragma unroll
+		for(int j = 1; j < FAST_FCH; ++j)
+			pre[j] = pre[j - 1] + (unsigned)nfr[j - 1];
+		// where each lane's voice stands when the chunk begins: one vector
+		// multiply-add per lane instead of a scalar one per voice
+		const uint64_t lbase = ((((uint64_t)(unsigned)sv[SV_PHLO]) | ((uint64_t)(unsigned)sv[SV_PHHI] << 32)) >>
+				(unsigned)dv[DV_MM]) + (uint64_t)before * (unsigned)dv[DV_DPH];
+		const int base_lo = (int)(unsigned)lbase, base_hi = (int)(unsigned)(lbase >> 32);
 		int cur_off = rdl(my_off, 0), cur_nch = rdl(my_nch, 0);
 		for(int v = 0; v < nv; ++v) {
-			if(!rdl(dv[DV_SETTLED], v))
+			if(!((settled_mask >> v) & 1ull))
 				continue;
 			const int voff = rdl(my_off, v);
 			if(voff != cur_off) {
@@ -403,22 +415,31 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 				cur_off = voff;
 				cur_nch = rdl(my_nch, v);
 			}
-			const unsigned mm = (unsigned)rdl(dv[DV_MM], v), dph = (unsigned)rdl(dv[DV_DPH], v);
+			const unsigned dph = (unsigned)rdl(dv[DV_DPH], v);
 			const unsigned sizem = (unsigned)rdl(dv[DV_SIZEM], v), doff = (unsigned)rdl(dv[DV_DOFF], v);
 			const int v0 = rdl(dv[DV_V0], v), v1 = rdl(dv[DV_V1], v), amp = rdl(sv[SV_A], v);
-			const uint64_t phase = (uint64_t)(unsigned)rdl(sv[SV_PHLO], v) |
-					((uint64_t)(unsigned)rdl(sv[SV_PHHI], v) << 32);
 			const unsigned dph16 = dph >> 16;
 			// The phase fragment f starts from is ((phase >> mm) + frames_before(f) * dph)
 			// mod (size << 24): the reference's "ph %= size << 24; ...; ph += frames * dph"
 			// per fragment (wtosc.c:259-285) is addition mod size << 24.
-			uint64_t ph = (phase >> mm) + (uint64_t)before * dph;
+			uint64_t ph = (uint64_t)(unsigned)rdl(base_lo, v) | ((uint64_t)(unsigned)rdl(base_hi, v) << 32);
 			uint64_t phs[FAST_FCH];
+			if(!(sizem & (sizem - 1)) && !(ph >> 48)) {
+				// a power-of-two size (the built-in waves and their mip levels):
+				// the modulus is a mask - every fragment of the chunk straight
+				// from the base, no chain, no branches
+				const uint64_t mask = ((uint64_t)sizem << 24) - 1;
 #pragma unroll
-			for(int j = 0; j < FAST_FCH; ++j) {
-				ph = wrap_phase(ph, sizem);
-				phs[j] = ph;
-				ph += (uint64_t)dph * (unsigned)nfr[j];
+				for(int j = 0; j < FAST_FCH; ++j)
+					phs[j] = (ph + (uint64_t)dph * pre[j]) & mask;
+				ph = phs[FAST_FCH - 1] + (uint64_t)dph * (unsigned)nfr[FAST_FCH - 1];
+			} else {
+#pragma unroll
+				for(int j = 0; j < FAST_FCH; ++j) {
+					ph = wrap_phase(ph, sizem);
+					phs[j] = ph;
+					ph += (uint64_t)dph * (unsigned)nfr[j];
+				}
 			}
 			// vector pass, branch free: all wave data loads of the chunk can be
 			// in flight together (lanes past a short fragment read inside the
@@ -446,7 +467,7 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 				// what the oscillator is left with after the batch: the
 				// unwrapped end of the last fragment (wtosc.c:284)
 				const bool me = lane == v;
-				const uint64_t endph = ph << mm;
+				const uint64_t endph = ph << (unsigned)rdl(dv[DV_MM], v);
 				WRL(sv[SV_PHLO], (int)(unsigned)endph);
 				WRL(sv[SV_PHHI], (int)(unsigned)(endph >> 32));
 			}
