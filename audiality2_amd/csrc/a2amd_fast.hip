@@ -741,6 +741,11 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 			nfr[j] = (j < nf) ? frames_of(ffr, f0 + j) : 0;
 		}
 		const unsigned before = (unsigned)frames_of(fst, f0);
+		unsigned pre[OSC2_FCH];		// frames from the start of the chunk to each fragment
+		pre[0] = 0;
+#pragma unroll
+		for(int j = 1; j < OSC2_FCH; ++j)
+			pre[j] = pre[j - 1] + (unsigned)nfr[j - 1];
 		int cur_off = rdl(my_off, 0), cur_nch = rdl(my_nch, 0);
 		for(int v = 0; v < nv; ++v) {
 			if(!rdl(settled_l, v))
@@ -766,14 +771,28 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 				uint64_t ph = (phase >> mm) + (uint64_t)before * dph;
 				const uint64_t lanedph = (uint64_t)(unsigned)lane * dph;
 				const int16_t *dbase = wavepool + doff;
+				uint64_t phs[OSC2_FCH];
+				if(!(sizem & (sizem - 1)) && !(ph >> 48)) {
+					// power-of-two size: the modulus is a mask (as in k_leaf_oscpan)
+					const uint64_t mask = ((uint64_t)sizem << 24) - 1;
+#pragma unroll
+					for(int j = 0; j < OSC2_FCH; ++j)
+						phs[j] = (ph + (uint64_t)dph * pre[j]) & mask;
+					ph = phs[OSC2_FCH - 1] + (uint64_t)dph * (unsigned)nfr[OSC2_FCH - 1];
+				} else {
+#pragma unroll
+					for(int j = 0; j < OSC2_FCH; ++j) {
+						ph = wrap_phase(ph, sizem);
+						phs[j] = ph;
+						ph += (uint64_t)dph * (unsigned)nfr[j];
+					}
+				}
 #pragma unroll
 				for(int j = 0; j < OSC2_FCH; ++j) {
-					ph = wrap_phase(ph, sizem);
-					ph16[o][j] = (unsigned)((ph + lanedph) >> 16);
+					ph16[o][j] = (unsigned)((phs[j] + lanedph) >> 16);
 					ph2[o][j] = ph16[o][j] + (dph >> 17);
 					qa[o][j] = *(const Quad16 *)(dbase + (int)(ph16[o][j] >> 8) - 1);
 					qb[o][j] = *(const Quad16 *)(dbase + (int)(ph2[o][j] >> 8) - 1);
-					ph += (uint64_t)dph * (unsigned)nfr[j];
 				}
 				endph[o] = ph << mm;
 			}
