@@ -46,7 +46,7 @@ def build_oracle(force=False):
     odir = os.path.join(ROOT, "oracle")
     targets = ["restate"]
     if os.path.exists("/root/reference/src/core.c") and shutil.which("cmake"):
-        targets += ["ref", "tools"]
+        targets += ["ref", "tools", "optionb"]    # (optionb links the drop-in built just before)
     subprocess.run(["make", "-s", "-C", odir] + (["-B"] if force else []) + targets, check=True)
     return os.path.join(odir, "liba2oracle.so")
 

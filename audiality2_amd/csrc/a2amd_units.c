@@ -117,7 +117,17 @@ static void die(HOSTSTATE *hs, const char *what, int rc)
 
 static const A2P_unitdesc *orig_desc(const char *sym)
 {
+	/* the engine's own descriptor of a wrapped unit: the next definition of the
+	 * symbol in load order (interposition), or - in an engine
+	 * built with the drop-in in its unit table - the same
+	 * object under the name <sym>_cpu */
 	const A2P_unitdesc *d = (const A2P_unitdesc *)dlsym(RTLD_NEXT, sym);
+	if(!d)
+	{
+		char alt[96];
+		snprintf(alt, sizeof(alt), "%s_cpu", sym);
+		d = (const A2P_unitdesc *)dlsym(RTLD_DEFAULT, alt);
+	}
 	if(!d)
 	{
 		fprintf(stderr, "a2amd units: the engine has no %s to wrap\n", sym);

@@ -233,3 +233,20 @@ def test_dropin_xsource_and_xsink_voices(tmp_path, program, env):
     assert res[0][0] == res[1][0]
     assert res[0][1].any() == (program != "Capture" and bool(env))
     assert np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,args,frames", [c for c in CASES if c[0] in ("sustain", "scripted", "fm", "fx")])
+def test_in_tree_build_option(tmp_path, name, args, frames):
+    """INTEGRATION.md option B: the engine built WITHOUT the replaced units' sources
+    and with its four wrapped descriptors renamed <name>_cpu, linked against the
+    drop-in (oracle/Makefile: optionb) - no LD_PRELOAD involved."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_render_b")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_render_b not built")
+    out = tmp_path / f"{name}.pcm"
+    subprocess.run([exe, f"{A2S}/{name}.a2s", "Main", str(frames), "64", "48000", "2", str(out)] + args,
+                   check=True, cwd=A2S, timeout=600)
+    got = fnv1a_fragments(read_pcm(out, 2, 64))
+    want = np.load(os.path.join(GOLDEN, f"{name}.hash.npy"))
+    assert len(differing_fragments(name, got, want)) == 0
