@@ -250,3 +250,18 @@ def test_in_tree_build_option(tmp_path, name, args, frames):
     got = fnv1a_fragments(read_pcm(out, 2, 64))
     want = np.load(os.path.join(GOLDEN, f"{name}.hash.npy"))
     assert len(differing_fragments(name, got, want)) == 0
+
+
+@pytest.mark.gpu
+def test_reference_player_runs_on_the_dropin():
+    """The reference's own player, the way its benchmark script drives it
+    (benchmark/benchmark.sh: a2play -dbuffer -r44100 <song> -pSong -st500), with the
+    drop-in preloaded.  The buffer driver discards the audio, so this only checks that
+    the player runs to the end (bit-exactness is what every other test here is about)."""
+    a2play = os.path.join(ROOT, "oracle", "_ref", "a2play")
+    if not (os.path.exists(a2play) and os.path.exists(UNITS_SO)):
+        pytest.skip("oracle/_ref/a2play or liba2amd_units.so not built")
+    for script, prog in (("scripted", "Main"), ("fm", "Main")):
+        r = subprocess.run([a2play, "-dbuffer", "-r44100", f"{script}.a2s", f"-p{prog}", "-st3"], cwd=A2S,
+                           env=dict(os.environ, LD_PRELOAD=UNITS_SO), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "Offline mode" in r.stdout + r.stderr, (r.stdout + r.stderr)[-500:]
