@@ -1256,7 +1256,7 @@ void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list
 		int *src = p.busmem + vc.own_off + (size_t)f * vc.own_nch * A2D_FRAG;
 		int *dst = p.busmem + vc.out_off + (size_t)f * vc.out_nch * A2D_FRAG;
 		int i0 = src[lane], i1 = src[A2D_FRAG + lane];
-		if(consume) {
+		if(consume & 1) {
 			// every bus of this batch is read here and nowhere else: leave it
 			// zeroed for the next batch (no memset between batches)
 			src[lane] = 0;
@@ -1272,7 +1272,7 @@ void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list
 			if(v1 > lim) v1 = lim;
 		}
 		int o0 = mul64s(i0, v0, 24), o1 = mul64s(i1, v1, 24);
-		if(consume && vc.out_off == 0) {
+		if((consume & 2) && vc.out_off == 0) {
 			// ... and the master bus has one writer, the root: a plain store
 			dst[lane] = o0;
 			dst[A2D_FRAG + lane] = o1;

@@ -899,7 +899,7 @@ int pick_fast_vpw(int n)
 	return std::min(std::max(v, 1), 64);
 }
 
-int launch_depth(a2amd_ctx *c, int d, bool consume, A2DCommitSet *pend)
+int launch_depth(a2amd_ctx *c, int d, int consume, A2DCommitSet *pend)	// consume: 1 zero what is read, 2 root stores the master bus
 {
 	const DepthRange &r = c->depth_ranges[d];
 	if(r.fast_count) {
@@ -1089,7 +1089,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		if(e1 && !(c->n_fast_leaf && !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn))
 			HIPCHK(c, hipEventRecord(e1, c->stream));
 		for(int d = (int)c->depth_ranges.size() - 1; d >= 1; --d)
-			if(int r = launch_depth(c, d, consume, &pend))
+			if(int r = launch_depth(c, d, consume ? 3 : 0, &pend))
 				return r;
 		// (the ROOT phase may run elsewhere, or later: nothing stays pending across calls)
 		if(!(phases & A2AMD_RENDER_ROOT))
@@ -1099,11 +1099,13 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		// The root chain adds into the master bus.  When its phase runs on its own
 		// (multi-GPU steps: several SUBTREES phases may have gone by since the
 		// last one, audiality2_amd/shard.py) the master bus is cleared here.
-		if(!(phases & A2AMD_RENDER_SUBTREES))
+		// (... unless the root is a plain driver chain: then it stores the master bus)
+		const bool root_stores = consume || c->consume_ok;
+		if(!(phases & A2AMD_RENDER_SUBTREES) && !root_stores)
 			HIPCHK(c, hipMemsetAsync(c->d_busmem.d, 0,
 					(size_t)c->nfrags * c->cfg.channels * A2D_FRAG * sizeof(int32_t), c->stream));
 		if(!c->depth_ranges.empty())
-			if(int r = launch_depth(c, 0, consume, &pend))
+			if(int r = launch_depth(c, 0, (consume ? 1 : 0) | (root_stores ? 2 : 0), &pend))
 				return r;
 		flush_commits();
 		if(e2)
