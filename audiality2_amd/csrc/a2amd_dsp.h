@@ -87,17 +87,18 @@ DEV int mul24(int a, int b)
 DEV int hermite(const int16_t *d, unsigned ph)
 {
 	int i = (int)(ph >> 8);
-	int x = (int)(ph & 0xff) << 7;
+	const int frac = (int)(ph & 0xff);
 	int dm = d[i - 1], d0 = d[i], d1 = d[i + 1], d2 = d[i + 2];
 	int c = (d1 - dm) >> 1;
 	int a = (3 * (d0 - d1) + d2 - dm) >> 1;
 	int b = dm - d0 + c - a;
-	// |a|, |a + b|, |a + c| < 2^20 and x < 2^15: the 24 bit multiplier gives the
-	// low 32 bits of the reference's int products (wrap-around included) at
-	// full rate; spelled as the instruction, the compiler does not prove it
-	a = mul24(a, x) >> 15;
-	a = mul24(wadd(a, b), x) >> 15;
-	return d0 + (mul24(wadd(a, c), x) >> 15);
+	// The reference multiplies by x = frac << 7 in 32 bit ints (wrap-around and all)
+	// and shifts right by 15; with p = a * frac exact (|a| < 2^20, frac < 2^8) that is
+	// bits 8..24 of p, sign extended: a full-rate 24 bit multiply and a bit-field
+	// extract (spelled as instructions; the compiler does not prove the ranges)
+	a = __builtin_amdgcn_sbfe(mul24(a, frac), 8, 17);
+	a = __builtin_amdgcn_sbfe(mul24(wadd(a, b), frac), 8, 17);
+	return d0 + __builtin_amdgcn_sbfe(mul24(wadd(a, c), frac), 8, 17);
 }
 
 // wtosc_Inter, A2_HIFI build (config.h:108), wtosc.c:28-33

@@ -45,15 +45,18 @@ DEV int rdl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 // (including its wrap-around) at full rate.
 DEV int hermite4(int dm, int d0, int d1, int d2, int frac)
 {
-	int x = frac << 7;
 	int c = (d1 - dm) >> 1;
 	int a = (3 * (d0 - d1) + d2 - dm) >> 1;
 	int b = dm - d0 + c - a;
-	// (spelled as the instruction: left to itself the compiler proves the 24 bit
-	// range for one of the three only and uses the slower 32 bit multiply)
-	a = fm_mul24(a, x) >> 15;
-	a = fm_mul24(a + b, x) >> 15;
-	return d0 + (fm_mul24(a + c, x) >> 15);
+	// The reference multiplies by x = frac << 7 in 32 bit ints (wrap-around and
+	// all) and shifts right by 15.  With p = a * frac exact (|a| < 2^20, frac <
+	// 2^8), the low 32 bits of p << 7 are p's bits 0..24 moved up, so that result
+	// is bits 8..24 of p, sign extended: one full-rate 24 bit multiply and one
+	// bit-field extract, no x.  (Spelled as instructions: left to itself the
+	// compiler proves the 24 bit range for one of the three products only.)
+	a = __builtin_amdgcn_sbfe(fm_mul24(a, frac), 8, 17);
+	a = __builtin_amdgcn_sbfe(fm_mul24(a + b, frac), 8, 17);
+	return d0 + __builtin_amdgcn_sbfe(fm_mul24(a + c, frac), 8, 17);
 }
 
 // Four consecutive int16 samples as two dwords from a 2-byte aligned address
