@@ -151,6 +151,7 @@ int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const 
 int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, int nfrags, int consume,
 		const A2DCommitSet *commits, void *stream);
 int a2d_launch_commit(const A2DParams &hp, const A2DCommit &cm, void *stream);
+int a2d_launch_park(int32_t *stage, int32_t *bus, unsigned words, void *stream);
 int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
 		int vpw, void *stream);
 // runs[idx[i]] = val[i] for the few voices whose record run changed this batch

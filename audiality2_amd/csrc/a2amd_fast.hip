@@ -1819,6 +1819,24 @@ int a2d_launch_leaf_fmpan(const A2DParams *dparams, const A2DParams &hp, int kin
 	return -1;
 }
 
+// root-bus partials -> staging buffer, leaving the bus zeroed (a2amd_rootbus_copy)
+__global__ void k_park(int32_t *__restrict__ stage, int32_t *__restrict__ bus, unsigned words)
+{
+	for(unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) {
+		stage[i] = bus[i];
+		bus[i] = 0;
+	}
+}
+
+int a2d_launch_park(int32_t *stage, int32_t *bus, unsigned words, void *stream)
+{
+	if(!words)
+		return 0;
+	hipLaunchKernelGGL(k_park, dim3((words + 255) / 256 < 1024 ? (words + 255) / 256 : 1024), dim3(256), 0,
+			(hipStream_t)stream, stage, bus, words);
+	return (int)hipGetLastError();
+}
+
 int a2d_launch_commit(const A2DParams &hp, const A2DCommit &cm, void *stream)
 {
 	if(cm.nlist <= 0)

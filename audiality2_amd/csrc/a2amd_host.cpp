@@ -221,7 +221,9 @@ struct a2amd_ctx {
 	// root stores the master bus instead of adding to it - the batch needs no memset.
 	bool owners_all_driver = false;		// (static: set when the lists are rebuilt)
 	bool consume_ok = false;		// ... and none of them carries records this batch
-	bool bus_clean = false;			// bus memory behind the master bus is known to be zero
+	bool others_clean = false;		// every bus but the root's is known to be zero
+	bool root_clean = false;		// ... and the root's own bus
+	bool capturing = false;			// issue_kernels is being captured into a graph
 	int n_clients = 0;			// units whose clients are served (a2amd_unit_clients mode != 0)
 	unsigned shadow_epoch = 0;
 
@@ -569,7 +571,7 @@ int upload(a2amd_ctx *c)
 		const int32_t *before = c->d_busmem.d;
 		if(int r = grow(c, c->d_busmem, c->bus_used, 1, false)) return r;
 		if(c->d_busmem.d != before)
-			c->bus_clean = false;
+			c->others_clean = c->root_clean = false;
 	}
 	if(c->fbd_count)
 		if(int r = grow(c, c->d_fbdmem, c->fbd_count, 2 * (size_t)A2D_FBD_BUFSIZE, true)) return r;
@@ -995,7 +997,12 @@ void end_batch(a2amd_ctx *c)
 int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2)
 {
 	// (self-cleaning buses need both phases in one go: the root's bus is read in ROOT)
-	const bool consume = c->consume_ok && (phases & A2AMD_RENDER_SUBTREES) && (phases & A2AMD_RENDER_ROOT);
+	const bool has_sub = (phases & A2AMD_RENDER_SUBTREES) != 0, has_root = (phases & A2AMD_RENDER_ROOT) != 0;
+	const bool consume = c->consume_ok && has_sub && has_root;
+	// Split phases (multi-GPU steps): the group buses are read - and zeroed - in the
+	// SUBTREES phase; the root's bus by the ROOT phase on the rank that runs it, or
+	// by a2amd_rootbus_copy() when the partials are parked (shard.GroupedRootReduce).
+	const bool consume_sub = c->consume_ok && has_sub && !has_root;
 	A2DCommitSet pend;
 	pend.n = 0;
 	pend.c[0].nlist = pend.c[1].nlist = 0;
@@ -1005,9 +1012,13 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		pend.n = 0;
 	};
 	if(phases & A2AMD_RENDER_SUBTREES) {
-		if(!(consume && c->bus_clean))
+		// (a graph of a self-cleaning batch holds no memset: whoever launches it
+		// clears the buses first if they are not known to be clean, ensure_clean())
+		const bool selfclean = consume || consume_sub;
+		if(c->capturing ? !selfclean : !(selfclean && c->others_clean && c->root_clean))
 			HIPCHK(c, hipMemsetAsync(c->d_busmem.d, 0, c->bus_used * sizeof(int32_t), c->stream));
-		c->bus_clean = consume;
+		c->others_clean = selfclean;
+		c->root_clean = consume;
 		if(e0)
 			HIPCHK(c, hipEventRecord(e0, c->stream));
 		if(c->n_fast_leaf) {
@@ -1089,7 +1100,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		if(e1 && !(c->n_fast_leaf && !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn))
 			HIPCHK(c, hipEventRecord(e1, c->stream));
 		for(int d = (int)c->depth_ranges.size() - 1; d >= 1; --d)
-			if(int r = launch_depth(c, d, consume ? 3 : 0, &pend))
+			if(int r = launch_depth(c, d, consume ? 3 : consume_sub ? 1 : 0, &pend))
 				return r;
 		// (the ROOT phase may run elsewhere, or later: nothing stays pending across calls)
 		if(!(phases & A2AMD_RENDER_ROOT))
@@ -1101,12 +1112,15 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		// last one, audiality2_amd/shard.py) the master bus is cleared here.
 		// (... unless the root is a plain driver chain: then it stores the master bus)
 		const bool root_stores = consume || c->consume_ok;
-		if(!(phases & A2AMD_RENDER_SUBTREES) && !root_stores)
+		if(!has_sub && !root_stores)
 			HIPCHK(c, hipMemsetAsync(c->d_busmem.d, 0,
 					(size_t)c->nfrags * c->cfg.channels * A2D_FRAG * sizeof(int32_t), c->stream));
+		// (on its own the phase also leaves the root's bus zeroed behind it)
 		if(!c->depth_ranges.empty())
-			if(int r = launch_depth(c, 0, (consume ? 1 : 0) | (root_stores ? 2 : 0), &pend))
+			if(int r = launch_depth(c, 0, root_stores ? 3 : 0, &pend))
 				return r;
+		if(!has_sub && root_stores)
+			c->root_clean = true;
 		flush_commits();
 		if(e2)
 			HIPCHK(c, hipEventRecord(e2, c->stream));
@@ -1130,6 +1144,16 @@ void drop_graphs(a2amd_ctx *c)
 	}
 }
 
+// before a graph of a self-cleaning batch (it holds no memset) is launched
+int ensure_clean(a2amd_ctx *c)
+{
+	if(c->consume_ok && !(c->others_clean && c->root_clean)) {
+		HIPCHK(c, hipMemsetAsync(c->d_busmem.d, 0, c->bus_used * sizeof(int32_t), c->stream));
+		c->others_clean = c->root_clean = true;
+	}
+	return 0;
+}
+
 // capture 'steps' consecutive runs of the uploaded batch into one graph
 int build_graph(a2amd_ctx *c, int slot, int steps, unsigned phases = A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT)
 {
@@ -1139,11 +1163,13 @@ int build_graph(a2amd_ctx *c, int slot, int steps, unsigned phases = A2AMD_RENDE
 	int r = 0;
 	// (a captured run does not happen now: every graph starts from buses of
 	// unknown state, and what it leaves behind is noted when it is launched)
-	const bool clean = c->bus_clean;
-	c->bus_clean = false;
+	const bool oc = c->others_clean, rc = c->root_clean;
+	c->capturing = true;
 	for(int i = 0; i < steps && !r; ++i)
 		r = issue_kernels(c, phases, nullptr, nullptr, nullptr);
-	c->bus_clean = clean;
+	c->capturing = false;
+	c->others_clean = oc;
+	c->root_clean = rc;
 	e = hipStreamEndCapture(c->stream, &c->graph[slot]);
 	if(r)
 		return r;
@@ -2007,8 +2033,17 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 			c->uploaded && !c->profiling && c->stream && c->with_recs.empty() && !getenv("A2AMD_NO_GRAPH")) {
 		const int slot = kphases == A2AMD_RENDER_SUBTREES ? 2 : kphases == A2AMD_RENDER_ROOT ? 3 : 1;
 		if(c->gexec[slot] || !build_graph(c, slot, 1, kphases)) {
+			if(slot != 3)
+				if(int r = ensure_clean(c))
+					return r;
 			HIPCHK(c, hipGraphLaunch(c->gexec[slot], c->stream));
-			c->bus_clean = c->consume_ok && slot == 1;
+			if(slot == 1)
+				c->others_clean = c->root_clean = c->consume_ok;
+			else if(slot == 2) {
+				c->others_clean = c->consume_ok;
+				c->root_clean = false;
+			} else if(c->consume_ok)
+				c->root_clean = true;
 			if(kphases & A2AMD_RENDER_ROOT) {
 				c->stats.fragments += c->nfrags;
 				c->stats.voice_fragments += (uint64_t)c->nfrags * (c->list_all.size() - c->n_list_pads);
@@ -2091,14 +2126,18 @@ int a2amd_replay(a2amd_ctx *c, unsigned steps)
 	}
 	while(steps) {
 		if(graphs && steps >= (unsigned)GRAPH_STEPS) {
+			if(int r = ensure_clean(c))
+				return r;
 			HIPCHK(c, hipGraphLaunch(c->gexec[0], c->stream));
-			c->bus_clean = c->consume_ok;
+			c->others_clean = c->root_clean = c->consume_ok;
 			steps -= GRAPH_STEPS;
 			c->stats.fragments += (uint64_t)c->nfrags * GRAPH_STEPS;
 			c->stats.voice_fragments += (uint64_t)c->nfrags * (c->list_all.size() - c->n_list_pads) * GRAPH_STEPS;
 		} else if(graphs) {
+			if(int r = ensure_clean(c))
+				return r;
 			HIPCHK(c, hipGraphLaunch(c->gexec[1], c->stream));
-			c->bus_clean = c->consume_ok;
+			c->others_clean = c->root_clean = c->consume_ok;
 			--steps;
 			c->stats.fragments += c->nfrags;
 			c->stats.voice_fragments += (uint64_t)c->nfrags * (c->list_all.size() - c->n_list_pads);
@@ -2151,7 +2190,15 @@ int a2amd_rootbus_copy(a2amd_ctx *c, void *stage, int to_stage)
 		return r;
 	if(!stage)
 		return c->fail(A2AMD_EINVAL, "no staging buffer");
-	HIPCHK(c, hipMemcpyAsync(to_stage ? stage : bus, to_stage ? bus : stage, bytes, hipMemcpyDeviceToDevice, c->stream));
+	if(to_stage) {
+		// park: copy out and leave the root's bus zeroed for the next SUBTREES phase
+		if(a2d_launch_park((int32_t *)stage, (int32_t *)bus, (unsigned)(bytes / 4), c->stream))
+			return c->fail(A2AMD_EHIP, "park launch failed: %s", hipGetErrorString(hipGetLastError()));
+		c->root_clean = true;
+	} else {
+		HIPCHK(c, hipMemcpyAsync(bus, stage, bytes, hipMemcpyDeviceToDevice, c->stream));
+		c->root_clean = false;
+	}
 	return A2AMD_OK;
 }
 
