@@ -448,15 +448,18 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 			// in flight together (lanes past a short fragment read inside the
 			// A2_WAVEPOST pad and are masked at the sum)
 			const uint64_t lanedph = (uint64_t)(unsigned)lane * dph;
-			const int16_t *dbase = wavepool + doff;
+			// (uniform base one sample early + an unsigned 32 bit byte offset per
+			// lane: the loads take the scalar-base addressing form, no 64 bit adds)
+			const char *dm1 = (const char *)(wavepool + doff - 1);
 			Quad16 qa[FAST_FCH], qb[FAST_FCH];
 			unsigned ph16[FAST_FCH], ph2[FAST_FCH];
 #pragma unroll
 			for(int j = 0; j < FAST_FCH; ++j) {
 				ph16[j] = (unsigned)((phs[j] + lanedph) >> 16);
+				asm("" : "+v"(ph16[j]));	// (keeps the offset a 32 bit value in the compiler's eyes)
 				ph2[j] = ph16[j] + (dph16 >> 1);
-				qa[j] = *(const Quad16 *)(dbase + (int)(ph16[j] >> 8) - 1);
-				qb[j] = *(const Quad16 *)(dbase + (int)(ph2[j] >> 8) - 1);
+				qa[j] = *(const Quad16 *)(dm1 + (size_t)((ph16[j] >> 7) & ~1u));
+				qb[j] = *(const Quad16 *)(dm1 + (size_t)((ph2[j] >> 7) & ~1u));
 			}
 #pragma unroll
 			for(int j = 0; j < FAST_FCH; ++j) {
@@ -793,9 +796,10 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 #pragma unroll
 				for(int j = 0; j < OSC2_FCH; ++j) {
 					ph16[o][j] = (unsigned)((phs[j] + lanedph) >> 16);
+					asm("" : "+v"(ph16[o][j]));	// (32 bit offsets: scalar-base loads, as in k_leaf_oscpan)
 					ph2[o][j] = ph16[o][j] + (dph >> 17);
-					qa[o][j] = *(const Quad16 *)(dbase + (int)(ph16[o][j] >> 8) - 1);
-					qb[o][j] = *(const Quad16 *)(dbase + (int)(ph2[o][j] >> 8) - 1);
+					qa[o][j] = *(const Quad16 *)((const char *)(dbase - 1) + (size_t)((ph16[o][j] >> 7) & ~1u));
+					qb[o][j] = *(const Quad16 *)((const char *)(dbase - 1) + (size_t)((ph2[o][j] >> 7) & ~1u));
 				}
 				endph[o] = ph << mm;
 			}
