@@ -463,7 +463,7 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 			}
 #pragma unroll
 			for(int j = 0; j < FAST_FCH; ++j) {
-				int sm = (dbg & 2) ? (int)ph16[j] : inter_quads(qa[j], qb[j], ph16[j], ph2[j]);
+				int sm = inter_quads(qa[j], qb[j], ph16[j], ph2[j]);
 				int x = mul64s(sm, amp, 17);
 				x = (lane < nfr[j]) ? x : 0;
 				acc0[j] = wadd(acc0[j], mul64s(x, v0, 24));
