@@ -447,7 +447,16 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 			// vector pass, branch free: all wave data loads of the chunk can be
 			// in flight together (lanes past a short fragment read inside the
 			// A2_WAVEPOST pad and are masked at the sum)
-			const uint64_t lanedph = (uint64_t)(unsigned)lane * dph;
+			// (lane * dph once per voice; opaque to the compiler, which otherwise
+			// re-does the half-rate 64 bit multiply-add for every fragment)
+			unsigned ldl, ldh;
+			{
+				const uint64_t t = (uint64_t)(unsigned)lane * dph;
+				ldl = (unsigned)t;
+				ldh = (unsigned)(t >> 32);
+				asm("" : "+v"(ldl), "+v"(ldh));
+			}
+			const uint64_t lanedph = (uint64_t)ldl | ((uint64_t)ldh << 32);
 			// (uniform base one sample early + an unsigned 32 bit byte offset per
 			// lane: the loads take the scalar-base addressing form, no 64 bit adds)
 			const char *dm1 = (const char *)(wavepool + doff - 1);
