@@ -304,6 +304,24 @@ struct a2amd_ctx {
 	hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
 	int32_t *h_master = nullptr;	// pinned
 	size_t h_master_cap = 0;
+	// Identical-batch fast path: a batch without records, with the same fragment
+	// lengths as the one uploaded before it and nothing changed in between (no
+	// births, deaths, waves, clients) finds everything it needs on the device
+	// already - no blob, no copy - and its launch sequence in a graph.
+	bool blob_quiet = false;		// the uploaded blob describes a record-free batch
+	int blob_nfrags = 0;
+	unsigned blob_frames[A2D_MAXBATCH];
+	int quiet_streak = 0;			// consecutive batches that took the fast path
+	// A2AMD_RENDER_ASYNC: master-bus readbacks in flight (a2amd_collect delivers them)
+	struct Readback {
+		int32_t *h = nullptr;		// pinned
+		size_t cap = 0;
+		hipEvent_t ev = nullptr;
+		int nfrags = 0;
+		unsigned total = 0;
+		uint8_t frames[A2D_MAXBATCH];
+	} rb[2];
+	int rb_head = 0, rb_count = 0;
 
 	a2amd_stats stats;
 
@@ -557,6 +575,24 @@ bool is_driver_chain(const a2amd_ctx *c, const HVoice &v)
 
 int upload(a2amd_ctx *c)
 {
+	if(c->blob_quiet && c->with_recs.empty() && c->prev_with_recs.empty() && !c->voices_dirty &&
+			!c->udesc_dirty && !c->waves_dirty && !c->lists_dirty && !c->ptab_dirty &&
+			c->dirty_voices.empty() && c->fbd_to_zero.empty() && c->nfrags == c->blob_nfrags &&
+			c->bus_used <= c->d_busmem.cap &&
+			!memcmp(c->fragframes, c->blob_frames, (size_t)c->nfrags * sizeof(unsigned))) {
+		bool inject = false;
+		for(const XioSlot &x : c->xio)
+			if(x.unit >= 0 && (x.inj_used || (c->units[x.unit].xio_mode & A2AMD_XIO_INJECT)))
+				inject = true;
+		if(!inject) {
+			// the same quiet batch again: the device has it all (graphs stay valid)
+			++c->quiet_streak;
+			c->uploaded = true;
+			return 0;
+		}
+	}
+	c->blob_quiet = false;
+	c->quiet_streak = 0;
 	drop_graphs(c);
 	const size_t nv = c->voices.size(), nu = c->units.size();
 	// capacities
@@ -872,6 +908,9 @@ int upload(a2amd_ctx *c)
 				(int)nsc, c->d_runs.d, c->stream))
 			return c->fail(A2AMD_EHIP, "scatter launch failed");
 	c->uploaded = true;
+	c->blob_quiet = recs.empty() && dyn_all.empty();
+	c->blob_nfrags = c->nfrags;
+	memcpy(c->blob_frames, c->fragframes, (size_t)c->nfrags * sizeof(unsigned));
 	return 0;
 }
 
@@ -933,7 +972,7 @@ int pick_vpw(int n)
 
 void end_batch(a2amd_ctx *c)
 {
-	drop_graphs(c);
+	// (graphs survive: upload() drops them unless the next batch is the same quiet one)
 	// Records made after the last fragment of the batch was closed belong to
 	// the first fragment of the next batch: carry them over.
 	const int done = c->nfrags;
@@ -1267,6 +1306,7 @@ void a2amd_close(a2amd_ctx *c)
 	for(int k = 0; k < 2; ++k) { if(c->h_blob[k]) hipHostFree(c->h_blob[k]); if(c->blob_ev[k]) hipEventDestroy(c->blob_ev[k]); }
 	if(c->h_master)
 		hipHostFree(c->h_master);
+	for(int k = 0; k < 2; ++k) { if(c->rb[k].h) hipHostFree(c->rb[k].h); if(c->rb[k].ev) hipEventDestroy(c->rb[k].ev); }
 	for(hipEvent_t e : c->ev_pool)
 		hipEventDestroy(e);
 	if(c->own_stream)
@@ -2026,11 +2066,13 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		c->ev2 = c->ev_pool[c->ev_used + 2];
 		c->ev_used += 3;
 	}
-	// Re-running a kept, record-free batch phase by phase (multi-GPU steps): one
-	// graph launch per phase instead of 3-5 separate commands.
+	// A record-free batch that has been seen before runs from a graph - one launch
+	// instead of 3-5 separate commands: a kept batch re-run phase by phase
+	// (multi-GPU steps), or the engine recording the same quiet batch again.
 	const unsigned kphases = phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT);
-	if((phases & A2AMD_RENDER_KEEP) && kphases && kphases == (phases & ~A2AMD_RENDER_KEEP) &&
-			c->uploaded && !c->profiling && c->stream && c->with_recs.empty() && !getenv("A2AMD_NO_GRAPH")) {
+	bool issued = false;
+	if(kphases && c->uploaded && !c->profiling && c->stream && c->with_recs.empty() && !getenv("A2AMD_NO_GRAPH") &&
+			((phases & A2AMD_RENDER_KEEP) ? kphases == (phases & ~A2AMD_RENDER_KEEP) : c->quiet_streak >= 1)) {
 		const int slot = kphases == A2AMD_RENDER_SUBTREES ? 2 : kphases == A2AMD_RENDER_ROOT ? 3 : 1;
 		if(c->gexec[slot] || !build_graph(c, slot, 1, kphases)) {
 			if(slot != 3)
@@ -2048,12 +2090,12 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 				c->stats.fragments += c->nfrags;
 				c->stats.voice_fragments += (uint64_t)c->nfrags * (c->list_all.size() - c->n_list_pads);
 			}
-			return (int)total;
+			issued = true;
 		}
 	}
 	// Events only when profiling (each one from the pool, used once until read):
 	// re-recording an event the GPU has not reached yet makes the runtime wait.
-	if(phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT))
+	if(kphases && !issued)
 		if(int r = c->profiling ? issue_kernels(c, phases, c->ev0, c->ev1, c->ev2) :
 				issue_kernels(c, phases, nullptr, nullptr, nullptr))
 			return r;
@@ -2065,6 +2107,36 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 	if(phases & A2AMD_RENDER_READBACK) {
 		const int nch = c->cfg.channels;
 		size_t n = (size_t)c->nfrags * nch * A2D_FRAG;
+		if(phases & A2AMD_RENDER_ASYNC) {
+			// enqueue the copy and return: a2amd_collect() waits for it and fills
+			// the caller's buffers, up to two batches later
+			for(const XioSlot &x : c->xio)
+				if(x.unit >= 0 && x.tapped)
+					return c->fail(A2AMD_EUNSUPPORTED, "asynchronous readback with READ clients attached");
+			if(c->rb_count == 2)
+				return c->fail(A2AMD_ESTATE, "two readbacks in flight: a2amd_collect() first");
+			a2amd_ctx::Readback &rb = c->rb[(c->rb_head + c->rb_count) & 1];
+			if(n > rb.cap) {
+				if(rb.h)
+					HIPCHK(c, hipHostFree(rb.h));
+				rb.h = nullptr;
+				rb.cap = 0;
+				HIPCHK(c, hipHostMalloc((void **)&rb.h, n * sizeof(int32_t), hipHostMallocDefault));
+				rb.cap = n;
+			}
+			if(!rb.ev)
+				HIPCHK(c, hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming));
+			HIPCHK(c, hipMemcpyAsync(rb.h, c->d_busmem.d, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipEventRecord(rb.ev, c->stream));
+			rb.nfrags = c->nfrags;
+			rb.total = total;
+			for(int f = 0; f < c->nfrags; ++f)
+				rb.frames[f] = (uint8_t)c->fragframes[f];
+			++c->rb_count;
+			if(!(phases & A2AMD_RENDER_KEEP))
+				end_batch(c);
+			return (int)total;
+		}
 		if(!out)
 			return c->fail(A2AMD_EINVAL, "readback without output buffers");
 		if(total > cap)
@@ -2105,6 +2177,29 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 	if(!(phases & A2AMD_RENDER_KEEP) && (phases & (A2AMD_RENDER_READBACK | A2AMD_RENDER_ROOT)))
 		end_batch(c);
 	return (int)total;
+}
+
+int a2amd_collect(a2amd_ctx *c, int32_t *const *out, unsigned cap)
+{
+	use_device(c);
+	if(!c->rb_count)
+		return 0;
+	a2amd_ctx::Readback &rb = c->rb[c->rb_head];
+	if(!out)
+		return c->fail(A2AMD_EINVAL, "collect without output buffers");
+	if(rb.total > cap)
+		return c->fail(A2AMD_EINVAL, "output capacity %u < %u frames", cap, rb.total);
+	HIPCHK(c, hipEventSynchronize(rb.ev));
+	const int nch = c->cfg.channels;
+	unsigned pos = 0;
+	for(int f = 0; f < rb.nfrags; ++f) {
+		for(int ch = 0; ch < nch; ++ch)
+			memcpy(out[ch] + pos, rb.h + ((size_t)f * nch + ch) * A2D_FRAG, rb.frames[f] * sizeof(int32_t));
+		pos += rb.frames[f];
+	}
+	c->rb_head ^= 1;
+	--c->rb_count;
+	return (int)rb.total;
 }
 
 int a2amd_replay(a2amd_ctx *c, unsigned steps)

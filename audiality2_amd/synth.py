@@ -115,18 +115,25 @@ class Scene:
                       be.unit_init(k, K_XINSERT, PROCADD, channels, channels, 1)]
         return self.rootv
 
-    def add_group(self, fb=(63.1, 75.6, 100.4), gains=(0.3, 0.25, 0.25)):
-        """inline 0 *; fbdelay * *; fbdelay * >   (benchmark/fmtest4.a2s shape)"""
+    # the two delays of benchmark/fmtest4.a2s:83-95 (tempo 120 4: a tick is 125 ms):
+    # (fbdelay, ldelay, rdelay) in ms and (fbgain, lgain, rgain)
+    FMTEST4 = (((631.25, 756.25, 1003.75), (0.03, 0.05, 0.05)),
+               ((868.75, 1126.25, 1378.75), (0.03, 0.05, 0.05)))
+
+    def add_group(self, fb=(63.1, 75.6, 100.4), gains=(0.3, 0.25, 0.25), preset=None):
+        """inline 0 *; fbdelay * *; fbdelay * >   (benchmark/fmtest4.a2s shape);
+        preset="fmtest4": that song's own delay times and gains (BASELINE configs[3])"""
         be, k = self.be, self._key()
         u = [be.unit_init(k, K_INLINE, 0, 0, 2, 0),
              be.unit_init(k, K_FBDELAY, 0, 2, 2, 0),
              be.unit_init(k, K_FBDELAY, PROCADD, 2, 2, 1)]
-        for d in (u[1], u[2]):
-            for reg, ms in enumerate(fb):
+        for i, d in enumerate((u[1], u[2])):
+            dfb, dg = self.FMTEST4[i] if preset == "fmtest4" else (fb, gains)
+            for reg, ms in enumerate(dfb):
                 be.unit_write(d, reg, fix(ms))
-            be.unit_write(d, 4, fix(gains[0]))
-            be.unit_write(d, 5, fix(gains[1]))
-            be.unit_write(d, 6, fix(gains[2]))
+            be.unit_write(d, 4, fix(dg[0]))
+            be.unit_write(d, 5, fix(dg[1]))
+            be.unit_write(d, 6, fix(dg[2]))
         g = dict(units=u, leaves=[])
         self.groups.append(g)
         return g

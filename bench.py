@@ -1,25 +1,37 @@
 #!/usr/bin/env python3
 """bench.py - voice-samples/sec of the MI355X voice-render path.
 
-Workload (BASELINE.json configs[1]): 1 024 sustained voices, wtosc -> panmix,
-48 kHz, fragment = 64 frames, stereo, per GPU.  One "step" = one batch of
---batch fragments (default 256 = 16384 frames = 341 ms of audio, an offline
-a2_Run() buffer) rendered for all voices: upload happened before the timed
-region (the command stream of sustained voices is empty and identical for every
-batch, so the same uploaded batch is re-run; each run renders the NEXT 341 ms
-of audio).
+Default workload = BASELINE.json configs[3], the largest single-GPU config:
+65 536 sustained leaf voices, each `wtosc; wtosc(add); panmix`, 256 per group
+voice `inline; fbdelay; fbdelay` with the delay settings of the reference's
+benchmark/fmtest4.a2s:83-95 (256 groups, 512 fbdelay instances), 48 kHz,
+fragment = 64 frames, stereo.  --config 1 / 2 select configs[1] (1 024 x
+wtosc->panmix) and configs[2] (16 384 x wtosc->filter12->panmix); both are
+also run briefly and reported as extra keys of the default line.
+
+One "step" = one offline a2_Run() buffer of --batch fragments (default 256 =
+16 384 frames = 341 ms of audio) rendered for all voices THROUGH THE PRODUCT
+ENTRY POINTS: a2amd_fragment_repeat() records the batch (an engine whose VMs all
+sleep), a2amd_render(UPLOAD | SUBTREES | ROOT | READBACK | ASYNC) renders it and
+enqueues the master bus for the host, a2amd_collect() delivers the previous
+step's audio into host buffers while the GPU renders the next one.  Every step's
+audio reaches the host inside the timed region; steps covered by the committed
+oracle golden (tests/golden/bench_cfg*.hash.npy, made by make_bench_golden.py)
+are compared hash by hash per fragment, the rest by a steady-state check.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns
-its own voice subtrees (weak scaling: --voices per GPU); per step each rank
-renders its subtrees into its partial of the root voice's inline bus, the
-partials are summed with ONE RCCL reduce (int32, wrap-around sum => exact in
-any order), and rank 0 runs the root chain (panmix must see the sum,
+its own voice subtrees (weak scaling: the config's voices per GPU); per step
+each rank renders its subtrees into its partial of the root voice's inline bus,
+the partials are summed with ONE RCCL reduce (int32, wrap-around sum => exact
+in any order), and rank 0 runs the root chain (panmix must see the sum,
 SURVEY.md 8e).
 
 Prints one JSON line (rank 0).  Extra objects: "roofline" (the dominant kernel
-against the HBM roofline, timed with HIP events on the launch stream inside
-the timed region) and "cpu_baseline" (the compiled reference, or the C port,
-timed on this host's cores on a bounded sample of the same workload).
+against the HBM roofline, timed with HIP events on the launch stream),
+"roofline_valu" (the same kernel against the integer-VALU issue rate, from the
+PMC instruction counts under profiles/), "realtime" (measured per-fragment round
+trips at this voice count) and "cpu_baseline" (the compiled reference timed on
+this host's cores on a bounded sample of the same workload).
 """
 import argparse
 import ctypes
@@ -34,15 +46,32 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BYTES_PER_VOICE_SAMPLE = {          # algorithmic HBM bytes
-    "osc-pan": 504.0 / 64.0,        # 7.9 B: (152+96 B state) x2 + 8 B bus share per fragment
-    "osc-filter-pan": 792.0 / 64.0,  # 12.4 B with filter12's 144 B state
-    "osc2-pan": (504.0 + 2 * 152.0) / 64.0,
-    # fm units: 64 B of operator state per operator + panmix, read + written, + bus share
-    **{f"{k}-pan": ((64.0 * n + 96.0) * 2 + 8.0) / 64.0 for k, n in
+# algorithmic HBM bytes per voice-fragment (state read + written, bus share)
+BYTES_PER_VOICE_FRAGMENT = {
+    "osc-pan": 504.0,               # (152 + 96 B state) x 2 + 8 B bus share
+    "osc-filter-pan": 792.0,        # + filter12's 144 B x 2
+    "osc2-pan": 504.0 + 2 * 152.0,  # + the second oscillator
+    **{f"{k}-pan": (64.0 * n + 96.0) * 2 + 8.0 for k, n in
        (("fm1", 1), ("fm2", 2), ("fm3", 3), ("fm4", 4), ("fm3p", 3), ("fm4p", 4), ("fm2r", 2), ("fm4r", 4))},
 }
+FBDELAY_BYTES_PER_FRAGMENT = 24.0 * 64 + 240.0      # 6 x 4 B per sample + state per fragment
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s
+# integer VALU issue: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz (MI355X_MICROARCH.md)
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+LEAF_KERNEL = {"osc-pan": "k_leaf_oscpan", "osc-filter-pan": "k_leaf_oscfiltpan", "osc2-pan": "k_leaf_osc2pan"}
+
+CONFIGS = {   # BASELINE.json configs[i]
+    1: dict(voices=1024, chain="osc-pan", groups=0,
+            label="1024 voices wtosc->panmix under the root, 48 kHz, fragment=64, stereo (BASELINE configs[1])"),
+    2: dict(voices=16384, chain="osc-filter-pan", groups=0,
+            label="16384 voices wtosc->filter12->panmix under the root, 48 kHz, fragment=64, stereo "
+                  "(BASELINE configs[2])"),
+    3: dict(voices=65536, chain="osc2-pan", groups=256,
+            label="65536 voices 2xwtosc->panmix, 256 per group voice inline->fbdelay->fbdelay "
+                  "(benchmark/fmtest4.a2s delay settings; 256 groups, 512 fbdelays), 48 kHz, fragment=64, "
+                  "stereo (BASELINE configs[3])"),
+}
+UP, SUB, ROOTP, RB, KEEP, ASYNC = 4, 1, 2, 8, 16, 32
 
 
 class Stats(ctypes.Structure):
@@ -67,42 +96,80 @@ def fnv1a_fragments(pcm, frag=64):
     return h
 
 
-def cpu_baseline(voices, chain, oracle_fragments=600):
+def golden_path(voices, chain, groups):
+    return os.path.join(ROOT, "tests", "golden", f"bench_{chain}_{voices}v_{groups}g.hash.npy")
+
+
+def build_scene(be, voices, chain, groups, world=1, rank=0):
+    """The synthetic voice tree of a config (every rank plays different voices)."""
+    from audiality2_amd import shard, synth
+    sc = synth.Scene(be)
+    sc.root()
+    sc.nvoices = shard.voice_range(rank, voices)[0]
+    if groups:
+        per = voices // groups
+        for _ in range(groups):
+            grp = sc.add_group(preset="fmtest4")
+            sc.add_voices(per, chain=chain, group=grp, total=voices * world)
+    else:
+        sc.add_voices(voices, chain=chain, total=voices * world)
+    return sc
+
+
+def host_threads():
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(voices, chain, groups, oracle_fragments=100):
     """Reference (oracle/_ref/ref_bench) if it travelled, else the C port."""
-    program = {"osc-pan": "OscPan", "osc-filter-pan": "OscFilterPan", "osc2-pan": "Osc2Pan", "fm1-pan": "Fm1Pan", "fm2-pan": "Fm2Pan",
-               "fm4-pan": "Fm4Pan"}.get(chain)
+    program = {"osc-pan": "OscPan", "osc-filter-pan": "OscFilterPan", "osc2-pan": "Osc2Pan", "fm1-pan": "Fm1Pan",
+               "fm2-pan": "Fm2Pan", "fm4-pan": "Fm4Pan"}.get(chain)
+    if groups and chain == "osc2-pan":
+        program = "Osc2PanGroups"
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
     script = os.path.join(ROOT, "tests", "a2s", "bench.a2s")
-    ncores = os.cpu_count() or 1
+    ncores = host_threads()
     if program and os.path.exists(exe):
-        frags = {"osc-pan": 7500, "fm4-pan": 1000, "fm2-pan": 2500}.get(chain, 4000)   # a few seconds of one core
+        # about 10 s of one core at ~1e8 (2 oscillators) .. 2e8 voice-samples/s
+        per_frag = voices * 64.0
+        frags1 = int(max(50, min(7500, 1.5e9 / per_frag)))
+        # every thread is an independent engine state and needs whole groups
+        tmax = min(ncores, max(1, voices // 256))
         res = {}
-        for threads in sorted({1, min(ncores, 16)}):
+        for threads in sorted({1, tmax}):
+            frags = frags1 if threads == 1 else int(min(7500, frags1 * min(threads, 16)))
             try:
                 out = subprocess.run([exe, script, program, str(voices), str(frags), str(threads)],
-                                     capture_output=True, text=True, timeout=180, check=True).stdout
+                                     capture_output=True, text=True, timeout=300, check=True).stdout
                 res[threads] = json.loads(out.strip().splitlines()[-1])
+                if res[threads].get("active_voices", 0) < res[threads].get("voices", 0):
+                    res[threads] = {"error": f"only {res[threads].get('active_voices')} voices came up"}
             except Exception as e:  # noqa: BLE001
                 res[threads] = {"error": str(e)}
         ok = {t: r for t, r in res.items() if "voice_samples_per_s" in r}
         if ok:
             best = max(ok, key=lambda t: ok[t]["voice_samples_per_s"])
-            return {"value": ok[best]["voice_samples_per_s"], "unit": "voice-samples/s", "cores": best,
+            r = ok[best]
+            return {"value": r["voice_samples_per_s"], "unit": "voice-samples/s", "cores": best,
                     "kind": "reference",
                     "single_thread_value": ok.get(1, {}).get("voice_samples_per_s"),
                     "host_cores": ncores,
-                    "sample": f"{voices} voices {chain}, {frags} fragments of 64 frames "
-                              f"({frags * 64 / 48000:.1f} s of audio), reference engine via a2_Run(64), "
-                              f"{best} thread(s) = {best} independent engine states"}
+                    "sample": f"{r['voices']} voices {chain}" + (f" in groups of 256 (inline->fbdelay->fbdelay)" if groups else "")
+                              + f", {r['fragments']} fragments of 64 frames ({r['fragments'] * 64 / 48000:.2f} s of audio), "
+                              f"the compiled reference engine via a2_Run(64), {best} thread(s) = {best} independent "
+                              f"engine states (the reference is single-threaded per state); {r['seconds']:.1f} s wall",
+                    "errors": {str(t): r["error"] for t, r in res.items() if "error" in r} or None}
     # the C restatement, driven through the same call protocol
     from audiality2_amd import synth
     from audiality2_amd.replay import Backend
     lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liba2oracle.so"))
     be = Backend(lib, "a2o_", 48000, synth.basepitch_for(48000), 2)
-    sc = synth.Scene(be)
-    sc.root()
-    sc.add_voices(voices, chain=chain)
-    sc.run(1, batch=1)
+    sc = build_scene(be, voices, chain, groups)
+    sc.walk(64)
+    be.render(64)
     lib.a2o_fragment_repeat.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
     t0 = time.perf_counter()
     done = 0
@@ -115,25 +182,248 @@ def cpu_baseline(voices, chain, oracle_fragments=600):
     be.close()
     return {"value": voices * 64.0 * oracle_fragments / dt, "unit": "voice-samples/s", "cores": 1,
             "kind": "port", "host_cores": ncores,
-            "sample": f"{voices} voices {chain}, {oracle_fragments} fragments of 64 frames, "
+            "sample": f"{voices} voices {chain}, {groups} groups, {oracle_fragments} fragments of 64 frames, "
                       f"C restatement (oracle/a2o.c), 1 thread"}
+
+
+def pmc_entry(chain, voices, groups, B):
+    """PMC-derived figures for this workload's dominant kernel (profiles/*.json, tools/pmc_summary.py)."""
+    key = f"{chain}/{voices}/{groups}/{B}"
+    for name in ("r02_pmc.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if key in d:
+            return d[key]
+        old = f"{chain}/{voices}/{B}"
+        if not groups and old in d:
+            return d[old]
+    return {}
+
+
+class Runner:
+    """One config on one GPU through the product entry points."""
+
+    def __init__(self, audiality2_amd, voices, chain, groups, B, device=0):
+        self.voices, self.chain, self.groups, self.B = voices, chain, groups, B
+        self.be = audiality2_amd.open_backend(48000, None, 2, device=device, max_batch=B)
+        lib = self.lib = self.be.lib
+        lib.a2amd_fragment_repeat.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
+        lib.a2amd_get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
+        lib.a2amd_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.a2amd_collect.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.POINTER(ctypes.c_int32)), ctypes.c_uint]
+        lib.a2amd_collect.restype = ctypes.c_int
+        self.frames = B * 64
+        self.bufs = [np.zeros((2, self.frames), dtype=np.int32) for _ in range(2)]
+        self.ptrs = []
+        for b in self.bufs:
+            p = (ctypes.POINTER(ctypes.c_int32) * 2)()
+            for c in range(2):
+                p[c] = b[c].ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+            self.ptrs.append(p)
+        self.sc = build_scene(self.be, voices, chain, groups)
+        self.step_no = 0            # steps issued
+        self.got = 0                # steps collected
+        self.kept = {}              # step -> audio (the steps the golden covers, and the last one)
+        self.keep_upto = 0
+        self.last = None
+
+    def err(self):
+        return RuntimeError(self.be._err(self.be.ctx).decode(errors="replace"))
+
+    def issue(self):
+        if self.step_no == 0:
+            self.sc.walk(64)        # the explicit engine walk: voice inits + control writes
+            n = self.B - 1
+        else:
+            n = self.B
+        if n and self.lib.a2amd_fragment_repeat(self.be.ctx, 64, n):
+            raise self.err()
+        if self.be._render(self.be.ctx, UP | SUB | ROOTP | RB | ASYNC, None, 0) < 0:
+            raise self.err()
+        self.step_no += 1
+
+    def collect(self):
+        k = self.got & 1
+        if self.lib.a2amd_collect(self.be.ctx, self.ptrs[k], self.frames) != self.frames:
+            raise self.err()
+        if self.got < self.keep_upto:
+            self.kept[self.got] = self.bufs[k].copy()
+        self.last = self.bufs[k]
+        self.got += 1
+
+    def run(self, nsteps):
+        """nsteps steps, every one delivered to host buffers; at most two in flight."""
+        for _ in range(nsteps):
+            self.issue()
+            if self.step_no - self.got == 2:
+                self.collect()
+        while self.got < self.step_no:
+            self.collect()
+
+    def profile(self, nsteps):
+        """Same steps with every launch bracketed by HIP events on the launch stream."""
+        self.lib.a2amd_set_profiling(self.be.ctx, 1)
+        self.run(nsteps)
+        st = Stats()
+        self.lib.a2amd_get_stats(self.be.ctx, ctypes.byref(st))
+        self.lib.a2amd_set_profiling(self.be.ctx, 0)
+        n = max(st.timed_batches, 1)
+        return st.timed_leaf_ms / n, st.timed_all_ms / n, int(st.timed_batches)
+
+    def realtime(self, n=300):
+        """One 64-frame fragment per render, full synchronous round trip (records up,
+        kernels, master bus back): what a realtime driver with buffer=64 would see of
+        the GPU side (the engine's own voice walk is not in it)."""
+        out = np.zeros((2, 64), dtype=np.int32)
+        p = (ctypes.POINTER(ctypes.c_int32) * 2)()
+        for c in range(2):
+            p[c] = out[c].ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        ts = []
+        for i in range(n + 20):
+            t0 = time.perf_counter()
+            if self.lib.a2amd_fragment_repeat(self.be.ctx, 64, 1):
+                raise self.err()
+            if self.be._render(self.be.ctx, UP | SUB | ROOTP | RB, p, 64) != 64:
+                raise self.err()
+            if i >= 20:
+                ts.append((time.perf_counter() - t0) * 1e3)
+        ts = np.sort(np.array(ts))
+        budget = 64.0 / 48000.0 * 1e3
+        return {"voices": self.voices, "fragments_timed": n, "fragment_ms_p50": float(ts[len(ts) // 2]),
+                "fragment_ms_p99": float(ts[min(len(ts) - 1, int(len(ts) * 0.99))]), "fragment_ms_max": float(ts[-1]),
+                "budget_ms": budget, "holds_realtime": bool(ts[min(len(ts) - 1, int(len(ts) * 0.99))] <= budget),
+                "scope": "GPU side of one 64-frame fragment through a2amd_fragment_repeat + a2amd_render(ALL), "
+                         "synchronous; the engine's own CPU voice walk is not included"}
+
+    def close(self):
+        self.be.close()
+
+
+def check_golden(r, nsteps):
+    """Compare every rendered step the committed oracle golden covers; returns
+    (steps compared, all equal) or (0, None) without a golden for this workload."""
+    path = golden_path(r.voices, r.chain, r.groups)
+    if not os.path.exists(path):
+        return 0, None
+    gold = np.load(path)
+    n = min(len(gold) // r.B, nsteps)
+    ok = True
+    for s in range(n):
+        if s not in r.kept:
+            return s, None
+        if not np.array_equal(fnv1a_fragments(r.kept[s]), gold[s * r.B:(s + 1) * r.B]):
+            ok = False
+    return n, ok
+
+
+def golden_steps(voices, chain, groups, B):
+    path = golden_path(voices, chain, groups)
+    return len(np.load(path)) // B if os.path.exists(path) else 0
+
+
+def measure_single(audiality2_amd, cfg, B, steps, warmup, device=0, with_realtime=True):
+    """One config at N=1: returns the dict of measured figures."""
+    import gc
+    import torch
+    r = Runner(audiality2_amd, cfg["voices"], cfg["chain"], cfg["groups"], B, device)
+    gsteps = golden_steps(cfg["voices"], cfg["chain"], cfg["groups"], B)
+    r.keep_upto = gsteps
+    r.run(1)                        # step 0: voices are born
+    r.run(warmup)
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()                    # a full collection mid-loop costs tens of ms of host time
+    t0 = time.perf_counter()
+    r.run(steps)                    # (run() returns when the last step's audio is in host memory)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    total_steps = 1 + warmup + steps
+    compared, ok = check_golden(r, total_steps)
+    if ok is False:
+        raise SystemExit("bench.py: GPU render differs from the oracle golden; refusing to report a number")
+    last = r.last.copy()
+    # steady state beyond the golden: the scene is stationary, so every later step must
+    # stay within the level of the verified ones (catches silence, runaway, stuck output)
+    peak_ref = max((int(np.abs(a).max()) for a in r.kept.values()), default=None)
+    leaf_ms, all_ms, nprof = r.profile(min(steps, 32))
+    res = {"voices": cfg["voices"], "chain": cfg["chain"], "groups": cfg["groups"], "seconds": dt,
+           "value": float(cfg["voices"]) * B * 64 * steps / dt, "ms_per_step": dt / steps * 1e3,
+           "leaf_ms": leaf_ms, "all_ms": all_ms, "launches_timed": nprof,
+           "golden_steps_compared": compared, "parity_vs_golden": ok,
+           "timed_steps_covered_by_golden": max(0, min(compared, total_steps) - 1 - warmup),
+           "last_step_peak": int(np.abs(last).max()), "golden_peak": peak_ref,
+           "last_step_nonzero": bool(last.any())}
+    if with_realtime:
+        res["realtime"] = r.realtime()
+    r.close()
+    return res
+
+
+def roofline_objects(res, B):
+    chain, voices, groups = res["chain"], res["voices"], res["groups"]
+    bpvf = BYTES_PER_VOICE_FRAGMENT[chain]
+    alg = bpvf * voices * B
+    pmc = pmc_entry(chain, voices, groups, B)
+    leaf_s = res["leaf_ms"] * 1e-3
+    achieved = alg / leaf_s / 1e9 if leaf_s > 0 else None
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+            "traffic": pmc.get("hbm_bytes_per_launch"),
+            "kernel": LEAF_KERNEL.get(chain, "k_leaf_fmpan" if chain.startswith("fm") else "k_voices"),
+            "avg_launch_ms": res["leaf_ms"], "launches_timed": res["launches_timed"],
+            "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_voice_sample": bpvf / 64.0,
+            "timing": "HIP events on the launch stream around every launch, separate pass right after the "
+                      "timed region (graph replay off)",
+            "all_kernels_ms_per_step": res["all_ms"],
+            "other_kernels_ms_per_step": res["all_ms"] - res["leaf_ms"]}
+    if groups:
+        roof["other_kernels"] = (f"{groups} group chains inline->fbdelay->fbdelay + the root chain: "
+                                 f"{2 * groups * FBDELAY_BYTES_PER_FRAGMENT * B / 1e6:.1f} MB algorithmic per step")
+    ipvf = pmc.get("valu_insts_per_voice_fragment")
+    valu = {"bound": "valu-issue", "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
+            "kernel": roof["kernel"], "valu_insts_per_voice_fragment": ipvf,
+            "source": pmc.get("source", "no PMC summary for this workload under profiles/"),
+            "note": "wave-level VALU instructions per voice-fragment (PMC SQ_INSTS_VALU / voice-fragments) x 64 "
+                    "lanes / kernel time, against 256 CU x 4 SIMD x 16 lanes x 2.4 GHz"}
+    if ipvf and leaf_s > 0:
+        valu["achieved"] = ipvf * 64.0 * voices * B / leaf_s / 1e12
+        valu["frac"] = valu["achieved"] / VALU_PEAK_TLANEOPS
+    else:
+        valu["achieved"] = valu["frac"] = None
+    return roof, valu
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--voices", type=int, default=1024, help="voices per GPU")
-    ap.add_argument("--chain", default="osc-pan", choices=sorted(BYTES_PER_VOICE_SAMPLE))
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json configs[i]")
+    ap.add_argument("--voices", type=int, default=None, help="override: voices per GPU")
+    ap.add_argument("--chain", default=None, choices=sorted(BYTES_PER_VOICE_FRAGMENT))
+    ap.add_argument("--groups", type=int, default=None,
+                    help="override: this many inline->fbdelay->fbdelay group voices over the leaves")
     ap.add_argument("--batch", type=int, default=256, help="fragments per step (256 = 341 ms of audio)")
-    ap.add_argument("--groups", type=int, default=0,
-                    help="put the voices under this many inline->fbdelay->fbdelay group voices (config 4 shape)")
     ap.add_argument("--reduce-group", type=int, default=8,
                     help="N>1: steps whose root-bus partials are summed by one collective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] / configs[2] extra keys")
+    ap.add_argument("--no-realtime", action="store_true")
     args = ap.parse_args()
+
+    cfg = dict(CONFIGS[args.config])
+    custom = False
+    for k in ("voices", "chain", "groups"):
+        if getattr(args, k) is not None and getattr(args, k) != cfg[k]:
+            cfg[k] = getattr(args, k)
+            custom = True
+    if custom:
+        cfg["label"] = (f"{cfg['voices']} voices/GPU, {cfg['chain']}, {cfg['groups']} groups, 48 kHz, fragment=64, "
+                        f"stereo (custom; not a BASELINE config)")
 
     import torch
     import torch.distributed as dist
@@ -147,194 +437,164 @@ def main():
     # A2AMD_BENCH_FORCE_DIST=1: take the multi-rank code path (torch stream,
     # phase-split render, RCCL reduce of the root bus) even with one rank
     multi = world > 1 or os.environ.get("A2AMD_BENCH_FORCE_DIST") == "1"
-    if multi:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
 
     import audiality2_amd
-    from audiality2_amd import shard, synth
-    from audiality2_amd.replay import Backend
-
     B = args.batch
-    # N=1: the library launches on its own stream and replays the steady-state
-    # step from a hipGraph.  N>1: everything (kernels and the RCCL reduce) is
-    # ordered on one torch stream.
-    tstream = torch.cuda.Stream(device=local_rank) if multi else None
-    if tstream is not None:
-        torch.cuda.set_stream(tstream)
+
+    if not multi:
+        res = measure_single(audiality2_amd, cfg, B, args.steps, args.warmup, local_rank,
+                             with_realtime=not args.no_realtime)
+        roof, valu = roofline_objects(res, B)
+        line = {
+            "metric": "voice-samples/sec (measured realtime figure reported alongside)",
+            "value": res["value"], "unit": "voice-samples/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": cfg["label"], "voices_per_gpu": cfg["voices"], "chain": cfg["chain"],
+                       "groups": cfg["groups"], "fragments_per_step": B, "samplerate": 48000,
+                       "sharding": "single GPU",
+                       "timed_region": "per step: a2amd_fragment_repeat(64, B) + a2amd_render(UPLOAD|SUBTREES|"
+                                       "ROOT|READBACK|ASYNC) + a2amd_collect() of the previous step into host "
+                                       "buffers (double-buffered); every step's master bus reaches the host"},
+            "realtime_factor": res["value"] / (cfg["voices"] * 48000.0),
+            "parity_vs_golden": res["parity_vs_golden"],
+            "parity": {k: res[k] for k in ("golden_steps_compared", "timed_steps_covered_by_golden",
+                                           "last_step_peak", "golden_peak", "last_step_nonzero")},
+            "roofline": roof, "roofline_valu": valu,
+        }
+        if "realtime" in res:
+            line["realtime"] = res["realtime"]
+        if not args.no_extra and not custom and args.config == 3:
+            # the other two single-GPU BASELINE configs, same code path, shorter runs
+            extra = {}
+            for i in (1, 2):
+                e = measure_single(audiality2_amd, CONFIGS[i], B, max(20, args.steps // 2), args.warmup, local_rank,
+                                   with_realtime=not args.no_realtime)
+                er, ev = roofline_objects(e, B)
+                extra[f"configs[{i}]"] = {
+                    "workload": CONFIGS[i]["label"], "value": e["value"], "ms_per_step": e["ms_per_step"],
+                    "parity_vs_golden": e["parity_vs_golden"], "golden_steps_compared": e["golden_steps_compared"],
+                    "roofline": {k: er[k] for k in ("kernel", "avg_launch_ms", "achieved", "frac", "traffic",
+                                                    "all_kernels_ms_per_step")},
+                    "roofline_valu": {k: ev[k] for k in ("valu_insts_per_voice_fragment", "achieved", "frac")},
+                    "realtime": {k: e["realtime"][k] for k in ("fragment_ms_p50", "fragment_ms_p99", "holds_realtime")}
+                    if "realtime" in e else None}
+            line["other_configs"] = extra
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg["voices"], cfg["chain"], cfg["groups"])
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
+        return
+
+    # ------------------------------------------------------------------ N > 1
+    from audiality2_amd import shard
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group("nccl", rank=rank, world_size=world,
+                            device_id=torch.device("cuda", local_rank))
+    # everything (kernels and the RCCL reduce) is ordered on one torch stream
+    tstream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(tstream)
     be = audiality2_amd.open_backend(48000, None, 2, device=local_rank, max_batch=B,
-                                     stream=tstream.cuda_stream if tstream is not None else None)
+                                     stream=tstream.cuda_stream)
     lib = be.lib
     lib.a2amd_fragment_repeat.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
     lib.a2amd_get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
     lib.a2amd_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.a2amd_rootbus.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
-    lib.a2amd_replay.argtypes = [ctypes.c_void_p, ctypes.c_uint]
-
-    # ---- build the voice tree; every rank plays different voices -----------
-    sc = synth.Scene(be)
-    sc.root()
-    sc.nvoices = shard.voice_range(rank, args.voices)[0]
-    if args.groups:
-        per = args.voices // args.groups
-        for gi in range(args.groups):
-            grp = sc.add_group()
-            sc.add_voices(per, chain=args.chain, group=grp, total=args.voices * world)
-    else:
-        sc.add_voices(args.voices, chain=args.chain, total=args.voices * world)
+    lib.a2amd_rootbus_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    sc = build_scene(be, cfg["voices"], cfg["chain"], cfg["groups"], world, rank)
 
     def repeat(n):
-        rc = lib.a2amd_fragment_repeat(be.ctx, 64, n)
-        if rc:
+        if lib.a2amd_fragment_repeat(be.ctx, 64, n):
             raise RuntimeError(be._err(be.ctx))
 
-    # first batch: the explicit engine walk (voice inits + control writes)
     sc.walk(64)
     repeat(B - 1)
-    first = be.render(B * 64)
-
-    # parity gate: per-fragment hashes of the first 8 fragments against the
-    # committed golden of this exact workload (tests/golden/, rendered by the CPU
-    # oracle in the test-suite); other workloads are gated by tests/ only
-    parity = None
-    gold = os.path.join(ROOT, "tests", "golden", "bench_default_first8.hash.npy")
-    if (rank == 0 and world == 1 and not args.no_parity and args.voices == 1024 and args.chain == "osc-pan"
-            and not args.groups and B >= 8 and os.path.exists(gold)):
-        parity = bool(np.array_equal(fnv1a_fragments(first[:, :8 * 64]), np.load(gold)))
-        if not parity:
-            raise SystemExit("bench.py: GPU render differs from the golden render; refusing to report a number")
-
-    # ---- steady state: record once, upload once, re-run ----------------------
-    UP, SUB, ROOTP, RB, KEEP = 4, 1, 2, 8, 16
+    be.render(B * 64)
+    # steady state: record once, upload once, re-run phase by phase
     repeat(B)
     be.render(0, phases=UP | KEEP)
+    ptr, nbytes = ctypes.c_void_p(), ctypes.c_uint64()
+    if lib.a2amd_rootbus(be.ctx, ctypes.byref(ptr), ctypes.byref(nbytes)):
+        raise RuntimeError(be._err(be.ctx))
+    rootbus = shard.wrap_device_bus(ptr.value, nbytes.value, torch.device("cuda", local_rank))
+    render = be._render                 # (the raw entry point: no output arrays in the step loop)
 
-    rootbus = None
-    if multi:
-        ptr, nbytes = ctypes.c_void_p(), ctypes.c_uint64()
-        if lib.a2amd_rootbus(be.ctx, ctypes.byref(ptr), ctypes.byref(nbytes)):
+    def phase(ph):
+        if render(be.ctx, ph | KEEP, None, 0) < 0:
             raise RuntimeError(be._err(be.ctx))
 
-        rootbus = shard.wrap_device_bus(ptr.value, nbytes.value, torch.device("cuda", local_rank))
+    def copy_fn(p, to_stage):
+        if lib.a2amd_rootbus_copy(be.ctx, p, to_stage):
+            raise RuntimeError(be._err(be.ctx))
 
-    # N>1: the root-bus sums of `--reduce-group` steps travel in one collective that
+    # the root-bus sums of `--reduce-group` steps travel in one collective that
     # overlaps the next group's subtree kernels (audiality2_amd/shard.py)
-    pipe = None
-    if multi:
-        lib.a2amd_rootbus_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-        render = be._render                 # (the raw entry point: no output arrays in the step loop)
-
-        def phase(ph):
-            if render(be.ctx, ph | KEEP, None, 0) < 0:
-                raise RuntimeError(be._err(be.ctx))
-
-        def copy_fn(ptr, to_stage):
-            if lib.a2amd_rootbus_copy(be.ctx, ptr, to_stage):
-                raise RuntimeError(be._err(be.ctx))
-
-        pipe = shard.GroupedRootReduce(rootbus, lambda: phase(SUB), lambda: phase(ROOTP), rank,
-                                       group=args.reduce_group, copy_fn=copy_fn)
-
-    def run(nsteps):
-        if not multi:
-            if lib.a2amd_replay(be.ctx, nsteps):
-                raise RuntimeError(be._err(be.ctx))
-            return
-        pipe.run(nsteps)
-
+    pipe = shard.GroupedRootReduce(rootbus, lambda: phase(SUB), lambda: phase(ROOTP), rank,
+                                   group=args.reduce_group, copy_fn=copy_fn)
     # barrier = a (pre-warmed) 1-element all-reduce every rank must join, with the
     # device idle on both sides; dist.barrier() itself costs tens of ms on first use
-    token = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", local_rank)) if multi else None
+    token = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", local_rank))
 
     def fence():
         torch.cuda.synchronize()
-        if multi:
-            dist.all_reduce(token)
-            torch.cuda.synchronize()
+        dist.all_reduce(token)
+        torch.cuda.synchronize()
 
     fence()                 # first use builds the RCCL communicator: keep it out of the timing
-    run(args.warmup)
+    pipe.run(args.warmup)
     fence()
     fence()
     import gc
     gc.collect()
-    gc.disable()            # a full collection mid-loop costs tens of ms of host time
+    gc.disable()
     t0 = time.perf_counter()
-    run(args.steps)
+    pipe.run(args.steps)
     fence()
     dt = time.perf_counter() - t0
     gc.enable()
-    if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
 
-    # kernel durations: the same step, every launch bracketed by HIP events on
-    # the launch stream (profiling disables the graph replay; N>1: one step at a
-    # time, so that every step's events pair up)
-    def run_serial(nsteps):
-        for _ in range(nsteps):
-            be.render(0, phases=SUB | KEEP)
-            shard.reduce_root_bus(rootbus, dst=0)
-            if rank == 0:
-                be.render(0, phases=ROOTP | KEEP)
-
-    nprof = min(args.steps, 64)
+    nprof = min(args.steps, 32)
     lib.a2amd_set_profiling(be.ctx, 1)
-    (run_serial if multi else run)(nprof)
+    for _ in range(nprof):      # one step at a time, so that every step's events pair up
+        be.render(0, phases=SUB | KEEP)
+        shard.reduce_root_bus(rootbus, dst=0)
+        if rank == 0:
+            be.render(0, phases=ROOTP | KEEP)
     st = Stats()
     lib.a2amd_get_stats(be.ctx, ctypes.byref(st))
     lib.a2amd_set_profiling(be.ctx, 0)
     last = be.render(B * 64, phases=RB) if rank == 0 else None
     if rank != 0:
         be.render(0, phases=ROOTP)      # close the batch on the other ranks
-
+    line = None
     if rank == 0:
-        vs_per_step = float(args.voices) * world * B * 64
-        value = vs_per_step * args.steps / dt
-        leaf_ms = st.timed_leaf_ms / max(st.timed_batches, 1)
-        traffic = None      # HBM bytes per launch from PMC counters (profiles/README.md), if collected
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f).get(f"{args.chain}/{args.voices}/{B}", {}).get("hbm_bytes_per_launch")
-        except OSError:
-            pass
-        bpvs = BYTES_PER_VOICE_SAMPLE[args.chain]
-        achieved = bpvs * args.voices * B * 64 / (leaf_ms * 1e-3) / 1e9 if leaf_ms > 0 else None
+        value = float(cfg["voices"]) * world * B * 64 * args.steps / dt
+        res = {"chain": cfg["chain"], "voices": cfg["voices"], "groups": cfg["groups"],
+               "leaf_ms": st.timed_leaf_ms / max(st.timed_batches, 1),
+               "all_ms": st.timed_all_ms / max(st.timed_batches, 1), "launches_timed": int(st.timed_batches)}
+        roof, valu = roofline_objects(res, B)
         line = {
-            "metric": "voice-samples/sec (max realtime voices @48kHz reported alongside)",
+            "metric": "voice-samples/sec (measured realtime figure reported alongside)",
             "value": value, "unit": "voice-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"{args.voices} voices/GPU, {args.chain} (wtosc->panmix = BASELINE "
-                                   f"configs[1]), 48 kHz, fragment=64, stereo",
-                       "voices_per_gpu": args.voices, "chain": args.chain, "groups": args.groups,
-                       "fragments_per_step": B,
-                       "samplerate": 48000, "sharding": "voice subtrees per GPU + 1 RCCL int32 reduce "
-                       "of the root bus per step" if multi else "single GPU"},
-            "realtime_factor": value / (args.voices * world * 48000.0),
-            "max_realtime_voices_at_this_rate": int(value / 48000.0),
-            "parity_vs_golden": parity,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bpvs * args.voices * B * 64,
-                         "kernel": {"osc-pan": "k_leaf_oscpan", "osc-filter-pan": "k_leaf_oscfiltpan", "osc2-pan": "k_leaf_osc2pan"}.get(
-                             args.chain, "k_leaf_fmpan" if args.chain.startswith("fm") else "k_voices (leaf launch)"),
-                         "avg_launch_ms": leaf_ms,
-                         "timing": "HIP events on the launch stream around every launch, separate pass of "
-                                   f"{nprof} steps right after the timed region (graph replay off)",
-                         "launches_timed": int(st.timed_batches),
-                         "algorithmic_bytes_per_voice_sample": bpvs,
-                         "all_kernels_ms_per_step": st.timed_all_ms / max(st.timed_batches, 1)},
+            "config": {"workload": cfg["label"] + f" per GPU x {world}", "voices_per_gpu": cfg["voices"],
+                       "chain": cfg["chain"], "groups": cfg["groups"], "fragments_per_step": B, "samplerate": 48000,
+                       "sharding": "voice subtrees per GPU + 1 RCCL int32 reduce of the root bus per "
+                                   f"{args.reduce_group} steps, root chain on rank 0"},
+            "realtime_factor": value / (cfg["voices"] * world * 48000.0),
+            "parity_vs_golden": None,
+            "roofline": roof, "roofline_valu": valu,
             "output_check": {"peak": int(np.abs(last).max()), "nonzero": bool(last.any())},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.voices, args.chain)
     be.close()
-    if multi:
-        dist.destroy_process_group()
+    dist.destroy_process_group()
     # The contract line is the LAST thing on stdout: RCCL writes a version banner
     # through C stdio, which sits in libc's buffer until it is flushed.
     sys.stdout.flush()

@@ -221,6 +221,7 @@ int  a2amd_inline_end(a2amd_ctx *ctx, int unit);
 #define A2AMD_RENDER_UPLOAD   4u  /* ship the recorded commands to the GPU    */
 #define A2AMD_RENDER_READBACK 8u  /* master bus -> out[], wait for the GPU    */
 #define A2AMD_RENDER_KEEP    16u  /* keep the recording (re-run it next call) */
+#define A2AMD_RENDER_ASYNC   32u  /* READBACK does not wait: a2amd_collect() delivers */
 #define A2AMD_RENDER_ALL     15u
 /*
  * Evaluate the recorded fragments on the GPU.  With A2AMD_RENDER_ALL the
@@ -237,6 +238,13 @@ int  a2amd_inline_end(a2amd_ctx *ctx, int unit);
  */
 int  a2amd_render(a2amd_ctx *ctx, unsigned phases, int32_t *const *out,
 		unsigned out_capacity_frames);
+/* Deliver the oldest batch rendered with A2AMD_RENDER_READBACK | A2AMD_RENDER_ASYNC
+ * (a2_ProcessMaster, src/core.c:1900-1907, one batch late): waits for its copy,
+ * writes out[c][0..frames) and returns the frame count, 0 when none is in
+ * flight.  At most two may be: render, render, collect, render, collect ...
+ * keeps the GPU busy while the host consumes the previous batch (an offline
+ * a2_Run() loop whose caller reads buffer k while buffer k+1 renders). */
+int  a2amd_collect(a2amd_ctx *ctx, int32_t *const *out, unsigned out_capacity_frames);
 /* Re-run the uploaded, record-free batch 'steps' more times (each run renders
  * the next batch of audio; see A2AMD_RENDER_KEEP).  The launch sequence is
  * captured once into a hipGraph and replayed, 8 runs per graph launch, unless

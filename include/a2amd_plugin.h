@@ -26,8 +26,8 @@
  *   a2_inline_unitdesc    wraps    src/units/inline.c:50-69
  *   a2_xinsert_unitdesc   wraps    src/units/xinsert.c:232-252
  * Imported from the engine at load time (public API, include/a2_waves.h:183,
- * include/a2_properties.h:106-107): a2_GetWave, a2_GetStateProperty,
- * a2_SetStateProperty.
+ * include/a2_properties.h:106-107, include/a2_drivers.h:109): a2_GetWave,
+ * a2_GetStateProperty, a2_SetStateProperty, a2_GetDriver.
  */
 #ifndef A2AMD_PLUGIN_H
 #define A2AMD_PLUGIN_H
@@ -149,6 +149,43 @@ typedef struct A2P_xinsert
 	A2P_xinsert_client	*clients;
 	void (*SetProcess)(A2P_unit *u);	/* called when clients come and go, xinsertapi.c:108,135 */
 } A2P_xinsert;
+
+/* A2_driver / A2_audiodriver, include/a2_drivers.h:147-167, :287-304.  The engine
+ * installs its per-buffer entry point in A2_audiodriver.Process
+ * (src/audiality2.c:507-511: a2_AudioCallback); whoever drives the engine - the
+ * offline "buffer" driver's Run() (src/drivers/bufferdrv.c:28-40, from a2_Run(),
+ * src/core.c:2004), or a realtime driver's own audio thread - calls it once per
+ * buffer and then reads buffers[c][0..frames).  The drop-in puts its own
+ * Process in front of the engine's (found through the public a2_GetDriver(),
+ * a2_drivers.h:109): the engine's walk of the whole buffer is RECORDED, then
+ * rendered on the GPU in one go (up to 256 fragments per round trip) and
+ * buffers[] filled - one synchronisation per a2_Run() buffer instead of one per
+ * 64-frame fragment. */
+typedef struct A2P_driver
+{
+	struct A2P_driver	*next;
+	A2P_config		*config;
+	int			type;		/* A2_drivertypes: A2_AUDIODRIVER = 2 */
+	const char		*name;
+	int			flags;
+	int			optc;
+	const char		**optv;
+	int  (*Open)(struct A2P_driver *driver);
+	void (*Close)(struct A2P_driver *driver);
+	void (*Destroy)(struct A2P_driver *driver);
+} A2P_driver;
+#define A2P_AUDIODRIVER	2
+
+typedef struct A2P_audiodriver
+{
+	A2P_driver	driver;
+	int  (*Run)(struct A2P_audiodriver *driver, unsigned frames);
+	void (*Lock)(struct A2P_audiodriver *driver);
+	void (*Unlock)(struct A2P_audiodriver *driver);
+	void		*state;
+	void (*Process)(struct A2P_audiodriver *driver, unsigned frames);
+	int32_t		**buffers;
+} A2P_audiodriver;
 
 #define A2P_BLOCK_SIZE	384		/* A2_BLOCK_SIZE, include/audiality2.h.cmake:53 */
 #define A2P_PNOISESEED	0x0002000a	/* A2_PNOISESEED, include/a2_properties.h:71 */

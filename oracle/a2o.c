@@ -345,9 +345,9 @@ struct a2o_ctx
 	a2o_wave	*waves;
 	int		nwaves;
 	a2o_unit	*units;
-	int		nunits, cap_units;
+	int		nunits, cap_units, unit_hint;	/* no dead unit slot below unit_hint */
 	a2o_voice	**voices;
-	int		nvoices, cap_voices;
+	int		nvoices, cap_voices, voice_hint;
 	a2o_voice	*building;	/* voice being populated */
 
 	/* inline windows currently open (src/core.c:1769: recursion depth) */
@@ -707,9 +707,10 @@ int a2o_unit_init(a2o_ctx *c, uint64_t key, int kind, unsigned flags,
 			c->cap_voices = nc;
 		}
 		/* reuse a dead voice record if there is one */
-		for(i = 0; i < c->nvoices; ++i)
+		for(i = c->voice_hint; i < c->nvoices; ++i)
 			if(!c->voices[i]->live)
 				break;
+		c->voice_hint = i + 1;
 		if(i < c->nvoices)
 		{
 			free(c->voices[i]);
@@ -723,9 +724,10 @@ int a2o_unit_init(a2o_ctx *c, uint64_t key, int kind, unsigned flags,
 		return fail(c, A2AMD_EUNSUPPORTED, "chain longer than %d",
 				A2AMD_MAXCHAIN);
 
-	for(id = 0; id < c->nunits; ++id)
+	for(id = c->unit_hint; id < c->nunits; ++id)
 		if(!c->units[id].live)
 			break;
+	c->unit_hint = id + 1;
 	if(id == c->nunits)
 	{
 		if(c->nunits == c->cap_units)
@@ -866,10 +868,15 @@ int a2o_unit_deinit(a2o_ctx *c, int id)
 	free(u->rbuf);
 	u->lbuf = u->rbuf = NULL;	/* (u->tap stays readable until the slot is reused) */
 	u->live = 0;
+	if(id < c->unit_hint)
+		c->unit_hint = id;
 	if(c->building == v)
 		c->building = NULL;
 	if(--v->nlive == 0)
+	{
 		v->live = 0;
+		c->voice_hint = 0;
+	}
 	return A2AMD_OK;
 }
 

@@ -1,12 +1,21 @@
 #!/usr/bin/env python3
-"""Golden check value for bench.py's parity gate: per-fragment FNV-1a 64 of the
-first 8 fragments of the default bench workload (1 024 voices wtosc->panmix
-under the root voice, synth.Scene parameters), rendered by the CPU oracle.
-bench.py only reads the resulting data file; tests/test_oracle_cpu.py checks
-that the file still matches the oracle."""
+"""Golden check values for bench.py's parity gate and the full-size GPU tests:
+per-fragment FNV-1a 64 hashes of the first STEPS x 256 fragments of each
+single-GPU BASELINE config at FULL size (configs[1] 1 024 x wtosc->panmix,
+configs[2] 16 384 x wtosc->filter12->panmix, configs[3] 65 536 x 2xwtosc->panmix
+under 256 inline->fbdelay->fbdelay groups with fmtest4's delay settings),
+rendered by the CPU oracle from the scene bench.py builds (bench.build_scene).
+
+  python tests/golden/make_bench_golden.py [1 2 3]      (configs[3]: ~5 min of one core)
+
+bench.py and tests/test_gpu_parity.py only read the resulting data files;
+tests/test_oracle_cpu.py re-renders the head of each with the oracle.  8 steps =
+2.73 s of audio: the longest delay tap of configs[3] (1 378.75 ms) has been
+feeding back for more than a second by the end."""
 import ctypes
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -15,21 +24,46 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+STEPS, B = 8, 256
 
-def render(voices=1024, chain="osc-pan", fragments=8):
+
+def render(voices, chain, groups, fragments, progress=False):
+    """int32 [2, fragments * 64] from the oracle, for bench.py's scene."""
+    import bench
     from audiality2_amd import synth
     from audiality2_amd.replay import Backend
-    be = Backend(ctypes.CDLL(os.path.join(ROOT, "oracle", "liba2oracle.so")), "a2o_", 48000,
-                 synth.basepitch_for(48000), 2)
-    sc = synth.Scene(be)
-    sc.root()
-    sc.add_voices(voices, chain=chain, total=voices)
-    out = sc.run(fragments, batch=fragments)
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liba2oracle.so"))
+    lib.a2o_fragment_repeat.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
+    be = Backend(lib, "a2o_", 48000, synth.basepitch_for(48000), 2, max_batch=64)
+    sc = bench.build_scene(be, voices, chain, groups)
+    outs = []
+    sc.walk(64)
+    done, pending = 0, 1
+    t0 = time.time()
+    while done < fragments:
+        n = min(64 - pending, fragments - done - pending)
+        if n:
+            assert lib.a2o_fragment_repeat(be.ctx, 64, n) == 0
+        outs.append(be.render((pending + n) * 64).copy())
+        done += pending + n
+        pending = 0
+        if progress:
+            print(f"\r{done}/{fragments} fragments, {time.time() - t0:.0f} s", end="", flush=True)
+    if progress:
+        print()
     be.close()
-    return out
+    return np.concatenate(outs, axis=1)
 
 
 if __name__ == "__main__":
+    import bench
     from conftest import fnv1a_fragments
-    np.save(os.path.join(HERE, "bench_default_first8.hash.npy"), fnv1a_fragments(render()))
-    print("written")
+    which = [int(a) for a in sys.argv[1:]] or [1, 2, 3]
+    for i in which:
+        cfg = bench.CONFIGS[i]
+        pcm = render(cfg["voices"], cfg["chain"], cfg["groups"], STEPS * B, progress=True)
+        path = bench.golden_path(cfg["voices"], cfg["chain"], cfg["groups"])
+        np.save(path, fnv1a_fragments(pcm))
+        # the head of the audio itself, for a readable diff when a hash differs
+        np.save(path.replace(".hash.npy", ".head.npy"), pcm[:, :256])
+        print("written", path, "peak", int(np.abs(pcm).max()))

@@ -9,24 +9,33 @@ import pytest
 from conftest import ROOT
 
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-            "vs_baseline", "dtype", "data", "config", "roofline"}
+            "vs_baseline", "dtype", "data", "config", "roofline", "roofline_valu"}
 
 
 @pytest.mark.gpu
 def test_bench_prints_one_contract_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    """Default run = BASELINE configs[3] at full size, every step's audio delivered to
+    the host, the steps the oracle golden covers compared hash by hash."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert REQUIRED <= set(d), REQUIRED - set(d)
-    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 3 and d["higher_is_better"] is True
     assert d["unit"] == "voice-samples/s" and d["value"] > 0 and d["parity_vs_golden"] is True
+    assert "configs[3]" in d["config"]["workload"] and d["config"]["voices_per_gpu"] == 65536
+    # steps 0..7 are in the golden: step 0, three warm-up steps, four timed steps
+    assert d["parity"]["golden_steps_compared"] == 8 and d["parity"]["timed_steps_covered_by_golden"] == 4
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["kernel"] == "k_leaf_osc2pan"
+    assert d["roofline_valu"]["bound"] == "valu-issue"
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["realtime"]["fragment_ms_p99"] > 0
+    for k in ("configs[1]", "configs[2]"):
+        assert d["other_configs"][k]["value"] > 0 and d["other_configs"][k]["parity_vs_golden"] is True
 
 
 @pytest.mark.gpu
@@ -36,7 +45,7 @@ def test_bench_line_is_last_on_stdout_under_torchrun():
     line rank 0 prints."""
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
-                        "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                        "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--config", "1"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT,
                        env=dict(os.environ, A2AMD_BENCH_FORCE_DIST="1"))
     assert r.returncode == 0, r.stderr[-2000:]

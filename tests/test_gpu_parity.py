@@ -539,3 +539,176 @@ def test_xsource_and_xsink_units(oracle_lib):
     assert sorted(gtaps) == sorted(wtaps) == [1, 2, 3, 4, 5] + [100 + f for f in range(2, 9)]
     for f in wtaps:
         assert wtaps[f].any() and np.array_equal(gtaps[f], wtaps[f]), f"tapped input differs in fragment {f}"
+
+
+# ---------------------------------------------------------------------------
+# round 2: the product loop bench.py times (quiet batches recorded again and again,
+# asynchronous readback, graph reuse) and the launch shapes it times
+# ---------------------------------------------------------------------------
+def _async_steps(gpu, sc, nsteps, B, first=True):
+    """bench.py's step loop: fragment_repeat + render(... READBACK|ASYNC) + collect,
+    at most two batches in flight.  Returns int32 [2, nsteps*B*64]."""
+    import ctypes as C
+    lib = gpu.lib
+    lib.a2amd_fragment_repeat.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
+    lib.a2amd_collect.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.c_uint]
+    outs, inflight = [], 0
+
+    def collect():
+        out = np.zeros((2, B * 64), dtype=np.int32)
+        p = (C.POINTER(C.c_int32) * 2)()
+        for c in range(2):
+            p[c] = out[c].ctypes.data_as(C.POINTER(C.c_int32))
+        assert lib.a2amd_collect(gpu.ctx, p, B * 64) == B * 64, gpu._err(gpu.ctx)
+        outs.append(out)
+
+    for s in range(nsteps):
+        n = B
+        if first and s == 0:
+            sc.walk(64)
+            n = B - 1
+        if n:
+            assert lib.a2amd_fragment_repeat(gpu.ctx, 64, n) == 0, gpu._err(gpu.ctx)
+        assert gpu._render(gpu.ctx, 4 | 1 | 2 | 8 | 32, None, 0) == B * 64, gpu._err(gpu.ctx)
+        inflight += 1
+        if inflight == 2:
+            collect()
+            inflight -= 1
+    while inflight:
+        collect()
+        inflight -= 1
+    return np.concatenate(outs, axis=1)
+
+
+def _oracle_fragments(oracle_lib, build, nfrags):
+    import ctypes as C
+    ora = make_oracle(oracle_lib)
+    oracle_lib.a2o_fragment_repeat.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
+    sc = build(ora)
+    sc.walk(64)
+    outs, done, pending = [], 0, 1
+    while done < nfrags:
+        n = min(64 - pending, nfrags - done - pending)
+        if n:
+            assert oracle_lib.a2o_fragment_repeat(ora.ctx, 64, n) == 0
+        outs.append(ora.render((pending + n) * 64).copy())
+        done += pending + n
+        pending = 0
+    ora.close()
+    return np.concatenate(outs, axis=1)
+
+
+def test_async_readback_quiet_graph_path_matches_oracle(oracle_lib):
+    """Seven steps of 16 fragments through fragment_repeat / render(ASYNC) / collect:
+    the second identical quiet batch takes the no-upload path and builds the graph,
+    later ones replay it; births in between drop it and the path is found again."""
+    def build(be):
+        sc = synth.Scene(be)
+        sc.root()
+        g = sc.add_group(preset="fmtest4")
+        sc.add_voices(96, chain="osc2-pan", group=g, total=512)
+        sc.add_voices(160, chain="osc-pan", total=512)
+        sc.add_voices(64, chain="osc-filter-pan", total=512)
+        return sc
+    gpu = make_gpu(max_batch=16)
+    sc = build(gpu)
+    a = _async_steps(gpu, sc, 4, 16)
+    sc.add_voices(32, chain="osc-pan", total=512)        # births: slow path, graphs dropped
+    sc.walk(64)
+    b0 = gpu.render(64)
+    b = _async_steps(gpu, sc, 3, 16, first=False)
+    gpu.close()
+    got = np.concatenate([a, b0, b], axis=1)
+
+    ora = make_oracle(oracle_lib)
+    sc = build(ora)
+    parts = [sc.run(64, batch=64)]
+    sc.add_voices(32, chain="osc-pan", total=512)
+    parts.append(sc.run(1 + 48, batch=49))
+    ora.close()
+    want = np.concatenate(parts, axis=1)
+    assert first_diff(got, want) is None
+
+
+@pytest.mark.parametrize("vpw,ysplit", [(4, 1), (8, 32), (32, 8), (64, 32), (8, 8)])
+@pytest.mark.parametrize("chain", ["osc-pan", "osc2-pan"])
+def test_leaf_launch_shapes_at_bench_batch_match_oracle(oracle_lib, monkeypatch, chain, vpw, ysplit):
+    """The time-sliced leaf kernels at the batch length bench.py times (256 fragments:
+    up to 32 slices, each starting from the closed-form phase) over every launch shape
+    the host may pick, 2 x 256 fragments, against the oracle."""
+    monkeypatch.setenv("A2AMD_VPW", str(vpw))
+    monkeypatch.setenv("A2AMD_YSPLIT", str(ysplit))
+    n = 2304 if chain == "osc-pan" else 1536
+
+    def build(be):
+        sc = synth.Scene(be)
+        sc.root()
+        sc.add_voices(n, chain=chain, total=4096)
+        return sc
+    gpu = make_gpu(max_batch=256)
+    got = _async_steps(gpu, build(gpu), 2, 256)
+    gpu.close()
+    want = _oracle_fragments(oracle_lib, build, 512)
+    assert first_diff(got, want) is None
+
+
+@pytest.mark.parametrize("fvpw", [1, 8, 32])
+def test_filter_leaf_launch_shapes_at_bench_batch_match_oracle(oracle_lib, monkeypatch, fvpw):
+    monkeypatch.setenv("A2AMD_FVPW", str(fvpw))
+
+    def build(be):
+        sc = synth.Scene(be)
+        sc.root()
+        sc.add_voices(1100, chain="osc-filter-pan", total=4096)
+        return sc
+    gpu = make_gpu(max_batch=256)
+    got = _async_steps(gpu, build(gpu), 2, 256)
+    gpu.close()
+    want = _oracle_fragments(oracle_lib, build, 512)
+    assert first_diff(got, want) is None
+
+
+@pytest.mark.parametrize("config", [1, 2, 3])
+def test_baseline_configs_at_full_size_match_oracle_golden(config):
+    """BASELINE configs[1..3] at FULL size (1 024 / 16 384 / 65 536 voices, 512
+    fbdelays in configs[3]), 8 steps of 256 fragments = 2.73 s of audio, against the
+    per-fragment hashes the CPU oracle rendered in the build container
+    (tests/golden/make_bench_golden.py; minutes of oracle time)."""
+    import bench
+    cfg = bench.CONFIGS[config]
+    want = np.load(bench.golden_path(cfg["voices"], cfg["chain"], cfg["groups"]))
+    gpu = make_gpu(max_batch=256)
+    sc = bench.build_scene(gpu, cfg["voices"], cfg["chain"], cfg["groups"])
+    got = fnv1a_fragments(_async_steps(gpu, sc, 8, 256))
+    gpu.close()
+    bad = np.nonzero(got != want)[0]
+    assert not len(bad), f"configs[{config}]: {len(bad)} fragments differ, first {bad[:8]}"
+
+
+def test_config3_full_size_is_linear_in_the_voice_subsets():
+    """Size-independent property at configs[3]'s full size: the mix is a wrap-around
+    integer sum, the group chains (fbdelay with constant gains) and the root chain
+    (unity gains) are linear up to their truncating shifts ... which are NOT linear,
+    so the exact statement is per group: a scene holding only groups [0, 128) plus a
+    scene holding only groups [128, 256) renders, group bus by group bus, what the
+    full scene renders - and with the root at vol 1.0, pan 0 (panmix.c:259: an exact
+    identity on each channel) the master buses add up bit for bit."""
+    import bench
+    cfg = bench.CONFIGS[3]
+    outs = []
+    for lo, hi in ((0, 256), (0, 128), (128, 256)):
+        gpu = make_gpu(max_batch=256)
+        sc = synth.Scene(gpu)
+        sc.root()
+        per = cfg["voices"] // cfg["groups"]
+        for gi in range(cfg["groups"]):
+            if lo <= gi < hi:
+                grp = sc.add_group(preset="fmtest4")
+                sc.add_voices(per, chain=cfg["chain"], group=grp, total=cfg["voices"])
+            else:
+                sc.nvoices += per       # (voice parameters depend on the voice's number)
+        outs.append(_async_steps(gpu, sc, 3, 256))
+        gpu.close()
+    full, a, b = (o.astype(np.int64) for o in outs)
+    s = ((a + b + 2 ** 31) % 2 ** 32 - 2 ** 31)
+    assert first_diff(full.astype(np.int32), s.astype(np.int32)) is None

@@ -116,14 +116,21 @@ def test_scene_edge_cases(oracle_lib):
 
 
 def test_bench_parity_golden_matches_oracle(oracle_lib):
-    """bench.py gates its number on tests/golden/bench_default_first8.hash.npy
-    (data only); the file must be what the oracle renders for that workload."""
+    """bench.py gates its numbers on tests/golden/bench_<chain>_<voices>v_<groups>g.hash.npy
+    (data only, 8 steps x 256 fragments at full size, tests/golden/make_bench_golden.py);
+    the files must be what the oracle renders for those workloads.  Re-rendered here:
+    the first fragments of each (the whole of them takes minutes of oracle time)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("mbg", os.path.join(GOLDEN, "make_bench_golden.py"))
     mbg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mbg)
-    want = np.load(os.path.join(GOLDEN, "bench_default_first8.hash.npy"))
-    assert np.array_equal(fnv1a_fragments(mbg.render()), want)
+    import bench
+    for i, nfr in ((1, 64), (2, 8), (3, 2)):
+        cfg = bench.CONFIGS[i]
+        want = np.load(bench.golden_path(cfg["voices"], cfg["chain"], cfg["groups"]))
+        assert len(want) == mbg.STEPS * mbg.B
+        got = fnv1a_fragments(mbg.render(cfg["voices"], cfg["chain"], cfg["groups"], nfr))
+        assert np.array_equal(got, want[:nfr]), f"configs[{i}]"
 
 
 def test_oracle_xinsert_clients(oracle_lib):

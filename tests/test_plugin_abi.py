@@ -50,6 +50,12 @@ SAME(A2_unitdesc, A2P_unitdesc, OpenState); SAME(A2_unitdesc, A2P_unitdesc, Clos
 SIZE(A2_vmstate, A2P_vmstate); SAME(A2_vmstate, A2P_vmstate, waketime); SAME(A2_vmstate, A2P_vmstate, r);
 SIZE(A2_config, A2P_config); SAME(A2_config, A2P_config, interface); SAME(A2_config, A2P_config, samplerate);
 SAME(A2_config, A2P_config, channels); SAME(A2_config, A2P_config, basepitch);
+SIZE(A2_driver, A2P_driver); SAME(A2_driver, A2P_driver, config); SAME(A2_driver, A2P_driver, type);
+SAME(A2_driver, A2P_driver, Destroy);
+SIZE(A2_audiodriver, A2P_audiodriver); SAME(A2_audiodriver, A2P_audiodriver, Run);
+SAME(A2_audiodriver, A2P_audiodriver, state); SAME(A2_audiodriver, A2P_audiodriver, Process);
+SAME(A2_audiodriver, A2P_audiodriver, buffers);
+_Static_assert(A2_AUDIODRIVER == A2P_AUDIODRIVER, "drivertype");
 _Static_assert(sizeof(A2_wave) == sizeof(A2P_wave), "A2_wave");
 _Static_assert(offsetof(A2_wave, d.wave.data) == offsetof(A2P_wave, data), "data");
 _Static_assert(offsetof(A2_wave, d.wave.size) == offsetof(A2P_wave, size), "size");

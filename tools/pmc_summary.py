@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc counter_collection CSVs per kernel (mean per launch).
+"""Summarise rocprofv3 --pmc counter_collection CSVs per kernel (median launch).
 
     python tools/pmc_summary.py <dir-with-rocprof-output> [label]
 
@@ -25,11 +25,10 @@ def short(name):
 def main():
     root = sys.argv[1]
     label = sys.argv[2] if len(sys.argv) > 2 else ""
-    acc = collections.defaultdict(lambda: [0.0, 0])
-    launches = collections.Counter()
+    # per (kernel, counter): dispatch id -> value summed over the rows of that dispatch
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
     for fn in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
         with open(fn, newline="") as f:
-            seen = set()
             for row in csv.DictReader(f):
                 k = short(row.get("Kernel_Name", ""))
                 c = row.get("Counter_Name", "")
@@ -37,16 +36,17 @@ def main():
                     v = float(row.get("Counter_Value", "0"))
                 except ValueError:
                     continue
-                acc[(k, c)][0] += v
-                did = (k, c, row.get("Dispatch_Id"))
-                if did not in seen:
-                    seen.add(did)
-                    acc[(k, c)][1] += 1
+                per[(k, c)][(fn, row.get("Dispatch_Id"))] += v
     out = {}
-    for (k, c), (tot, n) in sorted(acc.items()):
-        mean = tot / max(n, 1)
+    for (k, c), d in sorted(per.items()):
+        vals = sorted(d.values())
+        # the MEDIAN launch: the set-up batch is an outlier both ways (the leaf kernels
+        # find only voices with records there and do next to nothing; the general kernel
+        # executes every voice's init records)
+        mean = vals[len(vals) // 2] if vals else 0.0
+        steady = vals
         out.setdefault(k, {})[c] = mean
-        print(f"{label:>28s} {k:24s} {c:24s} {mean:16.6g} per launch ({n} launches)")
+        print(f"{label:>28s} {k:24s} {c:24s} {mean:16.6g} median launch of {len(vals)}")
     for k, d in out.items():
         if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
             hbm = (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Fold the "JSON {...}" lines tools/pmc_summary.py printed (one per counter pass)
+into the per-workload table bench.py reads (profiles/rNN_pmc.json).
+
+    python tools/pmc_to_json.py gpurun_out/round2/pmc_summary.txt > profiles/r02_pmc.json
+
+Keys are "chain/voices/groups/fragments-per-step"; per key the dominant leaf
+kernel's HBM traffic per launch ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950
+correction of MI355X_MICROARCH.md) and its wave-level instruction counts per
+voice-fragment, plus the same for every other kernel of the step under "kernels".
+"""
+import json
+import sys
+
+LEAF = {"osc-pan": "k_leaf_oscpan", "osc-filter-pan": "k_leaf_oscfiltpan", "osc2-pan": "k_leaf_osc2pan"}
+
+
+def main():
+    merged = {}
+    for line in open(sys.argv[1]):
+        if not line.startswith("JSON "):
+            continue
+        for label, kernels in json.loads(line[5:]).items():
+            for k, d in kernels.items():
+                merged.setdefault(label, {}).setdefault(k, {}).update(d)
+    out = {}
+    for label, kernels in merged.items():
+        chain, voices, groups, B = label.split("/")
+        voices, groups, B = int(voices), int(groups), int(B)
+        leaf = LEAF.get(chain, "k_leaf_fmpan")
+        e = {"kernel": leaf, "source": f"rocprofv3 --pmc passes of bench.py --config shape {label} (tools/profile_round2.sh), "
+                                       "median launch", "kernels": {}}
+        for k, d in kernels.items():
+            kd = dict(d)
+            if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
+                kd["hbm_bytes_per_launch"] = (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0
+            for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM"):
+                if c in d:
+                    kd[c.lower()[3:] + "_per_voice_fragment"] = d[c] / (voices * B)
+            if "SQ_ACTIVE_INST_VALU" in d and "SQ_WAVE_CYCLES" in d and d["SQ_WAVE_CYCLES"]:
+                kd["valu_active_over_wave_cycles"] = d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"]
+            e["kernels"][k] = kd
+        lk = e["kernels"].get(leaf, {})
+        e["hbm_bytes_per_launch"] = lk.get("hbm_bytes_per_launch")
+        e["valu_insts_per_voice_fragment"] = lk.get("insts_valu_per_voice_fragment")
+        e["salu_insts_per_voice_fragment"] = lk.get("insts_salu_per_voice_fragment")
+        e["formula"] = "(2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction, MI355X_MICROARCH.md)"
+        out[label] = e
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
