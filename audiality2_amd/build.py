@@ -36,7 +36,7 @@ def build_units(force=False):
     out = os.path.join(HERE, "liba2amd_units.so")
     if force or _newer(out, deps):
         subprocess.run(["gcc", "-O2", "-Wall", "-fPIC", "-shared", "-o", out, src,
-                        "-L" + HERE, "-la2amd", "-ldl", "-Wl,-rpath,$ORIGIN"], check=True)
+                        "-L" + HERE, "-la2amd", "-ldl", "-lpthread", "-Wl,-rpath,$ORIGIN"], check=True)
     return out
 
 

@@ -151,6 +151,8 @@ int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const 
 int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, int nfrags, int consume,
 		const A2DCommitSet *commits, void *stream);
 int a2d_launch_commit(const A2DParams &hp, const A2DCommit &cm, void *stream);
+// quiet "inline; fbdelay 2->2 ... ; fbdelay 2->2 >" voices (one workgroup each)
+int a2d_launch_bus_fbdchain(const A2DParams *dparams, const int *dlist, int nlist, int consume, void *stream);
 int a2d_launch_park(int32_t *stage, int32_t *bus, unsigned words, void *stream);
 int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
 		int vpw, void *stream);

@@ -1301,6 +1301,122 @@ void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list
 	}
 }
 
+// ---------------------------------------------------------------------------
+// inline -> fbdelay 2->2 [-> fbdelay 2->2 ...] (last one wired, adding): the group
+// voices of BASELINE config 4 / benchmark/fmtest4.a2s:83-95
+// ---------------------------------------------------------------------------
+// fbdelay (fbdelay.c:69-126) is a recurrence in time only through its delay lines:
+// frame t reads what frames t - fbdelay / t - ldelay / t - rdelay wrote.  With every
+// tap at least R frames long (and at most 131072 - R), R consecutive frames read
+// nothing any of them writes: they are independent, and the units of the chain run
+// back to back on each frame.  So the batch is cut into rounds of
+// floor(min(tap) / 64) whole fragments - with fmtest4's 631 ... 1379 ms taps the
+// whole 256-fragment batch is ONE round - and the 1024 threads of the voice's
+// workgroup take the frames of a round in parallel (consecutive threads =
+// consecutive delay-line addresses), with a barrier between rounds.  The general
+// kernel walks the same chain one fragment after the other on one wavefront.
+#define FBC_THREADS 1024
+#define FBC_MAXD 4
+struct FbdU { int fb, l, r, dry, fbg, lg, rg, pos, add; int *b0, *b1; };
+
+__global__ __launch_bounds__(FBC_THREADS)
+void k_bus_fbdchain(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int consume)
+{
+	const A2DParams &p = *pp;
+	const int slot = list[blockIdx.x];
+	if(p.runs[slot].count)
+		return;		// carries records this batch: the general kernel renders it
+	if(!p.vactive[slot])
+		return;
+	const A2DVoice &vc = p.voices[slot];
+	const int nd = vc.nunits - 1;
+	const int M = A2D_FBD_BUFSIZE - 1;
+	FbdU d[FBC_MAXD];
+	int dmin = A2D_FBD_BUFSIZE, dmax = 0;
+#pragma unroll
+	for(int k = 0; k < FBC_MAXD; ++k)
+		if(k < nd) {
+			const int *w = p.ustate + (size_t)vc.unit[k + 1] * A2D_USTATE;
+			d[k].fb = w[DW_FBDELAY]; d[k].l = w[DW_LDELAY]; d[k].r = w[DW_RDELAY];
+			d[k].dry = w[DW_DRYGAIN]; d[k].fbg = w[DW_FBGAIN]; d[k].lg = w[DW_LGAIN]; d[k].rg = w[DW_RGAIN];
+			d[k].pos = w[DW_BUFPOS];
+			d[k].b0 = p.fbdmem + (size_t)w[DW_BUFIDX] * 2 * A2D_FBD_BUFSIZE;
+			d[k].b1 = d[k].b0 + A2D_FBD_BUFSIZE;
+			d[k].add = (int)A2D_ADD(p.udesc[vc.unit[k + 1]]);
+			dmin = min(dmin, min(d[k].fb, min(d[k].l, d[k].r)));
+			dmax = max(dmax, max(d[k].fb, max(d[k].l, d[k].r)));
+		}
+	// fragments per round (the host only lists voices whose taps allow >= 1)
+	const int rf = max(1, min(dmin, A2D_FBD_BUFSIZE - dmax) / A2D_FRAG);
+	const int nfrags = p.nfrags;
+	int *own = p.busmem + vc.own_off;
+	int *out = p.busmem + vc.out_off;
+	const int out_nch = vc.out_nch;
+	for(int f0 = 0; f0 < nfrags; f0 += rf) {
+		const int fend = min(nfrags, f0 + rf);
+		for(int idx = f0 * A2D_FRAG + (int)threadIdx.x; idx < fend * A2D_FRAG; idx += FBC_THREADS) {
+			const int f = idx >> 6, lane = idx & 63;
+			if(lane >= p.fragframes[f])
+				continue;
+			const int t = (int)p.fragstart[f] + lane;
+			int *src = own + (size_t)f * 2 * A2D_FRAG;
+			int x0 = src[lane], x1 = src[A2D_FRAG + lane];
+			if(consume) {
+				// every bus of this batch is read by its owner's fast kernel and
+				// nowhere else: leave it zeroed for the next batch
+				src[lane] = 0;
+				src[A2D_FRAG + lane] = 0;
+			}
+#pragma unroll
+			for(int k = 0; k < FBC_MAXD; ++k)
+				if(k < nd) {
+					const FbdU &u = d[k];
+					const int pos = wadd(u.pos, t);
+					int o0 = mul64s(u.b1[(pos - u.fb) & M], u.fbg, 16);
+					int o1 = mul64s(u.b0[(pos - u.fb) & M], u.fbg, 16);
+					const int t0 = u.b0[(pos - u.l) & M], t1 = u.b1[(pos - u.r) & M];
+					u.b0[pos & M] = wadd(x0, o0);
+					u.b1[pos & M] = wadd(x1, o1);
+					o0 = wadd(o0, mul64s(t0, u.lg, 16));
+					o1 = wadd(o1, mul64s(t1, u.rg, 16));
+					o0 = wadd(o0, mul64s(x0, u.dry, 16));
+					o1 = wadd(o1, mul64s(x1, u.dry, 16));
+					if(k == nd - 1) {	// wired, adding: into the output bus
+						int *dst = out + (size_t)f * out_nch * A2D_FRAG;
+						if(o0)
+							atomicAdd(&dst[lane], o0);
+						if(o1)
+							atomicAdd(&dst[A2D_FRAG + lane], o1);
+					} else if(u.add) {
+						x0 = wadd(x0, o0);
+						x1 = wadd(x1, o1);
+					} else {
+						x0 = o0;
+						x1 = o1;
+					}
+				}
+		}
+		if(fend < nfrags)
+			__syncthreads();	// (delay-line stores of this round visible to the next)
+	}
+	if(threadIdx.x == 0) {
+		int total = 0;
+		for(int f = 0; f < nfrags; ++f)
+			total += p.fragframes[f];
+		for(int k = 0; k < nd; ++k)
+			p.ustate[(size_t)vc.unit[k + 1] * A2D_USTATE + DW_BUFPOS] = wadd(d[k].pos, total);
+	}
+}
+
+int a2d_launch_bus_fbdchain(const A2DParams *dparams, const int *dlist, int nlist, int consume, void *stream)
+{
+	if(nlist <= 0)
+		return 0;
+	hipLaunchKernelGGL(k_bus_fbdchain, dim3(nlist), dim3(FBC_THREADS), 0, (hipStream_t)stream,
+			dparams, dlist, nlist, consume);
+	return (int)hipGetLastError();
+}
+
 int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
 		int vpw, int ysplit, int *ustage, void *stream, void *event_after_main, A2DCommit *defer)
 {

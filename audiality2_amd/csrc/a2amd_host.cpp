@@ -133,8 +133,10 @@ struct HUnit {
 	Ramp cutoff = {0, 0, 0, 0};
 	unsigned flags = 0;
 	int nin = 0, nout = 0, wired = 0;
-	// fbdelay: delay line pair index
+	// fbdelay: delay line pair index, and the three tap lengths in frames (what the
+	// device holds, fbdelay.c:194-196,231-247): they decide the voice's launch class
 	int fbdbuf = -1;
+	int fbd_taps[3] = { 0, 0, 0 };
 	// fm: slot in the operator state pool
 	int fmslot = -1;
 	// xinsert: client slot (tap / inject buffers) and A2AMD_XIO_* mode
@@ -170,8 +172,9 @@ struct HVoice {
 	int cls = 0;			// launch class (CLS_*), set when the lists are rebuilt
 };
 
-struct DepthRange { int fast_first = 0, fast_count = 0, gen_first = 0, gen_count = 0, dyn_first = 0, dyn_count = 0; };
-enum { CLS_GENERIC = 0, CLS_OSCPAN, CLS_OSCFILTPAN, CLS_BUSDRIVER, CLS_BUSGENERIC, CLS_OSC2PAN, CLS_FMPAN };
+struct DepthRange { int fast_first = 0, fast_count = 0, fbd_first = 0, fbd_count = 0, gen_first = 0, gen_count = 0,
+		dyn_first = 0, dyn_count = 0; };
+enum { CLS_GENERIC = 0, CLS_OSCPAN, CLS_OSCFILTPAN, CLS_BUSDRIVER, CLS_BUSGENERIC, CLS_OSC2PAN, CLS_FMPAN, CLS_FBDCHAIN };
 
 // host side of an xinsert client slot
 struct XioSlot {
@@ -266,7 +269,11 @@ struct a2amd_ctx {
 
 	// wave pool (int16 samples)
 	size_t wavepool_used = 0;
-	std::vector<std::pair<size_t, size_t>> wavepool_free;	// (offset, length) of dropped waves' regions
+	std::vector<std::pair<size_t, size_t>> wavepool_free;	// (offset, length) of dropped waves' regions, sorted, coalesced
+	// a dropped wave's pool region and table slot serve the batch being recorded to its
+	// end (oscillators still name it until they have rendered a window and noticed)
+	std::vector<std::pair<size_t, size_t>> deferred_wavepool_free;
+	std::vector<int> free_wave_slots, deferred_wave_slots;
 
 	DevBuf<A2DVoice> d_voices;
 	DevBuf<uint32_t> d_udesc;
@@ -573,6 +580,32 @@ bool is_driver_chain(const a2amd_ctx *c, const HVoice &v)
 			!xi.xio_mode;	// (clients: the general kernel serves them)
 }
 
+// a tap the frame-parallel delay kernel can take: at least one fragment long, and
+// short enough not to wrap onto the frames being written
+inline bool fbd_tap_ok(int frames) { return frames >= A2D_FRAG && frames <= A2D_FBD_BUFSIZE - A2D_FRAG; }
+
+// inline 0 2; fbdelay 2 2 [; fbdelay 2 2 ...]; the last one wired and adding
+// (the group voices of benchmark/fmtest4.a2s:83-95), every tap >= one fragment
+bool is_fbdchain(const a2amd_ctx *c, const HVoice &v)
+{
+	if(v.nunits < 2 || v.nunits > 5 || v.own_nch != 2 || v.out_nch < 2 || v.own_off < 0 || v.inline_pos != 0)
+		return false;
+	const HUnit &il = c->units[v.unit[0]];
+	if(il.kind != A2AMD_INLINE || (il.flags & A2AMD_PROCADD) || il.wired || il.nout != 2)
+		return false;
+	for(int k = 1; k < v.nunits; ++k) {
+		const HUnit &d = c->units[v.unit[k]];
+		const bool last = k == v.nunits - 1;
+		if(d.kind != A2AMD_FBDELAY || d.nin != 2 || d.nout != 2 || (d.wired != 0) != last ||
+				(last && !(d.flags & A2AMD_PROCADD)))
+			return false;
+		for(int t = 0; t < 3; ++t)
+			if(!fbd_tap_ok(d.fbd_taps[t]))
+				return false;
+	}
+	return true;
+}
+
 int upload(a2amd_ctx *c)
 {
 	if(c->blob_quiet && c->with_recs.empty() && c->prev_with_recs.empty() && !c->voices_dirty &&
@@ -733,6 +766,7 @@ int upload(a2amd_ctx *c)
 		bool owners_ok = !getenv("A2AMD_NO_SELFCLEAN"), root_driver = false;
 		std::vector<int> fast_leaf, osc2_leaf, filt_leaf, fm_leaf, gen_leaf;
 		std::map<int, std::pair<std::vector<int>, std::vector<int>>> bydepth;
+		std::map<int, std::vector<int>> fbd_bydepth;
 		int maxdepth = -1;
 		for(size_t vi = 0; vi < nv; ++vi) {
 			HVoice &v = c->voices[vi];
@@ -744,13 +778,14 @@ int upload(a2amd_ctx *c)
 			}
 			if(v.inline_pos >= 0) {
 				auto &d = bydepth[v.depth];
-				v.cls = !(c->no_fast & 4) && is_driver_chain(c, v) ? CLS_BUSDRIVER : CLS_BUSGENERIC;
+				v.cls = !(c->no_fast & 4) && is_driver_chain(c, v) ? CLS_BUSDRIVER :
+						!(c->no_fast & 32) && v.depth > 0 && is_fbdchain(c, v) ? CLS_FBDCHAIN : CLS_BUSGENERIC;
 				// (the master bus at offset 0 is the root's alone)
-				if(v.cls != CLS_BUSDRIVER || (v.out_off == 0) != (v.depth == 0))
+				if(v.cls == CLS_BUSGENERIC || (v.out_off == 0) != (v.depth == 0))
 					owners_ok = false;
 				else if(v.depth == 0)
 					root_driver = true;
-				(v.cls == CLS_BUSDRIVER ? d.first : d.second).push_back((int)vi);
+				(v.cls == CLS_BUSDRIVER ? d.first : v.cls == CLS_FBDCHAIN ? fbd_bydepth[v.depth] : d.second).push_back((int)vi);
 				maxdepth = std::max(maxdepth, v.depth);
 			} else {
 				v.cls = !(c->no_fast & 1) && is_oscpan_chain(c, v) ? CLS_OSCPAN :
@@ -796,6 +831,9 @@ int upload(a2amd_ctx *c)
 			r.fast_first = (int)c->list_all.size();
 			r.fast_count = (int)l.first.size();
 			c->list_all.insert(c->list_all.end(), l.first.begin(), l.first.end());
+			r.fbd_first = (int)c->list_all.size();
+			r.fbd_count = (int)fbd_bydepth[d].size();
+			c->list_all.insert(c->list_all.end(), fbd_bydepth[d].begin(), fbd_bydepth[d].end());
 			r.gen_first = (int)c->list_all.size();
 			r.gen_count = (int)l.second.size();
 			c->list_all.insert(c->list_all.end(), l.second.begin(), l.second.end());
@@ -818,7 +856,7 @@ int upload(a2amd_ctx *c)
 			// (fm-panmix voices execute their own records in k_leaf_fmpan)
 			if(v.cls == CLS_OSCPAN || v.cls == CLS_OSCFILTPAN || v.cls == CLS_OSC2PAN)
 				dyn_leaf.push_back(vi);
-			else if(v.cls == CLS_BUSDRIVER && v.depth < (int)dyn_bus.size())
+			else if((v.cls == CLS_BUSDRIVER || v.cls == CLS_FBDCHAIN) && v.depth < (int)dyn_bus.size())
 				dyn_bus[v.depth].push_back(vi);
 		}
 		// (the walk order usually has them grouped by bus already)
@@ -951,6 +989,11 @@ int launch_depth(a2amd_ctx *c, int d, int consume, A2DCommitSet *pend)	// consum
 		pend->n = 0;
 		++c->stats.launches;
 	}
+	if(r.fbd_count) {
+		if(a2d_launch_bus_fbdchain(c->d_params, c->d_list.d + r.fbd_first, r.fbd_count, consume & 1, c->stream))
+			return c->fail(A2AMD_EHIP, "delay chain launch failed: %s", hipGetErrorString(hipGetLastError()));
+		++c->stats.launches;
+	}
 	if(r.gen_count) {
 		if(a2d_launch_voices(c->d_params, c->d_list.d + r.gen_first, r.gen_count, 1, c->stream))
 			return c->fail(A2AMD_EHIP, "bus launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -968,6 +1011,29 @@ int pick_vpw(int n)
 {
 	int v = n / 4096;
 	return std::min(std::max(v, 1), (int)A2D_MAXVPW);
+}
+
+// give a region of the wave pool back: kept sorted by offset, neighbours merged
+void wavepool_release(a2amd_ctx *c, size_t off, size_t len)
+{
+	if(!len)
+		return;
+	auto &fl = c->wavepool_free;
+	auto it = std::lower_bound(fl.begin(), fl.end(), std::make_pair(off, (size_t)0));
+	it = fl.insert(it, std::make_pair(off, len));
+	if(it + 1 != fl.end() && it->first + it->second == (it + 1)->first) {
+		it->second += (it + 1)->second;
+		it = fl.erase(it + 1) - 1;
+	}
+	if(it != fl.begin() && (it - 1)->first + (it - 1)->second == it->first) {
+		(it - 1)->second += it->second;
+		it = fl.erase(it) - 1;
+	}
+	// the tail of the pool grows back into unused space
+	if(it->first + it->second == c->wavepool_used) {
+		c->wavepool_used = it->first;
+		fl.erase(it);
+	}
 }
 
 void end_batch(a2amd_ctx *c)
@@ -1026,6 +1092,12 @@ void end_batch(a2amd_ctx *c)
 		c->xio_free.push_back(b);
 	}
 	c->xio_deferred_free.clear();
+	for(auto &r : c->deferred_wavepool_free)
+		wavepool_release(c, r.first, r.second);
+	c->deferred_wavepool_free.clear();
+	for(int w : c->deferred_wave_slots)
+		c->free_wave_slots.push_back(w);
+	c->deferred_wave_slots.clear();
 	c->nfrags = 0;
 	c->cur_frag = 0;
 	c->frag_open = false;
@@ -1338,12 +1410,18 @@ int a2amd_wave_upload(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w)
 		if(c->waves[i].live && c->waves[i].key == key)
 			id = (int)i;
 	if(id < 0) {
-		id = (int)c->waves.size();
-		c->waves.push_back(HWave());
-		c->mwaves.push_back(A2DWave());
+		if(!c->free_wave_slots.empty()) {
+			id = c->free_wave_slots.back();
+			c->free_wave_slots.pop_back();
+		} else {
+			id = (int)c->waves.size();
+			c->waves.push_back(HWave());
+			c->mwaves.push_back(A2DWave());
+		}
 	} else {
-		// same key again: the old data is replaced
-		c->wavepool_free.push_back(std::make_pair(c->waves[id].pool_off, c->waves[id].pool_len));
+		// same key again: the old data is replaced (what is recorded plays the old)
+		if(c->waves[id].pool_len)
+			c->deferred_wavepool_free.push_back(std::make_pair(c->waves[id].pool_off, c->waves[id].pool_len));
 		--c->stats.live_waves;
 	}
 	HWave &hw = c->waves[id];
@@ -1366,7 +1444,7 @@ int a2amd_wave_upload(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w)
 			c->wavepool_free[k].first += total;
 			c->wavepool_free[k].second -= total;
 			if(!c->wavepool_free[k].second)
-				c->wavepool_free.erase(c->wavepool_free.begin() + k);
+				c->wavepool_free.erase(c->wavepool_free.begin() + (long)k);
 			// work in flight may still read the old contents
 			HIPCHK(c, hipStreamSynchronize(c->stream));
 			break;
@@ -1399,8 +1477,16 @@ int a2amd_wave_drop(a2amd_ctx *c, uint64_t key)
 			c->waves[i].live = false;
 			c->waves[i].dw.size[0] = 0;	// "unloaded", waves.c:717-723
 			if(c->waves[i].pool_len)
-				c->wavepool_free.push_back(std::make_pair(c->waves[i].pool_off, c->waves[i].pool_len));
+				c->deferred_wavepool_free.push_back(std::make_pair(c->waves[i].pool_off, c->waves[i].pool_len));
 			c->waves[i].pool_len = 0;
+			c->waves[i].key = 0;
+			c->deferred_wave_slots.push_back((int)i);
+			if(!c->nfrags && !c->frag_open) {
+				// nothing recorded that could play it: free at once
+				for(auto &r : c->deferred_wavepool_free)
+					wavepool_release(c, r.first, r.second);
+				c->deferred_wavepool_free.clear();
+			}
 			c->mwaves[i] = c->waves[i].dw;
 			c->waves_dirty = true;
 			--c->stats.live_waves;
@@ -1582,6 +1668,11 @@ int a2amd_unit_init(a2amd_ctx *c, uint64_t key, int kind, unsigned flags, int ni
 			u.fbdbuf = c->fbd_count++;
 		c->fbd_to_zero.push_back(u.fbdbuf);
 		initval = u.fbdbuf;
+		{	// fbdelay_Initialize, fbdelay.c:183-196: 400 / 280 / 320 ms
+			static const int ms[3] = { 400, 280, 320 };
+			for(int t = 0; t < 3; ++t)
+				u.fbd_taps[t] = (int)((int64_t)(ms[t] << 16) * c->cfg.samplerate / 65536000);
+		}
 		break;
 	  case A2AMD_INLINE:
 		v.inline_pos = u.chainpos;
@@ -1678,6 +1769,14 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 			if(nmode == A2D_OSC_NOISE && !(u.shadow_ok && u.shadow_epoch == c->shadow_epoch))
 				return c->fail(A2AMD_EUNSUPPORTED, "oscillator switched to noise after rendering through "
 						"fragment_repeat/replay: its phase was not shadowed on the host");
+			{
+				// the wavetable leaf kernels only know mip-mapped waves (and "off"): a
+				// voice that moves between the two kinds changes its launch class
+				const bool was = u.mode == A2D_OSC_MIPWAVE || u.mode == A2D_OSC_OFF;
+				const bool is = nmode == A2D_OSC_MIPWAVE || nmode == A2D_OSC_OFF;
+				if(was != is)
+					c->lists_dirty = true;
+			}
 			if(u.mode == A2D_OSC_NOISE && nmode != A2D_OSC_NOISE)
 				--c->n_noise;
 			if(u.mode != A2D_OSC_NOISE && nmode == A2D_OSC_NOISE)
@@ -1735,6 +1834,14 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 	  case A2AMD_FBDELAY:
 		if(reg < 0 || reg > 6)
 			return c->fail(A2AMD_EINVAL, "fbdelay register %d", reg);
+		if(reg < 3) {	// fbdelay_FBDelay / LDelay / RDelay, fbdelay.c:231-247
+			const int frames = (int)((int64_t)value * c->cfg.samplerate / 65536000);
+			// (a tap that stops or starts being at least a fragment long moves the
+			// voice between the frame-parallel delay kernel and the general one)
+			if(fbd_tap_ok(frames) != fbd_tap_ok(u.fbd_taps[reg]))
+				c->lists_dirty = true;
+			u.fbd_taps[reg] = frames;
+		}
 		break;
 	  case A2AMD_INLINE:
 	  case A2AMD_XINSERT:

@@ -27,6 +27,7 @@
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -43,17 +44,16 @@ extern int a2_SetStateProperty(void *iface, int prop, int v);
 extern int a2r_Error(void *st, int e, const char *info) __attribute__((weak));
 extern int a2_XinsertRemoveClient(A2P_xinsert_client *xic) __attribute__((weak));
 
-#define MAXSTATES 16
-#define MAXWAVES  4096
-#define MAXPEND   1024
-#define MAXZOMBIES 16
+#define MAXSTATES 256		/* engine states (master + substates) alive at once in one process */
 
 /* a READ client's window, waiting for the audio of its fragment */
 typedef struct PENDING
 {
 	A2P_xinsert		*xi;
 	A2P_xinsert_client	*xic;
-	int			uid;
+	int			uid;		/* backend unit, or -1: the root xinsert (its input is the master bus) */
+	int			frag;		/* fragment of the batch the window lies in */
+	unsigned		pos;		/* root xinsert: frames into the buffer */
 	const char		*what;		/* for error reports */
 	unsigned		offset, frames;
 } PENDING;
@@ -63,22 +63,44 @@ typedef struct HOSTSTATE
 	A2P_config	*cfg;
 	a2amd_ctx	*ctx;
 	int		refs;
+	int		failed;		/* the backend reported an error: this state renders silence from here on */
 	int		depth;		/* open inline windows */
 	unsigned	base;		/* engine offset of the current root window */
 	A2P_vmstate	*root_vms;	/* the root voice (first voice of a state) */
 	A2P_vmstate	*chain_vms;	/* voice whose chain is being populated */
 	A2P_unit	*chain_last;
-	A2P_wave	*wave_ptr[MAXWAVES];
-	int		wave_id[MAXWAVES];
-	int		nwaves;
+	A2P_xinsert	*root_xi;	/* the root voice's xinsert (the engine's own instance) */
+	void		*engine_state;	/* A2_state, for a2r_Error */
+	/* wave registry: engine object -> device wave id */
+	A2P_wave	**wave_ptr;
+	int		*wave_id;
+	int		nwaves, cap_waves;
+	int		swept;		/* the registry has been checked for released waves in this buffer */
 	int32_t		out[A2AMD_MAXCHANNELS][A2AMD_MAXFRAG];
-	PENDING		pend[MAXPEND];
-	int		npend;
-	A2P_xinsert	*zombies[MAXZOMBIES];	/* client lists of xinserts that died owing windows */
-	int		nzombies;
+	PENDING		*pend;
+	int		npend, cap_pend;
+	A2P_xinsert	**zombies;	/* client lists of xinserts that died owing windows */
+	int		nzombies, cap_zombies;
+	/* One GPU round trip per driver buffer (a2_Run() / a realtime driver's callback)
+	 * instead of one per root window: */
+	unsigned	max_batch;	/* fragments the backend records between renders */
+	A2P_audiodriver	*drv;		/* the state's audio driver, once our Process sits in front of the engine's */
+	void		(*drv_process)(A2P_audiodriver *driver, unsigned frames);	/* the engine's: a2_AudioCallback */
+	int		in_buffer;	/* inside drv_process() */
+	int		decided;	/* ... and 'batching' has been chosen for this buffer */
+	int		batching;	/* the buffer is recorded whole and rendered at its end */
+	unsigned	batch_frags;	/* backend fragments recorded since the last render */
+	unsigned	rec_pos;	/* frames of the buffer recorded so far */
+	unsigned	win_pos;	/* ... up to the start of the open root window */
+	unsigned	acc_pos;	/* frames of the buffer rendered so far (in acc) */
+	unsigned	acc_cap;
+	int32_t		*acc[A2AMD_MAXCHANNELS];	/* the buffer's master bus, as rendered */
+	int32_t		*rinj[A2AMD_MAXCHANNELS];	/* what WRITE clients of the root xinsert produced */
+	int		rinj_used;
 } HOSTSTATE;
 
 static HOSTSTATE states[MAXSTATES];
+static pthread_mutex_t states_mtx = PTHREAD_MUTEX_INITIALIZER;	/* independent master states may open from different threads */
 
 /* Our per-instance data lives in the engine's 384 byte instance block: right
  * behind the A2_unit header (the cache line after the one the engine's dispatch
@@ -96,6 +118,8 @@ typedef struct XTRA
 	A2P_process_cb	orig_process;
 	A2P_wave	*wave;		/* wtosc: the wave it plays (engine object), or NULL */
 	int		chain_checked;	/* the units behind us in the voice have been looked at */
+	int		refused;	/* an unsupported client was reported once */
+	void		(*orig_setprocess)(A2P_unit *u);	/* root xinsert: the engine's xi_SetProcess */
 } XTRA;
 
 _Static_assert(sizeof(A2P_unit) <= 64 && 64 + sizeof(XTRA) <= A2P_BLOCK_SIZE, "XTRA placement");
@@ -108,11 +132,25 @@ static inline XTRA *xtra(A2P_unit *u)
 	return (XTRA *)((char *)u + 64);
 }
 
-static void die(HOSTSTATE *hs, const char *what, int rc)
+/* A backend call failed.  There is no CPU path to continue on, and a library
+ * inside somebody's audio application does not get to abort(): the error goes
+ * to the engine's own channel (a2r_Error, src/interface.c:401-424 - the
+ * application sees it through a2_LastRTError() / its log) and this engine state
+ * renders silence from here on. */
+static void fail(HOSTSTATE *hs, const char *what, int rc)
 {
-	fprintf(stderr, "a2amd units: %s failed (%d): %s\n", what, rc,
-			a2amd_last_error(hs ? hs->ctx : NULL));
-	abort();	/* there is no CPU fallback to continue on */
+	static char msg[MAXSTATES][160];	/* (a2r_Error keeps the pointer: realtime states post it to the API side) */
+	char *m;
+	if(hs && hs->failed)
+		return;
+	m = msg[hs ? hs - states : 0];
+	snprintf(m, sizeof(msg[0]), "a2amd: %s failed (%d): %s", what, rc, a2amd_last_error(hs ? hs->ctx : NULL));
+	if(hs)
+		hs->failed = 1;
+	if(a2r_Error && hs && hs->engine_state)
+		a2r_Error(hs->engine_state, A2P_INTERNAL, m);
+	else
+		fprintf(stderr, "a2amd units: %s\n", m);
 }
 
 static const A2P_unitdesc *orig_desc(const char *sym)
@@ -129,50 +167,80 @@ static const A2P_unitdesc *orig_desc(const char *sym)
 		d = (const A2P_unitdesc *)dlsym(RTLD_DEFAULT, alt);
 	}
 	if(!d)
-	{
 		fprintf(stderr, "a2amd units: the engine has no %s to wrap\n", sym);
-		abort();
-	}
-	return d;
+	return d;	/* NULL: the caller fails its OpenState / Initialize, the engine reports it */
 }
 
 /* ---- state open / close (A2_unitdesc.OpenState / CloseState) -------------*/
 static int amd_open(A2P_config *cfg, void **statedata)
 {
-	int i, f = -1;
+	int i, f = -1, rc = 0;
+	/* No GPU: fail where the engine can still fail cleanly - a2_RegisterUnit()
+	 * returns the error and a2_Open() hands it to the application
+	 * (src/units.c:142-146, src/audiality2.c:256-260).  (The backend itself is opened
+	 * later: A2_config.basepitch is not valid yet.) */
+	if(a2amd_device_count() <= 0)
+	{
+		fprintf(stderr, "a2amd units: no usable HIP device; this library has no CPU fallback\n");
+		return A2P_DEVICEOPEN;
+	}
+	pthread_mutex_lock(&states_mtx);
 	for(i = 0; i < MAXSTATES; ++i)
 		if(states[i].refs && states[i].cfg == cfg)
 		{
 			++states[i].refs;
 			*statedata = &states[i];
+			pthread_mutex_unlock(&states_mtx);
 			return 0;
 		}
 		else if(!states[i].refs && f < 0)
 			f = i;
 	if(f < 0)
-		return 1;
-	memset(&states[f], 0, sizeof(HOSTSTATE));
-	states[f].cfg = cfg;
-	states[f].refs = 1;
-	*statedata = &states[f];
-	return 0;
+		rc = A2P_OOMEMORY;
+	else
+	{
+		memset(&states[f], 0, sizeof(HOSTSTATE));
+		states[f].cfg = cfg;
+		states[f].refs = 1;
+		*statedata = &states[f];
+	}
+	pthread_mutex_unlock(&states_mtx);
+	return rc;
 }
 
 static void amd_close(void *statedata)
 {
 	HOSTSTATE *hs = (HOSTSTATE *)statedata;
-	if(hs && !--hs->refs && hs->ctx)
+	int c;
+	if(!hs)
+		return;
+	pthread_mutex_lock(&states_mtx);
+	if(!--hs->refs)
 	{
-		a2amd_close(hs->ctx);
+		if(hs->ctx)
+			a2amd_close(hs->ctx);
 		hs->ctx = NULL;
+		/* (the engine clears A2_audiodriver.Process itself when the state closes,
+		 * src/audiality2.c:733) */
+		free(hs->wave_ptr);
+		free(hs->wave_id);
+		free(hs->pend);
+		free(hs->zombies);
+		for(c = 0; c < A2AMD_MAXCHANNELS; ++c)
+		{
+			free(hs->acc[c]);
+			free(hs->rinj[c]);
+		}
+		memset(hs, 0, sizeof(*hs));
 	}
+	pthread_mutex_unlock(&states_mtx);
 }
 
 /* the backend is opened on first use: A2_config.basepitch is only valid once
  * a2_Open() has returned (audiality2.c:398) */
 static a2amd_ctx *ctx_of(HOSTSTATE *hs)
 {
-	if(!hs->ctx)
+	if(!hs->ctx && !hs->failed)
 	{
 		a2amd_config c;
 		int rc;
@@ -190,9 +258,19 @@ static a2amd_ctx *ctx_of(HOSTSTATE *hs)
 			int n = a2amd_device_count();
 			c.device = n > 0 ? (int)(hs - states) % n : 0;
 		}
-		c.max_batch = 1;
+		/* fragments recorded per GPU round trip: a whole driver buffer, up to 256
+		 * (A2AMD_BATCH=1: one round trip per root window, as in round 1) */
+		c.max_batch = getenv("A2AMD_BATCH") ? (unsigned)atoi(getenv("A2AMD_BATCH")) : 256;
+		if(c.max_batch < 1)
+			c.max_batch = 1;
+		if(c.max_batch > 256)
+			c.max_batch = 256;
+		hs->max_batch = c.max_batch;
 		if((rc = a2amd_open(&c, &hs->ctx)))
-			die(NULL, "a2amd_open", rc);
+		{
+			hs->ctx = NULL;
+			fail(hs, "a2amd_open", rc);
+		}
 	}
 	return hs->ctx;
 }
@@ -211,6 +289,8 @@ static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned 
 	x->vms = vms;
 	x->kind = kind;
 	x->uid = -1;
+	if(!ctx)
+		return A2P_DEVICEOPEN;	/* no GPU backend: the engine reports A2_VOICEINIT and drops the voice */
 	if(!hs->root_vms)
 		hs->root_vms = vms;
 	x->is_root = vms == hs->root_vms;
@@ -227,7 +307,7 @@ static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned 
 		lflags |= A2AMD_PROCADD;
 	}
 	if(x->is_root && kind == A2AMD_XINSERT)
-		forward = 0;	/* stays with the engine */
+		forward = 0;	/* stays with the engine (its input is the master bus we hand back) */
 	if(forward && !hs->chain_last && kind != A2AMD_INLINE &&
 			(u->ninputs || ((flags & A2AMD_PROCADD) && !wired)))
 	{
@@ -236,7 +316,7 @@ static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned 
 		fprintf(stderr, "a2amd units: '%s' is the first GPU-rendered unit of its voice but takes its "
 				"input from a unit that is not replaced: mixed CPU/GPU chains are not "
 				"supported (no CPU fallback)\n", u->descriptor->name);
-		return 1;	/* A2_VOICEINIT for this voice */
+		return A2P_NOTIMPLEMENTED;	/* A2_VOICEINIT for this voice */
 	}
 	if(forward)
 	{
@@ -246,7 +326,7 @@ static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned 
 		{
 			fprintf(stderr, "a2amd units: cannot instantiate unit kind %d: %s\n", kind,
 					a2amd_last_error(ctx));
-			return 1;	/* the engine reports A2_VOICEINIT and drops the voice */
+			return A2P_NOTIMPLEMENTED;	/* the engine reports A2_VOICEINIT and drops the voice */
 		}
 	}
 	hs->chain_last = u;
@@ -257,36 +337,50 @@ static void amd_deinit(A2P_unit *u)
 {
 	XTRA *x = xtra(u);
 	int rc;
+	if(!x->hs)
+		return;
 	if(x->hs->chain_last == u)
 		x->hs->chain_last = NULL;
-	if(x->uid >= 0 && (rc = a2amd_unit_deinit(x->hs->ctx, x->uid)))
-		die(x->hs, "a2amd_unit_deinit", rc);
+	if(x->uid >= 0 && !x->hs->failed && (rc = a2amd_unit_deinit(x->hs->ctx, x->uid)))
+		fail(x->hs, "a2amd_unit_deinit", rc);
 }
 
 /* ---- Process ---------------------------------------------------------------------*/
 /* A wave released by the application keeps its A2_wave for one more engine
- * cycle with size[0] = 0 ("unloaded", waves.c:711-718); the engine's wtosc looks
- * at that at the top of every Process call (wtosc.c:168-183) and so do we: the
- * device copy is dropped, every oscillator playing it goes silent. */
-static void check_unloaded(XTRA *x)
+ * cycle with size[0] = 0 ("unloaded", a2_discard_wave, waves.c:711-718: set
+ * under the engine lock, i.e. between two buffers; freed by an end-of-cycle
+ * event once every state has processed a buffer).  The engine's wtosc looks at
+ * that at the top of every Process call (wtosc.c:168-183), which only matters
+ * for oscillators playing the wave; the registry below must forget the object in
+ * that one cycle whether anybody plays it or not - the allocator hands the same
+ * address to the next wave - so it is swept once per buffer, before the first
+ * voice is walked. */
+static void sweep_waves(HOSTSTATE *hs)
 {
-	HOSTSTATE *hs = x->hs;
-	A2P_wave *w = x->wave;
 	int i, rc;
-	if(!w || (w->type != A2AMD_WWAVE && w->type != A2AMD_WMIPWAVE) || w->size[0])
-		return;
-	x->wave = NULL;
-	for(i = 0; i < hs->nwaves; ++i)
-		if(hs->wave_ptr[i] == w)
+	for(i = 0; i < hs->nwaves; )
+	{
+		A2P_wave *w = hs->wave_ptr[i];
+		if((w->type == A2AMD_WWAVE || w->type == A2AMD_WMIPWAVE) && !w->size[0])
 		{
-			if((rc = a2amd_wave_drop(hs->ctx, (uint64_t)(uintptr_t)w)))
-				die(hs, "a2amd_wave_drop", rc);
-			/* forget the address: malloc may hand it out again */
+			if(!hs->failed && (rc = a2amd_wave_drop(hs->ctx, (uint64_t)(uintptr_t)w)))
+				fail(hs, "a2amd_wave_drop", rc);
 			hs->wave_ptr[i] = hs->wave_ptr[hs->nwaves - 1];
 			hs->wave_id[i] = hs->wave_id[hs->nwaves - 1];
 			--hs->nwaves;
-			break;
 		}
+		else
+			++i;
+	}
+}
+
+/* ... and an oscillator playing such a wave forgets it like wtosc_check_unloaded */
+static void check_unloaded(XTRA *x)
+{
+	A2P_wave *w = x->wave;
+	if(!w || (w->type != A2AMD_WWAVE && w->type != A2AMD_WMIPWAVE) || w->size[0])
+		return;
+	x->wave = NULL;
 }
 
 /* Units of the engine (or of the application, a2_RegisterUnit) that are NOT
@@ -312,16 +406,23 @@ static int is_ours(const A2P_unitdesc *d)
 static void check_chain_behind(A2P_unit *u)
 {
 	const A2P_unit *n;
+	XTRA *x = xtra(u);
 
 	for(n = u->next; n && !is_ours(n->descriptor); n = n->next)
 		if(n->descriptor->maxinputs || n->descriptor->maxoutputs)	/* (the unit's own counts are
 				not meaningful for a port-less unit: the engine still hands env one) */
 		{
-			fprintf(stderr, "a2amd units: unit '%s' (%u in, %u out) sits behind a GPU-rendered '%s' in "
-					"one voice but is not replaced: mixed CPU/GPU chains are not supported "
-					"(no CPU fallback)\n", n->descriptor->name, n->ninputs, n->noutputs,
-					u->descriptor->name);
-			abort();
+			/* reported once per voice through the engine's error channel; that
+			 * unit keeps processing the silence in its CPU buffers */
+			static char msg[200];
+			snprintf(msg, sizeof(msg), "a2amd: unit '%s' sits behind a GPU-rendered '%s' in one voice "
+					"but is not replaced: it processes silence (mixed CPU/GPU chains are "
+					"not supported, no CPU fallback)", n->descriptor->name, u->descriptor->name);
+			if(a2r_Error && x->hs->engine_state)
+				a2r_Error(x->hs->engine_state, A2P_NOTIMPLEMENTED, msg);
+			else
+				fprintf(stderr, "a2amd units: %s\n", msg);
+			return;
 		}
 }
 
@@ -333,14 +434,30 @@ static void client_error(A2P_xinsert *xi, int res, const char *info)
 		fprintf(stderr, "a2amd units: %s: error %d\n", info, res);
 }
 
+static PENDING *new_pending(HOSTSTATE *hs)
+{
+	if(hs->npend == hs->cap_pend)
+	{
+		int nc = hs->cap_pend ? hs->cap_pend * 2 : 256;
+		PENDING *np = (PENDING *)realloc(hs->pend, nc * sizeof(PENDING));
+		if(!np)
+			return NULL;
+		hs->pend = np;
+		hs->cap_pend = nc;
+	}
+	return &hs->pend[hs->npend++];
+}
+
 /* xi_process (src/units/xinsert.c:60-142) for an xinsert whose audio is on the
  * GPU.  WRITE-only clients (a2_SourceCallback, a2_OpenSource) produce audio
  * without looking at any: they run here, in the walk, and their sum travels
  * with the batch.  READ-only clients (a2_SinkCallback, a2_OpenSink) are handed
  * the unit's input, which exists once the fragment has been rendered: their
- * windows are noted and served, in walk order, when the root window's audio
- * comes back (deliver_pending).  An insert client (READ and WRITE) would need
- * its voice's audio on the host in the middle of the GPU batch. */
+ * windows are noted and served, in walk order, when the audio comes back
+ * (deliver_pending).  An insert client (READ and WRITE) would need its voice's
+ * audio on the host in the middle of the GPU batch: reported through the
+ * engine's error channel, once, and not served (it sees nothing, the voice's
+ * signal passes through as if it were not there). */
 static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned frames)
 {
 	HOSTSTATE *hs = x->hs;
@@ -352,6 +469,8 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 	unsigned mode = 0;
 	int rc, i;
 	unsigned s;
+	if(hs->failed)
+		return;
 	/* xsink hands every client its inputs (xsink.c:41-44), xsource adds up every
 	 * client's output (xsource.c:69-77); xinsert looks at the client's flags */
 	for(xic = xi->clients; xic; xic = xic->next)
@@ -361,17 +480,23 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 			mode |= A2AMD_XIO_INJECT;
 		else if((xic->flags & A2P_XI_READ) && (xic->flags & A2P_XI_WRITE))
 		{
-			fprintf(stderr, "a2amd units: an insert client (a2_InsertCallback) was attached to a voice "
-					"other than the root voice: its audio is on the GPU (sink and source "
-					"clients are served; inserts are unsupported, no CPU fallback)\n");
-			abort();
+			if(!x->refused)
+			{
+				x->refused = 1;
+				client_error(xi, A2P_NOTIMPLEMENTED, "a2amd: insert client (a2_InsertCallback) on a voice "
+						"other than the root voice: its audio is on the GPU; not served (sink "
+						"and source clients are)");
+			}
 		}
 		else
 			mode |= (xic->flags & A2P_XI_WRITE) ? A2AMD_XIO_INJECT : A2AMD_XIO_TAP;
 	if(mode != x->client_mode)
 	{
 		if((rc = a2amd_unit_clients(hs->ctx, x->uid, mode)))
-			die(hs, "a2amd_unit_clients", rc);
+		{
+			fail(hs, "a2amd_unit_clients", rc);
+			return;
+		}
 		x->client_mode = mode;
 	}
 	if(mode & A2AMD_XIO_INJECT)
@@ -387,7 +512,7 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 		memset(sum, 0, sizeof(sum));
 		for(xic = xi->clients; xic; xic = xic->next)
 		{
-			if(x->kind == A2AMD_XINSERT && !(xic->flags & A2P_XI_WRITE))
+			if(x->kind == A2AMD_XINSERT && ((xic->flags & (A2P_XI_READ | A2P_XI_WRITE)) != A2P_XI_WRITE))
 				continue;
 			memset(tmp, 0, sizeof(tmp));
 			for(i = 0; i < nch; ++i)
@@ -401,7 +526,7 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 		for(i = 0; i < nch; ++i)
 			sump[i] = sum[i];
 		if((rc = a2amd_unit_inject(hs->ctx, x->uid, offset - hs->base, frames, sump)))
-			die(hs, "a2amd_unit_inject", rc);
+			fail(hs, "a2amd_unit_inject", rc);
 	}
 	if(mode & A2AMD_XIO_TAP)
 		for(xic = xi->clients; xic; xic = xic->next)
@@ -409,19 +534,23 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 			PENDING *p;
 			if(x->kind == A2AMD_XINSERT && (xic->flags & A2P_XI_WRITE))
 				continue;
-			if(hs->npend >= MAXPEND)
-				die(hs, "more sink client windows in one fragment than the drop-in holds", -MAXPEND);
-			p = &hs->pend[hs->npend++];
+			if(!(p = new_pending(hs)))
+			{
+				fail(hs, "out of memory for sink client windows", -1);
+				return;
+			}
 			p->xi = xi;
 			p->xic = xic;
 			p->uid = x->uid;
+			p->frag = hs->batch_frags ? (int)hs->batch_frags - 1 : 0;
+			p->pos = 0;
 			p->what = what;
 			p->offset = offset - hs->base;
 			p->frames = frames;
 		}
 }
 
-/* The root window has been rendered: hand the READ clients their windows. */
+/* Audio is back: hand the READ clients their windows, in walk order. */
 static void deliver_pending(HOSTSTATE *hs)
 {
 	int k, i, n, rc;
@@ -435,12 +564,25 @@ static void deliver_pending(HOSTSTATE *hs)
 		 * stand-in xi_deinit left for it, is alive) */
 		for(c = p->xi->clients; c && c != p->xic; c = c->next)
 			;
-		if(!c)
+		if(!c || hs->failed)
 			continue;
-		if((n = a2amd_unit_tapped(hs->ctx, p->uid, 0, bufs)) < 0)
-			die(hs, "a2amd_unit_tapped", n);
-		for(i = 0; i < n; ++i)
-			bufp[i] = (int32_t *)bufs[i] + p->offset;
+		if(p->uid < 0)
+		{
+			/* the root xinsert's input is the master bus as rendered */
+			n = p->xi->header.ninputs;
+			for(i = 0; i < n; ++i)
+				bufp[i] = hs->acc[i] + p->pos;
+		}
+		else
+		{
+			if((n = a2amd_unit_tapped(hs->ctx, p->uid, (unsigned)p->frag, bufs)) < 0)
+			{
+				fail(hs, "a2amd_unit_tapped", n);
+				continue;
+			}
+			for(i = 0; i < n; ++i)
+				bufp[i] = (int32_t *)bufs[i] + p->offset;
+		}
 		if((rc = c->callback(bufp, n, p->frames, c->userdata)))
 			client_error(p->xi, rc, p->what);
 	}
@@ -456,11 +598,142 @@ static void deliver_pending(HOSTSTATE *hs)
 	hs->nzombies = 0;
 }
 
+/* ---- one GPU round trip per driver buffer ----------------------------------------
+ * The engine's per-buffer entry point (a2_AudioCallback, src/core.c:1927-2001)
+ * cuts a buffer into fragments of at most 64 frames, walks the voice tree once
+ * per fragment and copies the master bus into A2_audiodriver.buffers.  Nothing it
+ * or the VM reads during that walk is produced by audio rendering (the noise
+ * oscillators' draw counts and filter coefficients are mirrored on the host), so
+ * the walk of the whole buffer can be RECORDED first and rendered afterwards: our
+ * Process, installed in front of the engine's, lets the engine walk, then renders
+ * the recorded batch (up to 256 fragments per launch sequence, more than one
+ * sequence for longer buffers) and writes the result where a2_ProcessMaster
+ * (core.c:1900-1907) would have.  Sink clients get their windows after that, in
+ * walk order (they cannot tell: they run inside the same a2_Run()).  The one
+ * thing that cannot be deferred is an INSERT client on the root xinsert - it
+ * transforms the master bus on the CPU window by window - so a buffer that starts
+ * with one attached is rendered the old way, one round trip per root window. */
+static int root_has_inserts(HOSTSTATE *hs)
+{
+	A2P_xinsert_client *c;
+	if(!hs->root_xi)
+		return 0;
+	for(c = hs->root_xi->clients; c; c = c->next)
+		if((c->flags & A2P_XI_READ) && (c->flags & A2P_XI_WRITE))
+			return 1;
+	return 0;
+}
+
+static int grow_acc(HOSTSTATE *hs, unsigned frames)
+{
+	int c;
+	if(frames <= hs->acc_cap)
+		return 1;
+	for(c = 0; c < hs->cfg->channels && c < A2AMD_MAXCHANNELS; ++c)
+	{
+		int32_t *a = (int32_t *)realloc(hs->acc[c], frames * sizeof(int32_t));
+		int32_t *r = a ? (int32_t *)realloc(hs->rinj[c], frames * sizeof(int32_t)) : NULL;
+		if(a)
+			hs->acc[c] = a;
+		if(r)
+			hs->rinj[c] = r;
+		if(!a || !r)
+			return 0;
+	}
+	hs->acc_cap = frames;
+	return 1;
+}
+
+/* render what has been recorded of the buffer so far */
+static void flush_batch(HOSTSTATE *hs)
+{
+	int32_t *outp[A2AMD_MAXCHANNELS];
+	int c, n;
+	if(!hs->batch_frags)
+		return;
+	for(c = 0; c < A2AMD_MAXCHANNELS; ++c)
+		outp[c] = hs->acc[c] ? hs->acc[c] + hs->acc_pos : NULL;
+	if(!hs->failed)
+	{
+		n = a2amd_render(hs->ctx, A2AMD_RENDER_ALL, outp, hs->acc_cap - hs->acc_pos);
+		if(n != (int)(hs->rec_pos - hs->acc_pos))
+			fail(hs, "a2amd_render", n);
+	}
+	if(hs->failed)
+		for(c = 0; c < hs->cfg->channels; ++c)
+			memset(hs->acc[c] + hs->acc_pos, 0, (hs->rec_pos - hs->acc_pos) * sizeof(int32_t));
+	hs->acc_pos = hs->rec_pos;
+	hs->batch_frags = 0;
+	if(hs->npend || hs->nzombies)
+		deliver_pending(hs);
+}
+
+static HOSTSTATE *state_of_config(A2P_config *cfg)
+{
+	int i;
+	for(i = 0; i < MAXSTATES; ++i)
+		if(states[i].refs && states[i].cfg == cfg)
+			return &states[i];
+	return NULL;
+}
+
+static void amd_drv_process(A2P_audiodriver *drv, unsigned frames)
+{
+	HOSTSTATE *hs = state_of_config(drv->driver.config);
+	int c;
+	unsigned s;
+	if(!hs || !hs->drv_process)
+		return;
+	hs->in_buffer = 1;
+	hs->decided = hs->batching = hs->swept = 0;
+	hs->rec_pos = hs->win_pos = hs->acc_pos = 0;
+	hs->batch_frags = 0;
+	hs->rinj_used = 0;
+	if(!grow_acc(hs, frames))
+		hs->decided = 1;	/* (out of memory: this buffer the old way) */
+	hs->drv_process(drv, frames);	/* a2_AudioCallback: the engine walks, our units record */
+	if(hs->batching)
+	{
+		flush_batch(hs);
+		for(c = 0; c < hs->cfg->channels; ++c)
+		{
+			if(hs->rinj_used)
+				for(s = 0; s < hs->acc_pos; ++s)
+					hs->acc[c][s] = (int32_t)((uint32_t)hs->acc[c][s] + (uint32_t)hs->rinj[c][s]);
+			memcpy(drv->buffers[c], hs->acc[c], hs->acc_pos * sizeof(int32_t));
+		}
+	}
+	hs->in_buffer = hs->batching = 0;
+}
+
+/* put our Process in front of the engine's (which a2_Open installs after the
+ * units' states are open, src/audiality2.c:507-511): done from inside the first
+ * buffer the engine processes, which is itself rendered window by window */
+static void hook_driver(HOSTSTATE *hs)
+{
+	A2P_driver *d;
+	if(hs->drv || hs->max_batch <= 1)
+		return;
+	for(d = (A2P_driver *)hs->cfg->drivers; d; d = d->next)
+		if(d->type == A2P_AUDIODRIVER)
+		{
+			A2P_audiodriver *ad = (A2P_audiodriver *)d;
+			if(!ad->Process || ad->Process == amd_drv_process)
+				return;
+			hs->drv = ad;
+			hs->drv_process = ad->Process;
+			ad->Process = amd_drv_process;
+			return;
+		}
+}
+
 static void forward_process(XTRA *x, unsigned offset, unsigned frames)
 {
 	HOSTSTATE *hs = x->hs;
 	uint32_t noise = 0, before = 0;
 	int rc, v = 0, is_noise = 0;
+	if(hs->failed)
+		return;
 	if(x->kind == A2AMD_WTOSC)
 	{
 		check_unloaded(x);
@@ -475,7 +748,7 @@ static void forward_process(XTRA *x, unsigned offset, unsigned frames)
 		noise = before = (uint32_t)v;
 	}
 	if((rc = a2amd_unit_process(hs->ctx, x->uid, offset - hs->base, frames, is_noise ? &noise : NULL)))
-		die(hs, "a2amd_unit_process", rc);
+		fail(hs, "a2amd_unit_process", rc);
 	if(noise != before)
 		a2_SetStateProperty(hs->cfg->interface, A2P_PNOISESEED, (int)noise);
 }
@@ -491,16 +764,22 @@ static void amd_process(A2P_unit *u, unsigned offset, unsigned frames)
 		check_chain_behind(u);
 	}
 	forward_process(x, offset, frames);
-	if(x->is_root && x->kind == A2AMD_PANMIX)
+	if(x->is_root && x->kind == A2AMD_PANMIX && !hs->batching)
 	{
 		/* end of a root window: render it and hand the result to the engine */
 		int32_t *outp[A2AMD_MAXCHANNELS];
 		int c, n;
 		for(c = 0; c < A2AMD_MAXCHANNELS; ++c)
 			outp[c] = hs->out[c];
-		n = a2amd_render(hs->ctx, A2AMD_RENDER_ALL, outp, A2AMD_MAXFRAG);
-		if(n != (int)frames)
-			die(hs, "a2amd_render", n);
+		if(!hs->failed)
+		{
+			n = a2amd_render(hs->ctx, A2AMD_RENDER_ALL, outp, A2AMD_MAXFRAG);
+			if(n != (int)frames)
+				fail(hs, "a2amd_render", n);
+		}
+		if(hs->failed)
+			memset(hs->out, 0, sizeof(hs->out));
+		hs->batch_frags = 0;
 		for(c = 0; c < u->noutputs; ++c)
 			memcpy(u->outputs[c] + offset, hs->out[c], frames * sizeof(int32_t));
 		if(hs->npend || hs->nzombies)
@@ -517,16 +796,106 @@ static void amd_inline_process(A2P_unit *u, unsigned offset, unsigned frames)
 	if(!hs->depth)
 	{
 		/* a window of the root voice opens a backend fragment */
-		if((rc = a2amd_fragment(hs->ctx, frames)))
-			die(hs, "a2amd_fragment", rc);
+		hook_driver(hs);
+		if(!hs->swept)
+		{
+			sweep_waves(hs);
+			hs->swept = hs->in_buffer;	/* (outside our driver hook: every root window) */
+		}
+		if(hs->in_buffer && !hs->decided)
+		{
+			hs->decided = 1;
+			hs->batching = !root_has_inserts(hs);
+		}
+		if(hs->batching && hs->batch_frags == hs->max_batch)
+			flush_batch(hs);
+		if(!hs->failed && (rc = a2amd_fragment(hs->ctx, frames)))
+			fail(hs, "a2amd_fragment", rc);
+		++hs->batch_frags;
 		hs->base = offset;
+		hs->win_pos = hs->rec_pos;
+		hs->rec_pos += frames;
 	}
 	forward_process(x, offset, frames);
 	++hs->depth;
 	x->orig_process(u, offset, frames);	/* the engine walks the subvoices */
 	--hs->depth;
-	if((rc = a2amd_inline_end(hs->ctx, x->uid)))
-		die(hs, "a2amd_inline_end", rc);
+	if(!hs->failed && (rc = a2amd_inline_end(hs->ctx, x->uid)))
+		fail(hs, "a2amd_inline_end", rc);
+}
+
+/* The root voice's xinsert stays the engine's (it feeds the master bus and the
+ * application's clients - a2play's sink, an insert effect - with the audio we
+ * hand back).  In a batched buffer that audio does not exist yet when it runs:
+ * READ clients get their windows from the rendered master bus afterwards,
+ * WRITE-only clients run now and their output is added to the buffer at the end
+ * (xi_process, xinsert.c:95-119: output = input + what the clients wrote). */
+static void amd_rootx_process(A2P_unit *u, unsigned offset, unsigned frames)
+{
+	XTRA *x = xtra(u);
+	HOSTSTATE *hs = x->hs;
+	A2P_xinsert *xi = (A2P_xinsert *)u;
+	A2P_xinsert_client *xic;
+	int i, rc;
+	unsigned s;
+	if(!hs->batching)
+	{
+		x->orig_process(u, offset, frames);
+		return;
+	}
+	for(xic = xi->clients; xic; xic = xic->next)
+	{
+		if(!(xic->flags & A2P_XI_WRITE))
+		{
+			PENDING *p = new_pending(hs);
+			if(!p)
+			{
+				fail(hs, "out of memory for sink client windows", -1);
+				return;
+			}
+			p->xi = xi;
+			p->xic = xic;
+			p->uid = -1;
+			p->frag = 0;
+			p->pos = hs->win_pos;
+			p->what = "xinsert client callback";
+			p->offset = 0;
+			p->frames = frames;
+		}
+		else if(!(xic->flags & A2P_XI_READ))
+		{
+			int32_t tmp[A2AMD_MAXCHANNELS][A2AMD_MAXFRAG];
+			int32_t *bufp[A2AMD_MAXCHANNELS];
+			if(!hs->rinj_used)
+			{
+				for(i = 0; i < hs->cfg->channels; ++i)
+					memset(hs->rinj[i], 0, hs->acc_cap * sizeof(int32_t));
+				hs->rinj_used = 1;
+			}
+			memset(tmp, 0, sizeof(tmp));
+			for(i = 0; i < u->ninputs; ++i)
+				bufp[i] = tmp[i];
+			if((rc = xic->callback(bufp, u->ninputs, frames, xic->userdata)))
+				client_error(xi, rc, "xinsert client callback");
+			for(i = 0; i < u->ninputs && i < hs->cfg->channels; ++i)
+				for(s = 0; s < frames; ++s)
+					hs->rinj[i][hs->win_pos + s] = (int32_t)((uint32_t)hs->rinj[i][hs->win_pos + s] +
+							(uint32_t)tmp[i][s]);
+		}
+		else if(!x->refused)
+		{
+			/* (attached after the buffer began: served from the next one) */
+			x->refused = 1;
+		}
+	}
+}
+
+static void amd_rootx_setprocess(A2P_unit *u)
+{
+	XTRA *x = xtra(u);
+	x->orig_setprocess(u);		/* xi_SetProcess picks the engine's variant ... */
+	x->orig_process = u->Process;
+	u->Process = amd_rootx_process;	/* ... which runs unless the buffer is batched */
 }
 
 /* ---- control register writes --------------------------------------------------*/
@@ -539,8 +908,24 @@ static int wave_id_of(HOSTSTATE *hs, A2P_wave *w)
 	for(i = 0; i < hs->nwaves; ++i)
 		if(hs->wave_ptr[i] == w)
 			return hs->wave_id[i];
-	if(hs->nwaves >= MAXWAVES)
-		die(hs, "more waves in use than the drop-in's registry holds", -MAXWAVES);
+	if(hs->failed || !ctx_of(hs))
+		return -1;
+	if(hs->nwaves == hs->cap_waves)
+	{
+		int nc = hs->cap_waves ? hs->cap_waves * 2 : 256;
+		A2P_wave **np = (A2P_wave **)realloc(hs->wave_ptr, nc * sizeof(A2P_wave *));
+		int *ni = np ? (int *)realloc(hs->wave_id, nc * sizeof(int)) : NULL;
+		if(np)
+			hs->wave_ptr = np;
+		if(ni)
+			hs->wave_id = ni;
+		if(!np || !ni)
+		{
+			fail(hs, "out of memory for the wave registry", -1);
+			return -1;
+		}
+		hs->cap_waves = nc;
+	}
 	memset(&d, 0, sizeof(d));
 	d.type = w->type;
 	d.flags = w->flags;
@@ -553,7 +938,10 @@ static int wave_id_of(HOSTSTATE *hs, A2P_wave *w)
 	}
 	id = a2amd_wave_upload(ctx_of(hs), (uint64_t)(uintptr_t)w, &d);
 	if(id < 0)
-		die(hs, "a2amd_wave_upload", id);
+	{
+		fail(hs, "a2amd_wave_upload", id);
+		return -1;
+	}
 	hs->wave_ptr[hs->nwaves] = w;
 	hs->wave_id[hs->nwaves++] = id;
 	return id;
@@ -568,8 +956,10 @@ static void amd_write(A2P_unit *u, int reg, int v, unsigned start, unsigned dur)
 		x->wave = a2_GetWave(x->hs->cfg->interface, v >> 16);
 		v = wave_id_of(x->hs, x->wave);
 	}
+	if(x->hs->failed)
+		return;
 	if((rc = a2amd_unit_write(x->hs->ctx, x->uid, reg, v, start, dur, x->vms->r[A2P_R_TRANSPOSE])))
-		die(x->hs, "a2amd_unit_write", rc);
+		fail(x->hs, "a2amd_unit_write", rc);
 }
 
 #define WR(n) static void wr##n(A2P_unit *u, int v, unsigned s, unsigned d) { amd_write(u, n, v, s, d); }
@@ -673,16 +1063,25 @@ typedef struct WRAPSTATE { HOSTSTATE *hs; void *orig_sd; } WRAPSTATE;
 static int wrap_open(const char *sym, A2P_config *cfg, void **statedata)
 {
 	const A2P_unitdesc *od = orig_desc(sym);
-	WRAPSTATE *ws = (WRAPSTATE *)calloc(1, sizeof(WRAPSTATE));
+	WRAPSTATE *ws;
 	void *hs = NULL;
 	int rc;
-	if(!ws)
-		return 1;
+	if(!od)
+		return A2P_NOTIMPLEMENTED;
+	if(!(ws = (WRAPSTATE *)calloc(1, sizeof(WRAPSTATE))))
+		return A2P_OOMEMORY;
 	if((rc = amd_open(cfg, &hs)))
+	{
+		free(ws);
 		return rc;
+	}
 	ws->hs = (HOSTSTATE *)hs;
 	if(od->OpenState && (rc = od->OpenState(cfg, &ws->orig_sd)))
+	{
+		amd_close(hs);
+		free(ws);
 		return rc;
+	}
 	*statedata = ws;
 	return 0;
 }
@@ -691,7 +1090,7 @@ static void wrap_close(const char *sym, void *statedata)
 {
 	const A2P_unitdesc *od = orig_desc(sym);
 	WRAPSTATE *ws = (WRAPSTATE *)statedata;
-	if(od->CloseState)
+	if(od && od->CloseState)
 		od->CloseState(ws->orig_sd);
 	amd_close(ws->hs);
 	free(ws);
@@ -703,7 +1102,11 @@ static void inl_close(void *sd) { wrap_close("a2_inline_unitdesc", sd); }
 static int inl_init(A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned flags)
 {
 	WRAPSTATE *ws = (WRAPSTATE *)sd;
-	int rc = orig_desc("a2_inline_unitdesc")->Initialize(u, vms, ws->orig_sd, flags);
+	const A2P_unitdesc *od = orig_desc("a2_inline_unitdesc");
+	int rc;
+	if(!ctx_of(ws->hs))
+		return A2P_DEVICEOPEN;	/* (before the engine's half has touched the voice) */
+	rc = od ? od->Initialize(u, vms, ws->orig_sd, flags) : A2P_NOTIMPLEMENTED;
 	if(rc)
 		return rc;
 	if((rc = amd_init(A2AMD_INLINE, u, vms, ws->hs, flags, 1)))
@@ -717,7 +1120,7 @@ static void inl_deinit(A2P_unit *u)
 {
 	const A2P_unitdesc *od = orig_desc("a2_inline_unitdesc");
 	amd_deinit(u);
-	if(od->Deinitialize)
+	if(od && od->Deinitialize)
 		od->Deinitialize(u);
 }
 
@@ -738,10 +1141,12 @@ static void amd_x_process(A2P_unit *u, unsigned offset, unsigned frames)
 		x->chain_checked = 1;
 		check_chain_behind(u);
 	}
+	if(hs->failed)
+		return;
 	if(((A2P_xinsert *)u)->clients || x->client_mode)
 		serve_clients(x, (A2P_xinsert *)u, offset, frames);
-	if((rc = a2amd_unit_process(hs->ctx, x->uid, offset - hs->base, frames, NULL)))
-		die(hs, "a2amd_unit_process", rc);
+	if(!hs->failed && (rc = a2amd_unit_process(hs->ctx, x->uid, offset - hs->base, frames, NULL)))
+		fail(hs, "a2amd_unit_process", rc);
 }
 
 static void amd_x_setprocess(A2P_unit *u)
@@ -752,7 +1157,11 @@ static void amd_x_setprocess(A2P_unit *u)
 static int x_init(const char *sym, int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned flags)
 {
 	WRAPSTATE *ws = (WRAPSTATE *)sd;
-	int rc = orig_desc(sym)->Initialize(u, vms, ws->orig_sd, flags);
+	const A2P_unitdesc *od = orig_desc(sym);
+	int rc;
+	if(!ctx_of(ws->hs))
+		return A2P_DEVICEOPEN;
+	rc = od ? od->Initialize(u, vms, ws->orig_sd, flags) : A2P_NOTIMPLEMENTED;
 	if(rc)
 		return rc;
 	if((rc = amd_init(kind, u, vms, ws->hs, flags, 1)))
@@ -762,6 +1171,16 @@ static int x_init(const char *sym, int kind, A2P_unit *u, A2P_vmstate *vms, void
 		((A2P_xinsert *)u)->SetProcess = amd_x_setprocess;
 		amd_x_setprocess(u);
 	}
+	else if(xtra(u)->is_root && kind == A2AMD_XINSERT)
+	{
+		/* the root voice's xinsert: the engine's Process, except in batched buffers */
+		A2P_xinsert *xi = (A2P_xinsert *)u;
+		xtra(u)->orig_setprocess = xi->SetProcess;
+		xi->SetProcess = amd_rootx_setprocess;
+		amd_rootx_setprocess(u);
+		ws->hs->root_xi = xi;
+		ws->hs->engine_state = xi->state;
+	}
 	return 0;
 }
 
@@ -769,7 +1188,10 @@ static void x_deinit(const char *sym, A2P_unit *u)
 {
 	const A2P_unitdesc *od = orig_desc(sym);
 	HOSTSTATE *hs = xtra(u)->hs;
+	A2P_xinsert *z = NULL;
 	int k, n = 0;
+	if(hs->root_xi == (A2P_xinsert *)u)
+		hs->root_xi = NULL;
 	/* Windows its READ clients are still owed: the voice dies in the middle of a
 	 * fragment that is not rendered yet.  xi_Deinitialize (xinsert.c:204-211)
 	 * would tell the clients they are removed now; instead the client list
@@ -779,12 +1201,21 @@ static void x_deinit(const char *sym, A2P_unit *u)
 	for(k = 0; k < hs->npend; ++k)
 		if((A2P_unit *)hs->pend[k].xi == u)
 			++n;
-	if(n && a2_XinsertRemoveClient && hs->nzombies < MAXZOMBIES)
+	if(n && a2_XinsertRemoveClient && hs->nzombies == hs->cap_zombies)
 	{
-		A2P_xinsert *xi = (A2P_xinsert *)u, *z = (A2P_xinsert *)malloc(sizeof(A2P_xinsert));
+		int nc = hs->cap_zombies ? hs->cap_zombies * 2 : 16;
+		A2P_xinsert **nz = (A2P_xinsert **)realloc(hs->zombies, nc * sizeof(A2P_xinsert *));
+		if(nz)
+		{
+			hs->zombies = nz;
+			hs->cap_zombies = nc;
+		}
+	}
+	if(n && a2_XinsertRemoveClient && hs->nzombies < hs->cap_zombies &&
+			(z = (A2P_xinsert *)malloc(sizeof(A2P_xinsert))))
+	{
+		A2P_xinsert *xi = (A2P_xinsert *)u;
 		A2P_xinsert_client *c;
-		if(!z)
-			die(hs, "out of memory", -1);
 		*z = *xi;
 		z->SetProcess = amd_x_setprocess;
 		for(c = z->clients; c; c = c->next)
@@ -797,14 +1228,14 @@ static void x_deinit(const char *sym, A2P_unit *u)
 	}
 	else if(n)
 	{
-		/* (an engine that hides a2_XinsertRemoveClient: those windows are lost) */
+		/* (out of memory, or an engine that hides a2_XinsertRemoveClient: those windows are lost) */
 		for(n = k = 0; k < hs->npend; ++k)
 			if((A2P_unit *)hs->pend[k].xi != u)
 				hs->pend[n++] = hs->pend[k];
 		hs->npend = n;
 	}
 	amd_deinit(u);
-	if(od->Deinitialize)
+	if(od && od->Deinitialize)
 		od->Deinitialize(u);
 }
 

@@ -187,6 +187,12 @@ typedef struct A2P_audiodriver
 	int32_t		**buffers;
 } A2P_audiodriver;
 
+/* A2_errors codes the drop-in returns / reports (include/a2_types.h:131-277) */
+#define A2P_OOMEMORY		2
+#define A2P_NOTIMPLEMENTED	23
+#define A2P_DEVICEOPEN		27
+#define A2P_INTERNAL		133
+
 #define A2P_BLOCK_SIZE	384		/* A2_BLOCK_SIZE, include/audiality2.h.cmake:53 */
 #define A2P_PNOISESEED	0x0002000a	/* A2_PNOISESEED, include/a2_properties.h:71 */
 #define A2P_MATCHIO	0x00010000

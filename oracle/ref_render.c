@@ -73,6 +73,21 @@ static A2_errors source_cb(int32_t **buffers, unsigned nbuffers, unsigned frames
 	return A2_OK;
 }
 
+/* A2REF_INSERT=1: an insert callback (a2_InsertCallback, audiality2.h.cmake:538):
+ * reads what it is handed and writes back a function of it and of the time. */
+static unsigned insert_pos;
+static A2_errors insert_cb(int32_t **buffers, unsigned nbuffers, unsigned frames, void *userdata)
+{
+	unsigned c, s;
+	if(!buffers)
+		return A2_OK;
+	for(c = 0; c < nbuffers; ++c)
+		for(s = 0; s < frames; ++s)
+			buffers[c][s] = buffers[c][s] / 2 + (int)(((insert_pos + s) * 31u) & 0xffff) - 0x8000;
+	insert_pos += frames;
+	return A2_OK;
+}
+
 /* A2REF_FOREIGN=1: the application registers a unit of its own
  * (a2_RegisterUnit, a2_units.h:327) before the script is compiled: "thru", 1-2
  * channels, copies (or adds) its inputs to its outputs. */
@@ -119,9 +134,9 @@ int main(int argc, const char *argv[])
 	A2_config *cfg;
 	A2_driver *drv;
 	A2_interface *i;
-	A2_handle bank, prog, upwave = -1, vh, srcstream = -1, sinkstream = -1;
+	A2_handle bank, prog, upwave = -1, vh, ch, srcstream = -1, sinkstream = -1;
 	unsigned long long stream_hash = 0xCBF29CE484222325ull, stream_frames = 0;
-	int release_at = 0;
+	int release_at = 0, sink_dies = 0, sinkstream_done = 0;
 	/* A2REF_KILL=<frame>: a2_Kill() the voice the program runs on, timestamped */
 	int kill_at = getenv("A2REF_KILL") ? atoi(getenv("A2REF_KILL")) : -1;
 	FILE *pcm;
@@ -181,17 +196,23 @@ int main(int argc, const char *argv[])
 	a2_TimestampReset(i);
 	if((vh = a2_Starta(i, a2_RootVoice(i), prog, nargs, pargs)) < 0)
 		return 1;
-	if(getenv("A2REF_SOURCE") && a2_SourceCallback(i, vh, source_cb, NULL) < 0)
+	/* A2REF_ROOTCLIENTS=1: the clients below go on the root voice (the root driver's
+	 * xinsert, audiality2.c:271-291 - where a2play puts its sink) instead */
+	if(getenv("A2REF_ROOTCLIENTS"))
+		ch = a2_RootVoice(i);
+	else
+		ch = vh;
+	if(getenv("A2REF_SOURCE") && a2_SourceCallback(i, ch, source_cb, NULL) < 0)
 	{
 		fprintf(stderr, "a2_SourceCallback failed: %s\n", a2_ErrorString(a2_LastError()));
 		return 1;
 	}
-	if(getenv("A2REF_SINK") && a2_SinkCallback(i, vh, sink_cb, NULL) < 0)
+	if(getenv("A2REF_SINK") && a2_SinkCallback(i, ch, sink_cb, NULL) < 0)
 	{
 		fprintf(stderr, "a2_SinkCallback failed: %s\n", a2_ErrorString(a2_LastError()));
 		return 1;
 	}
-	if(getenv("A2REF_INSERT") && a2_InsertCallback(i, vh, source_cb, NULL) < 0)
+	if(getenv("A2REF_INSERT") && a2_InsertCallback(i, ch, insert_cb, NULL) < 0)
 		return 1;
 	/* A2REF_SRCSTREAM=<channel> / A2REF_SINKSTREAM=<channel>: the buffered
 	 * variants (a2_OpenSource / a2_OpenSink, audiality2.h.cmake:561-577): a
@@ -202,8 +223,8 @@ int main(int argc, const char *argv[])
 		const char *both = getenv("A2REF_STREAMS");
 		const char *src = getenv("A2REF_SRCSTREAM") ? getenv("A2REF_SRCSTREAM") : both ? "1" : NULL;
 		const char *snk = getenv("A2REF_SINKSTREAM") ? getenv("A2REF_SINKSTREAM") : both ? "0" : NULL;
-		if((src && (srcstream = a2_OpenSource(i, vh, atoi(src), 4 * buffer, 0)) < 0) ||
-				(snk && (sinkstream = a2_OpenSink(i, vh, atoi(snk), 4 * buffer, 0)) < 0))
+		if((src && (srcstream = a2_OpenSource(i, ch, atoi(src), 4 * buffer, 0)) < 0) ||
+				(snk && (sinkstream = a2_OpenSink(i, ch, atoi(snk), 4 * buffer, 0)) < 0))
 		{
 			fprintf(stderr, "cannot open streams: %s\n", a2_ErrorString(a2_LastError()));
 			return 1;
@@ -221,6 +242,12 @@ int main(int argc, const char *argv[])
 			a2_Kill(i, vh);
 			kill_at = -1;
 			srcstream = -1;		/* (its reader is going away) */
+			/* ... and so is the sink stream's writer: in an offline state the engine
+			 * free()s the client object the moment the voice dies
+			 * (a2_XinsertRemoveClient, xinsertapi.c:149-153) while the stream handle
+			 * keeps pointing at it (xi_stream_available, xinsertapi.c:376-381), so
+			 * the stream must not be touched after this a2_Run() */
+			sink_dies = 1;
 		}
 		if(srcstream >= 0)
 		{
@@ -232,6 +259,41 @@ int main(int argc, const char *argv[])
 			{
 				fprintf(stderr, "a2_Write: %s\n", a2_ErrorString(k));
 				return 1;
+			}
+		}
+		/* A2REF_REUPLOAD=1 (with A2REF_UPLOAD): half way through, kill the voices that
+		 * play the uploaded wave, release it two buffers later - while NOTHING plays
+		 * it -, and two buffers after that upload a different wave (which tends to get
+		 * the released A2_wave's address) and start the program again on it */
+		if(getenv("A2REF_REUPLOAD") && upwave >= 0)
+		{
+			static int phase, at;
+			if(phase == 0 && done >= frames / 2)
+			{
+				a2_Kill(i, vh);
+				phase = 1;
+				at = done;
+			}
+			else if(phase == 1 && done >= at + 2 * buffer)
+			{
+				if(a2_Release(i, upwave))
+				{
+					fprintf(stderr, "a2_Release failed: use A2REF_REALTIME=1\n");
+					return 1;
+				}
+				phase = 2;
+			}
+			else if(phase == 2 && done >= at + 4 * buffer)
+			{
+				static int16_t data2[3000];
+				for(k = 0; k < 3000; ++k)
+					data2[k] = (int16_t)(((k * 4001) % 7919 - 3959) * 4);
+				if((upwave = a2_UploadWave(i, A2_WMIPWAVE, 0, A2_LOOPED, A2_I16, data2, sizeof(data2))) < 0)
+					return 1;
+				pargs[nargs - 1] = upwave << 16;
+				if((vh = a2_Starta(i, a2_RootVoice(i), prog, nargs, pargs)) < 0)
+					return 1;
+				phase = 3;
 			}
 		}
 		if(upwave >= 0 && done >= release_at)
@@ -247,7 +309,9 @@ int main(int argc, const char *argv[])
 		if(a2_Run(i, n) < 0)
 			return 1;
 		a2_PumpMessages(i);
-		if(sinkstream >= 0)
+		if(sink_dies)
+			sinkstream_done = 1;
+		if(sinkstream >= 0 && !sinkstream_done)
 		{
 			int32_t sb[4096];
 			int avail = a2_Available(i, sinkstream);

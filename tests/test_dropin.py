@@ -100,14 +100,17 @@ def test_dropin_refuses_to_run_without_gpu(tmp_path):
     r = subprocess.run([REF_RENDER, f"{A2S}/sustain.a2s", "Main", "640", "64", "48000", "2",
                         str(tmp_path / "x.pcm"), "1", "0.05"],
                        env=dict(os.environ, LD_PRELOAD=UNITS_SO), cwd=A2S, capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+    # no abort(): the units fail to initialise, the engine cannot start its root voice
+    # and a2_Open() fails - the application gets an error, never CPU-rendered audio
+    assert r.returncode not in (0, -6) and "no CPU fallback" in r.stderr, (r.returncode, r.stderr[-400:])
 
 
 @pytest.mark.gpu
 def test_dropin_refuses_mixed_chains(tmp_path):
     """A CPU unit with audio ports inside a GPU-rendered chain would process
-    silence: the drop-in aborts with a message instead (no silent fallback); a
-    voice that *starts* in a CPU unit is refused at instantiation."""
+    silence: the drop-in says so through the engine's error channel (a2r_Error,
+    never silently, never by abort()); a voice that *starts* in a CPU unit is
+    refused at instantiation."""
     need_ref()
     env = dict(os.environ, LD_PRELOAD=UNITS_SO, A2REF_FOREIGN="1")
     for script in ("mixed", "mixedhead"):   # (both fine on the CPU)
@@ -116,15 +119,15 @@ def test_dropin_refuses_mixed_chains(tmp_path):
         assert np.fromfile(tmp_path / "c.pcm", dtype="<i4").any()
     r = subprocess.run([REF_RENDER, f"{A2S}/mixed.a2s", "Main", "640", "64", "48000", "2", str(tmp_path / "m.pcm"), "0.1"],
                        env=env, cwd=A2S, capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and "mixed CPU/GPU chains are not supported" in r.stderr, r.stderr[-500:]
+    assert r.returncode == 0 and "mixed CPU/GPU chains are not supported" in r.stderr + r.stdout, r.stderr[-500:]
     r = subprocess.run([REF_RENDER, f"{A2S}/mixedhead.a2s", "Main", "640", "64", "48000", "2", str(tmp_path / "h.pcm"), "0.1"],
                        env=env, cwd=A2S, capture_output=True, text=True, timeout=120)
     assert "takes its input from a unit that is not replaced" in r.stderr, r.stderr[-500:]
     # an insert client (reads AND writes) on a voice other than the root would need
-    # that voice's audio on the host in the middle of the GPU batch: refused
+    # that voice's audio on the host in the middle of the GPU batch: reported, not served
     cmd = [REF_RENDER, f"{A2S}/sinkgroup.a2s", "Main", "640", "64", "48000", "2", str(tmp_path / "s.pcm"), "0.1"]
     r = subprocess.run(cmd, env=dict(env, A2REF_INSERT="1"), cwd=A2S, capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and "an insert client" in r.stderr, r.stderr[-500:]
+    assert r.returncode == 0 and "insert client" in r.stderr + r.stdout, r.stderr[-500:]
 
 
 @pytest.mark.gpu
@@ -133,7 +136,8 @@ def test_dropin_refuses_mixed_chains(tmp_path):
                                      # ... and the voice is killed 0.7 ms into a buffer: its clients are owed
                                      # the windows of a fragment that is rendered after the voice is gone
                                      ("SINK", "KILL"), ("SOURCE", "STREAMS", "SINK", "KILL")])
-def test_dropin_serves_sink_and_source_clients(tmp_path, script, frames, clients):
+@pytest.mark.parametrize("buffer", [64, 1024])
+def test_dropin_serves_sink_and_source_clients(tmp_path, script, frames, clients, buffer):
     """a2_SinkCallback / a2_SourceCallback on a voice in the middle
     of the graph (a group: inline; panmix; xinsert), and their buffered variants
     a2_OpenSink / a2_OpenSource (STREAMS).  The sink is handed what it is handed
@@ -148,24 +152,26 @@ def test_dropin_serves_sink_and_source_clients(tmp_path, script, frames, clients
             env["A2REF_KILL"] = str(frames // 2)
         if preload:
             env["LD_PRELOAD"] = UNITS_SO
-        r = subprocess.run([REF_RENDER, f"{A2S}/{script}.a2s", "Main", str(frames), "64", "48000", "2", str(out), "0.1"],
+        r = subprocess.run([REF_RENDER, f"{A2S}/{script}.a2s", "Main", str(frames), str(buffer), "48000", "2", str(out), "0.1"],
                            env=env, cwd=A2S, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-500:]
-        res.append(([ln for ln in r.stdout.splitlines() if ln.startswith("sink ")], np.fromfile(out, dtype="<i4")))
+        res.append(([ln for ln in r.stdout.splitlines() if ln.startswith("sink ")], read_pcm(out, 2, buffer).T.reshape(-1)))
     assert res[0][1].any()
     assert len(res[0][0]) == len([c for c in clients if c in ("SINK", "STREAMS")])
-    if "KILL" in clients:
-        assert all(f" frames {frames // 2 + 33} " in ln for ln in res[0][0]), res[0][0]
+    if "KILL" in clients and buffer == 64:
+        # (the callback sink sees the 33 frames of the fragment the voice dies in; the
+        # harness stops reading the sink STREAM with the buffer before: oracle/ref_render.c)
+        assert all(f" frames {frames // 2 + 33} " in ln for ln in res[0][0] if ln.startswith("sink peak")), res[0][0]
     assert not any(" frames 0 " in ln or "sink peak 0 " in ln for ln in res[0][0])
     assert res[0][0] == res[1][0]
-    a, b = (r[1].reshape(-1, 2, 64) for r in res)          # [buffer, channel, frame]
+    a, b = (r[1].reshape(-1, 2).T for r in res)            # [channel, frame]
     if "STREAMS" in clients:
         # A source stream fills only its own channel (1) of the buffers the engine
         # hands it (a2_sourcestream_process, xinsertapi.c:287-318) and xi_process
         # mixes ALL of them into the output (xinsert.c:113-118) - the others are
         # uninitialised stack arrays (xinsert.c:66).  What the reference adds to
         # channel 0 is whatever its stack held; the drop-in adds silence.
-        a, b = a[:, 1], b[:, 1]
+        a, b = a[1], b[1]
     assert np.array_equal(a, b)
 
 
@@ -265,3 +271,96 @@ def test_reference_player_runs_on_the_dropin():
         r = subprocess.run([a2play, "-dbuffer", "-r44100", f"{script}.a2s", f"-p{prog}", "-st3"], cwd=A2S,
                            env=dict(os.environ, LD_PRELOAD=UNITS_SO), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "Offline mode" in r.stdout + r.stderr, (r.stdout + r.stderr)[-500:]
+
+
+# ---------------------------------------------------------------------------
+# round 2: one GPU round trip per a2_Run() buffer (the drop-in's Process sits in front
+# of the engine's a2_AudioCallback, include/a2amd_plugin.h A2P_audiodriver)
+# ---------------------------------------------------------------------------
+BATCH_CASES = [c for c in CASES if c[0] in ("sustain", "filter", "delaybus", "scripted", "edge", "fm", "fx", "envwire",
+                                            "unload")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("buffer", [256, 4096, 1000, 20000])
+@pytest.mark.parametrize("name,args,frames", BATCH_CASES)
+def test_dropin_batches_whole_buffers(tmp_path, name, args, frames, buffer):
+    """a2_Run(buffer) with buffers of 4, 64, 15.6 and 312.5 fragments (the last one more
+    than the 256 fragments one launch sequence takes: rendered in two), compared
+    with the same binary and the same buffer size without the drop-in."""
+    need_ref()
+    outs = []
+    for pre in (None, UNITS_SO):
+        out = tmp_path / f"o{int(pre is not None)}.pcm"
+        env = dict(os.environ)
+        if pre:
+            env["LD_PRELOAD"] = pre
+        if name in REALTIME_CASES:
+            env["A2REF_REALTIME"] = "1"
+        if name in UPLOAD_CASES:
+            env["A2REF_UPLOAD"] = UPLOAD_CASES[name]
+        subprocess.run([REF_RENDER, f"{A2S}/{name}.a2s", "Main", str(frames), str(buffer), "48000", "2", str(out)] + args,
+                       check=True, env=env, cwd=A2S, timeout=600)
+        outs.append(read_pcm(out, 2, buffer))
+    assert outs[0].any()
+    bad = np.nonzero((outs[0] != outs[1]).any(axis=0))[0]
+    if name in KNOWN_DEVIATIONS_BY_FRAME:
+        lo, hi = KNOWN_DEVIATIONS_BY_FRAME[name]
+        bad = bad[(bad < lo) | (bad >= hi)]
+    assert len(bad) == 0, f"{len(bad)} frames differ, first {bad[:5]}"
+
+
+# unload: the one window in which the reference's oscillators notice that their wave is
+# gone replays a neighbour's stale scratch (DESIGN.md section 5); it is the first 64-frame
+# fragment of the buffer that follows the release at frame 20000
+KNOWN_DEVIATIONS_BY_FRAME = {"unload": (20000, 20000 + 20000)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("buffer", [64, 256, 4096])
+@pytest.mark.parametrize("clients", [("SINK",), ("SOURCE",), ("SOURCE", "SINK"), ("STREAMS",), ("INSERT",),
+                                     ("INSERT", "SINK")])
+def test_dropin_root_voice_clients(tmp_path, clients, buffer):
+    """Clients on the ROOT voice's xinsert (where a2play attaches its sink): in a
+    batched buffer the master bus comes back after the engine's walk, so sinks are
+    served from it afterwards and sources are added on the host; an INSERT client
+    (reads and writes the master bus window by window on the CPU) makes the
+    drop-in render that buffer window by window, as in round 1."""
+    need_ref()
+    res = []
+    for preload in (False, True):
+        out = tmp_path / f"c{int(preload)}.pcm"
+        env = dict(os.environ, A2REF_ROOTCLIENTS="1", **{f"A2REF_{c}": "1" for c in clients})
+        if preload:
+            env["LD_PRELOAD"] = UNITS_SO
+        r = subprocess.run([REF_RENDER, f"{A2S}/scripted.a2s", "Main", "48000", str(buffer), "48000", "2", str(out), "0.2"],
+                           env=env, cwd=A2S, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-500:]
+        res.append(([ln for ln in r.stdout.splitlines() if ln.startswith("sink ")], read_pcm(out, 2, buffer)))
+    assert res[0][1].any()
+    assert res[0][0] == res[1][0] and len(res[0][0]) == len([c for c in clients if c in ("SINK", "STREAMS")])
+    a, b = res[0][1], res[1][1]
+    if "STREAMS" in clients:
+        a, b = a[1], b[1]       # (channel 0 gets the reference's uninitialised stack, see above)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_wave_released_without_players_then_reloaded(tmp_path):
+    """a wave released while nothing plays it must leave the drop-in's
+    registry in that engine cycle (the allocator hands its A2_wave address to the next
+    upload).  edge.a2s renders, plays and unloads waves of its own; here the harness
+    uploads a wave, releases it before any voice played it, uploads another one - very
+    likely at the same address - and a voice plays that."""
+    need_ref()
+    outs = []
+    for preload in (False, True):
+        out = tmp_path / f"w{int(preload)}.pcm"
+        env = dict(os.environ, A2REF_REALTIME="1", A2REF_UPLOAD="999999999", A2REF_REUPLOAD="1")
+        if preload:
+            env["LD_PRELOAD"] = UNITS_SO
+        subprocess.run([REF_RENDER, f"{A2S}/unload.a2s", "Main", "24064", "256", "48000", "2", str(out), "0.1"],
+                       check=True, env=env, cwd=A2S, timeout=300)
+        outs.append(read_pcm(out, 2, 256))
+    assert outs[0].any()
+    assert np.array_equal(outs[0], outs[1])

@@ -712,3 +712,35 @@ def test_config3_full_size_is_linear_in_the_voice_subsets():
     full, a, b = (o.astype(np.int64) for o in outs)
     s = ((a + b + 2 ** 31) % 2 ** 32 - 2 ** 31)
     assert first_diff(full.astype(np.int32), s.astype(np.int32)) is None
+
+
+@pytest.mark.parametrize("batch", [16, 64, 256])
+def test_delay_chain_kernel_rounds_match_oracle(oracle_lib, batch):
+    """k_bus_fbdchain: group voices inline->fbdelay->fbdelay with taps of 1.4 .. 29
+    fragments (rounds of 1, 3 and 9 fragments, several rounds per batch), one chain of
+    a single delay, one of three, one with a tap shorter than a fragment (general
+    kernel), delay times rewritten half way; the frame-parallel rounds must give what
+    the oracle's sample-by-sample loop gives."""
+    outs = []
+    for be in (make_gpu(max_batch=batch), make_oracle(oracle_lib)):
+        sc = synth.Scene(be)
+        sc.root()
+        groups = [sc.add_group(fb=(1.9, 2.4, 3.1), gains=(0.4, 0.3, 0.3)),
+                  sc.add_group(fb=(4.2, 5.0, 6.3), gains=(0.5, 0.25, 0.25)),
+                  sc.add_group(fb=(12.7, 20.0, 38.9), gains=(0.3, 0.4, 0.2)),
+                  sc.add_group(fb=(1.2, 0.5, 137.9), gains=(0.2, 0.3, 0.3)),
+                  sc.add_group(preset="fmtest4")]
+        for g in groups:
+            sc.add_voices(24, chain="osc2-pan", group=g, total=256)
+        a = sc.run(3 * batch + 5, batch=batch)
+        # a tap of the second group drops below one fragment (-> general kernel), one
+        # of the fourth grows above (-> delay kernel)
+        be.unit_write(groups[1]["units"][1], 1, synth.fix(0.9))
+        be.unit_write(groups[3]["units"][2], 1, synth.fix(3.3))
+        be.unit_write(groups[3]["units"][2], 0, synth.fix(2.0))
+        be.unit_write(groups[3]["units"][1], 0, synth.fix(7.7))
+        be.unit_write(groups[3]["units"][1], 1, synth.fix(3.5))
+        b = sc.run(2 * batch + 3, batch=batch)
+        outs.append(np.concatenate([a, b], axis=1))
+        be.close()
+    assert first_diff(outs[0], outs[1]) is None

@@ -56,6 +56,8 @@ SIZE(A2_audiodriver, A2P_audiodriver); SAME(A2_audiodriver, A2P_audiodriver, Run
 SAME(A2_audiodriver, A2P_audiodriver, state); SAME(A2_audiodriver, A2P_audiodriver, Process);
 SAME(A2_audiodriver, A2P_audiodriver, buffers);
 _Static_assert(A2_AUDIODRIVER == A2P_AUDIODRIVER, "drivertype");
+_Static_assert(A2_OOMEMORY == A2P_OOMEMORY && A2_NOTIMPLEMENTED == A2P_NOTIMPLEMENTED &&
+		A2_DEVICEOPEN == A2P_DEVICEOPEN && A2_INTERNAL == A2P_INTERNAL, "error codes");
 _Static_assert(sizeof(A2_wave) == sizeof(A2P_wave), "A2_wave");
 _Static_assert(offsetof(A2_wave, d.wave.data) == offsetof(A2P_wave, data), "data");
 _Static_assert(offsetof(A2_wave, d.wave.size) == offsetof(A2P_wave, size), "size");
