@@ -123,6 +123,7 @@ struct A2DParams {
 	const A2DRec   *recs;
 	const A2DWave  *waves;
 	const int16_t  *wavepool;
+	const int32_t  *wavecoef;	// [wave pool index][3]: Hermite a, b, c:d0 of the window at that sample
 	int32_t        *busmem;
 	int32_t        *fbdmem;		// [bufidx][2][A2D_FBD_BUFSIZE]
 	const uint32_t *ptab;		// 64 x {base, coeff}, pitch.c:70-96
@@ -154,6 +155,8 @@ int a2d_launch_commit(const A2DParams &hp, const A2DCommit &cm, void *stream);
 // quiet "inline; fbdelay 2->2 ... ; fbdelay 2->2 >" voices (one workgroup each)
 int a2d_launch_bus_fbdchain(const A2DParams *dparams, const int *dlist, int nlist, int consume, void *stream);
 int a2d_launch_park(int32_t *stage, int32_t *bus, unsigned words, void *stream);
+// Hermite coefficient entries for wave pool samples [lo, hi) (reads pool[lo-1 .. hi+1])
+int a2d_launch_build_coef(const int16_t *pool, int *coef, unsigned lo, unsigned hi, void *stream);
 int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
 		int vpw, void *stream);
 // runs[idx[i]] = val[i] for the few voices whose record run changed this batch

@@ -84,6 +84,54 @@ DEV int inter_dwords(const int16_t *d, unsigned ph, unsigned dph16)
 	return inter_quads(qa, qb, ph, ph2);
 }
 
+// Hermite coefficients of one window, precomputed per wave sample when the wave is
+// uploaded (k_build_coef): a2_Hermite's a, b and - packed - c (high half) and d[i]
+// (low half).  The settled paths fetch one 12 byte entry per tap instead of four
+// samples and go straight into the three multiply-shift-add steps, which are the
+// reference's own (a2_dsp.h:64-74: x = frac << 7, 32 bit wrap-around products,
+// arithmetic >> 15) - a third fewer vector instructions per tap than unpacking the
+// samples and deriving a, b, c for every output frame.
+struct __attribute__((aligned(4))) Coef3 { int a, b, cd; };
+
+DEV int hermite_c(const Coef3 k, unsigned ph)
+{
+	const int x = (int)((ph & 0xffu) << 7);
+	int t = wmul(k.a, x) >> 15;
+	t = wmul(wadd(t, k.b), x) >> 15;
+	t = wmul(wadd(t, k.cd >> 16), x) >> 15;
+	return wadd((int)(int16_t)(k.cd & 0xffff), t);
+}
+
+// wtosc_Inter (wtosc.c:28-33) from the coefficient table: cb = entry of the level's
+// first payload sample, ph / ph2 = 24:8 phases of the two taps
+DEV Coef3 coef_at(const char *cb, unsigned ph)
+{
+	return *(const Coef3 *)(cb + (size_t)((ph >> 8) * 12u));
+}
+
+__global__ void k_build_coef(const int16_t *__restrict__ pool, int *__restrict__ coef, unsigned lo, unsigned hi)
+{
+	const unsigned j = lo + blockIdx.x * blockDim.x + threadIdx.x;
+	if(j >= hi)
+		return;
+	const int dm = pool[j - 1], d0 = pool[j], d1 = pool[j + 1], d2 = pool[j + 2];
+	const int c = (d1 - dm) >> 1;
+	const int a = (3 * (d0 - d1) + d2 - dm) >> 1;
+	const int b = dm - d0 + c - a;
+	coef[3 * (size_t)j] = a;
+	coef[3 * (size_t)j + 1] = b;
+	coef[3 * (size_t)j + 2] = (int)(((unsigned)c << 16) | ((unsigned)d0 & 0xffffu));
+}
+
+// coefficient entries for pool samples [lo, hi): needs pool[lo - 1 .. hi + 1]
+int a2d_launch_build_coef(const int16_t *pool, int *coef, unsigned lo, unsigned hi, void *stream)
+{
+	if(hi <= lo)
+		return 0;
+	hipLaunchKernelGGL(k_build_coef, dim3((hi - lo + 255) / 256), dim3(256), 0, (hipStream_t)stream, pool, coef, lo, hi);
+	return (int)hipGetLastError();
+}
+
 // ---- cold paths: kept out of line so the hot loop stays small -------------
 // (all operands are wave-uniform; results go back to SGPRs via readfirstlane)
 __device__ __attribute__((noinline)) int cold_ramp_delta(int target, int value, int timer, int frames,
@@ -281,11 +329,12 @@ enum { SV_MODE = 0, SV_WAVE, SV_DPHASE, SV_PHLO, SV_PHHI, SV_PRAMP, SV_P = 6, SV
 // Extra per-lane words derived once per launch from a voice's state
 enum { DV_SETTLED = 0, DV_MM, DV_DPH, DV_SIZEM, DV_DOFF, DV_V0, DV_V1, DV_NWORDS };
 
-__global__ __launch_bounds__(64 * FAST_WPB)
+__global__ __launch_bounds__(64 * FAST_WPB) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
 		int ysplit, const A2DVoice *__restrict__ voices, const int *ustate,
 		int *ustage, const int16_t *__restrict__ wavepool,
-		const A2DWave *__restrict__ waves, const uint32_t *__restrict__ ptab, int *__restrict__ busmem)
+		const A2DWave *__restrict__ waves, const uint32_t *__restrict__ ptab, int *__restrict__ busmem,
+		const int *__restrict__ wavecoef)
 {
 	const A2DParams &p = *pp;
 	const int wv = threadIdx.x >> 6;
@@ -457,26 +506,31 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 				asm("" : "+v"(ldl), "+v"(ldh));
 			}
 			const uint64_t lanedph = (uint64_t)ldl | ((uint64_t)ldh << 32);
-			// (uniform base one sample early + an unsigned 32 bit byte offset per
-			// lane: the loads take the scalar-base addressing form, no 64 bit adds)
-			const char *dm1 = (const char *)(wavepool + doff - 1);
-			Quad16 qa[FAST_FCH], qb[FAST_FCH];
-			unsigned ph16[FAST_FCH], ph2[FAST_FCH];
+			// (uniform base = the coefficient entry of the level's first payload
+			// sample, + an unsigned 32 bit byte offset per lane: the loads take the
+			// scalar-base addressing form, no 64 bit adds.  Four fragments' entries
+			// in flight at a time: 24 registers.)
+			const char *cb = (const char *)(wavecoef + 3 * (size_t)doff);
 #pragma unroll
-			for(int j = 0; j < FAST_FCH; ++j) {
-				ph16[j] = (unsigned)((phs[j] + lanedph) >> 16);
-				asm("" : "+v"(ph16[j]));	// (keeps the offset a 32 bit value in the compiler's eyes)
-				ph2[j] = ph16[j] + (dph16 >> 1);
-				qa[j] = *(const Quad16 *)(dm1 + (size_t)((ph16[j] >> 7) & ~1u));
-				qb[j] = *(const Quad16 *)(dm1 + (size_t)((ph2[j] >> 7) & ~1u));
-			}
+			for(int h = 0; h < FAST_FCH; h += 4) {
+				Coef3 ka[4], kb[4];
+				unsigned pa[4], pb[4];
 #pragma unroll
-			for(int j = 0; j < FAST_FCH; ++j) {
-				int sm = inter_quads(qa[j], qb[j], ph16[j], ph2[j]);
-				int x = mul64s(sm, amp, 17);
-				x = (lane < nfr[j]) ? x : 0;
-				acc0[j] = wadd(acc0[j], mul64s(x, v0, 24));
-				acc1[j] = wadd(acc1[j], mul64s(x, v1, 24));
+				for(int j = 0; j < 4; ++j) {
+					pa[j] = (unsigned)((phs[h + j] + lanedph) >> 16);
+					asm("" : "+v"(pa[j]));	// (keeps the offset a 32 bit value in the compiler's eyes)
+					pb[j] = pa[j] + (dph16 >> 1);
+					ka[j] = coef_at(cb, pa[j]);
+					kb[j] = coef_at(cb, pb[j]);
+				}
+#pragma unroll
+				for(int j = 0; j < 4; ++j) {
+					int sm = hermite_c(ka[j], pa[j]) + hermite_c(kb[j], pb[j]);
+					int x = mul64s(sm, amp, 17);
+					x = (lane < nfr[h + j]) ? x : 0;
+					acc0[h + j] = wadd(acc0[h + j], mul64s(x, v0, 24));
+					acc1[h + j] = wadd(acc1[h + j], mul64s(x, v1, 24));
+				}
 			}
 			if(last_slice && c == c_hi - 1) {
 				// what the oscillator is left with after the batch: the
@@ -641,11 +695,11 @@ DEV void osc_to_lanes(int (&so)[OV_NWORDS], const OscS &o, bool me)
 	WRL(so[OV_A + 2], o.a.delta); WRL(so[OV_A + 3], o.a.timer);
 }
 
-__global__ __launch_bounds__(64 * FAST_WPB)
+__global__ __launch_bounds__(64 * FAST_WPB) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
 		int ysplit, const A2DVoice *__restrict__ voices, const int *ustate, int *ustage,
 		const int16_t *__restrict__ wavepool, const A2DWave *__restrict__ waves,
-		const uint32_t *__restrict__ ptab, int *__restrict__ busmem)
+		const uint32_t *__restrict__ ptab, int *__restrict__ busmem, const int *__restrict__ wavecoef)
 {
 	const A2DParams &p = *pp;
 	const int wv = threadIdx.x >> 6;
@@ -772,20 +826,20 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 				cur_nch = rdl(my_nch, v);
 			}
 			const int v0 = rdl(v0l, v), v1 = rdl(v1l, v);
-			Quad16 qa[2][OSC2_FCH], qb[2][OSC2_FCH];
-			unsigned ph16[2][OSC2_FCH], ph2[2][OSC2_FCH];
-			int amp[2];
+			// one oscillator after the other: the eight coefficient entries of a
+			// chunk (4 fragments x 2 taps, 24 registers) in flight at a time
+			int xs[OSC2_FCH];
 			uint64_t endph[2];
 #pragma unroll
 			for(int o = 0; o < 2; ++o) {
 				const unsigned mm = (unsigned)rdl(od[o][OD_MM], v), dph = (unsigned)rdl(od[o][OD_DPH], v);
 				const unsigned sizem = (unsigned)rdl(od[o][OD_SIZEM], v), doff = (unsigned)rdl(od[o][OD_DOFF], v);
-				amp[o] = rdl(so[o][OV_A], v);
+				const int amp = rdl(so[o][OV_A], v);
 				const uint64_t phase = (uint64_t)(unsigned)rdl(so[o][OV_PHLO], v) |
 						((uint64_t)(unsigned)rdl(so[o][OV_PHHI], v) << 32);
 				uint64_t ph = (phase >> mm) + (uint64_t)before * dph;
 				const uint64_t lanedph = (uint64_t)(unsigned)lane * dph;
-				const int16_t *dbase = wavepool + doff;
+				const char *cb = (const char *)(wavecoef + 3 * (size_t)doff);
 				uint64_t phs[OSC2_FCH];
 				if(!(sizem & (sizem - 1)) && !(ph >> 48)) {
 					// power-of-two size: the modulus is a mask (as in k_leaf_oscpan)
@@ -802,22 +856,27 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 						ph += (uint64_t)dph * (unsigned)nfr[j];
 					}
 				}
+				Coef3 ka[OSC2_FCH], kb[OSC2_FCH];
+				unsigned pa[OSC2_FCH], pb[OSC2_FCH];
 #pragma unroll
 				for(int j = 0; j < OSC2_FCH; ++j) {
-					ph16[o][j] = (unsigned)((phs[j] + lanedph) >> 16);
-					asm("" : "+v"(ph16[o][j]));	// (32 bit offsets: scalar-base loads, as in k_leaf_oscpan)
-					ph2[o][j] = ph16[o][j] + (dph >> 17);
-					qa[o][j] = *(const Quad16 *)((const char *)(dbase - 1) + (size_t)((ph16[o][j] >> 7) & ~1u));
-					qb[o][j] = *(const Quad16 *)((const char *)(dbase - 1) + (size_t)((ph2[o][j] >> 7) & ~1u));
+					pa[j] = (unsigned)((phs[j] + lanedph) >> 16);
+					asm("" : "+v"(pa[j]));	// (32 bit offsets: scalar-base loads, as in k_leaf_oscpan)
+					pb[j] = pa[j] + (dph >> 17);
+					ka[j] = coef_at(cb, pa[j]);
+					kb[j] = coef_at(cb, pb[j]);
+				}
+#pragma unroll
+				for(int j = 0; j < OSC2_FCH; ++j) {
+					const int y = mul64s(hermite_c(ka[j], pa[j]) + hermite_c(kb[j], pb[j]), amp, 17);
+					// the second oscillator adds into the scratch buffer (wrap-around)
+					xs[j] = o ? wadd(xs[j], y) : y;
 				}
 				endph[o] = ph << mm;
 			}
 #pragma unroll
 			for(int j = 0; j < OSC2_FCH; ++j) {
-				// the second oscillator adds into the scratch buffer (wrap-around)
-				int x = wadd(mul64s(inter_quads(qa[0][j], qb[0][j], ph16[0][j], ph2[0][j]), amp[0], 17),
-						mul64s(inter_quads(qa[1][j], qb[1][j], ph16[1][j], ph2[1][j]), amp[1], 17));
-				x = (lane < nfr[j]) ? x : 0;
+				const int x = (lane < nfr[j]) ? xs[j] : 0;
 				acc0[j] = wadd(acc0[j], mul64s(x, v0, 24));
 				acc1[j] = wadd(acc1[j], mul64s(x, v1, 24));
 			}
@@ -920,7 +979,8 @@ enum { FV_Q = 0, FV_LP = 4, FV_BP, FV_HP, FV_F1, FV_D1, FV_D2, FV_NWORDS };
 __global__ __launch_bounds__(64 * FAST_WPB)
 void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
 		const A2DVoice *__restrict__ voices, int *ustate, const int16_t *__restrict__ wavepool,
-		const A2DWave *__restrict__ waves, const uint32_t *__restrict__ ptab, int *__restrict__ busmem)
+		const A2DWave *__restrict__ waves, const uint32_t *__restrict__ ptab, int *__restrict__ busmem,
+		const int *__restrict__ wavecoef)
 {
 	extern __shared__ __attribute__((aligned(16))) int tiles[];
 	const A2DParams &p = *pp;
@@ -1023,7 +1083,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 			// four settled voices at a time: their wave data loads overlap
 			if(v + 3 < nv && (rdl(dv[DV_SETTLED], v) & rdl(dv[DV_SETTLED], v + 1) &
 					rdl(dv[DV_SETTLED], v + 2) & rdl(dv[DV_SETTLED], v + 3))) {
-				Quad16 qa[4], qb[4];
+				Coef3 qa[4], qb[4];
 				unsigned qph[4], qph2[4];
 				int qamp[4];
 #pragma unroll
@@ -1036,14 +1096,14 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 					uint64_t ph = wrap_phase((phase >> mm) + (uint64_t)total * dph, sizem);
 					qph[k] = (unsigned)((ph + (uint64_t)(unsigned)lane * dph) >> 16);
 					qph2[k] = qph[k] + (dph >> 17);
-					const int16_t *dbase = wavepool + doff;
-					qa[k] = *(const Quad16 *)(dbase + (int)(qph[k] >> 8) - 1);
-					qb[k] = *(const Quad16 *)(dbase + (int)(qph2[k] >> 8) - 1);
+					const char *cb = (const char *)(wavecoef + 3 * (size_t)doff);
+					qa[k] = coef_at(cb, qph[k]);
+					qb[k] = coef_at(cb, qph2[k]);
 					qamp[k] = rdl(sv[SV_A], vk);
 				}
 #pragma unroll
 				for(int k = 0; k < 4; ++k) {
-					int sm = inter_quads(qa[k], qb[k], qph[k], qph2[k]);
+					int sm = hermite_c(qa[k], qph[k]) + hermite_c(qb[k], qph2[k]);
 					int xk = mul64s(sm, qamp[k], 17);
 					tile[(v + k) * FILT_PITCH + lane] = (lane < n) ? xk : 0;
 				}
@@ -1059,7 +1119,9 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 				// start of fragment f = ((phase >> mm) + frames_before * dph) mod (size << 24)
 				uint64_t ph = wrap_phase((phase >> mm) + (uint64_t)total * dph, sizem);
 				unsigned ph16 = (unsigned)((ph + (uint64_t)(unsigned)lane * dph) >> 16);
-				int sm = inter_dwords(wavepool + doff, ph16, dph >> 16);
+				const unsigned ph16b = ph16 + (dph >> 17);
+				const char *cb = (const char *)(wavecoef + 3 * (size_t)doff);
+				int sm = hermite_c(coef_at(cb, ph16), ph16) + hermite_c(coef_at(cb, ph16b), ph16b);
 				x = mul64s(sm, amp, 17);
 			} else {
 				OscS o;
@@ -1429,7 +1491,7 @@ int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const 
 	int nblocks = (nwaves + FAST_WPB - 1) / FAST_WPB;
 	hipLaunchKernelGGL(k_leaf_oscpan, dim3(nblocks, ysplit), dim3(64 * FAST_WPB), 0, (hipStream_t)stream,
 			dparams, dlist, nlist, vpw, ysplit, hp.voices, (const int *)hp.ustate,
-			ysplit > 1 ? ustage : hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
+			ysplit > 1 ? ustage : hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem, hp.wavecoef);
 	if(event_after_main)
 		hipEventRecord((hipEvent_t)event_after_main, (hipStream_t)stream);
 	if(ysplit > 1) {
@@ -1455,7 +1517,7 @@ int a2d_launch_leaf_osc2pan(const A2DParams *dparams, const A2DParams &hp, const
 	int nblocks = (nwaves + FAST_WPB - 1) / FAST_WPB;
 	hipLaunchKernelGGL(k_leaf_osc2pan, dim3(nblocks, ysplit), dim3(64 * FAST_WPB), 0, (hipStream_t)stream,
 			dparams, dlist, nlist, vpw, ysplit, hp.voices, (const int *)hp.ustate,
-			ysplit > 1 ? ustage : hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
+			ysplit > 1 ? ustage : hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem, hp.wavecoef);
 	if(ysplit > 1) {
 		A2DCommit cm = { dlist, nlist, 2, ustage };
 		if(defer)
@@ -1494,7 +1556,7 @@ int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, co
 	int nblocks = (nwaves + FAST_WPB - 1) / FAST_WPB;
 	size_t lds = (size_t)FAST_WPB * vpw * FILT_PITCH * sizeof(int);
 	hipLaunchKernelGGL(k_leaf_oscfiltpan, dim3(nblocks), dim3(64 * FAST_WPB), lds, (hipStream_t)stream,
-			dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
+			dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem, hp.wavecoef);
 	return (int)hipGetLastError();
 }
 

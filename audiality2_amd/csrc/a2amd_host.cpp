@@ -284,6 +284,7 @@ struct a2amd_ctx {
 	DevBuf<A2DRec> d_recs;
 	DevBuf<A2DWave> d_waves;
 	DevBuf<int16_t> d_wavepool;
+	DevBuf<int32_t> d_wavecoef;	// cap in pool samples, 3 words each (a2amd_fast.hip: Coef3)
 	DevBuf<int32_t> d_busmem;
 	DevBuf<int32_t> d_fbdmem;	// cap in buffer pairs
 	DevBuf<int32_t> d_fmstate;	// cap in slots of A2D_FMSTATE words
@@ -886,6 +887,7 @@ int upload(a2amd_ctx *c)
 	p.runs = c->d_runs.d;
 	p.waves = c->d_waves.d;
 	p.wavepool = c->d_wavepool.d;
+	p.wavecoef = c->d_wavecoef.d;
 	p.busmem = c->d_busmem.d;
 	p.fbdmem = c->d_fbdmem.d;
 	p.ptab = c->d_ptab;
@@ -1359,6 +1361,8 @@ int a2amd_open(const a2amd_config *cfg, a2amd_ctx **out)
 	OPENCHK(hipMalloc((void **)&c->d_ptab, sizeof(c->ptab)));
 	OPENCHK(hipMalloc((void **)&c->d_wavepool.d, (size_t)(8u << 20) * sizeof(int16_t)));
 	c->d_wavepool.cap = 8u << 20;
+	OPENCHK(hipMalloc((void **)&c->d_wavecoef.d, (size_t)(8u << 20) * 3 * sizeof(int32_t)));
+	c->d_wavecoef.cap = 8u << 20;
 #undef OPENCHK
 	*out = c;
 	return A2AMD_OK;
@@ -1373,7 +1377,7 @@ void a2amd_close(a2amd_ctx *c)
 	drop_graphs(c);
 	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
 	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
-	hipFree(c->d_waves.d); hipFree(c->d_wavepool.d); hipFree(c->d_busmem.d);
+	hipFree(c->d_waves.d); hipFree(c->d_wavepool.d); hipFree(c->d_wavecoef.d); hipFree(c->d_busmem.d);
 	hipFree(c->d_fbdmem.d); hipFree(c->d_fmstate.d); hipFree(c->d_xio.d); hipFree(c->d_fmsine); hipFree(c->d_list.d); hipFree(c->d_scatter.d); hipFree(c->d_ptab); hipFree(c->d_blob.d);
 	for(int k = 0; k < 2; ++k) { if(c->h_blob[k]) hipHostFree(c->h_blob[k]); if(c->blob_ev[k]) hipEventDestroy(c->blob_ev[k]); }
 	if(c->h_master)
@@ -1450,8 +1454,17 @@ int a2amd_wave_upload(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w)
 			break;
 		}
 	if(pos == (size_t)-1) {
-		if(c->wavepool_used + total > c->d_wavepool.cap)
+		if(c->wavepool_used + total > c->d_wavepool.cap) {
 			if(int r = grow(c, c->d_wavepool, c->wavepool_used + total, 1, true)) return r;
+			// the coefficient table follows the pool: rebuilt for what is in it
+			if(int r = grow(c, c->d_wavecoef, c->d_wavepool.cap, 3, false)) return r;
+			if(c->wavepool_used > 3 && a2d_launch_build_coef(c->d_wavepool.d, c->d_wavecoef.d, 1,
+					(unsigned)c->wavepool_used - 2, c->stream))
+				return c->fail(A2AMD_EHIP, "coefficient build failed");
+			c->waves_dirty = true;
+			drop_graphs(c);		// (the kernels take the table's address as an argument)
+			c->blob_quiet = false;
+		}
 		pos = c->wavepool_used;
 		c->wavepool_used += total;
 	}
@@ -1464,6 +1477,10 @@ int a2amd_wave_upload(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w)
 		hw.dw.off[l] = (uint32_t)(pos + A2AMD_WAVEPRE);
 		pos += n;
 	}
+	// Hermite coefficients of every window of the region (a2amd_fast.hip: k_build_coef)
+	if(total > 3 && a2d_launch_build_coef(c->d_wavepool.d, c->d_wavecoef.d, (unsigned)hw.pool_off + 1,
+			(unsigned)(hw.pool_off + total) - 2, c->stream))
+		return c->fail(A2AMD_EHIP, "coefficient build failed");
 	c->mwaves[id] = hw.dw;
 	c->waves_dirty = true;
 	++c->stats.live_waves;
