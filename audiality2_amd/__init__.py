@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liba2amd.so")
+# (A2AMD_LIB: another build of the same library, for A/B experiments)
+LIB_PATH = os.environ.get("A2AMD_LIB") or os.path.join(_HERE, "liba2amd.so")
 
 _lib = None
 

@@ -91,15 +91,18 @@ DEV int inter_dwords(const int16_t *d, unsigned ph, unsigned dph16)
 // reference's own (a2_dsp.h:64-74: x = frac << 7, 32 bit wrap-around products,
 // arithmetic >> 15) - a third fewer vector instructions per tap than unpacking the
 // samples and deriving a, b, c for every output frame.
-struct __attribute__((aligned(4))) Coef3 { int a, b, cd; };
+// (one 3-component vector value: stays in the three consecutive registers the 12 byte
+// load fills; as a struct of three ints the compiler copies the members elsewhere
+// right behind every load, and waits for the load to do so)
+typedef int Coef3 __attribute__((ext_vector_type(3), aligned(4)));
 
 DEV int hermite_c(const Coef3 k, unsigned ph)
 {
 	const int x = (int)((ph & 0xffu) << 7);
-	int t = wmul(k.a, x) >> 15;
-	t = wmul(wadd(t, k.b), x) >> 15;
-	t = wmul(wadd(t, k.cd >> 16), x) >> 15;
-	return wadd((int)(int16_t)(k.cd & 0xffff), t);
+	int t = wmul(k.x, x) >> 15;
+	t = wmul(wadd(t, k.y), x) >> 15;
+	t = wmul(wadd(t, k.z >> 16), x) >> 15;
+	return wadd((int)(int16_t)(k.z & 0xffff), t);
 }
 
 // wtosc_Inter (wtosc.c:28-33) from the coefficient table: cb = entry of the level's
@@ -961,49 +964,176 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 // ---------------------------------------------------------------------------
 // wtosc -> filter12 (1 ch) -> panmix 1->2: the BASELINE config 3 voice
 // ---------------------------------------------------------------------------
-// The oscillator and the pan stage are independent per frame (lane = frame);
-// the filter is a recurrence in time (lane = voice).  A wavefront owns up to 64
-// voices, lane v holding ALL state of voice v, and walks the fragments in order:
-//   A  for each voice (state -> SGPRs by readlane): oscillator frames -> row v
-//      of a [voices][64+1] LDS tile
-//   B  every lane runs f12_process (filter12.c:74-119) along its own row, the
-//      filter memories d1/d2 and the q ramper staying in its registers
-//   C  for each voice: row v * pan gains, summed over the voices in registers,
-//      one atomic per (fragment, channel, frame) into the bus
-// The +1 row pitch makes both the row accesses (A, C) and the column accesses
-// (B: lane v reads tile[v][s]) bank-conflict free.
+// The oscillator and the pan stage are independent per frame (lane = frame,
+// throughput work); the filter (f12_process, filter12.c:74-119) is a recurrence in
+// time that no lane can help another with (lane = voice, a dependent chain of 64
+// steps per fragment).  Round 1 ran the three stages one after the other on ONE
+// wavefront owning 8 voices: the filter stage then issues a wave-wide instruction
+// for 8 busy lanes, 176 of the 253 vector instructions per voice-fragment.  Here a
+// workgroup of four wavefronts owns up to 64 voices and runs the stages as a
+// pipeline over the fragments, a barrier per step:
+//
+//   wavefront 0      B(f)    every lane = one voice: filter fragment f in place
+//   wavefronts 1-3   A(f+1)  oscillators of fragment f+1 -> rows of the next tile
+//                    C(f-1)  rows of fragment f-1 x pan gains -> bus (atomics)
+//
+// through a ring of three [voices][64+1] LDS tiles (+1: row and column accesses
+// both bank-conflict free).  The filter stage is all lanes busy (15-19 instructions
+// per step) and alone on its SIMD, the other two stages fill the other three.
 #define FILT_MAXV   64
 #define FILT_PITCH  65
+#ifndef FILT_WAVES
+#define FILT_WAVES  8	// wavefronts per workgroup: one filters, the others run the oscillators / pans (16 spill)
+#endif
+#ifndef FILT_BATCH
+#define FILT_BATCH  5	// settled voices whose coefficient loads are in flight together
+#endif
 enum { FV_Q = 0, FV_LP = 4, FV_BP, FV_HP, FV_F1, FV_D1, FV_D2, FV_NWORDS };
 
-__global__ __launch_bounds__(64 * FAST_WPB)
-void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
+// one filter step (f12_process, filter12.c:98-117)
+template<bool LPONLY>
+DEV int filt_step(int xin, int qq, int ff, int lp, int bp, int hp, int &d1, int &d2)
+{
+	const int d1s = d1 >> 4;
+	const int l = wadd(d2, wmul(ff, d1s) >> 8);
+	const int h = wsub(wsub(xin >> 5, l), wmul(qq, d1s) >> 8);
+	const int b = wadd(wmul(ff, h >> 4) >> 8, d1);
+	d1 = b;
+	d2 = l;
+	return LPONLY ? (wmul(l, lp) >> 3) : (wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3);
+}
+
+// the filter along one voice's row: n frames in place.  The LDS round trip (~130
+// cycles) must not sit on the recurrence: a full fragment is taken sixteen frames at
+// a time - sixteen reads in flight, sixteen steps in registers, sixteen writes.
+template<bool LPONLY, bool QREST>
+DEV void filt_row(int *row, int n, int ff, int lp, int bp, int hp, int &d1, int &d2, int &qv, int qdelta)
+{
+	if(n == A2D_FRAG) {
+#pragma unroll 1
+		for(int s0 = 0; s0 < A2D_FRAG; s0 += 16) {
+			int x[16];
+#pragma unroll
+			for(int k = 0; k < 16; ++k)
+				x[k] = row[s0 + k];
+#pragma unroll
+			for(int k = 0; k < 16; ++k) {
+				x[k] = filt_step<LPONLY>(x[k], qv >> 12, ff, lp, bp, hp, d1, d2);
+				if(!QREST)
+					qv = wadd(qv, qdelta);
+			}
+#pragma unroll
+			for(int k = 0; k < 16; ++k)
+				row[s0 + k] = x[k];
+		}
+		return;
+	}
+	for(int s = 0; s < n; ++s) {
+		row[s] = filt_step<LPONLY>(row[s], qv >> 12, ff, lp, bp, hp, d1, d2);
+		if(!QREST)
+			qv = wadd(qv, qdelta);
+	}
+}
+
+__global__ __launch_bounds__(64 * FILT_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpg,
 		const A2DVoice *__restrict__ voices, int *ustate, const int16_t *__restrict__ wavepool,
 		const A2DWave *__restrict__ waves, const uint32_t *__restrict__ ptab, int *__restrict__ busmem,
 		const int *__restrict__ wavecoef)
 {
-	extern __shared__ __attribute__((aligned(16))) int tiles[];
+	extern __shared__ __attribute__((aligned(16))) int tiles[];	// 3 x [vpg][FILT_PITCH]
 	const A2DParams &p = *pp;
 	const int wv = threadIdx.x >> 6;
 	const int lane = threadIdx.x & 63;
-	const int first = (blockIdx.x * FAST_WPB + wv) * vpw;
-	if(first >= nlist)
-		return;
-	const int nv = min(vpw, nlist - first);
+	const int first = blockIdx.x * vpg;
+	const int nv = min(vpg, nlist - first);		// (the grid has no empty workgroups)
 	const int nfrags = p.nfrags;
 	const int dbg = p.debug;
 	FastPtrs g = { wavepool, waves, ptab, dbg };
-	int *tile = tiles + wv * vpw * FILT_PITCH;
+	const int tsize = vpg * FILT_PITCH;
 
-	int ffr[A2D_MAXBATCH / 64], fst[A2D_MAXBATCH / 64];
+	// (fragment lengths straight from the parameter block, once per stage: no per-lane tables)
+#define FILT_FRAMES(f) ((int)rfl((int)p.fragframes[f]))
+#define FILT_START(f)  ((int)rfl((int)p.fragstart[f]))
+
+	if(wv == 0) {
+		// ================= the filter wavefront: lane = voice =================
+		int fv[FV_NWORDS], u1 = 0;
 #pragma unroll
-	for(int k = 0; k < A2D_MAXBATCH / 64; ++k) {
-		ffr[k] = (k * 64 + lane < nfrags) ? p.fragframes[k * 64 + lane] : 0;
-		fst[k] = (k * 64 + lane < nfrags) ? p.fragstart[k * 64 + lane] : 0;
+		for(int k = 0; k < FV_NWORDS; ++k)
+			fv[k] = 0;
+		bool mine = false;
+		if(lane < nv)
+			mine = p.runs[list[first + lane]].count == 0;
+		if(mine) {
+			u1 = voices[list[first + lane]].unit[1];
+			const int *w1 = ustate + (size_t)u1 * A2D_USTATE;
+#pragma unroll
+			for(int k = 0; k < 4; ++k)
+				fv[FV_Q + k] = w1[FW_Q + k];
+			fv[FV_LP] = w1[FW_LP]; fv[FV_BP] = w1[FW_BP]; fv[FV_HP] = w1[FW_HP];
+			fv[FV_F1] = w1[FW_F1]; fv[FV_D1] = w1[FW_D1A]; fv[FV_D2] = w1[FW_D2A];
+		}
+		// the common shapes, decided for the whole wavefront: low pass only, q at rest
+		const bool lponly = __all(!mine || (fv[FV_BP] == 0 && fv[FV_HP] == 0));
+#ifdef FILT_PROF
+		long long tb = 0, tw = 0;
+#endif
+		for(int st = -1; st <= nfrags; ++st) {
+			const int f = st;
+#ifdef FILT_PROF
+			const long long c0 = __builtin_readcyclecounter();
+#endif
+			if(f >= 0 && f < nfrags && mine) {
+				const int n = FILT_FRAMES(f);
+				int *row = tiles + (f % 3) * tsize + lane * FILT_PITCH;
+				Ramp q = { fv[FV_Q], fv[FV_Q + 1], fv[FV_Q + 2], fv[FV_Q + 3] };
+				ramp_prepare(q, n);	// (f12_process, filter12.c:86-96; no cutoff ramp in a quiet voice)
+				const int ff = fv[FV_F1] >> 12, lp = fv[FV_LP], bp = fv[FV_BP], hp = fv[FV_HP];
+				int d1 = fv[FV_D1], d2 = fv[FV_D2], qv = q.value;
+				const bool qrest = __all(q.delta == 0);
+				if(lponly && qrest)
+					filt_row<true, true>(row, n, ff, lp, bp, hp, d1, d2, qv, q.delta);
+				else if(qrest)
+					filt_row<false, true>(row, n, ff, lp, bp, hp, d1, d2, qv, q.delta);
+				else
+					filt_row<false, false>(row, n, ff, lp, bp, hp, d1, d2, qv, q.delta);
+				ramp_run(q, n);
+				fv[FV_Q] = q.value; fv[FV_Q + 1] = q.target; fv[FV_Q + 2] = q.delta; fv[FV_Q + 3] = q.timer;
+				fv[FV_D1] = d1;
+				fv[FV_D2] = d2;
+			}
+#ifdef FILT_PROF
+			const long long c1 = __builtin_readcyclecounter();
+#endif
+			__syncthreads();
+#ifdef FILT_PROF
+			tb += c1 - c0;
+			tw += __builtin_readcyclecounter() - c1;
+#endif
+		}
+#ifdef FILT_PROF
+		if(blockIdx.x == 7 && lane == 0 && nfrags > 100)
+			printf("filter wave: %lld cycles filtering, %lld waiting (%d fragments)\n", tb, tw, nfrags);
+#endif
+		if(mine) {
+			int *w1 = ustate + (size_t)u1 * A2D_USTATE;
+#pragma unroll
+			for(int k = 0; k < 4; ++k)
+				w1[FW_Q + k] = fv[FV_Q + k];
+			w1[FW_D1A] = fv[FV_D1];
+			w1[FW_D2A] = fv[FV_D2];
+		}
+		return;
 	}
 
-	int sv[SV_NWORDS], dv[DV_NWORDS], fv[FV_NWORDS];
-	int u0 = 0, u1 = 0, u2 = 0, my_off = -1, my_nch = 2;
+	// ============ oscillator / pan wavefronts: lane = frame, voices [vb, ve) ============
+	const int per = (nv + FILT_WAVES - 2) / (FILT_WAVES - 1);
+	const int vb = (wv - 1) * per, ve = min(nv, vb + per);
+	const int mv = max(0, ve - vb);		// my voices: lane l parks voice vb + l
+
+	int sv[SV_NWORDS], dv[DV_NWORDS];
+	int u0 = 0, u2 = 0, my_off = -1, my_nch = 2;
 	bool mine = false;	// this lane's voice is ours to render (no records this batch)
 #pragma unroll
 	for(int k = 0; k < SV_NWORDS; ++k)
@@ -1011,21 +1141,16 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 #pragma unroll
 	for(int k = 0; k < DV_NWORDS; ++k)
 		dv[k] = 0;
-#pragma unroll
-	for(int k = 0; k < FV_NWORDS; ++k)
-		fv[k] = 0;
-	if(lane < nv)
-		mine = p.runs[list[first + lane]].count == 0;
+	if(lane < mv)
+		mine = p.runs[list[first + vb + lane]].count == 0;
 	const unsigned long long mine_mask = __ballot(mine);
 	if(mine) {
-		const A2DVoice &vc = voices[list[first + lane]];
+		const A2DVoice &vc = voices[list[first + vb + lane]];
 		u0 = vc.unit[0];
-		u1 = vc.unit[1];
 		u2 = vc.unit[2];
 		my_off = vc.out_off;
 		my_nch = vc.out_nch;
 		const int *w0 = ustate + (size_t)u0 * A2D_USTATE;
-		const int *w1 = ustate + (size_t)u1 * A2D_USTATE;
 		const int *w2 = ustate + (size_t)u2 * A2D_USTATE;
 		sv[SV_MODE] = w0[OW_MODE]; sv[SV_WAVE] = w0[OW_WAVE]; sv[SV_DPHASE] = w0[OW_DPHASE];
 		sv[SV_PHLO] = w0[OW_PHASE_LO]; sv[SV_PHHI] = w0[OW_PHASE_HI]; sv[SV_PRAMP] = w0[OW_PRAMPING];
@@ -1035,10 +1160,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 			sv[SV_A + k] = w0[OW_A + k];
 			sv[SV_VOL + k] = w2[PW_VOL + k];
 			sv[SV_PAN + k] = w2[PW_PAN + k];
-			fv[FV_Q + k] = w1[FW_Q + k];
 		}
-		fv[FV_LP] = w1[FW_LP]; fv[FV_BP] = w1[FW_BP]; fv[FV_HP] = w1[FW_HP];
-		fv[FV_F1] = w1[FW_F1]; fv[FV_D1] = w1[FW_D1A]; fv[FV_D2] = w1[FW_D2A];
 		bool settled = sv[SV_MODE] == A2D_OSC_MIPWAVE && sv[SV_DPHASE] && !sv[SV_PRAMP] &&
 				!(sv[SV_P + 3] | sv[SV_P + 2] | sv[SV_A + 3] | sv[SV_A + 2] |
 				  sv[SV_VOL + 3] | sv[SV_VOL + 2] | sv[SV_PAN + 3] | sv[SV_PAN + 2]) &&
@@ -1069,187 +1191,215 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		}
 		dv[DV_SETTLED] = settled ? 1 : 0;
 	}
-	unsigned total = 0;	// frames rendered so far
-
-	for(int f = 0; f < nfrags; ++f) {
-		const int n = frames_of(ffr, f);
-		// ---- A: oscillators, frame = lane ----
-		for(int v = 0; v < nv; ++v) {
-			int x;
-			if(!((mine_mask >> v) & 1ull)) {
-				tile[v * FILT_PITCH + lane] = 0;
-				continue;
-			}
-			// four settled voices at a time: their wave data loads overlap
-			if(v + 3 < nv && (rdl(dv[DV_SETTLED], v) & rdl(dv[DV_SETTLED], v + 1) &
-					rdl(dv[DV_SETTLED], v + 2) & rdl(dv[DV_SETTLED], v + 3))) {
-				Coef3 qa[4], qb[4];
-				unsigned qph[4], qph2[4];
-				int qamp[4];
-#pragma unroll
-				for(int k = 0; k < 4; ++k) {
-					const int vk = v + k;
-					const unsigned mm = (unsigned)rdl(dv[DV_MM], vk), dph = (unsigned)rdl(dv[DV_DPH], vk);
-					const unsigned sizem = (unsigned)rdl(dv[DV_SIZEM], vk), doff = (unsigned)rdl(dv[DV_DOFF], vk);
-					const uint64_t phase = (uint64_t)(unsigned)rdl(sv[SV_PHLO], vk) |
-							((uint64_t)(unsigned)rdl(sv[SV_PHHI], vk) << 32);
-					uint64_t ph = wrap_phase((phase >> mm) + (uint64_t)total * dph, sizem);
-					qph[k] = (unsigned)((ph + (uint64_t)(unsigned)lane * dph) >> 16);
-					qph2[k] = qph[k] + (dph >> 17);
-					const char *cb = (const char *)(wavecoef + 3 * (size_t)doff);
-					qa[k] = coef_at(cb, qph[k]);
-					qb[k] = coef_at(cb, qph2[k]);
-					qamp[k] = rdl(sv[SV_A], vk);
-				}
-#pragma unroll
-				for(int k = 0; k < 4; ++k) {
-					int sm = hermite_c(qa[k], qph[k]) + hermite_c(qb[k], qph2[k]);
-					int xk = mul64s(sm, qamp[k], 17);
-					tile[(v + k) * FILT_PITCH + lane] = (lane < n) ? xk : 0;
-				}
-				v += 3;
-				continue;
-			}
-			if(rdl(dv[DV_SETTLED], v)) {
-				const unsigned mm = (unsigned)rdl(dv[DV_MM], v), dph = (unsigned)rdl(dv[DV_DPH], v);
-				const unsigned sizem = (unsigned)rdl(dv[DV_SIZEM], v), doff = (unsigned)rdl(dv[DV_DOFF], v);
-				const int amp = rdl(sv[SV_A], v);
-				const uint64_t phase = (uint64_t)(unsigned)rdl(sv[SV_PHLO], v) |
-						((uint64_t)(unsigned)rdl(sv[SV_PHHI], v) << 32);
-				// start of fragment f = ((phase >> mm) + frames_before * dph) mod (size << 24)
-				uint64_t ph = wrap_phase((phase >> mm) + (uint64_t)total * dph, sizem);
-				unsigned ph16 = (unsigned)((ph + (uint64_t)(unsigned)lane * dph) >> 16);
-				const unsigned ph16b = ph16 + (dph >> 17);
-				const char *cb = (const char *)(wavecoef + 3 * (size_t)doff);
-				int sm = hermite_c(coef_at(cb, ph16), ph16) + hermite_c(coef_at(cb, ph16b), ph16b);
-				x = mul64s(sm, amp, 17);
-			} else {
-				OscS o;
-				o.mode = rdl(sv[SV_MODE], v);
-				o.wave = rdl(sv[SV_WAVE], v);
-				o.dphase = (unsigned)rdl(sv[SV_DPHASE], v);
-				o.phase = (uint64_t)(unsigned)rdl(sv[SV_PHLO], v) |
-						((uint64_t)(unsigned)rdl(sv[SV_PHHI], v) << 32);
-				o.p_ramping = rdl(sv[SV_PRAMP], v);
-				o.p.value = rdl(sv[SV_P], v); o.p.target = rdl(sv[SV_P + 1], v);
-				o.p.delta = rdl(sv[SV_P + 2], v); o.p.timer = rdl(sv[SV_P + 3], v);
-				o.a.value = rdl(sv[SV_A], v); o.a.target = rdl(sv[SV_A + 1], v);
-				o.a.delta = rdl(sv[SV_A + 2], v); o.a.timer = rdl(sv[SV_A + 3], v);
-				x = osc_fragment_s(g, o, n, lane);
-				const bool me = lane == v;
-				WRL(sv[SV_MODE], o.mode);
-				WRL(sv[SV_WAVE], o.wave);
-				WRL(sv[SV_DPHASE], (int)o.dphase);
-				WRL(sv[SV_PHLO], (int)(unsigned)o.phase);
-				WRL(sv[SV_PHHI], (int)(unsigned)(o.phase >> 32));
-				WRL(sv[SV_PRAMP], o.p_ramping);
-				WRL(sv[SV_P], o.p.value); WRL(sv[SV_P + 1], o.p.target);
-				WRL(sv[SV_P + 2], o.p.delta); WRL(sv[SV_P + 3], o.p.timer);
-				WRL(sv[SV_A], o.a.value); WRL(sv[SV_A + 1], o.a.target);
-				WRL(sv[SV_A + 2], o.a.delta); WRL(sv[SV_A + 3], o.a.timer);
-			}
-			tile[v * FILT_PITCH + lane] = (lane < n) ? x : 0;
-		}
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		// ---- B: filter12, voice = lane (f12_process, filter12.c:74-119; no
-		// cutoff ramp in a quiet voice: df = 0) ----
-		if(mine) {
-			Ramp q = { fv[FV_Q], fv[FV_Q + 1], fv[FV_Q + 2], fv[FV_Q + 3] };
-			ramp_prepare(q, n);
-			const int ff = fv[FV_F1] >> 12, lp = fv[FV_LP], bp = fv[FV_BP], hp = fv[FV_HP];
-			int d1 = fv[FV_D1], d2 = fv[FV_D2], qv = q.value;
-			int *row = tile + lane * FILT_PITCH;
-			// the next input is fetched a sample ahead: with few voices a lane's
-			// recurrence is the critical path and the LDS latency would sit on it
-			int xin = row[0];
-			for(int s = 0; s < n; ++s) {
-				const int xnext = row[s + 1];	// (row pitch 65: in bounds)
-				int qq = qv >> 12;
-				int d1s = d1 >> 4;
-				int l = wadd(d2, wmul(ff, d1s) >> 8);
-				int h = wsub(wsub(xin >> 5, l), wmul(qq, d1s) >> 8);
-				int b = wadd(wmul(ff, h >> 4) >> 8, d1);
-				row[s] = wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3;
-				d1 = b;
-				d2 = l;
-				qv = wadd(qv, q.delta);
-				xin = xnext;
-			}
-			ramp_run(q, n);
-			fv[FV_Q] = q.value; fv[FV_Q + 1] = q.target; fv[FV_Q + 2] = q.delta; fv[FV_Q + 3] = q.timer;
-			fv[FV_D1] = d1;
-			fv[FV_D2] = d2;
-		}
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		// ---- C: pan + mix-down, frame = lane ----
-		int acc0 = 0, acc1 = 0;
-		int cur_off = rdl(my_off, 0), cur_nch = rdl(my_nch, 0);
-		for(int v = 0; v < nv; ++v) {
-			if(!((mine_mask >> v) & 1ull))
-				continue;
-			const int voff = rdl(my_off, v);
-			if(voff != cur_off) {
-				if(cur_off >= 0) {
-					int *dst = busmem + cur_off + (size_t)f * cur_nch * A2D_FRAG;
-					if(acc0) atomicAdd(&dst[lane], acc0);
-					if(acc1) atomicAdd(&dst[A2D_FRAG + lane], acc1);
-				}
-				acc0 = acc1 = 0;
-				cur_off = voff;
-				cur_nch = rdl(my_nch, v);
-			}
-			const int y = tile[v * FILT_PITCH + lane];
-			if(rdl(dv[DV_SETTLED], v)) {
-				const int v0 = rdl(dv[DV_V0], v), v1 = rdl(dv[DV_V1], v);
-				if(lane < n) {
-					acc0 = wadd(acc0, mul64s(y, v0, 24));
-					acc1 = wadd(acc1, mul64s(y, v1, 24));
-				}
-			} else {
-				Ramp vol, pan;
-				vol.value = rdl(sv[SV_VOL], v); vol.target = rdl(sv[SV_VOL + 1], v);
-				vol.delta = rdl(sv[SV_VOL + 2], v); vol.timer = rdl(sv[SV_VOL + 3], v);
-				pan.value = rdl(sv[SV_PAN], v); pan.target = rdl(sv[SV_PAN + 1], v);
-				pan.delta = rdl(sv[SV_PAN + 2], v); pan.timer = rdl(sv[SV_PAN + 3], v);
-				pan_fragment_s(vol, pan, y, n, lane, acc0, acc1);
-				const bool me = lane == v;
-				WRL(sv[SV_VOL], vol.value); WRL(sv[SV_VOL + 1], vol.target);
-				WRL(sv[SV_VOL + 2], vol.delta); WRL(sv[SV_VOL + 3], vol.timer);
-				WRL(sv[SV_PAN], pan.value); WRL(sv[SV_PAN + 1], pan.target);
-				WRL(sv[SV_PAN + 2], pan.delta); WRL(sv[SV_PAN + 3], pan.timer);
-			}
-		}
-		if(cur_off >= 0 && !(dbg & 1)) {
-			int *dst = busmem + cur_off + (size_t)f * cur_nch * A2D_FRAG;
-			if(acc0) atomicAdd(&dst[lane], acc0);
-			if(acc1) atomicAdd(&dst[A2D_FRAG + lane], acc1);
-		}
-		total += (unsigned)n;
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		__builtin_amdgcn_wave_barrier();
+	// Every lane keeps its settled voice's phase at the start of the next fragment to
+	// render, in units of the voice's mip level and already reduced mod size << 24
+	// (wtosc.c:259-285: "ph %= size << 24; ...; ph += frames * dph" per fragment is
+	// this recurrence) - one vector update per stage for all voices, instead of a
+	// scalar 64 bit multiply and modulo per voice and stage.
+	uint64_t curph = 0;
+	if(mine && dv[DV_SETTLED]) {
+		const uint64_t phase = (uint64_t)(unsigned)sv[SV_PHLO] | ((uint64_t)(unsigned)sv[SV_PHHI] << 32);
+		curph = (phase >> (unsigned)dv[DV_MM]) % ((uint64_t)(unsigned)dv[DV_SIZEM] << 24);
 	}
+	uint64_t lastph = 0;	// ... and at the start of the last fragment rendered (for the end state)
+
+#ifdef FILT_PROF
+	long long ta = 0, tc = 0, tw = 0;
+#endif
+	for(int st = -1; st <= nfrags; ++st) {
+#ifdef FILT_PROF
+		const long long c0 = __builtin_readcyclecounter();
+#endif
+		// ---- A: oscillators of fragment st + 1, frame = lane.  The coefficient loads of
+		// the wavefront's first FILT_BATCH settled voices are issued here, the pan stage
+		// of fragment st - 1 runs while they are in flight, the Hermite arithmetic after.
+		const int fa = st + 1;
+		Coef3 pqa[FILT_BATCH], pqb[FILT_BATCH];
+		unsigned pqph[FILT_BATCH], pqph2[FILT_BATCH];
+		int pnb = 0;
+		if(fa < nfrags) {
+			while(pnb < FILT_BATCH && pnb < mv && ((mine_mask >> pnb) & 1ull) && rdl(dv[DV_SETTLED], pnb))
+				++pnb;
+			const unsigned cur_lo = (unsigned)curph, cur_hi = (unsigned)(curph >> 32);
+			// (branch free: an unused slot fetches voice 0's entries again - with branches
+			// around the slots the compiler waits for each pair of loads before the next)
+			if(pnb) {
+#pragma unroll
+				for(int k = 0; k < FILT_BATCH; ++k) {
+					const int vk = k < pnb ? k : 0;
+					const unsigned dph = (unsigned)rdl(dv[DV_DPH], vk), doff = (unsigned)rdl(dv[DV_DOFF], vk);
+					const uint64_t ph = (uint64_t)(unsigned)rdl((int)cur_lo, vk) |
+							((uint64_t)(unsigned)rdl((int)cur_hi, vk) << 32);
+					pqph[k] = (unsigned)((ph + (uint64_t)(unsigned)lane * dph) >> 16);
+					pqph2[k] = pqph[k] + (dph >> 17);
+					const char *cb = (const char *)(wavecoef + 3 * (size_t)doff);
+					pqa[k] = coef_at(cb, pqph[k]);
+					pqb[k] = coef_at(cb, pqph2[k]);
+				}
+			}
+		}
+		// ---- C: pan + mix-down of fragment st - 1, frame = lane ----
+		const int fc = st - 1;
+		if(fc >= 0) {
+			const int n = FILT_FRAMES(fc);
+			const int *tile = tiles + (fc % 3) * tsize + vb * FILT_PITCH;
+			int acc0 = 0, acc1 = 0;
+			int cur_off = rdl(my_off, 0), cur_nch = rdl(my_nch, 0);
+			// (the rows of the first FILT_BATCH voices are fetched together: one LDS
+			// round trip instead of one per voice)
+			int yrow[FILT_BATCH];
+#pragma unroll
+			for(int k = 0; k < FILT_BATCH; ++k)
+				yrow[k] = (k < mv) ? tile[k * FILT_PITCH + lane] : 0;
+			for(int v = 0; v < mv; ++v) {
+				if(!((mine_mask >> v) & 1ull))
+					continue;
+				const int voff = rdl(my_off, v);
+				if(voff != cur_off) {
+					if(cur_off >= 0 && !(dbg & 1)) {
+						int *dst = busmem + cur_off + (size_t)fc * cur_nch * A2D_FRAG;
+						if(acc0) atomicAdd(&dst[lane], acc0);
+						if(acc1) atomicAdd(&dst[A2D_FRAG + lane], acc1);
+					}
+					acc0 = acc1 = 0;
+					cur_off = voff;
+					cur_nch = rdl(my_nch, v);
+				}
+				int y;
+				if(v < FILT_BATCH) {
+					y = yrow[0];
+#pragma unroll
+					for(int k = 1; k < FILT_BATCH; ++k)
+						y = (v == k) ? yrow[k] : y;
+				} else
+					y = tile[v * FILT_PITCH + lane];
+				if(rdl(dv[DV_SETTLED], v)) {
+					const int v0 = rdl(dv[DV_V0], v), v1 = rdl(dv[DV_V1], v);
+					if(lane < n) {
+						acc0 = wadd(acc0, mul64s(y, v0, 24));
+						acc1 = wadd(acc1, mul64s(y, v1, 24));
+					}
+				} else {
+					Ramp vol, pan;
+					vol.value = rdl(sv[SV_VOL], v); vol.target = rdl(sv[SV_VOL + 1], v);
+					vol.delta = rdl(sv[SV_VOL + 2], v); vol.timer = rdl(sv[SV_VOL + 3], v);
+					pan.value = rdl(sv[SV_PAN], v); pan.target = rdl(sv[SV_PAN + 1], v);
+					pan.delta = rdl(sv[SV_PAN + 2], v); pan.timer = rdl(sv[SV_PAN + 3], v);
+					pan_fragment_s(vol, pan, y, n, lane, acc0, acc1);
+					const bool me = lane == v;
+					WRL(sv[SV_VOL], vol.value); WRL(sv[SV_VOL + 1], vol.target);
+					WRL(sv[SV_VOL + 2], vol.delta); WRL(sv[SV_VOL + 3], vol.timer);
+					WRL(sv[SV_PAN], pan.value); WRL(sv[SV_PAN + 1], pan.target);
+					WRL(sv[SV_PAN + 2], pan.delta); WRL(sv[SV_PAN + 3], pan.timer);
+				}
+			}
+			if(cur_off >= 0 && !(dbg & 1)) {
+				int *dst = busmem + cur_off + (size_t)fc * cur_nch * A2D_FRAG;
+				if(acc0) atomicAdd(&dst[lane], acc0);
+				if(acc1) atomicAdd(&dst[A2D_FRAG + lane], acc1);
+			}
+		}
+#ifdef FILT_PROF
+		const long long c1 = __builtin_readcyclecounter();
+#endif
+		// ---- A, second half ----
+		if(fa < nfrags) {
+			const int n = FILT_FRAMES(fa);
+			int *tile = tiles + (fa % 3) * tsize + vb * FILT_PITCH;
+			const unsigned cur_lo = (unsigned)curph, cur_hi = (unsigned)(curph >> 32);
+			if(pnb) {
+				int xs[FILT_BATCH];
+#pragma unroll
+				for(int k = 0; k < FILT_BATCH; ++k) {
+					int sm = hermite_c(pqa[k], pqph[k]) + hermite_c(pqb[k], pqph2[k]);
+					xs[k] = mul64s(sm, rdl(sv[SV_A], k < pnb ? k : 0), 17);
+				}
+#pragma unroll
+				for(int k = 0; k < FILT_BATCH; ++k)
+					if(k < pnb)
+						tile[k * FILT_PITCH + lane] = (lane < n) ? xs[k] : 0;
+			}
+			for(int v = pnb; v < mv; ++v) {
+				int x;
+				if(!((mine_mask >> v) & 1ull)) {
+					tile[v * FILT_PITCH + lane] = 0;
+					continue;
+				}
+				if(rdl(dv[DV_SETTLED], v)) {
+					const unsigned dph = (unsigned)rdl(dv[DV_DPH], v), doff = (unsigned)rdl(dv[DV_DOFF], v);
+					const int amp = rdl(sv[SV_A], v);
+					const uint64_t ph = (uint64_t)(unsigned)rdl((int)cur_lo, v) | ((uint64_t)(unsigned)rdl((int)cur_hi, v) << 32);
+					unsigned ph16 = (unsigned)((ph + (uint64_t)(unsigned)lane * dph) >> 16);
+					const unsigned ph16b = ph16 + (dph >> 17);
+					const char *cb = (const char *)(wavecoef + 3 * (size_t)doff);
+					int sm = hermite_c(coef_at(cb, ph16), ph16) + hermite_c(coef_at(cb, ph16b), ph16b);
+					x = mul64s(sm, amp, 17);
+				} else {
+					OscS o;
+					o.mode = rdl(sv[SV_MODE], v);
+					o.wave = rdl(sv[SV_WAVE], v);
+					o.dphase = (unsigned)rdl(sv[SV_DPHASE], v);
+					o.phase = (uint64_t)(unsigned)rdl(sv[SV_PHLO], v) |
+							((uint64_t)(unsigned)rdl(sv[SV_PHHI], v) << 32);
+					o.p_ramping = rdl(sv[SV_PRAMP], v);
+					o.p.value = rdl(sv[SV_P], v); o.p.target = rdl(sv[SV_P + 1], v);
+					o.p.delta = rdl(sv[SV_P + 2], v); o.p.timer = rdl(sv[SV_P + 3], v);
+					o.a.value = rdl(sv[SV_A], v); o.a.target = rdl(sv[SV_A + 1], v);
+					o.a.delta = rdl(sv[SV_A + 2], v); o.a.timer = rdl(sv[SV_A + 3], v);
+					x = osc_fragment_s(g, o, n, lane);
+					const bool me = lane == v;
+					WRL(sv[SV_MODE], o.mode);
+					WRL(sv[SV_WAVE], o.wave);
+					WRL(sv[SV_DPHASE], (int)o.dphase);
+					WRL(sv[SV_PHLO], (int)(unsigned)o.phase);
+					WRL(sv[SV_PHHI], (int)(unsigned)(o.phase >> 32));
+					WRL(sv[SV_PRAMP], o.p_ramping);
+					WRL(sv[SV_P], o.p.value); WRL(sv[SV_P + 1], o.p.target);
+					WRL(sv[SV_P + 2], o.p.delta); WRL(sv[SV_P + 3], o.p.timer);
+					WRL(sv[SV_A], o.a.value); WRL(sv[SV_A + 1], o.a.target);
+					WRL(sv[SV_A + 2], o.a.delta); WRL(sv[SV_A + 3], o.a.timer);
+				}
+				tile[v * FILT_PITCH + lane] = (lane < n) ? x : 0;
+			}
+			// every settled voice moves on by n frames (all lanes at once)
+			if(mine && dv[DV_SETTLED]) {
+				lastph = curph;
+				uint64_t ph = curph + (uint64_t)(unsigned)dv[DV_DPH] * (unsigned)n;
+				const unsigned size = (unsigned)dv[DV_SIZEM];
+				unsigned hi = (unsigned)(ph >> 24);
+				if(hi >= size) {
+					hi -= size;		// (one period further, usually; short mip levels wrap more often)
+					if(hi >= size)
+						hi = (size & (size - 1)) ? hi % size : (hi & (size - 1));
+					ph = ((uint64_t)hi << 24) | (ph & 0xffffffu);
+				}
+				curph = ph;
+			}
+		}
+#ifdef FILT_PROF
+		const long long c2 = __builtin_readcyclecounter();
+#endif
+		__syncthreads();
+#ifdef FILT_PROF
+		ta += c1 - c0;
+		tc += c2 - c1;
+		tw += __builtin_readcyclecounter() - c2;
+#endif
+	}
+#ifdef FILT_PROF
+	if(blockIdx.x == 7 && lane == 0 && wv == 1 && nfrags > 100)
+		printf("osc/pan wave (%d voices): %lld cycles issue+pan, %lld oscillators, %lld waiting\n", mv, ta, tc, tw);
+#endif
 
 	if(mine) {
 		if(dv[DV_SETTLED]) {
 			// the unwrapped end of the last fragment (wtosc.c:284)
-			const unsigned mm = (unsigned)dv[DV_MM], dph = (unsigned)dv[DV_DPH];
-			const unsigned nlast = (unsigned)frames_of(ffr, nfrags - 1);
-			const uint64_t phase = (uint64_t)(unsigned)sv[SV_PHLO] | ((uint64_t)(unsigned)sv[SV_PHHI] << 32);
-			uint64_t ph = (phase >> mm) + (uint64_t)(total - nlast) * dph;
-			const unsigned size = (unsigned)dv[DV_SIZEM];
-			unsigned hi = (unsigned)(ph >> 24);		// wrap_phase, per lane
-			if(ph >> 56)
-				ph %= (uint64_t)size << 24;
-			else if(hi >= size)
-				ph = ((uint64_t)(hi % size) << 24) | (ph & 0xffffffu);
-			ph = (ph + (uint64_t)dph * nlast) << mm;
+			const uint64_t ph = (lastph + (uint64_t)(unsigned)dv[DV_DPH] * (unsigned)FILT_FRAMES(nfrags - 1)) <<
+					(unsigned)dv[DV_MM];
 			sv[SV_PHLO] = (int)(unsigned)ph;
 			sv[SV_PHHI] = (int)(unsigned)(ph >> 32);
 		}
 		int *w0 = ustate + (size_t)u0 * A2D_USTATE;
-		int *w1 = ustate + (size_t)u1 * A2D_USTATE;
 		int *w2 = ustate + (size_t)u2 * A2D_USTATE;
 		w0[OW_MODE] = sv[SV_MODE]; w0[OW_WAVE] = sv[SV_WAVE]; w0[OW_DPHASE] = sv[SV_DPHASE];
 		w0[OW_PHASE_LO] = sv[SV_PHLO]; w0[OW_PHASE_HI] = sv[SV_PHHI]; w0[OW_PRAMPING] = sv[SV_PRAMP];
@@ -1259,10 +1409,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 			w0[OW_A + k] = sv[SV_A + k];
 			w2[PW_VOL + k] = sv[SV_VOL + k];
 			w2[PW_PAN + k] = sv[SV_PAN + k];
-			w1[FW_Q + k] = fv[FV_Q + k];
 		}
-		w1[FW_D1A] = fv[FV_D1];
-		w1[FW_D2A] = fv[FV_D2];
 	}
 }
 
@@ -1547,16 +1694,16 @@ int a2d_launch_scatter_runs(const int *didx, const A2DRun *dval, int n, A2DRun *
 }
 
 int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
-		int vpw, void *stream)
+		int vpg, void *stream)
 {
 	if(nlist <= 0)
 		return 0;
-	vpw = vpw < 1 ? 1 : (vpw > FILT_MAXV ? FILT_MAXV : vpw);
-	int nwaves = (nlist + vpw - 1) / vpw;
-	int nblocks = (nwaves + FAST_WPB - 1) / FAST_WPB;
-	size_t lds = (size_t)FAST_WPB * vpw * FILT_PITCH * sizeof(int);
-	hipLaunchKernelGGL(k_leaf_oscfiltpan, dim3(nblocks), dim3(64 * FAST_WPB), lds, (hipStream_t)stream,
-			dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem, hp.wavecoef);
+	// voices per workgroup (one filter wavefront's lanes)
+	vpg = vpg < 1 ? 1 : (vpg > FILT_MAXV ? FILT_MAXV : vpg);
+	int nblocks = (nlist + vpg - 1) / vpg;
+	size_t lds = (size_t)3 * vpg * FILT_PITCH * sizeof(int);
+	hipLaunchKernelGGL(k_leaf_oscfiltpan, dim3(nblocks), dim3(64 * FILT_WAVES), lds, (hipStream_t)stream,
+			dparams, dlist, nlist, vpg, hp.voices, hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem, hp.wavecoef);
 	return (int)hipGetLastError();
 }
 

@@ -378,6 +378,7 @@ int grow(a2amd_ctx *c, DevBuf<T> &b, size_t need, size_t elem_mult, bool keep)
 	return 0;
 }
 
+double *dbg_counters();	// (A2AMD_HOSTTIMING counters, defined with the timing dump below)
 int rec_tag(const a2amd_ctx *c) { return c->frag_open ? c->cur_frag : c->nfrags; }
 
 void touch(a2amd_ctx *c, int vi)
@@ -456,6 +457,8 @@ int close_fragment(a2amd_ctx *c)
 	const unsigned nframes = c->fragframes[f];
 	(void)nframes;
 	if(c->walked_started != c->n_started_live) {
+		if(c->hosttiming)
+			dbg_counters()[2] += 1;
 		// a live voice got no Process call this fragment: say so, or
 		// the kernel would apply the default
 		for(size_t vi = 0; vi < c->voices.size(); ++vi) {
@@ -469,6 +472,8 @@ int close_fragment(a2amd_ctx *c)
 				}
 				v.recs.push_back(r);
 				v.touched = c->serial_base + f;
+				if(c->hosttiming)
+					dbg_counters()[3] += 1;
 			}
 		}
 	}
@@ -620,6 +625,8 @@ int upload(a2amd_ctx *c)
 				inject = true;
 		if(!inject) {
 			// the same quiet batch again: the device has it all (graphs stay valid)
+			if(c->hosttiming)
+				dbg_counters()[0] += 1;
 			++c->quiet_streak;
 			c->uploaded = true;
 			return 0;
@@ -755,6 +762,10 @@ int upload(a2amd_ctx *c)
 		}
 	c->prev_with_recs.clear();
 	c->stats.records += recs.size();
+	if(c->hosttiming) {
+		dbg_counters()[1] += (double)recs.size();
+		dbg_counters()[4] += (double)c->with_recs.size();
+	}
 
 	// Launch lists.  Static part, rebuilt when the voice tree changes: every
 	// listed voice by class -
@@ -1158,13 +1169,12 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			++c->stats.launches;
 		}
 		if(c->n_filt_leaf) {
-			// sweep (MI355X, ms per 256 fragments): 1 024 voices best at 1 voice per
-			// wavefront (1.11), 4 096 at 4 (1.36), 16 384 at 8 (2.37): one wavefront
-			// per SIMD while that is possible, then two
+			// voices per workgroup = lanes of its filter wavefront: all 64 once there
+			// are enough voices for a workgroup on every CU, else spread out (a
+			// workgroup takes as long as its filter chain, whatever its voice count)
 			const int nf = c->n_filt_leaf;
 			int vpw = getenv("A2AMD_FVPW") ? atoi(getenv("A2AMD_FVPW")) :
-					nf <= 16384 ? std::min(std::max((nf + 1023) / 1024, 1), 8) :
-					std::min(std::max((nf + 2047) / 2048, 1), 32);
+					std::min(std::max((nf + 511) / 512, 1), 32);
 			if(a2d_launch_leaf_oscfiltpan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf,
 					c->n_filt_leaf, vpw, c->stream))
 				return c->fail(A2AMD_EHIP, "filter leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -2147,9 +2157,13 @@ static double now_us()
 	return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
 }
 static double g_t[4], g_n;
+static double g_cnt[6];		// quiet uploads, records shipped, walk scans, R_NOPs, voices with records, graph launches
 struct TimingDump { ~TimingDump() { if(getenv("A2AMD_HOSTTIMING") && g_n) fprintf(stderr,
-	"a2amd host timing per render: upload %.1f us, issue %.1f us, readback %.1f us (%g renders)\n",
-	g_t[0] / g_n, g_t[1] / g_n, g_t[2] / g_n, g_n); } } g_timing_dump;
+	"a2amd host timing per render: upload %.1f us, issue %.1f us, readback %.1f us (%g renders; %g quiet uploads, "
+	"%g graph launches, %g records, %g voices with records, %g walk scans, %g R_NOPs)\n",
+	g_t[0] / g_n, g_t[1] / g_n, g_t[2] / g_n, g_n, g_cnt[0], g_cnt[5], g_cnt[1], g_cnt[4], g_cnt[2], g_cnt[3]); } } g_timing_dump;
+
+namespace { double *dbg_counters() { return g_cnt; } }
 
 int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned cap)
 {
@@ -2203,6 +2217,8 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 				if(int r = ensure_clean(c))
 					return r;
 			HIPCHK(c, hipGraphLaunch(c->gexec[slot], c->stream));
+			if(c->hosttiming)
+				dbg_counters()[5] += 1;
 			if(slot == 1)
 				c->others_clean = c->root_clean = c->consume_ok;
 			else if(slot == 2) {

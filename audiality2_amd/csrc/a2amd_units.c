@@ -31,6 +31,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "../../include/a2amd.h"
 #include "../../include/a2amd_plugin.h"
 
@@ -677,11 +678,35 @@ static HOSTSTATE *state_of_config(A2P_config *cfg)
 	return NULL;
 }
 
+/* A2AMD_HOSTTIMING=1: where a buffer's time goes (the engine's walk incl. our
+ * recording callbacks / the GPU round trip), printed when the process exits */
+static double t_walk, t_flush, n_buffers;
+static int timing_on = -1;
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+static void timing_dump(void)
+{
+	if(n_buffers)
+		fprintf(stderr, "a2amd units: per driver buffer: engine walk + recording %.1f us, render + delivery %.1f us "
+				"(%g buffers)\n", t_walk / n_buffers * 1e6, t_flush / n_buffers * 1e6, n_buffers);
+}
+
 static void amd_drv_process(A2P_audiodriver *drv, unsigned frames)
 {
 	HOSTSTATE *hs = state_of_config(drv->driver.config);
 	int c;
 	unsigned s;
+	double t0 = 0, t1 = 0;
+	if(timing_on < 0)
+	{
+		timing_on = getenv("A2AMD_HOSTTIMING") != NULL;
+		if(timing_on)
+			atexit(timing_dump);
+	}
 	if(!hs || !hs->drv_process)
 		return;
 	hs->in_buffer = 1;
@@ -691,7 +716,11 @@ static void amd_drv_process(A2P_audiodriver *drv, unsigned frames)
 	hs->rinj_used = 0;
 	if(!grow_acc(hs, frames))
 		hs->decided = 1;	/* (out of memory: this buffer the old way) */
+	if(timing_on)
+		t0 = now_s();
 	hs->drv_process(drv, frames);	/* a2_AudioCallback: the engine walks, our units record */
+	if(timing_on)
+		t1 = now_s();
 	if(hs->batching)
 	{
 		flush_batch(hs);
@@ -704,6 +733,12 @@ static void amd_drv_process(A2P_audiodriver *drv, unsigned frames)
 		}
 	}
 	hs->in_buffer = hs->batching = 0;
+	if(timing_on)
+	{
+		t_walk += t1 - t0;
+		t_flush += now_s() - t1;
+		n_buffers += 1;
+	}
 }
 
 /* put our Process in front of the engine's (which a2_Open installs after the
@@ -753,10 +788,20 @@ static void forward_process(XTRA *x, unsigned offset, unsigned frames)
 		a2_SetStateProperty(hs->cfg->interface, A2P_PNOISESEED, (int)noise);
 }
 
+static int null_walk = -1;	/* A2AMD_NULLWALK=1 (measurement only): leaf units record nothing - the engine's bare walk */
+
 static void amd_process(A2P_unit *u, unsigned offset, unsigned frames)
 {
-	XTRA *x = xtra(u);
-	HOSTSTATE *hs = x->hs;
+	XTRA *x;
+	HOSTSTATE *hs;
+	if(null_walk < 0)
+		null_walk = getenv("A2AMD_NULLWALK") ? atoi(getenv("A2AMD_NULLWALK")) : 0;
+	if(null_walk == 2)
+		return;
+	x = xtra(u);
+	hs = x->hs;
+	if(null_walk == 1 && !x->is_root)
+		return;
 
 	if(!x->chain_checked)
 	{

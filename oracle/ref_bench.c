@@ -45,10 +45,16 @@ static void *run(void *arg)
 	A2_interface *i;
 	A2_handle bank, prog;
 	int args[2], f, av = 0;
+	/* A2REF_BUFFER=<frames>: the a2_Run() buffer (default 64 = one fragment per call;
+	 * a2play's default is 4096); 'fragments' stays a count of 64 frame units */
+	int buffer = getenv("A2REF_BUFFER") ? atoi(getenv("A2REF_BUFFER")) : 64;
+	int nbuf;
 	double t0;
 	if(!(drv = a2_NewDriver(A2_AUDIODRIVER, "buffer")))
 		return NULL;
-	if(!(cfg = a2_OpenConfig(48000, 64, 2, A2_AUTOCLOSE)))
+	if(buffer < 64)
+		buffer = 64;
+	if(!(cfg = a2_OpenConfig(48000, buffer, 2, A2_AUTOCLOSE)))
 		return NULL;
 	a2_AddDriver(cfg, drv);
 	if(!(i = a2_Open(cfg)))
@@ -63,13 +69,21 @@ static void *run(void *arg)
 	if(a2_Starta(i, a2_RootVoice(i), prog, 2, args) < 0)
 		return NULL;
 	/* warm-up: instantiates the voices */
-	for(f = 0; f < j->voices / 4 * 2 / 64 + 16; ++f)
-		a2_Run(i, 64);
+	/* (grouped programs populate one group of 256 voices per 2.7 ms = 2.1 fragments) */
+	{
+		int wf = j->voices / 4 * 2 / 64 + 16;
+		if(strstr(j->program, "Groups") && wf < j->voices / 256 * 21 / 10 + 32)
+			wf = j->voices / 256 * 21 / 10 + 32;
+		for(f = 0; f < (wf + buffer / 64 - 1) / (buffer / 64); ++f)
+			a2_Run(i, buffer);
+	}
 	j->hash = 0xcbf29ce484222325ULL;
 	t0 = now();
-	for(f = 0; f < j->fragments; ++f)
+	nbuf = (j->fragments * 64 + buffer - 1) / buffer;
+	j->fragments = nbuf * (buffer / 64);
+	for(f = 0; f < nbuf; ++f)
 	{
-		a2_Run(i, 64);
+		a2_Run(i, buffer);
 		if(getenv("A2REF_HASH"))	/* correctness runs only: costs time */
 		{
 			int c;
@@ -77,7 +91,7 @@ static void *run(void *arg)
 			for(c = 0; c < 2; ++c)
 			{
 				const unsigned char *b = (const unsigned char *)((A2_audiodriver *)drv)->buffers[c];
-				for(k = 0; k < 64 * 4; ++k)
+				for(k = 0; k < (unsigned)buffer * 4; ++k)
 					j->hash = (j->hash ^ b[k]) * 0x100000001b3ULL;
 			}
 		}
@@ -131,8 +145,8 @@ int main(int argc, const char *argv[])
 	}
 	printf("{\"voice_samples_per_s\": %.6g, \"seconds\": %.6f, \"voices\": %d, "
 			"\"fragments\": %d, \"threads\": %d, \"active_voices\": %d",
-			(double)(voices / threads) * threads * 64.0 * fragments / worst,
-			worst, (voices / threads) * threads, fragments, threads, active);
+			(double)(voices / threads) * threads * 64.0 * jobs[0].fragments / worst,
+			worst, (voices / threads) * threads, jobs[0].fragments, threads, active);
 	if(getenv("A2REF_HASH"))
 	{
 		printf(", \"hashes\": [");

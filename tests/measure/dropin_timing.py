@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 R = os.path.join(ROOT, "oracle", "_ref", "ref_render")
 U = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
 A2S = os.path.join(ROOT, "tests", "a2s")
-CASES = [("scripted", ["0.2"]), ("fm", ["0.15"]), ("fx", ["0.1"]), ("delaybus", ["2", "4", "0.05"])]
+CASES = [("scripted", ["0.2"]), ("fm", ["0.15"]), ("fx", ["0.1"]), ("delaybus", ["2", "4", "0.05"]), ("song", ["0.08"])]
 
 
 def run(script, args, frames, buffer, preload):
@@ -35,7 +35,7 @@ def run(script, args, frames, buffer, preload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=30.0)
-    ap.add_argument("--buffer", type=int, default=64)
+    ap.add_argument("--buffer", type=int, default=4096, help="a2_Run() buffer in frames (a2play's default: 4096)")
     a = ap.parse_args()
     frames = int(a.seconds * 48000) // a.buffer * a.buffer
     for script, args in CASES:
@@ -44,7 +44,9 @@ def main():
         same = open(fc, "rb").read() == open(fg, "rb").read()
         print(json.dumps({"script": script, "audio_s": frames / 48000.0, "buffer": a.buffer,
                           "cpu_reference_s": round(tc, 3), "gpu_dropin_s": round(tg, 3),
+                          "dropin_over_cpu": round(tg / tc, 2),
                           "us_per_fragment_gpu": round(tg / (frames / 64.0) * 1e6, 1),
+                          "us_per_buffer_gpu": round(tg / (frames / float(a.buffer)) * 1e6, 1),
                           "bit_identical": same}))
 
 

@@ -21,8 +21,11 @@ U = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
 A2S = os.path.join(ROOT, "tests", "a2s")
 
 
+BUFFER = int(os.environ.get("A2REF_BUFFER", "64"))     # a2_Run() buffer: 64 = realtime-style, 4096 = a2play's
+
+
 def run(program, voices, frags, preload, threads=1):
-    env = dict(os.environ)
+    env = dict(os.environ, A2REF_BUFFER=str(BUFFER))
     if preload:
         env["LD_PRELOAD"] = U
     out = subprocess.run([B, "bench.a2s", program, str(voices), str(frags), str(threads)], env=env, cwd=A2S,
@@ -32,12 +35,12 @@ def run(program, voices, frags, preload, threads=1):
 
 def main():
     for program, cpu_frags in (("OscPan", 300), ("OscPanScripted", 300), ("OscFilterPan", 200), ("Osc2Pan", 200),
-                               ("Fm1Pan", 300), ("Fm2Pan", 150), ("Fm4Pan", 60)):
+                               ("Osc2PanGroups", 200), ("Fm1Pan", 300), ("Fm2Pan", 150), ("Fm4Pan", 60)):
         for voices in (1024, 4096, 16384, 32768):
             c = run(program, voices, max(cpu_frags * 1024 // voices, 20), False)
-            g = run(program, voices, 300, True)
+            g = run(program, voices, max(300, 4 * BUFFER // 64), True)
             frag_us = g["seconds"] / g["fragments"] * 1e6
-            print(json.dumps({"program": program, "voices": voices,
+            print(json.dumps({"program": program, "voices": voices, "buffer_frames": BUFFER,
                               "cpu_reference_vs_per_s": c["voice_samples_per_s"],
                               "engine_plus_dropin_vs_per_s": g["voice_samples_per_s"],
                               "speedup": round(g["voice_samples_per_s"] / c["voice_samples_per_s"], 2),
