@@ -1058,6 +1058,9 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 
 	if(wv == 0) {
 		// ================= the filter wavefront: lane = voice =================
+		// (its dependent chain is the workgroup's critical path: first in line for
+		// the issue slots of the SIMD it shares with oscillator wavefronts)
+		__builtin_amdgcn_s_setprio(3);
 		int fv[FV_NWORDS], u1 = 0;
 #pragma unroll
 		for(int k = 0; k < FV_NWORDS; ++k)

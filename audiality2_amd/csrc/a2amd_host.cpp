@@ -124,6 +124,11 @@ struct HUnit {
 	// wtosc shadow: enough of A2_wtosc to count noise draws on the host
 	int mode = A2D_OSC_OFF, wave = -1;
 	unsigned shadow_epoch = 0;	// == ctx epoch while every Process call came through unit_process
+	// wtosc: the walk time (frames since the context opened) up to which the shadow below
+	// has been advanced.  Windows the host reported through the default map
+	// (a2amd_default_map) are caught up with in closed form when the shadow is next
+	// needed (shadow_catch_up): none of them touches this struct.
+	uint64_t shadow_time = 0;
 	unsigned dphase = 0;
 	int p_ramping = 0;
 	uint64_t phase = 0;
@@ -229,6 +234,15 @@ struct a2amd_ctx {
 	bool capturing = false;			// issue_kernels is being captured into a graph
 	int n_clients = 0;			// units whose clients are served (a2amd_unit_clients mode != 0)
 	unsigned shadow_epoch = 0;
+	// The default map: one byte per voice slot, set by the HOST for a voice that
+	// received exactly the engine's default window (Process(0, all frames) on every
+	// unit, nothing else) in the open fragment - the one-store-per-voice fast path of
+	// the voice walk (a2amd_default_map).  Cleared when a fragment opens.
+	std::vector<uint8_t> defmap;
+	bool defmap_used = false;		// the host asked for the map in the open fragment
+	bool defmap_dirty = false;		// ... in some fragment since it was last zeroed
+	uint64_t walk_time = 0;			// frames of all fragments before the open one
+	unsigned prev_frames = 0;		// length of the fragment before the open one
 
 	// fragment clock
 	bool frag_open = false;
@@ -391,11 +405,25 @@ void touch(a2amd_ctx *c, int vi)
 	}
 }
 
+void voice_catch_up(a2amd_ctx *c, int vi);
+
 void push_rec(a2amd_ctx *c, int vi, int op, int unit, int reg, int value, unsigned dur, unsigned start)
 {
 	touch(c, vi);
 	{
 		HVoice &dv = c->voices[vi];
+		if(c->frag_open && c->defmap_used && (size_t)vi < c->defmap.size() && c->defmap[vi]) {
+			// the host marked this voice's default window in the map and now
+			// something follows in the same fragment after all: the mark
+			// becomes the ordinary bookkeeping
+			voice_catch_up(c, vi);
+			c->defmap[vi] = 0;
+			dv.default_seg = c->serial_base + c->cur_frag;
+			if(dv.walked != c->serial_base + c->cur_frag) {
+				dv.walked = c->serial_base + c->cur_frag;
+				++c->walked_started;
+			}
+		}
 		if(dv.default_seg == c->serial_base + rec_tag(c)) {
 			// the default window of this fragment was left unrecorded; now
 			// something follows it, so it has to be spelled out first
@@ -448,6 +476,64 @@ int bus_alloc(a2amd_ctx *c, int nch)
 	return (int)off;
 }
 
+// ---- lazy phase shadow ---------------------------------------------------------------
+// What wtosc_wavetable (wtosc.c:239-286) does to the phase of a settled, looped,
+// mip-mapped oscillator over k consecutive default windows of f1 .. fk frames:
+//   ph = (phase >> mm) % m;  phase = (ph + dph * f) << mm         per window
+// composes to  ((((phase >> mm) % m + dph * (F - fk)) % m) + dph * fk) << mm,  F = sum f.
+// So windows the host only marked in the default map need no per-window host work:
+// the shadow is caught up when it is next looked at.
+bool shadow_lazy_ok(const a2amd_ctx *c, const HUnit &u)
+{
+	if(u.kind != A2AMD_WTOSC)
+		return true;
+	if(u.mode == A2D_OSC_NOISE || !(u.shadow_ok && u.shadow_epoch == c->shadow_epoch))
+		return u.mode != A2D_OSC_NOISE;	// (a lost shadow stays lost; noise needs every call)
+	if(u.mode == A2D_OSC_OFF)
+		return u.p.timer == 0;		// wtosc_Off with the ramper at rest: nothing moves
+	if(u.mode != A2D_OSC_MIPWAVE || u.wave < 0)
+		return false;
+	const A2DWave &w = c->waves[u.wave].dw;
+	return (w.flags & 0x100u) && w.size[0] && u.dphase && !u.p.timer && !u.p_ramping;
+}
+
+// advance the shadow of wtosc 'u' over default windows from u.shadow_time to 'upto'
+// (a fragment boundary); 'last' = frames of the last of those windows
+void shadow_catch_up(a2amd_ctx *c, HUnit &u, uint64_t upto, unsigned last)
+{
+	if(u.kind != A2AMD_WTOSC || upto <= u.shadow_time)
+		return;
+	const uint64_t F = upto - u.shadow_time;
+	u.shadow_time = upto;
+	if(!(u.shadow_ok && u.shadow_epoch == c->shadow_epoch) || u.mode != A2D_OSC_MIPWAVE || u.wave < 0)
+		return;		// (off: nothing moves; lost shadows stay lost)
+	const A2DWave &w = c->waves[u.wave].dw;
+	if(!w.size[0])
+		return;		// (unloaded: the next real call notices, wtosc.c:168-183)
+	unsigned dph = ((u.dphase + 255) >> 8) * w.period;
+	unsigned mm = 0;
+	for(; (dph > (A2D_MAXPHINC << 8)) && (mm < A2D_MIPS - 1); ++mm)
+		dph >>= 1;
+	dph = (unsigned)(((uint64_t)u.dphase * w.period) >> mm);
+	const uint64_t m = (uint64_t)w.size[mm] << 24;
+	if(last > F)
+		last = (unsigned)F;
+	uint64_t ph = (u.phase >> mm) % m;
+	ph = (ph + (uint64_t)dph * (F - last)) % m;
+	u.phase = (ph + (uint64_t)dph * last) << mm;
+}
+
+// ... for every oscillator of voice 'vi', up to where the walk stands now
+void voice_catch_up(a2amd_ctx *c, int vi)
+{
+	HVoice &v = c->voices[vi];
+	const bool marked = c->frag_open && (size_t)vi < c->defmap.size() && c->defmap[vi];
+	const uint64_t upto = c->walk_time + (marked ? c->fragframes[c->cur_frag] : 0);
+	const unsigned last = marked ? c->fragframes[c->cur_frag] : c->prev_frames;
+	for(int k = 0; k < v.nunits; ++k)
+		shadow_catch_up(c, c->units[v.unit[k]], upto, last);
+}
+
 // the engine-visible walk found no work for the VMs: close the fragment
 int close_fragment(a2amd_ctx *c)
 {
@@ -455,7 +541,13 @@ int close_fragment(a2amd_ctx *c)
 		return 0;
 	const int f = c->cur_frag;
 	const unsigned nframes = c->fragframes[f];
-	(void)nframes;
+	if(c->defmap_used) {
+		size_t n = 0;
+		const size_t nv = std::min(c->defmap.size(), c->voices.size());
+		for(size_t k = 0; k < nv; ++k)
+			n += c->defmap[k];
+		c->walked_started += (int)n;
+	}
 	if(c->walked_started != c->n_started_live) {
 		if(c->hosttiming)
 			dbg_counters()[2] += 1;
@@ -463,8 +555,15 @@ int close_fragment(a2amd_ctx *c)
 		// the kernel would apply the default
 		for(size_t vi = 0; vi < c->voices.size(); ++vi) {
 			HVoice &v = c->voices[vi];
+			if(c->defmap_used && vi < c->defmap.size() && c->defmap[vi])
+				continue;	// (walked: the host marked its default window)
 			if(v.live && v.started && !v.dying && v.walked != c->serial_base + f &&
 					v.touched != c->serial_base + f) {
+				// (its oscillators stand still for this fragment: the shadows are
+				// caught up to its start and skip it)
+				voice_catch_up(c, (int)vi);
+				for(int k = 0; k < v.nunits; ++k)
+					c->units[v.unit[k]].shadow_time = c->walk_time + nframes;
 				A2DRec r = { A2D_HEAD(f, R_NOP, 0, 0), 0, 0, 0 };
 				if(!v.listed_recs) {
 					v.listed_recs = true;
@@ -478,6 +577,9 @@ int close_fragment(a2amd_ctx *c)
 		}
 	}
 	c->frag_open = false;
+	c->walk_time += nframes;
+	c->prev_frames = nframes;
+	c->defmap_used = false;
 	return 0;
 }
 
@@ -1539,6 +1641,16 @@ int a2amd_fragment(a2amd_ctx *c, unsigned frames)
 	c->frag_open = true;
 	c->walked_started = 0;
 	c->building = -1;
+	if(c->defmap_dirty || c->defmap.size() < c->voices.size() + 4096) {
+		// (the map only moves here, at a fragment boundary: the host holds its
+		// address for the length of a fragment)
+		if(c->defmap.size() < c->voices.size() + 4096)
+			c->defmap.assign(c->voices.size() * 2 + 65536, 0);
+		else
+			std::fill(c->defmap.begin(), c->defmap.begin() + std::min(c->defmap.size(), c->voices.size()), 0);
+		c->defmap_dirty = false;
+	}
+	c->defmap_used = false;
 	return A2AMD_OK;
 }
 
@@ -1558,6 +1670,8 @@ int a2amd_fragment_repeat(a2amd_ctx *c, unsigned frames, unsigned count)
 		// every live voice gets the default window: nothing to record, but
 		// tell close_fragment() that nobody was skipped
 		c->frag_open = false;
+		c->walk_time += frames;
+		c->prev_frames = frames;
 	}
 	return A2AMD_OK;
 }
@@ -1681,6 +1795,7 @@ int a2amd_unit_init(a2amd_ctx *c, uint64_t key, int kind, unsigned flags, int ni
 		u.wave = -1;
 		u.shadow_ok = true;
 		u.shadow_epoch = c->shadow_epoch;
+		u.shadow_time = c->walk_time;
 		break;
 	  case A2AMD_FILTER12:	// f12_Initialize -> f12_CutOff(u, 0, 0, 0), filter12.c:141-147,203
 		ramp_init(u.cutoff, 0);
@@ -1779,6 +1894,8 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 	HUnit &u = c->units[ui];
 	c->building = -1;
 	start &= 255;		// a2_VoiceControl, core.c:148
+	if(u.kind == A2AMD_WTOSC)
+		voice_catch_up(c, u.voice);
 	switch(u.kind) {
 	  case A2AMD_WTOSC:
 		switch(reg) {
@@ -2009,6 +2126,11 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 	} else if(v.win_off != (int)offset || v.win_frames != (int)frames)
 		return c->fail(A2AMD_ESTATE, "units of one voice processed over different windows");
 
+	if(u.kind == A2AMD_WTOSC) {
+		// windows the host only marked in the default map come first
+		shadow_catch_up(c, u, c->walk_time, c->prev_frames);
+		u.shadow_time = c->walk_time + offset + frames;
+	}
 	switch(u.kind) {
 	  case A2AMD_WTOSC:
 		if(u.mode == A2D_OSC_NOISE) {
@@ -2069,6 +2191,48 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 			push_rec(c, vi, R_SEG, 0, 0, 0, offset | (frames << 16), 0);
 	}
 	return A2AMD_OK;
+}
+
+int a2amd_voice_process(a2amd_ctx *c, int head, unsigned offset, unsigned frames, uint32_t *noisestate)
+{
+	if(head < 0 || head >= (int)c->units.size() || !c->units[head].live)
+		return c->fail(A2AMD_EINVAL, "process of dead unit %d", head);
+	const int vi = c->units[head].voice;
+	const int n = c->voices[vi].nunits;
+	for(int k = 0; k < n; ++k) {
+		const int ui = c->voices[vi].unit[k];
+		if(c->units[ui].kind == A2AMD_INLINE)
+			return c->fail(A2AMD_EINVAL, "voice_process on a voice with an inline unit");
+		if(int r = a2amd_unit_process(c, ui, offset, frames, noisestate))
+			return r;
+	}
+	// may the host mark this voice in the default map from the next fragment on?
+	const HVoice &v = c->voices[vi];
+	if((size_t)vi >= c->defmap.size())
+		return 0;
+	for(int k = 0; k < n; ++k) {
+		const HUnit &u = c->units[v.unit[k]];
+		if(!shadow_lazy_ok(c, u) || u.xio_mode || (u.kind == A2AMD_FILTER12 && (u.cutoff.timer || u.cutoff.delta)))
+			return 0;
+	}
+	return 1;
+}
+
+int a2amd_voice_slot(a2amd_ctx *c, int ui)
+{
+	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live)
+		return c->fail(A2AMD_EINVAL, "slot of dead unit %d", ui);
+	return c->units[ui].voice;
+}
+
+uint8_t *a2amd_default_map(a2amd_ctx *c, unsigned *nslots)
+{
+	if(!c->frag_open)
+		return nullptr;
+	c->defmap_used = c->defmap_dirty = true;
+	if(nslots)
+		*nslots = (unsigned)c->defmap.size();
+	return c->defmap.data();
 }
 
 int a2amd_unit_clients(a2amd_ctx *c, int ui, unsigned mode)

@@ -23,6 +23,7 @@
 struct WaveLDS {
 	int scratch[A2D_MAXCH][A2D_FRAG];	// the voice's scratch bus (core.c:365-395)
 	int otile[A2D_MAXCH][A2D_FRAG];		// pending adds into the output bus
+	int ftmp[2][A2D_FRAG];			// filter12: the recurrence's results, before they are wired out
 	int us[A2D_MAXCHAIN][A2D_USTATE];	// unit states of the current voice
 	int cursor[A2D_MAXVPW];			// next unread record of each of our voices
 };
@@ -383,30 +384,51 @@ DEV void f12_process(Ctx &c, uint32_t desc, int *w, int offset, int frames)
 		df = wadd(wsub(f1, f0), frames >> 1) / frames;
 	}
 	if(c.lane < channels) {
+		// the recurrence, one lane per channel.  Sixteen frames at a time: sixteen
+		// inputs fetched together, sixteen steps in registers, sixteen results
+		// stored - with one LDS read and a read-modify-write per step on the
+		// chain, the LDS latency was most of a filtered voice's fragment.
 		int ch = c.lane;
 		int d1 = w[FW_D1A + ch], d2 = w[FW_D2A + ch];
 		int qv = q.value;
-		for(int s = offset; s < offset + frames; ++s) {
-			int f = f0 >> 12;
-			int qq = qv >> 12;
-			int d1s = d1 >> 4;
-			int l = wadd(d2, wmul(f, d1s) >> 8);
-			int h = wsub(wsub(c.l->scratch[ch][s] >> 5, l), wmul(qq, d1s) >> 8);
-			int b = wadd(wmul(f, h >> 4) >> 8, d1);
-			int fout = wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3;
-			if(A2D_WIRED(desc))
-				c.l->otile[ch][s] = wadd(c.l->otile[ch][s], fout);
-			else if(A2D_ADD(desc))
-				c.l->scratch[ch][s] = wadd(c.l->scratch[ch][s], fout);
-			else
-				c.l->scratch[ch][s] = fout;
-			d1 = b;
-			d2 = l;
-			f0 = wadd(f0, df);
-			qv = wadd(qv, q.delta);
+		const int *in = c.l->scratch[ch];
+		int *out = c.l->ftmp[ch];
+		for(int s0 = offset; s0 < offset + frames; s0 += 16) {
+			int x[16];
+			const int nn = min(16, offset + frames - s0);
+#pragma unroll
+			for(int k = 0; k < 16; ++k)
+				x[k] = in[min(s0 + k, A2D_FRAG - 1)];
+#pragma unroll
+			for(int k = 0; k < 16; ++k)
+				if(k < nn) {
+					int f = f0 >> 12;
+					int qq = qv >> 12;
+					int d1s = d1 >> 4;
+					int l = wadd(d2, wmul(f, d1s) >> 8);
+					int h = wsub(wsub(x[k] >> 5, l), wmul(qq, d1s) >> 8);
+					int b = wadd(wmul(f, h >> 4) >> 8, d1);
+					x[k] = wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3;
+					d1 = b;
+					d2 = l;
+					f0 = wadd(f0, df);
+					qv = wadd(qv, q.delta);
+				}
+#pragma unroll
+			for(int k = 0; k < 16; ++k)
+				if(k < nn)
+					out[s0 + k] = x[k];
 		}
 		w[FW_D1A + ch] = d1;
 		w[FW_D2A + ch] = d2;
+	}
+	lds_sync();
+	// ... and every lane puts its frame's result where the unit's wiring says
+	{
+		const int k = c.lane - offset;
+		if(k >= 0 && k < frames)
+			for(int ch = 0; ch < channels; ++ch)
+				emit(c, desc, ch, c.l->ftmp[ch][c.lane]);
 	}
 	ramp_run(q, frames);
 	lds_sync();
@@ -1009,6 +1031,12 @@ void k_voices(const A2DParams *__restrict__ pp, const int *__restrict__ list, in
 		c.l->cursor[lane] = 0;
 	lds_sync();
 
+	// One voice per wavefront (the usual shape below a few thousand voices): its unit
+	// states, its record cursor and its liveness stay in LDS / registers for the whole
+	// batch instead of travelling to memory and back for every fragment - on a
+	// plumbing-sized scene (a song: a few dozen voices, four nesting levels) those
+	// round trips were most of a fragment's time.
+	const bool resident = last - first == 1;
 	for(int f = 0; f < p.nfrags; ++f) {
 		const int nframes = p.fragframes[f];
 		int cur_off = -1, cur_nch = 0;
@@ -1025,11 +1053,13 @@ void k_voices(const A2DParams *__restrict__ pp, const int *__restrict__ list, in
 			c.own_off = v.own_off;
 			c.own_nch = v.own_nch;
 			// unit states -> LDS
-			for(int u = 0; u < v.nunits; ++u)
-				if(lane < A2D_USTATE)
-					c.l->us[u][lane] = p.ustate[(size_t)v.unit[u] * A2D_USTATE + lane];
-			lds_sync();
-			int active = p.vactive[slot];
+			if(!resident || f == 0) {
+				for(int u = 0; u < v.nunits; ++u)
+					if(lane < A2D_USTATE)
+						c.l->us[u][lane] = p.ustate[(size_t)v.unit[u] * A2D_USTATE + lane];
+				lds_sync();
+			}
+			int active = (!resident || f == 0) ? p.vactive[slot] : c.l->cursor[A2D_MAXVPW - 1];
 
 			// records of this fragment: the run is sorted by fragment;
 			// skip what earlier fragments consumed
@@ -1083,12 +1113,17 @@ void k_voices(const A2DParams *__restrict__ pp, const int *__restrict__ list, in
 			}
 			// unit states -> memory
 			lds_sync();
-			for(int u = 0; u < v.nunits; ++u)
-				if(lane < A2D_USTATE)
-					p.ustate[(size_t)v.unit[u] * A2D_USTATE + lane] = c.l->us[u][lane];
+			if(!resident || f == p.nfrags - 1) {
+				for(int u = 0; u < v.nunits; ++u)
+					if(lane < A2D_USTATE)
+						p.ustate[(size_t)v.unit[u] * A2D_USTATE + lane] = c.l->us[u][lane];
+				if(lane == 0)
+					p.vactive[slot] = active;
+			}
 			if(lane == 0) {
-				p.vactive[slot] = active;
 				c.l->cursor[vi - first] = r0 - run.first;
+				if(resident)
+					c.l->cursor[A2D_MAXVPW - 1] = active;	// (a one-voice wavefront uses cursor[0] only)
 			}
 			lds_sync();
 		}

@@ -67,6 +67,11 @@ typedef struct HOSTSTATE
 	int		failed;		/* the backend reported an error: this state renders silence from here on */
 	int		depth;		/* open inline windows */
 	unsigned	base;		/* engine offset of the current root window */
+	unsigned	win_frames;	/* ... and its length = the open backend fragment */
+	uint8_t		*map;		/* the backend's default map for that fragment (a2amd_default_map) */
+	unsigned	map_cap;
+	int		noise_oscs;	/* oscillators playing the noise wave: their voices need the engine's RNG */
+	int		no_quick;	/* A2AMD_NO_QUICK=1: every Process call is forwarded (A/B measurements) */
 	A2P_vmstate	*root_vms;	/* the root voice (first voice of a state) */
 	A2P_vmstate	*chain_vms;	/* voice whose chain is being populated */
 	A2P_unit	*chain_last;
@@ -117,7 +122,10 @@ typedef struct XTRA
 	unsigned	client_mode;	/* xinsert / xsink / xsource: A2AMD_XIO_*, what its clients need */
 	int		is_root;
 	A2P_process_cb	orig_process;
-	A2P_wave	*wave;		/* wtosc: the wave it plays (engine object), or NULL */
+	int		is_noise;	/* wtosc: it plays the noise wave (set by its 'w' write) */
+	int		is_head;	/* first forwarded unit of its voice */
+	int		slot;		/* head: the voice's slot in the backend's default map */
+	A2P_unit	*head;		/* the voice's head unit, once its chain was found to be all ours */
 	int		chain_checked;	/* the units behind us in the voice have been looked at */
 	int		refused;	/* an unsupported client was reported once */
 	void		(*orig_setprocess)(A2P_unit *u);	/* root xinsert: the engine's xi_SetProcess */
@@ -267,6 +275,7 @@ static a2amd_ctx *ctx_of(HOSTSTATE *hs)
 		if(c.max_batch > 256)
 			c.max_batch = 256;
 		hs->max_batch = c.max_batch;
+		hs->no_quick = getenv("A2AMD_NO_QUICK") != NULL;
 		if((rc = a2amd_open(&c, &hs->ctx)))
 		{
 			hs->ctx = NULL;
@@ -321,6 +330,7 @@ static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned 
 	}
 	if(forward)
 	{
+		x->is_head = !hs->chain_last && !x->is_root;
 		x->uid = a2amd_unit_init(ctx, (uint64_t)(uintptr_t)vms, kind, lflags, u->ninputs,
 				u->noutputs, wired, vms->r[A2P_R_TRANSPOSE], vms->waketime & 0xff);
 		if(x->uid < 0)
@@ -342,6 +352,8 @@ static void amd_deinit(A2P_unit *u)
 		return;
 	if(x->hs->chain_last == u)
 		x->hs->chain_last = NULL;
+	x->hs->noise_oscs -= x->is_noise;
+	x->is_noise = 0;
 	if(x->uid >= 0 && !x->hs->failed && (rc = a2amd_unit_deinit(x->hs->ctx, x->uid)))
 		fail(x->hs, "a2amd_unit_deinit", rc);
 }
@@ -373,15 +385,6 @@ static void sweep_waves(HOSTSTATE *hs)
 		else
 			++i;
 	}
-}
-
-/* ... and an oscillator playing such a wave forgets it like wtosc_check_unloaded */
-static void check_unloaded(XTRA *x)
-{
-	A2P_wave *w = x->wave;
-	if(!w || (w->type != A2AMD_WWAVE && w->type != A2AMD_WMIPWAVE) || w->size[0])
-		return;
-	x->wave = NULL;
 }
 
 /* Units of the engine (or of the application, a2_RegisterUnit) that are NOT
@@ -770,10 +773,7 @@ static void forward_process(XTRA *x, unsigned offset, unsigned frames)
 	if(hs->failed)
 		return;
 	if(x->kind == A2AMD_WTOSC)
-	{
-		check_unloaded(x);
-		is_noise = x->wave && x->wave->type == A2AMD_WNOISE;
-	}
+		is_noise = x->is_noise;
 	if(is_noise)
 	{
 		/* the engine-global RNG the noise oscillators share with the VM's
@@ -786,6 +786,91 @@ static void forward_process(XTRA *x, unsigned offset, unsigned frames)
 		fail(hs, "a2amd_unit_process", rc);
 	if(noise != before)
 		a2_SetStateProperty(hs->cfg->interface, A2P_PNOISESEED, (int)noise);
+}
+
+/* ---- the walk's hot path ---------------------------------------------------------------
+ * a2_VoiceProcess calls every unit of every voice once per window (core.c:1875-1876);
+ * with tens of thousands of voices whose VMs sleep, that call - and the memory it
+ * touches - is all the engine thread does.  For a voice whose chain consists of
+ * replaced units only ("simple": no inline, no x-units, no unit of the engine's or the
+ * application's in between), the first unit's Process speaks for the whole chain
+ * (a2amd_voice_process) and the others' are empty; once the backend agrees that the
+ * voice is at rest (no noise, no ramping pitch or cutoff), the first unit's Process
+ * shrinks to one byte store into the backend's default map per fragment
+ * (amd_quick_process) until a register of the voice is written again. */
+static void amd_head_process(A2P_unit *u, unsigned offset, unsigned frames);
+
+static void amd_noop(A2P_unit *u, unsigned offset, unsigned frames)
+{
+}
+
+static void amd_quick_process(A2P_unit *u, unsigned offset, unsigned frames)
+{
+	XTRA *x = (XTRA *)((char *)u + 64);	/* (own units only: no descriptor look-up) */
+	HOSTSTATE *hs = x->hs;
+	if(offset == hs->base && frames == hs->win_frames && (unsigned)x->slot < hs->map_cap)
+	{
+		hs->map[x->slot] = 1;	/* Process(0, all frames) on each unit: the default */
+		return;
+	}
+	u->Process = amd_head_process;
+	amd_head_process(u, offset, frames);
+}
+
+static void amd_head_process(A2P_unit *u, unsigned offset, unsigned frames)
+{
+	XTRA *x = (XTRA *)((char *)u + 64);
+	HOSTSTATE *hs = x->hs;
+	uint32_t noise = 0, before = 0;
+	int rc, v = 0;
+	if(hs->failed)
+		return;
+	if(hs->noise_oscs)
+	{
+		/* (the engine-global RNG of the noise oscillators, internals.h:682; only
+		 * while some oscillator of this state plays the noise wave) */
+		a2_GetStateProperty(hs->cfg->interface, A2P_PNOISESEED, &v);
+		noise = before = (uint32_t)v;
+	}
+	rc = a2amd_voice_process(hs->ctx, x->uid, offset - hs->base, frames, hs->noise_oscs ? &noise : NULL);
+	if(rc < 0)
+		fail(hs, "a2amd_voice_process", rc);
+	else if(rc == 1 && !hs->no_quick)
+		u->Process = amd_quick_process;
+	if(noise != before)
+		a2_SetStateProperty(hs->cfg->interface, A2P_PNOISESEED, (int)noise);
+}
+
+/* is the voice 'u' heads made of our own plain units only?  then wire it up */
+static int setup_simple_chain(A2P_unit *u)
+{
+	static const A2P_unitdesc *const plain[] = {
+		&a2_wtosc_unitdesc, &a2_panmix_unitdesc, &a2_filter12_unitdesc, &a2_fbdelay_unitdesc,
+		&a2_fm1_unitdesc, &a2_fm2_unitdesc, &a2_fm3_unitdesc, &a2_fm4_unitdesc, &a2_fm3p_unitdesc,
+		&a2_fm4p_unitdesc, &a2_fm2r_unitdesc, &a2_fm4r_unitdesc, &a2_dc_unitdesc,
+		&a2_waveshaper_unitdesc, &a2_dcblock_unitdesc, &a2_limiter_unitdesc };
+	XTRA *x = xtra(u);
+	A2P_unit *n;
+	unsigned i;
+	int slot;
+	for(n = u; n; n = n->next)
+	{
+		for(i = 0; i < sizeof(plain) / sizeof(plain[0]); ++i)
+			if(n->descriptor == plain[i])
+				break;
+		if(i == sizeof(plain) / sizeof(plain[0]) || xtra(n)->uid < 0)
+			return 0;
+	}
+	if((slot = a2amd_voice_slot(x->hs->ctx, x->uid)) < 0)
+		return 0;
+	x->slot = slot;
+	for(n = u; n; n = n->next)
+	{
+		xtra(n)->head = u;
+		xtra(n)->chain_checked = 1;
+		n->Process = n == u ? amd_head_process : amd_noop;
+	}
+	return 1;
 }
 
 static int null_walk = -1;	/* A2AMD_NULLWALK=1 (measurement only): leaf units record nothing - the engine's bare walk */
@@ -807,6 +892,11 @@ static void amd_process(A2P_unit *u, unsigned offset, unsigned frames)
 	{
 		x->chain_checked = 1;
 		check_chain_behind(u);
+		if(x->is_head && setup_simple_chain(u))
+		{
+			amd_head_process(u, offset, frames);
+			return;
+		}
 	}
 	forward_process(x, offset, frames);
 	if(x->is_root && x->kind == A2AMD_PANMIX && !hs->batching)
@@ -858,6 +948,10 @@ static void amd_inline_process(A2P_unit *u, unsigned offset, unsigned frames)
 			fail(hs, "a2amd_fragment", rc);
 		++hs->batch_frags;
 		hs->base = offset;
+		hs->win_frames = frames;
+		hs->map = hs->failed ? NULL : a2amd_default_map(hs->ctx, &hs->map_cap);
+		if(!hs->map)
+			hs->map_cap = 0;
 		hs->win_pos = hs->rec_pos;
 		hs->rec_pos += frames;
 	}
@@ -998,9 +1092,15 @@ static void amd_write(A2P_unit *u, int reg, int v, unsigned start, unsigned dur)
 	int rc;
 	if(x->kind == A2AMD_WTOSC && reg == 0)		/* wtosc_Wave, wtosc.c:433-440 */
 	{
-		x->wave = a2_GetWave(x->hs->cfg->interface, v >> 16);
-		v = wave_id_of(x->hs, x->wave);
+		A2P_wave *w = a2_GetWave(x->hs->cfg->interface, v >> 16);
+		const int noise = w && w->type == A2AMD_WNOISE;
+		x->hs->noise_oscs += noise - x->is_noise;
+		x->is_noise = noise;
+		v = wave_id_of(x->hs, w);
 	}
+	/* (a voice that was reporting its default windows through the map calls in again) */
+	if(x->head && x->head->Process == amd_quick_process)
+		x->head->Process = amd_head_process;
 	if(x->hs->failed)
 		return;
 	if((rc = a2amd_unit_write(x->hs->ctx, x->uid, reg, v, start, dur, x->vms->r[A2P_R_TRANSPOSE])))

@@ -188,6 +188,24 @@ int  a2amd_unit_write(a2amd_ctx *ctx, int unit, int reg, int value,
  * correctly. */
 int  a2amd_unit_process(a2amd_ctx *ctx, int unit, unsigned offset,
 		unsigned frames, uint32_t *noisestate);
+/* The voice walk's hot path (a2_VoiceProcess, src/core.c:1875-1876: one Process call
+ * per unit and window).  a2amd_voice_process() = a2amd_unit_process() on every unit
+ * of the voice 'head_unit' belongs to, in chain order, for one window (voices
+ * without an inline unit).  It returns 1 when, from the next fragment on, the host
+ * may report this voice's DEFAULT window - Process(0, all frames of the fragment)
+ * on each unit and nothing else: what a voice whose VM sleeps gets - by storing 1 at
+ * a2amd_default_map()[a2amd_voice_slot()] instead of calling anything: one byte
+ * store per voice and fragment, which is what lets one engine thread walk tens of
+ * thousands of sleeping voices.  (0: keep calling - a noise oscillator, a ramping
+ * pitch or cutoff, clients.)  Any unit_write / unit_deinit on the voice ends the
+ * permission until voice_process() grants it again; a mark followed by such a call
+ * in the same fragment is handled (the window is recorded first).  The map's
+ * address is valid for the open fragment only: ask once per fragment. */
+int  a2amd_voice_process(a2amd_ctx *ctx, int head_unit, unsigned offset, unsigned frames,
+		uint32_t *noisestate);
+int  a2amd_voice_slot(a2amd_ctx *ctx, int unit);
+uint8_t *a2amd_default_map(a2amd_ctx *ctx, unsigned *nslots);
+
 /* Clients of an A2AMD_XINSERT / A2AMD_XSINK / A2AMD_XSOURCE unit
  * (a2_XinsertAddClient, src/xinsertapi.c:72-111; served by xi_process,
  * src/units/xinsert.c:60-142, xsink_Process, xsink.c:27-46, xsrc_process,
