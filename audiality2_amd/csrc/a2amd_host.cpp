@@ -14,6 +14,8 @@
 // collects (core.c:479-480, inline.c:32-33), so all children of all parents can
 // run first and each parent picks the sum up where its inline unit sits.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>		// (types only: the library is bound at run time, a2amd_dist_init)
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -29,6 +31,43 @@
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
+
+namespace {
+struct Rccl {
+	void *lib = nullptr;
+	ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+	const char *(*GetErrorString)(ncclResult_t) = nullptr;
+} g_rccl;
+
+// RCCL is bound on first use: the copy the process already has (a host application
+// that brought its own, e.g. PyTorch's) if there is one - two copies in one process
+// would each run their own proxy threads and topology detection - else ROCm's
+bool rccl_bind()
+{
+	if(g_rccl.Reduce)
+		return true;
+	const char *names[] = { "librccl.so.1", "librccl.so" };
+	void *h = nullptr;
+	for(const char *n : names)
+		if(!h)
+			h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+	for(const char *n : names)
+		if(!h)
+			h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+	if(!h)
+		return false;
+	g_rccl.lib = h;
+	*(void **)&g_rccl.GetUniqueId = dlsym(h, "ncclGetUniqueId");
+	*(void **)&g_rccl.CommInitRank = dlsym(h, "ncclCommInitRank");
+	*(void **)&g_rccl.CommDestroy = dlsym(h, "ncclCommDestroy");
+	*(void **)&g_rccl.GetErrorString = dlsym(h, "ncclGetErrorString");
+	*(void **)&g_rccl.Reduce = dlsym(h, "ncclReduce");
+	return g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.Reduce;
+}
+} // namespace
 
 namespace {
 
@@ -344,6 +383,12 @@ struct a2amd_ctx {
 		uint8_t frames[A2D_MAXBATCH];
 	} rb[2];
 	int rb_head = 0, rb_count = 0;
+
+	// multi-GPU: this context renders the voice subtrees it was given; the root
+	// voice's inline bus is summed over the ranks' contexts by one RCCL reduce per
+	// batch, the root chain runs on rank 0 (a2amd_dist_init)
+	ncclComm_t comm = nullptr;
+	int dist_rank = 0, dist_ranks = 1;
 
 	a2amd_stats stats;
 
@@ -1487,6 +1532,8 @@ void a2amd_close(a2amd_ctx *c)
 	use_device(c);
 	hipStreamSynchronize(c->stream);
 	drop_graphs(c);
+	if(c->comm && g_rccl.CommDestroy)
+		g_rccl.CommDestroy(c->comm);
 	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
 	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
 	hipFree(c->d_waves.d); hipFree(c->d_wavepool.d); hipFree(c->d_wavecoef.d); hipFree(c->d_busmem.d);
@@ -2328,6 +2375,7 @@ struct TimingDump { ~TimingDump() { if(getenv("A2AMD_HOSTTIMING") && g_n) fprint
 	g_t[0] / g_n, g_t[1] / g_n, g_t[2] / g_n, g_n, g_cnt[0], g_cnt[5], g_cnt[1], g_cnt[4], g_cnt[2], g_cnt[3]); } } g_timing_dump;
 
 namespace { double *dbg_counters() { return g_cnt; } }
+static int dist_reduce_root(a2amd_ctx *c);
 
 int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned cap)
 {
@@ -2371,42 +2419,65 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 	// A record-free batch that has been seen before runs from a graph - one launch
 	// instead of 3-5 separate commands: a kept batch re-run phase by phase
 	// (multi-GPU steps), or the engine recording the same quiet batch again.
-	const unsigned kphases = phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT);
-	bool issued = false;
-	if(kphases && c->uploaded && !c->profiling && c->stream && c->with_recs.empty() && !getenv("A2AMD_NO_GRAPH") &&
-			((phases & A2AMD_RENDER_KEEP) ? kphases == (phases & ~A2AMD_RENDER_KEEP) : c->quiet_streak >= 1)) {
-		const int slot = kphases == A2AMD_RENDER_SUBTREES ? 2 : kphases == A2AMD_RENDER_ROOT ? 3 : 1;
-		if(c->gexec[slot] || !build_graph(c, slot, 1, kphases)) {
-			if(slot != 3)
-				if(int r = ensure_clean(c))
-					return r;
-			HIPCHK(c, hipGraphLaunch(c->gexec[slot], c->stream));
-			if(c->hosttiming)
-				dbg_counters()[5] += 1;
-			if(slot == 1)
-				c->others_clean = c->root_clean = c->consume_ok;
-			else if(slot == 2) {
-				c->others_clean = c->consume_ok;
-				c->root_clean = false;
-			} else if(c->consume_ok)
-				c->root_clean = true;
-			if(kphases & A2AMD_RENDER_ROOT) {
-				c->stats.fragments += c->nfrags;
-				c->stats.voice_fragments += (uint64_t)c->nfrags * (c->list_all.size() - c->n_list_pads);
+	auto run_phases = [&](unsigned kphases) -> int {
+		if(!kphases)
+			return 0;
+		if(c->uploaded && !c->profiling && c->stream && c->with_recs.empty() && !getenv("A2AMD_NO_GRAPH") &&
+				((phases & A2AMD_RENDER_KEEP) ? (phases & ~A2AMD_RENDER_KEEP) ==
+				 (phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT)) : c->quiet_streak >= 1)) {
+			const int slot = kphases == A2AMD_RENDER_SUBTREES ? 2 : kphases == A2AMD_RENDER_ROOT ? 3 : 1;
+			if(c->gexec[slot] || !build_graph(c, slot, 1, kphases)) {
+				if(slot != 3)
+					if(int r = ensure_clean(c))
+						return r;
+				HIPCHK(c, hipGraphLaunch(c->gexec[slot], c->stream));
+				if(c->hosttiming)
+					dbg_counters()[5] += 1;
+				if(slot == 1)
+					c->others_clean = c->root_clean = c->consume_ok;
+				else if(slot == 2) {
+					c->others_clean = c->consume_ok;
+					c->root_clean = false;
+				} else if(c->consume_ok)
+					c->root_clean = true;
+				if(kphases & A2AMD_RENDER_ROOT) {
+					c->stats.fragments += c->nfrags;
+					c->stats.voice_fragments += (uint64_t)c->nfrags * (c->list_all.size() - c->n_list_pads);
+				}
+				return 0;
 			}
-			issued = true;
 		}
-	}
-	// Events only when profiling (each one from the pool, used once until read):
-	// re-recording an event the GPU has not reached yet makes the runtime wait.
-	if(kphases && !issued)
-		if(int r = c->profiling ? issue_kernels(c, phases, c->ev0, c->ev1, c->ev2) :
-				issue_kernels(c, phases, nullptr, nullptr, nullptr))
+		// Events only when profiling (each one from the pool, used once until read):
+		// re-recording an event the GPU has not reached yet makes the runtime wait.
+		const bool sub = (kphases & A2AMD_RENDER_SUBTREES) != 0, root = (kphases & A2AMD_RENDER_ROOT) != 0;
+		return c->profiling ? issue_kernels(c, kphases | (phases & A2AMD_RENDER_KEEP), sub ? c->ev0 : nullptr,
+				sub ? c->ev1 : nullptr, root ? c->ev2 : nullptr) :
+				issue_kernels(c, kphases | (phases & A2AMD_RENDER_KEEP), nullptr, nullptr, nullptr);
+	};
+	const unsigned kphases = phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT);
+	if(c->comm && kphases == (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT)) {
+		// multi-GPU batch: every rank its subtrees, ONE reduce of the root voice's
+		// inline bus over xGMI, the root chain on rank 0 (its panmix must see the
+		// sum: the multiply truncates)
+		if(int r = run_phases(A2AMD_RENDER_SUBTREES))
 			return r;
+		if(int r = dist_reduce_root(c))
+			return r;
+		if(c->dist_rank == 0)
+			if(int r = run_phases(A2AMD_RENDER_ROOT))
+				return r;
+	} else if(int r = run_phases(kphases))
+		return r;
 	double t2 = timing ? now_us() : 0;
 	if(timing) {
 		g_t[1] += t2 - t1;
 		g_n += 1;
+	}
+	if((phases & A2AMD_RENDER_READBACK) && c->comm && c->dist_rank != 0) {
+		// (the master bus exists on rank 0 only)
+		if(!(phases & A2AMD_RENDER_KEEP))
+			end_batch(c);
+		return (int)total;
 	}
 	if(phases & A2AMD_RENDER_READBACK) {
 		const int nch = c->cfg.channels;
@@ -2559,6 +2630,66 @@ int a2amd_replay(a2amd_ctx *c, unsigned steps)
 				return r;
 			--steps;
 		}
+	}
+	return A2AMD_OK;
+}
+
+// ---- multi-GPU: RCCL over xGMI, called from here (no framework in the data path) -------
+int a2amd_dist_unique_id(void *id128)
+{
+	if(!id128 || !rccl_bind()) {
+		snprintf(g_err, sizeof(g_err), "a2amd_dist_unique_id: RCCL (librccl.so) is not available");
+		return A2AMD_ENODEVICE;
+	}
+	static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId");
+	ncclResult_t r = g_rccl.GetUniqueId((ncclUniqueId *)id128);
+	if(r != ncclSuccess) {
+		snprintf(g_err, sizeof(g_err), "ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "failed");
+		return A2AMD_EHIP;
+	}
+	return A2AMD_OK;
+}
+
+int a2amd_dist_init(a2amd_ctx *c, const void *id128, int rank, int nranks)
+{
+	use_device(c);
+	if(!id128 || rank < 0 || rank >= nranks)
+		return c->fail(A2AMD_EINVAL, "dist_init: rank %d of %d", rank, nranks);
+	if(c->comm)
+		return c->fail(A2AMD_ESTATE, "dist_init: already initialised");
+	if(!rccl_bind())
+		return c->fail(A2AMD_ENODEVICE, "dist_init: RCCL (librccl.so) is not available");
+	ncclUniqueId id;
+	memcpy(&id, id128, sizeof(id));
+	ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+	if(r != ncclSuccess) {
+		c->comm = nullptr;
+		return c->fail(A2AMD_EHIP, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "failed");
+	}
+	c->dist_rank = rank;
+	c->dist_ranks = nranks;
+	drop_graphs(c);
+	c->blob_quiet = false;
+	return A2AMD_OK;
+}
+
+int a2amd_rootbus(a2amd_ctx *c, void **devptr, uint64_t *bytes);
+
+// the exchange step of a batch: sum the ranks' partials of the root voice's inline bus
+// into rank 0's (int32 wrap-around sum: any order gives the same bits)
+static int dist_reduce_root(a2amd_ctx *c)
+{
+	void *bus;
+	uint64_t bytes;
+	if(int r = a2amd_rootbus(c, &bus, &bytes))
+		return r;
+	ncclResult_t r = g_rccl.Reduce(bus, bus, bytes / 4, ncclInt32, ncclSum, 0, c->comm, c->stream);
+	if(r != ncclSuccess)
+		return c->fail(A2AMD_EHIP, "ncclReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "failed");
+	if(c->dist_rank != 0) {
+		// our partial has been delivered: the bus starts the next batch empty
+		HIPCHK(c, hipMemsetAsync(bus, 0, bytes, c->stream));
+		c->root_clean = true;
 	}
 	return A2AMD_OK;
 }

@@ -206,8 +206,9 @@ def pmc_entry(chain, voices, groups, B):
 class Runner:
     """One config on one GPU through the product entry points."""
 
-    def __init__(self, audiality2_amd, voices, chain, groups, B, device=0):
+    def __init__(self, audiality2_amd, voices, chain, groups, B, device=0, world=1, rank=0):
         self.voices, self.chain, self.groups, self.B = voices, chain, groups, B
+        self.rank = rank
         self.be = audiality2_amd.open_backend(48000, None, 2, device=device, max_batch=B)
         lib = self.lib = self.be.lib
         lib.a2amd_fragment_repeat.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
@@ -223,7 +224,7 @@ class Runner:
             for c in range(2):
                 p[c] = b[c].ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
             self.ptrs.append(p)
-        self.sc = build_scene(self.be, voices, chain, groups)
+        self.sc = build_scene(self.be, voices, chain, groups, world, rank)
         self.step_no = 0            # steps issued
         self.got = 0                # steps collected
         self.kept = {}              # step -> audio (the steps the golden covers, and the last one)
@@ -247,6 +248,10 @@ class Runner:
 
     def collect(self):
         k = self.got & 1
+        if self.rank != 0:          # (multi-GPU: the audio comes out on rank 0)
+            self.got += 1
+            self.last = self.bufs[k]
+            return
         if self.lib.a2amd_collect(self.be.ctx, self.ptrs[k], self.frames) != self.frames:
             raise self.err()
         if self.got < self.keep_upto:
@@ -488,52 +493,28 @@ def main():
         return
 
     # ------------------------------------------------------------------ N > 1
-    from audiality2_amd import shard
+    # One process per GPU.  Every rank builds its own subtrees under its own copy of the
+    # root voice and runs the SAME product loop as N = 1; inside a2amd_render() the
+    # ranks' root-bus partials are summed by one ncclReduce (RCCL over xGMI, called from
+    # liba2amd on the render stream) and rank 0 runs the root chain and gets the audio.
+    # torch.distributed only carries the 128 byte RCCL id to the other ranks and the
+    # timing barriers the bench contract asks for.
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     dist.init_process_group("nccl", rank=rank, world_size=world,
                             device_id=torch.device("cuda", local_rank))
-    # everything (kernels and the RCCL reduce) is ordered on one torch stream
-    tstream = torch.cuda.Stream(device=local_rank)
-    torch.cuda.set_stream(tstream)
-    be = audiality2_amd.open_backend(48000, None, 2, device=local_rank, max_batch=B,
-                                     stream=tstream.cuda_stream)
-    lib = be.lib
-    lib.a2amd_fragment_repeat.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
-    lib.a2amd_get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
-    lib.a2amd_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    lib.a2amd_rootbus.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
-    lib.a2amd_rootbus_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-    sc = build_scene(be, cfg["voices"], cfg["chain"], cfg["groups"], world, rank)
-
-    def repeat(n):
-        if lib.a2amd_fragment_repeat(be.ctx, 64, n):
-            raise RuntimeError(be._err(be.ctx))
-
-    sc.walk(64)
-    repeat(B - 1)
-    be.render(B * 64)
-    # steady state: record once, upload once, re-run phase by phase
-    repeat(B)
-    be.render(0, phases=UP | KEEP)
-    ptr, nbytes = ctypes.c_void_p(), ctypes.c_uint64()
-    if lib.a2amd_rootbus(be.ctx, ctypes.byref(ptr), ctypes.byref(nbytes)):
-        raise RuntimeError(be._err(be.ctx))
-    rootbus = shard.wrap_device_bus(ptr.value, nbytes.value, torch.device("cuda", local_rank))
-    render = be._render                 # (the raw entry point: no output arrays in the step loop)
-
-    def phase(ph):
-        if render(be.ctx, ph | KEEP, None, 0) < 0:
-            raise RuntimeError(be._err(be.ctx))
-
-    def copy_fn(p, to_stage):
-        if lib.a2amd_rootbus_copy(be.ctx, p, to_stage):
-            raise RuntimeError(be._err(be.ctx))
-
-    # the root-bus sums of `--reduce-group` steps travel in one collective that
-    # overlaps the next group's subtree kernels (audiality2_amd/shard.py)
-    pipe = shard.GroupedRootReduce(rootbus, lambda: phase(SUB), lambda: phase(ROOTP), rank,
-                                   group=args.reduce_group, copy_fn=copy_fn)
+    r = Runner(audiality2_amd, cfg["voices"], cfg["chain"], cfg["groups"], B, local_rank, world=world, rank=rank)
+    lib = r.lib
+    lib.a2amd_dist_unique_id.argtypes = [ctypes.c_void_p]
+    lib.a2amd_dist_init.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    idbuf = (ctypes.c_uint8 * 128)()
+    if rank == 0 and lib.a2amd_dist_unique_id(idbuf):
+        raise r.err()
+    idt = torch.tensor(list(idbuf), dtype=torch.uint8, device=torch.device("cuda", local_rank))
+    dist.broadcast(idt, src=0)
+    idbuf = (ctypes.c_uint8 * 128)(*idt.cpu().tolist())
+    if lib.a2amd_dist_init(r.be.ctx, idbuf, rank, world):
+        raise r.err()
     # barrier = a (pre-warmed) 1-element all-reduce every rank must join, with the
     # device idle on both sides; dist.barrier() itself costs tens of ms on first use
     token = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", local_rank))
@@ -543,41 +524,29 @@ def main():
         dist.all_reduce(token)
         torch.cuda.synchronize()
 
-    fence()                 # first use builds the RCCL communicator: keep it out of the timing
-    pipe.run(args.warmup)
+    fence()
+    r.run(1)                # step 0: voices are born (the first reduce builds RCCL's channels)
+    r.run(args.warmup)
     fence()
     fence()
     import gc
     gc.collect()
     gc.disable()
     t0 = time.perf_counter()
-    pipe.run(args.steps)
+    r.run(args.steps)
     fence()
     dt = time.perf_counter() - t0
     gc.enable()
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-
-    nprof = min(args.steps, 32)
-    lib.a2amd_set_profiling(be.ctx, 1)
-    for _ in range(nprof):      # one step at a time, so that every step's events pair up
-        be.render(0, phases=SUB | KEEP)
-        shard.reduce_root_bus(rootbus, dst=0)
-        if rank == 0:
-            be.render(0, phases=ROOTP | KEEP)
-    st = Stats()
-    lib.a2amd_get_stats(be.ctx, ctypes.byref(st))
-    lib.a2amd_set_profiling(be.ctx, 0)
-    last = be.render(B * 64, phases=RB) if rank == 0 else None
-    if rank != 0:
-        be.render(0, phases=ROOTP)      # close the batch on the other ranks
+    leaf_ms, all_ms, nprof = r.profile(min(args.steps, 16))
+    last = r.last
     line = None
     if rank == 0:
         value = float(cfg["voices"]) * world * B * 64 * args.steps / dt
         res = {"chain": cfg["chain"], "voices": cfg["voices"], "groups": cfg["groups"],
-               "leaf_ms": st.timed_leaf_ms / max(st.timed_batches, 1),
-               "all_ms": st.timed_all_ms / max(st.timed_batches, 1), "launches_timed": int(st.timed_batches)}
+               "leaf_ms": leaf_ms, "all_ms": all_ms, "launches_timed": nprof}
         roof, valu = roofline_objects(res, B)
         line = {
             "metric": "voice-samples/sec (measured realtime figure reported alongside)",
@@ -586,13 +555,18 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": cfg["label"] + f" per GPU x {world}", "voices_per_gpu": cfg["voices"],
                        "chain": cfg["chain"], "groups": cfg["groups"], "fragments_per_step": B, "samplerate": 48000,
-                       "sharding": "voice subtrees per GPU + 1 RCCL int32 reduce of the root bus per "
-                                   f"{args.reduce_group} steps, root chain on rank 0"},
+                       "sharding": "voice subtrees per GPU; per step ONE ncclReduce(int32, sum) of the root voice's "
+                                   "inline bus over xGMI inside a2amd_render (RCCL called from liba2amd), root "
+                                   "chain + audio delivery on rank 0",
+                       "timed_region": "per step and rank: a2amd_fragment_repeat(64, B) + a2amd_render(UPLOAD|"
+                                       "SUBTREES|ROOT|READBACK|ASYNC); rank 0: a2amd_collect() of the previous "
+                                       "step into host buffers"},
             "realtime_factor": value / (cfg["voices"] * world * 48000.0),
             "parity_vs_golden": None,
             "roofline": roof, "roofline_valu": valu,
             "output_check": {"peak": int(np.abs(last).max()), "nonzero": bool(last.any())},
         }
+    be = r.be
     be.close()
     dist.destroy_process_group()
     # The contract line is the LAST thing on stdout: RCCL writes a version banner

@@ -277,6 +277,23 @@ int  a2amd_rootbus(a2amd_ctx *ctx, void **devptr, uint64_t *bytes);
  * (audiality2_amd/shard.py: GroupedRootReduce). */
 int  a2amd_rootbus_copy(a2amd_ctx *ctx, void *stage, int to_stage);
 
+/* ---- multi-GPU ----------------------------------------*/
+/* One context per GPU (one process per GPU, or several contexts in one process),
+ * each recording and rendering the voice SUBTREES it is given - the children of the
+ * root voice, e.g. the a2_NewGroup groups (src/interface.c:888), dealt over the
+ * contexts by the host - under its own copy of the root voice.  The only exchange is
+ * the root voice's inline bus: a2amd_render(... SUBTREES | ROOT ...) on a context
+ * that went through a2amd_dist_init() renders its subtrees, sums the bus over all
+ * ranks with ONE ncclReduce(int32, sum) per batch on the context's stream (RCCL over
+ * xGMI, called from this library; wrap-around integer sums give the same bits in
+ * any order), and runs the root chain - whose panmix truncates, so it must see the
+ * sum - on rank 0, where READBACK / a2amd_collect deliver the audio; on the other
+ * ranks READBACK delivers nothing.  The 128 byte id comes from a2amd_dist_unique_id()
+ * on one rank and reaches the others through whatever channel the host application
+ * has (MPI, a socket, torch.distributed's store). */
+int  a2amd_dist_unique_id(void *id128);
+int  a2amd_dist_init(a2amd_ctx *ctx, const void *id128, int rank, int nranks);
+
 /* Begin 'count' further fragments of 'frames' frames in which the engine's
  * voice walk finds every VM asleep: each live voice gets exactly one
  * Process(0, frames) per unit and nothing else happens (src/core.c:1852-1878

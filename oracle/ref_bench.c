@@ -72,8 +72,8 @@ static void *run(void *arg)
 	/* (grouped programs populate one group of 256 voices per 2.7 ms = 2.1 fragments) */
 	{
 		int wf = j->voices / 4 * 2 / 64 + 16;
-		if(strstr(j->program, "Groups") && wf < j->voices / 256 * 21 / 10 + 32)
-			wf = j->voices / 256 * 21 / 10 + 32;
+		if(strstr(j->program, "Groups") && wf < j->voices / 256 * 3 + 64)
+			wf = j->voices / 256 * 3 + 64;
 		for(f = 0; f < (wf + buffer / 64 - 1) / (buffer / 64); ++f)
 			a2_Run(i, buffer);
 	}

@@ -744,3 +744,34 @@ def test_delay_chain_kernel_rounds_match_oracle(oracle_lib, batch):
         outs.append(np.concatenate([a, b], axis=1))
         be.close()
     assert first_diff(outs[0], outs[1]) is None
+
+
+def test_dist_render_with_one_rank_equals_plain_render():
+    """a2amd_dist_init(): the multi-GPU batch (subtrees, ONE ncclReduce of the root bus on
+    the render stream, root chain on rank 0) with a communicator of one rank - all this
+    box can form - must render what the plain path renders, batch after batch (the reduce
+    of one rank's partial onto itself, bus hygiene between the split phases, graphs of
+    the split phases)."""
+    import ctypes as C
+    outs = []
+    for use_dist in (False, True):
+        gpu = make_gpu(max_batch=32)
+        if use_dist:
+            lib = gpu.lib
+            lib.a2amd_dist_unique_id.argtypes = [C.c_void_p]
+            lib.a2amd_dist_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+            idbuf = (C.c_uint8 * 128)()
+            assert lib.a2amd_dist_unique_id(idbuf) == 0
+            assert lib.a2amd_dist_init(gpu.ctx, idbuf, 0, 1) == 0, gpu._err(gpu.ctx)
+        sc = synth.Scene(gpu)
+        sc.root()
+        g = sc.add_group(preset="fmtest4")
+        sc.add_voices(64, chain="osc2-pan", group=g, total=512)
+        g2 = sc.add_group()
+        sc.add_voices(32, chain="osc-filter-pan", group=g2, total=512)
+        sc.add_voices(200, chain="osc-pan", total=512)
+        sc.add_voices(16, chain="fm2-pan", total=512)
+        outs.append(_async_steps(gpu, sc, 5, 32))
+        gpu.close()
+    assert outs[0].any()
+    assert first_diff(outs[0], outs[1]) is None
