@@ -2169,6 +2169,25 @@ __global__ void k_park(int32_t *__restrict__ stage, int32_t *__restrict__ bus, u
 	}
 }
 
+// dst += src (wrap-around), src cleared: the same-device stand-in for the RCCL reduce
+// of a2amd_render_group (several contexts of one process on ONE GPU)
+__global__ void k_add_bus(int32_t *__restrict__ dst, int32_t *__restrict__ src, unsigned words)
+{
+	for(unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) {
+		dst[i] = (int32_t)((uint32_t)dst[i] + (uint32_t)src[i]);
+		src[i] = 0;
+	}
+}
+
+int a2d_launch_add_bus(int32_t *dst, int32_t *src, unsigned words, void *stream)
+{
+	if(!words)
+		return 0;
+	hipLaunchKernelGGL(k_add_bus, dim3((words + 255) / 256 < 1024 ? (words + 255) / 256 : 1024), dim3(256), 0,
+			(hipStream_t)stream, dst, src, words);
+	return (int)hipGetLastError();
+}
+
 int a2d_launch_park(int32_t *stage, int32_t *bus, unsigned words, void *stream)
 {
 	if(!words)

@@ -37,6 +37,9 @@ struct Rccl {
 	void *lib = nullptr;
 	ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
 	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
 	ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
 	const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -65,6 +68,9 @@ bool rccl_bind()
 	*(void **)&g_rccl.CommDestroy = dlsym(h, "ncclCommDestroy");
 	*(void **)&g_rccl.GetErrorString = dlsym(h, "ncclGetErrorString");
 	*(void **)&g_rccl.Reduce = dlsym(h, "ncclReduce");
+	*(void **)&g_rccl.CommInitAll = dlsym(h, "ncclCommInitAll");
+	*(void **)&g_rccl.GroupStart = dlsym(h, "ncclGroupStart");
+	*(void **)&g_rccl.GroupEnd = dlsym(h, "ncclGroupEnd");
 	return g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.Reduce;
 }
 } // namespace
@@ -389,6 +395,8 @@ struct a2amd_ctx {
 	// batch, the root chain runs on rank 0 (a2amd_dist_init)
 	ncclComm_t comm = nullptr;
 	int dist_rank = 0, dist_ranks = 1;
+	bool dist_local = false;	// one of several contexts of this process (a2amd_dist_init_local)
+	hipEvent_t grp_ev = nullptr;	// ... its SUBTREES phase is done / its partial has been taken
 
 	a2amd_stats stats;
 
@@ -1534,6 +1542,8 @@ void a2amd_close(a2amd_ctx *c)
 	drop_graphs(c);
 	if(c->comm && g_rccl.CommDestroy)
 		g_rccl.CommDestroy(c->comm);
+	if(c->grp_ev)
+		hipEventDestroy(c->grp_ev);
 	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
 	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
 	hipFree(c->d_waves.d); hipFree(c->d_wavepool.d); hipFree(c->d_wavecoef.d); hipFree(c->d_busmem.d);
@@ -2455,7 +2465,7 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 				issue_kernels(c, kphases | (phases & A2AMD_RENDER_KEEP), nullptr, nullptr, nullptr);
 	};
 	const unsigned kphases = phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT);
-	if(c->comm && kphases == (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT)) {
+	if(c->comm && !c->dist_local && kphases == (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT)) {
 		// multi-GPU batch: every rank its subtrees, ONE reduce of the root voice's
 		// inline bus over xGMI, the root chain on rank 0 (its panmix must see the
 		// sum: the multiply truncates)
@@ -2473,7 +2483,7 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		g_t[1] += t2 - t1;
 		g_n += 1;
 	}
-	if((phases & A2AMD_RENDER_READBACK) && c->comm && c->dist_rank != 0) {
+	if((phases & A2AMD_RENDER_READBACK) && c->comm && !c->dist_local && c->dist_rank != 0) {
 		// (the master bus exists on rank 0 only)
 		if(!(phases & A2AMD_RENDER_KEEP))
 			end_batch(c);
@@ -2673,7 +2683,138 @@ int a2amd_dist_init(a2amd_ctx *c, const void *id128, int rank, int nranks)
 	return A2AMD_OK;
 }
 
+int a2amd_dist_init_local(a2amd_ctx *const *ctxs, int n)
+{
+	if(!ctxs || n < 1 || n > 64)
+		return A2AMD_EINVAL;
+	a2amd_ctx *c0 = ctxs[0];
+	bool distinct = true;
+	for(int i = 0; i < n; ++i) {
+		if(ctxs[i]->comm || ctxs[i]->dist_local)
+			return c0->fail(A2AMD_ESTATE, "dist_init_local: context %d is already part of a group", i);
+		for(int k = 0; k < i; ++k)
+			if(ctxs[k]->cfg.device == ctxs[i]->cfg.device)
+				distinct = false;
+	}
+	if(n > 1 && distinct) {
+		// one communicator per GPU, all in this process (ncclCommInitAll)
+		if(!rccl_bind() || !g_rccl.CommInitAll || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+			return c0->fail(A2AMD_ENODEVICE, "dist_init_local: RCCL (librccl.so) is not available");
+		std::vector<ncclComm_t> comms(n);
+		std::vector<int> devs(n);
+		for(int i = 0; i < n; ++i)
+			devs[i] = ctxs[i]->cfg.device;
+		ncclResult_t r = g_rccl.CommInitAll(comms.data(), n, devs.data());
+		if(r != ncclSuccess)
+			return c0->fail(A2AMD_EHIP, "ncclCommInitAll: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "failed");
+		for(int i = 0; i < n; ++i)
+			ctxs[i]->comm = comms[i];
+	}
+	// (contexts sharing a GPU - a test box - exchange with a device-local add instead:
+	// RCCL refuses two ranks on one device)
+	for(int i = 0; i < n; ++i) {
+		a2amd_ctx *c = ctxs[i];
+		use_device(c);
+		c->dist_local = true;
+		c->dist_rank = i;
+		c->dist_ranks = n;
+		if(!c->grp_ev)
+			HIPCHK(c, hipEventCreateWithFlags(&c->grp_ev, hipEventDisableTiming));
+		drop_graphs(c);
+		c->blob_quiet = false;
+	}
+	return A2AMD_OK;
+}
+
 int a2amd_rootbus(a2amd_ctx *c, void **devptr, uint64_t *bytes);
+
+int a2amd_render_group(a2amd_ctx *const *ctxs, int n, unsigned phases, int32_t *const *out, unsigned cap)
+{
+	if(!ctxs || n < 1)
+		return A2AMD_EINVAL;
+	a2amd_ctx *c0 = ctxs[0];
+	if(n == 1 && !c0->dist_local)
+		return a2amd_render(c0, phases, out, cap);
+	for(int i = 0; i < n; ++i)
+		if(!ctxs[i]->dist_local || ctxs[i]->dist_rank != i || ctxs[i]->dist_ranks != n)
+			return c0->fail(A2AMD_ESTATE, "render_group: not the group of a2amd_dist_init_local()");
+	const unsigned keep = phases & A2AMD_RENDER_KEEP;
+	// every context: its commands up, its subtrees rendered (the kernels of the
+	// different GPUs run side by side: nothing here waits)
+	int frames = 0;
+	for(int i = 0; i < n; ++i) {
+		int r = a2amd_render(ctxs[i], (phases & (A2AMD_RENDER_UPLOAD | A2AMD_RENDER_SUBTREES)) | keep, nullptr, 0);
+		if(r < 0) {
+			if(i)
+				c0->fail(r, "%s", ctxs[i]->err);
+			return r;
+		}
+		if(i == 0)
+			frames = r;
+		else if(r != frames)
+			return c0->fail(A2AMD_ESTATE, "render_group: context %d recorded %d frames, context 0 %d", i, r, frames);
+	}
+	if(!frames)
+		return 0;
+	if(phases & A2AMD_RENDER_SUBTREES) {
+		// the exchange: the partials of the root voice's inline bus -> context 0
+		std::vector<void *> bus(n);
+		uint64_t bytes = 0;
+		for(int i = 0; i < n; ++i) {
+			uint64_t b;
+			if(int r = a2amd_rootbus(ctxs[i], &bus[i], &b))
+				return i ? c0->fail(r, "%s", ctxs[i]->err) : r;
+			if(i && b != bytes)
+				return c0->fail(A2AMD_ESTATE, "render_group: root buses of different shapes");
+			bytes = b;
+		}
+		if(c0->comm) {
+			// ONE ncclReduce(int32, sum) over xGMI: a group call, one thread drives all ranks
+			ncclResult_t r = g_rccl.GroupStart();
+			for(int i = 0; i < n && r == ncclSuccess; ++i) {
+				use_device(ctxs[i]);
+				r = g_rccl.Reduce(bus[i], bus[i], bytes / 4, ncclInt32, ncclSum, 0, ctxs[i]->comm, ctxs[i]->stream);
+			}
+			ncclResult_t r2 = g_rccl.GroupEnd();
+			if(r != ncclSuccess || r2 != ncclSuccess)
+				return c0->fail(A2AMD_EHIP, "ncclReduce: %s", g_rccl.GetErrorString ?
+						g_rccl.GetErrorString(r != ncclSuccess ? r : r2) : "failed");
+			for(int i = 1; i < n; ++i) {
+				a2amd_ctx *c = ctxs[i];
+				use_device(c);
+				HIPCHK(c, hipMemsetAsync(bus[i], 0, bytes, c->stream));
+				c->root_clean = true;
+			}
+		} else {
+			// contexts sharing one GPU: context 0's stream adds the others' partials
+			// (and clears them) once their subtrees are done
+			use_device(c0);
+			for(int i = 1; i < n; ++i) {
+				a2amd_ctx *c = ctxs[i];
+				HIPCHK(c, hipEventRecord(c->grp_ev, c->stream));
+				HIPCHK(c0, hipStreamWaitEvent(c0->stream, c->grp_ev, 0));
+				if(a2d_launch_add_bus((int32_t *)bus[0], (int32_t *)bus[i], (unsigned)(bytes / 4), c0->stream))
+					return c0->fail(A2AMD_EHIP, "bus add launch failed");
+				c->root_clean = true;
+			}
+			// (their next batch must not start before the partials were taken)
+			HIPCHK(c0, hipEventRecord(c0->grp_ev, c0->stream));
+			for(int i = 1; i < n; ++i)
+				HIPCHK(ctxs[i], hipStreamWaitEvent(ctxs[i]->stream, c0->grp_ev, 0));
+		}
+	}
+	// the root chain and the audio: context 0
+	use_device(c0);
+	int r = a2amd_render(c0, (phases & (A2AMD_RENDER_ROOT | A2AMD_RENDER_READBACK | A2AMD_RENDER_ASYNC)) | keep, out, cap);
+	if(r < 0)
+		return r;
+	if(!keep && (phases & (A2AMD_RENDER_READBACK | A2AMD_RENDER_ROOT)))
+		for(int i = 1; i < n; ++i) {
+			use_device(ctxs[i]);
+			end_batch(ctxs[i]);
+		}
+	return frames;
+}
 
 // the exchange step of a batch: sum the ranks' partials of the root voice's inline bus
 // into rank 0's (int32 wrap-around sum: any order gives the same bits)

@@ -293,6 +293,17 @@ int  a2amd_rootbus_copy(a2amd_ctx *ctx, void *stage, int to_stage);
  * has (MPI, a socket, torch.distributed's store). */
 int  a2amd_dist_unique_id(void *id128);
 int  a2amd_dist_init(a2amd_ctx *ctx, const void *id128, int rank, int nranks);
+/* The same inside ONE process - one engine state spread over several GPUs: the n
+ * contexts (one per GPU, ctxs[0] owning the root chain) form a group
+ * (ncclCommInitAll), and a2amd_render_group() renders a batch all of them recorded:
+ * every context's subtrees, the one reduce (an RCCL group call from the calling
+ * thread), the root chain + READBACK on ctxs[0].  Each context must have been given
+ * the same fragments (a2amd_fragment) and its own copy of the root voice.  (Contexts
+ * that share a GPU - a single-GPU test box - exchange with a device-local add: RCCL
+ * does not take two ranks on one device.) */
+int  a2amd_dist_init_local(a2amd_ctx *const *ctxs, int n);
+int  a2amd_render_group(a2amd_ctx *const *ctxs, int n, unsigned phases, int32_t *const *out,
+		unsigned out_capacity_frames);
 
 /* Begin 'count' further fragments of 'frames' frames in which the engine's
  * voice walk finds every VM asleep: each live voice gets exactly one

@@ -775,3 +775,67 @@ def test_dist_render_with_one_rank_equals_plain_render():
         gpu.close()
     assert outs[0].any()
     assert first_diff(outs[0], outs[1]) is None
+
+
+def test_render_group_of_two_contexts_equals_one_context():
+    """a2amd_dist_init_local() / a2amd_render_group(): ONE voice tree spread over two
+    contexts of this process (each with its own copy of the root voice; the groups and
+    the voices under the root dealt alternately), their root-bus partials summed, the
+    root chain on context 0 - must render what one context holding all of it renders.
+    (Both contexts on this box's one GPU: the exchange is the device-local add; with
+    distinct GPUs the same entry point issues the RCCL group reduce.)"""
+    import ctypes as C
+    B, steps, ngroups, per = 16, 4, 6, 24
+
+    def populate(sc, mine):
+        for gi in range(ngroups):
+            if mine(gi):
+                grp = sc.add_group(preset="fmtest4") if gi % 2 else sc.add_group()
+                sc.add_voices(per, chain="osc2-pan" if gi % 3 else "osc-filter-pan", group=grp, total=512)
+            else:
+                sc.nvoices += per
+        for k in range(4):          # ... and voices straight under the root
+            if mine(ngroups + k):
+                sc.add_voices(16, chain="osc-pan", total=512)
+            else:
+                sc.nvoices += 16
+
+    one = make_gpu(max_batch=B)
+    sc = synth.Scene(one)
+    sc.root()
+    populate(sc, lambda i: True)
+    want = _async_steps(one, sc, steps, B)
+    one.close()
+
+    a, b = make_gpu(max_batch=B), make_gpu(max_batch=B)
+    lib = a.lib
+    lib.a2amd_dist_init_local.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.a2amd_render_group.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_uint, C.POINTER(C.POINTER(C.c_int32)), C.c_uint]
+    lib.a2amd_fragment_repeat.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
+    ctxs = (C.c_void_p * 2)(a.ctx, b.ctx)
+    assert lib.a2amd_dist_init_local(ctxs, 2) == 0, a._err(a.ctx)
+    scs = []
+    for be, parity in ((a, 0), (b, 1)):
+        s2 = synth.Scene(be)
+        s2.root()
+        populate(s2, lambda i, parity=parity: i % 2 == parity)
+        scs.append(s2)
+    outs = []
+    for s in range(steps):
+        n = B
+        if s == 0:
+            for s2 in scs:
+                s2.walk(64)
+            n = B - 1
+        for be in (a, b):
+            assert lib.a2amd_fragment_repeat(be.ctx, 64, n) == 0, be._err(be.ctx)
+        out = np.zeros((2, B * 64), dtype=np.int32)
+        p = (C.POINTER(C.c_int32) * 2)()
+        for c in range(2):
+            p[c] = out[c].ctypes.data_as(C.POINTER(C.c_int32))
+        assert lib.a2amd_render_group(ctxs, 2, 15, p, B * 64) == B * 64, a._err(a.ctx)
+        outs.append(out)
+    a.close()
+    b.close()
+    got = np.concatenate(outs, axis=1)
+    assert want.any() and first_diff(got, want) is None
