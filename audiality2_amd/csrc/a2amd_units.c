@@ -46,6 +46,21 @@ extern int a2r_Error(void *st, int e, const char *info) __attribute__((weak));
 extern int a2_XinsertRemoveClient(A2P_xinsert_client *xic) __attribute__((weak));
 
 #define MAXSTATES 256		/* engine states (master + substates) alive at once in one process */
+#define MAXDEV    8		/* GPUs one engine state may be spread over (A2AMD_DEVICES) */
+
+/* A2AMD_DEVICES > 1: what the engine asked of a voice before it was first processed -
+ * i.e. before the drop-in knows which bus, and therefore which GPU, it belongs to */
+typedef struct BIRTHOP
+{
+	A2P_unit	*u;
+	A2P_vmstate	*vms;		/* the voice */
+	int		is_write;
+	int		kind, nin, nout, wired;		/* Initialize */
+	unsigned	flags, wakefrac;
+	int		reg, v;				/* write */
+	unsigned	start, dur;
+	int		transpose;
+} BIRTHOP;
 
 /* a READ client's window, waiting for the audio of its fragment */
 typedef struct PENDING
@@ -53,6 +68,7 @@ typedef struct PENDING
 	A2P_xinsert		*xi;
 	A2P_xinsert_client	*xic;
 	int			uid;		/* backend unit, or -1: the root xinsert (its input is the master bus) */
+	int			dev;
 	int			frag;		/* fragment of the batch the window lies in */
 	unsigned		pos;		/* root xinsert: frames into the buffer */
 	const char		*what;		/* for error reports */
@@ -62,14 +78,21 @@ typedef struct PENDING
 typedef struct HOSTSTATE
 {
 	A2P_config	*cfg;
-	a2amd_ctx	*ctx;
+	a2amd_ctx	*ctx;		/* = ctxs[0]: owns the root chain, delivers the audio */
+	int		ndev;		/* contexts (GPUs) this state's voice subtrees are dealt over */
+	a2amd_ctx	*ctxs[MAXDEV];
+	int		root_uid[2][MAXDEV];	/* the root voice's inline and panmix in every context */
+	int		rr;		/* next context for a voice that mixes straight into the root's bus */
+	int		dev_stack[72];	/* context of each open inline window, by depth */
+	BIRTHOP		*births;
+	int		nbirths, cap_births;
 	int		refs;
 	int		failed;		/* the backend reported an error: this state renders silence from here on */
 	int		depth;		/* open inline windows */
 	unsigned	base;		/* engine offset of the current root window */
 	unsigned	win_frames;	/* ... and its length = the open backend fragment */
-	uint8_t		*map;		/* the backend's default map for that fragment (a2amd_default_map) */
-	unsigned	map_cap;
+	uint8_t		*map[MAXDEV];	/* the backends' default maps for that fragment (a2amd_default_map) */
+	unsigned	map_cap[MAXDEV];
 	int		noise_oscs;	/* oscillators playing the noise wave: their voices need the engine's RNG */
 	int		no_quick;	/* A2AMD_NO_QUICK=1: every Process call is forwarded (A/B measurements) */
 	A2P_vmstate	*root_vms;	/* the root voice (first voice of a state) */
@@ -79,7 +102,7 @@ typedef struct HOSTSTATE
 	void		*engine_state;	/* A2_state, for a2r_Error */
 	/* wave registry: engine object -> device wave id */
 	A2P_wave	**wave_ptr;
-	int		*wave_id;
+	int		(*wave_id)[MAXDEV];	/* per context, -1 = not uploaded there */
 	int		nwaves, cap_waves;
 	int		swept;		/* the registry has been checked for released waves in this buffer */
 	int32_t		out[A2AMD_MAXCHANNELS][A2AMD_MAXFRAG];
@@ -118,6 +141,8 @@ typedef struct XTRA
 	HOSTSTATE	*hs;
 	A2P_vmstate	*vms;
 	int		uid;		/* backend unit id, -1 = not forwarded */
+	int		dev;		/* which of the state's contexts holds the voice */
+	int		pending;	/* its Initialize / writes wait in HOSTSTATE.births for the voice's first window */
 	int		kind;
 	unsigned	client_mode;	/* xinsert / xsink / xsource: A2AMD_XIO_*, what its clients need */
 	int		is_root;
@@ -153,7 +178,7 @@ static void fail(HOSTSTATE *hs, const char *what, int rc)
 	if(hs && hs->failed)
 		return;
 	m = msg[hs ? hs - states : 0];
-	snprintf(m, sizeof(msg[0]), "a2amd: %s failed (%d): %s", what, rc, a2amd_last_error(hs ? hs->ctx : NULL));
+	snprintf(m, sizeof(msg[0]), "a2amd: %s failed (%d): %s", what, rc, a2amd_last_error(NULL));
 	if(hs)
 		hs->failed = 1;
 	if(a2r_Error && hs && hs->engine_state)
@@ -226,9 +251,11 @@ static void amd_close(void *statedata)
 	pthread_mutex_lock(&states_mtx);
 	if(!--hs->refs)
 	{
-		if(hs->ctx)
-			a2amd_close(hs->ctx);
+		for(c = 0; c < MAXDEV; ++c)
+			if(hs->ctxs[c])
+				a2amd_close(hs->ctxs[c]);
 		hs->ctx = NULL;
+		free(hs->births);
 		/* (the engine clears A2_audiodriver.Process itself when the state closes,
 		 * src/audiality2.c:733) */
 		free(hs->wave_ptr);
@@ -276,13 +303,106 @@ static a2amd_ctx *ctx_of(HOSTSTATE *hs)
 			c.max_batch = 256;
 		hs->max_batch = c.max_batch;
 		hs->no_quick = getenv("A2AMD_NO_QUICK") != NULL;
-		if((rc = a2amd_open(&c, &hs->ctx)))
+		/* A2AMD_DEVICES=<n>: this ONE engine state is spread over n GPUs - every voice
+		 * subtree below the root (an a2_NewGroup group, src/interface.c:888, or a voice
+		 * playing straight into the root's bus) lives on one of them, dealt round robin;
+		 * the root chain runs on the first.  Devices c.device, c.device + 1, ... (modulo
+		 * the number present: on a single-GPU box the contexts share it). */
+		hs->ndev = getenv("A2AMD_DEVICES") ? atoi(getenv("A2AMD_DEVICES")) : 1;
+		if(hs->ndev < 1)
+			hs->ndev = 1;
+		if(hs->ndev > MAXDEV)
+			hs->ndev = MAXDEV;
+		if(hs->cfg->channels != 2)
+			hs->ndev = 1;	/* (mono substates - a2_Render's - stay on one GPU) */
 		{
-			hs->ctx = NULL;
-			fail(hs, "a2amd_open", rc);
+			int d, nd = a2amd_device_count(), base = c.device;
+			for(d = 0; d < hs->ndev && !hs->failed; ++d)
+			{
+				c.device = nd > 0 ? (base + d) % nd : 0;
+				if((rc = a2amd_open(&c, &hs->ctxs[d])))
+				{
+					hs->ctxs[d] = NULL;
+					fail(hs, "a2amd_open", rc);
+				}
+			}
+			if(!hs->failed && hs->ndev > 1 && (rc = a2amd_dist_init_local(hs->ctxs, hs->ndev)))
+				fail(hs, "a2amd_dist_init_local", rc);
+			if(hs->failed)
+				for(d = 0; d < MAXDEV; ++d)
+					if(hs->ctxs[d])
+					{
+						a2amd_close(hs->ctxs[d]);
+						hs->ctxs[d] = NULL;
+					}
+			hs->ctx = hs->ctxs[0];
 		}
 	}
 	return hs->ctx;
+}
+
+#define XCTX(x) ((x)->hs->ctxs[(x)->dev])
+
+static int wave_id_of(HOSTSTATE *hs, int dev, A2P_wave *w);
+static inline XTRA *xtra(A2P_unit *u);
+
+static BIRTHOP *new_birthop(HOSTSTATE *hs)
+{
+	if(hs->nbirths == hs->cap_births)
+	{
+		int nc = hs->cap_births ? hs->cap_births * 2 : 256;
+		BIRTHOP *nb = (BIRTHOP *)realloc(hs->births, nc * sizeof(BIRTHOP));
+		if(!nb)
+			return NULL;
+		hs->births = nb;
+		hs->cap_births = nc;
+	}
+	memset(&hs->births[hs->nbirths], 0, sizeof(BIRTHOP));
+	return &hs->births[hs->nbirths++];
+}
+
+/* A2AMD_DEVICES > 1: the voice of unit 'x' is being processed for the first time.
+ * Where its output goes is known now - into the bus of the innermost open inline
+ * window - and with that its GPU: the one that holds that bus, or, if that is the
+ * root's (every context has a partial of it), the next one in turn.  Its units are
+ * created there and the register writes it has received so far follow. */
+static void route_voice(XTRA *x)
+{
+	HOSTSTATE *hs = x->hs;
+	A2P_vmstate *vms = x->vms;
+	const int dev = hs->depth <= 1 ? hs->rr++ % hs->ndev : hs->dev_stack[hs->depth - 1];
+	int k, n = 0, rc;
+	for(k = 0; k < hs->nbirths; ++k)
+	{
+		BIRTHOP *b = &hs->births[k];
+		XTRA *bx;
+		if(b->vms != vms)
+		{
+			hs->births[n++] = *b;
+			continue;
+		}
+		bx = xtra(b->u);
+		if(hs->failed)
+			continue;
+		if(!b->is_write)
+		{
+			bx->dev = dev;
+			bx->pending = 0;
+			bx->uid = a2amd_unit_init(hs->ctxs[dev], (uint64_t)(uintptr_t)vms, b->kind, b->flags, b->nin,
+					b->nout, b->wired, b->transpose, b->wakefrac);
+			if(bx->uid < 0)
+				fail(hs, "a2amd_unit_init", bx->uid);
+		}
+		else
+		{
+			int v = b->v;
+			if(bx->kind == A2AMD_WTOSC && b->reg == 0)
+				v = wave_id_of(hs, dev, a2_GetWave(hs->cfg->interface, v >> 16));
+			if(bx->uid >= 0 && (rc = a2amd_unit_write(hs->ctxs[dev], bx->uid, b->reg, v, b->start, b->dur, b->transpose)))
+				fail(hs, "a2amd_unit_write", rc);
+		}
+	}
+	hs->nbirths = n;
 }
 
 /* ---- Initialize / Deinitialize ---------------------------------------------*/
@@ -328,16 +448,42 @@ static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned 
 				"supported (no CPU fallback)\n", u->descriptor->name);
 		return A2P_NOTIMPLEMENTED;	/* A2_VOICEINIT for this voice */
 	}
-	if(forward)
+	if(forward && hs->ndev > 1 && !x->is_root)
 	{
+		/* which GPU?  known when the voice is first processed (route_voice) */
+		BIRTHOP *b = new_birthop(hs);
+		if(!b)
+			return A2P_OOMEMORY;
+		x->is_head = !hs->chain_last;
+		x->pending = 1;
+		b->u = u;
+		b->vms = vms;
+		b->kind = kind;
+		b->flags = lflags;
+		b->nin = u->ninputs;
+		b->nout = u->noutputs;
+		b->wired = wired;
+		b->transpose = vms->r[A2P_R_TRANSPOSE];
+		b->wakefrac = vms->waketime & 0xff;
+	}
+	else if(forward)
+	{
+		int d;
 		x->is_head = !hs->chain_last && !x->is_root;
-		x->uid = a2amd_unit_init(ctx, (uint64_t)(uintptr_t)vms, kind, lflags, u->ninputs,
-				u->noutputs, wired, vms->r[A2P_R_TRANSPOSE], vms->waketime & 0xff);
-		if(x->uid < 0)
+		/* (the root voice's units exist in every context: each renders its subtrees
+		 * into its own partial of the root's bus) */
+		for(d = x->is_root ? hs->ndev - 1 : 0; d >= 0; --d)
 		{
-			fprintf(stderr, "a2amd units: cannot instantiate unit kind %d: %s\n", kind,
-					a2amd_last_error(ctx));
-			return A2P_NOTIMPLEMENTED;	/* the engine reports A2_VOICEINIT and drops the voice */
+			x->uid = a2amd_unit_init(hs->ctxs[d], (uint64_t)(uintptr_t)vms, kind, lflags, u->ninputs,
+					u->noutputs, wired, vms->r[A2P_R_TRANSPOSE], vms->waketime & 0xff);
+			if(x->uid < 0)
+			{
+				fprintf(stderr, "a2amd units: cannot instantiate unit kind %d: %s\n", kind,
+						a2amd_last_error(hs->ctxs[d]));
+				return A2P_NOTIMPLEMENTED;	/* the engine reports A2_VOICEINIT and drops the voice */
+			}
+			if(x->is_root && (kind == A2AMD_INLINE || kind == A2AMD_PANMIX))
+				hs->root_uid[kind == A2AMD_PANMIX][d] = x->uid;
 		}
 	}
 	hs->chain_last = u;
@@ -354,7 +500,27 @@ static void amd_deinit(A2P_unit *u)
 		x->hs->chain_last = NULL;
 	x->hs->noise_oscs -= x->is_noise;
 	x->is_noise = 0;
-	if(x->uid >= 0 && !x->hs->failed && (rc = a2amd_unit_deinit(x->hs->ctx, x->uid)))
+	if(x->pending)
+	{
+		/* never processed: nothing of it exists on any GPU */
+		HOSTSTATE *hs = x->hs;
+		int k, n = 0;
+		for(k = 0; k < hs->nbirths; ++k)
+			if(hs->births[k].u != u)
+				hs->births[n++] = hs->births[k];
+		hs->nbirths = n;
+		x->pending = 0;
+		return;
+	}
+	if(x->is_root && x->hs->ndev > 1 && (x->kind == A2AMD_INLINE || x->kind == A2AMD_PANMIX))
+	{
+		int d;
+		for(d = 0; d < x->hs->ndev; ++d)
+			if(!x->hs->failed && (rc = a2amd_unit_deinit(x->hs->ctxs[d], x->hs->root_uid[x->kind == A2AMD_PANMIX][d])))
+				fail(x->hs, "a2amd_unit_deinit", rc);
+		return;
+	}
+	if(x->uid >= 0 && !x->hs->failed && (rc = a2amd_unit_deinit(XCTX(x), x->uid)))
 		fail(x->hs, "a2amd_unit_deinit", rc);
 }
 
@@ -376,10 +542,13 @@ static void sweep_waves(HOSTSTATE *hs)
 		A2P_wave *w = hs->wave_ptr[i];
 		if((w->type == A2AMD_WWAVE || w->type == A2AMD_WMIPWAVE) && !w->size[0])
 		{
-			if(!hs->failed && (rc = a2amd_wave_drop(hs->ctx, (uint64_t)(uintptr_t)w)))
-				fail(hs, "a2amd_wave_drop", rc);
+			int d;
+			for(d = 0; d < hs->ndev; ++d)
+				if(hs->wave_id[i][d] >= 0 && !hs->failed &&
+						(rc = a2amd_wave_drop(hs->ctxs[d], (uint64_t)(uintptr_t)w)))
+					fail(hs, "a2amd_wave_drop", rc);
 			hs->wave_ptr[i] = hs->wave_ptr[hs->nwaves - 1];
-			hs->wave_id[i] = hs->wave_id[hs->nwaves - 1];
+			memcpy(hs->wave_id[i], hs->wave_id[hs->nwaves - 1], sizeof(hs->wave_id[i]));
 			--hs->nwaves;
 		}
 		else
@@ -496,7 +665,7 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 			mode |= (xic->flags & A2P_XI_WRITE) ? A2AMD_XIO_INJECT : A2AMD_XIO_TAP;
 	if(mode != x->client_mode)
 	{
-		if((rc = a2amd_unit_clients(hs->ctx, x->uid, mode)))
+		if((rc = a2amd_unit_clients(XCTX(x), x->uid, mode)))
 		{
 			fail(hs, "a2amd_unit_clients", rc);
 			return;
@@ -529,7 +698,7 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 		}
 		for(i = 0; i < nch; ++i)
 			sump[i] = sum[i];
-		if((rc = a2amd_unit_inject(hs->ctx, x->uid, offset - hs->base, frames, sump)))
+		if((rc = a2amd_unit_inject(XCTX(x), x->uid, offset - hs->base, frames, sump)))
 			fail(hs, "a2amd_unit_inject", rc);
 	}
 	if(mode & A2AMD_XIO_TAP)
@@ -546,6 +715,7 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 			p->xi = xi;
 			p->xic = xic;
 			p->uid = x->uid;
+			p->dev = x->dev;
 			p->frag = hs->batch_frags ? (int)hs->batch_frags - 1 : 0;
 			p->pos = 0;
 			p->what = what;
@@ -579,7 +749,7 @@ static void deliver_pending(HOSTSTATE *hs)
 		}
 		else
 		{
-			if((n = a2amd_unit_tapped(hs->ctx, p->uid, (unsigned)p->frag, bufs)) < 0)
+			if((n = a2amd_unit_tapped(hs->ctxs[p->dev], p->uid, (unsigned)p->frag, bufs)) < 0)
 			{
 				fail(hs, "a2amd_unit_tapped", n);
 				continue;
@@ -659,7 +829,7 @@ static void flush_batch(HOSTSTATE *hs)
 		outp[c] = hs->acc[c] ? hs->acc[c] + hs->acc_pos : NULL;
 	if(!hs->failed)
 	{
-		n = a2amd_render(hs->ctx, A2AMD_RENDER_ALL, outp, hs->acc_cap - hs->acc_pos);
+		n = a2amd_render_group(hs->ctxs, hs->ndev, A2AMD_RENDER_ALL, outp, hs->acc_cap - hs->acc_pos);
 		if(n != (int)(hs->rec_pos - hs->acc_pos))
 			fail(hs, "a2amd_render", n);
 	}
@@ -782,7 +952,16 @@ static void forward_process(XTRA *x, unsigned offset, unsigned frames)
 		a2_GetStateProperty(hs->cfg->interface, A2P_PNOISESEED, &v);
 		noise = before = (uint32_t)v;
 	}
-	if((rc = a2amd_unit_process(hs->ctx, x->uid, offset - hs->base, frames, is_noise ? &noise : NULL)))
+	if(x->is_root && hs->ndev > 1)
+	{
+		/* the root voice's units are walked in every context */
+		int d;
+		for(d = 0; d < hs->ndev && !hs->failed; ++d)
+			if((rc = a2amd_unit_process(hs->ctxs[d], hs->root_uid[x->kind == A2AMD_PANMIX][d], offset - hs->base,
+					frames, NULL)))
+				fail(hs, "a2amd_unit_process", rc);
+	}
+	else if((rc = a2amd_unit_process(XCTX(x), x->uid, offset - hs->base, frames, is_noise ? &noise : NULL)))
 		fail(hs, "a2amd_unit_process", rc);
 	if(noise != before)
 		a2_SetStateProperty(hs->cfg->interface, A2P_PNOISESEED, (int)noise);
@@ -808,9 +987,9 @@ static void amd_quick_process(A2P_unit *u, unsigned offset, unsigned frames)
 {
 	XTRA *x = (XTRA *)((char *)u + 64);	/* (own units only: no descriptor look-up) */
 	HOSTSTATE *hs = x->hs;
-	if(offset == hs->base && frames == hs->win_frames && (unsigned)x->slot < hs->map_cap)
+	if(offset == hs->base && frames == hs->win_frames && (unsigned)x->slot < hs->map_cap[x->dev])
 	{
-		hs->map[x->slot] = 1;	/* Process(0, all frames) on each unit: the default */
+		hs->map[x->dev][x->slot] = 1;	/* Process(0, all frames) on each unit: the default */
 		return;
 	}
 	u->Process = amd_head_process;
@@ -832,7 +1011,7 @@ static void amd_head_process(A2P_unit *u, unsigned offset, unsigned frames)
 		a2_GetStateProperty(hs->cfg->interface, A2P_PNOISESEED, &v);
 		noise = before = (uint32_t)v;
 	}
-	rc = a2amd_voice_process(hs->ctx, x->uid, offset - hs->base, frames, hs->noise_oscs ? &noise : NULL);
+	rc = a2amd_voice_process(XCTX(x), x->uid, offset - hs->base, frames, hs->noise_oscs ? &noise : NULL);
 	if(rc < 0)
 		fail(hs, "a2amd_voice_process", rc);
 	else if(rc == 1 && !hs->no_quick)
@@ -861,7 +1040,7 @@ static int setup_simple_chain(A2P_unit *u)
 		if(i == sizeof(plain) / sizeof(plain[0]) || xtra(n)->uid < 0)
 			return 0;
 	}
-	if((slot = a2amd_voice_slot(x->hs->ctx, x->uid)) < 0)
+	if((slot = a2amd_voice_slot(XCTX(x), x->uid)) < 0)
 		return 0;
 	x->slot = slot;
 	for(n = u; n; n = n->next)
@@ -887,6 +1066,8 @@ static void amd_process(A2P_unit *u, unsigned offset, unsigned frames)
 	hs = x->hs;
 	if(null_walk == 1 && !x->is_root)
 		return;
+	if(x->pending)
+		route_voice(x);
 
 	if(!x->chain_checked)
 	{
@@ -908,7 +1089,7 @@ static void amd_process(A2P_unit *u, unsigned offset, unsigned frames)
 			outp[c] = hs->out[c];
 		if(!hs->failed)
 		{
-			n = a2amd_render(hs->ctx, A2AMD_RENDER_ALL, outp, A2AMD_MAXFRAG);
+			n = a2amd_render_group(hs->ctxs, hs->ndev, A2AMD_RENDER_ALL, outp, A2AMD_MAXFRAG);
 			if(n != (int)frames)
 				fail(hs, "a2amd_render", n);
 		}
@@ -944,22 +1125,39 @@ static void amd_inline_process(A2P_unit *u, unsigned offset, unsigned frames)
 		}
 		if(hs->batching && hs->batch_frags == hs->max_batch)
 			flush_batch(hs);
-		if(!hs->failed && (rc = a2amd_fragment(hs->ctx, frames)))
-			fail(hs, "a2amd_fragment", rc);
+		{
+			int d;
+			for(d = 0; d < hs->ndev; ++d)
+			{
+				if(!hs->failed && (rc = a2amd_fragment(hs->ctxs[d], frames)))
+					fail(hs, "a2amd_fragment", rc);
+				hs->map[d] = hs->failed ? NULL : a2amd_default_map(hs->ctxs[d], &hs->map_cap[d]);
+				if(!hs->map[d])
+					hs->map_cap[d] = 0;
+			}
+		}
 		++hs->batch_frags;
 		hs->base = offset;
 		hs->win_frames = frames;
-		hs->map = hs->failed ? NULL : a2amd_default_map(hs->ctx, &hs->map_cap);
-		if(!hs->map)
-			hs->map_cap = 0;
 		hs->win_pos = hs->rec_pos;
 		hs->rec_pos += frames;
 	}
+	if(x->pending)
+		route_voice(x);
 	forward_process(x, offset, frames);
+	if(hs->depth < 70)
+		hs->dev_stack[hs->depth] = x->dev;	/* (our subvoices' buses live where we do) */
 	++hs->depth;
 	x->orig_process(u, offset, frames);	/* the engine walks the subvoices */
 	--hs->depth;
-	if(!hs->failed && (rc = a2amd_inline_end(hs->ctx, x->uid)))
+	if(x->is_root && hs->ndev > 1)
+	{
+		int d;
+		for(d = 0; d < hs->ndev && !hs->failed; ++d)
+			if((rc = a2amd_inline_end(hs->ctxs[d], hs->root_uid[0][d])))
+				fail(hs, "a2amd_inline_end", rc);
+	}
+	else if(!hs->failed && (rc = a2amd_inline_end(XCTX(x), x->uid)))
 		fail(hs, "a2amd_inline_end", rc);
 }
 
@@ -1038,22 +1236,27 @@ static void amd_rootx_setprocess(A2P_unit *u)
 }
 
 /* ---- control register writes --------------------------------------------------*/
-static int wave_id_of(HOSTSTATE *hs, A2P_wave *w)
+static int wave_id_of(HOSTSTATE *hs, int dev, A2P_wave *w)
 {
 	a2amd_wavedesc d;
-	int i, id, levels;
+	int i, k, id, levels, slot = -1;
 	if(!w)
 		return -1;
 	for(i = 0; i < hs->nwaves; ++i)
 		if(hs->wave_ptr[i] == w)
-			return hs->wave_id[i];
+		{
+			if(hs->wave_id[i][dev] >= 0)
+				return hs->wave_id[i][dev];
+			slot = i;	/* (known, but not on this GPU yet) */
+			break;
+		}
 	if(hs->failed || !ctx_of(hs))
 		return -1;
-	if(hs->nwaves == hs->cap_waves)
+	if(slot < 0 && hs->nwaves == hs->cap_waves)
 	{
 		int nc = hs->cap_waves ? hs->cap_waves * 2 : 256;
 		A2P_wave **np = (A2P_wave **)realloc(hs->wave_ptr, nc * sizeof(A2P_wave *));
-		int *ni = np ? (int *)realloc(hs->wave_id, nc * sizeof(int)) : NULL;
+		int (*ni)[MAXDEV] = np ? (int (*)[MAXDEV])realloc(hs->wave_id, nc * sizeof(hs->wave_id[0])) : NULL;
 		if(np)
 			hs->wave_ptr = np;
 		if(ni)
@@ -1075,14 +1278,20 @@ static int wave_id_of(HOSTSTATE *hs, A2P_wave *w)
 		d.size[i] = w->size[i];
 		d.data[i] = w->data[i];
 	}
-	id = a2amd_wave_upload(ctx_of(hs), (uint64_t)(uintptr_t)w, &d);
+	id = a2amd_wave_upload(hs->ctxs[dev], (uint64_t)(uintptr_t)w, &d);
 	if(id < 0)
 	{
 		fail(hs, "a2amd_wave_upload", id);
 		return -1;
 	}
-	hs->wave_ptr[hs->nwaves] = w;
-	hs->wave_id[hs->nwaves++] = id;
+	if(slot < 0)
+	{
+		slot = hs->nwaves++;
+		hs->wave_ptr[slot] = w;
+		for(k = 0; k < MAXDEV; ++k)
+			hs->wave_id[slot][k] = -1;
+	}
+	hs->wave_id[slot][dev] = id;
 	return id;
 }
 
@@ -1096,14 +1305,34 @@ static void amd_write(A2P_unit *u, int reg, int v, unsigned start, unsigned dur)
 		const int noise = w && w->type == A2AMD_WNOISE;
 		x->hs->noise_oscs += noise - x->is_noise;
 		x->is_noise = noise;
-		v = wave_id_of(x->hs, w);
+		if(!x->pending)
+			v = wave_id_of(x->hs, x->dev, w);
+	}
+	if(x->pending)
+	{
+		/* (its voice has no GPU yet: route_voice() replays this) */
+		BIRTHOP *b = new_birthop(x->hs);
+		if(!b)
+		{
+			fail(x->hs, "out of memory", -1);
+			return;
+		}
+		b->u = u;
+		b->vms = x->vms;
+		b->is_write = 1;
+		b->reg = reg;
+		b->v = v;
+		b->start = start;
+		b->dur = dur;
+		b->transpose = x->vms->r[A2P_R_TRANSPOSE];
+		return;
 	}
 	/* (a voice that was reporting its default windows through the map calls in again) */
 	if(x->head && x->head->Process == amd_quick_process)
 		x->head->Process = amd_head_process;
 	if(x->hs->failed)
 		return;
-	if((rc = a2amd_unit_write(x->hs->ctx, x->uid, reg, v, start, dur, x->vms->r[A2P_R_TRANSPOSE])))
+	if((rc = a2amd_unit_write(XCTX(x), x->uid, reg, v, start, dur, x->vms->r[A2P_R_TRANSPOSE])))
 		fail(x->hs, "a2amd_unit_write", rc);
 }
 
@@ -1288,9 +1517,11 @@ static void amd_x_process(A2P_unit *u, unsigned offset, unsigned frames)
 	}
 	if(hs->failed)
 		return;
+	if(x->pending)
+		route_voice(x);
 	if(((A2P_xinsert *)u)->clients || x->client_mode)
 		serve_clients(x, (A2P_xinsert *)u, offset, frames);
-	if(!hs->failed && (rc = a2amd_unit_process(hs->ctx, x->uid, offset - hs->base, frames, NULL)))
+	if(!hs->failed && (rc = a2amd_unit_process(XCTX(x), x->uid, offset - hs->base, frames, NULL)))
 		fail(hs, "a2amd_unit_process", rc);
 }
 
@@ -1311,7 +1542,7 @@ static int x_init(const char *sym, int kind, A2P_unit *u, A2P_vmstate *vms, void
 		return rc;
 	if((rc = amd_init(kind, u, vms, ws->hs, flags, 1)))
 		return rc;
-	if(xtra(u)->uid >= 0)
+	if(xtra(u)->uid >= 0 || xtra(u)->pending)
 	{
 		((A2P_xinsert *)u)->SetProcess = amd_x_setprocess;
 		amd_x_setprocess(u);

@@ -364,3 +364,53 @@ def test_wave_released_without_players_then_reloaded(tmp_path):
         outs.append(read_pcm(out, 2, 256))
     assert outs[0].any()
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [2, 3])
+@pytest.mark.parametrize("name,args,frames", [c for c in CASES if c[0] in ("sustain", "delaybus", "scripted", "edge", "fm",
+                                                                           "envwire")] + [("song", ["0.08"], 96000)])
+def test_one_engine_state_over_several_contexts(tmp_path, name, args, frames, devices):
+    """A2AMD_DEVICES=n: ONE engine state's voice subtrees dealt over n backend contexts
+    (one per GPU; here they share the box's GPU), every context with its own copy of the
+    root voice, new voices routed when they are first processed, the root-bus partials
+    summed per buffer (a2amd_render_group), the root chain on the first context: the
+    audio must be the single-context audio = the CPU reference's."""
+    need_ref()
+    outs = []
+    for dev in (None, devices):
+        out = tmp_path / f"d{dev or 0}.pcm"
+        env = dict(os.environ)
+        if dev:
+            env["LD_PRELOAD"] = UNITS_SO
+            env["A2AMD_DEVICES"] = str(dev)
+        if name in REALTIME_CASES:
+            env["A2REF_REALTIME"] = "1"
+        subprocess.run([REF_RENDER, f"{A2S}/{name}.a2s", "Main", str(frames), "1024", "48000", "2", str(out)] + args,
+                       check=True, env=env, cwd=A2S, timeout=600)
+        outs.append(read_pcm(out, 2, 1024))
+    assert outs[0].any()
+    bad = np.nonzero((outs[0] != outs[1]).any(axis=0))[0]
+    assert len(bad) == 0, f"{len(bad)} frames differ, first {bad[:5]}"
+
+
+@pytest.mark.gpu
+def test_fuzz_scripts_over_two_contexts(tmp_path):
+    """A handful of the fuzzer's random scripts (tests/fuzz_scripts.py) with the voice
+    tree spread over two contexts."""
+    need_ref()
+    import fuzz_scripts
+    for seed in range(100, 108):
+        path = tmp_path / f"f{seed}.a2s"
+        path.write_text(fuzz_scripts.make_script(seed))
+        outs = []
+        for dev in (None, 2):
+            out = tmp_path / f"f{seed}_{dev or 0}.pcm"
+            env = dict(os.environ)
+            if dev:
+                env["LD_PRELOAD"] = UNITS_SO
+                env["A2AMD_DEVICES"] = "2"
+            subprocess.run([REF_RENDER, str(path), "Main", "48000", "512", "48000", "2", str(out), "0.15"],
+                           check=True, env=env, cwd=tmp_path, timeout=600)
+            outs.append(np.fromfile(out, dtype="<i4"))
+        assert np.array_equal(outs[0], outs[1]), f"seed {seed}"
