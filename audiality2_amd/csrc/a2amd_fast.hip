@@ -207,10 +207,12 @@ struct FastPtrs {
 // wtosc_wavetable (wtosc.c:239-286) / wtosc_Off (:108-126).  Returns the sample
 // the oscillator leaves in the scratch buffer for this lane.  Everything named
 // o.* lives in SGPRs.
+// (lane = index of the frame within the window: lanes before a window that starts
+// inside the fragment come in negative, k_leaf_recs)
 DEV int osc_fragment_s(const FastPtrs &g, OscS &o, int nframes, int lane)
 {
 	int x = 0;
-	const bool in = lane < nframes;
+	const bool in = (unsigned)lane < (unsigned)nframes;
 	if(o.mode == A2D_OSC_MIPWAVE) {
 		const A2DWave *w = g.waves + o.wave;
 		const unsigned size0 = w->size[0], period = w->period, flags = w->flags;
@@ -271,7 +273,7 @@ DEV void pan_fragment_s(Ramp &vol, Ramp &pan, int x, int nframes, int lane, int 
 			pan.value > 0xffffff || pan.value < -0xffffff;
 	ramp_prepare_s(vol, nframes);
 	ramp_prepare_s(pan, nframes);
-	if(lane < nframes) {
+	if((unsigned)lane < (unsigned)nframes) {
 		int vk = wadd(vol.value, wmul(vol.delta, lane));
 		int pk = wadd(pan.value, wmul(pan.delta, lane));
 		int vp = mul64s(pk, vk, 24);
@@ -959,6 +961,353 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 		for(int k = 0; k < 8; ++k)
 			wp[k] = sp[k];
 	}
+}
+
+// ---------------------------------------------------------------------------
+// The same voices in a batch in which they carry command records
+// ---------------------------------------------------------------------------
+// A voice whose VM woke up during the batch - control writes between windows,
+// windows that start or end inside a fragment (a2_VoiceProcess, core.c:1852-1878),
+// its birth (Initialize + the first writes) and its death - is skipped by the two
+// kernels above (runs[slot].count != 0).  In a scripted scene that is every voice
+// in every batch.  k_leaf_recs<NOSC> renders those voices of the wtosc[+wtosc]->panmix
+// classes: the per-fragment path of the kernels above (scalar control, lane = frame)
+// with the record stream of k_voices - R_SEG windows, R_WRITE (wtosc.c:433-504,
+// panmix.c:219-249 through a2_SetRamper, a2_dsp.h:161-170), R_INIT (wtosc.c:390-423,
+// panmix.c:252-284), R_KILL - executed on the scalar unit between the windows.  State
+// stays in registers (one voice per lane, read out with v_readlane) over the whole
+// batch; the sums of RECS_FCH fragments of all the wavefront's voices on one bus go
+// out in one atomic add per fragment and channel.
+#define RECS_FCH 4
+#define RECS_WPB 8		// wavefronts per workgroup
+
+DEV void osc_init_s(const FastPtrs &g, OscS &o, int pitch)
+{
+	// wtosc_Initialize, wtosc.c:390-423 (value = transpose + basepitch)
+	o.wave = -1;
+	o.mode = A2D_OSC_OFF;
+	o.phase = 0;
+	o.p_ramping = 0;
+	ramp_init(o.a, 0);
+	ramp_init(o.p, pitch);
+	o.dphase = (unsigned)rfl((int)p2i(g.ptab, o.p.value >> 8));
+}
+
+DEV void osc_write_s(const FastPtrs &g, OscS &o, int reg, int v, int start, int dur)
+{
+	switch(reg) {
+	  case 0: {	// wtosc_Wave, wtosc.c:433-483 (the host resolved the handle; only
+			// mip-mapped waves and "off" reach this kernel)
+		int wt = 0;
+		o.wave = v;
+		if(v >= 0) {
+			const A2DWave *w = g.waves + v;
+			wt = w->type;
+			if(wt == 3 && w->size[0] > (unsigned)A2D_WTOSC_MAXLENGTH)
+				wt = 0;
+		}
+		if(wt == 3)
+			o.mode = A2D_OSC_MIPWAVE;
+		else {
+			o.wave = -1;
+			o.mode = A2D_OSC_OFF;
+		}
+		break;
+	  }
+	  case 1:	// wtosc_Pitch, wtosc.c:486-492 (host added transpose + basepitch)
+		ramp_set(o.p, v, start, dur);
+		if(!dur)
+			o.p_ramping = 1;
+		break;
+	  case 2:
+		ramp_set(o.a, v, start, dur);
+		break;
+	  case 3:	// wtosc_Phase -> wtosc_set_phase, wtosc.c:369-378
+		if(o.wave < 0)
+			o.phase = 0;
+		else {
+			const unsigned period = g.waves[o.wave].period;
+			const int ph = (int)((unsigned)v + ((((unsigned)start) * (o.dphase >> 8)) >> 8));
+			o.phase = (uint64_t)(((int64_t)ph * (int64_t)period) * 256);
+		}
+		break;
+	}
+}
+
+template<int NOSC>
+__global__ __launch_bounds__(64 * RECS_WPB)
+void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
+		const A2DVoice *__restrict__ voices, int *ustate, int *vactive,
+		const int16_t *__restrict__ wavepool, const A2DWave *__restrict__ waves,
+		const uint32_t *__restrict__ ptab, int *__restrict__ busmem)
+{
+#ifdef RECS_PROF
+	const long long t_in = __builtin_readcyclecounter();
+	long long t_win = 0, t_rec = 0;
+	int n_win = 0, n_rec = 0;
+#endif
+	const A2DParams &p = *pp;
+	const int wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	const int first = (blockIdx.x * RECS_WPB + wv) * vpw;
+	// (a wavefront past the end of the list still meets the others at the barriers)
+	const int nv = max(0, min(vpw, nlist - first));
+	// what the workgroup's wavefronts are left with at the end of a chunk: summed
+	// here before it goes to the bus (two buffers: one barrier per chunk)
+	__shared__ int part[2][RECS_WPB][RECS_FCH * 2][64];
+	__shared__ int part_off[2][RECS_WPB], part_nch[2][RECS_WPB];
+	const int nfrags = p.nfrags;
+	const int dbg = p.debug;
+	const A2DRec *__restrict__ recs = p.recs;
+	FastPtrs g = { wavepool, waves, ptab, dbg };
+
+	int ffr[A2D_MAXBATCH / 64];
+#pragma unroll
+	for(int k = 0; k < A2D_MAXBATCH / 64; ++k)
+		ffr[k] = (k * 64 + lane < nfrags) ? p.fragframes[k * 64 + lane] : 0;
+
+	// lane v keeps voice v
+	int so[NOSC][OV_NWORDS], sp[8], uu[NOSC + 1];
+	int my_off = -1, my_nch = 2, rcur = 0, rend = 0, act = 0, slot = -1;
+#pragma unroll
+	for(int o = 0; o < NOSC; ++o)
+#pragma unroll
+		for(int k = 0; k < OV_NWORDS; ++k)
+			so[o][k] = 0;
+#pragma unroll
+	for(int k = 0; k < 8; ++k)
+		sp[k] = 0;
+#pragma unroll
+	for(int o = 0; o <= NOSC; ++o)
+		uu[o] = 0;
+	if(lane < nv) {
+		slot = list[first + lane];
+		const A2DVoice &vc = voices[slot];
+		my_off = vc.out_off;
+		my_nch = vc.out_nch;
+#pragma unroll
+		for(int o = 0; o < NOSC; ++o) {
+			uu[o] = vc.unit[o];
+			const int *w = ustate + (size_t)uu[o] * A2D_USTATE;
+			so[o][OV_MODE] = w[OW_MODE]; so[o][OV_WAVE] = w[OW_WAVE]; so[o][OV_DPHASE] = w[OW_DPHASE];
+			so[o][OV_PHLO] = w[OW_PHASE_LO]; so[o][OV_PHHI] = w[OW_PHASE_HI]; so[o][OV_PRAMP] = w[OW_PRAMPING];
+#pragma unroll
+			for(int k = 0; k < 4; ++k) {
+				so[o][OV_P + k] = w[OW_P + k];
+				so[o][OV_A + k] = w[OW_A + k];
+			}
+		}
+		uu[NOSC] = vc.unit[NOSC];
+		const int *wp = ustate + (size_t)uu[NOSC] * A2D_USTATE;
+#pragma unroll
+		for(int k = 0; k < 8; ++k)
+			sp[k] = wp[k];
+		const A2DRun run = p.runs[slot];
+		rcur = run.first;
+		rend = run.first + run.count;
+		act = vactive[slot];
+	}
+
+#ifdef RECS_PROF
+	const long long t_pro = __builtin_readcyclecounter();
+#endif
+	for(int f0 = 0; f0 < nfrags; f0 += RECS_FCH) {
+		const int nf = min((int)RECS_FCH, nfrags - f0);
+		int acc0[RECS_FCH], acc1[RECS_FCH];
+#pragma unroll
+		for(int j = 0; j < RECS_FCH; ++j)
+			acc0[j] = acc1[j] = 0;
+		int cur_off = nv ? rdl(my_off, 0) : -1, cur_nch = rdl(my_nch, 0);
+		for(int v = 0; v < nv; ++v) {
+			const int voff = rdl(my_off, v);
+			if(voff != cur_off) {
+				flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+				cur_off = voff;
+				cur_nch = rdl(my_nch, v);
+			}
+			OscS os[NOSC];
+			Ramp vol, pan;
+#pragma unroll
+			for(int o = 0; o < NOSC; ++o)
+				osc_from_lanes(os[o], so[o], v);
+			vol.value = rdl(sp[0], v); vol.target = rdl(sp[1], v); vol.delta = rdl(sp[2], v); vol.timer = rdl(sp[3], v);
+			pan.value = rdl(sp[4], v); pan.target = rdl(sp[5], v); pan.delta = rdl(sp[6], v); pan.timer = rdl(sp[7], v);
+			int rc = rdl(rcur, v), active = rdl(act, v);
+			const int re = rdl(rend, v);
+			const bool me = lane == v;
+			for(int j = 0; j < nf; ++j) {
+				const int f = f0 + j;
+				const int n = frames_of(ffr, f);
+				int o0 = 0, o1 = 0;
+				// one window of the chain: frames [off, off + len) of the fragment
+				auto window = [&](int off, int len) {
+#ifdef RECS_PROF
+					const long long w0 = __builtin_readcyclecounter();
+#endif
+					const int fl = lane - off;
+					int x = osc_fragment_s(g, os[0], len, fl);
+					if(NOSC > 1)
+						x = wadd(x, osc_fragment_s(g, os[NOSC - 1], len, fl));
+					pan_fragment_s(vol, pan, x, len, fl, o0, o1);
+#ifdef RECS_PROF
+					asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+					t_win += __builtin_readcyclecounter() - w0 + (o0 & 0);
+					++n_win;
+#endif
+				};
+				uint32_t head = rc < re ? (uint32_t)rfl((int)recs[rc].head) : 0xffffffffu;
+				if((int)A2D_RFRAG(head) != f || rc >= re) {
+					// no records in this fragment: the engine called Process(0, frames)
+					// once on every unit (core.c:1875-1876)
+					if(active)
+						window(0, n);
+				} else {
+					do {
+						const int value = rfl(recs[rc].value);
+						const unsigned dur = (unsigned)rfl((int)recs[rc].dur);
+						const unsigned start = (unsigned)rfl((int)recs[rc].start);
+						const int u = (int)A2D_RUNIT(head), reg = (int)A2D_RREG(head);
+						switch(A2D_ROP(head)) {
+						  case R_SEG:
+							if(active)
+								window((int)(dur & 0xffffu), (int)(dur >> 16));
+							break;
+						  case R_INIT:
+							// (the words this kernel does not keep: wtosc's noise
+							// sample and seed)
+#pragma unroll
+							for(int o = 0; o <= NOSC; ++o)
+								if(u == o && lane < A2D_USTATE)
+									ustate[(size_t)rdl(uu[o], v) * A2D_USTATE + lane] = 0;
+#pragma unroll
+							for(int o = 0; o < NOSC; ++o)
+								if(u == o)
+									osc_init_s(g, os[o], value);
+							if(u == NOSC) {		// panmix_Initialize, panmix.c:252-284
+								ramp_init(vol, 65536);
+								ramp_init(pan, 0);
+							}
+							active = 1;
+							break;
+						  case R_WRITE:
+#pragma unroll
+							for(int o = 0; o < NOSC; ++o)
+								if(u == o)
+									osc_write_s(g, os[o], reg, value, (int)start, (int)dur);
+							if(u == NOSC) {
+								if(reg == 0)
+									ramp_set(vol, value, (int)start, (int)dur);
+								else
+									ramp_set(pan, value, (int)start, (int)dur);
+							}
+							break;
+						  case R_KILL:
+							active = 0;
+							break;
+						  default:
+							break;
+						}
+						++rc;
+						head = rc < re ? (uint32_t)rfl((int)recs[rc].head) : 0xffffffffu;
+					} while(rc < re && (int)A2D_RFRAG(head) == f);
+				}
+#pragma unroll
+				for(int jj = 0; jj < RECS_FCH; ++jj)
+					if(jj == j) {
+						acc0[jj] = wadd(acc0[jj], o0);
+						acc1[jj] = wadd(acc1[jj], o1);
+					}
+			}
+#pragma unroll
+			for(int o = 0; o < NOSC; ++o)
+				osc_to_lanes(so[o], os[o], me);
+			WRL(sp[0], vol.value); WRL(sp[1], vol.target); WRL(sp[2], vol.delta); WRL(sp[3], vol.timer);
+			WRL(sp[4], pan.value); WRL(sp[5], pan.target); WRL(sp[6], pan.delta); WRL(sp[7], pan.timer);
+			WRL(rcur, rc);
+			WRL(act, active);
+		}
+		// Sixteen thousand voices playing straight into one bus are as many atomic
+		// adds on the same 512 bytes per fragment; the workgroup sums its wavefronts'
+		// chunks in LDS first (neighbours in the list share their bus: it is sorted).
+		{
+			const int pb = (f0 / RECS_FCH) & 1;
+#pragma unroll
+			for(int j = 0; j < RECS_FCH; ++j) {
+				part[pb][wv][2 * j][lane] = acc0[j];
+				part[pb][wv][2 * j + 1][lane] = acc1[j];
+			}
+			if(lane == 0) {
+				part_off[pb][wv] = cur_off;
+				part_nch[pb][wv] = cur_nch;
+			}
+			__syncthreads();
+			// wavefront r owns row r of the chunk: fragment r / 2, channel r % 2
+			for(int row = wv; row < 2 * nf; row += RECS_WPB) {
+				int sum = 0, off = -1, nch = 2;
+				for(int w = 0; w <= RECS_WPB; ++w) {
+					const int woff = w < RECS_WPB ? part_off[pb][w] : -2;
+					if(woff != off) {
+						if(off >= 0 && sum && !(dbg & 1))
+							atomicAdd(busmem + off + ((size_t)(f0 + (row >> 1)) * nch + (row & 1)) * A2D_FRAG + lane, sum);
+						sum = 0;
+						off = woff;
+						nch = w < RECS_WPB ? part_nch[pb][w] : 2;
+					}
+					if(w < RECS_WPB && woff >= 0)
+						sum = wadd(sum, part[pb][w][row][lane]);
+				}
+			}
+		}
+	}
+
+#ifdef RECS_PROF
+	const long long t_loop = __builtin_readcyclecounter();
+#endif
+	// state out (these voices are nobody else's this batch: straight to the state array)
+	if(lane < nv) {
+#pragma unroll
+		for(int o = 0; o < NOSC; ++o) {
+			int *w = ustate + (size_t)uu[o] * A2D_USTATE;
+			w[OW_MODE] = so[o][OV_MODE]; w[OW_WAVE] = so[o][OV_WAVE]; w[OW_DPHASE] = so[o][OV_DPHASE];
+			w[OW_PHASE_LO] = so[o][OV_PHLO]; w[OW_PHASE_HI] = so[o][OV_PHHI]; w[OW_PRAMPING] = so[o][OV_PRAMP];
+#pragma unroll
+			for(int k = 0; k < 4; ++k) {
+				w[OW_P + k] = so[o][OV_P + k];
+				w[OW_A + k] = so[o][OV_A + k];
+			}
+		}
+		int *wp = ustate + (size_t)uu[NOSC] * A2D_USTATE;
+#pragma unroll
+		for(int k = 0; k < 8; ++k)
+			wp[k] = sp[k];
+		vactive[slot] = act;
+	}
+#ifdef RECS_PROF
+	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+	if((blockIdx.x == 0 || blockIdx.x == 700) && wv == 1 && lane == 0)
+		printf("k_leaf_recs<%d> block %d: %d voices x %d fragments: prologue %lld, loop %lld (of which %d windows %lld), epilogue %lld cycles\n",
+				NOSC, (int)blockIdx.x, nv, nfrags, t_pro - t_in, t_loop - t_pro, n_win, t_win,
+				(long long)__builtin_readcyclecounter() - t_loop);
+#endif
+}
+
+int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc, const int *dlist, int nlist,
+		int vpw, void *stream)
+{
+	if(nlist <= 0)
+		return 0;
+	vpw = min(max(vpw, 1), 64);
+	const int nwaves = (nlist + vpw - 1) / vpw;
+	const int nblocks = (nwaves + RECS_WPB - 1) / RECS_WPB;
+	if(nosc == 1)
+		hipLaunchKernelGGL(k_leaf_recs<1>, dim3(nblocks), dim3(64 * RECS_WPB), 0, (hipStream_t)stream,
+				dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.vactive, hp.wavepool, hp.waves,
+				hp.ptab, hp.busmem);
+	else
+		hipLaunchKernelGGL(k_leaf_recs<2>, dim3(nblocks), dim3(64 * RECS_WPB), 0, (hipStream_t)stream,
+				dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.vactive, hp.wavepool, hp.waves,
+				hp.ptab, hp.busmem);
+	return (int)hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------

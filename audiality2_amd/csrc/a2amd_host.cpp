@@ -174,6 +174,8 @@ struct HUnit {
 	// (a2amd_default_map) are caught up with in closed form when the shadow is next
 	// needed (shadow_catch_up): none of them touches this struct.
 	uint64_t shadow_time = 0;
+	long long shadow_serial = 0;	// ... as a fragment serial (the shadow stands at the START of that fragment),
+					// or -1 while it stands inside a fragment
 	unsigned dphase = 0;
 	int p_ramping = 0;
 	uint64_t phase = 0;
@@ -199,6 +201,11 @@ struct HVoice {
 	bool live = false, dying = false;
 	bool resolved = false, started = false;
 	bool listed_recs = false;	// already in a2amd_ctx::with_recs
+	uint8_t plain = 0;		// 0 not known, 1 every unit's Process is nothing or an oscillator's phase shadow
+					// (a2amd_voice_process takes its short path), 2 not so
+	uint8_t osc_mask = 0;		// ... bit k: unit k of the chain is a wtosc
+	bool mode_mix = false;		// an oscillator played something else than a mip-mapped wave at some
+					// point of the batch being recorded (its records go to the general kernel)
 	int nunits = 0;
 	int win_off = -1, win_frames = 0;
 	int win_done = 0;		// units of the chain that have processed the window in progress
@@ -266,6 +273,7 @@ struct a2amd_ctx {
 	std::vector<int> dirty_voices;		// voice mirror entries to re-upload
 	long long serial_base = 0;		// fragments rendered before this batch
 	int n_leaf_dyn = 0, static_len = 0;
+	int n_dyn_osc1 = 0, n_dyn_osc2 = 0;	// ... of n_leaf_dyn, first in the list: k_leaf_recs<1 | 2> renders them
 	int n_started_live = 0;			// voices the engine is walking
 	int walked_started = 0;			// ... of which it has walked this many in the open fragment
 	int n_noise = 0, n_cutoff_ramps = 0;
@@ -288,6 +296,8 @@ struct a2amd_ctx {
 	bool defmap_dirty = false;		// ... in some fragment since it was last zeroed
 	uint64_t walk_time = 0;			// frames of all fragments before the open one
 	unsigned prev_frames = 0;		// length of the fragment before the open one
+	std::vector<uint8_t> fraglog;		// lengths of the last 65 536 fragments, by serial & 0xffff: what a shadow
+						// that is caught up later replays (a ramping pitch has no closed form)
 
 	// fragment clock
 	bool frag_open = false;
@@ -530,62 +540,11 @@ int bus_alloc(a2amd_ctx *c, int nch)
 }
 
 // ---- lazy phase shadow ---------------------------------------------------------------
-// What wtosc_wavetable (wtosc.c:239-286) does to the phase of a settled, looped,
-// mip-mapped oscillator over k consecutive default windows of f1 .. fk frames:
-//   ph = (phase >> mm) % m;  phase = (ph + dph * f) << mm         per window
-// composes to  ((((phase >> mm) % m + dph * (F - fk)) % m) + dph * fk) << mm,  F = sum f.
-// So windows the host only marked in the default map need no per-window host work:
-// the shadow is caught up when it is next looked at.
-bool shadow_lazy_ok(const a2amd_ctx *c, const HUnit &u)
-{
-	if(u.kind != A2AMD_WTOSC)
-		return true;
-	if(u.mode == A2D_OSC_NOISE || !(u.shadow_ok && u.shadow_epoch == c->shadow_epoch))
-		return u.mode != A2D_OSC_NOISE;	// (a lost shadow stays lost; noise needs every call)
-	if(u.mode == A2D_OSC_OFF)
-		return u.p.timer == 0;		// wtosc_Off with the ramper at rest: nothing moves
-	if(u.mode != A2D_OSC_MIPWAVE || u.wave < 0)
-		return false;
-	const A2DWave &w = c->waves[u.wave].dw;
-	return (w.flags & 0x100u) && w.size[0] && u.dphase && !u.p.timer && !u.p_ramping;
-}
-
-// advance the shadow of wtosc 'u' over default windows from u.shadow_time to 'upto'
-// (a fragment boundary); 'last' = frames of the last of those windows
-void shadow_catch_up(a2amd_ctx *c, HUnit &u, uint64_t upto, unsigned last)
-{
-	if(u.kind != A2AMD_WTOSC || upto <= u.shadow_time)
-		return;
-	const uint64_t F = upto - u.shadow_time;
-	u.shadow_time = upto;
-	if(!(u.shadow_ok && u.shadow_epoch == c->shadow_epoch) || u.mode != A2D_OSC_MIPWAVE || u.wave < 0)
-		return;		// (off: nothing moves; lost shadows stay lost)
-	const A2DWave &w = c->waves[u.wave].dw;
-	if(!w.size[0])
-		return;		// (unloaded: the next real call notices, wtosc.c:168-183)
-	unsigned dph = ((u.dphase + 255) >> 8) * w.period;
-	unsigned mm = 0;
-	for(; (dph > (A2D_MAXPHINC << 8)) && (mm < A2D_MIPS - 1); ++mm)
-		dph >>= 1;
-	dph = (unsigned)(((uint64_t)u.dphase * w.period) >> mm);
-	const uint64_t m = (uint64_t)w.size[mm] << 24;
-	if(last > F)
-		last = (unsigned)F;
-	uint64_t ph = (u.phase >> mm) % m;
-	ph = (ph + (uint64_t)dph * (F - last)) % m;
-	u.phase = (ph + (uint64_t)dph * last) << mm;
-}
-
-// ... for every oscillator of voice 'vi', up to where the walk stands now
-void voice_catch_up(a2amd_ctx *c, int vi)
-{
-	HVoice &v = c->voices[vi];
-	const bool marked = c->frag_open && (size_t)vi < c->defmap.size() && c->defmap[vi];
-	const uint64_t upto = c->walk_time + (marked ? c->fragframes[c->cur_frag] : 0);
-	const unsigned last = marked ? c->fragframes[c->cur_frag] : c->prev_frames;
-	for(int k = 0; k < v.nunits; ++k)
-		shadow_catch_up(c, c->units[v.unit[k]], upto, last);
-}
+// (defined with the rest of the wtosc shadow, below a2amd_unit_write)
+bool shadow_lazy_ok(const a2amd_ctx *c, const HUnit &u);
+void shadow_catch_up(a2amd_ctx *c, HUnit &u, uint64_t upto, long long upto_serial);
+void voice_catch_up(a2amd_ctx *c, int vi);
+long long now_serial(const a2amd_ctx *c) { return c->serial_base + rec_tag(c); }
 
 // the engine-visible walk found no work for the VMs: close the fragment
 int close_fragment(a2amd_ctx *c)
@@ -615,8 +574,10 @@ int close_fragment(a2amd_ctx *c)
 				// (its oscillators stand still for this fragment: the shadows are
 				// caught up to its start and skip it)
 				voice_catch_up(c, (int)vi);
-				for(int k = 0; k < v.nunits; ++k)
+				for(int k = 0; k < v.nunits; ++k) {
 					c->units[v.unit[k]].shadow_time = c->walk_time + nframes;
+					c->units[v.unit[k]].shadow_serial = c->serial_base + f + 1;
+				}
 				A2DRec r = { A2D_HEAD(f, R_NOP, 0, 0), 0, 0, 0 };
 				if(!v.listed_recs) {
 					v.listed_recs = true;
@@ -1026,11 +987,36 @@ int upload(a2amd_ctx *c)
 			else if((v.cls == CLS_BUSDRIVER || v.cls == CLS_FBDCHAIN) && v.depth < (int)dyn_bus.size())
 				dyn_bus[v.depth].push_back(vi);
 		}
+		// Voices of the wtosc[+wtosc]->panmix classes whose records are what
+		// k_leaf_recs executes (windows, writes, births, deaths; oscillators on
+		// mip-mapped waves throughout the batch) go first, by class; the rest -
+		// filter voices, a wave of another kind somewhere in the batch - to the
+		// general kernel.
+		std::vector<int> dyn_o1, dyn_o2, dyn_rest;
+		const bool no_recs_kernel = (c->no_fast & 64) != 0;
+		for(int vi : dyn_leaf) {
+			const HVoice &v = c->voices[vi];
+			bool ok = !no_recs_kernel && (v.cls == CLS_OSCPAN || v.cls == CLS_OSC2PAN) && !v.mode_mix;
+			if(ok)
+				for(const A2DRec &r : v.recs) {
+					const unsigned op = A2D_ROP(r.head);
+					if(op != R_SEG && op != R_WRITE && op != R_INIT && op != R_KILL && op != R_NOP) {
+						ok = false;
+						break;
+					}
+				}
+			(!ok ? dyn_rest : v.cls == CLS_OSCPAN ? dyn_o1 : dyn_o2).push_back(vi);
+		}
 		// (the walk order usually has them grouped by bus already)
 		auto by_bus_dyn = [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; };
-		if(!std::is_sorted(dyn_leaf.begin(), dyn_leaf.end(), by_bus_dyn))
-			std::stable_sort(dyn_leaf.begin(), dyn_leaf.end(), by_bus_dyn);
-		std::vector<int> dyn = dyn_leaf;
+		for(std::vector<int> *l : { &dyn_o1, &dyn_o2, &dyn_rest })
+			if(!std::is_sorted(l->begin(), l->end(), by_bus_dyn))
+				std::stable_sort(l->begin(), l->end(), by_bus_dyn);
+		std::vector<int> dyn = dyn_o1;
+		dyn.insert(dyn.end(), dyn_o2.begin(), dyn_o2.end());
+		dyn.insert(dyn.end(), dyn_rest.begin(), dyn_rest.end());
+		c->n_dyn_osc1 = (int)dyn_o1.size();
+		c->n_dyn_osc2 = (int)dyn_o2.size();
 		c->n_leaf_dyn = (int)dyn_leaf.size();
 		for(size_t d = 0; d < dyn_bus.size(); ++d) {
 			c->depth_ranges[d].dyn_first = (int)dyn.size();
@@ -1234,6 +1220,7 @@ void end_batch(a2amd_ctx *c)
 		} else {
 			v.touched = -1;
 			v.listed_recs = false;
+			v.mode_mix = false;
 		}
 	}
 	c->with_recs = carry;
@@ -1369,9 +1356,20 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
-		if(c->n_leaf_dyn) {
-			if(a2d_launch_voices(c->d_params, c->d_dyn, c->n_leaf_dyn,
-					pick_vpw(c->n_leaf_dyn), c->stream))
+		for(int k = 0, at = 0; k < 2; at += k ? c->n_dyn_osc2 : c->n_dyn_osc1, ++k) {
+			const int n = k ? c->n_dyn_osc2 : c->n_dyn_osc1;
+			if(!n)
+				continue;
+			// a wavefront walks its voices one after the other, fragment by fragment:
+			// as many wavefronts as the chip holds before a wavefront gets a second voice
+			int vpw = getenv("A2AMD_RVPW") ? atoi(getenv("A2AMD_RVPW")) : (n + 8191) / 8192;
+			if(a2d_launch_leaf_recs(c->d_params, c->hparams, k + 1, c->d_dyn + at, n, vpw, c->stream))
+				return c->fail(A2AMD_EHIP, "leaf records launch failed: %s", hipGetErrorString(hipGetLastError()));
+			++c->stats.launches;
+		}
+		if(c->n_leaf_dyn - c->n_dyn_osc1 - c->n_dyn_osc2 > 0) {
+			const int n = c->n_leaf_dyn - c->n_dyn_osc1 - c->n_dyn_osc2;
+			if(a2d_launch_voices(c->d_params, c->d_dyn + c->n_dyn_osc1 + c->n_dyn_osc2, n, pick_vpw(n), c->stream))
 				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
@@ -1695,6 +1693,9 @@ int a2amd_fragment(a2amd_ctx *c, unsigned frames)
 		return c->fail(A2AMD_ESTATE, "more than max_batch=%u fragments without a render", c->cfg.max_batch);
 	c->cur_frag = c->nfrags++;
 	c->fragframes[c->cur_frag] = frames;
+	if(c->fraglog.empty())
+		c->fraglog.assign(65536, 0);
+	c->fraglog[(size_t)((c->serial_base + c->cur_frag) & 0xffff)] = (uint8_t)frames;
 	c->frag_open = true;
 	c->walked_started = 0;
 	c->building = -1;
@@ -1833,6 +1834,7 @@ int a2amd_unit_init(a2amd_ctx *c, uint64_t key, int kind, unsigned flags, int ni
 	u.voice = vi;
 	u.chainpos = v.nunits;
 	v.unit[v.nunits++] = ui;
+	v.plain = 0;
 	++v.nlive;
 	c->mudesc[ui] = A2D_DESC(kind, add ? 1 : 0, nin, nout, wired ? 1 : 0);
 	c->udesc_dirty = true;
@@ -1852,7 +1854,10 @@ int a2amd_unit_init(a2amd_ctx *c, uint64_t key, int kind, unsigned flags, int ni
 		u.wave = -1;
 		u.shadow_ok = true;
 		u.shadow_epoch = c->shadow_epoch;
-		u.shadow_time = c->walk_time;
+		// (the shadow starts with the oscillator's first window: a voice made between
+		// two walks sees the previous fragment still open, and plays no part in it)
+		u.shadow_time = ~(uint64_t)0;
+		u.shadow_serial = -1;
 		break;
 	  case A2AMD_FILTER12:	// f12_Initialize -> f12_CutOff(u, 0, 0, 0), filter12.c:141-147,203
 		ramp_init(u.cutoff, 0);
@@ -1935,6 +1940,7 @@ int a2amd_unit_deinit(a2amd_ctx *c, int ui)
 		}
 		v.dying = true;
 		v.live = false;
+		v.plain = 0;
 		if(v.own_off >= 0)
 			c->deferred_bus_free.push_back(std::make_pair(v.own_off, v.own_nch));
 		c->deferred_free_voices.push_back(u.voice);
@@ -1977,6 +1983,9 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 				const bool is = nmode == A2D_OSC_MIPWAVE || nmode == A2D_OSC_OFF;
 				if(was != is)
 					c->lists_dirty = true;
+				if(!was || !is)
+					c->voices[u.voice].mode_mix = true;
+				c->voices[u.voice].plain = 0;
 			}
 			if(u.mode == A2D_OSC_NOISE && nmode != A2D_OSC_NOISE)
 				--c->n_noise;
@@ -2018,6 +2027,7 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 			ramp_set(u.cutoff, value + transpose, (int)start, (int)dur);
 			bool is = u.cutoff.timer != 0;
 			c->n_cutoff_ramps += (int)is - (int)was;
+			c->voices[u.voice].plain = 0;
 			if(dur < 256)
 				push_rec(c, u.voice, R_F1SET, u.chainpos, 0,
 						f12_coeff(c->ptab, u.cutoff.value, c->cfg.samplerate), 0, 0);
@@ -2156,6 +2166,105 @@ static void shadow_wave(a2amd_ctx *c, HUnit &u, unsigned frames)
 	}
 }
 
+namespace {
+
+// ---- lazy phase shadow ---------------------------------------------------------------
+// What wtosc_wavetable (wtosc.c:239-286) does to the phase of a settled, looped,
+// mip-mapped oscillator over k consecutive default windows of f1 .. fk frames:
+//   ph = (phase >> mm) % m;  phase = (ph + dph * f) << mm         per window
+// composes to  ((((phase >> mm) % m + dph * (F - fk)) % m) + dph * fk) << mm,  F = sum f.
+// So windows the host only marked in the default map need no per-window host work:
+// the shadow is caught up when it is next looked at - in closed form once nothing but
+// the phase moves, fragment by fragment (their lengths are in a2amd_ctx::fraglog)
+// while the pitch still ramps.
+
+// nothing but the phase moves, and the closed form applies.  (The pitch ramper must
+// have been snapped onto its target by the a2_PrepareRamper that follows its last
+// ramping window, a2_dsp.h:130-133 - wtosc_run_pitch can leave it short of that with
+// the timer at zero, wtosc.c:91-93 - or the next a2_SetRamper starts from elsewhere.)
+bool shadow_settled(const a2amd_ctx *c, const HUnit &u)
+{
+	if(u.p.timer || u.p.delta || u.p.value != u.p.target)
+		return false;
+	if(u.mode == A2D_OSC_OFF)
+		return true;		// wtosc_Off with the ramper at rest: nothing moves at all
+	if(u.mode != A2D_OSC_MIPWAVE || u.wave < 0)
+		return false;
+	const A2DWave &w = c->waves[u.wave].dw;
+	return (w.flags & 0x100u) && w.size[0] && u.dphase && !u.p_ramping;
+}
+
+// may the host report this unit's default windows through the default map?
+bool shadow_lazy_ok(const a2amd_ctx *c, const HUnit &u)
+{
+	if(u.kind != A2AMD_WTOSC)
+		return true;
+	if(u.mode == A2D_OSC_NOISE)
+		return false;			// (every call hands the engine's RNG back advanced)
+	if(!(u.shadow_ok && u.shadow_epoch == c->shadow_epoch))
+		return true;			// (a lost shadow stays lost)
+	return u.shadow_serial >= 0;		// the shadow stands on a fragment boundary
+}
+
+// advance the shadow of wtosc 'u' over default windows from u.shadow_time to 'upto',
+// the start of fragment 'upto_serial'
+void shadow_catch_up(a2amd_ctx *c, HUnit &u, uint64_t upto, long long upto_serial)
+{
+	if(u.kind != A2AMD_WTOSC || upto <= u.shadow_time)
+		return;
+	const bool valid = u.shadow_ok && u.shadow_epoch == c->shadow_epoch && u.mode != A2D_OSC_NOISE;
+	if(valid && u.shadow_serial >= 0) {
+		// whole default windows, fragment by fragment while something but the phase moves
+		while(u.shadow_time < upto && !shadow_settled(c, u)) {
+			if(upto_serial - u.shadow_serial > 65535 || u.shadow_serial >= upto_serial) {
+				u.shadow_ok = false;	// (older than the fragment log: given up)
+				break;
+			}
+			const unsigned len = c->fraglog[(size_t)(u.shadow_serial & 0xffff)];
+			if(u.mode == A2D_OSC_OFF) {	// wtosc_Off, wtosc.c:108-126
+				ramp_prepare(u.p, (int)len);
+				ramp_run(u.p, (int)len);
+			} else
+				shadow_wave(c, u, len);
+			u.shadow_time += len;
+			++u.shadow_serial;
+		}
+		if(u.shadow_ok && u.shadow_time < upto && u.mode == A2D_OSC_MIPWAVE && u.wave >= 0 &&
+				c->waves[u.wave].dw.size[0]) {
+			// ... and the rest in one step
+			const A2DWave &w = c->waves[u.wave].dw;
+			const uint64_t F = upto - u.shadow_time;
+			unsigned last = c->fraglog[(size_t)((upto_serial - 1) & 0xffff)];
+			unsigned dph = ((u.dphase + 255) >> 8) * w.period;
+			unsigned mm = 0;
+			for(; (dph > (A2D_MAXPHINC << 8)) && (mm < A2D_MIPS - 1); ++mm)
+				dph >>= 1;
+			dph = (unsigned)(((uint64_t)u.dphase * w.period) >> mm);
+			const uint64_t m = (uint64_t)w.size[mm] << 24;
+			if(last > F)
+				last = (unsigned)F;
+			uint64_t ph = (u.phase >> mm) % m;
+			ph = (ph + (uint64_t)dph * (F - last)) % m;
+			u.phase = (ph + (uint64_t)dph * last) << mm;
+		}
+	}
+	u.shadow_time = upto;
+	u.shadow_serial = upto_serial;
+}
+
+// ... for every oscillator of voice 'vi', up to where the walk stands now
+void voice_catch_up(a2amd_ctx *c, int vi)
+{
+	HVoice &v = c->voices[vi];
+	const bool marked = c->frag_open && (size_t)vi < c->defmap.size() && c->defmap[vi];
+	const uint64_t upto = c->walk_time + (marked ? c->fragframes[c->cur_frag] : 0);
+	const long long serial = now_serial(c) + (marked ? 1 : 0);
+	for(int k = 0; k < v.nunits; ++k)
+		shadow_catch_up(c, c->units[v.unit[k]], upto, serial);
+}
+
+} // namespace
+
 int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, uint32_t *noisestate)
 {
 	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live)
@@ -2166,10 +2275,13 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 	const int vi = u.voice;
 	HVoice &v = c->voices[vi];
 	c->building = -1;
-	if(!v.resolved)
+	if(!v.resolved) {
 		resolve_out(c, v);
+		v.plain = 0;
+	}
 	if(!v.started) {
 		v.started = true;
+		v.plain = 0;
 		++c->n_started_live;
 	}
 	touch(c, vi);
@@ -2185,8 +2297,9 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 
 	if(u.kind == A2AMD_WTOSC) {
 		// windows the host only marked in the default map come first
-		shadow_catch_up(c, u, c->walk_time, c->prev_frames);
+		shadow_catch_up(c, u, c->walk_time, c->serial_base + c->cur_frag);
 		u.shadow_time = c->walk_time + offset + frames;
+		u.shadow_serial = offset + frames == c->fragframes[c->cur_frag] ? c->serial_base + c->cur_frag + 1 : -1;
 	}
 	switch(u.kind) {
 	  case A2AMD_WTOSC:
@@ -2202,6 +2315,9 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 			shadow_run_pitch(c, u, frames);
 			uint64_t end = u.phase + (uint64_t)frames * u.dphase;
 			uint64_t draws = u.dphase >= (1u << 23) ? frames : (end >> 23) - (u.phase >> 23);
+			static const bool trace = getenv("A2AMD_DEBUG_NOISE") != nullptr;	// (debugging the phase shadow
+			if(trace)								// against oracle/a2o.c's trace)
+				fprintf(stderr, "NOISE phase %llx dphase %x frames %u\n", (unsigned long long)u.phase, u.dphase, frames);
 			uint32_t st = *noisestate;
 			for(uint64_t i = 0; i < draws; ++i)
 				st = st * 1566083941u + 1u;
@@ -2225,6 +2341,8 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 					f12_coeff(c->ptab, u.cutoff.value, c->cfg.samplerate), 0, 0);
 		}
 		c->n_cutoff_ramps += (int)(u.cutoff.timer != 0) - (int)was;
+		if(was && !u.cutoff.timer)
+			v.plain = 0;	// (the ramp has arrived: the voice may be plain again)
 		break;
 	  }
 	  case A2AMD_INLINE:
@@ -2250,11 +2368,90 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 	return A2AMD_OK;
 }
 
+namespace {
+// is every unit of the voice one whose Process leaves nothing to do on the host
+// but - for a wtosc - the phase shadow?
+void classify_plain(a2amd_ctx *c, HVoice &v)
+{
+	v.plain = 2;
+	v.osc_mask = 0;
+	if(!v.live || v.dying || !v.resolved || !v.started || v.inline_pos >= 0)
+		return;
+	for(int k = 0; k < v.nunits; ++k) {
+		const HUnit &u = c->units[v.unit[k]];
+		switch(u.kind) {
+		  case A2AMD_WTOSC:
+			if(u.mode == A2D_OSC_NOISE)
+				return;
+			v.osc_mask |= (uint8_t)(1u << k);
+			break;
+		  case A2AMD_FILTER12:
+			if(u.cutoff.timer || u.cutoff.delta)
+				return;
+			break;
+		  case A2AMD_INLINE: case A2AMD_XINSERT: case A2AMD_XSINK: case A2AMD_XSOURCE:
+			return;
+		  default:
+			break;
+		}
+	}
+	v.plain = 1;
+}
+} // namespace
+
 int a2amd_voice_process(a2amd_ctx *c, int head, unsigned offset, unsigned frames, uint32_t *noisestate)
 {
 	if(head < 0 || head >= (int)c->units.size() || !c->units[head].live)
 		return c->fail(A2AMD_EINVAL, "process of dead unit %d", head);
 	const int vi = c->units[head].voice;
+	HVoice &pv = c->voices[vi];
+	if(!pv.plain)
+		classify_plain(c, pv);
+	static const int dbgw = getenv("A2AMD_DBG_WALK") ? atoi(getenv("A2AMD_DBG_WALK")) : 0;
+	if(pv.plain == 1 && !(dbgw & 1)) {
+		// The short path: one pass of bookkeeping for the whole chain (what
+		// a2amd_unit_process does unit by unit), the oscillators' shadows, and the
+		// window - unrecorded if it is the default one.
+		if(!c->frag_open || !frames || offset + frames > c->fragframes[c->cur_frag])
+			return c->fail(A2AMD_ESTATE, "process [%u,+%u) outside the open fragment", offset, frames);
+		const long long serial = c->serial_base + c->cur_frag;
+		c->building = -1;
+		if(pv.touched != serial) {
+			pv.touched = serial;
+			pv.frag_mark = pv.recs.size();
+		}
+		if(pv.walked != serial) {
+			pv.walked = serial;
+			++c->walked_started;
+		}
+		pv.win_off = (int)offset;
+		pv.win_frames = (int)frames;
+		const bool whole = offset + frames == c->fragframes[c->cur_frag];
+		bool lazy = true;
+		for(unsigned m = pv.osc_mask, k = 0; m; m >>= 1, ++k) {
+			if(!(m & 1))
+				continue;
+			HUnit &u = c->units[pv.unit[k]];
+			shadow_catch_up(c, u, c->walk_time, serial);
+			u.shadow_time = c->walk_time + offset + frames;
+			u.shadow_serial = whole ? serial + 1 : -1;
+			if(u.shadow_ok && u.shadow_epoch == c->shadow_epoch) {
+				if(u.mode == A2D_OSC_OFF) {	// wtosc_Off, wtosc.c:108-126
+					ramp_prepare(u.p, (int)frames);
+					ramp_run(u.p, (int)frames);
+				} else
+					shadow_wave(c, u, frames);
+				lazy = lazy && whole;
+			} else
+				u.shadow_ok = false;
+		}
+		if(offset == 0 && whole && pv.recs.size() == pv.frag_mark && pv.deferred.empty()) {
+			pv.default_seg = serial;
+			pv.win_done = 0;
+		} else
+			push_rec(c, vi, R_SEG, 0, 0, 0, offset | (frames << 16), 0);
+		return lazy && (size_t)vi < c->defmap.size() && !(dbgw & 2) ? 1 : 0;
+	}
 	const int n = c->voices[vi].nunits;
 	for(int k = 0; k < n; ++k) {
 		const int ui = c->voices[vi].unit[k];
@@ -2272,7 +2469,7 @@ int a2amd_voice_process(a2amd_ctx *c, int head, unsigned offset, unsigned frames
 		if(!shadow_lazy_ok(c, u) || u.xio_mode || (u.kind == A2AMD_FILTER12 && (u.cutoff.timer || u.cutoff.delta)))
 			return 0;
 	}
-	return 1;
+	return (dbgw & 2) ? 0 : 1;
 }
 
 int a2amd_voice_slot(a2amd_ctx *c, int ui)
@@ -2544,8 +2741,13 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 			}
 		}
 		HIPCHK(c, hipStreamSynchronize(c->stream));
-		if(timing)
+		if(timing) {
 			g_t[2] += now_us() - t2;
+			static const int trace = getenv("A2AMD_HOSTTIMING") ? atoi(getenv("A2AMD_HOSTTIMING")) : 0;
+			if(trace >= 2)
+				fprintf(stderr, "a2amd render: %d fragments, upload %.1f us, issue %.1f us, readback %.1f us\n",
+						c->nfrags, t1 - t0, t2 - t1, now_us() - t2);
+		}
 		unsigned pos = 0;
 		for(int f = 0; f < c->nfrags; ++f) {
 			for(int ch = 0; ch < nch; ++ch)

@@ -876,7 +876,7 @@ static void amd_drv_process(A2P_audiodriver *drv, unsigned frames)
 	double t0 = 0, t1 = 0;
 	if(timing_on < 0)
 	{
-		timing_on = getenv("A2AMD_HOSTTIMING") != NULL;
+		timing_on = getenv("A2AMD_HOSTTIMING") ? atoi(getenv("A2AMD_HOSTTIMING")) : 0;
 		if(timing_on)
 			atexit(timing_dump);
 	}
@@ -908,9 +908,13 @@ static void amd_drv_process(A2P_audiodriver *drv, unsigned frames)
 	hs->in_buffer = hs->batching = 0;
 	if(timing_on)
 	{
+		const double t2 = now_s();
 		t_walk += t1 - t0;
-		t_flush += now_s() - t1;
+		t_flush += t2 - t1;
 		n_buffers += 1;
+		if(timing_on >= 2)
+			fprintf(stderr, "a2amd buffer: %u frames, walk %.1f us, render + delivery %.1f us\n", frames,
+					(t1 - t0) * 1e6, (t2 - t1) * 1e6);
 	}
 }
 

@@ -111,6 +111,12 @@ class Backend:
         self._render = fn("render", i32, vp, u32, C.POINTER(C.POINTER(C.c_int32)), u32)
         self._set_pt = fn("set_pitch_table", i32, vp, C.POINTER(C.c_uint32))
         self._get_pt = fn("get_pitch_table", i32, vp, C.POINTER(C.c_uint32))
+        # the host walk's short cuts (the product library only; the checker has none)
+        self.has_walk = hasattr(lib, prefix + "voice_process")
+        if self.has_walk:
+            self._voice_process = fn("voice_process", i32, vp, i32, u32, u32, C.POINTER(C.c_uint32))
+            self._voice_slot = fn("voice_slot", i32, vp, i32)
+            self._default_map = fn("default_map", C.POINTER(C.c_uint8), vp, C.POINTER(u32))
         cfg = a2amd_config(C.sizeof(a2amd_config), samplerate, basepitch, channels,
                            device, max_batch, stream)
         self.ctx = vp()
@@ -163,6 +169,26 @@ class Backend:
         return self._chk(self._unit_process(self.ctx, unit, offset, frames,
                                             C.byref(self.noise) if use_noise else None),
                          "unit_process")
+
+    def voice_process(self, units, offset, frames):
+        """One window of a whole voice (units = its chain): a2amd_voice_process where the
+        library has it, else unit by unit.  Returns 1 when the voice's default windows may
+        be reported through mark_default() from the next fragment on."""
+        if self.has_walk:
+            return self._chk(self._voice_process(self.ctx, units[0], offset, frames, C.byref(self.noise)),
+                             "voice_process")
+        for u in units:
+            self.unit_process(u, offset, frames)
+        return 0
+
+    def mark_default(self, units):
+        """The voice got exactly the default window in the open fragment: one byte store
+        into the default map (a2amd_default_map)."""
+        n = C.c_uint(0)
+        m = self._default_map(self.ctx, C.byref(n))
+        slot = self._chk(self._voice_slot(self.ctx, units[0]), "voice_slot")
+        assert m and slot < n.value
+        m[slot] = 1
 
     def inline_end(self, unit):
         return self._chk(self._inline_end(self.ctx, unit), "inline_end")

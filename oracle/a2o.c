@@ -1101,6 +1101,8 @@ static void wtosc_noise(a2o_ctx *c, a2o_unit *o, int32_t *out, unsigned offset,
 	unsigned s, end = offset + frames;
 	wtosc_run_pitch(c, o, frames);
 	ramp_prepare(&o->a, (int)frames);
+	if(getenv("A2AMD_DEBUG_NOISE"))		/* (to compare with the product's host-side phase shadow) */
+		fprintf(stderr, "NOISE phase %llx dphase %x frames %u\n", (unsigned long long)o->phase, o->dphase, frames);
 	for(s = offset; s < end; ++s)
 	{
 		uint64_t nph = o->phase + o->dphase;

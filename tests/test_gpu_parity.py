@@ -244,6 +244,159 @@ def test_fm_leaf_kernel_executes_records(oracle_lib, monkeypatch, vpw):
     assert first_diff(got, want) is None
 
 
+def _wt_script(be, chain, nvoices=300, batches=3, bfrags=16, seed=11, groups=0, walk=False, noise=False):
+    """Wavetable voices the way a script drives them (BASELINE variants 2b / 3b):
+    control writes between sub-fragment windows - pitch, amplitude, pan, volume
+    ramps of all lengths, phase resets, switches between mip-mapped waves and off
+    - voices born in the middle of a fragment and voices dying, under the root
+    and under delay groups.  walk=True: through the host walk's short cuts
+    (a2amd_voice_process per window, a byte in the default map for a default
+    window once the library allows it) where the backend has them.  noise=True:
+    oscillators also switch to the noise generator and back - how many draws of
+    the engine's one RNG a window takes depends on the phase the oscillator had
+    reached as a wavetable oscillator (the host's phase shadow)."""
+    rng = np.random.default_rng(seed)
+    quick = {}
+
+    def window(units, off, n):
+        if walk:
+            quick[units[0]] = be.voice_process(units, off, n)
+        else:
+            for u in units:
+                be.unit_process(u, off, n)
+
+    def default(units):
+        if walk and quick.get(units[0]) == 1:
+            be.mark_default(units)
+        else:
+            window(units, 0, 64)
+
+    sc = synth.Scene(be)
+    sc.root()
+    homes = [sc.add_group() for _ in range(groups)] or [None]
+    for g in homes:
+        sc.add_voices(nvoices // len(homes), chain=chain, group=g, total=nvoices)
+    nosc = 2 if chain.startswith("osc2") else 1
+    lists = [sc.leaves] + [g["leaves"] for g in sc.groups]
+    chunks = []
+    frag = 0
+    for _ in range(batches):
+        for _ in range(bfrags):
+            frag += 1
+            nall = sum(len(l) for l in lists)
+            busy = set(int(k) for k in rng.choice(nall, nall // 4, replace=False))
+            newborn = None
+            if frag % 3 == 2:
+                g = homes[frag % len(homes)]
+                dst = sc.leaves if g is None else g["leaves"]
+                sc.add_voices(1, chain=chain, group=g, total=nvoices)
+                newborn = (dst[-1], int(rng.integers(1, 63)))
+            counter = [0]
+
+            def leaf(units):
+                k = counter[0]
+                counter[0] += 1
+                pan = units[-1]
+                if newborn and units is newborn[0]:
+                    window(units, newborn[1], 64 - newborn[1])
+                    return
+                if k not in busy:
+                    default(units)
+                    return
+                cut = sorted(set(int(c) for c in rng.integers(1, 64, int(rng.integers(1, 4)))))
+                at = 0
+                for c in cut + [64]:
+                    dur = int(rng.choice([0, 100, 3000, 70000, 2000000]))
+                    osc = units[int(rng.integers(0, nosc))]
+                    reg = int(rng.integers(0, 4))
+                    if reg == 0:        # off, or another mip-mapped wave
+                        val = int(rng.choice([-1] + [sc.wave_ids[i] for i in (0, 3, 7, 11, 23)] +
+                                             ([sc.noise_id] * 3 if noise else [])))
+                    elif reg == 1:
+                        val = synth.fix(float(rng.uniform(-3, 3)))
+                    elif reg == 2:
+                        val = synth.fix(float(rng.uniform(0, 1.5)))
+                    else:
+                        val = int(rng.integers(0, 65536))
+                    be.unit_write(osc, reg, val, int(rng.integers(0, 256)), dur)
+                    if rng.random() < 0.4:
+                        be.unit_write(pan, int(rng.integers(0, 2)), synth.fix(float(rng.uniform(-1.5, 1.5))), 0, dur)
+                    window(units, at, c - at)
+                    at = c
+
+            be.fragment(64)
+            be.unit_process(sc.rootv[0], 0, 64)
+            for g in sc.groups:
+                be.unit_process(g["units"][0], 0, 64)
+                for units in g["leaves"]:
+                    leaf(units)
+                be.inline_end(g["units"][0])
+                be.unit_process(g["units"][1], 0, 64)
+                be.unit_process(g["units"][2], 0, 64)
+            for units in sc.leaves:
+                leaf(units)
+            be.inline_end(sc.rootv[0])
+            be.unit_process(sc.rootv[1], 0, 64)
+            be.unit_process(sc.rootv[2], 0, 64)
+            if frag % 4 == 3:       # ... and one dies
+                l = lists[int(rng.integers(0, len(lists)))]
+                if len(l) > 4:
+                    k = int(rng.integers(0, len(l)))
+                    for u in l[k]:
+                        be.unit_deinit(u)
+                    quick.pop(l[k][0], None)
+                    del l[k]
+        chunks.append(be.render(bfrags * 64))
+    return np.concatenate(chunks, axis=1)
+
+
+@pytest.mark.parametrize("chain,groups", [("osc-pan", 0), ("osc2-pan", 3), ("osc-filter-pan", 0)])
+@pytest.mark.parametrize("bfrags", [1, 16])
+def test_host_walk_short_cuts_match_oracle(oracle_lib, chain, groups, bfrags):
+    """a2amd_voice_process + a2amd_default_map (what the drop-in's Process callbacks
+    use): whole-voice windows, default windows reported by one byte store also
+    while the voice's pitch is still ramping (the phase shadow replays those
+    fragments when it is next needed), against the oracle driven unit by unit."""
+    gpu = make_gpu(max_batch=16)
+    got = _wt_script(gpu, chain, groups=groups, bfrags=bfrags, batches=48 // bfrags, walk=True, noise=True)
+    gpu.close()
+    ora = make_oracle(oracle_lib)
+    want = _wt_script(ora, chain, groups=groups, bfrags=bfrags, batches=48 // bfrags, walk=True, noise=True)
+    ora.close()
+    assert want.any()
+    assert first_diff(got, want) is None
+
+
+@pytest.mark.parametrize("chain,groups", [("osc-pan", 0), ("osc2-pan", 0), ("osc2-pan", 3), ("osc-filter-pan", 0)])
+@pytest.mark.parametrize("rvpw", [1, 5, 64])
+def test_wavetable_leaf_kernel_executes_records(oracle_lib, monkeypatch, chain, groups, rvpw):
+    """k_leaf_recs: wtosc[+wtosc]->panmix voices that carry records in a batch
+    (writes between windows, windows inside a fragment, births, deaths) are
+    rendered by the records-executing leaf kernel, not the general one (filter
+    voices still are); with one, a few and 64 voices per wavefront."""
+    monkeypatch.setenv("A2AMD_RVPW", str(rvpw))
+    gpu = make_gpu(max_batch=16)
+    got = _wt_script(gpu, chain, groups=groups)
+    gpu.close()
+    ora = make_oracle(oracle_lib)
+    want = _wt_script(ora, chain, groups=groups)
+    ora.close()
+    assert want.any()
+    assert first_diff(got, want) is None
+
+
+def test_wavetable_records_kernel_matches_general_kernel(monkeypatch):
+    """... and A/B against the general kernel on the same script at a size the
+    oracle would take long over (A2AMD_NO_FAST=64 sends the records to k_voices)."""
+    outs = []
+    for no in ("0", "64"):
+        monkeypatch.setenv("A2AMD_NO_FAST", no)
+        gpu = make_gpu(max_batch=64)
+        outs.append(_wt_script(gpu, "osc2-pan", nvoices=6000, batches=2, bfrags=64, groups=8))
+        gpu.close()
+    assert outs[0].any() and first_diff(outs[0], outs[1]) is None
+
+
 def test_wave_drop_and_pool_reuse(oracle_lib):
     """Waves come and go (a2_UploadWave / a2_Release while oscillators play
     them): a dropped wave silences its oscillators, its region of the device

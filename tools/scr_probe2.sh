@@ -1,0 +1,8 @@
+# per-buffer / per-render host timing trace of the engine + drop-in (tail = steady state)
+cd $GRAFT_REPO_ROOT/tests/a2s
+B=../../oracle/_ref/ref_bench
+U=../../audiality2_amd/liba2amd_units.so
+for BUF in 4096 64; do
+echo "== ${PROG:-OscPanScripted} ${V:-16384} buffer $BUF"
+A2REF_BUFFER=$BUF A2AMD_HOSTTIMING=2 LD_PRELOAD=$U timeout 200 $B bench.a2s ${PROG:-OscPanScripted} ${V:-16384} 512 1 2>&1 | grep -v "^a2amd units\|^a2amd host" | tail -7
+done
