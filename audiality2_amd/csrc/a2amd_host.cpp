@@ -163,19 +163,17 @@ template<class T> struct DevBuf {
 struct HUnit {
 	// --- what a Process call of a wtosc / any unit reads and writes: one cache line ---
 	bool live = false;
-	bool shadow_ok = true;
 	int kind = 0;
 	int voice = -1, chainpos = 0;
-	// wtosc shadow: enough of A2_wtosc to count noise draws on the host
+	// wtosc: what the launch classes and the drop-in need to know of A2_wtosc at all
+	// times - which Process variant is installed (wtosc.c:433-483) ...
 	int mode = A2D_OSC_OFF, wave = -1;
-	unsigned shadow_epoch = 0;	// == ctx epoch while every Process call came through unit_process
-	// wtosc: the walk time (frames since the context opened) up to which the shadow below
-	// has been advanced.  Windows the host reported through the default map
-	// (a2amd_default_map) are caught up with in closed form when the shadow is next
-	// needed (shadow_catch_up): none of them touches this struct.
-	uint64_t shadow_time = 0;
-	long long shadow_serial = 0;	// ... as a fragment serial (the shadow stands at the START of that fragment),
-					// or -1 while it stands inside a fragment
+	// ... and, ONLY while that is wtosc_Noise, enough of the rest to count the draws a
+	// window takes from the engine's one RNG (wtosc.c:129-152): phase, increment, pitch
+	// ramper.  In every other mode these fields are stale - the device's unit state is
+	// the authority - and are rebuilt when the oscillator is switched to noise
+	// (shadow_rebuild: the state the device was left with by the last batch + this
+	// batch's records of the voice so far).
 	unsigned dphase = 0;
 	int p_ramping = 0;
 	uint64_t phase = 0;
@@ -201,9 +199,8 @@ struct HVoice {
 	bool live = false, dying = false;
 	bool resolved = false, started = false;
 	bool listed_recs = false;	// already in a2amd_ctx::with_recs
-	uint8_t plain = 0;		// 0 not known, 1 every unit's Process is nothing or an oscillator's phase shadow
-					// (a2amd_voice_process takes its short path), 2 not so
-	uint8_t osc_mask = 0;		// ... bit k: unit k of the chain is a wtosc
+	uint8_t plain = 0;		// 0 not known, 1 no unit's Process leaves anything to do on the host but note
+					// the window (a2amd_voice_process takes its short path), 2 not so
 	bool mode_mix = false;		// an oscillator played something else than a mip-mapped wave at some
 					// point of the batch being recorded (its records go to the general kernel)
 	int nunits = 0;
@@ -286,7 +283,8 @@ struct a2amd_ctx {
 	bool root_clean = false;		// ... and the root's own bus
 	bool capturing = false;			// issue_kernels is being captured into a graph
 	int n_clients = 0;			// units whose clients are served (a2amd_unit_clients mode != 0)
-	unsigned shadow_epoch = 0;
+	std::vector<int32_t> snap_ustate, snap_vactive;	// unit states / voice liveness as the last batch left them
+	bool snap_valid = false;			// (fetched when an oscillator is switched to noise)
 	// The default map: one byte per voice slot, set by the HOST for a voice that
 	// received exactly the engine's default window (Process(0, all frames) on every
 	// unit, nothing else) in the open fragment - the one-store-per-voice fast path of
@@ -296,8 +294,6 @@ struct a2amd_ctx {
 	bool defmap_dirty = false;		// ... in some fragment since it was last zeroed
 	uint64_t walk_time = 0;			// frames of all fragments before the open one
 	unsigned prev_frames = 0;		// length of the fragment before the open one
-	std::vector<uint8_t> fraglog;		// lengths of the last 65 536 fragments, by serial & 0xffff: what a shadow
-						// that is caught up later replays (a ramping pitch has no closed form)
 
 	// fragment clock
 	bool frag_open = false;
@@ -468,37 +464,35 @@ void touch(a2amd_ctx *c, int vi)
 	}
 }
 
-void voice_catch_up(a2amd_ctx *c, int vi);
+// The windows of the open fragment that were left unrecorded so far - the voice's
+// default window, noted in HVoice::default_seg or by the host in the default map -
+// become records: something else follows in the same fragment after all.
+void spell_out_pending(a2amd_ctx *c, int vi)
+{
+	HVoice &dv = c->voices[vi];
+	if(c->frag_open && c->defmap_used && (size_t)vi < c->defmap.size() && c->defmap[vi]) {
+		c->defmap[vi] = 0;
+		dv.default_seg = c->serial_base + c->cur_frag;
+		if(dv.walked != c->serial_base + c->cur_frag) {
+			dv.walked = c->serial_base + c->cur_frag;
+			++c->walked_started;
+		}
+	}
+	if(dv.default_seg == c->serial_base + rec_tag(c)) {
+		dv.default_seg = -1;
+		A2DRec seg = { A2D_HEAD(rec_tag(c), R_SEG, 0, 0), 0, (unsigned)c->fragframes[rec_tag(c)] << 16, 0 };
+		if(!dv.listed_recs) {
+			dv.listed_recs = true;
+			c->with_recs.push_back(vi);
+		}
+		dv.recs.push_back(seg);
+	}
+}
 
 void push_rec(a2amd_ctx *c, int vi, int op, int unit, int reg, int value, unsigned dur, unsigned start)
 {
 	touch(c, vi);
-	{
-		HVoice &dv = c->voices[vi];
-		if(c->frag_open && c->defmap_used && (size_t)vi < c->defmap.size() && c->defmap[vi]) {
-			// the host marked this voice's default window in the map and now
-			// something follows in the same fragment after all: the mark
-			// becomes the ordinary bookkeeping
-			voice_catch_up(c, vi);
-			c->defmap[vi] = 0;
-			dv.default_seg = c->serial_base + c->cur_frag;
-			if(dv.walked != c->serial_base + c->cur_frag) {
-				dv.walked = c->serial_base + c->cur_frag;
-				++c->walked_started;
-			}
-		}
-		if(dv.default_seg == c->serial_base + rec_tag(c)) {
-			// the default window of this fragment was left unrecorded; now
-			// something follows it, so it has to be spelled out first
-			dv.default_seg = -1;
-			A2DRec seg = { A2D_HEAD(rec_tag(c), R_SEG, 0, 0), 0, (unsigned)c->fragframes[rec_tag(c)] << 16, 0 };
-			if(!dv.listed_recs) {
-				dv.listed_recs = true;
-				c->with_recs.push_back(vi);
-			}
-			dv.recs.push_back(seg);
-		}
-	}
+	spell_out_pending(c, vi);
 	A2DRec r;
 	r.head = A2D_HEAD(rec_tag(c), op, unit, reg);
 	r.value = value;
@@ -539,11 +533,6 @@ int bus_alloc(a2amd_ctx *c, int nch)
 	return (int)off;
 }
 
-// ---- lazy phase shadow ---------------------------------------------------------------
-// (defined with the rest of the wtosc shadow, below a2amd_unit_write)
-bool shadow_lazy_ok(const a2amd_ctx *c, const HUnit &u);
-void shadow_catch_up(a2amd_ctx *c, HUnit &u, uint64_t upto, long long upto_serial);
-void voice_catch_up(a2amd_ctx *c, int vi);
 long long now_serial(const a2amd_ctx *c) { return c->serial_base + rec_tag(c); }
 
 // the engine-visible walk found no work for the VMs: close the fragment
@@ -571,13 +560,6 @@ int close_fragment(a2amd_ctx *c)
 				continue;	// (walked: the host marked its default window)
 			if(v.live && v.started && !v.dying && v.walked != c->serial_base + f &&
 					v.touched != c->serial_base + f) {
-				// (its oscillators stand still for this fragment: the shadows are
-				// caught up to its start and skip it)
-				voice_catch_up(c, (int)vi);
-				for(int k = 0; k < v.nunits; ++k) {
-					c->units[v.unit[k]].shadow_time = c->walk_time + nframes;
-					c->units[v.unit[k]].shadow_serial = c->serial_base + f + 1;
-				}
 				A2DRec r = { A2D_HEAD(f, R_NOP, 0, 0), 0, 0, 0 };
 				if(!v.listed_recs) {
 					v.listed_recs = true;
@@ -1693,9 +1675,6 @@ int a2amd_fragment(a2amd_ctx *c, unsigned frames)
 		return c->fail(A2AMD_ESTATE, "more than max_batch=%u fragments without a render", c->cfg.max_batch);
 	c->cur_frag = c->nfrags++;
 	c->fragframes[c->cur_frag] = frames;
-	if(c->fraglog.empty())
-		c->fraglog.assign(65536, 0);
-	c->fraglog[(size_t)((c->serial_base + c->cur_frag) & 0xffff)] = (uint8_t)frames;
 	c->frag_open = true;
 	c->walked_started = 0;
 	c->building = -1;
@@ -1720,8 +1699,6 @@ int a2amd_fragment_repeat(a2amd_ctx *c, unsigned frames, unsigned count)
 	if(c->n_clients)
 		return c->fail(A2AMD_EUNSUPPORTED, "fragment_repeat with clients on %d xinsert / xsink / xsource "
 				"unit(s): their callbacks need every window", c->n_clients);
-	if(count)
-		++c->shadow_epoch;	// oscillator phases advance without the host seeing it
 	for(unsigned i = 0; i < count; ++i) {
 		if(int r = a2amd_fragment(c, frames))
 			return r;
@@ -1852,12 +1829,6 @@ int a2amd_unit_init(a2amd_ctx *c, uint64_t key, int kind, unsigned flags, int ni
 		u.p_ramping = 0;
 		u.mode = A2D_OSC_OFF;
 		u.wave = -1;
-		u.shadow_ok = true;
-		u.shadow_epoch = c->shadow_epoch;
-		// (the shadow starts with the oscillator's first window: a voice made between
-		// two walks sees the previous fragment still open, and plays no part in it)
-		u.shadow_time = ~(uint64_t)0;
-		u.shadow_serial = -1;
 		break;
 	  case A2AMD_FILTER12:	// f12_Initialize -> f12_CutOff(u, 0, 0, 0), filter12.c:141-147,203
 		ramp_init(u.cutoff, 0);
@@ -1950,6 +1921,8 @@ int a2amd_unit_deinit(a2amd_ctx *c, int ui)
 	return A2AMD_OK;
 }
 
+static int shadow_rebuild(a2amd_ctx *c, int ui);
+
 int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, unsigned dur, int transpose)
 {
 	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live)
@@ -1957,8 +1930,6 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 	HUnit &u = c->units[ui];
 	c->building = -1;
 	start &= 255;		// a2_VoiceControl, core.c:148
-	if(u.kind == A2AMD_WTOSC)
-		voice_catch_up(c, u.voice);
 	switch(u.kind) {
 	  case A2AMD_WTOSC:
 		switch(reg) {
@@ -1973,9 +1944,9 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 			}
 			int nmode = wt == A2AMD_WNOISE ? A2D_OSC_NOISE : wt == A2AMD_WWAVE ? A2D_OSC_WAVE :
 					wt == A2AMD_WMIPWAVE ? A2D_OSC_MIPWAVE : A2D_OSC_OFF;
-			if(nmode == A2D_OSC_NOISE && !(u.shadow_ok && u.shadow_epoch == c->shadow_epoch))
-				return c->fail(A2AMD_EUNSUPPORTED, "oscillator switched to noise after rendering through "
-						"fragment_repeat/replay: its phase was not shadowed on the host");
+			if(nmode == A2D_OSC_NOISE && u.mode != A2D_OSC_NOISE)
+				if(int r = shadow_rebuild(c, ui))	// from here on the host counts its draws
+					return r;
 			{
 				// the wavetable leaf kernels only know mip-mapped waves (and "off"): a
 				// voice that moves between the two kinds changes its launch class
@@ -2166,104 +2137,160 @@ static void shadow_wave(a2amd_ctx *c, HUnit &u, unsigned frames)
 	}
 }
 
-namespace {
-
-// ---- lazy phase shadow ---------------------------------------------------------------
-// What wtosc_wavetable (wtosc.c:239-286) does to the phase of a settled, looped,
-// mip-mapped oscillator over k consecutive default windows of f1 .. fk frames:
-//   ph = (phase >> mm) % m;  phase = (ph + dph * f) << mm         per window
-// composes to  ((((phase >> mm) % m + dph * (F - fk)) % m) + dph * fk) << mm,  F = sum f.
-// So windows the host only marked in the default map need no per-window host work:
-// the shadow is caught up when it is next looked at - in closed form once nothing but
-// the phase moves, fragment by fragment (their lengths are in a2amd_ctx::fraglog)
-// while the pitch still ramps.
-
-// nothing but the phase moves, and the closed form applies.  (The pitch ramper must
-// have been snapped onto its target by the a2_PrepareRamper that follows its last
-// ramping window, a2_dsp.h:130-133 - wtosc_run_pitch can leave it short of that with
-// the timer at zero, wtosc.c:91-93 - or the next a2_SetRamper starts from elsewhere.)
-bool shadow_settled(const a2amd_ctx *c, const HUnit &u)
+// one window of a wtosc as far as phase and pitch go (any Process variant)
+static void shadow_window(a2amd_ctx *c, HUnit &u, unsigned frames)
 {
-	if(u.p.timer || u.p.delta || u.p.value != u.p.target)
-		return false;
-	if(u.mode == A2D_OSC_OFF)
-		return true;		// wtosc_Off with the ramper at rest: nothing moves at all
-	if(u.mode != A2D_OSC_MIPWAVE || u.wave < 0)
-		return false;
-	const A2DWave &w = c->waves[u.wave].dw;
-	return (w.flags & 0x100u) && w.size[0] && u.dphase && !u.p_ramping;
+	switch(u.mode) {
+	  case A2D_OSC_OFF:	// wtosc_Off, wtosc.c:108-126
+		ramp_prepare(u.p, (int)frames);
+		ramp_run(u.p, (int)frames);
+		break;
+	  case A2D_OSC_NOISE:	// wtosc_noise, wtosc.c:129-152
+		shadow_run_pitch(c, u, frames);
+		u.phase += (uint64_t)frames * u.dphase;
+		break;
+	  default:
+		if(u.wave >= 0)
+			shadow_wave(c, u, frames);
+		break;
+	}
 }
 
-// may the host report this unit's default windows through the default map?
-bool shadow_lazy_ok(const a2amd_ctx *c, const HUnit &u)
+// which Process variant wtosc_Wave (wtosc.c:433-483) installs for wave slot 'value'
+static int wave_mode(const a2amd_ctx *c, int value, int *id)
 {
-	if(u.kind != A2AMD_WTOSC)
-		return true;
-	if(u.mode == A2D_OSC_NOISE)
-		return false;			// (every call hands the engine's RNG back advanced)
-	if(!(u.shadow_ok && u.shadow_epoch == c->shadow_epoch))
-		return true;			// (a lost shadow stays lost)
-	return u.shadow_serial >= 0;		// the shadow stands on a fragment boundary
+	int wt = A2AMD_WOFF;
+	*id = -1;
+	if(value >= 0 && value < (int)c->waves.size() && c->waves[value].live) {
+		*id = value;
+		wt = c->waves[value].dw.type;
+		if((wt == A2AMD_WWAVE || wt == A2AMD_WMIPWAVE) && c->waves[value].dw.size[0] > (unsigned)A2D_WTOSC_MAXLENGTH)
+			wt = A2AMD_WOFF;
+	}
+	return wt == A2AMD_WNOISE ? A2D_OSC_NOISE : wt == A2AMD_WWAVE ? A2D_OSC_WAVE :
+			wt == A2AMD_WMIPWAVE ? A2D_OSC_MIPWAVE : A2D_OSC_OFF;
 }
 
-// advance the shadow of wtosc 'u' over default windows from u.shadow_time to 'upto',
-// the start of fragment 'upto_serial'
-void shadow_catch_up(a2amd_ctx *c, HUnit &u, uint64_t upto, long long upto_serial)
+// ---- the oscillator state when it is needed on the host ----------------------------------
+// The engine-global noise generator is shared by every noise oscillator and the VM's RAND
+// instructions, so a window of a noise oscillator has to hand it back advanced by the right
+// number of draws (a2amd_unit_process), and that number depends on the oscillator's phase
+// and pitch - which, for an oscillator that has been playing a wave, only the device knows
+// (scripts do switch oscillators from a wave to noise: benchmark/k2epilogue.a2s).  Round 1
+// and the first half of round 2 shadowed every oscillator's phase on the host, window by
+// window; that was a fifth of the engine thread's time with scripted voices.  Now nothing is
+// shadowed while a wave plays.  When an oscillator is switched to noise, its state is
+// rebuilt: the unit state words the device was left with by the last batch (one device to
+// host copy of the state array per batch in which that happens), advanced over this batch's
+// records of the voice up to now - the same arithmetic the kernels will run on them.
+static int shadow_rebuild(a2amd_ctx *c, int ui)
 {
-	if(u.kind != A2AMD_WTOSC || upto <= u.shadow_time)
-		return;
-	const bool valid = u.shadow_ok && u.shadow_epoch == c->shadow_epoch && u.mode != A2D_OSC_NOISE;
-	if(valid && u.shadow_serial >= 0) {
-		// whole default windows, fragment by fragment while something but the phase moves
-		while(u.shadow_time < upto && !shadow_settled(c, u)) {
-			if(upto_serial - u.shadow_serial > 65535 || u.shadow_serial >= upto_serial) {
-				u.shadow_ok = false;	// (older than the fragment log: given up)
+	HUnit &u = c->units[ui];
+	const int vi = u.voice;
+	spell_out_pending(c, vi);
+	if(!c->snap_valid) {
+		use_device(c);
+		const size_t nu = std::min(c->units.size(), c->d_ustate.cap), nv = std::min(c->voices.size(), c->d_vactive.cap);
+		c->snap_ustate.assign(nu * A2D_USTATE, 0);
+		c->snap_vactive.assign(nv, 0);
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		if(nu)
+			HIPCHK(c, hipMemcpy(c->snap_ustate.data(), c->d_ustate.d, nu * A2D_USTATE * sizeof(int32_t),
+					hipMemcpyDeviceToHost));
+		if(nv)
+			HIPCHK(c, hipMemcpy(c->snap_vactive.data(), c->d_vactive.d, nv * sizeof(int32_t), hipMemcpyDeviceToHost));
+		c->snap_valid = true;
+	}
+	HUnit t = u;		// (its own copy: mode and wave as they were when the batch began)
+	t.mode = A2D_OSC_OFF;
+	t.wave = -1;
+	t.dphase = 0;
+	t.p_ramping = 0;
+	t.phase = 0;
+	t.p = Ramp{ 0, 0, 0, 0 };
+	bool active = false;
+	if((size_t)(ui + 1) * A2D_USTATE <= c->snap_ustate.size()) {
+		const int32_t *w = &c->snap_ustate[(size_t)ui * A2D_USTATE];
+		t.mode = w[OW_MODE];
+		t.wave = w[OW_WAVE];
+		t.dphase = (unsigned)w[OW_DPHASE];
+		t.phase = (uint64_t)(uint32_t)w[OW_PHASE_LO] | ((uint64_t)(uint32_t)w[OW_PHASE_HI] << 32);
+		t.p_ramping = w[OW_PRAMPING];
+		t.p = Ramp{ w[OW_P], w[OW_P + 1], w[OW_P + 2], w[OW_P + 3] };
+		if(t.wave >= (int)c->waves.size())
+			t.wave = -1;
+	}
+	if((size_t)vi < c->snap_vactive.size())
+		active = c->snap_vactive[vi] != 0;
+	// this batch's fragments up to the open one, the way k_voices executes them
+	const HVoice &v = c->voices[vi];
+	const int upto = rec_tag(c);
+	size_t r = 0;
+	for(int f = 0; f <= upto && f < A2D_MAXBATCH; ++f) {
+		if(!(r < v.recs.size() && (int)A2D_RFRAG(v.recs[r].head) == f)) {
+			// no records: the default window - but not of the open fragment (the voice's
+			// turn has not come, or its window so far would have been spelled out above)
+			if(active && f < upto)
+				shadow_window(c, t, c->fragframes[f]);
+			continue;
+		}
+		for(; r < v.recs.size() && (int)A2D_RFRAG(v.recs[r].head) == f; ++r) {
+			const A2DRec &rec = v.recs[r];
+			const bool mine = (int)A2D_RUNIT(rec.head) == u.chainpos;
+			switch(A2D_ROP(rec.head)) {
+			  case R_SEG:
+				if(active)
+					shadow_window(c, t, rec.dur >> 16);
+				break;
+			  case R_INIT:
+				active = true;
+				if(mine) {	// wtosc_Initialize, wtosc.c:390-423
+					ramp_init(t.p, rec.value);
+					t.dphase = p2i(c->ptab, t.p.value >> 8);
+					t.phase = 0;
+					t.p_ramping = 0;
+					t.mode = A2D_OSC_OFF;
+					t.wave = -1;
+				}
+				break;
+			  case R_KILL:
+				active = false;
+				break;
+			  case R_WRITE:
+				if(!mine)
+					break;
+				switch(A2D_RREG(rec.head)) {
+				  case 0:
+					t.mode = wave_mode(c, rec.value, &t.wave);
+					if(t.mode == A2D_OSC_OFF)
+						t.wave = -1;
+					break;
+				  case 1:	// wtosc_Pitch, wtosc.c:486-492 (transpose and base pitch are in the record)
+					ramp_set(t.p, rec.value, (int)rec.start, (int)rec.dur);
+					if(!rec.dur)
+						t.p_ramping = 1;
+					break;
+				  case 3:	// wtosc_set_phase, wtosc.c:369-378
+					if(t.wave < 0)
+						t.phase = 0;
+					else {
+						int ph = (int)((unsigned)rec.value + ((rec.start * (t.dphase >> 8)) >> 8));
+						t.phase = (uint64_t)(((int64_t)ph * (int64_t)c->waves[t.wave].dw.period) * 256);
+					}
+					break;
+				}
+				break;
+			  default:
 				break;
 			}
-			const unsigned len = c->fraglog[(size_t)(u.shadow_serial & 0xffff)];
-			if(u.mode == A2D_OSC_OFF) {	// wtosc_Off, wtosc.c:108-126
-				ramp_prepare(u.p, (int)len);
-				ramp_run(u.p, (int)len);
-			} else
-				shadow_wave(c, u, len);
-			u.shadow_time += len;
-			++u.shadow_serial;
-		}
-		if(u.shadow_ok && u.shadow_time < upto && u.mode == A2D_OSC_MIPWAVE && u.wave >= 0 &&
-				c->waves[u.wave].dw.size[0]) {
-			// ... and the rest in one step
-			const A2DWave &w = c->waves[u.wave].dw;
-			const uint64_t F = upto - u.shadow_time;
-			unsigned last = c->fraglog[(size_t)((upto_serial - 1) & 0xffff)];
-			unsigned dph = ((u.dphase + 255) >> 8) * w.period;
-			unsigned mm = 0;
-			for(; (dph > (A2D_MAXPHINC << 8)) && (mm < A2D_MIPS - 1); ++mm)
-				dph >>= 1;
-			dph = (unsigned)(((uint64_t)u.dphase * w.period) >> mm);
-			const uint64_t m = (uint64_t)w.size[mm] << 24;
-			if(last > F)
-				last = (unsigned)F;
-			uint64_t ph = (u.phase >> mm) % m;
-			ph = (ph + (uint64_t)dph * (F - last)) % m;
-			u.phase = (ph + (uint64_t)dph * last) << mm;
 		}
 	}
-	u.shadow_time = upto;
-	u.shadow_serial = upto_serial;
+	u.dphase = t.dphase;
+	u.p_ramping = t.p_ramping;
+	u.phase = t.phase;
+	u.p = t.p;
+	return A2AMD_OK;
 }
-
-// ... for every oscillator of voice 'vi', up to where the walk stands now
-void voice_catch_up(a2amd_ctx *c, int vi)
-{
-	HVoice &v = c->voices[vi];
-	const bool marked = c->frag_open && (size_t)vi < c->defmap.size() && c->defmap[vi];
-	const uint64_t upto = c->walk_time + (marked ? c->fragframes[c->cur_frag] : 0);
-	const long long serial = now_serial(c) + (marked ? 1 : 0);
-	for(int k = 0; k < v.nunits; ++k)
-		shadow_catch_up(c, c->units[v.unit[k]], upto, serial);
-}
-
-} // namespace
 
 int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, uint32_t *noisestate)
 {
@@ -2295,12 +2322,6 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 	} else if(v.win_off != (int)offset || v.win_frames != (int)frames)
 		return c->fail(A2AMD_ESTATE, "units of one voice processed over different windows");
 
-	if(u.kind == A2AMD_WTOSC) {
-		// windows the host only marked in the default map come first
-		shadow_catch_up(c, u, c->walk_time, c->serial_base + c->cur_frag);
-		u.shadow_time = c->walk_time + offset + frames;
-		u.shadow_serial = offset + frames == c->fragframes[c->cur_frag] ? c->serial_base + c->cur_frag + 1 : -1;
-	}
 	switch(u.kind) {
 	  case A2AMD_WTOSC:
 		if(u.mode == A2D_OSC_NOISE) {
@@ -2323,14 +2344,8 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 				st = st * 1566083941u + 1u;
 			*noisestate = st;
 			u.phase = end;
-		} else if(u.shadow_ok && u.shadow_epoch == c->shadow_epoch) {
-			if(u.mode == A2D_OSC_OFF) {	// wtosc_Off, wtosc.c:108-126
-				ramp_prepare(u.p, (int)frames);
-				ramp_run(u.p, (int)frames);
-			} else
-				shadow_wave(c, u, frames);
-		} else
-			u.shadow_ok = false;
+		}
+		// (any other mode: the device does it all, and keeps the state - shadow_rebuild)
 		break;
 	  case A2AMD_FILTER12: {	// the head of f12_process, filter12.c:86-96
 		bool was = u.cutoff.timer != 0;
@@ -2374,7 +2389,6 @@ namespace {
 void classify_plain(a2amd_ctx *c, HVoice &v)
 {
 	v.plain = 2;
-	v.osc_mask = 0;
 	if(!v.live || v.dying || !v.resolved || !v.started || v.inline_pos >= 0)
 		return;
 	for(int k = 0; k < v.nunits; ++k) {
@@ -2383,7 +2397,6 @@ void classify_plain(a2amd_ctx *c, HVoice &v)
 		  case A2AMD_WTOSC:
 			if(u.mode == A2D_OSC_NOISE)
 				return;
-			v.osc_mask |= (uint8_t)(1u << k);
 			break;
 		  case A2AMD_FILTER12:
 			if(u.cutoff.timer || u.cutoff.delta)
@@ -2410,8 +2423,8 @@ int a2amd_voice_process(a2amd_ctx *c, int head, unsigned offset, unsigned frames
 	static const int dbgw = getenv("A2AMD_DBG_WALK") ? atoi(getenv("A2AMD_DBG_WALK")) : 0;
 	if(pv.plain == 1 && !(dbgw & 1)) {
 		// The short path: one pass of bookkeeping for the whole chain (what
-		// a2amd_unit_process does unit by unit), the oscillators' shadows, and the
-		// window - unrecorded if it is the default one.
+		// a2amd_unit_process does unit by unit) and the window - unrecorded if it is
+		// the default one.
 		if(!c->frag_open || !frames || offset + frames > c->fragframes[c->cur_frag])
 			return c->fail(A2AMD_ESTATE, "process [%u,+%u) outside the open fragment", offset, frames);
 		const long long serial = c->serial_base + c->cur_frag;
@@ -2426,31 +2439,13 @@ int a2amd_voice_process(a2amd_ctx *c, int head, unsigned offset, unsigned frames
 		}
 		pv.win_off = (int)offset;
 		pv.win_frames = (int)frames;
-		const bool whole = offset + frames == c->fragframes[c->cur_frag];
-		bool lazy = true;
-		for(unsigned m = pv.osc_mask, k = 0; m; m >>= 1, ++k) {
-			if(!(m & 1))
-				continue;
-			HUnit &u = c->units[pv.unit[k]];
-			shadow_catch_up(c, u, c->walk_time, serial);
-			u.shadow_time = c->walk_time + offset + frames;
-			u.shadow_serial = whole ? serial + 1 : -1;
-			if(u.shadow_ok && u.shadow_epoch == c->shadow_epoch) {
-				if(u.mode == A2D_OSC_OFF) {	// wtosc_Off, wtosc.c:108-126
-					ramp_prepare(u.p, (int)frames);
-					ramp_run(u.p, (int)frames);
-				} else
-					shadow_wave(c, u, frames);
-				lazy = lazy && whole;
-			} else
-				u.shadow_ok = false;
-		}
-		if(offset == 0 && whole && pv.recs.size() == pv.frag_mark && pv.deferred.empty()) {
+		if(offset == 0 && frames == c->fragframes[c->cur_frag] && pv.recs.size() == pv.frag_mark &&
+				pv.deferred.empty()) {
 			pv.default_seg = serial;
 			pv.win_done = 0;
 		} else
 			push_rec(c, vi, R_SEG, 0, 0, 0, offset | (frames << 16), 0);
-		return lazy && (size_t)vi < c->defmap.size() && !(dbgw & 2) ? 1 : 0;
+		return (size_t)vi < c->defmap.size() && !(dbgw & 2) ? 1 : 0;
 	}
 	const int n = c->voices[vi].nunits;
 	for(int k = 0; k < n; ++k) {
@@ -2466,7 +2461,8 @@ int a2amd_voice_process(a2amd_ctx *c, int head, unsigned offset, unsigned frames
 		return 0;
 	for(int k = 0; k < n; ++k) {
 		const HUnit &u = c->units[v.unit[k]];
-		if(!shadow_lazy_ok(c, u) || u.xio_mode || (u.kind == A2AMD_FILTER12 && (u.cutoff.timer || u.cutoff.delta)))
+		if((u.kind == A2AMD_WTOSC && u.mode == A2D_OSC_NOISE) || u.xio_mode ||
+				(u.kind == A2AMD_FILTER12 && (u.cutoff.timer || u.cutoff.delta)))
 			return 0;
 	}
 	return (dbgw & 2) ? 0 : 1;
@@ -2600,8 +2596,7 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 			;	// nothing recorded: records made outside any fragment wait for the next batch
 		return 0;
 	}
-	if(phases & A2AMD_RENDER_KEEP)
-		++c->shadow_epoch;	// a kept batch runs again: phases move on without host calls
+	c->snap_valid = false;		// (the device's unit states move on)
 	if(phases & A2AMD_RENDER_UPLOAD)
 		if(int r = upload(c))
 			return r;
@@ -2792,13 +2787,13 @@ int a2amd_collect(a2amd_ctx *c, int32_t *const *out, unsigned cap)
 int a2amd_replay(a2amd_ctx *c, unsigned steps)
 {
 	use_device(c);
+	c->snap_valid = false;
 	const int GRAPH_STEPS = 8;
 	if(!c->uploaded || !c->nfrags)
 		return c->fail(A2AMD_ESTATE, "replay without an uploaded batch");
 	for(int vi = 0; vi < (int)c->voices.size(); ++vi)
 		if(!c->voices[vi].recs.empty())
 			return c->fail(A2AMD_ESTATE, "replay of a batch that carries command records");
-	++c->shadow_epoch;
 	bool graphs = c->stream != nullptr && !c->profiling && !getenv("A2AMD_NO_GRAPH");
 	if(graphs && !c->gexec[0]) {
 		if(build_graph(c, 0, GRAPH_STEPS) || build_graph(c, 1, 1)) {
