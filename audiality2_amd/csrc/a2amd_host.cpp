@@ -201,6 +201,7 @@ struct HVoice {
 	bool listed_recs = false;	// already in a2amd_ctx::with_recs
 	uint8_t plain = 0;		// 0 not known, 1 no unit's Process leaves anything to do on the host but note
 					// the window (a2amd_voice_process takes its short path), 2 not so
+	bool fancy_recs = false;	// this batch's records hold something k_leaf_recs does not execute
 	bool mode_mix = false;		// an oscillator played something else than a mip-mapped wave at some
 					// point of the batch being recorded (its records go to the general kernel)
 	int nunits = 0;
@@ -266,6 +267,9 @@ struct a2amd_ctx {
 	std::vector<HWave> waves;
 	int building = -1;
 	std::vector<int> stack;			// open inline windows (unit ids)
+	std::vector<A2DRec> up_recs;		// upload()'s scratch, kept for their capacity
+	std::vector<int> up_idx, up_now;
+	std::vector<A2DRun> up_val;
 	std::vector<int> with_recs, prev_with_recs;	// voices carrying records this / last batch
 	std::vector<int> dirty_voices;		// voice mirror entries to re-upload
 	long long serial_base = 0;		// fragments rendered before this batch
@@ -493,6 +497,8 @@ void push_rec(a2amd_ctx *c, int vi, int op, int unit, int reg, int value, unsign
 {
 	touch(c, vi);
 	spell_out_pending(c, vi);
+	if(op != R_SEG && op != R_WRITE && op != R_INIT && op != R_KILL)
+		c->voices[vi].fancy_recs = true;
 	A2DRec r;
 	r.head = A2D_HEAD(rec_tag(c), op, unit, reg);
 	r.value = value;
@@ -826,19 +832,18 @@ int upload(a2amd_ctx *c)
 	// dense runs[slot] table (zero = quiet voice); only the entries that change
 	// are written, by a scatter kernel: this batch's runs, and zeros for the
 	// voices that carried records last batch but not now.
-	std::vector<A2DRec> recs;
-	std::vector<int> sc_idx;
-	std::vector<A2DRun> sc_val;
-	std::vector<int> now;
+	std::vector<A2DRec> &recs = c->up_recs;
+	std::vector<int> &sc_idx = c->up_idx, &now = c->up_now;
+	std::vector<A2DRun> &sc_val = c->up_val;
+	recs.clear();
+	now.clear();
 	{
-		size_t total = 0;
-		for(int vi : c->with_recs)
-			total += c->voices[vi].recs.size();
-		recs.reserve(total);
-		sc_idx.reserve(c->with_recs.size() + c->prev_with_recs.size());
-		sc_val.reserve(c->with_recs.size() + c->prev_with_recs.size());
-		now.reserve(c->with_recs.size());
+		const size_t nsc = c->with_recs.size() + c->prev_with_recs.size();
+		sc_idx.resize(nsc);
+		sc_val.resize(nsc);
+		now.resize(c->with_recs.size());
 	}
+	size_t nsc_used = 0, nnow = 0;
 	for(int vi : c->with_recs) {
 		HVoice &v = c->voices[vi];
 		if(v.recs.empty()) {
@@ -847,17 +852,20 @@ int upload(a2amd_ctx *c)
 		}
 		A2DRun r = { (int)recs.size(), (int)v.recs.size() };
 		recs.insert(recs.end(), v.recs.begin(), v.recs.end());
-		sc_idx.push_back(vi);
-		sc_val.push_back(r);
-		now.push_back(vi);
+		sc_idx[nsc_used] = vi;
+		sc_val[nsc_used++] = r;
+		now[nnow++] = vi;
 	}
-	c->with_recs = now;
+	now.resize(nnow);
+	c->with_recs.swap(now);
 	for(int vi : c->prev_with_recs)
 		if(vi < (int)nv && c->voices[vi].recs.empty()) {
 			A2DRun z = { 0, 0 };
-			sc_idx.push_back(vi);
-			sc_val.push_back(z);
+			sc_idx[nsc_used] = vi;
+			sc_val[nsc_used++] = z;
 		}
+	sc_idx.resize(nsc_used);
+	sc_val.resize(nsc_used);
 	c->prev_with_recs.clear();
 	c->stats.records += recs.size();
 	if(c->hosttiming) {
@@ -978,15 +986,9 @@ int upload(a2amd_ctx *c)
 		const bool no_recs_kernel = (c->no_fast & 64) != 0;
 		for(int vi : dyn_leaf) {
 			const HVoice &v = c->voices[vi];
-			bool ok = !no_recs_kernel && (v.cls == CLS_OSCPAN || v.cls == CLS_OSC2PAN) && !v.mode_mix;
-			if(ok)
-				for(const A2DRec &r : v.recs) {
-					const unsigned op = A2D_ROP(r.head);
-					if(op != R_SEG && op != R_WRITE && op != R_INIT && op != R_KILL && op != R_NOP) {
-						ok = false;
-						break;
-					}
-				}
+			// (close_fragment's R_NOP is the one other record k_leaf_recs takes - as nothing)
+			const bool ok = !no_recs_kernel && (v.cls == CLS_OSCPAN || v.cls == CLS_OSC2PAN) && !v.mode_mix &&
+					!v.fancy_recs;
 			(!ok ? dyn_rest : v.cls == CLS_OSCPAN ? dyn_o1 : dyn_o2).push_back(vi);
 		}
 		// (the walk order usually has them grouped by bus already)
@@ -1187,13 +1189,15 @@ void end_batch(a2amd_ctx *c)
 		size_t keep = 0;
 		// (a voice that was set up but not walked yet keeps everything)
 		const bool unborn = v.live && !v.resolved;
-		for(size_t i = 0; i < v.recs.size(); ++i)
-			if(unborn || (int)A2D_RFRAG(v.recs[i].head) >= done) {
-				A2DRec r = v.recs[i];
-				int f = (int)A2D_RFRAG(r.head) - done;
-				r.head = (r.head & 0xffff0000u) | (uint32_t)(f < 0 ? 0 : f);
-				v.recs[keep++] = r;
-			}
+		// (the records are in fragment order: nothing to carry over unless the last one is)
+		if(unborn || (!v.recs.empty() && (int)A2D_RFRAG(v.recs.back().head) >= done))
+			for(size_t i = 0; i < v.recs.size(); ++i)
+				if(unborn || (int)A2D_RFRAG(v.recs[i].head) >= done) {
+					A2DRec r = v.recs[i];
+					int f = (int)A2D_RFRAG(r.head) - done;
+					r.head = (r.head & 0xffff0000u) | (uint32_t)(f < 0 ? 0 : f);
+					v.recs[keep++] = r;
+				}
 		v.recs.resize(keep);
 		v.frag_mark = 0;
 		if(keep) {
@@ -1203,6 +1207,7 @@ void end_batch(a2amd_ctx *c)
 			v.touched = -1;
 			v.listed_recs = false;
 			v.mode_mix = false;
+			v.fancy_recs = false;
 		}
 	}
 	c->with_recs = carry;
@@ -2868,6 +2873,9 @@ int a2amd_dist_init(a2amd_ctx *c, const void *id128, int rank, int nranks)
 		return c->fail(A2AMD_ENODEVICE, "dist_init: RCCL (librccl.so) is not available");
 	ncclUniqueId id;
 	memcpy(&id, id128, sizeof(id));
+	// (RCCL checks the runtime's last-error slot as it goes: an error some earlier,
+	// unrelated call of this process left there must not become its "unhandled cuda error")
+	(void)hipGetLastError();
 	ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
 	if(r != ncclSuccess) {
 		c->comm = nullptr;
@@ -2901,6 +2909,7 @@ int a2amd_dist_init_local(a2amd_ctx *const *ctxs, int n)
 		std::vector<int> devs(n);
 		for(int i = 0; i < n; ++i)
 			devs[i] = ctxs[i]->cfg.device;
+		(void)hipGetLastError();	// (see a2amd_dist_init)
 		ncclResult_t r = g_rccl.CommInitAll(comms.data(), n, devs.data());
 		if(r != ncclSuccess)
 			return c0->fail(A2AMD_EHIP, "ncclCommInitAll: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "failed");

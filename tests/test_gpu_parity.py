@@ -8,7 +8,7 @@ import pytest
 
 from audiality2_amd import synth
 from audiality2_amd.replay import Trace, replay
-from conftest import GOLDEN, fnv1a_fragments, make_gpu, make_oracle, KNOWN_DEVIATIONS, differing_fragments
+from conftest import GOLDEN, ROOT, fnv1a_fragments, make_gpu, make_oracle, KNOWN_DEVIATIONS, differing_fragments
 
 pytestmark = pytest.mark.gpu
 
@@ -899,12 +899,8 @@ def test_delay_chain_kernel_rounds_match_oracle(oracle_lib, batch):
     assert first_diff(outs[0], outs[1]) is None
 
 
-def test_dist_render_with_one_rank_equals_plain_render():
-    """a2amd_dist_init(): the multi-GPU batch (subtrees, ONE ncclReduce of the root bus on
-    the render stream, root chain on rank 0) with a communicator of one rank - all this
-    box can form - must render what the plain path renders, batch after batch (the reduce
-    of one rank's partial onto itself, bus hygiene between the split phases, graphs of
-    the split phases)."""
+def _dist_one_rank():
+    """(body of the test below; runs in a process of its own)"""
     import ctypes as C
     outs = []
     for use_dist in (False, True):
@@ -928,6 +924,23 @@ def test_dist_render_with_one_rank_equals_plain_render():
         gpu.close()
     assert outs[0].any()
     assert first_diff(outs[0], outs[1]) is None
+
+
+def test_dist_render_with_one_rank_equals_plain_render():
+    """a2amd_dist_init(): the multi-GPU batch (subtrees, ONE ncclReduce of the root bus on
+    the render stream, root chain on rank 0) with a communicator of one rank - all this
+    box can form - must render what the plain path renders, batch after batch (the reduce
+    of one rank's partial onto itself, bus hygiene between the split phases, graphs of
+    the split phases).  In a process of its own, as an application would be: this test
+    process may by now hold two ROCm runtimes (the system's, which liba2amd.so is linked
+    against, and the copy bundled with torch, which other tests import), and RCCL then
+    finds the wrong one."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path[:0] = [%r, %r]; import test_gpu_parity as t; "
+                        "t._dist_one_rank()" % (os.path.dirname(os.path.abspath(__file__)), ROOT)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
 
 
 def test_render_group_of_two_contexts_equals_one_context():
