@@ -2631,7 +2631,11 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 			return 0;
 		if(c->uploaded && !c->profiling && c->stream && c->with_recs.empty() && !getenv("A2AMD_NO_GRAPH") &&
 				((phases & A2AMD_RENDER_KEEP) ? (phases & ~A2AMD_RENDER_KEEP) ==
-				 (phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT)) : c->quiet_streak >= 1)) {
+				 (phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT)) :
+				 // (not for a realtime driver's one-fragment batches: measured, hipGraphLaunch
+				 // costs more there than the three or four launches it replaces - 170 us
+				 // against 25 us of host time per fragment at 65 536 voices)
+				 c->quiet_streak >= 1 && c->nfrags >= 8)) {
 			const int slot = kphases == A2AMD_RENDER_SUBTREES ? 2 : kphases == A2AMD_RENDER_ROOT ? 3 : 1;
 			if(c->gexec[slot] || !build_graph(c, slot, 1, kphases)) {
 				if(slot != 3)

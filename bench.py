@@ -484,6 +484,22 @@ def main():
                     "roofline_valu": {k: ev[k] for k in ("valu_insts_per_voice_fragment", "achieved", "frac")},
                     "realtime": {k: e["realtime"][k] for k in ("fragment_ms_p50", "fragment_ms_p99", "holds_realtime")}
                     if "realtime" in e else None}
+            # variant 2b of SURVEY 8(d): the same voices driven like a script drives them - in
+            # every second fragment a voice gets a window that ends inside the fragment, a
+            # pitch ramp, and the rest of the fragment (k_leaf_recs).  The driver is Python
+            # over the C ABI, so only the kernels are timed (HIP events).
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import scripted_timing
+            sres = scripted_timing.measure(voices=4096, chain="osc-pan", batch=64, period=2, what="pitch",
+                                           names=("quiet", "scripted", "scripted2"), Stats=Stats)
+            extra["variant 2b (scripted)"] = {
+                "workload": "4096 voices wtosc->panmix, 64-fragment batches, a split window and a pitch ramp on every "
+                            "voice in every second fragment",
+                "kernels_ms_per_batch": sres["scripted2"]["kernels_ms_per_batch"],
+                "kernel_voice_samples_per_s": sres["scripted2"]["voice_samples_per_s"],
+                "quiet_kernels_ms_per_batch": sres["quiet"]["kernels_ms_per_batch"],
+                "timing": "HIP events around the batch's kernels; the engine-in-the-loop figure for this "
+                          "variant is in profiles/ (tests/measure/engine_in_loop.py)"}
             line["other_configs"] = extra
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg["voices"], cfg["chain"], cfg["groups"])

@@ -24,39 +24,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import audiality2_amd  # noqa: E402
 from audiality2_amd import synth  # noqa: E402
-from bench import Stats  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--voices", type=int, default=16384)
-    ap.add_argument("--chain", default="osc-pan")
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--period", type=int, default=2)
-    ap.add_argument("--what", default="pitch")
-    args = ap.parse_args()
-    be = audiality2_amd.open_backend(48000, None, 2, max_batch=args.batch)
+def measure(voices=16384, chain="osc-pan", batch=64, period=2, what="pitch", names=("quiet", "scripted", "scripted2", "scripted3", "quiet2"),
+            Stats=None):
+    if Stats is None:       # (bench.py passes its own: ctypes ties a2amd_get_stats to one class object)
+        from bench import Stats
+    be = audiality2_amd.open_backend(48000, None, 2, max_batch=batch)
     lib = be.lib
     sc = synth.Scene(be)
     sc.root()
-    sc.add_voices(args.voices, chain=args.chain)
+    sc.add_voices(voices, chain=chain)
     sc.run(1, batch=1)
     rng = np.random.default_rng(3)
-    cuts = rng.integers(1, 64, args.voices)
-    nosc = 2 if args.chain.startswith("osc2") else 1
+    cuts = rng.integers(1, 64, voices)
+    nosc = 2 if chain.startswith("osc2") else 1
 
-    def batch(scripted):
-        for f in range(args.batch):
+    def run_batch(scripted):
+        for f in range(batch):
             be.fragment(64)
             be.unit_process(sc.rootv[0], 0, 64)
             for k, units in enumerate(sc.leaves):
-                if scripted and (f + k) % args.period == 0:
+                if scripted and (f + k) % period == 0:
                     c = int(cuts[k])
                     for u in units:
                         be.unit_process(u, 0, c)
-                    if args.what == "amp":
+                    if what == "amp":
                         be.unit_write(units[0], 2, synth.fix(0.001 * (1 + (f + k) % 5)), 0, 0)
-                    elif args.what == "pitch":
+                    elif what == "pitch":
                         be.unit_write(units[(f + k) % nosc], 1, synth.fix(((k % 61) - 30) / 12.0 + 0.01 * ((f + k) % 3)),
                                       17, 3 * 48 << 8)
                     for u in units:
@@ -69,20 +64,32 @@ def main():
             be.unit_process(sc.rootv[2], 0, 64)
         st0 = Stats()
         lib.a2amd_get_stats(be.ctx, ctypes.byref(st0))
-        out = be.render(args.batch * 64)
+        out = be.render(batch * 64)
         st1 = Stats()
         lib.a2amd_get_stats(be.ctx, ctypes.byref(st1))
         return (st1.timed_all_ms - st0.timed_all_ms), int(np.abs(out).max())
 
     lib.a2amd_set_profiling(be.ctx, 1)
     res = {}
-    for name, scripted in (("quiet", False), ("scripted", True), ("scripted2", True), ("scripted3", True), ("quiet2", False)):
-        ms, peak = batch(scripted)
+    for name in names:
+        ms, peak = run_batch(name.startswith("scripted"))
         res[name] = {"kernels_ms_per_batch": round(ms, 4),
-                     "voice_samples_per_s": float("%.3g" % (args.voices * args.batch * 64 / (ms * 1e-3))), "peak": peak}
+                     "voice_samples_per_s": float("%.3g" % (voices * batch * 64 / (ms * 1e-3))), "peak": peak}
+    be.close()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--voices", type=int, default=16384)
+    ap.add_argument("--chain", default="osc-pan")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--period", type=int, default=2)
+    ap.add_argument("--what", default="pitch")
+    args = ap.parse_args()
+    res = measure(args.voices, args.chain, args.batch, args.period, args.what)
     print(json.dumps({"voices": args.voices, "chain": args.chain, "fragments_per_batch": args.batch, "what": args.what,
                       "voices_with_records_per_fragment": 1.0 / args.period, **res}))
-    be.close()
 
 
 if __name__ == "__main__":
