@@ -360,6 +360,9 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	const bool last_slice = c_hi >= nchunks;
 	if(c_lo >= nchunks)
 		return;
+	// (the slices that exist; voices that still have something moving are dealt over
+	// them - slice s walks the whole batch for every nslices-th of them)
+	const int nslices = (nchunks + per - 1) / per;
 
 	// fragment lengths and their prefix sums: lane l of ffr[k] / fst[k] holds
 	// fragment 64*k + l (byte loads are vector memory operations: once, here)
@@ -549,8 +552,9 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 		flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
 	}
 
-	// ---- voices with something still moving: slice 0 walks the whole batch ----
-	if(slice == 0 && unsettled_mask) {
+	// ---- voices with something still moving: one slice each walks the whole batch ----
+	const unsigned long long todo_mask = unsettled_mask & __ballot(lane % nslices == slice);
+	if(todo_mask) {
 		for(int f0 = 0; f0 < nfrags; f0 += FAST_FCH) {
 			const int nf = min((int)FAST_FCH, nfrags - f0);
 			int acc0[FAST_FCH], acc1[FAST_FCH];
@@ -559,7 +563,7 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 				acc0[j] = acc1[j] = 0;
 			int cur_off = rdl(my_off, 0), cur_nch = rdl(my_nch, 0);
 			for(int v = 0; v < nv; ++v) {
-				if(!((unsettled_mask >> v) & 1ull))
+				if(!((todo_mask >> v) & 1ull))
 					continue;
 				const int voff = rdl(my_off, v);
 				if(voff != cur_off) {
@@ -616,9 +620,9 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	// State out.  With one slice it goes straight back; with several the other
 	// slices are still reading the old state, so it is staged and committed by
 	// k_commit_oscpan afterwards.  The last slice owns the settled voices (their
-	// end phase), slice 0 the others.
+	// end phase), the slice that walked it each of the others.
 	const bool settled_l = dv[DV_SETTLED] != 0;
-	if(mine && ((settled_l && last_slice) || (!settled_l && slice == 0))) {
+	if(mine && ((settled_l && last_slice) || (!settled_l && lane % nslices == slice))) {
 		int *w0 = ustage + (size_t)u0 * A2D_USTATE;
 		int *w1 = ustage + (size_t)u1 * A2D_USTATE;
 		w0[OW_MODE] = sv[SV_MODE]; w0[OW_WAVE] = sv[SV_WAVE]; w0[OW_DPHASE] = sv[SV_DPHASE];
@@ -724,6 +728,9 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 	const bool last_slice = c_hi >= nchunks;
 	if(c_lo >= nchunks)
 		return;
+	// (the slices that exist; voices that still have something moving are dealt over
+	// them - slice s walks the whole batch for every nslices-th of them)
+	const int nslices = (nchunks + per - 1) / per;
 
 	int ffr[A2D_MAXBATCH / 64], fst[A2D_MAXBATCH / 64];
 #pragma unroll
@@ -897,8 +904,9 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 		flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
 	}
 
-	// ---- voices with something still moving: slice 0 walks the whole batch ----
-	if(slice == 0 && unsettled_mask) {
+	// ---- voices with something still moving: one slice each walks the whole batch ----
+	const unsigned long long todo_mask = unsettled_mask & __ballot(lane % nslices == slice);
+	if(todo_mask) {
 		for(int f0 = 0; f0 < nfrags; f0 += OSC2_FCH) {
 			const int nf = min((int)OSC2_FCH, nfrags - f0);
 			int acc0[OSC2_FCH], acc1[OSC2_FCH];
@@ -907,7 +915,7 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 				acc0[j] = acc1[j] = 0;
 			int cur_off = rdl(my_off, 0), cur_nch = rdl(my_nch, 0);
 			for(int v = 0; v < nv; ++v) {
-				if(!((unsettled_mask >> v) & 1ull))
+				if(!((todo_mask >> v) & 1ull))
 					continue;
 				const int voff = rdl(my_off, v);
 				if(voff != cur_off) {
@@ -944,7 +952,7 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 		}
 	}
 
-	if(mine && ((settled_l && last_slice) || (!settled_l && slice == 0))) {
+	if(mine && ((settled_l && last_slice) || (!settled_l && lane % nslices == slice))) {
 #pragma unroll
 		for(int o = 0; o < 2; ++o) {
 			int *w = ustage + (size_t)uu[o] * A2D_USTATE;

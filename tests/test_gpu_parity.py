@@ -805,6 +805,38 @@ def test_leaf_launch_shapes_at_bench_batch_match_oracle(oracle_lib, monkeypatch,
     assert first_diff(got, want) is None
 
 
+@pytest.mark.parametrize("vpw,ysplit", [(4, 1), (4, 8), (32, 8), (8, 3)])
+@pytest.mark.parametrize("chain", ["osc-pan", "osc2-pan"])
+def test_voices_still_ramping_are_dealt_over_the_time_slices(oracle_lib, monkeypatch, chain, vpw, ysplit):
+    """Voices without records in a batch whose rampers are still on their way (long
+    pitch glides, fades, pan sweeps started batches ago - what envelopes do) take the
+    leaf kernels' per-fragment path; each time slice walks the whole batch for its share
+    of them.  Ramps of every length end inside and between the batches."""
+    monkeypatch.setenv("A2AMD_VPW", str(vpw))
+    monkeypatch.setenv("A2AMD_YSPLIT", str(ysplit))
+
+    def build(be):
+        sc = synth.Scene(be)
+        sc.root()
+        sc.add_voices(900, chain=chain, total=2048)
+        for k, units in enumerate(sc.leaves):
+            frames = (700, 3000, 5000, 9000, 14000)[k % 5]
+            if k % 3 == 0:
+                be.unit_write(units[0], 1, synth.fix(((k % 61) - 30) / 12.0 + 0.7), 0, frames << 8)      # pitch glide
+            if k % 3 == 1:
+                be.unit_write(units[k % (len(units) - 1)], 2, synth.fix(0.0004 * (k % 7)), 0, frames << 8)   # fade
+            if k % 4 == 2:
+                be.unit_write(units[-1], 1, synth.fix(((k % 9) - 4) / 3.0), 0, frames << 8)                  # pan sweep
+            if k % 7 == 3:
+                be.unit_write(units[-1], 0, synth.fix(0.5), 0, frames << 8)                                  # volume
+        return sc
+    gpu = make_gpu(max_batch=64)
+    got = _async_steps(gpu, build(gpu), 4, 64)
+    gpu.close()
+    want = _oracle_fragments(oracle_lib, build, 256)
+    assert first_diff(got, want) is None
+
+
 @pytest.mark.parametrize("fvpw", [1, 8, 32])
 def test_filter_leaf_launch_shapes_at_bench_batch_match_oracle(oracle_lib, monkeypatch, fvpw):
     monkeypatch.setenv("A2AMD_FVPW", str(fvpw))
