@@ -156,6 +156,8 @@ int a2d_launch_commit(const A2DParams &hp, const A2DCommit &cm, void *stream);
 int a2d_launch_bus_fbdchain(const A2DParams *dparams, const int *dlist, int nlist, int consume, void *stream);
 int a2d_launch_park(int32_t *stage, int32_t *bus, unsigned words, void *stream);
 int a2d_launch_add_bus(int32_t *dst, int32_t *src, unsigned words, void *stream);
+// bus[f][ch][64] (nch channels per fragment) += inj[f][ch][64] (8 channels per fragment), ch < n
+int a2d_launch_add_inject(const int32_t *inj, int32_t *bus, int nch, int n, int nfrags, void *stream);
 // Hermite coefficient entries for wave pool samples [lo, hi) (reads pool[lo-1 .. hi+1])
 int a2d_launch_build_coef(const int16_t *pool, int *coef, unsigned lo, unsigned hi, void *stream);
 int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,

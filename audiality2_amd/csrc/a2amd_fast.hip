@@ -2536,6 +2536,22 @@ __global__ void k_add_bus(int32_t *__restrict__ dst, int32_t *__restrict__ src, 
 	}
 }
 
+__global__ void k_add_inject(const int32_t *__restrict__ inj, int32_t *__restrict__ bus, int nch, int n)
+{
+	const int f = blockIdx.x, lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+	if(ch < n)
+		bus[((size_t)f * nch + ch) * A2D_FRAG + lane] = wadd(bus[((size_t)f * nch + ch) * A2D_FRAG + lane],
+				inj[((size_t)f * 8 + ch) * A2D_FRAG + lane]);
+}
+
+int a2d_launch_add_inject(const int32_t *inj, int32_t *bus, int nch, int n, int nfrags, void *stream)
+{
+	if(nfrags <= 0 || n <= 0)
+		return 0;
+	hipLaunchKernelGGL(k_add_inject, dim3(nfrags), dim3(64 * 8), 0, (hipStream_t)stream, inj, bus, nch, n);
+	return (int)hipGetLastError();
+}
+
 int a2d_launch_add_bus(int32_t *dst, int32_t *src, unsigned words, void *stream)
 {
 	if(!words)

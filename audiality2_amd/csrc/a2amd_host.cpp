@@ -238,6 +238,8 @@ struct XioSlot {
 	std::vector<int32_t> tap, inj;	// [fragment][A2AMD_MAXCHANNELS][64]
 	bool inj_used = false;
 	bool tapped = false;		// had READ clients at some point of the batch being recorded
+	std::vector<int32_t> late;	// a2amd_unit_insert: what insert clients made of the taps, same layout
+	bool late_used = false;
 };
 
 struct HWave {
@@ -2341,8 +2343,8 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 			shadow_run_pitch(c, u, frames);
 			uint64_t end = u.phase + (uint64_t)frames * u.dphase;
 			uint64_t draws = u.dphase >= (1u << 23) ? frames : (end >> 23) - (u.phase >> 23);
-			static const bool trace = getenv("A2AMD_DEBUG_NOISE") != nullptr;	// (debugging the phase shadow
-			if(trace)								// against oracle/a2o.c's trace)
+			static const bool trace = getenv("A2AMD_DEBUG_NOISE") != nullptr;	// (debugging aid: the test
+			if(trace)								// suite's checker prints the same line)
 				fprintf(stderr, "NOISE phase %llx dphase %x frames %u\n", (unsigned long long)u.phase, u.dphase, frames);
 			uint32_t st = *noisestate;
 			for(uint64_t i = 0; i < draws; ++i)
@@ -2496,7 +2498,8 @@ int a2amd_unit_clients(a2amd_ctx *c, int ui, unsigned mode)
 			(c->units[ui].kind != A2AMD_XINSERT && c->units[ui].kind != A2AMD_XSINK &&
 			 c->units[ui].kind != A2AMD_XSOURCE))
 		return c->fail(A2AMD_EINVAL, "unit %d is not a live xinsert / xsink / xsource", ui);
-	if((mode & ~(unsigned)(A2AMD_XIO_TAP | A2AMD_XIO_INJECT)) ||
+	if((mode & ~(unsigned)(A2AMD_XIO_TAP | A2AMD_XIO_INJECT | A2AMD_XIO_MUTE)) ||
+			((mode & A2AMD_XIO_MUTE) && (!(mode & A2AMD_XIO_TAP) || a2amd_unit_insertable(c, ui) != 1)) ||
 			(c->units[ui].kind == A2AMD_XSINK && (mode & A2AMD_XIO_INJECT)) ||
 			(c->units[ui].kind == A2AMD_XSOURCE && (mode & A2AMD_XIO_TAP)))
 		return c->fail(A2AMD_EINVAL, "client mode %#x on unit kind %d", mode, c->units[ui].kind);
@@ -2544,6 +2547,41 @@ int a2amd_unit_inject(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, co
 			d[k] = wadd(d[k], bufs[ch][k]);
 	}
 	x.inj_used = true;
+	return A2AMD_OK;
+}
+
+int a2amd_unit_insertable(a2amd_ctx *c, int ui)
+{
+	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live)
+		return c->fail(A2AMD_EINVAL, "insertable: dead unit %d", ui);
+	const HUnit &u = c->units[ui];
+	const HVoice &v = c->voices[u.voice];
+	// the render has one seam: between everything below the root voice and the root's
+	// own chain.  A unit that is the last of a voice playing straight into the root's
+	// bus can have its output added there in between.
+	// (known once the voice has been processed for the first time: resolve_out)
+	return u.kind == A2AMD_XINSERT && v.resolved && v.depth == 1 && v.out_off != 0 && u.chainpos == v.nunits - 1 &&
+			u.wired && (u.flags & A2AMD_PROCADD) && !c->comm ? 1 : 0;
+}
+
+int a2amd_unit_insert(a2amd_ctx *c, int ui, unsigned fragment, unsigned offset, unsigned frames,
+		const int32_t *const *bufs)
+{
+	if(ui < 0 || ui >= (int)c->units.size() || c->units[ui].xio < 0 || c->xio[c->units[ui].xio].last_unit != ui)
+		return c->fail(A2AMD_EINVAL, "unit %d has had no clients", ui);
+	if(!c->uploaded || (int)fragment >= c->nfrags || !frames || offset + frames > c->fragframes[fragment])
+		return c->fail(A2AMD_ESTATE, "insert [%u,+%u) of fragment %u: not between the SUBTREES and the ROOT phase "
+				"of a batch that has it", offset, frames, fragment);
+	const HUnit &u = c->units[ui];
+	XioSlot &x = c->xio[u.xio];
+	if(x.late.empty())
+		x.late.assign(A2D_XIO_HALF, 0);
+	for(int ch = 0; ch < u.nin; ++ch) {
+		int32_t *d = x.late.data() + ((size_t)fragment * A2AMD_MAXCHANNELS + ch) * A2D_FRAG + offset;
+		for(unsigned k = 0; k < frames; ++k)
+			d[k] = wadd(d[k], bufs[ch][k]);
+	}
+	x.late_used = true;
 	return A2AMD_OK;
 }
 
@@ -2677,8 +2715,44 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		if(c->dist_rank == 0)
 			if(int r = run_phases(A2AMD_RENDER_ROOT))
 				return r;
-	} else if(int r = run_phases(kphases))
-		return r;
+	} else {
+		if(kphases == A2AMD_RENDER_ROOT) {
+			// what insert clients made of the voices' taps since the SUBTREES phase
+			// (a2amd_unit_insert) joins the voices' output bus before the root chain runs
+			for(size_t k = 0; k < c->xio.size(); ++k) {
+				XioSlot &x = c->xio[k];
+				if(!x.late_used)
+					continue;
+				const size_t n = (size_t)c->nfrags * A2AMD_MAXCHANNELS * A2D_FRAG;
+				// (also for a voice that died in the course of the batch: its unit and
+				// voice entries stay until the batch ends)
+				if(x.last_unit >= 0 && x.last_unit < (int)c->units.size() && c->units[x.last_unit].voice >= 0) {
+					const HVoice &v = c->voices[c->units[x.last_unit].voice];
+					HIPCHK(c, hipMemcpyAsync(c->d_xio.d + k * A2D_XIO_SLOT + A2D_XIO_HALF, x.late.data(),
+							n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+					HIPCHK(c, hipStreamSynchronize(c->stream));	// (x.late is pageable and cleared next)
+					if(a2d_launch_add_inject(c->d_xio.d + k * A2D_XIO_SLOT + A2D_XIO_HALF, c->d_busmem.d + v.out_off,
+							v.out_nch, std::min(c->units[x.last_unit].nin, v.out_nch), c->nfrags, c->stream))
+						return c->fail(A2AMD_EHIP, "insert launch failed");
+				}
+				std::fill(x.late.begin(), x.late.begin() + n, 0);
+				x.late_used = false;
+			}
+		}
+		if(int r = run_phases(kphases))
+			return r;
+	}
+	if((phases & A2AMD_RENDER_TAPS) && !(phases & A2AMD_RENDER_READBACK)) {
+		// the seam for insert clients: the batch's taps so far, on the host
+		for(size_t k = 0; k < c->xio.size(); ++k) {
+			XioSlot &x = c->xio[k];
+			if(x.unit >= 0 && x.tapped)
+				HIPCHK(c, hipMemcpyAsync(x.tap.data(), c->d_xio.d + k * A2D_XIO_SLOT,
+						(size_t)c->nfrags * A2AMD_MAXCHANNELS * A2D_FRAG * sizeof(int32_t),
+						hipMemcpyDeviceToHost, c->stream));
+		}
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+	}
 	double t2 = timing ? now_us() : 0;
 	if(timing) {
 		g_t[1] += t2 - t1;

@@ -561,7 +561,10 @@ DEV void xinsert_process(Ctx &c, uint32_t desc, const int *w, int offset, int fr
 		if(tap)
 			tap[ch * A2D_FRAG] = in;
 		if(A2D_WIRED(desc))
-			c.l->otile[ch][c.lane] = wadd(c.l->otile[ch][c.lane], wadd(in, add));
+			// (mode 4: there are insert clients - the input is not passed on,
+			// xinsert.c:101-104,121-123; what they make of it arrives before the root
+			// chain runs, a2amd_unit_insert)
+			c.l->otile[ch][c.lane] = wadd(c.l->otile[ch][c.lane], (mode & 4) ? add : wadd(in, add));
 		else if(A2D_ADD(desc))
 			// in == out on the scratch bus: the client output lands in the
 			// input before "out += in" doubles it (xinsert.c:113-124)

@@ -73,6 +73,7 @@ typedef struct PENDING
 	unsigned		pos;		/* root xinsert: frames into the buffer */
 	const char		*what;		/* for error reports */
 	unsigned		offset, frames;
+	int			insert;		/* a READ and WRITE client: served in the middle of the render */
 } PENDING;
 
 typedef struct HOSTSTATE
@@ -94,6 +95,7 @@ typedef struct HOSTSTATE
 	uint8_t		*map[MAXDEV];	/* the backends' default maps for that fragment (a2amd_default_map) */
 	unsigned	map_cap[MAXDEV];
 	int		noise_oscs;	/* oscillators playing the noise wave: their voices need the engine's RNG */
+	int		ninserts;	/* pending windows of insert clients in the batch being recorded */
 	int		no_quick;	/* A2AMD_NO_QUICK=1: every Process call is forwarded (A/B measurements) */
 	A2P_vmstate	*root_vms;	/* the root voice (first voice of a state) */
 	A2P_vmstate	*chain_vms;	/* voice whose chain is being populated */
@@ -618,6 +620,7 @@ static PENDING *new_pending(HOSTSTATE *hs)
 		hs->pend = np;
 		hs->cap_pend = nc;
 	}
+	memset(&hs->pend[hs->npend], 0, sizeof(PENDING));
 	return &hs->pend[hs->npend++];
 }
 
@@ -653,12 +656,17 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 			mode |= A2AMD_XIO_INJECT;
 		else if((xic->flags & A2P_XI_READ) && (xic->flags & A2P_XI_WRITE))
 		{
-			if(!x->refused)
+			/* an insert client: where the render has a seam for it (the last unit of a voice
+			 * directly below the root: a2_NewGroup's xinsert), its input is tapped and not
+			 * passed on, and flush_batch() runs it between the two halves of the render */
+			if(hs->ndev == 1 && a2amd_unit_insertable(XCTX(x), x->uid) == 1)
+				mode |= A2AMD_XIO_TAP | A2AMD_XIO_MUTE;
+			else if(!x->refused)
 			{
 				x->refused = 1;
 				client_error(xi, A2P_NOTIMPLEMENTED, "a2amd: insert client (a2_InsertCallback) on a voice "
-						"other than the root voice: its audio is on the GPU; not served (sink "
-						"and source clients are)");
+						"that is neither the root voice nor directly below it (or with A2AMD_DEVICES > 1): "
+						"its audio is on the GPU; not served (sink and source clients are)");
 			}
 		}
 		else
@@ -705,7 +713,8 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 		for(xic = xi->clients; xic; xic = xic->next)
 		{
 			PENDING *p;
-			if(x->kind == A2AMD_XINSERT && (xic->flags & A2P_XI_WRITE))
+			const int ins = x->kind == A2AMD_XINSERT && (xic->flags & A2P_XI_READ) && (xic->flags & A2P_XI_WRITE);
+			if(x->kind == A2AMD_XINSERT && (xic->flags & A2P_XI_WRITE) && !(ins && (mode & A2AMD_XIO_MUTE)))
 				continue;
 			if(!(p = new_pending(hs)))
 			{
@@ -721,6 +730,8 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 			p->what = what;
 			p->offset = offset - hs->base;
 			p->frames = frames;
+			p->insert = ins;
+			hs->ninserts += ins;
 		}
 }
 
@@ -738,7 +749,7 @@ static void deliver_pending(HOSTSTATE *hs)
 		 * stand-in xi_deinit left for it, is alive) */
 		for(c = p->xi->clients; c && c != p->xic; c = c->next)
 			;
-		if(!c || hs->failed)
+		if(!c || hs->failed || p->insert)
 			continue;
 		if(p->uid < 0)
 		{
@@ -818,6 +829,60 @@ static int grow_acc(HOSTSTATE *hs, unsigned frames)
 	return 1;
 }
 
+/* The insert clients' turn, between the two halves of the render: each is handed a copy
+ * of its window of the unit's input and what it makes of it is summed up as the unit's
+ * output (xi_process, xinsert.c:95-118), in walk order. */
+static void deliver_inserts(HOSTSTATE *hs)
+{
+	int k, i, n, rc;
+	unsigned s;
+	for(k = 0; k < hs->npend; ++k)
+	{
+		PENDING *p = &hs->pend[k];
+		const int32_t *bufs[A2AMD_MAXCHANNELS];
+		int32_t tmp[A2AMD_MAXCHANNELS][A2AMD_MAXFRAG];
+		int32_t *bufp[A2AMD_MAXCHANNELS];
+		const int32_t *outp[A2AMD_MAXCHANNELS];
+		A2P_xinsert_client *c;
+		if(!p->insert || hs->failed)
+			continue;
+		for(c = p->xi->clients; c && c != p->xic; c = c->next)
+			;
+		if(!c)
+			continue;
+		if((n = a2amd_unit_tapped(hs->ctxs[p->dev], p->uid, (unsigned)p->frag, bufs)) < 0)
+		{
+			fail(hs, "a2amd_unit_tapped", n);
+			continue;
+		}
+		for(i = 0; i < n; ++i)
+		{
+			for(s = 0; s < p->frames; ++s)
+				tmp[i][s] = bufs[i][p->offset + s];
+			bufp[i] = tmp[i];
+			outp[i] = tmp[i];
+		}
+		if((rc = c->callback(bufp, n, p->frames, c->userdata)))
+			client_error(p->xi, rc, p->what);
+		if((rc = a2amd_unit_insert(hs->ctxs[p->dev], p->uid, (unsigned)p->frag, p->offset, p->frames, outp)))
+			fail(hs, "a2amd_unit_insert", rc);
+	}
+	hs->ninserts = 0;
+}
+
+/* the batch recorded so far -> audio (outp[channel], at most cap frames) */
+static int render_batch(HOSTSTATE *hs, int32_t **outp, unsigned cap)
+{
+	int n;
+	if(!hs->ninserts)
+		return a2amd_render_group(hs->ctxs, hs->ndev, A2AMD_RENDER_ALL, outp, cap);
+	/* (insert clients are only accepted with one context) */
+	if((n = a2amd_render(hs->ctx, A2AMD_RENDER_UPLOAD | A2AMD_RENDER_SUBTREES | A2AMD_RENDER_TAPS, NULL, 0)) < 0)
+		return n;
+	deliver_inserts(hs);
+	return a2amd_render(hs->ctx, A2AMD_RENDER_ROOT | A2AMD_RENDER_READBACK, outp, cap);
+}
+
 /* render what has been recorded of the buffer so far */
 static void flush_batch(HOSTSTATE *hs)
 {
@@ -829,7 +894,7 @@ static void flush_batch(HOSTSTATE *hs)
 		outp[c] = hs->acc[c] ? hs->acc[c] + hs->acc_pos : NULL;
 	if(!hs->failed)
 	{
-		n = a2amd_render_group(hs->ctxs, hs->ndev, A2AMD_RENDER_ALL, outp, hs->acc_cap - hs->acc_pos);
+		n = render_batch(hs, outp, hs->acc_cap - hs->acc_pos);
 		if(n != (int)(hs->rec_pos - hs->acc_pos))
 			fail(hs, "a2amd_render", n);
 	}
@@ -1093,7 +1158,7 @@ static void amd_process(A2P_unit *u, unsigned offset, unsigned frames)
 			outp[c] = hs->out[c];
 		if(!hs->failed)
 		{
-			n = a2amd_render_group(hs->ctxs, hs->ndev, A2AMD_RENDER_ALL, outp, A2AMD_MAXFRAG);
+			n = render_batch(hs, outp, A2AMD_MAXFRAG);
 			if(n != (int)frames)
 				fail(hs, "a2amd_render", n);
 		}

@@ -214,11 +214,27 @@ uint8_t *a2amd_default_map(a2amd_ctx *ctx, unsigned *nslots);
  * on: A2AMD_XIO_TAP leaves every window's input where a2amd_unit_tapped() finds
  * it after a READBACK render (what READ-only clients are handed),
  * A2AMD_XIO_INJECT adds what a2amd_unit_inject() collected to the unit's output
- * (what WRITE-only clients produced).  Insert clients (READ and WRITE) would
- * need the audio on the host in the middle of a batch: not supported. */
+ * (what WRITE-only clients produced).
+ * Insert clients (READ and WRITE: a2_InsertCallback; xi_process hands each of them
+ * a copy of the input and emits the sum of what they made of it INSTEAD of the
+ * input, xinsert.c:95-123) need the voice's audio on the host in the middle of
+ * the render.  That is served where the render has a seam: on a unit for which
+ * a2amd_unit_insertable() says 1 - the last unit of a voice directly below the root
+ * voice (the xinsert of a2_NewGroup's driver, audiality2.c:283-302), wired and
+ * adding.  Mode A2AMD_XIO_TAP | A2AMD_XIO_MUTE: the unit's input is tapped and NOT
+ * passed on; the host renders a2amd_render(UPLOAD | SUBTREES | TAPS), reads the
+ * windows with a2amd_unit_tapped(), runs the clients and hands the sum of their
+ * outputs back with a2amd_unit_insert(), then a2amd_render(ROOT | READBACK) adds
+ * it to the voice's output before the root chain runs. */
 #define A2AMD_XIO_TAP     1u
 #define A2AMD_XIO_INJECT  2u
+#define A2AMD_XIO_MUTE    4u
 int  a2amd_unit_clients(a2amd_ctx *ctx, int unit, unsigned mode);
+int  a2amd_unit_insertable(a2amd_ctx *ctx, int unit);
+/* ... window [offset, offset+frames) of fragment 'fragment' of the batch being
+ * rendered (between its SUBTREES | TAPS and its ROOT phase); adds up over calls */
+int  a2amd_unit_insert(a2amd_ctx *ctx, int unit, unsigned fragment, unsigned offset, unsigned frames,
+		const int32_t *const *bufs);
 /* Add 'frames' frames per input channel (bufs[ch][0..frames)) to what the unit
  * emits over [offset, offset+frames) of the open fragment - call it before the
  * a2amd_unit_process() of that window. */
@@ -238,6 +254,7 @@ int  a2amd_inline_end(a2amd_ctx *ctx, int unit);
 #define A2AMD_RENDER_ROOT     2u  /* kernels: root voice chain -> master bus  */
 #define A2AMD_RENDER_UPLOAD   4u  /* ship the recorded commands to the GPU    */
 #define A2AMD_RENDER_READBACK 8u  /* master bus -> out[], wait for the GPU    */
+#define A2AMD_RENDER_TAPS     64u /* with SUBTREES, without ROOT: wait for the GPU and fetch the batch's taps (a2amd_unit_tapped) */
 #define A2AMD_RENDER_KEEP    16u  /* keep the recording (re-run it next call) */
 #define A2AMD_RENDER_ASYNC   32u  /* READBACK does not wait: a2amd_collect() delivers */
 #define A2AMD_RENDER_ALL     15u

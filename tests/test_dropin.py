@@ -123,10 +123,12 @@ def test_dropin_refuses_mixed_chains(tmp_path):
     r = subprocess.run([REF_RENDER, f"{A2S}/mixedhead.a2s", "Main", "640", "64", "48000", "2", str(tmp_path / "h.pcm"), "0.1"],
                        env=env, cwd=A2S, capture_output=True, text=True, timeout=120)
     assert "takes its input from a unit that is not replaced" in r.stderr, r.stderr[-500:]
-    # an insert client (reads AND writes) on a voice other than the root would need
-    # that voice's audio on the host in the middle of the GPU batch: reported, not served
+    # an insert client (reads AND writes) needs the voice's audio on the host in the
+    # middle of the render: served on the root voice and on voices directly below it
+    # (test_dropin_serves_sink_and_source_clients), elsewhere - here: with the voice
+    # tree spread over two contexts - reported, not served
     cmd = [REF_RENDER, f"{A2S}/sinkgroup.a2s", "Main", "640", "64", "48000", "2", str(tmp_path / "s.pcm"), "0.1"]
-    r = subprocess.run(cmd, env=dict(env, A2REF_INSERT="1"), cwd=A2S, capture_output=True, text=True, timeout=120)
+    r = subprocess.run(cmd, env=dict(env, A2REF_INSERT="1", A2AMD_DEVICES="2"), cwd=A2S, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "insert client" in r.stderr + r.stdout, r.stderr[-500:]
 
 
@@ -135,14 +137,19 @@ def test_dropin_refuses_mixed_chains(tmp_path):
 @pytest.mark.parametrize("clients", [(), ("SINK",), ("SOURCE",), ("SOURCE", "SINK"), ("STREAMS",), ("STREAMS", "SINK"),
                                      # ... and the voice is killed 0.7 ms into a buffer: its clients are owed
                                      # the windows of a fragment that is rendered after the voice is gone
-                                     ("SINK", "KILL"), ("SOURCE", "STREAMS", "SINK", "KILL")])
+                                     ("SINK", "KILL"), ("SOURCE", "STREAMS", "SINK", "KILL"),
+                                     # an insert client (a2_InsertCallback) on the group: it is handed the
+                                     # group's audio and what it returns replaces it, between the two halves
+                                     # of the render
+                                     ("INSERT",), ("INSERT", "SINK"), ("INSERT", "SOURCE", "SINK"), ("INSERT", "KILL")])
 @pytest.mark.parametrize("buffer", [64, 1024])
 def test_dropin_serves_sink_and_source_clients(tmp_path, script, frames, clients, buffer):
-    """a2_SinkCallback / a2_SourceCallback on a voice in the middle
-    of the graph (a group: inline; panmix; xinsert), and their buffered variants
-    a2_OpenSink / a2_OpenSource (STREAMS).  The sink is handed what it is handed
-    on the CPU (hash over everything it saw, in order), the source's audio is in
-    the output, the output is the reference's."""
+    """a2_SinkCallback / a2_SourceCallback / a2_InsertCallback on a voice
+    in the middle of the graph (a group: inline; panmix; xinsert), and the buffered
+    variants a2_OpenSink / a2_OpenSource (STREAMS).  The sink is handed what it is
+    handed on the CPU (hash over everything it saw, in order), the source's audio is
+    in the output, the insert client's output replaces the group's, the output is the
+    reference's."""
     need_ref()
     res = []
     for preload in (False, True):
