@@ -166,9 +166,9 @@ int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, co
 int a2d_launch_scatter_runs(const int *didx, const A2DRun *dval, int n, A2DRun *druns, void *stream);
 int a2d_launch_leaf_osc2pan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
 		int vpw, int ysplit, int *ustage, void *stream, A2DCommit *defer);
-// wtosc[+wtosc] -> panmix voices that carry records this batch (nosc = 1 | 2)
-int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc, const int *dlist, int nlist,
-		int vpw, void *stream);
+// wtosc[+wtosc] [-> filter12] -> panmix voices that carry records this batch (nosc = 1 | 2, filt = 0 | 1)
+int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc, int filt, const int *dlist,
+		int nlist, int vpw, void *stream);
 // fm -> panmix leaf voices of ONE unit kind (a2amd_unitkind A2AMD_FM1..FM4R)
 int a2d_launch_leaf_fmpan(const A2DParams *dparams, const A2DParams &hp, int kind, const int *dlist, int nlist,
 		int vpw, void *stream);

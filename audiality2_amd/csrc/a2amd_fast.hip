@@ -1042,7 +1042,47 @@ DEV void osc_write_s(const FastPtrs &g, OscS &o, int reg, int v, int start, int 
 	}
 }
 
-template<int NOSC>
+// filter12 state of one voice, wave-uniform (A2_filter12, filter12.c:36-56; one channel)
+enum { FS_Q = 0, FS_LP = 4, FS_BP, FS_HP, FS_F1, FS_D1, FS_D2, FS_F1NEXT, FS_RAMP, FS_NWORDS };
+struct FiltS { Ramp q; int lp, bp, hp, f1, d1, d2, f1next, ramp; };
+
+// One window of f12_process (filter12.c:74-119) over the frames a wavefront holds one per
+// lane: the recurrence runs on the SCALAR unit - a v_readlane, a dozen dependent scalar
+// operations (they issue back to back, where dependent vector operations of one wavefront
+// are four cycles apart) and a lane-select per frame.
+DEV int filt_window_s(FiltS &fs, int x, int off, int len, int lane)
+{
+	int f0 = fs.f1, df = 0, f1 = fs.f1;
+	ramp_prepare_s(fs.q, len);
+	if(fs.ramp) {		// the host ran the cutoff ramper and f12_pitch2coeff (R_F1RAMP)
+		f1 = fs.f1next;
+		df = rfl(wadd(wsub(f1, f0), len >> 1) / len);
+	}
+	int qv = fs.q.value, d1 = fs.d1, d2 = fs.d2;
+	const int qd = fs.q.delta, lp = fs.lp, bp = fs.bp, hp = fs.hp;
+	for(int s = 0; s < len; ++s) {
+		const int xin = rdl(x, off + s);
+		const int f = f0 >> 12, qq = qv >> 12;
+		const int d1s = d1 >> 4;
+		const int l = wadd(d2, wmul(f, d1s) >> 8);
+		const int h = wsub(wsub(xin >> 5, l), wmul(qq, d1s) >> 8);
+		const int b = wadd(wmul(f, h >> 4) >> 8, d1);
+		const int out = wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3;
+		d1 = b;
+		d2 = l;
+		f0 = wadd(f0, df);
+		qv = wadd(qv, qd);
+		x = (lane == off + s) ? out : x;
+	}
+	fs.d1 = d1;
+	fs.d2 = d2;
+	fs.q.value = qv;	// (= a2_RunRamper(&q, 1) per frame)
+	fs.f1 = f1;
+	fs.ramp = 0;
+	return x;
+}
+
+template<int NOSC, int FILT>
 __global__ __launch_bounds__(64 * RECS_WPB)
 void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
 		const A2DVoice *__restrict__ voices, int *ustate, int *vactive,
@@ -1075,8 +1115,12 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 		ffr[k] = (k * 64 + lane < nfrags) ? p.fragframes[k * 64 + lane] : 0;
 
 	// lane v keeps voice v
-	int so[NOSC][OV_NWORDS], sp[8], uu[NOSC + 1];
+	int so[NOSC][OV_NWORDS], sp[8], uu[NOSC + FILT + 1];
+	int sf[FS_NWORDS];		// filter12 (FILT): q ramper, lp bp hp, f1, d1 d2, f1next, ramp flag
 	int my_off = -1, my_nch = 2, rcur = 0, rend = 0, act = 0, slot = -1;
+#pragma unroll
+	for(int k = 0; k < FS_NWORDS; ++k)
+		sf[k] = 0;
 #pragma unroll
 	for(int o = 0; o < NOSC; ++o)
 #pragma unroll
@@ -1086,7 +1130,7 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 	for(int k = 0; k < 8; ++k)
 		sp[k] = 0;
 #pragma unroll
-	for(int o = 0; o <= NOSC; ++o)
+	for(int o = 0; o <= NOSC + FILT; ++o)
 		uu[o] = 0;
 	if(lane < nv) {
 		slot = list[first + lane];
@@ -1105,8 +1149,17 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 				so[o][OV_A + k] = w[OW_A + k];
 			}
 		}
-		uu[NOSC] = vc.unit[NOSC];
-		const int *wp = ustate + (size_t)uu[NOSC] * A2D_USTATE;
+		if(FILT) {
+			uu[NOSC] = vc.unit[NOSC];
+			const int *wf = ustate + (size_t)uu[NOSC] * A2D_USTATE;
+#pragma unroll
+			for(int k = 0; k < 4; ++k)
+				sf[FS_Q + k] = wf[FW_Q + k];
+			sf[FS_LP] = wf[FW_LP]; sf[FS_BP] = wf[FW_BP]; sf[FS_HP] = wf[FW_HP]; sf[FS_F1] = wf[FW_F1];
+			sf[FS_D1] = wf[FW_D1A]; sf[FS_D2] = wf[FW_D2A]; sf[FS_F1NEXT] = wf[FW_F1NEXT]; sf[FS_RAMP] = wf[FW_RAMP];
+		}
+		uu[NOSC + FILT] = vc.unit[NOSC + FILT];
+		const int *wp = ustate + (size_t)uu[NOSC + FILT] * A2D_USTATE;
 #pragma unroll
 		for(int k = 0; k < 8; ++k)
 			sp[k] = wp[k];
@@ -1140,6 +1193,14 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 				osc_from_lanes(os[o], so[o], v);
 			vol.value = rdl(sp[0], v); vol.target = rdl(sp[1], v); vol.delta = rdl(sp[2], v); vol.timer = rdl(sp[3], v);
 			pan.value = rdl(sp[4], v); pan.target = rdl(sp[5], v); pan.delta = rdl(sp[6], v); pan.timer = rdl(sp[7], v);
+			FiltS fs;
+			if(FILT) {
+				fs.q.value = rdl(sf[FS_Q], v); fs.q.target = rdl(sf[FS_Q + 1], v);
+				fs.q.delta = rdl(sf[FS_Q + 2], v); fs.q.timer = rdl(sf[FS_Q + 3], v);
+				fs.lp = rdl(sf[FS_LP], v); fs.bp = rdl(sf[FS_BP], v); fs.hp = rdl(sf[FS_HP], v);
+				fs.f1 = rdl(sf[FS_F1], v); fs.d1 = rdl(sf[FS_D1], v); fs.d2 = rdl(sf[FS_D2], v);
+				fs.f1next = rdl(sf[FS_F1NEXT], v); fs.ramp = rdl(sf[FS_RAMP], v);
+			}
 			int rc = rdl(rcur, v), active = rdl(act, v);
 			const int re = rdl(rend, v);
 			const bool me = lane == v;
@@ -1156,6 +1217,8 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 					int x = osc_fragment_s(g, os[0], len, fl);
 					if(NOSC > 1)
 						x = wadd(x, osc_fragment_s(g, os[NOSC - 1], len, fl));
+					if(FILT)
+						x = filt_window_s(fs, x, off, len, lane);
 					pan_fragment_s(vol, pan, x, len, fl, o0, o1);
 #ifdef RECS_PROF
 					asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
@@ -1184,14 +1247,21 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 							// (the words this kernel does not keep: wtosc's noise
 							// sample and seed)
 #pragma unroll
-							for(int o = 0; o <= NOSC; ++o)
+							for(int o = 0; o <= NOSC + FILT; ++o)
 								if(u == o && lane < A2D_USTATE)
 									ustate[(size_t)rdl(uu[o], v) * A2D_USTATE + lane] = 0;
 #pragma unroll
 							for(int o = 0; o < NOSC; ++o)
 								if(u == o)
 									osc_init_s(g, os[o], value);
-							if(u == NOSC) {		// panmix_Initialize, panmix.c:252-284
+							if(FILT && u == NOSC) {	// f12_Initialize, filter12.c:180-221; value = f1 from the host
+								ramp_init(fs.q, 0);
+								ramp_set(fs.q, 32768, 0, 0);	// f12_Q(u, 0, 0, 0)
+								fs.lp = 65536 >> 8;
+								fs.bp = fs.hp = fs.d1 = fs.d2 = fs.f1next = fs.ramp = 0;
+								fs.f1 = value;
+							}
+							if(u == NOSC + FILT) {	// panmix_Initialize, panmix.c:252-284
 								ramp_init(vol, 65536);
 								ramp_init(pan, 0);
 							}
@@ -1202,11 +1272,33 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 							for(int o = 0; o < NOSC; ++o)
 								if(u == o)
 									osc_write_s(g, os[o], reg, value, (int)start, (int)dur);
-							if(u == NOSC) {
+							if(FILT && u == NOSC) {	// filter12.c:149-177 (the host did the 1/q)
+								if(reg == 1)
+									ramp_set(fs.q, value, (int)start, (int)dur);
+								else if(reg == 2)
+									fs.lp = value >> 8;
+								else if(reg == 3)
+									fs.bp = value >> 8;
+								else if(reg == 4)
+									fs.hp = value >> 8;
+							}
+							if(u == NOSC + FILT) {
 								if(reg == 0)
 									ramp_set(vol, value, (int)start, (int)dur);
 								else
 									ramp_set(pan, value, (int)start, (int)dur);
+							}
+							break;
+						  case R_F1SET:		// f12_CutOff without a ramp: the host's coefficient
+							if(FILT) {
+								fs.f1 = value;
+								fs.ramp = 0;
+							}
+							break;
+						  case R_F1RAMP:	// ... and one per window while the cutoff ramps
+							if(FILT) {
+								fs.f1next = value;
+								fs.ramp = 1;
 							}
 							break;
 						  case R_KILL:
@@ -1229,6 +1321,12 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 #pragma unroll
 			for(int o = 0; o < NOSC; ++o)
 				osc_to_lanes(so[o], os[o], me);
+			if(FILT) {
+				WRL(sf[FS_Q], fs.q.value); WRL(sf[FS_Q + 1], fs.q.target); WRL(sf[FS_Q + 2], fs.q.delta);
+				WRL(sf[FS_Q + 3], fs.q.timer);
+				WRL(sf[FS_LP], fs.lp); WRL(sf[FS_BP], fs.bp); WRL(sf[FS_HP], fs.hp); WRL(sf[FS_F1], fs.f1);
+				WRL(sf[FS_D1], fs.d1); WRL(sf[FS_D2], fs.d2); WRL(sf[FS_F1NEXT], fs.f1next); WRL(sf[FS_RAMP], fs.ramp);
+			}
 			WRL(sp[0], vol.value); WRL(sp[1], vol.target); WRL(sp[2], vol.delta); WRL(sp[3], vol.timer);
 			WRL(sp[4], pan.value); WRL(sp[5], pan.target); WRL(sp[6], pan.delta); WRL(sp[7], pan.timer);
 			WRL(rcur, rc);
@@ -1284,7 +1382,15 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 				w[OW_A + k] = so[o][OV_A + k];
 			}
 		}
-		int *wp = ustate + (size_t)uu[NOSC] * A2D_USTATE;
+		if(FILT) {
+			int *wf = ustate + (size_t)uu[NOSC] * A2D_USTATE;
+#pragma unroll
+			for(int k = 0; k < 4; ++k)
+				wf[FW_Q + k] = sf[FS_Q + k];
+			wf[FW_LP] = sf[FS_LP]; wf[FW_BP] = sf[FS_BP]; wf[FW_HP] = sf[FS_HP]; wf[FW_F1] = sf[FS_F1];
+			wf[FW_D1A] = sf[FS_D1]; wf[FW_D2A] = sf[FS_D2]; wf[FW_F1NEXT] = sf[FS_F1NEXT]; wf[FW_RAMP] = sf[FS_RAMP];
+		}
+		int *wp = ustate + (size_t)uu[NOSC + FILT] * A2D_USTATE;
 #pragma unroll
 		for(int k = 0; k < 8; ++k)
 			wp[k] = sp[k];
@@ -1293,28 +1399,32 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 #ifdef RECS_PROF
 	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
 	if((blockIdx.x == 0 || blockIdx.x == 700) && wv == 1 && lane == 0)
-		printf("k_leaf_recs<%d> block %d: %d voices x %d fragments: prologue %lld, loop %lld (of which %d windows %lld), epilogue %lld cycles\n",
+		printf("k_leaf_recs<%d,..> block %d: %d voices x %d fragments: prologue %lld, loop %lld (of which %d windows %lld), epilogue %lld cycles\n",
 				NOSC, (int)blockIdx.x, nv, nfrags, t_pro - t_in, t_loop - t_pro, n_win, t_win,
 				(long long)__builtin_readcyclecounter() - t_loop);
 #endif
 }
 
-int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc, const int *dlist, int nlist,
-		int vpw, void *stream)
+int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc, int filt, const int *dlist,
+		int nlist, int vpw, void *stream)
 {
 	if(nlist <= 0)
 		return 0;
 	vpw = min(max(vpw, 1), 64);
 	const int nwaves = (nlist + vpw - 1) / vpw;
 	const int nblocks = (nwaves + RECS_WPB - 1) / RECS_WPB;
-	if(nosc == 1)
-		hipLaunchKernelGGL(k_leaf_recs<1>, dim3(nblocks), dim3(64 * RECS_WPB), 0, (hipStream_t)stream,
-				dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.vactive, hp.wavepool, hp.waves,
-				hp.ptab, hp.busmem);
+#define RECS_LAUNCH(N, F) hipLaunchKernelGGL((k_leaf_recs<N, F>), dim3(nblocks), dim3(64 * RECS_WPB), 0, \
+		(hipStream_t)stream, dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.vactive, hp.wavepool, \
+		hp.waves, hp.ptab, hp.busmem)
+	if(nosc == 1 && !filt)
+		RECS_LAUNCH(1, 0);
+	else if(nosc == 2 && !filt)
+		RECS_LAUNCH(2, 0);
+	else if(nosc == 1)
+		RECS_LAUNCH(1, 1);
 	else
-		hipLaunchKernelGGL(k_leaf_recs<2>, dim3(nblocks), dim3(64 * RECS_WPB), 0, (hipStream_t)stream,
-				dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.vactive, hp.wavepool, hp.waves,
-				hp.ptab, hp.busmem);
+		RECS_LAUNCH(2, 1);
+#undef RECS_LAUNCH
 	return (int)hipGetLastError();
 }
 

@@ -229,7 +229,8 @@ struct HVoice {
 
 struct DepthRange { int fast_first = 0, fast_count = 0, fbd_first = 0, fbd_count = 0, gen_first = 0, gen_count = 0,
 		dyn_first = 0, dyn_count = 0; };
-enum { CLS_GENERIC = 0, CLS_OSCPAN, CLS_OSCFILTPAN, CLS_BUSDRIVER, CLS_BUSGENERIC, CLS_OSC2PAN, CLS_FMPAN, CLS_FBDCHAIN };
+enum { CLS_GENERIC = 0, CLS_OSCPAN, CLS_OSCFILTPAN, CLS_BUSDRIVER, CLS_BUSGENERIC, CLS_OSC2PAN, CLS_FMPAN, CLS_FBDCHAIN,
+	CLS_OSC2FILTPAN };
 
 // host side of an xinsert client slot
 struct XioSlot {
@@ -276,7 +277,8 @@ struct a2amd_ctx {
 	std::vector<int> dirty_voices;		// voice mirror entries to re-upload
 	long long serial_base = 0;		// fragments rendered before this batch
 	int n_leaf_dyn = 0, static_len = 0;
-	int n_dyn_osc1 = 0, n_dyn_osc2 = 0;	// ... of n_leaf_dyn, first in the list: k_leaf_recs<1 | 2> renders them
+	int n_dyn_osc1 = 0, n_dyn_osc2 = 0, n_dyn_filt = 0;	// ... of n_leaf_dyn, first in the list: k_leaf_recs renders them
+	int n_o2f_leaf = 0;			// 2 x wtosc-filter12-panmix leaves (list_all, behind the general leaves)
 	int n_started_live = 0;			// voices the engine is walking
 	int walked_started = 0;			// ... of which it has walked this many in the open fragment
 	int n_noise = 0, n_cutoff_ramps = 0;
@@ -499,7 +501,7 @@ void push_rec(a2amd_ctx *c, int vi, int op, int unit, int reg, int value, unsign
 {
 	touch(c, vi);
 	spell_out_pending(c, vi);
-	if(op != R_SEG && op != R_WRITE && op != R_INIT && op != R_KILL)
+	if(op == R_NOISESEED)
 		c->voices[vi].fancy_recs = true;
 	A2DRec r;
 	r.head = A2D_HEAD(rec_tag(c), op, unit, reg);
@@ -663,7 +665,24 @@ bool is_oscfiltpan_chain(const a2amd_ctx *c, const HVoice &v)
 	return o.kind == A2AMD_WTOSC && !(o.flags & A2AMD_PROCADD) && !o.wired &&
 			(o.mode == A2D_OSC_MIPWAVE || o.mode == A2D_OSC_OFF) &&
 			f.kind == A2AMD_FILTER12 && f.nin == 1 && !f.wired && !(f.flags & A2AMD_PROCADD) &&
-			f.cutoff.timer == 0 && f.cutoff.delta == 0 &&
+			// (a ramping cutoff means an R_F1RAMP record per window: such a voice is never
+			// without records, and the quiet kernel skips voices with records)
+			pm.kind == A2AMD_PANMIX && pm.nin == 1 && pm.nout == 2 && pm.wired &&
+			(pm.flags & A2AMD_PROCADD);
+}
+
+// wtosc (replacing) + wtosc (adding) -> filter12 (1 channel, replacing) -> panmix 1->2 adding into the
+// output bus: the usual subtractive-synth note
+bool is_osc2filtpan_chain(const a2amd_ctx *c, const HVoice &v)
+{
+	if(v.nunits != 4 || v.out_nch < 2)
+		return false;
+	const HUnit &a = c->units[v.unit[0]], &b = c->units[v.unit[1]], &f = c->units[v.unit[2]], &pm = c->units[v.unit[3]];
+	return a.kind == A2AMD_WTOSC && !(a.flags & A2AMD_PROCADD) && !a.wired &&
+			(a.mode == A2D_OSC_MIPWAVE || a.mode == A2D_OSC_OFF) &&
+			b.kind == A2AMD_WTOSC && (b.flags & A2AMD_PROCADD) && !b.wired &&
+			(b.mode == A2D_OSC_MIPWAVE || b.mode == A2D_OSC_OFF) &&
+			f.kind == A2AMD_FILTER12 && f.nin == 1 && !f.wired && !(f.flags & A2AMD_PROCADD) &&
 			pm.kind == A2AMD_PANMIX && pm.nin == 1 && pm.nout == 2 && pm.wired &&
 			(pm.flags & A2AMD_PROCADD);
 }
@@ -884,7 +903,7 @@ int upload(a2amd_ctx *c)
 	// form the dynamic part (this batch's exceptions) and go to the general kernel.
 	if(c->lists_dirty) {
 		bool owners_ok = !getenv("A2AMD_NO_SELFCLEAN"), root_driver = false;
-		std::vector<int> fast_leaf, osc2_leaf, filt_leaf, fm_leaf, gen_leaf;
+		std::vector<int> fast_leaf, osc2_leaf, filt_leaf, fm_leaf, gen_leaf, o2f_leaf;
 		std::map<int, std::pair<std::vector<int>, std::vector<int>>> bydepth;
 		std::map<int, std::vector<int>> fbd_bydepth;
 		int maxdepth = -1;
@@ -911,11 +930,15 @@ int upload(a2amd_ctx *c)
 				v.cls = !(c->no_fast & 1) && is_oscpan_chain(c, v) ? CLS_OSCPAN :
 						!(c->no_fast & 8) && is_osc2pan_chain(c, v) ? CLS_OSC2PAN :
 						!(c->no_fast & 2) && is_oscfiltpan_chain(c, v) ? CLS_OSCFILTPAN :
+						// (no quiet kernel of its own: k_leaf_recs renders it, records or not - unless an
+						// oscillator leaves the mip-mapped waves somewhere in this batch)
+						!(c->no_fast & 128) && !v.mode_mix && is_osc2filtpan_chain(c, v) ? CLS_OSC2FILTPAN :
 						!(c->no_fast & 16) && is_fmpan_chain(c, v) ? CLS_FMPAN : CLS_GENERIC;
 				if(v.out_off == 0)
 					owners_ok = false;	// adds straight into the master bus
 				(v.cls == CLS_OSCPAN ? fast_leaf : v.cls == CLS_OSC2PAN ? osc2_leaf :
-				 v.cls == CLS_OSCFILTPAN ? filt_leaf : v.cls == CLS_FMPAN ? fm_leaf : gen_leaf).push_back((int)vi);
+				 v.cls == CLS_OSCFILTPAN ? filt_leaf : v.cls == CLS_FMPAN ? fm_leaf :
+				 v.cls == CLS_OSC2FILTPAN ? o2f_leaf : gen_leaf).push_back((int)vi);
 			}
 		}
 		auto by_bus = [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; };
@@ -944,6 +967,9 @@ int upload(a2amd_ctx *c)
 		}
 		c->list_all.insert(c->list_all.end(), gen_leaf.begin(), gen_leaf.end());
 		c->n_leaf = (int)gen_leaf.size();
+		std::stable_sort(o2f_leaf.begin(), o2f_leaf.end(), by_bus);
+		c->list_all.insert(c->list_all.end(), o2f_leaf.begin(), o2f_leaf.end());
+		c->n_o2f_leaf = (int)o2f_leaf.size();
 		c->depth_ranges.assign(maxdepth + 1, DepthRange());
 		for(int d = 0; d <= maxdepth; ++d) {
 			auto &l = bydepth[d];
@@ -984,25 +1010,26 @@ int upload(a2amd_ctx *c)
 		// mip-mapped waves throughout the batch) go first, by class; the rest -
 		// filter voices, a wave of another kind somewhere in the batch - to the
 		// general kernel.
-		std::vector<int> dyn_o1, dyn_o2, dyn_rest;
+		std::vector<int> dyn_o1, dyn_o2, dyn_f1, dyn_rest;
 		const bool no_recs_kernel = (c->no_fast & 64) != 0;
 		for(int vi : dyn_leaf) {
 			const HVoice &v = c->voices[vi];
 			// (close_fragment's R_NOP is the one other record k_leaf_recs takes - as nothing)
-			const bool ok = !no_recs_kernel && (v.cls == CLS_OSCPAN || v.cls == CLS_OSC2PAN) && !v.mode_mix &&
-					!v.fancy_recs;
-			(!ok ? dyn_rest : v.cls == CLS_OSCPAN ? dyn_o1 : dyn_o2).push_back(vi);
+			const bool ok = !no_recs_kernel && !v.mode_mix && !v.fancy_recs;
+			(!ok ? dyn_rest : v.cls == CLS_OSCPAN ? dyn_o1 : v.cls == CLS_OSC2PAN ? dyn_o2 : dyn_f1).push_back(vi);
 		}
 		// (the walk order usually has them grouped by bus already)
 		auto by_bus_dyn = [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; };
-		for(std::vector<int> *l : { &dyn_o1, &dyn_o2, &dyn_rest })
+		for(std::vector<int> *l : { &dyn_o1, &dyn_o2, &dyn_f1, &dyn_rest })
 			if(!std::is_sorted(l->begin(), l->end(), by_bus_dyn))
 				std::stable_sort(l->begin(), l->end(), by_bus_dyn);
 		std::vector<int> dyn = dyn_o1;
 		dyn.insert(dyn.end(), dyn_o2.begin(), dyn_o2.end());
+		dyn.insert(dyn.end(), dyn_f1.begin(), dyn_f1.end());
 		dyn.insert(dyn.end(), dyn_rest.begin(), dyn_rest.end());
 		c->n_dyn_osc1 = (int)dyn_o1.size();
 		c->n_dyn_osc2 = (int)dyn_o2.size();
+		c->n_dyn_filt = (int)dyn_f1.size();
 		c->n_leaf_dyn = (int)dyn_leaf.size();
 		for(size_t d = 0; d < dyn_bus.size(); ++d) {
 			c->depth_ranges[d].dyn_first = (int)dyn.size();
@@ -1208,6 +1235,8 @@ void end_batch(a2amd_ctx *c)
 		} else {
 			v.touched = -1;
 			v.listed_recs = false;
+			if(v.mode_mix)
+				c->lists_dirty = true;	// (it may have its leaf class back)
 			v.mode_mix = false;
 			v.fancy_recs = false;
 		}
@@ -1281,7 +1310,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			pick_fast_shape(c->n_fast_leaf, c->nfrags, &vpw, &ysplit);
 			// e1 right behind the main kernel when it is the only leaf kernel
 			// of the batch: "leaf" time is then that kernel alone
-			const bool solo = !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn;
+			const bool solo = !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn && !c->n_o2f_leaf;
 			if(a2d_launch_leaf_oscpan(c->d_params, c->hparams, c->d_list.d, c->n_fast_leaf,
 					vpw, ysplit, c->d_ustage.d, c->stream, solo ? (void *)e1 : nullptr, &pend.c[pend.n]))
 				return c->fail(A2AMD_EHIP, "fast leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1345,24 +1374,37 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
-		for(int k = 0, at = 0; k < 2; at += k ? c->n_dyn_osc2 : c->n_dyn_osc1, ++k) {
-			const int n = k ? c->n_dyn_osc2 : c->n_dyn_osc1;
-			if(!n)
-				continue;
-			// a wavefront walks its voices one after the other, fragment by fragment:
-			// as many wavefronts as the chip holds before a wavefront gets a second voice
-			int vpw = getenv("A2AMD_RVPW") ? atoi(getenv("A2AMD_RVPW")) : (n + 8191) / 8192;
-			if(a2d_launch_leaf_recs(c->d_params, c->hparams, k + 1, c->d_dyn + at, n, vpw, c->stream))
-				return c->fail(A2AMD_EHIP, "leaf records launch failed: %s", hipGetErrorString(hipGetLastError()));
-			++c->stats.launches;
+		{
+			// (a wavefront walks its voices one after the other, fragment by fragment: as many
+			// wavefronts as the chip holds before a wavefront gets a second voice)
+			auto recs = [&](int nosc, int filt, const int *list, int n) -> int {
+				if(!n)
+					return 0;
+				int vpw = getenv("A2AMD_RVPW") ? atoi(getenv("A2AMD_RVPW")) : (n + 8191) / 8192;
+				if(a2d_launch_leaf_recs(c->d_params, c->hparams, nosc, filt, list, n, vpw, c->stream))
+					return c->fail(A2AMD_EHIP, "leaf records launch failed: %s", hipGetErrorString(hipGetLastError()));
+				++c->stats.launches;
+				return 0;
+			};
+			// the 2 x wtosc-filter12-panmix leaves, with and without records ...
+			if(int r = recs(2, 1, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf + c->n_fm_leaf + c->n_leaf,
+					c->n_o2f_leaf))
+				return r;
+			// ... and of the classes that have quiet kernels of their own, this batch's voices with records
+			if(int r = recs(1, 0, c->d_dyn, c->n_dyn_osc1))
+				return r;
+			if(int r = recs(2, 0, c->d_dyn + c->n_dyn_osc1, c->n_dyn_osc2))
+				return r;
+			if(int r = recs(1, 1, c->d_dyn + c->n_dyn_osc1 + c->n_dyn_osc2, c->n_dyn_filt))
+				return r;
 		}
-		if(c->n_leaf_dyn - c->n_dyn_osc1 - c->n_dyn_osc2 > 0) {
-			const int n = c->n_leaf_dyn - c->n_dyn_osc1 - c->n_dyn_osc2;
-			if(a2d_launch_voices(c->d_params, c->d_dyn + c->n_dyn_osc1 + c->n_dyn_osc2, n, pick_vpw(n), c->stream))
+		if(c->n_leaf_dyn - c->n_dyn_osc1 - c->n_dyn_osc2 - c->n_dyn_filt > 0) {
+			const int n = c->n_leaf_dyn - c->n_dyn_osc1 - c->n_dyn_osc2 - c->n_dyn_filt;
+			if(a2d_launch_voices(c->d_params, c->d_dyn + c->n_dyn_osc1 + c->n_dyn_osc2 + c->n_dyn_filt, n, pick_vpw(n), c->stream))
 				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
-		if(e1 && !(c->n_fast_leaf && !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn))
+		if(e1 && !(c->n_fast_leaf && !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn && !c->n_o2f_leaf))
 			HIPCHK(c, hipEventRecord(e1, c->stream));
 		for(int d = (int)c->depth_ranges.size() - 1; d >= 1; --d)
 			if(int r = launch_depth(c, d, consume ? 3 : consume_sub ? 1 : 0, &pend))

@@ -162,6 +162,14 @@ class Scene:
                 oscs, pan = [units[0]], units[2]
                 be.unit_write(units[1], 0, p + fix(2.0))      # cutoff
                 be.unit_write(units[1], 1, fix(5.0))          # q
+            elif chain == "osc2-filter-pan":
+                units = [be.unit_init(key, K_WTOSC, 0, 0, 1, 0),
+                         be.unit_init(key, K_WTOSC, PROCADD, 0, 1, 0),
+                         be.unit_init(key, K_FILTER12, 0, 1, 1, 0),
+                         be.unit_init(key, K_PANMIX, PROCADD, 1, 2, 1)]
+                oscs, pan = units[:2], units[3]
+                be.unit_write(units[2], 0, p + fix(2.5))      # cutoff
+                be.unit_write(units[2], 1, fix(3.0))          # q
             elif chain == "osc2-pan":
                 units = [be.unit_init(key, K_WTOSC, 0, 0, 1, 0),
                          be.unit_init(key, K_WTOSC, PROCADD, 0, 1, 0),

@@ -277,6 +277,7 @@ def _wt_script(be, chain, nvoices=300, batches=3, bfrags=16, seed=11, groups=0, 
     for g in homes:
         sc.add_voices(nvoices // len(homes), chain=chain, group=g, total=nvoices)
     nosc = 2 if chain.startswith("osc2") else 1
+    filt = nosc if "filter" in chain else None      # chain position of the filter12
     lists = [sc.leaves] + [g["leaves"] for g in sc.groups]
     chunks = []
     frag = 0
@@ -321,6 +322,11 @@ def _wt_script(be, chain, nvoices=300, batches=3, bfrags=16, seed=11, groups=0, 
                     be.unit_write(osc, reg, val, int(rng.integers(0, 256)), dur)
                     if rng.random() < 0.4:
                         be.unit_write(pan, int(rng.integers(0, 2)), synth.fix(float(rng.uniform(-1.5, 1.5))), 0, dur)
+                    if filt is not None and rng.random() < 0.5:
+                        freg = int(rng.integers(0, 5))      # cutoff (set or ramp), q, lp, bp, hp
+                        fval = synth.fix(float(rng.uniform(-1, 5))) if freg == 0 else \
+                            synth.fix(float(rng.uniform(0.2, 9))) if freg == 1 else synth.fix(float(rng.uniform(0, 1)))
+                        be.unit_write(units[filt], freg, fval, int(rng.integers(0, 256)), dur)
                     window(units, at, c - at)
                     at = c
 
@@ -350,7 +356,7 @@ def _wt_script(be, chain, nvoices=300, batches=3, bfrags=16, seed=11, groups=0, 
     return np.concatenate(chunks, axis=1)
 
 
-@pytest.mark.parametrize("chain,groups", [("osc-pan", 0), ("osc2-pan", 3), ("osc-filter-pan", 0)])
+@pytest.mark.parametrize("chain,groups", [("osc-pan", 0), ("osc2-pan", 3), ("osc-filter-pan", 0), ("osc2-filter-pan", 2)])
 @pytest.mark.parametrize("bfrags", [1, 16])
 def test_host_walk_short_cuts_match_oracle(oracle_lib, chain, groups, bfrags):
     """a2amd_voice_process + a2amd_default_map (what the drop-in's Process callbacks
@@ -367,13 +373,16 @@ def test_host_walk_short_cuts_match_oracle(oracle_lib, chain, groups, bfrags):
     assert first_diff(got, want) is None
 
 
-@pytest.mark.parametrize("chain,groups", [("osc-pan", 0), ("osc2-pan", 0), ("osc2-pan", 3), ("osc-filter-pan", 0)])
+@pytest.mark.parametrize("chain,groups", [("osc-pan", 0), ("osc2-pan", 0), ("osc2-pan", 3), ("osc-filter-pan", 0),
+                                          ("osc-filter-pan", 2), ("osc2-filter-pan", 0), ("osc2-filter-pan", 3)])
 @pytest.mark.parametrize("rvpw", [1, 5, 64])
 def test_wavetable_leaf_kernel_executes_records(oracle_lib, monkeypatch, chain, groups, rvpw):
-    """k_leaf_recs: wtosc[+wtosc]->panmix voices that carry records in a batch
-    (writes between windows, windows inside a fragment, births, deaths) are
-    rendered by the records-executing leaf kernel, not the general one (filter
-    voices still are); with one, a few and 64 voices per wavefront."""
+    """k_leaf_recs: wtosc[+wtosc][->filter12]->panmix voices that carry records in a
+    batch (writes between windows, windows inside a fragment, births, deaths; with a
+    filter also cutoff sets and ramps, q ramps, lp/bp/hp) are rendered by the
+    records-executing leaf kernel, not the general one; the 2 x wtosc->filter12->panmix
+    voice (the usual subtractive note) always is; with one, a few and 64 voices per
+    wavefront."""
     monkeypatch.setenv("A2AMD_RVPW", str(rvpw))
     gpu = make_gpu(max_batch=16)
     got = _wt_script(gpu, chain, groups=groups)
