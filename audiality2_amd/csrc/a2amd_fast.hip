@@ -194,6 +194,8 @@ struct OscS {		// A2_wtosc, wave-uniform copy
 	uint64_t phase;
 	int p_ramping;
 	Ramp p, a;
+	int noise;		// (wtosc_noise only: the sample held between draws, and the engine RNG word
+	unsigned seed;		// the host recorded for the window, R_NOISESEED - k_leaf_recs)
 };
 
 struct FastPtrs {
@@ -256,6 +258,40 @@ DEV int osc_fragment_s(const FastPtrs &g, OscS &o, int nframes, int lane)
 				ramp_run(o.a, nframes);
 			}
 		}
+	} else if(o.mode == A2D_OSC_NOISE) {	// wtosc_noise, wtosc.c:129-152
+		// wtosc_run_pitch
+		ramp_prepare_s(o.p, nframes);
+		if(!(o.dphase && (!o.p.timer && !o.p_ramping))) {
+			unsigned lastv = (unsigned)o.p.value;
+			ramp_run(o.p, nframes);
+			o.p_ramping = o.p.delta;
+			o.dphase = (unsigned)rfl((int)p2i(g.ptab, (int)((lastv + (unsigned)o.p.value) >> 9)));
+		}
+		ramp_prepare_s(o.a, nframes);
+		// a frame draws from the engine's one LCG when its step crosses a 2^23 boundary of the
+		// phase: which draw a lane holds is a prefix count, the draws themselves a uniform loop
+		const uint64_t phk = o.phase + (uint64_t)(unsigned)(in ? lane : 0) * o.dphase;
+		const uint64_t nph = phk + o.dphase;
+		const bool draw = in && ((o.dphase >= (1u << 23)) || ((nph ^ phk) >> 23));
+		const unsigned long long m = __ballot(draw);
+		const int me = (int)(threadIdx.x & 63);
+		const unsigned long long below = (me >= 63) ? ~0ull : ((2ull << me) - 1ull);
+		const int mine = __popcll(m & below), total = __popcll(m);
+		int held = o.noise, myval = o.noise;
+		unsigned st = o.seed;
+		for(int j = 1; j <= total; ++j) {
+			held = noise_next(st) - 32767;
+			if(j == mine)
+				myval = held;
+		}
+		o.seed = st;
+		o.noise = held;
+		if(in) {
+			int ak = wadd(o.a.value, wmul(o.a.delta, lane));
+			x = wmul(myval, ak >> 10) >> 6;
+		}
+		o.phase += (uint64_t)(unsigned)nframes * o.dphase;
+		ramp_run(o.a, nframes);
 	} else {		// wtosc_Off, wtosc.c:108-126
 		ramp_prepare_s(o.p, nframes);
 		ramp_prepare_s(o.a, nframes);
@@ -688,6 +724,8 @@ DEV void osc_from_lanes(OscS &o, const int (&so)[OV_NWORDS], int v)
 	o.p.delta = rdl(so[OV_P + 2], v); o.p.timer = rdl(so[OV_P + 3], v);
 	o.a.value = rdl(so[OV_A], v); o.a.target = rdl(so[OV_A + 1], v);
 	o.a.delta = rdl(so[OV_A + 2], v); o.a.timer = rdl(so[OV_A + 3], v);
+	o.noise = 0;
+	o.seed = 0;
 }
 
 DEV void osc_to_lanes(int (&so)[OV_NWORDS], const OscS &o, bool me)
@@ -996,6 +1034,8 @@ DEV void osc_init_s(const FastPtrs &g, OscS &o, int pitch)
 	o.mode = A2D_OSC_OFF;
 	o.phase = 0;
 	o.p_ramping = 0;
+	o.noise = 0;
+	o.seed = 0;
 	ramp_init(o.a, 0);
 	ramp_init(o.p, pitch);
 	o.dphase = (unsigned)rfl((int)p2i(g.ptab, o.p.value >> 8));
@@ -1004,8 +1044,8 @@ DEV void osc_init_s(const FastPtrs &g, OscS &o, int pitch)
 DEV void osc_write_s(const FastPtrs &g, OscS &o, int reg, int v, int start, int dur)
 {
 	switch(reg) {
-	  case 0: {	// wtosc_Wave, wtosc.c:433-483 (the host resolved the handle; only
-			// mip-mapped waves and "off" reach this kernel)
+	  case 0: {	// wtosc_Wave, wtosc.c:433-483 (the host resolved the handle; mip-mapped
+			// waves, the noise generator and "off" reach this kernel)
 		int wt = 0;
 		o.wave = v;
 		if(v >= 0) {
@@ -1016,6 +1056,8 @@ DEV void osc_write_s(const FastPtrs &g, OscS &o, int reg, int v, int start, int 
 		}
 		if(wt == 3)
 			o.mode = A2D_OSC_MIPWAVE;
+		else if(wt == 1)
+			o.mode = A2D_OSC_NOISE;
 		else {
 			o.wave = -1;
 			o.mode = A2D_OSC_OFF;
@@ -1117,6 +1159,10 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 	// lane v keeps voice v
 	int so[NOSC][OV_NWORDS], sp[8], uu[NOSC + FILT + 1];
 	int sf[FS_NWORDS];		// filter12 (FILT): q ramper, lp bp hp, f1, d1 d2, f1next, ramp flag
+	int sn[NOSC][2];		// wtosc_noise: held sample, RNG word
+#pragma unroll
+	for(int o = 0; o < NOSC; ++o)
+		sn[o][0] = sn[o][1] = 0;
 	int my_off = -1, my_nch = 2, rcur = 0, rend = 0, act = 0, slot = -1;
 #pragma unroll
 	for(int k = 0; k < FS_NWORDS; ++k)
@@ -1148,6 +1194,8 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 				so[o][OV_P + k] = w[OW_P + k];
 				so[o][OV_A + k] = w[OW_A + k];
 			}
+			sn[o][0] = w[OW_NOISE];
+			sn[o][1] = w[OW_SEED];
 		}
 		if(FILT) {
 			uu[NOSC] = vc.unit[NOSC];
@@ -1189,8 +1237,11 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 			OscS os[NOSC];
 			Ramp vol, pan;
 #pragma unroll
-			for(int o = 0; o < NOSC; ++o)
+			for(int o = 0; o < NOSC; ++o) {
 				osc_from_lanes(os[o], so[o], v);
+				os[o].noise = rdl(sn[o][0], v);
+				os[o].seed = (unsigned)rdl(sn[o][1], v);
+			}
 			vol.value = rdl(sp[0], v); vol.target = rdl(sp[1], v); vol.delta = rdl(sp[2], v); vol.timer = rdl(sp[3], v);
 			pan.value = rdl(sp[4], v); pan.target = rdl(sp[5], v); pan.delta = rdl(sp[6], v); pan.timer = rdl(sp[7], v);
 			FiltS fs;
@@ -1304,6 +1355,12 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 						  case R_KILL:
 							active = 0;
 							break;
+						  case R_NOISESEED:	// the engine's RNG word as this window of a noise oscillator finds it
+#pragma unroll
+							for(int o = 0; o < NOSC; ++o)
+								if(u == o)
+									os[o].seed = (unsigned)value;
+							break;
 						  default:
 							break;
 						}
@@ -1319,8 +1376,11 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 					}
 			}
 #pragma unroll
-			for(int o = 0; o < NOSC; ++o)
+			for(int o = 0; o < NOSC; ++o) {
 				osc_to_lanes(so[o], os[o], me);
+				WRL(sn[o][0], os[o].noise);
+				WRL(sn[o][1], (int)os[o].seed);
+			}
 			if(FILT) {
 				WRL(sf[FS_Q], fs.q.value); WRL(sf[FS_Q + 1], fs.q.target); WRL(sf[FS_Q + 2], fs.q.delta);
 				WRL(sf[FS_Q + 3], fs.q.timer);
@@ -1381,6 +1441,8 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 				w[OW_P + k] = so[o][OV_P + k];
 				w[OW_A + k] = so[o][OV_A + k];
 			}
+			w[OW_NOISE] = sn[o][0];
+			w[OW_SEED] = sn[o][1];
 		}
 		if(FILT) {
 			int *wf = ustate + (size_t)uu[NOSC] * A2D_USTATE;

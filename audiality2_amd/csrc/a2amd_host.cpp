@@ -501,8 +501,6 @@ void push_rec(a2amd_ctx *c, int vi, int op, int unit, int reg, int value, unsign
 {
 	touch(c, vi);
 	spell_out_pending(c, vi);
-	if(op == R_NOISESEED)
-		c->voices[vi].fancy_recs = true;
 	A2DRec r;
 	r.head = A2D_HEAD(rec_tag(c), op, unit, reg);
 	r.value = value;
@@ -630,6 +628,10 @@ void sync_voice_mirror(a2amd_ctx *c, int vi)
 	m.own_nch = v.own_nch;
 }
 
+// what the wavetable leaf kernels play: mip-mapped waves, nothing, and - k_leaf_recs only, but a noise
+// oscillator's every window carries an R_NOISESEED record, so the quiet kernels never see one - noise
+inline bool leaf_mode(int mode) { return mode == A2D_OSC_MIPWAVE || mode == A2D_OSC_OFF || mode == A2D_OSC_NOISE; }
+
 // wtosc (mip-mapped wave playing) -> panmix 1->2 adding into the output bus
 bool is_oscpan_chain(const a2amd_ctx *c, const HVoice &v)
 {
@@ -637,7 +639,7 @@ bool is_oscpan_chain(const a2amd_ctx *c, const HVoice &v)
 		return false;
 	const HUnit &o = c->units[v.unit[0]], &pm = c->units[v.unit[1]];
 	return o.kind == A2AMD_WTOSC && !(o.flags & A2AMD_PROCADD) && !o.wired &&
-			(o.mode == A2D_OSC_MIPWAVE || o.mode == A2D_OSC_OFF) &&
+			leaf_mode(o.mode) &&
 			pm.kind == A2AMD_PANMIX && pm.nin == 1 && pm.nout == 2 && pm.wired &&
 			(pm.flags & A2AMD_PROCADD);
 }
@@ -649,9 +651,9 @@ bool is_osc2pan_chain(const a2amd_ctx *c, const HVoice &v)
 		return false;
 	const HUnit &a = c->units[v.unit[0]], &b = c->units[v.unit[1]], &pm = c->units[v.unit[2]];
 	return a.kind == A2AMD_WTOSC && !(a.flags & A2AMD_PROCADD) && !a.wired &&
-			(a.mode == A2D_OSC_MIPWAVE || a.mode == A2D_OSC_OFF) &&
+			leaf_mode(a.mode) &&
 			b.kind == A2AMD_WTOSC && (b.flags & A2AMD_PROCADD) && !b.wired &&
-			(b.mode == A2D_OSC_MIPWAVE || b.mode == A2D_OSC_OFF) &&
+			leaf_mode(b.mode) &&
 			pm.kind == A2AMD_PANMIX && pm.nin == 1 && pm.nout == 2 && pm.wired &&
 			(pm.flags & A2AMD_PROCADD);
 }
@@ -663,7 +665,7 @@ bool is_oscfiltpan_chain(const a2amd_ctx *c, const HVoice &v)
 		return false;
 	const HUnit &o = c->units[v.unit[0]], &f = c->units[v.unit[1]], &pm = c->units[v.unit[2]];
 	return o.kind == A2AMD_WTOSC && !(o.flags & A2AMD_PROCADD) && !o.wired &&
-			(o.mode == A2D_OSC_MIPWAVE || o.mode == A2D_OSC_OFF) &&
+			leaf_mode(o.mode) &&
 			f.kind == A2AMD_FILTER12 && f.nin == 1 && !f.wired && !(f.flags & A2AMD_PROCADD) &&
 			// (a ramping cutoff means an R_F1RAMP record per window: such a voice is never
 			// without records, and the quiet kernel skips voices with records)
@@ -679,9 +681,9 @@ bool is_osc2filtpan_chain(const a2amd_ctx *c, const HVoice &v)
 		return false;
 	const HUnit &a = c->units[v.unit[0]], &b = c->units[v.unit[1]], &f = c->units[v.unit[2]], &pm = c->units[v.unit[3]];
 	return a.kind == A2AMD_WTOSC && !(a.flags & A2AMD_PROCADD) && !a.wired &&
-			(a.mode == A2D_OSC_MIPWAVE || a.mode == A2D_OSC_OFF) &&
+			leaf_mode(a.mode) &&
 			b.kind == A2AMD_WTOSC && (b.flags & A2AMD_PROCADD) && !b.wired &&
-			(b.mode == A2D_OSC_MIPWAVE || b.mode == A2D_OSC_OFF) &&
+			leaf_mode(b.mode) &&
 			f.kind == A2AMD_FILTER12 && f.nin == 1 && !f.wired && !(f.flags & A2AMD_PROCADD) &&
 			pm.kind == A2AMD_PANMIX && pm.nin == 1 && pm.nout == 2 && pm.wired &&
 			(pm.flags & A2AMD_PROCADD);
@@ -1999,8 +2001,7 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 			{
 				// the wavetable leaf kernels only know mip-mapped waves (and "off"): a
 				// voice that moves between the two kinds changes its launch class
-				const bool was = u.mode == A2D_OSC_MIPWAVE || u.mode == A2D_OSC_OFF;
-				const bool is = nmode == A2D_OSC_MIPWAVE || nmode == A2D_OSC_OFF;
+				const bool was = leaf_mode(u.mode), is = leaf_mode(nmode);
 				if(was != is)
 					c->lists_dirty = true;
 				if(!was || !is)
