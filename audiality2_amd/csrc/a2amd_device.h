@@ -169,6 +169,9 @@ int a2d_launch_leaf_osc2pan(const A2DParams *dparams, const A2DParams &hp, const
 // wtosc[+wtosc] [-> filter12] -> panmix voices that carry records this batch (nosc = 1 | 2, filt = 0 | 1)
 int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc, int filt, const int *dlist,
 		int nlist, int vpw, void *stream);
+// ... all four kinds in one launch: lists[k] / counts[k] for (nosc, filt) = (1,0) (2,0) (1,1) (2,1)
+int a2d_launch_leaf_recs_all(const A2DParams *dparams, const A2DParams &hp, const int *const *lists, const int *counts,
+		int vpw, void *stream);
 // fm -> panmix leaf voices of ONE unit kind (a2amd_unitkind A2AMD_FM1..FM4R)
 int a2d_launch_leaf_fmpan(const A2DParams *dparams, const A2DParams &hp, int kind, const int *dlist, int nlist,
 		int vpw, void *stream);

@@ -1124,12 +1124,14 @@ DEV int filt_window_s(FiltS &fs, int x, int off, int len, int lane)
 	return x;
 }
 
+// (the body of the kernels below: gw = this wavefront's index among those of its class)
+typedef int RecsPart[RECS_WPB][RECS_FCH * 2][64];
 template<int NOSC, int FILT>
-__global__ __launch_bounds__(64 * RECS_WPB)
-void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
+DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw, int gw,
 		const A2DVoice *__restrict__ voices, int *ustate, int *vactive,
 		const int16_t *__restrict__ wavepool, const A2DWave *__restrict__ waves,
-		const uint32_t *__restrict__ ptab, int *__restrict__ busmem)
+		const uint32_t *__restrict__ ptab, int *__restrict__ busmem,
+		RecsPart *part, int (*part_off)[RECS_WPB], int (*part_nch)[RECS_WPB])
 {
 #ifdef RECS_PROF
 	const long long t_in = __builtin_readcyclecounter();
@@ -1139,13 +1141,11 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 	const A2DParams &p = *pp;
 	const int wv = threadIdx.x >> 6;
 	const int lane = threadIdx.x & 63;
-	const int first = (blockIdx.x * RECS_WPB + wv) * vpw;
+	const int first = gw * vpw;
 	// (a wavefront past the end of the list still meets the others at the barriers)
 	const int nv = max(0, min(vpw, nlist - first));
 	// what the workgroup's wavefronts are left with at the end of a chunk: summed
 	// here before it goes to the bus (two buffers: one barrier per chunk)
-	__shared__ int part[2][RECS_WPB][RECS_FCH * 2][64];
-	__shared__ int part_off[2][RECS_WPB], part_nch[2][RECS_WPB];
 	const int nfrags = p.nfrags;
 	const int dbg = p.debug;
 	const A2DRec *__restrict__ recs = p.recs;
@@ -1465,6 +1465,75 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 				NOSC, (int)blockIdx.x, nv, nfrags, t_pro - t_in, t_loop - t_pro, n_win, t_win,
 				(long long)__builtin_readcyclecounter() - t_loop);
 #endif
+}
+
+
+template<int NOSC, int FILT>
+__global__ __launch_bounds__(64 * RECS_WPB)
+void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
+		const A2DVoice *__restrict__ voices, int *ustate, int *vactive,
+		const int16_t *__restrict__ wavepool, const A2DWave *__restrict__ waves,
+		const uint32_t *__restrict__ ptab, int *__restrict__ busmem)
+{
+	__shared__ RecsPart part[2];
+	__shared__ int part_off[2][RECS_WPB], part_nch[2][RECS_WPB];
+	recs_body<NOSC, FILT>(pp, list, nlist, vpw, (int)(blockIdx.x * RECS_WPB + (threadIdx.x >> 6)), voices, ustate, vactive,
+			wavepool, waves, ptab, busmem, part, part_off, part_nch);
+}
+
+// All four kinds in one launch, for plumbing-sized scenes (a song: a few dozen voices of each kind):
+// on one stream the per-kind launches run one after the other although they are independent, and each
+// takes as long as ONE voice's serial walk through the batch.  A workgroup looks its kind up in the
+// segment table (whole workgroups per kind: they sum their wavefronts' output in LDS).
+struct RecsSegs { const int *list[4]; int count[4]; };	// (1,0) (2,0) (1,1) (2,1)
+
+__global__ __launch_bounds__(64 * RECS_WPB)
+void k_leaf_recs_all(const A2DParams *__restrict__ pp, RecsSegs segs, int vpw,
+		const A2DVoice *__restrict__ voices, int *ustate, int *vactive,
+		const int16_t *__restrict__ wavepool, const A2DWave *__restrict__ waves,
+		const uint32_t *__restrict__ ptab, int *__restrict__ busmem)
+{
+	__shared__ RecsPart part[2];
+	__shared__ int part_off[2][RECS_WPB], part_nch[2][RECS_WPB];
+	int b = (int)blockIdx.x, kind = -1;
+#pragma unroll
+	for(int k = 0; k < 4; ++k) {
+		const int nb = ((segs.count[k] + vpw - 1) / vpw + RECS_WPB - 1) / RECS_WPB;
+		if(kind < 0) {
+			if(b < nb)
+				kind = k;
+			else
+				b -= nb;
+		}
+	}
+	const int gw = b * RECS_WPB + (int)(threadIdx.x >> 6);
+#define RECS_BODY(K, N, F) case K: recs_body<N, F>(pp, segs.list[K], segs.count[K], vpw, gw, voices, ustate, vactive, \
+		wavepool, waves, ptab, busmem, part, part_off, part_nch); break
+	switch(rfl(kind)) {
+	  RECS_BODY(0, 1, 0);
+	  RECS_BODY(1, 2, 0);
+	  RECS_BODY(2, 1, 1);
+	  RECS_BODY(3, 2, 1);
+	}
+#undef RECS_BODY
+}
+
+int a2d_launch_leaf_recs_all(const A2DParams *dparams, const A2DParams &hp, const int *const *lists, const int *counts,
+		int vpw, void *stream)
+{
+	RecsSegs segs;
+	int nblocks = 0;
+	vpw = min(max(vpw, 1), 64);
+	for(int k = 0; k < 4; ++k) {
+		segs.list[k] = lists[k];
+		segs.count[k] = counts[k];
+		nblocks += ((counts[k] + vpw - 1) / vpw + RECS_WPB - 1) / RECS_WPB;
+	}
+	if(!nblocks)
+		return 0;
+	hipLaunchKernelGGL(k_leaf_recs_all, dim3(nblocks), dim3(64 * RECS_WPB), 0, (hipStream_t)stream, dparams, segs, vpw,
+			hp.voices, hp.ustate, hp.vactive, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
+	return (int)hipGetLastError();
 }
 
 int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc, int filt, const int *dlist,

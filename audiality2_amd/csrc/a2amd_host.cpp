@@ -703,12 +703,18 @@ bool is_fmpan_chain(const a2amd_ctx *c, const HVoice &v)
 // inline 0 2; panmix 2 2; xinsert 2 >  (a2_rootdriver / a2_groupdriver)
 bool is_driver_chain(const a2amd_ctx *c, const HVoice &v)
 {
-	if(v.nunits != 3 || v.own_nch != 2 || v.out_nch < 2 || v.own_off < 0)
+	if((v.nunits != 3 && v.nunits != 2) || v.own_nch != 2 || v.out_nch < 2 || v.own_off < 0)
 		return false;
-	const HUnit &il = c->units[v.unit[0]], &pm = c->units[v.unit[1]], &xi = c->units[v.unit[2]];
-	return il.kind == A2AMD_INLINE && !(il.flags & A2AMD_PROCADD) && !il.wired && il.nout == 2 &&
-			pm.kind == A2AMD_PANMIX && pm.nin == 2 && pm.nout == 2 && !pm.wired &&
-			!(pm.flags & A2AMD_PROCADD) &&
+	const HUnit &il = c->units[v.unit[0]], &pm = c->units[v.unit[1]];
+	if(!(il.kind == A2AMD_INLINE && !(il.flags & A2AMD_PROCADD) && !il.wired && il.nout == 2 &&
+			pm.kind == A2AMD_PANMIX && pm.nin == 2 && pm.nout == 2))
+		return false;
+	if(v.nunits == 2)
+		// inline 0 2; panmix 2 >  - what the drop-in's root voice looks like from here (the root's
+		// xinsert stays the engine's): the panmix itself adds into the output bus
+		return pm.wired && (pm.flags & A2AMD_PROCADD);
+	const HUnit &xi = c->units[v.unit[2]];
+	return !pm.wired && !(pm.flags & A2AMD_PROCADD) &&
 			xi.kind == A2AMD_XINSERT && xi.nin == 2 && xi.wired && (xi.flags & A2AMD_PROCADD) &&
 			!xi.xio_mode;	// (clients: the general kernel serves them)
 }
@@ -1004,8 +1010,14 @@ int upload(a2amd_ctx *c)
 			// (fm-panmix voices execute their own records in k_leaf_fmpan)
 			if(v.cls == CLS_OSCPAN || v.cls == CLS_OSCFILTPAN || v.cls == CLS_OSC2PAN)
 				dyn_leaf.push_back(vi);
-			else if((v.cls == CLS_BUSDRIVER || v.cls == CLS_FBDCHAIN) && v.depth < (int)dyn_bus.size())
+			else if((v.cls == CLS_BUSDRIVER || v.cls == CLS_FBDCHAIN) && v.depth < (int)dyn_bus.size()) {
 				dyn_bus[v.depth].push_back(vi);
+				static const int trace = getenv("A2AMD_HOSTTIMING") ? atoi(getenv("A2AMD_HOSTTIMING")) : 0;
+				if(trace >= 3 && !v.recs.empty())
+					fprintf(stderr, "a2amd: bus voice %d (depth %d, class %d) carries %zu records, first: frag %u op %u unit %u reg %u value %d\n",
+							vi, v.depth, v.cls, v.recs.size(), A2D_RFRAG(v.recs[0].head), A2D_ROP(v.recs[0].head),
+							A2D_RUNIT(v.recs[0].head), A2D_RREG(v.recs[0].head), v.recs[0].value);
+			}
 		}
 		// Voices of the wtosc[+wtosc]->panmix classes whose records are what
 		// k_leaf_recs executes (windows, writes, births, deaths; oscillators on
@@ -1388,17 +1400,25 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 				++c->stats.launches;
 				return 0;
 			};
-			// the 2 x wtosc-filter12-panmix leaves, with and without records ...
-			if(int r = recs(2, 1, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf + c->n_fm_leaf + c->n_leaf,
-					c->n_o2f_leaf))
-				return r;
-			// ... and of the classes that have quiet kernels of their own, this batch's voices with records
-			if(int r = recs(1, 0, c->d_dyn, c->n_dyn_osc1))
-				return r;
-			if(int r = recs(2, 0, c->d_dyn + c->n_dyn_osc1, c->n_dyn_osc2))
-				return r;
-			if(int r = recs(1, 1, c->d_dyn + c->n_dyn_osc1 + c->n_dyn_osc2, c->n_dyn_filt))
-				return r;
+			// the 2 x wtosc-filter12-panmix leaves, with and without records, and - of the classes that
+			// have quiet kernels of their own - this batch's voices with records
+			const int *lists[4] = { c->d_dyn, c->d_dyn + c->n_dyn_osc1, c->d_dyn + c->n_dyn_osc1 + c->n_dyn_osc2,
+					c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf + c->n_fm_leaf + c->n_leaf };
+			const int counts[4] = { c->n_dyn_osc1, c->n_dyn_osc2, c->n_dyn_filt, c->n_o2f_leaf };
+			const int total = counts[0] + counts[1] + counts[2] + counts[3];
+			const int kinds = (counts[0] != 0) + (counts[1] != 0) + (counts[2] != 0) + (counts[3] != 0);
+			if(kinds > 1 && total <= 4096 && !getenv("A2AMD_RVPW")) {
+				// few voices of several kinds (a song): one launch - on one stream the per-kind
+				// launches would run back to back, each as long as one voice's walk through the batch
+				if(a2d_launch_leaf_recs_all(c->d_params, c->hparams, lists, counts, 1, c->stream))
+					return c->fail(A2AMD_EHIP, "leaf records launch failed: %s", hipGetErrorString(hipGetLastError()));
+				++c->stats.launches;
+			} else {
+				static const int nosc[4] = { 1, 2, 1, 2 }, filt[4] = { 0, 0, 1, 1 };
+				for(int k = 0; k < 4; ++k)
+					if(int r = recs(nosc[k], filt[k], lists[k], counts[k]))
+						return r;
+			}
 		}
 		if(c->n_leaf_dyn - c->n_dyn_osc1 - c->n_dyn_osc2 - c->n_dyn_filt > 0) {
 			const int n = c->n_leaf_dyn - c->n_dyn_osc1 - c->n_dyn_osc2 - c->n_dyn_filt;
