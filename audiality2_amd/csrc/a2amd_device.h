@@ -111,6 +111,9 @@ enum { XW_SLOT = 0, XW_MODE = 1 };
 #ifndef A2D_FAST_FCH
 #define A2D_FAST_FCH 8	// k_leaf_oscpan: fragments per chunk (the host sizes the time slices by it)
 #endif
+#ifndef A2D_OSC2_FCH
+#define A2D_OSC2_FCH 4	// k_leaf_osc2pan: fragments per chunk
+#endif
 #define A2D_MAXBATCH 256
 #define A2D_MAXVPW   32       // voices one wavefront may walk per fragment
 

@@ -370,7 +370,10 @@ enum { SV_MODE = 0, SV_WAVE, SV_DPHASE, SV_PHLO, SV_PHHI, SV_PRAMP, SV_P = 6, SV
 // Extra per-lane words derived once per launch from a voice's state
 enum { DV_SETTLED = 0, DV_MM, DV_DPH, DV_SIZEM, DV_DOFF, DV_V0, DV_V1, DV_NWORDS };
 
-__global__ __launch_bounds__(64 * FAST_WPB) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef OSC1_WPE
+#define OSC1_WPE 4
+#endif
+__global__ __launch_bounds__(64 * FAST_WPB) __attribute__((amdgpu_waves_per_eu(OSC1_WPE, OSC1_WPE)))
 void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
 		int ysplit, const A2DVoice *__restrict__ voices, const int *ustate,
 		int *ustage, const int16_t *__restrict__ wavepool,
@@ -709,7 +712,7 @@ void k_commit_oscpan(A2DCommit cm, const A2DVoice *__restrict__ voices, const A2
 // ---------------------------------------------------------------------------
 // Same plan as k_leaf_oscpan with the oscillator state doubled; 4 fragments per
 // register chunk keep the 16 window loads of a chunk within the register budget.
-#define OSC2_FCH 4
+#define OSC2_FCH A2D_OSC2_FCH
 enum { OV_MODE = 0, OV_WAVE, OV_DPHASE, OV_PHLO, OV_PHHI, OV_PRAMP, OV_P = 6, OV_A = 10, OV_NWORDS = 14 };
 enum { OD_MM = 0, OD_DPH, OD_SIZEM, OD_DOFF, OD_NWORDS };
 
@@ -742,7 +745,10 @@ DEV void osc_to_lanes(int (&so)[OV_NWORDS], const OscS &o, bool me)
 	WRL(so[OV_A + 2], o.a.delta); WRL(so[OV_A + 3], o.a.timer);
 }
 
-__global__ __launch_bounds__(64 * FAST_WPB) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef OSC2_WPE
+#define OSC2_WPE 3	// (measured: 3 wavefronts per SIMD with 143 registers and no spills beat 4 with 128 and 39 spills by a fifth)
+#endif
+__global__ __launch_bounds__(64 * FAST_WPB) __attribute__((amdgpu_waves_per_eu(OSC2_WPE, OSC2_WPE)))
 void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
 		int ysplit, const A2DVoice *__restrict__ voices, const int *ustate, int *ustage,
 		const int16_t *__restrict__ wavepool, const A2DWave *__restrict__ waves,
@@ -1633,7 +1639,10 @@ DEV void filt_row(int *row, int n, int ff, int lp, int bp, int hp, int &d1, int 
 	}
 }
 
-__global__ __launch_bounds__(64 * FILT_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef FILT_WPE
+#define FILT_WPE 4
+#endif
+__global__ __launch_bounds__(64 * FILT_WAVES) __attribute__((amdgpu_waves_per_eu(FILT_WPE, FILT_WPE)))
 void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpg,
 		const A2DVoice *__restrict__ voices, int *ustate, const int16_t *__restrict__ wavepool,
 		const A2DWave *__restrict__ waves, const uint32_t *__restrict__ ptab, int *__restrict__ busmem,

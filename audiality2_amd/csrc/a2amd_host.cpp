@@ -1334,7 +1334,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		}
 		if(c->n_osc2_leaf) {
 			int vpw, ysplit;
-			pick_fast_shape(c->n_osc2_leaf, c->nfrags * A2D_FAST_FCH / 4, &vpw, &ysplit);	// (its chunks are 4 fragments)
+			pick_fast_shape(c->n_osc2_leaf, c->nfrags * A2D_FAST_FCH / A2D_OSC2_FCH, &vpw, &ysplit);	// (its own chunk length)
 			if(a2d_launch_leaf_osc2pan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf, c->n_osc2_leaf,
 					vpw, ysplit, c->d_ustage.d, c->stream, &pend.c[pend.n]))
 				return c->fail(A2AMD_EHIP, "2-osc leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
