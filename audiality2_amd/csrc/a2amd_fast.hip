@@ -137,15 +137,34 @@ int a2d_launch_build_coef(const int16_t *pool, int *coef, unsigned lo, unsigned 
 
 // ---- cold paths: kept out of line so the hot loop stays small -------------
 // (all operands are wave-uniform; results go back to SGPRs via readfirstlane)
+// trunc(n / d) for |n| < 2^52, 0 < d < 2^31, exactly: the quotient of the correctly rounded double
+// division is at most one off, and the remainder says which way (the compiler's 64 bit integer
+// division is a few hundred instructions; a scripted voice needs one per ramping control and window)
+DEV int64_t div_trunc_exact(int64_t n, int d)
+{
+	int64_t q = (int64_t)((double)n / (double)d);
+	const int64_t r = n - q * d;
+	if(n >= 0) {
+		if(r < 0) --q; else if(r >= d) ++q;
+	} else {
+		if(r > 0) ++q; else if(r <= -(int64_t)d) --q;
+	}
+	return q;
+}
+
 __device__ __attribute__((noinline)) int cold_ramp_delta(int target, int value, int timer, int frames,
 		int *newtimer)
 {
 	// the two ramping branches of a2_PrepareRamper, a2_dsp.h:134-148
 	if(frames <= (timer >> 8)) {
 		*newtimer = wsub(timer, frames << 8);
+		if(timer > 0)
+			return (int)div_trunc_exact((int64_t)wsub(target, value) * 256, timer);
 		return (int)((((int64_t)wsub(target, value)) * 256) / timer);
 	}
 	*newtimer = 0;
+	if(frames > 0)
+		return (int)div_trunc_exact((int64_t)wsub(target, value), frames);
 	return wsub(target, value) / frames;
 }
 
