@@ -1493,8 +1493,13 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 }
 
 
+#ifdef RECS_WPE
+#define RECS_ATTR __attribute__((amdgpu_waves_per_eu(RECS_WPE, 8)))
+#else
+#define RECS_ATTR
+#endif
 template<int NOSC, int FILT>
-__global__ __launch_bounds__(64 * RECS_WPB)
+__global__ __launch_bounds__(64 * RECS_WPB) RECS_ATTR
 void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
 		const A2DVoice *__restrict__ voices, int *ustate, int *vactive,
 		const int16_t *__restrict__ wavepool, const A2DWave *__restrict__ waves,

@@ -327,12 +327,9 @@ int  a2amd_render_group(a2amd_ctx *const *ctxs, int n, unsigned phases, int32_t 
  * Process(0, frames) per unit and nothing else happens (src/core.c:1852-1878
  * with no wake-ups).  Fails with A2AMD_EUNSUPPORTED while a noise oscillator,
  * a ramping filter cutoff or a unit with clients (a2amd_unit_clients) needs
- * per-call host work.  Fragments rendered
- * this way (and by A2AMD_RENDER_KEEP / a2amd_replay re-runs) advance the
- * oscillators without a2amd_unit_process calls, so the host loses track of
- * their phase: an oscillator alive across such a stretch can afterwards not be
- * switched from a wavetable to noise (A2AMD_EUNSUPPORTED) - the engine-driven
- * path, where every Process call arrives, has no such restriction. */
+ * per-call host work.  (An oscillator may be switched to noise after such a
+ * stretch: the host keeps no copy of a wavetable oscillator's phase, it fetches
+ * the device's when the switch comes.) */
 int  a2amd_fragment_repeat(a2amd_ctx *ctx, unsigned frames, unsigned count);
 
 /* ---- introspection (tests, bench) --------------------------------------*/
