@@ -1762,8 +1762,13 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 	}
 
 	// ============ oscillator / pan wavefronts: lane = frame, voices [vb, ve) ============
-	const int per = (nv + FILT_WAVES - 2) / (FILT_WAVES - 1);
-	const int vb = (wv - 1) * per, ve = min(nv, vb + per);
+	// (every fourth wavefront of a workgroup lands on the SIMD of wavefront 0, the filter: those
+	// stay idle - they only meet the others at the barriers - so that the filter's dependent
+	// chain has its SIMD to itself: 1.34 -> 1.25 ms per 256 fragments at 16 384 voices)
+	const int noscw = FILT_WAVES - FILT_WAVES / 4;
+	const int ow = (wv & 3) ? wv - 1 - (wv >> 2) : -1;
+	const int per = (nv + noscw - 1) / noscw;
+	const int vb = ow < 0 ? nv : ow * per, ve = min(nv, vb + per);
 	const int mv = max(0, ve - vb);		// my voices: lane l parks voice vb + l
 
 	int sv[SV_NWORDS], dv[DV_NWORDS];
