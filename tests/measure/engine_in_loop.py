@@ -34,7 +34,8 @@ def run(program, voices, frags, preload, threads=1):
 
 
 def main():
-    for program, cpu_frags in (("OscPan", 300), ("OscPanScripted", 300), ("OscFilterPan", 200), ("Osc2Pan", 200),
+    for program, cpu_frags in (("OscPan", 300), ("OscPanScripted", 300), ("OscFilterPan", 200), ("OscFilterPanScripted", 200),
+                               ("Osc2Pan", 200),
                                ("Osc2PanGroups", 200), ("Fm1Pan", 300), ("Fm2Pan", 150), ("Fm4Pan", 60)):
         for voices in (1024, 4096, 16384, 32768):
             c = run(program, voices, max(cpu_frags * 1024 // voices, 20), False)
