@@ -291,6 +291,8 @@ struct a2amd_ctx {
 	bool root_clean = false;		// ... and the root's own bus
 	bool capturing = false;			// issue_kernels is being captured into a graph
 	int n_clients = 0;			// units whose clients are served (a2amd_unit_clients mode != 0)
+	int sub_resume = -1;			// SUBTREES phase paused for insert clients: the depth it goes on with
+	int paused_at = 0;			// ... and the depth whose insert clients are to be served now (0: none)
 	std::vector<int32_t> snap_ustate, snap_vactive;	// unit states / voice liveness as the last batch left them
 	bool snap_valid = false;			// (fetched when an oscillator is switched to noise)
 	// The default map: one byte per voice slot, set by the HOST for a voice that
@@ -1289,6 +1291,18 @@ void end_batch(a2amd_ctx *c)
 	c->cur_frag = 0;
 	c->frag_open = false;
 	c->uploaded = false;
+	c->sub_resume = -1;
+	c->paused_at = 0;
+}
+
+// does a voice at nesting depth d hold an xinsert in A2AMD_XIO_MUTE mode (insert clients)?
+bool depth_has_mutes(const a2amd_ctx *c, int d)
+{
+	for(const XioSlot &x : c->xio)
+		if(x.last_unit >= 0 && x.last_unit < (int)c->units.size() && (c->units[x.last_unit].xio_mode & A2AMD_XIO_MUTE) &&
+				c->units[x.last_unit].voice >= 0 && c->voices[c->units[x.last_unit].voice].depth == d)
+			return true;
+	return false;
 }
 
 // the kernels of one batch, in stream order; e* may be null
@@ -1310,6 +1324,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		pend.n = 0;
 	};
 	if(phases & A2AMD_RENDER_SUBTREES) {
+		if(c->sub_resume < 0) {
 		// (a graph of a self-cleaning batch holds no memset: whoever launches it
 		// clears the buses first if they are not known to be clean, ensure_clean())
 		const bool selfclean = consume || consume_sub;
@@ -1428,9 +1443,22 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		}
 		if(e1 && !(c->n_fast_leaf && !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn && !c->n_o2f_leaf))
 			HIPCHK(c, hipEventRecord(e1, c->stream));
-		for(int d = (int)c->depth_ranges.size() - 1; d >= 1; --d)
+		}	// (fresh start)
+		// the voices that own a bus, deepest first.  With A2AMD_RENDER_TAPS the walk stops behind a
+		// depth that holds a muted xinsert (insert clients: a2amd_unit_insertable): the host serves
+		// them and calls again.
+		const int dstart = c->sub_resume >= 0 ? c->sub_resume : (int)c->depth_ranges.size() - 1;
+		c->sub_resume = -1;
+		c->paused_at = 0;
+		for(int d = dstart; d >= 1; --d) {
 			if(int r = launch_depth(c, d, consume ? 3 : consume_sub ? 1 : 0, &pend))
 				return r;
+			if((phases & A2AMD_RENDER_TAPS) && depth_has_mutes(c, d)) {
+				c->paused_at = d;
+				c->sub_resume = d > 1 ? d - 1 : -1;
+				break;
+			}
+		}
 		// (the ROOT phase may run elsewhere, or later: nothing stays pending across calls)
 		if(!(phases & A2AMD_RENDER_ROOT))
 			flush_commits();
@@ -2562,7 +2590,7 @@ int a2amd_unit_clients(a2amd_ctx *c, int ui, unsigned mode)
 			 c->units[ui].kind != A2AMD_XSOURCE))
 		return c->fail(A2AMD_EINVAL, "unit %d is not a live xinsert / xsink / xsource", ui);
 	if((mode & ~(unsigned)(A2AMD_XIO_TAP | A2AMD_XIO_INJECT | A2AMD_XIO_MUTE)) ||
-			((mode & A2AMD_XIO_MUTE) && (!(mode & A2AMD_XIO_TAP) || a2amd_unit_insertable(c, ui) != 1)) ||
+			((mode & A2AMD_XIO_MUTE) && (!(mode & A2AMD_XIO_TAP) || a2amd_unit_insertable(c, ui) < 1)) ||
 			(c->units[ui].kind == A2AMD_XSINK && (mode & A2AMD_XIO_INJECT)) ||
 			(c->units[ui].kind == A2AMD_XSOURCE && (mode & A2AMD_XIO_TAP)))
 		return c->fail(A2AMD_EINVAL, "client mode %#x on unit kind %d", mode, c->units[ui].kind);
@@ -2619,12 +2647,17 @@ int a2amd_unit_insertable(a2amd_ctx *c, int ui)
 		return c->fail(A2AMD_EINVAL, "insertable: dead unit %d", ui);
 	const HUnit &u = c->units[ui];
 	const HVoice &v = c->voices[u.voice];
-	// the render has one seam: between everything below the root voice and the root's
-	// own chain.  A unit that is the last of a voice playing straight into the root's
-	// bus can have its output added there in between.
-	// (known once the voice has been processed for the first time: resolve_out)
-	return u.kind == A2AMD_XINSERT && v.resolved && v.depth == 1 && v.out_off != 0 && u.chainpos == v.nunits - 1 &&
-			u.wired && (u.flags & A2AMD_PROCADD) && !c->comm ? 1 : 0;
+	// The render goes nesting depth by nesting depth, deepest first, and can pause between two
+	// of them: a unit that is the last of its voice and adds into the voice's output bus (the
+	// parent's inline bus) can have its output replaced there before the parent's chain runs.
+	// (depth and bus are known once the voice has been processed for the first time: resolve_out)
+	return u.kind == A2AMD_XINSERT && v.resolved && v.depth >= 1 && v.out_off != 0 && u.chainpos == v.nunits - 1 &&
+			u.wired && (u.flags & A2AMD_PROCADD) && !c->comm ? v.depth : 0;
+}
+
+int a2amd_render_paused(a2amd_ctx *c)
+{
+	return c->paused_at;
 }
 
 int a2amd_unit_insert(a2amd_ctx *c, int ui, unsigned fragment, unsigned offset, unsigned frames,
@@ -2731,6 +2764,7 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		if(!kphases)
 			return 0;
 		if(c->uploaded && !c->profiling && c->stream && c->with_recs.empty() && !getenv("A2AMD_NO_GRAPH") &&
+				!(phases & A2AMD_RENDER_TAPS) && c->sub_resume < 0 && !c->paused_at &&
 				((phases & A2AMD_RENDER_KEEP) ? (phases & ~A2AMD_RENDER_KEEP) ==
 				 (phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT)) :
 				 // (not for a realtime driver's one-fragment batches: measured, hipGraphLaunch
@@ -2762,9 +2796,9 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		// Events only when profiling (each one from the pool, used once until read):
 		// re-recording an event the GPU has not reached yet makes the runtime wait.
 		const bool sub = (kphases & A2AMD_RENDER_SUBTREES) != 0, root = (kphases & A2AMD_RENDER_ROOT) != 0;
-		return c->profiling ? issue_kernels(c, kphases | (phases & A2AMD_RENDER_KEEP), sub ? c->ev0 : nullptr,
+		return c->profiling ? issue_kernels(c, kphases | (phases & (A2AMD_RENDER_KEEP | A2AMD_RENDER_TAPS)), sub ? c->ev0 : nullptr,
 				sub ? c->ev1 : nullptr, root ? c->ev2 : nullptr) :
-				issue_kernels(c, kphases | (phases & A2AMD_RENDER_KEEP), nullptr, nullptr, nullptr);
+				issue_kernels(c, kphases | (phases & (A2AMD_RENDER_KEEP | A2AMD_RENDER_TAPS)), nullptr, nullptr, nullptr);
 	};
 	const unsigned kphases = phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT);
 	if(c->comm && !c->dist_local && kphases == (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT)) {
@@ -2779,9 +2813,9 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 			if(int r = run_phases(A2AMD_RENDER_ROOT))
 				return r;
 	} else {
-		if(kphases == A2AMD_RENDER_ROOT) {
-			// what insert clients made of the voices' taps since the SUBTREES phase
-			// (a2amd_unit_insert) joins the voices' output bus before the root chain runs
+		if(kphases && !(phases & A2AMD_RENDER_UPLOAD)) {
+			// what insert clients made of the voices' taps since the render paused
+			// (a2amd_unit_insert) joins the voices' output bus before their parents' chains run
 			for(size_t k = 0; k < c->xio.size(); ++k) {
 				XioSlot &x = c->xio[k];
 				if(!x.late_used)

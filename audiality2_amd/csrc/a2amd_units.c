@@ -73,7 +73,8 @@ typedef struct PENDING
 	unsigned		pos;		/* root xinsert: frames into the buffer */
 	const char		*what;		/* for error reports */
 	unsigned		offset, frames;
-	int			insert;		/* a READ and WRITE client: served in the middle of the render */
+	int			insert;		/* a READ and WRITE client: served in the middle of the render, */
+	int			depth;		/* ... when it pauses behind this nesting depth */
 } PENDING;
 
 typedef struct HOSTSTATE
@@ -643,7 +644,7 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 	const char *what = x->kind == A2AMD_XSOURCE ? "xsource client callback" :
 			x->kind == A2AMD_XSINK ? "xsink client callback" : "xinsert client callback";
 	unsigned mode = 0;
-	int rc, i;
+	int rc, i, idepth = 0;
 	unsigned s;
 	if(hs->failed)
 		return;
@@ -656,16 +657,16 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 			mode |= A2AMD_XIO_INJECT;
 		else if((xic->flags & A2P_XI_READ) && (xic->flags & A2P_XI_WRITE))
 		{
-			/* an insert client: where the render has a seam for it (the last unit of a voice
-			 * directly below the root: a2_NewGroup's xinsert), its input is tapped and not
-			 * passed on, and flush_batch() runs it between the two halves of the render */
-			if(hs->ndev == 1 && a2amd_unit_insertable(XCTX(x), x->uid) == 1)
+			/* an insert client: where the render can pause for it (the last unit of a voice
+			 * below the root: a2_NewGroup's xinsert), its input is tapped and not passed on,
+			 * and render_batch() runs it before the parent voice's chain is rendered */
+			if(hs->ndev == 1 && (idepth = a2amd_unit_insertable(XCTX(x), x->uid)) >= 1)
 				mode |= A2AMD_XIO_TAP | A2AMD_XIO_MUTE;
 			else if(!x->refused)
 			{
 				x->refused = 1;
-				client_error(xi, A2P_NOTIMPLEMENTED, "a2amd: insert client (a2_InsertCallback) on a voice "
-						"that is neither the root voice nor directly below it (or with A2AMD_DEVICES > 1): "
+				client_error(xi, A2P_NOTIMPLEMENTED, "a2amd: insert client (a2_InsertCallback) on an xinsert "
+						"that is not the last unit of its voice (or with A2AMD_DEVICES > 1): "
 						"its audio is on the GPU; not served (sink and source clients are)");
 			}
 		}
@@ -731,6 +732,7 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 			p->offset = offset - hs->base;
 			p->frames = frames;
 			p->insert = ins;
+			p->depth = idepth;
 			hs->ninserts += ins;
 		}
 }
@@ -832,7 +834,7 @@ static int grow_acc(HOSTSTATE *hs, unsigned frames)
 /* The insert clients' turn, between the two halves of the render: each is handed a copy
  * of its window of the unit's input and what it makes of it is summed up as the unit's
  * output (xi_process, xinsert.c:95-118), in walk order. */
-static void deliver_inserts(HOSTSTATE *hs)
+static void deliver_inserts(HOSTSTATE *hs, int depth)
 {
 	int k, i, n, rc;
 	unsigned s;
@@ -844,7 +846,7 @@ static void deliver_inserts(HOSTSTATE *hs)
 		int32_t *bufp[A2AMD_MAXCHANNELS];
 		const int32_t *outp[A2AMD_MAXCHANNELS];
 		A2P_xinsert_client *c;
-		if(!p->insert || hs->failed)
+		if(!p->insert || p->depth != depth || hs->failed)
 			continue;
 		for(c = p->xi->clients; c && c != p->xic; c = c->next)
 			;
@@ -867,7 +869,6 @@ static void deliver_inserts(HOSTSTATE *hs)
 		if((rc = a2amd_unit_insert(hs->ctxs[p->dev], p->uid, (unsigned)p->frag, p->offset, p->frames, outp)))
 			fail(hs, "a2amd_unit_insert", rc);
 	}
-	hs->ninserts = 0;
 }
 
 /* the batch recorded so far -> audio (outp[channel], at most cap frames) */
@@ -877,9 +878,18 @@ static int render_batch(HOSTSTATE *hs, int32_t **outp, unsigned cap)
 	if(!hs->ninserts)
 		return a2amd_render_group(hs->ctxs, hs->ndev, A2AMD_RENDER_ALL, outp, cap);
 	/* (insert clients are only accepted with one context) */
+	hs->ninserts = 0;
 	if((n = a2amd_render(hs->ctx, A2AMD_RENDER_UPLOAD | A2AMD_RENDER_SUBTREES | A2AMD_RENDER_TAPS, NULL, 0)) < 0)
 		return n;
-	deliver_inserts(hs);
+	/* the render pauses behind every nesting depth that holds insert clients, deepest first */
+	while((n = a2amd_render_paused(hs->ctx)) > 0)
+	{
+		deliver_inserts(hs, n);
+		if(n == 1)
+			break;
+		if((n = a2amd_render(hs->ctx, A2AMD_RENDER_SUBTREES | A2AMD_RENDER_TAPS, NULL, 0)) < 0)
+			return n;
+	}
 	return a2amd_render(hs->ctx, A2AMD_RENDER_ROOT | A2AMD_RENDER_READBACK, outp, cap);
 }
 

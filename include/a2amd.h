@@ -231,6 +231,7 @@ uint8_t *a2amd_default_map(a2amd_ctx *ctx, unsigned *nslots);
 #define A2AMD_XIO_MUTE    4u
 int  a2amd_unit_clients(a2amd_ctx *ctx, int unit, unsigned mode);
 int  a2amd_unit_insertable(a2amd_ctx *ctx, int unit);
+int  a2amd_render_paused(a2amd_ctx *ctx);
 /* ... window [offset, offset+frames) of fragment 'fragment' of the batch being
  * rendered (between its SUBTREES | TAPS and its ROOT phase); adds up over calls */
 int  a2amd_unit_insert(a2amd_ctx *ctx, int unit, unsigned fragment, unsigned offset, unsigned frames,

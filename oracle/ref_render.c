@@ -88,6 +88,20 @@ static A2_errors insert_cb(int32_t **buffers, unsigned nbuffers, unsigned frames
 	return A2_OK;
 }
 
+/* (a second one, for the outer group of A2REF_NEST / A2REF_INSERT_OUTER) */
+static unsigned insert2_pos;
+static A2_errors insert2_cb(int32_t **buffers, unsigned nbuffers, unsigned frames, void *userdata)
+{
+	unsigned c, s;
+	if(!buffers)
+		return A2_OK;
+	for(c = 0; c < nbuffers; ++c)
+		for(s = 0; s < frames; ++s)
+			buffers[c][s] = -buffers[c][s] / 3 + (int)(((insert2_pos + s) * 7u) & 0x3fff);
+	insert2_pos += frames;
+	return A2_OK;
+}
+
 /* A2REF_FOREIGN=1: the application registers a unit of its own
  * (a2_RegisterUnit, a2_units.h:327) before the script is compiled: "thru", 1-2
  * channels, copies (or adds) its inputs to its outputs. */
@@ -194,8 +208,26 @@ int main(int argc, const char *argv[])
 		pargs[nargs++] = upwave << 16;
 	}
 	a2_TimestampReset(i);
-	if((vh = a2_Starta(i, a2_RootVoice(i), prog, nargs, pargs)) < 0)
-		return 1;
+	{
+		/* A2REF_NEST=n: the program is started under n nested groups (a2_NewGroup,
+		 * audiality2.h.cmake: the a2_groupdriver voices, inline; panmix; xinsert) instead
+		 * of straight under the root voice; A2REF_INSERT_OUTER=1 puts an insert client on
+		 * the outermost of them as well */
+		A2_handle parent = a2_RootVoice(i);
+		int k, nest = getenv("A2REF_NEST") ? atoi(getenv("A2REF_NEST")) : 0;
+		for(k = 0; k < nest; ++k)
+		{
+			if((parent = a2_NewGroup(i, parent)) < 0)
+			{
+				fprintf(stderr, "a2_NewGroup failed: %s\n", a2_ErrorString(a2_LastError()));
+				return 1;
+			}
+			if(!k && getenv("A2REF_INSERT_OUTER") && a2_InsertCallback(i, parent, insert2_cb, NULL) < 0)
+				return 1;
+		}
+		if((vh = a2_Starta(i, parent, prog, nargs, pargs)) < 0)
+			return 1;
+	}
 	/* A2REF_ROOTCLIENTS=1: the clients below go on the root voice (the root driver's
 	 * xinsert, audiality2.c:271-291 - where a2play puts its sink) instead */
 	if(getenv("A2REF_ROOTCLIENTS"))

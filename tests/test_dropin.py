@@ -183,6 +183,31 @@ def test_dropin_serves_sink_and_source_clients(tmp_path, script, frames, clients
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nest,outer", [(1, False), (2, False), (2, True), (3, True)])
+@pytest.mark.parametrize("buffer", [64, 1024])
+def test_dropin_serves_insert_clients_at_any_depth(tmp_path, nest, outer, buffer):
+    """a2_InsertCallback on group voices nested one to three levels below the root
+    (a2_NewGroup under a2_NewGroup ...: oracle/ref_render A2REF_NEST), one insert
+    client on the innermost voice and - outer - another on the outermost group: the
+    render pauses behind each of those depths, deepest first, and the audio is the
+    reference's."""
+    need_ref()
+    outs = []
+    for preload in (False, True):
+        out = tmp_path / f"n{int(preload)}.pcm"
+        env = dict(os.environ, A2REF_NEST=str(nest), A2REF_INSERT="1")
+        if outer:
+            env["A2REF_INSERT_OUTER"] = "1"
+        if preload:
+            env["LD_PRELOAD"] = UNITS_SO
+        r = subprocess.run([REF_RENDER, f"{A2S}/clients.a2s", "Main", "24000", str(buffer), "48000", "2", str(out), "0.1"],
+                           env=env, cwd=A2S, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "insert client" not in r.stderr, r.stderr[-500:]
+        outs.append(np.fromfile(out, dtype="<i4"))
+    assert outs[0].any() and np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
 def test_several_engine_states_share_the_gpu():
     """Independent engine states on their own host threads (the reference's
     only thread-safe arrangement) each get a backend context and a stream of
