@@ -903,6 +903,57 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 			const int v0 = rdl(v0l, v), v1 = rdl(v1l, v);
 			// one oscillator after the other: the eight coefficient entries of a
 			// chunk (4 fragments x 2 taps, 24 registers) in flight at a time
+#ifndef OSC2_SEQ
+			// the coefficient entries of BOTH oscillators (4 fragments x 2 taps x 2: 48 registers) are in
+			// flight before either is used (one oscillator after the other: -DOSC2_SEQ, 4 % slower)
+			int xs[OSC2_FCH];
+			uint64_t endph[2];
+			Coef3 ka[2][OSC2_FCH], kb[2][OSC2_FCH];
+			unsigned pa[2][OSC2_FCH], pb[2][OSC2_FCH];
+			int amps[2];
+#pragma unroll
+			for(int o = 0; o < 2; ++o) {
+				const unsigned mm = (unsigned)rdl(od[o][OD_MM], v), dph = (unsigned)rdl(od[o][OD_DPH], v);
+				const unsigned sizem = (unsigned)rdl(od[o][OD_SIZEM], v), doff = (unsigned)rdl(od[o][OD_DOFF], v);
+				amps[o] = rdl(so[o][OV_A], v);
+				const uint64_t phase = (uint64_t)(unsigned)rdl(so[o][OV_PHLO], v) |
+						((uint64_t)(unsigned)rdl(so[o][OV_PHHI], v) << 32);
+				uint64_t ph = (phase >> mm) + (uint64_t)before * dph;
+				const uint64_t lanedph = (uint64_t)(unsigned)lane * dph;
+				const char *cb = (const char *)(wavecoef + 3 * (size_t)doff);
+				uint64_t phs[OSC2_FCH];
+				if(!(sizem & (sizem - 1)) && !(ph >> 48)) {
+					const uint64_t mask = ((uint64_t)sizem << 24) - 1;
+#pragma unroll
+					for(int j = 0; j < OSC2_FCH; ++j)
+						phs[j] = (ph + (uint64_t)dph * pre[j]) & mask;
+					ph = phs[OSC2_FCH - 1] + (uint64_t)dph * (unsigned)nfr[OSC2_FCH - 1];
+				} else {
+#pragma unroll
+					for(int j = 0; j < OSC2_FCH; ++j) {
+						ph = wrap_phase(ph, sizem);
+						phs[j] = ph;
+						ph += (uint64_t)dph * (unsigned)nfr[j];
+					}
+				}
+#pragma unroll
+				for(int j = 0; j < OSC2_FCH; ++j) {
+					pa[o][j] = (unsigned)((phs[j] + lanedph) >> 16);
+					asm("" : "+v"(pa[o][j]));
+					pb[o][j] = pa[o][j] + (dph >> 17);
+					ka[o][j] = coef_at(cb, pa[o][j]);
+					kb[o][j] = coef_at(cb, pb[o][j]);
+				}
+				endph[o] = ph << mm;
+			}
+#pragma unroll
+			for(int o = 0; o < 2; ++o)
+#pragma unroll
+				for(int j = 0; j < OSC2_FCH; ++j) {
+					const int y = mul64s(hermite_c(ka[o][j], pa[o][j]) + hermite_c(kb[o][j], pb[o][j]), amps[o], 17);
+					xs[j] = o ? wadd(xs[j], y) : y;
+				}
+#else
 			int xs[OSC2_FCH];
 			uint64_t endph[2];
 #pragma unroll
@@ -949,6 +1000,7 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 				}
 				endph[o] = ph << mm;
 			}
+#endif
 #pragma unroll
 			for(int j = 0; j < OSC2_FCH; ++j) {
 				const int x = (lane < nfr[j]) ? xs[j] : 0;
