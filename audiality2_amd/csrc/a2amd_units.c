@@ -28,6 +28,7 @@
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <pthread.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -45,6 +46,7 @@ extern int a2_SetStateProperty(void *iface, int prop, int v);
 extern int a2r_Error(void *st, int e, const char *info) __attribute__((weak));
 extern int a2_XinsertRemoveClient(A2P_xinsert_client *xic) __attribute__((weak));
 
+#define WALK_AHEAD 32		/* most chain heads the walk's prefetch hints run ahead of the engine (look_ahead()) */
 #define MAXSTATES 256		/* engine states (master + substates) alive at once in one process */
 #define MAXDEV    8		/* GPUs one engine state may be spread over (A2AMD_DEVICES) */
 
@@ -98,6 +100,11 @@ typedef struct HOSTSTATE
 	int		noise_oscs;	/* oscillators playing the noise wave: their voices need the engine's RNG */
 	int		ninserts;	/* pending windows of insert clients in the batch being recorded */
 	int		no_quick;	/* A2AMD_NO_QUICK=1: every Process call is forwarded (A/B measurements) */
+	/* the last WALK_AHEAD chain heads the engine called, oldest first from walk_pos
+	 * (look_ahead()); emptied whenever a unit goes away */
+	struct XTRA	*walk_ring[WALK_AHEAD];
+	unsigned	walk_pos;
+	int		walk_ahead;	/* how many heads ahead; A2AMD_WALK_AHEAD=0 switches the hints off (A/B measurements) */
 	A2P_vmstate	*root_vms;	/* the root voice (first voice of a state) */
 	A2P_vmstate	*chain_vms;	/* voice whose chain is being populated */
 	A2P_unit	*chain_last;
@@ -142,9 +149,16 @@ static pthread_mutex_t states_mtx = PTHREAD_MUTEX_INITIALIZER;	/* independent ma
 typedef struct XTRA
 {
 	HOSTSTATE	*hs;
+	int		slot;		/* head: the voice's slot in the backend's default map */
+	int		dev;		/* which of the state's contexts holds the voice */
+	/* head of a chain of our own: what the engine will touch WALK_AHEAD voices from
+	 * here, as the last walk found it (prefetch hints only, never dereferenced) */
+	A2P_unit	*ahead;		/* that voice's head unit ... */
+	A2P_unit	*ahead_tail[2];	/* ... the units behind it ... */
+	A2P_vmstate	*ahead_vms;	/* ... and its VM state, inside its A2_voice */
+	A2P_unit	*tail[2];	/* head: the units behind this one */
 	A2P_vmstate	*vms;
 	int		uid;		/* backend unit id, -1 = not forwarded */
-	int		dev;		/* which of the state's contexts holds the voice */
 	int		pending;	/* its Initialize / writes wait in HOSTSTATE.births for the voice's first window */
 	int		kind;
 	unsigned	client_mode;	/* xinsert / xsink / xsource: A2AMD_XIO_*, what its clients need */
@@ -152,7 +166,6 @@ typedef struct XTRA
 	A2P_process_cb	orig_process;
 	int		is_noise;	/* wtosc: it plays the noise wave (set by its 'w' write) */
 	int		is_head;	/* first forwarded unit of its voice */
-	int		slot;		/* head: the voice's slot in the backend's default map */
 	A2P_unit	*head;		/* the voice's head unit, once its chain was found to be all ours */
 	int		chain_checked;	/* the units behind us in the voice have been looked at */
 	int		refused;	/* an unsupported client was reported once */
@@ -306,6 +319,9 @@ static a2amd_ctx *ctx_of(HOSTSTATE *hs)
 			c.max_batch = 256;
 		hs->max_batch = c.max_batch;
 		hs->no_quick = getenv("A2AMD_NO_QUICK") != NULL;
+		hs->walk_ahead = getenv("A2AMD_WALK_AHEAD") ? atoi(getenv("A2AMD_WALK_AHEAD")) : 12;
+		if(hs->walk_ahead < 0 || hs->walk_ahead > WALK_AHEAD)
+			hs->walk_ahead = WALK_AHEAD;
 		/* A2AMD_DEVICES=<n>: this ONE engine state is spread over n GPUs - every voice
 		 * subtree below the root (an a2_NewGroup group, src/interface.c:888, or a voice
 		 * playing straight into the root's bus) lives on one of them, dealt round robin;
@@ -497,6 +513,8 @@ static void amd_deinit(A2P_unit *u)
 {
 	XTRA *x = xtra(u);
 	int rc;
+	if(x->hs)
+		memset(x->hs->walk_ring, 0, sizeof(x->hs->walk_ring));
 	if(!x->hs)
 		return;
 	if(x->hs->chain_last == u)
@@ -1062,10 +1080,60 @@ static void amd_noop(A2P_unit *u, unsigned offset, unsigned frames)
 {
 }
 
+/* With tens of thousands of voices the walk is DRAM latency: the engine chases v->next,
+ * v->units and u->next through blocks it allocated one by one (a sampling profiler finds
+ * 40 % of the thread at the first instruction of amd_noop: the u->Process load through
+ * u->next, core.c:1875-1876).  The order of the walk is the same fragment after fragment
+ * while no voice comes or goes, so every chain head remembers what the engine touched
+ * walk_ahead heads after it last time and asks for those lines now.  Hints only: a stale
+ * pointer is never dereferenced, and the ring is emptied whenever a unit is destroyed (the
+ * XTRA it points at would be a freed block). */
+static inline void look_ahead(HOSTSTATE *hs, XTRA *x, A2P_unit *u)
+{
+	XTRA *t = hs->walk_ring[hs->walk_pos];
+	if(t && t->ahead != u && t != x)
+	{
+		t->ahead = u;
+		t->ahead_tail[0] = x->tail[0];
+		t->ahead_tail[1] = x->tail[1];
+		t->ahead_vms = x->vms;
+	}
+	hs->walk_ring[hs->walk_pos] = x;
+	hs->walk_pos = (hs->walk_pos + 1) % (unsigned)hs->walk_ahead;
+	if(x->ahead)
+	{
+		/* (blocks and voices come from malloc, 16 byte aligned: the 64 bytes of an
+		 * A2_unit - next first, Process last - usually lie on two cache lines)
+		 * A2_voice as the engine lays it out (internals.h:559-586): next / events
+		 * in the 32 bytes before the VM state, whose first word is the wake time;
+		 * flags behind the registers; units / sub behind the register write table */
+		const char *h = (const char *)x->ahead;
+		const char *v = (const char *)x->ahead_vms - 4 * sizeof(void *);
+		const size_t flags = 4 * sizeof(void *) + sizeof(A2P_vmstate) + 4;
+		const size_t units = flags + 4 + 64 * 2 * sizeof(void *);
+		int k;
+		__builtin_prefetch(h);
+		__builtin_prefetch(h + 64);		/* ... and the XTRA behind it */
+		__builtin_prefetch(h + 64 + offsetof(XTRA, tail) - 1);
+		for(k = 0; k < 2; ++k)
+		{
+			__builtin_prefetch(x->ahead_tail[k]);
+			__builtin_prefetch((const char *)x->ahead_tail[k] + 56);
+		}
+		__builtin_prefetch(v);
+		__builtin_prefetch(x->ahead_vms);
+		__builtin_prefetch(v + flags);
+		__builtin_prefetch(v + units);
+		__builtin_prefetch(v + units + 15);
+	}
+}
+
 static void amd_quick_process(A2P_unit *u, unsigned offset, unsigned frames)
 {
 	XTRA *x = (XTRA *)((char *)u + 64);	/* (own units only: no descriptor look-up) */
 	HOSTSTATE *hs = x->hs;
+	if(hs->walk_ahead)
+		look_ahead(hs, x, u);
 	if(offset == hs->base && frames == hs->win_frames && (unsigned)x->slot < hs->map_cap[x->dev])
 	{
 		hs->map[x->dev][x->slot] = 1;	/* Process(0, all frames) on each unit: the default */
@@ -1083,6 +1151,8 @@ static void amd_head_process(A2P_unit *u, unsigned offset, unsigned frames)
 	int rc, v = 0;
 	if(hs->failed)
 		return;
+	if(hs->walk_ahead)
+		look_ahead(hs, x, u);
 	if(hs->noise_oscs)
 	{
 		/* (the engine-global RNG of the noise oscillators, internals.h:682; only
@@ -1122,6 +1192,8 @@ static int setup_simple_chain(A2P_unit *u)
 	if((slot = a2amd_voice_slot(XCTX(x), x->uid)) < 0)
 		return 0;
 	x->slot = slot;
+	x->tail[0] = u->next;
+	x->tail[1] = u->next ? u->next->next : NULL;
 	for(n = u; n; n = n->next)
 	{
 		xtra(n)->head = u;
