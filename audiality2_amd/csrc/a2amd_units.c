@@ -156,23 +156,24 @@ typedef struct XTRA
 	A2P_unit	*ahead;		/* that voice's head unit ... */
 	A2P_unit	*ahead_tail[2];	/* ... the units behind it ... */
 	A2P_vmstate	*ahead_vms;	/* ... and its VM state, inside its A2_voice */
-	A2P_unit	*tail[2];	/* head: the units behind this one */
+	/* (what a register write and the first unit's Process read ends with the first 64 bytes) */
 	A2P_vmstate	*vms;
 	int		uid;		/* backend unit id, -1 = not forwarded */
-	int		pending;	/* its Initialize / writes wait in HOSTSTATE.births for the voice's first window */
-	int		kind;
+	int16_t		kind;
+	int8_t		pending;	/* its Initialize / writes wait in HOSTSTATE.births for the voice's first window */
+	int8_t		is_noise;	/* wtosc: it plays the noise wave (set by its 'w' write) */
+	A2P_unit	*head;		/* the voice's head unit, once its chain was found to be all ours */
+	A2P_unit	*tail[2];	/* head: the units behind this one */
 	unsigned	client_mode;	/* xinsert / xsink / xsource: A2AMD_XIO_*, what its clients need */
 	int		is_root;
 	A2P_process_cb	orig_process;
-	int		is_noise;	/* wtosc: it plays the noise wave (set by its 'w' write) */
 	int		is_head;	/* first forwarded unit of its voice */
-	A2P_unit	*head;		/* the voice's head unit, once its chain was found to be all ours */
 	int		chain_checked;	/* the units behind us in the voice have been looked at */
 	int		refused;	/* an unsupported client was reported once */
 	void		(*orig_setprocess)(A2P_unit *u);	/* root xinsert: the engine's xi_SetProcess */
 } XTRA;
 
-_Static_assert(sizeof(A2P_unit) <= 64 && 64 + sizeof(XTRA) <= A2P_BLOCK_SIZE, "XTRA placement");
+_Static_assert(sizeof(A2P_unit) <= 64 && 64 + sizeof(XTRA) <= A2P_BLOCK_SIZE && offsetof(XTRA, head) == 64, "XTRA placement");
 
 static inline XTRA *xtra(A2P_unit *u)
 {
@@ -1084,16 +1085,19 @@ static void amd_noop(A2P_unit *u, unsigned offset, unsigned frames)
  * v->units and u->next through blocks it allocated one by one (a sampling profiler finds
  * 40 % of the thread at the first instruction of amd_noop: the u->Process load through
  * u->next, core.c:1875-1876).  The order of the walk is the same fragment after fragment
- * while no voice comes or goes, so every chain head remembers what the engine touched
- * walk_ahead heads after it last time and asks for those lines now.  Hints only: a stale
+ * while no voice comes or goes, so every unit of ours that does anything in its Process -
+ * the heads of our own chains, the units of group voices - remembers which of them the
+ * engine called walk_ahead calls later last time, and asks for that one's lines now.  Hints only: a stale
  * pointer is never dereferenced, and the ring is emptied whenever a unit is destroyed (the
  * XTRA it points at would be a freed block). */
 static inline void look_ahead(HOSTSTATE *hs, XTRA *x, A2P_unit *u)
 {
 	XTRA *t = hs->walk_ring[hs->walk_pos];
-	if(t && t->ahead != u && t != x)
+	/* (bit 0: the unit keeps its XTRA at the end of its block, xtra()) */
+	A2P_unit *me = (A2P_unit *)((uintptr_t)u | ((char *)x != (char *)u + 64));
+	if(t && t->ahead != me && t != x)
 	{
-		t->ahead = u;
+		t->ahead = me;
 		t->ahead_tail[0] = x->tail[0];
 		t->ahead_tail[1] = x->tail[1];
 		t->ahead_vms = x->vms;
@@ -1107,14 +1111,16 @@ static inline void look_ahead(HOSTSTATE *hs, XTRA *x, A2P_unit *u)
 		 * A2_voice as the engine lays it out (internals.h:559-586): next / events
 		 * in the 32 bytes before the VM state, whose first word is the wake time;
 		 * flags behind the registers; units / sub behind the register write table */
-		const char *h = (const char *)x->ahead;
+		const char *h = (const char *)((uintptr_t)x->ahead & ~(uintptr_t)1);
+		const char *hx = ((uintptr_t)x->ahead & 1) ? h + A2P_BLOCK_SIZE - sizeof(XTRA) : h + 64;
 		const char *v = (const char *)x->ahead_vms - 4 * sizeof(void *);
 		const size_t flags = 4 * sizeof(void *) + sizeof(A2P_vmstate) + 4;
 		const size_t units = flags + 4 + 64 * 2 * sizeof(void *);
 		int k;
 		__builtin_prefetch(h);
-		__builtin_prefetch(h + 64);		/* ... and the XTRA behind it */
-		__builtin_prefetch(h + 64 + offsetof(XTRA, tail) - 1);
+		__builtin_prefetch(h + 56);
+		__builtin_prefetch(hx);			/* ... and what we keep of it */
+		__builtin_prefetch(hx + offsetof(XTRA, head) - 1);
 		for(k = 0; k < 2; ++k)
 		{
 			__builtin_prefetch(x->ahead_tail[k]);
@@ -1230,6 +1236,8 @@ static void amd_process(A2P_unit *u, unsigned offset, unsigned frames)
 			return;
 		}
 	}
+	if(hs->walk_ahead)
+		look_ahead(hs, x, u);
 	forward_process(x, offset, frames);
 	if(x->is_root && x->kind == A2AMD_PANMIX && !hs->batching)
 	{
@@ -1295,6 +1303,8 @@ static void amd_inline_process(A2P_unit *u, unsigned offset, unsigned frames)
 	}
 	if(x->pending)
 		route_voice(x);
+	if(hs->walk_ahead)
+		look_ahead(hs, x, u);
 	forward_process(x, offset, frames);
 	if(hs->depth < 70)
 		hs->dev_stack[hs->depth] = x->dev;	/* (our subvoices' buses live where we do) */
