@@ -1165,10 +1165,18 @@ DEV void osc_write_s(const FastPtrs &g, OscS &o, int reg, int v, int start, int 
 enum { FS_Q = 0, FS_LP = 4, FS_BP, FS_HP, FS_F1, FS_D1, FS_D2, FS_F1NEXT, FS_RAMP, FS_NWORDS };
 struct FiltS { Ramp q; int lp, bp, hp, f1, d1, d2, f1next, ramp; };
 
+// (v_writelane_b32: one lane of a vector register from a scalar one; the lane select goes
+// through M0 - two scalar registers in one VOP3 are one too many for the constant bus)
+DEV int writelane_s(int y, int val, int sel)
+{
+	asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(y) : "s"(val), "s"(sel) : "m0");
+	return y;
+}
+
 // One window of f12_process (filter12.c:74-119) over the frames a wavefront holds one per
-// lane: the recurrence runs on the SCALAR unit - a v_readlane, a dozen dependent scalar
-// operations (they issue back to back, where dependent vector operations of one wavefront
-// are four cycles apart) and a lane-select per frame.
+// lane: the recurrence runs on the SCALAR unit - per frame a v_readlane, 26 scalar
+// operations (nine of them the dependent chain d1 -> d1) and a v_writelane.  Measured on a
+// wavefront that has its SIMD to itself (a song: -DRECS_PROF): ~7 cycles per instruction.
 DEV int filt_window_s(FiltS &fs, int x, int off, int len, int lane)
 {
 	int f0 = fs.f1, df = 0, f1 = fs.f1;
@@ -1179,7 +1187,10 @@ DEV int filt_window_s(FiltS &fs, int x, int off, int len, int lane)
 	}
 	int qv = fs.q.value, d1 = fs.d1, d2 = fs.d2;
 	const int qd = fs.q.delta, lp = fs.lp, bp = fs.bp, hp = fs.hp;
-	for(int s = 0; s < len; ++s) {
+	// (input and output in registers of their own: reading frame s + 1 does not wait
+	// for frame s to be written)
+	int y = x;
+	auto frame = [&](int s) {
 		const int xin = rdl(x, off + s);
 		const int f = f0 >> 12, qq = qv >> 12;
 		const int d1s = d1 >> 4;
@@ -1191,14 +1202,26 @@ DEV int filt_window_s(FiltS &fs, int x, int off, int len, int lane)
 		d2 = l;
 		f0 = wadd(f0, df);
 		qv = wadd(qv, qd);
-		x = (lane == off + s) ? out : x;
+		y = writelane_s(y, out, off + s);
+	};
+	// (four frames per trip: the output sums of one frame fill the waits of the next
+	// one's recurrence, and a taken branch costs a wavefront on its own more than an
+	// instruction)
+	int s = 0;
+	for(; s + 4 <= len; s += 4) {
+		frame(s);
+		frame(s + 1);
+		frame(s + 2);
+		frame(s + 3);
 	}
+	for(; s < len; ++s)
+		frame(s);
 	fs.d1 = d1;
 	fs.d2 = d2;
 	fs.q.value = qv;	// (= a2_RunRamper(&q, 1) per frame)
 	fs.f1 = f1;
 	fs.ramp = 0;
-	return x;
+	return y;
 }
 
 // (the body of the kernels below: gw = this wavefront's index among those of its class)
@@ -1212,6 +1235,7 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 {
 #ifdef RECS_PROF
 	const long long t_in = __builtin_readcyclecounter();
+	const unsigned long long rt_in = __builtin_amdgcn_s_memrealtime();
 	long long t_win = 0, t_rec = 0;
 	int n_win = 0, n_rec = 0;
 #endif
@@ -1442,6 +1466,9 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 							break;
 						}
 						++rc;
+#ifdef RECS_PROF
+						++n_rec;
+#endif
 						head = rc < re ? (uint32_t)rfl((int)recs[rc].head) : 0xffffffffu;
 					} while(rc < re && (int)A2D_RFRAG(head) == f);
 				}
@@ -1473,6 +1500,9 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 		// adds on the same 512 bytes per fragment; the workgroup sums its wavefronts'
 		// chunks in LDS first (neighbours in the list share their bus: it is sorted).
 		{
+#ifdef RECS_PROF
+			const long long r0 = __builtin_readcyclecounter();
+#endif
 			const int pb = (f0 / RECS_FCH) & 1;
 #pragma unroll
 			for(int j = 0; j < RECS_FCH; ++j) {
@@ -1500,6 +1530,10 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 						sum = wadd(sum, part[pb][w][row][lane]);
 				}
 			}
+#ifdef RECS_PROF
+			asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+			t_rec += __builtin_readcyclecounter() - r0;
+#endif
 		}
 	}
 
@@ -1537,10 +1571,10 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	}
 #ifdef RECS_PROF
 	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
-	if((blockIdx.x == 0 || blockIdx.x == 700) && wv == 1 && lane == 0)
-		printf("k_leaf_recs<%d,..> block %d: %d voices x %d fragments: prologue %lld, loop %lld (of which %d windows %lld), epilogue %lld cycles\n",
-				NOSC, (int)blockIdx.x, nv, nfrags, t_pro - t_in, t_loop - t_pro, n_win, t_win,
-				(long long)__builtin_readcyclecounter() - t_loop);
+	if(nv > 0 && (blockIdx.x % 175) < 8 && lane == 0)
+		printf("k_leaf_recs<%d,%d> block %d wave %d: %d voices x %d fragments: prologue %lld, loop %lld (of which %d windows %lld, %d records, block sums %lld), epilogue %lld cycles; %llu ticks of 10 ns\n",
+				NOSC, FILT, (int)blockIdx.x, wv, nv, nfrags, t_pro - t_in, t_loop - t_pro, n_win, t_win, n_rec, t_rec,
+				(long long)__builtin_readcyclecounter() - t_loop, (unsigned long long)__builtin_amdgcn_s_memrealtime() - rt_in);
 #endif
 }
 
