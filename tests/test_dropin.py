@@ -81,6 +81,29 @@ def test_dropin_mono_root_and_odd_buffers(tmp_path, channels, buffer):
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ahead", [0, 1, 5, 32])
+@pytest.mark.parametrize("script,arg", [("scripted", "0.2"), ("song", "0.08")])
+def test_dropin_walk_prefetch_hints_change_nothing(tmp_path, script, arg, ahead):
+    """look_ahead() (a2amd_units.c): every unit of ours that is called remembers which
+    one the engine called N calls later in the last walk and prefetches its blocks.
+    Hints only - but the ring of recent callers points into engine-owned blocks, and
+    notes are born and die all the time in these scripts: with the ring off, short,
+    odd and at its longest the render must be the reference's."""
+    need_ref()
+    outs = []
+    for pre in (None, UNITS_SO):
+        out = tmp_path / f"o{int(pre is not None)}.pcm"
+        env = dict(os.environ, A2AMD_WALK_AHEAD=str(ahead))
+        if pre:
+            env["LD_PRELOAD"] = pre
+        subprocess.run([REF_RENDER, f"{A2S}/{script}.a2s", "Main", str(64 * 1500), "64", "48000", "2", str(out), arg],
+                       check=True, env=env, cwd=A2S, timeout=600)
+        outs.append(np.fromfile(out, dtype="<i4"))
+    assert outs[0].any()
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_reference_render_is_reproducible(tmp_path):
     """The harness itself (no drop-in) reproduces the golden fixture: the
     fixtures are what the reference renders, run to run."""
