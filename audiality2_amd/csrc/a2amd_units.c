@@ -1076,6 +1076,7 @@ static void forward_process(XTRA *x, unsigned offset, unsigned frames)
  * shrinks to one byte store into the backend's default map per fragment
  * (amd_quick_process) until a register of the voice is written again. */
 static void amd_head_process(A2P_unit *u, unsigned offset, unsigned frames);
+static void head_process(A2P_unit *u, XTRA *x, HOSTSTATE *hs, unsigned offset, unsigned frames);
 
 static void amd_noop(A2P_unit *u, unsigned offset, unsigned frames)
 {
@@ -1087,9 +1088,9 @@ static void amd_noop(A2P_unit *u, unsigned offset, unsigned frames)
  * u->next, core.c:1875-1876).  The order of the walk is the same fragment after fragment
  * while no voice comes or goes, so every unit of ours that does anything in its Process -
  * the heads of our own chains, the units of group voices - remembers which of them the
- * engine called walk_ahead calls later last time, and asks for that one's lines now.  Hints only: a stale
- * pointer is never dereferenced, and the ring is emptied whenever a unit is destroyed (the
- * XTRA it points at would be a freed block). */
+ * engine called walk_ahead calls later last time, and asks for that one's lines now.
+ * Hints only: a stale pointer is never dereferenced, and the ring is emptied whenever a
+ * unit is destroyed (the XTRA it points at would be a freed block). */
 static inline void look_ahead(HOSTSTATE *hs, XTRA *x, A2P_unit *u)
 {
 	XTRA *t = hs->walk_ring[hs->walk_pos];
@@ -1146,19 +1147,24 @@ static void amd_quick_process(A2P_unit *u, unsigned offset, unsigned frames)
 		return;
 	}
 	u->Process = amd_head_process;
-	amd_head_process(u, offset, frames);
+	head_process(u, x, hs, offset, frames);
 }
 
 static void amd_head_process(A2P_unit *u, unsigned offset, unsigned frames)
 {
 	XTRA *x = (XTRA *)((char *)u + 64);
 	HOSTSTATE *hs = x->hs;
+	if(hs->walk_ahead)
+		look_ahead(hs, x, u);
+	head_process(u, x, hs, offset, frames);
+}
+
+static void head_process(A2P_unit *u, XTRA *x, HOSTSTATE *hs, unsigned offset, unsigned frames)
+{
 	uint32_t noise = 0, before = 0;
 	int rc, v = 0;
 	if(hs->failed)
 		return;
-	if(hs->walk_ahead)
-		look_ahead(hs, x, u);
 	if(hs->noise_oscs)
 	{
 		/* (the engine-global RNG of the noise oscillators, internals.h:682; only
