@@ -25,6 +25,7 @@
 //                   steps the rampers and the wavefronts then split the
 //                   fragments.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <algorithm>
 #include <stdlib.h>
 #include "a2amd_device.h"
@@ -1174,7 +1175,7 @@ DEV int writelane_s(int y, int val, int sel)
 }
 
 // One window of f12_process (filter12.c:74-119) over the frames a wavefront holds one per
-// lane: the recurrence runs on the SCALAR unit - per frame a v_readlane, 26 scalar
+// lane: the recurrence runs on the SCALAR unit - per frame a v_readlane, 17 to 26 scalar
 // operations (nine of them the dependent chain d1 -> d1) and a v_writelane.  Measured on a
 // wavefront that has its SIMD to itself (a song: -DRECS_PROF): ~7 cycles per instruction.
 DEV int filt_window_s(FiltS &fs, int x, int off, int len, int lane)
@@ -1190,32 +1191,52 @@ DEV int filt_window_s(FiltS &fs, int x, int off, int len, int lane)
 	// (input and output in registers of their own: reading frame s + 1 does not wait
 	// for frame s to be written)
 	int y = x;
-	auto frame = [&](int s) {
+	// Three things most windows do not need, each a twelfth to a seventh of the frame's
+	// instructions (the variant is chosen per window, uniformly):
+	//   bit 0  bp = hp = 0, the plain low-pass most voices are: their products drop out of the sum
+	//   bit 1  q is not ramping
+	//   bit 2  the cutoff is not ramping
+	auto frame = [&](int s, auto variant) {
+		constexpr int V = decltype(variant)::value;
 		const int xin = rdl(x, off + s);
 		const int f = f0 >> 12, qq = qv >> 12;
 		const int d1s = d1 >> 4;
 		const int l = wadd(d2, wmul(f, d1s) >> 8);
 		const int h = wsub(wsub(xin >> 5, l), wmul(qq, d1s) >> 8);
 		const int b = wadd(wmul(f, h >> 4) >> 8, d1);
-		const int out = wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3;
+		const int out = ((V & 1) ? wmul(l, lp) : wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp))) >> 3;
 		d1 = b;
 		d2 = l;
-		f0 = wadd(f0, df);
-		qv = wadd(qv, qd);
+		if(!(V & 4))
+			f0 = wadd(f0, df);
+		if(!(V & 2))
+			qv = wadd(qv, qd);
 		y = writelane_s(y, out, off + s);
 	};
 	// (four frames per trip: the output sums of one frame fill the waits of the next
 	// one's recurrence, and a taken branch costs a wavefront on its own more than an
 	// instruction)
-	int s = 0;
-	for(; s + 4 <= len; s += 4) {
-		frame(s);
-		frame(s + 1);
-		frame(s + 2);
-		frame(s + 3);
+	auto frames = [&](auto variant) {
+		int s = 0;
+		for(; s + 4 <= len; s += 4) {
+			frame(s, variant);
+			frame(s + 1, variant);
+			frame(s + 2, variant);
+			frame(s + 3, variant);
+		}
+		for(; s < len; ++s)
+			frame(s, variant);
+	};
+	switch(((bp | hp) == 0 ? 1 : 0) | (qd == 0 ? 2 : 0) | (df == 0 ? 4 : 0)) {
+	  case 0: frames(std::integral_constant<int, 0>()); break;
+	  case 1: frames(std::integral_constant<int, 1>()); break;
+	  case 2: frames(std::integral_constant<int, 2>()); break;
+	  case 3: frames(std::integral_constant<int, 3>()); break;
+	  case 4: frames(std::integral_constant<int, 4>()); break;
+	  case 5: frames(std::integral_constant<int, 5>()); break;
+	  case 6: frames(std::integral_constant<int, 6>()); break;
+	  default: frames(std::integral_constant<int, 7>()); break;
 	}
-	for(; s < len; ++s)
-		frame(s);
 	fs.d1 = d1;
 	fs.d2 = d2;
 	fs.q.value = qv;	// (= a2_RunRamper(&q, 1) per frame)
