@@ -1104,7 +1104,8 @@ static inline void look_ahead(HOSTSTATE *hs, XTRA *x, A2P_unit *u)
 		t->ahead_vms = x->vms;
 	}
 	hs->walk_ring[hs->walk_pos] = x;
-	hs->walk_pos = (hs->walk_pos + 1) % (unsigned)hs->walk_ahead;
+	if(++hs->walk_pos >= (unsigned)hs->walk_ahead)	/* (no division on this path) */
+		hs->walk_pos = 0;
 	if(x->ahead)
 	{
 		/* (blocks and voices come from malloc, 16 byte aligned: the 64 bytes of an
