@@ -1536,18 +1536,21 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 			}
 			__syncthreads();
 			// wavefront r owns row r of the chunk: fragment r / 2, channel r % 2
-			for(int row = wv; row < 2 * nf; row += RECS_WPB) {
+			// (a launch of a few dozen voices - a song - comes with ONE wavefront per
+			// workgroup: nobody to sum with, and nobody's slow chunk to wait for)
+			const int wpb = (int)(blockDim.x >> 6);
+			for(int row = wv; row < 2 * nf; row += wpb) {
 				int sum = 0, off = -1, nch = 2;
-				for(int w = 0; w <= RECS_WPB; ++w) {
-					const int woff = w < RECS_WPB ? part_off[pb][w] : -2;
+				for(int w = 0; w <= wpb; ++w) {
+					const int woff = w < wpb ? part_off[pb][w] : -2;
 					if(woff != off) {
 						if(off >= 0 && sum && !(dbg & 1))
 							atomicAdd(busmem + off + ((size_t)(f0 + (row >> 1)) * nch + (row & 1)) * A2D_FRAG + lane, sum);
 						sum = 0;
 						off = woff;
-						nch = w < RECS_WPB ? part_nch[pb][w] : 2;
+						nch = w < wpb ? part_nch[pb][w] : 2;
 					}
-					if(w < RECS_WPB && woff >= 0)
+					if(w < wpb && woff >= 0)
 						sum = wadd(sum, part[pb][w][row][lane]);
 				}
 			}
@@ -1614,7 +1617,7 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 {
 	__shared__ RecsPart part[2];
 	__shared__ int part_off[2][RECS_WPB], part_nch[2][RECS_WPB];
-	recs_body<NOSC, FILT>(pp, list, nlist, vpw, (int)(blockIdx.x * RECS_WPB + (threadIdx.x >> 6)), voices, ustate, vactive,
+	recs_body<NOSC, FILT>(pp, list, nlist, vpw, (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), voices, ustate, vactive,
 			wavepool, waves, ptab, busmem, part, part_off, part_nch);
 }
 
@@ -1633,9 +1636,10 @@ void k_leaf_recs_all(const A2DParams *__restrict__ pp, RecsSegs segs, int vpw,
 	__shared__ RecsPart part[2];
 	__shared__ int part_off[2][RECS_WPB], part_nch[2][RECS_WPB];
 	int b = (int)blockIdx.x, kind = -1;
+	const int wpb = (int)(blockDim.x >> 6);
 #pragma unroll
 	for(int k = 0; k < 4; ++k) {
-		const int nb = ((segs.count[k] + vpw - 1) / vpw + RECS_WPB - 1) / RECS_WPB;
+		const int nb = ((segs.count[k] + vpw - 1) / vpw + wpb - 1) / wpb;
 		if(kind < 0) {
 			if(b < nb)
 				kind = k;
@@ -1643,7 +1647,7 @@ void k_leaf_recs_all(const A2DParams *__restrict__ pp, RecsSegs segs, int vpw,
 				b -= nb;
 		}
 	}
-	const int gw = b * RECS_WPB + (int)(threadIdx.x >> 6);
+	const int gw = b * wpb + (int)(threadIdx.x >> 6);
 #define RECS_BODY(K, N, F) case K: recs_body<N, F>(pp, segs.list[K], segs.count[K], vpw, gw, voices, ustate, vactive, \
 		wavepool, waves, ptab, busmem, part, part_off, part_nch); break
 	switch(rfl(kind)) {
@@ -1655,20 +1659,36 @@ void k_leaf_recs_all(const A2DParams *__restrict__ pp, RecsSegs segs, int vpw,
 #undef RECS_BODY
 }
 
+// Wavefronts per workgroup of the records kernels: RECS_WPB to sum in LDS before the bus
+// atomics, ONE while the launch has fewer wavefronts than the GPU has CUs - then each voice
+// runs at its own pace instead of meeting the seven others at a barrier every four fragments
+// (a song: the slowest voice changes from chunk to chunk, and the sum of the chunks' maxima
+// was 15 % more than the slowest voice's own time).
+static int recs_wpb(int nwaves)
+{
+	static const int force = getenv("A2AMD_RECS_WPB") ? atoi(getenv("A2AMD_RECS_WPB")) : 0;
+	if(force >= 1 && force <= RECS_WPB)
+		return force;
+	return nwaves <= 256 ? 1 : RECS_WPB;
+}
+
 int a2d_launch_leaf_recs_all(const A2DParams *dparams, const A2DParams &hp, const int *const *lists, const int *counts,
 		int vpw, void *stream)
 {
 	RecsSegs segs;
-	int nblocks = 0;
+	int nblocks = 0, nwaves = 0;
 	vpw = min(max(vpw, 1), 64);
+	for(int k = 0; k < 4; ++k)
+		nwaves += (counts[k] + vpw - 1) / vpw;
+	const int wpb = recs_wpb(nwaves);
 	for(int k = 0; k < 4; ++k) {
 		segs.list[k] = lists[k];
 		segs.count[k] = counts[k];
-		nblocks += ((counts[k] + vpw - 1) / vpw + RECS_WPB - 1) / RECS_WPB;
+		nblocks += ((counts[k] + vpw - 1) / vpw + wpb - 1) / wpb;
 	}
 	if(!nblocks)
 		return 0;
-	hipLaunchKernelGGL(k_leaf_recs_all, dim3(nblocks), dim3(64 * RECS_WPB), 0, (hipStream_t)stream, dparams, segs, vpw,
+	hipLaunchKernelGGL(k_leaf_recs_all, dim3(nblocks), dim3(64 * wpb), 0, (hipStream_t)stream, dparams, segs, vpw,
 			hp.voices, hp.ustate, hp.vactive, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
 	return (int)hipGetLastError();
 }
@@ -1680,8 +1700,9 @@ int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc
 		return 0;
 	vpw = min(max(vpw, 1), 64);
 	const int nwaves = (nlist + vpw - 1) / vpw;
-	const int nblocks = (nwaves + RECS_WPB - 1) / RECS_WPB;
-#define RECS_LAUNCH(N, F) hipLaunchKernelGGL((k_leaf_recs<N, F>), dim3(nblocks), dim3(64 * RECS_WPB), 0, \
+	const int wpb = recs_wpb(nwaves);
+	const int nblocks = (nwaves + wpb - 1) / wpb;
+#define RECS_LAUNCH(N, F) hipLaunchKernelGGL((k_leaf_recs<N, F>), dim3(nblocks), dim3(64 * wpb), 0, \
 		(hipStream_t)stream, dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.vactive, hp.wavepool, \
 		hp.waves, hp.ptab, hp.busmem)
 	if(nosc == 1 && !filt)
