@@ -1660,16 +1660,18 @@ void k_leaf_recs_all(const A2DParams *__restrict__ pp, RecsSegs segs, int vpw,
 }
 
 // Wavefronts per workgroup of the records kernels: RECS_WPB to sum in LDS before the bus
-// atomics, ONE while the launch has fewer wavefronts than the GPU has CUs - then each voice
-// runs at its own pace instead of meeting the seven others at a barrier every four fragments
-// (a song: the slowest voice changes from chunk to chunk, and the sum of the chunks' maxima
-// was 15 % more than the slowest voice's own time).
+// atomics, ONE while all of the launch's wavefronts are resident at once anyway (32 KB of LDS
+// per workgroup: five per CU) - then each voice runs at its own pace instead of meeting the
+// seven others at a barrier every four fragments (a song: the slowest voice changes from
+// chunk to chunk, and the sum of the chunks' maxima was 15-20 % more than the slowest voice's
+// own time; 64 fragments of 512 / 1 024 / 2 048 scripted filter voices: 0.49 / 0.52 / 1.21 ms
+// with one wavefront per workgroup, 0.61 / 0.62 / 0.63 with eight).
 static int recs_wpb(int nwaves)
 {
 	static const int force = getenv("A2AMD_RECS_WPB") ? atoi(getenv("A2AMD_RECS_WPB")) : 0;
 	if(force >= 1 && force <= RECS_WPB)
 		return force;
-	return nwaves <= 256 ? 1 : RECS_WPB;
+	return nwaves <= 1024 ? 1 : RECS_WPB;
 }
 
 int a2d_launch_leaf_recs_all(const A2DParams *dparams, const A2DParams &hp, const int *const *lists, const int *counts,
