@@ -138,6 +138,18 @@ class Scene:
         self.groups.append(g)
         return g
 
+    def add_bus_group(self, parent=None):
+        """A group voice as a2_NewGroup makes it (src/interface.c:888: the program
+        a2_groupdriver, audiality2.c:292-302): inline 0 *; panmix * *; xinsert * > -
+        under the root voice or under another such group."""
+        be, k = self.be, self._key()
+        u = [be.unit_init(k, K_INLINE, 0, 0, 2, 0),
+             be.unit_init(k, K_PANMIX, 0, 2, 2, 0),
+             be.unit_init(k, K_XINSERT, PROCADD, 2, 2, 1)]
+        g = dict(units=u, leaves=[], subs=[])
+        (self.groups if parent is None else parent.setdefault("subs", [])).append(g)
+        return g
+
     def add_voices(self, n, chain="osc-pan", group=None, total=None):
         """n sustained voices with the per-voice parameters of SURVEY.md 8(d):
         wave 7k mod 24, pitch ((k mod 61)-30)/12 oct, pan ((k mod 17)-8)/8 ..."""
@@ -216,14 +228,19 @@ class Scene:
         be.fragment(frames)
         if self.rootv:
             be.unit_process(self.rootv[0], 0, frames)
-        for g in self.groups:
+        def walk_group(g):
             be.unit_process(g["units"][0], 0, frames)
+            for sub in g.get("subs", ()):
+                walk_group(sub)
             for units in g["leaves"]:
                 for u in units:
                     be.unit_process(u, 0, frames)
             be.inline_end(g["units"][0])
-            be.unit_process(g["units"][1], 0, frames)
-            be.unit_process(g["units"][2], 0, frames)
+            for u in g["units"][1:]:
+                be.unit_process(u, 0, frames)
+
+        for g in self.groups:
+            walk_group(g)
         for units in self.leaves:
             for u in units:
                 be.unit_process(u, 0, frames)

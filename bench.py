@@ -71,6 +71,12 @@ CONFIGS = {   # BASELINE.json configs[i]
                   "(benchmark/fmtest4.a2s delay settings; 256 groups, 512 fbdelays), 48 kHz, fragment=64, "
                   "stereo (BASELINE configs[3])"),
 }
+CONFIGS[4] = dict(   # BASELINE configs[4] / SURVEY 8(d) config #5: one top-level group per GPU
+    voices=32768, chain="osc-filter-pan", groups=0, tree=128,
+    label="32768 voices wtosc->filter12->panmix per GPU: one top-level group voice (a2_NewGroup's driver "
+          "inline->panmix->xinsert) of 128 sub-groups x 256 voices; 8 GPUs = the 262144 voices of BASELINE "
+          "configs[4], the groups' sum into the root bus = ONE ncclReduce per buffer")
+TOP_GROUP_VOICES = 32768
 UP, SUB, ROOTP, RB, KEEP, ASYNC = 4, 1, 2, 8, 16, 32
 
 
@@ -96,17 +102,27 @@ def fnv1a_fragments(pcm, frag=64):
     return h
 
 
-def golden_path(voices, chain, groups):
+def golden_path(voices, chain, groups, tree=0):
+    if tree:    # configs[4]: keyed by the voices of the WHOLE job (all ranks)
+        return os.path.join(ROOT, "tests", "golden", f"bench_cfg4_{chain}_{voices}v_{tree}sub.hash.npy")
     return os.path.join(ROOT, "tests", "golden", f"bench_{chain}_{voices}v_{groups}g.hash.npy")
 
 
-def build_scene(be, voices, chain, groups, world=1, rank=0):
+def build_scene(be, voices, chain, groups, world=1, rank=0, tree=0):
     """The synthetic voice tree of a config (every rank plays different voices)."""
     from audiality2_amd import shard, synth
     sc = synth.Scene(be)
     sc.root()
     sc.nvoices = shard.voice_range(rank, voices)[0]
-    if groups:
+    if tree:
+        # configs[4]: top-level groups of `tree` sub-groups x 256 voices, this rank's share
+        assert voices % TOP_GROUP_VOICES == 0 and TOP_GROUP_VOICES % tree == 0
+        for _ in range(voices // TOP_GROUP_VOICES):
+            top = sc.add_bus_group()
+            for _ in range(tree):
+                sub = sc.add_bus_group(top)
+                sc.add_voices(TOP_GROUP_VOICES // tree, chain=chain, group=sub, total=voices * world)
+    elif groups:
         per = voices // groups
         for _ in range(groups):
             grp = sc.add_group(preset="fmtest4")
@@ -186,6 +202,95 @@ def cpu_baseline(voices, chain, groups, oracle_fragments=100):
                       f"C restatement (oracle/a2o.c), 1 thread"}
 
 
+# ---------------------------------------------------------------------------------------------
+# The PRODUCT as an application gets it: the reference engine itself (A2S compiler, VM, event
+# scheduler, voice walk: one CPU thread; oracle/_ref/ref_bench = the compiled reference + a
+# timing harness) calling a2_Run(), its units replaced by the drop-in (LD_PRELOAD of
+# liba2amd_units.so).  north_star's entry point (src/core.c:2004-2011, bufferdrv.c:28-40).
+ENGINE_CASES = [   # label, program of tests/a2s/bench.a2s, voices
+    ("configs[1]", "OscPan", 1024), ("configs[2]", "OscFilterPan", 16384),
+    ("configs[3]", "Osc2PanGroups", 65536),
+    ("variant 2b (scripted)", "OscPanScripted", 16384), ("variant 3b (scripted)", "OscFilterPanScripted", 16384),
+]
+ENGINE_BUFFERS = (4096, 64)     # a2play's offline buffer; one fragment per a2_Run() = a realtime driver's
+
+
+def engine_run(program, voices, fragments, buffer, dropin, hash_fragments=0, env_extra=None, wait=True):
+    """One ref_bench process; returns its JSON (or the Popen when wait=False)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+    env = dict(os.environ, A2REF_BUFFER=str(buffer))
+    env.pop("LD_PRELOAD", None)
+    if hash_fragments:
+        env["A2REF_HASH"] = str(hash_fragments)
+    if dropin:
+        env["LD_PRELOAD"] = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
+    env.update(env_extra or {})
+    p = subprocess.Popen([exe, "bench.a2s", program, str(voices), str(fragments), "1"], env=env,
+                         cwd=os.path.join(ROOT, "tests", "a2s"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    return engine_result(p) if wait else p
+
+
+def engine_result(p, timeout=600):
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        return {"error": "timeout"}
+    if p.returncode != 0:
+        return {"error": f"rc {p.returncode}: {err[-300:]}"}
+    try:
+        return json.loads(out.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return {"error": f"no JSON: {out[-200:]} {err[-200:]}"}
+
+
+def engine_in_loop(cases=ENGINE_CASES, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fragments=1024):
+    """a2_Run() with the reference engine in the loop, drop-in vs the engine's own CPU units:
+    voice-samples/s, time per 64-frame fragment (p50 / p99 over the a2_Run() calls), and the
+    FNV-1a hash of the first `hash_fragments` fragments after the warm-up from both runs."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+    if not os.path.exists(exe):
+        return {"error": "oracle/_ref/ref_bench (the compiled reference) did not travel"}
+    # the CPU renders: independent processes, one thread each, all at once (the box has the cores)
+    cpu = {}
+    for label, program, voices in cases:
+        for buf in buffers:
+            hf = hash_fragments if voices < 65536 else min(hash_fragments, 16)
+            nfr = max(hf, buf // 64)
+            cpu[(label, buf)] = (hf, engine_run(program, voices, nfr, buf, False, hf, wait=False))
+    cpu = {k: (hf, engine_result(p)) for k, (hf, p) in cpu.items()}
+    out = {"entry_point": "a2_Run(frames) of the compiled reference engine (oracle/_ref/ref_bench, one engine state, one "
+                          "CPU thread for compiler + VM + voice walk), units = the drop-in (LD_PRELOAD=liba2amd_units.so)",
+           "hash": "FNV-1a 64 of the first fragments rendered after the warm-up, ch0 then ch1 per 64-frame fragment",
+           "cases": {}}
+    all_equal = True
+    for label, program, voices in cases:
+        entry = {"program": program, "voices": voices}
+        for buf in buffers:
+            hf, c = cpu[(label, buf)]
+            nfr = max(gpu_fragments if buf > 64 else 600, buf // 64 * 4)
+            g = engine_run(program, voices, nfr, buf, True, hf)
+            e = {}
+            if "error" in g or "error" in c:
+                e["error"] = g.get("error") or c.get("error")
+                all_equal = False
+            else:
+                per = buf // 64
+                e = {"voice_samples_per_s": g["voice_samples_per_s"],
+                     "us_per_fragment_p50": g["run_us_p50"] / per, "us_per_fragment_p99": g["run_us_p99"] / per,
+                     "us_per_fragment_mean": g["seconds"] / g["fragments"] * 1e6,
+                     "fragments_timed": g["fragments"], "active_voices": g["active_voices"],
+                     "realtime_at_48k": bool(g["run_us_p99"] / per <= 64.0 / 48000.0 * 1e6),
+                     "cpu_units_voice_samples_per_s": c["voice_samples_per_s"],
+                     "hash_fragments": hf, "hash": g["hashes"][0], "cpu_hash": c["hashes"][0],
+                     "hash_equal": g["hashes"][0] == c["hashes"][0] and g["active_voices"] == c["active_voices"]}
+                all_equal = all_equal and e["hash_equal"]
+            entry[f"a2_Run({buf})"] = e
+        out["cases"][label] = entry
+    out["hash_equal"] = all_equal
+    return out
+
+
 def pmc_entry(chain, voices, groups, B):
     """PMC-derived figures for this workload's dominant kernel (profiles/*.json, tools/pmc_summary.py)."""
     key = f"{chain}/{voices}/{groups}/{B}"
@@ -206,9 +311,9 @@ def pmc_entry(chain, voices, groups, B):
 class Runner:
     """One config on one GPU through the product entry points."""
 
-    def __init__(self, audiality2_amd, voices, chain, groups, B, device=0, world=1, rank=0):
+    def __init__(self, audiality2_amd, voices, chain, groups, B, device=0, world=1, rank=0, tree=0):
         self.voices, self.chain, self.groups, self.B = voices, chain, groups, B
-        self.rank = rank
+        self.rank, self.world, self.tree = rank, world, tree
         self.be = audiality2_amd.open_backend(48000, None, 2, device=device, max_batch=B)
         lib = self.lib = self.be.lib
         lib.a2amd_fragment_repeat.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
@@ -224,7 +329,7 @@ class Runner:
             for c in range(2):
                 p[c] = b[c].ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
             self.ptrs.append(p)
-        self.sc = build_scene(self.be, voices, chain, groups, world, rank)
+        self.sc = build_scene(self.be, voices, chain, groups, world, rank, tree)
         self.step_no = 0            # steps issued
         self.got = 0                # steps collected
         self.kept = {}              # step -> audio (the steps the golden covers, and the last one)
@@ -310,10 +415,16 @@ class Runner:
 def check_golden(r, nsteps):
     """Compare every rendered step the committed oracle golden covers; returns
     (steps compared, all equal) or (0, None) without a golden for this workload."""
-    path = golden_path(r.voices, r.chain, r.groups)
+    path = golden_path(r.voices * r.world if r.tree else r.voices, r.chain, r.groups, r.tree)
     if not os.path.exists(path):
         return 0, None
     gold = np.load(path)
+    if r.tree:
+        # configs[4]: the golden holds the first fragments of step 0 (of the whole job's audio)
+        if 0 not in r.kept:
+            return 0, None
+        n = min(len(gold), r.B)
+        return 1, bool(np.array_equal(fnv1a_fragments(r.kept[0][:, :n * 64]), gold[:n]))
     n = min(len(gold) // r.B, nsteps)
     ok = True
     for s in range(n):
@@ -324,8 +435,10 @@ def check_golden(r, nsteps):
     return n, ok
 
 
-def golden_steps(voices, chain, groups, B):
-    path = golden_path(voices, chain, groups)
+def golden_steps(voices, chain, groups, B, tree=0):
+    path = golden_path(voices, chain, groups, tree)
+    if tree:
+        return 1 if os.path.exists(path) else 0
     return len(np.load(path)) // B if os.path.exists(path) else 0
 
 
@@ -333,8 +446,8 @@ def measure_single(audiality2_amd, cfg, B, steps, warmup, device=0, with_realtim
     """One config at N=1: returns the dict of measured figures."""
     import gc
     import torch
-    r = Runner(audiality2_amd, cfg["voices"], cfg["chain"], cfg["groups"], B, device)
-    gsteps = golden_steps(cfg["voices"], cfg["chain"], cfg["groups"], B)
+    r = Runner(audiality2_amd, cfg["voices"], cfg["chain"], cfg["groups"], B, device, tree=cfg.get("tree", 0))
+    gsteps = golden_steps(cfg["voices"], cfg["chain"], cfg["groups"], B, cfg.get("tree", 0))
     r.keep_upto = gsteps
     r.run(1)                        # step 0: voices are born
     r.run(warmup)
@@ -420,6 +533,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] / configs[2] extra keys")
     ap.add_argument("--no-realtime", action="store_true")
+    ap.add_argument("--no-engine", action="store_true", help="skip the engine-in-the-loop (a2_Run) object")
     args = ap.parse_args()
 
     cfg = dict(CONFIGS[args.config])
@@ -428,7 +542,11 @@ def main():
         if getattr(args, k) is not None and getattr(args, k) != cfg[k]:
             cfg[k] = getattr(args, k)
             custom = True
-    if custom:
+    if custom and args.config == 4 and cfg["chain"] == CONFIGS[4]["chain"] and cfg["voices"] % TOP_GROUP_VOICES == 0:
+        ng = cfg["voices"] // TOP_GROUP_VOICES
+        cfg["label"] = (f"{cfg['voices']} voices wtosc->filter12->panmix per GPU: {ng} top-level group voices of 128 "
+                        f"sub-groups x 256 voices" + (" = ALL of BASELINE configs[4] on one GPU" if ng == 8 else ""))
+    elif custom:
         cfg["label"] = (f"{cfg['voices']} voices/GPU, {cfg['chain']}, {cfg['groups']} groups, 48 kHz, fragment=64, "
                         f"stereo (custom; not a BASELINE config)")
 
@@ -505,6 +623,8 @@ def main():
             line["other_configs"] = extra
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg["voices"], cfg["chain"], cfg["groups"])
+        if not args.no_engine and not custom and args.config == 3:
+            line["engine_in_loop"] = engine_in_loop()
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
@@ -521,7 +641,9 @@ def main():
     os.environ.setdefault("MASTER_PORT", "29511")
     dist.init_process_group("nccl", rank=rank, world_size=world,
                             device_id=torch.device("cuda", local_rank))
-    r = Runner(audiality2_amd, cfg["voices"], cfg["chain"], cfg["groups"], B, local_rank, world=world, rank=rank)
+    r = Runner(audiality2_amd, cfg["voices"], cfg["chain"], cfg["groups"], B, local_rank, world=world, rank=rank,
+               tree=cfg.get("tree", 0))
+    r.keep_upto = golden_steps(cfg["voices"] * world, cfg["chain"], cfg["groups"], B, cfg.get("tree", 0)) if cfg.get("tree") else 0
     lib = r.lib
     lib.a2amd_dist_unique_id.argtypes = [ctypes.c_void_p]
     lib.a2amd_dist_init.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
@@ -562,6 +684,9 @@ def main():
     last = r.last
     line = None
     if rank == 0:
+        compared, ok = check_golden(r, 1 + args.warmup + args.steps) if cfg.get("tree") else (0, None)
+        if ok is False:
+            raise SystemExit("bench.py: the ranks' summed render differs from the oracle golden; refusing to report a number")
         value = float(cfg["voices"]) * world * B * 64 * args.steps / dt
         res = {"chain": cfg["chain"], "voices": cfg["voices"], "groups": cfg["groups"],
                "leaf_ms": leaf_ms, "all_ms": all_ms, "launches_timed": nprof}
@@ -580,7 +705,11 @@ def main():
                                        "SUBTREES|ROOT|READBACK|ASYNC); rank 0: a2amd_collect() of the previous "
                                        "step into host buffers"},
             "realtime_factor": value / (cfg["voices"] * world * 48000.0),
-            "parity_vs_golden": None,
+            "parity_vs_golden": ok,
+            "parity": {"golden_fragments_compared": min(B, 64) if compared else 0,
+                       "what": "the first fragments of step 0 of the WHOLE job's audio (all ranks' subtrees summed by "
+                               "the reduce, root chain on rank 0) against the CPU oracle's render of the whole scene"}
+            if cfg.get("tree") else None,
             "roofline": roof, "roofline_valu": valu,
             "output_check": {"peak": int(np.abs(last).max()), "nonzero": bool(last.any())},
         }

@@ -9,7 +9,12 @@
  * thread-safe arrangement (include/audiality2.h.cmake:163-166).
  *
  * usage: ref_bench <script.a2s> <program> <voices> <fragments> <threads>
- * prints: one JSON line {voice_samples_per_s, seconds, voices, fragments, threads, active_voices}
+ * prints: one JSON line {voice_samples_per_s, seconds, voices, fragments, threads, active_voices,
+ *         run_us_p50 / p99 / max (per a2_Run() call of thread 0), buffer_frames}
+ * env:    A2REF_BUFFER=<frames> per a2_Run() call (default 64)
+ *         A2REF_HASH=1   FNV-1a 64 of everything rendered while timed, per state ("hashes")
+ *         A2REF_HASH=<n> (n > 1) ... of the first n 64-frame fragments' worth of frames only, so
+ *                        that a short CPU run and a long drop-in run can be compared
  */
 #include <pthread.h>
 #include <stdio.h>
@@ -28,7 +33,15 @@ typedef struct JOB
 	int		active;
 	int		ok;
 	unsigned long long hash;	/* FNV-1a 64 of everything the state rendered while timed */
+	double		*run_s;		/* seconds per a2_Run() call */
+	int		nruns, buffer;
 } JOB;
+
+static int cmp_double(const void *a, const void *b)
+{
+	double x = *(const double *)a, y = *(const double *)b;
+	return (x > y) - (x < y);
+}
 
 static double now(void)
 {
@@ -49,7 +62,8 @@ static void *run(void *arg)
 	 * a2play's default is 4096); 'fragments' stays a count of 64 frame units */
 	int buffer = getenv("A2REF_BUFFER") ? atoi(getenv("A2REF_BUFFER")) : 64;
 	int nbuf;
-	double t0;
+	long hash_frames = 0, hashed = 0;
+	double t0, t1;
 	if(!(drv = a2_NewDriver(A2_AUDIODRIVER, "buffer")))
 		return NULL;
 	if(buffer < 64)
@@ -78,23 +92,38 @@ static void *run(void *arg)
 			a2_Run(i, buffer);
 	}
 	j->hash = 0xcbf29ce484222325ULL;
-	t0 = now();
 	nbuf = (j->fragments * 64 + buffer - 1) / buffer;
 	j->fragments = nbuf * (buffer / 64);
+	j->run_s = calloc(nbuf, sizeof(double));
+	j->nruns = nbuf;
+	j->buffer = buffer;
+	if(getenv("A2REF_HASH"))
+	{
+		long n = atol(getenv("A2REF_HASH"));
+		hash_frames = n > 1 ? n * 64 : (long)nbuf * buffer;
+	}
+	t0 = t1 = now();
 	for(f = 0; f < nbuf; ++f)
 	{
+		double t2;
 		a2_Run(i, buffer);
-		if(getenv("A2REF_HASH"))	/* correctness runs only: costs time */
+		if(hashed < hash_frames)
 		{
-			int c;
+			/* per 64-frame fragment, channel 0 then channel 1: the same value whatever the buffer */
+			int c, o;
 			unsigned k;
-			for(c = 0; c < 2; ++c)
-			{
-				const unsigned char *b = (const unsigned char *)((A2_audiodriver *)drv)->buffers[c];
-				for(k = 0; k < (unsigned)buffer * 4; ++k)
-					j->hash = (j->hash ^ b[k]) * 0x100000001b3ULL;
-			}
+			for(o = 0; o < buffer && hashed < hash_frames; o += 64, hashed += 64)
+				for(c = 0; c < 2; ++c)
+				{
+					const unsigned char *b = (const unsigned char *)
+							(((A2_audiodriver *)drv)->buffers[c] + o);
+					for(k = 0; k < 64 * 4; ++k)
+						j->hash = (j->hash ^ b[k]) * 0x100000001b3ULL;
+				}
 		}
+		t2 = now();
+		j->run_s[f] = t2 - t1;
+		t1 = t2;
 	}
 	j->seconds = now() - t0;
 	a2_GetStateProperty(i, A2_PACTIVEVOICES, &av);
@@ -147,6 +176,11 @@ int main(int argc, const char *argv[])
 			"\"fragments\": %d, \"threads\": %d, \"active_voices\": %d",
 			(double)(voices / threads) * threads * 64.0 * jobs[0].fragments / worst,
 			worst, (voices / threads) * threads, jobs[0].fragments, threads, active);
+	qsort(jobs[0].run_s, jobs[0].nruns, sizeof(double), cmp_double);
+	printf(", \"buffer_frames\": %d, \"run_us_p50\": %.1f, \"run_us_p99\": %.1f, \"run_us_max\": %.1f",
+			jobs[0].buffer, jobs[0].run_s[jobs[0].nruns / 2] * 1e6,
+			jobs[0].run_s[(int)((jobs[0].nruns - 1) * 0.99)] * 1e6,
+			jobs[0].run_s[jobs[0].nruns - 1] * 1e6);
 	if(getenv("A2REF_HASH"))
 	{
 		printf(", \"hashes\": [");

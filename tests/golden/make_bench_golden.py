@@ -6,7 +6,10 @@ configs[2] 16 384 x wtosc->filter12->panmix, configs[3] 65 536 x 2xwtosc->panmix
 under 256 inline->fbdelay->fbdelay groups with fmtest4's delay settings),
 rendered by the CPU oracle from the scene bench.py builds (bench.build_scene).
 
-  python tests/golden/make_bench_golden.py [1 2 3]      (configs[3]: ~5 min of one core)
+  python tests/golden/make_bench_golden.py [1 2 3 4]    (configs[3]: ~5 min of one core)
+
+configs[4] (4): 64 fragments of the whole job's audio for 1, 2, 4 and 8 top-level groups of
+128 sub-groups x 256 wtosc->filter12->panmix voices (32 768 ... 262 144 voices).
 
 bench.py and tests/test_gpu_parity.py only read the resulting data files;
 tests/test_oracle_cpu.py re-renders the head of each with the oracle.  8 steps =
@@ -27,7 +30,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 STEPS, B = 8, 256
 
 
-def render(voices, chain, groups, fragments, progress=False):
+CFG4_FRAGMENTS = 64      # configs[4]: 262 144 voices; 64 fragments are ~25 s of oracle time
+CFG4_TOTALS = (32768, 65536, 131072, 262144)     # the whole job at 1, 2, 4, 8 GPUs (bench.py --config 4)
+
+
+def render(voices, chain, groups, fragments, progress=False, tree=0):
     """int32 [2, fragments * 64] from the oracle, for bench.py's scene."""
     import bench
     from audiality2_amd import synth
@@ -35,7 +42,7 @@ def render(voices, chain, groups, fragments, progress=False):
     lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liba2oracle.so"))
     lib.a2o_fragment_repeat.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
     be = Backend(lib, "a2o_", 48000, synth.basepitch_for(48000), 2, max_batch=64)
-    sc = bench.build_scene(be, voices, chain, groups)
+    sc = bench.build_scene(be, voices, chain, groups, tree=tree)
     outs = []
     sc.walk(64)
     done, pending = 0, 1
@@ -58,7 +65,18 @@ def render(voices, chain, groups, fragments, progress=False):
 if __name__ == "__main__":
     import bench
     from conftest import fnv1a_fragments
-    which = [int(a) for a in sys.argv[1:]] or [1, 2, 3]
+    which = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
+    if 4 in which:
+        # BASELINE configs[4]: top-level groups of 128 sub-groups x 256
+        # wtosc->filter12->panmix voices, one per GPU; the whole job's audio at 1, 2, 4 and 8 GPUs
+        which.remove(4)
+        cfg = bench.CONFIGS[4]
+        for total in CFG4_TOTALS:
+            pcm = render(total, cfg["chain"], 0, CFG4_FRAGMENTS, progress=True, tree=cfg["tree"])
+            path = bench.golden_path(total, cfg["chain"], 0, cfg["tree"])
+            np.save(path, fnv1a_fragments(pcm))
+            np.save(path.replace(".hash.npy", ".head.npy"), pcm[:, :256])
+            print("written", path, "peak", int(np.abs(pcm).max()))
     for i in which:
         cfg = bench.CONFIGS[i]
         pcm = render(cfg["voices"], cfg["chain"], cfg["groups"], STEPS * B, progress=True)

@@ -1046,3 +1046,84 @@ def test_render_group_of_two_contexts_equals_one_context():
     b.close()
     got = np.concatenate(outs, axis=1)
     assert want.any() and first_diff(got, want) is None
+
+
+# ---------------------------------------------------------------------------
+# round 3: BASELINE configs[4] - 8 top-level groups (a2_NewGroup,
+# src/interface.c:888) x 128 sub-groups x 256 wtosc->filter12->panmix voices = 262 144
+# voices, group g -> GPU g, ONE reduce of the root voice's inline bus per buffer
+# ---------------------------------------------------------------------------
+def _cfg4_group(contexts, devices=None, fragments=64):
+    """The whole configs[4] scene dealt over `contexts` contexts (top-level group g on
+    context g * contexts // 8) through a2amd_dist_init_local / a2amd_render_group;
+    returns the per-fragment hashes of the audio context 0 delivers."""
+    import ctypes as C
+    import audiality2_amd
+    import bench
+    cfg = bench.CONFIGS[4]
+    total, per = 262144, 262144 // contexts
+    bes = [audiality2_amd.open_backend(48000, None, 2, device=(devices[i] if devices else 0), max_batch=fragments)
+           for i in range(contexts)]
+    lib = bes[0].lib
+    lib.a2amd_dist_init_local.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.a2amd_render_group.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_uint, C.POINTER(C.POINTER(C.c_int32)), C.c_uint]
+    lib.a2amd_fragment_repeat.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
+    ctxs = (C.c_void_p * contexts)(*[be.ctx for be in bes])
+    if contexts > 1:
+        assert lib.a2amd_dist_init_local(ctxs, contexts) == 0, bes[0]._err(bes[0].ctx)
+    for i, be in enumerate(bes):
+        # rank i of `contexts`: its voices are numbered from i * per, amplitudes follow the whole job's size
+        sc = bench.build_scene(be, per, cfg["chain"], 0, world=contexts, rank=i, tree=cfg["tree"])
+        sc.walk(64)
+        assert lib.a2amd_fragment_repeat(be.ctx, 64, fragments - 1) == 0, be._err(be.ctx)
+    out = np.zeros((2, fragments * 64), dtype=np.int32)
+    p = (C.POINTER(C.c_int32) * 2)()
+    for c in range(2):
+        p[c] = out[c].ctypes.data_as(C.POINTER(C.c_int32))
+    assert lib.a2amd_render_group(ctxs, contexts, 15, p, fragments * 64) == fragments * 64, bes[0]._err(bes[0].ctx)
+    for be in bes:
+        be.close()
+    return fnv1a_fragments(out)
+
+
+def _cfg4_golden():
+    import bench
+    cfg = bench.CONFIGS[4]
+    return np.load(bench.golden_path(262144, cfg["chain"], 0, cfg["tree"]))
+
+
+@pytest.mark.parametrize("contexts", [1, 8])
+def test_config4_full_size_matches_oracle_golden(contexts):
+    """All 262 144 voices of configs[4] on this box's GPU: in ONE context, and as the
+    8-GPU job lays it out - one context per top-level group, each with its own copy of
+    the root voice, the eight root-bus partials summed, the root chain on context 0
+    (a2amd_render_group; on one GPU the sum is the device-local add) - against the 64
+    fragments the CPU oracle rendered of the whole scene (make_bench_golden.py 4)."""
+    want = _cfg4_golden()
+    got = _cfg4_group(contexts, fragments=len(want))
+    bad = np.nonzero(got != want)[0]
+    assert not len(bad), f"configs[4] over {contexts} context(s): {len(bad)} fragments differ, first {bad[:8]}"
+
+
+def _cfg4_rccl(n):
+    """(body of the test below, in a process of its own: see test_dist_render_with_one_rank...)"""
+    want = _cfg4_golden()
+    got = _cfg4_group(n, devices=list(range(n)), fragments=len(want))
+    bad = np.nonzero(got != want)[0]
+    assert not len(bad), f"configs[4] over {n} GPUs: {len(bad)} fragments differ, first {bad[:8]}"
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_config4_over_distinct_gpus_matches_oracle_golden(n):
+    """The same with the contexts on DISTINCT GPUs: ncclCommInitAll + one grouped
+    ncclReduce(int32, sum) of the root bus over xGMI inside a2amd_render_group.  Needs
+    n visible GPUs (the single-GPU test box skips; an 8-GPU node runs all three)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < n:
+        pytest.skip(f"{torch.cuda.device_count()} GPU(s) visible, {n} needed")
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path[:0] = [%r, %r]; import test_gpu_parity as t; "
+                        "t._cfg4_rccl(%d)" % (os.path.dirname(os.path.abspath(__file__)), ROOT, n)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]

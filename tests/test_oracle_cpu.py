@@ -131,6 +131,13 @@ def test_bench_parity_golden_matches_oracle(oracle_lib):
         assert len(want) == mbg.STEPS * mbg.B
         got = fnv1a_fragments(mbg.render(cfg["voices"], cfg["chain"], cfg["groups"], nfr))
         assert np.array_equal(got, want[:nfr]), f"configs[{i}]"
+    # configs[4]: the whole job's audio with 1 and 2 top-level groups (32 768 / 65 536 voices)
+    cfg = bench.CONFIGS[4]
+    for total, nfr in ((32768, 8), (65536, 3)):
+        want = np.load(bench.golden_path(total, cfg["chain"], 0, cfg["tree"]))
+        assert len(want) == mbg.CFG4_FRAGMENTS
+        got = fnv1a_fragments(mbg.render(total, cfg["chain"], 0, nfr, tree=cfg["tree"]))
+        assert np.array_equal(got, want[:nfr]), f"configs[4] with {total} voices"
 
 
 def test_oracle_xinsert_clients(oracle_lib):
