@@ -20,7 +20,7 @@ def build_lib(force=False):
     srcs = [os.path.join(csrc, "a2amd_host.cpp"), os.path.join(csrc, "a2amd_kernels.hip"),
             os.path.join(csrc, "a2amd_fast.hip")]
     deps = srcs + [os.path.join(csrc, "a2amd_device.h"), os.path.join(csrc, "a2amd_dsp.h"),
-                   os.path.join(ROOT, "include", "a2amd.h")]
+                   os.path.join(csrc, "a2amd_fm.h"), os.path.join(ROOT, "include", "a2amd.h")]
     out = os.path.join(HERE, "liba2amd.so")
     if force or _newer(out, deps):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -32,7 +32,8 @@ def build_lib(force=False):
 def build_units(force=False):
     """The drop-in unit descriptors (plain C) on top of liba2amd.so."""
     src = os.path.join(HERE, "csrc", "a2amd_units.c")
-    deps = [src, os.path.join(ROOT, "include", "a2amd.h"), os.path.join(ROOT, "include", "a2amd_plugin.h")]
+    deps = [src, os.path.join(ROOT, "include", "a2amd.h"), os.path.join(ROOT, "include", "a2amd_plugin.h"),
+            os.path.join(ROOT, "include", "a2amd_walk.h")]
     out = os.path.join(HERE, "liba2amd_units.so")
     if force or _newer(out, deps):
         subprocess.run(["gcc", "-O2", "-Wall", "-fPIC", "-shared", "-o", out, src,
@@ -46,7 +47,7 @@ def build_oracle(force=False):
     odir = os.path.join(ROOT, "oracle")
     targets = ["restate"]
     if os.path.exists("/root/reference/src/core.c") and shutil.which("cmake"):
-        targets += ["ref", "tools", "optionb"]    # (optionb links the drop-in built just before)
+        targets += ["ref", "tools", "optionb", "optionc"]    # (optionb / optionc link the drop-in built just before)
     subprocess.run(["make", "-s", "-C", odir] + (["-B"] if force else []) + targets, check=True)
     return os.path.join(odir, "liba2oracle.so")
 

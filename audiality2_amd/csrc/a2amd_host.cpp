@@ -2719,6 +2719,28 @@ struct TimingDump { ~TimingDump() { if(getenv("A2AMD_HOSTTIMING") && g_n) fprint
 namespace { double *dbg_counters() { return g_cnt; } }
 static int dist_reduce_root(a2amd_ctx *c);
 
+// What the READ clients of a context's x-units are to be handed: the tapped windows of the
+// batch, device -> host (a2amd_unit_tapped reads them).  final: the batch is complete - a
+// slot stays tapped into the next batch only while its unit still has READ clients.
+static int fetch_taps(a2amd_ctx *c, bool final)
+{
+	bool any = false;
+	for(size_t k = 0; k < c->xio.size(); ++k) {
+		XioSlot &x = c->xio[k];
+		if(x.unit >= 0 && x.tapped) {
+			if(final)
+				x.tapped = (c->units[x.unit].xio_mode & A2AMD_XIO_TAP) != 0;
+			HIPCHK(c, hipMemcpyAsync(x.tap.data(), c->d_xio.d + k * A2D_XIO_SLOT,
+					(size_t)c->nfrags * A2AMD_MAXCHANNELS * A2D_FRAG * sizeof(int32_t),
+					hipMemcpyDeviceToHost, c->stream));
+			any = true;
+		}
+	}
+	if(any)
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+	return 0;
+}
+
 int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned cap)
 {
 	use_device(c);
@@ -2839,17 +2861,10 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		if(int r = run_phases(kphases))
 			return r;
 	}
-	if((phases & A2AMD_RENDER_TAPS) && !(phases & A2AMD_RENDER_READBACK)) {
+	if((phases & A2AMD_RENDER_TAPS) && !(phases & A2AMD_RENDER_READBACK))
 		// the seam for insert clients: the batch's taps so far, on the host
-		for(size_t k = 0; k < c->xio.size(); ++k) {
-			XioSlot &x = c->xio[k];
-			if(x.unit >= 0 && x.tapped)
-				HIPCHK(c, hipMemcpyAsync(x.tap.data(), c->d_xio.d + k * A2D_XIO_SLOT,
-						(size_t)c->nfrags * A2AMD_MAXCHANNELS * A2D_FRAG * sizeof(int32_t),
-						hipMemcpyDeviceToHost, c->stream));
-		}
-		HIPCHK(c, hipStreamSynchronize(c->stream));
-	}
+		if(int r = fetch_taps(c, false))
+			return r;
 	double t2 = timing ? now_us() : 0;
 	if(timing) {
 		g_t[1] += t2 - t1;
@@ -3189,6 +3204,13 @@ int a2amd_render_group(a2amd_ctx *const *ctxs, int n, unsigned phases, int32_t *
 	int r = a2amd_render(c0, (phases & (A2AMD_RENDER_ROOT | A2AMD_RENDER_READBACK | A2AMD_RENDER_ASYNC)) | keep, out, cap);
 	if(r < 0)
 		return r;
+	// sink clients on voices of the other contexts: their taps come back with the audio
+	if((phases & A2AMD_RENDER_READBACK) && !(phases & A2AMD_RENDER_ASYNC))
+		for(int i = 1; i < n; ++i) {
+			use_device(ctxs[i]);
+			if(int r2 = fetch_taps(ctxs[i], true))
+				return c0->fail(r2, "%s", ctxs[i]->err);
+		}
 	if(!keep && (phases & (A2AMD_RENDER_READBACK | A2AMD_RENDER_ROOT)))
 		for(int i = 1; i < n; ++i) {
 			use_device(ctxs[i]);

@@ -100,6 +100,13 @@ typedef struct HOSTSTATE
 	int		noise_oscs;	/* oscillators playing the noise wave: their voices need the engine's RNG */
 	int		ninserts;	/* pending windows of insert clients in the batch being recorded */
 	int		no_quick;	/* A2AMD_NO_QUICK=1: every Process call is forwarded (A/B measurements) */
+	/* a2amd_walkview (INTEGRATION.md option C): which voices report their default windows
+	 * through the map right now, as a stamp per (context, slot) */
+	uint32_t	*qstamp[MAXDEV];
+	unsigned	qstamp_cap[MAXDEV];
+	uint32_t	stamp_ctr;
+	int		walker;		/* liba2amd_walk.so walks this state: no prefetch hints of our own */
+	unsigned	serial;		/* a number of its own for every engine state ever opened (a2amd_walkview) */
 	/* the last WALK_AHEAD chain heads the engine called, oldest first from walk_pos
 	 * (look_ahead()); emptied whenever a unit goes away */
 	struct XTRA	*walk_ring[WALK_AHEAD];
@@ -173,7 +180,19 @@ typedef struct XTRA
 	void		(*orig_setprocess)(A2P_unit *u);	/* root xinsert: the engine's xi_SetProcess */
 } XTRA;
 
+_Static_assert(MAXDEV == A2AMD_WALK_MAXDEV, "a2amd_walkview");
 _Static_assert(sizeof(A2P_unit) <= 64 && 64 + sizeof(XTRA) <= A2P_BLOCK_SIZE && offsetof(XTRA, head) == 64, "XTRA placement");
+
+/* the voice of head unit 'x' starts (on) / stops reporting its default windows through the map */
+static inline void set_stamp(HOSTSTATE *hs, XTRA *x, int on)
+{
+	if((unsigned)x->slot < hs->qstamp_cap[x->dev])
+	{
+		if(on && !++hs->stamp_ctr)
+			hs->stamp_ctr = 1;
+		hs->qstamp[x->dev][x->slot] = on ? hs->stamp_ctr : 0;
+	}
+}
 
 static inline XTRA *xtra(A2P_unit *u)
 {
@@ -250,9 +269,13 @@ static int amd_open(A2P_config *cfg, void **statedata)
 		rc = A2P_OOMEMORY;
 	else
 	{
+		static unsigned serials;
 		memset(&states[f], 0, sizeof(HOSTSTATE));
 		states[f].cfg = cfg;
 		states[f].refs = 1;
+		if(!++serials)
+			++serials;
+		states[f].serial = serials;
 		*statedata = &states[f];
 	}
 	pthread_mutex_unlock(&states_mtx);
@@ -279,6 +302,8 @@ static void amd_close(void *statedata)
 		free(hs->wave_id);
 		free(hs->pend);
 		free(hs->zombies);
+		for(c = 0; c < MAXDEV; ++c)
+			free(hs->qstamp[c]);
 		for(c = 0; c < A2AMD_MAXCHANNELS; ++c)
 		{
 			free(hs->acc[c]);
@@ -520,6 +545,8 @@ static void amd_deinit(A2P_unit *u)
 		return;
 	if(x->hs->chain_last == u)
 		x->hs->chain_last = NULL;
+	if(x->head == u)
+		set_stamp(x->hs, x, 0);		/* (head of a chain of our own: its slot goes back to the backend) */
 	x->hs->noise_oscs -= x->is_noise;
 	x->is_noise = 0;
 	if(x->pending)
@@ -1140,7 +1167,7 @@ static void amd_quick_process(A2P_unit *u, unsigned offset, unsigned frames)
 {
 	XTRA *x = (XTRA *)((char *)u + 64);	/* (own units only: no descriptor look-up) */
 	HOSTSTATE *hs = x->hs;
-	if(hs->walk_ahead)
+	if(hs->walk_ahead && !hs->walker)
 		look_ahead(hs, x, u);
 	if(offset == hs->base && frames == hs->win_frames && (unsigned)x->slot < hs->map_cap[x->dev])
 	{
@@ -1148,6 +1175,7 @@ static void amd_quick_process(A2P_unit *u, unsigned offset, unsigned frames)
 		return;
 	}
 	u->Process = amd_head_process;
+	set_stamp(hs, x, 0);
 	head_process(u, x, hs, offset, frames);
 }
 
@@ -1155,7 +1183,7 @@ static void amd_head_process(A2P_unit *u, unsigned offset, unsigned frames)
 {
 	XTRA *x = (XTRA *)((char *)u + 64);
 	HOSTSTATE *hs = x->hs;
-	if(hs->walk_ahead)
+	if(hs->walk_ahead && !hs->walker)
 		look_ahead(hs, x, u);
 	head_process(u, x, hs, offset, frames);
 }
@@ -1177,7 +1205,10 @@ static void head_process(A2P_unit *u, XTRA *x, HOSTSTATE *hs, unsigned offset, u
 	if(rc < 0)
 		fail(hs, "a2amd_voice_process", rc);
 	else if(rc == 1 && !hs->no_quick)
+	{
 		u->Process = amd_quick_process;
+		set_stamp(hs, x, 1);
+	}
 	if(noise != before)
 		a2_SetStateProperty(hs->cfg->interface, A2P_PNOISESEED, (int)noise);
 }
@@ -1205,6 +1236,20 @@ static int setup_simple_chain(A2P_unit *u)
 	if((slot = a2amd_voice_slot(XCTX(x), x->uid)) < 0)
 		return 0;
 	x->slot = slot;
+	if((unsigned)slot >= x->hs->qstamp_cap[x->dev])
+	{
+		unsigned nc = x->hs->qstamp_cap[x->dev] ? x->hs->qstamp_cap[x->dev] : 1024;
+		uint32_t *nq;
+		while(nc <= (unsigned)slot)
+			nc *= 2;
+		if((nq = (uint32_t *)realloc(x->hs->qstamp[x->dev], nc * sizeof(uint32_t))))
+		{
+			memset(nq + x->hs->qstamp_cap[x->dev], 0, (nc - x->hs->qstamp_cap[x->dev]) * sizeof(uint32_t));
+			x->hs->qstamp[x->dev] = nq;
+			x->hs->qstamp_cap[x->dev] = nc;
+		}	/* (else: no stamps for this voice - the walk keeps visiting it) */
+	}
+	set_stamp(x->hs, x, 0);
 	x->tail[0] = u->next;
 	x->tail[1] = u->next ? u->next->next : NULL;
 	for(n = u; n; n = n->next)
@@ -1497,7 +1542,10 @@ static void amd_write(A2P_unit *u, int reg, int v, unsigned start, unsigned dur)
 	}
 	/* (a voice that was reporting its default windows through the map calls in again) */
 	if(x->head && x->head->Process == amd_quick_process)
+	{
 		x->head->Process = amd_head_process;
+		set_stamp(x->hs, (XTRA *)((char *)x->head + 64), 0);
+	}
 	if(x->hs->failed)
 		return;
 	if((rc = a2amd_unit_write(XCTX(x), x->uid, reg, v, start, dur, x->vms->r[A2P_R_TRANSPOSE])))
@@ -1801,3 +1849,43 @@ const A2P_unitdesc a2_xsink_unitdesc = { "xsink", A2P_XINSERT, NULL, NULL, NULL,
 	1, A2AMD_MAXCHANNELS, 0, 0, A2P_BLOCK_SIZE, xsink_init, xsink_deinit, xsink_open, xsink_close };
 const A2P_unitdesc a2_xsource_unitdesc = { "xsource", A2P_XINSERT, NULL, NULL, NULL,
 	0, 0, 1, A2AMD_MAXCHANNELS, A2P_BLOCK_SIZE, xsource_init, xsource_deinit, xsource_open, xsource_close };
+
+
+/* ---- INTEGRATION.md option C: what liba2amd_walk.so (a2amd_walk.c) asks of the units --------*/
+int a2amd_units_walkview(const void *cfg, a2amd_walkview *out)
+{
+	int i, rc = -1;
+	pthread_mutex_lock(&states_mtx);
+	for(i = 0; i < MAXSTATES; ++i)
+		if(states[i].refs && states[i].cfg == cfg)
+		{
+			HOSTSTATE *hs = &states[i];
+			out->cfg = cfg;
+			out->map = hs->map;
+			out->map_cap = hs->map_cap;
+			out->base = &hs->base;
+			out->win_frames = &hs->win_frames;
+			out->qstamp = hs->qstamp;
+			out->qstamp_cap = hs->qstamp_cap;
+			out->walker = &hs->walker;
+			out->serial = &hs->serial;
+			out->serial_value = hs->serial;
+			rc = 0;
+			break;
+		}
+	pthread_mutex_unlock(&states_mtx);
+	return rc;
+}
+
+uint32_t a2amd_units_standing(const void *head_unit, uint32_t *slotdev)
+{
+	const A2P_unit *head = (const A2P_unit *)head_unit;
+	const XTRA *x;
+	if(!head || head->Process != amd_quick_process)
+		return 0;
+	x = (const XTRA *)((const char *)head + 64);
+	if((unsigned)x->slot >= x->hs->qstamp_cap[x->dev] || (unsigned)x->slot >= (1u << 28))
+		return 0;
+	*slotdev = (uint32_t)x->slot | ((uint32_t)x->dev << 28);
+	return x->hs->qstamp[x->dev][x->slot];
+}

@@ -1,0 +1,279 @@
+/*
+ * a2amd_walk.c - INTEGRATION.md option C: Audiality 2's voice walk with a short cut for
+ * sleeping voices.  Builds into liba2amd_walk.so, loaded in front of libaudiality2 together
+ * with the drop-in units (LD_PRELOAD="liba2amd_walk.so liba2amd_units.so", or link order).
+ *
+ * What it replaces: a2_ProcessVoices (src/core.c:1883-1896), the loop over a list of sibling
+ * voices that a2_AudioCallback (core.c:1968) and the inline unit (a2_ProcessSubvoices,
+ * core.c:1749-1759) call once per window.  The engine's loop visits EVERY voice in EVERY
+ * fragment: a2_VoiceProcess (core.c:1847-1880) asks the VM / event queue how long the voice
+ * sleeps and calls Process on each of its units.  For a voice whose VM sleeps through the
+ * window, whose event queue is empty and whose units are all the drop-in's, that visit has
+ * exactly one effect - "this voice got the default window" - which the drop-in units record as
+ * one byte store (a2amd_default_map, include/a2amd.h).  With tens of thousands of voices the
+ * visit itself (the 1 424 byte A2_voice, its unit blocks: DRAM latency on a pointer chase) is
+ * what one engine thread spends its time on (SURVEY.md 8e caveat 2: 1.7 ms per fragment for
+ * 65 536 idle voices, 8 ms for 262 144).
+ *
+ * What it does instead: per list of siblings it remembers, position by position, which voice
+ * stood there in the last walk and where its byte in the default map is.  A voice that still
+ * stands there, has no events and does not wake before the window ends (the engine's own
+ * test, a2_VoiceProcessVMEv, core.c:1816-1823, on the engine's own fields) gets the byte
+ * store right here - one cache line of the A2_voice read, prefetched a few positions ahead
+ * from the remembered pointers - and nothing else.  Every other voice is handed, alone, to the
+ * ENGINE'S OWN a2_ProcessVoices (found with dlsym(RTLD_NEXT)): VM, events, unit calls, voice
+ * death are the engine's code, not a copy of it.  The audio is bit-identical by construction:
+ * the short cut stores the byte the unit's own Process would have stored.
+ *
+ * This is the wake-queue idea of SURVEY.md 8e (ii) / 8f-4 in the form that needs no hook on
+ * the engine's event sends: the test reads A2_voice.events and A2_vmstate.waketime directly.
+ *
+ * Compiled against the engine's INTERNAL headers (src/internals.h: A2_voice, A2_state), which
+ * is why it is a separate library with its own recipe (oracle/Makefile, target optionc): it is
+ * locked to the engine version it was built for, and the compiler checks every field it
+ * touches.  The engine binary itself is unmodified; all it has to be is what a default -fPIC
+ * build is - a library that calls its own a2_ProcessVoices through the PLT.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "internals.h"			/* the engine's: A2_state, A2_voice (src/internals.h:559-586, :600-700) */
+#include "../../include/a2amd_walk.h"	/* a2amd_walkview */
+
+#define AHEAD		12		/* positions the prefetch runs ahead */
+#define STAMP_NOUNITS	0xffffffffu	/* a voice without units and without subvoices: nothing to do while it sleeps */
+
+typedef struct ENT
+{
+	A2_voice	*v;		/* the voice that stood at this position of the list in the last walk */
+	uint32_t	slotdev;	/* its byte in the default map: slot (bits 0..27), context (28..31) */
+	uint32_t	stamp;		/* a2amd_units_standing() when it was last visited; 0 = always visit */
+} ENT;
+
+typedef struct LIST
+{
+	A2_voice	**head;		/* the list: &parent->sub (key) */
+	ENT		*e;
+	unsigned	n, cap;
+} LIST;
+
+typedef struct WSTATE
+{
+	A2_state	*st;
+	a2amd_walkview	view;
+	int		served;		/* the drop-in serves this state */
+	LIST		*lists;		/* open addressing on 'head' */
+	unsigned	nlists, cap_lists;
+	unsigned long long skipped, visited;
+} WSTATE;
+
+static void (*engine_walk)(A2_state *st, A2_voice **head, unsigned offset, unsigned frames);
+static WSTATE *wstates[256];
+static pthread_mutex_t wmtx = PTHREAD_MUTEX_INITIALIZER;
+static __thread WSTATE *last_ws;
+static int walk_off = -1, walk_stats, walk_cut;
+
+static WSTATE *wstate_of(A2_state *st)
+{
+	WSTATE *w = last_ws;
+	int i, f = -1;
+	if(w && w->st == st && w->view.cfg == st->config && (!w->served || *w->view.serial == w->view.serial_value))
+		return w;
+	pthread_mutex_lock(&wmtx);
+	for(i = 0; i < 256; ++i)
+		if(wstates[i] && wstates[i]->st == st)
+			break;
+		else if(!wstates[i] && f < 0)
+			f = i;
+	if(i < 256)
+		w = wstates[i];
+	else if(f >= 0 && (w = (WSTATE *)calloc(1, sizeof(WSTATE))))
+	{
+		w->st = st;
+		wstates[f] = w;
+	}
+	else
+		w = NULL;
+	pthread_mutex_unlock(&wmtx);
+	if(w && (w->view.cfg != st->config || (w->served && *w->view.serial != w->view.serial_value)))
+	{
+		/* a new engine state (at the address of a closed one, possibly): forget everything */
+		unsigned k;
+		for(k = 0; k < w->cap_lists; ++k)
+			free(w->lists[k].e);
+		free(w->lists);
+		w->lists = NULL;
+		w->nlists = w->cap_lists = 0;
+		w->served = a2amd_units_walkview(st->config, &w->view) == 0;
+		if(!w->served)
+			w->view.cfg = st->config;
+		else
+			*w->view.walker = 1;
+	}
+	last_ws = w;
+	return w;
+}
+
+static LIST *list_of(WSTATE *w, A2_voice **head)
+{
+	unsigned k, mask;
+	if(w->nlists * 2 >= w->cap_lists)
+	{
+		unsigned nc = w->cap_lists ? w->cap_lists * 2 : 64, j;
+		LIST *nl = (LIST *)calloc(nc, sizeof(LIST));
+		if(!nl)
+			return NULL;
+		for(j = 0; j < w->cap_lists; ++j)
+			if(w->lists[j].head)
+			{
+				k = (unsigned)(((uintptr_t)w->lists[j].head >> 4) * 2654435761u) & (nc - 1);
+				while(nl[k].head)
+					k = (k + 1) & (nc - 1);
+				nl[k] = w->lists[j];
+			}
+		free(w->lists);
+		w->lists = nl;
+		w->cap_lists = nc;
+	}
+	mask = w->cap_lists - 1;
+	k = (unsigned)(((uintptr_t)head >> 4) * 2654435761u) & mask;
+	while(w->lists[k].head && w->lists[k].head != head)
+		k = (k + 1) & mask;
+	if(!w->lists[k].head)
+	{
+		w->lists[k].head = head;
+		++w->nlists;
+	}
+	return &w->lists[k];
+}
+
+static void report(void)
+{
+	int i;
+	for(i = 0; i < 256; ++i)
+		if(wstates[i] && (wstates[i]->skipped || wstates[i]->visited))
+			fprintf(stderr, "a2amd walk: state %p: %llu voice visits skipped, %llu made\n",
+					(void *)wstates[i]->st, wstates[i]->skipped, wstates[i]->visited);
+}
+
+static void bind_engine(void)
+{
+	*(void **)&engine_walk = dlsym(RTLD_NEXT, "a2_ProcessVoices");
+	if(!engine_walk)
+		fprintf(stderr, "a2amd walk: no a2_ProcessVoices behind this one - load liba2amd_walk.so IN FRONT of "
+				"libaudiality2\n");
+	walk_off = getenv("A2AMD_WALK_OFF") != NULL;	/* A/B: every voice is handed to the engine's loop */
+	/* test hook: voices are handed to the engine's loop one by one even in a state the drop-in
+	 * does not serve (the engine's own CPU units): exercises the cut / relink / voice death
+	 * logic without a GPU; no visit is ever skipped there */
+	walk_cut = getenv("A2AMD_WALK_CUT") != NULL;
+	if((walk_stats = getenv("A2AMD_WALK_STATS") != NULL))
+		atexit(report);
+}
+
+/* The replacement.  Same contract as the engine's (internals.h:968-973). */
+void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned frames)
+{
+	WSTATE *w;
+	LIST *l;
+	const a2amd_walkview *vw;
+	unsigned k = 0, now;
+	int deflt;
+	if(walk_off < 0)
+		bind_engine();
+	if(!engine_walk)
+		return;		/* (reported once; the state renders silence) */
+	if(!*head)
+		return;
+	/* a lone voice (the root voice, a group with one child): nothing to remember */
+	if(walk_off || !(*head)->next || !(w = wstate_of(st)) || !(w->served || walk_cut) || !(l = list_of(w, head)))
+	{
+		engine_walk(st, head, offset, frames);
+		return;
+	}
+	vw = &w->view;
+	/* only the open root window - one backend fragment - can be reported through the map
+	 * (amd_quick_process, a2amd_units.c, makes the same test) */
+	deflt = w->served && offset == *vw->base && frames == *vw->win_frames;
+	now = st->now_fragstart + (offset << 8);	/* a2_VoiceProcess, core.c:1856 */
+	while(*head)
+	{
+		A2_voice *v = *head, *next, *one;
+		if(k < l->n)
+		{
+			ENT *e = &l->e[k];
+			if(k + AHEAD < l->n)
+				__builtin_prefetch(l->e[k + AHEAD].v);	/* (a hint: never dereferenced here) */
+			/* asleep for the whole window?  a2_VoiceProcessVMEv (core.c:1816-1823) with an empty
+			 * event queue returns (waketime - now) >> 8 frames; a2_VoiceProcess then makes ONE
+			 * Process call per unit for the window if that is at least its length */
+			if(w->served && e->v == v && e->stamp && !v->events &&
+					(a2_TSDiff(v->s.waketime, now) >> 8) >= (int)frames)
+			{
+				if(e->stamp == STAMP_NOUNITS)
+				{
+					head = &v->next;
+					++k;
+					++w->skipped;
+					continue;
+				}
+				if(deflt)
+				{
+					const unsigned dev = e->slotdev >> 28, slot = e->slotdev & 0x0fffffffu;
+					if(slot < vw->map_cap[dev] && slot < vw->qstamp_cap[dev] &&
+							vw->qstamp[dev][slot] == e->stamp)
+					{
+						vw->map[dev][slot] = 1;		/* = amd_quick_process() */
+						head = &v->next;
+						++k;
+						++w->skipped;
+						continue;
+					}
+				}
+			}
+		}
+		/* everything else is the engine's business: its own loop, on this voice alone */
+		next = v->next;
+		one = v;
+		v->next = NULL;
+		engine_walk(st, &one, offset, frames);
+		++w->visited;
+		if(!one)
+		{
+			*head = next;		/* the voice ended and was freed (a2_VoiceFree, core.c:1892) */
+			continue;
+		}
+		v->next = next;
+		/* what to do with it while it sleeps */
+		if(k >= l->cap)
+		{
+			unsigned nc = l->cap ? l->cap * 2 : 16;
+			ENT *ne = (ENT *)realloc(l->e, nc * sizeof(ENT));
+			if(ne)
+			{
+				l->e = ne;
+				l->cap = nc;
+			}
+		}
+		if(k < l->cap)
+		{
+			ENT *e = &l->e[k];
+			if(k >= l->n)
+				l->n = k + 1;
+			e->v = v;
+			e->slotdev = 0;
+			if(v->sub)
+				e->stamp = 0;		/* its subvoices need the walk (core.c:1888-1889) */
+			else if(!v->units)
+				e->stamp = STAMP_NOUNITS;
+			else
+				e->stamp = w->served ? a2amd_units_standing(v->units, &e->slotdev) : 0;
+		}
+		head = &v->next;
+		++k;
+	}
+	l->n = k < l->n ? k : l->n;	/* (the list got shorter) */
+}

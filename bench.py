@@ -215,15 +215,19 @@ ENGINE_CASES = [   # label, program of tests/a2s/bench.a2s, voices
 ENGINE_BUFFERS = (4096, 64)     # a2play's offline buffer; one fragment per a2_Run() = a realtime driver's
 
 
-def engine_run(program, voices, fragments, buffer, dropin, hash_fragments=0, env_extra=None, wait=True):
-    """One ref_bench process; returns its JSON (or the Popen when wait=False)."""
+WALK_SO = os.path.join(ROOT, "oracle", "_ref", "liba2amd_walk.so")
+
+
+def engine_run(program, voices, fragments, buffer, dropin, hash_fragments=0, env_extra=None, wait=True, walk=False):
+    """One ref_bench process; returns its JSON (or the Popen when wait=False).
+    walk: INTEGRATION.md option C - liba2amd_walk.so in front of the units."""
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
     env = dict(os.environ, A2REF_BUFFER=str(buffer))
     env.pop("LD_PRELOAD", None)
     if hash_fragments:
         env["A2REF_HASH"] = str(hash_fragments)
     if dropin:
-        env["LD_PRELOAD"] = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
+        env["LD_PRELOAD"] = (WALK_SO + " " if walk else "") + os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
     env.update(env_extra or {})
     p = subprocess.Popen([exe, "bench.a2s", program, str(voices), str(fragments), "1"], env=env,
                          cwd=os.path.join(ROOT, "tests", "a2s"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -239,9 +243,14 @@ def engine_result(p, timeout=600):
     if p.returncode != 0:
         return {"error": f"rc {p.returncode}: {err[-300:]}"}
     try:
-        return json.loads(out.strip().splitlines()[-1])
+        res = json.loads(out.strip().splitlines()[-1])
     except (ValueError, IndexError):
         return {"error": f"no JSON: {out[-200:]} {err[-200:]}"}
+    for ln in err.splitlines():     # (A2AMD_WALK_STATS=1)
+        if ln.startswith("a2amd walk:") and "voice visits skipped" in ln:
+            w = ln.split()
+            res["walk_stats"] = (int(w[w.index("voice") - 1]), int(w[w.index("made") - 1]))
+    return res
 
 
 def engine_in_loop(cases=ENGINE_CASES, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fragments=1024):

@@ -205,6 +205,9 @@ extern const A2P_unitdesc a2_wtosc_unitdesc, a2_panmix_unitdesc, a2_filter12_uni
 		a2_fm3p_unitdesc, a2_fm4p_unitdesc, a2_fm2r_unitdesc, a2_fm4r_unitdesc,
 		a2_dc_unitdesc, a2_waveshaper_unitdesc, a2_dcblock_unitdesc, a2_limiter_unitdesc;
 
+
+#include "a2amd_walk.h"	/* INTEGRATION.md option C: what liba2amd_walk.so asks of the units */
+
 #ifdef __cplusplus
 }
 #endif

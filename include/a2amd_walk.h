@@ -1,0 +1,48 @@
+/*
+ * a2amd_walk.h - the interface between the drop-in units (liba2amd_units.so) and the
+ * replacement of the engine's voice walk (liba2amd_walk.so, INTEGRATION.md option C).
+ * No engine types in it: a2amd_walk.c includes the engine's own internal headers next to
+ * this file, a2amd_units.c the mirror declarations of a2amd_plugin.h.
+ */
+#ifndef A2AMD_WALK_H
+#define A2AMD_WALK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- INTEGRATION.md option C: the engine's voice walk with a short cut for sleeping voices ----
+ * a2_ProcessVoices (src/core.c:1883-1896) visits every voice in every fragment, whatever its
+ * units do; audiality2_amd/csrc/a2amd_walk.c (compiled against the ENGINE's internal headers
+ * into liba2amd_walk.so, loaded in front of libaudiality2) interposes that one function and
+ * skips the visit for a voice that would get nothing but the default window.  What it needs
+ * from the drop-in units: */
+#define A2AMD_WALK_MAXDEV 8
+typedef struct a2amd_walkview
+{
+	const void		*cfg;		/* the A2_config this view belongs to (a2amd_units_walkview) */
+	uint8_t *const		*map;		/* [dev]: the backends' default maps of the open fragment (a2amd_default_map) */
+	const unsigned		*map_cap;	/* [dev] */
+	const unsigned		*base;		/* engine offset and length of the open root window: only the window */
+	const unsigned		*win_frames;	/* (*base, *win_frames) may be reported through the map */
+	uint32_t *const		*qstamp;	/* [dev][slot]: non-zero while that voice's head unit reports its default
+						 * windows through the map (A2_unit.Process == the drop-in's byte store);
+						 * a new value every time it starts to */
+	const unsigned		*qstamp_cap;	/* [dev] */
+	int			*walker;	/* set by the walk: the units' own prefetch hints are switched off */
+	const unsigned		*serial;	/* *serial == serial_value while the engine state this view was made for is open */
+	unsigned		serial_value;
+} a2amd_walkview;
+/* The view of the engine state with this A2_config; 0, or -1 when the drop-in does not serve it. */
+int a2amd_units_walkview(const void *cfg, a2amd_walkview *out);
+/* 'head' = the first unit of a voice (A2_voice.units).  Returns the voice's current stamp -
+ * 0 unless the unit is the head of a chain of the drop-in's own units in byte-store mode -
+ * and its slot (bits 0..27) and context (bits 28..31) in *slotdev. */
+uint32_t a2amd_units_standing(const void *head, uint32_t *slotdev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* A2AMD_WALK_H */

@@ -227,6 +227,17 @@ int main(int argc, const char *argv[])
 		}
 		if((vh = a2_Starta(i, parent, prog, nargs, pargs)) < 0)
 			return 1;
+		/* A2REF_SIBLING=1: a second subtree under the root voice, made AFTER the program's
+		 * voice (so the engine's newest-first walk reaches it first): a group
+		 * (a2_NewGroup) playing the same program.  With the drop-in's A2AMD_DEVICES=2
+		 * the program's own voice - the one the clients below attach to - then lives
+		 * in the SECOND backend context. */
+		if(getenv("A2REF_SIBLING"))
+		{
+			A2_handle g = a2_NewGroup(i, a2_RootVoice(i));
+			if(g < 0 || a2_Starta(i, g, prog, nargs, pargs) < 0)
+				return 1;
+		}
 	}
 	/* A2REF_ROOTCLIENTS=1: the clients below go on the root voice (the root driver's
 	 * xinsert, audiality2.c:271-291 - where a2play puts its sink) instead */

@@ -14,7 +14,13 @@ from conftest import GOLDEN, ROOT, differing_fragments, fnv1a_fragments
 
 REF_RENDER = os.path.join(ROOT, "oracle", "_ref", "ref_render")
 UNITS_SO = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
+# INTEGRATION.md option C: the replacement of the engine's voice walk, in front of the units
+WALK_SO = os.path.join(ROOT, "oracle", "_ref", "liba2amd_walk.so")
 A2S = os.path.join(ROOT, "tests", "a2s")
+
+
+def preload(walk=False):
+    return f"{WALK_SO} {UNITS_SO}" if walk else UNITS_SO
 
 # name, program args, frames (as in tests/golden/make_goldens.py)
 CASES = [("sustain", ["4", "0.05"], 9600), ("filter", ["4", "0.02"], 48000),
@@ -43,11 +49,12 @@ def need_ref():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("walk", [False, True])
 @pytest.mark.parametrize("name,args,frames", CASES)
-def test_engine_with_dropin_units_matches_reference(tmp_path, name, args, frames):
+def test_engine_with_dropin_units_matches_reference(tmp_path, name, args, frames, walk):
     need_ref()
     out = tmp_path / f"{name}.pcm"
-    env = dict(os.environ, LD_PRELOAD=UNITS_SO)
+    env = dict(os.environ, LD_PRELOAD=preload(walk))
     if name in REALTIME_CASES:
         env["A2REF_REALTIME"] = "1"
     if name in UPLOAD_CASES:
@@ -255,17 +262,18 @@ def test_several_engine_states_share_the_gpu():
 def test_engine_with_dropin_units_matches_reference_run(tmp_path, name, args, frames):
     need_ref()
     outs = []
-    for preload in (False, True):
-        out = tmp_path / f"{name}{int(preload)}.pcm"
+    for pre in (0, 1, 2):
+        out = tmp_path / f"{name}{pre}.pcm"
         env = dict(os.environ)
-        if preload:
-            env["LD_PRELOAD"] = UNITS_SO
+        if pre:
+            env["LD_PRELOAD"] = preload(pre == 2)
         subprocess.run([REF_RENDER, f"{A2S}/{name}.a2s", "Main", str(frames), "64", "48000", "2", str(out)] + args,
                        check=True, env=env, cwd=A2S, timeout=900)
         outs.append(np.fromfile(out, dtype="<i4"))
     assert outs[0].any()
-    bad = np.nonzero(outs[0] != outs[1])[0]
-    assert len(bad) == 0, f"{len(bad)} samples differ, first at frame {bad[0] // 2 if len(bad) else -1}"
+    for o in outs[1:]:
+        bad = np.nonzero(outs[0] != o)[0]
+        assert len(bad) == 0, f"{len(bad)} samples differ, first at frame {bad[0] // 2 if len(bad) else -1}"
 
 
 @pytest.mark.gpu
@@ -450,6 +458,34 @@ def test_one_engine_state_over_several_contexts(tmp_path, name, args, frames, de
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("clients", [("SINK",), ("SOURCE", "SINK"), ("SINKSTREAM", "SINK"), ("SINK", "KILL")])
+@pytest.mark.parametrize("buffer", [64, 1024])
+def test_sink_clients_on_a_voice_of_the_second_context(tmp_path, clients, buffer):
+    """A2AMD_DEVICES=2 with a sink client (a2_SinkCallback / a2_OpenSink) on a group that
+    is routed to the SECOND backend context (A2REF_SIBLING puts another subtree in front
+    of it in the engine's walk): a2amd_render_group must bring that context's tapped
+    windows back with the audio, or the client is handed zeros (round 2's advisor
+    finding).  Sink hash, stream hash and audio against the CPU run."""
+    need_ref()
+    frames = 9600
+    res = []
+    for preload in (False, True):
+        out = tmp_path / f"c{int(preload)}.pcm"
+        env = dict(os.environ, A2REF_SIBLING="1", **{f"A2REF_{c}": "0" if c == "SINKSTREAM" else "1" for c in clients})
+        if "KILL" in clients:
+            env["A2REF_KILL"] = str(frames // 2)
+        if preload:
+            env["LD_PRELOAD"] = UNITS_SO
+            env["A2AMD_DEVICES"] = "2"
+        r = subprocess.run([REF_RENDER, f"{A2S}/sinkgroup.a2s", "Main", str(frames), str(buffer), "48000", "2", str(out), "0.1"],
+                           env=env, cwd=A2S, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-500:]
+        res.append((np.fromfile(out, dtype="<i4"), [l for l in r.stdout.splitlines() if "sink" in l or "stream" in l]))
+    assert res[0][0].any() and np.array_equal(res[0][0], res[1][0])
+    assert res[0][1] and res[0][1] == res[1][1], (res[0][1], res[1][1])
+
+
+@pytest.mark.gpu
 def test_fuzz_scripts_over_two_contexts(tmp_path):
     """A handful of the fuzzer's random scripts (tests/fuzz_scripts.py) with the voice
     tree spread over two contexts."""
@@ -469,3 +505,69 @@ def test_fuzz_scripts_over_two_contexts(tmp_path):
                            check=True, env=env, cwd=tmp_path, timeout=600)
             outs.append(np.fromfile(out, dtype="<i4"))
         assert np.array_equal(outs[0], outs[1]), f"seed {seed}"
+
+
+# ---------------------------------------------------------------------------
+# round 3: the whole stack at the sizes it is measured at.  bench.py's engine_in_loop
+# object times a2_Run() of the reference engine with the drop-in at BASELINE sizes; the
+# same runs, hash-compared with the engine's own CPU units, with the walk's prefetch
+# hints off and on (A2AMD_WALK_AHEAD), offline buffers and one fragment per a2_Run().
+# ---------------------------------------------------------------------------
+import functools
+
+
+@functools.lru_cache(maxsize=None)
+def _cpu_engine_hash(program, voices, buffer, hf):
+    import bench
+    r = bench.engine_run(program, voices, max(hf, buffer // 64), buffer, False, hf)
+    assert "error" not in r, r
+    return r["hashes"][0], r["active_voices"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,buffer", [("ahead12", 64), ("ahead12", 4096), ("ahead0", 64), ("walk", 64), ("walk", 4096)])
+@pytest.mark.parametrize("program,voices", [("OscPan", 65536), ("OscFilterPan", 16384), ("Osc2PanGroups", 65536),
+                                            ("OscPanScripted", 16384), ("OscFilterPanScripted", 16384)])
+def test_engine_in_loop_at_measured_sizes_matches_cpu_units(program, voices, buffer, variant):
+    """variant: the units alone with their prefetch hints on / off (INTEGRATION option A),
+    or behind the replacement of the engine's voice walk (option C: sleeping voices are
+    not visited)."""
+    import bench
+    need_ref()
+    hf = 16 if voices >= 65536 else 48
+    want, active = _cpu_engine_hash(program, voices, buffer, hf)
+    g = bench.engine_run(program, voices, max(2 * hf, 2 * buffer // 64), buffer, True, hf, walk=variant == "walk",
+                         env_extra={"A2AMD_WALK_AHEAD": "0" if variant == "ahead0" else "12", "A2AMD_WALK_STATS": "1"})
+    assert "error" not in g, g
+    assert g["active_voices"] == active >= voices
+    assert g["hashes"][0] == want, f"{program} x {voices}, a2_Run({buffer}), {variant}: audio differs"
+    if variant == "walk":
+        # the short cut was taken: most visits of sleeping voices were skipped
+        skipped, made = g["walk_stats"]
+        assert skipped > made if "Scripted" not in program else skipped > 0, g["walk_stats"]
+
+
+def test_walk_hands_voices_to_the_engine_one_by_one_without_changing_anything(tmp_path):
+    """liba2amd_walk.so's slow path - a voice cut out of its sibling list, handed alone to
+    the engine's own a2_ProcessVoices, linked back in or dropped when it died - with the
+    engine's CPU units (A2AMD_WALK_CUT: the test hook that takes that path in a state the
+    drop-in does not serve): notes born and dying all the time, groups, delay buses."""
+    need_ref()
+    if not os.path.exists(WALK_SO):
+        pytest.skip("oracle/_ref/liba2amd_walk.so not built")
+    for script, arg, frames in (("scripted", "0.2", 48000), ("song", "0.08", 96000), ("churn", "0.05", 96000),
+                                ("delaybus", "2", 24000)):
+        outs = []
+        for walk in (False, True):
+            out = tmp_path / f"{script}{int(walk)}.pcm"
+            env = dict(os.environ, A2AMD_WALK_CUT="1", A2AMD_WALK_STATS="1")
+            env.pop("LD_PRELOAD", None)
+            if walk:
+                env["LD_PRELOAD"] = WALK_SO
+            r = subprocess.run([REF_RENDER, f"{A2S}/{script}.a2s", "Main", str(frames), "64", "48000", "2", str(out), arg],
+                               env=env, cwd=A2S, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-500:]
+            if walk:
+                assert "voice visits skipped" in r.stderr and " 0 voice visits skipped" in r.stderr, r.stderr[-300:]
+            outs.append(np.fromfile(out, dtype="<i4"))
+        assert outs[0].any() and np.array_equal(outs[0], outs[1]), script

@@ -14,6 +14,7 @@ from fuzz_scripts import make_script
 
 REF_RENDER = os.path.join(ROOT, "oracle", "_ref", "ref_render")
 UNITS_SO = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
+WALK_SO = os.path.join(ROOT, "oracle", "_ref", "liba2amd_walk.so")     # INTEGRATION.md option C
 SECONDS = 1.5
 
 
@@ -30,11 +31,12 @@ def test_random_script_matches_reference(tmp_path, seed):
     script = tmp_path / f"fuzz{seed}.a2s"
     script.write_text(make_script(seed))
     outs, sinks = [], []
-    for preload in (False, True):
-        out = tmp_path / f"o{int(preload)}.pcm"
+    # the engine's own units; the drop-in units; the drop-in units behind the replaced voice walk
+    for preload in (0, 1, 2):
+        out = tmp_path / f"o{preload}.pcm"
         env = dict(os.environ)
         if preload:
-            env["LD_PRELOAD"] = UNITS_SO
+            env["LD_PRELOAD"] = UNITS_SO if preload == 1 else f"{WALK_SO} {UNITS_SO}"
         if seed % 3 == 0:       # Main is a group with an xinsert: give it clients
             env["A2REF_SINK"] = "1"
             if seed % 6 == 0:
@@ -47,9 +49,10 @@ def test_random_script_matches_reference(tmp_path, seed):
         assert r.returncode == 0, (seed, preload, r.stderr[-800:])
         outs.append(np.fromfile(out, dtype="<i4"))
         sinks.append([ln for ln in r.stdout.splitlines() if ln.startswith("sink ")])
-    assert sinks[0] == sinks[1] and len(sinks[0]) == (seed % 3 == 0), (seed, sinks)
+    assert sinks[0] == sinks[1] == sinks[2] and len(sinks[0]) == (seed % 3 == 0), (seed, sinks)
     assert outs[0].any(), f"seed {seed}: the reference rendered silence"
-    bad = np.nonzero(outs[0] != outs[1])[0]
-    assert len(bad) == 0, (f"seed {seed}: {len(bad)} samples differ, first at {bad[:3]} "
-                           f"; config (rate, buffer, channels) = {engine_config(seed)}; "
-                           f"script: python tests/fuzz_scripts.py {seed}")
+    for k in (1, 2):
+        bad = np.nonzero(outs[0] != outs[k])[0]
+        assert len(bad) == 0, (f"seed {seed}{' (voice walk replaced)' if k == 2 else ''}: {len(bad)} samples differ, "
+                               f"first at {bad[:3]}; config (rate, buffer, channels) = {engine_config(seed)}; "
+                               f"script: python tests/fuzz_scripts.py {seed}")
