@@ -65,7 +65,7 @@ typedef struct WSTATE
 	A2_state	*st;
 	a2amd_walkview	view;
 	int		served;		/* the drop-in serves this state */
-	LIST		*lists;		/* open addressing on 'head' */
+	LIST		**lists;	/* open addressing on 'head'; the LISTs stay where they are (nested calls hold them) */
 	unsigned	nlists, cap_lists;
 	unsigned long long skipped, visited;
 } WSTATE;
@@ -103,7 +103,11 @@ static WSTATE *wstate_of(A2_state *st)
 		/* a new engine state (at the address of a closed one, possibly): forget everything */
 		unsigned k;
 		for(k = 0; k < w->cap_lists; ++k)
-			free(w->lists[k].e);
+			if(w->lists[k])
+			{
+				free(w->lists[k]->e);
+				free(w->lists[k]);
+			}
 		free(w->lists);
 		w->lists = NULL;
 		w->nlists = w->cap_lists = 0;
@@ -123,14 +127,14 @@ static LIST *list_of(WSTATE *w, A2_voice **head)
 	if(w->nlists * 2 >= w->cap_lists)
 	{
 		unsigned nc = w->cap_lists ? w->cap_lists * 2 : 64, j;
-		LIST *nl = (LIST *)calloc(nc, sizeof(LIST));
+		LIST **nl = (LIST **)calloc(nc, sizeof(LIST *));
 		if(!nl)
 			return NULL;
 		for(j = 0; j < w->cap_lists; ++j)
-			if(w->lists[j].head)
+			if(w->lists[j])
 			{
-				k = (unsigned)(((uintptr_t)w->lists[j].head >> 4) * 2654435761u) & (nc - 1);
-				while(nl[k].head)
+				k = (unsigned)(((uintptr_t)w->lists[j]->head >> 4) * 2654435761u) & (nc - 1);
+				while(nl[k])
 					k = (k + 1) & (nc - 1);
 				nl[k] = w->lists[j];
 			}
@@ -140,14 +144,16 @@ static LIST *list_of(WSTATE *w, A2_voice **head)
 	}
 	mask = w->cap_lists - 1;
 	k = (unsigned)(((uintptr_t)head >> 4) * 2654435761u) & mask;
-	while(w->lists[k].head && w->lists[k].head != head)
+	while(w->lists[k] && w->lists[k]->head != head)
 		k = (k + 1) & mask;
-	if(!w->lists[k].head)
+	if(!w->lists[k])
 	{
-		w->lists[k].head = head;
+		if(!(w->lists[k] = (LIST *)calloc(1, sizeof(LIST))))
+			return NULL;
+		w->lists[k]->head = head;
 		++w->nlists;
 	}
-	return &w->lists[k];
+	return w->lists[k];
 }
 
 static void report(void)
@@ -174,6 +180,42 @@ static void bind_engine(void)
 		atexit(report);
 }
 
+/* Asleep for the whole window, and nothing to do for it but the byte store?  a2_VoiceProcessVMEv
+ * (core.c:1816-1823) with an empty event queue returns (waketime - now) >> 8 frames;
+ * a2_VoiceProcess then makes ONE Process call per unit for the window if that is at least its
+ * length.  (would_...: the test alone; sleeps_...: and the store.) */
+static inline int would_sleep_unseen(const WSTATE *w, const LIST *l, unsigned k, const A2_voice *v, unsigned now,
+		unsigned frames, int deflt)
+{
+	const a2amd_walkview *vw = &w->view;
+	const ENT *e;
+	unsigned dev, slot;
+	if(k >= l->n)
+		return 0;
+	e = &l->e[k];
+	if(!w->served || e->v != v || !e->stamp || v->events || (a2_TSDiff(v->s.waketime, now) >> 8) < (int)frames)
+		return 0;
+	if(e->stamp == STAMP_NOUNITS)
+		return 1;
+	/* only the open root window - one backend fragment - can be reported through the map
+	 * (amd_quick_process, a2amd_units.c, makes the same test) */
+	if(!deflt)
+		return 0;
+	dev = e->slotdev >> 28;
+	slot = e->slotdev & 0x0fffffffu;
+	return slot < vw->map_cap[dev] && slot < vw->qstamp_cap[dev] && vw->qstamp[dev][slot] == e->stamp;
+}
+
+static inline int sleeps_unseen(const WSTATE *w, const LIST *l, unsigned k, const A2_voice *v, unsigned now,
+		unsigned frames, int deflt)
+{
+	if(!would_sleep_unseen(w, l, k, v, now, frames, deflt))
+		return 0;
+	if(l->e[k].stamp != STAMP_NOUNITS)
+		w->view.map[l->e[k].slotdev >> 28][l->e[k].slotdev & 0x0fffffffu] = 1;	/* = amd_quick_process() */
+	return 1;
+}
+
 /* The replacement.  Same contract as the engine's (internals.h:968-973). */
 void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned frames)
 {
@@ -195,85 +237,65 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 		return;
 	}
 	vw = &w->view;
-	/* only the open root window - one backend fragment - can be reported through the map
-	 * (amd_quick_process, a2amd_units.c, makes the same test) */
 	deflt = w->served && offset == *vw->base && frames == *vw->win_frames;
 	now = st->now_fragstart + (offset << 8);	/* a2_VoiceProcess, core.c:1856 */
 	while(*head)
 	{
-		A2_voice *v = *head, *next, *one;
-		if(k < l->n)
+		A2_voice *v = *head, *last, *rest, *p;
+		unsigned run = 1, kk;
+		if(k + AHEAD < l->n)
+			__builtin_prefetch(l->e[k + AHEAD].v);	/* (a hint: never dereferenced here) */
+		if(sleeps_unseen(w, l, k, v, now, frames, deflt))
 		{
-			ENT *e = &l->e[k];
-			if(k + AHEAD < l->n)
-				__builtin_prefetch(l->e[k + AHEAD].v);	/* (a hint: never dereferenced here) */
-			/* asleep for the whole window?  a2_VoiceProcessVMEv (core.c:1816-1823) with an empty
-			 * event queue returns (waketime - now) >> 8 frames; a2_VoiceProcess then makes ONE
-			 * Process call per unit for the window if that is at least its length */
-			if(w->served && e->v == v && e->stamp && !v->events &&
-					(a2_TSDiff(v->s.waketime, now) >> 8) >= (int)frames)
-			{
-				if(e->stamp == STAMP_NOUNITS)
-				{
-					head = &v->next;
-					++k;
-					++w->skipped;
-					continue;
-				}
-				if(deflt)
-				{
-					const unsigned dev = e->slotdev >> 28, slot = e->slotdev & 0x0fffffffu;
-					if(slot < vw->map_cap[dev] && slot < vw->qstamp_cap[dev] &&
-							vw->qstamp[dev][slot] == e->stamp)
-					{
-						vw->map[dev][slot] = 1;		/* = amd_quick_process() */
-						head = &v->next;
-						++k;
-						++w->skipped;
-						continue;
-					}
-				}
-			}
-		}
-		/* everything else is the engine's business: its own loop, on this voice alone */
-		next = v->next;
-		one = v;
-		v->next = NULL;
-		engine_walk(st, &one, offset, frames);
-		++w->visited;
-		if(!one)
-		{
-			*head = next;		/* the voice ended and was freed (a2_VoiceFree, core.c:1892) */
+			head = &v->next;
+			++k;
+			++w->skipped;
 			continue;
 		}
-		v->next = next;
-		/* what to do with it while it sleeps */
-		if(k >= l->cap)
+		/* everything else is the engine's business: its own loop, on this voice - and on the
+		 * voices behind it that need a visit as well - cut out of the list for the call */
+		last = v;
+		while(run < 4096 && last->next && !would_sleep_unseen(w, l, k + run, last->next, now, frames, deflt))
 		{
-			unsigned nc = l->cap ? l->cap * 2 : 16;
-			ENT *ne = (ENT *)realloc(l->e, nc * sizeof(ENT));
-			if(ne)
+			last = last->next;
+			++run;
+		}
+		rest = last->next;
+		last->next = NULL;
+		engine_walk(st, head, offset, frames);
+		w->visited += run;
+		/* what is left of them (voices that ended were freed: a2_VoiceFree, core.c:1892) goes back in
+		 * front of the rest; and what to do with each while it sleeps */
+		for(p = *head; p; p = p->next)
+		{
+			kk = k++;
+			if(kk >= l->cap)
 			{
-				l->e = ne;
-				l->cap = nc;
+				unsigned nc = l->cap ? l->cap * 2 : 16;
+				ENT *ne = (ENT *)realloc(l->e, nc * sizeof(ENT));
+				if(ne)
+				{
+					l->e = ne;
+					l->cap = nc;
+				}
 			}
+			if(kk < l->cap)
+			{
+				ENT *e = &l->e[kk];
+				if(kk >= l->n)
+					l->n = kk + 1;
+				e->v = p;
+				e->slotdev = 0;
+				if(p->sub)
+					e->stamp = 0;		/* its subvoices need the walk (core.c:1888-1889) */
+				else if(!p->units)
+					e->stamp = STAMP_NOUNITS;
+				else
+					e->stamp = w->served ? a2amd_units_standing(p->units, &e->slotdev) : 0;
+			}
+			head = &p->next;
 		}
-		if(k < l->cap)
-		{
-			ENT *e = &l->e[k];
-			if(k >= l->n)
-				l->n = k + 1;
-			e->v = v;
-			e->slotdev = 0;
-			if(v->sub)
-				e->stamp = 0;		/* its subvoices need the walk (core.c:1888-1889) */
-			else if(!v->units)
-				e->stamp = STAMP_NOUNITS;
-			else
-				e->stamp = w->served ? a2amd_units_standing(v->units, &e->slotdev) : 0;
-		}
-		head = &v->next;
-		++k;
+		*head = rest;
 	}
 	l->n = k < l->n ? k : l->n;	/* (the list got shorter) */
 }

@@ -210,6 +210,7 @@ def cpu_baseline(voices, chain, groups, oracle_fragments=100):
 ENGINE_CASES = [   # label, program of tests/a2s/bench.a2s, voices
     ("configs[1]", "OscPan", 1024), ("configs[2]", "OscFilterPan", 16384),
     ("configs[3]", "Osc2PanGroups", 65536),
+    ("configs[4] in one engine state", "FilterTree", 262144),
     ("variant 2b (scripted)", "OscPanScripted", 16384), ("variant 3b (scripted)", "OscFilterPanScripted", 16384),
 ]
 ENGINE_BUFFERS = (4096, 64)     # a2play's offline buffer; one fragment per a2_Run() = a realtime driver's
@@ -253,50 +254,71 @@ def engine_result(p, timeout=600):
     return res
 
 
-def engine_in_loop(cases=ENGINE_CASES, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fragments=1024):
+def engine_in_loop(cases=None, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fragments=1024):
     """a2_Run() with the reference engine in the loop, drop-in vs the engine's own CPU units:
     voice-samples/s, time per 64-frame fragment (p50 / p99 over the a2_Run() calls), and the
-    FNV-1a hash of the first `hash_fragments` fragments after the warm-up from both runs."""
+    FNV-1a hash of the first `hash_fragments` fragments after the warm-up from both runs.
+    Two ways of loading the drop-in: "units" = LD_PRELOAD=liba2amd_units.so
+    (option A: the engine's voice walk untouched), "units+walk" = liba2amd_walk.so in front
+    of it (option C: the engine's a2_ProcessVoices replaced, sleeping voices are not visited)."""
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
     if not os.path.exists(exe):
         return {"error": "oracle/_ref/ref_bench (the compiled reference) did not travel"}
+    cases = list(cases or ENGINE_CASES)
+    modes = [("units", False)] + ([("units+walk", True)] if os.path.exists(WALK_SO) else [])
     # the CPU renders: independent processes, one thread each, all at once (the box has the cores)
     cpu = {}
     for label, program, voices in cases:
         for buf in buffers:
-            hf = hash_fragments if voices < 65536 else min(hash_fragments, 16)
+            hf = hash_fragments if voices < 65536 else min(hash_fragments, 16 if voices < 262144 else 8)
             nfr = max(hf, buf // 64)
             cpu[(label, buf)] = (hf, engine_run(program, voices, nfr, buf, False, hf, wait=False))
-    cpu = {k: (hf, engine_result(p)) for k, (hf, p) in cpu.items()}
+    cpu = {k: (hf, engine_result(p, timeout=900)) for k, (hf, p) in cpu.items()}
     out = {"entry_point": "a2_Run(frames) of the compiled reference engine (oracle/_ref/ref_bench, one engine state, one "
-                          "CPU thread for compiler + VM + voice walk), units = the drop-in (LD_PRELOAD=liba2amd_units.so)",
-           "hash": "FNV-1a 64 of the first fragments rendered after the warm-up, ch0 then ch1 per 64-frame fragment",
+                          "CPU thread for compiler + VM + voice walk); units: LD_PRELOAD=liba2amd_units.so; units+walk: "
+                          "liba2amd_walk.so (the engine's a2_ProcessVoices replaced: sleeping voices are not visited) "
+                          "in front of it",
+           "hash": "FNV-1a 64 of the first fragments rendered after the warm-up, ch0 then ch1 per 64-frame fragment; "
+                   "cpu_hash = the same engine with its own CPU units",
            "cases": {}}
     all_equal = True
+    rt = {m: 0 for m, _ in modes}
     for label, program, voices in cases:
         entry = {"program": program, "voices": voices}
         for buf in buffers:
             hf, c = cpu[(label, buf)]
             nfr = max(gpu_fragments if buf > 64 else 600, buf // 64 * 4)
-            g = engine_run(program, voices, nfr, buf, True, hf)
             e = {}
-            if "error" in g or "error" in c:
-                e["error"] = g.get("error") or c.get("error")
+            if "error" in c:
+                e["error"] = "CPU run: " + c["error"]
                 all_equal = False
             else:
-                per = buf // 64
-                e = {"voice_samples_per_s": g["voice_samples_per_s"],
-                     "us_per_fragment_p50": g["run_us_p50"] / per, "us_per_fragment_p99": g["run_us_p99"] / per,
-                     "us_per_fragment_mean": g["seconds"] / g["fragments"] * 1e6,
-                     "fragments_timed": g["fragments"], "active_voices": g["active_voices"],
-                     "realtime_at_48k": bool(g["run_us_p99"] / per <= 64.0 / 48000.0 * 1e6),
-                     "cpu_units_voice_samples_per_s": c["voice_samples_per_s"],
-                     "hash_fragments": hf, "hash": g["hashes"][0], "cpu_hash": c["hashes"][0],
-                     "hash_equal": g["hashes"][0] == c["hashes"][0] and g["active_voices"] == c["active_voices"]}
-                all_equal = all_equal and e["hash_equal"]
+                e = {"cpu_units_voice_samples_per_s": c["voice_samples_per_s"], "hash_fragments": hf,
+                     "cpu_hash": c["hashes"][0]}
+                for mode, walk in modes:
+                    g = engine_run(program, voices, nfr, buf, True, hf, walk=walk)
+                    if "error" in g:
+                        e[mode] = {"error": g["error"]}
+                        all_equal = False
+                        continue
+                    per = buf // 64
+                    m = {"voice_samples_per_s": g["voice_samples_per_s"],
+                         "us_per_fragment_p50": g["run_us_p50"] / per, "us_per_fragment_p99": g["run_us_p99"] / per,
+                         "us_per_fragment_mean": g["seconds"] / g["fragments"] * 1e6,
+                         "fragments_timed": g["fragments"], "active_voices": g["active_voices"],
+                         "realtime_at_48k": bool(g["run_us_p99"] / per <= 64.0 / 48000.0 * 1e6),
+                         "hash": g["hashes"][0],
+                         "hash_equal": g["hashes"][0] == c["hashes"][0] and g["active_voices"] == c["active_voices"]}
+                    all_equal = all_equal and m["hash_equal"]
+                    if buf == 64 and m["realtime_at_48k"] and m["hash_equal"] and "Scripted" not in program:
+                        rt[mode] = max(rt[mode], voices)
+                    e[mode] = m
             entry[f"a2_Run({buf})"] = e
         out["cases"][label] = entry
     out["hash_equal"] = all_equal
+    out["max_realtime_voices_one_engine_state"] = {
+        "what": "largest of the sustained-voice cases above whose a2_Run(64) - one synchronous GPU round trip per "
+                "64-frame fragment - has p99 <= 1.333 ms, audio equal to the CPU render", **rt}
     return out
 
 

@@ -78,6 +78,8 @@ static void *run(void *arg)
 	if((prog = a2_Get(i, bank, j->program)) < 0)
 		return NULL;
 	args[0] = (j->voices / 4) << 16;
+	if(strstr(j->program, "Tree"))		/* FilterTree(G): top-level groups of 32 768 voices */
+		args[0] = (j->voices / 32768) << 16;
 	args[1] = (int)(65536.0 * 4.0 / (j->voices > 4 ? j->voices : 4));
 	a2_TimestampReset(i);
 	if(a2_Starta(i, a2_RootVoice(i), prog, 2, args) < 0)
@@ -88,6 +90,8 @@ static void *run(void *arg)
 		int wf = j->voices / 4 * 2 / 64 + 16;
 		if(strstr(j->program, "Groups") && wf < j->voices / 256 * 3 + 64)
 			wf = j->voices / 256 * 3 + 64;
+		if(strstr(j->program, "Tree"))
+			wf = 320;		/* (128 sub-groups x 2.7 ms, all top groups at once) */
 		for(f = 0; f < (wf + buffer / 64 - 1) / (buffer / 64); ++f)
 			a2_Run(i, buffer);
 	}

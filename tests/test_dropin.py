@@ -524,17 +524,22 @@ def _cpu_engine_hash(program, voices, buffer, hf):
     return r["hashes"][0], r["active_voices"]
 
 
+ENGINE_SIZES = [(p, v, var, b) for p, v in (("OscPan", 65536), ("OscFilterPan", 16384), ("Osc2PanGroups", 65536),
+                                            ("OscPanScripted", 16384), ("OscFilterPanScripted", 16384))
+                for var, b in (("ahead12", 64), ("ahead12", 4096), ("ahead0", 64), ("walk", 64), ("walk", 4096))]
+# BASELINE configs[4]'s voice tree in ONE engine state: 8 top-level groups x 128 sub-groups x 256 voices
+ENGINE_SIZES += [("FilterTree", 262144, "ahead12", 64), ("FilterTree", 262144, "walk", 64), ("FilterTree", 262144, "walk", 4096)]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant,buffer", [("ahead12", 64), ("ahead12", 4096), ("ahead0", 64), ("walk", 64), ("walk", 4096)])
-@pytest.mark.parametrize("program,voices", [("OscPan", 65536), ("OscFilterPan", 16384), ("Osc2PanGroups", 65536),
-                                            ("OscPanScripted", 16384), ("OscFilterPanScripted", 16384)])
+@pytest.mark.parametrize("program,voices,variant,buffer", ENGINE_SIZES)
 def test_engine_in_loop_at_measured_sizes_matches_cpu_units(program, voices, buffer, variant):
     """variant: the units alone with their prefetch hints on / off (INTEGRATION option A),
     or behind the replacement of the engine's voice walk (option C: sleeping voices are
     not visited)."""
     import bench
     need_ref()
-    hf = 16 if voices >= 65536 else 48
+    hf = 8 if voices >= 262144 else 16 if voices >= 65536 else 48
     want, active = _cpu_engine_hash(program, voices, buffer, hf)
     g = bench.engine_run(program, voices, max(2 * hf, 2 * buffer // 64), buffer, True, hf, walk=variant == "walk",
                          env_extra={"A2AMD_WALK_AHEAD": "0" if variant == "ahead0" else "12", "A2AMD_WALK_STATS": "1"})
