@@ -43,14 +43,18 @@
 #include "internals.h"			/* the engine's: A2_state, A2_voice (src/internals.h:559-586, :600-700) */
 #include "../../include/a2amd_walk.h"	/* a2amd_walkview */
 
-#define AHEAD		12		/* positions the prefetch runs ahead */
+#define AHEAD		40		/* positions the prefetch runs ahead (a DRAM access at ~3 ns per position) */
 #define STAMP_NOUNITS	0xffffffffu	/* a voice without units and without subvoices: nothing to do while it sleeps */
+#define E_NOEVENTS	1u		/* ENT.flags: its event queue was empty when it was last looked at */
+#define E_APIHANDLE	2u		/* ... it has an API handle: the application can send it events at any time */
 
 typedef struct ENT
 {
 	A2_voice	*v;		/* the voice that stood at this position of the list in the last walk */
 	uint32_t	slotdev;	/* its byte in the default map: slot (bits 0..27), context (28..31) */
 	uint32_t	stamp;		/* a2amd_units_standing() when it was last visited; 0 = always visit */
+	uint32_t	wake;		/* A2_vmstate.waketime when it was last looked at */
+	uint32_t	flags;		/* E_* */
 } ENT;
 
 typedef struct LIST
@@ -58,6 +62,8 @@ typedef struct LIST
 	A2_voice	**head;		/* the list: &parent->sub (key) */
 	ENT		*e;
 	unsigned	n, cap;
+	unsigned long long epoch;	/* e[0..n) was the whole list, in order, when the state's epoch had this value */
+	unsigned long long quiet_visit;	/* the parent was found asleep, without events, for the window of this visit */
 } LIST;
 
 typedef struct WSTATE
@@ -67,14 +73,20 @@ typedef struct WSTATE
 	int		served;		/* the drop-in serves this state */
 	LIST		**lists;	/* open addressing on 'head'; the LISTs stay where they are (nested calls hold them) */
 	unsigned	nlists, cap_lists;
-	unsigned long long skipped, visited;
+	unsigned long long epoch;	/* bumped by every a2_VoiceNew / a2_VoiceFree of the state: the lists' structure */
+	unsigned long long visits, cur_visit;	/* the engine call in progress one level up (quiet_visit) */
+	int		hooks_broken;	/* a list changed without the epoch moving: never trust remembered lists */
+	unsigned long long last_use;	/* (the table of states is finite: the longest unused one makes room) */
+	unsigned long long skipped, unread, visited;
 } WSTATE;
 
 static void (*engine_walk)(A2_state *st, A2_voice **head, unsigned offset, unsigned frames);
+static A2_voice *(*engine_voicenew)(A2_state *st, A2_voice *parent, unsigned when);
+static void (*engine_voicefree)(A2_state *st, A2_voice **head);
 static WSTATE *wstates[256];
 static pthread_mutex_t wmtx = PTHREAD_MUTEX_INITIALIZER;
 static __thread WSTATE *last_ws;
-static int walk_off = -1, walk_stats, walk_cut;
+static int walk_off = -1, walk_stats, walk_cut, walk_nocache;
 
 static WSTATE *wstate_of(A2_state *st)
 {
@@ -83,20 +95,36 @@ static WSTATE *wstate_of(A2_state *st)
 	if(w && w->st == st && w->view.cfg == st->config && (!w->served || *w->view.serial == w->view.serial_value))
 		return w;
 	pthread_mutex_lock(&wmtx);
-	for(i = 0; i < 256; ++i)
-		if(wstates[i] && wstates[i]->st == st)
-			break;
-		else if(!wstates[i] && f < 0)
-			f = i;
-	if(i < 256)
-		w = wstates[i];
-	else if(f >= 0 && (w = (WSTATE *)calloc(1, sizeof(WSTATE))))
 	{
-		w->st = st;
-		wstates[f] = w;
+		static unsigned long long tick;
+		int lru = -1;
+		for(i = 0; i < 256; ++i)
+			if(wstates[i] && wstates[i]->st == st)
+				break;
+			else if(!wstates[i] && f < 0)
+				f = i;
+			else if(wstates[i] && (lru < 0 || wstates[i]->last_use < wstates[lru]->last_use))
+				lru = i;
+		if(i < 256)
+			w = wstates[i];
+		else if(f >= 0 && (w = (WSTATE *)calloc(1, sizeof(WSTATE))))
+		{
+			w->st = st;
+			wstates[f] = w;
+		}
+		else if(f < 0 && lru >= 0 && wstates[lru]->cur_visit == 0)
+		{
+			/* states come and go (a2_Render's substates) and nobody tells us: the longest unused
+			 * entry is given to this one; a state that lost its entry while alive starts over */
+			w = wstates[lru];
+			w->st = st;
+			w->view.cfg = NULL;
+		}
+		else
+			w = NULL;
+		if(w)
+			w->last_use = ++tick;
 	}
-	else
-		w = NULL;
 	pthread_mutex_unlock(&wmtx);
 	if(w && (w->view.cfg != st->config || (w->served && *w->view.serial != w->view.serial_value)))
 	{
@@ -111,6 +139,7 @@ static WSTATE *wstate_of(A2_state *st)
 		free(w->lists);
 		w->lists = NULL;
 		w->nlists = w->cap_lists = 0;
+		++w->epoch;
 		w->served = a2amd_units_walkview(st->config, &w->view) == 0;
 		if(!w->served)
 			w->view.cfg = st->config;
@@ -161,18 +190,26 @@ static void report(void)
 	int i;
 	for(i = 0; i < 256; ++i)
 		if(wstates[i] && (wstates[i]->skipped || wstates[i]->visited))
-			fprintf(stderr, "a2amd walk: state %p: %llu voice visits skipped, %llu made\n",
-					(void *)wstates[i]->st, wstates[i]->skipped, wstates[i]->visited);
+			fprintf(stderr, "a2amd walk: state %p: %llu voice visits skipped, %llu made (%llu of the skipped without "
+					"reading the voice%s)\n", (void *)wstates[i]->st, wstates[i]->skipped, wstates[i]->visited,
+					wstates[i]->unread, wstates[i]->hooks_broken ? "; HOOKS BROKEN" : "");
 }
 
 static void bind_engine(void)
 {
 	*(void **)&engine_walk = dlsym(RTLD_NEXT, "a2_ProcessVoices");
-	if(!engine_walk)
-		fprintf(stderr, "a2amd walk: no a2_ProcessVoices behind this one - load liba2amd_walk.so IN FRONT of "
-				"libaudiality2\n");
+	*(void **)&engine_voicenew = dlsym(RTLD_NEXT, "a2_VoiceNew");
+	*(void **)&engine_voicefree = dlsym(RTLD_NEXT, "a2_VoiceFree");
+	if(!engine_walk || !engine_voicenew || !engine_voicefree)
+	{
+		fprintf(stderr, "a2amd walk: no a2_ProcessVoices / a2_VoiceNew / a2_VoiceFree behind these - load "
+				"liba2amd_walk.so IN FRONT of libaudiality2\n");
+		engine_walk = NULL;
+	}
 	walk_off = getenv("A2AMD_WALK_OFF") != NULL;	/* A/B: every voice is handed to the engine's loop */
-	/* test hook: voices are handed to the engine's loop one by one even in a state the drop-in
+	/* A/B: lists are never trusted from memory - every sleeping voice's A2_voice is read */
+	walk_nocache = getenv("A2AMD_WALK_NOCACHE") != NULL;
+	/* test hook: voices are handed to the engine's loop run by run even in a state the drop-in
 	 * does not serve (the engine's own CPU units): exercises the cut / relink / voice death
 	 * logic without a GPU; no visit is ever skipped there */
 	walk_cut = getenv("A2AMD_WALK_CUT") != NULL;
@@ -180,20 +217,42 @@ static void bind_engine(void)
 		atexit(report);
 }
 
+/* The two places where the engine's voice lists change (src/core.c:456-482, :532-581), interposed
+ * like the walk itself: what is remembered about the lists of a state holds while its epoch does. */
+A2_voice *a2_VoiceNew(A2_state *st, A2_voice *parent, unsigned when)
+{
+	WSTATE *w;
+	if(walk_off < 0)
+		bind_engine();
+	if(!engine_walk)
+		return NULL;
+	if((w = wstate_of(st)))
+		++w->epoch;
+	return engine_voicenew(st, parent, when);
+}
+
+void a2_VoiceFree(A2_state *st, A2_voice **head)
+{
+	WSTATE *w;
+	if(walk_off < 0)
+		bind_engine();
+	if(!engine_walk)
+		return;
+	if((w = wstate_of(st)))
+		++w->epoch;
+	engine_voicefree(st, head);
+}
+
 /* Asleep for the whole window, and nothing to do for it but the byte store?  a2_VoiceProcessVMEv
  * (core.c:1816-1823) with an empty event queue returns (waketime - now) >> 8 frames;
  * a2_VoiceProcess then makes ONE Process call per unit for the window if that is at least its
- * length.  (would_...: the test alone; sleeps_...: and the store.) */
-static inline int would_sleep_unseen(const WSTATE *w, const LIST *l, unsigned k, const A2_voice *v, unsigned now,
+ * length.  'wake' / 'noevents': the voice's own fields, or what the entry remembers of them. */
+static inline int entry_sleeps(const WSTATE *w, const ENT *e, unsigned wake, int noevents, unsigned now,
 		unsigned frames, int deflt)
 {
 	const a2amd_walkview *vw = &w->view;
-	const ENT *e;
 	unsigned dev, slot;
-	if(k >= l->n)
-		return 0;
-	e = &l->e[k];
-	if(!w->served || e->v != v || !e->stamp || v->events || (a2_TSDiff(v->s.waketime, now) >> 8) < (int)frames)
+	if(!e->stamp || !noevents || (a2_TSDiff(wake, now) >> 8) < (int)frames)
 		return 0;
 	if(e->stamp == STAMP_NOUNITS)
 		return 1;
@@ -206,14 +265,35 @@ static inline int would_sleep_unseen(const WSTATE *w, const LIST *l, unsigned k,
 	return slot < vw->map_cap[dev] && slot < vw->qstamp_cap[dev] && vw->qstamp[dev][slot] == e->stamp;
 }
 
-static inline int sleeps_unseen(const WSTATE *w, const LIST *l, unsigned k, const A2_voice *v, unsigned now,
+/* ... looking at the voice itself (one cache line of it) */
+static inline int voice_sleeps(const WSTATE *w, LIST *l, unsigned k, const A2_voice *v, unsigned now,
 		unsigned frames, int deflt)
 {
-	if(!would_sleep_unseen(w, l, k, v, now, frames, deflt))
+	ENT *e;
+	if(k >= l->n || !w->served)
 		return 0;
-	if(l->e[k].stamp != STAMP_NOUNITS)
-		w->view.map[l->e[k].slotdev >> 28][l->e[k].slotdev & 0x0fffffffu] = 1;	/* = amd_quick_process() */
-	return 1;
+	e = &l->e[k];
+	if(e->v != v)
+		return 0;
+	e->wake = v->s.waketime;
+	e->flags = (e->flags & ~E_NOEVENTS) | (v->events ? 0 : E_NOEVENTS);
+	return entry_sleeps(w, e, e->wake, e->flags & E_NOEVENTS, now, frames, deflt);
+}
+
+/* ... from memory: the list has not changed since it was last walked, its parent slept through
+ * this window without events - so nobody can have sent this voice an event or moved its wake
+ * time since they were last read (only a voice's own VM, its parent's VM and event handling,
+ * and - for a voice with an API handle - the application ever do) */
+static inline int entry_sleeps_unread(const WSTATE *w, const ENT *e, unsigned now, unsigned frames, int deflt)
+{
+	return (e->flags & (E_NOEVENTS | E_APIHANDLE)) == E_NOEVENTS &&
+			entry_sleeps(w, e, e->wake, 1, now, frames, deflt);
+}
+
+static inline void mark_default(const WSTATE *w, const ENT *e)
+{
+	if(e->stamp != STAMP_NOUNITS)
+		w->view.map[e->slotdev >> 28][e->slotdev & 0x0fffffffu] = 1;	/* = amd_quick_process() */
 }
 
 /* The replacement.  Same contract as the engine's (internals.h:968-973). */
@@ -221,49 +301,103 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 {
 	WSTATE *w;
 	LIST *l;
-	const a2amd_walkview *vw;
 	unsigned k = 0, now;
-	int deflt;
+	int deflt, cached;
 	if(walk_off < 0)
 		bind_engine();
 	if(!engine_walk)
 		return;		/* (reported once; the state renders silence) */
-	if(!*head)
-		return;
-	/* a lone voice (the root voice, a group with one child): nothing to remember */
-	if(walk_off || !(*head)->next || !(w = wstate_of(st)) || !(w->served || walk_cut) || !(l = list_of(w, head)))
+	if(walk_off || !(w = wstate_of(st)) || !(w->served || walk_cut) || !(l = list_of(w, head)))
 	{
 		engine_walk(st, head, offset, frames);
 		return;
 	}
-	vw = &w->view;
-	deflt = w->served && offset == *vw->base && frames == *vw->win_frames;
+	deflt = w->served && offset == *w->view.base && frames == *w->view.win_frames;
 	now = st->now_fragstart + (offset << 8);	/* a2_VoiceProcess, core.c:1856 */
-	while(*head)
+	/* may the list be taken from memory?  (see entry_sleeps_unread) */
+	cached = w->served && !walk_nocache && !w->hooks_broken && l->n && l->epoch == w->epoch &&
+			l->quiet_visit && l->quiet_visit == w->cur_visit;
+	l->quiet_visit = 0;
+	for(;;)
 	{
-		A2_voice *v = *head, *last, *rest, *p;
+		A2_voice *v, *last, *rest, *p;
 		unsigned run = 1, kk;
-		if(k + AHEAD < l->n)
-			__builtin_prefetch(l->e[k + AHEAD].v);	/* (a hint: never dereferenced here) */
-		if(sleeps_unseen(w, l, k, v, now, frames, deflt))
+		unsigned long long epoch0, visit0;
+		if(cached)
 		{
-			head = &v->next;
-			++k;
-			++w->skipped;
-			continue;
+			if(k >= l->n)
+				break;
+			if(entry_sleeps_unread(w, &l->e[k], now, frames, deflt))
+			{
+				mark_default(w, &l->e[k]);
+				++k;
+				++w->skipped;
+				++w->unread;
+				continue;
+			}
+			/* (head: the link that points at this voice - an address, not a load) */
+			v = l->e[k].v;
+			if(k)
+				head = &l->e[k - 1].v->next;
+		}
+		else
+		{
+			if(!(v = *head))
+				break;
+			if(k + AHEAD < l->n)
+				__builtin_prefetch(l->e[k + AHEAD].v);	/* (a hint: never dereferenced here) */
+			if(voice_sleeps(w, l, k, v, now, frames, deflt))
+			{
+				mark_default(w, &l->e[k]);
+				head = &v->next;
+				++k;
+				++w->skipped;
+				continue;
+			}
+			if(k < l->n && l->e[k].v != v && l->epoch == w->epoch && w->served && !w->hooks_broken)
+			{
+				/* the list changed and neither a2_VoiceNew nor a2_VoiceFree came by here: an engine
+				 * build that binds them locally - remembered lists cannot be trusted */
+				w->hooks_broken = 1;
+				fprintf(stderr, "a2amd walk: a2_VoiceNew / a2_VoiceFree are not interposable in this engine "
+						"build; every voice's wake time will be read in every fragment\n");
+			}
 		}
 		/* everything else is the engine's business: its own loop, on this voice - and on the
 		 * voices behind it that need a visit as well - cut out of the list for the call */
 		last = v;
-		while(run < 4096 && last->next && !would_sleep_unseen(w, l, k + run, last->next, now, frames, deflt))
-		{
-			last = last->next;
-			++run;
-		}
+		if(cached)
+			while(run < 4096 && k + run < l->n && !entry_sleeps_unread(w, &l->e[k + run], now, frames, deflt))
+			{
+				last = l->e[k + run].v;
+				++run;
+			}
+		else
+			while(run < 4096 && last->next && !voice_sleeps(w, l, k + run, last->next, now, frames, deflt))
+			{
+				last = last->next;
+				++run;
+			}
+		/* a voice of the run that sleeps through the window with no events (a group voice: its
+		 * subvoices need the walk) cannot send its subvoices anything in this window: their list
+		 * may be taken from memory by the call its inline unit will make */
+		for(p = v, kk = 0; kk < run; p = p->next, ++kk)
+			if(p->sub && !p->events && (a2_TSDiff(p->s.waketime, now) >> 8) >= (int)frames)
+			{
+				LIST *sl = list_of(w, &p->sub);
+				if(sl)
+					sl->quiet_visit = w->visits + 1;
+			}
 		rest = last->next;
 		last->next = NULL;
+		epoch0 = w->epoch;
+		visit0 = w->cur_visit;
+		w->cur_visit = ++w->visits;
 		engine_walk(st, head, offset, frames);
+		w->cur_visit = visit0;
 		w->visited += run;
+		if(w->epoch != epoch0)
+			cached = 0;		/* voices were born or died (anywhere): the rest of the list is read */
 		/* what is left of them (voices that ended were freed: a2_VoiceFree, core.c:1892) goes back in
 		 * front of the rest; and what to do with each while it sleeps */
 		for(p = *head; p; p = p->next)
@@ -286,6 +420,8 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 					l->n = kk + 1;
 				e->v = p;
 				e->slotdev = 0;
+				e->wake = p->s.waketime;
+				e->flags = (p->events ? 0 : E_NOEVENTS) | ((p->flags & A2_APIHANDLE) ? E_APIHANDLE : 0);
 				if(p->sub)
 					e->stamp = 0;		/* its subvoices need the walk (core.c:1888-1889) */
 				else if(!p->units)
@@ -293,9 +429,17 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 				else
 					e->stamp = w->served ? a2amd_units_standing(p->units, &e->slotdev) : 0;
 			}
+			else
+				cached = 0;
 			head = &p->next;
 		}
 		*head = rest;
 	}
-	l->n = k < l->n ? k : l->n;	/* (the list got shorter) */
+	if(!cached)
+	{
+		/* walked link by link to its end: e[0..k) is the list */
+		if(k < l->n)
+			l->n = k;
+		l->epoch = l->n == k ? w->epoch : w->epoch - 1;
+	}
 }

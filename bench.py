@@ -250,7 +250,7 @@ def engine_result(p, timeout=600):
     for ln in err.splitlines():     # (A2AMD_WALK_STATS=1)
         if ln.startswith("a2amd walk:") and "voice visits skipped" in ln:
             w = ln.split()
-            res["walk_stats"] = (int(w[w.index("voice") - 1]), int(w[w.index("made") - 1]))
+            res["walk_stats"] = (int(w[w.index("voice") - 1]), int(w[w.index("made") - 1]), int(w[w.index("made") + 1].lstrip("(")))
     return res
 
 

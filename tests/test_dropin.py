@@ -19,7 +19,7 @@ WALK_SO = os.path.join(ROOT, "oracle", "_ref", "liba2amd_walk.so")
 A2S = os.path.join(ROOT, "tests", "a2s")
 
 
-def preload(walk=False):
+def preload_libs(walk=False):
     return f"{WALK_SO} {UNITS_SO}" if walk else UNITS_SO
 
 # name, program args, frames (as in tests/golden/make_goldens.py)
@@ -54,7 +54,7 @@ def need_ref():
 def test_engine_with_dropin_units_matches_reference(tmp_path, name, args, frames, walk):
     need_ref()
     out = tmp_path / f"{name}.pcm"
-    env = dict(os.environ, LD_PRELOAD=preload(walk))
+    env = dict(os.environ, LD_PRELOAD=preload_libs(walk))
     if name in REALTIME_CASES:
         env["A2REF_REALTIME"] = "1"
     if name in UPLOAD_CASES:
@@ -172,8 +172,8 @@ def test_dropin_refuses_mixed_chains(tmp_path):
                                      # group's audio and what it returns replaces it, between the two halves
                                      # of the render
                                      ("INSERT",), ("INSERT", "SINK"), ("INSERT", "SOURCE", "SINK"), ("INSERT", "KILL")])
-@pytest.mark.parametrize("buffer", [64, 1024])
-def test_dropin_serves_sink_and_source_clients(tmp_path, script, frames, clients, buffer):
+@pytest.mark.parametrize("buffer,walk", [(64, False), (1024, False), (64, True)])
+def test_dropin_serves_sink_and_source_clients(tmp_path, script, frames, clients, buffer, walk):
     """a2_SinkCallback / a2_SourceCallback / a2_InsertCallback on a voice
     in the middle of the graph (a group: inline; panmix; xinsert), and the buffered
     variants a2_OpenSink / a2_OpenSource (STREAMS).  The sink is handed what it is
@@ -188,7 +188,7 @@ def test_dropin_serves_sink_and_source_clients(tmp_path, script, frames, clients
         if "KILL" in clients:
             env["A2REF_KILL"] = str(frames // 2)
         if preload:
-            env["LD_PRELOAD"] = UNITS_SO
+            env["LD_PRELOAD"] = preload_libs(walk)
         r = subprocess.run([REF_RENDER, f"{A2S}/{script}.a2s", "Main", str(frames), str(buffer), "48000", "2", str(out), "0.1"],
                            env=env, cwd=A2S, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-500:]
@@ -266,7 +266,7 @@ def test_engine_with_dropin_units_matches_reference_run(tmp_path, name, args, fr
         out = tmp_path / f"{name}{pre}.pcm"
         env = dict(os.environ)
         if pre:
-            env["LD_PRELOAD"] = preload(pre == 2)
+            env["LD_PRELOAD"] = preload_libs(pre == 2)
         subprocess.run([REF_RENDER, f"{A2S}/{name}.a2s", "Main", str(frames), "64", "48000", "2", str(out)] + args,
                        check=True, env=env, cwd=A2S, timeout=900)
         outs.append(np.fromfile(out, dtype="<i4"))
@@ -548,8 +548,10 @@ def test_engine_in_loop_at_measured_sizes_matches_cpu_units(program, voices, buf
     assert g["hashes"][0] == want, f"{program} x {voices}, a2_Run({buffer}), {variant}: audio differs"
     if variant == "walk":
         # the short cut was taken: most visits of sleeping voices were skipped
-        skipped, made = g["walk_stats"]
-        assert skipped > made if "Scripted" not in program else skipped > 0, g["walk_stats"]
+        skipped, made, unread = g["walk_stats"]
+        assert skipped > made if "Scripted" not in program and voices < 262144 else skipped > 0, g["walk_stats"]
+        # ... and most of those without touching the voice: the lists were taken from memory
+        assert unread > skipped // 2 if "Scripted" not in program else unread > 0, g["walk_stats"]
 
 
 def test_walk_hands_voices_to_the_engine_one_by_one_without_changing_anything(tmp_path):
