@@ -64,6 +64,14 @@ typedef struct LIST
 	unsigned	n, cap;
 	unsigned long long epoch;	/* e[0..n) was the whole list, in order, when the state's epoch had this value */
 	unsigned long long quiet_visit;	/* the parent was found asleep, without events, for the window of this visit */
+	/* the whole list in one test: every voice of it sleeps, reports through the map (or has nothing
+	 * to report), and nothing about that can have changed while the epoch holds and no voice of
+	 * the list has been visited */
+	int		sum_ok;
+	unsigned long long sum_epoch;
+	uint32_t	sum_wake;	/* the earliest wake time in the list */
+	uint32_t	sum_dev, sum_lo, sum_cnt;	/* their bytes in the default map: one range of one context ... */
+	int		sum_range;	/* ... or not (then entry by entry) */
 } LIST;
 
 typedef struct WSTATE
@@ -302,7 +310,7 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 	WSTATE *w;
 	LIST *l;
 	unsigned k = 0, now;
-	int deflt, cached;
+	int deflt, cached, all_unread;
 	if(walk_off < 0)
 		bind_engine();
 	if(!engine_walk)
@@ -318,6 +326,19 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 	cached = w->served && !walk_nocache && !w->hooks_broken && l->n && l->epoch == w->epoch &&
 			l->quiet_visit && l->quiet_visit == w->cur_visit;
 	l->quiet_visit = 0;
+	if(cached && l->sum_ok && l->sum_epoch == w->epoch && deflt && (a2_TSDiff(l->sum_wake, now) >> 8) >= (int)frames &&
+			(!l->sum_cnt || l->sum_lo + l->sum_cnt <= w->view.map_cap[l->sum_dev]))
+	{
+		if(l->sum_range)
+			memset(w->view.map[l->sum_dev] + l->sum_lo, 1, l->sum_cnt);
+		else
+			for(k = 0; k < l->n; ++k)
+				mark_default(w, &l->e[k]);
+		w->skipped += l->n;
+		w->unread += l->n;
+		return;
+	}
+	all_unread = cached && deflt;
 	for(;;)
 	{
 		A2_voice *v, *last, *rest, *p;
@@ -365,6 +386,8 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 		}
 		/* everything else is the engine's business: its own loop, on this voice - and on the
 		 * voices behind it that need a visit as well - cut out of the list for the call */
+		all_unread = 0;
+		l->sum_ok = 0;
 		last = v;
 		if(cached)
 			while(run < 4096 && k + run < l->n && !entry_sleeps_unread(w, &l->e[k + run], now, frames, deflt))
@@ -434,6 +457,52 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 			head = &p->next;
 		}
 		*head = rest;
+	}
+	if(cached && all_unread && !l->sum_ok && l->n)
+	{
+		/* every voice of the list slept, unseen: next time one test will do (until a voice of the
+		 * list is visited again or the epoch moves) */
+		uint32_t lo = 0xffffffffu, hi = 0, cnt = 0, dev = l->e[0].slotdev >> 28;
+		int one_dev = 1, best = 0x7fffffff;
+		for(k = 0; k < l->n; ++k)
+		{
+			const ENT *e = &l->e[k];
+			const int d = a2_TSDiff(e->wake, now);
+			if(d < best)
+			{
+				best = d;
+				l->sum_wake = e->wake;
+			}
+			if(e->stamp == STAMP_NOUNITS)
+				continue;
+			if(!cnt)
+				dev = e->slotdev >> 28;
+			one_dev &= (e->slotdev >> 28) == dev;
+			if((e->slotdev & 0x0fffffffu) < lo)
+				lo = e->slotdev & 0x0fffffffu;
+			if((e->slotdev & 0x0fffffffu) > hi)
+				hi = e->slotdev & 0x0fffffffu;
+			++cnt;
+		}
+		l->sum_dev = dev;
+		l->sum_lo = cnt ? lo : 0;
+		l->sum_cnt = cnt;
+		/* (slots are unique: n of them between lo and hi = lo + n - 1 are exactly that range) */
+		l->sum_range = !cnt || (one_dev && hi - lo + 1 == cnt);
+		if(!l->sum_range)
+		{
+			/* entry by entry, then: bound by the smallest map */
+			l->sum_lo = 0;
+			l->sum_cnt = 0;
+			for(k = 0; k < l->n; ++k)
+				if(l->e[k].stamp != STAMP_NOUNITS &&
+						(l->e[k].slotdev & 0x0fffffffu) >= w->view.map_cap[l->e[k].slotdev >> 28])
+					break;
+			if(k < l->n)
+				return;
+		}
+		l->sum_epoch = w->epoch;
+		l->sum_ok = 1;
 	}
 	if(!cached)
 	{

@@ -528,7 +528,10 @@ ENGINE_SIZES = [(p, v, var, b) for p, v in (("OscPan", 65536), ("OscFilterPan", 
                                             ("OscPanScripted", 16384), ("OscFilterPanScripted", 16384))
                 for var, b in (("ahead12", 64), ("ahead12", 4096), ("ahead0", 64), ("walk", 64), ("walk", 4096))]
 # BASELINE configs[4]'s voice tree in ONE engine state: 8 top-level groups x 128 sub-groups x 256 voices
-ENGINE_SIZES += [("FilterTree", 262144, "ahead12", 64), ("FilterTree", 262144, "walk", 64), ("FilterTree", 262144, "walk", 4096)]
+ENGINE_SIZES += [("FilterTree", 262144, "ahead12", 64), ("FilterTree", 262144, "walk", 64), ("FilterTree", 262144, "walk", 4096),
+                 # ... with the 8 top-level groups dealt over 8 backend contexts (A2AMD_DEVICES=8: the 8-GPU
+                 # layout; on this box they share the GPU and the root-bus sum is the device-local add)
+                 ("FilterTree", 262144, "walk8", 4096)]
 
 
 @pytest.mark.gpu
@@ -541,12 +544,15 @@ def test_engine_in_loop_at_measured_sizes_matches_cpu_units(program, voices, buf
     need_ref()
     hf = 8 if voices >= 262144 else 16 if voices >= 65536 else 48
     want, active = _cpu_engine_hash(program, voices, buffer, hf)
-    g = bench.engine_run(program, voices, max(2 * hf, 2 * buffer // 64), buffer, True, hf, walk=variant == "walk",
-                         env_extra={"A2AMD_WALK_AHEAD": "0" if variant == "ahead0" else "12", "A2AMD_WALK_STATS": "1"})
+    extra = {"A2AMD_WALK_AHEAD": "0" if variant == "ahead0" else "12", "A2AMD_WALK_STATS": "1"}
+    if variant == "walk8":
+        extra["A2AMD_DEVICES"] = "8"
+    g = bench.engine_run(program, voices, max(2 * hf, 2 * buffer // 64), buffer, True, hf, walk=variant.startswith("walk"),
+                         env_extra=extra)
     assert "error" not in g, g
     assert g["active_voices"] == active >= voices
     assert g["hashes"][0] == want, f"{program} x {voices}, a2_Run({buffer}), {variant}: audio differs"
-    if variant == "walk":
+    if variant.startswith("walk"):
         # the short cut was taken: most visits of sleeping voices were skipped
         skipped, made, unread = g["walk_stats"]
         assert skipped > made if "Scripted" not in program and voices < 262144 else skipped > 0, g["walk_stats"]
