@@ -1166,12 +1166,15 @@ DEV void osc_write_s(const FastPtrs &g, OscS &o, int reg, int v, int start, int 
 enum { FS_Q = 0, FS_LP = 4, FS_BP, FS_HP, FS_F1, FS_D1, FS_D2, FS_F1NEXT, FS_RAMP, FS_NWORDS };
 struct FiltS { Ramp q; int lp, bp, hp, f1, d1, d2, f1next, ramp; };
 
-// (v_writelane_b32: one lane of a vector register from a scalar one; the lane select goes
-// through M0 - two scalar registers in one VOP3 are one too many for the constant bus)
+// (v_writelane_b32: one lane of a vector register from a scalar one.  Through the compiler's own
+// intrinsic - this clang has no __builtin for it, the name binds to llvm.amdgcn.writelane - the
+// lane select is routed through M0 by the compiler (two scalar registers in one VOP3 are one too
+// many for the constant bus), where round 2's inline asm named m0 as a clobber, which the
+// compiler does not promise to honour)
+extern "C" __device__ int a2d_writelane(int src, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 DEV int writelane_s(int y, int val, int sel)
 {
-	asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(y) : "s"(val), "s"(sel) : "m0");
-	return y;
+	return a2d_writelane(val, sel, y);
 }
 
 // One window of f12_process (filter12.c:74-119) over the frames a wavefront holds one per
@@ -1746,6 +1749,18 @@ int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc
 #ifndef FILT_BATCH
 #define FILT_BATCH  5	// settled voices whose coefficient loads are in flight together
 #endif
+#ifndef FILT_PARTNER
+#define FILT_PARTNER 0	// voices of an oscillator wavefront that shares the filter wavefront's SIMD
+#endif
+// Two shapes measured in round 3 and left switched off (tools/filt_sweep_*.sh, profiles/r03_filt_sweep.jsonl:
+// 1.25 - 1.38 ms against 1.26 ms per 256 fragments x 16 384 voices - the oscillator wavefronts that
+// sit next to a filter wavefront just wait longer at the barrier):
+#ifndef FILT_LIGHT
+#define FILT_LIGHT -1	// voices of an oscillator wavefront next to the OTHER workgroup's filter wavefront (-1: even share)
+#endif
+#ifndef FILT_ROT
+#define FILT_ROT 0	// 1: workgroups that share a CU put their filter wavefronts on different SIMDs
+#endif
 enum { FV_Q = 0, FV_LP = 4, FV_BP, FV_HP, FV_F1, FV_D1, FV_D2, FV_NWORDS };
 
 // one filter step (f12_process, filter12.c:98-117)
@@ -1817,7 +1832,12 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 #define FILT_FRAMES(f) ((int)rfl((int)p.fragframes[f]))
 #define FILT_START(f)  ((int)rfl((int)p.fragstart[f]))
 
-	if(wv == 0) {
+	// Which wavefront filters: wavefront w of a workgroup runs on SIMD w & 3, and the workgroups
+	// of a launch are dealt over the 256 CUs round robin - workgroups 256 apart share a CU.
+	// Their filter wavefronts (each a stream of dependent instructions that wants a SIMD's issue
+	// slots to itself) go to different SIMDs.
+	const int fw = FILT_ROT ? (int)((blockIdx.x >> 8) & 3u) : 0;
+	if(wv == fw) {
 		// ================= the filter wavefront: lane = voice =================
 		// (its dependent chain is the workgroup's critical path: first in line for
 		// the issue slots of the SIMD it shares with oscillator wavefronts)
@@ -1877,8 +1897,9 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 #endif
 		}
 #ifdef FILT_PROF
-		if(blockIdx.x == 7 && lane == 0 && nfrags > 100)
-			printf("filter wave: %lld cycles filtering, %lld waiting (%d fragments)\n", tb, tw, nfrags);
+		if((blockIdx.x == 7 || blockIdx.x == 263) && lane == 0 && nfrags > 100)
+			printf("block %d wave %d (filter, %d voices): %lld cycles filtering, %lld waiting (%d fragments)\n",
+					(int)blockIdx.x, wv, nv, tb, tw, nfrags);
 #endif
 		if(mine) {
 			int *w1 = ustate + (size_t)u1 * A2D_USTATE;
@@ -1892,13 +1913,40 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 	}
 
 	// ============ oscillator / pan wavefronts: lane = frame, voices [vb, ve) ============
-	// (every fourth wavefront of a workgroup lands on the SIMD of wavefront 0, the filter: those
-	// stay idle - they only meet the others at the barriers - so that the filter's dependent
-	// chain has its SIMD to itself: 1.34 -> 1.25 ms per 256 fragments at 16 384 voices)
-	const int noscw = FILT_WAVES - FILT_WAVES / 4;
-	const int ow = (wv & 3) ? wv - 1 - (wv >> 2) : -1;
-	const int per = (nv + noscw - 1) / noscw;
-	const int vb = ow < 0 ? nv : ow * per, ve = min(nv, vb + per);
+	// Every fourth wavefront of a workgroup lands on the SIMD of wavefront 0, the filter, whose
+	// stream of dependent instructions is the workgroup's critical path: those "partner"
+	// wavefronts take FILT_PARTNER voices each (0: they only meet the others at the barriers) -
+	// what the filter's SIMD has left over when the other three carry the rest of the
+	// oscillator / pan work - and the other wavefronts share the remaining voices evenly.
+	// With FILT_ROT two workgroups share a CU, their filter wavefronts on SIMDs fw and fw ^ 1: the
+	// oscillator wavefronts of THIS workgroup that run on SIMD fw ^ 1 sit next to the other
+	// workgroup's filter wavefront and take fewer voices ("light": FILT_LIGHT each, -1 = an even
+	// share), so that the four SIMDs of the CU carry about the same number of instructions.
+	const int npart = FILT_WAVES / 4 - 1;			// the other wavefronts on the filter's SIMD
+	const int nlight = (FILT_ROT && FILT_LIGHT >= 0) ? FILT_WAVES / 4 : 0;
+	const int nfull = FILT_WAVES - 1 - npart - nlight;
+	const int pshare = min(FILT_PARTNER, nv / (FILT_WAVES - 1));	// (never more than an even share)
+	const int lshare = nlight ? min(FILT_LIGHT, nv / (FILT_WAVES - 1)) : 0;
+	const int rem = nv - npart * pshare - nlight * lshare;
+	const int per = (rem + nfull - 1) / nfull;
+	const int sm = wv & 3;
+	int vb, ve;
+	if(sm == fw) {
+		const int pi = (wv >> 2) - 1;			// (wv >> 2 == 0 is the filter wavefront)
+		vb = rem + nlight * lshare + pi * pshare;
+		ve = min(nv, vb + pshare);
+	} else if(nlight && sm == (fw ^ 1)) {
+		vb = rem + (wv >> 2) * lshare;
+		ve = min(nv, vb + lshare);
+	} else {
+		// my index among the wavefronts of the SIMDs that hold no filter wavefront
+		int fi = 0;
+		for(int k = 0; k < sm; ++k)
+			fi += (k != fw && !(nlight && k == (fw ^ 1)));
+		fi += (wv >> 2) * (nlight ? 2 : 3);
+		vb = fi * per;
+		ve = min(rem, vb + per);
+	}
 	const int mv = max(0, ve - vb);		// my voices: lane l parks voice vb + l
 
 	int sv[SV_NWORDS], dv[DV_NWORDS];
@@ -2156,8 +2204,9 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 #endif
 	}
 #ifdef FILT_PROF
-	if(blockIdx.x == 7 && lane == 0 && wv == 1 && nfrags > 100)
-		printf("osc/pan wave (%d voices): %lld cycles issue+pan, %lld oscillators, %lld waiting\n", mv, ta, tc, tw);
+	if((blockIdx.x == 7 || blockIdx.x == 263) && lane == 0 && nfrags > 100)
+		printf("block %d wave %d (osc/pan, %d voices): %lld cycles issue+pan, %lld oscillators, %lld waiting\n",
+				(int)blockIdx.x, wv, mv, ta, tc, tw);
 #endif
 
 	if(mine) {

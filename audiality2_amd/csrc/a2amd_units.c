@@ -47,7 +47,6 @@ extern int a2r_Error(void *st, int e, const char *info) __attribute__((weak));
 extern int a2_XinsertRemoveClient(A2P_xinsert_client *xic) __attribute__((weak));
 
 #define WALK_AHEAD 32		/* most chain heads the walk's prefetch hints run ahead of the engine (look_ahead()) */
-#define MAXSTATES 256		/* engine states (master + substates) alive at once in one process */
 #define MAXDEV    8		/* GPUs one engine state may be spread over (A2AMD_DEVICES) */
 
 /* A2AMD_DEVICES > 1: what the engine asked of a voice before it was first processed -
@@ -107,6 +106,13 @@ typedef struct HOSTSTATE
 	uint32_t	stamp_ctr;
 	int		walker;		/* liba2amd_walk.so walks this state: no prefetch hints of our own */
 	unsigned	serial;		/* a number of its own for every engine state ever opened (a2amd_walkview) */
+	/* Engine states (master states and a2_Render's substates) come and go; their records are
+	 * allocated as needed, chained, and reused when a state has closed - never freed: the voice
+	 * walk of INTEGRATION.md option C holds pointers into them (a2amd_walkview). */
+	struct HOSTSTATE *next_state;
+	int		index;		/* position in that chain (A2AMD_DEVICE=all deals states over the GPUs by it) */
+	char		errmsg[160];	/* (a2r_Error keeps the pointer: realtime states post it to the API side) */
+	char		chainmsg[200];
 	/* the last WALK_AHEAD chain heads the engine called, oldest first from walk_pos
 	 * (look_ahead()); emptied whenever a unit goes away */
 	struct XTRA	*walk_ring[WALK_AHEAD];
@@ -145,7 +151,7 @@ typedef struct HOSTSTATE
 	int		rinj_used;
 } HOSTSTATE;
 
-static HOSTSTATE states[MAXSTATES];
+static HOSTSTATE *states;	/* chain of every record ever allocated; refs == 0: closed, reusable */
 static pthread_mutex_t states_mtx = PTHREAD_MUTEX_INITIALIZER;	/* independent master states may open from different threads */
 
 /* Our per-instance data lives in the engine's 384 byte instance block: right
@@ -209,12 +215,12 @@ static inline XTRA *xtra(A2P_unit *u)
  * renders silence from here on. */
 static void fail(HOSTSTATE *hs, const char *what, int rc)
 {
-	static char msg[MAXSTATES][160];	/* (a2r_Error keeps the pointer: realtime states post it to the API side) */
+	static char nostate[160];
 	char *m;
 	if(hs && hs->failed)
 		return;
-	m = msg[hs ? hs - states : 0];
-	snprintf(m, sizeof(msg[0]), "a2amd: %s failed (%d): %s", what, rc, a2amd_last_error(NULL));
+	m = hs ? hs->errmsg : nostate;
+	snprintf(m, sizeof(nostate), "a2amd: %s failed (%d): %s", what, rc, a2amd_last_error(NULL));
 	if(hs)
 		hs->failed = 1;
 	if(a2r_Error && hs && hs->engine_state)
@@ -244,7 +250,7 @@ static const A2P_unitdesc *orig_desc(const char *sym)
 /* ---- state open / close (A2_unitdesc.OpenState / CloseState) -------------*/
 static int amd_open(A2P_config *cfg, void **statedata)
 {
-	int i, f = -1, rc = 0;
+	int rc = 0;
 	/* No GPU: fail where the engine can still fail cleanly - a2_RegisterUnit()
 	 * returns the error and a2_Open() hands it to the application
 	 * (src/units.c:142-146, src/audiality2.c:256-260).  (The backend itself is opened
@@ -255,28 +261,41 @@ static int amd_open(A2P_config *cfg, void **statedata)
 		return A2P_DEVICEOPEN;
 	}
 	pthread_mutex_lock(&states_mtx);
-	for(i = 0; i < MAXSTATES; ++i)
-		if(states[i].refs && states[i].cfg == cfg)
-		{
-			++states[i].refs;
-			*statedata = &states[i];
-			pthread_mutex_unlock(&states_mtx);
-			return 0;
-		}
-		else if(!states[i].refs && f < 0)
-			f = i;
-	if(f < 0)
-		rc = A2P_OOMEMORY;
-	else
 	{
 		static unsigned serials;
-		memset(&states[f], 0, sizeof(HOSTSTATE));
-		states[f].cfg = cfg;
-		states[f].refs = 1;
-		if(!++serials)
-			++serials;
-		states[f].serial = serials;
-		*statedata = &states[f];
+		HOSTSTATE *hs, *freeone = NULL, **tail = &states;
+		int n = 0;
+		for(hs = states; hs; tail = &hs->next_state, hs = hs->next_state, ++n)
+			if(hs->refs && hs->cfg == cfg)
+			{
+				++hs->refs;
+				*statedata = hs;
+				pthread_mutex_unlock(&states_mtx);
+				return 0;
+			}
+			else if(!hs->refs && !freeone)
+				freeone = hs;
+		if(!freeone && (freeone = (HOSTSTATE *)calloc(1, sizeof(HOSTSTATE))))
+		{
+			freeone->index = n;
+			*tail = freeone;
+		}
+		if(!freeone)
+			rc = A2P_OOMEMORY;
+		else
+		{
+			HOSTSTATE *nx = freeone->next_state;
+			const int ix = freeone->index;
+			memset(freeone, 0, sizeof(HOSTSTATE));
+			freeone->next_state = nx;
+			freeone->index = ix;
+			freeone->cfg = cfg;
+			freeone->refs = 1;
+			if(!++serials)
+				++serials;
+			freeone->serial = serials;
+			*statedata = freeone;
+		}
 	}
 	pthread_mutex_unlock(&states_mtx);
 	return rc;
@@ -309,7 +328,13 @@ static void amd_close(void *statedata)
 			free(hs->acc[c]);
 			free(hs->rinj[c]);
 		}
-		memset(hs, 0, sizeof(*hs));
+		{
+			HOSTSTATE *nx = hs->next_state;
+			const int ix = hs->index;
+			memset(hs, 0, sizeof(*hs));	/* (refs = 0: free for the next state; serial = 0: a2amd_walkview) */
+			hs->next_state = nx;
+			hs->index = ix;
+		}
 	}
 	pthread_mutex_unlock(&states_mtx);
 }
@@ -334,7 +359,7 @@ static a2amd_ctx *ctx_of(HOSTSTATE *hs)
 		if(getenv("A2AMD_DEVICE") && !strcmp(getenv("A2AMD_DEVICE"), "all"))
 		{
 			int n = a2amd_device_count();
-			c.device = n > 0 ? (int)(hs - states) % n : 0;
+			c.device = n > 0 ? hs->index % n : 0;
 		}
 		/* fragments recorded per GPU round trip: a whole driver buffer, up to 256
 		 * (A2AMD_BATCH=1: one round trip per root window, as in round 1) */
@@ -636,8 +661,8 @@ static void check_chain_behind(A2P_unit *u)
 		{
 			/* reported once per voice through the engine's error channel; that
 			 * unit keeps processing the silence in its CPU buffers */
-			static char msg[200];
-			snprintf(msg, sizeof(msg), "a2amd: unit '%s' sits behind a GPU-rendered '%s' in one voice "
+			char *msg = x->hs->chainmsg;	/* (per state: a2r_Error keeps the pointer) */
+			snprintf(msg, sizeof(x->hs->chainmsg), "a2amd: unit '%s' sits behind a GPU-rendered '%s' in one voice "
 					"but is not replaced: it processes silence (mixed CPU/GPU chains are "
 					"not supported, no CPU fallback)", n->descriptor->name, u->descriptor->name);
 			if(a2r_Error && x->hs->engine_state)
@@ -965,10 +990,10 @@ static void flush_batch(HOSTSTATE *hs)
 
 static HOSTSTATE *state_of_config(A2P_config *cfg)
 {
-	int i;
-	for(i = 0; i < MAXSTATES; ++i)
-		if(states[i].refs && states[i].cfg == cfg)
-			return &states[i];
+	HOSTSTATE *hs;
+	for(hs = states; hs; hs = hs->next_state)
+		if(hs->refs && hs->cfg == cfg)
+			return hs;
 	return NULL;
 }
 
@@ -1434,8 +1459,12 @@ static void amd_rootx_process(A2P_unit *u, unsigned offset, unsigned frames)
 		}
 		else if(!x->refused)
 		{
-			/* (attached after the buffer began: served from the next one) */
+			/* attached after the buffer began (a timestamped a2_InsertCallback landing in the
+			 * middle of a batched buffer): served from the next buffer on - and said so, once,
+			 * since the reference would have replaced the master bus from this window on */
 			x->refused = 1;
+			client_error(hs->root_xi, A2P_NOTIMPLEMENTED, "a2amd: insert client attached to the root voice in the "
+					"middle of a buffer: it takes effect with the next a2_Run() buffer");
 		}
 	}
 }
@@ -1824,6 +1853,8 @@ static void x_deinit(const char *sym, A2P_unit *u)
 		for(n = k = 0; k < hs->npend; ++k)
 			if((A2P_unit *)hs->pend[k].xi != u)
 				hs->pend[n++] = hs->pend[k];
+			else if(hs->pend[k].insert && hs->ninserts > 0)
+				--hs->ninserts;		/* (render_batch pauses for insert windows only while there are some) */
 		hs->npend = n;
 	}
 	amd_deinit(u);
@@ -1854,12 +1885,12 @@ const A2P_unitdesc a2_xsource_unitdesc = { "xsource", A2P_XINSERT, NULL, NULL, N
 /* ---- INTEGRATION.md option C: what liba2amd_walk.so (a2amd_walk.c) asks of the units --------*/
 int a2amd_units_walkview(const void *cfg, a2amd_walkview *out)
 {
-	int i, rc = -1;
+	HOSTSTATE *hs;
+	int rc = -1;
 	pthread_mutex_lock(&states_mtx);
-	for(i = 0; i < MAXSTATES; ++i)
-		if(states[i].refs && states[i].cfg == cfg)
+	for(hs = states; hs; hs = hs->next_state)
+		if(hs->refs && hs->cfg == cfg)
 		{
-			HOSTSTATE *hs = &states[i];
 			out->cfg = cfg;
 			out->map = hs->map;
 			out->map_cap = hs->map_cap;

@@ -296,7 +296,9 @@ def engine_in_loop(cases=None, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fr
                 e = {"cpu_units_voice_samples_per_s": c["voice_samples_per_s"], "hash_fragments": hf,
                      "cpu_hash": c["hashes"][0]}
                 for mode, walk in modes:
-                    g = engine_run(program, voices, nfr, buf, True, hf, walk=walk)
+                    # (without the walk's short cut a fragment costs ~40 ns per voice of engine walk: bound the run)
+                    nrun = nfr if walk else max(hf, buf // 64, min(nfr, int(2.5e6 / (voices * 0.04))))
+                    g = engine_run(program, voices, nrun, buf, True, hf, walk=walk)
                     if "error" in g:
                         e[mode] = {"error": g["error"]}
                         all_equal = False
@@ -325,18 +327,50 @@ def engine_in_loop(cases=None, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fr
 def pmc_entry(chain, voices, groups, B):
     """PMC-derived figures for this workload's dominant kernel (profiles/*.json, tools/pmc_summary.py)."""
     key = f"{chain}/{voices}/{groups}/{B}"
-    for name in ("r02_pmc.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
         except (OSError, ValueError):
             continue
         if key in d:
-            return d[key]
+            return dict(d[key], file=f"profiles/{name}")
         old = f"{chain}/{voices}/{B}"
         if not groups and old in d:
-            return d[old]
+            return dict(d[old], file=f"profiles/{name}")
     return {}
+
+
+_CODE_SHA = None
+
+
+def kernel_code_sha(kernel):
+    """Hash of the kernel's disassembly in the liba2amd.so THIS run loaded (tools/isa_mix.py):
+    figures kept under profiles/ carry the hash of the binary they were measured on."""
+    global _CODE_SHA
+    if _CODE_SHA is None:
+        _CODE_SHA = {}
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import hashlib
+            import isa_mix
+            for name, ins in isa_mix.extract():
+                _CODE_SHA[name] = hashlib.sha256("\n".join(f"{m} {ops}" for _, m, ops, _ in ins).encode()).hexdigest()[:16]
+        except Exception as e:  # noqa: BLE001  (no llvm-objdump on the box: say so in the line)
+            _CODE_SHA = {"error": str(e)}
+    for name, sha in _CODE_SHA.items():
+        if kernel in name and "commit" not in name:
+            return sha
+    return None
+
+
+def valu_mix_entry(kernel):
+    """The measured issue rate of the kernel's own instruction mix (tools/valu_mix.py)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_valu_mix.json")) as f:
+            return json.load(f)["kernels"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 class Runner:
@@ -514,6 +548,29 @@ def measure_single(audiality2_amd, cfg, B, steps, warmup, device=0, with_realtim
     return res
 
 
+def realtime_sweep(audiality2_amd, device=0, chain="osc-filter-pan", sizes=(65536, 131072, 262144, 524288), n=200):
+    """The other half of BASELINE's metric - max realtime voices - on the GPU side: the largest
+    N for which ONE 64-frame fragment of N sustained voices (wtosc->filter12->panmix, the
+    north-star's voice) makes the full synchronous round trip (record, upload, kernels, master
+    bus back on the host) in p99 <= 1.333 ms.  The engine's own CPU voice walk is not in this
+    figure; engine_in_loop has the same with the reference engine calling a2_Run(64)."""
+    rows, best = [], 0
+    for nv in sizes:
+        r = Runner(audiality2_amd, nv, chain, 0, 1, device)
+        r.run(2)                    # voices are born, one quiet fragment
+        rt = r.realtime(n)
+        r.close()
+        rows.append({k: rt[k] for k in ("voices", "fragment_ms_p50", "fragment_ms_p99", "fragment_ms_max", "holds_realtime")})
+        if rt["holds_realtime"]:
+            best = nv
+        else:
+            break
+    return {"chain": chain, "budget_ms": 64.0 / 48000.0 * 1e3, "max_realtime_voices": best,
+            "largest_size_tried": rows[-1]["voices"], "sweep": rows,
+            "scope": "GPU side: a2amd_fragment_repeat(64, 1) + a2amd_render(UPLOAD|SUBTREES|ROOT|READBACK), synchronous, "
+                     "per 64-frame fragment; one MI355X"}
+
+
 def roofline_objects(res, B):
     chain, voices, groups = res["chain"], res["voices"], res["groups"]
     bpvf = BYTES_PER_VOICE_FRAGMENT[chain]
@@ -535,16 +592,40 @@ def roofline_objects(res, B):
         roof["other_kernels"] = (f"{groups} group chains inline->fbdelay->fbdelay + the root chain: "
                                  f"{2 * groups * FBDELAY_BYTES_PER_FRAGMENT * B / 1e6:.1f} MB algorithmic per step")
     ipvf = pmc.get("valu_insts_per_voice_fragment")
-    valu = {"bound": "valu-issue", "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
-            "kernel": roof["kernel"], "valu_insts_per_voice_fragment": ipvf,
+    kern = roof["kernel"]
+    sha_now = kernel_code_sha(kern)
+    sha_pmc = pmc.get("code_sha")
+    # counters are not collected in this run (separate rocprofv3 passes: tools/profile_round3.sh);
+    # what is quoted from profiles/ says which binary it was measured on
+    roof["traffic_source"] = {"file": pmc.get("file"), "measured_on_code_sha": sha_pmc, "this_run_code_sha": sha_now,
+                              "stale": (sha_pmc != sha_now) if (sha_pmc and sha_now) else None}
+    mix = valu_mix_entry(kern)
+    hot = (mix or {}).get("hot_loops", {}).get("taps") or {}
+    meas = hot.get("measured") or {}
+    mix_peak = max((v.get("independent_T", 0.0) for v in meas.values() if isinstance(v, dict)), default=0.0) or None
+    mix_dep = max((v.get("as_in_kernel_T", 0.0) for v in meas.values() if isinstance(v, dict)), default=0.0) or None
+    valu = {"bound": "valu-issue", "peak": mix_peak or VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
+            "peak_is": ("the measured rate at which the SIMDs issue THIS kernel's hot-loop instruction mix with independent "
+                        "operands (tools/isa_mix.py reads the mix off the shipped binary, tools/ubench/valu_mix.hip issues it)")
+            if mix_peak else "nominal (no mix measurement for this kernel under profiles/)",
+            "nominal_peak": VALU_PEAK_TLANEOPS,
+            "nominal_peak_is": "256 CU x 4 SIMD x 16 lanes x 2.4 GHz: every wave64 instruction taken as 4 cycles",
+            "mix_rate_with_the_kernels_dependencies": mix_dep,
+            "mix": {"fraction_2_cycle": hot.get("fraction_2_cycle"), "by_class": hot.get("by_class"),
+                    "additive_model_T": hot.get("additive_mix_rate_T_lane_ops"),
+                    "measured_on_code_sha": (mix or {}).get("code_sha"), "this_run_code_sha": sha_now,
+                    "stale": ((mix or {}).get("code_sha") != sha_now) if (mix and sha_now) else None},
+            "kernel": kern, "valu_insts_per_voice_fragment": ipvf,
             "source": pmc.get("source", "no PMC summary for this workload under profiles/"),
-            "note": "wave-level VALU instructions per voice-fragment (PMC SQ_INSTS_VALU / voice-fragments) x 64 "
-                    "lanes / kernel time, against 256 CU x 4 SIMD x 16 lanes x 2.4 GHz"}
+            "insts_measured_on_code_sha": sha_pmc,
+            "note": "achieved = wave-level VALU instructions per voice-fragment (PMC SQ_INSTS_VALU / voice-fragments, "
+                    "separate rocprofv3 pass) x 64 lanes / this run's kernel time"}
     if ipvf and leaf_s > 0:
         valu["achieved"] = ipvf * 64.0 * voices * B / leaf_s / 1e12
-        valu["frac"] = valu["achieved"] / VALU_PEAK_TLANEOPS
+        valu["frac"] = valu["achieved"] / valu["peak"]
+        valu["frac_of_nominal"] = valu["achieved"] / VALU_PEAK_TLANEOPS
     else:
-        valu["achieved"] = valu["frac"] = None
+        valu["achieved"] = valu["frac"] = valu["frac_of_nominal"] = None
     return roof, valu
 
 
@@ -652,10 +733,14 @@ def main():
                 "timing": "HIP events around the batch's kernels; the engine-in-the-loop figure for this "
                           "variant is in profiles/ (tests/measure/engine_in_loop.py)"}
             line["other_configs"] = extra
+        if not args.no_realtime and not custom and args.config == 3:
+            line["max_realtime_voices"] = realtime_sweep(audiality2_amd, local_rank)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg["voices"], cfg["chain"], cfg["groups"])
         if not args.no_engine and not custom and args.config == 3:
             line["engine_in_loop"] = engine_in_loop()
+            if "max_realtime_voices" in line and "max_realtime_voices_one_engine_state" in line["engine_in_loop"]:
+                line["max_realtime_voices"]["engine_in_loop"] = line["engine_in_loop"]["max_realtime_voices_one_engine_state"]
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)

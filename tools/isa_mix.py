@@ -218,8 +218,8 @@ def sregs_written(m, ops):
     out = set()
     first = ops.split(",")[0].strip() if ops else ""
     cands = [first]
-    if "_co_" in m and "," in ops:
-        cands.append(ops.split(",")[1].strip())
+    if ("_co_" in m or m.startswith(("v_mad_u64_u32", "v_mad_i64_i32", "v_div_scale"))) and "," in ops:
+        cands.append(ops.split(",")[1].strip())     # (the carry / flag output)
     for c in cands:
         mm = re.match(r"s\[(\d+):(\d+)\]$", c)
         if mm:
@@ -239,6 +239,8 @@ def emit(body, path, name):
     for _, m, ops, _ in body:
         if not is_valu(m) or m.startswith("v_cmpx") or "exec" in ops.split(",")[0]:
             continue
+        if not (base_mnemonic(m) in RATE_NAME or m.endswith("_sdwa")):
+            continue        # (compares, conversions, the division helper of the cold path: not part of the hot mix)
         if sregs_written(m, ops) & set(range(0, 34)):
             continue        # (would overwrite the benchmark kernel's own arguments)
         kept.append((m, ops))

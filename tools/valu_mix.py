@@ -39,7 +39,7 @@ def main():
                 exe = os.path.join(ub, "variants", f"valu_mix_{tag}")
                 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-w", f"-DMIX_INC=\"variants/mix_{tag}.inc\"",
                                 "-o", exe, "valu_mix.hip"], cwd=ub, check=True)
-                r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+                r = subprocess.run(["timeout", "120", exe], capture_output=True, text=True)
                 try:
                     meas = json.loads(r.stdout.strip().splitlines()[-1])
                 except (ValueError, IndexError):
