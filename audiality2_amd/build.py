@@ -41,13 +41,35 @@ def build_units(force=False):
     return out
 
 
+def build_walk(force=False, engine=None):
+    """INTEGRATION.md option C: liba2amd_walk.so, the engine's voice walk with the short cut for
+    sleeping voices.  Compiled against the ENGINE's internal headers (src/internals.h), so it
+    is built where the engine's source tree is (A2_ENGINE_SRC, default /root/reference) and for
+    that engine version; elsewhere the library built before travels as it is."""
+    engine = engine or os.environ.get("A2_ENGINE_SRC", "/root/reference")
+    out = os.path.join(HERE, "liba2amd_walk.so")
+    if not (os.path.exists(os.path.join(engine, "src", "internals.h")) and shutil.which("cmake")):
+        return out if os.path.exists(out) else None
+    src = os.path.join(HERE, "csrc", "a2amd_walk.c")
+    inc = os.path.join(HERE, "_engine_include")
+    deps = [src, os.path.join(ROOT, "include", "a2amd_walk.h"), os.path.join(HERE, "liba2amd_units.so")]
+    if force or _newer(out, deps):
+        subprocess.run(["cmake", f"-DENGINE={engine}", f"-DOUT={inc}", "-P", os.path.join(HERE, "csrc", "engine_header.cmake")],
+                       check=True, stdout=subprocess.DEVNULL)
+        subprocess.run(["gcc", "-O2", "-Wall", "-fPIC", "-shared", "-I" + inc] +
+                       ["-I" + os.path.join(engine, d) for d in ("include", "src", "src/units", "src/drivers")] +
+                       ["-o", out, src, "-L" + HERE, "-la2amd_units", "-la2amd", "-ldl", "-lpthread", "-Wl,-rpath,$ORIGIN"],
+                       check=True)
+    return out
+
+
 def build_oracle(force=False):
     """Test infrastructure: the CPU restatement and, when the reference tree
     is present, the compiled reference + its harness (oracle/_ref)."""
     odir = os.path.join(ROOT, "oracle")
     targets = ["restate"]
     if os.path.exists("/root/reference/src/core.c") and shutil.which("cmake"):
-        targets += ["ref", "tools", "optionb", "optionc"]    # (optionb / optionc link the drop-in built just before)
+        targets += ["ref", "tools", "optionb"]    # (optionb links the drop-in built just before)
     subprocess.run(["make", "-s", "-C", odir] + (["-B"] if force else []) + targets, check=True)
     return os.path.join(odir, "liba2oracle.so")
 
@@ -55,4 +77,5 @@ def build_oracle(force=False):
 def build_all(force=False):
     lib = build_lib(force)
     build_units(force)
+    build_walk(force)
     return lib, build_oracle(force)

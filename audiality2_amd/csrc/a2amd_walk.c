@@ -29,7 +29,7 @@
  * the engine's event sends: the test reads A2_voice.events and A2_vmstate.waketime directly.
  *
  * Compiled against the engine's INTERNAL headers (src/internals.h: A2_voice, A2_state), which
- * is why it is a separate library with its own recipe (oracle/Makefile, target optionc): it is
+ * is why it is a separate library with its own recipe (build.py: build_walk): it is
  * locked to the engine version it was built for, and the compiler checks every field it
  * touches.  The engine binary itself is unmodified; all it has to be is what a default -fPIC
  * build is - a library that calls its own a2_ProcessVoices through the PLT.

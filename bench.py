@@ -216,7 +216,7 @@ ENGINE_CASES = [   # label, program of tests/a2s/bench.a2s, voices
 ENGINE_BUFFERS = (4096, 64)     # a2play's offline buffer; one fragment per a2_Run() = a realtime driver's
 
 
-WALK_SO = os.path.join(ROOT, "oracle", "_ref", "liba2amd_walk.so")
+WALK_SO = os.path.join(ROOT, "audiality2_amd", "liba2amd_walk.so")
 
 
 def engine_run(program, voices, fragments, buffer, dropin, hash_fragments=0, env_extra=None, wait=True, walk=False):

@@ -15,7 +15,7 @@ from conftest import GOLDEN, ROOT, differing_fragments, fnv1a_fragments
 REF_RENDER = os.path.join(ROOT, "oracle", "_ref", "ref_render")
 UNITS_SO = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
 # INTEGRATION.md option C: the replacement of the engine's voice walk, in front of the units
-WALK_SO = os.path.join(ROOT, "oracle", "_ref", "liba2amd_walk.so")
+WALK_SO = os.path.join(ROOT, "audiality2_amd", "liba2amd_walk.so")
 A2S = os.path.join(ROOT, "tests", "a2s")
 
 
@@ -567,7 +567,7 @@ def test_walk_hands_voices_to_the_engine_one_by_one_without_changing_anything(tm
     drop-in does not serve): notes born and dying all the time, groups, delay buses."""
     need_ref()
     if not os.path.exists(WALK_SO):
-        pytest.skip("oracle/_ref/liba2amd_walk.so not built")
+        pytest.skip("audiality2_amd/liba2amd_walk.so not built")
     for script, arg, frames in (("scripted", "0.2", 48000), ("song", "0.08", 96000), ("churn", "0.05", 96000),
                                 ("delaybus", "2", 24000)):
         outs = []

@@ -14,7 +14,7 @@ from fuzz_scripts import make_script
 
 REF_RENDER = os.path.join(ROOT, "oracle", "_ref", "ref_render")
 UNITS_SO = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
-WALK_SO = os.path.join(ROOT, "oracle", "_ref", "liba2amd_walk.so")     # INTEGRATION.md option C
+WALK_SO = os.path.join(ROOT, "audiality2_amd", "liba2amd_walk.so")     # INTEGRATION.md option C
 SECONDS = 1.5
 
 

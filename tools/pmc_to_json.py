@@ -15,7 +15,21 @@ import sys
 LEAF = {"osc-pan": "k_leaf_oscpan", "osc-filter-pan": "k_leaf_oscfiltpan", "osc2-pan": "k_leaf_osc2pan"}
 
 
+def code_shas():
+    """kernel symbol -> hash of its disassembly in the liba2amd.so the counters were collected on"""
+    import hashlib
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    try:
+        import isa_mix
+        return {n: hashlib.sha256("\n".join(f"{m} {ops}" for _, m, ops, _ in ins).encode()).hexdigest()[:16]
+                for n, ins in isa_mix.extract()}
+    except Exception:  # noqa: BLE001
+        return {}
+
+
 def main():
+    shas = code_shas()
     merged = {}
     for line in open(sys.argv[1]):
         if not line.startswith("JSON "):
@@ -28,7 +42,7 @@ def main():
         chain, voices, groups, B = label.split("/")
         voices, groups, B = int(voices), int(groups), int(B)
         leaf = LEAF.get(chain, "k_leaf_fmpan")
-        e = {"kernel": leaf, "source": f"rocprofv3 --pmc passes of bench.py --config shape {label} (tools/profile_round2.sh), "
+        e = {"kernel": leaf, "source": f"rocprofv3 --pmc passes of bench.py --config shape {label} (tools/profile_round3.sh), "
                                        "median launch", "kernels": {}}
         for k, d in kernels.items():
             kd = dict(d)
@@ -40,6 +54,7 @@ def main():
             if "SQ_ACTIVE_INST_VALU" in d and "SQ_WAVE_CYCLES" in d and d["SQ_WAVE_CYCLES"]:
                 kd["valu_active_over_wave_cycles"] = d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"]
             e["kernels"][k] = kd
+        e["code_sha"] = next((h for n, h in shas.items() if leaf in n and "commit" not in n), None)
         lk = e["kernels"].get(leaf, {})
         e["hbm_bytes_per_launch"] = lk.get("hbm_bytes_per_launch")
         e["valu_insts_per_voice_fragment"] = lk.get("insts_valu_per_voice_fragment")
