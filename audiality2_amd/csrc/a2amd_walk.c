@@ -57,10 +57,18 @@ typedef struct ENT
 	uint32_t	flags;		/* E_* */
 } ENT;
 
+/* ... and what the engine will touch when it visits that voice: its unit blocks (prefetch hints
+ * for the voices that are handed to the engine's loop, never dereferenced here) */
+typedef struct UPTR
+{
+	A2_unit		*u[3];
+} UPTR;
+
 typedef struct LIST
 {
 	A2_voice	**head;		/* the list: &parent->sub (key) */
 	ENT		*e;
+	UPTR		*up;		/* (parallel to e) */
 	unsigned	n, cap;
 	unsigned long long epoch;	/* e[0..n) was the whole list, in order, when the state's epoch had this value */
 	unsigned long long quiet_visit;	/* the parent was found asleep, without events, for the window of this visit */
@@ -142,6 +150,7 @@ static WSTATE *wstate_of(A2_state *st)
 			if(w->lists[k])
 			{
 				free(w->lists[k]->e);
+				free(w->lists[k]->up);
 				free(w->lists[k]);
 			}
 		free(w->lists);
@@ -298,6 +307,25 @@ static inline int entry_sleeps_unread(const WSTATE *w, const ENT *e, unsigned no
 			entry_sleeps(w, e, e->wake, 1, now, frames, deflt);
 }
 
+/* the engine is about to visit this voice: the lines it will touch - the A2_voice's first line
+ * (events, wake time), the one with its flags, the one with 'units' and 'sub', and its unit
+ * blocks (A2_unit: next first, Process last - 64 bytes that usually straddle two lines; the
+ * drop-in's own data behind them) - are asked for now, a run of voices ahead of the calls */
+static inline void hint_visit(const A2_voice *v, const UPTR *up)
+{
+	int q;
+	__builtin_prefetch(v);
+	__builtin_prefetch(&v->flags);
+	__builtin_prefetch(&v->units);
+	for(q = 0; q < 3 && up->u[q]; ++q)
+	{
+		__builtin_prefetch(up->u[q]);
+		__builtin_prefetch((const char *)up->u[q] + 56);
+		if(!q)
+			__builtin_prefetch((const char *)up->u[q] + 128);
+	}
+}
+
 static inline void mark_default(const WSTATE *w, const ENT *e)
 {
 	if(e->stamp != STAMP_NOUNITS)
@@ -389,16 +417,21 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 		all_unread = 0;
 		l->sum_ok = 0;
 		last = v;
+		if(k < l->n && l->e[k].v == v)
+			hint_visit(v, &l->up[k]);
 		if(cached)
 			while(run < 4096 && k + run < l->n && !entry_sleeps_unread(w, &l->e[k + run], now, frames, deflt))
 			{
 				last = l->e[k + run].v;
+				hint_visit(last, &l->up[k + run]);
 				++run;
 			}
 		else
 			while(run < 4096 && last->next && !voice_sleeps(w, l, k + run, last->next, now, frames, deflt))
 			{
 				last = last->next;
+				if(k + run < l->n && l->e[k + run].v == last)
+					hint_visit(last, &l->up[k + run]);
 				++run;
 			}
 		/* a voice of the run that sleeps through the window with no events (a group voice: its
@@ -430,9 +463,12 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 			{
 				unsigned nc = l->cap ? l->cap * 2 : 16;
 				ENT *ne = (ENT *)realloc(l->e, nc * sizeof(ENT));
+				UPTR *nu = ne ? (UPTR *)realloc(l->up, nc * sizeof(UPTR)) : NULL;
 				if(ne)
-				{
 					l->e = ne;
+				if(nu)
+				{
+					l->up = nu;
 					l->cap = nc;
 				}
 			}
@@ -441,6 +477,13 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 				ENT *e = &l->e[kk];
 				if(kk >= l->n)
 					l->n = kk + 1;
+				A2_unit *pu = p->units;
+				int q;
+				for(q = 0; q < 3; ++q)
+				{
+					l->up[kk].u[q] = pu;
+					pu = pu ? pu->next : NULL;
+				}
 				e->v = p;
 				e->slotdev = 0;
 				e->wake = p->s.waketime;

@@ -548,15 +548,17 @@ def measure_single(audiality2_amd, cfg, B, steps, warmup, device=0, with_realtim
     return res
 
 
-def realtime_sweep(audiality2_amd, device=0, chain="osc-filter-pan", sizes=(65536, 131072, 262144, 524288), n=200):
+def realtime_sweep(audiality2_amd, device=0, chain="osc-filter-pan", sizes=(262144, 524288), n=200):
     """The other half of BASELINE's metric - max realtime voices - on the GPU side: the largest
     N for which ONE 64-frame fragment of N sustained voices (wtosc->filter12->panmix, the
-    north-star's voice) makes the full synchronous round trip (record, upload, kernels, master
+    north-star's voice, in BASELINE configs[4]'s tree: top-level groups of 128 sub-groups x 256
+    voices - under ONE bus every voice's mix-down lands on the same 512 bytes) makes the full
+    synchronous round trip (record, upload, kernels, master
     bus back on the host) in p99 <= 1.333 ms.  The engine's own CPU voice walk is not in this
     figure; engine_in_loop has the same with the reference engine calling a2_Run(64)."""
     rows, best = [], 0
     for nv in sizes:
-        r = Runner(audiality2_amd, nv, chain, 0, 1, device)
+        r = Runner(audiality2_amd, nv, chain, 0, 1, device, tree=CONFIGS[4]["tree"])
         r.run(2)                    # voices are born, one quiet fragment
         rt = r.realtime(n)
         r.close()
@@ -565,7 +567,8 @@ def realtime_sweep(audiality2_amd, device=0, chain="osc-filter-pan", sizes=(6553
             best = nv
         else:
             break
-    return {"chain": chain, "budget_ms": 64.0 / 48000.0 * 1e3, "max_realtime_voices": best,
+    return {"chain": chain, "tree": "top-level groups of 128 sub-groups x 256 voices (a2_NewGroup drivers)",
+            "budget_ms": 64.0 / 48000.0 * 1e3, "max_realtime_voices": best,
             "largest_size_tried": rows[-1]["voices"], "sweep": rows,
             "scope": "GPU side: a2amd_fragment_repeat(64, 1) + a2amd_render(UPLOAD|SUBTREES|ROOT|READBACK), synchronous, "
                      "per 64-frame fragment; one MI355X"}

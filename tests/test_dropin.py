@@ -524,14 +524,16 @@ def _cpu_engine_hash(program, voices, buffer, hf):
     return r["hashes"][0], r["active_voices"]
 
 
-ENGINE_SIZES = [(p, v, var, b) for p, v in (("OscPan", 65536), ("OscFilterPan", 16384), ("Osc2PanGroups", 65536),
-                                            ("OscPanScripted", 16384), ("OscFilterPanScripted", 16384))
-                for var, b in (("ahead12", 64), ("ahead12", 4096), ("ahead0", 64), ("walk", 64), ("walk", 4096))]
-# BASELINE configs[4]'s voice tree in ONE engine state: 8 top-level groups x 128 sub-groups x 256 voices
-ENGINE_SIZES += [("FilterTree", 262144, "ahead12", 64), ("FilterTree", 262144, "walk", 64), ("FilterTree", 262144, "walk", 4096),
-                 # ... with the 8 top-level groups dealt over 8 backend contexts (A2AMD_DEVICES=8: the 8-GPU
-                 # layout; on this box they share the GPU and the root-bus sum is the device-local add)
-                 ("FilterTree", 262144, "walk8", 4096)]
+ALL5 = (("ahead12", 64), ("ahead12", 4096), ("ahead0", 64), ("walk", 64), ("walk", 4096))
+ENGINE_SIZES = [(p, v, var, b) for p, v, vs in (
+    ("OscPan", 65536, ALL5[:1] + ALL5[2:]), ("OscFilterPan", 16384, ALL5),
+    # (every CPU leg of the two big grouped scenes costs half a minute and more: one buffer size each)
+    ("Osc2PanGroups", 65536, (("ahead12", 4096), ("walk", 4096))),
+    ("OscPanScripted", 16384, ALL5), ("OscFilterPanScripted", 16384, ALL5)) for var, b in vs]
+# BASELINE configs[4]'s voice tree in ONE engine state: 8 top-level groups x 128 sub-groups x 256 voices -
+# behind the replaced voice walk, and with the 8 top-level groups dealt over 8 backend contexts as well
+# (A2AMD_DEVICES=8: the 8-GPU layout; on this box they share the GPU and the root-bus sum is the device-local add)
+ENGINE_SIZES += [("FilterTree", 262144, "walk", 4096), ("FilterTree", 262144, "walk8", 4096)]
 
 
 @pytest.mark.gpu
