@@ -2566,6 +2566,24 @@ int a2amd_voice_process(a2amd_ctx *c, int head, unsigned offset, unsigned frames
 	return (dbgw & 2) ? 0 : 1;
 }
 
+int a2amd_voice_markable(a2amd_ctx *c, int ui)
+{
+	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live)
+		return c->fail(A2AMD_EINVAL, "markable: dead unit %d", ui);
+	const int vi = c->units[ui].voice;
+	const HVoice &v = c->voices[vi];
+	// (walked at least once: its output bus is resolved, its place in the launch order known)
+	if(!v.live || v.dying || !v.resolved || !v.started || (size_t)vi >= c->defmap.size())
+		return 0;
+	for(int k = 0; k < v.nunits; ++k) {
+		const HUnit &u = c->units[v.unit[k]];
+		if((u.kind == A2AMD_WTOSC && u.mode == A2D_OSC_NOISE) || u.xio_mode ||
+				(u.kind == A2AMD_FILTER12 && (u.cutoff.timer || u.cutoff.delta)))
+			return 0;
+	}
+	return 1;
+}
+
 int a2amd_voice_slot(a2amd_ctx *c, int ui)
 {
 	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live)

@@ -200,6 +200,24 @@ static inline void set_stamp(HOSTSTATE *hs, XTRA *x, int on)
 	}
 }
 
+/* room for the stamp of (context, slot); without it that voice simply keeps being visited */
+static void stamp_room(HOSTSTATE *hs, int dev, int slot)
+{
+	if((unsigned)slot >= hs->qstamp_cap[dev])
+	{
+		unsigned nc = hs->qstamp_cap[dev] ? hs->qstamp_cap[dev] : 1024;
+		uint32_t *nq;
+		while(nc <= (unsigned)slot)
+			nc *= 2;
+		if((nq = (uint32_t *)realloc(hs->qstamp[dev], nc * sizeof(uint32_t))))
+		{
+			memset(nq + hs->qstamp_cap[dev], 0, (nc - hs->qstamp_cap[dev]) * sizeof(uint32_t));
+			hs->qstamp[dev] = nq;
+			hs->qstamp_cap[dev] = nc;
+		}
+	}
+}
+
 static inline XTRA *xtra(A2P_unit *u)
 {
 	if(u->descriptor == &a2_inline_unitdesc || u->descriptor == &a2_xinsert_unitdesc ||
@@ -1261,19 +1279,7 @@ static int setup_simple_chain(A2P_unit *u)
 	if((slot = a2amd_voice_slot(XCTX(x), x->uid)) < 0)
 		return 0;
 	x->slot = slot;
-	if((unsigned)slot >= x->hs->qstamp_cap[x->dev])
-	{
-		unsigned nc = x->hs->qstamp_cap[x->dev] ? x->hs->qstamp_cap[x->dev] : 1024;
-		uint32_t *nq;
-		while(nc <= (unsigned)slot)
-			nc *= 2;
-		if((nq = (uint32_t *)realloc(x->hs->qstamp[x->dev], nc * sizeof(uint32_t))))
-		{
-			memset(nq + x->hs->qstamp_cap[x->dev], 0, (nc - x->hs->qstamp_cap[x->dev]) * sizeof(uint32_t));
-			x->hs->qstamp[x->dev] = nq;
-			x->hs->qstamp_cap[x->dev] = nc;
-		}	/* (else: no stamps for this voice - the walk keeps visiting it) */
-	}
+	stamp_room(x->hs, x->dev, slot);
 	set_stamp(x->hs, x, 0);
 	x->tail[0] = u->next;
 	x->tail[1] = u->next ? u->next->next : NULL;
@@ -1380,8 +1386,10 @@ static void amd_inline_process(A2P_unit *u, unsigned offset, unsigned frames)
 	}
 	if(x->pending)
 		route_voice(x);
-	if(hs->walk_ahead)
+	if(hs->walk_ahead && !hs->walker)
 		look_ahead(hs, x, u);
+	if(x->head && !(offset == hs->base && frames == hs->win_frames))
+		set_stamp(hs, x, 0);	/* (a window that is not the default one: group_standing()) */
 	forward_process(x, offset, frames);
 	if(hs->depth < 70)
 		hs->dev_stack[hs->depth] = x->dev;	/* (our subvoices' buses live where we do) */
@@ -1570,10 +1578,12 @@ static void amd_write(A2P_unit *u, int reg, int v, unsigned start, unsigned dur)
 		return;
 	}
 	/* (a voice that was reporting its default windows through the map calls in again) */
-	if(x->head && x->head->Process == amd_quick_process)
+	if(x->head)
 	{
-		x->head->Process = amd_head_process;
-		set_stamp(x->hs, (XTRA *)((char *)x->head + 64), 0);
+		/* (also a group voice: a2amd_units_standing() grants it again after the next visit) */
+		if(x->head->Process == amd_quick_process)
+			x->head->Process = amd_head_process;
+		set_stamp(x->hs, xtra(x->head), 0);
 	}
 	if(x->hs->failed)
 		return;
@@ -1908,11 +1918,62 @@ int a2amd_units_walkview(const void *cfg, a2amd_walkview *out)
 	return rc;
 }
 
+/* A voice whose chain starts with an inline unit - a group (a2_NewGroup's driver), a delay bus:
+ * its default window is Process(offset, frames) on each of its units and, in between, the walk of
+ * its subvoices.  When the walk finds the whole subtree asleep there is nothing in that but the
+ * backend's "this voice got its default window" - the same byte in the default map. */
+static uint32_t group_standing(A2P_unit *head, uint32_t *slotdev)
+{
+	XTRA *x = xtra(head);
+	HOSTSTATE *hs = x->hs;
+	A2P_unit *n;
+	if(!hs || x->is_root || x->pending || x->uid < 0 || hs->failed || hs->no_quick)
+		return 0;
+	if(!x->head)
+	{
+		/* first time: every unit of the chain ours and in the voice's context; the voice's slot */
+		int slot;
+		for(n = head; n; n = n->next)
+			if(!is_ours(n->descriptor) || xtra(n)->uid < 0 || xtra(n)->pending || xtra(n)->dev != x->dev)
+				return 0;
+		if((slot = a2amd_voice_slot(XCTX(x), x->uid)) < 0 || slot >= (1 << 28))
+			return 0;
+		x->slot = slot;
+		stamp_room(hs, x->dev, slot);
+		if((unsigned)slot >= hs->qstamp_cap[x->dev])
+			return 0;
+		for(n = head; n; n = n->next)
+			xtra(n)->head = head;
+	}
+	for(n = head; n; n = n->next)
+	{
+		const int k = xtra(n)->kind;
+		if((k == A2AMD_XINSERT || k == A2AMD_XSINK || k == A2AMD_XSOURCE) &&
+				(((A2P_xinsert *)n)->clients || xtra(n)->client_mode))
+		{
+			set_stamp(hs, x, 0);	/* clients want every window */
+			return 0;
+		}
+	}
+	if(!hs->qstamp[x->dev][x->slot])
+	{
+		if(a2amd_voice_markable(XCTX(x), x->uid) != 1)
+			return 0;
+		set_stamp(hs, x, 1);
+	}
+	*slotdev = (uint32_t)x->slot | ((uint32_t)x->dev << 28);
+	return hs->qstamp[x->dev][x->slot];
+}
+
 uint32_t a2amd_units_standing(const void *head_unit, uint32_t *slotdev)
 {
 	const A2P_unit *head = (const A2P_unit *)head_unit;
 	const XTRA *x;
-	if(!head || head->Process != amd_quick_process)
+	if(!head)
+		return 0;
+	if(head->descriptor == &a2_inline_unitdesc)
+		return group_standing((A2P_unit *)head, slotdev);
+	if(head->Process != amd_quick_process)
 		return 0;
 	x = (const XTRA *)((const char *)head + 64);
 	if((unsigned)x->slot >= x->hs->qstamp_cap[x->dev] || (unsigned)x->slot >= (1u << 28))

@@ -47,6 +47,7 @@
 #define STAMP_NOUNITS	0xffffffffu	/* a voice without units and without subvoices: nothing to do while it sleeps */
 #define E_NOEVENTS	1u		/* ENT.flags: its event queue was empty when it was last looked at */
 #define E_APIHANDLE	2u		/* ... it has an API handle: the application can send it events at any time */
+#define E_GROUP		4u		/* ... it has subvoices: it sleeps unseen only if their whole list does (ENT.sub) */
 
 typedef struct ENT
 {
@@ -55,6 +56,7 @@ typedef struct ENT
 	uint32_t	stamp;		/* a2amd_units_standing() when it was last visited; 0 = always visit */
 	uint32_t	wake;		/* A2_vmstate.waketime when it was last looked at */
 	uint32_t	flags;		/* E_* */
+	struct LIST	*sub;		/* E_GROUP: the list of its subvoices */
 } ENT;
 
 /* ... and what the engine will touch when it visits that voice: its unit blocks (prefetch hints
@@ -77,7 +79,9 @@ typedef struct LIST
 	 * the list has been visited */
 	int		sum_ok;
 	unsigned long long sum_epoch;
-	uint32_t	sum_wake;	/* the earliest wake time in the list */
+	uint32_t	sum_wake;	/* the earliest wake time in the list - and in the lists below it */
+	unsigned	*gidx, ng;	/* the entries with subvoices (E_GROUP), as of the summary */
+	unsigned long long sum_voices;	/* voices in the list and below */
 	uint32_t	sum_dev, sum_lo, sum_cnt;	/* their bytes in the default map: one range of one context ... */
 	int		sum_range;	/* ... or not (then entry by entry) */
 } LIST;
@@ -151,6 +155,7 @@ static WSTATE *wstate_of(A2_state *st)
 			{
 				free(w->lists[k]->e);
 				free(w->lists[k]->up);
+				free(w->lists[k]->gidx);
 				free(w->lists[k]);
 			}
 		free(w->lists);
@@ -264,6 +269,33 @@ void a2_VoiceFree(A2_state *st, A2_voice **head)
  * (core.c:1816-1823) with an empty event queue returns (waketime - now) >> 8 frames;
  * a2_VoiceProcess then makes ONE Process call per unit for the window if that is at least its
  * length.  'wake' / 'noevents': the voice's own fields, or what the entry remembers of them. */
+/* A whole list asleep: its summary holds (nothing was born or died, no voice of it was visited
+ * since), its earliest wake time - the lists below included - lies beyond the window, and the same
+ * goes for the subvoice lists of its group voices, whose own standing with the units is checked
+ * too.  O(lists), not O(voices). */
+static int list_sleeps(const WSTATE *w, const LIST *sl, unsigned now, unsigned frames)
+{
+	const a2amd_walkview *vw = &w->view;
+	unsigned g;
+	if(!sl || !sl->n || !sl->sum_ok || sl->sum_epoch != w->epoch || sl->epoch != w->epoch ||
+			(a2_TSDiff(sl->sum_wake, now) >> 8) < (int)frames ||
+			(sl->sum_cnt && sl->sum_lo + sl->sum_cnt > vw->map_cap[sl->sum_dev]))
+		return 0;
+	for(g = 0; g < sl->ng; ++g)
+	{
+		const ENT *e = &sl->e[sl->gidx[g]];
+		if(e->stamp != STAMP_NOUNITS)
+		{
+			const unsigned dev = e->slotdev >> 28, slot = e->slotdev & 0x0fffffffu;
+			if(!(slot < vw->map_cap[dev] && slot < vw->qstamp_cap[dev] && vw->qstamp[dev][slot] == e->stamp))
+				return 0;
+		}
+		if(!list_sleeps(w, e->sub, now, frames))
+			return 0;
+	}
+	return 1;
+}
+
 static inline int entry_sleeps(const WSTATE *w, const ENT *e, unsigned wake, int noevents, unsigned now,
 		unsigned frames, int deflt)
 {
@@ -271,15 +303,22 @@ static inline int entry_sleeps(const WSTATE *w, const ENT *e, unsigned wake, int
 	unsigned dev, slot;
 	if(!e->stamp || !noevents || (a2_TSDiff(wake, now) >> 8) < (int)frames)
 		return 0;
-	if(e->stamp == STAMP_NOUNITS)
-		return 1;
-	/* only the open root window - one backend fragment - can be reported through the map
-	 * (amd_quick_process, a2amd_units.c, makes the same test) */
-	if(!deflt)
-		return 0;
-	dev = e->slotdev >> 28;
-	slot = e->slotdev & 0x0fffffffu;
-	return slot < vw->map_cap[dev] && slot < vw->qstamp_cap[dev] && vw->qstamp[dev][slot] == e->stamp;
+	if(e->stamp != STAMP_NOUNITS)
+	{
+		/* only the open root window - one backend fragment - can be reported through the map
+		 * (amd_quick_process, a2amd_units.c, makes the same test) */
+		if(!deflt)
+			return 0;
+		dev = e->slotdev >> 28;
+		slot = e->slotdev & 0x0fffffffu;
+		if(!(slot < vw->map_cap[dev] && slot < vw->qstamp_cap[dev] && vw->qstamp[dev][slot] == e->stamp))
+			return 0;
+	}
+	/* a voice with subvoices (a group): they would be walked for this window (core.c:1749-1759,
+	 * :1888-1889) - unless their whole list sleeps, and then they get this very window */
+	if(e->flags & E_GROUP)
+		return deflt && list_sleeps(w, e->sub, now, frames);
+	return 1;
 }
 
 /* ... looking at the voice itself (one cache line of it) */
@@ -332,6 +371,38 @@ static inline void mark_default(const WSTATE *w, const ENT *e)
 		w->view.map[e->slotdev >> 28][e->slotdev & 0x0fffffffu] = 1;	/* = amd_quick_process() */
 }
 
+/* the default window for every voice of a sleeping list (list_sleeps) and of the lists below it */
+static void mark_list(WSTATE *w, const LIST *sl)
+{
+	unsigned k, g;
+	if(sl->sum_range)
+	{
+		if(sl->sum_cnt)
+			memset(w->view.map[sl->sum_dev] + sl->sum_lo, 1, sl->sum_cnt);
+	}
+	else
+		for(k = 0; k < sl->n; ++k)
+			if(!(sl->e[k].flags & E_GROUP))
+				mark_default(w, &sl->e[k]);
+	for(g = 0; g < sl->ng; ++g)
+	{
+		mark_default(w, &sl->e[sl->gidx[g]]);
+		mark_list(w, sl->e[sl->gidx[g]].sub);
+	}
+}
+
+/* ... for one voice that sleeps unseen (entry_sleeps), its subvoices included */
+static inline void mark_entry(WSTATE *w, const ENT *e)
+{
+	mark_default(w, e);
+	if(e->flags & E_GROUP)
+	{
+		mark_list(w, e->sub);
+		w->skipped += e->sub->sum_voices;
+		w->unread += e->sub->sum_voices;
+	}
+}
+
 /* The replacement.  Same contract as the engine's (internals.h:968-973). */
 void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned frames)
 {
@@ -354,16 +425,11 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 	cached = w->served && !walk_nocache && !w->hooks_broken && l->n && l->epoch == w->epoch &&
 			l->quiet_visit && l->quiet_visit == w->cur_visit;
 	l->quiet_visit = 0;
-	if(cached && l->sum_ok && l->sum_epoch == w->epoch && deflt && (a2_TSDiff(l->sum_wake, now) >> 8) >= (int)frames &&
-			(!l->sum_cnt || l->sum_lo + l->sum_cnt <= w->view.map_cap[l->sum_dev]))
+	if(cached && deflt && list_sleeps(w, l, now, frames))
 	{
-		if(l->sum_range)
-			memset(w->view.map[l->sum_dev] + l->sum_lo, 1, l->sum_cnt);
-		else
-			for(k = 0; k < l->n; ++k)
-				mark_default(w, &l->e[k]);
-		w->skipped += l->n;
-		w->unread += l->n;
+		mark_list(w, l);
+		w->skipped += l->sum_voices;
+		w->unread += l->sum_voices;
 		return;
 	}
 	all_unread = cached && deflt;
@@ -378,7 +444,7 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 				break;
 			if(entry_sleeps_unread(w, &l->e[k], now, frames, deflt))
 			{
-				mark_default(w, &l->e[k]);
+				mark_entry(w, &l->e[k]);
 				++k;
 				++w->skipped;
 				++w->unread;
@@ -397,7 +463,7 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 				__builtin_prefetch(l->e[k + AHEAD].v);	/* (a hint: never dereferenced here) */
 			if(voice_sleeps(w, l, k, v, now, frames, deflt))
 			{
-				mark_default(w, &l->e[k]);
+				mark_entry(w, &l->e[k]);
 				head = &v->next;
 				++k;
 				++w->skipped;
@@ -487,9 +553,11 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 				e->v = p;
 				e->slotdev = 0;
 				e->wake = p->s.waketime;
-				e->flags = (p->events ? 0 : E_NOEVENTS) | ((p->flags & A2_APIHANDLE) ? E_APIHANDLE : 0);
-				if(p->sub)
-					e->stamp = 0;		/* its subvoices need the walk (core.c:1888-1889) */
+				e->flags = (p->events ? 0 : E_NOEVENTS) | ((p->flags & A2_APIHANDLE) ? E_APIHANDLE : 0) |
+						(p->sub ? E_GROUP : 0);
+				e->sub = p->sub ? list_of(w, &p->sub) : NULL;
+				if(p->sub && !e->sub)
+					e->stamp = 0;		/* (out of memory: its subvoices keep being walked) */
 				else if(!p->units)
 					e->stamp = STAMP_NOUNITS;
 				else
@@ -501,20 +569,48 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 		}
 		*head = rest;
 	}
-	if(cached && all_unread && !l->sum_ok && l->n)
+	if(cached && all_unread && l->n)
 	{
 		/* every voice of the list slept, unseen: next time one test will do (until a voice of the
-		 * list is visited again or the epoch moves) */
-		uint32_t lo = 0xffffffffu, hi = 0, cnt = 0, dev = l->e[0].slotdev >> 28;
-		int one_dev = 1, best = 0x7fffffff;
+		 * list is visited again, the epoch moves, or the earliest wake time - in this list or below -
+		 * comes) */
+		uint32_t lo = 0xffffffffu, hi = 0, cnt = 0, dev = 0, ng = 0;
+		int one_dev = 1, best = 0x7fffffff, fits = 1;
+		unsigned long long voices = l->n;
+		l->sum_ok = 0;
+		for(k = 0; k < l->n; ++k)
+			ng += (l->e[k].flags & E_GROUP) != 0;
+		if(ng > l->ng || !l->gidx)
+		{
+			unsigned *gi = (unsigned *)realloc(l->gidx, (ng ? ng : 1) * sizeof(unsigned));
+			if(!gi)
+				return;
+			l->gidx = gi;
+		}
+		l->ng = 0;
 		for(k = 0; k < l->n; ++k)
 		{
 			const ENT *e = &l->e[k];
-			const int d = a2_TSDiff(e->wake, now);
+			int d = a2_TSDiff(e->wake, now);
 			if(d < best)
 			{
 				best = d;
 				l->sum_wake = e->wake;
+			}
+			if(e->stamp != STAMP_NOUNITS &&
+					(e->slotdev & 0x0fffffffu) >= w->view.map_cap[e->slotdev >> 28])
+				fits = 0;
+			if(e->flags & E_GROUP)
+			{
+				l->gidx[l->ng++] = k;
+				d = a2_TSDiff(e->sub->sum_wake, now);
+				if(d < best)
+				{
+					best = d;
+					l->sum_wake = e->sub->sum_wake;
+				}
+				voices += e->sub->sum_voices;
+				continue;
 			}
 			if(e->stamp == STAMP_NOUNITS)
 				continue;
@@ -527,23 +623,14 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 				hi = e->slotdev & 0x0fffffffu;
 			++cnt;
 		}
+		if(!fits)
+			return;
+		l->sum_voices = voices;
 		l->sum_dev = dev;
-		l->sum_lo = cnt ? lo : 0;
-		l->sum_cnt = cnt;
-		/* (slots are unique: n of them between lo and hi = lo + n - 1 are exactly that range) */
+		/* (slots are unique: cnt of them between lo and hi = lo + cnt - 1 are exactly that range) */
 		l->sum_range = !cnt || (one_dev && hi - lo + 1 == cnt);
-		if(!l->sum_range)
-		{
-			/* entry by entry, then: bound by the smallest map */
-			l->sum_lo = 0;
-			l->sum_cnt = 0;
-			for(k = 0; k < l->n; ++k)
-				if(l->e[k].stamp != STAMP_NOUNITS &&
-						(l->e[k].slotdev & 0x0fffffffu) >= w->view.map_cap[l->e[k].slotdev >> 28])
-					break;
-			if(k < l->n)
-				return;
-		}
+		l->sum_lo = (cnt && l->sum_range) ? lo : 0;
+		l->sum_cnt = l->sum_range ? cnt : 0;
 		l->sum_epoch = w->epoch;
 		l->sum_ok = 1;
 	}

@@ -204,6 +204,16 @@ int  a2amd_unit_process(a2amd_ctx *ctx, int unit, unsigned offset,
 int  a2amd_voice_process(a2amd_ctx *ctx, int head_unit, unsigned offset, unsigned frames,
 		uint32_t *noisestate);
 int  a2amd_voice_slot(a2amd_ctx *ctx, int unit);
+/* The same for ANY voice, bus owners included (a voice with an inline unit: a2_NewGroup's driver, a
+ * delay bus): 1 when the default window of the voice 'unit' belongs to - Process(0, all frames) on
+ * each unit, a2amd_inline_end() included - may be reported by the byte store alone.  That is the case
+ * once the voice has been processed at least once and while none of its units needs per-call host
+ * work (noise, a ramping cutoff, clients).  A host that walks the voice tree itself and finds a
+ * whole subtree asleep (src/core.c:1883-1896 would visit every voice of it) marks the subtree's
+ * voices and makes no call at all.  Voices that get records in the same fragment must be
+ * processed by calls, parents before children (their output bus is resolved from the open inline
+ * windows). */
+int  a2amd_voice_markable(a2amd_ctx *ctx, int unit);
 uint8_t *a2amd_default_map(a2amd_ctx *ctx, unsigned *nslots);
 
 /* Clients of an A2AMD_XINSERT / A2AMD_XSINK / A2AMD_XSOURCE unit
