@@ -302,6 +302,10 @@ struct a2amd_ctx {
 	std::vector<uint8_t> defmap;
 	bool defmap_used = false;		// the host asked for the map in the open fragment
 	bool defmap_dirty = false;		// ... in some fragment since it was last zeroed
+	// voices whose default window is reported "until further notice" (a2amd_default_hold): as if
+	// their byte in the map were stored in every fragment
+	std::vector<uint8_t> held;
+	size_t n_held = 0;
 	uint64_t walk_time = 0;			// frames of all fragments before the open one
 	unsigned prev_frames = 0;		// length of the fragment before the open one
 
@@ -462,6 +466,7 @@ int grow(a2amd_ctx *c, DevBuf<T> &b, size_t need, size_t elem_mult, bool keep)
 }
 
 double *dbg_counters();	// (A2AMD_HOSTTIMING counters, defined with the timing dump below)
+double *dbg_why();
 int rec_tag(const a2amd_ctx *c) { return c->frag_open ? c->cur_frag : c->nfrags; }
 
 void touch(a2amd_ctx *c, int vi)
@@ -474,14 +479,32 @@ void touch(a2amd_ctx *c, int vi)
 	}
 }
 
+static inline bool is_held(const a2amd_ctx *c, int vi)
+{
+	return (size_t)vi < c->held.size() && c->held[vi];
+}
+
+static inline void unhold(a2amd_ctx *c, int vi)
+{
+	if(is_held(c, vi)) {
+		c->held[vi] = 0;
+		--c->n_held;
+	}
+}
+
 // The windows of the open fragment that were left unrecorded so far - the voice's
 // default window, noted in HVoice::default_seg or by the host in the default map -
 // become records: something else follows in the same fragment after all.
 void spell_out_pending(a2amd_ctx *c, int vi)
 {
 	HVoice &dv = c->voices[vi];
-	if(c->frag_open && c->defmap_used && (size_t)vi < c->defmap.size() && c->defmap[vi]) {
-		c->defmap[vi] = 0;
+	const bool marked = c->frag_open && c->defmap_used && (size_t)vi < c->defmap.size() && c->defmap[vi];
+	if(marked || (c->frag_open && is_held(c, vi))) {
+		// (a held voice that gets a record after all - its chain taken down from outside the
+		// walk, say - had its default window in this fragment like a marked one; the hold ends)
+		if(marked)
+			c->defmap[vi] = 0;
+		unhold(c, vi);
 		dv.default_seg = c->serial_base + c->cur_frag;
 		if(dv.walked != c->serial_base + c->cur_frag) {
 			dv.walked = c->serial_base + c->cur_frag;
@@ -559,6 +582,7 @@ int close_fragment(a2amd_ctx *c)
 			n += c->defmap[k];
 		c->walked_started += (int)n;
 	}
+	c->walked_started += (int)c->n_held;
 	if(c->walked_started != c->n_started_live) {
 		if(c->hosttiming)
 			dbg_counters()[2] += 1;
@@ -566,7 +590,7 @@ int close_fragment(a2amd_ctx *c)
 		// the kernel would apply the default
 		for(size_t vi = 0; vi < c->voices.size(); ++vi) {
 			HVoice &v = c->voices[vi];
-			if(c->defmap_used && vi < c->defmap.size() && c->defmap[vi])
+			if((c->defmap_used && vi < c->defmap.size() && c->defmap[vi]) || is_held(c, (int)vi))
 				continue;	// (walked: the host marked its default window)
 			if(v.live && v.started && !v.dying && v.walked != c->serial_base + f &&
 					v.touched != c->serial_base + f) {
@@ -749,22 +773,72 @@ bool is_fbdchain(const a2amd_ctx *c, const HVoice &v)
 
 int upload(a2amd_ctx *c)
 {
+	if(c->hosttiming) {
+		// (A2AMD_HOSTTIMING: why a batch did not take the quiet path - first reason that applies)
+		const int why = !c->blob_quiet ? 0 : !c->with_recs.empty() ? 1 : !c->prev_with_recs.empty() ? 2 :
+				c->voices_dirty ? 3 : c->udesc_dirty ? 4 : c->waves_dirty ? 5 : c->lists_dirty ? 6 : c->ptab_dirty ? 7 :
+				!c->dirty_voices.empty() ? 8 : !c->fbd_to_zero.empty() ? 9 : c->nfrags != c->blob_nfrags ? 10 :
+				c->bus_used > c->d_busmem.cap ? 11 :
+				memcmp(c->fragframes, c->blob_frames, (size_t)c->nfrags * sizeof(unsigned)) ? 10 : 12;
+		dbg_why()[why] += 1;
+	}
 	if(c->blob_quiet && c->with_recs.empty() && c->prev_with_recs.empty() && !c->voices_dirty &&
 			!c->udesc_dirty && !c->waves_dirty && !c->lists_dirty && !c->ptab_dirty &&
-			c->dirty_voices.empty() && c->fbd_to_zero.empty() && c->nfrags == c->blob_nfrags &&
-			c->bus_used <= c->d_busmem.cap &&
-			!memcmp(c->fragframes, c->blob_frames, (size_t)c->nfrags * sizeof(unsigned))) {
+			c->dirty_voices.empty() && c->fbd_to_zero.empty() && c->bus_used <= c->d_busmem.cap) {
 		bool inject = false;
 		for(const XioSlot &x : c->xio)
 			if(x.unit >= 0 && (x.inj_used || (c->units[x.unit].xio_mode & A2AMD_XIO_INJECT)))
 				inject = true;
-		if(!inject) {
+		const bool same = c->nfrags == c->blob_nfrags &&
+				!memcmp(c->fragframes, c->blob_frames, (size_t)c->nfrags * sizeof(unsigned));
+		if(!inject && same) {
 			// the same quiet batch again: the device has it all (graphs stay valid)
 			if(c->hosttiming)
 				dbg_counters()[0] += 1;
 			++c->quiet_streak;
 			c->uploaded = true;
 			return 0;
+		}
+		if(!inject && c->d_params && c->stream) {
+			// A quiet batch again, cut into fragments differently - the engine's root voice woke
+			// up in the middle of a fragment, which it does every 3 906 frames while it idles at
+			// 'end' (core.c:1195), i.e. once per a2play buffer: nothing per voice has changed, only
+			// the fragment table of the parameter block.  That block alone goes up again (a few
+			// hundred bytes instead of a pass over every voice); graphs read it on the device and
+			// stay valid while the NUMBER of fragments - their launch shapes - is the same.
+			A2DParams p = c->hparams;
+			p.nfrags = c->nfrags;
+			memset(p.fragframes, 0, sizeof(p.fragframes));
+			memset(p.fragstart, 0, sizeof(p.fragstart));
+			for(int f = 0, acc = 0; f < c->nfrags; ++f) {
+				p.fragframes[f] = (uint8_t)c->fragframes[f];
+				p.fragstart[f] = (uint16_t)acc;
+				acc += (int)c->fragframes[f];
+			}
+			const int bi = c->blob_i;
+			c->blob_i ^= 1;
+			if(c->blob_busy[bi]) {
+				HIPCHK(c, hipEventSynchronize(c->blob_ev[bi]));
+				c->blob_busy[bi] = false;
+			}
+			if(c->h_blob[bi] && c->h_blob_cap[bi] >= sizeof(A2DParams) && c->blob_ev[bi]) {
+				memcpy(c->h_blob[bi], &p, sizeof(p));
+				HIPCHK(c, hipMemcpyAsync(c->d_blob.d, c->h_blob[bi], sizeof(p), hipMemcpyHostToDevice, c->stream));
+				HIPCHK(c, hipEventRecord(c->blob_ev[bi], c->stream));
+				c->blob_busy[bi] = true;
+				c->hparams = p;
+				if(c->nfrags != c->blob_nfrags) {
+					drop_graphs(c);
+					c->quiet_streak = 0;
+				} else
+					++c->quiet_streak;
+				c->blob_nfrags = c->nfrags;
+				memcpy(c->blob_frames, c->fragframes, (size_t)c->nfrags * sizeof(unsigned));
+				if(c->hosttiming)
+					dbg_counters()[0] += 1;
+				c->uploaded = true;
+				return 0;
+			}
 		}
 	}
 	c->blob_quiet = false;
@@ -2003,6 +2077,7 @@ int a2amd_unit_deinit(a2amd_ctx *c, int ui)
 	if(--v.nlive == 0) {
 		// a2_VoiceFree (core.c:532-591) took the whole chain down
 		push_rec(c, u.voice, R_KILL, 0, 0, 0, 0, 0);
+		unhold(c, u.voice);
 		if(v.started) {
 			--c->n_started_live;
 			if(c->frag_open && v.walked == c->serial_base + c->cur_frag)
@@ -2400,6 +2475,7 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 	const int vi = u.voice;
 	HVoice &v = c->voices[vi];
 	c->building = -1;
+	unhold(c, vi);		// (a call speaks for itself)
 	if(!v.resolved) {
 		resolve_out(c, v);
 		v.plain = 0;
@@ -2516,6 +2592,7 @@ int a2amd_voice_process(a2amd_ctx *c, int head, unsigned offset, unsigned frames
 		return c->fail(A2AMD_EINVAL, "process of dead unit %d", head);
 	const int vi = c->units[head].voice;
 	HVoice &pv = c->voices[vi];
+	unhold(c, vi);
 	if(!pv.plain)
 		classify_plain(c, pv);
 	static const int dbgw = getenv("A2AMD_DBG_WALK") ? atoi(getenv("A2AMD_DBG_WALK")) : 0;
@@ -2589,6 +2666,37 @@ int a2amd_voice_slot(a2amd_ctx *c, int ui)
 	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live)
 		return c->fail(A2AMD_EINVAL, "slot of dead unit %d", ui);
 	return c->units[ui].voice;
+}
+
+int a2amd_default_hold(a2amd_ctx *c, const uint32_t *slots, unsigned n, unsigned lo, int on)
+{
+	if(on && c->held.size() < c->voices.size())
+		c->held.resize(c->voices.size() * 2 + 65536, 0);
+	for(unsigned k = 0; k < n; ++k) {
+		const size_t vi = slots ? slots[k] : (size_t)lo + k;
+		if(!on) {
+			unhold(c, (int)vi);
+			continue;
+		}
+		if(vi >= c->voices.size())
+			return c->fail(A2AMD_EINVAL, "default_hold: slot %zu", vi);
+		const HVoice &v = c->voices[vi];
+		if(!v.live || v.dying || !v.resolved || !v.started)
+			return c->fail(A2AMD_ESTATE, "default_hold: voice %zu has not been processed yet", vi);
+		if(!c->held[vi]) {
+			c->held[vi] = 1;
+			++c->n_held;
+		}
+	}
+	return A2AMD_OK;
+}
+
+int a2amd_default_release_all(a2amd_ctx *c)
+{
+	if(c->n_held)
+		std::fill(c->held.begin(), c->held.end(), 0);
+	c->n_held = 0;
+	return A2AMD_OK;
 }
 
 uint8_t *a2amd_default_map(a2amd_ctx *c, unsigned *nslots)
@@ -2728,13 +2836,17 @@ static double now_us()
 	return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
 }
 static double g_t[4], g_n;
+static double g_why[13];
 static double g_cnt[6];		// quiet uploads, records shipped, walk scans, R_NOPs, voices with records, graph launches
 struct TimingDump { ~TimingDump() { if(getenv("A2AMD_HOSTTIMING") && g_n) fprintf(stderr,
 	"a2amd host timing per render: upload %.1f us, issue %.1f us, readback %.1f us (%g renders; %g quiet uploads, "
 	"%g graph launches, %g records, %g voices with records, %g walk scans, %g R_NOPs)\n",
-	g_t[0] / g_n, g_t[1] / g_n, g_t[2] / g_n, g_n, g_cnt[0], g_cnt[5], g_cnt[1], g_cnt[4], g_cnt[2], g_cnt[3]); } } g_timing_dump;
+	g_t[0] / g_n, g_t[1] / g_n, g_t[2] / g_n, g_n, g_cnt[0], g_cnt[5], g_cnt[1], g_cnt[4], g_cnt[2], g_cnt[3]);
+	if(getenv("A2AMD_HOSTTIMING") && g_n) { fprintf(stderr, "a2amd uploads by first reason against the quiet path "
+	"(blob, recs, prev recs, voices, udesc, waves, lists, ptab, dirty voices, fbd, nfrags, bus, none):");
+	for(int k = 0; k < 13; ++k) fprintf(stderr, " %g", g_why[k]); fprintf(stderr, "\n"); } } } g_timing_dump;
 
-namespace { double *dbg_counters() { return g_cnt; } }
+namespace { double *dbg_counters() { return g_cnt; } double *dbg_why() { return g_why; } }
 static int dist_reduce_root(a2amd_ctx *c);
 
 // What the READ clients of a context's x-units are to be handed: the tapped windows of the

@@ -1911,10 +1911,31 @@ int a2amd_units_walkview(const void *cfg, a2amd_walkview *out)
 			out->walker = &hs->walker;
 			out->serial = &hs->serial;
 			out->serial_value = hs->serial;
+			out->state = hs;
 			rc = 0;
 			break;
 		}
 	pthread_mutex_unlock(&states_mtx);
+	return rc;
+}
+
+int a2amd_units_hold(void *state, unsigned dev, const uint32_t *slots, unsigned n, int on)
+{
+	HOSTSTATE *hs = (HOSTSTATE *)state;
+	int rc = 0, d;
+	if(!hs || hs->failed)
+		return -1;
+	if(!n && !on)
+	{
+		for(d = 0; d < hs->ndev; ++d)
+			if(hs->ctxs[d])
+				a2amd_default_release_all(hs->ctxs[d]);
+		return 0;
+	}
+	if(dev >= (unsigned)hs->ndev || !hs->ctxs[dev])
+		return -1;
+	if((rc = a2amd_default_hold(hs->ctxs[dev], slots, n, 0, on)) && on)
+		a2amd_default_hold(hs->ctxs[dev], slots, n, 0, 0);	/* (all or nothing) */
 	return rc;
 }
 

@@ -82,6 +82,7 @@ typedef struct LIST
 	uint32_t	sum_wake;	/* the earliest wake time in the list - and in the lists below it */
 	unsigned	*gidx, ng;	/* the entries with subvoices (E_GROUP), as of the summary */
 	unsigned long long sum_voices;	/* voices in the list and below */
+	unsigned long long held_gen;	/* == WSTATE.hold_gen: the list's voices are held (a2amd_units_hold) */
 	uint32_t	sum_dev, sum_lo, sum_cnt;	/* their bytes in the default map: one range of one context ... */
 	int		sum_range;	/* ... or not (then entry by entry) */
 } LIST;
@@ -96,6 +97,10 @@ typedef struct WSTATE
 	unsigned long long epoch;	/* bumped by every a2_VoiceNew / a2_VoiceFree of the state: the lists' structure */
 	unsigned long long visits, cur_visit;	/* the engine call in progress one level up (quiet_visit) */
 	int		hooks_broken;	/* a list changed without the epoch moving: never trust remembered lists */
+	unsigned long long hold_gen;	/* holds made under an older value have been released wholesale */
+	unsigned	n_held;		/* lists held */
+	uint32_t	*scratch;	/* slots of a list, per context */
+	unsigned	scratch_cap;
 	unsigned long long last_use;	/* (the table of states is finite: the longest unused one makes room) */
 	unsigned long long skipped, unread, visited;
 } WSTATE;
@@ -106,7 +111,7 @@ static void (*engine_voicefree)(A2_state *st, A2_voice **head);
 static WSTATE *wstates[256];
 static pthread_mutex_t wmtx = PTHREAD_MUTEX_INITIALIZER;
 static __thread WSTATE *last_ws;
-static int walk_off = -1, walk_stats, walk_cut, walk_nocache;
+static int walk_off = -1, walk_stats, walk_cut, walk_nocache, walk_nohold;
 
 static WSTATE *wstate_of(A2_state *st)
 {
@@ -162,6 +167,8 @@ static WSTATE *wstate_of(A2_state *st)
 		w->lists = NULL;
 		w->nlists = w->cap_lists = 0;
 		++w->epoch;
+		++w->hold_gen;		/* (the closed state's contexts, and their holds, are gone) */
+		w->n_held = 0;
 		w->served = a2amd_units_walkview(st->config, &w->view) == 0;
 		if(!w->served)
 			w->view.cfg = st->config;
@@ -231,12 +238,28 @@ static void bind_engine(void)
 	walk_off = getenv("A2AMD_WALK_OFF") != NULL;	/* A/B: every voice is handed to the engine's loop */
 	/* A/B: lists are never trusted from memory - every sleeping voice's A2_voice is read */
 	walk_nocache = getenv("A2AMD_WALK_NOCACHE") != NULL;
+	/* A/B: sleeping lists are marked fragment by fragment instead of being put on hold */
+	walk_nohold = getenv("A2AMD_WALK_NOHOLD") != NULL;
 	/* test hook: voices are handed to the engine's loop run by run even in a state the drop-in
 	 * does not serve (the engine's own CPU units): exercises the cut / relink / voice death
 	 * logic without a GPU; no visit is ever skipped there */
 	walk_cut = getenv("A2AMD_WALK_CUT") != NULL;
 	if((walk_stats = getenv("A2AMD_WALK_STATS") != NULL))
 		atexit(report);
+}
+
+/* a voice is about to be made or freed: what is remembered about the state's lists is void, and
+ * no voice stays on hold (its slot may be somebody else's a moment later) */
+static void structure_changes(WSTATE *w)
+{
+	++w->epoch;
+	if(w->n_held)
+	{
+		if(w->served)
+			a2amd_units_hold(w->view.state, 0, NULL, 0, 0);
+		++w->hold_gen;
+		w->n_held = 0;
+	}
 }
 
 /* The two places where the engine's voice lists change (src/core.c:456-482, :532-581), interposed
@@ -249,7 +272,7 @@ A2_voice *a2_VoiceNew(A2_state *st, A2_voice *parent, unsigned when)
 	if(!engine_walk)
 		return NULL;
 	if((w = wstate_of(st)))
-		++w->epoch;
+		structure_changes(w);
 	return engine_voicenew(st, parent, when);
 }
 
@@ -261,7 +284,7 @@ void a2_VoiceFree(A2_state *st, A2_voice **head)
 	if(!engine_walk)
 		return;
 	if((w = wstate_of(st)))
-		++w->epoch;
+		structure_changes(w);
 	engine_voicefree(st, head);
 }
 
@@ -371,24 +394,69 @@ static inline void mark_default(const WSTATE *w, const ENT *e)
 		w->view.map[e->slotdev >> 28][e->slotdev & 0x0fffffffu] = 1;	/* = amd_quick_process() */
 }
 
+/* The voices of a sleeping list (list_sleeps) are put ON HOLD with the backend - "default window
+ * in every fragment until further notice" (a2amd_default_hold) - instead of being marked fragment
+ * by fragment: a list asleep costs nothing at all until its earliest wake time comes, a voice is
+ * born or dies, or its parent wakes.  on = 0 releases them (before any of them is handed to the
+ * engine's loop). */
+static int hold_list(WSTATE *w, LIST *sl, int on)
+{
+	unsigned k, dev, n;
+	if(on && walk_nohold)
+		return -1;
+	if(sl->n > w->scratch_cap)
+	{
+		uint32_t *ns = (uint32_t *)realloc(w->scratch, sl->n * 2 * sizeof(uint32_t));
+		if(!ns)
+			return -1;
+		w->scratch = ns;
+		w->scratch_cap = sl->n * 2;
+	}
+	for(dev = 0; dev < A2AMD_WALK_MAXDEV; ++dev)
+	{
+		for(n = k = 0; k < sl->n; ++k)
+			if(sl->e[k].stamp != STAMP_NOUNITS && (sl->e[k].slotdev >> 28) == dev)
+				w->scratch[n++] = sl->e[k].slotdev & 0x0fffffffu;
+		if(n && a2amd_units_hold(w->view.state, dev, w->scratch, n, on) && on)
+		{
+			hold_list(w, sl, 0);
+			return -1;
+		}
+	}
+	if(on)
+	{
+		sl->held_gen = w->hold_gen;
+		++w->n_held;
+	}
+	else if(sl->held_gen == w->hold_gen)
+	{
+		sl->held_gen = 0;
+		--w->n_held;
+	}
+	return 0;
+}
+
 /* the default window for every voice of a sleeping list (list_sleeps) and of the lists below it */
-static void mark_list(WSTATE *w, const LIST *sl)
+static void mark_list(WSTATE *w, LIST *sl)
 {
 	unsigned k, g;
-	if(sl->sum_range)
+	if(sl->held_gen != w->hold_gen && hold_list(w, sl, 1))
 	{
-		if(sl->sum_cnt)
-			memset(w->view.map[sl->sum_dev] + sl->sum_lo, 1, sl->sum_cnt);
+		/* (no hold to be had: fragment by fragment, then) */
+		if(sl->sum_range)
+		{
+			if(sl->sum_cnt)
+				memset(w->view.map[sl->sum_dev] + sl->sum_lo, 1, sl->sum_cnt);
+		}
+		else
+			for(k = 0; k < sl->n; ++k)
+				if(!(sl->e[k].flags & E_GROUP))
+					mark_default(w, &sl->e[k]);
+		for(g = 0; g < sl->ng; ++g)
+			mark_default(w, &sl->e[sl->gidx[g]]);
 	}
-	else
-		for(k = 0; k < sl->n; ++k)
-			if(!(sl->e[k].flags & E_GROUP))
-				mark_default(w, &sl->e[k]);
 	for(g = 0; g < sl->ng; ++g)
-	{
-		mark_default(w, &sl->e[sl->gidx[g]]);
 		mark_list(w, sl->e[sl->gidx[g]].sub);
-	}
 }
 
 /* ... for one voice that sleeps unseen (entry_sleeps), its subvoices included */
@@ -432,6 +500,9 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 		w->unread += l->sum_voices;
 		return;
 	}
+	/* voice by voice, then: none of them stays on hold */
+	if(l->held_gen == w->hold_gen && w->hold_gen)
+		hold_list(w, l, 0);
 	all_unread = cached && deflt;
 	for(;;)
 	{

@@ -214,6 +214,13 @@ int  a2amd_voice_slot(a2amd_ctx *ctx, int unit);
  * processed by calls, parents before children (their output bus is resolved from the open inline
  * windows). */
 int  a2amd_voice_markable(a2amd_ctx *ctx, int unit);
+/* ... and for as long as the host says: the n voices slots[0..n) (or, with slots == NULL, the range
+ * [lo, lo + n) of slots) count as having stored their byte in EVERY fragment from the open one on
+ * (on != 0) until the hold is released (on == 0), the voice is processed by a call, gets a record,
+ * or dies.  A host that has found a subtree asleep until some known time does nothing at all for it
+ * per fragment.  a2amd_default_release_all() ends every hold of the context. */
+int  a2amd_default_hold(a2amd_ctx *ctx, const uint32_t *slots, unsigned n, unsigned lo, int on);
+int  a2amd_default_release_all(a2amd_ctx *ctx);
 uint8_t *a2amd_default_map(a2amd_ctx *ctx, unsigned *nslots);
 
 /* Clients of an A2AMD_XINSERT / A2AMD_XSINK / A2AMD_XSOURCE unit

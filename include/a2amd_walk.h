@@ -34,6 +34,7 @@ typedef struct a2amd_walkview
 	int			*walker;	/* set by the walk: the units' own prefetch hints are switched off */
 	const unsigned		*serial;	/* *serial == serial_value while the engine state this view was made for is open */
 	unsigned		serial_value;
+	void			*state;		/* for a2amd_units_hold() */
 } a2amd_walkview;
 /* The view of the engine state with this A2_config; 0, or -1 when the drop-in does not serve it. */
 int a2amd_units_walkview(const void *cfg, a2amd_walkview *out);
@@ -41,6 +42,11 @@ int a2amd_units_walkview(const void *cfg, a2amd_walkview *out);
  * 0 unless the unit is the head of a chain of the drop-in's own units in byte-store mode -
  * and its slot (bits 0..27) and context (bits 28..31) in *slotdev. */
 uint32_t a2amd_units_standing(const void *head, uint32_t *slotdev);
+/* a2amd_default_hold() / a2amd_default_release_all() (include/a2amd.h) on context 'dev' of the engine
+ * state 'state' (a2amd_walkview.state): the voices in slots[0..n) report their default window in
+ * every fragment until released.  n == 0 and on == 0: every hold of the state, in all contexts. */
+int a2amd_units_hold(void *state, unsigned dev, const uint32_t *slots, unsigned n, int on);
+
 
 #ifdef __cplusplus
 }

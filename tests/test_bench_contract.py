@@ -17,7 +17,7 @@ def test_bench_prints_one_contract_line():
     """Default run = BASELINE configs[3] at full size, every step's audio delivered to
     the host, the steps the oracle golden covers compared hash by hash."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--no-cpu-baseline", "--no-engine"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1

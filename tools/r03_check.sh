@@ -3,7 +3,7 @@ O=gpurun_out/r03d; mkdir -p $O
 python -m pytest tests/test_dropin.py -q -x -k "engine_in_loop_at or walk" > $O/t_walk.log 2>&1; echo "walk tests rc $?" > $O/summary
 python - > $O/engine_scripted.json 2> $O/engine.err <<'PY'
 import json, bench
-cases = [c for c in bench.ENGINE_CASES if "Scripted" in c[1] or c[2] == 65536]
+cases = [c for c in bench.ENGINE_CASES if c[2] >= 16384]
 print(json.dumps(bench.engine_in_loop(cases)))
 PY
 python - > $O/rt_sweep.json 2>> $O/engine.err <<'PY'
