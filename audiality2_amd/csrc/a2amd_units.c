@@ -106,6 +106,7 @@ typedef struct HOSTSTATE
 	uint32_t	stamp_ctr;
 	int		walker;		/* liba2amd_walk.so walks this state: no prefetch hints of our own */
 	unsigned	serial;		/* a number of its own for every engine state ever opened (a2amd_walkview) */
+	unsigned	frag_serial;	/* root windows opened so far (a2amd_walkview) */
 	/* Engine states (master states and a2_Render's substates) come and go; their records are
 	 * allocated as needed, chained, and reused when a state has closed - never freed: the voice
 	 * walk of INTEGRATION.md option C holds pointers into them (a2amd_walkview). */
@@ -1379,6 +1380,7 @@ static void amd_inline_process(A2P_unit *u, unsigned offset, unsigned frames)
 			}
 		}
 		++hs->batch_frags;
+		++hs->frag_serial;
 		hs->base = offset;
 		hs->win_frames = frames;
 		hs->win_pos = hs->rec_pos;
@@ -1912,6 +1914,7 @@ int a2amd_units_walkview(const void *cfg, a2amd_walkview *out)
 			out->serial = &hs->serial;
 			out->serial_value = hs->serial;
 			out->state = hs;
+			out->frag_serial = &hs->frag_serial;
 			rc = 0;
 			break;
 		}

@@ -83,6 +83,7 @@ typedef struct LIST
 	unsigned	*gidx, ng;	/* the entries with subvoices (E_GROUP), as of the summary */
 	unsigned long long sum_voices;	/* voices in the list and below */
 	unsigned long long held_gen;	/* == WSTATE.hold_gen: the list's voices are held (a2amd_units_hold) */
+	unsigned	reached;	/* the fragment (a2amd_walkview.frag_serial) in which the walk last passed it asleep */
 	uint32_t	sum_dev, sum_lo, sum_cnt;	/* their bytes in the default map: one range of one context ... */
 	int		sum_range;	/* ... or not (then entry by entry) */
 } LIST;
@@ -256,7 +257,28 @@ static void structure_changes(WSTATE *w)
 	if(w->n_held)
 	{
 		if(w->served)
+		{
+			/* In the middle of a walk (a voice's program ended, a note was spawned): the held
+			 * lists the walk has already passed in this fragment HAVE had their default window in
+			 * it - that is stored, byte by byte, before the holds go; the lists it has not
+			 * reached yet get whatever the rest of the walk finds for them (a list whose parent
+			 * has just died gets nothing, as in the engine: core.c:1856-1868, :1892). */
+			const unsigned cur = *w->view.frag_serial;
+			unsigned t, k;
+			for(t = 0; t < w->cap_lists; ++t)
+			{
+				const LIST *sl = w->lists[t];
+				if(!sl || sl->held_gen != w->hold_gen || sl->reached != cur)
+					continue;
+				for(k = 0; k < sl->n; ++k)
+				{
+					const ENT *e = &sl->e[k];
+					if(e->stamp != STAMP_NOUNITS && (e->slotdev & 0x0fffffffu) < w->view.map_cap[e->slotdev >> 28])
+						w->view.map[e->slotdev >> 28][e->slotdev & 0x0fffffffu] = 1;
+				}
+			}
 			a2amd_units_hold(w->view.state, 0, NULL, 0, 0);
+		}
 		++w->hold_gen;
 		w->n_held = 0;
 	}
@@ -440,6 +462,7 @@ static int hold_list(WSTATE *w, LIST *sl, int on)
 static void mark_list(WSTATE *w, LIST *sl)
 {
 	unsigned k, g;
+	sl->reached = *w->view.frag_serial;
 	if(sl->held_gen != w->hold_gen && hold_list(w, sl, 1))
 	{
 		/* (no hold to be had: fragment by fragment, then) */

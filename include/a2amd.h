@@ -218,7 +218,9 @@ int  a2amd_voice_markable(a2amd_ctx *ctx, int unit);
  * [lo, lo + n) of slots) count as having stored their byte in EVERY fragment from the open one on
  * (on != 0) until the hold is released (on == 0), the voice is processed by a call, gets a record,
  * or dies.  A host that has found a subtree asleep until some known time does nothing at all for it
- * per fragment.  a2amd_default_release_all() ends every hold of the context. */
+ * per fragment.  a2amd_default_release_all() ends every hold of the context - from the OPEN fragment
+ * on: a host that releases in the middle of its walk stores the bytes of the voices whose turn had
+ * already come in this fragment itself. */
 int  a2amd_default_hold(a2amd_ctx *ctx, const uint32_t *slots, unsigned n, unsigned lo, int on);
 int  a2amd_default_release_all(a2amd_ctx *ctx);
 uint8_t *a2amd_default_map(a2amd_ctx *ctx, unsigned *nslots);

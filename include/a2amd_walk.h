@@ -35,6 +35,7 @@ typedef struct a2amd_walkview
 	const unsigned		*serial;	/* *serial == serial_value while the engine state this view was made for is open */
 	unsigned		serial_value;
 	void			*state;		/* for a2amd_units_hold() */
+	const unsigned		*frag_serial;	/* counts the root windows (= backend fragments) the state has opened */
 } a2amd_walkview;
 /* The view of the engine state with this A2_config; 0, or -1 when the drop-in does not serve it. */
 int a2amd_units_walkview(const void *cfg, a2amd_walkview *out);
