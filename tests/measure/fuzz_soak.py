@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-off differential fuzz soak (see tests/test_fuzz_dropin.py): seeds A..B,
 reference engine with its own units vs with the drop-in.  Prints failures and a
-summary line.   python tests/measure/fuzz_soak.py 24 400"""
+summary line.   python tests/measure/fuzz_soak.py 24 400
+A2FUZZ_WALK=1: the drop-in behind the replaced voice walk (INTEGRATION.md option C)."""
 import json
 import os
 import subprocess
@@ -16,6 +17,8 @@ from fuzz_scripts import make_script  # noqa: E402
 
 R = os.path.join(ROOT, "oracle", "_ref", "ref_render")
 U = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
+if os.environ.get("A2FUZZ_WALK"):
+    U = os.path.join(ROOT, "audiality2_amd", "liba2amd_walk.so") + " " + U
 
 
 def main():
@@ -57,7 +60,7 @@ def main():
     for e in errors:
         print("ERROR", e, flush=True)
     print(json.dumps({"seeds": [a, b], "frames": frames, "mismatching_seeds": [x[0] for x in bad],
-                      "errors": len(errors), "silent": silent}))
+                      "errors": len(errors), "silent": silent, "walk": bool(os.environ.get("A2FUZZ_WALK"))}))
 
 
 if __name__ == "__main__":

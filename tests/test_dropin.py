@@ -38,7 +38,10 @@ CASES = [("sustain", ["4", "0.05"], 9600), ("filter", ["4", "0.02"], 48000),
          ("unload", ["0.1"], 48000)]
 # no fixture, compared with the reference run on the same box: 10 s of voice churn
 # (20 000 births and deaths, ~300 voices alive)
-LIVE_CASES = [("churn", ["0.05"], 10 * 48000)]
+LIVE_CASES = [("churn", ["0.05"], 10 * 48000),
+              # sleeping subtrees (held by the replaced voice walk) next to births, deaths, wake-ups and a
+              # group that ends with everything under it asleep
+              ("holds", ["0.02"], 3 * 48000)]
 REALTIME_CASES = {"edge", "unload"}      # see tests/golden/make_goldens.py
 UPLOAD_CASES = {"unload": "20000"}
 
