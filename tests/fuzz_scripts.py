@@ -151,6 +151,31 @@ def held_program(rng, name):
                       f".rel\ta 0; d {r(rng, 1, 40, 1)}", "\t1() { force rel }", "}"])
 
 
+def pad_programs(rng):
+    """Seeds >= 1000: sustained, sleeping voices in (nested) groups next to everything else - what the
+    replaced voice walk (INTEGRATION.md option C) skips, holds and has to let go of again: pads that
+    sleep for good, pads that wake a few times a second, groups that end with all their voices asleep."""
+    L = []
+    shapes = [("wtosc; panmix", "w {w}; p P; a V; pan {pan}"),
+              ("wtosc; filter12; panmix", "w {w}; p P; a V; pan {pan}; cutoff (P + 2); q 3"),
+              ("wtosc A; wtosc B; panmix", "A.w {w}; B.w sine; A.p P; B.p (P + .01); A.a V; B.a V; pan {pan}")]
+    for i, (st, setup) in enumerate(shapes):
+        su = setup.format(w=rng.choice(WAVES[:9]), pan=pos(r(rng, -1, 1)))
+        L.append(f"Pad{i}(P V)\n{{\n\tstruct {{ {st} }}\n\t{su}; set\n\tfor {{ d 100000 }}\n}}\n")
+    pre = "A." if False else ""
+    L.append("PadW(P V)\n{\n\tstruct { wtosc; panmix }\n\tw triangle; p P; a V; set\n"
+             f"\tfor {{ d {r(rng, 90, 400, 1)}; p (P + rand 1); d {r(rng, 60, 300, 1)}; p P }}\n}}\n")
+    # PG: a group of pads (N of them), optionally with a life time; PGG: a group of such groups
+    bus = rng.choice(["inline 0 2; panmix 2 2; xinsert 2 >", "inline 0 2; fbdelay D 2 2; panmix 2 >"])
+    L.append(f"PG(P V N Life)\n{{\n\tstruct {{ {bus} }}\n\t!Q P\n"
+             f"\tN {{ Pad0 Q V; +Q .07; Pad1 Q V; +Q .05; Pad2 Q V; d .02 }}\n\tPadW (P + 1) V\n"
+             "\tif Life > 0 { d Life } else { for { d 100000 } }\n}\n")
+    L.append("PGG(P V N Life)\n{\n\tstruct { inline 0 2; panmix 2 2; xinsert 2 > }\n"
+             "\tPG P V N 0\n\tPG (P + .3) V N (Life * .6)\n\tPad1 (P - 1) V\n"
+             "\tif Life > 0 { d Life } else { for { d 100000 } }\n}\n")
+    return L
+
+
 def make_script(seed):
     rng = random.Random(seed)
     nv = rng.randint(4, 8)
@@ -166,6 +191,11 @@ def make_script(seed):
         # Main is a group (a2_NewGroup's driver shape): the test attaches a sink, and for
         # every other such seed a source as well, to its xinsert (A2REF_SINK / A2REF_SOURCE)
         main += ["\tstruct { inline 0 2; panmix 2 2; xinsert 2 > }", f"\tvol {r(rng, 0.4, 1)}; set"]
+    if seed >= 1000:
+        parts += pad_programs(rng)
+        for _ in range(rng.randint(1, 3)):
+            life = rng.choice(["0", r(rng, 200, 1500, 0)])
+            main.append(f"\t{rng.choice(['PG', 'PGG'])} {pos(r(rng, -1.5, 1))} (V * .2) {rng.randint(2, 9)} {life}")
     main += ["\t!P 0", "\tfor {"]
     for _ in range(rng.randint(6, 14)):
         if rng.random() < 0.25:
