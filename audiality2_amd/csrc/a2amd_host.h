@@ -1,0 +1,480 @@
+// a2amd_host.h - what the translation units of liba2amd.so's host half share: the recorded
+// scene (units, voices, waves, client slots), the context, the host copies of the few
+// reference formulas the host evaluates, and the functions that cross file boundaries.
+//   a2amd_host.cpp    the C ABI: state, waves, fragment clock, unit callbacks (the recorder)
+//   a2amd_sched.cpp   what a batch becomes on the device: upload, launch order, graphs
+//   a2amd_render.cpp  a2amd_render / collect / replay, statistics
+//   a2amd_dist.cpp    multi-GPU: RCCL binding, the root-bus reduce, render groups
+#ifndef A2AMD_HOST_H
+#define A2AMD_HOST_H
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>		// (types only: the library is bound at run time, a2amd_dist_init)
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <vector>
+
+#include "../../include/a2amd.h"
+#include "a2amd_device.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace a2h {
+struct Rccl {
+	void *lib = nullptr;
+	ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+	const char *(*GetErrorString)(ncclResult_t) = nullptr;
+
+};
+extern Rccl g_rccl;
+bool rccl_bind();
+
+extern thread_local char g_err[256];
+
+
+// ---- host copies of the few reference formulas the host must evaluate ----
+struct Ramp { int value, target, delta, timer; };
+
+inline int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+inline int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+inline int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+
+// a2_InitRamper / a2_PrepareRamper / a2_RunRamper / a2_SetRamper, a2_dsp.h:121-170
+inline void ramp_init(Ramp &r, int v) { r.value = r.target = (int)((unsigned)v << 8); r.delta = r.timer = 0; }
+inline void ramp_prepare(Ramp &r, int frames)
+{
+	if(!r.timer) {
+		r.value = r.target;
+		r.delta = 0;
+	} else if(frames <= (r.timer >> 8)) {
+		r.delta = (int)((((int64_t)wsub(r.target, r.value)) * 256) / r.timer);
+		r.timer = wsub(r.timer, frames << 8);
+	} else {
+		r.delta = wsub(r.target, r.value) / frames;
+		r.timer = 0;
+	}
+}
+inline void ramp_run(Ramp &r, int frames) { r.value = wadd(r.value, wmul(r.delta, frames)); }
+inline void ramp_set(Ramp &r, int target, int start, int duration)
+{
+	r.target = (int)((unsigned)target << 8);
+	r.timer = wadd(duration, start);
+	if(r.timer < 256)
+		r.value = r.target;
+	else
+		r.value = wadd(r.value, wmul(r.delta, start) >> 8);
+}
+
+// a2_pitch_open, pitch.c:70-96
+inline void build_pitch_table(uint32_t *tab)
+{
+	unsigned b = 0x80000000u;
+	for(unsigned i = 0; i < 64; ++i) {
+		unsigned b2 = (unsigned)((double)0x80000000u * powf(2.0f, (i + 1) * (1.0f / 64)) + 0.5f);
+		tab[2 * i] = b;
+		tab[2 * i + 1] = (b2 - b + 128) >> 8;
+		b = b2;
+	}
+}
+
+// a2_P2I, pitch.c:57-67
+inline unsigned p2i(const uint32_t *tab, int pitch)
+{
+	int n = pitch & 0xffff, oct = pitch >> 16;
+	unsigned dph = tab[2 * (n >> 10) + 1] * (unsigned)(n & 0x3ff);
+	dph >>= 2;
+	dph += tab[2 * (n >> 10)];
+	return dph >> ((unsigned)(7 - oct) & 31u);
+}
+
+// f12_pitch2coeff, filter12.c:65-72 -- float/double libm maths: host only
+inline int f12_coeff(const uint32_t *tab, int cutoff_value, int samplerate)
+{
+	float f = p2i(tab, cutoff_value >> 8) * (261.626f / 16777216.0f);
+	if(f > (samplerate >> 2))
+		return 362 << 16;
+	return (int)(512.0f * 65536.0f * sin(M_PI * f / samplerate));
+}
+
+// dcb_pitch2coeff, dcblock.c:57-64: the same maths from a 16:16 pitch
+inline int dcb_coeff(const uint32_t *tab, int cutoff, int samplerate)
+{
+	float f = p2i(tab, cutoff) * (261.626f / 16777216.0f);
+	if(f > (samplerate >> 2))
+		return 362 << 16;
+	return (int)(512.0f * 65536.0f * sin(M_PI * f / samplerate));
+}
+
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if(e_ != hipSuccess) \
+	return (c)->fail(A2AMD_EHIP, "%s: %s", #call, hipGetErrorString(e_)); } while(0)
+
+template<class T> struct DevBuf {
+	T *d = nullptr;
+	size_t cap = 0;
+};
+
+struct HUnit {
+	// --- what a Process call of a wtosc / any unit reads and writes: one cache line ---
+	bool live = false;
+	int kind = 0;
+	int voice = -1, chainpos = 0;
+	// wtosc: what the launch classes and the drop-in need to know of A2_wtosc at all
+	// times - which Process variant is installed (wtosc.c:433-483) ...
+	int mode = A2D_OSC_OFF, wave = -1;
+	// ... and, ONLY while that is wtosc_Noise, enough of the rest to count the draws a
+	// window takes from the engine's one RNG (wtosc.c:129-152): phase, increment, pitch
+	// ramper.  In every other mode these fields are stale - the device's unit state is
+	// the authority - and are rebuilt when the oscillator is switched to noise
+	// (shadow_rebuild: the state the device was left with by the last batch + this
+	// batch's records of the voice so far).
+	unsigned dphase = 0;
+	int p_ramping = 0;
+	uint64_t phase = 0;
+	Ramp p = {0, 0, 0, 0};
+	// --- second line ---
+	// filter12 shadow: the cutoff ramper never leaves the host
+	Ramp cutoff = {0, 0, 0, 0};
+	unsigned flags = 0;
+	int nin = 0, nout = 0, wired = 0;
+	// fbdelay: delay line pair index, and the three tap lengths in frames (what the
+	// device holds, fbdelay.c:194-196,231-247): they decide the voice's launch class
+	int fbdbuf = -1;
+	int fbd_taps[3] = { 0, 0, 0 };
+	// fm: slot in the operator state pool
+	int fmslot = -1;
+	// xinsert: client slot (tap / inject buffers) and A2AMD_XIO_* mode
+	int xio = -1;
+	unsigned xio_mode = 0;
+};
+
+struct HVoice {
+	// --- touched by every Process call of the voice: kept within one cache line ---
+	bool live = false, dying = false;
+	bool resolved = false, started = false;
+	bool listed_recs = false;	// already in a2amd_ctx::with_recs
+	uint8_t plain = 0;		// 0 not known, 1 no unit's Process leaves anything to do on the host but note
+					// the window (a2amd_voice_process takes its short path), 2 not so
+	bool fancy_recs = false;	// this batch's records hold something k_leaf_recs does not execute
+	bool mode_mix = false;		// an oscillator played something else than a mip-mapped wave at some
+					// point of the batch being recorded (its records go to the general kernel)
+	int nunits = 0;
+	int win_off = -1, win_frames = 0;
+	int win_done = 0;		// units of the chain that have processed the window in progress
+	long long touched = -1;		// serial of the fragment of the last touch
+	long long walked = -1;		// serial of the last fragment the engine made a Process call in
+	long long default_seg = -1;	// serial of the fragment whose only event so far is the default
+					// window (one Process(0, frames) per unit): no record is made
+					// for it unless something else follows in that fragment
+	size_t frag_mark = 0;		// recs.size() when that fragment was first touched
+	// --- second line: the records ---
+	std::vector<A2DRec> recs;	// this batch, fragment order
+	std::vector<A2DRec> deferred;	// writes waiting behind the open window's SEG record
+	// --- structure (set up once) ---
+	uint64_t key = 0;
+	int nlive = 0;
+	int unit[A2D_MAXCHAIN];
+	int depth = 0;
+	int inline_pos = -1;		// chain position of the inline unit, if any
+	int out_off = 0, out_nch = 0;
+	int own_off = -1, own_nch = 0;
+	int cls = 0;			// launch class (CLS_*), set when the lists are rebuilt
+};
+
+struct DepthRange { int fast_first = 0, fast_count = 0, fbd_first = 0, fbd_count = 0, gen_first = 0, gen_count = 0,
+		dyn_first = 0, dyn_count = 0; };
+enum { CLS_GENERIC = 0, CLS_OSCPAN, CLS_OSCFILTPAN, CLS_BUSDRIVER, CLS_BUSGENERIC, CLS_OSC2PAN, CLS_FMPAN, CLS_FBDCHAIN,
+	CLS_OSC2FILTPAN };
+
+// host side of an xinsert client slot
+struct XioSlot {
+	int unit = -1;
+	int last_unit = -1;		// whose taps 'tap' holds (that unit may be gone by now)
+	std::vector<int32_t> tap, inj;	// [fragment][A2AMD_MAXCHANNELS][64]
+	bool inj_used = false;
+	bool tapped = false;		// had READ clients at some point of the batch being recorded
+	std::vector<int32_t> late;	// a2amd_unit_insert: what insert clients made of the taps, same layout
+	bool late_used = false;
+};
+
+struct HWave {
+	bool live = false;
+	uint64_t key = 0;
+	A2DWave dw;
+	size_t pool_off = 0, pool_len = 0;	// its region of the device wave pool (int16 units)
+};
+
+} // namespace a2h
+using namespace a2h;
+
+struct a2amd_ctx {
+	a2amd_config cfg;
+	char err[256];
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+	bool profiling = false;
+	std::vector<hipEvent_t> ev_pool;	// triples: before leaf, after leaf, after root
+	size_t ev_used = 0;
+	uint32_t ptab[128];
+
+	std::vector<HUnit> units;
+	std::vector<int> free_units, deferred_free_units;
+	std::vector<HVoice> voices;
+	std::vector<int> free_voices, deferred_free_voices;
+	std::vector<HWave> waves;
+	int building = -1;
+	std::vector<int> stack;			// open inline windows (unit ids)
+	std::vector<A2DRec> up_recs;		// upload()'s scratch, kept for their capacity
+	std::vector<int> up_idx, up_now;
+	std::vector<A2DRun> up_val;
+	std::vector<int> with_recs, prev_with_recs;	// voices carrying records this / last batch
+	std::vector<int> dirty_voices;		// voice mirror entries to re-upload
+	long long serial_base = 0;		// fragments rendered before this batch
+	int n_leaf_dyn = 0, static_len = 0;
+	int n_dyn_osc1 = 0, n_dyn_osc2 = 0, n_dyn_filt = 0;	// ... of n_leaf_dyn, first in the list: k_leaf_recs renders them
+	int n_o2f_leaf = 0;			// 2 x wtosc-filter12-panmix leaves (list_all, behind the general leaves)
+	int n_started_live = 0;			// voices the engine is walking
+	int walked_started = 0;			// ... of which it has walked this many in the open fragment
+	int n_noise = 0, n_cutoff_ramps = 0;
+	// Self-cleaning buses: when every bus is read by k_bus_driver (its owner is a plain
+	// driver chain without records this batch), that kernel zeroes what it read and the
+	// root stores the master bus instead of adding to it - the batch needs no memset.
+	bool owners_all_driver = false;		// (static: set when the lists are rebuilt)
+	bool consume_ok = false;		// ... and none of them carries records this batch
+	bool others_clean = false;		// every bus but the root's is known to be zero
+	bool root_clean = false;		// ... and the root's own bus
+	bool capturing = false;			// issue_kernels is being captured into a graph
+	int n_clients = 0;			// units whose clients are served (a2amd_unit_clients mode != 0)
+	int sub_resume = -1;			// SUBTREES phase paused for insert clients: the depth it goes on with
+	int paused_at = 0;			// ... and the depth whose insert clients are to be served now (0: none)
+	std::vector<int32_t> snap_ustate, snap_vactive;	// unit states / voice liveness as the last batch left them
+	bool snap_valid = false;			// (fetched when an oscillator is switched to noise)
+	// The default map: one byte per voice slot, set by the HOST for a voice that
+	// received exactly the engine's default window (Process(0, all frames) on every
+	// unit, nothing else) in the open fragment - the one-store-per-voice fast path of
+	// the voice walk (a2amd_default_map).  Cleared when a fragment opens.
+	std::vector<uint8_t> defmap;
+	bool defmap_used = false;		// the host asked for the map in the open fragment
+	bool defmap_dirty = false;		// ... in some fragment since it was last zeroed
+	// voices whose default window is reported "until further notice" (a2amd_default_hold): as if
+	// their byte in the map were stored in every fragment
+	std::vector<uint8_t> held;
+	size_t n_held = 0;
+	uint64_t walk_time = 0;			// frames of all fragments before the open one
+	unsigned prev_frames = 0;		// length of the fragment before the open one
+
+	// fragment clock
+	bool frag_open = false;
+	int cur_frag = 0, nfrags = 0;
+	unsigned fragframes[A2D_MAXBATCH];
+	bool uploaded = false;
+
+	// host mirrors of host-owned device tables
+	std::vector<A2DVoice> mvoices;
+	std::vector<uint32_t> mudesc;
+	std::vector<A2DWave> mwaves;
+	bool voices_dirty = true, udesc_dirty = true, waves_dirty = true, lists_dirty = true, ptab_dirty = true;
+	std::vector<int> list_all;		// leaf list followed by per-depth lists
+	int n_leaf = 0;
+	int n_fast_leaf = 0, n_osc2_leaf = 0, n_filt_leaf = 0;	// list_all = [wtosc-panmix | 2 x wtosc-panmix | wtosc-filter12-panmix | fm-panmix | general leaves | per depth ...]
+	int n_fm_leaf = 0, fm_kind_count[8] = { 0 };		// fm-panmix: grouped by unit kind (fm1..fm4r), one launch each
+	int n_list_pads = 0;
+	std::vector<DepthRange> depth_ranges;	// index = depth
+	bool hosttiming = false;		// A2AMD_HOSTTIMING
+	int no_fast = 0;			// A2AMD_NO_FAST bit mask: 1 wtosc-panmix, 2 wtosc-filter12-panmix, 4 driver chains -> general kernel (debugging / A-B tests)
+
+	// bus memory allocator (units of int32)
+	size_t bus_stride_frames;
+	size_t bus_used = 0;
+	std::map<int, std::vector<int>> bus_free;	// nch -> offsets
+	std::vector<std::pair<int,int>> deferred_bus_free;
+
+	// fbdelay buffers
+	int fbd_count = 0;
+	std::vector<int> fbd_free, fbd_deferred_free, fbd_to_zero;
+	// fm operator state pool
+	int fm_count = 0;
+	std::vector<int> fm_free, fm_deferred_free;
+
+	// xinsert client slots
+	std::vector<XioSlot> xio;
+	std::vector<int> xio_free, xio_deferred_free;
+
+	// wave pool (int16 samples)
+	size_t wavepool_used = 0;
+	std::vector<std::pair<size_t, size_t>> wavepool_free;	// (offset, length) of dropped waves' regions, sorted, coalesced
+	// a dropped wave's pool region and table slot serve the batch being recorded to its
+	// end (oscillators still name it until they have rendered a window and noticed)
+	std::vector<std::pair<size_t, size_t>> deferred_wavepool_free;
+	std::vector<int> free_wave_slots, deferred_wave_slots;
+
+	DevBuf<A2DVoice> d_voices;
+	DevBuf<uint32_t> d_udesc;
+	DevBuf<int32_t> d_ustate;	// cap in units
+	DevBuf<int32_t> d_ustage;	// staging copy for time-sliced kernels
+	DevBuf<int32_t> d_vactive;
+	DevBuf<A2DRun> d_runs;
+	DevBuf<A2DRec> d_recs;
+	DevBuf<A2DWave> d_waves;
+	DevBuf<int16_t> d_wavepool;
+	DevBuf<int32_t> d_wavecoef;	// cap in pool samples, 3 words each (a2amd_fast.hip: Coef3)
+	DevBuf<int32_t> d_busmem;
+	DevBuf<int32_t> d_fbdmem;	// cap in buffer pairs
+	DevBuf<int32_t> d_fmstate;	// cap in slots of A2D_FMSTATE words
+	DevBuf<int32_t> d_xio;		// cap in slots of A2D_XIO_SLOT words
+	uint32_t *d_fmsine = nullptr;
+	DevBuf<int> d_list;
+	DevBuf<int> d_scatter;	// idx[k] then A2DRun[k] for k_scatter_runs
+	uint32_t *d_ptab = nullptr;
+	A2DParams *d_params = nullptr;	// = start of the device blob of the uploaded batch
+	// Everything a batch ships - parameter block, records, run-table updates,
+	// this batch's exception lists - is assembled in ONE pinned staging buffer
+	// and sent with one asynchronous copy (no host sync at upload; two staging
+	// buffers alternate, each guarded by an event).
+	DevBuf<char> d_blob;
+	char *h_blob[2] = { nullptr, nullptr };
+	size_t h_blob_cap[2] = { 0, 0 };
+	hipEvent_t blob_ev[2] = { nullptr, nullptr };
+	bool blob_busy[2] = { false, false };
+	int blob_i = 0;
+	const int *d_dyn = nullptr;	// this batch's exception lists inside the blob
+	A2DParams hparams;
+	// [0] = GRAPH_STEPS whole runs of the batch, [1] = one run, [2] = its SUBTREES
+	// phase alone, [3] = its ROOT phase alone (multi-GPU steps)
+	hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
+	hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
+	int32_t *h_master = nullptr;	// pinned
+	size_t h_master_cap = 0;
+	// Identical-batch fast path: a batch without records, with the same fragment
+	// lengths as the one uploaded before it and nothing changed in between (no
+	// births, deaths, waves, clients) finds everything it needs on the device
+	// already - no blob, no copy - and its launch sequence in a graph.
+	bool blob_quiet = false;		// the uploaded blob describes a record-free batch
+	int blob_nfrags = 0;
+	unsigned blob_frames[A2D_MAXBATCH];
+	int quiet_streak = 0;			// consecutive batches that took the fast path
+	// A2AMD_RENDER_ASYNC: master-bus readbacks in flight (a2amd_collect delivers them)
+	struct Readback {
+		int32_t *h = nullptr;		// pinned
+		size_t cap = 0;
+		hipEvent_t ev = nullptr;
+		int nfrags = 0;
+		unsigned total = 0;
+		uint8_t frames[A2D_MAXBATCH];
+	} rb[2];
+	int rb_head = 0, rb_count = 0;
+
+	// multi-GPU: this context renders the voice subtrees it was given; the root
+	// voice's inline bus is summed over the ranks' contexts by one RCCL reduce per
+	// batch, the root chain runs on rank 0 (a2amd_dist_init)
+	ncclComm_t comm = nullptr;
+	int dist_rank = 0, dist_ranks = 1;
+	bool dist_local = false;	// one of several contexts of this process (a2amd_dist_init_local)
+	hipEvent_t grp_ev = nullptr;	// ... its SUBTREES phase is done / its partial has been taken
+
+	a2amd_stats stats;
+
+	int fail(int code, const char *fmt, ...)
+	{
+		va_list ap;
+		va_start(ap, fmt);
+		vsnprintf(err, sizeof(err), fmt, ap);
+		va_end(ap);
+		snprintf(g_err, sizeof(g_err), "%s", err);
+		return code;
+	}
+};
+
+// The current HIP device is per host thread; a context may be driven from a
+// thread other than the one that opened it, and contexts of one process may
+// live on different GPUs (one engine state per GPU).
+static inline void use_device(const a2amd_ctx *c) { (void)hipSetDevice(c->cfg.device); }
+
+namespace a2h {
+// grow a device array; keep = preserve old contents (device-owned data)
+template<class T>
+int grow(a2amd_ctx *c, DevBuf<T> &b, size_t need, size_t elem_mult, bool keep)
+{
+	if(need <= b.cap)
+		return 0;
+	// (big elements - the 1 MB client slots - start small)
+	size_t ncap = std::max(need, b.cap ? b.cap * 2 : (elem_mult >= 65536 ? (size_t)2 : (size_t)1024));
+	T *nd = nullptr;
+	HIPCHK(c, hipMalloc((void **)&nd, ncap * elem_mult * sizeof(T)));
+	if(keep && b.d && b.cap) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		HIPCHK(c, hipMemcpyAsync(nd, b.d, b.cap * elem_mult * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+	}
+	// (on the context's stream: a memset on the null stream is not ordered with
+	// what this stream does to the new buffer next)
+	if(keep)
+		HIPCHK(c, hipMemsetAsync((char *)nd + b.cap * elem_mult * sizeof(T), 0,
+				(ncap - b.cap) * elem_mult * sizeof(T), c->stream));
+	if(keep)	// ... nor with the synchronous copies some callers make into it right away
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+	if(b.d) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		HIPCHK(c, hipFree(b.d));
+	}
+	b.d = nd;
+	b.cap = ncap;
+	return 0;
+}
+
+inline int rec_tag(const a2amd_ctx *c) { return c->frag_open ? c->cur_frag : c->nfrags; }
+static inline bool is_held(const a2amd_ctx *c, int vi)
+{
+	return (size_t)vi < c->held.size() && c->held[vi];
+}
+
+static inline void unhold(a2amd_ctx *c, int vi)
+{
+	if(is_held(c, vi)) {
+		c->held[vi] = 0;
+		--c->n_held;
+	}
+}
+
+// (the wavetable leaf kernels only know mip-mapped waves, "off" and noise)
+inline bool leaf_mode(int mode) { return mode == A2D_OSC_MIPWAVE || mode == A2D_OSC_OFF || mode == A2D_OSC_NOISE; }
+// a tap the frame-parallel delay kernel can take: at least one fragment long, and
+// short enough not to wrap onto the frames being written
+inline bool fbd_tap_ok(int frames) { return frames >= A2D_FRAG && frames <= A2D_FBD_BUFSIZE - A2D_FRAG; }
+// a2amd_sched.cpp
+void drop_graphs(a2amd_ctx *c);
+void touch(a2amd_ctx *c, int vi);
+void spell_out_pending(a2amd_ctx *c, int vi);
+void push_rec(a2amd_ctx *c, int vi, int op, int unit, int reg, int value, unsigned dur, unsigned start);
+int bus_alloc(a2amd_ctx *c, int nch);
+int close_fragment(a2amd_ctx *c);
+void resolve_out(a2amd_ctx *c, HVoice &v);
+void sync_voice_mirror(a2amd_ctx *c, int vi);
+int upload(a2amd_ctx *c);
+void wavepool_release(a2amd_ctx *c, size_t off, size_t len);
+void end_batch(a2amd_ctx *c);
+int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2);
+int ensure_clean(a2amd_ctx *c);
+int build_graph(a2amd_ctx *c, int slot, int steps, unsigned phases = A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT);
+long long now_serial(const a2amd_ctx *c);
+// a2amd_render.cpp
+double *dbg_counters();	// (A2AMD_HOSTTIMING counters)
+double *dbg_why();
+int fetch_taps(a2amd_ctx *c, bool final);
+// a2amd_dist.cpp
+int dist_reduce_root(a2amd_ctx *c);
+} // namespace a2h
+
+#endif // A2AMD_HOST_H
