@@ -86,6 +86,7 @@ typedef struct HOSTSTATE
 	a2amd_ctx	*ctxs[MAXDEV];
 	int		root_uid[2][MAXDEV];	/* the root voice's inline and panmix in every context */
 	int		rr;		/* next context for a voice that mixes straight into the root's bus */
+	int		load[MAXDEV];	/* units alive in each context: a new subtree goes where the fewest are */
 	int		dev_stack[72];	/* context of each open inline window, by depth */
 	BIRTHOP		*births;
 	int		nbirths, cap_births;
@@ -459,7 +460,20 @@ static void route_voice(XTRA *x)
 {
 	HOSTSTATE *hs = x->hs;
 	A2P_vmstate *vms = x->vms;
-	const int dev = hs->depth <= 1 ? hs->rr++ % hs->ndev : hs->dev_stack[hs->depth - 1];
+	int dev;
+	if(hs->depth <= 1)
+	{
+		/* a subtree of its own: the context with the fewest units so far, in turn among equals
+		 * (groups made in a row before any of their voices exist are dealt round robin) */
+		int d, best = hs->rr % hs->ndev;
+		for(d = 1; d < hs->ndev; ++d)
+			if(hs->load[(hs->rr + d) % hs->ndev] < hs->load[best])
+				best = (hs->rr + d) % hs->ndev;
+		dev = best;
+		hs->rr = best + 1;
+	}
+	else
+		dev = hs->dev_stack[hs->depth - 1];
 	int k, n = 0, rc;
 	for(k = 0; k < hs->nbirths; ++k)
 	{
@@ -477,6 +491,7 @@ static void route_voice(XTRA *x)
 		{
 			bx->dev = dev;
 			bx->pending = 0;
+			++hs->load[dev];
 			bx->uid = a2amd_unit_init(hs->ctxs[dev], (uint64_t)(uintptr_t)vms, b->kind, b->flags, b->nin,
 					b->nout, b->wired, b->transpose, b->wakefrac);
 			if(bx->uid < 0)
@@ -613,6 +628,8 @@ static void amd_deinit(A2P_unit *u)
 				fail(x->hs, "a2amd_unit_deinit", rc);
 		return;
 	}
+	if(x->hs->ndev > 1 && x->hs->load[x->dev] > 0)
+		--x->hs->load[x->dev];
 	if(x->uid >= 0 && !x->hs->failed && (rc = a2amd_unit_deinit(XCTX(x), x->uid)))
 		fail(x->hs, "a2amd_unit_deinit", rc);
 }

@@ -297,7 +297,9 @@ def engine_in_loop(cases=None, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fr
                      "cpu_hash": c["hashes"][0]}
                 for mode, walk in modes:
                     # (without the walk's short cut a fragment costs ~40 ns per voice of engine walk: bound the run)
-                    nrun = nfr if walk else max(hf, buf // 64, min(nfr, int(2.5e6 / (voices * 0.04))))
+                    # ... and with it a fragment of a quiet scene costs microseconds: four times as many
+                    nrun = (nfr if "Scripted" in program else 4 * nfr) if walk else \
+                        max(hf, buf // 64, min(nfr, int(2.5e6 / (voices * 0.04))))
                     g = engine_run(program, voices, nrun, buf, True, hf, walk=walk)
                     if "error" in g:
                         e[mode] = {"error": g["error"]}
