@@ -762,20 +762,6 @@ def main():
     os.environ.setdefault("MASTER_PORT", "29511")
     dist.init_process_group("nccl", rank=rank, world_size=world,
                             device_id=torch.device("cuda", local_rank))
-    r = Runner(audiality2_amd, cfg["voices"], cfg["chain"], cfg["groups"], B, local_rank, world=world, rank=rank,
-               tree=cfg.get("tree", 0))
-    r.keep_upto = golden_steps(cfg["voices"] * world, cfg["chain"], cfg["groups"], B, cfg.get("tree", 0)) if cfg.get("tree") else 0
-    lib = r.lib
-    lib.a2amd_dist_unique_id.argtypes = [ctypes.c_void_p]
-    lib.a2amd_dist_init.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-    idbuf = (ctypes.c_uint8 * 128)()
-    if rank == 0 and lib.a2amd_dist_unique_id(idbuf):
-        raise r.err()
-    idt = torch.tensor(list(idbuf), dtype=torch.uint8, device=torch.device("cuda", local_rank))
-    dist.broadcast(idt, src=0)
-    idbuf = (ctypes.c_uint8 * 128)(*idt.cpu().tolist())
-    if lib.a2amd_dist_init(r.be.ctx, idbuf, rank, world):
-        raise r.err()
     # barrier = a (pre-warmed) 1-element all-reduce every rank must join, with the
     # device idle on both sides; dist.barrier() itself costs tens of ms on first use
     token = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", local_rank))
@@ -785,22 +771,41 @@ def main():
         dist.all_reduce(token)
         torch.cuda.synchronize()
 
-    fence()
-    r.run(1)                # step 0: voices are born (the first reduce builds RCCL's channels)
-    r.run(args.warmup)
-    fence()
-    fence()
-    import gc
-    gc.collect()
-    gc.disable()
-    t0 = time.perf_counter()
-    r.run(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    def timed_job(cfg, steps, warmup):
+        """A Runner of its own RCCL communicator, born, warmed up and timed: (runner, seconds)."""
+        r = Runner(audiality2_amd, cfg["voices"], cfg["chain"], cfg["groups"], B, local_rank, world=world, rank=rank,
+                   tree=cfg.get("tree", 0))
+        r.keep_upto = golden_steps(cfg["voices"] * world, cfg["chain"], cfg["groups"], B, cfg.get("tree", 0)) \
+            if cfg.get("tree") else 0
+        lib = r.lib
+        lib.a2amd_dist_unique_id.argtypes = [ctypes.c_void_p]
+        lib.a2amd_dist_init.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        idbuf = (ctypes.c_uint8 * 128)()
+        if rank == 0 and lib.a2amd_dist_unique_id(idbuf):
+            raise r.err()
+        idt = torch.tensor(list(idbuf), dtype=torch.uint8, device=torch.device("cuda", local_rank))
+        dist.broadcast(idt, src=0)
+        idbuf = (ctypes.c_uint8 * 128)(*idt.cpu().tolist())
+        if lib.a2amd_dist_init(r.be.ctx, idbuf, rank, world):
+            raise r.err()
+        fence()
+        r.run(1)                # step 0: voices are born (the first reduce builds RCCL's channels)
+        r.run(warmup)
+        fence()
+        fence()
+        import gc
+        gc.collect()
+        gc.disable()
+        t0 = time.perf_counter()
+        r.run(steps)
+        fence()
+        dt = time.perf_counter() - t0
+        gc.enable()
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return r, float(t.item())
+
+    r, dt = timed_job(cfg, args.steps, args.warmup)
     leaf_ms, all_ms, nprof = r.profile(min(args.steps, 16))
     last = r.last
     line = None
@@ -834,8 +839,26 @@ def main():
             "roofline": roof, "roofline_valu": valu,
             "output_check": {"peak": int(np.abs(last).max()), "nonzero": bool(last.any())},
         }
-    be = r.be
-    be.close()
+    r.be.close()
+    if args.config == 3 and not custom and not args.no_extra:
+        # BASELINE configs[4] in the same launch: one top-level group of 128 sub-groups x 256
+        # wtosc->filter12->panmix voices per rank - at --gpus 8 that IS configs[4] - the ranks' root-bus
+        # partials summed by the same reduce, the whole job's audio gated on the oracle golden of this rank count
+        c4 = dict(CONFIGS[4])
+        r4, dt4 = timed_job(c4, max(8, args.steps // 2), args.warmup)
+        leaf4, all4, _ = r4.profile(8)
+        if rank == 0:
+            cmp4, ok4 = check_golden(r4, 2)
+            if ok4 is False:
+                raise SystemExit("bench.py: configs[4]: the ranks' summed render differs from the oracle golden")
+            st4 = max(8, args.steps // 2)
+            line["other_configs"] = {"configs[4]": {
+                "workload": c4["label"] + f" x {world}" + (" = BASELINE configs[4]" if world == 8 else ""),
+                "value": float(c4["voices"]) * world * B * 64 * st4 / dt4, "ms_per_step": dt4 / st4 * 1e3,
+                "voices_total": c4["voices"] * world, "parity_vs_golden": ok4,
+                "golden_fragments_compared": min(B, 64) if cmp4 else 0,
+                "kernel": "k_leaf_oscfiltpan", "avg_launch_ms": leaf4, "all_kernels_ms_per_step": all4}}
+        r4.be.close()
     dist.destroy_process_group()
     # The contract line is the LAST thing on stdout: RCCL writes a version banner
     # through C stdio, which sits in libc's buffer until it is flushed.
