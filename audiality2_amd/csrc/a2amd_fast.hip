@@ -1811,6 +1811,7 @@ DEV void filt_row(int *row, int n, int ff, int lp, int bp, int hp, int &d1, int 
 #ifndef FILT_WPE
 #define FILT_WPE 4
 #endif
+__device__ unsigned g_filt_turn[4096];	// FILT_ROT == 2: workgroups arriving on a CU take turns (k_leaf_oscfiltpan)
 __global__ __launch_bounds__(64 * FILT_WAVES) __attribute__((amdgpu_waves_per_eu(FILT_WPE, FILT_WPE)))
 void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpg,
 		const A2DVoice *__restrict__ voices, int *ustate, const int16_t *__restrict__ wavepool,
@@ -1832,11 +1833,39 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 #define FILT_FRAMES(f) ((int)rfl((int)p.fragframes[f]))
 #define FILT_START(f)  ((int)rfl((int)p.fragstart[f]))
 
-	// Which wavefront filters: wavefront w of a workgroup runs on SIMD w & 3, and the workgroups
-	// of a launch are dealt over the 256 CUs round robin - workgroups 256 apart share a CU.
-	// Their filter wavefronts (each a stream of dependent instructions that wants a SIMD's issue
-	// slots to itself) go to different SIMDs.
-	const int fw = FILT_ROT ? (int)((blockIdx.x >> 8) & 3u) : 0;
+	// Which wavefront filters, and which oscillator wavefronts sit next to a filter wavefront.
+	// Where a wavefront runs is the hardware's choice (observed: wavefronts w and w + 4 of a
+	// workgroup share a SIMD, simd = {0, 2, 1, 3}[(w + s) & 3] with s changing from workgroup to
+	// workgroup), so with FILT_ROT == 2 the roles follow the PHYSICAL SIMD ids (s_getreg HW_ID):
+	// the workgroups that arrive on a CU take turns (a counter per CU in device memory) putting
+	// their filter wavefront - a stream of dependent instructions that wants a SIMD's issue slots -
+	// on SIMD 0 and on SIMD 1; the other wavefront of that SIMD stays idle ("partner"), and the
+	// oscillator wavefronts that sit on the OTHER workgroup's filter SIMD take fewer voices ("light").
+	__shared__ int s_simd[FILT_WAVES];
+	__shared__ int s_target;
+	int fw = 0, my_simd = wv & 3, tgt = 0;
+	if(FILT_ROT == 2) {
+		my_simd = (int)__builtin_amdgcn_s_getreg(2308) & 3;		// HW_ID.simd_id
+		if(lane == 0)
+			s_simd[wv] = my_simd;
+		if(threadIdx.x == 0) {
+			const unsigned hw = __builtin_amdgcn_s_getreg(63492);	// HW_ID: cu_id 11:8, sh_id 12, se_id 15:13
+			const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 15u;	// XCC_ID
+			const unsigned key = (xcc << 8) | ((hw >> 8) & 255u);
+			s_target = (int)(atomicAdd(&g_filt_turn[key & 4095u], 1u) & 1u);
+		}
+		__syncthreads();
+		tgt = s_target;
+		fw = -1;
+		for(int k = FILT_WAVES - 1; k >= 0; --k)
+			if(s_simd[k] == tgt)
+				fw = k;		// the first wavefront on that SIMD
+		if(fw < 0) {		// (nobody there: the roles by wavefront number, as without FILT_ROT)
+			fw = 0;
+			tgt = s_simd[0];
+		}
+	} else if(FILT_ROT)
+		fw = (int)((blockIdx.x >> 8) & 3u);
 	if(wv == fw) {
 		// ================= the filter wavefront: lane = voice =================
 		// (its dependent chain is the workgroup's critical path: first in line for
@@ -1898,8 +1927,8 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		}
 #ifdef FILT_PROF
 		if((blockIdx.x == 7 || blockIdx.x == 263) && lane == 0 && nfrags > 100)
-			printf("block %d wave %d (filter, %d voices): %lld cycles filtering, %lld waiting (%d fragments)\n",
-					(int)blockIdx.x, wv, nv, tb, tw, nfrags);
+			printf("block %d wave %d simd %d cu %d (filter, %d voices): %lld cycles filtering, %lld waiting (%d fragments)\n",
+					(int)blockIdx.x, wv, (int)__builtin_amdgcn_s_getreg(2308), (int)__builtin_amdgcn_s_getreg(6660), nv, tb, tw, nfrags);
 #endif
 		if(mine) {
 			int *w1 = ustate + (size_t)u1 * A2D_USTATE;
@@ -1922,30 +1951,53 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 	// oscillator wavefronts of THIS workgroup that run on SIMD fw ^ 1 sit next to the other
 	// workgroup's filter wavefront and take fewer voices ("light": FILT_LIGHT each, -1 = an even
 	// share), so that the four SIMDs of the CU carry about the same number of instructions.
-	const int npart = FILT_WAVES / 4 - 1;			// the other wavefronts on the filter's SIMD
-	const int nlight = (FILT_ROT && FILT_LIGHT >= 0) ? FILT_WAVES / 4 : 0;
-	const int nfull = FILT_WAVES - 1 - npart - nlight;
+	int npart = FILT_WAVES / 4 - 1;			// the other wavefronts on the filter's SIMD
+	int nlight = (FILT_ROT && FILT_LIGHT >= 0) ? FILT_WAVES / 4 : 0;
+	int role = 0, ridx = 0;				// 0 full, 1 light, 2 partner; my index among those of my role
+	if(FILT_ROT == 2) {
+		npart = nlight = 0;
+		for(int k = 0; k < FILT_WAVES; ++k) {
+			if(k == fw)
+				continue;
+			const int r = s_simd[k] == tgt ? 2 : (FILT_LIGHT >= 0 && s_simd[k] == (tgt ^ 1)) ? 1 : 0;
+			npart += r == 2;
+			nlight += r == 1;
+			if(k == wv)
+				role = r;
+		}
+		for(int k = 0; k < wv; ++k)
+			if(k != fw)
+				ridx += (s_simd[k] == tgt ? 2 : (FILT_LIGHT >= 0 && s_simd[k] == (tgt ^ 1)) ? 1 : 0) == role;
+	} else {
+		const int sm = wv & 3;
+		role = sm == fw ? 2 : (nlight && sm == (fw ^ 1)) ? 1 : 0;
+		if(role == 2)
+			ridx = (wv >> 2) - 1;			// (wv >> 2 == 0 is the filter wavefront)
+		else if(role == 1)
+			ridx = wv >> 2;
+		else {
+			for(int k = 0; k < sm; ++k)
+				ridx += (k != fw && !(nlight && k == (fw ^ 1)));
+			ridx += (wv >> 2) * (nlight ? 2 : 3);
+		}
+	}
+	const int nfull = max(1, FILT_WAVES - 1 - npart - nlight);
 	const int pshare = min(FILT_PARTNER, nv / (FILT_WAVES - 1));	// (never more than an even share)
 	const int lshare = nlight ? min(FILT_LIGHT, nv / (FILT_WAVES - 1)) : 0;
 	const int rem = nv - npart * pshare - nlight * lshare;
-	const int per = (rem + nfull - 1) / nfull;
-	const int sm = wv & 3;
+	// (an even deal: 32 voices over six wavefronts are 6 6 5 5 5 5 - with ceil(32 / 6) each the
+	// last one got 2 and the two SIMDs that hold the first four carried 12 voices to the third's 8)
+	const int per = rem / nfull, extra = rem % nfull;
 	int vb, ve;
-	if(sm == fw) {
-		const int pi = (wv >> 2) - 1;			// (wv >> 2 == 0 is the filter wavefront)
-		vb = rem + nlight * lshare + pi * pshare;
+	if(role == 2) {
+		vb = rem + nlight * lshare + ridx * pshare;
 		ve = min(nv, vb + pshare);
-	} else if(nlight && sm == (fw ^ 1)) {
-		vb = rem + (wv >> 2) * lshare;
+	} else if(role == 1) {
+		vb = rem + ridx * lshare;
 		ve = min(nv, vb + lshare);
 	} else {
-		// my index among the wavefronts of the SIMDs that hold no filter wavefront
-		int fi = 0;
-		for(int k = 0; k < sm; ++k)
-			fi += (k != fw && !(nlight && k == (fw ^ 1)));
-		fi += (wv >> 2) * (nlight ? 2 : 3);
-		vb = fi * per;
-		ve = min(rem, vb + per);
+		vb = ridx * per + min(ridx, extra);
+		ve = min(rem, vb + per + (ridx < extra ? 1 : 0));
 	}
 	const int mv = max(0, ve - vb);		// my voices: lane l parks voice vb + l
 
@@ -2205,8 +2257,8 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 	}
 #ifdef FILT_PROF
 	if((blockIdx.x == 7 || blockIdx.x == 263) && lane == 0 && nfrags > 100)
-		printf("block %d wave %d (osc/pan, %d voices): %lld cycles issue+pan, %lld oscillators, %lld waiting\n",
-				(int)blockIdx.x, wv, mv, ta, tc, tw);
+		printf("block %d wave %d simd %d cu %d (osc/pan, %d voices): %lld cycles issue+pan, %lld oscillators, %lld waiting\n",
+				(int)blockIdx.x, wv, (int)__builtin_amdgcn_s_getreg(2308), (int)__builtin_amdgcn_s_getreg(6660), mv, ta, tc, tw);
 #endif
 
 	if(mine) {
