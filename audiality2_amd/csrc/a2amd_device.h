@@ -14,6 +14,9 @@
 #define A2D_MIPS      10
 #define A2D_FBD_BUFSIZE 131072          // fbdelay.c:27
 #define A2D_MAXPHINC  512               // a2_waves.h:57
+#ifndef A2D_COEF_WORDS
+#define A2D_COEF_WORDS 3                 // words per entry of the Hermite coefficient table (a2amd_fast.hip)
+#endif
 #define A2D_WTOSC_MAXLENGTH (0x01000000 - 1 - 131)   // wtosc.c:55
 
 // unit kinds: numerically equal to a2amd_unitkind
@@ -126,7 +129,7 @@ struct A2DParams {
 	const A2DRec   *recs;
 	const A2DWave  *waves;
 	const int16_t  *wavepool;
-	const int32_t  *wavecoef;	// [wave pool index][3]: Hermite a, b, c:d0 of the window at that sample
+	const int32_t  *wavecoef;	// [wave pool index][A2D_COEF_WORDS]: Hermite a, b, c:d0 of the window at that sample
 	int32_t        *busmem;
 	int32_t        *fbdmem;		// [bufidx][2][A2D_FBD_BUFSIZE]
 	const uint32_t *ptab;		// 64 x {base, coeff}, pitch.c:70-96

@@ -28,6 +28,7 @@
 #include <type_traits>
 #include <algorithm>
 #include <stdlib.h>
+#include <type_traits>
 #include "a2amd_device.h"
 #include "a2amd_dsp.h"
 #include "a2amd_fm.h"
@@ -87,30 +88,96 @@ DEV int inter_dwords(const int16_t *d, unsigned ph, unsigned dph16)
 
 // Hermite coefficients of one window, precomputed per wave sample when the wave is
 // uploaded (k_build_coef): a2_Hermite's a, b and - packed - c (high half) and d[i]
-// (low half).  The settled paths fetch one 12 byte entry per tap instead of four
-// samples and go straight into the three multiply-shift-add steps, which are the
-// reference's own (a2_dsp.h:64-74: x = frac << 7, 32 bit wrap-around products,
-// arithmetic >> 15) - a third fewer vector instructions per tap than unpacking the
-// samples and deriving a, b, c for every output frame.
-// (one 3-component vector value: stays in the three consecutive registers the 12 byte
-// load fills; as a struct of three ints the compiler copies the members elsewhere
-// right behind every load, and waits for the load to do so)
-typedef int Coef3 __attribute__((ext_vector_type(3), aligned(4)));
+// (low half), one 12 byte entry per wave sample (A2D_COEF_WORDS 4: c and d[i] apart).  The settled paths fetch one entry per tap instead of four samples and go
+// straight into the three multiply-shift-add steps, which are the reference's own
+// (a2_dsp.h:64-74: x = frac << 7, 32 bit wrap-around products, arithmetic >> 15) - no
+// unpacking of samples, no deriving a, b, c for every output frame.
+// The table is read through ONE buffer descriptor (stride = entry, indexed): the entry index
+// phase >> 8 goes to the load as it is and the hardware scales it - no address
+// arithmetic in the vector unit; the level's first payload sample is the load's scalar
+// byte offset.  (Round 2 added a byte offset
+// (phase >> 8) * 12 to a scalar base: one more vector instruction per tap.)
+#if A2D_COEF_WORDS == 4
+typedef int Coef4 __attribute__((ext_vector_type(4)));		// a, b, c, d0
+#define A2D_COEF_LOAD "llvm.amdgcn.struct.buffer.load.v4i32"
+#else
+typedef int Coef4 __attribute__((ext_vector_type(3)));		// a, b, c:d0 (the halves come apart inside the adds: SDWA)
+#define A2D_COEF_LOAD "llvm.amdgcn.struct.buffer.load.v3i32"
+#endif
+typedef int CoefRsrc __attribute__((ext_vector_type(4)));
+extern "C" __device__ Coef4 a2d_coef_load(CoefRsrc rsrc, int vindex, int voffset, int soffset, int aux)
+		__asm(A2D_COEF_LOAD);
 
-DEV int hermite_c(const Coef3 k, unsigned ph)
+// the descriptor of the coefficient table (gfx9 buffer resource: base, stride in word 1
+// bits 16-29, no swizzle, num_records unlimited, DATA_FORMAT 32)
+DEV CoefRsrc coef_rsrc(const int *wavecoef)
 {
-	const int x = (int)((ph & 0xffu) << 7);
-	int t = wmul(k.x, x) >> 15;
-	t = wmul(wadd(t, k.y), x) >> 15;
-	t = wmul(wadd(t, k.z >> 16), x) >> 15;
-	return wadd((int)(int16_t)(k.z & 0xffff), t);
+	const uint64_t b = (uint64_t)wavecoef;
+	CoefRsrc r;
+	r.x = rfl((int)(unsigned)b);
+	r.y = rfl((int)(((unsigned)(b >> 32) & 0xffffu) | ((4u * A2D_COEF_WORDS) << 16)));
+	r.z = -1;
+	r.w = 0x00020000;
+	return r;
 }
 
-// wtosc_Inter (wtosc.c:28-33) from the coefficient table: cb = entry of the level's
-// first payload sample, ph / ph2 = 24:8 phases of the two taps
-DEV Coef3 coef_at(const char *cb, unsigned ph)
+// byte offset of the entry of pool sample doff (the table follows the pool: host, a2amd_host.cpp)
+DEV int coef_base(unsigned doff) { return (int)(doff * (4u * A2D_COEF_WORDS)); }
+
+// a2_Hermite's x = frac << 7 from a 24:8 phase, one instruction: the shift takes the low byte
+// of its operand (SDWA) - the compiler spells it as a shift and a mask
+DEV int frac_x(unsigned ph)
 {
-	return *(const Coef3 *)(cb + (size_t)((ph >> 8) * 12u));
+#ifdef A2D_NO_SDWA_X
+	return (int)((ph & 0xffu) << 7);
+#else
+	int x;
+	const int seven = 7;
+	asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
+			: "=v"(x) : "v"(seven), "v"(ph));
+	return x;
+#endif
+}
+
+DEV int hermite_c(const Coef4 k, unsigned ph)
+{
+	const int x = frac_x(ph);
+	int t = wmul(k.x, x) >> 15;
+	t = wmul(wadd(t, k.y), x) >> 15;
+#if A2D_COEF_WORDS == 4
+	t = wmul(wadd(t, k.z), x) >> 15;
+	return wadd(k.w, t);
+#else
+	t = wmul(wadd(t, k.z >> 16), x) >> 15;
+	return wadd((int)(int16_t)(k.z & 0xffff), t);
+#endif
+}
+
+// wtosc_Inter (wtosc.c:28-33) from the coefficient table: cb = coef_base() of the
+// level's first payload sample, ph = 24:8 phase of the tap
+DEV Coef4 coef_at(const CoefRsrc rs, int cb, unsigned ph)
+{
+	return a2d_coef_load(rs, (int)(ph >> 8), 0, cb, 0);
+}
+
+// The 24:8 phase of a tap: (ph + lane * dph) >> 16 for a wave-uniform 64 bit phase ph and
+// ldph = lane * dph (below 2^31: dph <= A2D_MAXPHINC << 16 on the settled paths).  Split at
+// bit 16 the sum needs no 64 bit vector arithmetic: the halves of ph stay scalar, the lane
+// part is two adds and a shift of the fast issue class (a 64 bit multiply-add and a funnel
+// shift otherwise).
+DEV unsigned tap_phase(uint64_t ph, unsigned ldph)
+{
+	const unsigned lo = (unsigned)ph & 0xffffu, hi = (unsigned)(ph >> 16);
+	return hi + ((lo + ldph) >> 16);
+}
+
+// lane * dph once per voice and oscillator (opaque to the compiler, which otherwise folds it
+// back into a multiply-add per fragment)
+DEV unsigned lane_dph(int lane, unsigned dph)
+{
+	unsigned t = (unsigned)lane * dph;
+	asm("" : "+v"(t));
+	return t;
 }
 
 __global__ void k_build_coef(const int16_t *__restrict__ pool, int *__restrict__ coef, unsigned lo, unsigned hi)
@@ -122,9 +189,15 @@ __global__ void k_build_coef(const int16_t *__restrict__ pool, int *__restrict__
 	const int c = (d1 - dm) >> 1;
 	const int a = (3 * (d0 - d1) + d2 - dm) >> 1;
 	const int b = dm - d0 + c - a;
-	coef[3 * (size_t)j] = a;
-	coef[3 * (size_t)j + 1] = b;
-	coef[3 * (size_t)j + 2] = (int)(((unsigned)c << 16) | ((unsigned)d0 & 0xffffu));
+	int *e = coef + A2D_COEF_WORDS * (size_t)j;
+	e[0] = a;
+	e[1] = b;
+#if A2D_COEF_WORDS == 4
+	e[2] = c;
+	e[3] = d0;
+#else
+	e[2] = (int)(((unsigned)c << 16) | ((unsigned)d0 & 0xffffu));
+#endif
 }
 
 // coefficient entries for pool samples [lo, hi): needs pool[lo - 1 .. hi + 1]
@@ -401,7 +474,7 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 		const int *__restrict__ wavecoef)
 {
 	const A2DParams &p = *pp;
-	const int wv = threadIdx.x >> 6;
+	const int wv = rfl((int)(threadIdx.x >> 6));	// (wave-uniform, and known to the compiler as such)
 	const int lane = threadIdx.x & 63;
 	const int first = (blockIdx.x * FAST_WPB + wv) * vpw;
 	if(first >= nlist)
@@ -410,6 +483,7 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	const int nfrags = p.nfrags;
 	const int dbg = p.debug;
 	FastPtrs g = { wavepool, waves, ptab, dbg };
+	const CoefRsrc crs = coef_rsrc(wavecoef);
 
 	// this wavefront's slice of the batch, in chunks of FAST_FCH fragments
 	const int nchunks = (nfrags + FAST_FCH - 1) / FAST_FCH;
@@ -565,30 +639,23 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 			// A2_WAVEPOST pad and are masked at the sum)
 			// (lane * dph once per voice; opaque to the compiler, which otherwise
 			// re-does the half-rate 64 bit multiply-add for every fragment)
-			unsigned ldl, ldh;
-			{
-				const uint64_t t = (uint64_t)(unsigned)lane * dph;
-				ldl = (unsigned)t;
-				ldh = (unsigned)(t >> 32);
-				asm("" : "+v"(ldl), "+v"(ldh));
-			}
-			const uint64_t lanedph = (uint64_t)ldl | ((uint64_t)ldh << 32);
+			const unsigned ldph = lane_dph(lane, dph);
 			// (uniform base = the coefficient entry of the level's first payload
 			// sample, + an unsigned 32 bit byte offset per lane: the loads take the
 			// scalar-base addressing form, no 64 bit adds.  Four fragments' entries
 			// in flight at a time: 24 registers.)
-			const char *cb = (const char *)(wavecoef + 3 * (size_t)doff);
+			const int cb = coef_base(doff);
 #pragma unroll
 			for(int h = 0; h < FAST_FCH; h += 4) {
-				Coef3 ka[4], kb[4];
+				Coef4 ka[4], kb[4];
 				unsigned pa[4], pb[4];
 #pragma unroll
 				for(int j = 0; j < 4; ++j) {
-					pa[j] = (unsigned)((phs[h + j] + lanedph) >> 16);
+					pa[j] = tap_phase(phs[h + j], ldph);
 					asm("" : "+v"(pa[j]));	// (keeps the offset a 32 bit value in the compiler's eyes)
 					pb[j] = pa[j] + (dph16 >> 1);
-					ka[j] = coef_at(cb, pa[j]);
-					kb[j] = coef_at(cb, pb[j]);
+					ka[j] = coef_at(crs, cb, pa[j]);
+					kb[j] = coef_at(crs, cb, pb[j]);
 				}
 #pragma unroll
 				for(int j = 0; j < 4; ++j) {
@@ -775,7 +842,7 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 		const uint32_t *__restrict__ ptab, int *__restrict__ busmem, const int *__restrict__ wavecoef)
 {
 	const A2DParams &p = *pp;
-	const int wv = threadIdx.x >> 6;
+	const int wv = rfl((int)(threadIdx.x >> 6));	// (wave-uniform, and known to the compiler as such)
 	const int lane = threadIdx.x & 63;
 	const int first = (blockIdx.x * FAST_WPB + wv) * vpw;
 	if(first >= nlist)
@@ -784,6 +851,7 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 	const int nfrags = p.nfrags;
 	const int dbg = p.debug;
 	FastPtrs g = { wavepool, waves, ptab, dbg };
+	const CoefRsrc crs = coef_rsrc(wavecoef);
 
 	const int nchunks = (nfrags + OSC2_FCH - 1) / OSC2_FCH;
 	const int per = (nchunks + ysplit - 1) / ysplit;
@@ -909,7 +977,7 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 			// flight before either is used (one oscillator after the other: -DOSC2_SEQ, 4 % slower)
 			int xs[OSC2_FCH];
 			uint64_t endph[2];
-			Coef3 ka[2][OSC2_FCH], kb[2][OSC2_FCH];
+			Coef4 ka[2][OSC2_FCH], kb[2][OSC2_FCH];
 			unsigned pa[2][OSC2_FCH], pb[2][OSC2_FCH];
 			int amps[2];
 #pragma unroll
@@ -920,8 +988,8 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 				const uint64_t phase = (uint64_t)(unsigned)rdl(so[o][OV_PHLO], v) |
 						((uint64_t)(unsigned)rdl(so[o][OV_PHHI], v) << 32);
 				uint64_t ph = (phase >> mm) + (uint64_t)before * dph;
-				const uint64_t lanedph = (uint64_t)(unsigned)lane * dph;
-				const char *cb = (const char *)(wavecoef + 3 * (size_t)doff);
+				const unsigned ldph = lane_dph(lane, dph);
+				const int cb = coef_base(doff);
 				uint64_t phs[OSC2_FCH];
 				if(!(sizem & (sizem - 1)) && !(ph >> 48)) {
 					const uint64_t mask = ((uint64_t)sizem << 24) - 1;
@@ -939,11 +1007,11 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 				}
 #pragma unroll
 				for(int j = 0; j < OSC2_FCH; ++j) {
-					pa[o][j] = (unsigned)((phs[j] + lanedph) >> 16);
+					pa[o][j] = tap_phase(phs[j], ldph);
 					asm("" : "+v"(pa[o][j]));
 					pb[o][j] = pa[o][j] + (dph >> 17);
-					ka[o][j] = coef_at(cb, pa[o][j]);
-					kb[o][j] = coef_at(cb, pb[o][j]);
+					ka[o][j] = coef_at(crs, cb, pa[o][j]);
+					kb[o][j] = coef_at(crs, cb, pb[o][j]);
 				}
 				endph[o] = ph << mm;
 			}
@@ -965,8 +1033,8 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 				const uint64_t phase = (uint64_t)(unsigned)rdl(so[o][OV_PHLO], v) |
 						((uint64_t)(unsigned)rdl(so[o][OV_PHHI], v) << 32);
 				uint64_t ph = (phase >> mm) + (uint64_t)before * dph;
-				const uint64_t lanedph = (uint64_t)(unsigned)lane * dph;
-				const char *cb = (const char *)(wavecoef + 3 * (size_t)doff);
+				const unsigned ldph = lane_dph(lane, dph);
+				const int cb = coef_base(doff);
 				uint64_t phs[OSC2_FCH];
 				if(!(sizem & (sizem - 1)) && !(ph >> 48)) {
 					// power-of-two size: the modulus is a mask (as in k_leaf_oscpan)
@@ -983,15 +1051,15 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 						ph += (uint64_t)dph * (unsigned)nfr[j];
 					}
 				}
-				Coef3 ka[OSC2_FCH], kb[OSC2_FCH];
+				Coef4 ka[OSC2_FCH], kb[OSC2_FCH];
 				unsigned pa[OSC2_FCH], pb[OSC2_FCH];
 #pragma unroll
 				for(int j = 0; j < OSC2_FCH; ++j) {
-					pa[j] = (unsigned)((phs[j] + lanedph) >> 16);
+					pa[j] = tap_phase(phs[j], ldph);
 					asm("" : "+v"(pa[j]));	// (32 bit offsets: scalar-base loads, as in k_leaf_oscpan)
 					pb[j] = pa[j] + (dph >> 17);
-					ka[j] = coef_at(cb, pa[j]);
-					kb[j] = coef_at(cb, pb[j]);
+					ka[j] = coef_at(crs, cb, pa[j]);
+					kb[j] = coef_at(crs, cb, pb[j]);
 				}
 #pragma unroll
 				for(int j = 0; j < OSC2_FCH; ++j) {
@@ -1264,7 +1332,7 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	int n_win = 0, n_rec = 0;
 #endif
 	const A2DParams &p = *pp;
-	const int wv = threadIdx.x >> 6;
+	const int wv = rfl((int)(threadIdx.x >> 6));	// (wave-uniform, and known to the compiler as such)
 	const int lane = threadIdx.x & 63;
 	const int first = gw * vpw;
 	// (a wavefront past the end of the list still meets the others at the barriers)
@@ -1744,7 +1812,9 @@ int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc
 #define FILT_MAXV   64
 #define FILT_PITCH  65
 #ifndef FILT_WAVES
-#define FILT_WAVES  8	// wavefronts per workgroup: one filters, the others run the oscillators / pans (16 spill)
+#define FILT_WAVES  16	// wavefronts per workgroup: one filters, the others run the oscillators / pans.  (One
+			// workgroup of 16 per CU with 64 voices - every lane of the filter wavefront busy - since the
+			// oscillator wavefronts have their all-settled loop; 8 and two workgroups per CU before.)
 #endif
 #ifndef FILT_BATCH
 #define FILT_BATCH  5	// settled voices whose coefficient loads are in flight together
@@ -1758,28 +1828,35 @@ int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc
 #ifndef FILT_LIGHT
 #define FILT_LIGHT -1	// voices of an oscillator wavefront next to the OTHER workgroup's filter wavefront (-1: even share)
 #endif
+#ifndef FILT_FASTV
+#define FILT_FASTV 6	// most voices an oscillator wavefront takes through its all-settled loop (0: the general loop only)
+#endif
 #ifndef FILT_ROT
 #define FILT_ROT 0	// 1: workgroups that share a CU put their filter wavefronts on different SIMDs
 #endif
 enum { FV_Q = 0, FV_LP = 4, FV_BP, FV_HP, FV_F1, FV_D1, FV_D2, FV_NWORDS };
 
-// one filter step (f12_process, filter12.c:98-117)
-template<bool LPONLY>
-DEV int filt_step(int xin, int qq, int ff, int lp, int bp, int hp, int &d1, int &d2)
+// one filter step (f12_process, filter12.c:98-117).  The filter wavefront's chain of dependent
+// instructions is what a pipeline step waits for, so two things that are not part of the recurrence
+// are done by the stages around it, all lanes busy: the oscillator stage stores the input already
+// shifted (x5 = in >> 5), and where the whole workgroup runs pure low pass filters (LPRAW) the row
+// keeps l and the pan stage scales it, (l * lp) >> 3.  12 instructions per frame instead of 15.
+template<bool LPRAW>
+DEV int filt_step(int x5, int qq, int ff, int lp, int bp, int hp, int &d1, int &d2)
 {
 	const int d1s = d1 >> 4;
 	const int l = wadd(d2, wmul(ff, d1s) >> 8);
-	const int h = wsub(wsub(xin >> 5, l), wmul(qq, d1s) >> 8);
+	const int h = wsub(wsub(x5, l), wmul(qq, d1s) >> 8);
 	const int b = wadd(wmul(ff, h >> 4) >> 8, d1);
 	d1 = b;
 	d2 = l;
-	return LPONLY ? (wmul(l, lp) >> 3) : (wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3);
+	return LPRAW ? l : (wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3);
 }
 
 // the filter along one voice's row: n frames in place.  The LDS round trip (~130
 // cycles) must not sit on the recurrence: a full fragment is taken sixteen frames at
 // a time - sixteen reads in flight, sixteen steps in registers, sixteen writes.
-template<bool LPONLY, bool QREST>
+template<bool LPRAW, bool QREST>
 DEV void filt_row(int *row, int n, int ff, int lp, int bp, int hp, int &d1, int &d2, int &qv, int qdelta)
 {
 	if(n == A2D_FRAG) {
@@ -1791,7 +1868,7 @@ DEV void filt_row(int *row, int n, int ff, int lp, int bp, int hp, int &d1, int 
 				x[k] = row[s0 + k];
 #pragma unroll
 			for(int k = 0; k < 16; ++k) {
-				x[k] = filt_step<LPONLY>(x[k], qv >> 12, ff, lp, bp, hp, d1, d2);
+				x[k] = filt_step<LPRAW>(x[k], qv >> 12, ff, lp, bp, hp, d1, d2);
 				if(!QREST)
 					qv = wadd(qv, qdelta);
 			}
@@ -1802,7 +1879,7 @@ DEV void filt_row(int *row, int n, int ff, int lp, int bp, int hp, int &d1, int 
 		return;
 	}
 	for(int s = 0; s < n; ++s) {
-		row[s] = filt_step<LPONLY>(row[s], qv >> 12, ff, lp, bp, hp, d1, d2);
+		row[s] = filt_step<LPRAW>(row[s], qv >> 12, ff, lp, bp, hp, d1, d2);
 		if(!QREST)
 			qv = wadd(qv, qdelta);
 	}
@@ -1820,13 +1897,14 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 {
 	extern __shared__ __attribute__((aligned(16))) int tiles[];	// 3 x [vpg][FILT_PITCH]
 	const A2DParams &p = *pp;
-	const int wv = threadIdx.x >> 6;
+	const int wv = rfl((int)(threadIdx.x >> 6));	// (wave-uniform, and known to the compiler as such)
 	const int lane = threadIdx.x & 63;
 	const int first = blockIdx.x * vpg;
 	const int nv = min(vpg, nlist - first);		// (the grid has no empty workgroups)
 	const int nfrags = p.nfrags;
 	const int dbg = p.debug;
 	FastPtrs g = { wavepool, waves, ptab, dbg };
+	const CoefRsrc crs = coef_rsrc(wavecoef);
 	const int tsize = vpg * FILT_PITCH;
 
 	// (fragment lengths straight from the parameter block, once per stage: no per-lane tables)
@@ -1841,6 +1919,12 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 	// their filter wavefront - a stream of dependent instructions that wants a SIMD's issue slots -
 	// on SIMD 0 and on SIMD 1; the other wavefront of that SIMD stays idle ("partner"), and the
 	// oscillator wavefronts that sit on the OTHER workgroup's filter SIMD take fewer voices ("light").
+	// The workgroup's share of a bus, fragment by fragment (a ring of three like the tiles): where all
+	// its voices mix into ONE stereo bus the oscillator / pan wavefronts add their sums here (LDS
+	// atomics) and an idle wavefront next to the filter ("flusher") adds the total to the bus in device
+	// memory one step later - one pair of global atomics per workgroup and fragment instead of one per
+	// wavefront (16 384 voices straight into the root bus: every wavefront of the chip on the same 128 words).
+	__shared__ int s_acc[3][2][A2D_FRAG];
 	__shared__ int s_simd[FILT_WAVES];
 	__shared__ int s_target;
 	int fw = 0, my_simd = wv & 3, tgt = 0;
@@ -1887,7 +1971,8 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 			fv[FV_LP] = w1[FW_LP]; fv[FV_BP] = w1[FW_BP]; fv[FV_HP] = w1[FW_HP];
 			fv[FV_F1] = w1[FW_F1]; fv[FV_D1] = w1[FW_D1A]; fv[FV_D2] = w1[FW_D2A];
 		}
-		// the common shapes, decided for the whole wavefront: low pass only, q at rest
+		// the common shapes, decided for the whole wavefront: low pass only (for the batch: the
+		// oscillator wavefronts come to the same answer from the same words), q at rest (per fragment)
 		const bool lponly = __all(!mine || (fv[FV_BP] == 0 && fv[FV_HP] == 0));
 #ifdef FILT_PROF
 		long long tb = 0, tw = 0;
@@ -1907,6 +1992,8 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 				const bool qrest = __all(q.delta == 0);
 				if(lponly && qrest)
 					filt_row<true, true>(row, n, ff, lp, bp, hp, d1, d2, qv, q.delta);
+				else if(lponly)
+					filt_row<true, false>(row, n, ff, lp, bp, hp, d1, d2, qv, q.delta);
 				else if(qrest)
 					filt_row<false, true>(row, n, ff, lp, bp, hp, d1, d2, qv, q.delta);
 				else
@@ -1981,6 +2068,49 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 			ridx += (wv >> 2) * (nlight ? 2 : 3);
 		}
 	}
+	const bool flusher = role == 2 && ridx == 0;
+	bool wgbus = false;
+	int wg_off = -1;
+	{
+		int off_l = -1, nch_l = 0;
+		bool m_l = false;
+		if(lane < nv && p.runs[list[first + lane]].count == 0) {
+			m_l = true;
+			off_l = voices[list[first + lane]].out_off;
+			nch_l = voices[list[first + lane]].out_nch;
+		}
+		const unsigned long long any = __ballot(m_l);
+		if(any && npart > 0 && !(dbg & 8)) {	// (A2AMD_DEBUG bit 3: every wavefront straight to the bus, as before)
+			wg_off = rdl(off_l, (int)__builtin_ctzll(any));
+			wgbus = wg_off >= 0 && __all(!m_l || (off_l == wg_off && nch_l == 2));
+		}
+	}
+	if(flusher) {
+		for(int k = lane; k < 3 * 2 * A2D_FRAG; k += 64)
+			(&s_acc[0][0][0])[k] = 0;
+	}
+	// one fragment's sums of this wavefront onto its bus
+	auto bus_add = [&](int off, int nch, int fc, int acc0, int acc1) __attribute__((always_inline)) {
+		if(dbg & 1)
+			return;
+		if(wgbus) {
+			if(acc0) atomicAdd(&s_acc[fc % 3][0][lane], acc0);
+			if(acc1) atomicAdd(&s_acc[fc % 3][1][lane], acc1);
+		} else {
+			int *dst = busmem + off + (size_t)fc * nch * A2D_FRAG;
+			if(acc0) atomicAdd(&dst[lane], acc0);
+			if(acc1) atomicAdd(&dst[A2D_FRAG + lane], acc1);
+		}
+	};
+	// the flusher: the workgroup's sum of fragment f (complete since the last barrier) to the bus
+	auto bus_flush = [&](int f) __attribute__((always_inline)) {
+		const int a0 = s_acc[f % 3][0][lane], a1 = s_acc[f % 3][1][lane];
+		s_acc[f % 3][0][lane] = 0;
+		s_acc[f % 3][1][lane] = 0;
+		int *dst = busmem + wg_off + (size_t)f * 2 * A2D_FRAG;
+		if(a0) atomicAdd(&dst[lane], a0);
+		if(a1) atomicAdd(&dst[A2D_FRAG + lane], a1);
+	};
 	const int nfull = max(1, FILT_WAVES - 1 - npart - nlight);
 	const int pshare = min(FILT_PARTNER, nv / (FILT_WAVES - 1));	// (never more than an even share)
 	const int lshare = nlight ? min(FILT_LIGHT, nv / (FILT_WAVES - 1)) : 0;
@@ -1999,10 +2129,21 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		vb = ridx * per + min(ridx, extra);
 		ve = min(rem, vb + per + (ridx < extra ? 1 : 0));
 	}
-	const int mv = max(0, ve - vb);		// my voices: lane l parks voice vb + l
+	const int mv = rfl(max(0, ve - vb));		// my voices: lane l parks voice vb + l
 
 	int sv[SV_NWORDS], dv[DV_NWORDS];
-	int u0 = 0, u2 = 0, my_off = -1, my_nch = 2;
+	int u0 = 0, u2 = 0, my_off = -1, my_nch = 2, my_lp = 0;
+	// The row format of the batch (filt_step): pure low pass filters in the whole workgroup leave
+	// l in the rows and the pan stage applies lp.  Every wavefront works it out from the same words.
+	bool lpraw;
+	{
+		bool plain = true;
+		if(lane < nv && p.runs[list[first + lane]].count == 0) {
+			const int *w1 = ustate + (size_t)voices[list[first + lane]].unit[1] * A2D_USTATE;
+			plain = w1[FW_BP] == 0 && w1[FW_HP] == 0;
+		}
+		lpraw = __all(plain);
+	}
 	bool mine = false;	// this lane's voice is ours to render (no records this batch)
 #pragma unroll
 	for(int k = 0; k < SV_NWORDS; ++k)
@@ -2017,6 +2158,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		const A2DVoice &vc = voices[list[first + vb + lane]];
 		u0 = vc.unit[0];
 		u2 = vc.unit[2];
+		my_lp = ustate[(size_t)vc.unit[1] * A2D_USTATE + FW_LP];
 		my_off = vc.out_off;
 		my_nch = vc.out_nch;
 		const int *w0 = ustate + (size_t)u0 * A2D_USTATE;
@@ -2071,6 +2213,142 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		curph = (phase >> (unsigned)dv[DV_MM]) % ((uint64_t)(unsigned)dv[DV_SIZEM] << 24);
 	}
 	uint64_t lastph = 0;	// ... and at the start of the last fragment rendered (for the end state)
+	uint64_t endph = 0;	// (the all-settled loop: the unwrapped phase after the last fragment)
+
+	// ---- The common case, a path of its own: every voice of this wavefront is ours, settled and
+	// mixes into the same stereo bus.  What the stages need per voice is then wave-uniform and constant
+	// over the batch - phase increment, table offset, amplitude, pan gains, bus - and lives in
+	// scalar registers for the whole fragment loop (the general loop below fetches it with a
+	// v_readlane per value, voice and fragment, behind lane masks it has to evaluate first); the
+	// phases advance in the scalar unit; lane * dph is kept per voice.  37 vector instructions per
+	// voice and fragment instead of 75.  (One barrier per step like the general loop and the
+	// filter wavefront: the wavefronts of a workgroup choose their loop independently.)
+	const bool fast = FILT_FASTV > 0 && !flusher && mv > 0 && mv <= FILT_FASTV && mine_mask == ((1ull << mv) - 1ull) &&
+			__all(lane >= mv || (dv[DV_SETTLED] && my_nch == 2 && my_off >= 0 && my_off == rdl(my_off, 0)));
+	// (one copy of the loop per number of voices, 1 .. FILT_FASTV: no guards inside)
+	auto fast_loop = [&](auto nvc, auto wgc) __attribute__((always_inline)) {
+		constexpr int NV = decltype(nvc)::value;
+		constexpr bool WG = decltype(wgc)::value;	// (the workgroup's sums meet in LDS: s_acc)
+		unsigned s_dph[NV], s_size[NV], ldph[NV];
+		int s_cb[NV], g_amp[NV], g_v0[NV], g_v1[NV], g_lp[NV];
+		uint64_t s_ph[NV];
+		const int bus = rdl(my_off, 0);
+#pragma unroll
+		for(int k = 0; k < NV; ++k) {
+			s_dph[k] = (unsigned)rdl(dv[DV_DPH], k);
+			s_size[k] = (unsigned)rdl(dv[DV_SIZEM], k);
+			s_cb[k] = coef_base((unsigned)rdl(dv[DV_DOFF], k));
+			// (the gains of a voice as vector registers, the same value in every lane:
+			// the scalar registers do not hold nine values for each of six voices)
+			g_amp[k] = rdl(sv[SV_A], k);
+			g_v0[k] = rdl(dv[DV_V0], k);
+			g_v1[k] = rdl(dv[DV_V1], k);
+			g_lp[k] = rdl(my_lp, k);
+			asm("" : "+v"(g_amp[k]), "+v"(g_v0[k]), "+v"(g_v1[k]), "+v"(g_lp[k]));
+			s_ph[k] = (uint64_t)(unsigned)rdl((int)(unsigned)curph, k) |
+					((uint64_t)(unsigned)rdl((int)(unsigned)(curph >> 32), k) << 32);
+			ldph[k] = lane_dph(lane, s_dph[k]);
+		}
+		for(int st = -1; st <= nfrags; ++st) {
+			// ---- A: the coefficient entries of fragment st + 1, all voices' in flight together ----
+			const int fa = st + 1;
+			Coef4 ka[NV], kb[NV];
+			unsigned pa[NV], pb[NV];
+			if(fa < nfrags) {
+#pragma unroll
+				for(int k = 0; k < NV; ++k) {
+					pa[k] = tap_phase(s_ph[k], ldph[k]);
+					pb[k] = pa[k] + (s_dph[k] >> 17);
+					ka[k] = coef_at(crs, s_cb[k], pa[k]);
+					kb[k] = coef_at(crs, s_cb[k], pb[k]);
+				}
+			}
+			// ---- C: pan + mix-down of fragment st - 1 (rows hold zeros past a short fragment's end) ----
+			const int fc = st - 1;
+			if(fc >= 0) {
+				const int *tile = tiles + (fc % 3) * tsize + vb * FILT_PITCH;
+				int y[NV];
+#pragma unroll
+				for(int k = 0; k < NV; ++k)
+					y[k] = tile[k * FILT_PITCH + lane];
+				int acc0 = 0, acc1 = 0;
+				if(lpraw) {
+#pragma unroll
+					for(int k = 0; k < NV; ++k)
+						y[k] = wmul(y[k], g_lp[k]) >> 3;
+				}
+#pragma unroll
+				for(int k = 0; k < NV; ++k) {
+					acc0 = wadd(acc0, mul64s(y[k], g_v0[k], 24));
+					acc1 = wadd(acc1, mul64s(y[k], g_v1[k], 24));
+				}
+				if(!(dbg & 1)) {
+					if(WG) {
+						if(acc0) atomicAdd(&s_acc[fc % 3][0][lane], acc0);
+						if(acc1) atomicAdd(&s_acc[fc % 3][1][lane], acc1);
+					} else {
+						int *dst = busmem + bus + (size_t)fc * 2 * A2D_FRAG;
+						if(acc0) atomicAdd(&dst[lane], acc0);
+						if(acc1) atomicAdd(&dst[A2D_FRAG + lane], acc1);
+					}
+				}
+			}
+			// ---- A, second half: Hermite, amplitude, rows of the next tile; the phases move on ----
+			if(fa < nfrags) {
+				const int n = FILT_FRAMES(fa);
+				int *tile = tiles + (fa % 3) * tsize + vb * FILT_PITCH;
+				int x[NV];
+#pragma unroll
+				for(int k = 0; k < NV; ++k)
+					x[k] = mul64s(hermite_c(ka[k], pa[k]) + hermite_c(kb[k], pb[k]), g_amp[k], 17) >> 5;	// (x5: filt_step)
+				if(n == A2D_FRAG) {
+#pragma unroll
+					for(int k = 0; k < NV; ++k)
+						tile[k * FILT_PITCH + lane] = x[k];
+				} else {
+#pragma unroll
+					for(int k = 0; k < NV; ++k)
+						tile[k * FILT_PITCH + lane] = (lane < n) ? x[k] : 0;
+				}
+				// (after the last fragment the phases stay unwrapped: what the epilogue stores, wtosc.c:284)
+				const bool wrap = fa != nfrags - 1;
+#pragma unroll
+				for(int k = 0; k < NV; ++k) {
+					uint64_t ph = s_ph[k] + (uint64_t)s_dph[k] * (unsigned)n;
+					unsigned hi = (unsigned)(ph >> 24);
+					if(hi >= s_size[k] && wrap) {
+						hi -= s_size[k];
+						if(hi >= s_size[k])
+							hi %= s_size[k];
+						ph = ((uint64_t)hi << 24) | (ph & 0xffffffu);
+					}
+					s_ph[k] = ph;
+				}
+			}
+			__syncthreads();
+		}
+#pragma unroll
+		for(int k = 0; k < NV; ++k)
+			if(lane == k)
+				endph = s_ph[k];
+	};
+	if(fast) {
+		switch(mv) {
+#define FAST_CASE(N) case N: if(N <= FILT_FASTV) { if(wgbus) fast_loop(std::integral_constant<int, N>{}, std::true_type{}); \
+			else fast_loop(std::integral_constant<int, N>{}, std::false_type{}); } break;
+		FAST_CASE(1) FAST_CASE(2) FAST_CASE(3) FAST_CASE(4) FAST_CASE(5) FAST_CASE(6) FAST_CASE(7) FAST_CASE(8)
+#undef FAST_CASE
+		}
+		// nothing but the oscillators' phases has moved (the general loop's epilogue below writes
+		// every word back; here the other state words are not even kept in registers)
+		if(mine) {
+			const uint64_t ph = endph << (unsigned)dv[DV_MM];
+			int *w0 = ustate + (size_t)u0 * A2D_USTATE;
+			w0[OW_PHASE_LO] = (int)(unsigned)ph;
+			w0[OW_PHASE_HI] = (int)(unsigned)(ph >> 32);
+		}
+		return;
+	}
 
 #ifdef FILT_PROF
 	long long ta = 0, tc = 0, tw = 0;
@@ -2083,7 +2361,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		// the wavefront's first FILT_BATCH settled voices are issued here, the pan stage
 		// of fragment st - 1 runs while they are in flight, the Hermite arithmetic after.
 		const int fa = st + 1;
-		Coef3 pqa[FILT_BATCH], pqb[FILT_BATCH];
+		Coef4 pqa[FILT_BATCH], pqb[FILT_BATCH];
 		unsigned pqph[FILT_BATCH], pqph2[FILT_BATCH];
 		int pnb = 0;
 		if(fa < nfrags) {
@@ -2099,11 +2377,11 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 					const unsigned dph = (unsigned)rdl(dv[DV_DPH], vk), doff = (unsigned)rdl(dv[DV_DOFF], vk);
 					const uint64_t ph = (uint64_t)(unsigned)rdl((int)cur_lo, vk) |
 							((uint64_t)(unsigned)rdl((int)cur_hi, vk) << 32);
-					pqph[k] = (unsigned)((ph + (uint64_t)(unsigned)lane * dph) >> 16);
+					pqph[k] = tap_phase(ph, (unsigned)lane * dph);
 					pqph2[k] = pqph[k] + (dph >> 17);
-					const char *cb = (const char *)(wavecoef + 3 * (size_t)doff);
-					pqa[k] = coef_at(cb, pqph[k]);
-					pqb[k] = coef_at(cb, pqph2[k]);
+					const int cb = coef_base(doff);
+					pqa[k] = coef_at(crs, cb, pqph[k]);
+					pqb[k] = coef_at(crs, cb, pqph2[k]);
 				}
 			}
 		}
@@ -2125,11 +2403,8 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 					continue;
 				const int voff = rdl(my_off, v);
 				if(voff != cur_off) {
-					if(cur_off >= 0 && !(dbg & 1)) {
-						int *dst = busmem + cur_off + (size_t)fc * cur_nch * A2D_FRAG;
-						if(acc0) atomicAdd(&dst[lane], acc0);
-						if(acc1) atomicAdd(&dst[A2D_FRAG + lane], acc1);
-					}
+					if(cur_off >= 0)
+						bus_add(cur_off, cur_nch, fc, acc0, acc1);
 					acc0 = acc1 = 0;
 					cur_off = voff;
 					cur_nch = rdl(my_nch, v);
@@ -2142,6 +2417,8 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 						y = (v == k) ? yrow[k] : y;
 				} else
 					y = tile[v * FILT_PITCH + lane];
+				if(lpraw)
+					y = wmul(y, rdl(my_lp, v)) >> 3;	// (filt_step: the row holds l)
 				if(rdl(dv[DV_SETTLED], v)) {
 					const int v0 = rdl(dv[DV_V0], v), v1 = rdl(dv[DV_V1], v);
 					if(lane < n) {
@@ -2162,12 +2439,11 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 					WRL(sv[SV_PAN + 2], pan.delta); WRL(sv[SV_PAN + 3], pan.timer);
 				}
 			}
-			if(cur_off >= 0 && !(dbg & 1)) {
-				int *dst = busmem + cur_off + (size_t)fc * cur_nch * A2D_FRAG;
-				if(acc0) atomicAdd(&dst[lane], acc0);
-				if(acc1) atomicAdd(&dst[A2D_FRAG + lane], acc1);
-			}
+			if(cur_off >= 0)
+				bus_add(cur_off, cur_nch, fc, acc0, acc1);
 		}
+		if(flusher && wgbus && st >= 2 && !(dbg & 1))
+			bus_flush(st - 2);
 #ifdef FILT_PROF
 		const long long c1 = __builtin_readcyclecounter();
 #endif
@@ -2186,7 +2462,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 #pragma unroll
 				for(int k = 0; k < FILT_BATCH; ++k)
 					if(k < pnb)
-						tile[k * FILT_PITCH + lane] = (lane < n) ? xs[k] : 0;
+						tile[k * FILT_PITCH + lane] = (lane < n) ? xs[k] >> 5 : 0;	// (x5: filt_step)
 			}
 			for(int v = pnb; v < mv; ++v) {
 				int x;
@@ -2198,10 +2474,10 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 					const unsigned dph = (unsigned)rdl(dv[DV_DPH], v), doff = (unsigned)rdl(dv[DV_DOFF], v);
 					const int amp = rdl(sv[SV_A], v);
 					const uint64_t ph = (uint64_t)(unsigned)rdl((int)cur_lo, v) | ((uint64_t)(unsigned)rdl((int)cur_hi, v) << 32);
-					unsigned ph16 = (unsigned)((ph + (uint64_t)(unsigned)lane * dph) >> 16);
+					unsigned ph16 = tap_phase(ph, (unsigned)lane * dph);
 					const unsigned ph16b = ph16 + (dph >> 17);
-					const char *cb = (const char *)(wavecoef + 3 * (size_t)doff);
-					int sm = hermite_c(coef_at(cb, ph16), ph16) + hermite_c(coef_at(cb, ph16b), ph16b);
+					const int cb = coef_base(doff);
+					int sm = hermite_c(coef_at(crs, cb, ph16), ph16) + hermite_c(coef_at(crs, cb, ph16b), ph16b);
 					x = mul64s(sm, amp, 17);
 				} else {
 					OscS o;
@@ -2228,7 +2504,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 					WRL(sv[SV_A], o.a.value); WRL(sv[SV_A + 1], o.a.target);
 					WRL(sv[SV_A + 2], o.a.delta); WRL(sv[SV_A + 3], o.a.timer);
 				}
-				tile[v * FILT_PITCH + lane] = (lane < n) ? x : 0;
+				tile[v * FILT_PITCH + lane] = (lane < n) ? x >> 5 : 0;
 			}
 			// every settled voice moves on by n frames (all lanes at once)
 			if(mine && dv[DV_SETTLED]) {
@@ -2255,6 +2531,9 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		tw += __builtin_readcyclecounter() - c2;
 #endif
 	}
+	// (step st flushed fragment st - 2; the last fragment's sums were complete at the last barrier)
+	if(flusher && wgbus && nfrags >= 1 && !(dbg & 1))
+		bus_flush(nfrags - 1);
 #ifdef FILT_PROF
 	if((blockIdx.x == 7 || blockIdx.x == 263) && lane == 0 && nfrags > 100)
 		printf("block %d wave %d simd %d cu %d (osc/pan, %d voices): %lld cycles issue+pan, %lld oscillators, %lld waiting\n",
@@ -2898,7 +3177,7 @@ void k_leaf_fmpan(const A2DParams *__restrict__ pp, const int *__restrict__ list
 	for(int i = threadIdx.x; i < 2048; i += 64 * FAST_WPB)
 		sine[i] = fmsine[i];
 	__syncthreads();
-	const int wv = threadIdx.x >> 6;
+	const int wv = rfl((int)(threadIdx.x >> 6));	// (wave-uniform, and known to the compiler as such)
 	const int lane = threadIdx.x & 63;
 	const int first = (blockIdx.x * FAST_WPB + wv) * vpw;
 	if(first >= nlist)
@@ -2947,7 +3226,7 @@ void k_leaf_fmpan_all(const A2DParams *__restrict__ pp, const int *__restrict__ 
 	for(int i = threadIdx.x; i < 2048; i += 64 * FAST_WPB)
 		sine[i] = fmsine[i];
 	__syncthreads();
-	const int wv = threadIdx.x >> 6;
+	const int wv = rfl((int)(threadIdx.x >> 6));	// (wave-uniform, and known to the compiler as such)
 	const int lane = threadIdx.x & 63;
 	int gw = blockIdx.x * FAST_WPB + wv;	// wavefront index; which kind's range is it in?
 	int kind = -1, first = 0, nv = 0, at = 0;

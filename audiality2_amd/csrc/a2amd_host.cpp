@@ -78,7 +78,7 @@ int a2amd_open(const a2amd_config *cfg, a2amd_ctx **out)
 	OPENCHK(hipMalloc((void **)&c->d_ptab, sizeof(c->ptab)));
 	OPENCHK(hipMalloc((void **)&c->d_wavepool.d, (size_t)(8u << 20) * sizeof(int16_t)));
 	c->d_wavepool.cap = 8u << 20;
-	OPENCHK(hipMalloc((void **)&c->d_wavecoef.d, (size_t)(8u << 20) * 3 * sizeof(int32_t)));
+	OPENCHK(hipMalloc((void **)&c->d_wavecoef.d, (size_t)(8u << 20) * A2D_COEF_WORDS * sizeof(int32_t)));
 	c->d_wavecoef.cap = 8u << 20;
 #undef OPENCHK
 	*out = c;
@@ -176,9 +176,12 @@ int a2amd_wave_upload(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w)
 		}
 	if(pos == (size_t)-1) {
 		if(c->wavepool_used + total > c->d_wavepool.cap) {
+			// (the kernels address the coefficient table by 32 bit byte offsets, up to 16 bytes per sample)
+			if(c->wavepool_used + total > ((size_t)1 << 27))
+				return c->fail(A2AMD_ENOMEM, "wave pool beyond 2^27 samples");
 			if(int r = grow(c, c->d_wavepool, c->wavepool_used + total, 1, true)) return r;
 			// the coefficient table follows the pool: rebuilt for what is in it
-			if(int r = grow(c, c->d_wavecoef, c->d_wavepool.cap, 3, false)) return r;
+			if(int r = grow(c, c->d_wavecoef, c->d_wavepool.cap, A2D_COEF_WORDS, false)) return r;
 			if(c->wavepool_used > 3 && a2d_launch_build_coef(c->d_wavepool.d, c->d_wavecoef.d, 1,
 					(unsigned)c->wavepool_used - 2, c->stream))
 				return c->fail(A2AMD_EHIP, "coefficient build failed");

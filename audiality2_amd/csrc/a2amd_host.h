@@ -330,7 +330,7 @@ struct a2amd_ctx {
 	DevBuf<A2DRec> d_recs;
 	DevBuf<A2DWave> d_waves;
 	DevBuf<int16_t> d_wavepool;
-	DevBuf<int32_t> d_wavecoef;	// cap in pool samples, 3 words each (a2amd_fast.hip: Coef3)
+	DevBuf<int32_t> d_wavecoef;	// cap in pool samples, A2D_COEF_WORDS words each (a2amd_fast.hip: Coef4)
 	DevBuf<int32_t> d_busmem;
 	DevBuf<int32_t> d_fbdmem;	// cap in buffer pairs
 	DevBuf<int32_t> d_fmstate;	// cap in slots of A2D_FMSTATE words

@@ -960,11 +960,12 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		}
 		if(c->n_filt_leaf) {
 			// voices per workgroup = lanes of its filter wavefront: all 64 once there
-			// are enough voices for a workgroup on every CU, else spread out (a
-			// workgroup takes as long as its filter chain, whatever its voice count)
+			// are enough voices for a workgroup on every CU (one 16-wavefront workgroup
+			// per CU), else spread out (a workgroup takes as long as its filter chain,
+			// whatever its voice count)
 			const int nf = c->n_filt_leaf;
 			int vpw = getenv("A2AMD_FVPW") ? atoi(getenv("A2AMD_FVPW")) :
-					std::min(std::max((nf + 511) / 512, 1), 32);
+					std::min(std::max((nf + 255) / 256, 1), 64);
 			if(a2d_launch_leaf_oscfiltpan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf,
 					c->n_filt_leaf, vpw, c->stream))
 				return c->fail(A2AMD_EHIP, "filter leaf launch failed: %s", hipGetErrorString(hipGetLastError()));

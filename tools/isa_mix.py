@@ -48,6 +48,7 @@ RATE_NAME = {
     "v_xad_u32": "add3", "v_dot2_i32_i16": "dot2_i32_i16", "v_pk_mad_i16": "pk_mad_i16",
 }
 FAST_T = 50.0       # T lane-ops/s above which an instruction is in the 2-cycle class
+TAP_LOADS = ("buffer_load_dwordx3", "buffer_load_dwordx4", "global_load_dwordx3")   # one Hermite coefficient entry (a2amd_fast.hip: coef_at)
 
 
 def rates_table():
@@ -148,17 +149,17 @@ def classify(ins, rates):
 def pick_loops(ins):
     """The loops worth looking at, by a rule that can be checked against the listing (--loops):
     'taps'       the SMALLEST loop that contains every wave-data tap load of the kernel
-                 (global_load_dwordx3: one Hermite coefficient entry, a2amd_fast.hip) - one trip
+                 (buffer_load_dwordx4 ... idxen: one Hermite coefficient entry, a2amd_fast.hip) - one trip
                  renders one chunk of fragments for the voices of a wavefront: the oscillator /
                  pan / mix-down work;
     'recurrence' the largest loop without any vector memory instruction that works on an LDS tile
                  (k_leaf_oscfiltpan: the filter wavefront's 16 frames of filter12 per trip).
     Kernels without tap loads: the innermost loop with the most VALU instructions."""
     loops = find_loops(ins)
-    nx3 = sum(m == "global_load_dwordx3" for _, m, _, _ in ins)
+    nx3 = sum(m in TAP_LOADS for _, m, _, _ in ins)
     out = {}
     if nx3:
-        full = [l for l in loops if sum(m == "global_load_dwordx3" for _, m, _, _ in ins[l[0]:l[1] + 1]) == nx3]
+        full = [l for l in loops if sum(m in TAP_LOADS for _, m, _, _ in ins[l[0]:l[1] + 1]) == nx3]
         if full:
             out["taps"] = min(full, key=lambda l: l[1] - l[0])
     novm = [l for l in loops if not any(m.startswith(("global_", "buffer_", "flat_")) for _, m, _, _ in ins[l[0]:l[1] + 1])]
@@ -298,7 +299,7 @@ def main():
                 if args.loops:
                     res["all_loops"] = [{"start": hex(ins[a][0]), "end": hex(ins[b][0]), "insts": b - a + 1,
                                          "valu": sum(is_valu(m) for _, m, _, _ in ins[a:b + 1]),
-                                         "tap_loads": sum(m == "global_load_dwordx3" for _, m, _, _ in ins[a:b + 1])}
+                                         "tap_loads": sum(m in TAP_LOADS for _, m, _, _ in ins[a:b + 1])}
                                         for a, b in sorted(find_loops(ins), key=lambda l: l[1] - l[0])]
                 if args.emit:
                     res["emitted_valu"] = emit(body, args.emit, w)
