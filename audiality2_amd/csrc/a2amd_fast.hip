@@ -1799,16 +1799,25 @@ int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc
 // steps per fragment).  Round 1 ran the three stages one after the other on ONE
 // wavefront owning 8 voices: the filter stage then issues a wave-wide instruction
 // for 8 busy lanes, 176 of the 253 vector instructions per voice-fragment.  Here a
-// workgroup of four wavefronts owns up to 64 voices and runs the stages as a
+// workgroup of FILT_WAVES wavefronts owns up to 64 voices and runs the stages as a
 // pipeline over the fragments, a barrier per step:
 //
-//   wavefront 0      B(f)    every lane = one voice: filter fragment f in place
-//   wavefronts 1-3   A(f+1)  oscillators of fragment f+1 -> rows of the next tile
-//                    C(f-1)  rows of fragment f-1 x pan gains -> bus (atomics)
+//   one wavefront    B(f)    every lane = one voice: filter fragment f in place
+//   the others       A(f+1)  oscillators of fragment f+1 -> rows of the next tile
+//                    C(f-1)  rows of fragment f-1 x pan gains -> bus
 //
 // through a ring of three [voices][64+1] LDS tiles (+1: row and column accesses
-// both bank-conflict free).  The filter stage is all lanes busy (15-19 instructions
-// per step) and alone on its SIMD, the other two stages fill the other three.
+// both bank-conflict free).  A step is as long as the filter wavefront's chain of
+// dependent instructions - 64 frames x 12 instructions, about 4 600 cycles - so
+// everything that is not the recurrence has been moved off that wavefront (filt_step)
+// and the other stages are kept well below that: wavefronts whose voices are all
+// settled run a loop of their own with the per-voice values in scalar registers (37
+// vector instructions per voice and fragment), and the workgroup's bus sums meet in
+// LDS before one wavefront adds them to the bus in device memory.
+// Round 3 measurements (16 384 voices x 256 fragments): 1.15 ms with 8 wavefronts x 32
+// voices and the general loop only; 0.85 with the all-settled loop; 0.72 with 16
+// wavefronts x 64 voices; 0.68 with the 12-instruction recurrence; 0.58 with the LDS
+// bus sums (configs[4]'s share, 32 768 voices on 128 buses: 2.42 -> 1.12 ms).
 #define FILT_MAXV   64
 #define FILT_PITCH  65
 #ifndef FILT_WAVES

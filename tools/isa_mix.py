@@ -149,11 +149,17 @@ def classify(ins, rates):
 def pick_loops(ins):
     """The loops worth looking at, by a rule that can be checked against the listing (--loops):
     'taps'       the SMALLEST loop that contains every wave-data tap load of the kernel
-                 (buffer_load_dwordx4 ... idxen: one Hermite coefficient entry, a2amd_fast.hip) - one trip
+                 (buffer_load_dwordx3 ... idxen: one Hermite coefficient entry, a2amd_fast.hip) - one trip
                  renders one chunk of fragments for the voices of a wavefront: the oscillator /
-                 pan / mix-down work;
-    'recurrence' the largest loop without any vector memory instruction that works on an LDS tile
-                 (k_leaf_oscfiltpan: the filter wavefront's 16 frames of filter12 per trip).
+                 pan / mix-down work.  Where no loop holds them all (k_leaf_oscfiltpan has one copy of
+                 its all-settled loop per number of voices and bus mode): the loops with the MOST tap
+                 loads that hold a whole pipeline step (a barrier; back edges to the same header count as one
+                 loop, its longest), of those the one with the fewest vector
+                 instructions, then the shortest - six
+                 voices, sums meeting in LDS: what the BASELINE configs run;
+    'recurrence' the smallest loop of at least 100 vector instructions without any vector memory
+                 instruction that works on an LDS tile (k_leaf_oscfiltpan: the filter wavefront's 16
+                 frames of filter12 per trip, the pure low pass shape the BASELINE voices have).
     Kernels without tap loads: the innermost loop with the most VALU instructions."""
     loops = find_loops(ins)
     nx3 = sum(m in TAP_LOADS for _, m, _, _ in ins)
@@ -162,12 +168,20 @@ def pick_loops(ins):
         full = [l for l in loops if sum(m in TAP_LOADS for _, m, _, _ in ins[l[0]:l[1] + 1]) == nx3]
         if full:
             out["taps"] = min(full, key=lambda l: l[1] - l[0])
+        else:
+            ntap = lambda l: sum(m in TAP_LOADS for _, m, _, _ in ins[l[0]:l[1] + 1])
+            most = max(ntap(l) for l in loops)
+            cand = [l for l in loops if ntap(l) == most]
+            steps = [l for l in cand if any(m == "s_barrier" for _, m, _, _ in ins[l[0]:l[1] + 1])]    # (a whole pipeline step)
+            # (several back edges to one header - 'continue' paths of short steps - are one loop: its last back edge)
+            steps = [l for l in steps if not any(o is not l and abs(o[0] - l[0]) <= 8 and o[1] > l[1] for o in steps)]
+            out["taps"] = min(steps or cand,
+                              key=lambda l: (sum(is_valu(m) for _, m, _, _ in ins[l[0]:l[1] + 1]), l[1] - l[0]))
     novm = [l for l in loops if not any(m.startswith(("global_", "buffer_", "flat_")) for _, m, _, _ in ins[l[0]:l[1] + 1])]
     novm = [l for l in novm if any(m.startswith("ds_") for _, m, _, _ in ins[l[0]:l[1] + 1])]     # (rows of an LDS tile)
+    novm = [l for l in novm if sum(is_valu(m) for _, m, _, _ in ins[l[0]:l[1] + 1]) >= 100]
     if novm:
-        big = max(novm, key=lambda l: sum(is_valu(m) for _, m, _, _ in ins[l[0]:l[1] + 1]))
-        if sum(is_valu(m) for _, m, _, _ in ins[big[0]:big[1] + 1]) >= 100:
-            out["recurrence"] = big
+        out["recurrence"] = min(novm, key=lambda l: l[1] - l[0])
     if not out:
         inner = [l for l in loops if not any(o != l and l[0] <= o[0] and o[1] <= l[1] for o in loops)] or loops
         if inner:
