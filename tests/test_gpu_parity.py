@@ -862,6 +862,41 @@ def test_filter_leaf_launch_shapes_at_bench_batch_match_oracle(oracle_lib, monke
     assert first_diff(got, want) is None
 
 
+@pytest.mark.parametrize("fvpw", [6, 64])
+def test_filter_leaf_paths_mixed_buses_filter_shapes_and_short_fragments(oracle_lib, monkeypatch, fvpw):
+    """k_leaf_oscfiltpan's round-3 paths side by side: wavefronts whose voices are all settled (their own
+    loop, per voice count 1..6) next to wavefronts with a voice that is not (a q ramp, an amplitude ramp:
+    the general loop); workgroups whose voices share one bus (sums meet in LDS) next to workgroups that
+    straddle buses; workgroups of pure low pass filters (the row keeps l) next to ones with band / high
+    pass mixed in; full fragments, then short ones, then single frames."""
+    monkeypatch.setenv("A2AMD_FVPW", str(fvpw))
+    outs = []
+    for be in (make_gpu(max_batch=32), make_oracle(oracle_lib)):
+        sc = synth.Scene(be)
+        sc.root()
+        groups = [sc.add_bus_group() for _ in range(3)]
+        for g, n in zip(groups, (37, 100, 203)):
+            sc.add_voices(n, chain="osc-filter-pan", group=g, total=1024)
+        sc.add_voices(150, chain="osc-filter-pan", total=1024)
+        leaves = [u for g in groups for u in g["leaves"]] + sc.leaves
+        for k, units in enumerate(leaves):
+            osc, filt, pan = units
+            if 128 <= k < 200 and k % 3 == 0:        # band / high pass mixed in: the full output expression
+                be.unit_write(filt, 3, synth.fix(0.4))
+                be.unit_write(filt, 4, synth.fix(-0.3))
+            if k % 53 == 7:                          # q on its way somewhere for 40 ms
+                be.unit_write(filt, 1, synth.fix(9.0), 0, 40 << 8)
+            if k % 61 == 11:                         # amplitude ramp: the oscillator is not settled
+                be.unit_write(osc, 2, synth.fix(0.001), 0, 25 << 8)
+        a = sc.run(40, batch=32, frames=64)
+        b = sc.run(7, batch=32, frames=23)
+        c = sc.run(3, batch=32, frames=1)
+        d = sc.run(36, batch=32, frames=64)
+        outs.append(np.concatenate([a, b, c, d], axis=1))
+        be.close()
+    assert first_diff(outs[0], outs[1]) is None
+
+
 @pytest.mark.parametrize("config", [1, 2, 3])
 def test_baseline_configs_at_full_size_match_oracle_golden(config):
     """BASELINE configs[1..3] at FULL size (1 024 / 16 384 / 65 536 voices, 512
