@@ -156,7 +156,7 @@ struct A2DCommitSet { A2DCommit c[2]; int n; };
 int a2d_launch_leaf_oscpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
 		int vpw, int ysplit, int *ustage, void *stream, void *event_after_main, A2DCommit *defer);
 int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, int nfrags, int consume,
-		const A2DCommitSet *commits, void *stream);
+		const A2DCommitSet *commits, void *stream, int *master_host = nullptr);	// master_host: where the root stores the master bus (pinned host memory) instead of the bus memory
 int a2d_launch_commit(const A2DParams &hp, const A2DCommit &cm, void *stream);
 // quiet "inline; fbdelay 2->2 ... ; fbdelay 2->2 >" voices (one workgroup each)
 int a2d_launch_bus_fbdchain(const A2DParams *dparams, const int *dlist, int nlist, int consume, void *stream);

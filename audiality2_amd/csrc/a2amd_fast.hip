@@ -2258,7 +2258,13 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 					((uint64_t)(unsigned)rdl((int)(unsigned)(curph >> 32), k) << 32);
 			ldph[k] = lane_dph(lane, s_dph[k]);
 		}
+#ifdef FILT_PROF
+		long long ta = 0, tc = 0, tw = 0;
+#endif
 		for(int st = -1; st <= nfrags; ++st) {
+#ifdef FILT_PROF
+			const long long c0 = __builtin_readcyclecounter();
+#endif
 			// ---- A: the coefficient entries of fragment st + 1, all voices' in flight together ----
 			const int fa = st + 1;
 			Coef4 ka[NV], kb[NV];
@@ -2302,6 +2308,9 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 					}
 				}
 			}
+#ifdef FILT_PROF
+			const long long c1 = __builtin_readcyclecounter();
+#endif
 			// ---- A, second half: Hermite, amplitude, rows of the next tile; the phases move on ----
 			if(fa < nfrags) {
 				const int n = FILT_FRAMES(fa);
@@ -2334,8 +2343,22 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 					s_ph[k] = ph;
 				}
 			}
+#ifdef FILT_PROF
+			const long long c2 = __builtin_readcyclecounter();
+#endif
 			__syncthreads();
+#ifdef FILT_PROF
+			ta += c1 - c0;
+			tc += c2 - c1;
+			tw += __builtin_readcyclecounter() - c2;
+#endif
 		}
+#ifdef FILT_PROF
+		if((blockIdx.x == 7 || blockIdx.x == 263) && lane == 0 && nfrags > 100)
+			printf("block %d wave %d simd %d cu %d (osc/pan, all-settled loop, %d voices, sums %s): %lld cycles loads+pan, %lld hermite+rows, %lld waiting\n",
+					(int)blockIdx.x, wv, (int)__builtin_amdgcn_s_getreg(2308), (int)__builtin_amdgcn_s_getreg(6660), NV,
+					WG ? "in LDS" : "to the bus", ta, tc, tw);
+#endif
 #pragma unroll
 		for(int k = 0; k < NV; ++k)
 			if(lane == k)
@@ -2576,7 +2599,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
 void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int consume,
-		A2DCommitSet commits)
+		A2DCommitSet commits, int *__restrict__ master_host)
 {
 	__shared__ int fr[A2D_MAXBATCH][5];	// per fragment: vol, dvol, pan, dpan, clamp
 	const A2DParams &p = *pp;
@@ -2656,9 +2679,12 @@ void k_bus_driver(const A2DParams *__restrict__ pp, const int *__restrict__ list
 		}
 		int o0 = mul64s(i0, v0, 24), o1 = mul64s(i1, v1, 24);
 		if((consume & 2) && vc.out_off == 0) {
-			// ... and the master bus has one writer, the root: a plain store
-			dst[lane] = o0;
-			dst[A2D_FRAG + lane] = o1;
+			// ... and the master bus has one writer, the root: a plain store - straight into the
+			// host's (pinned, mapped) readback buffer where the caller wants the audio there: no copy
+			// command behind the batch (a2amd_render: 13 us of a 68 us step at configs[1])
+			int *m = master_host ? master_host + (size_t)f * vc.out_nch * A2D_FRAG : dst;
+			m[lane] = o0;
+			m[A2D_FRAG + lane] = o1;
 			continue;
 		}
 		if(o0)
@@ -3378,7 +3404,7 @@ int a2d_launch_commit(const A2DParams &hp, const A2DCommit &cm, void *stream)
 }
 
 int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist, int nfrags, int consume,
-		const A2DCommitSet *commits, void *stream)
+		const A2DCommitSet *commits, void *stream, int *master_host)
 {
 	if(nlist <= 0)
 		return 0;
@@ -3393,6 +3419,6 @@ int a2d_launch_bus_driver(const A2DParams *dparams, const int *dlist, int nlist,
 			}
 	// grid.y: workgroups per voice, 4 fragments in flight each
 	hipLaunchKernelGGL(k_bus_driver, dim3(nlist + extra, nfrags >= 16 ? 16 : (nfrags + 3) / 4), dim3(256), 0,
-			(hipStream_t)stream, dparams, dlist, nlist, consume, cs);
+			(hipStream_t)stream, dparams, dlist, nlist, consume, cs, master_host);
 	return (int)hipGetLastError();
 }

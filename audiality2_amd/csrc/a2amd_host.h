@@ -354,8 +354,14 @@ struct a2amd_ctx {
 	A2DParams hparams;
 	// [0] = GRAPH_STEPS whole runs of the batch, [1] = one run, [2] = its SUBTREES
 	// phase alone, [3] = its ROOT phase alone (multi-GPU steps)
-	hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
-	hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
+	// captured batches: [slot + 4 * v], slot = which phases (a2amd_render: run_phases, a2amd_replay),
+	// v = where the root stores the master bus - 0 the bus memory, 1 / 2 one of the host's readback buffers
+	hipGraph_t graph[12] = {};
+	hipGraphExec_t gexec[12] = {};
+	const int32_t *gdst[12] = {};
+	bool gdirect[12] = {};		// (the captured root launch stored there)
+	int32_t *master_dst = nullptr;	// where the root of the batch being issued is to store the master bus (nullptr: bus memory)
+	bool master_direct = false;	// ... and its launch did
 	int32_t *h_master = nullptr;	// pinned
 	size_t h_master_cap = 0;
 	// Identical-batch fast path: a batch without records, with the same fragment

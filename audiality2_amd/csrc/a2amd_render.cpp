@@ -88,6 +88,53 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		c->ev2 = c->ev_pool[c->ev_used + 2];
 		c->ev_used += 3;
 	}
+	// Where the master bus is to go.  A quiet batch whose root is a plain driver chain, rendered and
+	// read back in one call: the root kernel stores the audio straight into the host's pinned (and
+	// device-mapped) readback buffer - no copy command behind the kernels, which at configs[1] is
+	// 13 of a step's 68 us (the copy and the gap in front of it).
+	c->master_dst = nullptr;
+	c->master_direct = false;
+	int gv = 0;		// graph variant: the destination is an argument of the root's kernel
+	{
+		const unsigned both = A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT;
+		static const bool off = getenv("A2AMD_NO_DIRECT") != nullptr;
+		bool taps = false;
+		for(const XioSlot &x : c->xio)
+			if(x.unit >= 0 && x.tapped)
+				taps = true;
+		if(!off && (phases & A2AMD_RENDER_READBACK) && (phases & both) == both && !(phases & A2AMD_RENDER_KEEP) &&
+				!(phases & A2AMD_RENDER_TAPS) && !c->comm && !c->dist_local && c->uploaded && c->with_recs.empty() &&
+				c->consume_ok && c->sub_resume < 0 && !c->paused_at && !taps) {
+			const size_t n = (size_t)c->nfrags * c->cfg.channels * A2D_FRAG;
+			if(phases & A2AMD_RENDER_ASYNC) {
+				if(c->rb_count < 2) {
+					const int ri = (c->rb_head + c->rb_count) & 1;
+					a2amd_ctx::Readback &rb = c->rb[ri];
+					if(n > rb.cap) {
+						if(rb.h)
+							HIPCHK(c, hipHostFree(rb.h));
+						rb.h = nullptr;
+						rb.cap = 0;
+						HIPCHK(c, hipHostMalloc((void **)&rb.h, n * sizeof(int32_t), hipHostMallocDefault));
+						rb.cap = n;
+					}
+					c->master_dst = rb.h;
+					gv = 1 + ri;
+				}
+			} else if(out) {
+				if(n > c->h_master_cap) {
+					if(c->h_master)
+						HIPCHK(c, hipHostFree(c->h_master));
+					c->h_master = nullptr;
+					c->h_master_cap = 0;
+					HIPCHK(c, hipHostMalloc((void **)&c->h_master, n * sizeof(int32_t), hipHostMallocDefault));
+					c->h_master_cap = n;
+				}
+				c->master_dst = c->h_master;
+				gv = 1;
+			}
+		}
+	}
 	// A record-free batch that has been seen before runs from a graph - one launch
 	// instead of 3-5 separate commands: a kept batch re-run phase by phase
 	// (multi-GPU steps), or the engine recording the same quiet batch again.
@@ -103,11 +150,13 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 				 // against 25 us of host time per fragment at 65 536 voices)
 				 c->quiet_streak >= 1 && c->nfrags >= 8)) {
 			const int slot = kphases == A2AMD_RENDER_SUBTREES ? 2 : kphases == A2AMD_RENDER_ROOT ? 3 : 1;
-			if(c->gexec[slot] || !build_graph(c, slot, 1, kphases)) {
+			const int gi = slot + 4 * (slot == 2 ? 0 : gv);
+			if((c->gexec[gi] && c->gdst[gi] == c->master_dst) || !build_graph(c, gi, 1, kphases)) {
 				if(slot != 3)
 					if(int r = ensure_clean(c))
 						return r;
-				HIPCHK(c, hipGraphLaunch(c->gexec[slot], c->stream));
+				HIPCHK(c, hipGraphLaunch(c->gexec[gi], c->stream));
+				c->master_direct = c->gdirect[gi];	// (what the captured launch did)
 				if(c->hosttiming)
 					dbg_counters()[5] += 1;
 				if(slot == 1)
@@ -207,7 +256,8 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 			}
 			if(!rb.ev)
 				HIPCHK(c, hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming));
-			HIPCHK(c, hipMemcpyAsync(rb.h, c->d_busmem.d, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+			if(!(c->master_direct && c->master_dst == rb.h))	// (else the root kernel has stored it there)
+				HIPCHK(c, hipMemcpyAsync(rb.h, c->d_busmem.d, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
 			HIPCHK(c, hipEventRecord(rb.ev, c->stream));
 			rb.nfrags = c->nfrags;
 			rb.total = total;
@@ -228,7 +278,8 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 			HIPCHK(c, hipHostMalloc((void **)&c->h_master, n * sizeof(int32_t), hipHostMallocDefault));
 			c->h_master_cap = n;
 		}
-		HIPCHK(c, hipMemcpyAsync(c->h_master, c->d_busmem.d, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+		if(!(c->master_direct && c->master_dst == c->h_master))	// (else the root kernel has stored it there)
+			HIPCHK(c, hipMemcpyAsync(c->h_master, c->d_busmem.d, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
 		for(size_t k = 0; k < c->xio.size(); ++k) {
 			// what the READ clients of xinsert units are to be handed
 			XioSlot &x = c->xio[k];

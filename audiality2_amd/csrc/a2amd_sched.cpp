@@ -767,8 +767,12 @@ int launch_depth(a2amd_ctx *c, int d, int consume, A2DCommitSet *pend)	// consum
 	const DepthRange &r = c->depth_ranges[d];
 	if(r.fast_count) {
 		// (state commits the time-sliced leaf kernels left behind ride along)
+		// (the root, a plain driver chain that stores the master bus: into the host's buffer where asked)
+		const bool direct = d == 0 && (consume & 2) && c->master_dst && r.fast_count == 1 && !r.gen_count && !r.fbd_count;
+		if(direct)
+			c->master_direct = true;
 		if(a2d_launch_bus_driver(c->d_params, c->d_list.d + r.fast_first, r.fast_count, c->nfrags, consume,
-				pend, c->stream))
+				pend, c->stream, direct ? c->master_dst : nullptr))
 			return c->fail(A2AMD_EHIP, "bus driver launch failed: %s", hipGetErrorString(hipGetLastError()));
 		pend->n = 0;
 		++c->stats.launches;
@@ -1091,7 +1095,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 
 void drop_graphs(a2amd_ctx *c)
 {
-	for(int i = 0; i < 4; ++i) {
+	for(int i = 0; i < 12; ++i) {
 		if(c->gexec[i]) {
 			hipGraphExecDestroy(c->gexec[i]);
 			c->gexec[i] = nullptr;
@@ -1116,6 +1120,14 @@ int ensure_clean(a2amd_ctx *c)
 // capture 'steps' consecutive runs of the uploaded batch into one graph
 int build_graph(a2amd_ctx *c, int slot, int steps, unsigned phases)
 {
+	if(c->gexec[slot]) {		// (built for another destination of the master bus)
+		hipGraphExecDestroy(c->gexec[slot]);
+		c->gexec[slot] = nullptr;
+	}
+	if(c->graph[slot]) {
+		hipGraphDestroy(c->graph[slot]);
+		c->graph[slot] = nullptr;
+	}
 	hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
 	if(e != hipSuccess)
 		return c->fail(A2AMD_EHIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
@@ -1123,6 +1135,7 @@ int build_graph(a2amd_ctx *c, int slot, int steps, unsigned phases)
 	// (a captured run does not happen now: every graph starts from buses of
 	// unknown state, and what it leaves behind is noted when it is launched)
 	const bool oc = c->others_clean, rc = c->root_clean;
+	c->master_direct = false;
 	c->capturing = true;
 	for(int i = 0; i < steps && !r; ++i)
 		r = issue_kernels(c, phases, nullptr, nullptr, nullptr);
@@ -1137,6 +1150,8 @@ int build_graph(a2amd_ctx *c, int slot, int steps, unsigned phases)
 	e = hipGraphInstantiate(&c->gexec[slot], c->graph[slot], nullptr, nullptr, 0);
 	if(e != hipSuccess)
 		return c->fail(A2AMD_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+	c->gdst[slot] = c->master_dst;
+	c->gdirect[slot] = c->master_direct;
 	return 0;
 }
 
