@@ -550,7 +550,7 @@ def measure_single(audiality2_amd, cfg, B, steps, warmup, device=0, with_realtim
     return res
 
 
-def realtime_sweep(audiality2_amd, device=0, chain="osc-filter-pan", sizes=(262144, 524288), n=200):
+def realtime_sweep(audiality2_amd, device=0, chain="osc-filter-pan", sizes=(262144, 524288, 1048576), n=200):
     """The other half of BASELINE's metric - max realtime voices - on the GPU side: the largest
     N for which ONE 64-frame fragment of N sustained voices (wtosc->filter12->panmix, the
     north-star's voice, in BASELINE configs[4]'s tree: top-level groups of 128 sub-groups x 256
