@@ -552,6 +552,16 @@ static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned 
 				"supported (no CPU fallback)\n", u->descriptor->name);
 		return A2P_NOTIMPLEMENTED;	/* A2_VOICEINIT for this voice */
 	}
+	if(forward && hs->ndev > 1 && x->is_root && kind != A2AMD_INLINE && kind != A2AMD_PANMIX)
+	{
+		/* Over several contexts the root voice's chain is mirrored in each of them, and the mirrors
+		 * are addressed by kind (root_uid): that covers the engine's own root driver, inline + panmix
+		 * (+ xinsert, which stays with the engine).  A custom root program with anything else in it
+		 * would need a unit id per context: refused, not approximated. */
+		fprintf(stderr, "a2amd units: the root voice runs '%s': with A2AMD_DEVICES > 1 only the stock root "
+				"driver (inline, panmix, xinsert) is supported\n", u->descriptor->name);
+		return A2P_NOTIMPLEMENTED;
+	}
 	if(forward && hs->ndev > 1 && !x->is_root)
 	{
 		/* which GPU?  known when the voice is first processed (route_voice) */
