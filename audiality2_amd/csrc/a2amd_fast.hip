@@ -832,8 +832,40 @@ DEV void osc_to_lanes(int (&so)[OV_NWORDS], const OscS &o, bool me)
 	WRL(so[OV_A + 2], o.a.delta); WRL(so[OV_A + 3], o.a.timer);
 }
 
+// ... and from / to the unit's state words in memory (wave-uniform address)
+// (volatile: what this wavefront stored a chunk ago must come from memory, not from a scalar or
+// vector cache line fetched before)
+DEV void osc_from_mem(OscS &o, const volatile int *w)
+{
+	o.mode = rfl(w[OW_MODE]);
+	o.wave = rfl(w[OW_WAVE]);
+	o.dphase = (unsigned)rfl(w[OW_DPHASE]);
+	o.phase = (uint64_t)(unsigned)rfl(w[OW_PHASE_LO]) | ((uint64_t)(unsigned)rfl(w[OW_PHASE_HI]) << 32);
+	o.p_ramping = rfl(w[OW_PRAMPING]);
+	o.p.value = rfl(w[OW_P]); o.p.target = rfl(w[OW_P + 1]);
+	o.p.delta = rfl(w[OW_P + 2]); o.p.timer = rfl(w[OW_P + 3]);
+	o.a.value = rfl(w[OW_A]); o.a.target = rfl(w[OW_A + 1]);
+	o.a.delta = rfl(w[OW_A + 2]); o.a.timer = rfl(w[OW_A + 3]);
+	o.noise = 0;
+	o.seed = 0;
+}
+
+DEV void osc_to_mem(int *w, const OscS &o)
+{
+	w[OW_MODE] = o.mode;
+	w[OW_WAVE] = o.wave;
+	w[OW_DPHASE] = (int)o.dphase;
+	w[OW_PHASE_LO] = (int)(unsigned)o.phase;
+	w[OW_PHASE_HI] = (int)(unsigned)(o.phase >> 32);
+	w[OW_PRAMPING] = o.p_ramping;
+	w[OW_P] = o.p.value; w[OW_P + 1] = o.p.target; w[OW_P + 2] = o.p.delta; w[OW_P + 3] = o.p.timer;
+	w[OW_A] = o.a.value; w[OW_A + 1] = o.a.target; w[OW_A + 2] = o.a.delta; w[OW_A + 3] = o.a.timer;
+}
+
 #ifndef OSC2_WPE
-#define OSC2_WPE 3	// (measured: 3 wavefronts per SIMD with 143 registers and no spills beat 4 with 128 and 39 spills by a fifth)
+#define OSC2_WPE 4	// (round 2: 3 wavefronts per SIMD with 143 registers and no spills beat 4 with 128 and 39 spills by a
+			// fifth.  Round 3: with only the settled loop's values parked in registers the kernel needs 118 -
+			// 4 wavefronts without spills: 2.30 -> 2.24 ms at configs[3]; 3 wavefronts of the same code: 2.40)
 #endif
 __global__ __launch_bounds__(64 * FAST_WPB) __attribute__((amdgpu_waves_per_eu(OSC2_WPE, OSC2_WPE)))
 void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
@@ -871,21 +903,19 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 		fst[k] = (k * 64 + lane < nfrags) ? p.fragstart[k * 64 + lane] : 0;
 	}
 
-	int so[2][OV_NWORDS], sp[8], od[2][OD_NWORDS], v0l = 0, v1l = 0, settled_l = 0;
+	// What stays in registers over the launch, one voice per lane: what the settled loop needs (level,
+	// increment, table, amplitude and phase per oscillator, the two pan gains, the bus).  Everything
+	// else of a voice's state is read when it is decided whether the voice is settled and again, from
+	// memory, by the loop for voices that are not - rare, and 30 registers a wavefront.
+	int od[2][OD_NWORDS], amp_l[2] = { 0, 0 }, phlo_l[2] = { 0, 0 }, phhi_l[2] = { 0, 0 };
+	int v0l = 0, v1l = 0, settled_l = 0;
 	int uu[3] = { 0, 0, 0 }, my_off = -1, my_nch = 2;
 	bool mine = false;
 #pragma unroll
-	for(int o = 0; o < 2; ++o) {
-#pragma unroll
-		for(int k = 0; k < OV_NWORDS; ++k)
-			so[o][k] = 0;
+	for(int o = 0; o < 2; ++o)
 #pragma unroll
 		for(int k = 0; k < OD_NWORDS; ++k)
 			od[o][k] = 0;
-	}
-#pragma unroll
-	for(int k = 0; k < 8; ++k)
-		sp[k] = 0;
 	if(lane < nv)
 		mine = p.runs[list[first + lane]].count == 0;
 	if(mine) {
@@ -893,23 +923,23 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 		my_off = vc.out_off;
 		my_nch = vc.out_nch;
 		bool settled = true;
+		int wave_l[2], dphase_l[2];
 #pragma unroll
 		for(int o = 0; o < 2; ++o) {
 			uu[o] = vc.unit[o];
 			const int *w = ustate + (size_t)uu[o] * A2D_USTATE;
-			so[o][OV_MODE] = w[OW_MODE]; so[o][OV_WAVE] = w[OW_WAVE]; so[o][OV_DPHASE] = w[OW_DPHASE];
-			so[o][OV_PHLO] = w[OW_PHASE_LO]; so[o][OV_PHHI] = w[OW_PHASE_HI]; so[o][OV_PRAMP] = w[OW_PRAMPING];
-#pragma unroll
-			for(int k = 0; k < 4; ++k) {
-				so[o][OV_P + k] = w[OW_P + k];
-				so[o][OV_A + k] = w[OW_A + k];
-			}
-			settled = settled && so[o][OV_MODE] == A2D_OSC_MIPWAVE && so[o][OV_DPHASE] && !so[o][OV_PRAMP] &&
-					!(so[o][OV_P + 3] | so[o][OV_P + 2] | so[o][OV_A + 3] | so[o][OV_A + 2]) &&
-					so[o][OV_P] == so[o][OV_P + 1] && so[o][OV_A] == so[o][OV_A + 1];
+			wave_l[o] = w[OW_WAVE];
+			dphase_l[o] = w[OW_DPHASE];
+			amp_l[o] = w[OW_A];
+			phlo_l[o] = w[OW_PHASE_LO];
+			phhi_l[o] = w[OW_PHASE_HI];
+			settled = settled && w[OW_MODE] == A2D_OSC_MIPWAVE && dphase_l[o] && !w[OW_PRAMPING] &&
+					!(w[OW_P + 3] | w[OW_P + 2] | w[OW_A + 3] | w[OW_A + 2]) &&
+					w[OW_P] == w[OW_P + 1] && w[OW_A] == w[OW_A + 1];
 		}
 		uu[2] = vc.unit[2];
 		const int *wp = ustate + (size_t)uu[2] * A2D_USTATE;
+		int sp[8];
 #pragma unroll
 		for(int k = 0; k < 8; ++k)
 			sp[k] = wp[k];		// vol ramper, pan ramper
@@ -917,8 +947,8 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 		if(settled) {
 #pragma unroll
 			for(int o = 0; o < 2; ++o) {
-				const A2DWave *w = waves + so[o][OV_WAVE];
-				const unsigned period = w->period, dphase = (unsigned)so[o][OV_DPHASE];
+				const A2DWave *w = waves + wave_l[o];
+				const unsigned period = w->period, dphase = (unsigned)dphase_l[o];
 				unsigned dph = ((dphase + 255) >> 8) * period, mm = 0;	// wtosc.c:250-258
 				for(; (dph > (A2D_MAXPHINC << 8)) && (mm < A2D_MIPS - 1); ++mm)
 					dph >>= 1;
@@ -984,9 +1014,9 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 			for(int o = 0; o < 2; ++o) {
 				const unsigned mm = (unsigned)rdl(od[o][OD_MM], v), dph = (unsigned)rdl(od[o][OD_DPH], v);
 				const unsigned sizem = (unsigned)rdl(od[o][OD_SIZEM], v), doff = (unsigned)rdl(od[o][OD_DOFF], v);
-				amps[o] = rdl(so[o][OV_A], v);
-				const uint64_t phase = (uint64_t)(unsigned)rdl(so[o][OV_PHLO], v) |
-						((uint64_t)(unsigned)rdl(so[o][OV_PHHI], v) << 32);
+				amps[o] = rdl(amp_l[o], v);
+				const uint64_t phase = (uint64_t)(unsigned)rdl(phlo_l[o], v) |
+						((uint64_t)(unsigned)rdl(phhi_l[o], v) << 32);
 				uint64_t ph = (phase >> mm) + (uint64_t)before * dph;
 				const unsigned ldph = lane_dph(lane, dph);
 				const int cb = coef_base(doff);
@@ -1029,9 +1059,9 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 			for(int o = 0; o < 2; ++o) {
 				const unsigned mm = (unsigned)rdl(od[o][OD_MM], v), dph = (unsigned)rdl(od[o][OD_DPH], v);
 				const unsigned sizem = (unsigned)rdl(od[o][OD_SIZEM], v), doff = (unsigned)rdl(od[o][OD_DOFF], v);
-				const int amp = rdl(so[o][OV_A], v);
-				const uint64_t phase = (uint64_t)(unsigned)rdl(so[o][OV_PHLO], v) |
-						((uint64_t)(unsigned)rdl(so[o][OV_PHHI], v) << 32);
+				const int amp = rdl(amp_l[o], v);
+				const uint64_t phase = (uint64_t)(unsigned)rdl(phlo_l[o], v) |
+						((uint64_t)(unsigned)rdl(phhi_l[o], v) << 32);
 				uint64_t ph = (phase >> mm) + (uint64_t)before * dph;
 				const unsigned ldph = lane_dph(lane, dph);
 				const int cb = coef_base(doff);
@@ -1080,8 +1110,8 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 				const bool me = lane == v;
 #pragma unroll
 				for(int o = 0; o < 2; ++o) {
-					WRL(so[o][OV_PHLO], (int)(unsigned)endph[o]);
-					WRL(so[o][OV_PHHI], (int)(unsigned)(endph[o] >> 32));
+					WRL(phlo_l[o], (int)(unsigned)endph[o]);
+					WRL(phhi_l[o], (int)(unsigned)(endph[o] >> 32));
 				}
 			}
 		}
@@ -1107,13 +1137,18 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 					cur_off = voff;
 					cur_nch = rdl(my_nch, v);
 				}
+				// (its state from memory and back: what this slice left after the chunk before is in
+				// the staging area - or, one slice, in place - from the second chunk on)
 				OscS oa, ob;
 				Ramp vol, pan;
-				osc_from_lanes(oa, so[0], v);
-				osc_from_lanes(ob, so[1], v);
-				vol.value = rdl(sp[0], v); vol.target = rdl(sp[1], v); vol.delta = rdl(sp[2], v); vol.timer = rdl(sp[3], v);
-				pan.value = rdl(sp[4], v); pan.target = rdl(sp[5], v); pan.delta = rdl(sp[6], v); pan.timer = rdl(sp[7], v);
-				const bool me = lane == v;
+				const int *src = f0 ? ustage : ustate;
+				osc_from_mem(oa, src + (size_t)rdl(uu[0], v) * A2D_USTATE);
+				osc_from_mem(ob, src + (size_t)rdl(uu[1], v) * A2D_USTATE);
+				{
+					const volatile int *wpv = src + (size_t)rdl(uu[2], v) * A2D_USTATE;
+					vol.value = rfl(wpv[0]); vol.target = rfl(wpv[1]); vol.delta = rfl(wpv[2]); vol.timer = rfl(wpv[3]);
+					pan.value = rfl(wpv[4]); pan.target = rfl(wpv[5]); pan.delta = rfl(wpv[6]); pan.timer = rfl(wpv[7]);
+				}
 				for(int j = 0; j < nf; ++j) {
 					const int n = frames_of(ffr, f0 + j);
 					int o0 = 0, o1 = 0;
@@ -1127,31 +1162,45 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 							acc1[jj] = wadd(acc1[jj], o1);
 						}
 				}
-				osc_to_lanes(so[0], oa, me);
-				osc_to_lanes(so[1], ob, me);
-				WRL(sp[0], vol.value); WRL(sp[1], vol.target); WRL(sp[2], vol.delta); WRL(sp[3], vol.timer);
-				WRL(sp[4], pan.value); WRL(sp[5], pan.target); WRL(sp[6], pan.delta); WRL(sp[7], pan.timer);
+				if(lane == 0) {
+					osc_to_mem(ustage + (size_t)rdl(uu[0], v) * A2D_USTATE, oa);
+					osc_to_mem(ustage + (size_t)rdl(uu[1], v) * A2D_USTATE, ob);
+					int *wpv = ustage + (size_t)rdl(uu[2], v) * A2D_USTATE;
+					wpv[0] = vol.value; wpv[1] = vol.target; wpv[2] = vol.delta; wpv[3] = vol.timer;
+					wpv[4] = pan.value; wpv[5] = pan.target; wpv[6] = pan.delta; wpv[7] = pan.timer;
+				}
 			}
 			flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");	// (the next chunk reads what lane 0 stored)
+			__builtin_amdgcn_s_waitcnt(0);
 		}
 	}
 
-	if(mine && ((settled_l && last_slice) || (!settled_l && lane % nslices == slice))) {
+	// A settled voice's state after the batch: as it was, with the oscillators' phases moved on (the
+	// last slice writes it; voices that were not settled were stored by the loop above).
+	if(mine && settled_l && last_slice) {
 #pragma unroll
 		for(int o = 0; o < 2; ++o) {
+			const int *wi = ustate + (size_t)uu[o] * A2D_USTATE;
 			int *w = ustage + (size_t)uu[o] * A2D_USTATE;
-			w[OW_MODE] = so[o][OV_MODE]; w[OW_WAVE] = so[o][OV_WAVE]; w[OW_DPHASE] = so[o][OV_DPHASE];
-			w[OW_PHASE_LO] = so[o][OV_PHLO]; w[OW_PHASE_HI] = so[o][OV_PHHI]; w[OW_PRAMPING] = so[o][OV_PRAMP];
+			if(w != wi) {
+				w[OW_MODE] = wi[OW_MODE]; w[OW_WAVE] = wi[OW_WAVE]; w[OW_DPHASE] = wi[OW_DPHASE];
+				w[OW_PRAMPING] = wi[OW_PRAMPING];
 #pragma unroll
-			for(int k = 0; k < 4; ++k) {
-				w[OW_P + k] = so[o][OV_P + k];
-				w[OW_A + k] = so[o][OV_A + k];
+				for(int k = 0; k < 4; ++k) {
+					w[OW_P + k] = wi[OW_P + k];
+					w[OW_A + k] = wi[OW_A + k];
+				}
 			}
+			w[OW_PHASE_LO] = phlo_l[o];
+			w[OW_PHASE_HI] = phhi_l[o];
 		}
+		const int *wpi = ustate + (size_t)uu[2] * A2D_USTATE;
 		int *wp = ustage + (size_t)uu[2] * A2D_USTATE;
+		if(wp != wpi)
 #pragma unroll
-		for(int k = 0; k < 8; ++k)
-			wp[k] = sp[k];
+			for(int k = 0; k < 8; ++k)
+				wp[k] = wpi[k];
 	}
 }
 
