@@ -463,6 +463,36 @@ enum { SV_MODE = 0, SV_WAVE, SV_DPHASE, SV_PHLO, SV_PHHI, SV_PRAMP, SV_P = 6, SV
 // Extra per-lane words derived once per launch from a voice's state
 enum { DV_SETTLED = 0, DV_MM, DV_DPH, DV_SIZEM, DV_DOFF, DV_V0, DV_V1, DV_NWORDS };
 
+// an oscillator's state from / to the unit's state words in memory (wave-uniform address)
+// (volatile: what this wavefront stored a chunk ago must come from memory, not from a scalar or
+// vector cache line fetched before)
+DEV void osc_from_mem(OscS &o, const volatile int *w)
+{
+	o.mode = rfl(w[OW_MODE]);
+	o.wave = rfl(w[OW_WAVE]);
+	o.dphase = (unsigned)rfl(w[OW_DPHASE]);
+	o.phase = (uint64_t)(unsigned)rfl(w[OW_PHASE_LO]) | ((uint64_t)(unsigned)rfl(w[OW_PHASE_HI]) << 32);
+	o.p_ramping = rfl(w[OW_PRAMPING]);
+	o.p.value = rfl(w[OW_P]); o.p.target = rfl(w[OW_P + 1]);
+	o.p.delta = rfl(w[OW_P + 2]); o.p.timer = rfl(w[OW_P + 3]);
+	o.a.value = rfl(w[OW_A]); o.a.target = rfl(w[OW_A + 1]);
+	o.a.delta = rfl(w[OW_A + 2]); o.a.timer = rfl(w[OW_A + 3]);
+	o.noise = 0;
+	o.seed = 0;
+}
+
+DEV void osc_to_mem(int *w, const OscS &o)
+{
+	w[OW_MODE] = o.mode;
+	w[OW_WAVE] = o.wave;
+	w[OW_DPHASE] = (int)o.dphase;
+	w[OW_PHASE_LO] = (int)(unsigned)o.phase;
+	w[OW_PHASE_HI] = (int)(unsigned)(o.phase >> 32);
+	w[OW_PRAMPING] = o.p_ramping;
+	w[OW_P] = o.p.value; w[OW_P + 1] = o.p.target; w[OW_P + 2] = o.p.delta; w[OW_P + 3] = o.p.timer;
+	w[OW_A] = o.a.value; w[OW_A + 1] = o.a.target; w[OW_A + 2] = o.a.delta; w[OW_A + 3] = o.a.timer;
+}
+
 #ifndef OSC1_WPE
 #define OSC1_WPE 4
 #endif
@@ -506,14 +536,13 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 		fst[k] = (k * 64 + lane < nfrags) ? p.fragstart[k * 64 + lane] : 0;
 	}
 
-	// lane v keeps voice v: its unit ids, output bus, the 22 state words and
-	// what follows from them for a settled voice
-	int sv[SV_NWORDS], dv[DV_NWORDS];
+	// lane v keeps voice v: its unit ids, output bus and what the settled loop needs - amplitude,
+	// phase, and what follows from the state words for a settled voice (dv).  The other state words
+	// are read here to decide whether the voice is settled, and again, from memory, by the loop for
+	// voices that are not (k_leaf_osc2pan: the registers they took cost spills in the loop that matters).
+	int dv[DV_NWORDS], amp_l = 0, phlo_l = 0, phhi_l = 0;
 	int u0 = 0, u1 = 0, my_off = -1, my_nch = 2;
 	bool mine = false;	// this lane's voice is ours to render (no records this batch)
-#pragma unroll
-	for(int k = 0; k < SV_NWORDS; ++k)
-		sv[k] = 0;
 #pragma unroll
 	for(int k = 0; k < DV_NWORDS; ++k)
 		dv[k] = 0;
@@ -527,6 +556,7 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 		my_nch = vc.out_nch;
 		const int *w0 = ustate + (size_t)u0 * A2D_USTATE;
 		const int *w1 = ustate + (size_t)u1 * A2D_USTATE;
+		int sv[SV_NWORDS];
 		sv[SV_MODE] = w0[OW_MODE]; sv[SV_WAVE] = w0[OW_WAVE]; sv[SV_DPHASE] = w0[OW_DPHASE];
 		sv[SV_PHLO] = w0[OW_PHASE_LO]; sv[SV_PHHI] = w0[OW_PHASE_HI]; sv[SV_PRAMP] = w0[OW_PRAMPING];
 #pragma unroll
@@ -570,6 +600,9 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 			dv[DV_V1] = v1;
 		}
 		dv[DV_SETTLED] = settled ? 1 : 0;
+		amp_l = sv[SV_A];
+		phlo_l = sv[SV_PHLO];
+		phhi_l = sv[SV_PHHI];
 	}
 	const unsigned long long unsettled_mask = __ballot(mine && !dv[DV_SETTLED]);
 	const unsigned long long settled_mask = __ballot(mine && dv[DV_SETTLED]);
@@ -595,7 +628,7 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 			pre[j] = pre[j - 1] + (unsigned)nfr[j - 1];
 		// where each lane's voice stands when the chunk begins: one vector
 		// multiply-add per lane instead of a scalar one per voice
-		const uint64_t lbase = ((((uint64_t)(unsigned)sv[SV_PHLO]) | ((uint64_t)(unsigned)sv[SV_PHHI] << 32)) >>
+		const uint64_t lbase = ((((uint64_t)(unsigned)phlo_l) | ((uint64_t)(unsigned)phhi_l << 32)) >>
 				(unsigned)dv[DV_MM]) + (uint64_t)before * (unsigned)dv[DV_DPH];
 		const int base_lo = (int)(unsigned)lbase, base_hi = (int)(unsigned)(lbase >> 32);
 		int cur_off = rdl(my_off, 0), cur_nch = rdl(my_nch, 0);
@@ -610,7 +643,7 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 			}
 			const unsigned dph = (unsigned)rdl(dv[DV_DPH], v);
 			const unsigned sizem = (unsigned)rdl(dv[DV_SIZEM], v), doff = (unsigned)rdl(dv[DV_DOFF], v);
-			const int v0 = rdl(dv[DV_V0], v), v1 = rdl(dv[DV_V1], v), amp = rdl(sv[SV_A], v);
+			const int v0 = rdl(dv[DV_V0], v), v1 = rdl(dv[DV_V1], v), amp = rdl(amp_l, v);
 			const unsigned dph16 = dph >> 16;
 			// The phase fragment f starts from is ((phase >> mm) + frames_before(f) * dph)
 			// mod (size << 24): the reference's "ph %= size << 24; ...; ph += frames * dph"
@@ -671,8 +704,8 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 				// unwrapped end of the last fragment (wtosc.c:284)
 				const bool me = lane == v;
 				const uint64_t endph = ph << (unsigned)rdl(dv[DV_MM], v);
-				WRL(sv[SV_PHLO], (int)(unsigned)endph);
-				WRL(sv[SV_PHHI], (int)(unsigned)(endph >> 32));
+				WRL(phlo_l, (int)(unsigned)endph);
+				WRL(phhi_l, (int)(unsigned)(endph >> 32));
 			}
 		}
 		flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
@@ -697,23 +730,16 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 					cur_off = voff;
 					cur_nch = rdl(my_nch, v);
 				}
+				// (its state from memory and back: k_leaf_osc2pan)
 				OscS o;
 				Ramp vol, pan;
-				o.mode = rdl(sv[SV_MODE], v);
-				o.wave = rdl(sv[SV_WAVE], v);
-				o.dphase = (unsigned)rdl(sv[SV_DPHASE], v);
-				o.phase = (uint64_t)(unsigned)rdl(sv[SV_PHLO], v) |
-						((uint64_t)(unsigned)rdl(sv[SV_PHHI], v) << 32);
-				o.p_ramping = rdl(sv[SV_PRAMP], v);
-				o.p.value = rdl(sv[SV_P], v); o.p.target = rdl(sv[SV_P + 1], v);
-				o.p.delta = rdl(sv[SV_P + 2], v); o.p.timer = rdl(sv[SV_P + 3], v);
-				o.a.value = rdl(sv[SV_A], v); o.a.target = rdl(sv[SV_A + 1], v);
-				o.a.delta = rdl(sv[SV_A + 2], v); o.a.timer = rdl(sv[SV_A + 3], v);
-				vol.value = rdl(sv[SV_VOL], v); vol.target = rdl(sv[SV_VOL + 1], v);
-				vol.delta = rdl(sv[SV_VOL + 2], v); vol.timer = rdl(sv[SV_VOL + 3], v);
-				pan.value = rdl(sv[SV_PAN], v); pan.target = rdl(sv[SV_PAN + 1], v);
-				pan.delta = rdl(sv[SV_PAN + 2], v); pan.timer = rdl(sv[SV_PAN + 3], v);
-				const bool me = lane == v;
+				const int *src = f0 ? ustage : ustate;
+				osc_from_mem(o, src + (size_t)rdl(u0, v) * A2D_USTATE);
+				{
+					const volatile int *wpv = src + (size_t)rdl(u1, v) * A2D_USTATE;
+					vol.value = rfl(wpv[0]); vol.target = rfl(wpv[1]); vol.delta = rfl(wpv[2]); vol.timer = rfl(wpv[3]);
+					pan.value = rfl(wpv[4]); pan.target = rfl(wpv[5]); pan.delta = rfl(wpv[6]); pan.timer = rfl(wpv[7]);
+				}
 				for(int j = 0; j < nf; ++j) {
 					int o0 = 0, o1 = 0;
 					oscpan_fragment(g, o, vol, pan, frames_of(ffr, f0 + j), lane, o0, o1);
@@ -724,22 +750,16 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 							acc1[jj] = wadd(acc1[jj], o1);
 						}
 				}
-				WRL(sv[SV_MODE], o.mode);
-				WRL(sv[SV_WAVE], o.wave);
-				WRL(sv[SV_DPHASE], (int)o.dphase);
-				WRL(sv[SV_PHLO], (int)(unsigned)o.phase);
-				WRL(sv[SV_PHHI], (int)(unsigned)(o.phase >> 32));
-				WRL(sv[SV_PRAMP], o.p_ramping);
-				WRL(sv[SV_P], o.p.value); WRL(sv[SV_P + 1], o.p.target);
-				WRL(sv[SV_P + 2], o.p.delta); WRL(sv[SV_P + 3], o.p.timer);
-				WRL(sv[SV_A], o.a.value); WRL(sv[SV_A + 1], o.a.target);
-				WRL(sv[SV_A + 2], o.a.delta); WRL(sv[SV_A + 3], o.a.timer);
-				WRL(sv[SV_VOL], vol.value); WRL(sv[SV_VOL + 1], vol.target);
-				WRL(sv[SV_VOL + 2], vol.delta); WRL(sv[SV_VOL + 3], vol.timer);
-				WRL(sv[SV_PAN], pan.value); WRL(sv[SV_PAN + 1], pan.target);
-				WRL(sv[SV_PAN + 2], pan.delta); WRL(sv[SV_PAN + 3], pan.timer);
+				if(lane == 0) {
+					osc_to_mem(ustage + (size_t)rdl(u0, v) * A2D_USTATE, o);
+					int *wpv = ustage + (size_t)rdl(u1, v) * A2D_USTATE;
+					wpv[0] = vol.value; wpv[1] = vol.target; wpv[2] = vol.delta; wpv[3] = vol.timer;
+					wpv[4] = pan.value; wpv[5] = pan.target; wpv[6] = pan.delta; wpv[7] = pan.timer;
+				}
 			}
 			flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");	// (the next chunk reads what lane 0 stored)
+			__builtin_amdgcn_s_waitcnt(0);
 		}
 	}
 
@@ -747,19 +767,24 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	// slices are still reading the old state, so it is staged and committed by
 	// k_commit_oscpan afterwards.  The last slice owns the settled voices (their
 	// end phase), the slice that walked it each of the others.
-	const bool settled_l = dv[DV_SETTLED] != 0;
-	if(mine && ((settled_l && last_slice) || (!settled_l && lane % nslices == slice))) {
+	// (a settled voice: as it was, the phase moved on; the others were stored by the loop above)
+	if(mine && dv[DV_SETTLED] && last_slice) {
+		const int *wi0 = ustate + (size_t)u0 * A2D_USTATE, *wi1 = ustate + (size_t)u1 * A2D_USTATE;
 		int *w0 = ustage + (size_t)u0 * A2D_USTATE;
 		int *w1 = ustage + (size_t)u1 * A2D_USTATE;
-		w0[OW_MODE] = sv[SV_MODE]; w0[OW_WAVE] = sv[SV_WAVE]; w0[OW_DPHASE] = sv[SV_DPHASE];
-		w0[OW_PHASE_LO] = sv[SV_PHLO]; w0[OW_PHASE_HI] = sv[SV_PHHI]; w0[OW_PRAMPING] = sv[SV_PRAMP];
+		if(w0 != wi0) {
+			w0[OW_MODE] = wi0[OW_MODE]; w0[OW_WAVE] = wi0[OW_WAVE]; w0[OW_DPHASE] = wi0[OW_DPHASE];
+			w0[OW_PRAMPING] = wi0[OW_PRAMPING];
 #pragma unroll
-		for(int k = 0; k < 4; ++k) {
-			w0[OW_P + k] = sv[SV_P + k];
-			w0[OW_A + k] = sv[SV_A + k];
-			w1[PW_VOL + k] = sv[SV_VOL + k];
-			w1[PW_PAN + k] = sv[SV_PAN + k];
+			for(int k = 0; k < 4; ++k) {
+				w0[OW_P + k] = wi0[OW_P + k];
+				w0[OW_A + k] = wi0[OW_A + k];
+				w1[PW_VOL + k] = wi1[PW_VOL + k];
+				w1[PW_PAN + k] = wi1[PW_PAN + k];
+			}
 		}
+		w0[OW_PHASE_LO] = phlo_l;
+		w0[OW_PHASE_HI] = phhi_l;
 	}
 }
 
@@ -830,36 +855,6 @@ DEV void osc_to_lanes(int (&so)[OV_NWORDS], const OscS &o, bool me)
 	WRL(so[OV_P + 2], o.p.delta); WRL(so[OV_P + 3], o.p.timer);
 	WRL(so[OV_A], o.a.value); WRL(so[OV_A + 1], o.a.target);
 	WRL(so[OV_A + 2], o.a.delta); WRL(so[OV_A + 3], o.a.timer);
-}
-
-// ... and from / to the unit's state words in memory (wave-uniform address)
-// (volatile: what this wavefront stored a chunk ago must come from memory, not from a scalar or
-// vector cache line fetched before)
-DEV void osc_from_mem(OscS &o, const volatile int *w)
-{
-	o.mode = rfl(w[OW_MODE]);
-	o.wave = rfl(w[OW_WAVE]);
-	o.dphase = (unsigned)rfl(w[OW_DPHASE]);
-	o.phase = (uint64_t)(unsigned)rfl(w[OW_PHASE_LO]) | ((uint64_t)(unsigned)rfl(w[OW_PHASE_HI]) << 32);
-	o.p_ramping = rfl(w[OW_PRAMPING]);
-	o.p.value = rfl(w[OW_P]); o.p.target = rfl(w[OW_P + 1]);
-	o.p.delta = rfl(w[OW_P + 2]); o.p.timer = rfl(w[OW_P + 3]);
-	o.a.value = rfl(w[OW_A]); o.a.target = rfl(w[OW_A + 1]);
-	o.a.delta = rfl(w[OW_A + 2]); o.a.timer = rfl(w[OW_A + 3]);
-	o.noise = 0;
-	o.seed = 0;
-}
-
-DEV void osc_to_mem(int *w, const OscS &o)
-{
-	w[OW_MODE] = o.mode;
-	w[OW_WAVE] = o.wave;
-	w[OW_DPHASE] = (int)o.dphase;
-	w[OW_PHASE_LO] = (int)(unsigned)o.phase;
-	w[OW_PHASE_HI] = (int)(unsigned)(o.phase >> 32);
-	w[OW_PRAMPING] = o.p_ramping;
-	w[OW_P] = o.p.value; w[OW_P + 1] = o.p.target; w[OW_P + 2] = o.p.delta; w[OW_P + 3] = o.p.timer;
-	w[OW_A] = o.a.value; w[OW_A + 1] = o.a.target; w[OW_A + 2] = o.a.delta; w[OW_A + 3] = o.a.timer;
 }
 
 #ifndef OSC2_WPE

@@ -741,10 +741,10 @@ int upload(a2amd_ctx *c)
 // (up to 8), then give a wavefront enough voices that about 4096 wavefronts
 // (one resident round of 256 CUs x 16) share the work; at least 4 voices, so
 // that their sum reaches the bus in one atomic instead of four, at most 32.
-void pick_fast_shape(int n, int nfrags, int *vpw, int *ysplit)
+void pick_fast_shape(int n, int nfrags, int *vpw, int *ysplit, int ymax = 32)
 {
 	const int nchunks = (nfrags + A2D_FAST_FCH - 1) / A2D_FAST_FCH;
-	int y = getenv("A2AMD_YSPLIT") ? atoi(getenv("A2AMD_YSPLIT")) : 32;
+	int y = getenv("A2AMD_YSPLIT") ? atoi(getenv("A2AMD_YSPLIT")) : ymax;
 	y = std::min(std::max(y, 1), nchunks);
 	int v = getenv("A2AMD_VPW") ? atoi(getenv("A2AMD_VPW")) :
 			std::min(std::max((int)(((long long)n * y + 4095) / 4096), 4), 32);
@@ -954,7 +954,8 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		}
 		if(c->n_osc2_leaf) {
 			int vpw, ysplit;
-			pick_fast_shape(c->n_osc2_leaf, c->nfrags * A2D_FAST_FCH / A2D_OSC2_FCH, &vpw, &ysplit);	// (its own chunk length)
+			// (its own chunk length; 16 time slices: 2.19 ms against 2.25 with 32 at configs[3], round 3)
+			pick_fast_shape(c->n_osc2_leaf, c->nfrags * A2D_FAST_FCH / A2D_OSC2_FCH, &vpw, &ysplit, 16);
 			if(a2d_launch_leaf_osc2pan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf, c->n_osc2_leaf,
 					vpw, ysplit, c->d_ustage.d, c->stream, &pend.c[pend.n]))
 				return c->fail(A2AMD_EHIP, "2-osc leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
