@@ -350,7 +350,9 @@ int a2amd_replay(a2amd_ctx *c, unsigned steps)
 		if(!c->voices[vi].recs.empty())
 			return c->fail(A2AMD_ESTATE, "replay of a batch that carries command records");
 	bool graphs = c->stream != nullptr && !c->profiling && !getenv("A2AMD_NO_GRAPH");
-	if(graphs && !c->gexec[0]) {
+	c->master_dst = nullptr;	// (replayed steps are not read back: the master bus stays in the bus memory)
+	c->master_direct = false;
+	if(graphs && (!c->gexec[0] || !c->gexec[1])) {
 		if(build_graph(c, 0, GRAPH_STEPS) || build_graph(c, 1, 1)) {
 			drop_graphs(c);
 			graphs = false;
