@@ -304,8 +304,26 @@ struct FastPtrs {
 // o.* lives in SGPRs.
 // (lane = index of the frame within the window: lanes before a window that starts
 // inside the fragment come in negative, k_leaf_recs)
-DEV int osc_fragment_s(const FastPtrs &g, OscS &o, int nframes, int lane)
+// One fragment (or window) of an oscillator in two halves: osc_fragment_begin() steps the state and
+// ISSUES the wave data loads, osc_fragment_end() interpolates.  A voice with two oscillators begins
+// both before it ends either - on a wavefront that has its SIMD to itself (a song's few voices) the
+// second oscillator's table look-ups and sample loads no longer wait for the first one's to return.
+struct OscPend { Quad16 qa, qb; unsigned ph, ph2; int ak, x; bool taps; };
+
+DEV int osc_fragment_end(const OscPend &pd)
 {
+	if(pd.taps)
+		return mul64s(inter_quads(pd.qa, pd.qb, pd.ph, pd.ph2), pd.ak, 17);
+	return pd.x;
+}
+
+DEV OscPend osc_fragment_begin(const FastPtrs &g, OscS &o, int nframes, int lane)
+{
+	OscPend pd;
+	pd.qa.lo = pd.qa.hi = pd.qb.lo = pd.qb.hi = 0;
+	pd.ph = pd.ph2 = 0;
+	pd.ak = 0;
+	pd.taps = false;
 	int x = 0;
 	const bool in = (unsigned)lane < (unsigned)nframes;
 	if(o.mode == A2D_OSC_MIPWAVE) {
@@ -340,10 +358,14 @@ DEV int osc_fragment_s(const FastPtrs &g, OscS &o, int nframes, int lane)
 				if(dph <= (A2D_MAXPHINC << 16)) {
 					const int16_t *d = g.wavepool + w->off[mm];
 					if(in) {
+						// (inter_dwords, its loads issued here and its arithmetic left to osc_fragment_end)
 						uint64_t phk = ph + (uint64_t)(unsigned)lane * dph;
-						int ak = wadd(o.a.value, wmul(o.a.delta, lane));
-						int v = inter_dwords(d, (unsigned)(phk >> 16), dph >> 16);
-						x = mul64s(v, ak, 17);
+						pd.ak = wadd(o.a.value, wmul(o.a.delta, lane));
+						pd.ph = (unsigned)(phk >> 16);
+						pd.ph2 = pd.ph + ((dph >> 16) >> 1);
+						pd.qa = *(const Quad16 *)(d + (int)(pd.ph >> 8) - 1);
+						pd.qb = *(const Quad16 *)(d + (int)(pd.ph2 >> 8) - 1);
+						pd.taps = true;
 					}
 				}
 				ph += (uint64_t)dph * (unsigned)nframes;
@@ -391,7 +413,14 @@ DEV int osc_fragment_s(const FastPtrs &g, OscS &o, int nframes, int lane)
 		ramp_run(o.p, nframes);
 		ramp_run(o.a, nframes);
 	}
-	return x;
+	pd.x = x;
+	return pd;
+}
+
+DEV int osc_fragment_s(const FastPtrs &g, OscS &o, int nframes, int lane)
+{
+	const OscPend pd = osc_fragment_begin(g, o, nframes, lane);
+	return osc_fragment_end(pd);
 }
 
 // One default fragment of panmix 1->2 adding into the voice's output bus
@@ -1147,8 +1176,8 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 				for(int j = 0; j < nf; ++j) {
 					const int n = frames_of(ffr, f0 + j);
 					int o0 = 0, o1 = 0;
-					int x = osc_fragment_s(g, oa, n, lane);
-					x = wadd(x, osc_fragment_s(g, ob, n, lane));
+					const OscPend pa_ = osc_fragment_begin(g, oa, n, lane), pb_ = osc_fragment_begin(g, ob, n, lane);
+					const int x = wadd(osc_fragment_end(pa_), osc_fragment_end(pb_));
 					pan_fragment_s(vol, pan, x, n, lane, o0, o1);
 #pragma unroll
 					for(int jj = 0; jj < OSC2_FCH; ++jj)
@@ -1362,6 +1391,21 @@ DEV int filt_window_s(FiltS &fs, int x, int off, int len, int lane)
 
 // (the body of the kernels below: gw = this wavefront's index among those of its class)
 typedef int RecsPart[RECS_WPB][RECS_FCH * 2][64];
+// A voice's next command record, fetched through the scalar cache and ahead of its use: the load is
+// issued when the record before it is taken up (a window's worth of work earlier) and does not queue
+// behind the wavefront's bus atomics as a vector load does (gfx9 counts both in vmcnt).  A lone
+// wavefront - a song's voice - used to sit out a memory round trip per fragment just to learn that the
+// fragment holds no record.
+typedef int RecQ __attribute__((ext_vector_type(4)));	// head, value, dur, start
+// (through the CONSTANT address space: a uniform address there is a scalar load the compiler issues
+// where it stands and waits for where the value is used - records are written by the host only)
+DEV RecQ rec_issue(const A2DRec *recs, int idx)
+{
+	typedef const __attribute__((address_space(4))) RecQ *CRecQ;
+	return *(CRecQ)(uintptr_t)(recs + idx);
+}
+DEV RecQ rec_ready(RecQ r) { return r; }
+
 template<int NOSC, int FILT>
 DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw, int gw,
 		const A2DVoice *__restrict__ voices, int *ustate, int *vactive,
@@ -1492,6 +1536,7 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 			int rc = rdl(rcur, v), active = rdl(act, v);
 			const int re = rdl(rend, v);
 			const bool me = lane == v;
+			RecQ nx = rec_issue(recs, rc < re ? rc : 0);
 			for(int j = 0; j < nf; ++j) {
 				const int f = f0 + j;
 				const int n = frames_of(ffr, f);
@@ -1502,9 +1547,13 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 					const long long w0 = __builtin_readcyclecounter();
 #endif
 					const int fl = lane - off;
-					int x = osc_fragment_s(g, os[0], len, fl);
-					if(NOSC > 1)
-						x = wadd(x, osc_fragment_s(g, os[NOSC - 1], len, fl));
+					int x;
+					if(NOSC > 1) {
+						const OscPend pa_ = osc_fragment_begin(g, os[0], len, fl);
+						const OscPend pb_ = osc_fragment_begin(g, os[NOSC - 1], len, fl);
+						x = wadd(osc_fragment_end(pa_), osc_fragment_end(pb_));
+					} else
+						x = osc_fragment_s(g, os[0], len, fl);
 					if(FILT)
 						x = filt_window_s(fs, x, off, len, lane);
 					pan_fragment_s(vol, pan, x, len, fl, o0, o1);
@@ -1514,7 +1563,8 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 					++n_win;
 #endif
 				};
-				uint32_t head = rc < re ? (uint32_t)rfl((int)recs[rc].head) : 0xffffffffu;
+				RecQ cur = rec_ready(nx);
+				uint32_t head = rc < re ? (uint32_t)cur.x : 0xffffffffu;
 				if((int)A2D_RFRAG(head) != f || rc >= re) {
 					// no records in this fragment: the engine called Process(0, frames)
 					// once on every unit (core.c:1875-1876)
@@ -1522,10 +1572,12 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 						window(0, n);
 				} else {
 					do {
-						const int value = rfl(recs[rc].value);
-						const unsigned dur = (unsigned)rfl((int)recs[rc].dur);
-						const unsigned start = (unsigned)rfl((int)recs[rc].start);
+						const int value = cur.y;
+						const unsigned dur = (unsigned)cur.z;
+						const unsigned start = (unsigned)cur.w;
 						const int u = (int)A2D_RUNIT(head), reg = (int)A2D_RREG(head);
+						++rc;
+						nx = rec_issue(recs, rc < re ? rc : 0);	// (on its way while this one is carried out)
 						switch(A2D_ROP(head)) {
 						  case R_SEG:
 							if(active)
@@ -1601,11 +1653,11 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 						  default:
 							break;
 						}
-						++rc;
 #ifdef RECS_PROF
 						++n_rec;
 #endif
-						head = rc < re ? (uint32_t)rfl((int)recs[rc].head) : 0xffffffffu;
+						cur = rec_ready(nx);
+						head = rc < re ? (uint32_t)cur.x : 0xffffffffu;
 					} while(rc < re && (int)A2D_RFRAG(head) == f);
 				}
 #pragma unroll
@@ -1640,6 +1692,11 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 			const long long r0 = __builtin_readcyclecounter();
 #endif
 			const int pb = (f0 / RECS_FCH) & 1;
+			if((int)(blockDim.x >> 6) == 1) {
+				// (a launch of a few dozen voices - a song - comes with ONE wavefront per workgroup:
+				// nobody to sum with, no barrier, no trip through LDS)
+				flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+			} else {
 #pragma unroll
 			for(int j = 0; j < RECS_FCH; ++j) {
 				part[pb][wv][2 * j][lane] = acc0[j];
@@ -1668,6 +1725,7 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 					if(w < wpb && woff >= 0)
 						sum = wadd(sum, part[pb][w][row][lane]);
 				}
+			}
 			}
 #ifdef RECS_PROF
 			asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
