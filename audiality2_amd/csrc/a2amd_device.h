@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #define A2D_MAXCHAIN   8      // units per voice (A2AMD_MAXCHAIN)
+#define A2D_MAXBATCH 256
 #define A2D_USTATE    24      // int32 words of device state per unit
 #define A2D_MAXCH      8
 #define A2D_FRAG      64
@@ -106,6 +107,48 @@ enum { R_SEG = 1, R_WRITE, R_INIT, R_KILL, R_F1SET, R_F1RAMP, R_NOISESEED, R_NOP
 
 struct A2DRun { int32_t first, count; };
 
+// ---- the scripted voice's VM on the device (include/a2amd_vm.h) ----------------
+// One per adopted voice, device resident (the device is the authority on everything in it
+// between adoption and recall): A2_vmstate (include/a2_vm.h:62-69), where a2_VoiceControl
+// (core.c:143-149) sends each VM register, and the cutoff rampers of the voice's filter12 units,
+// which for host-driven voices never leave the host (a2amd_host.h: HUnit::cutoff).
+#define A2D_VM_NOWRITE 0xffu
+#define A2D_VM_MAXCUT  2
+struct A2DVmVoice {
+	uint32_t waketime;		// A2_vmstate.waketime: 24:8 frames, engine time
+	uint32_t code, ncode;		// the function's text in the code pool (32 bit words)
+	uint16_t pc;
+	uint8_t  state, ncut;
+	int32_t  voice;			// backend voice slot (runs[] index)
+	int32_t  fault;			// a trap the analysis should have ruled out (0 = none): the VM stopped there
+	uint8_t  cmap[64];		// VM register -> chain position << 4 | unit register, A2D_VM_NOWRITE = none
+	uint8_t  kind[A2D_MAXCHAIN];	// unit kinds of the chain
+	uint8_t  cutpos[A2D_VM_MAXCUT];	// chain positions of the filter12 units whose cutoff the VM may write
+	uint8_t  pad[2];
+	int32_t  cut[A2D_VM_MAXCUT][4];	// ... and their cutoff rampers (A2_filter12.cutoff, filter12.c:38)
+	int32_t  r[64];			// A2_vmstate.r
+};
+
+// what the VM kernel needs beside the voices (host copy: a2amd_ctx)
+struct A2DVmParams {
+	A2DVmVoice     *vmv;		// [vm slot]
+	const int      *list;		// vm slots the kernel runs this batch
+	int32_t         n;
+	const uint32_t *code;		// code pool
+	const uint32_t *ptab;
+	const int32_t  *f1tab;		// [32][65536]: f12_pitch2coeff by (shift, fraction), or null
+	A2DRun         *runs;		// [voice slot]
+	A2DRun         *vmrun;		// [list index]: where each voice's records go (count pass -> emit pass)
+	A2DRec         *recs;		// the batch's record array (A2DParams::recs)
+	uint32_t        rec_base, rec_cap;	// the VM's region of it, in records
+	uint32_t       *total;		// records the count pass found; [1] = voices that faulted
+	uint32_t        now;		// engine time of the batch's first frame
+	uint32_t        msdur;		// A2_state.msdur
+	int32_t         samplerate, basepitch;
+	int32_t         nfrags;
+	uint8_t         fragframes[A2D_MAXBATCH];
+};
+
 // xinsert state words: client slot + 1 (0 = no clients) and A2AMD_XIO_* mode bits
 enum { XW_SLOT = 0, XW_MODE = 1 };
 #define A2D_XIO_HALF ((size_t)A2D_MAXBATCH * 8 * A2D_FRAG)	// words per direction of a slot
@@ -117,7 +160,6 @@ enum { XW_SLOT = 0, XW_MODE = 1 };
 #ifndef A2D_OSC2_FCH
 #define A2D_OSC2_FCH 4	// k_leaf_osc2pan: fragments per chunk
 #endif
-#define A2D_MAXBATCH 256
 #define A2D_MAXVPW   32       // voices one wavefront may walk per fragment
 
 struct A2DParams {
@@ -142,6 +184,9 @@ struct A2DParams {
 	uint8_t         fragframes[A2D_MAXBATCH];
 	uint16_t        fragstart[A2D_MAXBATCH];	// frames before each fragment
 };
+
+// a2amd_vm.hip: the count pass (emit = 0) or the emit pass of the VM kernel
+int a2d_launch_vm(const A2DVmParams &vp, int emit, void *stream);
 
 // launchers implemented in a2amd_kernels.hip (stream = hipStream_t)
 // dparams / dlist are device pointers; 'vpw' voices of the list per wavefront
@@ -173,8 +218,10 @@ int a2d_launch_scatter_runs(const int *didx, const A2DRun *dval, int n, A2DRun *
 int a2d_launch_leaf_osc2pan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
 		int vpw, int ysplit, int *ustage, void *stream, A2DCommit *defer);
 // wtosc[+wtosc] [-> filter12] -> panmix voices that carry records this batch (nosc = 1 | 2, filt = 0 | 1)
+// skip_empty: the list's voices get their records from the device VM (a2amd_vm.hip); those it left
+// without any this batch are rendered by their class's quiet kernel
 int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc, int filt, const int *dlist,
-		int nlist, int vpw, void *stream);
+		int nlist, int vpw, void *stream, int skip_empty = 0);
 // ... all four kinds in one launch: lists[k] / counts[k] for (nosc, filt) = (1,0) (2,0) (1,1) (2,1)
 int a2d_launch_leaf_recs_all(const A2DParams *dparams, const A2DParams &hp, const int *const *lists, const int *counts,
 		int vpw, void *stream);

@@ -1411,7 +1411,7 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 		const A2DVoice *__restrict__ voices, int *ustate, int *vactive,
 		const int16_t *__restrict__ wavepool, const A2DWave *__restrict__ waves,
 		const uint32_t *__restrict__ ptab, int *__restrict__ busmem,
-		RecsPart *part, int (*part_off)[RECS_WPB], int (*part_nch)[RECS_WPB])
+		RecsPart *part, int (*part_off)[RECS_WPB], int (*part_nch)[RECS_WPB], int skip_empty = 0)
 {
 #ifdef RECS_PROF
 	const long long t_in = __builtin_readcyclecounter();
@@ -1445,6 +1445,9 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	for(int o = 0; o < NOSC; ++o)
 		sn[o][0] = sn[o][1] = 0;
 	int my_off = -1, my_nch = 2, rcur = 0, rend = 0, act = 0, slot = -1;
+	// skip_empty: a list of voices whose records the device VM writes (a2amd_vm.hip) - the ones it
+	// left without any this batch are the quiet kernels' (runs[].count == 0), not ours
+	bool skip = false;
 #pragma unroll
 	for(int k = 0; k < FS_NWORDS; ++k)
 		sf[k] = 0;
@@ -1495,7 +1498,8 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 		const A2DRun run = p.runs[slot];
 		rcur = run.first;
 		rend = run.first + run.count;
-		act = vactive[slot];
+		skip = skip_empty && run.count == 0;
+		act = skip ? 0 : vactive[slot];
 	}
 
 #ifdef RECS_PROF
@@ -1738,7 +1742,7 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	const long long t_loop = __builtin_readcyclecounter();
 #endif
 	// state out (these voices are nobody else's this batch: straight to the state array)
-	if(lane < nv) {
+	if(lane < nv && !skip) {
 #pragma unroll
 		for(int o = 0; o < NOSC; ++o) {
 			int *w = ustate + (size_t)uu[o] * A2D_USTATE;
@@ -1786,12 +1790,12 @@ __global__ __launch_bounds__(64 * RECS_WPB) RECS_ATTR
 void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
 		const A2DVoice *__restrict__ voices, int *ustate, int *vactive,
 		const int16_t *__restrict__ wavepool, const A2DWave *__restrict__ waves,
-		const uint32_t *__restrict__ ptab, int *__restrict__ busmem)
+		const uint32_t *__restrict__ ptab, int *__restrict__ busmem, int skip_empty)
 {
 	__shared__ RecsPart part[2];
 	__shared__ int part_off[2][RECS_WPB], part_nch[2][RECS_WPB];
 	recs_body<NOSC, FILT>(pp, list, nlist, vpw, (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), voices, ustate, vactive,
-			wavepool, waves, ptab, busmem, part, part_off, part_nch);
+			wavepool, waves, ptab, busmem, part, part_off, part_nch, skip_empty);
 }
 
 // All four kinds in one launch, for plumbing-sized scenes (a song: a few dozen voices of each kind):
@@ -1869,7 +1873,7 @@ int a2d_launch_leaf_recs_all(const A2DParams *dparams, const A2DParams &hp, cons
 }
 
 int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc, int filt, const int *dlist,
-		int nlist, int vpw, void *stream)
+		int nlist, int vpw, void *stream, int skip_empty)
 {
 	if(nlist <= 0)
 		return 0;
@@ -1879,7 +1883,7 @@ int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc
 	const int nblocks = (nwaves + wpb - 1) / wpb;
 #define RECS_LAUNCH(N, F) hipLaunchKernelGGL((k_leaf_recs<N, F>), dim3(nblocks), dim3(64 * wpb), 0, \
 		(hipStream_t)stream, dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.vactive, hp.wavepool, \
-		hp.waves, hp.ptab, hp.busmem)
+		hp.waves, hp.ptab, hp.busmem, skip_empty)
 	if(nosc == 1 && !filt)
 		RECS_LAUNCH(1, 0);
 	else if(nosc == 2 && !filt)

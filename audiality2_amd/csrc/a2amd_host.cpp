@@ -99,6 +99,7 @@ void a2amd_close(a2amd_ctx *c)
 	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
 	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
 	hipFree(c->d_waves.d); hipFree(c->d_wavepool.d); hipFree(c->d_wavecoef.d); hipFree(c->d_busmem.d);
+	vm_close(c);
 	hipFree(c->d_fbdmem.d); hipFree(c->d_fmstate.d); hipFree(c->d_xio.d); hipFree(c->d_fmsine); hipFree(c->d_list.d); hipFree(c->d_scatter.d); hipFree(c->d_ptab); hipFree(c->d_blob.d);
 	for(int k = 0; k < 2; ++k) { if(c->h_blob[k]) hipHostFree(c->h_blob[k]); if(c->blob_ev[k]) hipEventDestroy(c->blob_ev[k]); }
 	if(c->h_master)
@@ -248,6 +249,8 @@ int a2amd_fragment(a2amd_ctx *c, unsigned frames)
 	close_fragment(c);
 	if(c->nfrags >= (int)c->cfg.max_batch)
 		return c->fail(A2AMD_ESTATE, "more than max_batch=%u fragments without a render", c->cfg.max_batch);
+	if(!c->nfrags)
+		c->vm.batch_time = c->walk_time;	// (the device VM's clock, a2amd_vm.cpp)
 	c->cur_frag = c->nfrags++;
 	c->fragframes[c->cur_frag] = frames;
 	c->frag_open = true;
@@ -457,6 +460,15 @@ int a2amd_unit_deinit(a2amd_ctx *c, int ui)
 {
 	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live)
 		return c->fail(A2AMD_EINVAL, "deinit of dead unit %d", ui);
+	if(c->voices[c->units[ui].voice].vm >= 0) {
+		// a voice the device VM runs is taken down (a2_VoiceFree on it or on a voice above it): what
+		// its VM did in this batch up to here goes on record first - the open fragment included when
+		// the voice has had its window in it (the host reported it by the map or a hold)
+		const int vi = c->units[ui].voice;
+		const bool had = c->frag_open && ((c->defmap_used && (size_t)vi < c->defmap.size() && c->defmap[vi]) || is_held(c, vi));
+		if(int r = vm_take_back(c, vi, had, nullptr))
+			return r;
+	}
 	HUnit &u = c->units[ui];
 	HVoice &v = c->voices[u.voice];
 	if(c->building == u.voice)
@@ -504,6 +516,8 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 	if(ui < 0 || ui >= (int)c->units.size() || !c->units[ui].live)
 		return c->fail(A2AMD_EINVAL, "write to dead unit %d", ui);
 	HUnit &u = c->units[ui];
+	if(c->voices[u.voice].vm >= 0)
+		return c->fail(A2AMD_ESTATE, "write to unit %d of a voice the device VM runs: a2amd_vm_recall() first", ui);
 	c->building = -1;
 	start &= 255;		// a2_VoiceControl, core.c:148
 	switch(u.kind) {
@@ -876,6 +890,8 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 	HUnit &u = c->units[ui];
 	const int vi = u.voice;
 	HVoice &v = c->voices[vi];
+	if(v.vm >= 0)
+		return c->fail(A2AMD_ESTATE, "process call on unit %d of a voice the device VM runs: a2amd_vm_recall() first", ui);
 	c->building = -1;
 	unhold(c, vi);		// (a call speaks for itself)
 	if(!v.resolved) {
@@ -994,6 +1010,8 @@ int a2amd_voice_process(a2amd_ctx *c, int head, unsigned offset, unsigned frames
 		return c->fail(A2AMD_EINVAL, "process of dead unit %d", head);
 	const int vi = c->units[head].voice;
 	HVoice &pv = c->voices[vi];
+	if(pv.vm >= 0)
+		return c->fail(A2AMD_ESTATE, "process call on a voice the device VM runs: a2amd_vm_recall() first");
 	unhold(c, vi);
 	if(!pv.plain)
 		classify_plain(c, pv);

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/a2amd.h"
+#include "../../include/a2amd_vm.h"
 #include "a2amd_device.h"
 
 #ifndef M_PI
@@ -191,6 +192,7 @@ struct HVoice {
 	int out_off = 0, out_nch = 0;
 	int own_off = -1, own_nch = 0;
 	int cls = 0;			// launch class (CLS_*), set when the lists are rebuilt
+	int vm = -1;			// slot of the device VM that runs this voice's program (a2amd_vm_adopt), or -1
 };
 
 struct DepthRange { int fast_first = 0, fast_count = 0, fbd_first = 0, fbd_count = 0, gen_first = 0, gen_count = 0,
@@ -216,6 +218,63 @@ struct HWave {
 	size_t pool_off = 0, pool_len = 0;	// its region of the device wave pool (int16 units)
 };
 
+
+// ---- the scripted voice's VM on the device (include/a2amd_vm.h, a2amd_vm.cpp) ----
+struct HVmProg {
+	uint64_t key = 0;		// the host's name for the function (its code pointer)
+	uint32_t off = 0, n = 0;	// its text in the code pool
+	uint64_t sum = 0;		// of the text: a key may come back with another program behind it
+};
+struct HVm {
+	bool live = false;
+	// adopted in the batch being recorded: the device takes over with the NEXT batch, the host's copy
+	// of the interpreter covers the rest of this one (fragments adopt_frag + 1 ...) at upload time
+	bool pending = false;
+	int adopt_frag = -1;
+	bool fresh = false;		// carried to the end of its first batch and sent up: the kernel runs it from the next batch on
+	int voice = -1, prog = -1;
+	uint8_t func = 0;
+	A2DVmVoice st;			// pending: the state; else stale (the device's is the authority)
+};
+struct VmHost {
+	std::vector<HVm> vms;
+	std::vector<int> free_slots;
+	std::vector<HVmProg> progs;
+	std::vector<uint32_t> code;	// host copy of the code pool
+	size_t code_uploaded = 0;	// words of it the device has
+	std::vector<int> pending;	// slots adopted in the open batch
+	int n_fresh = 0;		// ... of which upload() has sent this many up (they join the list when the batch ends)
+	std::vector<int> list;		// slots the kernel runs (active on the device), and ...
+	std::vector<int> cls_lists;	// ... their voices by launch class, for the records kernels: [osc1 | osc2 | filt1]
+	int n_cls[3] = { 0, 0, 0 };
+	bool list_dirty = false;
+	std::vector<std::pair<int, A2DVmVoice>> to_upload;	// (slot, state) going up with this batch
+	uint32_t t0 = 0;		// engine time of the context's frame 0 (walk_time = 0)
+	bool t0_valid = false;
+	uint32_t msdur = 0;
+	uint64_t batch_time = 0;	// walk_time when the batch being recorded began
+	uint64_t replayed = 0;		// frames the kept batch has been re-run over (a2amd_replay / KEEP)
+	std::vector<int32_t> f1tab;	// [32][65536], built on first need
+	uint32_t f1tab_sum = 0;		// (of the pitch table it was made from)
+	bool f1tab_up = false;
+	// the device's states as the last batch left them, fetched when the engine wants voices back:
+	// one voice at a time until it is clear that many are wanted, then all at once
+	std::vector<A2DVmVoice> snap;
+	std::vector<uint8_t> snap_have;
+	int snap_fetches = 0;
+	uint32_t rec_cap = 0;		// the VM's region of the blob, in records
+	size_t rec_off = 0;		// ... its byte offset in the blob
+	a2amd_vm_stats stats = {};
+	int unwalked = -1;		// a voice under the device VM that the host's walk left out of a fragment
+	DevBuf<A2DVmVoice> d_vmv;
+	DevBuf<uint32_t> d_code;
+	DevBuf<int> d_list;		// [active slots | class lists (voice slots)]
+	DevBuf<A2DRun> d_vmrun;
+	int32_t *d_f1tab = nullptr;
+	uint32_t *d_total = nullptr, *h_total = nullptr;	// {records, faults}; pinned
+	A2DVmVoice *h_stage = nullptr;	// pinned staging for recalls
+	size_t h_stage_cap = 0;
+};
 } // namespace a2h
 using namespace a2h;
 
@@ -392,6 +451,7 @@ struct a2amd_ctx {
 	hipEvent_t grp_ev = nullptr;	// ... its SUBTREES phase is done / its partial has been taken
 
 	a2amd_stats stats;
+	VmHost vm;
 
 	int fail(int code, const char *fmt, ...)
 	{
@@ -481,6 +541,15 @@ double *dbg_why();
 int fetch_taps(a2amd_ctx *c, bool final);
 // a2amd_dist.cpp
 int dist_reduce_root(a2amd_ctx *c);
+// a2amd_vm.cpp
+int vm_prepare_batch(a2amd_ctx *c);		// upload(): pending adoptions, program text, states
+int vm_build_lists(a2amd_ctx *c);		// ... and the kernel's list, the records kernels' class lists
+int vm_issue(a2amd_ctx *c);			// issue_kernels(): the VM kernel's two passes
+int vm_take_back(a2amd_ctx *c, int vi, bool inclusive, a2amd_vm_state *out);	// the voice is the host's again
+void vm_end_batch(a2amd_ctx *c);
+void vm_close(a2amd_ctx *c);
+int vm_blob_room(a2amd_ctx *c);			// records the VM's region of the blob should hold
+
 } // namespace a2h
 
 #endif // A2AMD_HOST_H

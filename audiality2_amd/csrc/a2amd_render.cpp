@@ -67,6 +67,9 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		return 0;
 	}
 	c->snap_valid = false;		// (the device's unit states move on)
+	if(c->vm.unwalked >= 0)
+		return c->fail(A2AMD_ESTATE, "voice %d is run by the device VM, but the host's walk left it out of a fragment "
+				"(no default window reported, no call)", c->vm.unwalked);
 	if(phases & A2AMD_RENDER_UPLOAD)
 		if(int r = upload(c))
 			return r;
@@ -142,6 +145,7 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		if(!kphases)
 			return 0;
 		if(c->uploaded && !c->profiling && c->stream && c->with_recs.empty() && !getenv("A2AMD_NO_GRAPH") &&
+				c->vm.list.empty() &&	// (the VM's passes meet the host in between: not for a graph)
 				!(phases & A2AMD_RENDER_TAPS) && c->sub_resume < 0 && !c->paused_at &&
 				((phases & A2AMD_RENDER_KEEP) ? (phases & ~A2AMD_RENDER_KEEP) ==
 				 (phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT)) :
@@ -349,7 +353,7 @@ int a2amd_replay(a2amd_ctx *c, unsigned steps)
 	for(int vi = 0; vi < (int)c->voices.size(); ++vi)
 		if(!c->voices[vi].recs.empty())
 			return c->fail(A2AMD_ESTATE, "replay of a batch that carries command records");
-	bool graphs = c->stream != nullptr && !c->profiling && !getenv("A2AMD_NO_GRAPH");
+	bool graphs = c->stream != nullptr && !c->profiling && !getenv("A2AMD_NO_GRAPH") && c->vm.list.empty();
 	c->master_dst = nullptr;	// (replayed steps are not read back: the master bus stays in the bus memory)
 	c->master_direct = false;
 	if(graphs && (!c->gexec[0] || !c->gexec[1])) {

@@ -123,6 +123,8 @@ int close_fragment(a2amd_ctx *c)
 				continue;	// (walked: the host marked its default window)
 			if(v.live && v.started && !v.dying && v.walked != c->serial_base + f &&
 					v.touched != c->serial_base + f) {
+				if(v.vm >= 0)
+					c->vm.unwalked = (int)vi;	// (its VM cannot be told to skip a fragment: a2amd_render fails)
 				A2DRec r = { A2D_HEAD(f, R_NOP, 0, 0), 0, 0, 0 };
 				if(!v.listed_recs) {
 					v.listed_recs = true;
@@ -300,6 +302,10 @@ bool is_fbdchain(const a2amd_ctx *c, const HVoice &v)
 
 int upload(a2amd_ctx *c)
 {
+	// (voices the device VM took over during this batch: the host's interpreter carries them to its
+	// end - records into their lists - and their states go up, a2amd_vm.cpp)
+	if(int r = vm_prepare_batch(c))
+		return r;
 	if(c->hosttiming) {
 		// (A2AMD_HOSTTIMING: why a batch did not take the quiet path - first reason that applies)
 		const int why = !c->blob_quiet ? 0 : !c->with_recs.empty() ? 1 : !c->prev_with_recs.empty() ? 2 :
@@ -310,7 +316,7 @@ int upload(a2amd_ctx *c)
 		dbg_why()[why] += 1;
 	}
 	if(c->blob_quiet && c->with_recs.empty() && c->prev_with_recs.empty() && !c->voices_dirty &&
-			!c->udesc_dirty && !c->waves_dirty && !c->lists_dirty && !c->ptab_dirty &&
+			!c->udesc_dirty && !c->waves_dirty && !c->lists_dirty && !c->ptab_dirty && !c->vm.list_dirty &&
 			c->dirty_voices.empty() && c->fbd_to_zero.empty() && c->bus_used <= c->d_busmem.cap) {
 		bool inject = false;
 		for(const XioSlot &x : c->xio)
@@ -602,7 +608,11 @@ int upload(a2amd_ctx *c)
 					hipMemcpyHostToDevice, c->stream));
 		c->lists_dirty = false;
 		c->owners_all_driver = owners_ok && root_driver;
+		if(!c->vm.list.empty() || c->vm.stats.live)
+			c->vm.list_dirty = true;	// (launch classes may have moved)
 	}
+	if(int r = vm_build_lists(c))
+		return r;
 	std::vector<int> dyn_all;
 	{
 		// this batch's exceptions (shipped in the blob)
@@ -692,8 +702,13 @@ int upload(a2amd_ctx *c)
 	const size_t o_idx = o_recs + up256((recs.size() + 1) * sizeof(A2DRec));
 	const size_t o_val = o_idx + up256(nsc * sizeof(int));
 	const size_t o_dyn = o_val + up256(nsc * sizeof(A2DRun));
-	const size_t total = o_dyn + up256(dyn_all.size() * sizeof(int));
-	if(int r = grow(c, c->d_blob, total, 1, false)) return r;
+	// ... and behind what the host makes, room for the records the device VM writes (a2amd_vm.cpp)
+	const size_t host_total = o_dyn + up256(dyn_all.size() * sizeof(int));
+	const size_t vm_room = (size_t)vm_blob_room(c);
+	const size_t total = host_total;
+	if(int r = grow(c, c->d_blob, host_total + vm_room * sizeof(A2DRec), 1, false)) return r;
+	c->vm.rec_off = host_total;
+	c->vm.rec_cap = (uint32_t)((c->d_blob.cap - host_total) / sizeof(A2DRec));
 	const int bi = c->blob_i;
 	c->blob_i ^= 1;
 	if(c->blob_busy[bi]) {		// the copy that last read this staging buffer must have run
@@ -898,6 +913,7 @@ void end_batch(a2amd_ctx *c)
 	c->uploaded = false;
 	c->sub_resume = -1;
 	c->paused_at = 0;
+	vm_end_batch(c);
 }
 
 // does a voice at nesting depth d hold an xinsert in A2AMD_XIO_MUTE mode (insert clients)?
@@ -939,6 +955,10 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		c->root_clean = consume;
 		if(e0)
 			HIPCHK(c, hipEventRecord(e0, c->stream));
+		// the scripted voices the device runs itself: their VMs first - the records of this batch,
+		// runs[] pointing at them (a2amd_vm.cpp / a2amd_vm.hip) - then the kernels as for host records
+		if(int r = vm_issue(c))
+			return r;
 		if(c->n_fast_leaf) {
 			int vpw, ysplit;
 			pick_fast_shape(c->n_fast_leaf, c->nfrags, &vpw, &ysplit);
@@ -1040,6 +1060,21 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 				for(int k = 0; k < 4; ++k)
 					if(int r = recs(nosc[k], filt[k], lists[k], counts[k]))
 						return r;
+			}
+			// ... and the voices whose records the device VM has just written, by class (those it
+			// left without records this batch were rendered by their quiet kernels above)
+			if(!c->vm.list.empty()) {
+				static const int nosc[3] = { 1, 2, 1 }, filt[3] = { 0, 0, 1 };
+				const int *l = c->vm.d_list.d + c->vm.list.size();
+				for(int k = 0; k < 3; l += c->vm.n_cls[k++]) {
+					const int n = c->vm.n_cls[k];
+					if(!n)
+						continue;
+					int vpw = getenv("A2AMD_RVPW") ? atoi(getenv("A2AMD_RVPW")) : (n + 8191) / 8192;
+					if(a2d_launch_leaf_recs(c->d_params, c->hparams, nosc[k], filt[k], l, n, vpw, c->stream, 1))
+						return c->fail(A2AMD_EHIP, "leaf records launch failed: %s", hipGetErrorString(hipGetLastError()));
+					++c->stats.launches;
+				}
 			}
 		}
 		if(c->n_leaf_dyn - c->n_dyn_osc1 - c->n_dyn_osc2 - c->n_dyn_filt > 0) {

@@ -35,6 +35,7 @@
 #include <time.h>
 #include "../../include/a2amd.h"
 #include "../../include/a2amd_plugin.h"
+#include "../../include/a2amd_vm.h"
 
 /* engine API we call back into (public: a2_waves.h:183, a2_properties.h:106) */
 extern A2P_wave *a2_GetWave(void *iface, int handle);
@@ -108,6 +109,8 @@ typedef struct HOSTSTATE
 	int		walker;		/* liba2amd_walk.so walks this state: no prefetch hints of our own */
 	unsigned	serial;		/* a number of its own for every engine state ever opened (a2amd_walkview) */
 	unsigned	frag_serial;	/* root windows opened so far (a2amd_walkview) */
+	unsigned	vm_live;	/* voices of this state the device VM runs (a2amd_units_vm_adopt) */
+	int		no_vm;		/* A2AMD_NO_VM=1: no voice is handed to the device VM (A/B measurements) */
 	/* Engine states (master states and a2_Render's substates) come and go; their records are
 	 * allocated as needed, chained, and reused when a state has closed - never freed: the voice
 	 * walk of INTEGRATION.md option C holds pointers into them (a2amd_walkview). */
@@ -186,6 +189,12 @@ typedef struct XTRA
 	int		chain_checked;	/* the units behind us in the voice have been looked at */
 	int		refused;	/* an unsupported client was reported once */
 	void		(*orig_setprocess)(A2P_unit *u);	/* root xinsert: the engine's xi_SetProcess */
+	/* head: the device VM runs the voice's program (a2amd_units_vm_adopt) / when the engine last had to
+	 * take it back, or looked at it and found it awake (frag_serial: a voice is offered to the VM when it
+	 * has been awake twice within a second or two - one that sleeps for minutes gains nothing) */
+	int		vm;
+	unsigned	vm_seen;
+	int		vm_seen_valid;
 } XTRA;
 
 _Static_assert(MAXDEV == A2AMD_WALK_MAXDEV, "a2amd_walkview");
@@ -390,6 +399,7 @@ static a2amd_ctx *ctx_of(HOSTSTATE *hs)
 			c.max_batch = 256;
 		hs->max_batch = c.max_batch;
 		hs->no_quick = getenv("A2AMD_NO_QUICK") != NULL;
+		hs->no_vm = getenv("A2AMD_NO_VM") != NULL;
 		hs->walk_ahead = getenv("A2AMD_WALK_AHEAD") ? atoi(getenv("A2AMD_WALK_AHEAD")) : 12;
 		if(hs->walk_ahead < 0 || hs->walk_ahead > WALK_AHEAD)
 			hs->walk_ahead = WALK_AHEAD;
@@ -435,6 +445,7 @@ static a2amd_ctx *ctx_of(HOSTSTATE *hs)
 
 static int wave_id_of(HOSTSTATE *hs, int dev, A2P_wave *w);
 static inline XTRA *xtra(A2P_unit *u);
+static int is_ours(const A2P_unitdesc *d);
 
 static BIRTHOP *new_birthop(HOSTSTATE *hs)
 {
@@ -606,6 +617,18 @@ static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned 
 
 static void amd_deinit(A2P_unit *u)
 {
+	if(is_ours(u->descriptor) && u->descriptor != &a2_inline_unitdesc && u->descriptor != &a2_xinsert_unitdesc &&
+			u->descriptor != &a2_xsink_unitdesc && u->descriptor != &a2_xsource_unitdesc)
+	{
+		/* (the head of a voice the device VM runs: the backend takes the voice back itself) */
+		XTRA *xv = (XTRA *)((char *)u + 64);
+		if(xv->vm && xv->head == u && xv->hs)
+		{
+			xv->vm = 0;
+			if(xv->hs->vm_live)
+				--xv->hs->vm_live;
+		}
+	}
 	XTRA *x = xtra(u);
 	int rc;
 	if(x->hs)
@@ -1942,6 +1965,7 @@ int a2amd_units_walkview(const void *cfg, a2amd_walkview *out)
 			out->serial_value = hs->serial;
 			out->state = hs;
 			out->frag_serial = &hs->frag_serial;
+			out->vm_live = &hs->vm_live;
 			rc = 0;
 			break;
 		}
@@ -2031,4 +2055,140 @@ uint32_t a2amd_units_standing(const void *head_unit, uint32_t *slotdev)
 		return 0;
 	*slotdev = (uint32_t)x->slot | ((uint32_t)x->dev << 28);
 	return x->hs->qstamp[x->dev][x->slot];
+}
+
+
+/* ---- scripted voices whose VM runs on the device (include/a2amd_vm.h) -------------
+ * The walk (a2amd_walk.c) sees the engine's side of a voice - VM state, program text, which VM
+ * register is wired to which unit's write callback - and calls here; this side knows which backend
+ * unit an A2_unit is and which register a write callback stands for. */
+static const A2P_write_cb wr_table[13] = { wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7, wr8, wr9, wr10, wr11, wr12 };
+
+int a2amd_units_vm_is(const void *head_unit)
+{
+	const A2P_unit *head = (const A2P_unit *)head_unit;
+	const XTRA *x;
+	if(!head || head->descriptor == &a2_inline_unitdesc || head->descriptor == &a2_xinsert_unitdesc ||
+			head->descriptor == &a2_xsink_unitdesc || head->descriptor == &a2_xsource_unitdesc || !is_ours(head->descriptor))
+		return 0;
+	x = (const XTRA *)((const char *)head + 64);
+	return x->head == head && x->vm;
+}
+
+int a2amd_units_vm_adopt(const void *head_unit, const uint32_t *code, unsigned nwords, const void *vmstate,
+		void *const *wr_unit, void *const *wr_fn, uint32_t now, uint32_t msdur)
+{
+	A2P_unit *head = (A2P_unit *)head_unit, *n;
+	XTRA *x;
+	HOSTSTATE *hs;
+	int32_t wu[A2AMD_VM_REGISTERS];
+	uint8_t wreg[A2AMD_VM_REGISTERS];
+	int r, k, prog, rc;
+	if(!head || !is_ours(head->descriptor) || head->descriptor == &a2_inline_unitdesc ||
+			head->descriptor == &a2_xinsert_unitdesc || head->descriptor == &a2_xsink_unitdesc ||
+			head->descriptor == &a2_xsource_unitdesc)
+		return -1;
+	x = (XTRA *)((char *)head + 64);
+	hs = x->hs;
+	/* a chain of our own plain units, wired up (setup_simple_chain), alive on one GPU */
+	if(!hs || hs->failed || hs->no_vm || x->head != head || x->pending || x->uid < 0 || x->vm)
+		return -2;
+	/* awake twice within 2 048 fragments (2.7 s)?  (a voice that wakes once a minute is better off
+	 * with the quiet kernels between its wake-ups) */
+	if(!x->vm_seen_valid || hs->frag_serial - x->vm_seen > 2048u)
+	{
+		x->vm_seen = hs->frag_serial;
+		x->vm_seen_valid = 1;
+		return -2;
+	}
+	x->vm_seen = hs->frag_serial;
+	for(r = 0; r < A2AMD_VM_REGISTERS; ++r)
+	{
+		wu[r] = -1;
+		wreg[r] = 0;
+		if(!wr_fn[r])
+			continue;
+		wu[r] = -2;	/* (somebody else's callback: fine as long as the program cannot reach it) */
+		for(k = 0; k < 13; ++k)
+			if((A2P_write_cb)wr_fn[r] == wr_table[k])
+				break;
+		if(k == 13)
+			continue;
+		for(n = head; n; n = n->next)
+			if((void *)n == wr_unit[r])
+				break;
+		if(!n || !is_ours(n->descriptor) || xtra(n)->uid < 0 || xtra(n)->dev != x->dev)
+			continue;
+		wu[r] = xtra(n)->uid;
+		wreg[r] = (uint8_t)k;
+	}
+	if((prog = a2amd_vm_program(XCTX(x), (uint64_t)(uintptr_t)code, code, nwords)) < 0)
+		return -1;
+	rc = a2amd_vm_adopt(XCTX(x), x->uid, prog, (const a2amd_vm_state *)vmstate, wu, wreg, now, msdur);
+	if(rc)
+	{
+		static int trace = -1;
+		if(trace < 0)
+			trace = getenv("A2AMD_VM_TRACE") != NULL;
+		if(trace)
+			fprintf(stderr, "a2amd units: voice not taken by the device VM: %s\n", a2amd_last_error(XCTX(x)));
+		return rc == A2AMD_EUNSUPPORTED ? -1 : -2;
+	}
+	/* from here on it stands like a sleeping voice: default windows through the map / holds */
+	head->Process = amd_quick_process;
+	set_stamp(hs, x, 1);
+	x->vm = 1;
+	++hs->vm_live;
+	return 0;
+}
+
+int a2amd_units_vm_recall(const void *const *heads, unsigned n, void *const *vmstates)
+{
+	unsigned k, j;
+	int rc = 0, d;
+	for(d = 0; d < MAXDEV; ++d)
+	{
+		/* (one backend call - one device round trip - per context) */
+		int32_t uids[64];
+		a2amd_vm_state sts[64];
+		unsigned idx[64], m = 0;
+		HOSTSTATE *hs = NULL;
+		for(k = 0; k <= n; ++k)
+		{
+			XTRA *x = k < n ? (XTRA *)((char *)heads[k] + 64) : NULL;
+			if(x && (!x->vm || x->dev != d))
+				continue;
+			if(x)
+			{
+				hs = x->hs;
+				uids[m] = x->uid;
+				idx[m++] = k;
+			}
+			if(m && (m == 64 || k == n))
+			{
+				XTRA *x0 = (XTRA *)((char *)heads[idx[0]] + 64);
+				int r2 = hs->failed ? -1 : a2amd_vm_recall(XCTX(x0), uids, m, sts);
+				if(r2 && !hs->failed)
+					fail(hs, "a2amd_vm_recall", r2);
+				for(j = 0; j < m; ++j)
+				{
+					A2P_unit *head = (A2P_unit *)heads[idx[j]];
+					XTRA *xj = (XTRA *)((char *)head + 64);
+					if(!r2)
+						memcpy(vmstates[idx[j]], &sts[j], sizeof(a2amd_vm_state));
+					xj->vm = 0;
+					xj->vm_seen = hs->frag_serial;
+					xj->vm_seen_valid = 0;	/* (not offered again before it has been seen awake twice more) */
+					head->Process = amd_head_process;
+					set_stamp(hs, xj, 0);
+					if(hs->vm_live)
+						--hs->vm_live;
+				}
+				if(r2)
+					rc = -1;
+				m = 0;
+			}
+		}
+	}
+	return rc;
 }

@@ -1,0 +1,947 @@
+// a2amd_vm.cpp - host side of the scripted voice's VM on the device (include/a2amd_vm.h):
+// the proof that a program stays inside the subset (a2amd_vm_analyze), the program texts and voice
+// states that live on the device, adoption and recall, and the two passes of the VM kernel per
+// batch.  The interpreter itself is a2amd_vmcore.h - compiled here for the host (a voice adopted
+// or taken back in the middle of a batch is carried over the rest / the start of that batch by the
+// host's copy, which writes the same records into the voice's host record list) and in
+// a2amd_vm.hip for the device.
+//
+// Life of an adopted voice:
+//   adopt    (fragment f of the batch being recorded; the engine has processed the voice in f)
+//            -> "pending": counts as a sleeping voice whose default window the host reports
+//               (a2amd_default_hold / the default map) from f + 1 on
+//   upload   the host interpreter runs the voice over fragments f + 1 .. end of the batch (records
+//            into HVoice::recs), the resulting state goes to the device, the voice joins the list
+//   batches  k_vm (a2amd_vm.hip): count pass, host reads the total, emit pass -> records in the
+//            blob's VM region + runs[voice]; the leaf kernels execute them like host records
+//   recall   the device's state as the last batch left it comes back (one copy per voice, or the
+//            whole array once several are wanted), the host interpreter runs it over the fragments
+//            of the open batch recorded so far, the engine gets its A2_vmstate; this batch the
+//            voice is rendered from host records
+#include "a2amd_host.h"
+#include "a2amd_vmcore.h"
+
+using namespace a2vm;
+
+namespace {
+
+uint64_t text_sum(const uint32_t *code, unsigned n)
+{
+	uint64_t h = 0xcbf29ce484222325ull;
+	for(unsigned i = 0; i < n; ++i)
+		h = (h ^ code[i]) * 0x100000001b3ull;
+	return h;
+}
+
+unsigned ins_size(unsigned op)		// a2_InsSize, src/compiler.c:111-131
+{
+	switch(op) {
+	  case A2AMD_OP_DELAY: case A2AMD_OP_TDELAY: case A2AMD_OP_LOAD: case A2AMD_OP_ADD: case A2AMD_OP_MUL:
+	  case A2AMD_OP_MOD: case A2AMD_OP_QUANT: case A2AMD_OP_RAND: case A2AMD_OP_PUSH: case A2AMD_OP_DEBUG:
+	  case A2AMD_OP_RAMP: case A2AMD_OP_RAMPALL:
+		return 2;
+	  default:
+		return 1;
+	}
+}
+
+// records of the host interpreter go where the recorder's go: the voice's list, fragment order
+struct HostE {
+	a2amd_ctx *c;
+	int vi;
+	void rec(int frag, int op, int unit, int reg, int value, unsigned dur, unsigned start)
+	{
+		HVoice &v = c->voices[vi];
+		A2DRec r;
+		r.head = A2D_HEAD(frag, op, unit, reg);
+		r.value = value;
+		r.dur = dur;
+		r.start = start;
+		if(!v.listed_recs) {
+			v.listed_recs = true;
+			c->with_recs.push_back(vi);
+		}
+		v.recs.push_back(r);
+	}
+	int count() const { return (int)c->voices[vi].recs.size(); }
+};
+
+Consts consts_of(a2amd_ctx *c)
+{
+	Consts K;
+	K.msdur = c->vm.msdur;
+	K.samplerate = c->cfg.samplerate;
+	K.basepitch = c->cfg.basepitch;
+	K.ptab = c->ptab;
+	K.f1tab = c->vm.f1tab.empty() ? nullptr : c->vm.f1tab.data();
+	return K;
+}
+
+// f12_pitch2coeff (filter12.c:65-72) for everything a2_P2I (pitch.c:57-67) can return: a2_P2I's
+// result is X(n) >> ((7 - oct) & 31) with X a function of the 16 fraction bits n alone, so 32 x
+// 65536 entries cover every pitch - made here with the reference's own float / double / libm
+// expression (a2amd_host.h: f12_coeff), which is why the device never evaluates a sine
+void build_f1tab(a2amd_ctx *c)
+{
+	VmHost &m = c->vm;
+	uint32_t sum = 0;
+	for(int i = 0; i < 128; ++i)
+		sum = sum * 31u + c->ptab[i];
+	if(!m.f1tab.empty() && m.f1tab_sum == sum)
+		return;
+	m.f1tab.resize((size_t)32 * 65536);
+	for(unsigned sh = 0; sh < 32; ++sh) {
+		// a pitch whose a2_P2I shift count is sh: oct = 7 - sh (any oct with (7 - oct) & 31 == sh)
+		const int oct = 7 - (int)sh;
+		for(unsigned n = 0; n < 65536; ++n) {
+			const int pitch = (int)(((unsigned)oct << 16) | n);
+			// (f12_coeff takes the ramper value: the pitch is value >> 8)
+			float f = a2h::p2i(c->ptab, pitch) * (261.626f / 16777216.0f);
+			int v;
+			if(f > (c->cfg.samplerate >> 2))
+				v = 362 << 16;
+			else
+				v = (int)(512.0f * 65536.0f * sin(M_PI * f / c->cfg.samplerate));
+			m.f1tab[(size_t)sh * 65536 + n] = v;
+		}
+	}
+	m.f1tab_sum = sum;
+	m.f1tab_up = false;
+}
+
+int analyze(const uint32_t *code, unsigned nwords, unsigned pc0, int32_t tick, uint32_t msdur, a2amd_vm_info *info)
+{
+	memset(info, 0, sizeof(*info));
+	info->opcode = info->at = -1;
+	if(!code || pc0 >= nwords || nwords > 65535) {
+		info->at = (int)pc0;
+		return info->reason = A2AMD_VM_BADCODE;
+	}
+	// pass 1: what is reachable, and is it all inside the subset
+	std::vector<uint8_t> seen(nwords, 0);
+	std::vector<unsigned> work(1, pc0), order;
+	seen[pc0] = 1;
+	uint64_t written = 0, marked = 0, explicit_ctl = 0;
+	bool any_all = false, any_timing = false;
+	auto fail = [&](int why, unsigned op, unsigned at) {
+		info->opcode = (int)op;
+		info->at = (int)at;
+		return info->reason = why;
+	};
+	while(!work.empty()) {
+		const unsigned pc = work.back();
+		work.pop_back();
+		order.push_back(pc);
+		const uint32_t w = code[pc];
+		const unsigned op = A2AMD_VM_OPCODE(w), a1 = A2AMD_VM_A1(w), a2 = A2AMD_VM_A2(w), sz = ins_size(op);
+		if(pc + sz > nwords)
+			return fail(A2AMD_VM_BADCODE, op, pc);
+		const int32_t a3 = sz == 2 ? (int32_t)code[pc + 1] : 0;
+		unsigned succ[2], ns = 0;
+		bool regs_a1 = false, regs_a2 = false;
+		switch(op) {
+		  case A2AMD_OP_JUMP:
+			succ[ns++] = a2;
+			break;
+		  case A2AMD_OP_LOOP:
+			written |= 1ull << (a1 & 63);
+			regs_a1 = true;
+			succ[ns++] = a2;
+			succ[ns++] = pc + sz;
+			break;
+		  case A2AMD_OP_JZ: case A2AMD_OP_JNZ: case A2AMD_OP_JG: case A2AMD_OP_JL: case A2AMD_OP_JGE: case A2AMD_OP_JLE:
+			regs_a1 = true;
+			succ[ns++] = a2;
+			succ[ns++] = pc + sz;
+			break;
+		  case A2AMD_OP_DELAYR: case A2AMD_OP_TDELAYR:
+			regs_a1 = true;
+			// fall through
+		  case A2AMD_OP_DELAY: case A2AMD_OP_TDELAY:
+			any_timing = true;
+			succ[ns++] = pc + sz;
+			break;
+		  case A2AMD_OP_SUBR: case A2AMD_OP_P2DR: case A2AMD_OP_NEGR: case A2AMD_OP_LOADR: case A2AMD_OP_ADDR:
+		  case A2AMD_OP_MULR: case A2AMD_OP_GR: case A2AMD_OP_LR: case A2AMD_OP_GER: case A2AMD_OP_LER:
+		  case A2AMD_OP_EQR: case A2AMD_OP_NER: case A2AMD_OP_ANDR: case A2AMD_OP_ORR: case A2AMD_OP_XORR:
+		  case A2AMD_OP_NOTR:
+			regs_a2 = true;
+			// fall through
+		  case A2AMD_OP_LOAD: case A2AMD_OP_ADD: case A2AMD_OP_MUL:
+			regs_a1 = true;
+			written |= 1ull << (a1 & 63);
+			marked |= 1ull << (a1 & 63);
+			succ[ns++] = pc + sz;
+			break;
+		  case A2AMD_OP_MOD: case A2AMD_OP_QUANT:
+			if(a3 == 0 || a3 == -1)
+				return fail(A2AMD_VM_DIVISOR, op, pc);
+			regs_a1 = true;
+			written |= 1ull << (a1 & 63);
+			marked |= 1ull << (a1 & 63);
+			succ[ns++] = pc + sz;
+			break;
+		  case A2AMD_OP_SET: case A2AMD_OP_RAMP:
+			regs_a1 = true;
+			explicit_ctl |= 1ull << (a1 & 63);
+			succ[ns++] = pc + sz;
+			break;
+		  case A2AMD_OP_RAMPR:
+			regs_a1 = regs_a2 = true;
+			explicit_ctl |= 1ull << (a1 & 63);
+			succ[ns++] = pc + sz;
+			break;
+		  case A2AMD_OP_RAMPALLR:
+			regs_a1 = true;
+			// fall through
+		  case A2AMD_OP_SETALL: case A2AMD_OP_RAMPALL:
+			any_all = true;
+			succ[ns++] = pc + sz;
+			break;
+		  default:
+			return fail(A2AMD_VM_OPCODE_OUT, op, pc);
+		}
+		if((regs_a1 && a1 >= A2AMD_VM_REGISTERS) || (regs_a2 && a2 >= A2AMD_VM_REGISTERS))
+			return fail(A2AMD_VM_BADCODE, op, pc);
+		for(unsigned k = 0; k < ns; ++k) {
+			if(succ[k] >= nwords)
+				return fail(A2AMD_VM_BADCODE, op, pc);
+			if(!seen[succ[k]]) {
+				seen[succ[k]] = 1;
+				work.push_back(succ[k]);
+			}
+		}
+	}
+	info->reachable = (uint32_t)order.size();
+	info->written = written;
+	// what a2_VoiceControl may be called for: the explicit targets, and - at every timing
+	// instruction and every SETALL / RAMPALL - whatever the register tracker holds: any register an
+	// arithmetic instruction stores to.  (The tracker's mask is 32 bits wide: a register's twin 32
+	// places up or down can stand in for it, core.c:1076-1083.)
+	info->controlled = explicit_ctl;
+	if(any_timing || any_all) {
+		info->controlled |= marked;
+	}
+	// pass 2: no cycle without a certain yield, no 1000 instructions between two of them
+	// (A2_OVERLOAD, core.c:1187-1190: the 1000th instruction of a VM run aborts the voice).
+	// A certain yield ends a VM run: DELAY with a non-zero duration, TDELAY with one while
+	// nothing reachable stores to R_TICK.
+	const bool tick_const = !(written & (1ull << A2AMD_VM_R_TICK));
+	auto certain_yield = [&](unsigned pc) {
+		const unsigned op = A2AMD_VM_OPCODE(code[pc]);
+		if(op == A2AMD_OP_DELAY)
+			return ms2t(msdur, (int32_t)code[pc + 1]) != 0;
+		if(op == A2AMD_OP_TDELAY)
+			return tick_const && ticks2t(msdur, tick, (int32_t)code[pc + 1]) != 0;
+		return false;
+	};
+	// longest[pc] = most instructions a VM run can execute from pc on, pc included (a yield counts
+	// and ends the run).  Depth first with an explicit stack; a grey node reached again = a cycle.
+	std::vector<int> longest(nwords, -1);
+	std::vector<uint8_t> colour(nwords, 0);
+	struct Frame { unsigned pc; unsigned k; };
+	uint32_t worst = 0;
+	for(unsigned start : order) {
+		// (every reachable instruction may begin a run: the successor of a yield does, and pc0)
+		if(longest[start] >= 0)
+			continue;
+		std::vector<Frame> st(1, Frame{ start, 0 });
+		colour[start] = 1;
+		while(!st.empty()) {
+			Frame &fr = st.back();
+			const unsigned pc = fr.pc;
+			const uint32_t w = code[pc];
+			const unsigned op = A2AMD_VM_OPCODE(w), a2 = A2AMD_VM_A2(w), sz = ins_size(op);
+			unsigned succ[2], ns = 0;
+			if(!certain_yield(pc)) {
+				if(op == A2AMD_OP_JUMP)
+					succ[ns++] = a2;
+				else if(op == A2AMD_OP_LOOP || (op >= A2AMD_OP_JZ && op <= A2AMD_OP_JLE)) {
+					succ[ns++] = a2;
+					succ[ns++] = pc + sz;
+				} else
+					succ[ns++] = pc + sz;
+			}
+			if(fr.k < ns) {
+				const unsigned nx = succ[fr.k++];
+				if(colour[nx] == 1)
+					return fail(A2AMD_VM_NOYIELD, op, pc);
+				if(colour[nx] == 0) {
+					colour[nx] = 1;
+					st.push_back(Frame{ nx, 0 });
+				}
+				continue;
+			}
+			int best = 0;
+			for(unsigned k = 0; k < ns; ++k)
+				best = std::max(best, longest[succ[k]]);
+			longest[pc] = best + 1;
+			colour[pc] = 2;
+			worst = std::max(worst, (uint32_t)longest[pc]);
+			st.pop_back();
+		}
+	}
+	info->longest = worst;
+	if(worst >= A2AMD_VM_INSLIMIT)
+		return fail(A2AMD_VM_NOYIELD, 0, pc0);
+	return info->reason = A2AMD_VM_OK;
+}
+
+const char *reason_text(int r)
+{
+	static const char *const t[] = { "ok", "bad code", "instruction outside the subset", "MOD / QUANT by 0 or -1",
+		"a loop without a certain delay (A2_OVERLOAD cannot be ruled out)", "writes a unit register the device VM does not",
+		"never writes a unit register" };
+	return r >= 0 && r <= A2AMD_VM_IDLE ? t[r] : "?";
+}
+
+int grow_stage(a2amd_ctx *c, size_t n)
+{
+	VmHost &m = c->vm;
+	if(n <= m.h_stage_cap)
+		return 0;
+	if(m.h_stage)
+		HIPCHK(c, hipHostFree(m.h_stage));
+	m.h_stage = nullptr;
+	m.h_stage_cap = 0;
+	const size_t cap = std::max(n, (size_t)64);
+	HIPCHK(c, hipHostMalloc((void **)&m.h_stage, cap * sizeof(A2DVmVoice), hipHostMallocDefault));
+	m.h_stage_cap = cap;
+	return 0;
+}
+
+// the state of an ACTIVE voice (one the device runs) as the last rendered batch left it
+int fetch_state(a2amd_ctx *c, int slot, A2DVmVoice *out)
+{
+	VmHost &m = c->vm;
+	use_device(c);
+	if(m.snap_have.size() < m.vms.size()) {
+		m.snap_have.resize(m.vms.size(), 0);
+		m.snap.resize(m.vms.size());
+	}
+	if(!m.snap_have[slot]) {
+		if(++m.snap_fetches > 8 && !m.list.empty()) {
+			// several are wanted (a chord released, a group killed): all of them, once
+			const size_t n = std::min(m.vms.size(), m.d_vmv.cap);
+			if(int r = grow_stage(c, n))
+				return r;
+			HIPCHK(c, hipMemcpyAsync(m.h_stage, m.d_vmv.d, n * sizeof(A2DVmVoice), hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			for(size_t k = 0; k < n; ++k)
+				if(!m.snap_have[k]) {
+					m.snap[k] = m.h_stage[k];
+					m.snap_have[k] = 1;
+				}
+		} else {
+			if(int r = grow_stage(c, 1))
+				return r;
+			HIPCHK(c, hipMemcpyAsync(m.h_stage, m.d_vmv.d + slot, sizeof(A2DVmVoice), hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			m.snap[slot] = m.h_stage[0];
+			m.snap_have[slot] = 1;
+		}
+	}
+	*out = m.snap[slot];
+	return 0;
+}
+
+} // namespace
+
+namespace a2h {
+
+// The voice vi goes back to the host in the open fragment g (or, outside any fragment, before the
+// first fragment of the next batch): its VM state is brought to the start of g (inclusive: to the
+// END of g - the voice has had its window in g, which the host reported by the map or a hold), the
+// records of the fragments the device VM would have covered in this batch go into the voice's
+// host record list, the filter cutoffs return to their host shadows.  out (may be null) = the
+// engine's A2_vmstate.
+int vm_take_back(a2amd_ctx *c, int vi, bool inclusive, a2amd_vm_state *out)
+{
+	VmHost &m = c->vm;
+	HVoice &v = c->voices[vi];
+	const int slot = v.vm;
+	if(slot < 0 || slot >= (int)m.vms.size() || !m.vms[slot].live)
+		return c->fail(A2AMD_ESTATE, "voice %d is not run by the device VM", vi);
+	HVm &h = m.vms[slot];
+	A2DVmVoice st;
+	int f0;
+	if(h.pending) {
+		st = h.st;
+		f0 = h.adopt_frag + 1;
+	} else {
+		if(int r = fetch_state(c, slot, &st))
+			return r;
+		f0 = 0;
+	}
+	// fragments of the open batch the VM has to be carried over
+	int f1 = c->frag_open ? c->cur_frag + (inclusive ? 1 : 0) : c->nfrags;
+	if(f1 > c->nfrags)
+		f1 = c->nfrags;
+	if(f0 < f1) {
+		const HVmProg &p = m.progs[h.prog];
+		const Consts K = consts_of(c);
+		HostE e = { c, vi };
+		uint64_t frames_before = 0;
+		for(int f = 0; f < f0; ++f)
+			frames_before += c->fragframes[f];
+		const uint32_t now = m.t0 + (uint32_t)((m.batch_time + frames_before) << 8);
+		const unsigned *ff = c->fragframes;
+		const size_t mark = c->voices[vi].recs.size();
+		run_batch(st, m.code.data() + p.off, K, e, now, f0, f1, [ff](int f) { return ff[f]; });
+		if(st.fault)
+			return c->fail(A2AMD_ESTATE, "device VM: voice %d faulted (trap %d at pc %u): the analysis let a program through "
+					"that it should not have", vi, st.fault, (unsigned)st.pc);
+		HVoice &vv = c->voices[vi];
+		if(inclusive && c->frag_open) {
+			// the open fragment's windows are on record now: nothing is left to be spelled out for it
+			// (sched: spell_out_pending) - or, if the VM did nothing in it, exactly the default window
+			bool any = false;
+			for(size_t k = mark; k < vv.recs.size(); ++k)
+				any |= (int)A2D_RFRAG(vv.recs[k].head) == c->cur_frag;
+			const long long serial = c->serial_base + c->cur_frag;
+			if(c->defmap_used && (size_t)vi < c->defmap.size() && c->defmap[vi])
+				c->defmap[vi] = 0;
+			vv.touched = serial;
+			vv.frag_mark = any ? mark : vv.recs.size();
+			vv.default_seg = any ? -1 : serial;
+			if(vv.walked != serial) {
+				vv.walked = serial;
+				++c->walked_started;
+			}
+		}
+	}
+	unhold(c, vi);
+	HVoice &vv = c->voices[vi];
+	// the cutoff rampers go back to where host-driven voices keep them
+	for(int k = 0; k < (int)st.ncut && k < A2D_VM_MAXCUT; ++k) {
+		HUnit &u = c->units[vv.unit[st.cutpos[k]]];
+		const bool was = u.cutoff.timer != 0;
+		u.cutoff.value = st.cut[k][0];
+		u.cutoff.target = st.cut[k][1];
+		u.cutoff.delta = st.cut[k][2];
+		u.cutoff.timer = st.cut[k][3];
+		c->n_cutoff_ramps += (int)(u.cutoff.timer != 0) - (int)was;
+	}
+	vv.plain = 0;
+	if(out) {
+		out->waketime = st.waketime;
+		out->state = st.state;
+		out->func = h.func;
+		out->pc = st.pc;
+		memcpy(out->r, st.r, sizeof(out->r));
+	}
+	// (its runs[] entry holds last batch's VM run: cleared with the next upload unless the voice
+	// carries host records by then)
+	if(!h.pending)
+		c->prev_with_recs.push_back(vi);
+	if(h.pending)
+		m.pending.erase(std::remove(m.pending.begin(), m.pending.end(), slot), m.pending.end());
+	else
+		m.list_dirty = true;
+	h.live = false;
+	h.pending = false;
+	m.free_slots.push_back(slot);
+	if((size_t)slot < m.snap_have.size())
+		m.snap_have[slot] = 0;
+	vv.vm = -1;
+	--m.stats.live;
+	++m.stats.recalled;
+	return A2AMD_OK;
+}
+
+int vm_blob_room(a2amd_ctx *c)
+{
+	VmHost &m = c->vm;
+	if(m.list.empty() && m.pending.empty())
+		return 0;
+	// (a guess; the count pass says what is needed, vm_issue grows the region when it is more)
+	const size_t n = m.list.size() + m.pending.size();
+	const size_t want = n * (size_t)std::max(c->nfrags, 1) * 2 + 4096;
+	return (int)std::min(std::max(want, (size_t)m.rec_cap), (size_t)1 << 28);
+}
+
+// upload(): the voices adopted during this batch are carried to its end by the host interpreter
+// and sent up; the kernel's list and the records kernels' class lists follow the membership
+int vm_prepare_batch(a2amd_ctx *c)
+{
+	VmHost &m = c->vm;
+	if(m.pending.empty() && m.to_upload.empty() && m.code_uploaded == m.code.size() && (m.f1tab_up || m.f1tab.empty()))
+		return 0;
+	use_device(c);
+	const std::vector<int> pend = m.pending;
+	for(int slot : pend) {
+		HVm &h = m.vms[slot];
+		if(!h.live || !h.pending)
+			continue;
+		const HVmProg &p = m.progs[h.prog];
+		const Consts K = consts_of(c);
+		HostE e = { c, h.voice };
+		uint64_t frames_before = 0;
+		for(int f = 0; f <= h.adopt_frag && f < c->nfrags; ++f)
+			frames_before += c->fragframes[f];
+		const uint32_t now = m.t0 + (uint32_t)((m.batch_time + frames_before) << 8);
+		const unsigned *ff = c->fragframes;
+		run_batch(h.st, m.code.data() + p.off, K, e, now, h.adopt_frag + 1, c->nfrags, [ff](int f) { return ff[f]; });
+		if(h.st.fault)
+			return c->fail(A2AMD_ESTATE, "device VM: voice %d faulted (trap %d at pc %u)", h.voice, h.st.fault, (unsigned)h.st.pc);
+		h.pending = false;
+		h.adopt_frag = -1;
+		h.fresh = true;		// (this batch it is rendered from the host's records: the kernel's turn comes with the next)
+		++m.n_fresh;
+		m.to_upload.push_back(std::make_pair(slot, h.st));
+	}
+	m.pending.clear();
+	if(m.code_uploaded != m.code.size()) {
+		if(int r = grow(c, m.d_code, m.code.size(), 1, true))
+			return r;
+		HIPCHK(c, hipMemcpyAsync(m.d_code.d + m.code_uploaded, m.code.data() + m.code_uploaded,
+				(m.code.size() - m.code_uploaded) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));	// (pageable source that may move)
+		m.code_uploaded = m.code.size();
+	}
+	if(!m.f1tab.empty() && !m.f1tab_up) {
+		if(!m.d_f1tab)
+			HIPCHK(c, hipMalloc((void **)&m.d_f1tab, m.f1tab.size() * sizeof(int32_t)));
+		HIPCHK(c, hipMemcpyAsync(m.d_f1tab, m.f1tab.data(), m.f1tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		m.f1tab_up = true;
+	}
+	if(!m.to_upload.empty()) {
+		if(int r = grow(c, m.d_vmv, m.vms.size(), 1, true))
+			return r;
+		if(int r = grow_stage(c, m.to_upload.size()))
+			return r;
+		// (contiguous runs of slots go up in one copy each)
+		std::sort(m.to_upload.begin(), m.to_upload.end(), [](const std::pair<int, A2DVmVoice> &a,
+				const std::pair<int, A2DVmVoice> &b) { return a.first < b.first; });
+		for(size_t k = 0; k < m.to_upload.size(); ++k)
+			m.h_stage[k] = m.to_upload[k].second;
+		for(size_t k = 0; k < m.to_upload.size();) {
+			size_t e = k + 1;
+			while(e < m.to_upload.size() && m.to_upload[e].first == m.to_upload[e - 1].first + 1)
+				++e;
+			HIPCHK(c, hipMemcpyAsync(m.d_vmv.d + m.to_upload[k].first, m.h_stage + k, (e - k) * sizeof(A2DVmVoice),
+					hipMemcpyHostToDevice, c->stream));
+			k = e;
+		}
+		HIPCHK(c, hipStreamSynchronize(c->stream));	// (the staging buffer is reused)
+		m.to_upload.clear();
+	}
+	return 0;
+}
+
+int vm_build_lists(a2amd_ctx *c)
+{
+	VmHost &m = c->vm;
+	if(m.list_dirty) {
+		use_device(c);
+		m.list.clear();
+		std::vector<int> cls[3];
+		for(size_t s = 0; s < m.vms.size(); ++s) {
+			const HVm &h = m.vms[s];
+			if(!h.live || h.pending || h.fresh)
+				continue;
+			m.list.push_back((int)s);
+		}
+		// the voices by launch class, each class sorted by output bus like the static lists
+		// (the classes are set when upload() rebuilds its lists: call after that)
+		for(int s : m.list) {
+			const HVoice &v = c->voices[m.vms[s].voice];
+			const int k = v.cls == CLS_OSCPAN ? 0 : v.cls == CLS_OSC2PAN ? 1 : v.cls == CLS_OSCFILTPAN ? 2 : -1;
+			if(k >= 0)
+				cls[k].push_back(m.vms[s].voice);
+		}
+		m.cls_lists.clear();
+		for(int k = 0; k < 3; ++k) {
+			std::stable_sort(cls[k].begin(), cls[k].end(), [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; });
+			m.n_cls[k] = (int)cls[k].size();
+			m.cls_lists.insert(m.cls_lists.end(), cls[k].begin(), cls[k].end());
+		}
+		const size_t n = m.list.size() + m.cls_lists.size();
+		if(int r = grow(c, m.d_list, n + 64, 1, false))
+			return r;
+		if(int r = grow(c, m.d_vmrun, m.list.size() + 64, 1, false))
+			return r;
+		if(n) {
+			std::vector<int> all = m.list;
+			all.insert(all.end(), m.cls_lists.begin(), m.cls_lists.end());
+			HIPCHK(c, hipMemcpyAsync(m.d_list.d, all.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+		}
+		m.list_dirty = false;
+	}
+	return 0;
+}
+
+// issue_kernels(): count pass, the host reads the total (and grows the blob's VM region when the
+// records do not fit), emit pass.  The leaf kernels that follow find runs[voice] and the records
+// where host records would be.
+int vm_issue(a2amd_ctx *c)
+{
+	VmHost &m = c->vm;
+	if(m.list.empty())
+		return 0;
+	if(c->capturing)
+		return c->fail(A2AMD_ESTATE, "device VM voices in a captured batch");
+	use_device(c);
+	if(!m.d_total) {
+		HIPCHK(c, hipMalloc((void **)&m.d_total, 2 * sizeof(uint32_t)));
+		HIPCHK(c, hipHostMalloc((void **)&m.h_total, 2 * sizeof(uint32_t), hipHostMallocDefault));
+	}
+	A2DVmParams vp;
+	memset(&vp, 0, sizeof(vp));
+	vp.vmv = m.d_vmv.d;
+	vp.list = m.d_list.d;
+	vp.n = (int32_t)m.list.size();
+	vp.code = m.d_code.d;
+	vp.ptab = c->d_ptab;
+	vp.f1tab = m.d_f1tab;
+	vp.runs = c->d_runs.d;
+	vp.vmrun = m.d_vmrun.d;
+	vp.recs = (A2DRec *)c->hparams.recs;
+	vp.total = m.d_total;
+	vp.now = m.t0 + (uint32_t)((m.batch_time + m.replayed) << 8);
+	vp.msdur = m.msdur;
+	vp.samplerate = c->cfg.samplerate;
+	vp.basepitch = c->cfg.basepitch;
+	vp.nfrags = c->nfrags;
+	for(int f = 0; f < c->nfrags; ++f)
+		vp.fragframes[f] = (uint8_t)c->fragframes[f];
+	HIPCHK(c, hipMemsetAsync(m.d_total, 0, 2 * sizeof(uint32_t), c->stream));
+	if(a2d_launch_vm(vp, 0, c->stream))
+		return c->fail(A2AMD_EHIP, "VM count launch failed: %s", hipGetErrorString(hipGetLastError()));
+	HIPCHK(c, hipMemcpyAsync(m.h_total, m.d_total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	const uint32_t total = m.h_total[0];
+	if(m.h_total[1])
+		return c->fail(A2AMD_ESTATE, "device VM: %u voice(s) faulted (the analysis let a program through that it should "
+				"not have)", m.h_total[1]);
+	if(total > m.rec_cap) {
+		// the blob grows behind its host-made part (which stays as it is)
+		const size_t ncap = std::max((size_t)total * 2, (size_t)65536);
+		const size_t nbytes = m.rec_off + ncap * sizeof(A2DRec);
+		char *nd = nullptr;
+		HIPCHK(c, hipMalloc((void **)&nd, nbytes));
+		HIPCHK(c, hipMemcpy(nd, c->d_blob.d, m.rec_off, hipMemcpyDeviceToDevice));
+		const ptrdiff_t o_recs = (const char *)c->hparams.recs - c->d_blob.d;
+		const ptrdiff_t o_dyn = (const char *)c->d_dyn - c->d_blob.d;
+		HIPCHK(c, hipFree(c->d_blob.d));
+		c->d_blob.d = nd;
+		c->d_blob.cap = nbytes;
+		c->hparams.recs = (const A2DRec *)(nd + o_recs);
+		c->d_params = (A2DParams *)nd;
+		c->d_dyn = (const int *)(nd + o_dyn);
+		HIPCHK(c, hipMemcpy(nd, &c->hparams, sizeof(A2DParams), hipMemcpyHostToDevice));
+		m.rec_cap = (uint32_t)ncap;
+		drop_graphs(c);
+		vp.recs = (A2DRec *)c->hparams.recs;
+	}
+	vp.rec_base = (uint32_t)((m.rec_off - (size_t)((const char *)c->hparams.recs - c->d_blob.d)) / sizeof(A2DRec));
+	vp.rec_cap = m.rec_cap;
+	if(a2d_launch_vm(vp, 1, c->stream))
+		return c->fail(A2AMD_EHIP, "VM emit launch failed: %s", hipGetErrorString(hipGetLastError()));
+	c->stats.launches += 2;
+	c->stats.records += total;
+	m.stats.vm_voice_batches += m.list.size();
+	m.stats.vm_records += total;
+	// (a kept batch that is run again renders the next stretch of time)
+	uint64_t frames = 0;
+	for(int f = 0; f < c->nfrags; ++f)
+		frames += c->fragframes[f];
+	m.replayed += frames;
+	return 0;
+}
+
+void vm_end_batch(a2amd_ctx *c)
+{
+	VmHost &m = c->vm;
+	m.replayed = 0;
+	m.snap_fetches = 0;
+	if(m.n_fresh) {
+		for(HVm &h : m.vms)
+			h.fresh = false;
+		m.n_fresh = 0;
+		m.list_dirty = true;
+	}
+	if(!m.snap_have.empty())
+		std::fill(m.snap_have.begin(), m.snap_have.end(), 0);
+}
+
+void vm_close(a2amd_ctx *c)
+{
+	VmHost &m = c->vm;
+	hipFree(m.d_vmv.d);
+	hipFree(m.d_code.d);
+	hipFree(m.d_list.d);
+	hipFree(m.d_vmrun.d);
+	hipFree(m.d_f1tab);
+	hipFree(m.d_total);
+	if(m.h_total)
+		hipHostFree(m.h_total);
+	if(m.h_stage)
+		hipHostFree(m.h_stage);
+}
+
+} // namespace a2h
+
+extern "C" {
+
+int a2amd_vm_analyze(const uint32_t *code, unsigned nwords, unsigned pc, int32_t tick, uint32_t msdur, a2amd_vm_info *info)
+{
+	a2amd_vm_info tmp;
+	return analyze(code, nwords, pc, tick, msdur, info ? info : &tmp);
+}
+
+int a2amd_vm_program(a2amd_ctx *c, uint64_t key, const uint32_t *code, unsigned nwords)
+{
+	VmHost &m = c->vm;
+	if(!code || !nwords || nwords > 65535)
+		return c->fail(A2AMD_EINVAL, "vm_program: %u words", nwords);
+	const uint64_t sum = text_sum(code, nwords);
+	for(size_t k = 0; k < m.progs.size(); ++k)
+		if(m.progs[k].key == key && m.progs[k].n == nwords && m.progs[k].sum == sum)
+			return (int)k;
+	HVmProg p;
+	p.key = key;
+	p.off = (uint32_t)m.code.size();
+	p.n = nwords;
+	p.sum = sum;
+	m.code.insert(m.code.end(), code, code + nwords);
+	m.progs.push_back(p);
+	m.stats.programs = (uint32_t)m.progs.size();
+	return (int)m.progs.size() - 1;
+}
+
+int a2amd_vm_adopt(a2amd_ctx *c, int head, int prog, const a2amd_vm_state *st, const int32_t *wr_unit,
+		const uint8_t *wr_reg, uint32_t now, uint32_t msdur)
+{
+	VmHost &m = c->vm;
+	if(head < 0 || head >= (int)c->units.size() || !c->units[head].live || !st || !wr_unit || !wr_reg)
+		return c->fail(A2AMD_EINVAL, "vm_adopt: bad unit %d", head);
+	if(prog < 0 || prog >= (int)m.progs.size())
+		return c->fail(A2AMD_EINVAL, "vm_adopt: program %d", prog);
+	const int vi = c->units[head].voice;
+	HVoice &v = c->voices[vi];
+	if(v.vm >= 0)
+		return c->fail(A2AMD_ESTATE, "vm_adopt: voice %d is adopted already", vi);
+	if(!c->frag_open || c->uploaded)
+		return c->fail(A2AMD_ESTATE, "vm_adopt outside a fragment");
+	if(!v.live || v.dying || !v.resolved || !v.started || v.inline_pos >= 0 || v.walked != c->serial_base + c->cur_frag)
+		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: voice %d has not been processed in the open fragment (or owns a bus)", vi);
+	if(st->state != A2AMD_VM_WAITING)
+		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: VM state %d (only a voice that waits in a delay is taken)", st->state);
+	if(m.t0_valid && m.msdur != msdur && (m.stats.live || !m.pending.empty()))
+		return c->fail(A2AMD_EINVAL, "vm_adopt: msdur %u, the context's voices run on %u", msdur, m.msdur);
+	const HVmProg &p = m.progs[prog];
+	A2DVmVoice d;
+	memset(&d, 0, sizeof(d));
+	memset(d.cmap, A2D_VM_NOWRITE, sizeof(d.cmap));
+	d.waketime = st->waketime;
+	d.code = p.off;
+	d.ncode = p.n;
+	d.pc = st->pc;
+	d.state = st->state;
+	d.voice = vi;
+	memcpy(d.r, st->r, sizeof(d.r));
+	bool need_f1 = false;
+	for(int k = 0; k < v.nunits; ++k) {
+		const HUnit &u = c->units[v.unit[k]];
+		d.kind[k] = (uint8_t)u.kind;
+		if(u.kind == A2AMD_WTOSC && u.mode == A2D_OSC_NOISE)
+			return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: a noise oscillator draws from the engine's RNG");
+		if(u.xio_mode || u.kind == A2AMD_XINSERT || u.kind == A2AMD_XSINK || u.kind == A2AMD_XSOURCE || u.kind == A2AMD_INLINE)
+			return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: unit kind %d in the chain", u.kind);
+		if(u.kind == A2AMD_FILTER12) {
+			// every filter12 of the chain brings its cutoff ramper along: one that is still ramping
+			// needs a coefficient per window whoever writes it
+			if(d.ncut >= A2D_VM_MAXCUT)
+				return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: more than %d filter12 units", A2D_VM_MAXCUT);
+			d.cutpos[d.ncut] = (uint8_t)k;
+			d.cut[d.ncut][0] = u.cutoff.value;
+			d.cut[d.ncut][1] = u.cutoff.target;
+			d.cut[d.ncut][2] = u.cutoff.delta;
+			d.cut[d.ncut][3] = u.cutoff.timer;
+			++d.ncut;
+			need_f1 = true;
+		}
+	}
+	a2amd_vm_info info;
+	if(analyze(m.code.data() + p.off, p.n, st->pc, st->r[A2AMD_VM_R_TICK], msdur, &info))
+		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: %s (opcode %d at %d)", reason_text(info.reason), info.opcode, info.at);
+	bool any = false;
+	for(int r = 0; r < A2AMD_VM_REGISTERS; ++r) {
+		if(wr_unit[r] == -1)
+			continue;
+		// (a register the VM can never pass to a2_VoiceControl may be wired to anything)
+		if(!(info.controlled & (1ull << r)))
+			continue;
+		int pos = -1;
+		for(int k = 0; k < v.nunits; ++k)
+			if(v.unit[k] == wr_unit[r])
+				pos = k;
+		if(pos < 0 || !write_supported(c->units[v.unit[pos]].kind, wr_reg[r]))
+			return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: %s (VM register %d -> unit %d register %d)",
+					reason_text(A2AMD_VM_TARGET), r, wr_unit[r], (int)wr_reg[r]);
+		d.cmap[r] = (uint8_t)((pos << 4) | wr_reg[r]);
+		need_f1 |= write_needs_f1tab(c->units[v.unit[pos]].kind, wr_reg[r]);
+		any = true;
+	}
+	// (the tracker's 32 bit mask lets register r + 32 ride on r's bit: a program that uses both
+	// halves is rare and its aliasing is reproduced by the interpreter - but the set of registers
+	// that may be written must then cover the twins too, which 'controlled' does not track)
+	if((info.written >> 32) && (uint32_t)info.written & (uint32_t)(info.written >> 32))
+		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: registers r and r + 32 both written (tracker aliasing)");
+	if(!any)
+		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: %s", reason_text(A2AMD_VM_IDLE));
+	if(need_f1)
+		build_f1tab(c);
+	// the context's clock: engine time of walk_time 0
+	{
+		uint64_t before = 0;	// frames of the batch's fragments before the open one
+		for(int f = 0; f < c->cur_frag; ++f)
+			before += c->fragframes[f];
+		const uint32_t t0 = now - (uint32_t)((m.batch_time + before) << 8);
+		if(m.t0_valid && t0 != m.t0 && (m.stats.live || !m.pending.empty()))
+			return c->fail(A2AMD_ESTATE, "vm_adopt: the engine's clock (%u) has left the context's (%u)", t0, m.t0);
+		m.t0 = t0;
+		m.t0_valid = true;
+		m.msdur = msdur;
+	}
+	int slot;
+	if(!m.free_slots.empty()) {
+		slot = m.free_slots.back();
+		m.free_slots.pop_back();
+	} else {
+		slot = (int)m.vms.size();
+		m.vms.push_back(HVm());
+	}
+	HVm &h = m.vms[slot];
+	h = HVm();
+	h.live = true;
+	h.pending = true;
+	h.adopt_frag = c->cur_frag;
+	h.voice = vi;
+	h.prog = prog;
+	h.func = st->func;
+	h.st = d;
+	m.pending.push_back(slot);
+	v.vm = slot;
+	v.plain = 0;
+	++m.stats.live;
+	++m.stats.adopted;
+	return A2AMD_OK;
+}
+
+int a2amd_vm_adopted(a2amd_ctx *c, int head)
+{
+	if(head < 0 || head >= (int)c->units.size() || !c->units[head].live)
+		return 0;
+	return c->voices[c->units[head].voice].vm >= 0;
+}
+
+int a2amd_vm_recall(a2amd_ctx *c, const int32_t *heads, unsigned n, a2amd_vm_state *out)
+{
+	if(!heads || !out)
+		return c->fail(A2AMD_EINVAL, "vm_recall: null argument");
+	if(n > 8)
+		c->vm.snap_fetches = 8;		// (several at once: one copy of all states)
+	for(unsigned k = 0; k < n; ++k) {
+		if(heads[k] < 0 || heads[k] >= (int)c->units.size() || !c->units[heads[k]].live)
+			return c->fail(A2AMD_EINVAL, "vm_recall: bad unit %d", heads[k]);
+		if(int r = vm_take_back(c, c->units[heads[k]].voice, false, &out[k]))
+			return r;
+	}
+	return A2AMD_OK;
+}
+
+int a2amd_vm_trace_host(const uint32_t *code, unsigned nwords, a2amd_vm_state *st, const int32_t *wr_unit,
+		const uint8_t *wr_reg, const int32_t *kinds, int nkinds, uint32_t now, uint32_t msdur, int32_t samplerate,
+		int32_t basepitch, const uint8_t *fragframes, unsigned nfrags, uint32_t *recs, unsigned cap)
+{
+	if(!code || !st || !wr_unit || !wr_reg || !kinds || !fragframes || !recs || nkinds < 1 || nkinds > A2D_MAXCHAIN)
+		return A2AMD_EINVAL;
+	static thread_local uint32_t ptab[128];
+	static thread_local std::vector<int32_t> f1;
+	static thread_local int f1_sr = 0;
+	build_pitch_table(ptab);
+	A2DVmVoice d;
+	memset(&d, 0, sizeof(d));
+	memset(d.cmap, A2D_VM_NOWRITE, sizeof(d.cmap));
+	d.waketime = st->waketime;
+	d.ncode = nwords;
+	d.pc = st->pc;
+	d.state = st->state;
+	memcpy(d.r, st->r, sizeof(d.r));
+	bool need_f1 = false;
+	for(int k = 0; k < nkinds; ++k) {
+		d.kind[k] = (uint8_t)kinds[k];
+		if(kinds[k] == A2AMD_FILTER12 && d.ncut < A2D_VM_MAXCUT) {
+			d.cutpos[d.ncut] = (uint8_t)k;
+			// (f12_Initialize, filter12.c:203: cutoff 0 + transpose, no ramp)
+			d.cut[d.ncut][0] = d.cut[d.ncut][1] = (int)((unsigned)st->r[A2AMD_VM_R_TRANSPOSE] << 8);
+			++d.ncut;
+			need_f1 = true;
+		}
+	}
+	for(int r = 0; r < A2AMD_VM_REGISTERS; ++r)
+		if(wr_unit[r] >= 0 && wr_unit[r] < nkinds) {
+			d.cmap[r] = (uint8_t)((wr_unit[r] << 4) | wr_reg[r]);
+			need_f1 |= write_needs_f1tab(kinds[wr_unit[r]], wr_reg[r]);
+		}
+	Consts K;
+	K.msdur = msdur;
+	K.samplerate = samplerate;
+	K.basepitch = basepitch;
+	K.ptab = ptab;
+	K.f1tab = nullptr;
+	if(need_f1) {
+		if(f1.empty() || f1_sr != samplerate) {
+			f1.resize((size_t)32 * 65536);
+			for(unsigned sh = 0; sh < 32; ++sh)
+				for(unsigned n = 0; n < 65536; ++n) {
+					const int pitch = (int)(((unsigned)(7 - (int)sh) << 16) | n);
+					float f = a2h::p2i(ptab, pitch) * (261.626f / 16777216.0f);
+					f1[(size_t)sh * 65536 + n] = f > (samplerate >> 2) ? 362 << 16 :
+							(int)(512.0f * 65536.0f * sin(M_PI * f / samplerate));
+				}
+			f1_sr = samplerate;
+		}
+		K.f1tab = f1.data();
+	}
+	std::vector<A2DRec> buf((size_t)cap + 8);
+	struct BoundedE {
+		A2DRec *out;
+		int n, cap;
+		void rec(int frag, int op, int unit, int reg, int value, unsigned dur, unsigned start)
+		{
+			if(n < cap) {
+				out[n].head = A2D_HEAD(frag, op, unit, reg);
+				out[n].value = value;
+				out[n].dur = dur;
+				out[n].start = start;
+			}
+			++n;
+		}
+		int count() const { return n; }
+	} e = { buf.data(), 0, (int)cap };
+	run_batch(d, code, K, e, now, 0, (int)nfrags, [fragframes](int f) { return (unsigned)fragframes[f]; });
+	if(d.fault)
+		return A2AMD_ESTATE;
+	st->waketime = d.waketime;
+	st->state = d.state;
+	st->pc = d.pc;
+	memcpy(st->r, d.r, sizeof(st->r));
+	const int n = std::min(e.n, (int)cap);
+	memcpy(recs, buf.data(), (size_t)n * sizeof(A2DRec));
+	return e.n;
+}
+
+int a2amd_vm_get_stats(a2amd_ctx *c, a2amd_vm_stats *out)
+{
+	if(!out)
+		return A2AMD_EINVAL;
+	*out = c->vm.stats;
+	return A2AMD_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,99 @@
+// a2amd_vm.hip - the scripted voice's VM on the device (include/a2amd_vm.h).
+//
+// k_vm: one LANE per adopted voice.  A voice's VM is a serial program over its own 64 registers
+// (a2_VoiceProcessVM, src/core.c:1166-1744) that runs a handful of instructions every few
+// milliseconds: lane = voice is its natural shape (nothing is wave-uniform, everything is
+// independent), and what the kernel moves is small - the voice's state (A2DVmVoice, 0.4 KB) in and
+// out once per batch, the program text from the cache.  Two passes per batch over the same
+// interpreter (a2amd_vmcore.h, the source the host's copy is compiled from):
+//
+//   count   runs every voice through the batch on a private copy of its state, counts the records
+//           it would emit, and gives each voice a place in the batch's record array: an exclusive
+//           prefix sum over the wavefront and one atomic add per wavefront on the running total
+//   emit    (after the host has made sure the total fits) runs them again and writes the records -
+//           R_WRITE / R_F1SET / R_F1RAMP / R_SEG exactly as the host's recorder makes them of the
+//           engine's calls - stores the advanced state, and points runs[voice] at the records: the
+//           leaf kernels launched next execute them like host records.
+//
+// HBM traffic per voice and batch: 2 x 0.4 KB state + 16 B per record, against 504-808 B per
+// voice and FRAGMENT of the leaf kernels: the VM is noise next to the rendering it controls.
+#include <hip/hip_runtime.h>
+#include "a2amd_device.h"
+#include "a2amd_vmcore.h"
+
+using namespace a2vm;
+
+#define VM_TPB 64		// one wavefront per workgroup: voices diverge, a short block retires early
+
+__global__ __launch_bounds__(VM_TPB)
+void k_vm_count(A2DVmParams vp)
+{
+	const int i = (int)(blockIdx.x * VM_TPB + threadIdx.x), lane = (int)(threadIdx.x & 63);
+	int n = 0, fault = 0;
+	if(i < vp.n) {
+		A2DVmVoice v = vp.vmv[vp.list[i]];
+		const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab };
+		CountE e = { 0 };
+		const uint8_t *ff = vp.fragframes;
+		run_batch(v, vp.code + v.code, K, e, vp.now, 0, vp.nfrags, [ff](int f) { return (unsigned)ff[f]; });
+		n = e.n;
+		fault = v.fault != 0;
+	}
+	// exclusive prefix over the wavefront (DPP-free: six shuffle steps once per launch)
+	int incl = n;
+#pragma unroll
+	for(int d = 1; d < 64; d <<= 1) {
+		const int t = __shfl_up(incl, d, 64);
+		if(lane >= d)
+			incl += t;
+	}
+	const int wave_total = __shfl(incl, 63, 64);
+	unsigned base = 0;
+	if(lane == 63 && wave_total)
+		base = atomicAdd(vp.total, (unsigned)wave_total);
+	base = (unsigned)__shfl((int)base, 63, 64);
+	if(i < vp.n) {
+		A2DRun r = { (int)(base + (unsigned)(incl - n)), n };
+		vp.vmrun[i] = r;
+	}
+	const unsigned long long fb = __ballot(fault);
+	if(lane == 0 && fb)
+		atomicAdd(vp.total + 1, (unsigned)__popcll(fb));
+}
+
+__global__ __launch_bounds__(VM_TPB)
+void k_vm_emit(A2DVmParams vp)
+{
+	const int i = (int)(blockIdx.x * VM_TPB + threadIdx.x);
+	if(i >= vp.n)
+		return;
+	const int slot = vp.list[i];
+	A2DVmVoice v = vp.vmv[slot];
+	const A2DRun place = vp.vmrun[i];
+	const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab };
+	A2DRun run = { 0, 0 };
+	if((unsigned)place.first + (unsigned)place.count <= vp.rec_cap) {
+		StoreE e = { vp.recs + vp.rec_base + place.first, 0 };
+		const uint8_t *ff = vp.fragframes;
+		run_batch(v, vp.code + v.code, K, e, vp.now, 0, vp.nfrags, [ff](int f) { return (unsigned)ff[f]; });
+		if(e.n) {
+			run.first = (int)(vp.rec_base + (unsigned)place.first);
+			run.count = e.n;
+		}
+		vp.vmv[slot] = v;
+	}
+	// (no room - the host checked: never - leaves the voice where it was, silent on the VM's side)
+	vp.runs[v.voice] = run;
+}
+
+int a2d_launch_vm(const A2DVmParams &vp, int emit, void *stream)
+{
+	if(vp.n <= 0)
+		return 0;
+	const int nblocks = (vp.n + VM_TPB - 1) / VM_TPB;
+	if(emit)
+		hipLaunchKernelGGL(k_vm_emit, dim3(nblocks), dim3(VM_TPB), 0, (hipStream_t)stream, vp);
+	else
+		hipLaunchKernelGGL(k_vm_count, dim3(nblocks), dim3(VM_TPB), 0, (hipStream_t)stream, vp);
+	return (int)hipGetLastError();
+}

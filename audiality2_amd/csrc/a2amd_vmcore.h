@@ -1,0 +1,484 @@
+// a2amd_vmcore.h - the interpreter of the scripted voice's VM, ONE source for the
+// HIP kernel (a2amd_vm.hip: one lane per voice) and for the host (a2amd_vm.cpp: catching a voice
+// up when the engine wants it back, the parity tests' a2amd_vm_trace_host).
+//
+// What it restates, for the instruction subset of include/a2amd_vm.h:
+//   a2_VoiceProcessVM      src/core.c:1166-1744   run()
+//   a2_VoiceControl        src/core.c:143-149     control()  (+ what the drop-in's write callbacks add:
+//                                                 a2amd_unit_write, a2amd_host.cpp)
+//   A2_regtracker          src/core.c:1064-1116   Tracker
+//   a2_ms2t / a2_ticks2t   src/core.c:1120-1131
+//   a2_VoiceProcessVMEv    src/core.c:1784-1839   (the "VM only" loop: an adopted voice has no events)
+//   a2_VoiceProcess        src/core.c:1847-1880   run_batch(): VM runs alternate with unit windows
+// and what it emits are the command records the host's recorder makes of the same calls
+// (a2amd_unit_write / a2amd_unit_process, a2amd_host.cpp): R_WRITE, R_F1SET, R_F1RAMP, R_SEG.
+// Arithmetic is the engine's on x86-64 / gcc: wrap-around ints, arithmetic >>, shift counts mod 32.
+#pragma once
+#include <stdint.h>
+#include "a2amd_device.h"
+#include "../../include/a2amd_vm.h"
+
+#if defined(__HIPCC__)
+#define VMFN __host__ __device__ inline
+#else
+#define VMFN inline
+#endif
+
+namespace a2vm {
+
+struct Consts {
+	uint32_t msdur;
+	int32_t samplerate, basepitch;
+	const uint32_t *ptab;		// 64 x {base, coeff}, pitch.c:70-96
+	const int32_t *f1tab;		// [32][65536] or null
+};
+
+enum { TRAP_NONE = 0, TRAP_OVERLOAD, TRAP_OPCODE, TRAP_DIVISOR, TRAP_PC };
+
+VMFN int vadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+VMFN int vsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+VMFN int vmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+
+// a2_ms2t, core.c:1128-1131
+VMFN unsigned ms2t(uint32_t msdur, int d)
+{
+	return (unsigned)(((int64_t)d * (int64_t)msdur + 0x7fffff) >> 24);
+}
+
+// a2_ticks2t, core.c:1120-1124 (the products are unsigned 64 bit there)
+VMFN unsigned ticks2t(uint32_t msdur, int tick, int d)
+{
+	const uint64_t t = ((uint64_t)(int64_t)d * (uint64_t)(int64_t)tick + 127) >> 8;
+	return (unsigned)((t * (uint64_t)msdur + 0x7fffffffu) >> 32);
+}
+
+// a2_P2I, pitch.c:57-67
+VMFN unsigned p2i(const uint32_t *tab, int pitch)
+{
+	const int n = pitch & 0xffff, oct = pitch >> 16;
+	unsigned dph = tab[2 * (n >> 10) + 1] * (unsigned)(n & 0x3ff);
+	dph >>= 2;
+	dph += tab[2 * (n >> 10)];
+	return dph >> ((unsigned)(7 - oct) & 31u);
+}
+
+// f12_pitch2coeff (filter12.c:65-72) / dcb_pitch2coeff (dcblock.c:57-64) of a 16:16 pitch, from the
+// table the host made with the reference's own float / libm expression for every value a2_P2I can
+// return: indexed by the shift count and the 16 fraction bits a2_P2I derives its result from
+VMFN int f1_of_pitch(const Consts &K, int pitch)
+{
+	const unsigned n = (unsigned)pitch & 0xffffu, sh = (unsigned)(7 - (pitch >> 16)) & 31u;
+	return K.f1tab[(size_t)sh * 65536u + n];
+}
+
+// a2_InitRamper ... a2_SetRamper, a2_dsp.h:121-170, on four words {value, target, delta, timer}
+VMFN void rp_prepare(int32_t *r, int frames)
+{
+	if(!r[3]) {
+		r[0] = r[1];
+		r[2] = 0;
+	} else if(frames <= (r[3] >> 8)) {
+		r[2] = (int)((((int64_t)vsub(r[1], r[0])) * 256) / r[3]);
+		r[3] = vsub(r[3], frames << 8);
+	} else {
+		r[2] = vsub(r[1], r[0]) / frames;
+		r[3] = 0;
+	}
+}
+VMFN void rp_run(int32_t *r, int frames) { r[0] = vadd(r[0], vmul(r[2], frames)); }
+VMFN void rp_set(int32_t *r, int target, int start, int duration)
+{
+	r[1] = (int)((unsigned)target << 8);
+	r[3] = vadd(duration, start);
+	if(r[3] < 256)
+		r[0] = r[1];
+	else
+		r[0] = vadd(r[0], vmul(r[2], start) >> 8);
+}
+
+// A2_regtracker, core.c:1064-1099.  (The mask is 32 bits wide and the engine shifts a 1 by the
+// register number: on its x86 targets registers r and r + 32 share a bit.  Kept.)
+struct Tracker {
+	uint32_t mask, position;
+	uint8_t regs[A2AMD_VM_REGISTERS];
+};
+VMFN void rt_mark(Tracker &rt, unsigned r)
+{
+	const uint32_t b = 1u << (r & 31u);
+	if(b & rt.mask)
+		return;
+	rt.mask |= b;
+	rt.regs[rt.position++ & 63u] = (uint8_t)r;
+}
+VMFN void rt_unmark(Tracker &rt, unsigned r)
+{
+	const uint32_t b = 1u << (r & 31u);
+	if(b & rt.mask) {
+		rt.mask &= ~b;
+		for(uint32_t i = 0; i < rt.position; ++i)
+			if(rt.regs[i] == r) {
+				rt.regs[i] = rt.regs[--rt.position];
+				break;
+			}
+	}
+}
+
+// Can the device VM make this register write?  (kind = a2amd_unitkind, reg = the unit's register
+// index.)  Not: wtosc 'w' (a wave handle: the host resolves and uploads waves, and the voice's
+// launch class hangs on it), fbdelay's tap lengths (launch class), anything without registers.
+VMFN bool write_supported(int kind, int reg)
+{
+	switch(kind) {
+	  case A2D_WTOSC:      return reg >= 1 && reg <= 3;
+	  case A2D_PANMIX:     return reg >= 0 && reg <= 1;
+	  case A2D_FILTER12:   return reg >= 0 && reg <= 4;
+	  case A2D_FBDELAY:    return reg >= 3 && reg <= 6;
+	  case A2D_DC:         return reg >= 0 && reg <= 1;
+	  case A2D_WAVESHAPER: return reg == 0;
+	  case A2D_DCBLOCK:    return reg == 0;
+	  case A2D_LIMITER:    return reg >= 0 && reg <= 1;
+	  default:
+		if(A2D_IS_FM(kind)) {
+			const int nops = kind == A2D_FM1 ? 1 : (kind == A2D_FM2 || kind == A2D_FM2R) ? 2 :
+					(kind == A2D_FM3 || kind == A2D_FM3P) ? 3 : 4;
+			return reg >= 0 && reg <= 3 * nops;
+		}
+		return false;
+	}
+}
+VMFN bool write_needs_f1tab(int kind, int reg)
+{
+	return (kind == A2D_FILTER12 || kind == A2D_DCBLOCK) && reg == 0;
+}
+
+// a2_VoiceControl (core.c:143-149) -> the unit's write callback -> the record a2amd_unit_write
+// (a2amd_host.cpp) makes of it.  E: rec(frag, op, unit, reg, value, dur, start).
+template<class E>
+VMFN void control(A2DVmVoice &v, const Consts &K, E &e, int frag, unsigned reg, unsigned start, unsigned dur)
+{
+	const unsigned m = v.cmap[reg & 63u];
+	if(m == A2D_VM_NOWRITE)
+		return;
+	const int pos = (int)(m >> 4), ureg = (int)(m & 15u), kind = v.kind[pos & 7];
+	int value = v.r[reg & 63u];
+	const int transpose = v.r[A2AMD_VM_R_TRANSPOSE];
+	start &= 255u;
+	switch(kind) {
+	  case A2D_WTOSC:
+		if(ureg == 1)		// wtosc_Pitch, wtosc.c:486-492
+			value = vadd(vadd(value, transpose), K.basepitch);
+		break;
+	  case A2D_FILTER12:
+		if(ureg == 0) {		// f12_CutOff, filter12.c:141-147: the ramper lives here
+			for(int k = 0; k < (int)v.ncut && k < A2D_VM_MAXCUT; ++k)
+				if(v.cutpos[k] == pos) {
+					rp_set(v.cut[k], vadd(value, transpose), (int)start, (int)dur);
+					if(dur < 256)
+						e.rec(frag, R_F1SET, pos, 0, f1_of_pitch(K, v.cut[k][0] >> 8), 0, 0);
+				}
+			return;
+		}
+		if(ureg == 1)		// f12_Q, filter12.c:149-162
+			value = value < 512 ? 32768 : (65536 << 8) / value;
+		break;
+	  case A2D_DCBLOCK:		// dcb_CutOff, dcblock.c:112-117
+		value = f1_of_pitch(K, vadd(value, transpose));
+		break;
+	  case A2D_LIMITER:		// limiter_Release / limiter_Threshold, limiter.c:201-213
+		if(ureg == 0)
+			value = (int)((unsigned)value << 8) / K.samplerate;
+		else {
+			const unsigned t = (unsigned)value << 8;
+			value = (int)(t < 256u ? 256u : t);
+		}
+		break;
+	  default:
+		if(A2D_IS_FM(kind) && ureg == 1)	// fm_Pitch, fm.c:403-483: operator 0 is the absolute one
+			value = vadd(vadd(value, transpose), K.basepitch);
+		break;
+	}
+	e.rec(frag, R_WRITE, pos, ureg, value, dur, start);
+}
+
+template<class E>
+VMFN void rt_apply(const Tracker &rt, A2DVmVoice &v, const Consts &K, E &e, int frag, unsigned start, unsigned dur)
+{
+	for(uint32_t i = 0; i < rt.position; ++i)
+		control(v, K, e, frag, rt.regs[i], start, dur);
+}
+
+// a2_VoiceProcessVM, core.c:1166-1744: instructions until a timing instruction with dt > 0.
+// Returns TRAP_NONE when the VM has rescheduled itself, a TRAP_* where the engine's would have
+// aborted (which a2amd_vm_analyze() has ruled out for every adopted voice).
+template<class E>
+VMFN int run(A2DVmVoice &v, const uint32_t *code, const Consts &K, E &e, int frag)
+{
+	int32_t *r = v.r;
+	unsigned inscount = A2AMD_VM_INSLIMIT;
+	Tracker rt;
+	rt.mask = rt.position = 0;
+	if(v.state == A2AMD_VM_WAITING)
+		v.state = A2AMD_VM_RUNNING;
+	for(;;) {
+		if(v.pc >= v.ncode)
+			return TRAP_PC;
+		const uint32_t w = code[v.pc];
+		const unsigned op = A2AMD_VM_OPCODE(w), a1 = A2AMD_VM_A1(w) & 63u, a2 = A2AMD_VM_A2(w);
+		// (two-word instructions keep a3 in the next word; read where it exists)
+		const int32_t a3 = (v.pc + 1u < v.ncode) ? (int32_t)code[v.pc + 1] : 0;
+		unsigned dt = 0;
+		bool timing = false;
+		if(!--inscount)
+			return TRAP_OVERLOAD;
+		switch(op) {
+		  // local flow control, core.c:1282-1320
+		  case A2AMD_OP_JUMP:
+			v.pc = (uint16_t)a2;
+			continue;
+		  case A2AMD_OP_LOOP:
+			r[a1] = vsub(r[a1], 65536);
+			if(r[a1] <= 0)
+				break;
+			v.pc = (uint16_t)a2;
+			continue;
+		  case A2AMD_OP_JZ:
+			if(r[a1])
+				break;
+			v.pc = (uint16_t)a2;
+			continue;
+		  case A2AMD_OP_JNZ:
+			if(!r[a1])
+				break;
+			v.pc = (uint16_t)a2;
+			continue;
+		  case A2AMD_OP_JG:
+			if(r[a1] <= 0)
+				break;
+			v.pc = (uint16_t)a2;
+			continue;
+		  case A2AMD_OP_JL:
+			if(r[a1] >= 0)
+				break;
+			v.pc = (uint16_t)a2;
+			continue;
+		  case A2AMD_OP_JGE:
+			if(r[a1] < 0)
+				break;
+			v.pc = (uint16_t)a2;
+			continue;
+		  case A2AMD_OP_JLE:
+			if(r[a1] > 0)
+				break;
+			v.pc = (uint16_t)a2;
+			continue;
+
+		  // timing, core.c:1323-1336
+		  case A2AMD_OP_DELAY:
+			dt = ms2t(K.msdur, a3);
+			++v.pc;
+			timing = true;
+			break;
+		  case A2AMD_OP_DELAYR:
+			dt = ms2t(K.msdur, r[a1]);
+			timing = true;
+			break;
+		  case A2AMD_OP_TDELAY:
+			dt = ticks2t(K.msdur, r[A2AMD_VM_R_TICK], a3);
+			++v.pc;
+			timing = true;
+			break;
+		  case A2AMD_OP_TDELAYR:
+			dt = ticks2t(K.msdur, r[A2AMD_VM_R_TICK], r[a1]);
+			timing = true;
+			break;
+
+		  // arithmetics, core.c:1339-1411
+		  case A2AMD_OP_SUBR:
+			r[a1] = vsub(r[a1], r[a2 & 63u]);
+			rt_mark(rt, a1);
+			break;
+		  case A2AMD_OP_P2DR: {
+			// A2_1K_DIV_MIDDLEC / a2_P2I(...), a2_pitch.h:42 (a zero increment divides by zero
+			// in the engine; there is nothing to match)
+			const unsigned d = p2i(K.ptab, r[a2 & 63u]);
+			r[a1] = d ? (int)(4202608409623LL / (int64_t)d) : 0;
+			rt_mark(rt, a1);
+			break;
+		  }
+		  case A2AMD_OP_NEGR:
+			r[a1] = vsub(0, r[a2 & 63u]);
+			rt_mark(rt, a1);
+			break;
+		  case A2AMD_OP_LOAD:
+			r[a1] = a3;
+			rt_mark(rt, a1);
+			++v.pc;
+			break;
+		  case A2AMD_OP_LOADR:
+			r[a1] = r[a2 & 63u];
+			rt_mark(rt, a1);
+			break;
+		  case A2AMD_OP_ADD:
+			r[a1] = vadd(r[a1], a3);
+			rt_mark(rt, a1);
+			++v.pc;
+			break;
+		  case A2AMD_OP_ADDR:
+			r[a1] = vadd(r[a1], r[a2 & 63u]);
+			rt_mark(rt, a1);
+			break;
+		  case A2AMD_OP_MUL:
+			r[a1] = (int)(((int64_t)r[a1] * (int64_t)a3) >> 16);
+			rt_mark(rt, a1);
+			++v.pc;
+			break;
+		  case A2AMD_OP_MULR:
+			r[a1] = (int)(((int64_t)r[a1] * (int64_t)r[a2 & 63u]) >> 16);
+			rt_mark(rt, a1);
+			break;
+		  case A2AMD_OP_MOD:
+			if(a3 == 0 || a3 == -1)
+				return TRAP_DIVISOR;
+			r[a1] %= a3;
+			rt_mark(rt, a1);
+			++v.pc;
+			break;
+		  case A2AMD_OP_QUANT:
+			if(a3 == 0 || a3 == -1)
+				return TRAP_DIVISOR;
+			r[a1] = vmul(r[a1] / a3, a3);
+			rt_mark(rt, a1);
+			++v.pc;
+			break;
+
+		  // comparison and boolean operators, core.c:1413-1456
+		  case A2AMD_OP_GR:  r[a1] = (r[a1] > r[a2 & 63u]) << 16;  rt_mark(rt, a1); break;
+		  case A2AMD_OP_LR:  r[a1] = (r[a1] < r[a2 & 63u]) << 16;  rt_mark(rt, a1); break;
+		  case A2AMD_OP_GER: r[a1] = (r[a1] >= r[a2 & 63u]) << 16; rt_mark(rt, a1); break;
+		  case A2AMD_OP_LER: r[a1] = (r[a1] <= r[a2 & 63u]) << 16; rt_mark(rt, a1); break;
+		  case A2AMD_OP_EQR: r[a1] = (r[a1] == r[a2 & 63u]) << 16; rt_mark(rt, a1); break;
+		  case A2AMD_OP_NER: r[a1] = (r[a1] != r[a2 & 63u]) << 16; rt_mark(rt, a1); break;
+		  case A2AMD_OP_ANDR: r[a1] = (r[a1] && r[a2 & 63u]) << 16; rt_mark(rt, a1); break;
+		  case A2AMD_OP_ORR:  r[a1] = (r[a1] || r[a2 & 63u]) << 16; rt_mark(rt, a1); break;
+		  case A2AMD_OP_XORR: r[a1] = (!r[a1] != !r[a2 & 63u]) << 16; rt_mark(rt, a1); break;
+		  case A2AMD_OP_NOTR: r[a1] = (!r[a2 & 63u]) << 16; rt_mark(rt, a1); break;
+
+		  // unit control, core.c:1459-1489
+		  case A2AMD_OP_SET:
+			control(v, K, e, frag, a1, v.waketime, 0);
+			rt_unmark(rt, a1);
+			break;
+		  case A2AMD_OP_SETALL:		// a2_RTSetAll, core.c:1109-1116
+			rt_apply(rt, v, K, e, frag, v.waketime, 0);
+			rt.mask = rt.position = 0;
+			break;
+		  case A2AMD_OP_RAMP:
+			control(v, K, e, frag, a1, v.waketime, ms2t(K.msdur, a3));
+			rt_unmark(rt, a1);
+			++v.pc;
+			break;
+		  case A2AMD_OP_RAMPR:
+			control(v, K, e, frag, a1, v.waketime, ms2t(K.msdur, r[a2 & 63u]));
+			rt_unmark(rt, a1);
+			break;
+		  case A2AMD_OP_RAMPALL:
+			rt_apply(rt, v, K, e, frag, v.waketime, ms2t(K.msdur, a3));
+			rt.mask = rt.position = 0;
+			++v.pc;
+			break;
+		  case A2AMD_OP_RAMPALLR:
+			rt_apply(rt, v, K, e, frag, v.waketime, ms2t(K.msdur, r[a1]));
+			rt.mask = rt.position = 0;
+			break;
+
+		  default:
+			return TRAP_OPCODE;
+		}
+		++v.pc;
+		if(!timing)
+			continue;
+		// "timing:", core.c:1719-1733
+		rt_apply(rt, v, K, e, frag, v.waketime, dt);
+		if(!dt)
+			continue;
+		v.state = A2AMD_VM_WAITING;
+		v.waketime += dt;
+		return TRAP_NONE;
+	}
+}
+
+// a2_VoiceProcess (core.c:1847-1880) over fragments [f0, f1) of a batch whose fragment f0 starts at
+// engine time 'now': at every window start the VM runs while it is due within that frame
+// (a2_VoiceProcessVMEv's "VM only" loop, core.c:1822-1838), then the units get their window - of
+// which the recorder keeps: a cutoff ramp's coefficient for the window (the head of f12_process,
+// filter12.c:86-96, as a2amd_unit_process makes it), and the window itself unless it is the
+// fragment's only event (the default window, a2amd_unit_process).  FF: frames of fragment f.
+// Returns the engine time at the end of fragment f1 - 1; v.fault is set where a trap stopped the VM.
+template<class E, class FF>
+VMFN uint32_t run_batch(A2DVmVoice &v, const uint32_t *code, const Consts &K, E &e, uint32_t now, int f0, int f1, FF frames_of)
+{
+	uint32_t fs = now;
+	for(int f = f0; f < f1; ++f) {
+		const int frames = (int)frames_of(f);
+		const int before = e.count();
+		int s = 0;
+		while(s < frames) {
+			const uint32_t t = fs + ((uint32_t)s << 8);
+			int res;
+			for(;;) {
+				const int nextvm = (int)(v.waketime - t);	// a2_TSDiff
+				if(nextvm > 255) {
+					res = nextvm >> 8;
+					break;
+				}
+				if(v.fault) {		// (stopped for good)
+					res = frames;
+					break;
+				}
+				const int trap = run(v, code, K, e, f);
+				if(trap) {
+					v.fault = trap;
+					res = frames;
+					break;
+				}
+			}
+			if(res > frames - s)
+				res = frames - s;
+			for(int k = 0; k < (int)v.ncut && k < A2D_VM_MAXCUT; ++k) {
+				rp_prepare(v.cut[k], res);
+				if(v.cut[k][2]) {
+					rp_run(v.cut[k], res);
+					e.rec(f, R_F1RAMP, v.cutpos[k], 0, f1_of_pitch(K, v.cut[k][0] >> 8), 0, 0);
+				}
+			}
+			if(!(s == 0 && res == frames && e.count() == before))
+				e.rec(f, R_SEG, 0, 0, 0, (unsigned)s | ((unsigned)res << 16), 0);
+			s += res;
+		}
+		fs += (uint32_t)frames << 8;
+	}
+	return fs;
+}
+
+struct CountE {
+	int n;
+	VMFN void rec(int, int, int, int, int, unsigned, unsigned) { ++n; }
+	VMFN int count() const { return n; }
+};
+
+struct StoreE {
+	A2DRec *out;
+	int n;
+	VMFN void rec(int frag, int op, int unit, int reg, int value, unsigned dur, unsigned start)
+	{
+		A2DRec r;
+		r.head = A2D_HEAD(frag, op, unit, reg);
+		r.value = value;
+		r.dur = dur;
+		r.start = start;
+		out[n++] = r;
+	}
+	VMFN int count() const { return n; }
+};
+
+} // namespace a2vm

@@ -42,12 +42,30 @@
 #include <string.h>
 #include "internals.h"			/* the engine's: A2_state, A2_voice (src/internals.h:559-586, :600-700) */
 #include "../../include/a2amd_walk.h"	/* a2amd_walkview */
+#include "../../include/a2amd_vm.h"	/* the opcode numbers the device VM is built with */
 
 #define AHEAD		40		/* positions the prefetch runs ahead (a DRAM access at ~3 ns per position) */
 #define STAMP_NOUNITS	0xffffffffu	/* a voice without units and without subvoices: nothing to do while it sleeps */
 #define E_NOEVENTS	1u		/* ENT.flags: its event queue was empty when it was last looked at */
 #define E_APIHANDLE	2u		/* ... it has an API handle: the application can send it events at any time */
 #define E_GROUP		4u		/* ... it has subvoices: it sleeps unseen only if their whole list does (ENT.sub) */
+#define E_VM		8u		/* ... its program runs on the device (a2amd_units_vm_adopt): asleep whatever its
+					 * (stale) wake time says, and handed to the engine only after a2amd_units_vm_recall */
+
+/* the device VM interprets the engine's bytecode: the numbers it was built with are the engine's */
+#define A2V(x) _Static_assert((int)OP_##x == (int)A2AMD_OP_##x, "opcode " #x);
+A2AMD_VM_ALLOPS
+#undef A2V
+_Static_assert((int)A2_OPCODES == (int)A2AMD_VM_OPCODES, "number of opcodes");
+_Static_assert(A2_REGISTERS == A2AMD_VM_REGISTERS && A2_INSLIMIT == A2AMD_VM_INSLIMIT, "VM limits");
+_Static_assert(R_TICK == A2AMD_VM_R_TICK && R_TRANSPOSE == A2AMD_VM_R_TRANSPOSE, "fixed registers");
+_Static_assert((int)A2_RUNNING == (int)A2AMD_VM_RUNNING && (int)A2_WAITING == (int)A2AMD_VM_WAITING &&
+		(int)A2_INTERRUPT == (int)A2AMD_VM_INTERRUPT && (int)A2_ENDING == (int)A2AMD_VM_ENDING &&
+		(int)A2_FINALIZING == (int)A2AMD_VM_FINALIZING, "VM states");
+_Static_assert(sizeof(A2_vmstate) == sizeof(a2amd_vm_state) && offsetof(A2_vmstate, r) == offsetof(a2amd_vm_state, r) &&
+		offsetof(A2_vmstate, pc) == offsetof(a2amd_vm_state, pc) && offsetof(A2_vmstate, state) == offsetof(a2amd_vm_state, state),
+		"A2_vmstate");
+_Static_assert(sizeof(A2_instruction) == 8, "A2_instruction");
 
 typedef struct ENT
 {
@@ -80,6 +98,7 @@ typedef struct LIST
 	int		sum_ok;
 	unsigned long long sum_epoch;
 	uint32_t	sum_wake;	/* the earliest wake time in the list - and in the lists below it */
+	int		sum_timed;	/* ... if any voice there has one (voices the device VM runs do not) */
 	unsigned	*gidx, ng;	/* the entries with subvoices (E_GROUP), as of the summary */
 	unsigned long long sum_voices;	/* voices in the list and below */
 	unsigned long long held_gen;	/* == WSTATE.hold_gen: the list's voices are held (a2amd_units_hold) */
@@ -104,6 +123,10 @@ typedef struct WSTATE
 	unsigned	scratch_cap;
 	unsigned long long last_use;	/* (the table of states is finite: the longest unused one makes room) */
 	unsigned long long skipped, unread, visited;
+	/* (code, pc) pairs the device VM has turned down for good: not offered again */
+	struct { const unsigned *code; unsigned pc; } vm_no[64];
+	unsigned	vm_no_pos;
+	unsigned long long adopted, recalled;
 } WSTATE;
 
 static void (*engine_walk)(A2_state *st, A2_voice **head, unsigned offset, unsigned frames);
@@ -112,7 +135,7 @@ static void (*engine_voicefree)(A2_state *st, A2_voice **head);
 static WSTATE *wstates[256];
 static pthread_mutex_t wmtx = PTHREAD_MUTEX_INITIALIZER;
 static __thread WSTATE *last_ws;
-static int walk_off = -1, walk_stats, walk_cut, walk_nocache, walk_nohold;
+static int walk_off = -1, walk_stats, walk_cut, walk_nocache, walk_nohold, walk_novm;
 
 static WSTATE *wstate_of(A2_state *st)
 {
@@ -245,6 +268,8 @@ static void bind_engine(void)
 	 * does not serve (the engine's own CPU units): exercises the cut / relink / voice death
 	 * logic without a GPU; no visit is ever skipped there */
 	walk_cut = getenv("A2AMD_WALK_CUT") != NULL;
+	/* A/B: no voice is offered to the device VM */
+	walk_novm = getenv("A2AMD_NO_VM") != NULL;
 	if((walk_stats = getenv("A2AMD_WALK_STATS") != NULL))
 		atexit(report);
 }
@@ -323,7 +348,7 @@ static int list_sleeps(const WSTATE *w, const LIST *sl, unsigned now, unsigned f
 	const a2amd_walkview *vw = &w->view;
 	unsigned g;
 	if(!sl || !sl->n || !sl->sum_ok || sl->sum_epoch != w->epoch || sl->epoch != w->epoch ||
-			(a2_TSDiff(sl->sum_wake, now) >> 8) < (int)frames ||
+			(sl->sum_timed && (a2_TSDiff(sl->sum_wake, now) >> 8) < (int)frames) ||
 			(sl->sum_cnt && sl->sum_lo + sl->sum_cnt > vw->map_cap[sl->sum_dev]))
 		return 0;
 	for(g = 0; g < sl->ng; ++g)
@@ -346,7 +371,7 @@ static inline int entry_sleeps(const WSTATE *w, const ENT *e, unsigned wake, int
 {
 	const a2amd_walkview *vw = &w->view;
 	unsigned dev, slot;
-	if(!e->stamp || !noevents || (a2_TSDiff(wake, now) >> 8) < (int)frames)
+	if(!e->stamp || !noevents || (!(e->flags & E_VM) && (a2_TSDiff(wake, now) >> 8) < (int)frames))
 		return 0;
 	if(e->stamp != STAMP_NOUNITS)
 	{
@@ -494,6 +519,80 @@ static inline void mark_entry(WSTATE *w, const ENT *e)
 	}
 }
 
+
+/* ---- voices whose VM runs on the device (include/a2amd_vm.h) ------------------------
+ * The engine is about to process the 'run' voices from 'v' on (linked by ->next): those the device
+ * VM runs get their A2_vmstate back first - what the engine's own VM would have left there by the
+ * start of this fragment (a2amd_units_vm_recall) - and are the engine's again. */
+static void recall_run(WSTATE *w, LIST *l, unsigned k, A2_voice *v, unsigned run)
+{
+	const void *heads[64];
+	void *states[64];
+	unsigned n = 0, kk;
+	A2_voice *p;
+	if(!w->served || !*w->view.vm_live)
+		return;
+	for(p = v, kk = 0; kk < run && p; p = p->next, ++kk)
+	{
+		int is_vm;
+		if(k + kk < l->n && l->e[k + kk].v == p)
+			is_vm = (l->e[k + kk].flags & E_VM) != 0;
+		else
+			is_vm = p->units && a2amd_units_vm_is(p->units);	/* (a list that is not the one remembered) */
+		if(!is_vm)
+			continue;
+		if(k + kk < l->n && l->e[k + kk].v == p)
+			l->e[k + kk].flags &= ~E_VM;
+		heads[n] = p->units;
+		states[n++] = &p->s;
+		if(n == 64)
+		{
+			a2amd_units_vm_recall(heads, n, states);
+			w->recalled += n;
+			n = 0;
+		}
+	}
+	if(n)
+	{
+		a2amd_units_vm_recall(heads, n, states);
+		w->recalled += n;
+	}
+}
+
+/* The engine has just processed 'p' in the open root window: can the device run its program from
+ * here on?  A leaf voice waiting in a delay, no events, no call stack, nobody outside the tree who
+ * could send it anything (no API handle) - and a program that a2amd_vm_analyze() can prove to stay
+ * inside the subset from p->s.pc on.  Returns 1 when the voice was handed over. */
+static int offer_to_vm(WSTATE *w, A2_state *st, A2_voice *p)
+{
+	void *wr_unit[A2_REGISTERS], *wr_fn[A2_REGISTERS];
+	const A2_function *fn;
+	unsigned r;
+	int rc;
+	if(walk_novm || !w->served || p->sub || p->events || p->stack || (p->flags & A2_APIHANDLE) || !p->units ||
+			!p->program || p->s.state != A2_WAITING)
+		return 0;
+	fn = &p->program->funcs[p->s.func];
+	for(r = 0; r < 64; ++r)
+		if(w->vm_no[r].code == fn->code && w->vm_no[r].pc == p->s.pc)
+			return 0;
+	for(r = 0; r < A2_REGISTERS; ++r)
+	{
+		wr_unit[r] = r < p->ncregs ? (void *)p->cregs[r].unit : NULL;
+		wr_fn[r] = r < p->ncregs ? (void *)p->cregs[r].write : NULL;
+	}
+	rc = a2amd_units_vm_adopt(p->units, fn->code, fn->size, &p->s, wr_unit, wr_fn,
+			st->now_fragstart + (*w->view.base << 8), st->msdur);
+	if(rc == -1)
+	{
+		w->vm_no[w->vm_no_pos & 63].code = fn->code;
+		w->vm_no[w->vm_no_pos++ & 63].pc = p->s.pc;
+	}
+	if(!rc)
+		++w->adopted;
+	return !rc;
+}
+
 /* The replacement.  Same contract as the engine's (internals.h:968-973). */
 void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned frames)
 {
@@ -604,6 +703,7 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 				if(sl)
 					sl->quiet_visit = w->visits + 1;
 			}
+		recall_run(w, l, k, v, run);
 		rest = last->next;
 		last->next = NULL;
 		epoch0 = w->epoch;
@@ -655,7 +755,14 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 				else if(!p->units)
 					e->stamp = STAMP_NOUNITS;
 				else
+				{
+					/* (a voice whose program the device can run from here on is handed over now)
+					 * (only from the root window itself: a voice processed window by window - its
+					 * parent woke in mid-fragment - would be wanted back for the next one) */
+					if(deflt && offer_to_vm(w, st, p))
+						e->flags |= E_VM;
 					e->stamp = w->served ? a2amd_units_standing(p->units, &e->slotdev) : 0;
+				}
 			}
 			else
 				cached = 0;
@@ -682,14 +789,19 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 			l->gidx = gi;
 		}
 		l->ng = 0;
+		l->sum_timed = 0;
 		for(k = 0; k < l->n; ++k)
 		{
 			const ENT *e = &l->e[k];
 			int d = a2_TSDiff(e->wake, now);
-			if(d < best)
+			if(!(e->flags & E_VM))		/* (a voice the device VM runs never wakes here) */
 			{
-				best = d;
-				l->sum_wake = e->wake;
+				l->sum_timed = 1;
+				if(d < best)
+				{
+					best = d;
+					l->sum_wake = e->wake;
+				}
 			}
 			if(e->stamp != STAMP_NOUNITS &&
 					(e->slotdev & 0x0fffffffu) >= w->view.map_cap[e->slotdev >> 28])
@@ -698,10 +810,14 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 			{
 				l->gidx[l->ng++] = k;
 				d = a2_TSDiff(e->sub->sum_wake, now);
-				if(d < best)
+				if(e->sub->sum_timed)
 				{
-					best = d;
-					l->sum_wake = e->sub->sum_wake;
+					l->sum_timed = 1;
+					if(d < best)
+					{
+						best = d;
+						l->sum_wake = e->sub->sum_wake;
+					}
 				}
 				voices += e->sub->sum_voices;
 				continue;

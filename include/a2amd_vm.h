@@ -1,0 +1,169 @@
+/*
+ * a2amd_vm.h - the scripted voice's VM on the device: C ABI of the part of
+ * liba2amd.so that stands in for a2_VoiceProcessVM / a2_VoiceProcessVMEv / a2_VoiceProcess
+ * (src/core.c:1166-1744, :1784-1839, :1847-1880) for voices whose program the host has PROVEN to
+ * stay inside a subset of the instruction set:
+ *
+ *   flow      JUMP LOOP JZ JNZ JG JL JGE JLE                     core.c:1282-1320
+ *   timing    DELAY DELAYR TDELAY TDELAYR                        core.c:1323-1336, :1721-1733
+ *   maths     SUBR P2DR NEGR LOAD LOADR ADD ADDR MUL MULR        core.c:1339-1388
+ *             MOD QUANT (immediate divisor not 0 / -1)
+ *   compare   GR LR GER LER EQR NER ANDR ORR XORR NOTR           core.c:1413-1456
+ *   control   SET SETALL RAMP RAMPR RAMPALL RAMPALLR             core.c:1459-1489
+ *             (a2_VoiceControl, core.c:143-149, through the register tracker, core.c:1064-1116)
+ *
+ * and - proven from the voice's current pc by a2amd_vm_analyze() - never reaches END / SLEEP /
+ * RETURN / CALL, spawning, messages, RAND (the engine-global RNG), a register divisor, or a loop
+ * without a delay of at least one 256th of a frame in it (A2_OVERLOAD, core.c:1190): such a voice can
+ * neither end nor fault nor touch anything outside its own registers and its own units' control
+ * registers, so nothing the engine does depends on WHEN its VM runs.  The engine hands the voice
+ * over (a2amd_vm_adopt: program text, A2_vmstate, which VM register feeds which unit register),
+ * stops visiting it (INTEGRATION.md option C: a2amd_walk.c treats it as asleep), and the device
+ * runs the VM between the unit windows: a kernel with one lane per voice interprets the ENGINE'S
+ * OWN bytecode and writes, per batch, the same command records the host would have recorded from
+ * the engine's write / Process calls (R_WRITE, R_SEG, R_F1SET, R_F1RAMP; a2amd_device.h), which
+ * the leaf kernels execute as before.  When the engine needs the voice back - an event in its
+ * queue, a window that is not the backend's fragment, a kill - a2amd_vm_recall() returns the
+ * A2_vmstate the engine's own VM would have reached by the start of the open fragment.
+ *
+ * Plain C types only.  The instruction encoding and the opcode numbers are the engine's
+ * (src/internals.h:152-231); a2amd_walk.c, compiled against that header, static-asserts every
+ * value below, tests/test_plugin_abi.py does the same from the test suite.
+ */
+#ifndef A2AMD_VM_H
+#define A2AMD_VM_H
+
+#include <stdint.h>
+#include "a2amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A2AMD_VM_REGISTERS	64	/* A2_REGISTERS, include/a2_vm.h:31 */
+#define A2AMD_VM_INSLIMIT	1000	/* A2_INSLIMIT, src/config.h:119 */
+#define A2AMD_VM_R_TICK		0	/* R_TICK, include/a2_vm.h:52 */
+#define A2AMD_VM_R_TRANSPOSE	1	/* R_TRANSPOSE */
+
+/* A2_vstates, include/a2_vm.h:41-48 */
+enum { A2AMD_VM_RUNNING = 0, A2AMD_VM_WAITING, A2AMD_VM_INTERRUPT, A2AMD_VM_ENDING, A2AMD_VM_FINALIZING };
+
+/* A2_opcodes, src/internals.h:152-207 (OP_END = 0, then A2_ALLINSTRUCTIONS in order) */
+#define A2AMD_VM_ALLOPS \
+	A2V(END) A2V(RETURN) A2V(CALL) \
+	A2V(JUMP) A2V(LOOP) A2V(JZ) A2V(JNZ) A2V(JG) A2V(JL) A2V(JGE) A2V(JLE) \
+	A2V(DELAY) A2V(DELAYR) A2V(TDELAY) A2V(TDELAYR) \
+	A2V(SLEEP) A2V(WAKE) A2V(FORCE) \
+	A2V(SUBR) A2V(DIVR) A2V(P2DR) A2V(NEGR) A2V(LOAD) A2V(LOADR) A2V(ADD) A2V(ADDR) \
+	A2V(MUL) A2V(MULR) A2V(MOD) A2V(MODR) A2V(QUANT) A2V(QUANTR) A2V(RAND) A2V(RANDR) \
+	A2V(GR) A2V(LR) A2V(GER) A2V(LER) A2V(EQR) A2V(NER) \
+	A2V(ANDR) A2V(ORR) A2V(XORR) A2V(NOTR) \
+	A2V(SET) A2V(SETALL) A2V(RAMP) A2V(RAMPR) A2V(RAMPALL) A2V(RAMPALLR) \
+	A2V(PUSH) A2V(PUSHR) \
+	A2V(SPAWN) A2V(SPAWNR) A2V(SPAWND) A2V(SPAWNDR) A2V(SPAWNV) A2V(SPAWNVR) A2V(SPAWNA) A2V(SPAWNAR) \
+	A2V(SEND) A2V(SENDR) A2V(SENDA) A2V(SENDS) A2V(WAIT) A2V(KILL) A2V(KILLR) A2V(KILLA) \
+	A2V(DETACH) A2V(DETACHR) A2V(DETACHA) \
+	A2V(DEBUG) A2V(DEBUGR) \
+	A2V(INITV) A2V(SIZEOF) A2V(SIZEOFR)
+#define A2V(x) A2AMD_OP_##x,
+typedef enum a2amd_vm_opcodes { A2AMD_VM_ALLOPS A2AMD_VM_OPCODES } a2amd_vm_opcodes;
+#undef A2V
+
+/* A2_instruction, src/internals.h:218-224: 32 bit words; opcode:8 a1:8 a2:16 [a3:32 in the next
+ * word for the two-word instructions, a2_InsSize, src/compiler.c:111-131] (little endian) */
+#define A2AMD_VM_OPCODE(w)	((unsigned)(w) & 0xffu)
+#define A2AMD_VM_A1(w)		(((unsigned)(w) >> 8) & 0xffu)
+#define A2AMD_VM_A2(w)		(((unsigned)(w) >> 16) & 0xffffu)
+
+/* A2_vmstate, include/a2_vm.h:62-69, field for field */
+typedef struct a2amd_vm_state {
+	uint32_t waketime;	/* 24:8 frames, engine time (A2_state.now_fragstart's clock) */
+	uint8_t  state;		/* A2AMD_VM_RUNNING ... */
+	uint8_t  func;
+	uint16_t pc;
+	int32_t  r[A2AMD_VM_REGISTERS];
+} a2amd_vm_state;
+
+/* Why a program is not taken (a2amd_vm_info.reason) */
+enum {
+	A2AMD_VM_OK = 0,
+	A2AMD_VM_BADCODE,	/* pc / jump target outside the function, truncated instruction */
+	A2AMD_VM_OPCODE_OUT,	/* reaches an instruction outside the subset (info.opcode, info.at) */
+	A2AMD_VM_DIVISOR,	/* MOD / QUANT by 0 or -1 */
+	A2AMD_VM_NOYIELD,	/* a cycle without a delay that is certain to be > 0, or a straight run
+				 * of A2_INSLIMIT instructions: A2_OVERLOAD cannot be ruled out */
+	A2AMD_VM_TARGET,	/* may write a VM register wired to a unit register the device VM does not
+				 * write (wtosc 'w', fbdelay's tap lengths, a unit that is not ours ...) */
+	A2AMD_VM_IDLE		/* never writes a unit register: nothing to gain (the voice sleeps anyway) */
+};
+
+typedef struct a2amd_vm_info {
+	int32_t  reason;	/* A2AMD_VM_OK: adoptable */
+	int32_t  opcode, at;	/* the offending instruction (A2AMD_VM_OPCODE_OUT, _DIVISOR, _NOYIELD) */
+	uint64_t written;	/* VM registers some reachable instruction stores to */
+	uint64_t controlled;	/* VM registers a reachable SET / RAMP / timing instruction may pass to
+				 * a2_VoiceControl (explicitly, or through the register tracker) */
+	uint32_t reachable;	/* instructions reachable from pc */
+	uint32_t longest;	/* most instructions between two certain yields */
+} a2amd_vm_info;
+
+/* Static analysis of the function 'code' (nwords 32 bit words) from 'pc': everything the voice can
+ * still execute.  tick = the voice's r[R_TICK] (TDELAY immediates are certain yields only while
+ * no reachable instruction writes R_TICK), msdur = A2_state.msdur (src/audiality2.c:499).  Pure
+ * host code: callable without a GPU.  Returns info->reason. */
+int a2amd_vm_analyze(const uint32_t *code, unsigned nwords, unsigned pc, int32_t tick, uint32_t msdur,
+		a2amd_vm_info *info);
+
+/* The text of one function (A2_function.code / .size, src/internals.h:417-425), uploaded once per
+ * context; 'key' identifies it on the host (the code pointer).  Returns a program id >= 0. */
+int a2amd_vm_program(a2amd_ctx *ctx, uint64_t key, const uint32_t *code, unsigned nwords);
+
+/* Hand the voice 'head_unit' belongs to over to the device VM, from the OPEN fragment on (in which
+ * the engine has already processed it: the device takes over with the next one).
+ *   st        the voice's A2_vmstate as the engine leaves it now (state A2AMD_VM_WAITING)
+ *   wr_unit   [A2AMD_VM_REGISTERS] backend unit id VM register i is wired to (A2_voice.cregs[i],
+ *             src/internals.h:573: the unit whose write callback a2_VoiceControl calls), -1 none
+ *   wr_reg    [A2AMD_VM_REGISTERS] ... and that unit's register index (a2amd_unit_write's 'reg')
+ *   now       engine time (A2_state.now_fragstart + (offset << 8), core.c:1855) of the START of the
+ *             open fragment
+ *   msdur     A2_state.msdur
+ * Fails with A2AMD_EUNSUPPORTED (and a reason in a2amd_last_error) when a2amd_vm_analyze() or the
+ * voice's chain says no; the voice then simply stays with the engine. */
+int a2amd_vm_adopt(a2amd_ctx *ctx, int head_unit, int prog, const a2amd_vm_state *st,
+		const int32_t *wr_unit, const uint8_t *wr_reg, uint32_t now, uint32_t msdur);
+
+/* 1 while the voice 'head_unit' belongs to is run by the device VM. */
+int a2amd_vm_adopted(a2amd_ctx *ctx, int head_unit);
+
+/* The engine wants n voices back, BEFORE it processes them in the open fragment: out[k] = the
+ * A2_vmstate the engine's own a2_VoiceProcess calls would have left in voice k by now (every VM run
+ * due before the start of the open fragment executed, none of those due in it).  From the open
+ * fragment on the voices are the host's again (their unit windows and writes arrive as calls).
+ * One device round trip for the lot. */
+int a2amd_vm_recall(a2amd_ctx *ctx, const int32_t *head_units, unsigned n, a2amd_vm_state *out);
+
+/* ---- test / measurement access (no GPU needed) -----------------------------------------*/
+/* Run the HOST copy of the interpreter - the same source the kernel is compiled from
+ * (csrc/a2amd_vmcore.h) - over 'nfrags' fragments of fragframes[] frames, the first starting at
+ * engine time 'now', and return the command records it emits (a2amd_device.h: A2DRec, 4 words
+ * each) in recs[0 .. return value), at most cap of them; *st is advanced.  kinds[chainpos] = the
+ * unit kinds of the voice's chain, wr_unit here = chain position.  f1tab may be NULL (no cutoff
+ * writes).  The parity tests drive this against traces of the compiled reference. */
+int a2amd_vm_trace_host(const uint32_t *code, unsigned nwords, a2amd_vm_state *st,
+		const int32_t *wr_unit, const uint8_t *wr_reg, const int32_t *kinds, int nkinds,
+		uint32_t now, uint32_t msdur, int32_t samplerate, int32_t basepitch,
+		const uint8_t *fragframes, unsigned nfrags, uint32_t *recs, unsigned cap);
+
+typedef struct a2amd_vm_stats {
+	uint64_t adopted, recalled, released;	/* voices, so far */
+	uint64_t vm_voice_batches;		/* sum over batches of voices the VM kernel ran */
+	uint64_t vm_records;			/* records it emitted */
+	uint32_t live;				/* voices under the device VM now */
+	uint32_t programs;
+} a2amd_vm_stats;
+int a2amd_vm_get_stats(a2amd_ctx *ctx, a2amd_vm_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* A2AMD_VM_H */

@@ -36,6 +36,7 @@ typedef struct a2amd_walkview
 	unsigned		serial_value;
 	void			*state;		/* for a2amd_units_hold() */
 	const unsigned		*frag_serial;	/* counts the root windows (= backend fragments) the state has opened */
+	const unsigned		*vm_live;	/* voices of the state the device VM runs right now (a2amd_units_vm_adopt) */
 } a2amd_walkview;
 /* The view of the engine state with this A2_config; 0, or -1 when the drop-in does not serve it. */
 int a2amd_units_walkview(const void *cfg, a2amd_walkview *out);
@@ -47,6 +48,28 @@ uint32_t a2amd_units_standing(const void *head, uint32_t *slotdev);
  * state 'state' (a2amd_walkview.state): the voices in slots[0..n) report their default window in
  * every fragment until released.  n == 0 and on == 0: every hold of the state, in all contexts. */
 int a2amd_units_hold(void *state, unsigned dev, const uint32_t *slots, unsigned n, int on);
+
+/* ---- the scripted voice's VM on the device (include/a2amd_vm.h) --------------------
+ * The walk is where a voice's VM state (A2_voice.s), its program (A2_voice.program) and its register
+ * wiring (A2_voice.cregs) are visible; the units know which backend unit each of them is.
+ *
+ * a2amd_units_vm_adopt: the engine has just processed the voice whose first unit is 'head' in the
+ * open root window; hand it to the device VM from the next fragment on.
+ *   code / nwords   the voice's current function (A2_function.code / .size, src/internals.h:417-425)
+ *   vmstate         &A2_voice.s (A2_vmstate, include/a2_vm.h:62-69)
+ *   wr_unit, wr_fn  A2_voice.cregs[i].unit / .write for the 64 VM registers (src/internals.h:573)
+ *   now             st->now_fragstart + (root window offset << 8): engine time of the open fragment's start
+ *   msdur           A2_state.msdur
+ * Returns 0 (adopted: the voice now counts as asleep for good - report its default windows like a
+ * sleeping voice's, never hand it to the engine without a2amd_units_vm_recall()), -1 (never, for this
+ * program from this pc: outside the subset), -2 (not now). */
+int a2amd_units_vm_adopt(const void *head, const uint32_t *code, unsigned nwords, const void *vmstate,
+		void *const *wr_unit, void *const *wr_fn, uint32_t now, uint32_t msdur);
+/* 1 when the voice is the device VM's. */
+int a2amd_units_vm_is(const void *head);
+/* The engine is about to process these n voices again: vmstates[k] (A2_vmstate *) receives what the
+ * engine's own VM would have left there by the start of the open fragment. */
+int a2amd_units_vm_recall(const void *const *heads, unsigned n, void *const *vmstates);
 
 
 #ifdef __cplusplus
