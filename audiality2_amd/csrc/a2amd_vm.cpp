@@ -726,10 +726,16 @@ int a2amd_vm_adopt(a2amd_ctx *c, int head, int prog, const a2amd_vm_state *st, c
 		return c->fail(A2AMD_ESTATE, "vm_adopt: voice %d is adopted already", vi);
 	if(!c->frag_open || c->uploaded)
 		return c->fail(A2AMD_ESTATE, "vm_adopt outside a fragment");
-	if(!v.live || v.dying || !v.resolved || !v.started || v.inline_pos >= 0 || v.walked != c->serial_base + c->cur_frag)
-		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: voice %d has not been processed in the open fragment (or owns a bus)", vi);
+	if(v.inline_pos >= 0)
+		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: voice %d owns a bus", vi);
+	// (not now - which says nothing about the program: A2AMD_ESTATE)
+	const bool marked = c->defmap_used && (size_t)vi < c->defmap.size() && c->defmap[vi];
+	if(!v.live || v.dying || !v.resolved || !v.started || (v.walked != c->serial_base + c->cur_frag && !marked))
+		return c->fail(A2AMD_ESTATE, "vm_adopt: voice %d has not been processed in the open fragment (live %d dying %d "
+				"resolved %d started %d walked %lld, fragment %lld)", vi, (int)v.live, (int)v.dying, (int)v.resolved,
+				(int)v.started, v.walked, c->serial_base + c->cur_frag);
 	if(st->state != A2AMD_VM_WAITING)
-		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: VM state %d (only a voice that waits in a delay is taken)", st->state);
+		return c->fail(A2AMD_ESTATE, "vm_adopt: VM state %d (only a voice that waits in a delay is taken)", st->state);
 	if(m.t0_valid && m.msdur != msdur && (m.stats.live || !m.pending.empty()))
 		return c->fail(A2AMD_EINVAL, "vm_adopt: msdur %u, the context's voices run on %u", msdur, m.msdur);
 	const HVmProg &p = m.progs[prog];

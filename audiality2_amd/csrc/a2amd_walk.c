@@ -244,8 +244,9 @@ static void report(void)
 	for(i = 0; i < 256; ++i)
 		if(wstates[i] && (wstates[i]->skipped || wstates[i]->visited))
 			fprintf(stderr, "a2amd walk: state %p: %llu voice visits skipped, %llu made (%llu of the skipped without "
-					"reading the voice%s)\n", (void *)wstates[i]->st, wstates[i]->skipped, wstates[i]->visited,
-					wstates[i]->unread, wstates[i]->hooks_broken ? "; HOOKS BROKEN" : "");
+					"reading the voice%s); %llu voices handed to the device VM, %llu taken back\n", (void *)wstates[i]->st,
+					wstates[i]->skipped, wstates[i]->visited, wstates[i]->unread,
+					wstates[i]->hooks_broken ? "; HOOKS BROKEN" : "", wstates[i]->adopted, wstates[i]->recalled);
 }
 
 static void bind_engine(void)
@@ -520,6 +521,54 @@ static inline void mark_entry(WSTATE *w, const ENT *e)
 }
 
 
+/* The list as remembered against the list as it is, after voices were born or died (the epoch
+ * moved): voices are born at the HEAD of their parent's list (a2_VoiceNew, core.c:474-475) and die
+ * anywhere.  Matching position by position, one birth would make every voice behind it a stranger
+ * - handed to the engine's loop although it sleeps, a voice the device VM runs taken back for
+ * nothing.  At a mismatch at position k: did the voices remembered at k, k + 1, ... die (the voice
+ * standing here is remembered a few places on), or were voices born in front of the one remembered
+ * here (it stands a few links on)?  The table is shifted accordingly; new places start blank. */
+static void realign(LIST *l, unsigned k, A2_voice *v)
+{
+	unsigned d, j;
+	A2_voice *p;
+	for(d = 1; d <= 16 && k + d < l->n; ++d)
+		if(l->e[k + d].v == v)
+		{
+			memmove(&l->e[k], &l->e[k + d], (l->n - k - d) * sizeof(ENT));
+			memmove(&l->up[k], &l->up[k + d], (l->n - k - d) * sizeof(UPTR));
+			l->n -= d;
+			return;
+		}
+	for(p = v, j = 1; j <= 4096 && p->next; ++j)
+	{
+		p = p->next;
+		if(p != l->e[k].v)
+			continue;
+		if(l->n + j > l->cap)
+		{
+			unsigned nc = (l->n + j) * 2;
+			ENT *ne = (ENT *)realloc(l->e, nc * sizeof(ENT));
+			UPTR *nu = ne ? (UPTR *)realloc(l->up, nc * sizeof(UPTR)) : NULL;
+			if(ne)
+				l->e = ne;
+			if(nu)
+				l->up = nu;
+			if(!ne || !nu)
+				return;
+			l->cap = nc;
+		}
+		memmove(&l->e[k + j], &l->e[k], (l->n - k) * sizeof(ENT));
+		memmove(&l->up[k + j], &l->up[k], (l->n - k) * sizeof(UPTR));
+		memset(&l->e[k], 0, j * sizeof(ENT));
+		memset(&l->up[k], 0, j * sizeof(UPTR));
+		for(p = v, d = 0; d < j; p = p->next, ++d)
+			l->e[k + d].v = p;	/* (stamp 0: visited once before anything is taken from memory) */
+		l->n += j;
+		return;
+	}
+}
+
 /* ---- voices whose VM runs on the device (include/a2amd_vm.h) ------------------------
  * The engine is about to process the 'run' voices from 'v' on (linked by ->next): those the device
  * VM runs get their A2_vmstate back first - what the engine's own VM would have left there by the
@@ -654,6 +703,8 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 				break;
 			if(k + AHEAD < l->n)
 				__builtin_prefetch(l->e[k + AHEAD].v);	/* (a hint: never dereferenced here) */
+			if(k < l->n && l->e[k].v != v && l->epoch != w->epoch)
+				realign(l, k, v);
 			if(voice_sleeps(w, l, k, v, now, frames, deflt))
 			{
 				mark_entry(w, &l->e[k]);
