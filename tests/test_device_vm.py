@@ -1,0 +1,283 @@
+"""scripted voices whose VM runs on the device (include/a2amd_vm.h).
+
+GPU tests: the reference engine with the drop-in and the replaced voice walk hands voices whose
+programs loop inside the supported subset to the device VM; the audio a2_Run() returns must be
+the audio the same engine renders with its own CPU units - with one-fragment buffers (the VM
+kernel runs per fragment) and with long ones (256-fragment batches; voices adopted and taken
+back in the middle of a batch are carried by the host's copy of the interpreter).
+
+CPU tests (no GPU): the static analysis that decides what the device VM may run, and the host
+copy of the interpreter - the same source the kernel is compiled from - on hand-assembled
+programs with known answers."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import audiality2_amd
+from conftest import ROOT
+
+REF_RENDER = os.path.join(ROOT, "oracle", "_ref", "ref_render")
+UNITS_SO = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
+WALK_SO = os.path.join(ROOT, "audiality2_amd", "liba2amd_walk.so")
+A2S = os.path.join(ROOT, "tests", "a2s")
+
+
+def need_ref():
+    if not (os.path.exists(REF_RENDER) and os.path.exists(UNITS_SO) and os.path.exists(WALK_SO)):
+        pytest.skip("oracle/_ref (compiled reference), liba2amd_units.so or liba2amd_walk.so not built")
+
+
+def render(tmp_path, tag, script, program, frames, buffer, args, preload=None, env_extra=None, rate=48000, channels=2):
+    out = tmp_path / f"{tag}.pcm"
+    env = dict(os.environ, A2AMD_WALK_STATS="1")
+    env.pop("LD_PRELOAD", None)
+    if preload:
+        env["LD_PRELOAD"] = preload
+    env.update(env_extra or {})
+    r = subprocess.run([REF_RENDER, f"{A2S}/{script}.a2s", program, str(frames), str(buffer), str(rate), str(channels),
+                        str(out)] + list(args), env=env, cwd=A2S, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-800:]
+    m = re.search(r"(\d+) voices handed to the device VM, (\d+) taken back", r.stderr)
+    return np.fromfile(out, dtype="<i4"), (int(m.group(1)), int(m.group(2))) if m else None, r.stderr
+
+
+def first_difference(a, b, channels, buffer):
+    bad = np.nonzero(a != b)[0]
+    if not len(bad):
+        return None
+    k = int(bad[0])
+    return f"{len(bad)} samples differ, first in buffer {k // (channels * buffer)}, frame {k % buffer}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("buffer", [64, 4096, 1000])
+def test_looping_voices_run_on_the_device_vm_and_sound_like_the_cpu_engine(tmp_path, buffer):
+    """tests/a2s/vmloops.a2s: every unit register the device VM writes, under LFOs, arpeggios, sweeps
+    (cutoff ramps through the coefficient table), tick delays, explicit ramps; voices that get
+    messages, are killed, detached, sit under a group that wakes in mid-fragment or under one that
+    ends.  3 s of it, against the engine's own CPU render."""
+    need_ref()
+    frames = 48000 * 3 // buffer * buffer
+    cpu, _, _ = render(tmp_path, "cpu", "vmloops", "Main", frames, buffer, ["0.08"])
+    vm, stats, err = render(tmp_path, "vm", "vmloops", "Main", frames, buffer, ["0.08"], preload=f"{WALK_SO} {UNITS_SO}")
+    assert cpu.any()
+    assert first_difference(cpu, vm, 2, buffer) is None, first_difference(cpu, vm, 2, buffer)
+    # the test is about the device VM: it must have been given the looping voices, and the engine
+    # must have wanted some of them back (messages, kills, the group's windows)
+    assert stats and stats[0] >= 12 and stats[1] >= 4, (stats, err[-400:])
+
+
+@pytest.mark.gpu
+def test_device_vm_off_is_the_same_audio(tmp_path):
+    """A2AMD_NO_VM=1: nothing is handed over - the A/B switch of the measurements."""
+    need_ref()
+    frames = 48000
+    a, sa, _ = render(tmp_path, "on", "vmloops", "Main", frames, 256, ["0.08"], preload=f"{WALK_SO} {UNITS_SO}")
+    b, sb, _ = render(tmp_path, "off", "vmloops", "Main", frames, 256, ["0.08"], preload=f"{WALK_SO} {UNITS_SO}",
+                      env_extra={"A2AMD_NO_VM": "1"})
+    assert np.array_equal(a, b) and a.any()
+    assert sa and sa[0] > 0 and sb and sb[0] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("program,n4", [("OscPanScripted", 256), ("OscFilterPanScripted", 256)])
+@pytest.mark.parametrize("buffer", [64, 4096])
+def test_scripted_bench_variants_on_the_device_vm(tmp_path, program, n4, buffer):
+    """BASELINE variants 2b / 3b (tests/a2s/bench.a2s) at 1 024 voices: every voice's VM wakes every
+    3 ms - all of them end up on the device, none comes back, and the audio is the CPU engine's."""
+    need_ref()
+    frames = 48000
+    cpu, _, _ = render(tmp_path, "cpu", "bench", program, frames, buffer, [str(n4), "0.002"])
+    vm, stats, _ = render(tmp_path, "vm", "bench", program, frames, buffer, [str(n4), "0.002"], preload=f"{WALK_SO} {UNITS_SO}")
+    assert cpu.any()
+    assert first_difference(cpu, vm, 2, buffer) is None, first_difference(cpu, vm, 2, buffer)
+    assert stats == (4 * n4, 0), stats
+
+
+# ---- CPU: analysis and host interpreter -------------------------------------------------------
+def lib():
+    L = audiality2_amd.load_library()
+    L.a2amd_vm_analyze.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint, ctypes.c_uint, ctypes.c_int32, ctypes.c_uint32,
+                                   ctypes.POINTER(VmInfo)]
+    L.a2amd_vm_analyze.restype = ctypes.c_int
+    return L
+
+
+class VmInfo(ctypes.Structure):
+    _fields_ = [("reason", ctypes.c_int32), ("opcode", ctypes.c_int32), ("at", ctypes.c_int32), ("written", ctypes.c_uint64),
+                ("controlled", ctypes.c_uint64), ("reachable", ctypes.c_uint32), ("longest", ctypes.c_uint32)]
+
+
+class VmState(ctypes.Structure):
+    _fields_ = [("waketime", ctypes.c_uint32), ("state", ctypes.c_uint8), ("func", ctypes.c_uint8), ("pc", ctypes.c_uint16),
+                ("r", ctypes.c_int32 * 64)]
+
+
+# opcode numbers (include/a2amd_vm.h; checked against the engine's by a2amd_walk.c and test_plugin_abi.py)
+OPS = ("END RETURN CALL JUMP LOOP JZ JNZ JG JL JGE JLE DELAY DELAYR TDELAY TDELAYR SLEEP WAKE FORCE SUBR DIVR P2DR NEGR "
+       "LOAD LOADR ADD ADDR MUL MULR MOD MODR QUANT QUANTR RAND RANDR GR LR GER LER EQR NER ANDR ORR XORR NOTR SET SETALL "
+       "RAMP RAMPR RAMPALL RAMPALLR PUSH PUSHR SPAWN").split()
+OP = {n: i for i, n in enumerate(OPS)}
+TWO = {"DELAY", "TDELAY", "LOAD", "ADD", "MUL", "MOD", "QUANT", "RAND", "PUSH", "RAMP", "RAMPALL"}
+
+
+def asm(*ins):
+    """(name, a1, a2[, a3]) -> 32 bit words (A2_instruction, src/internals.h:218-224)."""
+    words = []
+    for i in ins:
+        name, a1, a2 = i[0], i[1], i[2]
+        words.append(OP[name] | (a1 << 8) | (a2 << 16))
+        if name in TWO:
+            words.append(i[3] & 0xffffffff)
+    return (ctypes.c_uint32 * len(words))(*words), len(words)
+
+
+MSDUR = int(np.float32(48000) * np.float32(65.536) + np.float32(0.5))      # src/audiality2.c:499
+
+
+def analyze(code, n, pc=0, tick=1 << 16):
+    info = VmInfo()
+    r = lib().a2amd_vm_analyze(code, n, pc, tick, MSDUR, ctypes.byref(info))
+    return r, info
+
+
+def fx(v):
+    return int(round(v * 65536))
+
+
+def test_analysis_takes_a_delay_loop_and_names_what_it_controls():
+    # for { +r5 .01; d 3; -r5 .01 (ADD of a negative); d 3 }
+    code, n = asm(("ADD", 5, 0, fx(.01)), ("DELAY", 0, 0, fx(3)), ("ADD", 5, 0, fx(-.01)), ("DELAY", 0, 0, fx(3)), ("JUMP", 0, 0))
+    r, info = analyze(code, n)
+    assert r == 0 and info.reachable == 5
+    assert info.written == 1 << 5 and info.controlled == 1 << 5
+    assert info.longest == 3        # JUMP, ADD, DELAY: the longest stretch between two certain yields
+
+
+def test_analysis_refuses_what_the_device_cannot_or_must_not_run():
+    # an instruction outside the subset: END, SPAWN, RAND (the engine-global RNG), DIVR
+    for bad in (("END", 0, 0), ("SPAWN", 1, 2), ("RAND", 3, 0, 5), ("DIVR", 3, 4), ("SLEEP", 0, 0), ("CALL", 0, 1)):
+        code, n = asm(("DELAY", 0, 0, fx(1)), bad, ("JUMP", 0, 0))
+        r, info = analyze(code, n)
+        assert r == 2 and info.opcode == OP[bad[0]] and info.at == 2, (bad, r, info.opcode, info.at)
+    # ... unless it cannot be reached from where the voice stands
+    code, n = asm(("SPAWN", 1, 2), ("DELAY", 0, 0, fx(1)), ("JUMP", 0, 1))
+    assert analyze(code, n, pc=1)[0] == 0 and analyze(code, n, pc=0)[0] == 2
+    # a loop that may never yield: no delay at all, a delay of zero, a delay from a register
+    for body in ((("ADD", 3, 0, 1),), (("DELAY", 0, 0, 0),), (("DELAYR", 3, 0),), (("TDELAYR", 3, 0),)):
+        code, n = asm(*body, ("JUMP", 0, 0))
+        assert analyze(code, n)[0] == 4, body
+    # a tick delay is a certain yield while the program leaves R_TICK alone and the tick is not zero
+    code, n = asm(("TDELAY", 0, 0, fx(1)), ("JUMP", 0, 0))
+    assert analyze(code, n)[0] == 0 and analyze(code, n, tick=0)[0] == 4
+    code, n = asm(("TDELAY", 0, 0, fx(1)), ("ADD", 0, 0, 5), ("JUMP", 0, 0))
+    assert analyze(code, n)[0] == 4
+    # a counted loop without a delay inside: LOOP's back edge is a cycle
+    code, n = asm(("LOAD", 4, 0, fx(3)), ("ADD", 5, 0, 1), ("LOOP", 4, 2 + 0), ("DELAY", 0, 0, fx(1)), ("JUMP", 0, 0))
+    assert analyze(code, n)[0] == 4
+    # 1000 instructions in a row (A2_INSLIMIT) between two delays
+    code, n = asm(("DELAY", 0, 0, fx(1)), *[("ADDR", 5, 6)] * 1000, ("JUMP", 0, 0))
+    assert analyze(code, n)[0] == 4
+    code, n = asm(("DELAY", 0, 0, fx(1)), *[("ADDR", 5, 6)] * 900, ("JUMP", 0, 0))
+    assert analyze(code, n)[0] == 0
+    # divisors
+    for d in (0, -1):
+        code, n = asm(("MOD", 3, 0, d), ("DELAY", 0, 0, fx(1)), ("JUMP", 0, 0))
+        assert analyze(code, n)[0] == 3
+    # a jump out of the function, a truncated two-word instruction
+    code, n = asm(("DELAY", 0, 0, fx(1)), ("JUMP", 0, 77))
+    assert analyze(code, n)[0] == 1
+    code, n = asm(("DELAY", 0, 0, fx(1)), ("JUMP", 0, 0), ("LOAD", 1, 0, 0))
+    assert analyze(code, n - 1, pc=3)[0] == 1
+
+
+def trace_host(code, n, st, wr_unit, wr_reg, kinds, frags, now=0, cap=4096):
+    L = audiality2_amd.load_library()
+    L.a2amd_vm_trace_host.restype = ctypes.c_int
+    wu = (ctypes.c_int32 * 64)(*([-1] * 64))
+    wr = (ctypes.c_uint8 * 64)()
+    for reg, (u, ur) in zip(wr_unit, wr_reg):
+        wu[reg], wr[reg] = u, ur
+    kk = (ctypes.c_int32 * len(kinds))(*kinds)
+    ff = (ctypes.c_uint8 * len(frags))(*frags)
+    recs = (ctypes.c_uint32 * (4 * cap))()
+    k = L.a2amd_vm_trace_host(code, ctypes.c_uint(n), ctypes.byref(st), wu, wr, kk, len(kinds), ctypes.c_uint32(now),
+                              ctypes.c_uint32(MSDUR), 48000, 0, ff, len(frags), recs, cap)
+    assert 0 <= k <= cap, k
+    out = []
+    for i in range(k):
+        head, value, dur, start = recs[4 * i], ctypes.c_int32(recs[4 * i + 1]).value, recs[4 * i + 2], recs[4 * i + 3]
+        out.append((head & 0xffff, (head >> 16) & 0xff, (head >> 24) & 15, head >> 28, value, dur, start))
+    return out
+
+
+R_SEG, R_WRITE, R_F1SET, R_F1RAMP = 1, 2, 5, 6
+WTOSC, PANMIX, FILTER12 = 0, 1, 2
+
+
+def test_host_interpreter_known_answers():
+    """for { +p .01; d 3; -p .01; d 3 } on a wtosc -> panmix voice, engine time 0: the VM runs in
+    the frame its wake time lies in (core.c:1816-1823), the pending register goes out as a ramp over
+    the delay (core.c:1719-1726) with the wake time's fraction as start, windows are cut there."""
+    code, n = asm(("ADD", 5, 0, fx(.01)), ("DELAY", 0, 0, fx(3)), ("ADD", 5, 0, fx(-.01)), ("DELAY", 0, 0, fx(3)), ("JUMP", 0, 0))
+    st = VmState()
+    st.state = 1                            # A2_WAITING
+    st.waketime = (100 << 8) | 0x40         # frame 100.25 = fragment 1, frame 36
+    st.r[5] = fx(.5)
+    st.r[1] = fx(1)                         # transpose
+    recs = trace_host(code, n, st, [5], [(0, 1)], [WTOSC, PANMIX], [64] * 5)
+    dt = ((fx(3) * MSDUR + 0x7fffff) >> 24)
+    assert dt == 144 << 8                   # 3 ms at 48 kHz, 24:8
+    # fragment 0: nothing (the default window).  fragment 1: window [0, 36), the write, window [36, 64)
+    assert recs[0] == (1, R_SEG, 0, 0, 0, 0 | (36 << 16), 0)
+    assert recs[1] == (1, R_WRITE, 0, 1, fx(.5) + fx(.01) + fx(1), dt, 0x40)      # value + transpose (+ basepitch 0)
+    assert recs[2] == (1, R_SEG, 0, 0, 0, 36 | (28 << 16), 0)
+    # next wake 144 frames on: frame 244.25 = fragment 3, frame 52
+    assert recs[3] == (3, R_SEG, 0, 0, 0, 0 | (52 << 16), 0)
+    assert recs[4][:5] == (3, R_WRITE, 0, 1, fx(.5) + fx(1)) and recs[4][6] == 0x40
+    assert recs[5] == (3, R_SEG, 0, 0, 0, 52 | (12 << 16), 0)
+    assert len(recs) == 6
+    assert st.waketime == (388 << 8) | 0x40 and st.state == 1 and st.pc == 8      # (pc counts 32 bit words)
+    # a VM run at the very start of a fragment: the write comes first, the whole fragment is one explicit window
+    st2 = VmState()
+    st2.state = 1
+    st2.waketime = 128 << 8
+    recs = trace_host(code, n, st2, [5], [(0, 1)], [WTOSC, PANMIX], [64] * 3)
+    assert [r[1] for r in recs] == [R_WRITE, R_SEG] and recs[1] == (2, R_SEG, 0, 0, 0, 64 << 16, 0)
+
+
+def test_host_interpreter_cutoff_goes_through_the_coefficient_table():
+    """A filter12 cutoff ramp: f12_CutOff keeps the ramper (filter12.c:141-147), every window of the ramp
+    gets its coefficient (the head of f12_process, :86-96) - here from the table of f12_pitch2coeff over
+    everything a2_P2I can return, which must agree with the formula evaluated directly."""
+    import math
+    code, n = asm(("LOAD", 6, 0, fx(2)), ("DELAY", 0, 0, fx(4)), ("LOAD", 6, 0, fx(-1)), ("DELAY", 0, 0, fx(4)), ("JUMP", 0, 0))
+    st = VmState()
+    st.state = 1
+    st.waketime = 10 << 8
+    recs = trace_host(code, n, st, [6], [(1, 0)], [WTOSC, FILTER12, PANMIX], [64] * 8)
+    ramps = [r for r in recs if r[1] == R_F1RAMP]
+    assert len(ramps) >= 8 and not [r for r in recs if r[1] == R_F1SET]
+    # the first window of the ramp: 54 frames of a 192-frame ramp from 0 to 2.0 (ramper values are 8:24)
+    timer = (fx(4) * MSDUR + 0x7fffff) >> 24
+    delta = ((fx(2) << 8) * 256) // timer
+    value = delta * 54
+    pitch = value >> 8
+
+    def p2i(pitch):
+        tab = []
+        b = 0x80000000
+        for i in range(64):
+            b2 = int(float(0x80000000) * float(np.float32(2.0) ** np.float32((i + 1) * np.float32(1.0 / 64))) + 0.5)
+            tab.append((b, (b2 - b + 128) >> 8))
+            b = b2
+        nn, octv = pitch & 0xffff, pitch >> 16
+        base, coeff = tab[nn >> 10]
+        return ((((coeff * (nn & 0x3ff)) & 0xffffffff) >> 2) + base & 0xffffffff) >> ((7 - octv) & 31)
+    f = np.float32(p2i(pitch)) * np.float32(261.626 / 16777216.0)
+    want = 362 << 16 if f > 12000 else int(np.float32(512.0 * 65536.0) * math.sin(math.pi * float(f) / 48000))
+    assert ramps[0][4] == want, (ramps[0], want)

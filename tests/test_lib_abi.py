@@ -10,8 +10,8 @@ import pytest
 from conftest import ROOT
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "a2amd.h")).read()
+def declared_symbols(header="a2amd.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(a2amd_[a-z_0-9]+)\s*\(", text)))
 
@@ -27,6 +27,24 @@ def test_header_declares_the_boundary():
 def test_library_exports_every_declared_symbol(gpu_lib):
     for s in declared_symbols():
         assert hasattr(gpu_lib, s), f"liba2amd.so lacks {s}"
+    # the device VM's entry points
+    vm = declared_symbols("a2amd_vm.h")
+    assert "a2amd_vm_adopt" in vm and "a2amd_vm_recall" in vm and "a2amd_vm_analyze" in vm
+    for s in vm:
+        assert hasattr(gpu_lib, s), f"liba2amd.so lacks {s}"
+
+
+def test_walk_and_units_libraries_export_their_interface():
+    """include/a2amd_walk.h: what liba2amd_walk.so asks of liba2amd_units.so."""
+    units = os.path.join(ROOT, "audiality2_amd", "liba2amd_units.so")
+    if not os.path.exists(units):
+        pytest.skip("liba2amd_units.so not built")
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", units], capture_output=True, text=True, check=True).stdout
+    text = open(os.path.join(ROOT, "include", "a2amd_walk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for s in sorted(set(re.findall(r"\b(a2amd_units_[a-z_0-9]+)\s*\(", text))):
+        assert f" {s}\n" in out, f"liba2amd_units.so lacks {s}"
 
 
 def test_oracle_mirrors_the_call_protocol(oracle_lib):

@@ -68,6 +68,21 @@ _Static_assert(R_TRANSPOSE == A2P_R_TRANSPOSE, "transpose");
 _Static_assert(A2_MATCHIO == A2P_MATCHIO && A2_XINSERT == A2P_XINSERT, "flags");
 _Static_assert(A2_MAXFRAG == 64 && A2_MAXCHANNELS == 8 && A2_MIPLEVELS == 10, "limits");
 _Static_assert(A2_WAVEPRE == 1 && A2_WAVEPOST == 131, "pads");
+/* the device VM (include/a2amd_vm.h) interprets the engine's bytecode: opcode numbers, VM state
+ * layout and limits are the engine's (src/internals.h:152-224, include/a2_vm.h, src/config.h:119) */
+#include "internals.h"
+#include "a2amd_vm.h"
+#define A2V(x) _Static_assert((int)OP_##x == (int)A2AMD_OP_##x, "opcode " #x);
+A2AMD_VM_ALLOPS
+#undef A2V
+_Static_assert((int)A2_OPCODES == (int)A2AMD_VM_OPCODES, "opcodes");
+_Static_assert(A2_REGISTERS == A2AMD_VM_REGISTERS && A2_INSLIMIT == A2AMD_VM_INSLIMIT, "VM limits");
+_Static_assert(sizeof(A2_vmstate) == sizeof(a2amd_vm_state) && offsetof(A2_vmstate, r) == offsetof(a2amd_vm_state, r) &&
+		offsetof(A2_vmstate, pc) == offsetof(a2amd_vm_state, pc) && offsetof(A2_vmstate, func) == offsetof(a2amd_vm_state, func) &&
+		offsetof(A2_vmstate, state) == offsetof(a2amd_vm_state, state), "A2_vmstate");
+_Static_assert(sizeof(A2_instruction) == 8 && offsetof(A2_instruction, a3) == 4, "A2_instruction");
+_Static_assert((int)A2_WAITING == (int)A2AMD_VM_WAITING && (int)A2_ENDING == (int)A2AMD_VM_ENDING, "VM states");
+_Static_assert(R_TICK == A2AMD_VM_R_TICK && R_TRANSPOSE == A2AMD_VM_R_TRANSPOSE, "fixed registers");
 int main(void) { return 0; }
 '''
 
@@ -77,5 +92,5 @@ def test_plugin_structs_match_reference_headers(tmp_path):
         pytest.skip("reference tree / generated header not available here")
     src = tmp_path / "abi.c"
     src.write_text(SRC)
-    subprocess.run(["gcc", "-std=gnu11", "-fsyntax-only", f"-I{REFINC}", f"-I{REF}/include", f"-I{REF}/src", f"-I{REF}/src/units",
+    subprocess.run(["gcc", "-std=gnu11", "-fsyntax-only", f"-I{REFINC}", f"-I{REF}/include", f"-I{REF}/src", f"-I{REF}/src/units", f"-I{REF}/src/drivers",
                     f"-I{ROOT}/include", str(src)], check=True)
