@@ -53,7 +53,10 @@ def build_walk(force=False, engine=None):
         return out if os.path.exists(out) else None
     src = os.path.join(HERE, "csrc", "a2amd_walk.c")
     inc = os.path.join(HERE, "_engine_include")
-    deps = [src, os.path.join(ROOT, "include", "a2amd_walk.h"), os.path.join(HERE, "liba2amd_units.so")]
+    deps = [src, os.path.join(ROOT, "include", "a2amd_walk.h"), os.path.join(ROOT, "include", "a2amd_vm.h"),
+            os.path.join(HERE, "liba2amd_units.so")] + \
+           [os.path.join(engine, "src", f) for f in ("internals.h", "config.h")] + \
+           [os.path.join(engine, "include", f) for f in ("a2_vm.h", "a2_units.h", "audiality2.h.cmake")]
     if force or _newer(out, deps):
         subprocess.run(["cmake", f"-DENGINE={engine}", f"-DOUT={inc}", "-P", os.path.join(HERE, "csrc", "engine_header.cmake")],
                        check=True, stdout=subprocess.DEVNULL)

@@ -121,7 +121,6 @@ typedef struct WSTATE
 	unsigned	n_held;		/* lists held */
 	uint32_t	*scratch;	/* slots of a list, per context */
 	unsigned	scratch_cap;
-	unsigned long long last_use;	/* (the table of states is finite: the longest unused one makes room) */
 	unsigned long long skipped, unread, visited;
 	/* (code, pc) pairs the device VM has turned down for good: not offered again */
 	struct { const unsigned *code; unsigned pc; } vm_no[64];
@@ -132,47 +131,68 @@ typedef struct WSTATE
 static void (*engine_walk)(A2_state *st, A2_voice **head, unsigned offset, unsigned frames);
 static A2_voice *(*engine_voicenew)(A2_state *st, A2_voice *parent, unsigned when);
 static void (*engine_voicefree)(A2_state *st, A2_voice **head);
-static WSTATE *wstates[256];
+/* One record per engine state that has been walked: a table that grows (engine states - a2_Render's
+ * substates among them - come and go and nobody tells us).  A record is given to another state only
+ * when the one it was made for is provably closed (the drop-in's serial for it has moved on: no
+ * thread can be inside that state's calls any more); records of states the drop-in does not serve
+ * hold nothing (their lists are only ever filled under the A2AMD_WALK_CUT test hook). */
+static WSTATE **wstates;
+static unsigned n_wstates, cap_wstates;
 static pthread_mutex_t wmtx = PTHREAD_MUTEX_INITIALIZER;
 static __thread WSTATE *last_ws;
 static int walk_off = -1, walk_stats, walk_cut, walk_nocache, walk_nohold, walk_novm;
 
+static inline int wstate_closed(const WSTATE *w)
+{
+	return w->served && *w->view.serial != w->view.serial_value;
+}
+
 static WSTATE *wstate_of(A2_state *st)
 {
 	WSTATE *w = last_ws;
-	int i, f = -1;
+	unsigned i;
 	if(w && w->st == st && w->view.cfg == st->config && (!w->served || *w->view.serial == w->view.serial_value))
 		return w;
 	pthread_mutex_lock(&wmtx);
 	{
-		static unsigned long long tick;
-		int lru = -1;
-		for(i = 0; i < 256; ++i)
-			if(wstates[i] && wstates[i]->st == st)
+		WSTATE *dead = NULL;
+		w = NULL;
+		for(i = 0; i < n_wstates; ++i)
+			if(wstates[i]->st == st)
+			{
+				w = wstates[i];
 				break;
-			else if(!wstates[i] && f < 0)
-				f = i;
-			else if(wstates[i] && (lru < 0 || wstates[i]->last_use < wstates[lru]->last_use))
-				lru = i;
-		if(i < 256)
-			w = wstates[i];
-		else if(f >= 0 && (w = (WSTATE *)calloc(1, sizeof(WSTATE))))
+			}
+			else if(!dead && wstate_closed(wstates[i]))
+				dead = wstates[i];
+		if(!w && dead)
 		{
-			w->st = st;
-			wstates[f] = w;
-		}
-		else if(f < 0 && lru >= 0 && wstates[lru]->cur_visit == 0)
-		{
-			/* states come and go (a2_Render's substates) and nobody tells us: the longest unused
-			 * entry is given to this one; a state that lost its entry while alive starts over */
-			w = wstates[lru];
+			/* (a closed state's record: what it remembers is dropped below, like that of a new
+			 * state at the address of a closed one) */
+			w = dead;
 			w->st = st;
 			w->view.cfg = NULL;
+			w->served = 0;
 		}
-		else
-			w = NULL;
-		if(w)
-			w->last_use = ++tick;
+		if(!w && n_wstates < (1u << 20))
+		{
+			if(n_wstates == cap_wstates)
+			{
+				unsigned nc = cap_wstates ? cap_wstates * 2 : 64;
+				WSTATE **nw = (WSTATE **)realloc(wstates, nc * sizeof(WSTATE *));
+				if(nw)
+				{
+					wstates = nw;
+					cap_wstates = nc;
+				}
+			}
+			if(n_wstates < cap_wstates && (w = (WSTATE *)calloc(1, sizeof(WSTATE))))
+			{
+				w->st = st;
+				wstates[n_wstates++] = w;
+			}
+		}
+		/* (no record to be had: the caller hands the whole list to the engine's own loop) */
 	}
 	pthread_mutex_unlock(&wmtx);
 	if(w && (w->view.cfg != st->config || (w->served && *w->view.serial != w->view.serial_value)))
@@ -193,6 +213,7 @@ static WSTATE *wstate_of(A2_state *st)
 		++w->epoch;
 		++w->hold_gen;		/* (the closed state's contexts, and their holds, are gone) */
 		w->n_held = 0;
+		memset(w->vm_no, 0, sizeof(w->vm_no));
 		w->served = a2amd_units_walkview(st->config, &w->view) == 0;
 		if(!w->served)
 			w->view.cfg = st->config;
@@ -240,9 +261,9 @@ static LIST *list_of(WSTATE *w, A2_voice **head)
 
 static void report(void)
 {
-	int i;
-	for(i = 0; i < 256; ++i)
-		if(wstates[i] && (wstates[i]->skipped || wstates[i]->visited))
+	unsigned i;
+	for(i = 0; i < n_wstates; ++i)
+		if(wstates[i]->skipped || wstates[i]->visited)
 			fprintf(stderr, "a2amd walk: state %p: %llu voice visits skipped, %llu made (%llu of the skipped without "
 					"reading the voice%s); %llu voices handed to the device VM, %llu taken back\n", (void *)wstates[i]->st,
 					wstates[i]->skipped, wstates[i]->visited, wstates[i]->unread,
@@ -254,13 +275,28 @@ static void bind_engine(void)
 	*(void **)&engine_walk = dlsym(RTLD_NEXT, "a2_ProcessVoices");
 	*(void **)&engine_voicenew = dlsym(RTLD_NEXT, "a2_VoiceNew");
 	*(void **)&engine_voicefree = dlsym(RTLD_NEXT, "a2_VoiceFree");
+	{
+		/* This file reads and relinks the engine's OWN structures (A2_voice, A2_state) as the headers
+		 * it was compiled with lay them out: in front of another engine version it would corrupt
+		 * them.  The engine says which one it is. */
+		unsigned (*linked)(void) = NULL;
+		*(void **)&linked = dlsym(RTLD_NEXT, "a2_LinkedVersion");
+		if(!linked || linked() != (unsigned)A2_VERSION)
+		{
+			fprintf(stderr, "a2amd walk: built for Audiality 2 %d.%d.%d.%d, the engine behind it is %s: every voice list "
+					"goes to the engine's own loop\n", A2_MAJOR(A2_VERSION), A2_MINOR(A2_VERSION), A2_MICRO(A2_VERSION),
+					A2_BUILD(A2_VERSION), linked ? "another version" : "not there");
+			walk_off = 1;
+		}
+	}
 	if(!engine_walk || !engine_voicenew || !engine_voicefree)
 	{
 		fprintf(stderr, "a2amd walk: no a2_ProcessVoices / a2_VoiceNew / a2_VoiceFree behind these - load "
 				"liba2amd_walk.so IN FRONT of libaudiality2\n");
 		engine_walk = NULL;
 	}
-	walk_off = getenv("A2AMD_WALK_OFF") != NULL;	/* A/B: every voice is handed to the engine's loop */
+	if(walk_off < 1)
+		walk_off = getenv("A2AMD_WALK_OFF") != NULL;	/* A/B: every voice is handed to the engine's loop */
 	/* A/B: lists are never trusted from memory - every sleeping voice's A2_voice is read */
 	walk_nocache = getenv("A2AMD_WALK_NOCACHE") != NULL;
 	/* A/B: sleeping lists are marked fragment by fragment instead of being put on hold */
@@ -438,7 +474,8 @@ static inline void hint_visit(const A2_voice *v, const UPTR *up)
 
 static inline void mark_default(const WSTATE *w, const ENT *e)
 {
-	if(e->stamp != STAMP_NOUNITS)
+	/* (a backend that has failed hands out no map: map_cap 0, and the state renders silence) */
+	if(e->stamp != STAMP_NOUNITS && (e->slotdev & 0x0fffffffu) < w->view.map_cap[e->slotdev >> 28])
 		w->view.map[e->slotdev >> 28][e->slotdev & 0x0fffffffu] = 1;	/* = amd_quick_process() */
 }
 

@@ -176,6 +176,97 @@ def pad_programs(rng):
     return L
 
 
+def loop_programs(rng):
+    """Seeds >= 2000: voices whose programs keep LOOPING over the part of the instruction set the device VM
+    runs (include/a2amd_vm.h: SURVEY 8 f4) - random delays (milliseconds and ticks), counted and
+    conditional loops inside the endless one, sets, ramps of their own length, arithmetic on work
+    registers - plus the ways out of it: a handler that is sent messages, a kill, a detach, a group that
+    cuts its voices' windows, a parent that ends.  Some loops contain what the VM must refuse (rand, a
+    wave switch): those voices simply stay with the engine."""
+    shapes = [
+        ("wtosc; panmix", "w {w}; p P; a V; pan {pan}", ["p", "a", "pan", "vol", "phase"]),
+        ("wtosc; filter12; panmix", "w {w}; p P; a V; pan {pan}; cutoff (P + 2); q 3", ["p", "a", "cutoff", "q", "lp", "bp", "hp", "pan"]),
+        ("wtosc A; wtosc B; panmix", "A.w {w}; B.w sine; A.p P; B.p (P + .01); A.a V; B.a V; pan {pan}", ["A.p", "B.p", "A.a", "B.a", "pan"]),
+        ("wtosc A; wtosc B; filter12; panmix", "A.w {w}; B.w saw; A.p P; B.p (P - .01); A.a V; B.a V; cutoff (P + 3); q 5",
+         ["A.p", "B.a", "cutoff", "q", "pan"]),
+        ("fm2; panmix", "p P; a V; fb .2; p1 2; a1 .5", ["p", "a", "fb", "p1", "a1", "fb1", "pan"]),
+        ("wtosc; waveshaper; panmix", "w {w}; p P; a V; amount 2", ["amount", "a", "p"]),
+        ("wtosc; panmix 1 2; fbdelay 2 >", "w {w}; p P; a V; fbdelay 13; ldelay 17; rdelay 19", ["fbgain", "lgain", "rgain", "drygain", "a"]),
+    ]
+
+    def value(reg):
+        base = reg.split(".")[-1]
+        if base in ("p", "cutoff"):
+            return f"(P + {pos(r(rng, -1.5, 3))})"
+        if base in ("a", "vol"):
+            return f"(V * {r(rng, 0, 1.3)})"
+        if base == "pan":
+            return pos(r(rng, -1.3, 1.3))
+        if base == "q":
+            return r(rng, 0.002, 25)
+        if base in ("p1",):
+            return r(rng, 0.25, 4)
+        if base == "phase":
+            return r(rng, 0, 1)
+        if base == "amount":
+            return r(rng, 0, 8)
+        return r(rng, 0, 1)
+
+    def step(regs, depth=0):
+        k = rng.random()
+        reg = rng.choice(regs)
+        dly = f"d {r(rng, 0.4, 40, 2)}" if rng.random() < 0.8 else f"td {r(rng, 0.05, 0.5, 3)}"
+        if k < 0.30:
+            return [f"{reg} {value(reg)}; {dly}"]
+        if k < 0.42:
+            return [f"@{reg} {value(reg)}; {dly}"]
+        if k < 0.54:
+            return [f"+{reg} {pos(r(rng, -0.05, 0.05))}; {dly}"]
+        if k < 0.64:
+            return [f"{reg} {value(reg)}; ramp {reg} {r(rng, 1, 60, 1)}; {dly}"]
+        if k < 0.72:
+            return [f"*{reg} {r(rng, 0.7, 1.1)}; +X 1; {dly}"]
+        if k < 0.80 and depth < 2:
+            inner = sum((step(regs, depth + 1) for _ in range(rng.randint(1, 2))), [])
+            return [f"{rng.randint(2, 5)} {{ " + "; ".join(inner) + " }"]
+        if k < 0.88 and depth < 2:
+            inner = step(regs, depth + 1)
+            return [f"if X > {rng.randint(1, 6)} {{ X 0; " + "; ".join(inner) + " }"]
+        if k < 0.92:
+            return [f"+tr {pos(r(rng, -0.05, 0.05))}; {reg} {value(reg)}; {dly}", "if tr > .3 { tr 0 }", "if tr < -.3 { tr 0 }"]
+        if k < 0.95:
+            return [f"+{reg} (rand .02); {dly}"]           # the engine's RNG: not for the device
+        return [f"set; {dly}"]
+
+    L, names = [], []
+    for i in range(rng.randint(4, 7)):
+        st, setup, regs = rng.choice(shapes)
+        su = setup.format(w=rng.choice(WAVES[:9]), pan=pos(r(rng, -1, 1)))
+        body = sum((step(regs) for _ in range(rng.randint(2, 6))), [])
+        if rng.random() < 0.9:      # (else: an iteration may go by without a delay - the engine's A2_OVERLOAD ends such a voice,
+            body.append(f"d {r(rng, 0.5, 12, 2)}")     # and the device VM's analysis must have refused it)
+        tempo = f"\ttempo {rng.randint(90, 200)} {rng.choice([2, 4, 8])}\n" if rng.random() < 0.5 else ""
+        handler = ""
+        if rng.random() < 0.4:
+            reg = rng.choice(regs)
+            off = "; ".join(f"{a} 0" for a in regs if a.split(".")[-1] == "a") or "vol 0"
+            handler = f".rel\t{off}; d {r(rng, 2, 30, 1)}\n\t1(NP) {{ P NP; {reg} {value(reg)} }}\n\t2() {{ force rel }}\n"
+        name = f"L{i}"
+        names.append((name, bool(handler)))
+        L.append(f"{name}(P V)\n{{\n\tstruct {{ {st} }}\n{tempo}\t{su}; set\n\t!X 0\n\tfor {{\n\t\t" +
+                 "\n\t\t".join(body) + f"\n\t}}\n{handler}}}\n")
+    plain = [n for n, h in names]
+    # a group whose own program wakes every few ms: the voices under it are processed window by window
+    L.append("LG(P V)\n{\n\tstruct { inline 0 2; panmix 2 2; xinsert 2 > }\n\tvol .8; set\n" +
+             "".join(f"\t{rng.choice(plain)} (P + {pos(r(rng, -1, 1))}) V\n" for _ in range(rng.randint(1, 3))) +
+             f"\tfor {{ +pan .07; d {r(rng, 1.5, 9, 2)}; if pan > 1 {{ pan -1 }} }}\n}}\n")
+    # ... and one that ends, with looping voices under it
+    L.append("LM(P V Life)\n{\n\tstruct { inline 0 2; panmix 2 2; xinsert 2 > }\n" +
+             "".join(f"\t{rng.choice(plain)} (P + {pos(r(rng, -1, 1))}) V\n" for _ in range(rng.randint(1, 3))) +
+             "\td Life\n}\n")
+    return L, names
+
+
 def make_script(seed):
     rng = random.Random(seed)
     nv = rng.randint(4, 8)
@@ -196,6 +287,14 @@ def make_script(seed):
         for _ in range(rng.randint(1, 3)):
             life = rng.choice(["0", r(rng, 200, 1500, 0)])
             main.append(f"\t{rng.choice(['PG', 'PGG'])} {pos(r(rng, -1.5, 1))} (V * .2) {rng.randint(2, 9)} {life}")
+    if seed >= 2000:
+        lp, lnames = loop_programs(rng)
+        parts += lp
+        for name, _h in lnames:
+            main.append(f"\t{name} {pos(r(rng, -1.5, 1))} (V * .3)")
+        main.append(f"\tLG {pos(r(rng, -1, 1))} (V * .3)")
+        main.append(f"\tLM {pos(r(rng, -1, 1))} (V * .3) {r(rng, 150, 900, 0)}")
+        main.append("\td 40")
     main += ["\t!P 0", "\tfor {"]
     for _ in range(rng.randint(6, 14)):
         if rng.random() < 0.25:
@@ -203,6 +302,14 @@ def make_script(seed):
             vid = rng.randint(1, 6)
             how = rng.choice([f"{vid}<1", f"kill {vid}", f"detach {vid}"])
             main.append(f"\t\t{vid}:{rng.choice(held)} (P + {pos(r(rng, -1, 1))}) V; d {delay(rng)}; {how}; d {delay(rng)}")
+            continue
+        if seed >= 2000 and rng.random() < 0.35:
+            # a looping voice with an id: sent messages while its loop runs, then released, killed or detached
+            name, has_handler = rng.choice(lnames)
+            vid = rng.randint(7, 12)
+            how = rng.choice([f"kill {vid}", f"detach {vid}"] + ([f"{vid}<2"] if has_handler else []))
+            msg = f"{vid}<1 (P + {pos(r(rng, -1, 1))}); d {delay(rng)}; " if has_handler else ""
+            main.append(f"\t\t{vid}:{name} (P + {pos(r(rng, -1, 1))}) (V * .3); d {delay(rng)}; {msg}{how}; d {delay(rng)}")
             continue
         prog = rng.choice(names + buses)
         main.append(f"\t\t{prog} (P + {pos(r(rng, -1.5, 1))}) V; d {delay(rng)}")
