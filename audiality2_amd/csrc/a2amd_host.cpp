@@ -941,6 +941,7 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 		break;
 	  case A2AMD_FILTER12: {	// the head of f12_process, filter12.c:86-96
 		bool was = u.cutoff.timer != 0;
+		const bool moving = cutoff_moving(u);
 		ramp_prepare(u.cutoff, (int)frames);
 		if(u.cutoff.delta) {
 			ramp_run(u.cutoff, (int)frames);
@@ -948,8 +949,8 @@ int a2amd_unit_process(a2amd_ctx *c, int ui, unsigned offset, unsigned frames, u
 					f12_coeff(c->ptab, u.cutoff.value, c->cfg.samplerate), 0, 0);
 		}
 		c->n_cutoff_ramps += (int)(u.cutoff.timer != 0) - (int)was;
-		if(was && !u.cutoff.timer)
-			v.plain = 0;	// (the ramp has arrived: the voice may be plain again)
+		if(moving && !cutoff_moving(u))
+			v.plain = 0;	// (the ramp has arrived and the ramper has snapped to its target: the voice may be plain again)
 		break;
 	  }
 	  case A2AMD_INLINE:
@@ -991,7 +992,7 @@ void classify_plain(a2amd_ctx *c, HVoice &v)
 				return;
 			break;
 		  case A2AMD_FILTER12:
-			if(u.cutoff.timer || u.cutoff.delta)
+			if(cutoff_moving(u))
 				return;
 			break;
 		  case A2AMD_INLINE: case A2AMD_XINSERT: case A2AMD_XSINK: case A2AMD_XSOURCE:
@@ -1057,7 +1058,7 @@ int a2amd_voice_process(a2amd_ctx *c, int head, unsigned offset, unsigned frames
 	for(int k = 0; k < n; ++k) {
 		const HUnit &u = c->units[v.unit[k]];
 		if((u.kind == A2AMD_WTOSC && u.mode == A2D_OSC_NOISE) || u.xio_mode ||
-				(u.kind == A2AMD_FILTER12 && (u.cutoff.timer || u.cutoff.delta)))
+				(u.kind == A2AMD_FILTER12 && cutoff_moving(u)))
 			return 0;
 	}
 	return (dbgw & 2) ? 0 : 1;
@@ -1075,7 +1076,7 @@ int a2amd_voice_markable(a2amd_ctx *c, int ui)
 	for(int k = 0; k < v.nunits; ++k) {
 		const HUnit &u = c->units[v.unit[k]];
 		if((u.kind == A2AMD_WTOSC && u.mode == A2D_OSC_NOISE) || u.xio_mode ||
-				(u.kind == A2AMD_FILTER12 && (u.cutoff.timer || u.cutoff.delta)))
+				(u.kind == A2AMD_FILTER12 && cutoff_moving(u)))
 			return 0;
 	}
 	return 1;

@@ -514,6 +514,12 @@ static inline void unhold(a2amd_ctx *c, int vi)
 	}
 }
 
+// filter12's cutoff ramper, which lives on the host: does it still need the engine's Process calls?
+// Not only while it ramps: the call AFTER a ramp's last window is the one in which a2_PrepareRamper
+// snaps the value to the target (a2_dsp.h:131-135) - a ramp's tail can end a frame's worth short of it -
+// and the next a2_SetRamper starts from that value.  Only a ramper that has snapped may be left alone
+// (the voice "plain", its default windows reported through the map).
+inline bool cutoff_moving(const HUnit &u) { return u.cutoff.timer || u.cutoff.delta || u.cutoff.value != u.cutoff.target; }
 // (the wavetable leaf kernels only know mip-mapped waves, "off" and noise)
 inline bool leaf_mode(int mode) { return mode == A2D_OSC_MIPWAVE || mode == A2D_OSC_OFF || mode == A2D_OSC_NOISE; }
 // a tap the frame-parallel delay kernel can take: at least one fragment long, and
