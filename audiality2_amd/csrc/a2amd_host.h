@@ -240,6 +240,8 @@ struct VmHost {
 	std::vector<HVm> vms;
 	std::vector<int> free_slots;
 	std::vector<HVmProg> progs;
+	struct Proof { int prog; unsigned pc; int32_t tick; uint32_t msdur; a2amd_vm_info info; };
+	std::vector<Proof> proofs;	// a2amd_vm_analyze() results, by (program, pc, tick)
 	std::vector<uint32_t> code;	// host copy of the code pool
 	size_t code_uploaded = 0;	// words of it the device has
 	std::vector<int> pending;	// slots adopted in the open batch

@@ -553,7 +553,9 @@ int vm_build_lists(a2amd_ctx *c)
 		}
 		m.cls_lists.clear();
 		for(int k = 0; k < 3; ++k) {
-			std::stable_sort(cls[k].begin(), cls[k].end(), [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; });
+			auto by_bus = [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; };
+			if(!std::is_sorted(cls[k].begin(), cls[k].end(), by_bus))	// (slots follow the walk: usually grouped already)
+				std::stable_sort(cls[k].begin(), cls[k].end(), by_bus);
 			m.n_cls[k] = (int)cls[k].size();
 			m.cls_lists.insert(m.cls_lists.end(), cls[k].begin(), cls[k].end());
 		}
@@ -771,8 +773,26 @@ int a2amd_vm_adopt(a2amd_ctx *c, int head, int prog, const a2amd_vm_state *st, c
 			need_f1 = true;
 		}
 	}
+	// (thousands of voices of one program are adopted at the same few pcs: the proof is kept)
 	a2amd_vm_info info;
-	if(analyze(m.code.data() + p.off, p.n, st->pc, st->r[A2AMD_VM_R_TICK], msdur, &info))
+	{
+		const int32_t tick = st->r[A2AMD_VM_R_TICK];
+		bool hit = false;
+		for(const VmHost::Proof &q : m.proofs)
+			if(q.prog == prog && q.pc == st->pc && q.tick == tick && q.msdur == msdur) {
+				info = q.info;
+				hit = true;
+				break;
+			}
+		if(!hit) {
+			analyze(m.code.data() + p.off, p.n, st->pc, tick, msdur, &info);
+			if(m.proofs.size() >= 256)
+				m.proofs.erase(m.proofs.begin());
+			VmHost::Proof q = { prog, st->pc, tick, msdur, info };
+			m.proofs.push_back(q);
+		}
+	}
+	if(info.reason)
 		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: %s (opcode %d at %d)", reason_text(info.reason), info.opcode, info.at);
 	bool any = false;
 	for(int r = 0; r < A2AMD_VM_REGISTERS; ++r) {
