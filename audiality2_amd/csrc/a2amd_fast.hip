@@ -1389,6 +1389,27 @@ DEV int filt_window_s(FiltS &fs, int x, int off, int len, int lane)
 	return y;
 }
 
+// Round 4: the filter of the records kernels with lane = VOICE.  filt_window_s above runs filter12's
+// recurrence on the scalar unit, a window at a time, in the middle of the voice's walk: ~20 scalar
+// instructions per frame and voice at the 5-7 cycles a lone scalar stream issues at - two thirds of
+// what a scripted filter voice costs.  With RECS_VFILT the walk (lane = frame, scalar control) only
+// renders the oscillators of a window into the voice's row of an LDS tile and works out what the
+// window needs of the filter and of the pan stage - f0 and its step (the host's / the device VM's
+// coefficient records), the q ramp, the mix levels; the volume and pan rampers' values and steps -
+// in closed form (none of it depends on the audio), as one 12-word entry of a small pool.  When the
+// chunk is walked (or the pool is full) the wavefront turns round: every lane takes ONE VOICE and
+// runs the recurrence over its pending windows in place - 12 vector instructions per frame for up
+// to 64 voices at once - then, lane = frame again, the pan stage reads the rows back window by
+// window.  Filter state (d1, d2) never leaves the lane it is parked in.
+#ifndef RECS_VFILT
+#define RECS_VFILT 1
+#endif
+#define RECS_ENTRY 12		// words per pending window: [j | off << 4 | len << 12 | clamp << 20, f0, df, qv, qd, lp, bp, hp, vol, dvol, pan, dpan]
+DEV int recs_pool_cap(int vpw) { return vpw * RECS_FCH * 2 + 16; }
+DEV int recs_wave_words(int vpw) { return RECS_FCH * vpw * 65 + recs_pool_cap(vpw) * RECS_ENTRY; }
+static int recs_wave_words_host(int vpw) { return RECS_FCH * vpw * 65 + (vpw * RECS_FCH * 2 + 16) * RECS_ENTRY; }
+extern __shared__ int recs_dyn[];
+
 // (the body of the kernels below: gw = this wavefront's index among those of its class)
 typedef int RecsPart[RECS_WPB][RECS_FCH * 2][64];
 // A voice's next command record, fetched through the scalar cache and ahead of its use: the load is
@@ -1512,9 +1533,112 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 		for(int j = 0; j < RECS_FCH; ++j)
 			acc0[j] = acc1[j] = 0;
 		int cur_off = nv ? rdl(my_off, 0) : -1, cur_nch = rdl(my_nch, 0);
+		// RECS_VFILT: the windows walked but not yet filtered and panned - per voice (lane = voice) a run of
+		// pool entries [wbeg, wend) - and the turn-round that works them off
+		constexpr bool VF = FILT && RECS_VFILT;
+		int wbeg = 0, wend = 0, pool_n = 0;
+		int *const tile = recs_dyn + wv * recs_wave_words(vpw);
+		int *const pool = tile + RECS_FCH * vpw * 65;
+		const int pool_cap = recs_pool_cap(vpw);
+		auto turn = [&]() {
+			if(!pool_n)
+				return;
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			{	// lane = voice: f12_process's recurrence (filter12.c:97-118) over this voice's pending windows, in place
+				int e = wbeg, s = 0, len = 0, base = 0;
+				int f0v = 0, df = 0, qv = 0, qd = 0, lp = 0, bp = 0, hp = 0;
+				int d1 = sf[FS_D1], d2 = sf[FS_D2];
+				for(;;) {
+					if(s >= len && e < wend) {
+						const int *en = pool + e * RECS_ENTRY;
+						const int w0 = en[0];
+						f0v = en[1]; df = en[2]; qv = en[3]; qd = en[4]; lp = en[5]; bp = en[6]; hp = en[7];
+						base = ((w0 & 15) * vpw + lane) * 65 + ((w0 >> 4) & 255);
+						len = (w0 >> 12) & 255;
+						s = 0;
+						++e;
+					}
+					const bool act = s < len;
+					if(!__ballot(act))
+						break;
+					if(act) {
+						// (up to four frames per trip: their inputs are read before the first one's chain starts)
+						const int n4 = min(4, len - s);
+						int xin[4];
+#pragma unroll
+						for(int k = 0; k < 4; ++k)
+							xin[k] = k < n4 ? tile[base + s + k] : 0;
+#pragma unroll
+						for(int k = 0; k < 4; ++k)
+							if(k < n4) {
+								const int f = f0v >> 12, qq = qv >> 12;
+								const int d1s = d1 >> 4;
+								const int l = wadd(d2, wmul(f, d1s) >> 8);
+								const int h = wsub(wsub(xin[k] >> 5, l), wmul(qq, d1s) >> 8);
+								const int b = wadd(wmul(f, h >> 4) >> 8, d1);
+								tile[base + s + k] = wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3;
+								d1 = b;
+								d2 = l;
+								f0v = wadd(f0v, df);
+								qv = wadd(qv, qd);
+							}
+						s += n4;
+					}
+				}
+				sf[FS_D1] = d1;
+				sf[FS_D2] = d2;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			// lane = frame: panmix_process12 (panmix.c:78-125) window by window, voice by voice
+			for(int v = 0; v < nv; ++v) {
+				const int eb = rdl(wbeg, v), ee = rdl(wend, v);
+				if(eb == ee)
+					continue;
+				const int voff = rdl(my_off, v);
+				if(voff != cur_off) {
+					flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+					cur_off = voff;
+					cur_nch = rdl(my_nch, v);
+				}
+				for(int e = eb; e < ee; ++e) {
+					const int *en = pool + e * RECS_ENTRY;
+					const int w0 = rfl(en[0]), volv = rfl(en[8]), vold = rfl(en[9]), panv = rfl(en[10]), pand = rfl(en[11]);
+					const int j = w0 & 15, off = (w0 >> 4) & 255, len = (w0 >> 12) & 255;
+					const bool clamp = ((w0 >> 20) & 1) != 0;
+					const int fl = lane - off;
+					int o0 = 0, o1 = 0;
+					if((unsigned)fl < (unsigned)len) {
+						const int y = tile[(j * vpw + v) * 65 + lane];
+						int vk = wadd(volv, wmul(vold, fl));
+						int pk = wadd(panv, wmul(pand, fl));
+						int vp = mul64s(pk, vk, 24);
+						int v0 = wsub(vk, vp), v1 = wadd(vk, vp);
+						if(clamp) {
+							int lim = wshl(vk, 1);
+							if(v0 > lim) v0 = lim;
+							if(v1 > lim) v1 = lim;
+						}
+						o0 = mul64s(y, v0, 24);
+						o1 = mul64s(y, v1, 24);
+					}
+#pragma unroll
+					for(int jj = 0; jj < RECS_FCH; ++jj)
+						if(jj == j) {
+							acc0[jj] = wadd(acc0[jj], o0);
+							acc1[jj] = wadd(acc1[jj], o1);
+						}
+				}
+			}
+			wbeg = wend = 0;
+			pool_n = 0;
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		};
 		for(int v = 0; v < nv; ++v) {
 			const int voff = rdl(my_off, v);
-			if(voff != cur_off) {
+			if(!VF && voff != cur_off) {
 				flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
 				cur_off = voff;
 				cur_nch = rdl(my_nch, v);
@@ -1558,9 +1682,46 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 						x = wadd(osc_fragment_end(pa_), osc_fragment_end(pb_));
 					} else
 						x = osc_fragment_s(g, os[0], len, fl);
+					if(VF) {
+						// the window goes on the list: its oscillator samples into the voice's row, what the
+						// filter and the pan stage will need of it - all closed forms of the control state -
+						// into a pool entry (f12_process's head, filter12.c:86-96; panmix_process12's, panmix.c:84-95)
+						if(pool_n == pool_cap)
+							turn();
+						ramp_prepare_s(fs.q, len);
+						const int wf0 = fs.f1;
+						int wdf = 0;
+						if(fs.ramp) {
+							fs.f1 = fs.f1next;
+							wdf = rfl(wadd(wsub(fs.f1, wf0), len >> 1) / len);
+							fs.ramp = 0;
+						}
+						const int wqv = fs.q.value, wqd = fs.q.delta;
+						ramp_run(fs.q, len);
+						const bool clamp = pan.target > 0xffffff || pan.target < -0xffffff ||
+								pan.value > 0xffffff || pan.value < -0xffffff;
+						ramp_prepare_s(vol, len);
+						ramp_prepare_s(pan, len);
+						if((unsigned)fl < (unsigned)len)
+							tile[(j * vpw + v) * 65 + lane] = x;
+						int *en = pool + pool_n * RECS_ENTRY;
+						if(lane == 0) {
+							en[0] = j | (off << 4) | (len << 12) | ((int)clamp << 20);
+							en[1] = wf0; en[2] = wdf; en[3] = wqv; en[4] = wqd;
+							en[5] = fs.lp; en[6] = fs.bp; en[7] = fs.hp;
+							en[8] = vol.value; en[9] = vol.delta; en[10] = pan.value; en[11] = pan.delta;
+						}
+						ramp_run(vol, len);
+						ramp_run(pan, len);
+						if(rdl(wbeg, v) == rdl(wend, v))
+							WRL(wbeg, pool_n);
+						++pool_n;
+						WRL(wend, pool_n);
+					} else {
 					if(FILT)
 						x = filt_window_s(fs, x, off, len, lane);
 					pan_fragment_s(vol, pan, x, len, fl, o0, o1);
+					}
 #ifdef RECS_PROF
 					asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
 					t_win += __builtin_readcyclecounter() - w0 + (o0 & 0);
@@ -1604,6 +1765,10 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 								fs.lp = 65536 >> 8;
 								fs.bp = fs.hp = fs.d1 = fs.d2 = fs.f1next = fs.ramp = 0;
 								fs.f1 = value;
+								if(VF) {	// (the recurrence's state lives in the voice's lane: nothing of this
+									WRL(sf[FS_D1], 0);	// voice is pending - it was not alive before)
+									WRL(sf[FS_D2], 0);
+								}
 							}
 							if(u == NOSC + FILT) {	// panmix_Initialize, panmix.c:252-284
 								ramp_init(vol, 65536);
@@ -1681,13 +1846,18 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 				WRL(sf[FS_Q], fs.q.value); WRL(sf[FS_Q + 1], fs.q.target); WRL(sf[FS_Q + 2], fs.q.delta);
 				WRL(sf[FS_Q + 3], fs.q.timer);
 				WRL(sf[FS_LP], fs.lp); WRL(sf[FS_BP], fs.bp); WRL(sf[FS_HP], fs.hp); WRL(sf[FS_F1], fs.f1);
-				WRL(sf[FS_D1], fs.d1); WRL(sf[FS_D2], fs.d2); WRL(sf[FS_F1NEXT], fs.f1next); WRL(sf[FS_RAMP], fs.ramp);
+				if(!VF) {
+					WRL(sf[FS_D1], fs.d1); WRL(sf[FS_D2], fs.d2);
+				}
+				WRL(sf[FS_F1NEXT], fs.f1next); WRL(sf[FS_RAMP], fs.ramp);
 			}
 			WRL(sp[0], vol.value); WRL(sp[1], vol.target); WRL(sp[2], vol.delta); WRL(sp[3], vol.timer);
 			WRL(sp[4], pan.value); WRL(sp[5], pan.target); WRL(sp[6], pan.delta); WRL(sp[7], pan.timer);
 			WRL(rcur, rc);
 			WRL(act, active);
 		}
+		if(VF)
+			turn();
 		// Sixteen thousand voices playing straight into one bus are as many atomic
 		// adds on the same 512 bytes per fragment; the workgroup sums its wavefronts'
 		// chunks in LDS first (neighbours in the list share their bus: it is sorted).
@@ -1867,7 +2037,9 @@ int a2d_launch_leaf_recs_all(const A2DParams *dparams, const A2DParams &hp, cons
 	}
 	if(!nblocks)
 		return 0;
-	hipLaunchKernelGGL(k_leaf_recs_all, dim3(nblocks), dim3(64 * wpb), 0, (hipStream_t)stream, dparams, segs, vpw,
+	// (dynamic LDS: the filter kinds' window rows and pool, RECS_VFILT)
+	hipLaunchKernelGGL(k_leaf_recs_all, dim3(nblocks), dim3(64 * wpb), (size_t)wpb * recs_wave_words_host(vpw) * sizeof(int),
+			(hipStream_t)stream, dparams, segs, vpw,
 			hp.voices, hp.ustate, hp.vactive, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
 	return (int)hipGetLastError();
 }
@@ -1878,10 +2050,19 @@ int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc
 	if(nlist <= 0)
 		return 0;
 	vpw = min(max(vpw, 1), 64);
+	if(filt && RECS_VFILT)
+		vpw = min(vpw, 8);	// (rows of four fragments per voice in LDS)
 	const int nwaves = (nlist + vpw - 1) / vpw;
-	const int wpb = recs_wpb(nwaves);
+	int wpb = recs_wpb(nwaves);
+	size_t dyn = 0;
+	if(filt && RECS_VFILT) {
+		// the workgroup's static 32 KB (bus sums) + its wavefronts' rows and pools within 64 KB
+		const size_t per_wave = (size_t)recs_wave_words_host(vpw) * sizeof(int);
+		wpb = (int)max((size_t)1, min((size_t)wpb, (size_t)(30 * 1024) / per_wave));
+		dyn = wpb * per_wave;
+	}
 	const int nblocks = (nwaves + wpb - 1) / wpb;
-#define RECS_LAUNCH(N, F) hipLaunchKernelGGL((k_leaf_recs<N, F>), dim3(nblocks), dim3(64 * wpb), 0, \
+#define RECS_LAUNCH(N, F) hipLaunchKernelGGL((k_leaf_recs<N, F>), dim3(nblocks), dim3(64 * wpb), dyn, \
 		(hipStream_t)stream, dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.vactive, hp.wavepool, \
 		hp.waves, hp.ptab, hp.busmem, skip_empty)
 	if(nosc == 1 && !filt)
