@@ -1405,9 +1405,10 @@ DEV int filt_window_s(FiltS &fs, int x, int off, int len, int lane)
 #define RECS_VFILT 1
 #endif
 #define RECS_ENTRY 12		// words per pending window: [j | off << 4 | len << 12 | clamp << 20, f0, df, qv, qd, lp, bp, hp, vol, dvol, pan, dpan]
-DEV int recs_pool_cap(int vpw) { return vpw * RECS_FCH * 2 + 16; }
-DEV int recs_wave_words(int vpw) { return RECS_FCH * vpw * 65 + recs_pool_cap(vpw) * RECS_ENTRY; }
-static int recs_wave_words_host(int vpw) { return RECS_FCH * vpw * 65 + (vpw * RECS_FCH * 2 + 16) * RECS_ENTRY; }
+#define RECS_VF_FCH 2		// fragments per chunk on that path (rows of the chunk live in LDS)
+DEV int recs_pool_cap(int vpw) { return vpw * RECS_VF_FCH * 2 + 16; }
+DEV int recs_wave_words(int vpw) { return RECS_VF_FCH * vpw * 65 + recs_pool_cap(vpw) * RECS_ENTRY; }
+static int recs_wave_words_host(int vpw) { return RECS_VF_FCH * vpw * 65 + (vpw * RECS_VF_FCH * 2 + 16) * RECS_ENTRY; }
 extern __shared__ int recs_dyn[];
 
 // (the body of the kernels below: gw = this wavefront's index among those of its class)
@@ -1443,6 +1444,10 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	const A2DParams &p = *pp;
 	const int wv = rfl((int)(threadIdx.x >> 6));	// (wave-uniform, and known to the compiler as such)
 	const int lane = threadIdx.x & 63;
+	// (skip_empty bit 1: the launcher gave this launch the lane = voice filter, RECS_VFILT - worth it from a
+	// few voices per wavefront up; a song's one-voice wavefronts keep the scalar recurrence)
+	const bool VF = FILT && RECS_VFILT && (skip_empty & 2);
+	skip_empty &= 1;
 	const int first = gw * vpw;
 	// (a wavefront past the end of the list still meets the others at the barriers)
 	const int nv = max(0, min(vpw, nlist - first));
@@ -1526,8 +1531,9 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 #ifdef RECS_PROF
 	const long long t_pro = __builtin_readcyclecounter();
 #endif
-	for(int f0 = 0; f0 < nfrags; f0 += RECS_FCH) {
-		const int nf = min((int)RECS_FCH, nfrags - f0);
+	const int fch = VF ? RECS_VF_FCH : RECS_FCH;
+	for(int f0 = 0; f0 < nfrags; f0 += fch) {
+		const int nf = min(fch, nfrags - f0);
 		int acc0[RECS_FCH], acc1[RECS_FCH];
 #pragma unroll
 		for(int j = 0; j < RECS_FCH; ++j)
@@ -1535,10 +1541,9 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 		int cur_off = nv ? rdl(my_off, 0) : -1, cur_nch = rdl(my_nch, 0);
 		// RECS_VFILT: the windows walked but not yet filtered and panned - per voice (lane = voice) a run of
 		// pool entries [wbeg, wend) - and the turn-round that works them off
-		constexpr bool VF = FILT && RECS_VFILT;
 		int wbeg = 0, wend = 0, pool_n = 0;
 		int *const tile = recs_dyn + wv * recs_wave_words(vpw);
-		int *const pool = tile + RECS_FCH * vpw * 65;
+		int *const pool = tile + RECS_VF_FCH * vpw * 65;
 		const int pool_cap = recs_pool_cap(vpw);
 		auto turn = [&]() {
 			if(!pool_n)
@@ -1560,30 +1565,36 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 						++e;
 					}
 					const bool act = s < len;
-					if(!__ballot(act))
+					const unsigned long long am = __ballot(act);
+					if(!am)
 						break;
-					if(act) {
-						// (up to four frames per trip: their inputs are read before the first one's chain starts)
-						const int n4 = min(4, len - s);
-						int xin[4];
-#pragma unroll
-						for(int k = 0; k < 4; ++k)
-							xin[k] = k < n4 ? tile[base + s + k] : 0;
-#pragma unroll
-						for(int k = 0; k < 4; ++k)
-							if(k < n4) {
-								const int f = f0v >> 12, qq = qv >> 12;
-								const int d1s = d1 >> 4;
-								const int l = wadd(d2, wmul(f, d1s) >> 8);
-								const int h = wsub(wsub(xin[k] >> 5, l), wmul(qq, d1s) >> 8);
-								const int b = wadd(wmul(f, h >> 4) >> 8, d1);
-								tile[base + s + k] = wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3;
-								d1 = b;
-								d2 = l;
-								f0v = wadd(f0v, df);
-								qv = wadd(qv, qd);
-							}
-						s += n4;
+					auto step = [&](int xin, int at) {
+						const int f = f0v >> 12, qq = qv >> 12;
+						const int d1s = d1 >> 4;
+						const int l = wadd(d2, wmul(f, d1s) >> 8);
+						const int h = wsub(wsub(xin >> 5, l), wmul(qq, d1s) >> 8);
+						const int b = wadd(wmul(f, h >> 4) >> 8, d1);
+						tile[at] = wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3;
+						d1 = b;
+						d2 = l;
+						f0v = wadd(f0v, df);
+						qv = wadd(qv, qd);
+					};
+					if(!__ballot(act && len - s < 4)) {
+						// every busy lane has four frames of its window left: four steps, their inputs read
+						// before the first one's chain starts, nothing predicated but the lanes themselves
+						if(act) {
+							const int at = base + s;
+							const int x0 = tile[at], x1 = tile[at + 1], x2 = tile[at + 2], x3 = tile[at + 3];
+							step(x0, at);
+							step(x1, at + 1);
+							step(x2, at + 2);
+							step(x3, at + 3);
+							s += 4;
+						}
+					} else if(act) {
+						step(tile[base + s], base + s);
+						++s;
 					}
 				}
 				sf[FS_D1] = d1;
@@ -1603,8 +1614,8 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 					cur_nch = rdl(my_nch, v);
 				}
 				for(int e = eb; e < ee; ++e) {
-					const int *en = pool + e * RECS_ENTRY;
-					const int w0 = rfl(en[0]), volv = rfl(en[8]), vold = rfl(en[9]), panv = rfl(en[10]), pand = rfl(en[11]);
+					const int ev = pool[e * RECS_ENTRY + min(lane, RECS_ENTRY - 1)];	// (the entry, a word per lane)
+					const int w0 = rdl(ev, 0), volv = rdl(ev, 8), vold = rdl(ev, 9), panv = rdl(ev, 10), pand = rdl(ev, 11);
 					const int j = w0 & 15, off = (w0 >> 4) & 255, len = (w0 >> 12) & 255;
 					const bool clamp = ((w0 >> 20) & 1) != 0;
 					const int fl = lane - off;
@@ -1704,12 +1715,16 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 						ramp_prepare_s(pan, len);
 						if((unsigned)fl < (unsigned)len)
 							tile[(j * vpw + v) * 65 + lane] = x;
-						int *en = pool + pool_n * RECS_ENTRY;
-						if(lane == 0) {
-							en[0] = j | (off << 4) | (len << 12) | ((int)clamp << 20);
-							en[1] = wf0; en[2] = wdf; en[3] = wqv; en[4] = wqd;
-							en[5] = fs.lp; en[6] = fs.bp; en[7] = fs.hp;
-							en[8] = vol.value; en[9] = vol.delta; en[10] = pan.value; en[11] = pan.delta;
+						{
+							int ev = 0;
+							ev = writelane_s(ev, j | (off << 4) | (len << 12) | ((int)clamp << 20), 0);
+							ev = writelane_s(ev, wf0, 1); ev = writelane_s(ev, wdf, 2);
+							ev = writelane_s(ev, wqv, 3); ev = writelane_s(ev, wqd, 4);
+							ev = writelane_s(ev, fs.lp, 5); ev = writelane_s(ev, fs.bp, 6); ev = writelane_s(ev, fs.hp, 7);
+							ev = writelane_s(ev, vol.value, 8); ev = writelane_s(ev, vol.delta, 9);
+							ev = writelane_s(ev, pan.value, 10); ev = writelane_s(ev, pan.delta, 11);
+							if(lane < RECS_ENTRY)
+								pool[pool_n * RECS_ENTRY + lane] = ev;
 						}
 						ramp_run(vol, len);
 						ramp_run(pan, len);
@@ -1865,7 +1880,7 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 #ifdef RECS_PROF
 			const long long r0 = __builtin_readcyclecounter();
 #endif
-			const int pb = (f0 / RECS_FCH) & 1;
+			const int pb = (f0 / fch) & 1;
 			if((int)(blockDim.x >> 6) == 1) {
 				// (a launch of a few dozen voices - a song - comes with ONE wavefront per workgroup:
 				// nobody to sum with, no barrier, no trip through LDS)
@@ -2038,8 +2053,8 @@ int a2d_launch_leaf_recs_all(const A2DParams *dparams, const A2DParams &hp, cons
 	if(!nblocks)
 		return 0;
 	// (dynamic LDS: the filter kinds' window rows and pool, RECS_VFILT)
-	hipLaunchKernelGGL(k_leaf_recs_all, dim3(nblocks), dim3(64 * wpb), (size_t)wpb * recs_wave_words_host(vpw) * sizeof(int),
-			(hipStream_t)stream, dparams, segs, vpw,
+	// (plumbing-sized launches keep the scalar recurrence: no rows, no pool)
+	hipLaunchKernelGGL(k_leaf_recs_all, dim3(nblocks), dim3(64 * wpb), 0, (hipStream_t)stream, dparams, segs, vpw,
 			hp.voices, hp.ustate, hp.vactive, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
 	return (int)hipGetLastError();
 }
@@ -2050,12 +2065,25 @@ int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc
 	if(nlist <= 0)
 		return 0;
 	vpw = min(max(vpw, 1), 64);
-	if(filt && RECS_VFILT)
-		vpw = min(vpw, 8);	// (rows of four fragments per voice in LDS)
+	// The lane = voice filter (RECS_VFILT) pays from a few voices per wavefront up: at 4 096 voices and
+	// more the launch gets 4-8 voices per wavefront (fewer, fatter wavefronts: the scalar walk of a voice
+	// is latency, the recurrence 12 vector instructions per frame for all of a wavefront's voices).
+	// (measured, 64 fragments of voices with a split window and a pitch ramp in every second fragment: 16 384
+	// voices 3.46 -> 2.24 ms, 65 536: 13.5 -> 10.0; 4 096: 0.99 -> 1.36 - hence the threshold.  A2AMD_VFILT=0 / 1
+	// forces it off / on: A/B measurements, and the tests run the path at sizes an oracle can follow.)
+	const char *fv = getenv("A2AMD_VFILT");
+	const int force_vf = fv ? atoi(fv) : -1;
+	const bool vf = filt && RECS_VFILT && (force_vf >= 0 ? force_vf != 0 : nlist >= 12288);
+	if(vf && !getenv("A2AMD_RVPW"))
+		vpw = min(max((nlist + 4095) / 4096, 4), 8);
+	if(vf)
+		vpw = min(vpw, 16);
 	const int nwaves = (nlist + vpw - 1) / vpw;
 	int wpb = recs_wpb(nwaves);
 	size_t dyn = 0;
-	if(filt && RECS_VFILT) {
+	if(vf)
+		skip_empty |= 2;
+	if(vf) {
 		// the workgroup's static 32 KB (bus sums) + its wavefronts' rows and pools within 64 KB
 		const size_t per_wave = (size_t)recs_wave_words_host(vpw) * sizeof(int);
 		wpb = (int)max((size_t)1, min((size_t)wpb, (size_t)(30 * 1024) / per_wave));

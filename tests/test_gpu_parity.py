@@ -394,6 +394,37 @@ def test_wavetable_leaf_kernel_executes_records(oracle_lib, monkeypatch, chain, 
     assert first_diff(got, want) is None
 
 
+@pytest.mark.parametrize("chain,groups", [("osc-filter-pan", 0), ("osc-filter-pan", 2), ("osc2-filter-pan", 3)])
+@pytest.mark.parametrize("rvpw", [1, 3, 4, 16])
+def test_records_kernel_filter_with_lane_per_voice(oracle_lib, monkeypatch, chain, groups, rvpw):
+    """RECS_VFILT (round 4): above 12 288 voices the records kernels run filter12's recurrence with lane =
+    voice - the walk lists each window's filter and pan parameters, the recurrence runs over rows in LDS,
+    the pan stage reads them back.  Forced on here (A2AMD_VFILT=1) at sizes the oracle follows: the same
+    random script of writes, ramps, cutoff sets and sweeps, q ramps, mix changes, births and deaths, with 1,
+    3, 4 and 16 voices per wavefront (a pool that fills up in mid-voice turns the wavefront round early)."""
+    monkeypatch.setenv("A2AMD_VFILT", "1")
+    monkeypatch.setenv("A2AMD_RVPW", str(rvpw))
+    gpu = make_gpu(max_batch=16)
+    got = _wt_script(gpu, chain, groups=groups)
+    gpu.close()
+    ora = make_oracle(oracle_lib)
+    want = _wt_script(ora, chain, groups=groups)
+    ora.close()
+    assert want.any()
+    assert first_diff(got, want) is None
+
+
+def test_records_kernel_filter_lane_per_voice_matches_scalar_filter_at_size(monkeypatch):
+    """... and A/B against the scalar recurrence on the same script at 6 000 voices, 64-fragment batches."""
+    outs = []
+    for vf in ("0", "1"):
+        monkeypatch.setenv("A2AMD_VFILT", vf)
+        gpu = make_gpu(max_batch=64)
+        outs.append(_wt_script(gpu, "osc-filter-pan", nvoices=6000, batches=2, bfrags=64, groups=8))
+        gpu.close()
+    assert outs[0].any() and first_diff(outs[0], outs[1]) is None
+
+
 def test_wavetable_records_kernel_matches_general_kernel(monkeypatch):
     """... and A/B against the general kernel on the same script at a size the
     oracle would take long over (A2AMD_NO_FAST=64 sends the records to k_voices)."""
