@@ -70,6 +70,10 @@ enum {	// one operator (A2_fmosc, fm.c:84-93), A2D_FMSTATE / 4 words
 	FO_A = 0, FO_FB = 4, FO_P = 8, FO_LASTPITCH = 12, FO_PHASE, FO_DPHASE, FO_LAST, FO_WORDS };
 #define A2D_FMSTATE 64
 
+// A2DWave::flags, beside the engine's own (A2_LOOPED 0x100 ...): the settled wtosc -> panmix kernel reads this
+// wave's samples themselves instead of its Hermite coefficient entries (a2amd_wave_upload decides)
+#define A2D_WF_RAWTAPS 0x40000000u
+
 // mirror of A2_wave for the device: offsets index the int16 wave pool and point
 // at the first PAYLOAD sample of a level (i.e. data[level] + A2_WAVEPRE)
 struct A2DWave {

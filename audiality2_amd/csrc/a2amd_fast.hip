@@ -628,13 +628,16 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 			dv[DV_V0] = v0;
 			dv[DV_V1] = v1;
 		}
-		dv[DV_SETTLED] = settled ? 1 : 0;
+		// (a wave the host marked as too big to stay in the caches as coefficient entries - 12 bytes per
+		// sample and tap against 2 - is read as samples: A2D_WF_RAWTAPS, a2amd_wave_upload)
+		dv[DV_SETTLED] = settled ? ((sv[SV_MODE] == A2D_OSC_MIPWAVE && (waves[sv[SV_WAVE]].flags & A2D_WF_RAWTAPS)) ? 3 : 1) : 0;
 		amp_l = sv[SV_A];
 		phlo_l = sv[SV_PHLO];
 		phhi_l = sv[SV_PHHI];
 	}
 	const unsigned long long unsettled_mask = __ballot(mine && !dv[DV_SETTLED]);
 	const unsigned long long settled_mask = __ballot(mine && dv[DV_SETTLED]);
+	const unsigned long long raw_mask = __ballot(mine && dv[DV_SETTLED] == 3);
 
 	// ---- settled voices: this slice's chunks ---------------------------------
 	for(int c = c_lo; c < c_hi; ++c) {
@@ -707,6 +710,33 @@ void k_leaf_oscpan(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 			// scalar-base addressing form, no 64 bit adds.  Four fragments' entries
 			// in flight at a time: 24 registers.)
 			const int cb = coef_base(doff);
+			if((raw_mask >> v) & 1ull) {
+				// The north-star's case: a private sample wave that no cache holds.  The window a fragment
+				// reads is 64 * dph / 2^16 + 5 int16 samples (<= 266 bytes); as coefficient entries
+				// it would be six times that from HBM.  Two 8-byte loads per frame (the four samples of each
+				// tap: neighbouring lanes share their cache lines) and a2_Hermite (a2_dsp.h:64-74) in full.
+				const int16_t *d = wavepool + doff;
+#pragma unroll
+				for(int h = 0; h < FAST_FCH; h += 4) {
+					Quad16 qa[4], qb[4];
+					unsigned pa[4], pb[4];
+#pragma unroll
+					for(int j = 0; j < 4; ++j) {
+						pa[j] = tap_phase(phs[h + j], ldph);
+						pb[j] = pa[j] + (dph16 >> 1);
+						qa[j] = *(const Quad16 *)(d + (int)(pa[j] >> 8) - 1);
+						qb[j] = *(const Quad16 *)(d + (int)(pb[j] >> 8) - 1);
+					}
+#pragma unroll
+					for(int j = 0; j < 4; ++j) {
+						int sm = inter_quads(qa[j], qb[j], pa[j], pb[j]);
+						int x = mul64s(sm, amp, 17);
+						x = (lane < nfr[h + j]) ? x : 0;
+						acc0[h + j] = wadd(acc0[h + j], mul64s(x, v0, 24));
+						acc1[h + j] = wadd(acc1[h + j], mul64s(x, v1, 24));
+					}
+				}
+			} else
 #pragma unroll
 			for(int h = 0; h < FAST_FCH; h += 4) {
 				Coef4 ka[4], kb[4];

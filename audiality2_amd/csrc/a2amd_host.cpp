@@ -126,6 +126,37 @@ int a2amd_get_pitch_table(const a2amd_ctx *c, uint32_t *t)
 }
 
 // ---- waves ------------------------------------------------------------------
+} // extern "C"
+// Which waves the settled wtosc -> panmix kernel reads as SAMPLES (A2D_WF_RAWTAPS) rather than as Hermite
+// coefficient entries.  The entries save a third of the interpolation's vector instructions and cost six
+// times the bytes (12 per sample and tap against 2): right while the table sits in L2 / the Infinity
+// Cache - the 24 built-in waves are 1.5 MB of entries - wrong for a bank of private sample waves that no
+// cache holds (north_star: "wavetable / mipmap data ... behind coalesced HBM gathers").  So: by footprint.
+// Once the pool's entries outgrow A2AMD_COEF_CACHE_MB (default 192, about what the caches keep of a
+// streaming set), every wave of 4 096 samples or more is played from its samples.  A2AMD_RAW=0 / 1 forces
+// the choice for all waves (A/B measurements, tests).
+namespace a2h {
+void wave_tap_policy(a2amd_ctx *c)
+{
+	const char *e = getenv("A2AMD_RAW"), *m = getenv("A2AMD_COEF_CACHE_MB");
+	const int force = (e && *e) ? atoi(e) : -1;
+	const size_t budget = (size_t)((m && *m) ? atoi(m) : 192) << 20;
+	const bool big = c->wavepool_used * (4 * A2D_COEF_WORDS) > budget;
+	for(size_t i = 0; i < c->waves.size(); ++i) {
+		HWave &w = c->waves[i];
+		if(!w.live || w.dw.type != A2AMD_WMIPWAVE)
+			continue;
+		const bool raw = force >= 0 ? force != 0 : (big && w.dw.size[0] >= 4096);
+		const uint32_t f = (w.dw.flags & ~A2D_WF_RAWTAPS) | (raw ? A2D_WF_RAWTAPS : 0u);
+		if(f != w.dw.flags) {
+			w.dw.flags = f;
+			c->mwaves[i].flags = f;
+			c->waves_dirty = true;
+		}
+	}
+}
+}
+extern "C" {
 int a2amd_wave_upload(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w)
 {
 	use_device(c);
@@ -177,9 +208,10 @@ int a2amd_wave_upload(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w)
 		}
 	if(pos == (size_t)-1) {
 		if(c->wavepool_used + total > c->d_wavepool.cap) {
-			// (the kernels address the coefficient table by 32 bit byte offsets, up to 16 bytes per sample)
-			if(c->wavepool_used + total > ((size_t)1 << 27))
-				return c->fail(A2AMD_ENOMEM, "wave pool beyond 2^27 samples");
+			// (the kernels address the coefficient table by unsigned 32 bit byte offsets, A2D_COEF_WORDS words
+			// per sample: 2^32 / 12 = 357 M samples = 0.7 GB of wave data, 4.3 GB of entries)
+			if((c->wavepool_used + total) * (4 * A2D_COEF_WORDS) > (((size_t)1 << 32) - 4096))
+				return c->fail(A2AMD_ENOMEM, "wave pool beyond %zu samples", (((size_t)1 << 32) - 4096) / (4 * A2D_COEF_WORDS));
 			if(int r = grow(c, c->d_wavepool, c->wavepool_used + total, 1, true)) return r;
 			// the coefficient table follows the pool: rebuilt for what is in it
 			if(int r = grow(c, c->d_wavecoef, c->d_wavepool.cap, A2D_COEF_WORDS, false)) return r;
@@ -209,6 +241,7 @@ int a2amd_wave_upload(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w)
 	c->mwaves[id] = hw.dw;
 	c->waves_dirty = true;
 	++c->stats.live_waves;
+	wave_tap_policy(c);
 	return id;
 }
 

@@ -543,6 +543,8 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 int ensure_clean(a2amd_ctx *c);
 int build_graph(a2amd_ctx *c, int slot, int steps, unsigned phases = A2AMD_RENDER_SUBTREES | A2AMD_RENDER_ROOT);
 long long now_serial(const a2amd_ctx *c);
+// a2amd_host.cpp
+void wave_tap_policy(a2amd_ctx *c);
 // a2amd_render.cpp
 double *dbg_counters();	// (A2AMD_HOSTTIMING counters)
 double *dbg_why();

@@ -106,6 +106,31 @@ class Scene:
         self.next_key += 1
         return k
 
+    def private_waves(self, count, length=65536, period=256, seed=7):
+        """`count` looped, mip-mapped sample waves of `length` samples each that no two voices need share -
+        SURVEY 8(d)'s "private sample wave" case: the waves of a sampler, not the 24 built-in cycles that sit
+        in L2.  Deterministic content (a seeded random walk, band-limited a little), uploaded like
+        a2_UploadWave's result (src/waves.c:155-237: all mip levels, pads).  Voices made by add_voices(...,
+        private=True) play wave (voice number mod count)."""
+        rng = np.random.default_rng(seed)
+        base = rng.integers(-3000, 3001, size=length + 4096, dtype=np.int32)
+        base = np.cumsum(base)
+        base -= (np.arange(len(base)) * (base[-1] // len(base)))     # (no drift)
+        base = (base * (28000.0 / max(1, np.abs(base).max()))).astype(np.int16)
+        self.private_ids = []
+        for i in range(count):
+            # every wave a different stretch / polarity / level of the walk: distinct data, cheap to make
+            off = (i * 977) % 4096
+            w = base[off:off + length].astype(np.int32)
+            if i & 1:
+                w = -w
+            w = (w * (0.5 + 0.5 * ((i * 37) % 64) / 63.0)).astype(np.int16)
+            w[-64:] = (w[-64:].astype(np.int32) * np.arange(63, -1, -1) // 64 + w[:64].astype(np.int32) * np.arange(64) // 64).astype(np.int16)
+            sizes, data = wave_pyramid(w)
+            self.private_ids.append(self.be.wave_upload(0x10000 + i, WMIPWAVE, LOOPED, period,
+                                                        sizes + [0] * (MIPLEVELS - len(sizes)), data))
+        return self.private_ids
+
     # -- tree construction (what a2_PopulateVoice + the voice's first VM run do) --
     def root(self, channels=2):
         """a2_rootdriver (audiality2.c:271-280): inline 0 *; panmix * *; xinsert * >"""
@@ -150,7 +175,7 @@ class Scene:
         (self.groups if parent is None else parent.setdefault("subs", [])).append(g)
         return g
 
-    def add_voices(self, n, chain="osc-pan", group=None, total=None):
+    def add_voices(self, n, chain="osc-pan", group=None, total=None, private=False):
         """n sustained voices with the per-voice parameters of SURVEY.md 8(d):
         wave 7k mod 24, pitch ((k mod 61)-30)/12 oct, pan ((k mod 17)-8)/8 ..."""
         be = self.be
@@ -215,7 +240,8 @@ class Scene:
             else:
                 raise ValueError(chain)
             for j, o in enumerate(oscs):
-                be.unit_write(o, 0, self.wave_ids[(7 * k + j) % len(self.wave_ids)])
+                be.unit_write(o, 0, self.private_ids[(k + j) % len(self.private_ids)] if private else
+                              self.wave_ids[(7 * k + j) % len(self.wave_ids)])
                 be.unit_write(o, 1, p + (fix(0.01) if j == 0 else -fix(0.01)) * (len(oscs) > 1))
                 be.unit_write(o, 2, amp)
                 be.unit_write(o, 3, (k * 2654435761) % 65536)

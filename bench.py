@@ -77,6 +77,14 @@ CONFIGS[4] = dict(   # BASELINE configs[4] / SURVEY 8(d) config #5: one top-leve
           "inline->panmix->xinsert) of 128 sub-groups x 256 voices; 8 GPUs = the 262144 voices of BASELINE "
           "configs[4], the groups' sum into the root bus = ONE ncclReduce per buffer")
 TOP_GROUP_VOICES = 32768
+# Round 4: the path where north_star says it is bandwidth-bound - SURVEY 8(d)'s "private sample waves" case, which no
+# BASELINE config has: configs[1]'s voice (wtosc -> panmix) x 65 536 over 2 048 uploaded sample waves of 65 536 samples
+# (0.54 GB of int16 with their mip levels, 3.2 GB as Hermite coefficient entries: past every cache), 32 voices per
+# wave at the configs' mixed pitches (+-2.5 octaves: mip levels 0-2, 0.25-2 source samples per frame).
+CONFIGS[5] = dict(voices=65536, chain="osc-pan", groups=0, private=(2048, 65536, 256),
+                  label="65536 voices wtosc->panmix over 2048 private looped sample waves of 65536 samples (period 256), "
+                        "pitches +-2.5 octaves, 48 kHz, fragment=64, stereo (SURVEY 8d: the private-wave case; not a "
+                        "BASELINE config)")
 UP, SUB, ROOTP, RB, KEEP, ASYNC = 4, 1, 2, 8, 16, 32
 
 
@@ -102,19 +110,24 @@ def fnv1a_fragments(pcm, frag=64):
     return h
 
 
-def golden_path(voices, chain, groups, tree=0):
+def golden_path(voices, chain, groups, tree=0, private=None):
+    if private:
+        return os.path.join(ROOT, "tests", "golden", f"bench_{chain}_{voices}v_private{private[0]}x{private[1]}.hash.npy")
     if tree:    # configs[4]: keyed by the voices of the WHOLE job (all ranks)
         return os.path.join(ROOT, "tests", "golden", f"bench_cfg4_{chain}_{voices}v_{tree}sub.hash.npy")
     return os.path.join(ROOT, "tests", "golden", f"bench_{chain}_{voices}v_{groups}g.hash.npy")
 
 
-def build_scene(be, voices, chain, groups, world=1, rank=0, tree=0):
+def build_scene(be, voices, chain, groups, world=1, rank=0, tree=0, private=None):
     """The synthetic voice tree of a config (every rank plays different voices)."""
     from audiality2_amd import shard, synth
     sc = synth.Scene(be)
     sc.root()
     sc.nvoices = shard.voice_range(rank, voices)[0]
-    if tree:
+    if private:
+        sc.private_waves(*private)
+        sc.add_voices(voices, chain=chain, total=voices * world, private=True)
+    elif tree:
         # configs[4]: top-level groups of `tree` sub-groups x 256 voices, this rank's share
         assert voices % TOP_GROUP_VOICES == 0 and TOP_GROUP_VOICES % tree == 0
         for _ in range(voices // TOP_GROUP_VOICES):
@@ -139,12 +152,14 @@ def host_threads():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(voices, chain, groups, oracle_fragments=100):
+def cpu_baseline(voices, chain, groups, oracle_fragments=100, private=None):
     """Reference (oracle/_ref/ref_bench) if it travelled, else the C port."""
     program = {"osc-pan": "OscPan", "osc-filter-pan": "OscFilterPan", "osc2-pan": "Osc2Pan", "fm1-pan": "Fm1Pan",
                "fm2-pan": "Fm2Pan", "fm4-pan": "Fm4Pan"}.get(chain)
     if groups and chain == "osc2-pan":
         program = "Osc2PanGroups"
+    if private:
+        program = None      # (no script uploads sample waves: the C restatement plays the scene bench.py builds)
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
     script = os.path.join(ROOT, "tests", "a2s", "bench.a2s")
     ncores = host_threads()
@@ -183,7 +198,7 @@ def cpu_baseline(voices, chain, groups, oracle_fragments=100):
     from audiality2_amd.replay import Backend
     lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liba2oracle.so"))
     be = Backend(lib, "a2o_", 48000, synth.basepitch_for(48000), 2)
-    sc = build_scene(be, voices, chain, groups)
+    sc = build_scene(be, voices, chain, groups, private=private)
     sc.walk(64)
     be.render(64)
     lib.a2o_fragment_repeat.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
@@ -198,8 +213,8 @@ def cpu_baseline(voices, chain, groups, oracle_fragments=100):
     be.close()
     return {"value": voices * 64.0 * oracle_fragments / dt, "unit": "voice-samples/s", "cores": 1,
             "kind": "port", "host_cores": ncores,
-            "sample": f"{voices} voices {chain}, {groups} groups, {oracle_fragments} fragments of 64 frames, "
-                      f"C restatement (oracle/a2o.c), 1 thread"}
+            "sample": f"{voices} voices {chain}, {groups} groups" + (f", {private[0]} private waves of {private[1]} samples" if private else "")
+                      + f", {oracle_fragments} fragments of 64 frames, C restatement (oracle/a2o.c), 1 thread"}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -329,7 +344,7 @@ def engine_in_loop(cases=None, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fr
 def pmc_entry(chain, voices, groups, B):
     """PMC-derived figures for this workload's dominant kernel (profiles/*.json, tools/pmc_summary.py)."""
     key = f"{chain}/{voices}/{groups}/{B}"
-    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -378,9 +393,9 @@ def valu_mix_entry(kernel):
 class Runner:
     """One config on one GPU through the product entry points."""
 
-    def __init__(self, audiality2_amd, voices, chain, groups, B, device=0, world=1, rank=0, tree=0):
+    def __init__(self, audiality2_amd, voices, chain, groups, B, device=0, world=1, rank=0, tree=0, private=None):
         self.voices, self.chain, self.groups, self.B = voices, chain, groups, B
-        self.rank, self.world, self.tree = rank, world, tree
+        self.rank, self.world, self.tree, self.private = rank, world, tree, private
         self.be = audiality2_amd.open_backend(48000, None, 2, device=device, max_batch=B)
         lib = self.lib = self.be.lib
         lib.a2amd_fragment_repeat.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
@@ -396,7 +411,7 @@ class Runner:
             for c in range(2):
                 p[c] = b[c].ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
             self.ptrs.append(p)
-        self.sc = build_scene(self.be, voices, chain, groups, world, rank, tree)
+        self.sc = build_scene(self.be, voices, chain, groups, world, rank, tree, private)
         self.step_no = 0            # steps issued
         self.got = 0                # steps collected
         self.kept = {}              # step -> audio (the steps the golden covers, and the last one)
@@ -482,7 +497,7 @@ class Runner:
 def check_golden(r, nsteps):
     """Compare every rendered step the committed oracle golden covers; returns
     (steps compared, all equal) or (0, None) without a golden for this workload."""
-    path = golden_path(r.voices * r.world if r.tree else r.voices, r.chain, r.groups, r.tree)
+    path = golden_path(r.voices * r.world if r.tree else r.voices, r.chain, r.groups, r.tree, r.private)
     if not os.path.exists(path):
         return 0, None
     gold = np.load(path)
@@ -502,8 +517,8 @@ def check_golden(r, nsteps):
     return n, ok
 
 
-def golden_steps(voices, chain, groups, B, tree=0):
-    path = golden_path(voices, chain, groups, tree)
+def golden_steps(voices, chain, groups, B, tree=0, private=None):
+    path = golden_path(voices, chain, groups, tree, private)
     if tree:
         return 1 if os.path.exists(path) else 0
     return len(np.load(path)) // B if os.path.exists(path) else 0
@@ -513,8 +528,8 @@ def measure_single(audiality2_amd, cfg, B, steps, warmup, device=0, with_realtim
     """One config at N=1: returns the dict of measured figures."""
     import gc
     import torch
-    r = Runner(audiality2_amd, cfg["voices"], cfg["chain"], cfg["groups"], B, device, tree=cfg.get("tree", 0))
-    gsteps = golden_steps(cfg["voices"], cfg["chain"], cfg["groups"], B, cfg.get("tree", 0))
+    r = Runner(audiality2_amd, cfg["voices"], cfg["chain"], cfg["groups"], B, device, tree=cfg.get("tree", 0), private=cfg.get("private"))
+    gsteps = golden_steps(cfg["voices"], cfg["chain"], cfg["groups"], B, cfg.get("tree", 0), cfg.get("private"))
     r.keep_upto = gsteps
     r.run(1)                        # step 0: voices are born
     r.run(warmup)
@@ -537,7 +552,7 @@ def measure_single(audiality2_amd, cfg, B, steps, warmup, device=0, with_realtim
     # stay within the level of the verified ones (catches silence, runaway, stuck output)
     peak_ref = max((int(np.abs(a).max()) for a in r.kept.values()), default=None)
     leaf_ms, all_ms, nprof = r.profile(min(steps, 32))
-    res = {"voices": cfg["voices"], "chain": cfg["chain"], "groups": cfg["groups"], "seconds": dt,
+    res = {"voices": cfg["voices"], "chain": cfg["chain"], "groups": cfg["groups"], "private": cfg.get("private"), "seconds": dt,
            "value": float(cfg["voices"]) * B * 64 * steps / dt, "ms_per_step": dt / steps * 1e3,
            "leaf_ms": leaf_ms, "all_ms": all_ms, "launches_timed": nprof,
            "golden_steps_compared": compared, "parity_vs_golden": ok,
@@ -579,8 +594,23 @@ def realtime_sweep(audiality2_amd, device=0, chain="osc-filter-pan", sizes=(2621
 def roofline_objects(res, B):
     chain, voices, groups = res["chain"], res["voices"], res["groups"]
     bpvf = BYTES_PER_VOICE_FRAGMENT[chain]
+    private = res.get("private")
+    if private:
+        # + the window of its wave a voice reads per fragment ("unique wave bytes"): 64 frames x the source
+        # samples per frame at the mip level wtosc picks (wtosc.c:250-258: halved until <= 2.0) + 5 samples of
+        # interpolation margin, 2 bytes each; averaged over the scene's pitches
+        per = private[2]
+        wb = 0.0
+        for k in range(voices):
+            r = 2.0 ** (((k % 61) - 30) / 12.0) * per * 261.626 / 48000.0
+            while r > 2.0:
+                r *= 0.5
+            wb += 2.0 * (64.0 * r + 5.0)
+        bpvf = bpvf + wb / voices
     alg = bpvf * voices * B
-    pmc = pmc_entry(chain, voices, groups, B)
+    # (the private-wave scene is played from the waves' samples unless A2AMD_RAW=0 asks for coefficient entries)
+    coef_path = bool(private) and os.environ.get("A2AMD_RAW", "") == "0"
+    pmc = pmc_entry(chain + (("-private-coef" if coef_path else "-private") if private else ""), voices, groups, B)
     leaf_s = res["leaf_ms"] * 1e-3
     achieved = alg / leaf_s / 1e9 if leaf_s > 0 else None
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -593,6 +623,18 @@ def roofline_objects(res, B):
                       "timed region (graph replay off)",
             "all_kernels_ms_per_step": res["all_ms"],
             "other_kernels_ms_per_step": res["all_ms"] - res["leaf_ms"]}
+    if roof["traffic"] and leaf_s > 0:
+        # what the counters say really moved, against the same peak: for the BASELINE configs (24 built-in waves, state
+        # in registers over 256 fragments) a small fraction of the model's bytes; for the private-wave scene the figure
+        # that says whether HBM is the bound
+        roof["traffic_frac"] = roof["traffic"] / leaf_s / 1e9 / HBM_PEAK_GBPS
+        roof["traffic_over_algorithmic"] = roof["traffic"] / alg
+    if private:
+        roof["wave_data_read_as"] = "Hermite coefficient entries (12 B per sample and tap)" if coef_path else \
+            "int16 samples (A2D_WF_RAWTAPS: the footprint policy of a2amd_wave_upload; A2AMD_RAW=0 for the entries)"
+        roof["algorithmic_model"] = ("SURVEY 8(d): 504 B of unit state and bus share per voice-fragment + the window of its wave "
+                                     "a voice reads per fragment (64 x source samples per frame + 5 samples, int16), averaged "
+                                     "over the scene's pitches")
     if groups:
         roof["other_kernels"] = (f"{groups} group chains inline->fbdelay->fbdelay + the root chain: "
                                  f"{2 * groups * FBDELAY_BYTES_PER_FRAGMENT * B / 1e6:.1f} MB algorithmic per step")
@@ -741,7 +783,8 @@ def main():
         if not args.no_realtime and not custom and args.config == 3:
             line["max_realtime_voices"] = realtime_sweep(audiality2_amd, local_rank)
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg["voices"], cfg["chain"], cfg["groups"])
+            line["cpu_baseline"] = cpu_baseline(cfg["voices"], cfg["chain"], cfg["groups"], private=cfg.get("private"),
+                                                oracle_fragments=16 if cfg.get("private") else 100)
         if not args.no_engine and not custom and args.config == 3:
             line["engine_in_loop"] = engine_in_loop()
             if "max_realtime_voices" in line and "max_realtime_voices_one_engine_state" in line["engine_in_loop"]:

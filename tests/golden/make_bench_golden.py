@@ -34,7 +34,7 @@ CFG4_FRAGMENTS = 64      # configs[4]: 262 144 voices; 64 fragments are ~25 s of
 CFG4_TOTALS = (32768, 65536, 131072, 262144)     # the whole job at 1, 2, 4, 8 GPUs (bench.py --config 4)
 
 
-def render(voices, chain, groups, fragments, progress=False, tree=0):
+def render(voices, chain, groups, fragments, progress=False, tree=0, private=None):
     """int32 [2, fragments * 64] from the oracle, for bench.py's scene."""
     import bench
     from audiality2_amd import synth
@@ -42,7 +42,7 @@ def render(voices, chain, groups, fragments, progress=False, tree=0):
     lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liba2oracle.so"))
     lib.a2o_fragment_repeat.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
     be = Backend(lib, "a2o_", 48000, synth.basepitch_for(48000), 2, max_batch=64)
-    sc = bench.build_scene(be, voices, chain, groups, tree=tree)
+    sc = bench.build_scene(be, voices, chain, groups, tree=tree, private=private)
     outs = []
     sc.walk(64)
     done, pending = 0, 1
@@ -79,8 +79,10 @@ if __name__ == "__main__":
             print("written", path, "peak", int(np.abs(pcm).max()))
     for i in which:
         cfg = bench.CONFIGS[i]
-        pcm = render(cfg["voices"], cfg["chain"], cfg["groups"], STEPS * B, progress=True)
-        path = bench.golden_path(cfg["voices"], cfg["chain"], cfg["groups"])
+        # (config 5, the private-wave scene: two steps)
+        pcm = render(cfg["voices"], cfg["chain"], cfg["groups"], (2 if cfg.get("private") else STEPS) * B, progress=True,
+                     private=cfg.get("private"))
+        path = bench.golden_path(cfg["voices"], cfg["chain"], cfg["groups"], private=cfg.get("private"))
         np.save(path, fnv1a_fragments(pcm))
         # the head of the audio itself, for a readable diff when a hash differs
         np.save(path.replace(".hash.npy", ".head.npy"), pcm[:, :256])

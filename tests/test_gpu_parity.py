@@ -425,6 +425,29 @@ def test_records_kernel_filter_lane_per_voice_matches_scalar_filter_at_size(monk
     assert outs[0].any() and first_diff(outs[0], outs[1]) is None
 
 
+@pytest.mark.parametrize("raw", ["0", "1"])
+def test_private_sample_waves_as_coefficients_and_as_samples(oracle_lib, monkeypatch, raw):
+    """SURVEY 8(d)'s private-wave case at oracle size: 24 uploaded sample waves of 20 000 samples (not a power
+    of two: the phase wraps by a real modulo), 700 wtosc -> panmix voices over them at mixed pitches / mip
+    levels.  The settled kernel reads a wave either as Hermite coefficient entries (A2AMD_RAW=0) or as its
+    int16 samples (A2AMD_RAW=1: what the footprint policy picks for banks no cache holds) - both bit-equal
+    to the oracle, over 3 x 16 fragments with a short fragment in between."""
+    monkeypatch.setenv("A2AMD_RAW", raw)
+    outs = []
+    for be in (make_gpu(max_batch=16), make_oracle(oracle_lib)):
+        sc = synth.Scene(be)
+        sc.root()
+        sc.private_waves(24, length=20000, period=256)
+        sc.add_voices(700, chain="osc-pan", private=True)
+        a = sc.run(16, batch=16)
+        b = sc.run(1, batch=1, frames=23)
+        c = sc.run(32, batch=16)
+        outs.append(np.concatenate([a, b, c], axis=1))
+        be.close()
+    assert outs[1].any()
+    assert first_diff(outs[0], outs[1]) is None
+
+
 def test_wavetable_records_kernel_matches_general_kernel(monkeypatch):
     """... and A/B against the general kernel on the same script at a size the
     oracle would take long over (A2AMD_NO_FAST=64 sends the records to k_voices)."""
@@ -943,6 +966,27 @@ def test_baseline_configs_at_full_size_match_oracle_golden(config):
     gpu.close()
     bad = np.nonzero(got != want)[0]
     assert not len(bad), f"configs[{config}]: {len(bad)} fragments differ, first {bad[:8]}"
+
+
+@pytest.mark.parametrize("raw", ["", "0"])
+def test_private_wave_scene_at_full_size_matches_oracle_golden(monkeypatch, raw):
+    """bench.py --config 5 (SURVEY 8d's private-wave case): 65 536 wtosc -> panmix voices over 2 048 uploaded
+    sample waves of 65 536 samples - 0.54 GB of wave data, 3.2 GB of coefficient entries, addressed past
+    2^31 bytes - two steps of 256 fragments against the oracle's hashes; as the footprint policy plays it
+    (from the samples) and with the coefficient entries forced."""
+    import bench
+    if raw:
+        monkeypatch.setenv("A2AMD_RAW", raw)
+    else:
+        monkeypatch.delenv("A2AMD_RAW", raising=False)
+    cfg = bench.CONFIGS[5]
+    want = np.load(bench.golden_path(cfg["voices"], cfg["chain"], cfg["groups"], private=cfg["private"]))
+    gpu = make_gpu(max_batch=256)
+    sc = bench.build_scene(gpu, cfg["voices"], cfg["chain"], cfg["groups"], private=cfg["private"])
+    got = fnv1a_fragments(_async_steps(gpu, sc, 2, 256))
+    gpu.close()
+    bad = np.nonzero(got != want)[0]
+    assert not len(bad), f"private-wave scene: {len(bad)} fragments differ, first {bad[:8]}"
 
 
 def test_config3_full_size_is_linear_in_the_voice_subsets():
