@@ -65,7 +65,14 @@ def render(voices, chain, groups, fragments, progress=False, tree=0, private=Non
 if __name__ == "__main__":
     import bench
     from conftest import fnv1a_fragments
-    which = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
+    # --steps N: that many steps of 256 fragments for configs[1..3] (default 8; bench.py's default run issues 64:
+    # round 4 keeps goldens that cover every one of them)
+    argv = list(sys.argv[1:])
+    if "--steps" in argv:
+        k = argv.index("--steps")
+        STEPS = int(argv[k + 1])
+        del argv[k:k + 2]
+    which = [int(a) for a in argv] or [1, 2, 3, 4]
     if 4 in which:
         # BASELINE configs[4]: top-level groups of 128 sub-groups x 256
         # wtosc->filter12->panmix voices, one per GPU; the whole job's audio at 1, 2, 4 and 8 GPUs

@@ -964,7 +964,8 @@ def test_baseline_configs_at_full_size_match_oracle_golden(config):
     sc = bench.build_scene(gpu, cfg["voices"], cfg["chain"], cfg["groups"])
     got = fnv1a_fragments(_async_steps(gpu, sc, 8, 256))
     gpu.close()
-    bad = np.nonzero(got != want)[0]
+    assert len(want) >= len(got)        # (the golden covers every step of bench.py's default run; 8 steps here)
+    bad = np.nonzero(got != want[:len(got)])[0]
     assert not len(bad), f"configs[{config}]: {len(bad)} fragments differ, first {bad[:8]}"
 
 
