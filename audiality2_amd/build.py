@@ -34,11 +34,11 @@ def build_units(force=False):
     """The drop-in unit descriptors (plain C) on top of liba2amd.so."""
     src = os.path.join(HERE, "csrc", "a2amd_units.c")
     deps = [src, os.path.join(ROOT, "include", "a2amd.h"), os.path.join(ROOT, "include", "a2amd_plugin.h"),
-            os.path.join(ROOT, "include", "a2amd_walk.h")]
+            os.path.join(ROOT, "include", "a2amd_walk.h"), os.path.join(ROOT, "include", "a2amd_vm.h")]
     out = os.path.join(HERE, "liba2amd_units.so")
     if force or _newer(out, deps):
         subprocess.run(["gcc", "-O2", "-Wall", "-fPIC", "-shared", "-o", out, src,
-                        "-L" + HERE, "-la2amd", "-ldl", "-lpthread", "-Wl,-rpath,$ORIGIN"], check=True)
+                        "-L" + HERE, "-la2amd", "-ldl", "-lpthread", "-lm", "-Wl,-rpath,$ORIGIN"], check=True)
     return out
 
 

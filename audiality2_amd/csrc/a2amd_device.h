@@ -118,6 +118,23 @@ struct A2DRun { int32_t first, count; };
 // which for host-driven voices never leave the host (a2amd_host.h: HUnit::cutoff).
 #define A2D_VM_NOWRITE 0xffu
 #define A2D_VM_MAXCUT  2
+#define A2D_VM_MAXENV  2
+#define A2D_VM_ENVPOS  14		// cmap chain position that stands for "the target register of env unit <register nibble>"
+#define A2D_ENV_LUTSHIFT 6		// A2ENV_LUTSHIFT, env.c:27
+#define A2D_ENV_LUTSIZE  (1 << A2D_ENV_LUTSHIFT)
+#define A2D_ENV_LUTS     8		// A2ENVLUT_SPLINE, EXP1 .. EXP7 (env.c:36-47)
+// src/units/env.c's A2_env (:88-99) for a voice the device VM runs: a control-rate unit without audio
+// ports whose output is a register write on another unit through a control wire (env.c:135)
+struct A2DVmEnv {
+	int32_t ramper[4];		// A2_env.ramper
+	int32_t lut;			// which table (A2ENVLUT_*)
+	int32_t scale, offset, out;
+	int32_t active;			// its Process is env_ProcessLUT (else env_ProcessOff)
+	uint8_t regbase;		// VM register of its 'target' (then mode, down, time: env.c:50-56, registers[] = &vms->r[regbase])
+	uint8_t k;			// units of the (backend) chain in front of it: a write to one of them takes effect behind the window
+	uint8_t target;			// where its control output is wired: chain position << 4 | register, A2D_VM_NOWRITE = nowhere
+	uint8_t pad;
+};
 struct A2DVmVoice {
 	uint32_t waketime;		// A2_vmstate.waketime: 24:8 frames, engine time
 	uint32_t code, ncode;		// the function's text in the code pool (32 bit words)
@@ -130,6 +147,8 @@ struct A2DVmVoice {
 	uint8_t  cutpos[A2D_VM_MAXCUT];	// chain positions of the filter12 units whose cutoff the VM may write
 	uint8_t  pad[2];
 	int32_t  cut[A2D_VM_MAXCUT][4];	// ... and their cutoff rampers (A2_filter12.cutoff, filter12.c:38)
+	A2DVmEnv env[A2D_VM_MAXENV];	// the voice's env units, nenv of them
+	int32_t  nenv;
 	int32_t  r[64];			// A2_vmstate.r
 };
 
@@ -141,6 +160,7 @@ struct A2DVmParams {
 	const uint32_t *code;		// code pool
 	const uint32_t *ptab;
 	const int32_t  *f1tab;		// [32][65536]: f12_pitch2coeff by (shift, fraction), or null
+	const uint16_t *envlut;		// [A2D_ENV_LUTS][A2D_ENV_LUTSIZE + 2] (env.c:218-257), or null
 	A2DRun         *runs;		// [voice slot]
 	A2DRun         *vmrun;		// [list index]: where each voice's records go (count pass -> emit pass)
 	A2DRec         *recs;		// the batch's record array (A2DParams::recs)
@@ -151,6 +171,7 @@ struct A2DVmParams {
 	int32_t         samplerate, basepitch;
 	int32_t         nfrags;
 	uint8_t         fragframes[A2D_MAXBATCH];
+	uint8_t         fragbase[A2D_MAXBATCH];	// offset of each inside the engine's own fragment (core.c:1968)
 };
 
 // xinsert state words: client slot + 1 (0 = no clients) and A2AMD_XIO_* mode bits

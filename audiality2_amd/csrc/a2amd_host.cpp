@@ -286,6 +286,7 @@ int a2amd_fragment(a2amd_ctx *c, unsigned frames)
 		c->vm.batch_time = c->walk_time;	// (the device VM's clock, a2amd_vm.cpp)
 	c->cur_frag = c->nfrags++;
 	c->fragframes[c->cur_frag] = frames;
+	c->fragbase[c->cur_frag] = 0;
 	c->frag_open = true;
 	c->walked_started = 0;
 	c->building = -1;
@@ -299,6 +300,16 @@ int a2amd_fragment(a2amd_ctx *c, unsigned frames)
 		c->defmap_dirty = false;
 	}
 	c->defmap_used = false;
+	return A2AMD_OK;
+}
+
+int a2amd_fragment_offset(a2amd_ctx *c, unsigned offset)
+{
+	if(!c->frag_open || c->uploaded)
+		return c->fail(A2AMD_ESTATE, "fragment_offset outside a fragment");
+	if(offset + c->fragframes[c->cur_frag] > A2D_FRAG)
+		return c->fail(A2AMD_EINVAL, "fragment_offset %u with %u frames", offset, c->fragframes[c->cur_frag]);
+	c->fragbase[c->cur_frag] = (uint8_t)offset;
 	return A2AMD_OK;
 }
 

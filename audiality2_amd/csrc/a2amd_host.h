@@ -273,6 +273,9 @@ struct VmHost {
 	DevBuf<int> d_list;		// [active slots | class lists (voice slots)]
 	DevBuf<A2DRun> d_vmrun;
 	int32_t *d_f1tab = nullptr;
+	std::vector<uint16_t> envlut;	// [8][66] from the host's env unit (a2amd_vm_envluts)
+	uint16_t *d_envlut = nullptr;
+	bool envlut_up = false;
 	uint32_t *d_total = nullptr, *h_total = nullptr;	// {records, faults}; pinned
 	A2DVmVoice *h_stage = nullptr;	// pinned staging for recalls
 	size_t h_stage_cap = 0;
@@ -341,6 +344,7 @@ struct a2amd_ctx {
 	bool frag_open = false;
 	int cur_frag = 0, nfrags = 0;
 	unsigned fragframes[A2D_MAXBATCH];
+	uint8_t fragbase[A2D_MAXBATCH];	// where each starts inside the engine's own fragment (a2amd_fragment_offset)
 	bool uploaded = false;
 
 	// host mirrors of host-owned device tables
@@ -555,7 +559,7 @@ int dist_reduce_root(a2amd_ctx *c);
 int vm_prepare_batch(a2amd_ctx *c);		// upload(): pending adoptions, program text, states
 int vm_build_lists(a2amd_ctx *c);		// ... and the kernel's list, the records kernels' class lists
 int vm_issue(a2amd_ctx *c);			// issue_kernels(): the VM kernel's two passes
-int vm_take_back(a2amd_ctx *c, int vi, bool inclusive, a2amd_vm_state *out);	// the voice is the host's again
+int vm_take_back(a2amd_ctx *c, int vi, bool inclusive, a2amd_vm_state *out, a2amd_vm_env *envs_out = nullptr);	// the voice is the host's again
 void vm_end_batch(a2amd_ctx *c);
 void vm_close(a2amd_ctx *c);
 int vm_blob_room(a2amd_ctx *c);			// records the VM's region of the blob should hold

@@ -618,8 +618,13 @@ int upload(a2amd_ctx *c)
 		// this batch's exceptions (shipped in the blob)
 		std::vector<int> dyn_leaf;
 		std::vector<std::vector<int>> dyn_bus(c->depth_ranges.size());
+		static const bool dump = getenv("A2AMD_VM_DUMP") != nullptr;	// (debugging aid: the records of a batch, host-made ...)
 		for(int vi : c->with_recs) {
 			const HVoice &v = c->voices[vi];
+			if(dump)
+				for(const A2DRec &r : v.recs)
+					fprintf(stderr, "REC %lld v%d f%u op%u u%u r%u val %d dur %u start %u\n", c->serial_base, vi,
+							A2D_RFRAG(r.head), A2D_ROP(r.head), A2D_RUNIT(r.head), A2D_RREG(r.head), r.value, r.dur, r.start);
 			// (fm-panmix voices execute their own records in k_leaf_fmpan)
 			if(v.cls == CLS_OSCPAN || v.cls == CLS_OSCFILTPAN || v.cls == CLS_OSC2PAN)
 				dyn_leaf.push_back(vi);

@@ -33,6 +33,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <math.h>
 #include "../../include/a2amd.h"
 #include "../../include/a2amd_plugin.h"
 #include "../../include/a2amd_vm.h"
@@ -126,6 +127,11 @@ typedef struct HOSTSTATE
 	A2P_vmstate	*root_vms;	/* the root voice (first voice of a state) */
 	A2P_vmstate	*chain_vms;	/* voice whose chain is being populated */
 	A2P_unit	*chain_last;
+	A2P_unit	*chain_head;	/* ... its first forwarded unit, forwarded units so far, env units in front of them */
+	int		chain_nfwd;
+	A2P_unit	*chain_env[2];
+	int		chain_nenv;
+	int		envluts_sent[MAXDEV];	/* the context has env's tables (a2amd_vm_envluts) */
 	A2P_xinsert	*root_xi;	/* the root voice's xinsert (the engine's own instance) */
 	void		*engine_state;	/* A2_state, for a2r_Error */
 	/* wave registry: engine object -> device wave id */
@@ -195,6 +201,10 @@ typedef struct XTRA
 	int		vm;
 	unsigned	vm_seen;
 	int		vm_seen_valid;
+	/* head: the voice's env units (a2_env_unitdesc below) and how many forwarded units stand in front of each;
+	 * nenv > 2: too many for the device VM */
+	A2P_unit	*env[2];
+	uint8_t		nenv, env_before[2];
 } XTRA;
 
 _Static_assert(MAXDEV == A2AMD_WALK_MAXDEV, "a2amd_walkview");
@@ -543,6 +553,8 @@ static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned 
 	{
 		hs->chain_vms = vms;
 		hs->chain_last = NULL;
+		hs->chain_head = NULL;
+		hs->chain_nfwd = hs->chain_nenv = 0;
 	}
 	if(x->is_root && kind == A2AMD_PANMIX)
 	{
@@ -611,12 +623,30 @@ static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned 
 				hs->root_uid[kind == A2AMD_PANMIX][d] = x->uid;
 		}
 	}
+	if(forward)
+	{
+		if(!hs->chain_last)
+		{
+			/* (the env units the chain started with are this head's) */
+			int k;
+			hs->chain_head = u;
+			x->nenv = hs->chain_nenv;
+			for(k = 0; k < hs->chain_nenv && k < 2; ++k)
+			{
+				x->env[k] = hs->chain_env[k];
+				x->env_before[k] = 0;
+			}
+		}
+		++hs->chain_nfwd;
+	}
 	hs->chain_last = u;
 	return 0;
 }
 
 static void amd_deinit(A2P_unit *u)
 {
+	if(u->descriptor == &a2_env_unitdesc)
+		return;
 	if(is_ours(u->descriptor) && u->descriptor != &a2_inline_unitdesc && u->descriptor != &a2_xinsert_unitdesc &&
 			u->descriptor != &a2_xsink_unitdesc && u->descriptor != &a2_xsource_unitdesc)
 	{
@@ -711,7 +741,7 @@ static int is_ours(const A2P_unitdesc *d)
 		&a2_inline_unitdesc, &a2_xinsert_unitdesc, &a2_fm1_unitdesc, &a2_fm2_unitdesc,
 		&a2_fm3_unitdesc, &a2_fm4_unitdesc, &a2_fm3p_unitdesc, &a2_fm4p_unitdesc,
 		&a2_fm2r_unitdesc, &a2_fm4r_unitdesc, &a2_dc_unitdesc, &a2_waveshaper_unitdesc,
-		&a2_dcblock_unitdesc, &a2_limiter_unitdesc, &a2_xsink_unitdesc, &a2_xsource_unitdesc };
+		&a2_dcblock_unitdesc, &a2_limiter_unitdesc, &a2_xsink_unitdesc, &a2_xsource_unitdesc, &a2_env_unitdesc };
 	unsigned i;
 	for(i = 0; i < sizeof(ours) / sizeof(ours[0]); ++i)
 		if(d == ours[i])
@@ -724,7 +754,7 @@ static void check_chain_behind(A2P_unit *u)
 	const A2P_unit *n;
 	XTRA *x = xtra(u);
 
-	for(n = u->next; n && !is_ours(n->descriptor); n = n->next)
+	for(n = u->next; n && (!is_ours(n->descriptor) || n->descriptor == &a2_env_unitdesc); n = n->next)
 		if(n->descriptor->maxinputs || n->descriptor->maxoutputs)	/* (the unit's own counts are
 				not meaningful for a port-less unit: the engine still hands env one) */
 		{
@@ -1197,6 +1227,8 @@ static void forward_process(XTRA *x, unsigned offset, unsigned frames)
  * shrinks to one byte store into the backend's default map per fragment
  * (amd_quick_process) until a register of the voice is written again. */
 static void amd_head_process(A2P_unit *u, unsigned offset, unsigned frames);
+static int env_busy(const XTRA *head);
+static int env_chain_ok(A2P_unit *head);
 static void head_process(A2P_unit *u, XTRA *x, HOSTSTATE *hs, unsigned offset, unsigned frames);
 
 static void amd_noop(A2P_unit *u, unsigned offset, unsigned frames)
@@ -1298,7 +1330,7 @@ static void head_process(A2P_unit *u, XTRA *x, HOSTSTATE *hs, unsigned offset, u
 	rc = a2amd_voice_process(XCTX(x), x->uid, offset - hs->base, frames, hs->noise_oscs ? &noise : NULL);
 	if(rc < 0)
 		fail(hs, "a2amd_voice_process", rc);
-	else if(rc == 1 && !hs->no_quick)
+	else if(rc == 1 && !hs->no_quick && !(x->nenv && env_busy(x)))
 	{
 		u->Process = amd_quick_process;
 		set_stamp(hs, x, 1);
@@ -1321,12 +1353,16 @@ static int setup_simple_chain(A2P_unit *u)
 	int slot;
 	for(n = u; n; n = n->next)
 	{
+		if(n->descriptor == &a2_env_unitdesc)
+			continue;
 		for(i = 0; i < sizeof(plain) / sizeof(plain[0]); ++i)
 			if(n->descriptor == plain[i])
 				break;
 		if(i == sizeof(plain) / sizeof(plain[0]) || xtra(n)->uid < 0)
 			return 0;
 	}
+	if(x->nenv && !env_chain_ok(u))
+		return 0;
 	if((slot = a2amd_voice_slot(XCTX(x), x->uid)) < 0)
 		return 0;
 	x->slot = slot;
@@ -1337,9 +1373,13 @@ static int setup_simple_chain(A2P_unit *u)
 	for(n = u; n; n = n->next)
 	{
 		xtra(n)->head = u;
+		if(n->descriptor == &a2_env_unitdesc)
+			continue;	/* (keeps its own Process) */
 		xtra(n)->chain_checked = 1;
 		n->Process = n == u ? amd_head_process : amd_noop;
 	}
+	for(i = 0; i < x->nenv; ++i)
+		xtra(x->env[i])->head = u;	/* (those in front of the head too) */
 	return 1;
 }
 
@@ -1424,6 +1464,8 @@ static void amd_inline_process(A2P_unit *u, unsigned offset, unsigned frames)
 			{
 				if(!hs->failed && (rc = a2amd_fragment(hs->ctxs[d], frames)))
 					fail(hs, "a2amd_fragment", rc);
+				if(offset && !hs->failed && (rc = a2amd_fragment_offset(hs->ctxs[d], offset)))
+					fail(hs, "a2amd_fragment_offset", rc);
 				hs->map[d] = hs->failed ? NULL : a2amd_default_map(hs->ctxs[d], &hs->map_cap[d]);
 				if(!hs->map[d])
 					hs->map_cap[d] = 0;
@@ -1645,6 +1687,7 @@ static void amd_write(A2P_unit *u, int reg, int v, unsigned start, unsigned dur)
 
 #define WR(n) static void wr##n(A2P_unit *u, int v, unsigned s, unsigned d) { amd_write(u, n, v, s, d); }
 WR(0) WR(1) WR(2) WR(3) WR(4) WR(5) WR(6) WR(7) WR(8) WR(9) WR(10) WR(11) WR(12)
+static const A2P_write_cb wr_table[13] = { wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7, wr8, wr9, wr10, wr11, wr12 };
 
 /* ---- the replaced units -----------------------------------------------------------*/
 #define OWN_UNIT(K, name, regvals) \
@@ -1686,6 +1729,297 @@ const A2P_unitdesc a2_filter12_unitdesc = { "filter12", A2P_MATCHIO, filter12_re
 	A2P_BLOCK_SIZE, filter12_init, amd_deinit, amd_open, amd_close };
 const A2P_unitdesc a2_fbdelay_unitdesc = { "fbdelay", 0, fbdelay_regs, NULL, NULL, 1, 2, 1, 2,
 	A2P_BLOCK_SIZE, fbdelay_init, amd_deinit, amd_open, amd_close };
+
+/* ---- env, src/units/env.c ---------------------------------------------------
+ * A control-rate unit: no audio ports, four registers (target mode down time), one control output
+ * that the program wires to a register of another unit of the voice (a2_ControlWire, core.c:330-345).
+ * A write to 'target' starts a segment; linear ones are passed on as a ramp of the wired register
+ * (env.c:172-181), the others walk one of eight tables, one step per window, and write the wired
+ * register at the head of every window (env.c:116-134).
+ * It is ours - rather than the engine's, which would do as well while the engine runs the voice -
+ * so that the segment in flight can travel with the voice: when the device VM takes the voice
+ * (a2amd_units_vm_adopt) the state below goes along, the device steps the segment (a2amd_vmcore.h:
+ * env_target / env_lut, the same arithmetic) and writes it back on recall.  Between those, on a
+ * voice the ENGINE runs, this is the reference's unit restated: it renders nothing, its output is
+ * the wired unit's write callback - the same record a VM instruction's write would leave. */
+typedef struct ENVSTATE
+{
+	int32_t		ramper[4];	/* A2_ramper {value, target, delta, timer}, a2_dsp.h */
+	int32_t		lut;		/* table of the running segment */
+	int32_t		scale, offset, out;	/* env.c:96-98 */
+	uint32_t	msdur;
+} ENVSTATE;
+#define ENVS(u)	((ENVSTATE *)((char *)(u) + 64 + sizeof(XTRA)))
+_Static_assert(64 + sizeof(XTRA) + sizeof(ENVSTATE) <= A2P_BLOCK_SIZE, "ENVSTATE placement");
+#define ENV_LUTSIZE 64	/* A2ENV_LUTSIZE, env.c:27-28 */
+
+static uint16_t env_luts[8][ENV_LUTSIZE + 2];	/* spline, EXP1 .. EXP7 (env.c:36-47) */
+static pthread_once_t env_luts_once = PTHREAD_ONCE_INIT;
+
+/* env_InitLUTs, env.c:218-257: the expressions - and the types they are evaluated in - are the
+ * reference's, so that every entry comes out the same (float constants widened to double next to a
+ * double, libm's cos / pow) */
+static void env_make_luts(void)
+{
+	static const char degree[7] = { 1, 2, 3, 4, 6, 9, 13 };
+	int i, j;
+	for(i = 0; i < ENV_LUTSIZE; ++i)
+		env_luts[0][i] = (1.0f - cos(i * M_PI / (ENV_LUTSIZE - 1))) * 16384.0f + 0.5f;
+	for(j = 0; j < 7; ++j)
+	{
+		const float d = degree[j];
+		const double c = pow(0.1f, d);
+		const double rc = 0.002f + 0.1f * pow(0.8f, d);
+		for(i = 0; i < ENV_LUTSIZE; ++i)
+		{
+			const double x = 1.0f - (double)i / ENV_LUTSIZE;
+			const double r = (1.0f - x) * rc;
+			env_luts[1 + j][i] = (pow(c, x) * (1.0f - r) + r - c * x) * 32768.0f + 0.5f;
+		}
+	}
+	for(j = 0; j < 8; ++j)
+		env_luts[j][ENV_LUTSIZE] = env_luts[j][ENV_LUTSIZE + 1] = 32768;
+}
+
+/* a2_PrepareRamper / a2_RunRamper / a2_SetRamper, a2_dsp.h (wrapping 32 bit arithmetic, as
+ * a2amd_vmcore.h: rp_prepare, rp_run, rp_set) */
+static inline int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+static inline int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+static inline int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+static void ramper_prepare(int32_t *r, int frames)
+{
+	if(!r[3])
+	{
+		r[0] = r[1];
+		r[2] = 0;
+	}
+	else if(frames <= (r[3] >> 8))
+	{
+		r[2] = (int32_t)(((int64_t)wsub(r[1], r[0]) * 256) / r[3]);
+		r[3] = wsub(r[3], frames << 8);
+	}
+	else
+	{
+		r[2] = wsub(r[1], r[0]) / frames;
+		r[3] = 0;
+	}
+}
+static void ramper_set(int32_t *r, int target, int start, int duration)
+{
+	r[1] = (int32_t)((uint32_t)target << 8);
+	r[3] = wadd(duration, start);
+	if(r[3] < 256)
+		r[0] = r[1];
+	else
+		r[0] = wadd(r[0], wmul(r[2], start) >> 8);
+}
+
+static void env_off(A2P_unit *u, unsigned offset, unsigned frames)
+{
+}
+
+/* one window of a running segment: env_ProcessLUT, env.c:116-134 */
+static void env_run(A2P_unit *u, unsigned offset, unsigned frames)
+{
+	ENVSTATE *e = ENVS(u);
+	A2P_cport *co = (A2P_cport *)u->coutputs;
+	const uint16_t *t = env_luts[e->lut & 7];
+	uint32_t i, f;
+	ramper_prepare(e->ramper, (int)frames);
+	e->ramper[0] = wadd(e->ramper[0], wmul(e->ramper[2], (int)frames));
+	i = (uint32_t)(e->ramper[0] >> (24 - 6));
+	if(i > ENV_LUTSIZE)
+		i = ENV_LUTSIZE;	/* (never: the unity ramp stays inside the table) */
+	f = (uint32_t)(e->ramper[0] >> (24 - 16 - 6)) & 65535u;
+	e->out = (int32_t)((f * (uint32_t)t[i + 1] + (65536u - f) * (uint32_t)t[i]) >> 7);
+	e->out = wadd((int32_t)(((int64_t)e->out * e->scale) >> 24), e->offset);
+	co->write(co->unit, e->out, offset, frames << 8);
+	if(!e->ramper[2])
+		u->Process = env_off;
+}
+
+/* a write to 'target': env_Target, env.c:137-215 */
+static void env_target(A2P_unit *u, int v, unsigned start, unsigned dur)
+{
+	ENVSTATE *e = ENVS(u);
+	XTRA *x = xtra(u);
+	const int *ci = u->registers;
+	A2P_cport *co = (A2P_cport *)u->coutputs;
+	int mode, lut;
+	if(!co->write)
+		return;
+	if(ci[3])	/* the 'time' register overrides the ramp's duration */
+		dur = (unsigned)(((int64_t)ci[3] * e->msdur + 0x7fffff) >> 24);
+	if(dur >= 256 - start)
+	{
+		mode = ci[2] >> 16;	/* 'down', unless going up or LINKed to 'mode' */
+		if(v >= e->out || !mode)
+			mode = ci[1] >> 16;
+	}
+	else
+		mode = 1;	/* (no time to bend anything) */
+	if(mode == -1)		/* SPLINE */
+	{
+		lut = 0;
+		mode = 1;
+	}
+	else if(mode >= 2 && mode <= 8)		/* EXP1 .. EXP7 */
+		lut = mode - 1;
+	else if(mode >= -8 && mode <= -2)	/* IEXP1 .. IEXP7: the same tables, walked backwards */
+		lut = -mode - 1;
+	else
+	{
+		e->out = v;
+		co->write(co->unit, v, start, dur);
+		u->Process = env_off;
+		return;
+	}
+	e->lut = lut;
+	if(mode >= 0)
+	{
+		e->scale = wsub(v, e->out);
+		e->offset = e->out;
+		e->ramper[0] = 0;
+		ramper_set(e->ramper, 1 << 16, (int)start, (int)dur);
+	}
+	else
+	{
+		e->scale = wsub(e->out, v);
+		e->offset = wsub(e->out, e->scale);
+		e->ramper[0] = (1 << 16) << 8;
+		ramper_set(e->ramper, 0, (int)start, (int)dur);
+	}
+	u->Process = env_run;
+	/* (the voice's units want their windows one by one while a segment runs) */
+	if(x->head && x->hs)
+	{
+		if(x->head->Process == amd_quick_process)
+			x->head->Process = amd_head_process;
+		set_stamp(x->hs, xtra(x->head), 0);
+	}
+}
+
+static int env_init(A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned flags)
+{
+	HOSTSTATE *hs = (HOSTSTATE *)sd;
+	XTRA *x = xtra(u);
+	ENVSTATE *e = ENVS(u);
+	memset(x, 0, sizeof(*x));
+	memset(e, 0, sizeof(*e));
+	x->hs = hs;
+	x->vms = vms;
+	x->kind = -1;
+	x->uid = -1;
+	if(hs->chain_vms != vms)
+	{
+		hs->chain_vms = vms;
+		hs->chain_last = NULL;
+		hs->chain_head = NULL;
+		hs->chain_nfwd = hs->chain_nenv = 0;
+	}
+	if(hs->chain_head)
+	{
+		XTRA *hx = xtra(hs->chain_head);
+		if(hx->nenv < 2)
+		{
+			hx->env[hx->nenv] = u;
+			hx->env_before[hx->nenv] = (uint8_t)hs->chain_nfwd;
+		}
+		if(hx->nenv < 3)
+			++hx->nenv;
+	}
+	else
+	{
+		if(hs->chain_nenv < 2)
+			hs->chain_env[hs->chain_nenv] = u;
+		if(hs->chain_nenv < 3)
+			++hs->chain_nenv;
+	}
+	e->msdur = hs->cfg->samplerate * 65.536f + .5f;	/* env.c:236 */
+	u->registers[0] = 0;		/* env.c:243-246 */
+	u->registers[1] = 1;		/* A2ENVRM_LINEAR - as the reference has it: not shifted */
+	u->registers[2] = 0;		/* A2ENVRM_LINK */
+	u->registers[3] = 0;
+	u->Process = env_off;
+	return 0;
+}
+
+static int env_open(A2P_config *cfg, void **statedata)
+{
+	pthread_once(&env_luts_once, env_make_luts);
+	return amd_open(cfg, statedata);
+}
+
+/* a segment is running on one of the head's env units */
+static int env_busy(const XTRA *head)
+{
+	int k;
+	for(k = 0; k < head->nenv && k < 2; ++k)
+		if(head->env[k]->Process == env_run)
+			return 1;
+	return head->nenv > 2;
+}
+
+/* Which forwarded unit of head's chain - by position - and which of its registers is this write
+ * callback?  -1: none of ours. */
+static int wired_to(A2P_unit *head, const A2P_cport *co, int *reg)
+{
+	A2P_unit *n;
+	int k, pos = 0;
+	for(k = 0; k < 13; ++k)
+		if(co->write == wr_table[k])
+			break;
+	if(k == 13)
+		return -1;
+	for(n = head; n; n = n->next)
+	{
+		if(n->descriptor == &a2_env_unitdesc)
+			continue;
+		if(n == co->unit)
+		{
+			*reg = k;
+			return pos;
+		}
+		++pos;
+	}
+	return -1;
+}
+
+/* With the head's Process speaking for the whole chain (setup_simple_chain) the chain's window is
+ * ONE event; the engine gives the window to unit after unit (core.c:1875-1876), with an env's write
+ * between two of them.  The two agree when every env either runs before all the others, or is wired
+ * to a unit in front of it - which has rendered the window either way. */
+static int env_chain_ok(A2P_unit *head)
+{
+	XTRA *x = xtra(head);
+	int k;
+	if(x->nenv > 2)
+		return 0;
+	for(k = 0; k < x->nenv; ++k)
+	{
+		const A2P_cport *co = (const A2P_cport *)x->env[k]->coutputs;
+		int reg, pos;
+		if(!co->write)
+			continue;
+		if((pos = wired_to(head, co, &reg)) < 0)
+			return 0;	/* (wired to another env, or to a register of somebody else's) */
+		if(x->env_before[k] && pos >= x->env_before[k])
+			return 0;
+	}
+	return 1;
+}
+
+static const A2P_crdesc env_regs[] = { { "target", env_target }, { "mode", NULL }, { "down", NULL }, { "time", NULL },
+		{ NULL, NULL } };
+static const A2P_codesc env_couts[] = { { "out" }, { NULL } };
+/* env.c:301-338: ramp modes as 16:16 values */
+static const A2P_constdesc env_consts[] = {
+	{ "IEXP7", -8 * 65536 }, { "IEXP6", -7 * 65536 }, { "IEXP5", -6 * 65536 }, { "IEXP4", -5 * 65536 }, { "IEXP3", -4 * 65536 },
+	{ "IEXP2", -3 * 65536 }, { "IEXP1", -2 * 65536 }, { "SPLINE", -1 * 65536 }, { "LINK", 0 }, { "LINEAR", 1 << 16 },
+	{ "EXP1", 2 << 16 }, { "EXP2", 3 << 16 }, { "EXP3", 4 << 16 }, { "EXP4", 5 << 16 }, { "EXP5", 6 << 16 },
+	{ "EXP6", 7 << 16 }, { "EXP7", 8 << 16 }, { NULL, 0 } };
+const A2P_unitdesc a2_env_unitdesc = { "env", 0, env_regs, env_couts, env_consts, 0, 0, 0, 0,
+	A2P_BLOCK_SIZE, env_init, amd_deinit, env_open, amd_close };
 
 /* ---- the FM oscillators, fm.c:509-834 ----------------------------------------------
  * Eight descriptors over one register list (phase, then p a fb per operator,
@@ -2040,9 +2374,17 @@ static uint32_t group_standing(A2P_unit *head, uint32_t *slotdev)
 	return hs->qstamp[x->dev][x->slot];
 }
 
+/* the walk hands over A2_voice.units: the chain's head is its first unit that is not an env */
+static inline const A2P_unit *past_envs(const A2P_unit *u)
+{
+	while(u && u->descriptor == &a2_env_unitdesc)
+		u = u->next;
+	return u;
+}
+
 uint32_t a2amd_units_standing(const void *head_unit, uint32_t *slotdev)
 {
-	const A2P_unit *head = (const A2P_unit *)head_unit;
+	const A2P_unit *head = past_envs((const A2P_unit *)head_unit);
 	const XTRA *x;
 	if(!head)
 		return 0;
@@ -2062,11 +2404,10 @@ uint32_t a2amd_units_standing(const void *head_unit, uint32_t *slotdev)
  * The walk (a2amd_walk.c) sees the engine's side of a voice - VM state, program text, which VM
  * register is wired to which unit's write callback - and calls here; this side knows which backend
  * unit an A2_unit is and which register a write callback stands for. */
-static const A2P_write_cb wr_table[13] = { wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7, wr8, wr9, wr10, wr11, wr12 };
 
 int a2amd_units_vm_is(const void *head_unit)
 {
-	const A2P_unit *head = (const A2P_unit *)head_unit;
+	const A2P_unit *head = past_envs((const A2P_unit *)head_unit);
 	const XTRA *x;
 	if(!head || head->descriptor == &a2_inline_unitdesc || head->descriptor == &a2_xinsert_unitdesc ||
 			head->descriptor == &a2_xsink_unitdesc || head->descriptor == &a2_xsource_unitdesc || !is_ours(head->descriptor))
@@ -2078,11 +2419,12 @@ int a2amd_units_vm_is(const void *head_unit)
 int a2amd_units_vm_adopt(const void *head_unit, const uint32_t *code, unsigned nwords, const void *vmstate,
 		void *const *wr_unit, void *const *wr_fn, uint32_t now, uint32_t msdur)
 {
-	A2P_unit *head = (A2P_unit *)head_unit, *n;
+	A2P_unit *head = (A2P_unit *)past_envs((const A2P_unit *)head_unit), *n;
 	XTRA *x;
 	HOSTSTATE *hs;
 	int32_t wu[A2AMD_VM_REGISTERS];
 	uint8_t wreg[A2AMD_VM_REGISTERS];
+	a2amd_vm_env envs[A2AMD_VM_MAXENV];
 	int r, k, prog, rc;
 	if(!head || !is_ours(head->descriptor) || head->descriptor == &a2_inline_unitdesc ||
 			head->descriptor == &a2_xinsert_unitdesc || head->descriptor == &a2_xsink_unitdesc ||
@@ -2102,6 +2444,40 @@ int a2amd_units_vm_adopt(const void *head_unit, const uint32_t *code, unsigned n
 		return -2;
 	}
 	x->vm_seen = hs->frag_serial;
+	if(x->nenv > A2AMD_VM_MAXENV)
+		return -1;
+	for(k = 0; k < x->nenv; ++k)
+	{
+		/* the voice's env units: state, place in the chain, where the control output goes */
+		A2P_unit *eu = x->env[k];
+		const ENVSTATE *e = ENVS(eu);
+		const A2P_cport *co = (const A2P_cport *)eu->coutputs;
+		a2amd_vm_env *o = &envs[k];
+		int reg = 0, pos;
+		memset(o, 0, sizeof(*o));
+		memcpy(o->ramper, e->ramper, sizeof(o->ramper));
+		o->lut = e->lut;
+		o->scale = e->scale;
+		o->offset = e->offset;
+		o->out = e->out;
+		o->active = eu->Process == env_run;
+		o->regbase = (int32_t)(eu->registers - x->vms->r);
+		o->before = x->env_before[k];
+		o->out_unit = -1;
+		if(co->write)
+		{
+			if((pos = wired_to(head, co, &reg)) < 0)
+				return -1;
+			o->out_unit = xtra(co->unit)->uid;
+			o->out_reg = reg;
+		}
+	}
+	if(x->nenv && !hs->envluts_sent[x->dev])
+	{
+		if((rc = a2amd_vm_envluts(XCTX(x), &env_luts[0][0])))
+			return -1;
+		hs->envluts_sent[x->dev] = 1;
+	}
 	for(r = 0; r < A2AMD_VM_REGISTERS; ++r)
 	{
 		wu[r] = -1;
@@ -2109,6 +2485,13 @@ int a2amd_units_vm_adopt(const void *head_unit, const uint32_t *code, unsigned n
 		if(!wr_fn[r])
 			continue;
 		wu[r] = -2;	/* (somebody else's callback: fine as long as the program cannot reach it) */
+		if((A2P_write_cb)wr_fn[r] == env_target)
+		{
+			for(k = 0; k < x->nenv; ++k)
+				if((void *)x->env[k] == wr_unit[r])
+					wu[r] = -3 - k;
+			continue;
+		}
 		for(k = 0; k < 13; ++k)
 			if((A2P_write_cb)wr_fn[r] == wr_table[k])
 				break;
@@ -2124,7 +2507,7 @@ int a2amd_units_vm_adopt(const void *head_unit, const uint32_t *code, unsigned n
 	}
 	if((prog = a2amd_vm_program(XCTX(x), (uint64_t)(uintptr_t)code, code, nwords)) < 0)
 		return -1;
-	rc = a2amd_vm_adopt(XCTX(x), x->uid, prog, (const a2amd_vm_state *)vmstate, wu, wreg, now, msdur);
+	rc = a2amd_vm_adopt(XCTX(x), x->uid, prog, (const a2amd_vm_state *)vmstate, wu, wreg, now, msdur, envs, x->nenv);
 	if(rc)
 	{
 		static int trace = -1;
@@ -2151,11 +2534,12 @@ int a2amd_units_vm_recall(const void *const *heads, unsigned n, void *const *vms
 		/* (one backend call - one device round trip - per context) */
 		int32_t uids[64];
 		a2amd_vm_state sts[64];
+		a2amd_vm_env envs[64][A2AMD_VM_MAXENV];
 		unsigned idx[64], m = 0;
 		HOSTSTATE *hs = NULL;
 		for(k = 0; k <= n; ++k)
 		{
-			XTRA *x = k < n ? (XTRA *)((char *)heads[k] + 64) : NULL;
+			XTRA *x = k < n ? (XTRA *)((char *)past_envs((const A2P_unit *)heads[k]) + 64) : NULL;
 			if(x && (!x->vm || x->dev != d))
 				continue;
 			if(x)
@@ -2166,16 +2550,29 @@ int a2amd_units_vm_recall(const void *const *heads, unsigned n, void *const *vms
 			}
 			if(m && (m == 64 || k == n))
 			{
-				XTRA *x0 = (XTRA *)((char *)heads[idx[0]] + 64);
-				int r2 = hs->failed ? -1 : a2amd_vm_recall(XCTX(x0), uids, m, sts);
+				XTRA *x0 = (XTRA *)((char *)past_envs((const A2P_unit *)heads[idx[0]]) + 64);
+				int r2 = hs->failed ? -1 : a2amd_vm_recall(XCTX(x0), uids, m, sts, &envs[0][0]);
 				if(r2 && !hs->failed)
 					fail(hs, "a2amd_vm_recall", r2);
 				for(j = 0; j < m; ++j)
 				{
-					A2P_unit *head = (A2P_unit *)heads[idx[j]];
+					A2P_unit *head = (A2P_unit *)past_envs((const A2P_unit *)heads[idx[j]]);
 					XTRA *xj = (XTRA *)((char *)head + 64);
+					int q;
 					if(!r2)
 						memcpy(vmstates[idx[j]], &sts[j], sizeof(a2amd_vm_state));
+					for(q = 0; !r2 && q < xj->nenv && q < A2AMD_VM_MAXENV; ++q)
+					{
+						/* its env units are where the device left them */
+						ENVSTATE *e = ENVS(xj->env[q]);
+						const a2amd_vm_env *o = &envs[j][q];
+						memcpy(e->ramper, o->ramper, sizeof(e->ramper));
+						e->lut = o->lut;
+						e->scale = o->scale;
+						e->offset = o->offset;
+						e->out = o->out;
+						xj->env[q]->Process = o->active ? env_run : env_off;
+					}
 					xj->vm = 0;
 					xj->vm_seen = hs->frag_serial;
 					xj->vm_seen_valid = 0;	/* (not offered again before it has been seen awake twice more) */

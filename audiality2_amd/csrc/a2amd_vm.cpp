@@ -74,6 +74,7 @@ Consts consts_of(a2amd_ctx *c)
 	K.basepitch = c->cfg.basepitch;
 	K.ptab = c->ptab;
 	K.f1tab = c->vm.f1tab.empty() ? nullptr : c->vm.f1tab.data();
+	K.envlut = c->vm.envlut.empty() ? nullptr : c->vm.envlut.data();
 	return K;
 }
 
@@ -355,7 +356,7 @@ namespace a2h {
 // records of the fragments the device VM would have covered in this batch go into the voice's
 // host record list, the filter cutoffs return to their host shadows.  out (may be null) = the
 // engine's A2_vmstate.
-int vm_take_back(a2amd_ctx *c, int vi, bool inclusive, a2amd_vm_state *out)
+int vm_take_back(a2amd_ctx *c, int vi, bool inclusive, a2amd_vm_state *out, a2amd_vm_env *envs_out)
 {
 	VmHost &m = c->vm;
 	HVoice &v = c->voices[vi];
@@ -386,8 +387,9 @@ int vm_take_back(a2amd_ctx *c, int vi, bool inclusive, a2amd_vm_state *out)
 			frames_before += c->fragframes[f];
 		const uint32_t now = m.t0 + (uint32_t)((m.batch_time + frames_before) << 8);
 		const unsigned *ff = c->fragframes;
+		const uint8_t *fb = c->fragbase;
 		const size_t mark = c->voices[vi].recs.size();
-		run_batch(st, m.code.data() + p.off, K, e, now, f0, f1, [ff](int f) { return ff[f]; });
+		run_batch(st, m.code.data() + p.off, K, e, now, f0, f1, [ff, fb](int f) { return ff[f] | ((unsigned)fb[f] << 8); });
 		if(st.fault)
 			return c->fail(A2AMD_ESTATE, "device VM: voice %d faulted (trap %d at pc %u): the analysis let a program through "
 					"that it should not have", vi, st.fault, (unsigned)st.pc);
@@ -423,6 +425,21 @@ int vm_take_back(a2amd_ctx *c, int vi, bool inclusive, a2amd_vm_state *out)
 		c->n_cutoff_ramps += (int)(u.cutoff.timer != 0) - (int)was;
 	}
 	vv.plain = 0;
+	if(envs_out)
+		for(int k = 0; k < A2AMD_VM_MAXENV; ++k) {
+			a2amd_vm_env &o = envs_out[k];
+			memset(&o, 0, sizeof(o));
+			if(k >= st.nenv)
+				continue;
+			memcpy(o.ramper, st.env[k].ramper, sizeof(o.ramper));
+			o.lut = st.env[k].lut;
+			o.scale = st.env[k].scale;
+			o.offset = st.env[k].offset;
+			o.out = st.env[k].out;
+			o.active = st.env[k].active;
+			o.regbase = st.env[k].regbase;
+			o.before = st.env[k].k;
+		}
 	if(out) {
 		out->waketime = st.waketime;
 		out->state = st.state;
@@ -465,7 +482,8 @@ int vm_blob_room(a2amd_ctx *c)
 int vm_prepare_batch(a2amd_ctx *c)
 {
 	VmHost &m = c->vm;
-	if(m.pending.empty() && m.to_upload.empty() && m.code_uploaded == m.code.size() && (m.f1tab_up || m.f1tab.empty()))
+	if(m.pending.empty() && m.to_upload.empty() && m.code_uploaded == m.code.size() && (m.f1tab_up || m.f1tab.empty()) &&
+			(m.envlut_up || m.envlut.empty()))
 		return 0;
 	use_device(c);
 	const std::vector<int> pend = m.pending;
@@ -481,7 +499,8 @@ int vm_prepare_batch(a2amd_ctx *c)
 			frames_before += c->fragframes[f];
 		const uint32_t now = m.t0 + (uint32_t)((m.batch_time + frames_before) << 8);
 		const unsigned *ff = c->fragframes;
-		run_batch(h.st, m.code.data() + p.off, K, e, now, h.adopt_frag + 1, c->nfrags, [ff](int f) { return ff[f]; });
+		const uint8_t *fb = c->fragbase;
+		run_batch(h.st, m.code.data() + p.off, K, e, now, h.adopt_frag + 1, c->nfrags, [ff, fb](int f) { return ff[f] | ((unsigned)fb[f] << 8); });
 		if(h.st.fault)
 			return c->fail(A2AMD_ESTATE, "device VM: voice %d faulted (trap %d at pc %u)", h.voice, h.st.fault, (unsigned)h.st.pc);
 		h.pending = false;
@@ -505,6 +524,13 @@ int vm_prepare_batch(a2amd_ctx *c)
 		HIPCHK(c, hipMemcpyAsync(m.d_f1tab, m.f1tab.data(), m.f1tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		m.f1tab_up = true;
+	}
+	if(!m.envlut.empty() && !m.envlut_up) {
+		if(!m.d_envlut)
+			HIPCHK(c, hipMalloc((void **)&m.d_envlut, m.envlut.size() * sizeof(uint16_t)));
+		HIPCHK(c, hipMemcpyAsync(m.d_envlut, m.envlut.data(), m.envlut.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		m.envlut_up = true;
 	}
 	if(!m.to_upload.empty()) {
 		if(int r = grow(c, m.d_vmv, m.vms.size(), 1, true))
@@ -598,6 +624,7 @@ int vm_issue(a2amd_ctx *c)
 	vp.code = m.d_code.d;
 	vp.ptab = c->d_ptab;
 	vp.f1tab = m.d_f1tab;
+	vp.envlut = m.d_envlut;
 	vp.runs = c->d_runs.d;
 	vp.vmrun = m.d_vmrun.d;
 	vp.recs = (A2DRec *)c->hparams.recs;
@@ -607,8 +634,10 @@ int vm_issue(a2amd_ctx *c)
 	vp.samplerate = c->cfg.samplerate;
 	vp.basepitch = c->cfg.basepitch;
 	vp.nfrags = c->nfrags;
-	for(int f = 0; f < c->nfrags; ++f)
+	for(int f = 0; f < c->nfrags; ++f) {
 		vp.fragframes[f] = (uint8_t)c->fragframes[f];
+		vp.fragbase[f] = c->fragbase[f];
+	}
 	HIPCHK(c, hipMemsetAsync(m.d_total, 0, 2 * sizeof(uint32_t), c->stream));
 	if(a2d_launch_vm(vp, 0, c->stream))
 		return c->fail(A2AMD_EHIP, "VM count launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -642,6 +671,21 @@ int vm_issue(a2amd_ctx *c)
 	vp.rec_cap = m.rec_cap;
 	if(a2d_launch_vm(vp, 1, c->stream))
 		return c->fail(A2AMD_EHIP, "VM emit launch failed: %s", hipGetErrorString(hipGetLastError()));
+	static const bool dump = getenv("A2AMD_VM_DUMP") != nullptr;	// (... and device-made)
+	if(dump) {
+		std::vector<A2DRun> runs(m.list.size());
+		std::vector<A2DRec> recs(total);
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		HIPCHK(c, hipMemcpy(runs.data(), m.d_vmrun.d, runs.size() * sizeof(A2DRun), hipMemcpyDeviceToHost));
+		if(total)
+			HIPCHK(c, hipMemcpy(recs.data(), vp.recs + vp.rec_base, total * sizeof(A2DRec), hipMemcpyDeviceToHost));
+		for(size_t k = 0; k < runs.size(); ++k)
+			for(int q = 0; q < runs[k].count && (size_t)(runs[k].first + q) < recs.size(); ++q) {
+				const A2DRec &r = recs[runs[k].first + q];
+				fprintf(stderr, "REC %lld v%d f%u op%u u%u r%u val %d dur %u start %u (vm)\n", c->serial_base, m.vms[m.list[k]].voice,
+						A2D_RFRAG(r.head), A2D_ROP(r.head), A2D_RUNIT(r.head), A2D_RREG(r.head), r.value, r.dur, r.start);
+			}
+	}
 	c->stats.launches += 2;
 	c->stats.records += total;
 	m.stats.vm_voice_batches += m.list.size();
@@ -677,6 +721,7 @@ void vm_close(a2amd_ctx *c)
 	hipFree(m.d_list.d);
 	hipFree(m.d_vmrun.d);
 	hipFree(m.d_f1tab);
+	hipFree(m.d_envlut);
 	hipFree(m.d_total);
 	if(m.h_total)
 		hipHostFree(m.h_total);
@@ -714,8 +759,17 @@ int a2amd_vm_program(a2amd_ctx *c, uint64_t key, const uint32_t *code, unsigned 
 	return (int)m.progs.size() - 1;
 }
 
+int a2amd_vm_envluts(a2amd_ctx *c, const uint16_t *luts)
+{
+	if(!luts)
+		return c->fail(A2AMD_EINVAL, "vm_envluts: null");
+	c->vm.envlut.assign(luts, luts + A2D_ENV_LUTS * (A2D_ENV_LUTSIZE + 2));
+	c->vm.envlut_up = false;
+	return A2AMD_OK;
+}
+
 int a2amd_vm_adopt(a2amd_ctx *c, int head, int prog, const a2amd_vm_state *st, const int32_t *wr_unit,
-		const uint8_t *wr_reg, uint32_t now, uint32_t msdur)
+		const uint8_t *wr_reg, uint32_t now, uint32_t msdur, const a2amd_vm_env *envs, int nenv)
 {
 	VmHost &m = c->vm;
 	if(head < 0 || head >= (int)c->units.size() || !c->units[head].live || !st || !wr_unit || !wr_reg)
@@ -795,12 +849,51 @@ int a2amd_vm_adopt(a2amd_ctx *c, int head, int prog, const a2amd_vm_state *st, c
 	if(info.reason)
 		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: %s (opcode %d at %d)", reason_text(info.reason), info.opcode, info.at);
 	bool any = false;
+	// the voice's env units: where their control outputs go must be a register the device VM writes
+	if(nenv < 0 || nenv > A2AMD_VM_MAXENV || (nenv && !envs))
+		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: %d env units", nenv);
+	if(nenv && m.envlut.empty())
+		return c->fail(A2AMD_ESTATE, "vm_adopt: env units, but no tables (a2amd_vm_envluts)");
+	d.nenv = nenv;
+	for(int k = 0; k < nenv; ++k) {
+		A2DVmEnv &en = d.env[k];
+		memcpy(en.ramper, envs[k].ramper, sizeof(en.ramper));
+		en.lut = envs[k].lut;
+		en.scale = envs[k].scale;
+		en.offset = envs[k].offset;
+		en.out = envs[k].out;
+		en.active = envs[k].active;
+		if(envs[k].regbase < 0 || envs[k].regbase + 3 >= A2AMD_VM_REGISTERS || envs[k].before < 0 || envs[k].before > v.nunits ||
+				envs[k].lut < 0 || envs[k].lut >= A2D_ENV_LUTS)
+			return c->fail(A2AMD_EINVAL, "vm_adopt: env unit %d", k);
+		en.regbase = (uint8_t)envs[k].regbase;
+		en.k = (uint8_t)envs[k].before;
+		en.target = A2D_VM_NOWRITE;
+		if(envs[k].out_unit != -1) {
+			int pos = -1;
+			for(int q = 0; q < v.nunits; ++q)
+				if(v.unit[q] == envs[k].out_unit)
+					pos = q;
+			if(pos < 0 || !write_supported(c->units[v.unit[pos]].kind, envs[k].out_reg))
+				return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: %s (env unit %d -> unit %d register %d)",
+						reason_text(A2AMD_VM_TARGET), k, envs[k].out_unit, envs[k].out_reg);
+			en.target = (uint8_t)((pos << 4) | envs[k].out_reg);
+			need_f1 |= write_needs_f1tab(c->units[v.unit[pos]].kind, envs[k].out_reg);
+			if(en.active)
+				any = true;	// (a running segment is work the engine no longer has to do)
+		}
+	}
 	for(int r = 0; r < A2AMD_VM_REGISTERS; ++r) {
 		if(wr_unit[r] == -1)
 			continue;
 		// (a register the VM can never pass to a2_VoiceControl may be wired to anything)
 		if(!(info.controlled & (1ull << r)))
 			continue;
+		if(wr_unit[r] <= -3 && -3 - wr_unit[r] < nenv) {
+			d.cmap[r] = (uint8_t)((A2D_VM_ENVPOS << 4) | (-3 - wr_unit[r]));
+			any |= d.env[-3 - wr_unit[r]].target != A2D_VM_NOWRITE;
+			continue;
+		}
 		int pos = -1;
 		for(int k = 0; k < v.nunits; ++k)
 			if(v.unit[k] == wr_unit[r])
@@ -865,7 +958,7 @@ int a2amd_vm_adopted(a2amd_ctx *c, int head)
 	return c->voices[c->units[head].voice].vm >= 0;
 }
 
-int a2amd_vm_recall(a2amd_ctx *c, const int32_t *heads, unsigned n, a2amd_vm_state *out)
+int a2amd_vm_recall(a2amd_ctx *c, const int32_t *heads, unsigned n, a2amd_vm_state *out, a2amd_vm_env *envs_out)
 {
 	if(!heads || !out)
 		return c->fail(A2AMD_EINVAL, "vm_recall: null argument");
@@ -874,7 +967,7 @@ int a2amd_vm_recall(a2amd_ctx *c, const int32_t *heads, unsigned n, a2amd_vm_sta
 	for(unsigned k = 0; k < n; ++k) {
 		if(heads[k] < 0 || heads[k] >= (int)c->units.size() || !c->units[heads[k]].live)
 			return c->fail(A2AMD_EINVAL, "vm_recall: bad unit %d", heads[k]);
-		if(int r = vm_take_back(c, c->units[heads[k]].voice, false, &out[k]))
+		if(int r = vm_take_back(c, c->units[heads[k]].voice, false, &out[k], envs_out ? envs_out + (size_t)k * A2AMD_VM_MAXENV : nullptr))
 			return r;
 	}
 	return A2AMD_OK;
@@ -920,6 +1013,7 @@ int a2amd_vm_trace_host(const uint32_t *code, unsigned nwords, a2amd_vm_state *s
 	K.basepitch = basepitch;
 	K.ptab = ptab;
 	K.f1tab = nullptr;
+	K.envlut = nullptr;
 	if(need_f1) {
 		if(f1.empty() || f1_sr != samplerate) {
 			f1.resize((size_t)32 * 65536);

@@ -32,10 +32,10 @@ void k_vm_count(A2DVmParams vp)
 	int n = 0, fault = 0;
 	if(i < vp.n) {
 		A2DVmVoice v = vp.vmv[vp.list[i]];
-		const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab };
+		const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab, vp.envlut };
 		CountE e = { 0 };
-		const uint8_t *ff = vp.fragframes;
-		run_batch(v, vp.code + v.code, K, e, vp.now, 0, vp.nfrags, [ff](int f) { return (unsigned)ff[f]; });
+		const uint8_t *ff = vp.fragframes, *fb = vp.fragbase;
+		run_batch(v, vp.code + v.code, K, e, vp.now, 0, vp.nfrags, [ff, fb](int f) { return (unsigned)ff[f] | ((unsigned)fb[f] << 8); });
 		n = e.n;
 		fault = v.fault != 0;
 	}
@@ -70,12 +70,12 @@ void k_vm_emit(A2DVmParams vp)
 	const int slot = vp.list[i];
 	A2DVmVoice v = vp.vmv[slot];
 	const A2DRun place = vp.vmrun[i];
-	const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab };
+	const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab, vp.envlut };
 	A2DRun run = { 0, 0 };
 	if((unsigned)place.first + (unsigned)place.count <= vp.rec_cap) {
 		StoreE e = { vp.recs + vp.rec_base + place.first, 0 };
-		const uint8_t *ff = vp.fragframes;
-		run_batch(v, vp.code + v.code, K, e, vp.now, 0, vp.nfrags, [ff](int f) { return (unsigned)ff[f]; });
+		const uint8_t *ff = vp.fragframes, *fb = vp.fragbase;
+		run_batch(v, vp.code + v.code, K, e, vp.now, 0, vp.nfrags, [ff, fb](int f) { return (unsigned)ff[f] | ((unsigned)fb[f] << 8); });
 		if(e.n) {
 			run.first = (int)(vp.rec_base + (unsigned)place.first);
 			run.count = e.n;

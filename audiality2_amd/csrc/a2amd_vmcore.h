@@ -31,9 +31,12 @@ struct Consts {
 	int32_t samplerate, basepitch;
 	const uint32_t *ptab;		// 64 x {base, coeff}, pitch.c:70-96
 	const int32_t *f1tab;		// [32][65536] or null
+	const uint16_t *envlut;		// [A2D_ENV_LUTS][A2D_ENV_LUTSIZE + 2] or null
 };
 
 enum { TRAP_NONE = 0, TRAP_OVERLOAD, TRAP_OPCODE, TRAP_DIVISOR, TRAP_PC };
+// (env keeps its own copy of the state's msdur, env.c:236: the same expression)
+VMFN uint32_t en_msdur(const Consts &K) { return K.msdur; }
 
 VMFN int vadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 VMFN int vsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
@@ -151,6 +154,78 @@ VMFN bool write_needs_f1tab(int kind, int reg)
 	return (kind == A2D_FILTER12 || kind == A2D_DCBLOCK) && reg == 0;
 }
 
+template<class E>
+VMFN void write_unit(A2DVmVoice &v, const Consts &K, E &e, int frag, unsigned m, int value, unsigned start, unsigned dur);
+
+// env_Target, env.c:137-215: a write to an env unit's 'target' register.  Linear / zero-length segments go
+// straight through the control wire; the others set up a unity ramp over a table that env_lut() below
+// walks window by window.  ci = the unit's registers in the VM's register file (target, mode, down, time).
+template<class E>
+VMFN void env_target(A2DVmVoice &v, const Consts &K, E &e, int frag, int slot, int val, unsigned start, unsigned dur)
+{
+	A2DVmEnv &en = v.env[slot & (A2D_VM_MAXENV - 1)];
+	const int32_t *ci = v.r + en.regbase;
+	if(en.target == A2D_VM_NOWRITE)		// (output not connected)
+		return;
+	if(ci[3])				// ramp duration override, env.c:148-149
+		dur = ms2t(en_msdur(K), ci[3]);
+	int mode;
+	if(dur >= 256u - start) {
+		mode = ci[2] >> 16;
+		if(val >= en.out || mode == 0)
+			mode = ci[1] >> 16;
+	} else
+		mode = 1;
+	int lut;
+	if(mode == -1) {			// A2ENVRM_SPLINE
+		lut = 0;
+		mode = 1;
+	} else if(mode >= 2 && mode <= 8)	// EXP1 .. EXP7
+		lut = 1 + mode - 2;
+	else if(mode >= -8 && mode <= -2)	// IEXP1 .. IEXP7
+		lut = 1 - mode - 2;
+	else {					// LINK, LINEAR, anything else
+		en.out = val;
+		en.active = 0;
+		write_unit(v, K, e, frag, en.target, val, start, dur);
+		return;
+	}
+	en.lut = lut;
+	int rstart, rend;
+	if(mode >= 0) {
+		rstart = 0;
+		rend = 1 << 16;
+		en.scale = vsub(val, en.out);
+		en.offset = en.out;
+	} else {
+		rstart = 1 << 16;
+		rend = 0;
+		en.scale = vsub(en.out, val);
+		en.offset = vsub(en.out, en.scale);
+	}
+	en.ramper[0] = (int)((unsigned)rstart << 8);
+	rp_set(en.ramper, rend, (int)start, (int)dur);
+	en.active = 1;
+}
+
+// env_ProcessLUT, env.c:116-134: one window of a running segment; the write goes to the wired register with
+// the window's offset as start and its length as duration
+VMFN void env_lut(const Consts &K, A2DVmEnv &en, int frames)
+{
+	const uint16_t *t = K.envlut + (size_t)en.lut * (A2D_ENV_LUTSIZE + 2);
+	rp_prepare(en.ramper, frames);
+	rp_run(en.ramper, frames);
+	uint32_t i = (uint32_t)(en.ramper[0] >> (24 - A2D_ENV_LUTSHIFT));
+	if(i > A2D_ENV_LUTSIZE)		// (never: the unity ramp stays inside the table)
+		i = A2D_ENV_LUTSIZE;
+	const uint32_t f = (uint32_t)(en.ramper[0] >> (24 - 16 - A2D_ENV_LUTSHIFT)) & 65535u;
+	// (as the engine computes it: unsigned 32 bit products, then int)
+	en.out = (int)((f * (uint32_t)t[i + 1] + (65536u - f) * (uint32_t)t[i]) >> 7);
+	en.out = vadd((int)(((int64_t)en.out * (int64_t)en.scale) >> 24), en.offset);
+	if(!en.ramper[2])
+		en.active = 0;
+}
+
 // a2_VoiceControl (core.c:143-149) -> the unit's write callback -> the record a2amd_unit_write
 // (a2amd_host.cpp) makes of it.  E: rec(frag, op, unit, reg, value, dur, start).
 template<class E>
@@ -159,8 +234,18 @@ VMFN void control(A2DVmVoice &v, const Consts &K, E &e, int frag, unsigned reg, 
 	const unsigned m = v.cmap[reg & 63u];
 	if(m == A2D_VM_NOWRITE)
 		return;
+	if((m >> 4) == A2D_VM_ENVPOS) {		// an env unit's 'target' register
+		env_target(v, K, e, frag, (int)(m & 15u), v.r[reg & 63u], start & 255u, dur);
+		return;
+	}
+	write_unit(v, K, e, frag, m, v.r[reg & 63u], start, dur);
+}
+
+// the unit's write callback -> the record a2amd_unit_write makes of it (m = chain position << 4 | register)
+template<class E>
+VMFN void write_unit(A2DVmVoice &v, const Consts &K, E &e, int frag, unsigned m, int value, unsigned start, unsigned dur)
+{
 	const int pos = (int)(m >> 4), ureg = (int)(m & 15u), kind = v.kind[pos & 7];
-	int value = v.r[reg & 63u];
 	const int transpose = v.r[A2AMD_VM_R_TRANSPOSE];
 	start &= 255u;
 	switch(kind) {
@@ -419,7 +504,10 @@ VMFN uint32_t run_batch(A2DVmVoice &v, const uint32_t *code, const Consts &K, E 
 {
 	uint32_t fs = now;
 	for(int f = f0; f < f1; ++f) {
-		const int frames = (int)frames_of(f);
+		// (frames | offset of the fragment inside the engine's own fragment << 8: what the engine hands
+		// a2_ProcessVoices as 'offset', core.c:1968 - not 0 where the root voice's program cut the fragment)
+		const unsigned ff = frames_of(f);
+		const int frames = (int)(ff & 255u), base = (int)(ff >> 8);
 		const int before = e.count();
 		int s = 0;
 		while(s < frames) {
@@ -444,15 +532,40 @@ VMFN uint32_t run_batch(A2DVmVoice &v, const uint32_t *code, const Consts &K, E 
 			}
 			if(res > frames - s)
 				res = frames - s;
-			for(int k = 0; k < (int)v.ncut && k < A2D_VM_MAXCUT; ++k) {
-				rp_prepare(v.cut[k], res);
-				if(v.cut[k][2]) {
-					rp_run(v.cut[k], res);
-					e.rec(f, R_F1RAMP, v.cutpos[k], 0, f1_of_pitch(K, v.cut[k][0] >> 8), 0, 0);
+			// The units get the window in chain order (core.c:1875-1876).  What the recorder keeps of that:
+			// a running env segment's write through its control wire (env.c:116-134) - into the records
+			// before the window if the target unit comes behind the env in the chain, behind it if the
+			// target has already rendered the window (push_rec, a2amd_sched.cpp) - and a ramping cutoff's
+			// coefficient for the window (the head of f12_process, filter12.c:86-96).
+			int nlate = 0, late_slot[A2D_VM_MAXENV];
+			if(v.nenv | v.ncut)
+				for(int p = 0; p <= A2D_MAXCHAIN; ++p) {
+					for(int k = 0; k < v.nenv && k < A2D_VM_MAXENV; ++k) {
+						A2DVmEnv &en = v.env[k];
+						if(en.k != p || !en.active)
+							continue;
+						env_lut(K, en, res);
+						const bool cutoff = v.kind[(en.target >> 4) & 7] == A2D_FILTER12 && (en.target & 15u) == 0;
+						if((int)(en.target >> 4) >= p || cutoff)	// (a cutoff write is host state, not a record)
+							write_unit(v, K, e, f, en.target, en.out, (unsigned)(base + s), (unsigned)res << 8);
+						else
+							late_slot[nlate++] = k;
+					}
+					for(int k = 0; k < (int)v.ncut && k < A2D_VM_MAXCUT; ++k)
+						if(v.cutpos[k] == p) {
+							rp_prepare(v.cut[k], res);
+							if(v.cut[k][2]) {
+								rp_run(v.cut[k], res);
+								e.rec(f, R_F1RAMP, v.cutpos[k], 0, f1_of_pitch(K, v.cut[k][0] >> 8), 0, 0);
+							}
+						}
 				}
-			}
-			if(!(s == 0 && res == frames && e.count() == before))
+			if(!(s == 0 && res == frames && e.count() == before && !nlate))
 				e.rec(f, R_SEG, 0, 0, 0, (unsigned)s | ((unsigned)res << 16), 0);
+			for(int k = 0; k < nlate; ++k) {
+				const A2DVmEnv &en = v.env[late_slot[k]];
+				write_unit(v, K, e, f, en.target, en.out, (unsigned)(base + s), (unsigned)res << 8);
+			}
 			s += res;
 		}
 		fs += (uint32_t)frames << 8;

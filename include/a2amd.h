@@ -157,6 +157,11 @@ int  a2amd_wave_drop(a2amd_ctx *ctx, uint64_t key);
 /* Begin the next fragment of 'frames' (1..64) sample frames; all following
  * init/write/process calls belong to it (src/core.c:1964-1973). */
 int  a2amd_fragment(a2amd_ctx *ctx, unsigned frames);
+/* Where the open fragment starts inside the ENGINE's own fragment: the 'offset' a2_VoiceProcess hands the
+ * units (src/core.c:1856-1876) - 0, unless the root voice's program woke in mid-fragment and the engine's
+ * fragment became two of the backend's.  Only the env units of voices the device VM runs need it (they pass
+ * it on as the start of their writes, src/units/env.c:131); default 0. */
+int  a2amd_fragment_offset(a2amd_ctx *ctx, unsigned offset);
 
 /* ---- unit callbacks --------------------------------------------------------*/
 /*

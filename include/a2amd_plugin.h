@@ -23,6 +23,8 @@
  *                         replace  src/units/fm.c:532,579,631,688,719,752,783,814
  *   a2_dc_unitdesc, a2_waveshaper_unitdesc, a2_dcblock_unitdesc, a2_limiter_unitdesc
  *                         replace  src/units/dc.c:262, waveshaper.c:172, dcblock.c:168, limiter.c:228
+ *   a2_env_unitdesc       replaces src/units/env.c:341-363 (control rate, no audio ports: the host keeps its state
+ *                         while the engine runs the voice's VM, the device while the device VM does)
  *   a2_inline_unitdesc    wraps    src/units/inline.c:50-69
  *   a2_xinsert_unitdesc   wraps    src/units/xinsert.c:232-252
  * Imported from the engine at load time (public API, include/a2_waves.h:183,
@@ -89,6 +91,11 @@ typedef void (*A2P_process_cb)(A2P_unit *u, unsigned offset, unsigned frames);
 /* A2_crdesc / A2_constdesc, include/a2_units.h:196-221 */
 typedef struct A2P_crdesc { const char *name; A2P_write_cb write; } A2P_crdesc;
 typedef struct A2P_constdesc { const char *name; int value; } A2P_constdesc;
+
+/* A2_codesc / A2_cport, include/a2_units.h:208-211, :254-266: a unit's control outputs; the engine fills a
+ * port from the voice's register write table when the program wires it (a2_ControlWire, src/core.c:330-345) */
+typedef struct A2P_codesc { const char *name; } A2P_codesc;
+typedef struct A2P_cport { A2P_unit *unit; A2P_write_cb write; } A2P_cport;
 
 /* A2_unitdesc, include/a2_units.h:225-251 */
 struct A2P_unitdesc
@@ -198,6 +205,7 @@ typedef struct A2P_audiodriver
 #define A2P_MATCHIO	0x00010000
 #define A2P_XINSERT	0x00020000
 
+extern const A2P_unitdesc a2_env_unitdesc;
 extern const A2P_unitdesc a2_wtosc_unitdesc, a2_panmix_unitdesc, a2_filter12_unitdesc,
 		a2_fbdelay_unitdesc, a2_inline_unitdesc, a2_xinsert_unitdesc,
 		a2_xsink_unitdesc, a2_xsource_unitdesc,

@@ -118,11 +118,33 @@ int a2amd_vm_analyze(const uint32_t *code, unsigned nwords, unsigned pc, int32_t
  * context; 'key' identifies it on the host (the code pointer).  Returns a program id >= 0. */
 int a2amd_vm_program(a2amd_ctx *ctx, uint64_t key, const uint32_t *code, unsigned nwords);
 
+/* An env unit in the voice's chain (src/units/env.c): a control-rate unit without audio ports
+ * whose output is a register write on another unit through a control wire (env.c:135).  For a voice the
+ * device VM runs, its state travels with the VM state and its segments are evaluated on the device - window
+ * by window, in chain order - by the same interpreter. */
+#define A2AMD_VM_MAXENV 2
+typedef struct a2amd_vm_env {
+	int32_t ramper[4];	/* A2_env.ramper {value, target, delta, timer}, env.c:92 */
+	int32_t lut;		/* A2ENVLUT_* (env.c:36-47) of the running segment */
+	int32_t scale, offset, out;	/* env.c:96-98 */
+	int32_t active;		/* its Process is env_ProcessLUT (env.c:116-134), not env_ProcessOff */
+	int32_t regbase;	/* the VM register its 'target' register is (then mode, down, time) */
+	int32_t before;		/* backend units of the voice's chain in front of it */
+	int32_t out_unit;	/* backend unit its control output is wired to (a2_ControlWire, core.c:330-345), -1 none */
+	int32_t out_reg;	/* ... and that unit's register */
+} a2amd_vm_env;
+/* The eight tables of env.c:218-257 (spline, EXP1 .. EXP7; 64 + 2 entries each), made by the host with the
+ * reference's expressions (float / double libm): once per context, before the first voice with an env unit
+ * is adopted. */
+int a2amd_vm_envluts(a2amd_ctx *ctx, const uint16_t *luts8x66);
+
 /* Hand the voice 'head_unit' belongs to over to the device VM, from the OPEN fragment on (in which
  * the engine has already processed it: the device takes over with the next one).
  *   st        the voice's A2_vmstate as the engine leaves it now (state A2AMD_VM_WAITING)
  *   wr_unit   [A2AMD_VM_REGISTERS] backend unit id VM register i is wired to (A2_voice.cregs[i],
- *             src/internals.h:573: the unit whose write callback a2_VoiceControl calls), -1 none
+ *             src/internals.h:573: the unit whose write callback a2_VoiceControl calls), -1 none,
+ *             -2 somebody else's callback, -3 - k the 'target' register of envs[k]
+ *   envs      the voice's env units, nenv <= A2AMD_VM_MAXENV of them (may be NULL / 0)
  *   wr_reg    [A2AMD_VM_REGISTERS] ... and that unit's register index (a2amd_unit_write's 'reg')
  *   now       engine time (A2_state.now_fragstart + (offset << 8), core.c:1855) of the START of the
  *             open fragment
@@ -130,7 +152,8 @@ int a2amd_vm_program(a2amd_ctx *ctx, uint64_t key, const uint32_t *code, unsigne
  * Fails with A2AMD_EUNSUPPORTED (and a reason in a2amd_last_error) when a2amd_vm_analyze() or the
  * voice's chain says no; the voice then simply stays with the engine. */
 int a2amd_vm_adopt(a2amd_ctx *ctx, int head_unit, int prog, const a2amd_vm_state *st,
-		const int32_t *wr_unit, const uint8_t *wr_reg, uint32_t now, uint32_t msdur);
+		const int32_t *wr_unit, const uint8_t *wr_reg, uint32_t now, uint32_t msdur,
+		const a2amd_vm_env *envs, int nenv);
 
 /* 1 while the voice 'head_unit' belongs to is run by the device VM. */
 int a2amd_vm_adopted(a2amd_ctx *ctx, int head_unit);
@@ -139,8 +162,10 @@ int a2amd_vm_adopted(a2amd_ctx *ctx, int head_unit);
  * A2_vmstate the engine's own a2_VoiceProcess calls would have left in voice k by now (every VM run
  * due before the start of the open fragment executed, none of those due in it).  From the open
  * fragment on the voices are the host's again (their unit windows and writes arrive as calls).
- * One device round trip for the lot. */
-int a2amd_vm_recall(a2amd_ctx *ctx, const int32_t *head_units, unsigned n, a2amd_vm_state *out);
+ * One device round trip for the lot.  envs_out (may be NULL): [n][A2AMD_VM_MAXENV], the state of voice k's
+ * env units as of the same moment (ramper, lut, scale, offset, out, active). */
+int a2amd_vm_recall(a2amd_ctx *ctx, const int32_t *head_units, unsigned n, a2amd_vm_state *out,
+		a2amd_vm_env *envs_out);
 
 /* ---- test / measurement access (no GPU needed) -----------------------------------------*/
 /* Run the HOST copy of the interpreter - the same source the kernel is compiled from

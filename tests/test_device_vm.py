@@ -72,6 +72,37 @@ def test_looping_voices_run_on_the_device_vm_and_sound_like_the_cpu_engine(tmp_p
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("buffer", [64, 4096, 1000])
+def test_env_segments_travel_with_the_voice_to_the_device_vm(tmp_path, buffer):
+    """tests/a2s/envloops.a2s: looping voices with env units - every table mode, amplitude / pan /
+    volume / pitch / cutoff targets, in front of and behind the target, 'time' overrides, two envelopes on one
+    voice - are adopted with their segments in flight; the device steps the tables (a2amd_vmcore.h: env_target,
+    env_lut) and the audio is the CPU engine's with ITS env unit (src/units/env.c), sample for sample."""
+    need_ref()
+    frames = 48000 * 3 // buffer * buffer
+    cpu, _, _ = render(tmp_path, "cpu", "envloops", "Main", frames, buffer, ["0.08"])
+    vm, stats, err = render(tmp_path, "vm", "envloops", "Main", frames, buffer, ["0.08"], preload=f"{WALK_SO} {UNITS_SO}")
+    assert cpu.any()
+    assert first_difference(cpu, vm, 2, buffer) is None, first_difference(cpu, vm, 2, buffer)
+    assert stats and stats[0] >= 12 and stats[1] >= 4, (stats, err[-400:])
+
+
+@pytest.mark.gpu
+def test_env_voices_without_the_device_vm(tmp_path):
+    """The same scene with the drop-in's env unit stepping its segments on the engine thread (A2AMD_NO_VM=1, and
+    without the walk at all): the unit is the reference's restated."""
+    need_ref()
+    frames = 48000 * 2
+    cpu, _, _ = render(tmp_path, "cpu", "envloops", "Main", frames, 256, ["0.08"])
+    a, sa, _ = render(tmp_path, "novm", "envloops", "Main", frames, 256, ["0.08"], preload=f"{WALK_SO} {UNITS_SO}",
+                      env_extra={"A2AMD_NO_VM": "1"})
+    b, _, _ = render(tmp_path, "units", "envloops", "Main", frames, 256, ["0.08"], preload=UNITS_SO)
+    assert first_difference(cpu, a, 2, 256) is None, first_difference(cpu, a, 2, 256)
+    assert first_difference(cpu, b, 2, 256) is None, first_difference(cpu, b, 2, 256)
+    assert sa and sa[0] == 0
+
+
+@pytest.mark.gpu
 def test_device_vm_off_is_the_same_audio(tmp_path):
     """A2AMD_NO_VM=1: nothing is handed over - the A/B switch of the measurements."""
     need_ref()
