@@ -227,6 +227,7 @@ ENGINE_CASES = [   # label, program of tests/a2s/bench.a2s, voices
     ("configs[3]", "Osc2PanGroups", 65536),
     ("configs[4] in one engine state", "FilterTree", 262144),
     ("variant 2b (scripted)", "OscPanScripted", 16384), ("variant 3b (scripted)", "OscFilterPanScripted", 16384),
+    ("variant 2e (env unit per voice)", "OscPanEnvScripted", 16384),
 ]
 ENGINE_BUFFERS = (4096, 64)     # a2play's offline buffer; one fragment per a2_Run() = a realtime driver's
 
@@ -282,40 +283,54 @@ def engine_in_loop(cases=None, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fr
     cases = list(cases or ENGINE_CASES)
     modes = [("units", False)] + ([("units+walk", True)] if os.path.exists(WALK_SO) else [])
     # the CPU renders: independent processes, one thread each, all at once (the box has the cores)
-    cpu = {}
+    cpu, plan = {}, {}
     for label, program, voices in cases:
         for buf in buffers:
             hf = hash_fragments if voices < 65536 else min(hash_fragments, 16 if voices < 262144 else 8)
-            nfr = max(hf, buf // 64)
-            cpu[(label, buf)] = (hf, engine_run(program, voices, nfr, buf, False, hf, wait=False))
-    cpu = {k: (hf, engine_result(p, timeout=900)) for k, (hf, p) in cpu.items()}
+            # how long each drop-in run is ...
+            nfr = max(gpu_fragments if buf > 64 else 600, buf // 64 * 4)
+            nruns = {}
+            for mode, walk in modes:
+                # (without the walk's short cut a fragment costs ~40 ns per voice of engine walk: bound the run)
+                # ... and with it a fragment of a quiet scene costs microseconds: four times as many
+                nruns[mode] = (nfr if "Scripted" in program else 4 * nfr) if walk else \
+                    max(hf, buf // 64, min(nfr, int(2.5e6 / (voices * 0.04))))
+            # ... and where the SECOND hashed window lies: as far into the shortest of them as the one-thread CPU
+            # render of the same scene gets in about a minute (1.5e9 voice-samples), on a 4 096-frame boundary
+            tail = min(int(1.5e9 / (voices * 64.0)), min(nruns.values()) - hf) // 64 * 64
+            tail = tail if tail >= hf else None
+            plan[(label, buf)] = (hf, nruns, tail)
+            ncpu = max(hf, buf // 64, (tail + hf) if tail is not None else 0)
+            cpu[(label, buf)] = engine_run(program, voices, ncpu, buf, False, hf, wait=False,
+                                           env_extra={"A2REF_HASH_AT": str(tail)} if tail is not None else None)
+    cpu = {k: engine_result(p, timeout=1200) for k, p in cpu.items()}
     out = {"entry_point": "a2_Run(frames) of the compiled reference engine (oracle/_ref/ref_bench, one engine state, one "
                           "CPU thread for compiler + VM + voice walk); units: LD_PRELOAD=liba2amd_units.so; units+walk: "
                           "liba2amd_walk.so (the engine's a2_ProcessVoices replaced: sleeping voices are not visited) "
                           "in front of it",
-           "hash": "FNV-1a 64 of the first fragments rendered after the warm-up, ch0 then ch1 per 64-frame fragment; "
-                   "cpu_hash = the same engine with its own CPU units",
+           "hash": "FNV-1a 64 of the first hash_fragments fragments rendered after the warm-up, ch0 then ch1 per 64-frame "
+                   "fragment; tail_hash: the same number of fragments from fragment tail_at of the timed run on (as deep "
+                   "into the run as the one-thread CPU render gets in about a minute); cpu_hash / cpu_tail_hash = the "
+                   "same engine with its own CPU units",
            "cases": {}}
     all_equal = True
     rt = {m: 0 for m, _ in modes}
     for label, program, voices in cases:
         entry = {"program": program, "voices": voices}
         for buf in buffers:
-            hf, c = cpu[(label, buf)]
-            nfr = max(gpu_fragments if buf > 64 else 600, buf // 64 * 4)
+            c = cpu[(label, buf)]
+            hf, nruns, tail = plan[(label, buf)]
             e = {}
             if "error" in c:
                 e["error"] = "CPU run: " + c["error"]
                 all_equal = False
             else:
                 e = {"cpu_units_voice_samples_per_s": c["voice_samples_per_s"], "hash_fragments": hf,
-                     "cpu_hash": c["hashes"][0]}
+                     "cpu_hash": c["hashes"][0], "tail_at": tail,
+                     "cpu_tail_hash": c["tail_hashes"][0] if tail is not None else None}
                 for mode, walk in modes:
-                    # (without the walk's short cut a fragment costs ~40 ns per voice of engine walk: bound the run)
-                    # ... and with it a fragment of a quiet scene costs microseconds: four times as many
-                    nrun = (nfr if "Scripted" in program else 4 * nfr) if walk else \
-                        max(hf, buf // 64, min(nfr, int(2.5e6 / (voices * 0.04))))
-                    g = engine_run(program, voices, nrun, buf, True, hf, walk=walk)
+                    g = engine_run(program, voices, nruns[mode], buf, True, hf, walk=walk,
+                                   env_extra={"A2REF_HASH_AT": str(tail)} if tail is not None else None)
                     if "error" in g:
                         e[mode] = {"error": g["error"]}
                         all_equal = False
@@ -326,8 +341,9 @@ def engine_in_loop(cases=None, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fr
                          "us_per_fragment_mean": g["seconds"] / g["fragments"] * 1e6,
                          "fragments_timed": g["fragments"], "active_voices": g["active_voices"],
                          "realtime_at_48k": bool(g["run_us_p99"] / per <= 64.0 / 48000.0 * 1e6),
-                         "hash": g["hashes"][0],
-                         "hash_equal": g["hashes"][0] == c["hashes"][0] and g["active_voices"] == c["active_voices"]}
+                         "hash": g["hashes"][0], "tail_hash": g["tail_hashes"][0] if tail is not None else None,
+                         "hash_equal": g["hashes"][0] == c["hashes"][0] and g["active_voices"] == c["active_voices"] and
+                                       (tail is None or g["tail_hashes"][0] == c["tail_hashes"][0])}
                     all_equal = all_equal and m["hash_equal"]
                     if buf == 64 and m["realtime_at_48k"] and m["hash_equal"] and "Scripted" not in program:
                         rt[mode] = max(rt[mode], voices)

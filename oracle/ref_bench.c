@@ -15,6 +15,8 @@
  *         A2REF_HASH=1   FNV-1a 64 of everything rendered while timed, per state ("hashes")
  *         A2REF_HASH=<n> (n > 1) ... of the first n 64-frame fragments' worth of frames only, so
  *                        that a short CPU run and a long drop-in run can be compared
+ *         A2REF_HASH_AT=<k>  a second hash ("tail_hashes") of the n fragments from fragment k of the
+ *                        timed run on: the far end of what both runs render
  */
 #include <pthread.h>
 #include <stdio.h>
@@ -33,6 +35,7 @@ typedef struct JOB
 	int		active;
 	int		ok;
 	unsigned long long hash;	/* FNV-1a 64 of everything the state rendered while timed */
+	unsigned long long hash2;	/* ... of the window A2REF_HASH_AT names */
 	double		*run_s;		/* seconds per a2_Run() call */
 	int		nruns, buffer;
 } JOB;
@@ -62,7 +65,7 @@ static void *run(void *arg)
 	 * a2play's default is 4096); 'fragments' stays a count of 64 frame units */
 	int buffer = getenv("A2REF_BUFFER") ? atoi(getenv("A2REF_BUFFER")) : 64;
 	int nbuf;
-	long hash_frames = 0, hashed = 0;
+	long hash_frames = 0, hashed = 0, at_frames = -1, pos = 0;
 	double t0, t1;
 	if(!(drv = a2_NewDriver(A2_AUDIODRIVER, "buffer")))
 		return NULL;
@@ -105,7 +108,10 @@ static void *run(void *arg)
 	{
 		long n = atol(getenv("A2REF_HASH"));
 		hash_frames = n > 1 ? n * 64 : (long)nbuf * buffer;
+		if(getenv("A2REF_HASH_AT"))
+			at_frames = atol(getenv("A2REF_HASH_AT")) * 64;
 	}
+	j->hash2 = 0xcbf29ce484222325ULL;
 	t0 = t1 = now();
 	for(f = 0; f < nbuf; ++f)
 	{
@@ -125,6 +131,21 @@ static void *run(void *arg)
 						j->hash = (j->hash ^ b[k]) * 0x100000001b3ULL;
 				}
 		}
+		if(at_frames >= 0 && pos + buffer > at_frames && pos < at_frames + hash_frames)
+		{
+			int c, o;
+			unsigned k;
+			for(o = 0; o < buffer; o += 64)
+				if(pos + o >= at_frames && pos + o < at_frames + hash_frames)
+					for(c = 0; c < 2; ++c)
+					{
+						const unsigned char *b = (const unsigned char *)
+								(((A2_audiodriver *)drv)->buffers[c] + o);
+						for(k = 0; k < 64 * 4; ++k)
+							j->hash2 = (j->hash2 ^ b[k]) * 0x100000001b3ULL;
+					}
+		}
+		pos += buffer;
 		t2 = now();
 		j->run_s[f] = t2 - t1;
 		t1 = t2;
@@ -191,6 +212,13 @@ int main(int argc, const char *argv[])
 		for(t = 0; t < threads; ++t)
 			printf("%s\"%016llx\"", t ? ", " : "", jobs[t].hash);
 		printf("]");
+		if(getenv("A2REF_HASH_AT"))
+		{
+			printf(", \"tail_hashes\": [");
+			for(t = 0; t < threads; ++t)
+				printf("%s\"%016llx\"", t ? ", " : "", jobs[t].hash2);
+			printf("]");
+		}
 	}
 	printf("}\n");
 	return 0;
