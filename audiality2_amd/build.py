@@ -18,7 +18,7 @@ def _newer(target, sources):
 def build_lib(force=False):
     csrc = os.path.join(HERE, "csrc")
     srcs = [os.path.join(csrc, f) for f in ("a2amd_host.cpp", "a2amd_sched.cpp", "a2amd_render.cpp", "a2amd_dist.cpp",
-                                            "a2amd_vm.cpp", "a2amd_kernels.hip", "a2amd_fast.hip", "a2amd_vm.hip")]
+                                            "a2amd_vm.cpp", "a2amd_kernels.hip", "a2amd_fast.hip", "a2amd_vm.hip", "a2amd_wavecap.hip")]
     deps = srcs + [os.path.join(csrc, "a2amd_host.h"), os.path.join(csrc, "a2amd_device.h"), os.path.join(csrc, "a2amd_dsp.h"),
                    os.path.join(csrc, "a2amd_fm.h"), os.path.join(csrc, "a2amd_vmcore.h"), os.path.join(ROOT, "include", "a2amd.h"),
                    os.path.join(ROOT, "include", "a2amd_vm.h")]

@@ -236,6 +236,10 @@ int a2d_launch_add_bus(int32_t *dst, int32_t *src, unsigned words, void *stream)
 int a2d_launch_add_inject(const int32_t *inj, int32_t *bus, int nch, int n, int nfrags, void *stream);
 // Hermite coefficient entries for wave pool samples [lo, hi) (reads pool[lo-1 .. hi+1])
 int a2d_launch_build_coef(const int16_t *pool, int *coef, unsigned lo, unsigned hi, void *stream);
+// a2amd_wavecap.hip
+int a2d_launch_capture(const int32_t *bus, int32_t *dst, const uint32_t *fragpos, int nfrags, int nch, void *stream);
+int a2d_launch_wave_from_pcm(const int32_t *pcm, int16_t *pool, const uint32_t *off, const uint32_t *size, int levels, int looped,
+		int pre, int post, void *stream);
 int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
 		int vpw, void *stream);
 // runs[idx[i]] = val[i] for the few voices whose record run changed this batch

@@ -100,6 +100,7 @@ void a2amd_close(a2amd_ctx *c)
 	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
 	hipFree(c->d_waves.d); hipFree(c->d_wavepool.d); hipFree(c->d_wavecoef.d); hipFree(c->d_busmem.d);
 	vm_close(c);
+	hipFree(c->capture.d); hipFree(c->capture.d_fragpos);
 	hipFree(c->d_fbdmem.d); hipFree(c->d_fmstate.d); hipFree(c->d_xio.d); hipFree(c->d_fmsine); hipFree(c->d_list.d); hipFree(c->d_scatter.d); hipFree(c->d_ptab); hipFree(c->d_blob.d);
 	for(int k = 0; k < 2; ++k) { if(c->h_blob[k]) hipHostFree(c->h_blob[k]); if(c->blob_ev[k]) hipEventDestroy(c->blob_ev[k]); }
 	if(c->h_master)
@@ -157,11 +158,137 @@ void wave_tap_policy(a2amd_ctx *c)
 }
 }
 extern "C" {
+} // extern "C"
+
+struct a2amd_capture {
+	int32_t *d;
+	size_t n;
+	int device;
+};
+
+namespace a2h {
+int capture_append(a2amd_ctx *c)
+{
+	a2amd_ctx::Capture &cp = c->capture;
+	std::vector<uint32_t> pos((size_t)c->nfrags + 1);
+	size_t n = cp.n;
+	for(int f = 0; f < c->nfrags; ++f) {
+		pos[f] = (uint32_t)n;
+		n += c->fragframes[f];
+	}
+	pos[c->nfrags] = (uint32_t)n;
+	if(n > 0x7fffffffu)
+		return c->fail(A2AMD_ENOMEM, "capture beyond 2^31 frames");
+	if(n > cp.cap) {
+		// (the stream is in order: the copy follows the kernels that wrote the old buffer)
+		const size_t ncap = std::max(n * 2, (size_t)1 << 16);
+		int32_t *nd = nullptr;
+		HIPCHK(c, hipMalloc((void **)&nd, ncap * sizeof(int32_t)));
+		if(cp.n)
+			HIPCHK(c, hipMemcpyAsync(nd, cp.d, cp.n * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		hipFree(cp.d);
+		cp.d = nd;
+		cp.cap = ncap;
+	}
+	if(!cp.d_fragpos)
+		HIPCHK(c, hipMalloc((void **)&cp.d_fragpos, (A2D_MAXBATCH + 1) * sizeof(uint32_t)));
+	HIPCHK(c, hipMemcpyAsync(cp.d_fragpos, pos.data(), pos.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));	// (pos is pageable and about to go)
+	if(a2d_launch_capture(c->d_busmem.d, cp.d, cp.d_fragpos, c->nfrags, c->cfg.channels, c->stream))
+		return c->fail(A2AMD_EHIP, "capture launch failed");
+	cp.n = n;
+	return 0;
+}
+} // namespace a2h
+
+extern "C" {
+
+int a2amd_capture_begin(a2amd_ctx *c)
+{
+	if(c->comm)
+		return c->fail(A2AMD_EUNSUPPORTED, "capture in a distributed context");
+	c->capture.on = true;
+	c->capture.n = 0;
+	drop_graphs(c);		// (a captured launch sequence may store the master bus in host memory)
+	return A2AMD_OK;
+}
+
+int a2amd_capture_end(a2amd_ctx *c, a2amd_capture **out)
+{
+	if(!out)
+		return c->fail(A2AMD_EINVAL, "capture_end: null");
+	*out = nullptr;
+	use_device(c);
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	if(c->capture.on && c->capture.n) {
+		a2amd_capture *cap = new a2amd_capture;
+		cap->d = c->capture.d;
+		cap->n = c->capture.n;
+		cap->device = c->cfg.device;
+		c->capture.d = nullptr;
+		c->capture.cap = 0;
+		*out = cap;
+	}
+	c->capture.on = false;
+	c->capture.n = 0;
+	return A2AMD_OK;
+}
+
+unsigned a2amd_capture_frames(const a2amd_capture *cap) { return cap ? (unsigned)cap->n : 0; }
+
+void a2amd_capture_free(a2amd_capture *cap)
+{
+	if(!cap)
+		return;
+	int dev = 0;
+	hipGetDevice(&dev);
+	hipSetDevice(cap->device);
+	hipFree(cap->d);
+	hipSetDevice(dev);
+	delete cap;
+}
+
+int a2amd_wave_stats(a2amd_ctx *c, uint64_t *h2d, uint32_t *uploaded, uint32_t *resident)
+{
+	if(h2d) *h2d = c->wave_h2d_bytes;
+	if(uploaded) *uploaded = c->waves_uploaded;
+	if(resident) *resident = c->waves_resident;
+	return A2AMD_OK;
+}
+
+static int wave_place(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w, const a2amd_capture *cap);
+
 int a2amd_wave_upload(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w)
 {
-	use_device(c);
 	if(!w)
 		return c->fail(A2AMD_EINVAL, "wave_upload: null descriptor");
+	return wave_place(c, key, w, nullptr);
+}
+
+int a2amd_wave_upload_captured(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w, const a2amd_capture *cap)
+{
+	if(!w || !cap)
+		return c->fail(A2AMD_EINVAL, "wave_upload_captured: null");
+	if(cap->device != c->cfg.device)
+		return c->fail(A2AMD_EUNSUPPORTED, "wave_upload_captured: the capture lives on GPU %d, the context on %d", cap->device, c->cfg.device);
+	if(w->type != A2AMD_WWAVE && w->type != A2AMD_WMIPWAVE)
+		return c->fail(A2AMD_EUNSUPPORTED, "wave_upload_captured: wave type %d", w->type);
+	// A2_NORMALIZE 0x10000, A2_XFADE 0x40000, A2_REVMIX 0x80000 (include/a2_waves.h:113-115): a2_postprocess and the
+	// normalising conversion of src/waves.c are host work on the whole wave
+	if(w->flags & 0x000d0000u)
+		return c->fail(A2AMD_EUNSUPPORTED, "wave_upload_captured: flags %#x ask for post-processing", w->flags);
+	if((size_t)w->size[0] != cap->n)
+		return c->fail(A2AMD_EUNSUPPORTED, "wave_upload_captured: the wave has %u samples, the capture %zu", w->size[0], cap->n);
+	for(int l = 1; l < (w->type == A2AMD_WMIPWAVE ? A2D_MIPS : 1); ++l)
+		if(w->size[l] != ((w->size[0] + (1u << l) - 1) >> l))	// a2_wave_alloc, waves.c:76
+			return c->fail(A2AMD_EINVAL, "wave_upload_captured: level %d has %u samples", l, w->size[l]);
+	return wave_place(c, key, w, cap);
+}
+
+static int wave_place(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w, const a2amd_capture *cap)
+{
+	use_device(c);
 	int id = -1;
 	for(size_t i = 0; i < c->waves.size(); ++i)
 		if(c->waves[i].live && c->waves[i].key == key)
@@ -227,13 +354,28 @@ int a2amd_wave_upload(a2amd_ctx *c, uint64_t key, const a2amd_wavedesc *w)
 	}
 	hw.pool_off = pos;
 	hw.pool_len = total;
+	uint32_t loff[A2D_MIPS] = { 0 }, lsize[A2D_MIPS] = { 0 };
+	const size_t pos0 = pos;
 	for(int l = 0; l < levels; ++l) {
 		size_t n = A2AMD_WAVEPRE + (size_t)w->size[l] + A2AMD_WAVEPOST;
-		HIPCHK(c, hipMemcpy(c->d_wavepool.d + pos, w->data[l], n * sizeof(int16_t), hipMemcpyHostToDevice));
+		if(!cap) {
+			HIPCHK(c, hipMemcpy(c->d_wavepool.d + pos, w->data[l], n * sizeof(int16_t), hipMemcpyHostToDevice));
+			c->wave_h2d_bytes += n * sizeof(int16_t);
+		}
+		loff[l] = (uint32_t)(pos - pos0);
+		lsize[l] = w->size[l];
 		hw.dw.size[l] = w->size[l];
 		hw.dw.off[l] = (uint32_t)(pos + A2AMD_WAVEPRE);
 		pos += n;
 	}
+	if(cap) {
+		// level 0 from the samples the device rendered, pads and mip levels derived here
+		if(levels && a2d_launch_wave_from_pcm(cap->d, c->d_wavepool.d + pos0, loff, lsize, levels, (w->flags & 0x100u) != 0,
+				A2AMD_WAVEPRE, A2AMD_WAVEPOST, c->stream))
+			return c->fail(A2AMD_EHIP, "wave build from capture failed");
+		++c->waves_resident;
+	} else
+		++c->waves_uploaded;
 	// Hermite coefficients of every window of the region (a2amd_fast.hip: k_build_coef)
 	if(total > 3 && a2d_launch_build_coef(c->d_wavepool.d, c->d_wavecoef.d, (unsigned)hw.pool_off + 1,
 			(unsigned)(hw.pool_off + total) - 2, c->stream))

@@ -425,6 +425,10 @@ struct a2amd_ctx {
 	hipGraphExec_t gexec[12] = {};
 	const int32_t *gdst[12] = {};
 	bool gdirect[12] = {};		// (the captured root launch stored there)
+	// channel 0 of what this context renders, kept on the device (a2amd_capture_begin)
+	struct Capture { int32_t *d = nullptr; size_t cap = 0, n = 0; bool on = false; uint32_t *d_fragpos = nullptr; } capture;
+	uint64_t wave_h2d_bytes = 0;
+	uint32_t waves_uploaded = 0, waves_resident = 0;
 	int32_t *master_dst = nullptr;	// where the root of the batch being issued is to store the master bus (nullptr: bus memory)
 	bool master_direct = false;	// ... and its launch did
 	int32_t *h_master = nullptr;	// pinned
@@ -549,6 +553,7 @@ int build_graph(a2amd_ctx *c, int slot, int steps, unsigned phases = A2AMD_RENDE
 long long now_serial(const a2amd_ctx *c);
 // a2amd_host.cpp
 void wave_tap_policy(a2amd_ctx *c);
+int capture_append(a2amd_ctx *c);	// a2amd_render(): the batch just rendered joins the capture
 // a2amd_render.cpp
 double *dbg_counters();	// (A2AMD_HOSTTIMING counters)
 double *dbg_why();

@@ -223,6 +223,9 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 		if(int r = run_phases(kphases))
 			return r;
 	}
+	if(c->capture.on && (kphases & A2AMD_RENDER_ROOT))
+		if(int r = capture_append(c))
+			return r;
 	if((phases & A2AMD_RENDER_TAPS) && !(phases & A2AMD_RENDER_READBACK))
 		// the seam for insert clients: the batch's taps so far, on the host
 		if(int r = fetch_taps(c, false))

@@ -791,7 +791,7 @@ int launch_depth(a2amd_ctx *c, int d, int consume, A2DCommitSet *pend)	// consum
 		// (... and only if nothing else adds into the master bus at depth 0: no voice with records there this
 		// batch, no leaf voice mixing straight into it - owners_all_driver says so for the static lists)
 		const bool direct = d == 0 && (consume & 2) && c->master_dst && r.fast_count == 1 && !r.gen_count && !r.fbd_count &&
-				!r.dyn_count && c->owners_all_driver;
+				!r.dyn_count && c->owners_all_driver && !c->capture.on;	// (a capture reads the bus memory)
 		if(direct)
 			c->master_direct = true;
 		if(a2d_launch_bus_driver(c->d_params, c->d_list.d + r.fast_first, r.fast_count, c->nfrags, consume,

@@ -131,6 +131,7 @@ typedef struct HOSTSTATE
 	int		chain_nfwd;
 	A2P_unit	*chain_env[2];
 	int		chain_nenv;
+	int		capturing;	/* a2_RenderWave's substate: what it renders is kept on the device */
 	int		envluts_sent[MAXDEV];	/* the context has env's tables (a2amd_vm_envluts) */
 	A2P_xinsert	*root_xi;	/* the root voice's xinsert (the engine's own instance) */
 	void		*engine_state;	/* A2_state, for a2r_Error */
@@ -164,6 +165,17 @@ typedef struct HOSTSTATE
 
 static HOSTSTATE *states;	/* chain of every record ever allocated; refs == 0: closed, reusable */
 static pthread_mutex_t states_mtx = PTHREAD_MUTEX_INITIALIZER;	/* independent master states may open from different threads */
+
+/* an a2_RenderWave() call in progress on this thread (the interposed entry point at the end of
+ * this file): the next engine state that opens is its off-line substate, and what that state renders is
+ * kept in device memory for the wave */
+typedef struct RENDERCAP
+{
+	struct HOSTSTATE	*sub;
+	a2amd_capture		*cap;
+	int			armed;
+} RENDERCAP;
+static __thread RENDERCAP *rendering;
 
 /* Our per-instance data lives in the engine's 384 byte instance block: right
  * behind the A2_unit header (the cache line after the one the engine's dispatch
@@ -333,6 +345,12 @@ static int amd_open(A2P_config *cfg, void **statedata)
 			if(!++serials)
 				++serials;
 			freeone->serial = serials;
+			if(rendering && rendering->armed)
+			{
+				rendering->armed = 0;
+				rendering->sub = freeone;
+				freeone->capturing = 1;
+			}
 			*statedata = freeone;
 		}
 	}
@@ -349,6 +367,17 @@ static void amd_close(void *statedata)
 	pthread_mutex_lock(&states_mtx);
 	if(!--hs->refs)
 	{
+		if(hs->capturing && rendering && rendering->sub == hs && hs->ctxs[0] && !hs->failed)
+			a2amd_capture_end(hs->ctxs[0], &rendering->cap);
+		if(getenv("A2AMD_WAVE_STATS") && hs->ctxs[0])
+		{
+			uint64_t bytes = 0;
+			uint32_t up = 0, res = 0;
+			a2amd_wave_stats(hs->ctxs[0], &bytes, &up, &res);
+			fprintf(stderr, "a2amd units: state %d%s: %u waves copied from the host (%llu bytes), %u built on the device from "
+					"what it rendered\n", hs->index, hs->capturing ? " (a2_RenderWave substate)" : "", up,
+					(unsigned long long)bytes, res);
+		}
 		for(c = 0; c < MAXDEV; ++c)
 			if(hs->ctxs[c])
 				a2amd_close(hs->ctxs[c]);
@@ -446,6 +475,8 @@ static a2amd_ctx *ctx_of(HOSTSTATE *hs)
 						hs->ctxs[d] = NULL;
 					}
 			hs->ctx = hs->ctxs[0];
+			if(hs->ctx && hs->capturing && (rc = a2amd_capture_begin(hs->ctx)))
+				hs->capturing = 0;	/* (the wave is uploaded from the engine's copy, then) */
 		}
 	}
 	return hs->ctx;
@@ -454,6 +485,7 @@ static a2amd_ctx *ctx_of(HOSTSTATE *hs)
 #define XCTX(x) ((x)->hs->ctxs[(x)->dev])
 
 static int wave_id_of(HOSTSTATE *hs, int dev, A2P_wave *w);
+static int wave_registered(HOSTSTATE *hs, A2P_wave *w, int dev, int id);
 static inline XTRA *xtra(A2P_unit *u);
 static int is_ours(const A2P_unitdesc *d);
 
@@ -1580,6 +1612,37 @@ static void amd_rootx_setprocess(A2P_unit *u)
 }
 
 /* ---- control register writes --------------------------------------------------*/
+/* the registry learns that engine wave w is wave 'id' of context 'dev'; returns id, -1 out of memory */
+static int wave_registered(HOSTSTATE *hs, A2P_wave *w, int dev, int id)
+{
+	int i, k, slot = -1;
+	for(i = 0; i < hs->nwaves; ++i)
+		if(hs->wave_ptr[i] == w)
+			slot = i;
+	if(slot < 0 && hs->nwaves == hs->cap_waves)
+	{
+		int nc = hs->cap_waves ? hs->cap_waves * 2 : 256;
+		A2P_wave **np = (A2P_wave **)realloc(hs->wave_ptr, nc * sizeof(A2P_wave *));
+		int (*ni)[MAXDEV] = np ? (int (*)[MAXDEV])realloc(hs->wave_id, nc * sizeof(hs->wave_id[0])) : NULL;
+		if(np)
+			hs->wave_ptr = np;
+		if(ni)
+			hs->wave_id = ni;
+		if(!np || !ni)
+			return -1;
+		hs->cap_waves = nc;
+	}
+	if(slot < 0)
+	{
+		slot = hs->nwaves++;
+		hs->wave_ptr[slot] = w;
+		for(k = 0; k < MAXDEV; ++k)
+			hs->wave_id[slot][k] = -1;
+	}
+	hs->wave_id[slot][dev] = id;
+	return id;
+}
+
 static int wave_id_of(HOSTSTATE *hs, int dev, A2P_wave *w)
 {
 	a2amd_wavedesc d;
@@ -2588,4 +2651,73 @@ int a2amd_units_vm_recall(const void *const *heads, unsigned n, void *const *vms
 		}
 	}
 	return rc;
+}
+
+
+/* ---- a2_RenderWave(), src/render.c:144-177 ----------------------------------------
+ * The engine's own function does all the work - opens the off-line substate, runs the program, writes the
+ * substate's output into the new wave, closes the stream (conversion, pads, mip levels on the host: the
+ * engine's A2_wave is complete and is what a2_GetWave() hands anybody).  This entry point stands in front
+ * of it (the same interposition as the unit descriptors: the compiler's call, src/compiler.c:3359, and the
+ * application's both bind here) only to note which state is the substate: that state's drop-in context keeps
+ * what it renders in device memory (a2amd_capture_begin), and when the engine has made its wave, the device
+ * builds ITS copy - samples, pads, mip levels, coefficient entries - from there (a2amd_wave_upload_captured)
+ * and the wave registry takes it as uploaded.  The rendered samples travel device -> host once, for the
+ * engine's copy, and never back.  Waves with A2_NORMALIZE / A2_XFADE / A2_REVMIX, a substate on another GPU,
+ * a state spread over several GPUs (A2AMD_DEVICES > 1): uploaded from the engine's copy on first use as
+ * before (wave_id_of).  A2AMD_NO_RESIDENT=1 switches this off (A/B). */
+int a2_RenderWave(void *iface, int wt, unsigned period, int flags, unsigned samplerate, unsigned length, void *props,
+		int program, unsigned argc, int *argv)
+{
+	static int (*engine_render)(void *, int, unsigned, int, unsigned, unsigned, void *, int, unsigned, int *);
+	RENDERCAP rc, *outer = rendering;
+	int wh;
+	if(!engine_render)
+		*(void **)&engine_render = dlsym(RTLD_NEXT, "a2_RenderWave");
+	if(!engine_render)
+	{
+		fprintf(stderr, "a2amd units: the engine's a2_RenderWave is not visible\n");
+		return -A2P_INTERNAL;
+	}
+	memset(&rc, 0, sizeof(rc));
+	rc.armed = !getenv("A2AMD_NO_RESIDENT");
+	rendering = &rc;
+	wh = engine_render(iface, wt, period, flags, samplerate, length, props, program, argc, argv);
+	rendering = outer;
+	if(rc.cap)
+	{
+		A2P_wave *w = wh >= 0 ? a2_GetWave(iface, wh) : NULL;
+		HOSTSTATE *hs;
+		pthread_mutex_lock(&states_mtx);
+		for(hs = states; hs; hs = hs->next_state)
+			if(hs->refs && hs->cfg && hs->cfg->interface == iface)
+				break;
+		pthread_mutex_unlock(&states_mtx);
+		if(w && hs && !hs->failed && ctx_of(hs) && hs->ndev == 1 && (w->type == A2AMD_WWAVE || w->type == A2AMD_WMIPWAVE) &&
+				w->size[0] == a2amd_capture_frames(rc.cap))
+		{
+			a2amd_wavedesc d;
+			int l, id, levels = w->type == A2AMD_WMIPWAVE ? A2AMD_MIPLEVELS : 1;
+			memset(&d, 0, sizeof(d));
+			d.type = w->type;
+			d.flags = w->flags;
+			d.period = w->period;
+			for(l = 0; l < levels; ++l)
+				d.size[l] = w->size[l];
+			id = a2amd_wave_upload_captured(hs->ctxs[0], (uint64_t)(uintptr_t)w, &d, rc.cap);
+			if(id >= 0 && wave_registered(hs, w, 0, id) < 0)
+				a2amd_wave_drop(hs->ctxs[0], (uint64_t)(uintptr_t)w);
+			/* (id < 0: not a failure of the state - the wave goes up from the engine's copy on first use) */
+			if(getenv("A2AMD_WAVE_STATS"))
+				fprintf(stderr, "a2amd units: a2_RenderWave: wave %d, %u frames: %s\n", wh, a2amd_capture_frames(rc.cap),
+						id >= 0 ? "device copy built from the capture" : a2amd_last_error(hs->ctxs[0]));
+		}
+		else if(getenv("A2AMD_WAVE_STATS"))
+			fprintf(stderr, "a2amd units: a2_RenderWave: wave %d (%p), capture of %u frames not used (state %p, %u samples)\n", wh,
+					(void *)w, a2amd_capture_frames(rc.cap), (void *)hs, w ? w->size[0] : 0);
+		a2amd_capture_free(rc.cap);
+	}
+	else if(getenv("A2AMD_WAVE_STATS"))
+		fprintf(stderr, "a2amd units: a2_RenderWave: wave %d, nothing captured (substate %p, armed %d)\n", wh, (void *)rc.sub, rc.armed);
+	return wh;
 }

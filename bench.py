@@ -513,12 +513,13 @@ class Runner:
 def check_golden(r, nsteps):
     """Compare every rendered step the committed oracle golden covers; returns
     (steps compared, all equal) or (0, None) without a golden for this workload."""
-    path = golden_path(r.voices * r.world if r.tree else r.voices, r.chain, r.groups, r.tree, r.private)
+    job = r.tree or r.world > 1     # (the whole job's audio: every rank's voices and groups in one oracle scene)
+    path = golden_path(r.voices * r.world if job else r.voices, r.chain, r.groups * (r.world if job else 1), r.tree, r.private)
     if not os.path.exists(path):
         return 0, None
     gold = np.load(path)
-    if r.tree:
-        # configs[4]: the golden holds the first fragments of step 0 (of the whole job's audio)
+    if job:
+        # configs[4], any config at N > 1: the golden holds the first fragments of step 0 (of the whole job's audio)
         if 0 not in r.kept:
             return 0, None
         n = min(len(gold), r.B)
@@ -645,7 +646,15 @@ def roofline_objects(res, B):
         # that says whether HBM is the bound
         roof["traffic_frac"] = roof["traffic"] / leaf_s / 1e9 / HBM_PEAK_GBPS
         roof["traffic_over_algorithmic"] = roof["traffic"] / alg
+    if not private:
+        # (say it in the line)  The BASELINE configs play 24 built-in waves and keep their state in registers
+        # over the 256 fragments of a launch: the kernel is bound by VALU issue - "roofline_valu" is the bound that
+        # applies - and 'achieved' / 'frac' here price SURVEY 8(d)'s MODEL bytes, which the chip does not move
+        roof["frac_is"] = "model bytes (SURVEY 8d: unit state + bus share per voice-fragment) over HBM peak - NOT traffic: " \
+                          "'traffic' / 'traffic_frac' are what the counters saw move; the binding roofline is roofline_valu"
+        roof["binding_roofline"] = "roofline_valu"
     if private:
+        roof["binding_roofline"] = "valu-issue (samples path) / hbm (A2AMD_RAW=0, coefficient entries): see traffic_frac"
         roof["wave_data_read_as"] = "Hermite coefficient entries (12 B per sample and tap)" if coef_path else \
             "int16 samples (A2D_WF_RAWTAPS: the footprint policy of a2amd_wave_upload; A2AMD_RAW=0 for the entries)"
         roof["algorithmic_model"] = ("SURVEY 8(d): 504 B of unit state and bus share per voice-fragment + the window of its wave "
@@ -834,8 +843,10 @@ def main():
         """A Runner of its own RCCL communicator, born, warmed up and timed: (runner, seconds)."""
         r = Runner(audiality2_amd, cfg["voices"], cfg["chain"], cfg["groups"], B, local_rank, world=world, rank=rank,
                    tree=cfg.get("tree", 0))
-        r.keep_upto = golden_steps(cfg["voices"] * world, cfg["chain"], cfg["groups"], B, cfg.get("tree", 0)) \
-            if cfg.get("tree") else 0
+        r.keep_upto = 1 if os.path.exists(golden_path(cfg["voices"] * world, cfg["chain"], cfg["groups"] * world,
+                                                      cfg.get("tree", 0))) else 0
+        if world == 1 and not cfg.get("tree"):      # (A2AMD_BENCH_FORCE_DIST=1: the single-GPU golden, every step)
+            r.keep_upto = golden_steps(cfg["voices"], cfg["chain"], cfg["groups"], B)
         lib = r.lib
         lib.a2amd_dist_unique_id.argtypes = [ctypes.c_void_p]
         lib.a2amd_dist_init.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
@@ -867,9 +878,13 @@ def main():
     r, dt = timed_job(cfg, args.steps, args.warmup)
     leaf_ms, all_ms, nprof = r.profile(min(args.steps, 16))
     last = r.last
+    # a realtime driver's view at N > 1: one 64-frame fragment per render - every fragment pays the reduce
+    fence()
+    frag_rt = None if args.no_realtime else r.realtime(200)
+    fence()
     line = None
     if rank == 0:
-        compared, ok = check_golden(r, 1 + args.warmup + args.steps) if cfg.get("tree") else (0, None)
+        compared, ok = check_golden(r, 1 + args.warmup + args.steps)
         if ok is False:
             raise SystemExit("bench.py: the ranks' summed render differs from the oracle golden; refusing to report a number")
         value = float(cfg["voices"]) * world * B * 64 * args.steps / dt
@@ -893,11 +908,17 @@ def main():
             "parity_vs_golden": ok,
             "parity": {"golden_fragments_compared": min(B, 64) if compared else 0,
                        "what": "the first fragments of step 0 of the WHOLE job's audio (all ranks' subtrees summed by "
-                               "the reduce, root chain on rank 0) against the CPU oracle's render of the whole scene"}
-            if cfg.get("tree") else None,
+                               "the reduce, root chain on rank 0) against the CPU oracle's render of the whole scene "
+                               "(tests/golden/make_bench_golden.py: every rank's voices and groups in one oracle state)"}
+            if compared else None,
             "roofline": roof, "roofline_valu": valu,
             "output_check": {"peak": int(np.abs(last).max()), "nonzero": bool(last.any())},
         }
+        if frag_rt:
+            frag_rt["scope"] = ("rank 0's side of one 64-frame fragment at N = %d: a2amd_fragment_repeat(64, 1) + a2amd_render(ALL), "
+                                "synchronous - records up, this rank's subtrees, the ncclReduce of the root bus (once per "
+                                "fragment in this mode), root chain, master bus back; the other ranks run the same loop" % world)
+            line["fragment_roundtrip_with_reduce"] = frag_rt
     r.be.close()
     if args.config == 3 and not custom and not args.no_extra:
         # BASELINE configs[4] in the same launch: one top-level group of 128 sub-groups x 256
@@ -919,6 +940,10 @@ def main():
                 "kernel": "k_leaf_oscfiltpan", "avg_launch_ms": leaf4, "all_kernels_ms_per_step": all4}}
         r4.be.close()
     dist.destroy_process_group()
+    if rank == 0 and not args.no_cpu_baseline:
+        # (one rank's share of the job on this box's host cores; the other ranks are done)
+        line["cpu_baseline"] = cpu_baseline(cfg["voices"], cfg["chain"], cfg["groups"])
+        line["cpu_baseline"]["sample"] += "; one rank's share of the job (%d of %d voices)" % (cfg["voices"], cfg["voices"] * world)
     # The contract line is the LAST thing on stdout: RCCL writes a version banner
     # through C stdio, which sits in libc's buffer until it is flushed.
     sys.stdout.flush()

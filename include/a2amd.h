@@ -153,6 +153,31 @@ int  a2amd_wave_upload(a2amd_ctx *ctx, uint64_t key, const a2amd_wavedesc *w);
  * still pointing at it fall silent like wtosc_check_unloaded (wtosc.c:168). */
 int  a2amd_wave_drop(a2amd_ctx *ctx, uint64_t key);
 
+/* ---- a wave the device rendered stays on the device ------------------------------
+ * a2_RenderWave (src/render.c:144-177) runs a program in an off-line one-channel substate and writes what
+ * the substate's driver delivers into a new wave (a2_Write(A2_I24), render.c:91; conversion, pads and
+ * mip levels when the stream closes: src/waves.c:155-237, :89-130, :513-527).  When the substate's units
+ * are the drop-in's, the samples exist in device memory first:
+ *   a2amd_capture_begin(sub)        from here on channel 0 of every batch the context renders is also kept,
+ *                                   device to device, in a capture buffer (frames closed up)
+ *   a2amd_capture_end(sub, &cap)    detaches the buffer (it outlives the context; *cap = NULL: nothing rendered)
+ *   a2amd_wave_upload_captured(ctx, key, w, cap)
+ *                                   as a2amd_wave_upload(), with level 0 converted from the capture on the device
+ *                                   (>> 8 into int16, waves.c:174-177), pads (a2_fix_pad) and mip levels
+ *                                   (a2_render_mipmaps) built there: w->data[] is not read, nothing is copied
+ *                                   from the host.  w->size[0] must be the capture's frame count and the flags
+ *                                   free of A2_NORMALIZE / A2_XFADE / A2_REVMIX (the host-side post-processing
+ *                                   of waves.c:300-390 is not restated): A2AMD_EUNSUPPORTED otherwise, and for a
+ *                                   capture on another GPU - the caller uploads the engine's copy instead. */
+typedef struct a2amd_capture a2amd_capture;
+int  a2amd_capture_begin(a2amd_ctx *ctx);
+int  a2amd_capture_end(a2amd_ctx *ctx, a2amd_capture **cap);
+unsigned a2amd_capture_frames(const a2amd_capture *cap);
+void a2amd_capture_free(a2amd_capture *cap);
+int  a2amd_wave_upload_captured(a2amd_ctx *ctx, uint64_t key, const a2amd_wavedesc *w, const a2amd_capture *cap);
+/* wave data copied from the host so far (bytes, waves) and waves built from captures */
+int  a2amd_wave_stats(a2amd_ctx *ctx, uint64_t *h2d_bytes, uint32_t *uploaded, uint32_t *resident);
+
 /* ---- fragment clock --------------------------------------------------------*/
 /* Begin the next fragment of 'frames' (1..64) sample frames; all following
  * init/write/process calls belong to it (src/core.c:1964-1973). */

@@ -70,7 +70,11 @@ KNOWN_DEVIATIONS = {"unload": [313]}
 
 
 def differing_fragments(name, got, want):
-    """Indices where the per-fragment hashes differ, minus the documented ones."""
+    """Indices where the per-fragment hashes differ from the reference's, minus the documented ones - and the
+    documented ones must be EXACTLY what differs: a whitelisted fragment that matches the reference after all
+    (the whitelist has gone stale, or hides something else) is reported as -1 - index."""
     import numpy as np
     bad = np.nonzero(got != want)[0]
-    return np.array([b for b in bad if b not in KNOWN_DEVIATIONS.get(name, [])], dtype=int)
+    known = KNOWN_DEVIATIONS.get(name, [])
+    stale = [k for k in known if k < len(got) and k not in bad]
+    return np.array([b for b in bad if b not in known] + [-1 - k for k in stale], dtype=int)

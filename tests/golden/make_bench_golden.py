@@ -10,6 +10,7 @@ rendered by the CPU oracle from the scene bench.py builds (bench.build_scene).
 
 configs[4] (4): 64 fragments of the whole job's audio for 1, 2, 4 and 8 top-level groups of
 128 sub-groups x 256 wtosc->filter12->panmix voices (32 768 ... 262 144 voices).
+30: configs[3] as `bench.py --gpus N` plays it, the whole job's audio at N = 2, 4, 8 (64 fragments).
 
 bench.py and tests/test_gpu_parity.py only read the resulting data files;
 tests/test_oracle_cpu.py re-renders the head of each with the oracle.  8 steps =
@@ -81,6 +82,17 @@ if __name__ == "__main__":
         for total in CFG4_TOTALS:
             pcm = render(total, cfg["chain"], 0, CFG4_FRAGMENTS, progress=True, tree=cfg["tree"])
             path = bench.golden_path(total, cfg["chain"], 0, cfg["tree"])
+            np.save(path, fnv1a_fragments(pcm))
+            np.save(path.replace(".hash.npy", ".head.npy"), pcm[:, :256])
+            print("written", path, "peak", int(np.abs(pcm).max()))
+    if 30 in which:
+        # configs[3] as bench.py --gpus N plays it (weak scaling: every rank its own 65 536 voices under its own 256
+        # groups, pitches spread over the whole job): the whole job's audio at 2, 4 and 8 GPUs, 64 fragments each
+        which.remove(30)
+        cfg = bench.CONFIGS[3]
+        for world in (2, 4, 8):
+            pcm = render(cfg["voices"] * world, cfg["chain"], cfg["groups"] * world, CFG4_FRAGMENTS, progress=True)
+            path = bench.golden_path(cfg["voices"] * world, cfg["chain"], cfg["groups"] * world)
             np.save(path, fnv1a_fragments(pcm))
             np.save(path.replace(".hash.npy", ".head.npy"), pcm[:, :256])
             print("written", path, "peak", int(np.abs(pcm).max()))
