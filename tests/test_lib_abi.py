@@ -51,7 +51,7 @@ def test_oracle_mirrors_the_call_protocol(oracle_lib):
     for s in declared_symbols():
         o = s.replace("a2amd_", "a2o_")
         if s in ("a2amd_version", "a2amd_device_count", "a2amd_rootbus", "a2amd_rootbus_copy", "a2amd_get_stats", "a2amd_set_profiling",
-                 "a2amd_replay", "a2amd_collect", "a2amd_fragment_offset", "a2amd_voice_process", "a2amd_voice_slot", "a2amd_voice_markable", "a2amd_default_hold", "a2amd_default_release_all", "a2amd_default_map", "a2amd_dist_unique_id", "a2amd_dist_init", "a2amd_dist_init_local", "a2amd_render_group", "a2amd_unit_insertable", "a2amd_unit_insert", "a2amd_render_paused"):
+                 "a2amd_replay", "a2amd_collect", "a2amd_fragment_offset", "a2amd_capture_begin", "a2amd_capture_end", "a2amd_capture_frames", "a2amd_capture_free", "a2amd_wave_upload_captured", "a2amd_wave_stats", "a2amd_voice_process", "a2amd_voice_slot", "a2amd_voice_markable", "a2amd_default_hold", "a2amd_default_release_all", "a2amd_default_map", "a2amd_dist_unique_id", "a2amd_dist_init", "a2amd_dist_init_local", "a2amd_render_group", "a2amd_unit_insertable", "a2amd_unit_insert", "a2amd_render_paused"):
             continue
         assert hasattr(oracle_lib, o), f"oracle lacks {o}"
 
