@@ -142,7 +142,7 @@ int a2amd_render_group(a2amd_ctx *const *ctxs, int n, unsigned phases, int32_t *
 	// different GPUs run side by side: nothing here waits)
 	int frames = 0;
 	for(int i = 0; i < n; ++i) {
-		int r = a2amd_render(ctxs[i], (phases & (A2AMD_RENDER_UPLOAD | A2AMD_RENDER_SUBTREES)) | keep, nullptr, 0);
+		int r = a2amd_render(ctxs[i], (phases & (A2AMD_RENDER_UPLOAD | A2AMD_RENDER_SUBTREES | A2AMD_RENDER_EXCHANGE)) | keep, nullptr, 0);
 		if(r < 0) {
 			if(i)
 				c0->fail(r, "%s", ctxs[i]->err);
@@ -155,7 +155,7 @@ int a2amd_render_group(a2amd_ctx *const *ctxs, int n, unsigned phases, int32_t *
 	}
 	if(!frames)
 		return 0;
-	if(phases & A2AMD_RENDER_SUBTREES) {
+	if(phases & (A2AMD_RENDER_SUBTREES | A2AMD_RENDER_EXCHANGE)) {
 		// the exchange: the partials of the root voice's inline bus -> context 0
 		std::vector<void *> bus(n);
 		uint64_t bytes = 0;

@@ -197,7 +197,7 @@ int a2amd_render(a2amd_ctx *c, unsigned phases, int32_t *const *out, unsigned ca
 			if(int r = run_phases(A2AMD_RENDER_ROOT))
 				return r;
 	} else {
-		if(kphases && !(phases & A2AMD_RENDER_UPLOAD)) {
+		if((kphases || (phases & A2AMD_RENDER_EXCHANGE)) && !(phases & A2AMD_RENDER_UPLOAD)) {
 			// what insert clients made of the voices' taps since the render paused
 			// (a2amd_unit_insert) joins the voices' output bus before their parents' chains run
 			for(size_t k = 0; k < c->xio.size(); ++k) {

@@ -677,6 +677,19 @@ static int amd_init(int kind, A2P_unit *u, A2P_vmstate *vms, void *sd, unsigned 
 
 static void amd_deinit(A2P_unit *u)
 {
+	{
+		/* a unit of the voice whose chain was populated last goes away: the next voice may be handed the
+		 * same A2_voice - what is known about "the chain being populated" (chain_last, the env units seen,
+		 * the head) must not survive */
+		XTRA *xc = xtra(u);
+		if(xc->hs && xc->hs->chain_vms == xc->vms)
+		{
+			xc->hs->chain_vms = NULL;
+			xc->hs->chain_last = NULL;
+			xc->hs->chain_head = NULL;
+			xc->hs->chain_nfwd = xc->hs->chain_nenv = 0;
+		}
+	}
 	if(u->descriptor == &a2_env_unitdesc)
 		return;
 	if(is_ours(u->descriptor) && u->descriptor != &a2_inline_unitdesc && u->descriptor != &a2_xinsert_unitdesc &&
@@ -862,13 +875,13 @@ static void serve_clients(XTRA *x, A2P_xinsert *xi, unsigned offset, unsigned fr
 			/* an insert client: where the render can pause for it (the last unit of a voice
 			 * below the root: a2_NewGroup's xinsert), its input is tapped and not passed on,
 			 * and render_batch() runs it before the parent voice's chain is rendered */
-			if(hs->ndev == 1 && (idepth = a2amd_unit_insertable(XCTX(x), x->uid)) >= 1)
+			if((idepth = a2amd_unit_insertable(XCTX(x), x->uid)) >= 1)
 				mode |= A2AMD_XIO_TAP | A2AMD_XIO_MUTE;
 			else if(!x->refused)
 			{
 				x->refused = 1;
 				client_error(xi, A2P_NOTIMPLEMENTED, "a2amd: insert client (a2_InsertCallback) on an xinsert "
-						"that is not the last unit of its voice (or with A2AMD_DEVICES > 1): "
+						"that is not the last unit of its voice: "
 						"its audio is on the GPU; not served (sink and source clients are)");
 			}
 		}
@@ -1036,7 +1049,7 @@ static int grow_acc(HOSTSTATE *hs, unsigned frames)
 /* The insert clients' turn, between the two halves of the render: each is handed a copy
  * of its window of the unit's input and what it makes of it is summed up as the unit's
  * output (xi_process, xinsert.c:95-118), in walk order. */
-static void deliver_inserts(HOSTSTATE *hs, int depth)
+static void deliver_inserts(HOSTSTATE *hs, int depth, int dev)
 {
 	int k, i, n, rc;
 	unsigned s;
@@ -1048,7 +1061,7 @@ static void deliver_inserts(HOSTSTATE *hs, int depth)
 		int32_t *bufp[A2AMD_MAXCHANNELS];
 		const int32_t *outp[A2AMD_MAXCHANNELS];
 		A2P_xinsert_client *c;
-		if(!p->insert || p->depth != depth || hs->failed)
+		if(!p->insert || p->depth != depth || p->dev != dev || hs->failed)
 			continue;
 		for(c = p->xi->clients; c && c != p->xic; c = c->next)
 			;
@@ -1079,19 +1092,27 @@ static int render_batch(HOSTSTATE *hs, int32_t **outp, unsigned cap)
 	int n;
 	if(!hs->ninserts)
 		return a2amd_render_group(hs->ctxs, hs->ndev, A2AMD_RENDER_ALL, outp, cap);
-	/* (insert clients are only accepted with one context) */
 	hs->ninserts = 0;
-	if((n = a2amd_render(hs->ctx, A2AMD_RENDER_UPLOAD | A2AMD_RENDER_SUBTREES | A2AMD_RENDER_TAPS, NULL, 0)) < 0)
-		return n;
-	/* the render pauses behind every nesting depth that holds insert clients, deepest first */
-	while((n = a2amd_render_paused(hs->ctx)) > 0)
 	{
-		deliver_inserts(hs, n);
-		if(n == 1)
-			break;
-		if((n = a2amd_render(hs->ctx, A2AMD_RENDER_SUBTREES | A2AMD_RENDER_TAPS, NULL, 0)) < 0)
-			return n;
+		/* every context renders its subtrees; the render pauses behind every nesting depth that holds
+		 * insert clients, deepest first */
+		int d;
+		for(d = 0; d < hs->ndev; ++d)
+		{
+			if((n = a2amd_render(hs->ctxs[d], A2AMD_RENDER_UPLOAD | A2AMD_RENDER_SUBTREES | A2AMD_RENDER_TAPS, NULL, 0)) < 0)
+				return n;
+			while((n = a2amd_render_paused(hs->ctxs[d])) > 0)
+			{
+				deliver_inserts(hs, n, d);
+				if(n == 1)
+					break;
+				if((n = a2amd_render(hs->ctxs[d], A2AMD_RENDER_SUBTREES | A2AMD_RENDER_TAPS, NULL, 0)) < 0)
+					return n;
+			}
+		}
 	}
+	if(hs->ndev > 1)	/* (what the clients of voices right below the root wrote, the exchange, the root chain) */
+		return a2amd_render_group(hs->ctxs, hs->ndev, A2AMD_RENDER_EXCHANGE | A2AMD_RENDER_ROOT | A2AMD_RENDER_READBACK, outp, cap);
 	return a2amd_render(hs->ctx, A2AMD_RENDER_ROOT | A2AMD_RENDER_READBACK, outp, cap);
 }
 

@@ -307,6 +307,9 @@ int  a2amd_inline_end(a2amd_ctx *ctx, int unit);
 #define A2AMD_RENDER_TAPS     64u /* with SUBTREES, without ROOT: wait for the GPU and fetch the batch's taps (a2amd_unit_tapped) */
 #define A2AMD_RENDER_KEEP    16u  /* keep the recording (re-run it next call) */
 #define A2AMD_RENDER_ASYNC   32u  /* READBACK does not wait: a2amd_collect() delivers */
+#define A2AMD_RENDER_EXCHANGE 128u /* a batch whose subtrees were rendered in steps (paused for insert clients): a2amd_render()
+				    * adds what the clients wrote since the last pause to the voices' buses and launches nothing;
+				    * a2amd_render_group() does that in every context, then the exchange of the root-bus partials */
 #define A2AMD_RENDER_ALL     15u
 /*
  * Evaluate the recorded fragments on the GPU.  With A2AMD_RENDER_ALL the

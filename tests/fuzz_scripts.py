@@ -176,7 +176,7 @@ def pad_programs(rng):
     return L
 
 
-def loop_programs(rng):
+def loop_programs(rng, envs=False):
     """Seeds >= 2000: voices whose programs keep LOOPING over the part of the instruction set the device VM
     runs (include/a2amd_vm.h: SURVEY 8 f4) - random delays (milliseconds and ticks), counted and
     conditional loops inside the endless one, sets, ramps of their own length, arithmetic on work
@@ -194,8 +194,27 @@ def loop_programs(rng):
         ("wtosc; panmix 1 2; fbdelay 2 >", "w {w}; p P; a V; fbdelay 13; ldelay 17; rdelay 19", ["fbgain", "lgain", "rgain", "drygain", "a"]),
     ]
 
+    if envs:
+        # seeds >= 3000: env units in those voices - amplitude, pan / volume and cutoff envelopes, in front
+        # of and behind what they drive, table modes at random: their segments travel with the voice to the device VM
+        shapes = shapes[:3] + [
+            ("env E; wtosc; panmix; wire E.out a", "w {w}; p P; pan {pan}; E.mode C.{m1}; E.down C.{m2}", ["E.target", "E.target", "p", "pan", "E.time"]),
+            ("wtosc; env E; panmix; wire E.out a", "w {w}; p P; pan {pan}; E.mode C.{m1}", ["E.target", "E.target", "p", "E.time"]),
+            ("env EP; env EV; wtosc; panmix; wire EP.out pan; wire EV.out vol",
+             "w {w}; p P; a V; EP.mode C.{m1}; EV.mode C.{m2}; EV.down C.{m1}", ["EP.target", "EV.target", "p", "a"]),
+            ("env EA; wtosc; filter12; env EF; panmix; wire EA.out a; wire EF.out cutoff",
+             "w {w}; p P; q 4; cutoff (P + 2); EA.mode C.{m1}; EA.down C.{m2}; EF.mode C.{m2}", ["EA.target", "EF.target", "q", "pan"]),
+            ("env EF; wtosc; filter12; panmix; wire EF.out cutoff", "w {w}; p P; a V; q 6; cutoff (P + 1); EF.mode C.{m1}; EF.down C.{m2}",
+             ["EF.target", "EF.target", "q", "a"]),
+        ]
+    MODES = ["LINEAR", "SPLINE", "LINK"] + [f"EXP{k}" for k in range(1, 8)] + [f"IEXP{k}" for k in range(1, 8)]
+
     def value(reg):
         base = reg.split(".")[-1]
+        if base == "target":
+            return value({"EP": "pan", "EF": "cutoff"}.get(reg.split(".")[0], "a"))
+        if base == "time":
+            return rng.choice(["0", r(rng, 1, 45, 1)])
         if base in ("p", "cutoff"):
             return f"(P + {pos(r(rng, -1.5, 3))})"
         if base in ("a", "vol"):
@@ -241,7 +260,7 @@ def loop_programs(rng):
     L, names = [], []
     for i in range(rng.randint(4, 7)):
         st, setup, regs = rng.choice(shapes)
-        su = setup.format(w=rng.choice(WAVES[:9]), pan=pos(r(rng, -1, 1)))
+        su = setup.format(w=rng.choice(WAVES[:9]), pan=pos(r(rng, -1, 1)), m1=rng.choice(MODES), m2=rng.choice(MODES))
         body = sum((step(regs) for _ in range(rng.randint(2, 6))), [])
         if rng.random() < 0.9:      # (else: an iteration may go by without a delay - the engine's A2_OVERLOAD ends such a voice,
             body.append(f"d {r(rng, 0.5, 12, 2)}")     # and the device VM's analysis must have refused it)
@@ -249,7 +268,7 @@ def loop_programs(rng):
         handler = ""
         if rng.random() < 0.4:
             reg = rng.choice(regs)
-            off = "; ".join(f"{a} 0" for a in regs if a.split(".")[-1] == "a") or "vol 0"
+            off = "; ".join(dict.fromkeys(f"{a} 0" for a in regs if a.split(".")[-1] == "a" or a in ("E.target", "EA.target", "EV.target"))) or "vol 0"
             handler = f".rel\t{off}; d {r(rng, 2, 30, 1)}\n\t1(NP) {{ P NP; {reg} {value(reg)} }}\n\t2() {{ force rel }}\n"
         name = f"L{i}"
         names.append((name, bool(handler)))
@@ -271,7 +290,7 @@ def make_script(seed):
     rng = random.Random(seed)
     nv = rng.randint(4, 8)
     names = [f"V{i}" for i in range(nv)]
-    parts = [f'def title\t"fuzz{seed}"', 'def a2sversion\t"1.9"', ""]
+    parts = [f'def title\t"fuzz{seed}"', 'def a2sversion\t"1.9"', 'def C\t\tunits.env.constants', ""]
     parts += [voice_program(rng, n) + "\n" for n in names]
     held = [f"H{i}" for i in range(2)]
     parts += [held_program(rng, h) + "\n" for h in held]
@@ -288,7 +307,7 @@ def make_script(seed):
             life = rng.choice(["0", r(rng, 200, 1500, 0)])
             main.append(f"\t{rng.choice(['PG', 'PGG'])} {pos(r(rng, -1.5, 1))} (V * .2) {rng.randint(2, 9)} {life}")
     if seed >= 2000:
-        lp, lnames = loop_programs(rng)
+        lp, lnames = loop_programs(rng, envs=seed >= 3000)
         parts += lp
         for name, _h in lnames:
             main.append(f"\t{name} {pos(r(rng, -1.5, 1))} (V * .3)")

@@ -184,13 +184,6 @@ def test_dropin_refuses_mixed_chains(tmp_path):
     r = subprocess.run([REF_RENDER, f"{A2S}/mixedhead.a2s", "Main", "640", "64", "48000", "2", str(tmp_path / "h.pcm"), "0.1"],
                        env=env, cwd=A2S, capture_output=True, text=True, timeout=120)
     assert "takes its input from a unit that is not replaced" in r.stderr, r.stderr[-500:]
-    # an insert client (reads AND writes) needs the voice's audio on the host in the
-    # middle of the render: served on the root voice and on voices directly below it
-    # (test_dropin_serves_sink_and_source_clients), elsewhere - here: with the voice
-    # tree spread over two contexts - reported, not served
-    cmd = [REF_RENDER, f"{A2S}/sinkgroup.a2s", "Main", "640", "64", "48000", "2", str(tmp_path / "s.pcm"), "0.1"]
-    r = subprocess.run(cmd, env=dict(env, A2REF_INSERT="1", A2AMD_DEVICES="2"), cwd=A2S, capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0 and "insert client" in r.stderr + r.stdout, r.stderr[-500:]
 
 
 @pytest.mark.gpu
@@ -244,14 +237,17 @@ def test_dropin_serves_sink_and_source_clients(tmp_path, script, frames, clients
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("devices", [1, 2, 3])
 @pytest.mark.parametrize("nest,outer", [(1, False), (2, False), (2, True), (3, True)])
 @pytest.mark.parametrize("buffer", [64, 1024])
-def test_dropin_serves_insert_clients_at_any_depth(tmp_path, nest, outer, buffer):
+def test_dropin_serves_insert_clients_at_any_depth(tmp_path, nest, outer, buffer, devices):
     """a2_InsertCallback on group voices nested one to three levels below the root
     (a2_NewGroup under a2_NewGroup ...: oracle/ref_render A2REF_NEST), one insert
     client on the innermost voice and - outer - another on the outermost group: the
     render pauses behind each of those depths, deepest first, and the audio is the
-    reference's."""
+    reference's.  devices > 1 (A2AMD_DEVICES): the voice tree spread over
+    that many backend contexts - every context pauses for the clients of its own voices,
+    then the root-bus partials are exchanged (a2amd_render_group, A2AMD_RENDER_EXCHANGE)."""
     need_ref()
     outs = []
     for preload in (False, True):
@@ -261,6 +257,8 @@ def test_dropin_serves_insert_clients_at_any_depth(tmp_path, nest, outer, buffer
             env["A2REF_INSERT_OUTER"] = "1"
         if preload:
             env["LD_PRELOAD"] = UNITS_SO
+            if devices > 1:
+                env["A2AMD_DEVICES"] = str(devices)
         r = subprocess.run([REF_RENDER, f"{A2S}/clients.a2s", "Main", "24000", str(buffer), "48000", "2", str(out), "0.1"],
                            env=env, cwd=A2S, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "insert client" not in r.stderr, r.stderr[-500:]

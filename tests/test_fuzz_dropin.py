@@ -26,7 +26,7 @@ def engine_config(seed):
 @pytest.mark.gpu
 # (>= 1000: with sleeping subtrees, fuzz_scripts.pad_programs; >= 2000: with voices that loop over the device VM's
 # part of the instruction set, fuzz_scripts.loop_programs - taken by the device VM, sent messages, killed, detached)
-@pytest.mark.parametrize("seed", list(range(24)) + list(range(1000, 1012)) + list(range(2000, 2024)))
+@pytest.mark.parametrize("seed", list(range(24)) + list(range(1000, 1012)) + list(range(2000, 2024)) + list(range(3000, 3016)))
 def test_random_script_matches_reference(tmp_path, seed):
     if not (os.path.exists(REF_RENDER) and os.path.exists(UNITS_SO)):
         pytest.skip("oracle/_ref (compiled reference) or liba2amd_units.so not built")
