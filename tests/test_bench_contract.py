@@ -26,8 +26,9 @@ def test_bench_prints_one_contract_line():
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 3 and d["higher_is_better"] is True
     assert d["unit"] == "voice-samples/s" and d["value"] > 0 and d["parity_vs_golden"] is True
     assert "configs[3]" in d["config"]["workload"] and d["config"]["voices_per_gpu"] == 65536
-    # steps 0..7 are in the golden: step 0, three warm-up steps, four timed steps
-    assert d["parity"]["golden_steps_compared"] == 8 and d["parity"]["timed_steps_covered_by_golden"] == 4
+    # the golden covers 64 steps (round 4: every step of the default run): here step 0, three warm-up steps and all
+    # six timed steps are compared hash by hash
+    assert d["parity"]["golden_steps_compared"] == 10 and d["parity"]["timed_steps_covered_by_golden"] == 6
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["kernel"] == "k_leaf_osc2pan"
