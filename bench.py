@@ -400,10 +400,14 @@ def kernel_code_sha(kernel):
 def valu_mix_entry(kernel):
     """The measured issue rate of the kernel's own instruction mix (tools/valu_mix.py)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_valu_mix.json")) as f:
-            return json.load(f)["kernels"].get(kernel)
+        for name in ("r04_valu_mix.json", "r03_valu_mix.json"):
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                with open(path) as f:
+                    return json.load(f)["kernels"].get(kernel)
     except (OSError, ValueError, KeyError):
-        return None
+        pass
+    return None
 
 
 class Runner:
