@@ -26,6 +26,9 @@ WALK_SO = os.path.join(ROOT, "audiality2_amd", "liba2amd_walk.so")
 A2S = os.path.join(ROOT, "tests", "a2s")
 
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
 def need_ref():
     if not (os.path.exists(REF_RENDER) and os.path.exists(UNITS_SO) and os.path.exists(WALK_SO)):
         pytest.skip("oracle/_ref (compiled reference), liba2amd_units.so or liba2amd_walk.so not built")
@@ -279,6 +282,97 @@ def test_host_interpreter_known_answers():
     st2.waketime = 128 << 8
     recs = trace_host(code, n, st2, [5], [(0, 1)], [WTOSC, PANMIX], [64] * 3)
     assert [r[1] for r in recs] == [R_WRITE, R_SEG] and recs[1] == (2, R_SEG, 0, 0, 0, 64 << 16, 0)
+
+
+KIND_OF = {n: k for k, n in enumerate("wtosc panmix filter12 fbdelay inline xinsert fm1 fm2 fm3 fm4 fm3p fm4p fm2r fm4r dc waveshaper "
+                                       "dcblock limiter xsink xsource".split())}        # a2amd_unitkind, include/a2amd.h
+
+
+def load_vm_traces():
+    import json
+    import lzma
+    with lzma.open(os.path.join(GOLDEN, "vm_traces.json.xz"), "rt") as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_host_interpreter_against_the_reference_vm(case):
+    """tests/golden/vm_traces.json.xz (made by tests/golden/make_vm_traces.py from oracle/ref_vmtrace.c: the COMPILED
+    REFERENCE's own VM running each looping voice of vmloops.a2s for 600 fragments, every unit register write and
+    every window logged).  The host copy of the device VM's interpreter - the header the kernel is compiled from -
+    takes over at the same moment (program text, A2_vmstate, register wiring, engine clock) and must produce the
+    same windows and the same writes: register, value as the unit's callback transforms it (a2amd_unit_write:
+    wtosc / fm pitch + transpose + base pitch, filter12's 1/q, limiter's release and threshold), duration, start -
+    in the same order, and end in the same VM state.  No GPU involved."""
+    d = load_vm_traces()[case]
+    L = audiality2_amd.load_library()
+    L.a2amd_vm_trace_host.restype = ctypes.c_int
+    n = len(d["code"])
+    code = (ctypes.c_uint32 * n)(*d["code"])
+    st = VmState()
+    st.waketime, st.state, st.func, st.pc = d["state"]["waketime"], d["state"]["state"], d["state"]["func"], d["state"]["pc"]
+    for k, v in enumerate(d["state"]["r"]):
+        st.r[k] = v
+    kinds = [KIND_OF[u] for u in d["units"]]
+    wu = (ctypes.c_int32 * 64)(*[pos for pos, _ in d["cregs"]])
+    wr = (ctypes.c_uint8 * 64)(*[max(reg, 0) for _, reg in d["cregs"]])
+    kk = (ctypes.c_int32 * len(kinds))(*kinds)
+    nfr = d["fragments"]
+    ff = (ctypes.c_uint8 * nfr)(*([64] * nfr))
+    cap = 1 << 16
+    recs = (ctypes.c_uint32 * (4 * cap))()
+    k = L.a2amd_vm_trace_host(code, ctypes.c_uint(n), ctypes.byref(st), wu, wr, kk, len(kinds), ctypes.c_uint32(d["now"]),
+                              ctypes.c_uint32(d["msdur"]), d["samplerate"], d["basepitch"], ff, nfr, recs, cap)
+    assert 0 < k < cap, k
+    got = []
+    for i in range(k):
+        head, value, dur, start = recs[4 * i], ctypes.c_int32(recs[4 * i + 1]).value, recs[4 * i + 2], recs[4 * i + 3]
+        frag, op, unit, reg = head & 0xffff, (head >> 16) & 0xff, (head >> 24) & 15, head >> 28
+        if op == R_SEG:
+            if dur != (64 << 16):           # (a whole-fragment window is the default window, explicit or not)
+                got.append((frag, "p", dur & 0xffff, dur >> 16))
+        elif op == R_WRITE:
+            if d["units"][unit] != "dcblock":       # (its cutoff arrives as a coefficient: the table's business, as below)
+                got.append((frag, "w", unit, reg, value, dur, start))
+        else:
+            assert op in (R_F1SET, R_F1RAMP), op    # (a filter coefficient: compared in the test below and on the GPU)
+
+    def i32(x):
+        return ((x + (1 << 31)) & 0xffffffff) - (1 << 31)
+
+    # (the engine cuts a fragment for the voice's PARENT too - the root voice's own timing - which the backend sees as
+    # two fragments: windows that follow each other without a write in between are one window here)
+    events = []
+    for e in d["events"]:
+        if e[0] == "p" and events and events[-1][0] == "p" and events[-1][1] == e[1] and events[-1][2] + events[-1][3] == e[2]:
+            events[-1] = ["p", e[1], events[-1][2], events[-1][3] + e[3]]
+        else:
+            events.append(list(e))
+    want = []
+    for e in events:
+        if e[0] == "p":
+            if (e[2], e[3]) != (0, 64):
+                want.append((e[1], "p", e[2], e[3]))
+            continue
+        _, frag, r, value, start, dur, transpose = e
+        pos, reg = d["cregs"][r]
+        kind = d["units"][pos]
+        if (kind == "filter12" and reg == 0) or kind == "dcblock":
+            continue                        # cutoff: host ramper + coefficient records / table value
+        if (kind == "wtosc" or kind.startswith("fm")) and reg == 1:
+            value = i32(value + transpose + d["basepitch"])
+        elif kind == "filter12" and reg == 1:
+            value = 32768 if value < 512 else (65536 << 8) // value
+        elif kind == "limiter":
+            value = i32((value << 8) & 0xffffffff) // d["samplerate"] if reg == 0 else max(256, (value << 8) & 0xffffffff)
+            if reg == 0 and i32((e[3] << 8) & 0xffffffff) < 0:
+                value = -((-i32((e[3] << 8) & 0xffffffff)) // d["samplerate"])     # (C division truncates)
+        want.append((frag, "w", pos, reg, value, dur, start & 255))
+    assert len(want) > 20
+    first = next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), None)
+    assert first is None and len(got) == len(want), (first, got[first:first + 3] if first is not None else len(got),
+                                                     want[first:first + 3] if first is not None else len(want))
+    assert (st.waketime, st.state, st.pc) == (d["end_state"]["waketime"], d["end_state"]["state"], d["end_state"]["pc"])
 
 
 def test_host_interpreter_cutoff_goes_through_the_coefficient_table():
