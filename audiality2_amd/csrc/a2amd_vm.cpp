@@ -977,7 +977,18 @@ int a2amd_vm_trace_host(const uint32_t *code, unsigned nwords, a2amd_vm_state *s
 		const uint8_t *wr_reg, const int32_t *kinds, int nkinds, uint32_t now, uint32_t msdur, int32_t samplerate,
 		int32_t basepitch, const uint8_t *fragframes, unsigned nfrags, uint32_t *recs, unsigned cap)
 {
+	return a2amd_vm_trace_host_env(code, nwords, st, wr_unit, wr_reg, kinds, nkinds, now, msdur, samplerate, basepitch,
+			fragframes, nullptr, nfrags, nullptr, 0, nullptr, recs, cap);
+}
+
+int a2amd_vm_trace_host_env(const uint32_t *code, unsigned nwords, a2amd_vm_state *st, const int32_t *wr_unit,
+		const uint8_t *wr_reg, const int32_t *kinds, int nkinds, uint32_t now, uint32_t msdur, int32_t samplerate,
+		int32_t basepitch, const uint8_t *fragframes, const uint8_t *fragbase, unsigned nfrags, a2amd_vm_env *envs, int nenv,
+		const uint16_t *envluts, uint32_t *recs, unsigned cap)
+{
 	if(!code || !st || !wr_unit || !wr_reg || !kinds || !fragframes || !recs || nkinds < 1 || nkinds > A2D_MAXCHAIN)
+		return A2AMD_EINVAL;
+	if(nenv < 0 || nenv > A2AMD_VM_MAXENV || (nenv && (!envs || !envluts)))
 		return A2AMD_EINVAL;
 	static thread_local uint32_t ptab[128];
 	static thread_local std::vector<int32_t> f1;
@@ -1006,14 +1017,38 @@ int a2amd_vm_trace_host(const uint32_t *code, unsigned nwords, a2amd_vm_state *s
 		if(wr_unit[r] >= 0 && wr_unit[r] < nkinds) {
 			d.cmap[r] = (uint8_t)((wr_unit[r] << 4) | wr_reg[r]);
 			need_f1 |= write_needs_f1tab(kinds[wr_unit[r]], wr_reg[r]);
+		} else if(wr_unit[r] <= -3 && -3 - wr_unit[r] < nenv)
+			d.cmap[r] = (uint8_t)((A2D_VM_ENVPOS << 4) | (-3 - wr_unit[r]));
+	d.nenv = nenv;
+	for(int k = 0; k < nenv; ++k) {
+		// (as a2amd_vm_adopt, with chain positions where that has backend unit ids)
+		A2DVmEnv &en = d.env[k];
+		memcpy(en.ramper, envs[k].ramper, sizeof(en.ramper));
+		en.lut = envs[k].lut;
+		en.scale = envs[k].scale;
+		en.offset = envs[k].offset;
+		en.out = envs[k].out;
+		en.active = envs[k].active;
+		if(envs[k].regbase < 0 || envs[k].regbase + 3 >= A2AMD_VM_REGISTERS || envs[k].before < 0 || envs[k].before > nkinds ||
+				envs[k].lut < 0 || envs[k].lut >= A2D_ENV_LUTS)
+			return A2AMD_EINVAL;
+		en.regbase = (uint8_t)envs[k].regbase;
+		en.k = (uint8_t)envs[k].before;
+		en.target = A2D_VM_NOWRITE;
+		if(envs[k].out_unit >= 0) {
+			if(envs[k].out_unit >= nkinds || !write_supported(kinds[envs[k].out_unit], envs[k].out_reg))
+				return A2AMD_EUNSUPPORTED;
+			en.target = (uint8_t)((envs[k].out_unit << 4) | envs[k].out_reg);
+			need_f1 |= write_needs_f1tab(kinds[envs[k].out_unit], envs[k].out_reg);
 		}
+	}
 	Consts K;
 	K.msdur = msdur;
 	K.samplerate = samplerate;
 	K.basepitch = basepitch;
 	K.ptab = ptab;
 	K.f1tab = nullptr;
-	K.envlut = nullptr;
+	K.envlut = envluts;
 	if(need_f1) {
 		if(f1.empty() || f1_sr != samplerate) {
 			f1.resize((size_t)32 * 65536);
@@ -1044,13 +1079,22 @@ int a2amd_vm_trace_host(const uint32_t *code, unsigned nwords, a2amd_vm_state *s
 		}
 		int count() const { return n; }
 	} e = { buf.data(), 0, (int)cap };
-	run_batch(d, code, K, e, now, 0, (int)nfrags, [fragframes](int f) { return (unsigned)fragframes[f]; });
+	run_batch(d, code, K, e, now, 0, (int)nfrags, [fragframes, fragbase](int f) {
+		return (unsigned)fragframes[f] | (fragbase ? (unsigned)fragbase[f] << 8 : 0u); });
 	if(d.fault)
 		return A2AMD_ESTATE;
 	st->waketime = d.waketime;
 	st->state = d.state;
 	st->pc = d.pc;
 	memcpy(st->r, d.r, sizeof(st->r));
+	for(int k = 0; k < nenv; ++k) {		// (where the segments stand at the end)
+		memcpy(envs[k].ramper, d.env[k].ramper, sizeof(envs[k].ramper));
+		envs[k].lut = d.env[k].lut;
+		envs[k].scale = d.env[k].scale;
+		envs[k].offset = d.env[k].offset;
+		envs[k].out = d.env[k].out;
+		envs[k].active = d.env[k].active;
+	}
 	const int n = std::min(e.n, (int)cap);
 	memcpy(recs, buf.data(), (size_t)n * sizeof(A2DRec));
 	return e.n;

@@ -179,6 +179,15 @@ int a2amd_vm_trace_host(const uint32_t *code, unsigned nwords, a2amd_vm_state *s
 		uint32_t now, uint32_t msdur, int32_t samplerate, int32_t basepitch,
 		const uint8_t *fragframes, unsigned nfrags, uint32_t *recs, unsigned cap);
 
+/* The same with the voice's env units (envs[k].out_unit = chain position of the wired unit, -1 none; wr_unit[r] = -3 - k
+ * for the VM register that is envs[k]'s 'target'; envluts = the eight tables of a2amd_vm_envluts(); *envs is advanced)
+ * and with the offset of every fragment inside the engine's own fragment (a2amd_fragment_offset; NULL: all 0). */
+int a2amd_vm_trace_host_env(const uint32_t *code, unsigned nwords, a2amd_vm_state *st,
+		const int32_t *wr_unit, const uint8_t *wr_reg, const int32_t *kinds, int nkinds,
+		uint32_t now, uint32_t msdur, int32_t samplerate, int32_t basepitch,
+		const uint8_t *fragframes, const uint8_t *fragbase, unsigned nfrags,
+		a2amd_vm_env *envs, int nenv, const uint16_t *envluts, uint32_t *recs, unsigned cap);
+
 typedef struct a2amd_vm_stats {
 	uint64_t adopted, recalled, released;	/* voices, so far */
 	uint64_t vm_voice_batches;		/* sum over batches of voices the VM kernel ran */

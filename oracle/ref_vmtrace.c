@@ -15,7 +15,13 @@
  *   - what the engine's own VM did with the voice over the next <fragments> fragments: every call of a unit's
  *     write callback (a2_VoiceControl, core.c:143-149: register, value, start, duration, and the voice's
  *     transpose register at that moment) and every window the voice's units were given (a2_VoiceProcess,
- *     core.c:1847-1880: offset, frames), in order.
+ *     core.c:1847-1880: offset, frames), in order ("p"; logged at the voice's first unit that is not an env, so that an env
+ *     unit's write through its control wire, env.c:131, lands on the side of the window it belongs to), and every
+ *     window of the ROOT voice ("r": where the engine cut its own fragments - the backend's fragments).
+ *   - for env units (src/units/env.c): where they sit in the chain, which VM registers are theirs, where the control
+ *     output is wired.  Their internal state is private to env.c; a trace is therefore started before the program
+ *     has written any env's 'target' (warm_fragments 0 and a delay at the head of the program), when it is the
+ *     state env_Initialize leaves (env.c:225-250).
  * tests/golden/make_vm_traces.py keeps the output as fixtures; tests/test_device_vm.py replays them.
  */
 #include <stdio.h>
@@ -53,7 +59,18 @@ T(16) T(17) T(18) T(19) T(20) T(21) T(22) T(23) T(24) T(25) T(26) T(27) T(28) T(
 T(32) T(33) T(34) T(35) T(36) T(37) T(38) T(39) T(40) T(41) T(42) T(43) T(44) T(45) T(46) T(47)
 T(48) T(49) T(50) T(51) T(52) T(53) T(54) T(55) T(56) T(57) T(58) T(59) T(60) T(61) T(62) T(63) };
 
-/* the window, as the LAST unit of the chain is given it (the units in front have had it by then) */
+static A2_process_cb orig_root_process;
+static void hook_root(A2_unit *u, unsigned offset, unsigned frames)
+{
+	if(nev < MAXEV)
+	{
+		ev[nev].kind = 'r'; ev[nev].frag = cur_frag; ev[nev].a = (int)offset; ev[nev].b = (int)frames;
+		++nev;
+	}
+	orig_root_process(u, offset, frames);
+}
+
+/* the window, as the voice's first audio unit is given it */
 static void hook_process(A2_unit *u, unsigned offset, unsigned frames)
 {
 	if(nev < MAXEV)
@@ -72,7 +89,8 @@ int main(int argc, const char *argv[])
 	A2_state *st;
 	A2_handle bank, prog;
 	A2_voice *root;
-	A2_unit *u, *last = NULL;
+	A2_unit *u, *last = NULL, *rootlast = NULL;
+	int nenvs = 0;
 	const A2_function *fn;
 	int args[8], nargs = 0, warm, nfrags, k, r, tries = 0;
 	RCHM_handleinfo *hi;
@@ -101,8 +119,7 @@ int main(int argc, const char *argv[])
 		a2_Run(i, 64);
 	hi = rchm_Get(&st->ss->hm, st->rootvoice);
 	root = hi ? (A2_voice *)hi->d.data : NULL;
-	voice = root ? root->sub : NULL;
-	while(voice && voice->s.state != A2_WAITING && tries++ < 64)
+	while(root && (!(voice = root->sub) || voice->s.state != A2_WAITING) && tries++ < 64)
 		a2_Run(i, 64);
 	if(!voice || !voice->program || voice->s.state != A2_WAITING || voice->sub || voice->events || voice->stack)
 	{
@@ -131,8 +148,25 @@ int main(int argc, const char *argv[])
 	for(u = voice->units, k = 0; u; u = u->next, ++k)
 	{
 		printf("%s\"%s\"", k ? ", " : "", u->descriptor->name);
-		last = u;
+		if(!strcmp(u->descriptor->name, "env"))
+			++nenvs;
+		else if(!last)
+			last = u;	/* (the first audio unit: where the voice's windows are logged) */
 	}
+	printf("],\n \"envs\": [");
+	for(u = voice->units, k = 0, r = 0; u; u = u->next, ++k)
+		if(!strcmp(u->descriptor->name, "env"))
+		{
+			/* which register of which unit is the control output wired to?  (a2_ControlWire, core.c:330-345,
+			 * copied unit and callback from the voice's register write table) */
+			int q, outreg = -1;
+			for(q = 0; q < voice->ncregs; ++q)
+				if(u->coutputs[0].write && voice->cregs[q].unit == u->coutputs[0].unit &&
+						voice->cregs[q].write == u->coutputs[0].write)
+					outreg = q;
+			printf("%s{\"unit\": %d, \"regbase\": %d, \"out_vmreg\": %d}", r++ ? ", " : "", k,
+					(int)(u->registers - voice->s.r), outreg);
+		}
 	printf("],\n \"cregs\": [");
 	for(r = 0; r < A2_REGISTERS; ++r)
 	{
@@ -154,8 +188,21 @@ int main(int argc, const char *argv[])
 			orig_write[r] = voice->cregs[r].write;
 			voice->cregs[r].write = tramp[r];
 		}
+	/* (an env's control output calls the wired unit's callback directly: through the same trampoline, then) */
+	for(u = voice->units; u; u = u->next)
+		if(!strcmp(u->descriptor->name, "env") && u->coutputs[0].write)
+			for(r = 0; r < voice->ncregs; ++r)
+				if(voice->cregs[r].unit == u->coutputs[0].unit && orig_write[r] == u->coutputs[0].write)
+					u->coutputs[0].write = tramp[r];
+	for(u = root->units; u; u = u->next)
+		rootlast = u;
 	for(cur_frag = 0; cur_frag < nfrags; ++cur_frag)
 	{
+		if(rootlast && rootlast->Process != hook_root)
+		{
+			orig_root_process = rootlast->Process;
+			rootlast->Process = hook_root;
+		}
 		if(last && last->Process != hook_process)
 		{
 			orig_process = last->Process;
@@ -174,7 +221,7 @@ int main(int argc, const char *argv[])
 		if(ev[k].kind == 'w')
 			printf("%s[\"w\", %d, %d, %d, %u, %u, %d]", k ? ", " : "", ev[k].frag, ev[k].a, ev[k].b, ev[k].c, ev[k].d, ev[k].e);
 		else
-			printf("%s[\"p\", %d, %d, %d]", k ? ", " : "", ev[k].frag, ev[k].a, ev[k].b);
+			printf("%s[\"%c\", %d, %d, %d]", k ? ", " : "", ev[k].kind, ev[k].frag, ev[k].a, ev[k].b);
 	printf("]}\n");
 	/* (the trampolines stay in place until the voice dies with the state) */
 	a2_Close(i);

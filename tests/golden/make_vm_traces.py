@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Fixtures that pin the device VM's interpreter (audiality2_amd/csrc/a2amd_vmcore.h) on the CPU: for each looping
-voice program of tests/a2s/vmloops.a2s, what the COMPILED REFERENCE's own VM did with the voice - every unit register
-write (a2_VoiceControl, src/core.c:143-149) and every window (a2_VoiceProcess, core.c:1847-1880) over 600 fragments -
+voice program of tests/a2s/vmloops.a2s and tests/a2s/envtrace.a2s (voices with env units), what the COMPILED REFERENCE's own VM did with the voice - every unit register
+write (a2_VoiceControl, src/core.c:143-149; an env's through its control wire, src/units/env.c:131), every window
+(a2_VoiceProcess, core.c:1847-1880) and every window of the root voice (= the backend's fragments) over 600 fragments -
 together with the program text, VM state and register wiring at the moment the trace starts (oracle/ref_vmtrace.c,
 built by oracle/Makefile against the reference's sources where they lie).
 
@@ -19,15 +20,22 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 EXE = os.path.join(ROOT, "oracle", "_ref", "ref_vmtrace")
 A2S = os.path.join(ROOT, "tests", "a2s")
 
-# program, arguments (as the script's Main passes them), warm-up fragments
-CASES = [("Lfo", [-1, .08, -.5], 20), ("Lfo", [.37, .05, .8], 33), ("Trem", [0, .08], 25), ("Arp", [.5, .08], 31), ("Duo", [-1.5, .08], 27),
-         ("Sweep", [-2, .08], 40), ("Pad", [-.5, .08], 22), ("Fm", [0, .08], 29), ("Fx", [.3, .08], 35), ("Dc", [.024], 21),
-         ("Echo", [1, .08], 26), ("Tr", [-1, .08], 24)]
+# script, program, arguments (as the script's Main passes them), warm-up fragments
+CASES = [("vmloops", "Lfo", [-1, .08, -.5], 20), ("vmloops", "Lfo", [.37, .05, .8], 33), ("vmloops", "Trem", [0, .08], 25),
+         ("vmloops", "Arp", [.5, .08], 31), ("vmloops", "Duo", [-1.5, .08], 27), ("vmloops", "Sweep", [-2, .08], 40),
+         ("vmloops", "Pad", [-.5, .08], 22), ("vmloops", "Fm", [0, .08], 29), ("vmloops", "Fx", [.3, .08], 35),
+         ("vmloops", "Dc", [.024], 21), ("vmloops", "Echo", [1, .08], 26), ("vmloops", "Tr", [-1, .08], 24),
+         # env units: traced from the program's first delay on, before any env's target was written
+         # (mode constants as 16:16 numbers: EXP3 = 4, IEXP2 = -3, SPLINE = -1, EXP7 = 8, IEXP7 = -8, EXP4 = 5, LINEAR = 1)
+         ("envtrace", "Front", [-1, .08, 4, -3], 0), ("envtrace", "Front", [-.2, .08, -1, -1], 0),
+         ("envtrace", "Front", [.4, .08, 8, -8], 0), ("envtrace", "Front", [.9, .08, -2, 7], 0),
+         ("envtrace", "Behind", [-.5, .08, 5], 0), ("envtrace", "Behind", [.2, .08, 1], 0), ("envtrace", "Timed", [0, .08], 0),
+         ("envtrace", "Two", [-.7, .08], 0), ("envtrace", "Siren", [-1.2, .08], 0), ("envtrace", "Plain", [.6, .08], 0)]
 
 if __name__ == "__main__":
     out = []
-    for prog, args, warm in CASES:
-        r = subprocess.run([EXE, "vmloops.a2s", prog, str(warm), "600"] + [repr(a) for a in args], cwd=A2S, capture_output=True,
+    for script, prog, args, warm in CASES:
+        r = subprocess.run([EXE, script + ".a2s", prog, str(warm), "600"] + [repr(a) for a in args], cwd=A2S, capture_output=True,
                            text=True, check=True)
         d = json.loads(r.stdout)
         print(prog, args, len(d["code"]), "code words,", len(d["events"]), "events")

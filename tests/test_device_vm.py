@@ -295,44 +295,102 @@ def load_vm_traces():
         return json.load(f)
 
 
-@pytest.mark.parametrize("case", range(12))
+class VmEnv(ctypes.Structure):       # a2amd_vm_env, include/a2amd_vm.h
+    _fields_ = [("ramper", ctypes.c_int32 * 4), ("lut", ctypes.c_int32), ("scale", ctypes.c_int32), ("offset", ctypes.c_int32),
+                ("out", ctypes.c_int32), ("active", ctypes.c_int32), ("regbase", ctypes.c_int32), ("before", ctypes.c_int32),
+                ("out_unit", ctypes.c_int32), ("out_reg", ctypes.c_int32)]
+
+
+def env_tables():
+    """env_InitLUTs, src/units/env.c:218-257, with the reference's expressions and types: float constants widened to
+    double next to a double, libm's cos / pow (math.* calls the same libm the reference was compiled against)."""
+    import math
+    f = lambda x: float(np.float32(x))
+    t = [[0] * 66 for _ in range(8)]
+    for i in range(64):
+        t[0][i] = int((1.0 - math.cos(i * math.pi / 63)) * 16384.0 + 0.5)
+    for j, deg in enumerate((1, 2, 3, 4, 6, 9, 13)):
+        c = math.pow(f(0.1), float(deg))
+        rc = f(0.002) + f(0.1) * math.pow(f(0.8), float(deg))
+        for i in range(64):
+            x = 1.0 - i / 64.0
+            r = (1.0 - x) * rc
+            t[1 + j][i] = int((math.pow(c, x) * (1.0 - r) + r - c * x) * 32768.0 + 0.5)
+    for row in t:
+        row[64] = row[65] = 32768
+    return (ctypes.c_uint16 * (8 * 66))(*[v for row in t for v in row])
+
+
+@pytest.mark.parametrize("case", range(22))
 def test_host_interpreter_against_the_reference_vm(case):
     """tests/golden/vm_traces.json.xz (made by tests/golden/make_vm_traces.py from oracle/ref_vmtrace.c: the COMPILED
-    REFERENCE's own VM running each looping voice of vmloops.a2s for 600 fragments, every unit register write and
-    every window logged).  The host copy of the device VM's interpreter - the header the kernel is compiled from -
-    takes over at the same moment (program text, A2_vmstate, register wiring, engine clock) and must produce the
-    same windows and the same writes: register, value as the unit's callback transforms it (a2amd_unit_write:
-    wtosc / fm pitch + transpose + base pitch, filter12's 1/q, limiter's release and threshold), duration, start -
-    in the same order, and end in the same VM state.  No GPU involved."""
+    REFERENCE's own VM running each looping voice of vmloops.a2s - and, cases 12 on, of envtrace.a2s: voices with env
+    units in every table mode, in front of and behind what they drive, with 'time' overrides, two on one voice - for 600
+    fragments, every unit register write, every window and the root voice's windows logged).  The host copy of the
+    device VM's interpreter - the header the kernel is compiled from - takes over at the same moment (program text,
+    A2_vmstate, register wiring, env placement, engine clock, the engine's fragments as the root voice cut them) and
+    must produce the same windows and the same writes: register, value as the unit's callback transforms it
+    (a2amd_unit_write: wtosc / fm pitch + transpose + base pitch, filter12's 1/q, limiter's release and threshold; an env
+    segment's per-window value through its control wire), duration, start - in the same order, and end in the same VM
+    state.  No GPU involved."""
     d = load_vm_traces()[case]
     L = audiality2_amd.load_library()
-    L.a2amd_vm_trace_host.restype = ctypes.c_int
+    L.a2amd_vm_trace_host_env.restype = ctypes.c_int
     n = len(d["code"])
     code = (ctypes.c_uint32 * n)(*d["code"])
     st = VmState()
     st.waketime, st.state, st.func, st.pc = d["state"]["waketime"], d["state"]["state"], d["state"]["func"], d["state"]["pc"]
     for k, v in enumerate(d["state"]["r"]):
         st.r[k] = v
-    kinds = [KIND_OF[u] for u in d["units"]]
-    wu = (ctypes.c_int32 * 64)(*[pos for pos, _ in d["cregs"]])
-    wr = (ctypes.c_uint8 * 64)(*[max(reg, 0) for _, reg in d["cregs"]])
-    kk = (ctypes.c_int32 * len(kinds))(*kinds)
-    nfr = d["fragments"]
-    ff = (ctypes.c_uint8 * nfr)(*([64] * nfr))
+    # chain positions as the backend counts them: env units are not backend units
+    env_units = [e["unit"] for e in d["envs"]]
+    bpos = {}
+    for k, u in enumerate(d["units"]):
+        if k not in env_units:
+            bpos[k] = len(bpos)
+    names = [u for k, u in enumerate(d["units"]) if k not in env_units]
+    kinds = [KIND_OF[u] for u in names]
+    wu, wr = [-1] * 64, [0] * 64
+    for r, (pos, reg) in enumerate(d["cregs"]):
+        if pos in bpos:
+            wu[r], wr[r] = bpos[pos], reg
+    envs = (VmEnv * 2)()
+    assert len(d["envs"]) <= 2
+    for k, e in enumerate(d["envs"]):
+        wu[e["regbase"]] = -3 - k                       # its 'target' register
+        envs[k].regbase = e["regbase"]
+        envs[k].before = sum(1 for q in bpos if q < e["unit"])
+        envs[k].out_unit, envs[k].out_reg = (-1, 0) if e["out_vmreg"] < 0 else (bpos[d["cregs"][e["out_vmreg"]][0]], d["cregs"][e["out_vmreg"]][1])
+    # the backend's fragments = the root voice's windows; every event belongs to the fragment whose "r" follows it
+    frames, base, events, pending = [], [], [], []
+    for e in d["events"]:
+        if e[0] == "r":
+            events += [(len(frames), e[2], x) for x in pending]
+            pending = []
+            frames.append(e[3])
+            base.append(e[2])
+        else:
+            pending.append(e)
+    assert not pending and sum(frames) == 64 * d["fragments"]
+    nfr = len(frames)
+    ff = (ctypes.c_uint8 * nfr)(*frames)
+    fb = (ctypes.c_uint8 * nfr)(*base)
     cap = 1 << 16
     recs = (ctypes.c_uint32 * (4 * cap))()
-    k = L.a2amd_vm_trace_host(code, ctypes.c_uint(n), ctypes.byref(st), wu, wr, kk, len(kinds), ctypes.c_uint32(d["now"]),
-                              ctypes.c_uint32(d["msdur"]), d["samplerate"], d["basepitch"], ff, nfr, recs, cap)
+    k = L.a2amd_vm_trace_host_env(code, ctypes.c_uint(n), ctypes.byref(st), (ctypes.c_int32 * 64)(*wu), (ctypes.c_uint8 * 64)(*wr),
+                                  (ctypes.c_int32 * len(kinds))(*kinds), len(kinds), ctypes.c_uint32(d["now"]),
+                                  ctypes.c_uint32(d["msdur"]), d["samplerate"], d["basepitch"], ff, fb, nfr, envs, len(d["envs"]),
+                                  env_tables(), recs, cap)
     assert 0 < k < cap, k
     got = []
     for i in range(k):
         head, value, dur, start = recs[4 * i], ctypes.c_int32(recs[4 * i + 1]).value, recs[4 * i + 2], recs[4 * i + 3]
         frag, op, unit, reg = head & 0xffff, (head >> 16) & 0xff, (head >> 24) & 15, head >> 28
         if op == R_SEG:
-            if dur != (64 << 16):           # (a whole-fragment window is the default window, explicit or not)
+            if dur != (frames[frag] << 16):     # (a whole-fragment window is the default window, explicit or not)
                 got.append((frag, "p", dur & 0xffff, dur >> 16))
         elif op == R_WRITE:
-            if d["units"][unit] != "dcblock":       # (its cutoff arrives as a coefficient: the table's business, as below)
+            if names[unit] != "dcblock":        # (its cutoff arrives as a coefficient: the table's business, as below)
                 got.append((frag, "w", unit, reg, value, dur, start))
         else:
             assert op in (R_F1SET, R_F1RAMP), op    # (a filter coefficient: compared in the test below and on the GPU)
@@ -340,22 +398,16 @@ def test_host_interpreter_against_the_reference_vm(case):
     def i32(x):
         return ((x + (1 << 31)) & 0xffffffff) - (1 << 31)
 
-    # (the engine cuts a fragment for the voice's PARENT too - the root voice's own timing - which the backend sees as
-    # two fragments: windows that follow each other without a write in between are one window here)
-    events = []
-    for e in d["events"]:
-        if e[0] == "p" and events and events[-1][0] == "p" and events[-1][1] == e[1] and events[-1][2] + events[-1][3] == e[2]:
-            events[-1] = ["p", e[1], events[-1][2], events[-1][3] + e[3]]
-        else:
-            events.append(list(e))
     want = []
-    for e in events:
+    for frag, fbase, e in events:
         if e[0] == "p":
-            if (e[2], e[3]) != (0, 64):
-                want.append((e[1], "p", e[2], e[3]))
+            if (e[2] - fbase, e[3]) != (0, frames[frag]):
+                want.append((frag, "p", e[2] - fbase, e[3]))
             continue
-        _, frag, r, value, start, dur, transpose = e
+        _, _, r, value, start, dur, transpose = e
         pos, reg = d["cregs"][r]
+        if pos in env_units:
+            continue                        # the VM's write to an env's 'target': it starts a segment, no record
         kind = d["units"][pos]
         if (kind == "filter12" and reg == 0) or kind == "dcblock":
             continue                        # cutoff: host ramper + coefficient records / table value
@@ -364,10 +416,9 @@ def test_host_interpreter_against_the_reference_vm(case):
         elif kind == "filter12" and reg == 1:
             value = 32768 if value < 512 else (65536 << 8) // value
         elif kind == "limiter":
-            value = i32((value << 8) & 0xffffffff) // d["samplerate"] if reg == 0 else max(256, (value << 8) & 0xffffffff)
-            if reg == 0 and i32((e[3] << 8) & 0xffffffff) < 0:
-                value = -((-i32((e[3] << 8) & 0xffffffff)) // d["samplerate"])     # (C division truncates)
-        want.append((frag, "w", pos, reg, value, dur, start & 255))
+            v8 = i32((value << 8) & 0xffffffff)
+            value = (abs(v8) // d["samplerate"]) * (1 if v8 >= 0 else -1) if reg == 0 else max(256, (value << 8) & 0xffffffff)
+        want.append((frag, "w", bpos[pos], reg, value, dur, start & 255))
     assert len(want) > 20
     first = next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), None)
     assert first is None and len(got) == len(want), (first, got[first:first + 3] if first is not None else len(got),
