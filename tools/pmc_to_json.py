@@ -42,7 +42,7 @@ def main():
         chain, voices, groups, B = label.split("/")
         voices, groups, B = int(voices), int(groups), int(B)
         leaf = LEAF.get(chain, "k_leaf_oscpan" if chain.startswith("osc-pan") else "k_leaf_fmpan")
-        e = {"kernel": leaf, "source": f"rocprofv3 --pmc passes of bench.py --config shape {label} (tools/profile_round3.sh / tools/r04_private_pmc.sh), "
+        e = {"kernel": leaf, "source": f"rocprofv3 --pmc passes of bench.py --config shape {label} (tools/profile_round4.sh), "
                                        "median launch", "kernels": {}}
         for k, d in kernels.items():
             kd = dict(d)
