@@ -1274,7 +1274,9 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 // batch; the sums of RECS_FCH fragments of all the wavefront's voices on one bus go
 // out in one atomic add per fragment and channel.
 #define RECS_FCH 4
+#ifndef RECS_WPB
 #define RECS_WPB 8		// wavefronts per workgroup
+#endif
 
 DEV void osc_init_s(const FastPtrs &g, OscS &o, int pitch)
 {
