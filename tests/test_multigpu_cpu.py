@@ -95,3 +95,34 @@ def test_int32_sum_wraps_like_the_bus():
     a = torch.tensor([2**31 - 1, -2**31, 5], dtype=torch.int32)
     b = torch.tensor([1, -1, -7], dtype=torch.int32)
     assert (a + b).tolist() == [-2**31, 2**31 - 1, -2]
+
+
+def test_whole_job_scene_is_the_union_of_the_ranks_scenes(oracle_lib):
+    """bench.py's N > 1 line gates the ranks' summed render on an oracle golden of ONE scene holding every rank's voices
+    and groups (tests/golden/make_bench_golden.py 30: build_scene(voices x N, groups x N) with world = 1).  That is only
+    the same audio if a rank's scene - its voices numbered from rank x voices, pitches spread over the whole job, under
+    its own delay groups - is exactly that rank's slice of the big scene: checked here with the oracle at a small size,
+    BASELINE configs[3]'s shape (two oscillators -> panmix under inline -> fbdelay -> fbdelay groups), root-bus partials
+    summed as the reduce sums them."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from audiality2_amd import synth
+    from audiality2_amd.replay import Backend
+    voices, groups, world, frags = 64, 4, 2, 12
+
+    def render(nvoices, ngroups, first, total):
+        be = Backend(oracle_lib, "a2o_", 48000, synth.basepitch_for(48000), 2)
+        sc = synth.Scene(be)
+        sc.nvoices = first
+        for _ in range(ngroups):
+            grp = sc.add_group(preset="fmtest4")
+            sc.add_voices(nvoices // ngroups, chain="osc2-pan", group=grp, total=total)
+        out = sc.run(frags, batch=4)
+        be.close()
+        return out.astype(np.int64)
+
+    parts = [render(voices, groups, r * voices, voices * world) for r in range(world)]
+    whole = render(voices * world, groups * world, 0, voices * world)
+    assert whole.any()
+    summed = ((sum(parts) + (1 << 31)) % (1 << 32)) - (1 << 31)        # int32 wrap-around, as ncclSum(int32)
+    assert np.array_equal(summed, whole)
