@@ -1,6 +1,7 @@
 """Parity of the HIP path (through the C ABI of liba2amd.so) with the CPU
 oracle and with the fixtures captured from the compiled reference.
 Bit-exact: everything on this path is integer arithmetic."""
+import ctypes
 import os
 
 import numpy as np
@@ -1238,3 +1239,72 @@ def test_config4_over_distinct_gpus_matches_oracle_golden(n):
                         "t._cfg4_rccl(%d)" % (os.path.dirname(os.path.abspath(__file__)), ROOT, n)],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+# ---- a wave built on the device from what the device rendered --------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("length,looped,mip", [(2000, False, False), (733, True, False), (3001, False, True), (4096, True, True),
+                                               (130, True, True), (5, True, True), (1, False, True), (64, False, True)])
+def test_wave_built_from_a_capture_equals_the_uploaded_wave(oracle_lib, length, looped, mip):
+    """a2amd_capture_begin / _end + a2amd_wave_upload_captured (the device-resident half of a2_RenderWave)
+    through the C ABI, without the engine: a context renders `length` frames of a small scene - fragments of 64 and a
+    partial last one, several batches - with the capture on; a second context builds a wave from the capture ON THE
+    DEVICE (level 0 = samples >> 8, pads, mip levels: src/waves.c:89-130, 174-177).  A third context and the oracle
+    get the same wave the host way: the rendered PCM converted and mip-mapped by synth.wave_pyramid (the numpy
+    restatement of those functions, pinned on the reference's built-in waves) and uploaded.  The same voices, over all
+    mip levels, on each of the three: identical audio.  One-shot and looped, plain and mip-mapped, lengths below the
+    pad (130), below a mip level's reach (5, 1), a whole number of fragments (64, 4096)."""
+    from audiality2_amd.replay import a2amd_wavedesc
+    sub = make_gpu(max_batch=8)
+    lib = sub.lib
+    lib.a2amd_capture_begin.argtypes = [ctypes.c_void_p]
+    lib.a2amd_capture_end.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+    lib.a2amd_capture_frames.argtypes = [ctypes.c_void_p]
+    lib.a2amd_capture_frames.restype = ctypes.c_uint
+    lib.a2amd_capture_free.argtypes = [ctypes.c_void_p]
+    lib.a2amd_wave_upload_captured.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(a2amd_wavedesc), ctypes.c_void_p]
+    assert lib.a2amd_capture_begin(sub.ctx) == 0
+    sc = synth.Scene(sub)
+    sc.root()
+    sc.add_voices(24, chain="osc-filter-pan")
+    pcm, left, pending = [], length, 0
+    while left:
+        n = min(64, left)
+        sc.walk(n)
+        left -= n
+        pending += n
+        if pending >= 7 * 64 or not left:
+            pcm.append(sub.render(pending))
+            pending = 0
+    pcm = np.concatenate(pcm, axis=1)[0]
+    cap = ctypes.c_void_p()
+    assert lib.a2amd_capture_end(sub.ctx, ctypes.byref(cap)) == 0 and cap.value
+    assert lib.a2amd_capture_frames(cap) == length == len(pcm)
+    sub.close()                                     # (the capture outlives its context)
+    assert length < 64 or np.abs(pcm).max() > 256
+    levels = synth.MIPLEVELS if mip else 1
+    sizes, data = synth.wave_pyramid((pcm >> 8).astype(np.int16), looped=looped, levels=levels)
+    wtype, flags, period = (synth.WMIPWAVE if mip else synth.WWAVE), (synth.LOOPED if looped else 0), 64
+    outs = []
+    for how in ("captured", "uploaded", "oracle"):
+        be = make_oracle(oracle_lib) if how == "oracle" else make_gpu(max_batch=8)
+        s2 = synth.Scene(be)
+        if how == "captured":
+            d = a2amd_wavedesc()
+            d.type, d.flags, d.period = wtype, flags, period
+            for lv in range(levels):
+                d.size[lv] = sizes[lv]
+            wid = lib.a2amd_wave_upload_captured(be.ctx, 0x7777, ctypes.byref(d), cap)
+            assert wid >= 0, be._err(be.ctx)
+        else:
+            wid = be.wave_upload(0x7777, wtype, flags, period, sizes + [0] * (synth.MIPLEVELS - len(sizes)), data)
+        s2.private_ids = [wid]
+        s2.root()
+        s2.add_voices(61, chain="osc-pan", private=True)
+        outs.append(s2.run(24, batch=8))
+        be.close()
+    lib.a2amd_capture_free(cap)
+    assert np.array_equal(outs[1], outs[2]), "uploaded wave: GPU vs oracle"
+    assert np.array_equal(outs[0], outs[1]), "wave built from the capture vs the uploaded one"
+    if length >= 64:
+        assert outs[0].any()
