@@ -132,6 +132,13 @@ typedef struct HOSTSTATE
 	A2P_unit	*chain_env[2];
 	int		chain_nenv;
 	int		capturing;	/* a2_RenderWave's substate: what it renders is kept on the device */
+	/* ... and in the state that asked for the wave: captures waiting for the engine thread to build the wave's
+	 * device copy from them, at the wave's first use (a2_RenderWave may be called from the API thread of a
+	 * realtime state: the backend context belongs to the engine thread) */
+	struct PENDCAP { A2P_wave *w; a2amd_capture *cap; } *pendcaps;
+	int		npendcaps, cap_pendcaps;
+	pthread_mutex_t	pendcaps_mtx;
+	int		pendcaps_mtx_ok;
 	int		envluts_sent[MAXDEV];	/* the context has env's tables (a2amd_vm_envluts) */
 	A2P_xinsert	*root_xi;	/* the root voice's xinsert (the engine's own instance) */
 	void		*engine_state;	/* A2_state, for a2r_Error */
@@ -345,6 +352,7 @@ static int amd_open(A2P_config *cfg, void **statedata)
 			if(!++serials)
 				++serials;
 			freeone->serial = serials;
+			freeone->pendcaps_mtx_ok = !pthread_mutex_init(&freeone->pendcaps_mtx, NULL);
 			if(rendering && rendering->armed)
 			{
 				rendering->armed = 0;
@@ -382,6 +390,11 @@ static void amd_close(void *statedata)
 			if(hs->ctxs[c])
 				a2amd_close(hs->ctxs[c]);
 		hs->ctx = NULL;
+		for(c = 0; c < hs->npendcaps; ++c)
+			a2amd_capture_free(hs->pendcaps[c].cap);
+		free(hs->pendcaps);
+		if(hs->pendcaps_mtx_ok)
+			pthread_mutex_destroy(&hs->pendcaps_mtx);
 		free(hs->births);
 		/* (the engine clears A2_audiodriver.Process itself when the state closes,
 		 * src/audiality2.c:733) */
@@ -485,7 +498,6 @@ static a2amd_ctx *ctx_of(HOSTSTATE *hs)
 #define XCTX(x) ((x)->hs->ctxs[(x)->dev])
 
 static int wave_id_of(HOSTSTATE *hs, int dev, A2P_wave *w);
-static int wave_registered(HOSTSTATE *hs, A2P_wave *w, int dev, int id);
 static inline XTRA *xtra(A2P_unit *u);
 static int is_ours(const A2P_unitdesc *d);
 
@@ -755,6 +767,20 @@ static void amd_deinit(A2P_unit *u)
 static void sweep_waves(HOSTSTATE *hs)
 {
 	int i, rc;
+	if(hs->npendcaps)
+	{
+		/* a rendered wave that was released before anybody played it: its capture goes with it */
+		pthread_mutex_lock(&hs->pendcaps_mtx);
+		for(i = 0; i < hs->npendcaps; )
+			if(!hs->pendcaps[i].w->size[0])
+			{
+				a2amd_capture_free(hs->pendcaps[i].cap);
+				hs->pendcaps[i] = hs->pendcaps[--hs->npendcaps];
+			}
+			else
+				++i;
+		pthread_mutex_unlock(&hs->pendcaps_mtx);
+	}
 	for(i = 0; i < hs->nwaves; )
 	{
 		A2P_wave *w = hs->wave_ptr[i];
@@ -1633,37 +1659,6 @@ static void amd_rootx_setprocess(A2P_unit *u)
 }
 
 /* ---- control register writes --------------------------------------------------*/
-/* the registry learns that engine wave w is wave 'id' of context 'dev'; returns id, -1 out of memory */
-static int wave_registered(HOSTSTATE *hs, A2P_wave *w, int dev, int id)
-{
-	int i, k, slot = -1;
-	for(i = 0; i < hs->nwaves; ++i)
-		if(hs->wave_ptr[i] == w)
-			slot = i;
-	if(slot < 0 && hs->nwaves == hs->cap_waves)
-	{
-		int nc = hs->cap_waves ? hs->cap_waves * 2 : 256;
-		A2P_wave **np = (A2P_wave **)realloc(hs->wave_ptr, nc * sizeof(A2P_wave *));
-		int (*ni)[MAXDEV] = np ? (int (*)[MAXDEV])realloc(hs->wave_id, nc * sizeof(hs->wave_id[0])) : NULL;
-		if(np)
-			hs->wave_ptr = np;
-		if(ni)
-			hs->wave_id = ni;
-		if(!np || !ni)
-			return -1;
-		hs->cap_waves = nc;
-	}
-	if(slot < 0)
-	{
-		slot = hs->nwaves++;
-		hs->wave_ptr[slot] = w;
-		for(k = 0; k < MAXDEV; ++k)
-			hs->wave_id[slot][k] = -1;
-	}
-	hs->wave_id[slot][dev] = id;
-	return id;
-}
-
 static int wave_id_of(HOSTSTATE *hs, int dev, A2P_wave *w)
 {
 	a2amd_wavedesc d;
@@ -1706,7 +1701,33 @@ static int wave_id_of(HOSTSTATE *hs, int dev, A2P_wave *w)
 		d.size[i] = w->size[i];
 		d.data[i] = w->data[i];
 	}
-	id = a2amd_wave_upload(hs->ctxs[dev], (uint64_t)(uintptr_t)w, &d);
+	id = -1;
+	if(hs->npendcaps)
+	{
+		/* the device rendered this wave (a2_RenderWave below): its copy is built from what the device kept - on
+		 * the context of this state that gets to play it first; others take the engine's copy */
+		a2amd_capture *cap = NULL;
+		pthread_mutex_lock(&hs->pendcaps_mtx);
+		for(i = 0; i < hs->npendcaps; ++i)
+			if(hs->pendcaps[i].w == w)
+			{
+				cap = hs->pendcaps[i].cap;
+				hs->pendcaps[i] = hs->pendcaps[--hs->npendcaps];
+				break;
+			}
+		pthread_mutex_unlock(&hs->pendcaps_mtx);
+		if(cap)
+		{
+			if(a2amd_capture_frames(cap) == w->size[0])
+				id = a2amd_wave_upload_captured(hs->ctxs[dev], (uint64_t)(uintptr_t)w, &d, cap);
+			if(getenv("A2AMD_WAVE_STATS"))
+				fprintf(stderr, "a2amd units: wave %p, %u frames rendered on the device: %s\n", (void *)w, a2amd_capture_frames(cap),
+						id >= 0 ? "device copy built from the capture" : "uploaded from the engine's copy");
+			a2amd_capture_free(cap);
+		}
+	}
+	if(id < 0)
+		id = a2amd_wave_upload(hs->ctxs[dev], (uint64_t)(uintptr_t)w, &d);
 	if(id < 0)
 	{
 		fail(hs, "a2amd_wave_upload", id);
@@ -2682,8 +2703,8 @@ int a2amd_units_vm_recall(const void *const *heads, unsigned n, void *const *vms
  * of it (the same interposition as the unit descriptors: the compiler's call, src/compiler.c:3359, and the
  * application's both bind here) only to note which state is the substate: that state's drop-in context keeps
  * what it renders in device memory (a2amd_capture_begin), and when the engine has made its wave, the device
- * builds ITS copy - samples, pads, mip levels, coefficient entries - from there (a2amd_wave_upload_captured)
- * and the wave registry takes it as uploaded.  The rendered samples travel device -> host once, for the
+ * builds ITS copy - samples, pads, mip levels, coefficient entries - from there (a2amd_wave_upload_captured; on the
+ * engine thread, when the wave is first played: wave_id_of) and the wave registry takes it as uploaded.  The rendered samples travel device -> host once, for the
  * engine's copy, and never back.  Waves with A2_NORMALIZE / A2_XFADE / A2_REVMIX, a substate on another GPU,
  * a state spread over several GPUs (A2AMD_DEVICES > 1): uploaded from the engine's copy on first use as
  * before (wave_id_of).  A2AMD_NO_RESIDENT=1 switches this off (A/B). */
@@ -2707,36 +2728,45 @@ int a2_RenderWave(void *iface, int wt, unsigned period, int flags, unsigned samp
 	rendering = outer;
 	if(rc.cap)
 	{
+		/* the capture waits, with the wave it belongs to, for the state's engine thread: the wave's device copy
+		 * is built at its first use (wave_id_of) */
 		A2P_wave *w = wh >= 0 ? a2_GetWave(iface, wh) : NULL;
 		HOSTSTATE *hs;
+		int kept = 0;
 		pthread_mutex_lock(&states_mtx);
 		for(hs = states; hs; hs = hs->next_state)
 			if(hs->refs && hs->cfg && hs->cfg->interface == iface)
 				break;
 		pthread_mutex_unlock(&states_mtx);
-		if(w && hs && !hs->failed && ctx_of(hs) && hs->ndev == 1 && (w->type == A2AMD_WWAVE || w->type == A2AMD_WMIPWAVE) &&
+		if(w && hs && hs->pendcaps_mtx_ok && (w->type == A2AMD_WWAVE || w->type == A2AMD_WMIPWAVE) &&
 				w->size[0] == a2amd_capture_frames(rc.cap))
 		{
-			a2amd_wavedesc d;
-			int l, id, levels = w->type == A2AMD_WMIPWAVE ? A2AMD_MIPLEVELS : 1;
-			memset(&d, 0, sizeof(d));
-			d.type = w->type;
-			d.flags = w->flags;
-			d.period = w->period;
-			for(l = 0; l < levels; ++l)
-				d.size[l] = w->size[l];
-			id = a2amd_wave_upload_captured(hs->ctxs[0], (uint64_t)(uintptr_t)w, &d, rc.cap);
-			if(id >= 0 && wave_registered(hs, w, 0, id) < 0)
-				a2amd_wave_drop(hs->ctxs[0], (uint64_t)(uintptr_t)w);
-			/* (id < 0: not a failure of the state - the wave goes up from the engine's copy on first use) */
-			if(getenv("A2AMD_WAVE_STATS"))
-				fprintf(stderr, "a2amd units: a2_RenderWave: wave %d, %u frames: %s\n", wh, a2amd_capture_frames(rc.cap),
-						id >= 0 ? "device copy built from the capture" : a2amd_last_error(hs->ctxs[0]));
+			pthread_mutex_lock(&hs->pendcaps_mtx);
+			if(hs->npendcaps == hs->cap_pendcaps)
+			{
+				int nc = hs->cap_pendcaps ? hs->cap_pendcaps * 2 : 16;
+				struct PENDCAP *np = (struct PENDCAP *)realloc(hs->pendcaps, nc * sizeof(*np));
+				if(np)
+				{
+					hs->pendcaps = np;
+					hs->cap_pendcaps = nc;
+				}
+			}
+			if(hs->npendcaps < hs->cap_pendcaps)
+			{
+				hs->pendcaps[hs->npendcaps].w = w;
+				hs->pendcaps[hs->npendcaps++].cap = rc.cap;
+				kept = 1;
+			}
+			pthread_mutex_unlock(&hs->pendcaps_mtx);
 		}
-		else if(getenv("A2AMD_WAVE_STATS"))
-			fprintf(stderr, "a2amd units: a2_RenderWave: wave %d (%p), capture of %u frames not used (state %p, %u samples)\n", wh,
-					(void *)w, a2amd_capture_frames(rc.cap), (void *)hs, w ? w->size[0] : 0);
-		a2amd_capture_free(rc.cap);
+		if(!kept)
+		{
+			if(getenv("A2AMD_WAVE_STATS"))
+				fprintf(stderr, "a2amd units: a2_RenderWave: wave %d (%p), capture of %u frames not used (state %p, %u samples)\n", wh,
+						(void *)w, a2amd_capture_frames(rc.cap), (void *)hs, w ? w->size[0] : 0);
+			a2amd_capture_free(rc.cap);
+		}
 	}
 	else if(getenv("A2AMD_WAVE_STATS"))
 		fprintf(stderr, "a2amd units: a2_RenderWave: wave %d, nothing captured (substate %p, armed %d)\n", wh, (void *)rc.sub, rc.armed);
