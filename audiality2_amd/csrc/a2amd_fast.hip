@@ -2167,6 +2167,9 @@ int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc
 // bus sums (configs[4]'s share, 32 768 voices on 128 buses: 2.42 -> 1.12 ms).
 #define FILT_MAXV   64
 #define FILT_PITCH  65
+#ifndef FILT_ROWAHEAD
+#define FILT_ROWAHEAD 1	// filt_row reads the next sixteen frames while it filters these sixteen
+#endif
 #ifndef FILT_WAVES
 #define FILT_WAVES  16	// wavefronts per workgroup: one filters, the others run the oscillators / pans.  (One
 			// workgroup of 16 per CU with 64 voices - every lane of the filter wavefront busy - since the
@@ -2216,6 +2219,31 @@ template<bool LPRAW, bool QREST>
 DEV void filt_row(int *row, int n, int ff, int lp, int bp, int hp, int &d1, int &d2, int &qv, int qdelta)
 {
 	if(n == A2D_FRAG) {
+#if FILT_ROWAHEAD
+		// (round 4: the next sixteen frames are on their way from the LDS while these sixteen are filtered -
+		// two register sets; before, each of a fragment's four groups waited out its own LDS round trip)
+		int xb[2][16];
+#pragma unroll
+		for(int k = 0; k < 16; ++k)
+			xb[0][k] = row[k];
+#pragma unroll
+		for(int g = 0; g < A2D_FRAG / 16; ++g) {
+			if(g + 1 < A2D_FRAG / 16) {
+#pragma unroll
+				for(int k = 0; k < 16; ++k)
+					xb[(g + 1) & 1][k] = row[(g + 1) * 16 + k];
+			}
+#pragma unroll
+			for(int k = 0; k < 16; ++k) {
+				xb[g & 1][k] = filt_step<LPRAW>(xb[g & 1][k], qv >> 12, ff, lp, bp, hp, d1, d2);
+				if(!QREST)
+					qv = wadd(qv, qdelta);
+			}
+#pragma unroll
+			for(int k = 0; k < 16; ++k)
+				row[g * 16 + k] = xb[g & 1][k];
+		}
+#else
 #pragma unroll 1
 		for(int s0 = 0; s0 < A2D_FRAG; s0 += 16) {
 			int x[16];
@@ -2232,6 +2260,7 @@ DEV void filt_row(int *row, int n, int ff, int lp, int bp, int hp, int &d1, int 
 			for(int k = 0; k < 16; ++k)
 				row[s0 + k] = x[k];
 		}
+#endif
 		return;
 	}
 	for(int s = 0; s < n; ++s) {
