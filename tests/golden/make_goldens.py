@@ -63,6 +63,22 @@ CASES = [
     ("k2loader", f"{REF}/benchmark/k2loader.a2s", "Song", 5 * 48000, []),
     ("k2trance", f"{REF}/benchmark/k2trance.a2s", "Song", 5 * 48000, []),
     ("pulsetronic", f"{REF}/benchmark/pulsetronic.a2s", "Song", 5 * 48000, []),
+    # the reference's test/data scripts (round 4; all 27 that start are soaked for 20 s by
+    # tests/measure/soak_long.py testdata): every mode of the env unit, ramps, events and messages,
+    # recursion, micro-tuning, noise phase, and one of its demo songs
+    ("td_envtest", f"{REF}/test/data/envtest.a2s", "Song", 5 * 48000, []),
+    ("td_envtest2", f"{REF}/test/data/envtest2.a2s", "Song", 5 * 48000, []),
+    ("td_envtest3", f"{REF}/test/data/envtest3.a2s", "Song", 5 * 48000, []),
+    ("td_envtest4", f"{REF}/test/data/envtest4.a2s", "Song", 5 * 48000, []),
+    ("td_pitchenvtest", f"{REF}/test/data/pitchenvtest.a2s", "Song", 5 * 48000, []),
+    ("td_ramptest", f"{REF}/test/data/ramptest.a2s", "Song", 5 * 48000, []),
+    ("td_ramptest2", f"{REF}/test/data/ramptest2.a2s", "Song", 5 * 48000, []),
+    ("td_ramptestenv", f"{REF}/test/data/ramptestenv.a2s", "Song", 5 * 48000, []),
+    ("td_evtest", f"{REF}/test/data/evtest.a2s", "Song", 5 * 48000, []),
+    ("td_recursetest", f"{REF}/test/data/recursetest.a2s", "Song", 5 * 48000, []),
+    ("td_microtonal", f"{REF}/test/data/microtonal.a2s", "Song", 5 * 48000, []),
+    ("td_noisephase", f"{REF}/test/data/noisephase.a2s", "Song", 5 * 48000, []),
+    ("td_evilnoises", f"{REF}/test/data/evilnoises.a2s", "Song", 5 * 48000, []),
 ]
 
 REALTIME_CASES = {"edge", "unload"}
@@ -88,7 +104,10 @@ def main():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
     tmp = "/tmp/a2amd_goldens"
     os.makedirs(tmp, exist_ok=True)
+    only = sys.argv[1:]        # (case names: just those, and not the dumps)
     for name, script, prog, frames, args in CASES:
+        if only and name not in only and not ("td" in only and name.startswith("td_")):
+            continue
         tr, pcm = f"{tmp}/{name}.trace", f"{tmp}/{name}.pcm"
         env = dict(os.environ)
         if name in REALTIME_CASES:
@@ -104,6 +123,8 @@ def main():
         np.save(f"{HERE}/{name}.hash.npy", fnv1a_fragments(audio))
         np.save(f"{HERE}/{name}.head.npy", audio[:, :4096])
         print(name, audio.shape, "peak", int(np.abs(audio).max()))
+    if only:
+        return
     subprocess.run([TOOLS, "dump", tmp], check=True)
     np.save(f"{HERE}/p2i_probe.npy", np.fromfile(f"{tmp}/p2i_probe.bin", dtype="<i4").reshape(-1, 2))
     raw = np.fromfile(f"{tmp}/builtin_waves.bin", dtype="<i2")

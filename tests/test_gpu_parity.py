@@ -13,7 +13,10 @@ from conftest import GOLDEN, ROOT, fnv1a_fragments, make_gpu, make_oracle, KNOWN
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["sustain", "filter", "delaybus", "scripted", "edge", "fm", "fmtest3", "fmtest4", "fx", "dctest", "wstest", "envwire", "unload", "k2intro", "k2intro44", "k2epilogue", "k2loader", "k2trance", "pulsetronic"]
+CASES = ["sustain", "filter", "delaybus", "scripted", "edge", "fm", "fmtest3", "fmtest4", "fx", "dctest", "wstest", "envwire", "unload", "k2intro", "k2intro44", "k2epilogue", "k2loader", "k2trance", "pulsetronic",
+         # the reference's own test/data scripts (make_goldens.py: td_*)
+         "td_envtest", "td_envtest2", "td_envtest3", "td_envtest4", "td_pitchenvtest", "td_ramptest", "td_ramptest2",
+         "td_ramptestenv", "td_evtest", "td_recursetest", "td_microtonal", "td_noisephase", "td_evilnoises"]
 
 
 def first_diff(a, b):
