@@ -916,9 +916,6 @@ DEV void osc_to_lanes(int (&so)[OV_NWORDS], const OscS &o, bool me)
 	WRL(so[OV_A + 2], o.a.delta); WRL(so[OV_A + 3], o.a.timer);
 }
 
-#ifndef OSC2_STAGGER
-#define OSC2_STAGGER 0
-#endif
 #ifndef OSC2_WPE
 #define OSC2_WPE 4	// (round 2: 3 wavefronts per SIMD with 143 registers and no spills beat 4 with 128 and 39 spills by a
 			// fifth.  Round 3: with only the settled loop's values parked in registers the kernel needs 118 -
@@ -952,12 +949,6 @@ void k_leaf_osc2pan(const A2DParams *__restrict__ pp, const int *__restrict__ li
 	// (the slices that exist; voices that still have something moving are dealt over
 	// them - slice s walks the whole batch for every nslices-th of them)
 	const int nslices = (nchunks + per - 1) / per;
-#if OSC2_STAGGER
-	// (experiment: the wavefronts of a SIMD run the same loop - ask for a voice's entries, wait, evaluate -
-	// and may do so in step; their slot number on the SIMD staggers where they start)
-	for(unsigned i = __builtin_amdgcn_s_getreg(6148) & 3u; i; --i)
-		__builtin_amdgcn_s_sleep(OSC2_STAGGER);
-#endif
 
 	int ffr[A2D_MAXBATCH / 64], fst[A2D_MAXBATCH / 64];
 #pragma unroll
