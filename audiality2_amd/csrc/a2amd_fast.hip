@@ -1421,6 +1421,83 @@ DEV int filt_window_s(FiltS &fs, int x, int off, int len, int lane)
 	return y;
 }
 
+// Round 4, last: the same window as a relaxation ALONG THE LANES (RECS_JFILT).  Frame s of the window
+// sits in lane s with its own input, cutoff and q; what it needs of frame s - 1 - d1 and d2, i.e. that
+// frame's b and l - it reads from lane s - 1 through the DPP wave shift, on the vector unit, every
+// lane at once.  One such step makes one more lane right: lane 0 takes the voice's state (the shift
+// has no source for it and leaves it alone), after step k lanes 0..k hold what f12_process
+// (filter12.c:97-118) computes for frames 0..k, and a lane that is right stays right, because its
+// left neighbour no longer changes.  len - 1 steps of 13 vector instructions (no v_readlane, no
+// v_writelane, no M0, the cutoff and q ramps in closed form per lane, the output sums once per
+// window with lane = frame) against 19 - 28 scalar ones per frame above; what the other lanes
+// compute in the meantime is thrown away, which costs a lone wavefront nothing.  A window that does
+// not begin at frame 0 is rotated to lane 0 and back (ds_bpermute).
+#ifndef RECS_JFILT
+#define RECS_JFILT 1
+#endif
+#define F12_JSTEP \
+	"s_nop 1\n\t" \
+	"v_mov_b32_dpp %[bsh], %[B] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+	"v_ashrrev_i32 %[ds], 4, %[bsh]\n\t" \
+	"v_mul_lo_u32 %[t1], %[F], %[ds]\n\t" \
+	"v_ashrrev_i32 %[t1], 8, %[t1]\n\t" \
+	"v_mul_lo_u32 %[t2], %[Q], %[ds]\n\t" \
+	"v_ashrrev_i32 %[t2], 8, %[t2]\n\t" \
+	"v_add_u32_dpp %[L], %[L], %[t1] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+	"v_sub_u32 %[H], %[X], %[L]\n\t" \
+	"v_sub_u32 %[H], %[H], %[t2]\n\t" \
+	"v_ashrrev_i32 %[t1], 4, %[H]\n\t" \
+	"v_mul_lo_u32 %[t1], %[F], %[t1]\n\t" \
+	"v_ashrrev_i32 %[t1], 8, %[t1]\n\t" \
+	"v_add_u32 %[B], %[t1], %[bsh]\n\t"
+DEV int filt_window_j(FiltS &fs, int x, int off, int len, int lane)
+{
+	const int f0 = fs.f1;
+	int df = 0, f1 = fs.f1;
+	ramp_prepare_s(fs.q, len);
+	if(fs.ramp) {		// the host ran the cutoff ramper and f12_pitch2coeff (R_F1RAMP)
+		f1 = fs.f1next;
+		df = rfl(wadd(wsub(f1, f0), len >> 1) / len);
+	}
+	const int qv = fs.q.value, qd = fs.q.delta;
+	const int d1i = fs.d1, d2i = fs.d2;
+	// lane = frame of the WINDOW
+	int xw = x;
+	if(off)
+		xw = __builtin_amdgcn_ds_bpermute(((lane + off) & 63) << 2, x);
+	const int X = xw >> 5;
+	const int F = wadd(f0, wmul(df, lane)) >> 12;
+	const int Q = wadd(qv, wmul(qd, lane)) >> 12;
+	// step 0: every lane from the voice's state - right for lane 0
+	const int ds0 = d1i >> 4;
+	int L = wadd(d2i, wmul(F, ds0) >> 8);
+	int H = wsub(wsub(X, L), wmul(Q, ds0) >> 8);
+	int B = wadd(wmul(F, H >> 4) >> 8, d1i);
+	int bsh = d1i;		// (lane 0 keeps this: d1 of the window's first frame)
+	int ds, t1, t2;
+	int n = len - 1;
+	for(; n > 4; n -= 8)
+		asm volatile(F12_JSTEP F12_JSTEP F12_JSTEP F12_JSTEP F12_JSTEP F12_JSTEP F12_JSTEP F12_JSTEP
+				: [bsh] "+v"(bsh), [L] "+v"(L), [B] "+v"(B), [H] "+v"(H), [ds] "=&v"(ds), [t1] "=&v"(t1), [t2] "=&v"(t2)
+				: [F] "v"(F), [Q] "v"(Q), [X] "v"(X));
+	if(n > 0)	// (steps past len - 1 change nothing)
+		asm volatile(F12_JSTEP F12_JSTEP F12_JSTEP F12_JSTEP
+				: [bsh] "+v"(bsh), [L] "+v"(L), [B] "+v"(B), [H] "+v"(H), [ds] "=&v"(ds), [t1] "=&v"(t1), [t2] "=&v"(t2)
+				: [F] "v"(F), [Q] "v"(Q), [X] "v"(X));
+	int yw = wmul(L, fs.lp);
+	if(fs.bp | fs.hp)
+		yw = wadd(wadd(yw, wmul(B, fs.bp)), wmul(H, fs.hp));
+	yw >>= 3;
+	fs.d1 = rdl(B, len - 1);
+	fs.d2 = rdl(L, len - 1);
+	fs.q.value = wadd(qv, wmul(qd, len));	// (= a2_RunRamper(&q, 1) per frame)
+	fs.f1 = f1;
+	fs.ramp = 0;
+	if(off)
+		yw = __builtin_amdgcn_ds_bpermute(((lane - off) & 63) << 2, yw);
+	return (unsigned)(lane - off) < (unsigned)len ? yw : x;
+}
+
 // Round 4: the filter of the records kernels with lane = VOICE.  filt_window_s above runs filter12's
 // recurrence on the scalar unit, a window at a time, in the middle of the voice's walk: ~20 scalar
 // instructions per frame and voice at the 5-7 cycles a lone scalar stream issues at - two thirds of
@@ -1460,7 +1537,7 @@ DEV RecQ rec_issue(const A2DRec *recs, int idx)
 }
 DEV RecQ rec_ready(RecQ r) { return r; }
 
-template<int NOSC, int FILT>
+template<int NOSC, int FILT, int VFT = 0>
 DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw, int gw,
 		const A2DVoice *__restrict__ voices, int *ustate, int *vactive,
 		const int16_t *__restrict__ wavepool, const A2DWave *__restrict__ waves,
@@ -1470,7 +1547,7 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 #ifdef RECS_PROF
 	const long long t_in = __builtin_readcyclecounter();
 	const unsigned long long rt_in = __builtin_amdgcn_s_memrealtime();
-	long long t_win = 0, t_rec = 0;
+	long long t_win = 0, t_rec = 0, t_osc = 0, t_flt = 0;
 	int n_win = 0, n_rec = 0;
 #endif
 	const A2DParams &p = *pp;
@@ -1478,7 +1555,10 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	const int lane = threadIdx.x & 63;
 	// (skip_empty bit 1: the launcher gave this launch the lane = voice filter, RECS_VFILT - worth it from a
 	// few voices per wavefront up; a song's one-voice wavefronts keep the scalar recurrence)
-	const bool VF = FILT && RECS_VFILT && (skip_empty & 2);
+	// (VFT, a kernel of its own: with both filters in one kernel the window filter's registers took
+	// k_leaf_recs<1, 1> from 127 to 132 vector registers - four wavefronts per SIMD to three - and a launch
+	// uses only one of the two)
+	constexpr bool VF = FILT && RECS_VFILT && VFT;
 	skip_empty &= 1;
 	const int first = gw * vpw;
 	// (a wavefront past the end of the list still meets the others at the barriers)
@@ -1765,8 +1845,17 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 						++pool_n;
 						WRL(wend, pool_n);
 					} else {
+#ifdef RECS_PROF
+					asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(x));
+					const long long w1 = __builtin_readcyclecounter();
+					t_osc += w1 - w0;
+#endif
 					if(FILT)
-						x = filt_window_s(fs, x, off, len, lane);
+						x = RECS_JFILT ? filt_window_j(fs, x, off, len, lane) : filt_window_s(fs, x, off, len, lane);
+#ifdef RECS_PROF
+					asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(x));
+					t_flt += __builtin_readcyclecounter() - w1;
+#endif
 					pan_fragment_s(vol, pan, x, len, fl, o0, o1);
 					}
 #ifdef RECS_PROF
@@ -1989,9 +2078,9 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 	}
 #ifdef RECS_PROF
 	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
-	if(nv > 0 && (blockIdx.x % 175) < 8 && lane == 0)
-		printf("k_leaf_recs<%d,%d> block %d wave %d: %d voices x %d fragments: prologue %lld, loop %lld (of which %d windows %lld, %d records, block sums %lld), epilogue %lld cycles; %llu ticks of 10 ns\n",
-				NOSC, FILT, (int)blockIdx.x, wv, nv, nfrags, t_pro - t_in, t_loop - t_pro, n_win, t_win, n_rec, t_rec,
+	if(nv > 0 && (FILT ? (blockIdx.x % 64) < 24 : (blockIdx.x % 175) < 2) && lane == 0)
+		printf("k_leaf_recs<%d,%d> block %d wave %d: %d voices x %d fragments: prologue %lld, loop %lld (of which %d windows %lld - oscillators %lld, filter %lld -, %d records, block sums %lld), epilogue %lld cycles; %llu ticks of 10 ns\n",
+				NOSC, FILT, (int)blockIdx.x, wv, nv, nfrags, t_pro - t_in, t_loop - t_pro, n_win, t_win, t_osc, t_flt, n_rec, t_rec,
 				(long long)__builtin_readcyclecounter() - t_loop, (unsigned long long)__builtin_amdgcn_s_memrealtime() - rt_in);
 #endif
 }
@@ -2002,7 +2091,7 @@ DEV void recs_body(const A2DParams *__restrict__ pp, const int *__restrict__ lis
 #else
 #define RECS_ATTR
 #endif
-template<int NOSC, int FILT>
+template<int NOSC, int FILT, int VFT = 0>
 __global__ __launch_bounds__(64 * RECS_WPB) RECS_ATTR
 void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpw,
 		const A2DVoice *__restrict__ voices, int *ustate, int *vactive,
@@ -2011,7 +2100,7 @@ void k_leaf_recs(const A2DParams *__restrict__ pp, const int *__restrict__ list,
 {
 	__shared__ RecsPart part[2];
 	__shared__ int part_off[2][RECS_WPB], part_nch[2][RECS_WPB];
-	recs_body<NOSC, FILT>(pp, list, nlist, vpw, (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), voices, ustate, vactive,
+	recs_body<NOSC, FILT, VFT>(pp, list, nlist, vpw, (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), voices, ustate, vactive,
 			wavepool, waves, ptab, busmem, part, part_off, part_nch, skip_empty);
 }
 
@@ -2113,8 +2202,6 @@ int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc
 	const int nwaves = (nlist + vpw - 1) / vpw;
 	int wpb = recs_wpb(nwaves);
 	size_t dyn = 0;
-	if(vf)
-		skip_empty |= 2;
 	if(vf) {
 		// the workgroup's static 32 KB (bus sums) + its wavefronts' rows and pools within 64 KB
 		const size_t per_wave = (size_t)recs_wave_words_host(vpw) * sizeof(int);
@@ -2122,13 +2209,21 @@ int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc
 		dyn = wpb * per_wave;
 	}
 	const int nblocks = (nwaves + wpb - 1) / wpb;
-#define RECS_LAUNCH(N, F) hipLaunchKernelGGL((k_leaf_recs<N, F>), dim3(nblocks), dim3(64 * wpb), dyn, \
+#define RECS_LAUNCH(N, F) hipLaunchKernelGGL((k_leaf_recs<N, F, 0>), dim3(nblocks), dim3(64 * wpb), dyn, \
 		(hipStream_t)stream, dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.vactive, hp.wavepool, \
 		hp.waves, hp.ptab, hp.busmem, skip_empty)
 	if(nosc == 1 && !filt)
 		RECS_LAUNCH(1, 0);
 	else if(nosc == 2 && !filt)
 		RECS_LAUNCH(2, 0);
+	else if(nosc == 1 && !vf)
+		RECS_LAUNCH(1, 1);
+	else if(!vf)
+		RECS_LAUNCH(2, 1);
+#undef RECS_LAUNCH
+#define RECS_LAUNCH(N, F) hipLaunchKernelGGL((k_leaf_recs<N, F, 1>), dim3(nblocks), dim3(64 * wpb), dyn, \
+		(hipStream_t)stream, dparams, dlist, nlist, vpw, hp.voices, hp.ustate, hp.vactive, hp.wavepool, \
+		hp.waves, hp.ptab, hp.busmem, skip_empty)
 	else if(nosc == 1)
 		RECS_LAUNCH(1, 1);
 	else
