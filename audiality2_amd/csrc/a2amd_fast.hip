@@ -2190,11 +2190,14 @@ int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc
 	// more the launch gets 4-8 voices per wavefront (fewer, fatter wavefronts: the scalar walk of a voice
 	// is latency, the recurrence 12 vector instructions per frame for all of a wavefront's voices).
 	// (measured, 64 fragments of voices with a split window and a pitch ramp in every second fragment: 16 384
-	// voices 3.46 -> 2.24 ms, 65 536: 13.5 -> 10.0; 4 096: 0.99 -> 1.36 - hence the threshold.  A2AMD_VFILT=0 / 1
+	// voices 3.46 -> 2.24 ms, 65 536: 13.5 -> 10.0; 4 096: 0.99 -> 1.36.  Against the window filter along the
+	// lanes (RECS_JFILT, the end of round 4) the margin is thinner - 12 288 voices 2.02 (window filter) / 2.17 ms,
+	// 16 384: 2.58 / 2.21, 32 768: 4.97 / 5.00, 65 536: 9.7 with it; two oscillators 16 384: 4.29 / 3.88,
+	// 32 768: 8.24 / 6.58 (profiles/r04_jfilt_ab.txt) - hence the threshold.  A2AMD_VFILT=0 / 1
 	// forces it off / on: A/B measurements, and the tests run the path at sizes an oracle can follow.)
 	const char *fv = getenv("A2AMD_VFILT");
 	const int force_vf = fv ? atoi(fv) : -1;
-	const bool vf = filt && RECS_VFILT && (force_vf >= 0 ? force_vf != 0 : nlist >= 12288);
+	const bool vf = filt && RECS_VFILT && (force_vf >= 0 ? force_vf != 0 : nlist >= 16384);
 	if(vf && !getenv("A2AMD_RVPW"))
 		vpw = min(max((nlist + 4095) / 4096, 4), 8);
 	if(vf)

@@ -401,7 +401,7 @@ def test_wavetable_leaf_kernel_executes_records(oracle_lib, monkeypatch, chain, 
 @pytest.mark.parametrize("chain,groups", [("osc-filter-pan", 0), ("osc-filter-pan", 2), ("osc2-filter-pan", 3)])
 @pytest.mark.parametrize("rvpw", [1, 3, 4, 16])
 def test_records_kernel_filter_with_lane_per_voice(oracle_lib, monkeypatch, chain, groups, rvpw):
-    """RECS_VFILT (round 4): above 12 288 voices the records kernels run filter12's recurrence with lane =
+    """RECS_VFILT (round 4): from 16 384 voices up the records kernels run filter12's recurrence with lane =
     voice - the walk lists each window's filter and pan parameters, the recurrence runs over rows in LDS,
     the pan stage reads them back.  Forced on here (A2AMD_VFILT=1) at sizes the oracle follows: the same
     random script of writes, ramps, cutoff sets and sweeps, q ramps, mix changes, births and deaths, with 1,
