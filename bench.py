@@ -832,6 +832,12 @@ def main():
     # timing barriers the bench contract asks for.
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    # The contract line is to be the ONLY thing on stdout: RCCL writes a version banner to fd 1 through C
+    # stdio when its first communicator comes up - until the line is printed, fd 1 is stderr.
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     dist.init_process_group("nccl", rank=rank, world_size=world,
                             device_id=torch.device("cuda", local_rank))
     # barrier = a (pre-warmed) 1-element all-reduce every rank must join, with the
@@ -948,10 +954,11 @@ def main():
         # (one rank's share of the job on this box's host cores; the other ranks are done)
         line["cpu_baseline"] = cpu_baseline(cfg["voices"], cfg["chain"], cfg["groups"])
         line["cpu_baseline"]["sample"] += "; one rank's share of the job (%d of %d voices)" % (cfg["voices"], cfg["voices"] * world)
-    # The contract line is the LAST thing on stdout: RCCL writes a version banner
-    # through C stdio, which sits in libc's buffer until it is flushed.
+    # (what sat in libc's buffer goes where fd 1 points now - stderr - before stdout is put back)
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(line), flush=True)
 

@@ -40,17 +40,19 @@ def test_bench_prints_one_contract_line():
 
 
 @pytest.mark.gpu
-def test_bench_line_is_last_on_stdout_under_torchrun():
+def test_bench_line_is_alone_on_stdout_under_torchrun():
     """The driver launches N>1 through torch.distributed.run; RCCL writes a version
-    banner to stdout through C stdio.  The contract line must still be the last
-    line rank 0 prints."""
+    banner to fd 1 through C stdio.  The contract line must be the ONLY line on
+    stdout (bench.py points fd 1 at stderr until it prints it)."""
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
                         "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--config", "1"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT,
                        env=dict(os.environ, A2AMD_BENCH_FORCE_DIST="1"))
     assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, lines[:-1]
+    d = json.loads(lines[0])
     assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["value"] > 0
 
 
