@@ -1933,8 +1933,16 @@ static void env_run(A2P_unit *u, unsigned offset, unsigned frames)
 	ramper_prepare(e->ramper, (int)frames);
 	e->ramper[0] = wadd(e->ramper[0], wmul(e->ramper[2], (int)frames));
 	i = (uint32_t)(e->ramper[0] >> (24 - 6));
-	if(i > ENV_LUTSIZE)
-		i = ENV_LUTSIZE;	/* (never: the unity ramp stays inside the table) */
+	/* A re-targeted unity ramp can overshoot 1.0 by a window's worth: the engine then reads on past the
+	 * table's two pad entries - into the NEXT table of its one malloc'ed array of eight (env.c:32-35, 259),
+	 * which is how env_luts is laid out too, so the same words come back (found by the differential fuzzer,
+	 * seed 3779).  Past the last table the engine reads its heap (or crashes: a negative ramp value is a
+	 * huge index); that nobody can follow, and the index stays in the array. */
+	{
+		const uint32_t imax = (uint32_t)(8 - (e->lut & 7)) * (ENV_LUTSIZE + 2) - 2;
+		if(i > imax)
+			i = imax;
+	}
 	f = (uint32_t)(e->ramper[0] >> (24 - 16 - 6)) & 65535u;
 	e->out = (int32_t)((f * (uint32_t)t[i + 1] + (65536u - f) * (uint32_t)t[i]) >> 7);
 	e->out = wadd((int32_t)(((int64_t)e->out * e->scale) >> 24), e->offset);

@@ -216,8 +216,13 @@ VMFN void env_lut(const Consts &K, A2DVmEnv &en, int frames)
 	rp_prepare(en.ramper, frames);
 	rp_run(en.ramper, frames);
 	uint32_t i = (uint32_t)(en.ramper[0] >> (24 - A2D_ENV_LUTSHIFT));
-	if(i > A2D_ENV_LUTSIZE)		// (never: the unity ramp stays inside the table)
-		i = A2D_ENV_LUTSIZE;
+	// A re-targeted unity ramp can overshoot 1.0 by a window's worth: the engine then reads on past the table's
+	// two pad entries - into the NEXT table of its one malloc'ed array of eight (env.c:32-35, 259), which is
+	// how ours is laid out too, so the same words come back.  Past the last table it reads the heap (or
+	// crashes: a negative ramp value is a huge index); that nobody can follow, and the index stays in the array.
+	const uint32_t imax = (uint32_t)(A2D_ENV_LUTS - en.lut) * (A2D_ENV_LUTSIZE + 2) - 2;
+	if(i > imax)
+		i = imax;
 	const uint32_t f = (uint32_t)(en.ramper[0] >> (24 - 16 - A2D_ENV_LUTSHIFT)) & 65535u;
 	// (as the engine computes it: unsigned 32 bit products, then int)
 	en.out = (int)((f * (uint32_t)t[i + 1] + (65536u - f) * (uint32_t)t[i]) >> 7);
