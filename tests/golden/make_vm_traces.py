@@ -30,7 +30,9 @@ CASES = [("vmloops", "Lfo", [-1, .08, -.5], 20), ("vmloops", "Lfo", [.37, .05, .
          ("envtrace", "Front", [-1, .08, 4, -3], 0), ("envtrace", "Front", [-.2, .08, -1, -1], 0),
          ("envtrace", "Front", [.4, .08, 8, -8], 0), ("envtrace", "Front", [.9, .08, -2, 7], 0),
          ("envtrace", "Behind", [-.5, .08, 5], 0), ("envtrace", "Behind", [.2, .08, 1], 0), ("envtrace", "Timed", [0, .08], 0),
-         ("envtrace", "Two", [-.7, .08], 0), ("envtrace", "Siren", [-1.2, .08], 0), ("envtrace", "Plain", [.6, .08], 0)]
+         ("envtrace", "Two", [-.7, .08], 0), ("envtrace", "Siren", [-1.2, .08], 0), ("envtrace", "Plain", [.6, .08], 0),
+         # a table look-up that runs past the table's end into the next one (round 4's soak, fuzz seed 3779)
+         ("envtrace", "Short", [-.5, .08], 0)]
 
 if __name__ == "__main__":
     out = []

@@ -321,11 +321,12 @@ def env_tables():
     return (ctypes.c_uint16 * (8 * 66))(*[v for row in t for v in row])
 
 
-@pytest.mark.parametrize("case", range(22))
+@pytest.mark.parametrize("case", range(23))
 def test_host_interpreter_against_the_reference_vm(case):
     """tests/golden/vm_traces.json.xz (made by tests/golden/make_vm_traces.py from oracle/ref_vmtrace.c: the COMPILED
     REFERENCE's own VM running each looping voice of vmloops.a2s - and, cases 12 on, of envtrace.a2s: voices with env
-    units in every table mode, in front of and behind what they drive, with 'time' overrides, two on one voice - for 600
+    units in every table mode, in front of and behind what they drive, with 'time' overrides, two on one voice, and
+    (case 22, 'Short') a table look-up that runs past its table's end into the engine's next table - for 600
     fragments, every unit register write, every window and the root voice's windows logged).  The host copy of the
     device VM's interpreter - the header the kernel is compiled from - takes over at the same moment (program text,
     A2_vmstate, register wiring, env placement, engine clock, the engine's fragments as the root voice cut them) and
