@@ -1,4 +1,5 @@
 """Build recipes: liba2amd.so (hipcc, gfx950) and the test oracle (gcc)."""
+import hashlib
 import os
 import shutil
 import subprocess
@@ -8,11 +9,42 @@ ROOT = os.path.dirname(HERE)
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def _newer(target, sources):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources)
+MARK = b"A2AMD_SRCHASH:"
+
+
+def source_hash(sources, cmd=()):
+    """sha256 over the CONTENTS of everything a library is built from (+ its recipe): the
+    stamp compiled into the library (`a2amd_srchash`, `-DA2AMD_SRCHASH`), so that a stale
+    binary is found by what it was made of, not by file times (which a checkout, a copy to
+    the GPU box or a touch changes)."""
+    h = hashlib.sha256()
+    for s in sources:
+        h.update(os.path.basename(s).encode() + b"\0")
+        with open(s, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    h.update(" ".join(cmd).encode())
+    return h.hexdigest()[:32]
+
+
+def stamped_hash(lib):
+    """the stamp a built library carries (None: no library, or one from before the stamps)"""
+    if not os.path.exists(lib):
+        return None
+    with open(lib, "rb") as f:
+        blob = f.read()
+    i = blob.find(MARK)
+    if i < 0:
+        return None
+    return blob[i + len(MARK):i + len(MARK) + 32].decode("ascii", "replace")
+
+
+def _stale(target, want):
+    return stamped_hash(target) != want
+
+
+def _define(h):
+    return '-DA2AMD_SRCHASH="%s"' % h
 
 
 def build_lib(force=False):
@@ -23,10 +55,10 @@ def build_lib(force=False):
                    os.path.join(csrc, "a2amd_fm.h"), os.path.join(csrc, "a2amd_vmcore.h"), os.path.join(ROOT, "include", "a2amd.h"),
                    os.path.join(ROOT, "include", "a2amd_vm.h")]
     out = os.path.join(HERE, "liba2amd.so")
-    if force or _newer(out, deps):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-Wno-unused-value", "-o", out] + srcs
-        subprocess.run(cmd, check=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+    want = source_hash(deps, flags)
+    if force or _stale(out, want):
+        subprocess.run([HIPCC] + flags + [_define(want), "-o", out] + srcs, check=True)
     return out
 
 
@@ -36,8 +68,10 @@ def build_units(force=False):
     deps = [src, os.path.join(ROOT, "include", "a2amd.h"), os.path.join(ROOT, "include", "a2amd_plugin.h"),
             os.path.join(ROOT, "include", "a2amd_walk.h"), os.path.join(ROOT, "include", "a2amd_vm.h")]
     out = os.path.join(HERE, "liba2amd_units.so")
-    if force or _newer(out, deps):
-        subprocess.run(["gcc", "-O2", "-Wall", "-fPIC", "-shared", "-o", out, src,
+    flags = ["-O2", "-Wall", "-fPIC", "-shared"]
+    want = source_hash(deps, flags)
+    if force or _stale(out, want):
+        subprocess.run(["gcc"] + flags + [_define(want), "-o", out, src,
                         "-L" + HERE, "-la2amd", "-ldl", "-lpthread", "-lm", "-Wl,-rpath,$ORIGIN"], check=True)
     return out
 
@@ -49,18 +83,23 @@ def build_walk(force=False, engine=None):
     that engine version; elsewhere the library built before travels as it is."""
     engine = engine or os.environ.get("A2_ENGINE_SRC", "/root/reference")
     out = os.path.join(HERE, "liba2amd_walk.so")
-    if not (os.path.exists(os.path.join(engine, "src", "internals.h")) and shutil.which("cmake")):
-        return out if os.path.exists(out) else None
     src = os.path.join(HERE, "csrc", "a2amd_walk.c")
+    # the stamp covers OUR sources only: the engine's headers are not on the GPU box, and a
+    # library made for another engine version is the maintainer's to rebuild (INTEGRATION.md C)
+    own = [src, os.path.join(ROOT, "include", "a2amd_walk.h"), os.path.join(ROOT, "include", "a2amd_vm.h"),
+           os.path.join(ROOT, "include", "a2amd_plugin.h")]
+    flags = ["-O2", "-Wall", "-fPIC", "-shared"]
+    want = source_hash(own, flags)
+    if not (os.path.exists(os.path.join(engine, "src", "internals.h")) and shutil.which("cmake")):
+        if os.path.exists(out) and _stale(out, want):
+            raise RuntimeError(f"{out} was not built from this tree's a2amd_walk.c (stamp {stamped_hash(out)}, "
+                               f"sources {want}) and the engine's source tree ({engine}) is not here to rebuild it")
+        return out if os.path.exists(out) else None
     inc = os.path.join(HERE, "_engine_include")
-    deps = [src, os.path.join(ROOT, "include", "a2amd_walk.h"), os.path.join(ROOT, "include", "a2amd_vm.h"),
-            os.path.join(HERE, "liba2amd_units.so")] + \
-           [os.path.join(engine, "src", f) for f in ("internals.h", "config.h")] + \
-           [os.path.join(engine, "include", f) for f in ("a2_vm.h", "a2_units.h", "audiality2.h.cmake")]
-    if force or _newer(out, deps):
+    if force or _stale(out, want):
         subprocess.run(["cmake", f"-DENGINE={engine}", f"-DOUT={inc}", "-P", os.path.join(HERE, "csrc", "engine_header.cmake")],
                        check=True, stdout=subprocess.DEVNULL)
-        subprocess.run(["gcc", "-O2", "-Wall", "-fPIC", "-shared", "-I" + inc] +
+        subprocess.run(["gcc"] + flags + [_define(want), "-I" + inc] +
                        ["-I" + os.path.join(engine, d) for d in ("include", "src", "src/units", "src/drivers")] +
                        ["-o", out, src, "-L" + HERE, "-la2amd_units", "-la2amd", "-ldl", "-lpthread", "-Wl,-rpath,$ORIGIN"],
                        check=True)

@@ -23,6 +23,10 @@ namespace a2h { thread_local char g_err[256] = ""; }
 extern "C" {
 
 const char *a2amd_version(void) { return "a2amd 0.1 (gfx950)"; }
+#ifndef A2AMD_SRCHASH
+#define A2AMD_SRCHASH "unstamped"
+#endif
+const char *a2amd_source_stamp(void) { return "A2AMD_SRCHASH:" A2AMD_SRCHASH; }
 
 const char *a2amd_last_error(const a2amd_ctx *c) { return c ? c->err : g_err; }
 

@@ -2652,8 +2652,11 @@ int a2amd_units_vm_recall(const void *const *heads, unsigned n, void *const *vms
 		HOSTSTATE *hs = NULL;
 		for(k = 0; k <= n; ++k)
 		{
-			XTRA *x = k < n ? (XTRA *)((char *)past_envs((const A2P_unit *)heads[k]) + 64) : NULL;
-			if(x && (!x->vm || x->dev != d))
+			/* a head is trusted only after the checks a2amd_units_vm_is() makes: the caller's note
+			 * that a voice is the device VM's may be older than the voice (addresses are reused) */
+			XTRA *x = k < n && a2amd_units_vm_is(heads[k]) ?
+					(XTRA *)((char *)past_envs((const A2P_unit *)heads[k]) + 64) : NULL;
+			if(k < n && (!x || x->dev != d))
 				continue;
 			if(x)
 			{
@@ -2780,3 +2783,8 @@ int a2_RenderWave(void *iface, int wt, unsigned period, int flags, unsigned samp
 		fprintf(stderr, "a2amd units: a2_RenderWave: wave %d, nothing captured (substate %p, armed %d)\n", wh, (void *)rc.sub, rc.armed);
 	return wh;
 }
+
+#ifndef A2AMD_SRCHASH
+#define A2AMD_SRCHASH "unstamped"
+#endif
+const char *a2amd_units_source_stamp(void) { return "A2AMD_SRCHASH:" A2AMD_SRCHASH; }

@@ -621,12 +621,18 @@ static void recall_run(WSTATE *w, LIST *l, unsigned k, A2_voice *v, unsigned run
 	for(p = v, kk = 0; kk < run && p; p = p->next, ++kk)
 	{
 		int is_vm;
-		if(k + kk < l->n && l->e[k + kk].v == p)
-			is_vm = (l->e[k + kk].flags & E_VM) != 0;
+		if(k + kk < l->n && l->e[k + kk].v == p && !(l->e[k + kk].flags & E_VM))
+			is_vm = 0;	/* (the common case: one remembered flag, the voice is not read) */
 		else
-			is_vm = p->units && a2amd_units_vm_is(p->units);	/* (a list that is not the one remembered) */
+			/* a remembered E_VM is a hint only - the entry may be older than the voice at this
+			 * address (a freed subtree, a reused A2_voice) - so the units are asked */
+			is_vm = p->units && a2amd_units_vm_is(p->units);
 		if(!is_vm)
+		{
+			if(k + kk < l->n && l->e[k + kk].v == p)
+				l->e[k + kk].flags &= ~E_VM;
 			continue;
+		}
 		if(k + kk < l->n && l->e[k + kk].v == p)
 			l->e[k + kk].flags &= ~E_VM;
 		heads[n] = p->units;
@@ -940,3 +946,8 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 		l->epoch = l->n == k ? w->epoch : w->epoch - 1;
 	}
 }
+
+#ifndef A2AMD_SRCHASH
+#define A2AMD_SRCHASH "unstamped"
+#endif
+const char *a2amd_walk_source_stamp(void) { return "A2AMD_SRCHASH:" A2AMD_SRCHASH; }

@@ -135,6 +135,10 @@ int  a2amd_open(const a2amd_config *cfg, a2amd_ctx **out);
 void a2amd_close(a2amd_ctx *ctx);
 const char *a2amd_last_error(const a2amd_ctx *ctx);   /* ctx may be NULL */
 const char *a2amd_version(void);
+/* "A2AMD_SRCHASH:<32 hex>": hash of the sources this library was built from (the build recipe
+ * compares it with the tree, audiality2_amd/build.py; liba2amd_units.so and liba2amd_walk.so
+ * carry the same kind of stamp). */
+const char *a2amd_source_stamp(void);
 /* Number of HIP devices a2amd_config.device may name (0 without a GPU). */
 int  a2amd_device_count(void);
 

@@ -65,6 +65,9 @@ int a2amd_units_hold(void *state, unsigned dev, const uint32_t *slots, unsigned 
  * program from this pc: outside the subset), -2 (not now). */
 int a2amd_units_vm_adopt(const void *head, const uint32_t *code, unsigned nwords, const void *vmstate,
 		void *const *wr_unit, void *const *wr_fn, uint32_t now, uint32_t msdur);
+/* build stamps ("A2AMD_SRCHASH:<32 hex>", see a2amd_source_stamp() in a2amd.h) */
+const char *a2amd_units_source_stamp(void);
+const char *a2amd_walk_source_stamp(void);
 /* 1 when the voice is the device VM's. */
 int a2amd_units_vm_is(const void *head);
 /* The engine is about to process these n voices again: vmstates[k] (A2_vmstate *) receives what the

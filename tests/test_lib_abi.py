@@ -50,7 +50,7 @@ def test_walk_and_units_libraries_export_their_interface():
 def test_oracle_mirrors_the_call_protocol(oracle_lib):
     for s in declared_symbols():
         o = s.replace("a2amd_", "a2o_")
-        if s in ("a2amd_version", "a2amd_device_count", "a2amd_rootbus", "a2amd_rootbus_copy", "a2amd_get_stats", "a2amd_set_profiling",
+        if s in ("a2amd_version", "a2amd_source_stamp", "a2amd_device_count", "a2amd_rootbus", "a2amd_rootbus_copy", "a2amd_get_stats", "a2amd_set_profiling",
                  "a2amd_replay", "a2amd_collect", "a2amd_fragment_offset", "a2amd_capture_begin", "a2amd_capture_end", "a2amd_capture_frames", "a2amd_capture_free", "a2amd_wave_upload_captured", "a2amd_wave_stats", "a2amd_voice_process", "a2amd_voice_slot", "a2amd_voice_markable", "a2amd_default_hold", "a2amd_default_release_all", "a2amd_default_map", "a2amd_dist_unique_id", "a2amd_dist_init", "a2amd_dist_init_local", "a2amd_render_group", "a2amd_unit_insertable", "a2amd_unit_insert", "a2amd_render_paused"):
             continue
         assert hasattr(oracle_lib, o), f"oracle lacks {o}"
@@ -74,3 +74,22 @@ def test_product_does_not_link_the_oracle():
                 text = open(os.path.join(dirpath, fn), errors="replace").read()
                 assert "a2o_" not in text, fn
                 assert "liba2oracle" not in text and "oracle/" not in text.replace("oracle/_ref", ""), fn
+
+
+def test_built_libraries_are_stamped_with_their_sources(gpu_lib):
+    """build() decides by a hash of the sources compiled into each library (not by file times):
+    the libraries in the tree must carry the stamp of the tree."""
+    from audiality2_amd import build as b
+    lib = os.path.join(ROOT, "audiality2_amd", "liba2amd.so")
+    gpu_lib.a2amd_source_stamp.restype = ctypes.c_char_p
+    stamp = gpu_lib.a2amd_source_stamp().decode()
+    assert stamp.startswith("A2AMD_SRCHASH:") and stamp[14:] == b.stamped_hash(lib)
+    assert b.build_lib() == lib and b.stamped_hash(lib) == stamp[14:]      # (nothing to rebuild)
+    for name in ("liba2amd_units.so", "liba2amd_walk.so"):
+        p = os.path.join(ROOT, "audiality2_amd", name)
+        if os.path.exists(p):
+            assert b.stamped_hash(p), f"{name} carries no source stamp"
+    # a stale walk library is refused where it cannot be rebuilt
+    walk = os.path.join(ROOT, "audiality2_amd", "liba2amd_walk.so")
+    if os.path.exists(walk):
+        assert b.build_walk(engine="/nonexistent") == walk

@@ -72,7 +72,7 @@ def extract(so=SO):
     try:
         dst = os.path.join(tmp, "lib.so")
         shutil.copy(so, dst)
-        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", dst], check=True, capture_output=True)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", dst], check=True, capture_output=True, cwd=tmp)
         funcs = []
         for fn in sorted(os.listdir(tmp)):
             if "gfx950" not in fn:
