@@ -117,6 +117,7 @@ struct A2DRun { int32_t first, count; };
 // (core.c:143-149) sends each VM register, and the cutoff rampers of the voice's filter12 units,
 // which for host-driven voices never leave the host (a2amd_host.h: HUnit::cutoff).
 #define A2D_VM_NOWRITE 0xffu
+#define A2D_VM_TRAPWRITE 0xfeu		// cmap: wired to something the device VM cannot write - the voice leaves before it would
 #define A2D_VM_MAXCUT  2
 #define A2D_VM_MAXENV  2
 #define A2D_VM_ENVPOS  14		// cmap chain position that stands for "the target register of env unit <register nibble>"
@@ -251,6 +252,16 @@ int a2d_launch_leaf_osc2pan(const A2DParams *dparams, const A2DParams &hp, const
 // without any this batch are rendered by their class's quiet kernel
 int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc, int filt, const int *dlist,
 		int nlist, int vpw, void *stream, int skip_empty = 0);
+// Round 5 (a2amd_win.hip): the same voices in two passes.  The control pass (lane = voice) walks the
+// records of fragments [fa, fb) and leaves one closed-form entry of A2D_WIN_WORDS words per window
+// in 'win' (entry indices from the pool counter wtop[0], at most wcap; wtop[1] != 0: the pool was
+// too small) and, per fragment and list position, where the voice's entries begin: widx[(f - fa) *
+// nlist + i], f = fa .. fb.  The render pass (lane = frame) evaluates the entries.
+#define A2D_WIN_WORDS 24
+int a2d_launch_win_ctl(const A2DParams *dparams, const A2DParams &hp, int nosc, int filt, const int *dlist, int nlist,
+		int skip_empty, int fa, int fb, int *win, unsigned *widx, unsigned *wtop, unsigned wcap, void *stream);
+int a2d_launch_win_render(const A2DParams &hp, int nosc, int filt, const int *dlist, int nlist, int fa, int fb,
+		const int *win, const unsigned *widx, void *stream);
 // ... all four kinds in one launch: lists[k] / counts[k] for (nosc, filt) = (1,0) (2,0) (1,1) (2,1)
 int a2d_launch_leaf_recs_all(const A2DParams *dparams, const A2DParams &hp, const int *const *lists, const int *counts,
 		int vpw, void *stream);

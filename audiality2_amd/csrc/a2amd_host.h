@@ -234,6 +234,8 @@ struct HVm {
 	bool fresh = false;		// carried to the end of its first batch and sent up: the kernel runs it from the next batch on
 	int voice = -1, prog = -1;
 	uint8_t func = 0;
+	bool has_exit = false;		// taken for a stretch only (vm_lookahead): the engine wants it back ...
+	uint32_t exit_when = 0;		// ... in the fragment that holds this engine time
 	A2DVmVoice st;			// pending: the state; else stale (the device's is the authority)
 };
 struct VmHost {
@@ -277,6 +279,7 @@ struct VmHost {
 	uint16_t *d_envlut = nullptr;
 	bool envlut_up = false;
 	uint32_t *d_total = nullptr, *h_total = nullptr;	// {records, faults}; pinned
+	uint32_t last_total = 0;	// records the count pass of this batch found
 	A2DVmVoice *h_stage = nullptr;	// pinned staging for recalls
 	size_t h_stage_cap = 0;
 };
@@ -459,6 +462,12 @@ struct a2amd_ctx {
 	int dist_rank = 0, dist_ranks = 1;
 	bool dist_local = false;	// one of several contexts of this process (a2amd_dist_init_local)
 	hipEvent_t grp_ev = nullptr;	// ... its SUBTREES phase is done / its partial has been taken
+
+	// the window kernels (a2amd_win.hip): the entries of a slab of the batch, where each voice's begin
+	// per fragment, the pool counter + overflow flag
+	DevBuf<int> d_win;
+	DevBuf<unsigned> d_widx;
+	unsigned *d_wtop = nullptr;
 
 	a2amd_stats stats;
 	VmHost vm;

@@ -935,6 +935,85 @@ bool depth_has_mutes(const a2amd_ctx *c, int d)
 }
 
 // the kernels of one batch, in stream order; e* may be null
+// The wavetable leaf voices that carry records this batch - the four host-made class lists (wtosc |
+// 2 x wtosc [-> filter12] -> panmix; the last one with its quiet voices) and the three lists of voices
+// whose records the device VM has just written - through the window kernels (a2amd_win.hip): per slab
+// of the batch the control pass of every list, then the render pass of every list.  The entry pool is
+// sized by the bound the control pass allocates by (a window per fragment and voice + one per record);
+// a batch whose entries would not fit A2AMD_WIN_MB (1 024) is cut into slabs of fragments.
+static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *counts)
+{
+	struct Job { int nosc, filt, n, skip; const int *list; };
+	static const int nosc[4] = { 1, 2, 1, 2 }, filt[4] = { 0, 0, 1, 1 };
+	Job jobs[7];
+	int nj = 0;
+	size_t nvoices = 0;
+	for(int k = 0; k < 4; ++k)
+		if(counts[k]) {
+			jobs[nj++] = Job{ nosc[k], filt[k], counts[k], 0, lists[k] };
+			nvoices += (size_t)counts[k];
+		}
+	size_t nrec = c->up_recs.size();
+	if(!c->vm.list.empty()) {
+		const int *l = c->vm.d_list.d + c->vm.list.size();
+		for(int k = 0; k < 3; l += c->vm.n_cls[k++])
+			if(c->vm.n_cls[k]) {
+				jobs[nj++] = Job{ nosc[k], filt[k], c->vm.n_cls[k], 1, l };
+				nvoices += (size_t)c->vm.n_cls[k];
+			}
+		nrec += c->vm.last_total;
+	}
+	if(!nj)
+		return 0;
+	static const size_t budget = (size_t)(getenv("A2AMD_WIN_MB") ? atoi(getenv("A2AMD_WIN_MB")) : 1024) * (1u << 20) /
+			(A2D_WIN_WORDS * sizeof(int));
+	const int nfrags = c->nfrags;
+	int per = nfrags;
+	if(nvoices * (size_t)nfrags + nrec > budget)
+		per = (int)std::min<size_t>((size_t)nfrags, std::max<size_t>(1, (budget > nrec ? budget - nrec : 1) / nvoices));
+	const size_t cap = nvoices * (size_t)per + nrec;
+	if(cap >= ((size_t)1 << 32))
+		return c->fail(A2AMD_EUNSUPPORTED, "a batch of %zu windows", cap);
+	if(cap > c->d_win.cap || nvoices * (size_t)(per + 1) > c->d_widx.cap || !c->d_wtop) {
+		if(c->capturing)
+			return c->fail(A2AMD_ESTATE, "window pool too small inside a graph capture");
+		if(int r = grow(c, c->d_win, cap, A2D_WIN_WORDS, false)) return r;
+		if(int r = grow(c, c->d_widx, nvoices * (size_t)(per + 1), 1, false)) return r;
+		if(!c->d_wtop)
+			HIPCHK(c, hipMalloc((void **)&c->d_wtop, 2 * sizeof(unsigned)));
+	}
+	for(int fa = 0; fa < nfrags; fa += per) {
+		const int fb = std::min(nfrags, fa + per);
+		HIPCHK(c, hipMemsetAsync(c->d_wtop, 0, 2 * sizeof(unsigned), c->stream));
+		size_t at = 0;
+		for(int j = 0; j < nj; ++j) {
+			const Job &b = jobs[j];
+			if(a2d_launch_win_ctl(c->d_params, c->hparams, b.nosc, b.filt, b.list, b.n, b.skip, fa, fb, c->d_win.d,
+					c->d_widx.d + at, c->d_wtop, (unsigned)std::min<size_t>(c->d_win.cap, 0xffffffffu), c->stream))
+				return c->fail(A2AMD_EHIP, "window control launch failed: %s", hipGetErrorString(hipGetLastError()));
+			at += (size_t)b.n * (size_t)(fb - fa + 1);
+			++c->stats.launches;
+		}
+		at = 0;
+		for(int j = 0; j < nj; ++j) {
+			const Job &b = jobs[j];
+			if(a2d_launch_win_render(c->hparams, b.nosc, b.filt, b.list, b.n, fa, fb, c->d_win.d, c->d_widx.d + at, c->stream))
+				return c->fail(A2AMD_EHIP, "window render launch failed: %s", hipGetErrorString(hipGetLastError()));
+			at += (size_t)b.n * (size_t)(fb - fa + 1);
+			++c->stats.launches;
+		}
+	}
+	static const bool check = getenv("A2AMD_WIN_CHECK") != nullptr;
+	if(check && !c->capturing) {
+		unsigned top[2] = { 0, 0 };
+		HIPCHK(c, hipMemcpyAsync(top, c->d_wtop, sizeof(top), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		if(top[1])
+			return c->fail(A2AMD_ESTATE, "window pool overflow (%u of %zu entries)", top[0], c->d_win.cap);
+	}
+	return 0;
+}
+
 int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2)
 {
 	// (self-cleaning buses need both phases in one go: the root's bus is read in ROOT)
@@ -1057,6 +1136,14 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			const int counts[4] = { c->n_dyn_osc1, c->n_dyn_osc2, c->n_dyn_filt, c->n_o2f_leaf };
 			const int total = counts[0] + counts[1] + counts[2] + counts[3];
 			const int kinds = (counts[0] != 0) + (counts[1] != 0) + (counts[2] != 0) + (counts[3] != 0);
+			// Round 5: the record stream resolved by a lane = voice control pass, the windows rendered
+			// from closed-form entries (a2amd_win.hip).  A2AMD_WIN=0: k_leaf_recs, the kernels of rounds
+			// 2-4 that interpret the records on the scalar unit of the rendering wavefront (A/B).
+			static const int use_win = getenv("A2AMD_WIN") ? atoi(getenv("A2AMD_WIN")) : 1;
+			if(use_win) {
+				if(int r = issue_windows(c, lists, counts))
+					return r;
+			} else {
 			if(kinds > 1 && total <= 4096 && !getenv("A2AMD_RVPW")) {
 				// few voices of several kinds (a song): one launch - on one stream the per-kind
 				// launches would run back to back, each as long as one voice's walk through the batch
@@ -1083,6 +1170,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 						return c->fail(A2AMD_EHIP, "leaf records launch failed: %s", hipGetErrorString(hipGetLastError()));
 					++c->stats.launches;
 				}
+			}
 			}
 		}
 		if(c->n_leaf_dyn - c->n_dyn_osc1 - c->n_dyn_osc2 - c->n_dyn_filt > 0) {

@@ -2530,7 +2530,7 @@ int a2amd_units_vm_is(const void *head_unit)
 }
 
 int a2amd_units_vm_adopt(const void *head_unit, const uint32_t *code, unsigned nwords, const void *vmstate,
-		void *const *wr_unit, void *const *wr_fn, uint32_t now, uint32_t msdur)
+		void *const *wr_unit, void *const *wr_fn, uint32_t now, uint32_t msdur, int *has_exit, uint32_t *exit_when)
 {
 	A2P_unit *head = (A2P_unit *)past_envs((const A2P_unit *)head_unit), *n;
 	XTRA *x;
@@ -2548,15 +2548,14 @@ int a2amd_units_vm_adopt(const void *head_unit, const uint32_t *code, unsigned n
 	/* a chain of our own plain units, wired up (setup_simple_chain), alive on one GPU */
 	if(!hs || hs->failed || hs->no_vm || x->head != head || x->pending || x->uid < 0 || x->vm)
 		return -2;
-	/* awake twice within 2 048 fragments (2.7 s)?  (a voice that wakes once a minute is better off
-	 * with the quiet kernels between its wake-ups) */
-	if(!x->vm_seen_valid || hs->frag_serial - x->vm_seen > 2048u)
-	{
-		x->vm_seen = hs->frag_serial;
-		x->vm_seen_valid = 1;
+	/* about to wake again within 2 048 fragments (2.7 s)?  (a voice that wakes once a minute is better off
+	 * with the quiet kernels between its wake-ups; rounds 3-4 waited for it to be SEEN awake twice, which
+	 * cost a long-lived voice its first period and a note - awake twice in its life - everything) */
+	if((int32_t)(((const a2amd_vm_state *)vmstate)->waketime - now) > (2048 * 64) << 8)
 		return -2;
-	}
-	x->vm_seen = hs->frag_serial;
+	/* (a voice just given back is not offered again in the same fragment) */
+	if(x->vm_seen_valid && x->vm_seen == hs->frag_serial)
+		return -2;
 	if(x->nenv > A2AMD_VM_MAXENV)
 		return -1;
 	for(k = 0; k < x->nenv; ++k)
@@ -2635,6 +2634,13 @@ int a2amd_units_vm_adopt(const void *head_unit, const uint32_t *code, unsigned n
 	set_stamp(hs, x, 1);
 	x->vm = 1;
 	++hs->vm_live;
+	if(has_exit)
+	{
+		uint32_t when = 0;
+		*has_exit = a2amd_vm_exit_time(XCTX(x), x->uid, &when);
+		if(exit_when)
+			*exit_when = when;
+	}
 	return 0;
 }
 
@@ -2691,7 +2697,7 @@ int a2amd_units_vm_recall(const void *const *heads, unsigned n, void *const *vms
 					}
 					xj->vm = 0;
 					xj->vm_seen = hs->frag_serial;
-					xj->vm_seen_valid = 0;	/* (not offered again before it has been seen awake twice more) */
+					xj->vm_seen_valid = 1;	/* (not offered again in this fragment) */
 					head->Process = amd_head_process;
 					set_stamp(hs, xj, 0);
 					if(hs->vm_live)

@@ -296,6 +296,46 @@ const char *reason_text(int r)
 	return r >= 0 && r <= A2AMD_VM_IDLE ? t[r] : "?";
 }
 
+// Where the device VM's stay ends for a voice the static analysis cannot vouch for: the host's copy of the
+// interpreter runs the voice's FUTURE VM runs, one after the other, on a copy of its state - nothing but
+// its own registers feeds them (no events: an event recalls the voice; no RAND; the env units and cutoff
+// rampers do not read back), so they are exactly the runs the device will make - until one of them
+// meets what the device cannot do: an instruction outside the subset (END, SLEEP, RETURN, CALL, WAKE, FORCE,
+// spawning, messages, RAND, DEBUG ...), a zero divisor, A2_OVERLOAD, a write through a register wired to
+// something the device VM does not write.  That run is the ENGINE'S: *exit_when = the wake time it starts
+// at, and the walk (a2amd_walk.c) takes the voice back in the fragment that holds it - so a note that ends
+// is the device's up to its last wake-up, and END itself (core.c:1191-1235: the attached / finalizing
+// logic, a2_VoiceFree) is done by the engine, at the frame the engine would have done it.  Without such a
+// run within VM_HORIZON ticks (or VM_MAXRUNS runs) the stay ends there; the voice may be taken again.
+// *records = what the runs emit (a stay without any is not worth a hand-over).
+#define VM_HORIZON	(1 << 29)	// 24:8 ticks: 43 s at 48 kHz
+#define VM_MAXRUNS	8192
+#define VM_MIN_STAY	2048		// frames: a shorter stay is not worth a hand-over and a recall
+static void vm_lookahead(const A2DVmVoice &d0, const uint32_t *code, const Consts &K, uint32_t now, uint32_t *exit_when,
+		int *records, int *runs_out)
+{
+	A2DVmVoice d = d0;
+	CountE e = { 0 };
+	int runs = 0;
+	*exit_when = d.waketime;
+	for(; runs < VM_MAXRUNS; ++runs) {
+		if((int)(d.waketime - now) > VM_HORIZON)
+			break;
+		const uint32_t at = d.waketime;
+		const int n0 = e.n;
+		if(run(d, code, K, e, 0)) {
+			e.n = n0;		// (that run's writes are not the device's)
+			*exit_when = at;
+			*records = e.n;
+			*runs_out = runs;
+			return;
+		}
+	}
+	*exit_when = d.waketime;
+	*records = e.n;
+	*runs_out = runs;
+}
+
 int grow_stage(a2amd_ctx *c, size_t n)
 {
 	VmHost &m = c->vm;
@@ -644,6 +684,7 @@ int vm_issue(a2amd_ctx *c)
 	HIPCHK(c, hipMemcpyAsync(m.h_total, m.d_total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	const uint32_t total = m.h_total[0];
+	m.last_total = total;
 	if(m.h_total[1])
 		return c->fail(A2AMD_ESTATE, "device VM: %u voice(s) faulted (the analysis let a program through that it should "
 				"not have)", m.h_total[1]);
@@ -846,7 +887,11 @@ int a2amd_vm_adopt(a2amd_ctx *c, int head, int prog, const a2amd_vm_state *st, c
 			m.proofs.push_back(q);
 		}
 	}
-	if(info.reason)
+	// What the analysis cannot prove for ALL of the program's future - it reaches an instruction outside the
+	// subset (every program that ends does), a loop it cannot bound - the look-ahead below settles for the
+	// stretch of it that comes first: the voice is taken with an exit time.
+	const bool dynamic = info.reason == A2AMD_VM_OPCODE_OUT || info.reason == A2AMD_VM_NOYIELD || info.reason == A2AMD_VM_DIVISOR;
+	if(info.reason && !dynamic)
 		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: %s (opcode %d at %d)", reason_text(info.reason), info.opcode, info.at);
 	bool any = false;
 	// the voice's env units: where their control outputs go must be a register the device VM writes
@@ -887,7 +932,7 @@ int a2amd_vm_adopt(a2amd_ctx *c, int head, int prog, const a2amd_vm_state *st, c
 		if(wr_unit[r] == -1)
 			continue;
 		// (a register the VM can never pass to a2_VoiceControl may be wired to anything)
-		if(!(info.controlled & (1ull << r)))
+		if(!dynamic && !(info.controlled & (1ull << r)))
 			continue;
 		if(wr_unit[r] <= -3 && -3 - wr_unit[r] < nenv) {
 			d.cmap[r] = (uint8_t)((A2D_VM_ENVPOS << 4) | (-3 - wr_unit[r]));
@@ -898,9 +943,14 @@ int a2amd_vm_adopt(a2amd_ctx *c, int head, int prog, const a2amd_vm_state *st, c
 		for(int k = 0; k < v.nunits; ++k)
 			if(v.unit[k] == wr_unit[r])
 				pos = k;
-		if(pos < 0 || !write_supported(c->units[v.unit[pos]].kind, wr_reg[r]))
+		if(pos < 0 || !write_supported(c->units[v.unit[pos]].kind, wr_reg[r])) {
+			if(dynamic) {	// (the stay ends in front of the first VM run that writes through it)
+				d.cmap[r] = A2D_VM_TRAPWRITE;
+				continue;
+			}
 			return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: %s (VM register %d -> unit %d register %d)",
 					reason_text(A2AMD_VM_TARGET), r, wr_unit[r], (int)wr_reg[r]);
+		}
 		d.cmap[r] = (uint8_t)((pos << 4) | wr_reg[r]);
 		need_f1 |= write_needs_f1tab(c->units[v.unit[pos]].kind, wr_reg[r]);
 		any = true;
@@ -908,12 +958,32 @@ int a2amd_vm_adopt(a2amd_ctx *c, int head, int prog, const a2amd_vm_state *st, c
 	// (the tracker's 32 bit mask lets register r + 32 ride on r's bit: a program that uses both
 	// halves is rare and its aliasing is reproduced by the interpreter - but the set of registers
 	// that may be written must then cover the twins too, which 'controlled' does not track)
-	if((info.written >> 32) && (uint32_t)info.written & (uint32_t)(info.written >> 32))
+	if(!dynamic && (info.written >> 32) && (uint32_t)info.written & (uint32_t)(info.written >> 32))
 		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: registers r and r + 32 both written (tracker aliasing)");
 	if(!any)
 		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: %s", reason_text(A2AMD_VM_IDLE));
 	if(need_f1)
 		build_f1tab(c);
+	bool has_exit = false;
+	uint32_t exit_when = 0;
+	if(dynamic) {
+		int nrec = 0, runs = 0;
+		const uint32_t msdur0 = m.msdur;
+		m.msdur = msdur;		// (consts_of)
+		vm_lookahead(d, m.code.data() + p.off, consts_of(c), now, &exit_when, &nrec, &runs);
+		m.msdur = msdur0;
+		has_exit = true;
+		if(!runs)	// the voice's very next VM run is the engine's: never, from this pc
+			return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: %s (opcode %d at %d) in the voice's next VM run",
+					reason_text(info.reason), info.opcode, info.at);
+		// a stay that is over within the buffer being walked, or that writes nothing, is not worth the hand-over
+		bool env_running = false;
+		for(int k = 0; k < nenv; ++k)
+			env_running |= d.env[k].active && d.env[k].target != A2D_VM_NOWRITE;
+		if((int)(exit_when - now) < (VM_MIN_STAY << 8) || (!nrec && !env_running))
+			return c->fail(A2AMD_ESTATE, "vm_adopt: the device VM's stay would be %d frames and %d writes long",
+					(int)(exit_when - now) >> 8, nrec);
+	}
 	// the context's clock: engine time of walk_time 0
 	{
 		uint64_t before = 0;	// frames of the batch's fragments before the open one
@@ -943,12 +1013,26 @@ int a2amd_vm_adopt(a2amd_ctx *c, int head, int prog, const a2amd_vm_state *st, c
 	h.prog = prog;
 	h.func = st->func;
 	h.st = d;
+	h.has_exit = has_exit;
+	h.exit_when = exit_when;
 	m.pending.push_back(slot);
 	v.vm = slot;
 	v.plain = 0;
 	++m.stats.live;
 	++m.stats.adopted;
 	return A2AMD_OK;
+}
+
+int a2amd_vm_exit_time(a2amd_ctx *c, int head, uint32_t *when)
+{
+	if(head < 0 || head >= (int)c->units.size() || !c->units[head].live)
+		return 0;
+	const int slot = c->voices[c->units[head].voice].vm;
+	if(slot < 0 || slot >= (int)c->vm.vms.size() || !c->vm.vms[slot].live || !c->vm.vms[slot].has_exit)
+		return 0;
+	if(when)
+		*when = c->vm.vms[slot].exit_when;
+	return 1;
 }
 
 int a2amd_vm_adopted(a2amd_ctx *c, int head)

@@ -34,7 +34,8 @@ struct Consts {
 	const uint16_t *envlut;		// [A2D_ENV_LUTS][A2D_ENV_LUTSIZE + 2] or null
 };
 
-enum { TRAP_NONE = 0, TRAP_OVERLOAD, TRAP_OPCODE, TRAP_DIVISOR, TRAP_PC };
+enum { TRAP_NONE = 0, TRAP_OVERLOAD, TRAP_OPCODE, TRAP_DIVISOR, TRAP_PC,
+	TRAP_TARGET };	// a write through a VM register wired to something the device VM does not write (A2D_VM_TRAPWRITE)
 // (env keeps its own copy of the state's msdur, env.c:236: the same expression)
 VMFN uint32_t en_msdur(const Consts &K) { return K.msdur; }
 
@@ -239,6 +240,10 @@ VMFN void control(A2DVmVoice &v, const Consts &K, E &e, int frag, unsigned reg, 
 	const unsigned m = v.cmap[reg & 63u];
 	if(m == A2D_VM_NOWRITE)
 		return;
+	if(m == A2D_VM_TRAPWRITE) {	// (only ever met by the host's look-ahead, which ends the voice's stay in front of this VM run)
+		v.fault = TRAP_TARGET;
+		return;
+	}
 	if((m >> 4) == A2D_VM_ENVPOS) {		// an env unit's 'target' register
 		env_target(v, K, e, frag, (int)(m & 15u), v.r[reg & 63u], start & 255u, dur);
 		return;
@@ -310,6 +315,8 @@ VMFN int run(A2DVmVoice &v, const uint32_t *code, const Consts &K, E &e, int fra
 	if(v.state == A2AMD_VM_WAITING)
 		v.state = A2AMD_VM_RUNNING;
 	for(;;) {
+		if(v.fault)
+			return v.fault;
 		if(v.pc >= v.ncode)
 			return TRAP_PC;
 		const uint32_t w = code[v.pc];
@@ -385,6 +392,26 @@ VMFN int run(A2DVmVoice &v, const uint32_t *code, const Consts &K, E &e, int fra
 		  // arithmetics, core.c:1339-1411
 		  case A2AMD_OP_SUBR:
 			r[a1] = vsub(r[a1], r[a2 & 63u]);
+			rt_mark(rt, a1);
+			break;
+		  // (register divisors: never proven by the static analysis - a voice whose program has them is
+		  // taken for a stretch the host's look-ahead has run through, vm_lookahead in a2amd_vm.cpp)
+		  case A2AMD_OP_DIVR:
+			if(!r[a2 & 63u])
+				return TRAP_DIVISOR;
+			r[a1] = (int)(((int64_t)r[a1] << 16) / (int64_t)r[a2 & 63u]);
+			rt_mark(rt, a1);
+			break;
+		  case A2AMD_OP_MODR:
+			if(r[a2 & 63u] == 0 || r[a2 & 63u] == -1)
+				return TRAP_DIVISOR;
+			r[a1] %= r[a2 & 63u];
+			rt_mark(rt, a1);
+			break;
+		  case A2AMD_OP_QUANTR:
+			if(r[a2 & 63u] == 0 || r[a2 & 63u] == -1)
+				return TRAP_DIVISOR;
+			r[a1] = vmul(r[a1] / r[a2 & 63u], r[a2 & 63u]);
 			rt_mark(rt, a1);
 			break;
 		  case A2AMD_OP_P2DR: {
@@ -489,6 +516,8 @@ VMFN int run(A2DVmVoice &v, const uint32_t *code, const Consts &K, E &e, int fra
 			continue;
 		// "timing:", core.c:1719-1733
 		rt_apply(rt, v, K, e, frag, v.waketime, dt);
+		if(v.fault)
+			return v.fault;
 		if(!dt)
 			continue;
 		v.state = A2AMD_VM_WAITING;

@@ -51,6 +51,8 @@
 #define E_GROUP		4u		/* ... it has subvoices: it sleeps unseen only if their whole list does (ENT.sub) */
 #define E_VM		8u		/* ... its program runs on the device (a2amd_units_vm_adopt): asleep whatever its
 					 * (stale) wake time says, and handed to the engine only after a2amd_units_vm_recall */
+#define E_VMEXIT	16u		/* ... for a stretch only: the engine gets it back in the fragment that holds ENT.vm_exit
+					 * (a2amd_vm_exit_time, include/a2amd_vm.h: the VM run that ends the voice, sleeps, calls ...) */
 
 /* the device VM interprets the engine's bytecode: the numbers it was built with are the engine's */
 #define A2V(x) _Static_assert((int)OP_##x == (int)A2AMD_OP_##x, "opcode " #x);
@@ -74,6 +76,7 @@ typedef struct ENT
 	uint32_t	stamp;		/* a2amd_units_standing() when it was last visited; 0 = always visit */
 	uint32_t	wake;		/* A2_vmstate.waketime when it was last looked at */
 	uint32_t	flags;		/* E_* */
+	uint32_t	vm_exit;	/* E_VMEXIT: engine time of the first VM run that is the engine's again */
 	struct LIST	*sub;		/* E_GROUP: the list of its subvoices */
 } ENT;
 
@@ -408,7 +411,8 @@ static inline int entry_sleeps(const WSTATE *w, const ENT *e, unsigned wake, int
 {
 	const a2amd_walkview *vw = &w->view;
 	unsigned dev, slot;
-	if(!e->stamp || !noevents || (!(e->flags & E_VM) && (a2_TSDiff(wake, now) >> 8) < (int)frames))
+	if(!e->stamp || !noevents || (!(e->flags & E_VM) && (a2_TSDiff(wake, now) >> 8) < (int)frames) ||
+			((e->flags & E_VMEXIT) && (a2_TSDiff(e->vm_exit, now) >> 8) < (int)frames))
 		return 0;
 	if(e->stamp != STAMP_NOUNITS)
 	{
@@ -630,11 +634,11 @@ static void recall_run(WSTATE *w, LIST *l, unsigned k, A2_voice *v, unsigned run
 		if(!is_vm)
 		{
 			if(k + kk < l->n && l->e[k + kk].v == p)
-				l->e[k + kk].flags &= ~E_VM;
+				l->e[k + kk].flags &= ~(E_VM | E_VMEXIT);
 			continue;
 		}
 		if(k + kk < l->n && l->e[k + kk].v == p)
-			l->e[k + kk].flags &= ~E_VM;
+			l->e[k + kk].flags &= ~(E_VM | E_VMEXIT);
 		heads[n] = p->units;
 		states[n++] = &p->s;
 		if(n == 64)
@@ -655,12 +659,13 @@ static void recall_run(WSTATE *w, LIST *l, unsigned k, A2_voice *v, unsigned run
  * here on?  A leaf voice waiting in a delay, no events, no call stack, nobody outside the tree who
  * could send it anything (no API handle) - and a program that a2amd_vm_analyze() can prove to stay
  * inside the subset from p->s.pc on.  Returns 1 when the voice was handed over. */
-static int offer_to_vm(WSTATE *w, A2_state *st, A2_voice *p)
+static int offer_to_vm(WSTATE *w, A2_state *st, A2_voice *p, int *has_exit, uint32_t *exit_when)
 {
 	void *wr_unit[A2_REGISTERS], *wr_fn[A2_REGISTERS];
 	const A2_function *fn;
 	unsigned r;
 	int rc;
+	*has_exit = 0;
 	if(walk_novm || !w->served || p->sub || p->events || p->stack || (p->flags & A2_APIHANDLE) || !p->units ||
 			!p->program || p->s.state != A2_WAITING)
 		return 0;
@@ -674,7 +679,7 @@ static int offer_to_vm(WSTATE *w, A2_state *st, A2_voice *p)
 		wr_fn[r] = r < p->ncregs ? (void *)p->cregs[r].write : NULL;
 	}
 	rc = a2amd_units_vm_adopt(p->units, fn->code, fn->size, &p->s, wr_unit, wr_fn,
-			st->now_fragstart + (*w->view.base << 8), st->msdur);
+			st->now_fragstart + (*w->view.base << 8), st->msdur, has_exit, exit_when);
 	if(rc == -1)
 	{
 		w->vm_no[w->vm_no_pos & 63].code = fn->code;
@@ -853,8 +858,17 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 					/* (a voice whose program the device can run from here on is handed over now)
 					 * (only from the root window itself: a voice processed window by window - its
 					 * parent woke in mid-fragment - would be wanted back for the next one) */
-					if(deflt && offer_to_vm(w, st, p))
+					int has_exit;
+					uint32_t exit_when;
+					if(deflt && offer_to_vm(w, st, p, &has_exit, &exit_when))
+					{
 						e->flags |= E_VM;
+						if(has_exit)
+						{
+							e->flags |= E_VMEXIT;
+							e->vm_exit = exit_when;
+						}
+					}
 					e->stamp = w->served ? a2amd_units_standing(p->units, &e->slotdev) : 0;
 				}
 			}
@@ -888,13 +902,23 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 		{
 			const ENT *e = &l->e[k];
 			int d = a2_TSDiff(e->wake, now);
-			if(!(e->flags & E_VM))		/* (a voice the device VM runs never wakes here) */
+			if(!(e->flags & E_VM))		/* (a voice the device VM runs never wakes here ... */
 			{
 				l->sum_timed = 1;
 				if(d < best)
 				{
 					best = d;
 					l->sum_wake = e->wake;
+				}
+			}
+			else if(e->flags & E_VMEXIT)	/* ... before the VM run that is the engine's again) */
+			{
+				d = a2_TSDiff(e->vm_exit, now);
+				l->sum_timed = 1;
+				if(d < best)
+				{
+					best = d;
+					l->sum_wake = e->vm_exit;
 				}
 			}
 			if(e->stamp != STAMP_NOUNITS &&

@@ -1,0 +1,913 @@
+// a2amd_win.hip - voices that carry command records, rendered in two passes (round 5).
+//
+// A scripted, enveloped or device-VM voice is a record stream: windows that begin and end inside
+// a fragment (a2_VoiceProcess, core.c:1852-1878), control writes between them (wtosc.c:433-504,
+// panmix.c:219-249, filter12.c:149-177 through a2_SetRamper, a2_dsp.h:161-170), births, deaths.
+// Rounds 2-4 interpreted that stream on the SCALAR unit of the wavefront that also rendered the
+// voice (k_leaf_recs, a2amd_fast.hip): one voice at a time per wavefront, more scalar than vector
+// instructions, 7-16x under the quiet kernels.  Nothing the stream does depends on the AUDIO:
+// rampers are linear in time (a2_dsp.h:128-155), an oscillator's phase is phase0 + k * dphase
+// (wtosc.c:239-286), which draw of the engine's LCG a noise frame holds is a count of phase
+// boundaries (wtosc.c:129-152), the filter's coefficient steps are the host's.  So the stream is
+// resolved apart from the rendering:
+//
+//   k_win_ctl<NOSC, FILT>   lane = VOICE.  Each lane walks its voice's records through the
+//                           batch's fragments and carries the voice's whole control state -
+//                           rampers, pitch -> increment (a2_P2I), mip level, phase, wave,
+//                           mode, liveness - in vector registers; for every window of the
+//                           chain it writes one closed-form ENTRY (A2D_WIN_WORDS words): where
+//                           each oscillator's taps start and how they step, amplitude, volume
+//                           and pan values and per-frame deltas, the filter's cutoff
+//                           coefficient and q with their steps.  64 voices per wavefront
+//                           instead of one; no per-voice state ever sits in a scalar register.
+//   k_win_render<NOSC>      lane = FRAME.  A wavefront takes a group of voices and a chunk of
+//                           fragments and evaluates their entries - two coefficient-table taps
+//                           per oscillator, the amplitude, the pan gains - with the entry in
+//                           scalar registers and no record kinds left to tell apart.  Because an
+//                           entry needs nothing of the window before it, the chunks of a batch
+//                           are independent: a song's few dozen voices fill thousands of
+//                           wavefronts instead of one serial walk each.
+//   k_win_render_f<NOSC>    the same with filter12 between the oscillators and the panmix: the
+//                           recurrence (filter12.c:97-118) is the one thing serial in time, so a
+//                           workgroup owns its voices for the whole batch and runs a pipeline over
+//                           the fragments like k_leaf_oscfiltpan - oscillator windows of fragment
+//                           f + 1 into LDS rows, ONE wavefront filtering fragment f with lane =
+//                           voice, the pan stage on fragment f - 1 - one barrier per step.
+//
+// State ownership: k_win_ctl reads and writes every unit state word except filter12's d1 / d2,
+// which are k_win_render_f's (a voice born in the batch resets them through a flag in the entry).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <algorithm>
+#include "a2amd_device.h"
+#include "a2amd_dsp.h"
+#include "a2amd_taps.h"
+
+// entry words (A2D_WIN_WORDS = 24)
+enum { WE_HEAD = 0,	// j | off << 8 | len << 16 | clamp << 24 | fresh << 25 | mode0 << 26 | mode1 << 28
+	WE_F0, WE_DF, WE_QV, WE_QD, WE_LP, WE_BP, WE_HP,	// filter12: coefficient + step, q + step, mix levels
+	WE_VOL, WE_DVOL, WE_PAN, WE_DPAN,			// panmix: values at the window's first frame, per-frame deltas
+	WE_OSC = 12 };						// 6 words per oscillator:
+enum { WO_A = 0, WO_B, WO_C, WO_DPH, WO_AK, WO_DA };		//   taps:  level offset in the pool, phase lo / hi, increment
+								//   noise: seed, held sample, phase lo, increment; then amplitude + delta
+enum { WM_SILENT = 0, WM_TAPS, WM_NOISE };
+#define WH_CLAMP (1u << 24)
+#define WH_FRESH (1u << 25)
+
+// (a uniform address through the constant address space is a scalar load)
+typedef int Int4 __attribute__((ext_vector_type(4)));
+DEV int sload(const void *p)
+{
+	typedef const __attribute__((address_space(4))) int *CI;
+	return *(CI)(uintptr_t)p;
+}
+DEV Int4 sload4(const void *p)
+{
+	typedef const __attribute__((address_space(4))) Int4 *CI4;
+	return *(CI4)(uintptr_t)p;
+}
+
+// ---------------------------------------------------------------------------
+// the control pass: lane = voice
+// ---------------------------------------------------------------------------
+struct OscV {		// A2_wtosc (wtosc.c:66-80), one per lane
+	int mode, wave;
+	unsigned dphase;
+	uint64_t phase;
+	int p_ramping;
+	Ramp p, a;
+	int noise;
+	unsigned seed;
+};
+
+// a2_PrepareRamper, a2_dsp.h:128-149 (the 64 bit division by an exact double division: the first
+// branch is only taken with timer >= 256 * frames > 0)
+DEV void ramp_prepare_v(Ramp &r, int frames)
+{
+	if(r.timer == 0) {
+		r.value = r.target;
+		r.delta = 0;
+	} else if(frames <= (r.timer >> 8)) {
+		r.delta = (int)div_trunc_exact((int64_t)wsub(r.target, r.value) * 256, r.timer);
+		r.timer = wsub(r.timer, frames << 8);
+	} else {
+		r.delta = frames > 0 ? wsub(r.target, r.value) / frames : 0;
+		r.timer = 0;
+	}
+}
+
+// ph %= (uint64_t)size << 24 (wtosc.c:260-263)
+DEV uint64_t wrap_phase_v(uint64_t ph, unsigned size)
+{
+	if(ph >> 56)
+		return size ? ph % ((uint64_t)size << 24) : ph;
+	unsigned hi = (unsigned)(ph >> 24);
+	if(hi >= size && size) {
+		if(!(size & (size - 1)))
+			hi &= size - 1;
+		else
+			hi %= size;
+		ph = ((uint64_t)hi << 24) | (ph & 0xffffffu);
+	}
+	return ph;
+}
+
+// wtosc_run_pitch, wtosc.c:89-105
+DEV void run_pitch_v(const uint32_t *ptab, OscV &o, int frames)
+{
+	ramp_prepare_v(o.p, frames);
+	if(o.dphase && (!o.p.timer && !o.p_ramping))
+		return;
+	const unsigned lastv = (unsigned)o.p.value;
+	ramp_run(o.p, frames);
+	o.p_ramping = o.p.delta;
+	o.dphase = p2i(ptab, (int)((lastv + (unsigned)o.p.value) >> 9));
+}
+
+// One window of an oscillator's control state (wtosc_wavetable wtosc.c:239-286, wtosc_noise :129-152,
+// wtosc_Off :108-126): steps the state over 'len' frames and says what the frames are made of.
+DEV int osc_window_v(const A2DWave *waves, const uint32_t *ptab, OscV &o, int len, int (&w)[6])
+{
+	int mode = WM_SILENT;
+	w[0] = w[1] = w[2] = w[3] = w[4] = w[5] = 0;
+	if(o.mode == A2D_OSC_MIPWAVE) {
+		const A2DWave *wv = waves + o.wave;
+		const unsigned size0 = wv->size[0];
+		if(!size0) {		// wtosc_check_unloaded, wtosc.c:168-183
+			o.wave = -1;
+			o.mode = A2D_OSC_OFF;
+			return mode;
+		}
+		const unsigned period = wv->period, flags = wv->flags;
+		run_pitch_v(ptab, o, len);
+		unsigned dph = ((o.dphase + 255) >> 8) * period;
+		ramp_prepare_v(o.a, len);
+		unsigned mm = 0;
+		for(; (dph > (A2D_MAXPHINC << 8)) && (mm < A2D_MIPS - 1); ++mm)
+			dph >>= 1;
+		uint64_t ph = o.phase >> mm;
+		dph = (unsigned)(((uint64_t)o.dphase * period) >> mm);
+		const unsigned sizem = wv->size[mm];
+		if(flags & 0x100u)
+			ph = wrap_phase_v(ph, sizem);
+		else if((ph >> 24) > (uint64_t)(sizem + 1))
+			return mode;	// all played: silence, state untouched
+		if(dph <= (A2D_MAXPHINC << 16)) {
+			mode = WM_TAPS;
+			w[WO_A] = (int)wv->off[mm];
+			w[WO_B] = (int)(unsigned)ph;
+			w[WO_C] = (int)(unsigned)(ph >> 32);
+			w[WO_DPH] = (int)dph;
+			w[WO_AK] = o.a.value;
+			w[WO_DA] = o.a.delta;
+		}
+		ph += (uint64_t)dph * (unsigned)len;
+		o.phase = ph << mm;
+		ramp_run(o.a, len);
+	} else if(o.mode == A2D_OSC_NOISE) {
+		run_pitch_v(ptab, o, len);
+		ramp_prepare_v(o.a, len);
+		mode = WM_NOISE;
+		w[WO_A] = (int)o.seed;
+		w[WO_B] = o.noise;
+		w[WO_C] = (int)(unsigned)o.phase;
+		w[WO_DPH] = (int)o.dphase;
+		w[WO_AK] = o.a.value;
+		w[WO_DA] = o.a.delta;
+		// a frame draws from the engine's LCG when its step crosses a 2^23 boundary of the phase
+		// (wtosc.c:140-144): how many do is a difference of two quotients
+		const uint64_t end = o.phase + (uint64_t)(unsigned)len * o.dphase;
+		const unsigned total = o.dphase >= (1u << 23) ? (unsigned)len : (unsigned)((end >> 23) - (o.phase >> 23));
+		unsigned st = o.seed;
+		int held = o.noise;
+		for(unsigned j = 0; j < total; ++j)
+			held = noise_next(st) - 32767;
+		o.seed = st;
+		o.noise = held;
+		o.phase = end;
+		ramp_run(o.a, len);
+	} else {
+		ramp_prepare_v(o.p, len);
+		ramp_prepare_v(o.a, len);
+		ramp_run(o.p, len);
+		ramp_run(o.a, len);
+	}
+	return mode;
+}
+
+// wtosc_Initialize, wtosc.c:390-423 (value = transpose + basepitch)
+DEV void osc_init_v(const uint32_t *ptab, OscV &o, int pitch)
+{
+	o.wave = -1;
+	o.mode = A2D_OSC_OFF;
+	o.phase = 0;
+	o.p_ramping = 0;
+	o.noise = 0;
+	o.seed = 0;
+	ramp_init(o.a, 0);
+	ramp_init(o.p, pitch);
+	o.dphase = p2i(ptab, o.p.value >> 8);
+}
+
+DEV void osc_write_v(const A2DWave *waves, OscV &o, int reg, int v, int start, int dur)
+{
+	switch(reg) {
+	  case 0: {	// wtosc_Wave, wtosc.c:433-483 (the host resolved the handle; mip-mapped waves, the
+			// noise generator and "off" reach these kernels)
+		int wt = 0;
+		o.wave = v;
+		if(v >= 0) {
+			const A2DWave *w = waves + v;
+			wt = w->type;
+			if(wt == 3 && w->size[0] > (unsigned)A2D_WTOSC_MAXLENGTH)
+				wt = 0;
+		}
+		if(wt == 3)
+			o.mode = A2D_OSC_MIPWAVE;
+		else if(wt == 1)
+			o.mode = A2D_OSC_NOISE;
+		else {
+			o.wave = -1;
+			o.mode = A2D_OSC_OFF;
+		}
+		break;
+	  }
+	  case 1:	// wtosc_Pitch, wtosc.c:486-492 (host added transpose + basepitch)
+		ramp_set(o.p, v, start, dur);
+		if(!dur)
+			o.p_ramping = 1;
+		break;
+	  case 2:
+		ramp_set(o.a, v, start, dur);
+		break;
+	  case 3:	// wtosc_Phase -> wtosc_set_phase, wtosc.c:369-378
+		if(o.wave < 0)
+			o.phase = 0;
+		else {
+			const unsigned period = waves[o.wave].period;
+			const int ph = (int)((unsigned)v + ((((unsigned)start) * (o.dphase >> 8)) >> 8));
+			o.phase = (uint64_t)(((int64_t)ph * (int64_t)period) * 256);
+		}
+		break;
+	}
+}
+
+struct FiltV { Ramp q; int lp, bp, hp, f1, f1next, ramp; };
+
+template<int NOSC, int FILT>
+DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int idx, int skip_empty,
+		int fa, int fb, int *__restrict__ win, unsigned *__restrict__ widx, unsigned *__restrict__ wtop, unsigned wcap,
+		const A2DVoice *__restrict__ voices, int *ustate, int *vactive, const A2DWave *__restrict__ waves,
+		const uint32_t *__restrict__ ptab)
+{
+	const A2DParams &p = *pp;
+	const int lane = threadIdx.x & 63;
+	const bool listed = idx < nlist;
+	const A2DRec *__restrict__ recs = p.recs;
+	OscV os[NOSC];
+	FiltV fs;
+	Ramp vol, pan;
+	int uu[NOSC + FILT + 1], slot = 0, rc = 0, re = 0, active = 0;
+	bool live = false;
+	fs.q.value = fs.q.target = fs.q.delta = fs.q.timer = 0;
+	fs.lp = fs.bp = fs.hp = fs.f1 = fs.f1next = fs.ramp = 0;
+	if(listed) {
+		slot = list[idx];
+		const A2DVoice &vc = voices[slot];
+#pragma unroll
+		for(int o = 0; o <= NOSC + FILT; ++o)
+			uu[o] = vc.unit[o];
+		const A2DRun run = p.runs[slot];
+		rc = run.first;
+		re = run.first + run.count;
+		// skip_empty: a list of voices whose records the device VM writes (a2amd_vm.hip) - the ones it
+		// left without any this batch are the quiet kernels' (runs[].count == 0), not ours
+		live = !(skip_empty && run.count == 0);
+	}
+	if(live) {
+#pragma unroll
+		for(int o = 0; o < NOSC; ++o) {
+			const int *w = ustate + (size_t)uu[o] * A2D_USTATE;
+			os[o].mode = w[OW_MODE]; os[o].wave = w[OW_WAVE]; os[o].dphase = (unsigned)w[OW_DPHASE];
+			os[o].phase = (uint64_t)(unsigned)w[OW_PHASE_LO] | ((uint64_t)(unsigned)w[OW_PHASE_HI] << 32);
+			os[o].p_ramping = w[OW_PRAMPING];
+			os[o].p = ramp_load(w + OW_P);
+			os[o].a = ramp_load(w + OW_A);
+			os[o].noise = w[OW_NOISE];
+			os[o].seed = (unsigned)w[OW_SEED];
+		}
+		if(FILT) {
+			const int *wf = ustate + (size_t)uu[NOSC] * A2D_USTATE;
+			fs.q = ramp_load(wf + FW_Q);
+			fs.lp = wf[FW_LP]; fs.bp = wf[FW_BP]; fs.hp = wf[FW_HP]; fs.f1 = wf[FW_F1];
+			fs.f1next = wf[FW_F1NEXT]; fs.ramp = wf[FW_RAMP];
+		}
+		const int *wp = ustate + (size_t)uu[NOSC + FILT] * A2D_USTATE;
+		vol = ramp_load(wp + PW_VOL);
+		pan = ramp_load(wp + PW_PAN);
+		active = vactive[slot];
+		// (a later slab of the batch: the records of the fragments before it have been carried out)
+		while(rc < re && (int)A2D_RFRAG(recs[rc].head) < fa)
+			++rc;
+	} else {
+#pragma unroll
+		for(int o = 0; o < NOSC; ++o) {
+			os[o].mode = 0; os[o].wave = -1; os[o].dphase = 0; os[o].phase = 0; os[o].p_ramping = 0;
+			os[o].p.value = os[o].p.target = os[o].p.delta = os[o].p.timer = 0;
+			os[o].a = os[o].p;
+			os[o].noise = 0; os[o].seed = 0;
+		}
+		vol.value = vol.target = vol.delta = vol.timer = 0;
+		pan = vol;
+	}
+
+	// room for this voice's entries: at most one per fragment without records and one per record
+	// (the wavefront takes its voices' sum from the launch's pool in one atomic)
+	unsigned e, elim;
+	{
+		const unsigned cap = live ? (unsigned)(fb - fa) + (unsigned)(re - rc) : 0u;
+		unsigned pre = cap;
+#pragma unroll
+		for(int d = 1; d < 64; d <<= 1) {
+			const unsigned t = (unsigned)__shfl_up((int)pre, d, 64);
+			if(lane >= d)
+				pre += t;
+		}
+		const unsigned total = (unsigned)__shfl((int)pre, 63, 64);
+		unsigned base = 0;
+		if(lane == 0 && total)
+			base = atomicAdd(wtop, total);
+		base = (unsigned)__shfl((int)base, 0, 64);
+		e = base + pre - cap;
+		elim = e + cap;
+		if(base + total > wcap) {	// (the host sizes the pool by the same bound: never; the voices of
+			if(lane == 0)		// this wavefront then render nothing and the flag says so)
+				atomicOr(wtop + 1, 1u);
+			elim = e = 0;
+			live = false;
+		}
+	}
+
+	int pending_fresh = 0;
+	for(int f = fa; f < fb; ++f) {
+		const int n = (int)p.fragframes[f];
+		if(listed)
+			widx[(size_t)(f - fa) * nlist + idx] = e;
+		// this lane's next thing to do in fragment f: its records, or - none - the engine's default
+		// Process(0, frames) on every unit (core.c:1875-1876)
+		Int4 r = { 0, 0, n << 16, 0 };
+		int op = 0;
+		bool inrec = false;
+		if(live) {
+			if(rc < re) {
+				const Int4 q = *(const Int4 *)(recs + rc);
+				if((int)A2D_RFRAG((unsigned)q.x) == f) {
+					r = q;
+					inrec = true;
+				}
+			}
+			op = inrec ? (int)A2D_ROP((unsigned)r.x) : (active ? R_SEG : 0);
+			if(inrec && !op)
+				op = R_NOP;
+		}
+		while(__ballot(op != 0)) {
+			const int value = r.y;
+			const unsigned dur = (unsigned)r.z, start = (unsigned)r.w;
+			const int u = (int)A2D_RUNIT((unsigned)r.x), reg = (int)A2D_RREG((unsigned)r.x);
+			if(op == R_SEG) {
+				if(active) {
+					// one window of the chain: frames [off, off + len) of the fragment
+					const int off = (int)(dur & 0xffffu), len = (int)(dur >> 16);
+					int W[A2D_WIN_WORDS];
+					unsigned head = (unsigned)(f & 0xff) | ((unsigned)off << 8) | ((unsigned)len << 16);
+#pragma unroll
+					for(int k = 0; k < A2D_WIN_WORDS; ++k)
+						W[k] = 0;
+#pragma unroll
+					for(int o = 0; o < NOSC; ++o) {
+						int w6[6];
+						const int m = osc_window_v(waves, ptab, os[o], len, w6);
+						head |= (unsigned)m << (26 + 2 * o);
+#pragma unroll
+						for(int k = 0; k < 6; ++k)
+							W[WE_OSC + 6 * o + k] = w6[k];
+					}
+					if(FILT) {
+						// f12_process's head, filter12.c:86-96 (the host / the device VM ran the cutoff
+						// ramper and f12_pitch2coeff: R_F1SET / R_F1RAMP)
+						ramp_prepare_v(fs.q, len);
+						W[WE_F0] = fs.f1;
+						if(fs.ramp) {
+							const int f0 = fs.f1;
+							fs.f1 = fs.f1next;
+							W[WE_DF] = len > 0 ? wadd(wsub(fs.f1, f0), len >> 1) / len : 0;
+							fs.ramp = 0;
+						}
+						W[WE_QV] = fs.q.value;
+						W[WE_QD] = fs.q.delta;
+						ramp_run(fs.q, len);
+						W[WE_LP] = fs.lp; W[WE_BP] = fs.bp; W[WE_HP] = fs.hp;
+						if(pending_fresh) {
+							head |= WH_FRESH;
+							pending_fresh = 0;
+						}
+					}
+					// panmix_process12's head, panmix.c:84-95
+					if(pan.target > 0xffffff || pan.target < -0xffffff || pan.value > 0xffffff || pan.value < -0xffffff)
+						head |= WH_CLAMP;
+					ramp_prepare_v(vol, len);
+					ramp_prepare_v(pan, len);
+					W[WE_VOL] = vol.value; W[WE_DVOL] = vol.delta;
+					W[WE_PAN] = pan.value; W[WE_DPAN] = pan.delta;
+					ramp_run(vol, len);
+					ramp_run(pan, len);
+					W[WE_HEAD] = (int)head;
+					if(e < elim) {
+						Int4 *dst = (Int4 *)(win + (size_t)e * A2D_WIN_WORDS);
+#pragma unroll
+						for(int k = 0; k < A2D_WIN_WORDS / 4; ++k) {
+							const Int4 q = { W[4 * k], W[4 * k + 1], W[4 * k + 2], W[4 * k + 3] };
+							dst[k] = q;
+						}
+						++e;
+					}
+				}
+			} else if(op == R_INIT) {
+#pragma unroll
+				for(int o = 0; o < NOSC; ++o)
+					if(u == o)
+						osc_init_v(ptab, os[o], value);
+				if(FILT && u == NOSC) {	// f12_Initialize, filter12.c:180-221; value = f1 from the host
+					ramp_init(fs.q, 0);
+					ramp_set(fs.q, 32768, 0, 0);	// f12_Q(u, 0, 0, 0)
+					fs.lp = 65536 >> 8;
+					fs.bp = fs.hp = fs.f1next = fs.ramp = 0;
+					fs.f1 = value;
+					pending_fresh = 1;
+					int *wf = ustate + (size_t)uu[NOSC] * A2D_USTATE;
+					wf[FW_D1B] = 0;
+					wf[FW_D2B] = 0;
+				}
+				if(u == NOSC + FILT) {	// panmix_Initialize, panmix.c:252-284
+					ramp_init(vol, 65536);
+					ramp_init(pan, 0);
+				}
+				active = 1;
+			} else if(op == R_WRITE) {
+#pragma unroll
+				for(int o = 0; o < NOSC; ++o)
+					if(u == o)
+						osc_write_v(waves, os[o], reg, value, (int)start, (int)dur);
+				if(FILT && u == NOSC) {	// filter12.c:149-177 (the host did the 1/q)
+					if(reg == 1)
+						ramp_set(fs.q, value, (int)start, (int)dur);
+					else if(reg == 2)
+						fs.lp = value >> 8;
+					else if(reg == 3)
+						fs.bp = value >> 8;
+					else if(reg == 4)
+						fs.hp = value >> 8;
+				}
+				if(u == NOSC + FILT) {
+					if(reg == 0)
+						ramp_set(vol, value, (int)start, (int)dur);
+					else
+						ramp_set(pan, value, (int)start, (int)dur);
+				}
+			} else if(op == R_F1SET) {	// f12_CutOff without a ramp: the host's coefficient
+				fs.f1 = value;
+				fs.ramp = 0;
+			} else if(op == R_F1RAMP) {	// ... and one per window while the cutoff ramps
+				fs.f1next = value;
+				fs.ramp = 1;
+			} else if(op == R_KILL) {
+				active = 0;
+			} else if(op == R_NOISESEED) {	// the engine's RNG word as this window of a noise oscillator finds it
+#pragma unroll
+				for(int o = 0; o < NOSC; ++o)
+					if(u == o)
+						os[o].seed = (unsigned)value;
+			}
+			// the next one
+			if(inrec) {
+				++rc;
+				inrec = false;
+				op = 0;
+				if(rc < re) {
+					const Int4 q = *(const Int4 *)(recs + rc);
+					if((int)A2D_RFRAG((unsigned)q.x) == f) {
+						r = q;
+						inrec = true;
+						op = (int)A2D_ROP((unsigned)q.x);
+						if(!op)
+							op = R_NOP;
+					}
+				}
+			} else
+				op = 0;
+		}
+		// a voice born without a window behind its birth in this slab: its filter still starts from
+		// rest - an entry without frames carries the flag
+		if(FILT && pending_fresh && f == fb - 1) {
+			if(e < elim) {
+				Int4 *dst = (Int4 *)(win + (size_t)e * A2D_WIN_WORDS);
+				const Int4 z = { 0, 0, 0, 0 };
+#pragma unroll
+				for(int k = 0; k < A2D_WIN_WORDS / 4; ++k)
+					dst[k] = z;
+				win[(size_t)e * A2D_WIN_WORDS + WE_HEAD] = (int)((unsigned)(f & 0xff) | WH_FRESH);
+				++e;
+			}
+			pending_fresh = 0;
+		}
+	}
+	if(listed)
+		widx[(size_t)(fb - fa) * nlist + idx] = e;
+
+	if(live) {
+#pragma unroll
+		for(int o = 0; o < NOSC; ++o) {
+			int *w = ustate + (size_t)uu[o] * A2D_USTATE;
+			w[OW_MODE] = os[o].mode; w[OW_WAVE] = os[o].wave; w[OW_DPHASE] = (int)os[o].dphase;
+			w[OW_PHASE_LO] = (int)(unsigned)os[o].phase; w[OW_PHASE_HI] = (int)(unsigned)(os[o].phase >> 32);
+			w[OW_PRAMPING] = os[o].p_ramping;
+			ramp_store(w + OW_P, os[o].p);
+			ramp_store(w + OW_A, os[o].a);
+			w[OW_NOISE] = os[o].noise;
+			w[OW_SEED] = (int)os[o].seed;
+		}
+		if(FILT) {
+			int *wf = ustate + (size_t)uu[NOSC] * A2D_USTATE;
+			ramp_store(wf + FW_Q, fs.q);
+			wf[FW_LP] = fs.lp; wf[FW_BP] = fs.bp; wf[FW_HP] = fs.hp; wf[FW_F1] = fs.f1;
+			wf[FW_F1NEXT] = fs.f1next; wf[FW_RAMP] = fs.ramp;
+		}
+		int *wp = ustate + (size_t)uu[NOSC + FILT] * A2D_USTATE;
+		ramp_store(wp + PW_VOL, vol);
+		ramp_store(wp + PW_PAN, pan);
+		vactive[slot] = active;
+	}
+}
+
+template<int NOSC, int FILT>
+__global__ __launch_bounds__(64)
+void k_win_ctl(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int skip_empty,
+		int fa, int fb, int *__restrict__ win, unsigned *__restrict__ widx, unsigned *__restrict__ wtop, unsigned wcap,
+		const A2DVoice *__restrict__ voices, int *ustate, int *vactive, const A2DWave *__restrict__ waves,
+		const uint32_t *__restrict__ ptab)
+{
+	win_ctl_body<NOSC, FILT>(pp, list, nlist, (int)(blockIdx.x * 64 + threadIdx.x), skip_empty, fa, fb, win, widx, wtop, wcap,
+			voices, ustate, vactive, waves, ptab);
+}
+
+// ---------------------------------------------------------------------------
+// the render passes: lane = frame
+// ---------------------------------------------------------------------------
+#define WIN_FCH 4		// fragments of a chunk (bus sums in registers)
+#define WIN_WPB 4		// wavefronts per workgroup of k_win_render
+
+struct WinE { Int4 q[A2D_WIN_WORDS / 4]; };
+DEV WinE win_load(const int *win, unsigned e)
+{
+	WinE E;
+#pragma unroll
+	for(int k = 0; k < A2D_WIN_WORDS / 4; ++k)
+		E.q[k] = sload4(win + (size_t)e * A2D_WIN_WORDS + 4 * k);
+	return E;
+}
+DEV int win_word(const WinE &E, int k) { return E.q[k >> 2][k & 3]; }
+
+// the oscillators of one window: what they leave in the voice's scratch buffer for this lane's frame
+// (fl = frame within the window; 'in' = the lane holds one)
+template<int NOSC>
+DEV int win_oscs(const WinE &E, const CoefRsrc rs, int fl, bool in)
+{
+	const unsigned head = (unsigned)win_word(E, WE_HEAD);
+	int x = 0;
+#pragma unroll
+	for(int o = 0; o < NOSC; ++o) {
+		const unsigned m = (head >> (26 + 2 * o)) & 3u;
+		const int b = WE_OSC + 6 * o;
+		if(m == WM_TAPS) {
+			if(in) {
+				const uint64_t ph = (uint64_t)(unsigned)win_word(E, b + WO_B) | ((uint64_t)(unsigned)win_word(E, b + WO_C) << 32);
+				const unsigned dph = (unsigned)win_word(E, b + WO_DPH);
+				const unsigned t1 = tap_phase(ph, (unsigned)fl * dph), t2 = t1 + ((dph >> 16) >> 1);
+				const int cb = coef_base((unsigned)win_word(E, b + WO_A));
+				const Coef4 k1 = coef_at(rs, cb, t1), k2 = coef_at(rs, cb, t2);
+				const int ak = wadd(win_word(E, b + WO_AK), wmul(win_word(E, b + WO_DA), fl));
+				x = wadd(x, mul64s(hermite_c(k1, t1) + hermite_c(k2, t2), ak, 17));
+			}
+		} else if(m == WM_NOISE) {
+			// wtosc_noise, wtosc.c:129-152: which draw of the LCG a frame holds is a prefix count over
+			// the window's frames, the draws themselves a uniform loop from the window's seed
+			const unsigned dph = (unsigned)win_word(E, b + WO_DPH);
+			const unsigned phk = (unsigned)win_word(E, b + WO_C) + (unsigned)(in ? fl : 0) * dph;
+			const bool draw = in && ((dph >= (1u << 23)) || (((phk + dph) ^ phk) >> 23));
+			const unsigned long long dm = __ballot(draw);
+			const int me = (int)(threadIdx.x & 63);
+			const unsigned long long below = (me >= 63) ? ~0ull : ((2ull << me) - 1ull);
+			const int mine = __popcll(dm & below), total = __popcll(dm);
+			int held = win_word(E, b + WO_B), myval = held;
+			unsigned st = (unsigned)win_word(E, b + WO_A);
+			for(int j = 1; j <= total; ++j) {
+				held = noise_next(st) - 32767;
+				if(j == mine)
+					myval = held;
+			}
+			if(in) {
+				const int ak = wadd(win_word(E, b + WO_AK), wmul(win_word(E, b + WO_DA), fl));
+				x = wadd(x, wmul(myval, ak >> 10) >> 6);
+			}
+		}
+	}
+	return x;
+}
+
+// panmix_process12 (panmix.c:78-125) of one window for input y
+DEV void win_pan(const WinE &E, int y, int fl, bool in, int &acc0, int &acc1)
+{
+	if(in) {
+		const int vk = wadd(win_word(E, WE_VOL), wmul(win_word(E, WE_DVOL), fl));
+		const int pk = wadd(win_word(E, WE_PAN), wmul(win_word(E, WE_DPAN), fl));
+		const int vp = mul64s(pk, vk, 24);
+		int v0 = wsub(vk, vp), v1 = wadd(vk, vp);
+		if((unsigned)win_word(E, WE_HEAD) & WH_CLAMP) {
+			const int lim = wshl(vk, 1);
+			if(v0 > lim) v0 = lim;
+			if(v1 > lim) v1 = lim;
+		}
+		acc0 = wadd(acc0, mul64s(y, v0, 24));
+		acc1 = wadd(acc1, mul64s(y, v1, 24));
+	}
+}
+
+template<int NOSC>
+__global__ __launch_bounds__(64 * WIN_WPB)
+void k_win_render(const int *__restrict__ list, int nlist, int vpw, int fa, int fb, const int *__restrict__ win,
+		const unsigned *__restrict__ widx, const A2DVoice *__restrict__ voices, const int *__restrict__ wavecoef,
+		int *__restrict__ busmem, int dbg)
+{
+	const int wv = rfl((int)(threadIdx.x >> 6));
+	const int lane = threadIdx.x & 63;
+	const int gw = (int)blockIdx.x * WIN_WPB + wv;
+	const int ngroups = (nlist + vpw - 1) / vpw;
+	const int group = gw % ngroups, chunk = gw / ngroups;
+	const int f0 = fa + chunk * WIN_FCH;
+	if(f0 >= fb)
+		return;
+	const int nf = min(WIN_FCH, fb - f0);
+	const int first = group * vpw, nv = min(vpw, nlist - first);
+	const CoefRsrc rs = coef_rsrc(wavecoef);
+	int acc0[WIN_FCH], acc1[WIN_FCH];
+#pragma unroll
+	for(int j = 0; j < WIN_FCH; ++j)
+		acc0[j] = acc1[j] = 0;
+	int cur_off = -1, cur_nch = 2;
+	for(int v = 0; v < nv; ++v) {
+		const int idx = first + v;
+		const int slot = sload(list + idx);
+		const int voff = sload(&voices[slot].out_off);
+		if(voff != cur_off) {
+			flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+			cur_off = voff;
+			cur_nch = sload(&voices[slot].out_nch);
+		}
+		unsigned eb = (unsigned)sload(widx + (size_t)(f0 - fa) * nlist + idx);
+#pragma unroll
+		for(int j = 0; j < WIN_FCH; ++j) {
+			if(j < nf) {
+				const unsigned ee = (unsigned)sload(widx + (size_t)(f0 + j + 1 - fa) * nlist + idx);
+				for(unsigned e = eb; e < ee; ++e) {
+					const WinE E = win_load(win, e);
+					const unsigned head = (unsigned)win_word(E, WE_HEAD);
+					const int fl = lane - (int)((head >> 8) & 0xffu);
+					const bool in = (unsigned)fl < ((head >> 16) & 0xffu);
+					const int x = win_oscs<NOSC>(E, rs, fl, in);
+					win_pan(E, x, fl, in, acc0[j], acc1[j]);
+				}
+				eb = ee;
+			}
+		}
+	}
+	flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+}
+
+// ---- with filter12: a workgroup owns its voices for the whole slab -----------------------------
+#define WINF_PITCH 65
+#define WINF_MAXW  16		// wavefronts per workgroup (one filters)
+// LDS: three tiles [vpg][65], then the per-wavefront bus sums of two fragments
+DEV int winf_lds_words(int vpg, int nw) { return 3 * vpg * WINF_PITCH + 2 * nw * 2 * 64 + 2 * nw * 2; }
+
+template<int NOSC>
+__global__ __launch_bounds__(64 * WINF_MAXW)
+void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, int fb, const int *__restrict__ win,
+		const unsigned *__restrict__ widx, const A2DVoice *__restrict__ voices, int *ustate,
+		const int *__restrict__ wavecoef, int *__restrict__ busmem, int dbg)
+{
+	extern __shared__ int winf_lds[];
+	const int nw = (int)(blockDim.x >> 6);		// >= 2
+	const int wv = rfl((int)(threadIdx.x >> 6));
+	const int lane = threadIdx.x & 63;
+	const int first = (int)blockIdx.x * vpg, nv = min(vpg, nlist - first);
+	const int nfr = fb - fa;
+	int *const tiles = winf_lds;
+	int *const part = winf_lds + 3 * vpg * WINF_PITCH;		// [2][nw][2][64]
+	int *const part_off = part + 2 * nw * 2 * 64;			// [2][nw] bus offset
+	int *const part_nch = part_off + 2 * nw;			// [2][nw]
+	const CoefRsrc rs = coef_rsrc(wavecoef);
+
+	// the filter wavefront: lane = voice, d1 / d2 in registers over the slab
+	int d1 = 0, d2 = 0, ufilt = -1;
+	if(wv == 0 && lane < nv) {
+		ufilt = voices[list[first + lane]].unit[NOSC];
+		d1 = ustate[(size_t)ufilt * A2D_USTATE + FW_D1A];
+		d2 = ustate[(size_t)ufilt * A2D_USTATE + FW_D2A];
+	}
+	// the others: a contiguous share of the voices each (neighbours in the list share their bus)
+	const int nworkers = nw - 1;
+	const int per = (nv + nworkers - 1) / nworkers;
+	const int lo = min(nv, (wv - 1) * per), hi = wv ? min(nv, lo + per) : 0;
+
+	for(int s = 0; s < nfr + 3; ++s) {
+		if(wv == 0) {
+			const int g = s - 1;		// fragment (of the slab) to filter
+			if(g >= 0 && g < nfr && lane < nv) {
+				int *const row = tiles + (g % 3) * vpg * WINF_PITCH + lane * WINF_PITCH;
+				const int idx = first + lane;
+				unsigned e = widx[(size_t)g * nlist + idx];
+				const unsigned ee = widx[(size_t)(g + 1) * nlist + idx];
+				for(; e < ee; ++e) {
+					// f12_process, filter12.c:97-118, over the window's frames in place
+					const Int4 *E = (const Int4 *)(win + (size_t)e * A2D_WIN_WORDS);
+					const Int4 q0 = E[0], q1 = E[1];
+					const unsigned head = (unsigned)q0.x;
+					int f0v = q0.y, qv = q0.w;
+					const int df = q0.z, qd = q1.x, lp = q1.y, bp = q1.z, hp = q1.w;
+					const int off = (int)((head >> 8) & 0xffu), len = (int)((head >> 16) & 0xffu);
+					if(head & WH_FRESH)
+						d1 = d2 = 0;
+					for(int k = 0; k < len; ++k) {
+						const int xin = row[off + k];
+						const int fq = f0v >> 12, qq = qv >> 12;
+						const int d1s = d1 >> 4;
+						const int l = wadd(d2, wmul(fq, d1s) >> 8);
+						const int h = wsub(wsub(xin >> 5, l), wmul(qq, d1s) >> 8);
+						const int b = wadd(wmul(fq, h >> 4) >> 8, d1);
+						row[off + k] = wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3;
+						d1 = b;
+						d2 = l;
+						f0v = wadd(f0v, df);
+						qv = wadd(qv, qd);
+					}
+				}
+			}
+		} else {
+			// (the last worker first: the bus sums of the fragment panned in the step before)
+			if(wv == nw - 1 && s >= 3) {
+				const int pb = (s - 3) & 1, g = s - 3;
+#pragma unroll
+				for(int ch = 0; ch < 2; ++ch) {
+					int sum = 0, off = -1, nch = 2;
+					for(int w = 1; w <= nw; ++w) {
+						const int woff = w < nw ? part_off[pb * nw + w] : -2;
+						if(woff != off) {
+							if(off >= 0 && sum && !(dbg & 1))
+								atomicAdd(busmem + off + ((size_t)(fa + g) * nch + ch) * A2D_FRAG + lane, sum);
+							sum = 0;
+							off = woff;
+							nch = w < nw ? part_nch[pb * nw + w] : 2;
+						}
+						if(w < nw && woff >= 0)
+							sum = wadd(sum, part[((pb * nw + w) * 2 + ch) * 64 + lane]);
+					}
+				}
+			}
+			// oscillators of fragment s into its tile
+			if(s < nfr) {
+				int *const tile = tiles + (s % 3) * vpg * WINF_PITCH;
+				for(int v = lo; v < hi; ++v) {
+					const int idx = first + v;
+					unsigned e = (unsigned)sload(widx + (size_t)s * nlist + idx);
+					const unsigned ee = (unsigned)sload(widx + (size_t)(s + 1) * nlist + idx);
+					for(; e < ee; ++e) {
+						const WinE E = win_load(win, e);
+						const unsigned head = (unsigned)win_word(E, WE_HEAD);
+						const int fl = lane - (int)((head >> 8) & 0xffu);
+						const bool in = (unsigned)fl < ((head >> 16) & 0xffu);
+						const int x = win_oscs<NOSC>(E, rs, fl, in);
+						if(in)
+							tile[v * WINF_PITCH + lane] = x;
+					}
+				}
+			}
+			// pan stage of fragment s - 2 out of its tile
+			if(s >= 2 && s - 2 < nfr) {
+				const int g = s - 2, pb = g & 1;
+				const int *const tile = tiles + (g % 3) * vpg * WINF_PITCH;
+				int a0 = 0, a1 = 0, cur_off = -1, cur_nch = 2;
+				for(int v = lo; v < hi; ++v) {
+					const int idx = first + v;
+					const int slot = sload(list + idx);
+					const int voff = sload(&voices[slot].out_off);
+					if(voff != cur_off) {
+						if(cur_off >= 0 && !(dbg & 1)) {
+							int *dst = busmem + cur_off + (size_t)(fa + g) * cur_nch * A2D_FRAG;
+							if(a0) atomicAdd(&dst[lane], a0);
+							if(a1) atomicAdd(&dst[A2D_FRAG + lane], a1);
+						}
+						a0 = a1 = 0;
+						cur_off = voff;
+						cur_nch = sload(&voices[slot].out_nch);
+					}
+					unsigned e = (unsigned)sload(widx + (size_t)g * nlist + idx);
+					const unsigned ee = (unsigned)sload(widx + (size_t)(g + 1) * nlist + idx);
+					for(; e < ee; ++e) {
+						const WinE E = win_load(win, e);
+						const unsigned head = (unsigned)win_word(E, WE_HEAD);
+						const int fl = lane - (int)((head >> 8) & 0xffu);
+						const bool in = (unsigned)fl < ((head >> 16) & 0xffu);
+						const int y = in ? tile[v * WINF_PITCH + lane] : 0;
+						win_pan(E, y, fl, in, a0, a1);
+					}
+				}
+				part[((pb * nw + wv) * 2 + 0) * 64 + lane] = a0;
+				part[((pb * nw + wv) * 2 + 1) * 64 + lane] = a1;
+				if(lane == 0) {
+					part_off[pb * nw + wv] = cur_off;
+					part_nch[pb * nw + wv] = cur_nch;
+				}
+			}
+		}
+		__syncthreads();
+	}
+	if(wv == 0 && lane < nv) {
+		ustate[(size_t)ufilt * A2D_USTATE + FW_D1A] = d1;
+		ustate[(size_t)ufilt * A2D_USTATE + FW_D2A] = d2;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+int a2d_launch_win_ctl(const A2DParams *dparams, const A2DParams &hp, int nosc, int filt, const int *dlist, int nlist,
+		int skip_empty, int fa, int fb, int *win, unsigned *widx, unsigned *wtop, unsigned wcap, void *stream)
+{
+	if(nlist <= 0 || fb <= fa)
+		return 0;
+	const int nblocks = (nlist + 63) / 64;
+#define CTL_LAUNCH(N, F) hipLaunchKernelGGL((k_win_ctl<N, F>), dim3(nblocks), dim3(64), 0, (hipStream_t)stream, dparams, dlist, \
+		nlist, skip_empty, fa, fb, win, widx, wtop, wcap, hp.voices, hp.ustate, hp.vactive, hp.waves, hp.ptab)
+	if(nosc == 1 && !filt)
+		CTL_LAUNCH(1, 0);
+	else if(nosc == 2 && !filt)
+		CTL_LAUNCH(2, 0);
+	else if(nosc == 1)
+		CTL_LAUNCH(1, 1);
+	else
+		CTL_LAUNCH(2, 1);
+#undef CTL_LAUNCH
+	return (int)hipGetLastError();
+}
+
+int a2d_launch_win_render(const A2DParams &hp, int nosc, int filt, const int *dlist, int nlist, int fa, int fb,
+		const int *win, const unsigned *widx, void *stream)
+{
+	if(nlist <= 0 || fb <= fa)
+		return 0;
+	if(!filt) {
+		// voices per wavefront: about 8 192 wavefronts in the launch, 4 to 32 voices to an atomic
+		const int nchunks = (fb - fa + WIN_FCH - 1) / WIN_FCH;
+		static const int force = getenv("A2AMD_WVPW") ? atoi(getenv("A2AMD_WVPW")) : 0;
+		int vpw = force > 0 ? force : (int)std::min<long long>(std::max<long long>(((long long)nlist * nchunks + 8191) / 8192, 1), 32);
+		vpw = std::min(std::max(vpw, 1), 64);
+		const int ngroups = (nlist + vpw - 1) / vpw;
+		const int nwaves = ngroups * nchunks;
+		const int nblocks = (nwaves + WIN_WPB - 1) / WIN_WPB;
+		if(nosc == 1)
+			hipLaunchKernelGGL((k_win_render<1>), dim3(nblocks), dim3(64 * WIN_WPB), 0, (hipStream_t)stream, dlist, nlist, vpw,
+					fa, fb, win, widx, hp.voices, hp.wavecoef, hp.busmem, hp.debug);
+		else
+			hipLaunchKernelGGL((k_win_render<2>), dim3(nblocks), dim3(64 * WIN_WPB), 0, (hipStream_t)stream, dlist, nlist, vpw,
+					fa, fb, win, widx, hp.voices, hp.wavecoef, hp.busmem, hp.debug);
+	} else {
+		// voices per workgroup = lanes of its filter wavefront: spread out until every CU has a couple of
+		// workgroups (a workgroup takes as long as its filter chain whatever its voice count), then fill up
+		static const int force = getenv("A2AMD_WFVPG") ? atoi(getenv("A2AMD_WFVPG")) : 0;
+		int vpg = force > 0 ? force : std::min(std::max((nlist + 511) / 512, 1), 48);
+		vpg = std::min(std::max(vpg, 1), 48);	// (48 rows x 3 tiles + the bus sums: within 64 KB of LDS)
+		// wavefronts: the filter's + one per ~4 voices
+		static const int forcew = getenv("A2AMD_WFWAVES") ? atoi(getenv("A2AMD_WFWAVES")) : 0;
+		int nw = forcew > 1 ? forcew : 1 + std::min(std::max((vpg + 3) / 4, 1), WINF_MAXW - 1);
+		nw = std::min(std::max(nw, 2), WINF_MAXW);
+		const int nblocks = (nlist + vpg - 1) / vpg;
+		const size_t dyn = (size_t)(3 * vpg * WINF_PITCH + 2 * nw * 2 * 64 + 2 * nw * 2) * sizeof(int);
+		if(nosc == 1)
+			hipLaunchKernelGGL((k_win_render_f<1>), dim3(nblocks), dim3(64 * nw), dyn, (hipStream_t)stream, dlist, nlist, vpg,
+					fa, fb, win, widx, hp.voices, hp.ustate, hp.wavecoef, hp.busmem, hp.debug);
+		else
+			hipLaunchKernelGGL((k_win_render_f<2>), dim3(nblocks), dim3(64 * nw), dyn, (hipStream_t)stream, dlist, nlist, vpg,
+					fa, fb, win, widx, hp.voices, hp.ustate, hp.wavecoef, hp.busmem, hp.debug);
+	}
+	return (int)hipGetLastError();
+}

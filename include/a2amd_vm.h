@@ -155,6 +155,16 @@ int a2amd_vm_adopt(a2amd_ctx *ctx, int head_unit, int prog, const a2amd_vm_state
 		const int32_t *wr_unit, const uint8_t *wr_reg, uint32_t now, uint32_t msdur,
 		const a2amd_vm_env *envs, int nenv);
 
+/* A voice whose program a2amd_vm_analyze() cannot vouch for as a whole - it reaches END, SLEEP, CALL /
+ * RETURN, WAKE / FORCE, spawning, messages, RAND, a register divisor that may be zero, a loop it cannot
+ * bound: every note of every song - is taken for the stretch of its future that needs none of that: the
+ * host runs the voice's coming VM runs ahead on a copy of its registers (they depend on nothing else)
+ * up to the first one that meets such an instruction.  That run, and what follows, is the engine's:
+ * returns 1 and *when = the engine time (24:8) it starts at - the voice has to be recalled in the
+ * fragment that holds that time, before the engine processes it there - or 0 for a voice taken for
+ * good (or not taken). */
+int a2amd_vm_exit_time(a2amd_ctx *ctx, int head_unit, uint32_t *when);
+
 /* 1 while the voice 'head_unit' belongs to is run by the device VM. */
 int a2amd_vm_adopted(a2amd_ctx *ctx, int head_unit);
 

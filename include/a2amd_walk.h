@@ -62,9 +62,11 @@ int a2amd_units_hold(void *state, unsigned dev, const uint32_t *slots, unsigned 
  *   msdur           A2_state.msdur
  * Returns 0 (adopted: the voice now counts as asleep for good - report its default windows like a
  * sleeping voice's, never hand it to the engine without a2amd_units_vm_recall()), -1 (never, for this
- * program from this pc: outside the subset), -2 (not now). */
+ * program from this pc: outside the subset), -2 (not now).
+ * *has_exit = 1: the voice was taken for a stretch only (a2amd_vm_exit_time(), a2amd_vm.h) - it has to be
+ * recalled and handed to the engine in the fragment that holds the engine time *exit_when. */
 int a2amd_units_vm_adopt(const void *head, const uint32_t *code, unsigned nwords, const void *vmstate,
-		void *const *wr_unit, void *const *wr_fn, uint32_t now, uint32_t msdur);
+		void *const *wr_unit, void *const *wr_fn, uint32_t now, uint32_t msdur, int *has_exit, uint32_t *exit_when);
 /* build stamps ("A2AMD_SRCHASH:<32 hex>", see a2amd_source_stamp() in a2amd.h) */
 const char *a2amd_units_source_stamp(void);
 const char *a2amd_walk_source_stamp(void);
