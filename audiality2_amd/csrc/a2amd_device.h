@@ -150,6 +150,8 @@ struct A2DVmVoice {
 	int32_t  cut[A2D_VM_MAXCUT][4];	// ... and their cutoff rampers (A2_filter12.cutoff, filter12.c:38)
 	A2DVmEnv env[A2D_VM_MAXENV];	// the voice's env units, nenv of them
 	int32_t  nenv;
+	uint32_t exit_when;		// has_exit: the VM run that starts at this wake time is the engine's (a2amd_vm_exit_time):
+	int32_t  has_exit;		// the device VM stops in front of it (the walk has recalled the voice by then)
 	int32_t  r[64];			// A2_vmstate.r
 };
 
@@ -253,15 +255,15 @@ int a2d_launch_leaf_osc2pan(const A2DParams *dparams, const A2DParams &hp, const
 int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc, int filt, const int *dlist,
 		int nlist, int vpw, void *stream, int skip_empty = 0);
 // Round 5 (a2amd_win.hip): the same voices in two passes.  The control pass (lane = voice) walks the
-// records of fragments [fa, fb) and leaves one closed-form entry of A2D_WIN_WORDS words per window
-// in 'win' (entry indices from the pool counter wtop[0], at most wcap; wtop[1] != 0: the pool was
-// too small) and, per fragment and list position, where the voice's entries begin: widx[(f - fa) *
-// nlist + i], f = fa .. fb.  The render pass (lane = frame) evaluates the entries.
+// records of fragments [fa, fb) and leaves closed-form window entries of A2D_WIN_WORDS words: the first
+// window of fragment f for list position i in its slot wslot[(f - fa) * nlist + i], further windows of
+// that fragment in the pool wext from index widx[(f - fa) * nlist + i] on (pool indices from the counter
+// wtop[0], at most wcap; wtop[1] != 0: the pool was too small).  The render pass (lane = frame) evaluates them.
 #define A2D_WIN_WORDS 24
 int a2d_launch_win_ctl(const A2DParams *dparams, const A2DParams &hp, int nosc, int filt, const int *dlist, int nlist,
-		int skip_empty, int fa, int fb, int *win, unsigned *widx, unsigned *wtop, unsigned wcap, void *stream);
+		int skip_empty, int fa, int fb, int *wslot, int *wext, unsigned *widx, unsigned *wtop, unsigned wcap, void *stream);
 int a2d_launch_win_render(const A2DParams &hp, int nosc, int filt, const int *dlist, int nlist, int fa, int fb,
-		const int *win, const unsigned *widx, void *stream);
+		const int *wslot, const int *wext, const unsigned *widx, void *stream);
 // ... all four kinds in one launch: lists[k] / counts[k] for (nosc, filt) = (1,0) (2,0) (1,1) (2,1)
 int a2d_launch_leaf_recs_all(const A2DParams *dparams, const A2DParams &hp, const int *const *lists, const int *counts,
 		int vpw, void *stream);

@@ -102,7 +102,7 @@ void a2amd_close(a2amd_ctx *c)
 		hipEventDestroy(c->grp_ev);
 	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
 	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
-	hipFree(c->d_win.d); hipFree(c->d_widx.d); hipFree(c->d_wtop);
+	hipFree(c->d_win.d); hipFree(c->d_wext.d); hipFree(c->d_widx.d); hipFree(c->d_wtop);
 	hipFree(c->d_waves.d); hipFree(c->d_wavepool.d); hipFree(c->d_wavecoef.d); hipFree(c->d_busmem.d);
 	vm_close(c);
 	hipFree(c->capture.d); hipFree(c->capture.d_fragpos);
@@ -711,6 +711,20 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 		return c->fail(A2AMD_ESTATE, "write to unit %d of a voice the device VM runs: a2amd_vm_recall() first", ui);
 	c->building = -1;
 	start &= 255;		// a2_VoiceControl, core.c:148
+	if(dur >= 256 && ((u.kind == A2AMD_WTOSC && (reg == 1 || reg == 2)) || u.kind == A2AMD_PANMIX ||
+			(u.kind == A2AMD_FILTER12 && reg == 1))) {
+		// a glide: the ramp lasts (start + dur) >> 8 frames from the frame the open window starts at (somewhere in
+		// the open fragment), then one more window settles the ramper (a2_PrepareRamper's first branch,
+		// a2_dsp.h:131-135; wtosc's extra pitch update, wtosc.c:99-100) - a margin of three fragments covers both
+		HVoice &v = c->voices[u.voice];
+		const uint64_t until = c->walk_time + 64 + ((start + dur) >> 8) + 192;
+		if(until > v.moving_until)
+			v.moving_until = until;
+		if(!v.listed_moving) {
+			v.listed_moving = true;
+			c->moving.push_back(u.voice);
+		}
+	}
 	switch(u.kind) {
 	  case A2AMD_WTOSC:
 		switch(reg) {

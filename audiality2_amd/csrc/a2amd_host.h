@@ -193,6 +193,12 @@ struct HVoice {
 	int own_off = -1, own_nch = 0;
 	int cls = 0;			// launch class (CLS_*), set when the lists are rebuilt
 	int vm = -1;			// slot of the device VM that runs this voice's program (a2amd_vm_adopt), or -1
+	// a control of the voice is gliding (a write with a duration: pitch / amplitude / q / volume / pan): until
+	// this walk_time the voice is rendered by the window kernels even in batches without records - the quiet
+	// kernels take a voice that is not settled fragment by fragment on the scalar unit (4x a settled one)
+	uint64_t moving_until = 0;
+	bool listed_moving = false;	// in a2amd_ctx::moving
+	long long moving_run = -1;	// serial_base of the batch in which upload() gave it the stand-in record run
 };
 
 struct DepthRange { int fast_first = 0, fast_count = 0, fbd_first = 0, fbd_count = 0, gen_first = 0, gen_count = 0,
@@ -463,9 +469,10 @@ struct a2amd_ctx {
 	bool dist_local = false;	// one of several contexts of this process (a2amd_dist_init_local)
 	hipEvent_t grp_ev = nullptr;	// ... its SUBTREES phase is done / its partial has been taken
 
-	// the window kernels (a2amd_win.hip): the entries of a slab of the batch, where each voice's begin
-	// per fragment, the pool counter + overflow flag
-	DevBuf<int> d_win;
+	// the window kernels (a2amd_win.hip): a slab's slots (one per fragment and voice), the pool of further
+	// windows, where each voice's begin per fragment, the pool counter + overflow flag
+	std::vector<int> moving;	// voices with moving_until set
+	DevBuf<int> d_win, d_wext;
 	DevBuf<unsigned> d_widx;
 	unsigned *d_wtop = nullptr;
 

@@ -315,7 +315,7 @@ int upload(a2amd_ctx *c)
 				memcmp(c->fragframes, c->blob_frames, (size_t)c->nfrags * sizeof(unsigned)) ? 10 : 12;
 		dbg_why()[why] += 1;
 	}
-	if(c->blob_quiet && c->with_recs.empty() && c->prev_with_recs.empty() && !c->voices_dirty &&
+	if(c->blob_quiet && c->with_recs.empty() && c->prev_with_recs.empty() && c->moving.empty() && !c->voices_dirty &&
 			!c->udesc_dirty && !c->waves_dirty && !c->lists_dirty && !c->ptab_dirty && !c->vm.list_dirty &&
 			c->dirty_voices.empty() && c->fbd_to_zero.empty() && c->bus_used <= c->d_busmem.cap) {
 		bool inject = false;
@@ -494,10 +494,52 @@ int upload(a2amd_ctx *c)
 		sc_val[nsc_used++] = r;
 		now[nnow++] = vi;
 	}
+	// Voices without records whose controls are still gliding (HVoice::moving_until): the quiet kernels take an
+	// unsettled voice fragment by fragment on the scalar unit for the whole batch; the window kernels resolve its
+	// rampers in closed form.  They are given ONE shared stand-in record that belongs to no fragment - a run the
+	// quiet kernels skip and the control pass never consumes: default windows throughout.
+	static const bool no_moving = getenv("A2AMD_NO_MOVING") != nullptr;
+	if(!c->moving.empty()) {
+		int nop_at = -1;
+		const uint64_t t0 = c->vm.batch_time;	// walk_time when this batch began
+		for(size_t i = 0; i < c->moving.size();) {
+			const int vi = c->moving[i];
+			HVoice &v = c->voices[vi];
+			if(!(v.live || v.dying) || v.moving_until <= t0) {
+				v.listed_moving = false;
+				v.moving_until = 0;
+				c->moving[i] = c->moving.back();
+				c->moving.pop_back();
+				continue;
+			}
+			++i;
+			if(no_moving || !v.recs.empty() || v.vm >= 0 || c->lists_dirty || v.mode_mix || !v.resolved ||
+					!(v.cls == CLS_OSCPAN || v.cls == CLS_OSC2PAN || v.cls == CLS_OSCFILTPAN))
+				continue;
+			if(nop_at < 0) {
+				nop_at = (int)recs.size();
+				A2DRec nop = { A2D_HEAD(0xffff, R_NOP, 0, 0), 0, 0, 0 };
+				recs.push_back(nop);
+			}
+			const A2DRun r = { nop_at, 1 };
+			sc_idx.resize(nsc_used + 1 + c->prev_with_recs.size());
+			sc_val.resize(sc_idx.size());
+			sc_idx[nsc_used] = vi;
+			sc_val[nsc_used++] = r;
+			now.resize(nnow + 1);
+			now[nnow++] = vi;
+			v.moving_run = c->serial_base;
+			v.listed_recs = true;
+		}
+	}
 	now.resize(nnow);
 	c->with_recs.swap(now);
+	if(sc_idx.size() < nsc_used + c->prev_with_recs.size()) {
+		sc_idx.resize(nsc_used + c->prev_with_recs.size());
+		sc_val.resize(sc_idx.size());
+	}
 	for(int vi : c->prev_with_recs)
-		if(vi < (int)nv && c->voices[vi].recs.empty()) {
+		if(vi < (int)nv && c->voices[vi].recs.empty() && c->voices[vi].moving_run != c->serial_base) {
 			A2DRun z = { 0, 0 };
 			sc_idx[nsc_used] = vi;
 			sc_val[nsc_used++] = z;
@@ -938,9 +980,9 @@ bool depth_has_mutes(const a2amd_ctx *c, int d)
 // The wavetable leaf voices that carry records this batch - the four host-made class lists (wtosc |
 // 2 x wtosc [-> filter12] -> panmix; the last one with its quiet voices) and the three lists of voices
 // whose records the device VM has just written - through the window kernels (a2amd_win.hip): per slab
-// of the batch the control pass of every list, then the render pass of every list.  The entry pool is
-// sized by the bound the control pass allocates by (a window per fragment and voice + one per record);
-// a batch whose entries would not fit A2AMD_WIN_MB (1 024) is cut into slabs of fragments.
+// of the batch the control pass of every list, then the render pass of every list.  A slot per fragment
+// and voice, a pool of further windows sized by the bound the control pass allocates by (one per record);
+// a batch whose slots would not fit A2AMD_WIN_MB (1 024) is cut into slabs of fragments.
 static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *counts)
 {
 	struct Job { int nosc, filt, n, skip; const int *list; };
@@ -969,16 +1011,17 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 			(A2D_WIN_WORDS * sizeof(int));
 	const int nfrags = c->nfrags;
 	int per = nfrags;
-	if(nvoices * (size_t)nfrags + nrec > budget)
-		per = (int)std::min<size_t>((size_t)nfrags, std::max<size_t>(1, (budget > nrec ? budget - nrec : 1) / nvoices));
-	const size_t cap = nvoices * (size_t)per + nrec;
+	if(nvoices * (size_t)nfrags > budget)
+		per = (int)std::min<size_t>((size_t)nfrags, std::max<size_t>(1, budget / nvoices));
+	const size_t nslots = nvoices * (size_t)per, cap = std::max<size_t>(nrec, 1);
 	if(cap >= ((size_t)1 << 32))
-		return c->fail(A2AMD_EUNSUPPORTED, "a batch of %zu windows", cap);
-	if(cap > c->d_win.cap || nvoices * (size_t)(per + 1) > c->d_widx.cap || !c->d_wtop) {
+		return c->fail(A2AMD_EUNSUPPORTED, "a batch of %zu records", cap);
+	if(nslots > c->d_win.cap || cap > c->d_wext.cap || nslots > c->d_widx.cap || !c->d_wtop) {
 		if(c->capturing)
 			return c->fail(A2AMD_ESTATE, "window pool too small inside a graph capture");
-		if(int r = grow(c, c->d_win, cap, A2D_WIN_WORDS, false)) return r;
-		if(int r = grow(c, c->d_widx, nvoices * (size_t)(per + 1), 1, false)) return r;
+		if(int r = grow(c, c->d_win, nslots, A2D_WIN_WORDS, false)) return r;
+		if(int r = grow(c, c->d_wext, cap, A2D_WIN_WORDS, false)) return r;
+		if(int r = grow(c, c->d_widx, nslots, 1, false)) return r;
 		if(!c->d_wtop)
 			HIPCHK(c, hipMalloc((void **)&c->d_wtop, 2 * sizeof(unsigned)));
 	}
@@ -988,18 +1031,20 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 		size_t at = 0;
 		for(int j = 0; j < nj; ++j) {
 			const Job &b = jobs[j];
-			if(a2d_launch_win_ctl(c->d_params, c->hparams, b.nosc, b.filt, b.list, b.n, b.skip, fa, fb, c->d_win.d,
-					c->d_widx.d + at, c->d_wtop, (unsigned)std::min<size_t>(c->d_win.cap, 0xffffffffu), c->stream))
+			if(a2d_launch_win_ctl(c->d_params, c->hparams, b.nosc, b.filt, b.list, b.n, b.skip, fa, fb,
+					c->d_win.d + at * A2D_WIN_WORDS, c->d_wext.d, c->d_widx.d + at, c->d_wtop,
+					(unsigned)std::min<size_t>(c->d_wext.cap, 0xffffffffu), c->stream))
 				return c->fail(A2AMD_EHIP, "window control launch failed: %s", hipGetErrorString(hipGetLastError()));
-			at += (size_t)b.n * (size_t)(fb - fa + 1);
+			at += (size_t)b.n * (size_t)(fb - fa);
 			++c->stats.launches;
 		}
 		at = 0;
 		for(int j = 0; j < nj; ++j) {
 			const Job &b = jobs[j];
-			if(a2d_launch_win_render(c->hparams, b.nosc, b.filt, b.list, b.n, fa, fb, c->d_win.d, c->d_widx.d + at, c->stream))
+			if(a2d_launch_win_render(c->hparams, b.nosc, b.filt, b.list, b.n, fa, fb, c->d_win.d + at * A2D_WIN_WORDS,
+					c->d_wext.d, c->d_widx.d + at, c->stream))
 				return c->fail(A2AMD_EHIP, "window render launch failed: %s", hipGetErrorString(hipGetLastError()));
-			at += (size_t)b.n * (size_t)(fb - fa + 1);
+			at += (size_t)b.n * (size_t)(fb - fa);
 			++c->stats.launches;
 		}
 	}
@@ -1009,7 +1054,7 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 		HIPCHK(c, hipMemcpyAsync(top, c->d_wtop, sizeof(top), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		if(top[1])
-			return c->fail(A2AMD_ESTATE, "window pool overflow (%u of %zu entries)", top[0], c->d_win.cap);
+			return c->fail(A2AMD_ESTATE, "window pool overflow (%u of %zu entries)", top[0], c->d_wext.cap);
 	}
 	return 0;
 }

@@ -1012,6 +1012,8 @@ int a2amd_vm_adopt(a2amd_ctx *c, int head, int prog, const a2amd_vm_state *st, c
 	h.voice = vi;
 	h.prog = prog;
 	h.func = st->func;
+	d.has_exit = has_exit;
+	d.exit_when = exit_when;
 	h.st = d;
 	h.has_exit = has_exit;
 	h.exit_when = exit_when;
@@ -1065,10 +1067,35 @@ int a2amd_vm_trace_host(const uint32_t *code, unsigned nwords, a2amd_vm_state *s
 			fragframes, nullptr, nfrags, nullptr, 0, nullptr, recs, cap);
 }
 
+static int trace_impl(const uint32_t *code, unsigned nwords, a2amd_vm_state *st, const int32_t *wr_unit,
+		const uint8_t *wr_reg, const int32_t *kinds, int nkinds, uint32_t now, uint32_t msdur, int32_t samplerate,
+		int32_t basepitch, const uint8_t *fragframes, const uint8_t *fragbase, unsigned nfrags, a2amd_vm_env *envs, int nenv,
+		const uint16_t *envluts, uint32_t *recs, unsigned cap, int32_t *has_exit, uint32_t *exit_when, int32_t *stay_records);
+
 int a2amd_vm_trace_host_env(const uint32_t *code, unsigned nwords, a2amd_vm_state *st, const int32_t *wr_unit,
 		const uint8_t *wr_reg, const int32_t *kinds, int nkinds, uint32_t now, uint32_t msdur, int32_t samplerate,
 		int32_t basepitch, const uint8_t *fragframes, const uint8_t *fragbase, unsigned nfrags, a2amd_vm_env *envs, int nenv,
 		const uint16_t *envluts, uint32_t *recs, unsigned cap)
+{
+	return trace_impl(code, nwords, st, wr_unit, wr_reg, kinds, nkinds, now, msdur, samplerate, basepitch, fragframes, fragbase,
+			nfrags, envs, nenv, envluts, recs, cap, nullptr, nullptr, nullptr);
+}
+
+int a2amd_vm_trace_host_exit(const uint32_t *code, unsigned nwords, a2amd_vm_state *st, const int32_t *wr_unit,
+		const uint8_t *wr_reg, const int32_t *kinds, int nkinds, uint32_t now, uint32_t msdur, int32_t samplerate,
+		int32_t basepitch, const uint8_t *fragframes, const uint8_t *fragbase, unsigned nfrags, a2amd_vm_env *envs, int nenv,
+		const uint16_t *envluts, uint32_t *recs, unsigned cap, int32_t *has_exit, uint32_t *exit_when, int32_t *stay_records)
+{
+	if(!has_exit || !exit_when)
+		return A2AMD_EINVAL;
+	return trace_impl(code, nwords, st, wr_unit, wr_reg, kinds, nkinds, now, msdur, samplerate, basepitch, fragframes, fragbase,
+			nfrags, envs, nenv, envluts, recs, cap, has_exit, exit_when, stay_records);
+}
+
+static int trace_impl(const uint32_t *code, unsigned nwords, a2amd_vm_state *st, const int32_t *wr_unit,
+		const uint8_t *wr_reg, const int32_t *kinds, int nkinds, uint32_t now, uint32_t msdur, int32_t samplerate,
+		int32_t basepitch, const uint8_t *fragframes, const uint8_t *fragbase, unsigned nfrags, a2amd_vm_env *envs, int nenv,
+		const uint16_t *envluts, uint32_t *recs, unsigned cap, int32_t *has_exit, uint32_t *exit_when, int32_t *stay_records)
 {
 	if(!code || !st || !wr_unit || !wr_reg || !kinds || !fragframes || !recs || nkinds < 1 || nkinds > A2D_MAXCHAIN)
 		return A2AMD_EINVAL;
@@ -1099,10 +1126,16 @@ int a2amd_vm_trace_host_env(const uint32_t *code, unsigned nwords, a2amd_vm_stat
 	}
 	for(int r = 0; r < A2AMD_VM_REGISTERS; ++r)
 		if(wr_unit[r] >= 0 && wr_unit[r] < nkinds) {
+			if(has_exit && !write_supported(kinds[wr_unit[r]], wr_reg[r])) {
+				d.cmap[r] = A2D_VM_TRAPWRITE;	// (as a2amd_vm_adopt under a look-ahead)
+				continue;
+			}
 			d.cmap[r] = (uint8_t)((wr_unit[r] << 4) | wr_reg[r]);
 			need_f1 |= write_needs_f1tab(kinds[wr_unit[r]], wr_reg[r]);
 		} else if(wr_unit[r] <= -3 && -3 - wr_unit[r] < nenv)
 			d.cmap[r] = (uint8_t)((A2D_VM_ENVPOS << 4) | (-3 - wr_unit[r]));
+		else if(has_exit && wr_unit[r] == -2)
+			d.cmap[r] = A2D_VM_TRAPWRITE;
 	d.nenv = nenv;
 	for(int k = 0; k < nenv; ++k) {
 		// (as a2amd_vm_adopt, with chain positions where that has backend unit ids)
@@ -1163,6 +1196,19 @@ int a2amd_vm_trace_host_env(const uint32_t *code, unsigned nwords, a2amd_vm_stat
 		}
 		int count() const { return n; }
 	} e = { buf.data(), 0, (int)cap };
+	if(has_exit) {
+		// the stretch the device VM would be given (a2amd_vm_adopt, vm_lookahead): the interpreter stops in front of
+		// the first VM run that is the engine's
+		int nrec = 0, runs = 0;
+		uint32_t when = 0;
+		vm_lookahead(d, code, K, now, &when, &nrec, &runs);
+		d.has_exit = 1;
+		d.exit_when = when;
+		*has_exit = 1;
+		*exit_when = when;
+		if(stay_records)
+			*stay_records = nrec;
+	}
 	run_batch(d, code, K, e, now, 0, (int)nfrags, [fragframes, fragbase](int f) {
 		return (unsigned)fragframes[f] | (fragbase ? (unsigned)fragbase[f] << 8 : 0u); });
 	if(d.fault)

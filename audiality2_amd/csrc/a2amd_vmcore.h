@@ -553,7 +553,7 @@ VMFN uint32_t run_batch(A2DVmVoice &v, const uint32_t *code, const Consts &K, E 
 					res = nextvm >> 8;
 					break;
 				}
-				if(v.fault) {		// (stopped for good)
+				if(v.fault || (v.has_exit && v.waketime == v.exit_when)) {	// (stopped for good; or at the run that is the engine's)
 					res = frames;
 					break;
 				}

@@ -90,6 +90,7 @@ typedef struct UPTR
 typedef struct LIST
 {
 	A2_voice	**head;		/* the list: &parent->sub (key) */
+	struct LIST	*above;		/* the list its parent voice stands in (NULL: the root's), as of the last walk */
 	ENT		*e;
 	UPTR		*up;		/* (parallel to e) */
 	unsigned	n, cap;
@@ -117,7 +118,10 @@ typedef struct WSTATE
 	int		served;		/* the drop-in serves this state */
 	LIST		**lists;	/* open addressing on 'head'; the LISTs stay where they are (nested calls hold them) */
 	unsigned	nlists, cap_lists;
-	unsigned long long epoch;	/* bumped by every a2_VoiceNew / a2_VoiceFree of the state: the lists' structure */
+	unsigned long long epoch;	/* what a remembered list's epoch must equal to count: a birth or a death makes the ONE list
+					 * it happened in stale (list_changed) - the others keep what they know; only a new engine
+					 * state, or a change that cannot be placed, moves this */
+	struct LIST	*cur_list;	/* the list the innermost a2_ProcessVoices in progress is walking (deaths happen there) */
 	unsigned long long visits, cur_visit;	/* the engine call in progress one level up (quiet_visit) */
 	int		hooks_broken;	/* a list changed without the epoch moving: never trust remembered lists */
 	unsigned long long hold_gen;	/* holds made under an older value have been released wholesale */
@@ -143,7 +147,7 @@ static WSTATE **wstates;
 static unsigned n_wstates, cap_wstates;
 static pthread_mutex_t wmtx = PTHREAD_MUTEX_INITIALIZER;
 static __thread WSTATE *last_ws;
-static int walk_off = -1, walk_stats, walk_cut, walk_nocache, walk_nohold, walk_novm;
+static int walk_off = -1, walk_stats, walk_cut, walk_nocache, walk_nohold, walk_novm, walk_globalepoch;
 
 static inline int wstate_closed(const WSTATE *w)
 {
@@ -302,6 +306,7 @@ static void bind_engine(void)
 		walk_off = getenv("A2AMD_WALK_OFF") != NULL;	/* A/B: every voice is handed to the engine's loop */
 	/* A/B: lists are never trusted from memory - every sleeping voice's A2_voice is read */
 	walk_nocache = getenv("A2AMD_WALK_NOCACHE") != NULL;
+	walk_globalepoch = getenv("A2AMD_WALK_GLOBALEPOCH") != NULL;	/* (A/B: rounds 3-4's one epoch per state) */
 	/* A/B: sleeping lists are marked fragment by fragment instead of being put on hold */
 	walk_nohold = getenv("A2AMD_WALK_NOHOLD") != NULL;
 	/* test hook: voices are handed to the engine's loop run by run even in a state the drop-in
@@ -316,6 +321,56 @@ static void bind_engine(void)
 
 /* a voice is about to be made or freed: what is remembered about the state's lists is void, and
  * no voice stays on hold (its slot may be somebody else's a moment later) */
+static LIST *list_lookup(const WSTATE *w, A2_voice **head)
+{
+	unsigned k, mask;
+	if(!w->cap_lists)
+		return NULL;
+	mask = w->cap_lists - 1;
+	k = (unsigned)(((uintptr_t)head >> 4) * 2654435761u) & mask;
+	while(w->lists[k] && w->lists[k]->head != head)
+		k = (k + 1) & mask;
+	return w->lists[k];
+}
+
+static int hold_list(WSTATE *w, LIST *sl, int on);
+
+/* A voice was born into, or died in, THIS list (round 5: rounds 3-4 moved the state's one epoch, which
+ * voided every remembered list and every summary of the state - a note played anywhere made the next
+ * walk read all 16 384 sleeping voices of a pad again).  The list itself is stale until it has been
+ * walked link by link; the summaries above it - which count its voices and its earliest wake time -
+ * are void; its hold (its voices' default windows, a2amd_units_hold) goes, because a slot of it may be
+ * somebody else's a moment later.  Every other list keeps what it knows. */
+static void list_changed(WSTATE *w, LIST *L)
+{
+	LIST *a;
+	unsigned depth = 0, k;
+	L->epoch = w->epoch - 1;
+	for(a = L; a; a = a->above)
+	{
+		a->sum_ok = 0;
+		if(++depth > 64)
+		{
+			/* (a stale 'above' chain - LISTs are reused with the addresses of their heads: give up on placing it) */
+			++w->epoch;
+			break;
+		}
+	}
+	if(L->held_gen == w->hold_gen && w->hold_gen)
+	{
+		if(w->served && L->reached == *w->view.frag_serial)
+			/* the walk has passed it in this fragment: its voices HAVE had their default window in it -
+			 * stored byte by byte before the hold goes (as structure_changes does for all) */
+			for(k = 0; k < L->n; ++k)
+			{
+				const ENT *e = &L->e[k];
+				if(e->stamp != STAMP_NOUNITS && (e->slotdev & 0x0fffffffu) < w->view.map_cap[e->slotdev >> 28])
+					w->view.map[e->slotdev >> 28][e->slotdev & 0x0fffffffu] = 1;
+			}
+		hold_list(w, L, 0);
+	}
+}
+
 static void structure_changes(WSTATE *w)
 {
 	++w->epoch;
@@ -359,7 +414,15 @@ A2_voice *a2_VoiceNew(A2_state *st, A2_voice *parent, unsigned when)
 	if(!engine_walk)
 		return NULL;
 	if((w = wstate_of(st)))
-		structure_changes(w);
+	{
+		/* born at the head of its parent's list (core.c:474-475) */
+		LIST *L = (parent && !walk_globalepoch) ? list_lookup(w, &parent->sub) : NULL;
+		if(L)
+			list_changed(w, L);
+		else if(!parent || walk_globalepoch || w->cap_lists == 0)
+			structure_changes(w);
+		/* (a parent whose list was never walked: nothing is remembered about it) */
+	}
 	return engine_voicenew(st, parent, when);
 }
 
@@ -371,7 +434,21 @@ void a2_VoiceFree(A2_state *st, A2_voice **head)
 	if(!engine_walk)
 		return;
 	if((w = wstate_of(st)))
-		structure_changes(w);
+	{
+		/* which list?  head is the link that points at the voice: the list's own head (a parent that
+		 * ends frees its subvoices through &v->sub, core.c:540-560) or, from the engine's loop
+		 * (core.c:1892), a link inside the list that loop was given - the one our walk is on */
+		LIST *L = walk_globalepoch ? NULL : list_lookup(w, head);
+		if(!L && !walk_globalepoch)
+			L = w->cur_list;
+		if(L)
+		{
+			/* (the voice's own subvoices go with it, core.c:548-551: through this hook, list by list) */
+			list_changed(w, L);
+		}
+		else
+			structure_changes(w);
+	}
 	engine_voicefree(st, head);
 }
 
@@ -808,11 +885,16 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 		epoch0 = w->epoch;
 		visit0 = w->cur_visit;
 		w->cur_visit = ++w->visits;
-		engine_walk(st, head, offset, frames);
+		{
+			LIST *outer = w->cur_list;
+			w->cur_list = l;
+			engine_walk(st, head, offset, frames);
+			w->cur_list = outer;
+		}
 		w->cur_visit = visit0;
 		w->visited += run;
-		if(w->epoch != epoch0)
-			cached = 0;		/* voices were born or died (anywhere): the rest of the list is read */
+		if(w->epoch != epoch0 || l->epoch != w->epoch)
+			cached = 0;		/* voices were born or died in THIS list: the rest of it is read */
 		/* what is left of them (voices that ended were freed: a2_VoiceFree, core.c:1892) goes back in
 		 * front of the rest; and what to do with each while it sleeps */
 		for(p = *head; p; p = p->next)
@@ -849,6 +931,8 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 				e->flags = (p->events ? 0 : E_NOEVENTS) | ((p->flags & A2_APIHANDLE) ? E_APIHANDLE : 0) |
 						(p->sub ? E_GROUP : 0);
 				e->sub = p->sub ? list_of(w, &p->sub) : NULL;
+				if(e->sub)
+					e->sub->above = l;
 				if(p->sub && !e->sub)
 					e->stamp = 0;		/* (out of memory: its subvoices keep being walked) */
 				else if(!p->units)

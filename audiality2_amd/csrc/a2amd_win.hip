@@ -43,28 +43,40 @@
 #include "a2amd_dsp.h"
 #include "a2amd_taps.h"
 
-// entry words (A2D_WIN_WORDS = 24)
-enum { WE_HEAD = 0,	// j | off << 8 | len << 16 | clamp << 24 | fresh << 25 | mode0 << 26 | mode1 << 28
+// Layout (round 5, second cut): one SLOT of A2D_WIN_WORDS words per (fragment, list position) -
+// wslot[(f - fa) * nlist + i] - holds the fragment's first window (the only one, for most voices in
+// most fragments); further windows of the same fragment ("extras": a script's sub-fragment
+// windows) go to the voice's run of the pool wext, in order, widx[(f - fa) * nlist + i] naming
+// the first.  So what a render wavefront needs for its voices in a fragment is ONE contiguous
+// block it can ask for ahead of time, and what 64 control lanes write per fragment is one too.
+//
+// slot / entry words (A2D_WIN_WORDS = 24)
+enum { WE_HEAD = 0,	// off | len << 6 | clamp << 13 | fresh << 14 | mode0 << 15 | mode1 << 17 | extras << 19
 	WE_F0, WE_DF, WE_QV, WE_QD, WE_LP, WE_BP, WE_HP,	// filter12: coefficient + step, q + step, mix levels
 	WE_VOL, WE_DVOL, WE_PAN, WE_DPAN,			// panmix: values at the window's first frame, per-frame deltas
 	WE_OSC = 12 };						// 6 words per oscillator:
 enum { WO_A = 0, WO_B, WO_C, WO_DPH, WO_AK, WO_DA };		//   taps:  level offset in the pool, phase lo / hi, increment
 								//   noise: seed, held sample, phase lo, increment; then amplitude + delta
 enum { WM_SILENT = 0, WM_TAPS, WM_NOISE };
-#define WH_CLAMP (1u << 24)
-#define WH_FRESH (1u << 25)
+#define WH_OFF(h)    ((int)((h) & 63u))
+#define WH_LEN(h)    ((int)(((h) >> 6) & 127u))
+#define WH_CLAMP     (1u << 13)
+#define WH_FRESH     (1u << 14)
+#define WH_MODE(h, o) (((h) >> (15 + 2 * (o))) & 3u)
+#define WH_EXTRAS(h) ((int)(((h) >> 19) & 127u))
 
 // (a uniform address through the constant address space is a scalar load)
 typedef int Int4 __attribute__((ext_vector_type(4)));
+typedef int Int8 __attribute__((ext_vector_type(8)));
 DEV int sload(const void *p)
 {
 	typedef const __attribute__((address_space(4))) int *CI;
 	return *(CI)(uintptr_t)p;
 }
-DEV Int4 sload4(const void *p)
+DEV Int8 sload8(const void *p)
 {
-	typedef const __attribute__((address_space(4))) Int4 *CI4;
-	return *(CI4)(uintptr_t)p;
+	typedef const __attribute__((address_space(4))) Int8 *CI8;
+	return *(CI8)(uintptr_t)p;
 }
 
 // ---------------------------------------------------------------------------
@@ -78,7 +90,25 @@ struct OscV {		// A2_wtosc (wtosc.c:66-80), one per lane
 	Ramp p, a;
 	int noise;
 	unsigned seed;
+	// what the oscillator reads of its wave (A2_wave, a2_waves.h:88-103), kept while the wave stays: the
+	// descriptor's period, flags and level 0 size (the host rewrites descriptors between batches only), and
+	// the mip level last played (cmm: -1 none yet, -2 the descriptor itself has not been read)
+	unsigned wperiod, wflags, wsize0;
+	int cmm;
+	unsigned csize, coff;
 };
+
+DEV void osc_wave_fields(const A2DWave *waves, OscV &o)
+{
+	o.cmm = -1;
+	o.wperiod = o.wflags = o.wsize0 = o.csize = o.coff = 0;
+	if(o.wave >= 0) {
+		const A2DWave *w = waves + o.wave;
+		o.wperiod = w->period;
+		o.wflags = w->flags;
+		o.wsize0 = w->size[0];
+	}
+}
 
 // a2_PrepareRamper, a2_dsp.h:128-149 (the 64 bit division by an exact double division: the first
 // branch is only taken with timer >= 256 * frames > 0)
@@ -112,8 +142,19 @@ DEV uint64_t wrap_phase_v(uint64_t ph, unsigned size)
 	return ph;
 }
 
+// a2_P2I, pitch.c:57-67, from the workgroup's copy of the table
+typedef uint32_t PTab[128];
+DEV unsigned p2i_s(const PTab &tab, int pitch)
+{
+	const int n = pitch & 0xffff, oct = pitch >> 16;
+	unsigned dph = tab[2 * (n >> 10) + 1] * (unsigned)(n & 0x3ff);
+	dph >>= 2;
+	dph += tab[2 * (n >> 10)];
+	return dph >> ((unsigned)(7 - oct) & 31u);
+}
+
 // wtosc_run_pitch, wtosc.c:89-105
-DEV void run_pitch_v(const uint32_t *ptab, OscV &o, int frames)
+DEV void run_pitch_v(const PTab &ptab, OscV &o, int frames)
 {
 	ramp_prepare_v(o.p, frames);
 	if(o.dphase && (!o.p.timer && !o.p_ramping))
@@ -121,40 +162,45 @@ DEV void run_pitch_v(const uint32_t *ptab, OscV &o, int frames)
 	const unsigned lastv = (unsigned)o.p.value;
 	ramp_run(o.p, frames);
 	o.p_ramping = o.p.delta;
-	o.dphase = p2i(ptab, (int)((lastv + (unsigned)o.p.value) >> 9));
+	o.dphase = p2i_s(ptab, (int)((lastv + (unsigned)o.p.value) >> 9));
 }
 
 // One window of an oscillator's control state (wtosc_wavetable wtosc.c:239-286, wtosc_noise :129-152,
 // wtosc_Off :108-126): steps the state over 'len' frames and says what the frames are made of.
-DEV int osc_window_v(const A2DWave *waves, const uint32_t *ptab, OscV &o, int len, int (&w)[6])
+DEV int osc_window_v(const A2DWave *waves, const PTab &ptab, OscV &o, int len, int (&w)[6])
 {
 	int mode = WM_SILENT;
 	w[0] = w[1] = w[2] = w[3] = w[4] = w[5] = 0;
 	if(o.mode == A2D_OSC_MIPWAVE) {
-		const A2DWave *wv = waves + o.wave;
-		const unsigned size0 = wv->size[0];
-		if(!size0) {		// wtosc_check_unloaded, wtosc.c:168-183
+		if(o.cmm == -2)
+			osc_wave_fields(waves, o);
+		if(!o.wsize0) {		// wtosc_check_unloaded, wtosc.c:168-183
 			o.wave = -1;
 			o.mode = A2D_OSC_OFF;
 			return mode;
 		}
-		const unsigned period = wv->period, flags = wv->flags;
+		const unsigned period = o.wperiod;
 		run_pitch_v(ptab, o, len);
 		unsigned dph = ((o.dphase + 255) >> 8) * period;
 		ramp_prepare_v(o.a, len);
-		unsigned mm = 0;
+		int mm = 0;
 		for(; (dph > (A2D_MAXPHINC << 8)) && (mm < A2D_MIPS - 1); ++mm)
 			dph >>= 1;
+		if(mm != o.cmm) {
+			const A2DWave *wv = waves + o.wave;
+			o.csize = wv->size[mm];
+			o.coff = wv->off[mm];
+			o.cmm = mm;
+		}
 		uint64_t ph = o.phase >> mm;
 		dph = (unsigned)(((uint64_t)o.dphase * period) >> mm);
-		const unsigned sizem = wv->size[mm];
-		if(flags & 0x100u)
-			ph = wrap_phase_v(ph, sizem);
-		else if((ph >> 24) > (uint64_t)(sizem + 1))
+		if(o.wflags & 0x100u)
+			ph = wrap_phase_v(ph, o.csize);
+		else if((ph >> 24) > (uint64_t)(o.csize + 1))
 			return mode;	// all played: silence, state untouched
 		if(dph <= (A2D_MAXPHINC << 16)) {
 			mode = WM_TAPS;
-			w[WO_A] = (int)wv->off[mm];
+			w[WO_A] = (int)o.coff;
 			w[WO_B] = (int)(unsigned)ph;
 			w[WO_C] = (int)(unsigned)(ph >> 32);
 			w[WO_DPH] = (int)dph;
@@ -196,7 +242,7 @@ DEV int osc_window_v(const A2DWave *waves, const uint32_t *ptab, OscV &o, int le
 }
 
 // wtosc_Initialize, wtosc.c:390-423 (value = transpose + basepitch)
-DEV void osc_init_v(const uint32_t *ptab, OscV &o, int pitch)
+DEV void osc_init_v(const PTab &ptab, OscV &o, int pitch)
 {
 	o.wave = -1;
 	o.mode = A2D_OSC_OFF;
@@ -204,9 +250,11 @@ DEV void osc_init_v(const uint32_t *ptab, OscV &o, int pitch)
 	o.p_ramping = 0;
 	o.noise = 0;
 	o.seed = 0;
+	o.cmm = -1;
+	o.wperiod = o.wflags = o.wsize0 = o.csize = o.coff = 0;
 	ramp_init(o.a, 0);
 	ramp_init(o.p, pitch);
-	o.dphase = p2i(ptab, o.p.value >> 8);
+	o.dphase = p2i_s(ptab, o.p.value >> 8);
 }
 
 DEV void osc_write_v(const A2DWave *waves, OscV &o, int reg, int v, int start, int dur)
@@ -230,6 +278,7 @@ DEV void osc_write_v(const A2DWave *waves, OscV &o, int reg, int v, int start, i
 			o.wave = -1;
 			o.mode = A2D_OSC_OFF;
 		}
+		osc_wave_fields(waves, o);
 		break;
 	  }
 	  case 1:	// wtosc_Pitch, wtosc.c:486-492 (host added transpose + basepitch)
@@ -244,9 +293,10 @@ DEV void osc_write_v(const A2DWave *waves, OscV &o, int reg, int v, int start, i
 		if(o.wave < 0)
 			o.phase = 0;
 		else {
-			const unsigned period = waves[o.wave].period;
+			if(o.cmm == -2)
+				osc_wave_fields(waves, o);
 			const int ph = (int)((unsigned)v + ((((unsigned)start) * (o.dphase >> 8)) >> 8));
-			o.phase = (uint64_t)(((int64_t)ph * (int64_t)period) * 256);
+			o.phase = (uint64_t)(((int64_t)ph * (int64_t)o.wperiod) * 256);
 		}
 		break;
 	}
@@ -256,9 +306,10 @@ struct FiltV { Ramp q; int lp, bp, hp, f1, f1next, ramp; };
 
 template<int NOSC, int FILT>
 DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int idx, int skip_empty,
-		int fa, int fb, int *__restrict__ win, unsigned *__restrict__ widx, unsigned *__restrict__ wtop, unsigned wcap,
+		int fa, int fb, int *__restrict__ wslot, int *__restrict__ wext, unsigned *__restrict__ widx,
+		unsigned *__restrict__ wtop, unsigned wcap,
 		const A2DVoice *__restrict__ voices, int *ustate, int *vactive, const A2DWave *__restrict__ waves,
-		const uint32_t *__restrict__ ptab)
+		const PTab &ptab, const uint8_t *ffr)
 {
 	const A2DParams &p = *pp;
 	const int lane = threadIdx.x & 63;
@@ -271,6 +322,9 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 	bool live = false;
 	fs.q.value = fs.q.target = fs.q.delta = fs.q.timer = 0;
 	fs.lp = fs.bp = fs.hp = fs.f1 = fs.f1next = fs.ramp = 0;
+#pragma unroll
+	for(int o = 0; o <= NOSC + FILT; ++o)
+		uu[o] = 0;
 	if(listed) {
 		slot = list[idx];
 		const A2DVoice &vc = voices[slot];
@@ -295,6 +349,10 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 			os[o].a = ramp_load(w + OW_A);
 			os[o].noise = w[OW_NOISE];
 			os[o].seed = (unsigned)w[OW_SEED];
+			// (the wave's descriptor is read when a window or a phase write first needs it: the state words of
+			// a unit that has not been initialized yet - a recycled slot - may hold anything)
+			os[o].cmm = -2;
+			os[o].wperiod = os[o].wflags = os[o].wsize0 = os[o].csize = os[o].coff = 0;
 		}
 		if(FILT) {
 			const int *wf = ustate + (size_t)uu[NOSC] * A2D_USTATE;
@@ -316,16 +374,18 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 			os[o].p.value = os[o].p.target = os[o].p.delta = os[o].p.timer = 0;
 			os[o].a = os[o].p;
 			os[o].noise = 0; os[o].seed = 0;
+			os[o].cmm = -1;
+			os[o].wperiod = os[o].wflags = os[o].wsize0 = os[o].csize = os[o].coff = 0;
 		}
 		vol.value = vol.target = vol.delta = vol.timer = 0;
 		pan = vol;
 	}
 
-	// room for this voice's entries: at most one per fragment without records and one per record
-	// (the wavefront takes its voices' sum from the launch's pool in one atomic)
+	// room for this voice's extras: at most one per record (the wavefront takes its voices' sum from the
+	// launch's pool in one atomic)
 	unsigned e, elim;
 	{
-		const unsigned cap = live ? (unsigned)(fb - fa) + (unsigned)(re - rc) : 0u;
+		const unsigned cap = live ? (unsigned)(re - rc) : 0u;
 		unsigned pre = cap;
 #pragma unroll
 		for(int d = 1; d < 64; d <<= 1) {
@@ -341,30 +401,37 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 		e = base + pre - cap;
 		elim = e + cap;
 		if(base + total > wcap) {	// (the host sizes the pool by the same bound: never; the voices of
-			if(lane == 0)		// this wavefront then render nothing and the flag says so)
+			if(lane == 0)		// this wavefront then lose their extra windows and the flag says so)
 				atomicOr(wtop + 1, 1u);
 			elim = e = 0;
-			live = false;
 		}
 	}
 
+	// the next two records of the voice, asked for ahead of their turn
+	const Int4 none = { 0, 0, 0, 0 };
+	Int4 rq = none, rq1 = none;
+	if(live) {
+		if(rc < re)
+			rq = *(const Int4 *)(recs + rc);
+		if(rc + 1 < re)
+			rq1 = *(const Int4 *)(recs + rc + 1);
+	}
 	int pending_fresh = 0;
 	for(int f = fa; f < fb; ++f) {
-		const int n = (int)p.fragframes[f];
-		if(listed)
-			widx[(size_t)(f - fa) * nlist + idx] = e;
+		const int n = (int)ffr[f];
+		int *const myslot = wslot + ((size_t)(f - fa) * nlist + (listed ? idx : 0)) * A2D_WIN_WORDS;
+		const unsigned e0 = e;
+		unsigned head0 = 0;
+		int nwin = 0;
 		// this lane's next thing to do in fragment f: its records, or - none - the engine's default
 		// Process(0, frames) on every unit (core.c:1875-1876)
 		Int4 r = { 0, 0, n << 16, 0 };
 		int op = 0;
 		bool inrec = false;
 		if(live) {
-			if(rc < re) {
-				const Int4 q = *(const Int4 *)(recs + rc);
-				if((int)A2D_RFRAG((unsigned)q.x) == f) {
-					r = q;
-					inrec = true;
-				}
+			if(rc < re && (int)A2D_RFRAG((unsigned)rq.x) == f) {
+				r = rq;
+				inrec = true;
 			}
 			op = inrec ? (int)A2D_ROP((unsigned)r.x) : (active ? R_SEG : 0);
 			if(inrec && !op)
@@ -379,7 +446,7 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 					// one window of the chain: frames [off, off + len) of the fragment
 					const int off = (int)(dur & 0xffffu), len = (int)(dur >> 16);
 					int W[A2D_WIN_WORDS];
-					unsigned head = (unsigned)(f & 0xff) | ((unsigned)off << 8) | ((unsigned)len << 16);
+					unsigned head = (unsigned)(off & 63) | ((unsigned)(len & 127) << 6);
 #pragma unroll
 					for(int k = 0; k < A2D_WIN_WORDS; ++k)
 						W[k] = 0;
@@ -387,7 +454,7 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 					for(int o = 0; o < NOSC; ++o) {
 						int w6[6];
 						const int m = osc_window_v(waves, ptab, os[o], len, w6);
-						head |= (unsigned)m << (26 + 2 * o);
+						head |= (unsigned)m << (15 + 2 * o);
 #pragma unroll
 						for(int k = 0; k < 6; ++k)
 							W[WE_OSC + 6 * o + k] = w6[k];
@@ -422,14 +489,21 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 					ramp_run(vol, len);
 					ramp_run(pan, len);
 					W[WE_HEAD] = (int)head;
-					if(e < elim) {
-						Int4 *dst = (Int4 *)(win + (size_t)e * A2D_WIN_WORDS);
+					// the fragment's first window into the voice's slot (its head word follows when the
+					// fragment is done: it counts the extras), the others into the pool
+					int *dst = nullptr;
+					if(!nwin) {
+						head0 = head;
+						dst = myslot;
+					} else if(e < elim)
+						dst = wext + (size_t)e++ * A2D_WIN_WORDS;
+					++nwin;
+					if(dst) {
 #pragma unroll
 						for(int k = 0; k < A2D_WIN_WORDS / 4; ++k) {
 							const Int4 q = { W[4 * k], W[4 * k + 1], W[4 * k + 2], W[4 * k + 3] };
-							dst[k] = q;
+							((Int4 *)dst)[k] = q;
 						}
-						++e;
 					}
 				}
 			} else if(op == R_INIT) {
@@ -491,38 +565,33 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 			// the next one
 			if(inrec) {
 				++rc;
+				rq = rq1;
+				rq1 = none;
+				if(rc + 1 < re)
+					rq1 = *(const Int4 *)(recs + rc + 1);
 				inrec = false;
 				op = 0;
-				if(rc < re) {
-					const Int4 q = *(const Int4 *)(recs + rc);
-					if((int)A2D_RFRAG((unsigned)q.x) == f) {
-						r = q;
-						inrec = true;
-						op = (int)A2D_ROP((unsigned)q.x);
-						if(!op)
-							op = R_NOP;
-					}
+				if(rc < re && (int)A2D_RFRAG((unsigned)rq.x) == f) {
+					r = rq;
+					inrec = true;
+					op = (int)A2D_ROP((unsigned)rq.x);
+					if(!op)
+						op = R_NOP;
 				}
 			} else
 				op = 0;
 		}
-		// a voice born without a window behind its birth in this slab: its filter still starts from
-		// rest - an entry without frames carries the flag
-		if(FILT && pending_fresh && f == fb - 1) {
-			if(e < elim) {
-				Int4 *dst = (Int4 *)(win + (size_t)e * A2D_WIN_WORDS);
-				const Int4 z = { 0, 0, 0, 0 };
-#pragma unroll
-				for(int k = 0; k < A2D_WIN_WORDS / 4; ++k)
-					dst[k] = z;
-				win[(size_t)e * A2D_WIN_WORDS + WE_HEAD] = (int)((unsigned)(f & 0xff) | WH_FRESH);
-				++e;
+		if(listed) {
+			// a voice born without a window behind its birth in this slab: its filter still starts from
+			// rest - the slab's last slot carries the flag, with or without frames
+			if(FILT && pending_fresh && f == fb - 1) {
+				head0 |= WH_FRESH;
+				pending_fresh = 0;
 			}
-			pending_fresh = 0;
+			myslot[WE_HEAD] = (int)(head0 | ((unsigned)(nwin > 1 ? min(nwin - 1, (int)(e - e0)) : 0) << 19));
+			widx[(size_t)(f - fa) * nlist + idx] = e0;
 		}
 	}
-	if(listed)
-		widx[(size_t)(fb - fa) * nlist + idx] = e;
 
 	if(live) {
 #pragma unroll
@@ -552,30 +621,40 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 template<int NOSC, int FILT>
 __global__ __launch_bounds__(64)
 void k_win_ctl(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int skip_empty,
-		int fa, int fb, int *__restrict__ win, unsigned *__restrict__ widx, unsigned *__restrict__ wtop, unsigned wcap,
+		int fa, int fb, int *__restrict__ wslot, int *__restrict__ wext, unsigned *__restrict__ widx,
+		unsigned *__restrict__ wtop, unsigned wcap,
 		const A2DVoice *__restrict__ voices, int *ustate, int *vactive, const A2DWave *__restrict__ waves,
 		const uint32_t *__restrict__ ptab)
 {
-	win_ctl_body<NOSC, FILT>(pp, list, nlist, (int)(blockIdx.x * 64 + threadIdx.x), skip_empty, fa, fb, win, widx, wtop, wcap,
-			voices, ustate, vactive, waves, ptab);
+	// the pitch table and the batch's fragment lengths: read in every window, from LDS
+	__shared__ PTab s_ptab;
+	__shared__ uint8_t s_ffr[A2D_MAXBATCH];
+	for(int k = (int)threadIdx.x; k < 128; k += 64)
+		s_ptab[k] = ptab[k];
+	for(int k = (int)threadIdx.x; k < A2D_MAXBATCH; k += 64)
+		s_ffr[k] = pp->fragframes[k];
+	__syncthreads();
+	win_ctl_body<NOSC, FILT>(pp, list, nlist, (int)(blockIdx.x * 64 + threadIdx.x), skip_empty, fa, fb, wslot, wext, widx, wtop, wcap,
+			voices, ustate, vactive, waves, s_ptab, s_ffr);
 }
 
 // ---------------------------------------------------------------------------
 // the render passes: lane = frame
 // ---------------------------------------------------------------------------
-#define WIN_FCH 4		// fragments of a chunk (bus sums in registers)
+#define WIN_FCH 4		// fragments of a chunk
 #define WIN_WPB 4		// wavefronts per workgroup of k_win_render
 
-struct WinE { Int4 q[A2D_WIN_WORDS / 4]; };
-DEV WinE win_load(const int *win, unsigned e)
+// an entry in scalar registers
+struct WinE { Int8 q[A2D_WIN_WORDS / 8]; };
+DEV WinE win_load(const int *base, size_t e)
 {
 	WinE E;
 #pragma unroll
-	for(int k = 0; k < A2D_WIN_WORDS / 4; ++k)
-		E.q[k] = sload4(win + (size_t)e * A2D_WIN_WORDS + 4 * k);
+	for(int k = 0; k < A2D_WIN_WORDS / 8; ++k)
+		E.q[k] = sload8(base + e * A2D_WIN_WORDS + 8 * k);
 	return E;
 }
-DEV int win_word(const WinE &E, int k) { return E.q[k >> 2][k & 3]; }
+DEV int win_word(const WinE &E, int k) { return E.q[k >> 3][k & 7]; }
 
 // the oscillators of one window: what they leave in the voice's scratch buffer for this lane's frame
 // (fl = frame within the window; 'in' = the lane holds one)
@@ -586,7 +665,7 @@ DEV int win_oscs(const WinE &E, const CoefRsrc rs, int fl, bool in)
 	int x = 0;
 #pragma unroll
 	for(int o = 0; o < NOSC; ++o) {
-		const unsigned m = (head >> (26 + 2 * o)) & 3u;
+		const unsigned m = WH_MODE(head, o);
 		const int b = WE_OSC + 6 * o;
 		if(m == WM_TAPS) {
 			if(in) {
@@ -642,11 +721,23 @@ DEV void win_pan(const WinE &E, int y, int fl, bool in, int &acc0, int &acc1)
 	}
 }
 
+DEV void bus_add(int *busmem, int off, int nch, int f, int lane, int dbg, int &a0, int &a1)
+{
+	if(off >= 0 && !(dbg & 1)) {
+		int *dst = busmem + off + (size_t)f * nch * A2D_FRAG;
+		if(a0)
+			atomicAdd(&dst[lane], a0);
+		if(a1)
+			atomicAdd(&dst[A2D_FRAG + lane], a1);
+	}
+	a0 = a1 = 0;
+}
+
 template<int NOSC>
 __global__ __launch_bounds__(64 * WIN_WPB)
-void k_win_render(const int *__restrict__ list, int nlist, int vpw, int fa, int fb, const int *__restrict__ win,
-		const unsigned *__restrict__ widx, const A2DVoice *__restrict__ voices, const int *__restrict__ wavecoef,
-		int *__restrict__ busmem, int dbg)
+void k_win_render(const int *__restrict__ list, int nlist, int vpw, int fa, int fb, const int *__restrict__ wslot,
+		const int *__restrict__ wext, const unsigned *__restrict__ widx, const A2DVoice *__restrict__ voices,
+		const int *__restrict__ wavecoef, int *__restrict__ busmem, int dbg)
 {
 	const int wv = rfl((int)(threadIdx.x >> 6));
 	const int lane = threadIdx.x & 63;
@@ -659,50 +750,92 @@ void k_win_render(const int *__restrict__ list, int nlist, int vpw, int fa, int 
 	const int nf = min(WIN_FCH, fb - f0);
 	const int first = group * vpw, nv = min(vpw, nlist - first);
 	const CoefRsrc rs = coef_rsrc(wavecoef);
-	int acc0[WIN_FCH], acc1[WIN_FCH];
-#pragma unroll
-	for(int j = 0; j < WIN_FCH; ++j)
-		acc0[j] = acc1[j] = 0;
-	int cur_off = -1, cur_nch = 2;
-	for(int v = 0; v < nv; ++v) {
-		const int idx = first + v;
-		const int slot = sload(list + idx);
-		const int voff = sload(&voices[slot].out_off);
-		if(voff != cur_off) {
-			flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
-			cur_off = voff;
-			cur_nch = sload(&voices[slot].out_nch);
-		}
-		unsigned eb = (unsigned)sload(widx + (size_t)(f0 - fa) * nlist + idx);
-#pragma unroll
-		for(int j = 0; j < WIN_FCH; ++j) {
-			if(j < nf) {
-				const unsigned ee = (unsigned)sload(widx + (size_t)(f0 + j + 1 - fa) * nlist + idx);
-				for(unsigned e = eb; e < ee; ++e) {
-					const WinE E = win_load(win, e);
-					const unsigned head = (unsigned)win_word(E, WE_HEAD);
-					const int fl = lane - (int)((head >> 8) & 0xffu);
-					const bool in = (unsigned)fl < ((head >> 16) & 0xffu);
-					const int x = win_oscs<NOSC>(E, rs, fl, in);
-					win_pan(E, x, fl, in, acc0[j], acc1[j]);
-				}
-				eb = ee;
-			}
-		}
+	// lane v keeps voice v's output bus
+	int l_off = -1, l_nch = 2;
+	if(lane < nv) {
+		const A2DVoice &vc = voices[list[first + lane]];
+		l_off = vc.out_off;
+		l_nch = vc.out_nch;
 	}
-	flush_acc(busmem, cur_off, cur_nch, f0, nf, lane, dbg, acc0, acc1);
+	for(int j = 0; j < nf; ++j) {
+		const int f = f0 + j;
+		// the slots of the wavefront's voices in this fragment: one contiguous block
+		const int *const sbase = wslot + ((size_t)(f - fa) * nlist + first) * A2D_WIN_WORDS;
+		const unsigned l_wi = lane < nv ? widx[(size_t)(f - fa) * nlist + first + lane] : 0u;
+		int a0 = 0, a1 = 0;
+		int cur_off = rdl(l_off, 0), cur_nch = rdl(l_nch, 0);
+		WinE cur = win_load(sbase, 0);
+		for(int v = 0; v < nv; ++v) {
+			// (the next voice's slot is on its way while this one is rendered)
+			const WinE nxt = win_load(sbase, (size_t)min(v + 1, nv - 1));
+			const int voff = rdl(l_off, v);
+			if(voff != cur_off) {
+				bus_add(busmem, cur_off, cur_nch, f, lane, dbg, a0, a1);
+				cur_off = voff;
+				cur_nch = rdl(l_nch, v);
+			}
+			const unsigned head = (unsigned)win_word(cur, WE_HEAD);
+			{
+				const int fl = lane - WH_OFF(head);
+				const bool in = (unsigned)fl < (unsigned)WH_LEN(head);
+				const int x = win_oscs<NOSC>(cur, rs, fl, in);
+				win_pan(cur, x, fl, in, a0, a1);
+			}
+			const int nx = WH_EXTRAS(head);
+			if(nx) {
+				const unsigned e0 = (unsigned)rdl((int)l_wi, v);
+				for(int k = 0; k < nx; ++k) {
+					const WinE E = win_load(wext, (size_t)e0 + k);
+					const unsigned h = (unsigned)win_word(E, WE_HEAD);
+					const int fl = lane - WH_OFF(h);
+					const bool in = (unsigned)fl < (unsigned)WH_LEN(h);
+					const int x = win_oscs<NOSC>(E, rs, fl, in);
+					win_pan(E, x, fl, in, a0, a1);
+				}
+			}
+			cur = nxt;
+		}
+		bus_add(busmem, cur_off, cur_nch, f, lane, dbg, a0, a1);
+	}
 }
 
 // ---- with filter12: a workgroup owns its voices for the whole slab -----------------------------
 #define WINF_PITCH 65
 #define WINF_MAXW  16		// wavefronts per workgroup (one filters)
-// LDS: three tiles [vpg][65], then the per-wavefront bus sums of two fragments
-DEV int winf_lds_words(int vpg, int nw) { return 3 * vpg * WINF_PITCH + 2 * nw * 2 * 64 + 2 * nw * 2; }
+
+// f12_process, filter12.c:97-118, over the frames [off, off + len) of a voice's row, in place
+DEV void winf_filter(int *row, int off, int len, int f0v, int df, int qv, int qd, int lp, int bp, int hp, int &d1, int &d2)
+{
+	auto step = [&](int xin, int at) {
+		const int fq = f0v >> 12, qq = qv >> 12;
+		const int d1s = d1 >> 4;
+		const int l = wadd(d2, wmul(fq, d1s) >> 8);
+		const int h = wsub(wsub(xin >> 5, l), wmul(qq, d1s) >> 8);
+		const int b = wadd(wmul(fq, h >> 4) >> 8, d1);
+		row[at] = wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3;
+		d1 = b;
+		d2 = l;
+		f0v = wadd(f0v, df);
+		qv = wadd(qv, qd);
+	};
+	int k = 0;
+	for(; k + 4 <= len; k += 4) {
+		// (four inputs read before the first one's chain starts)
+		const int at = off + k;
+		const int x0 = row[at], x1 = row[at + 1], x2 = row[at + 2], x3 = row[at + 3];
+		step(x0, at);
+		step(x1, at + 1);
+		step(x2, at + 2);
+		step(x3, at + 3);
+	}
+	for(; k < len; ++k)
+		step(row[off + k], off + k);
+}
 
 template<int NOSC>
 __global__ __launch_bounds__(64 * WINF_MAXW)
-void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, int fb, const int *__restrict__ win,
-		const unsigned *__restrict__ widx, const A2DVoice *__restrict__ voices, int *ustate,
+void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, int fb, const int *__restrict__ wslot,
+		const int *__restrict__ wext, const unsigned *__restrict__ widx, const A2DVoice *__restrict__ voices, int *ustate,
 		const int *__restrict__ wavecoef, int *__restrict__ busmem, int dbg)
 {
 	extern __shared__ int winf_lds[];
@@ -719,47 +852,53 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 
 	// the filter wavefront: lane = voice, d1 / d2 in registers over the slab
 	int d1 = 0, d2 = 0, ufilt = -1;
+	Int4 fq0 = { 0, 0, 0, 0 }, fq1 = fq0;		// the voice's slot of the fragment to be filtered next: words 0..7
+	unsigned fwi = 0;
 	if(wv == 0 && lane < nv) {
 		ufilt = voices[list[first + lane]].unit[NOSC];
 		d1 = ustate[(size_t)ufilt * A2D_USTATE + FW_D1A];
 		d2 = ustate[(size_t)ufilt * A2D_USTATE + FW_D2A];
+		const Int4 *S = (const Int4 *)(wslot + ((size_t)first + lane) * A2D_WIN_WORDS);
+		fq0 = S[0];
+		fq1 = S[1];
+		fwi = widx[first + lane];
 	}
 	// the others: a contiguous share of the voices each (neighbours in the list share their bus)
 	const int nworkers = nw - 1;
 	const int per = (nv + nworkers - 1) / nworkers;
 	const int lo = min(nv, (wv - 1) * per), hi = wv ? min(nv, lo + per) : 0;
+	int l_off = -1, l_nch = 2;
+	if(wv && lo + lane < hi) {
+		const A2DVoice &vc = voices[list[first + lo + lane]];
+		l_off = vc.out_off;
+		l_nch = vc.out_nch;
+	}
 
 	for(int s = 0; s < nfr + 3; ++s) {
 		if(wv == 0) {
 			const int g = s - 1;		// fragment (of the slab) to filter
 			if(g >= 0 && g < nfr && lane < nv) {
 				int *const row = tiles + (g % 3) * vpg * WINF_PITCH + lane * WINF_PITCH;
-				const int idx = first + lane;
-				unsigned e = widx[(size_t)g * nlist + idx];
-				const unsigned ee = widx[(size_t)(g + 1) * nlist + idx];
-				for(; e < ee; ++e) {
-					// f12_process, filter12.c:97-118, over the window's frames in place
-					const Int4 *E = (const Int4 *)(win + (size_t)e * A2D_WIN_WORDS);
-					const Int4 q0 = E[0], q1 = E[1];
-					const unsigned head = (unsigned)q0.x;
-					int f0v = q0.y, qv = q0.w;
-					const int df = q0.z, qd = q1.x, lp = q1.y, bp = q1.z, hp = q1.w;
-					const int off = (int)((head >> 8) & 0xffu), len = (int)((head >> 16) & 0xffu);
-					if(head & WH_FRESH)
+				const Int4 q0 = fq0, q1 = fq1;
+				const unsigned e0 = fwi;
+				if(g + 1 < nfr) {	// (the next fragment's, on their way while this one is filtered)
+					const Int4 *S = (const Int4 *)(wslot + ((size_t)(g + 1) * nlist + first + lane) * A2D_WIN_WORDS);
+					fq0 = S[0];
+					fq1 = S[1];
+					fwi = widx[(size_t)(g + 1) * nlist + first + lane];
+				}
+				const unsigned head = (unsigned)q0.x;
+				if(head & WH_FRESH)
+					d1 = d2 = 0;
+				winf_filter(row, WH_OFF(head), WH_LEN(head), q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, d1, d2);
+				const int nx = WH_EXTRAS(head);
+				for(int k = 0; k < nx; ++k) {
+					const Int4 *E = (const Int4 *)(wext + ((size_t)e0 + k) * A2D_WIN_WORDS);
+					const Int4 x0 = E[0], x1 = E[1];
+					const unsigned h = (unsigned)x0.x;
+					if(h & WH_FRESH)
 						d1 = d2 = 0;
-					for(int k = 0; k < len; ++k) {
-						const int xin = row[off + k];
-						const int fq = f0v >> 12, qq = qv >> 12;
-						const int d1s = d1 >> 4;
-						const int l = wadd(d2, wmul(fq, d1s) >> 8);
-						const int h = wsub(wsub(xin >> 5, l), wmul(qq, d1s) >> 8);
-						const int b = wadd(wmul(fq, h >> 4) >> 8, d1);
-						row[off + k] = wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3;
-						d1 = b;
-						d2 = l;
-						f0v = wadd(f0v, df);
-						qv = wadd(qv, qd);
-					}
+					winf_filter(row, WH_OFF(h), WH_LEN(h), x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, d1, d2);
 				}
 			}
 		} else {
@@ -784,21 +923,35 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 				}
 			}
 			// oscillators of fragment s into its tile
-			if(s < nfr) {
+			if(s < nfr && lo < hi) {
 				int *const tile = tiles + (s % 3) * vpg * WINF_PITCH;
+				const int *const sbase = wslot + ((size_t)s * nlist + first) * A2D_WIN_WORDS;
+				const unsigned l_wi = lo + lane < hi ? widx[(size_t)s * nlist + first + lo + lane] : 0u;
+				WinE cur = win_load(sbase, (size_t)lo);
 				for(int v = lo; v < hi; ++v) {
-					const int idx = first + v;
-					unsigned e = (unsigned)sload(widx + (size_t)s * nlist + idx);
-					const unsigned ee = (unsigned)sload(widx + (size_t)(s + 1) * nlist + idx);
-					for(; e < ee; ++e) {
-						const WinE E = win_load(win, e);
-						const unsigned head = (unsigned)win_word(E, WE_HEAD);
-						const int fl = lane - (int)((head >> 8) & 0xffu);
-						const bool in = (unsigned)fl < ((head >> 16) & 0xffu);
-						const int x = win_oscs<NOSC>(E, rs, fl, in);
+					const WinE nxt = win_load(sbase, (size_t)min(v + 1, hi - 1));
+					const unsigned head = (unsigned)win_word(cur, WE_HEAD);
+					{
+						const int fl = lane - WH_OFF(head);
+						const bool in = (unsigned)fl < (unsigned)WH_LEN(head);
+						const int x = win_oscs<NOSC>(cur, rs, fl, in);
 						if(in)
 							tile[v * WINF_PITCH + lane] = x;
 					}
+					const int nx = WH_EXTRAS(head);
+					if(nx) {
+						const unsigned e0 = (unsigned)rdl((int)l_wi, v - lo);
+						for(int k = 0; k < nx; ++k) {
+							const WinE E = win_load(wext, (size_t)e0 + k);
+							const unsigned h = (unsigned)win_word(E, WE_HEAD);
+							const int fl = lane - WH_OFF(h);
+							const bool in = (unsigned)fl < (unsigned)WH_LEN(h);
+							const int x = win_oscs<NOSC>(E, rs, fl, in);
+							if(in)
+								tile[v * WINF_PITCH + lane] = x;
+						}
+					}
+					cur = nxt;
 				}
 			}
 			// pan stage of fragment s - 2 out of its tile
@@ -806,29 +959,40 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 				const int g = s - 2, pb = g & 1;
 				const int *const tile = tiles + (g % 3) * vpg * WINF_PITCH;
 				int a0 = 0, a1 = 0, cur_off = -1, cur_nch = 2;
-				for(int v = lo; v < hi; ++v) {
-					const int idx = first + v;
-					const int slot = sload(list + idx);
-					const int voff = sload(&voices[slot].out_off);
-					if(voff != cur_off) {
-						if(cur_off >= 0 && !(dbg & 1)) {
-							int *dst = busmem + cur_off + (size_t)(fa + g) * cur_nch * A2D_FRAG;
-							if(a0) atomicAdd(&dst[lane], a0);
-							if(a1) atomicAdd(&dst[A2D_FRAG + lane], a1);
+				if(lo < hi) {
+					const int *const sbase = wslot + ((size_t)g * nlist + first) * A2D_WIN_WORDS;
+					const unsigned l_wi = lo + lane < hi ? widx[(size_t)g * nlist + first + lo + lane] : 0u;
+					cur_off = rdl(l_off, 0);
+					cur_nch = rdl(l_nch, 0);
+					WinE cur = win_load(sbase, (size_t)lo);
+					for(int v = lo; v < hi; ++v) {
+						const WinE nxt = win_load(sbase, (size_t)min(v + 1, hi - 1));
+						const int voff = rdl(l_off, v - lo);
+						if(voff != cur_off) {
+							bus_add(busmem, cur_off, cur_nch, fa + g, lane, dbg, a0, a1);
+							cur_off = voff;
+							cur_nch = rdl(l_nch, v - lo);
 						}
-						a0 = a1 = 0;
-						cur_off = voff;
-						cur_nch = sload(&voices[slot].out_nch);
-					}
-					unsigned e = (unsigned)sload(widx + (size_t)g * nlist + idx);
-					const unsigned ee = (unsigned)sload(widx + (size_t)(g + 1) * nlist + idx);
-					for(; e < ee; ++e) {
-						const WinE E = win_load(win, e);
-						const unsigned head = (unsigned)win_word(E, WE_HEAD);
-						const int fl = lane - (int)((head >> 8) & 0xffu);
-						const bool in = (unsigned)fl < ((head >> 16) & 0xffu);
-						const int y = in ? tile[v * WINF_PITCH + lane] : 0;
-						win_pan(E, y, fl, in, a0, a1);
+						const unsigned head = (unsigned)win_word(cur, WE_HEAD);
+						{
+							const int fl = lane - WH_OFF(head);
+							const bool in = (unsigned)fl < (unsigned)WH_LEN(head);
+							const int y = in ? tile[v * WINF_PITCH + lane] : 0;
+							win_pan(cur, y, fl, in, a0, a1);
+						}
+						const int nx = WH_EXTRAS(head);
+						if(nx) {
+							const unsigned e0 = (unsigned)rdl((int)l_wi, v - lo);
+							for(int k = 0; k < nx; ++k) {
+								const WinE E = win_load(wext, (size_t)e0 + k);
+								const unsigned h = (unsigned)win_word(E, WE_HEAD);
+								const int fl = lane - WH_OFF(h);
+								const bool in = (unsigned)fl < (unsigned)WH_LEN(h);
+								const int y = in ? tile[v * WINF_PITCH + lane] : 0;
+								win_pan(E, y, fl, in, a0, a1);
+							}
+						}
+						cur = nxt;
 					}
 				}
 				part[((pb * nw + wv) * 2 + 0) * 64 + lane] = a0;
@@ -851,13 +1015,13 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 // launchers
 // ---------------------------------------------------------------------------
 int a2d_launch_win_ctl(const A2DParams *dparams, const A2DParams &hp, int nosc, int filt, const int *dlist, int nlist,
-		int skip_empty, int fa, int fb, int *win, unsigned *widx, unsigned *wtop, unsigned wcap, void *stream)
+		int skip_empty, int fa, int fb, int *wslot, int *wext, unsigned *widx, unsigned *wtop, unsigned wcap, void *stream)
 {
 	if(nlist <= 0 || fb <= fa)
 		return 0;
 	const int nblocks = (nlist + 63) / 64;
 #define CTL_LAUNCH(N, F) hipLaunchKernelGGL((k_win_ctl<N, F>), dim3(nblocks), dim3(64), 0, (hipStream_t)stream, dparams, dlist, \
-		nlist, skip_empty, fa, fb, win, widx, wtop, wcap, hp.voices, hp.ustate, hp.vactive, hp.waves, hp.ptab)
+		nlist, skip_empty, fa, fb, wslot, wext, widx, wtop, wcap, hp.voices, hp.ustate, hp.vactive, hp.waves, hp.ptab)
 	if(nosc == 1 && !filt)
 		CTL_LAUNCH(1, 0);
 	else if(nosc == 2 && !filt)
@@ -871,12 +1035,12 @@ int a2d_launch_win_ctl(const A2DParams *dparams, const A2DParams &hp, int nosc, 
 }
 
 int a2d_launch_win_render(const A2DParams &hp, int nosc, int filt, const int *dlist, int nlist, int fa, int fb,
-		const int *win, const unsigned *widx, void *stream)
+		const int *wslot, const int *wext, const unsigned *widx, void *stream)
 {
 	if(nlist <= 0 || fb <= fa)
 		return 0;
 	if(!filt) {
-		// voices per wavefront: about 8 192 wavefronts in the launch, 4 to 32 voices to an atomic
+		// voices per wavefront: about 8 192 wavefronts in the launch, up to 32 voices to an atomic
 		const int nchunks = (fb - fa + WIN_FCH - 1) / WIN_FCH;
 		static const int force = getenv("A2AMD_WVPW") ? atoi(getenv("A2AMD_WVPW")) : 0;
 		int vpw = force > 0 ? force : (int)std::min<long long>(std::max<long long>(((long long)nlist * nchunks + 8191) / 8192, 1), 32);
@@ -886,10 +1050,10 @@ int a2d_launch_win_render(const A2DParams &hp, int nosc, int filt, const int *dl
 		const int nblocks = (nwaves + WIN_WPB - 1) / WIN_WPB;
 		if(nosc == 1)
 			hipLaunchKernelGGL((k_win_render<1>), dim3(nblocks), dim3(64 * WIN_WPB), 0, (hipStream_t)stream, dlist, nlist, vpw,
-					fa, fb, win, widx, hp.voices, hp.wavecoef, hp.busmem, hp.debug);
+					fa, fb, wslot, wext, widx, hp.voices, hp.wavecoef, hp.busmem, hp.debug);
 		else
 			hipLaunchKernelGGL((k_win_render<2>), dim3(nblocks), dim3(64 * WIN_WPB), 0, (hipStream_t)stream, dlist, nlist, vpw,
-					fa, fb, win, widx, hp.voices, hp.wavecoef, hp.busmem, hp.debug);
+					fa, fb, wslot, wext, widx, hp.voices, hp.wavecoef, hp.busmem, hp.debug);
 	} else {
 		// voices per workgroup = lanes of its filter wavefront: spread out until every CU has a couple of
 		// workgroups (a workgroup takes as long as its filter chain whatever its voice count), then fill up
@@ -904,10 +1068,10 @@ int a2d_launch_win_render(const A2DParams &hp, int nosc, int filt, const int *dl
 		const size_t dyn = (size_t)(3 * vpg * WINF_PITCH + 2 * nw * 2 * 64 + 2 * nw * 2) * sizeof(int);
 		if(nosc == 1)
 			hipLaunchKernelGGL((k_win_render_f<1>), dim3(nblocks), dim3(64 * nw), dyn, (hipStream_t)stream, dlist, nlist, vpg,
-					fa, fb, win, widx, hp.voices, hp.ustate, hp.wavecoef, hp.busmem, hp.debug);
+					fa, fb, wslot, wext, widx, hp.voices, hp.ustate, hp.wavecoef, hp.busmem, hp.debug);
 		else
 			hipLaunchKernelGGL((k_win_render_f<2>), dim3(nblocks), dim3(64 * nw), dyn, (hipStream_t)stream, dlist, nlist, vpg,
-					fa, fb, win, widx, hp.voices, hp.ustate, hp.wavecoef, hp.busmem, hp.debug);
+					fa, fb, wslot, wext, widx, hp.voices, hp.ustate, hp.wavecoef, hp.busmem, hp.debug);
 	}
 	return (int)hipGetLastError();
 }

@@ -228,6 +228,8 @@ ENGINE_CASES = [   # label, program of tests/a2s/bench.a2s, voices
     ("configs[4] in one engine state", "FilterTree", 262144),
     ("variant 2b (scripted)", "OscPanScripted", 16384), ("variant 3b (scripted)", "OscFilterPanScripted", 16384),
     ("variant 2e (env unit per voice)", "OscPanEnvScripted", 16384),
+    # configs[2]'s voices with 200 note births + 200 deaths per second in one group beside them (the walk's per-list epochs)
+    ("churn (configs[2] + 200 notes/s)", "OscFilterPanChurn", 16384),
 ]
 ENGINE_BUFFERS = (4096, 64)     # a2play's offline buffer; one fragment per a2_Run() = a realtime driver's
 
@@ -339,6 +341,10 @@ def engine_in_loop(cases=None, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fr
                     m = {"voice_samples_per_s": g["voice_samples_per_s"],
                          "us_per_fragment_p50": g["run_us_p50"] / per, "us_per_fragment_p99": g["run_us_p99"] / per,
                          "us_per_fragment_mean": g["seconds"] / g["fragments"] * 1e6,
+                         # (the first quarter of the timed calls - where a scripted scene's voices are handed to the
+                         # device VM - and the second half apart)
+                         "us_per_fragment_p99_startup": g.get("run_us_p99_startup", g["run_us_p99"]) / per,
+                         "us_per_fragment_p99_steady": g.get("run_us_p99_steady", g["run_us_p99"]) / per,
                          "fragments_timed": g["fragments"], "active_voices": g["active_voices"],
                          "realtime_at_48k": bool(g["run_us_p99"] / per <= 64.0 / 48000.0 * 1e6),
                          "hash": g["hashes"][0], "tail_hash": g["tail_hashes"][0] if tail is not None else None,
@@ -818,6 +824,21 @@ def main():
             line["engine_in_loop"] = engine_in_loop()
             if "max_realtime_voices" in line and "max_realtime_voices_one_engine_state" in line["engine_in_loop"]:
                 line["max_realtime_voices"]["engine_in_loop"] = line["engine_in_loop"]["max_realtime_voices_one_engine_state"]
+            # SURVEY 8(d)'s own definition of the metric - "wall time of the render loop (a2_Run calls only)" - at the
+            # top level, beside 'value' (which times the C ABI without an engine above it): configs[3] through
+            # a2_Run(4096) of the reference engine, with the drop-in behind the unit API alone ("units") and with the
+            # replaced voice walk in front of it ("units+walk", INTEGRATION.md option C)
+            try:
+                c3 = line["engine_in_loop"]["cases"]["configs[3]"]["a2_Run(4096)"]
+                line["value_a2_run"] = {"unit": "voice-samples/s", "workload": "configs[3], a2_Run(4096) of the reference engine",
+                                        **{m: c3[m]["voice_samples_per_s"] for m in ("units", "units+walk") if m in c3 and
+                                           "voice_samples_per_s" in c3[m]},
+                                        "hash_equal": all(c3[m].get("hash_equal", False) for m in ("units", "units+walk") if m in c3)}
+                rt = line["engine_in_loop"]["max_realtime_voices_one_engine_state"]
+                line["max_realtime_voices_units"] = rt.get("units")
+                line["max_realtime_voices_units_walk"] = rt.get("units+walk")
+            except (KeyError, TypeError):
+                pass
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)

@@ -198,6 +198,18 @@ int a2amd_vm_trace_host_env(const uint32_t *code, unsigned nwords, a2amd_vm_stat
 		const uint8_t *fragframes, const uint8_t *fragbase, unsigned nfrags,
 		a2amd_vm_env *envs, int nenv, const uint16_t *envluts, uint32_t *recs, unsigned cap);
 
+/* The same for a voice taken for a stretch (a2amd_vm_exit_time): the look-ahead a2amd_vm_adopt makes for a program
+ * the analysis cannot vouch for as a whole runs first - *has_exit = 1, *exit_when = the wake time of the first VM run
+ * that is the engine's (END, SLEEP, CALL, RAND ..., a write the device VM cannot make), *stay_records (may be NULL) =
+ * the writes the stay holds - and the interpreter stops in front of that run: the records returned are what the
+ * device VM produces up to there (default windows afterwards), *st is the state the engine gets back. */
+int a2amd_vm_trace_host_exit(const uint32_t *code, unsigned nwords, a2amd_vm_state *st,
+		const int32_t *wr_unit, const uint8_t *wr_reg, const int32_t *kinds, int nkinds,
+		uint32_t now, uint32_t msdur, int32_t samplerate, int32_t basepitch,
+		const uint8_t *fragframes, const uint8_t *fragbase, unsigned nfrags,
+		a2amd_vm_env *envs, int nenv, const uint16_t *envluts, uint32_t *recs, unsigned cap,
+		int32_t *has_exit, uint32_t *exit_when, int32_t *stay_records);
+
 typedef struct a2amd_vm_stats {
 	uint64_t adopted, recalled, released;	/* voices, so far */
 	uint64_t vm_voice_batches;		/* sum over batches of voices the VM kernel ran */

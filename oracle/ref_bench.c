@@ -201,6 +201,23 @@ int main(int argc, const char *argv[])
 			"\"fragments\": %d, \"threads\": %d, \"active_voices\": %d",
 			(double)(voices / threads) * threads * 64.0 * jobs[0].fragments / worst,
 			worst, (voices / threads) * threads, jobs[0].fragments, threads, active);
+	{
+		/* the first quarter of the timed calls (a drop-in that hands voices over to the device does it there) and
+		 * the second half (steady state) apart, before the whole is sorted */
+		int n = jobs[0].nruns, q = n / 4, h = n / 2;
+		double *tmp = malloc((n > 0 ? n : 1) * sizeof(double));
+		if(tmp && q > 0 && n - h > 0)
+		{
+			memcpy(tmp, jobs[0].run_s, q * sizeof(double));
+			qsort(tmp, q, sizeof(double), cmp_double);
+			printf(", \"run_us_p99_startup\": %.1f", tmp[(int)((q - 1) * 0.99)] * 1e6);
+			memcpy(tmp, jobs[0].run_s + h, (n - h) * sizeof(double));
+			qsort(tmp, n - h, sizeof(double), cmp_double);
+			printf(", \"run_us_p50_steady\": %.1f, \"run_us_p99_steady\": %.1f", tmp[(n - h) / 2] * 1e6,
+					tmp[(int)((n - h - 1) * 0.99)] * 1e6);
+		}
+		free(tmp);
+	}
 	qsort(jobs[0].run_s, jobs[0].nruns, sizeof(double), cmp_double);
 	printf(", \"buffer_frames\": %d, \"run_us_p50\": %.1f, \"run_us_p99\": %.1f, \"run_us_max\": %.1f",
 			jobs[0].buffer, jobs[0].run_s[jobs[0].nruns / 2] * 1e6,

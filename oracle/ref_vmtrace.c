@@ -18,6 +18,8 @@
  *     core.c:1847-1880: offset, frames), in order ("p"; logged at the voice's first unit that is not an env, so that an env
  *     unit's write through its control wire, env.c:131, lands on the side of the window it belongs to), and every
  *     window of the ROOT voice ("r": where the engine cut its own fragments - the backend's fragments).
+ *     A voice that ENDS inside the traced stretch (its program runs out: OP_END, core.c:1191-1235, then a2_VoiceFree)
+ *     is traced up to the fragment it goes away in ("gone"; "fragments" = that fragment + 1, no "end_state").
  *   - for env units (src/units/env.c): where they sit in the chain, which VM registers are theirs, where the control
  *     output is wired.  Their internal state is private to env.c; a trace is therefore started before the program
  *     has written any env's 'target' (warm_fragments 0 and a delay at the head of the program), when it is the
@@ -92,7 +94,7 @@ int main(int argc, const char *argv[])
 	A2_unit *u, *last = NULL, *rootlast = NULL;
 	int nenvs = 0;
 	const A2_function *fn;
-	int args[8], nargs = 0, warm, nfrags, k, r, tries = 0;
+	int args[8], nargs = 0, warm, nfrags, k, r, tries = 0, gone = -1;
 	RCHM_handleinfo *hi;
 	if(argc < 5)
 	{
@@ -113,7 +115,10 @@ int main(int argc, const char *argv[])
 	}
 	st = ((A2_interface_i *)i)->state;
 	a2_TimestampReset(i);
-	if(a2_Starta(i, a2_RootVoice(i), prog, nargs, args) < 0)
+	/* (A2_VMTRACE_DETACHED=1: started the way a script's "Note P V" starts a voice - detached, no handle - so that a
+	 * program that runs out really ends, core.c:1208-1221; a2_Starta's voice hangs around at END for its handle) */
+	if(getenv("A2_VMTRACE_DETACHED") ? a2_Playa(i, a2_RootVoice(i), prog, nargs, args) != A2_OK :
+			a2_Starta(i, a2_RootVoice(i), prog, nargs, args) < 0)
 		return 4;
 	for(k = 0; k < warm; ++k)
 		a2_Run(i, 64);
@@ -211,12 +216,18 @@ int main(int argc, const char *argv[])
 		a2_Run(i, 64);
 		if(root->sub != voice)
 		{
-			fprintf(stderr, "ref_vmtrace: the voice went away in fragment %d\n", cur_frag);
-			return 6;
+			/* the voice ended (a2_VoiceFree, core.c:1892) in this fragment: the trace stops here, "gone" says
+			 * where - the windows logged for this fragment end at the frame of its last VM run */
+			gone = cur_frag;
+			++cur_frag;
+			break;
 		}
 	}
-	printf(" \"fragments\": %d, \"end_state\": {\"waketime\": %u, \"state\": %d, \"pc\": %d},\n \"events\": [", nfrags,
-			voice->s.waketime, voice->s.state, voice->s.pc);
+	if(gone >= 0)
+		printf(" \"fragments\": %d, \"gone\": %d,\n \"events\": [", cur_frag, gone);
+	else
+		printf(" \"fragments\": %d, \"end_state\": {\"waketime\": %u, \"state\": %d, \"pc\": %d},\n \"events\": [", nfrags,
+				voice->s.waketime, voice->s.state, voice->s.pc);
 	for(k = 0; k < nev; ++k)
 		if(ev[k].kind == 'w')
 			printf("%s[\"w\", %d, %d, %d, %u, %u, %d]", k ? ", " : "", ev[k].frag, ev[k].a, ev[k].b, ev[k].c, ev[k].d, ev[k].e);

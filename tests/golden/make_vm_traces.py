@@ -32,15 +32,26 @@ CASES = [("vmloops", "Lfo", [-1, .08, -.5], 20), ("vmloops", "Lfo", [.37, .05, .
          ("envtrace", "Behind", [-.5, .08, 5], 0), ("envtrace", "Behind", [.2, .08, 1], 0), ("envtrace", "Timed", [0, .08], 0),
          ("envtrace", "Two", [-.7, .08], 0), ("envtrace", "Siren", [-1.2, .08], 0), ("envtrace", "Plain", [.6, .08], 0),
          # a table look-up that runs past the table's end into the next one (round 4's soak, fuzz seed 3779)
-         ("envtrace", "Short", [-.5, .08], 0)]
+         ("envtrace", "Short", [-.5, .08], 0),
+         # round 5: programs that run out, sleep, call, divide by registers, draw random numbers (tests/a2s/vmnotes.a2s) -
+         # the device VM has them for the stretch in front of the first VM run that needs the engine (a2amd_vm_exit_time);
+         # started detached (no handle), the voices that run out are traced until they are gone
+         ("vmnotes", "Note", [-1, .08, -.5], 0, "detached"), ("vmnotes", "Note", [.4, .05, .5], 0, "detached"),
+         ("vmnotes", "Pluck", [-.5, .08], 0, "detached"), ("vmnotes", "Tail", [.2, .08], 0, "detached"),
+         ("vmnotes", "Div", [0, .08], 0, "detached"), ("vmnotes", "Call", [-.3, .08], 0, "detached"),
+         ("vmnotes", "Rnd", [.1, .08], 0, "detached"), ("vmnotes", "Sleeper", [-.5, .08], 0, "detached"),
+         ("vmnotes", "Hang", [.3, .08], 0)]
 
 if __name__ == "__main__":
     out = []
-    for script, prog, args, warm in CASES:
+    for script, prog, args, warm, *how in CASES:
+        env = dict(os.environ)
+        if "detached" in how:
+            env["A2_VMTRACE_DETACHED"] = "1"
         r = subprocess.run([EXE, script + ".a2s", prog, str(warm), "600"] + [repr(a) for a in args], cwd=A2S, capture_output=True,
-                           text=True, check=True)
+                           text=True, check=True, env=env)
         d = json.loads(r.stdout)
-        print(prog, args, len(d["code"]), "code words,", len(d["events"]), "events")
+        print(prog, args, len(d["code"]), "code words,", len(d["events"]), "events", "gone in fragment %d" % d["gone"] if "gone" in d else "")
         out.append(d)
     path = os.path.join(HERE, "vm_traces.json.xz")
     with lzma.open(path, "wt") as f:

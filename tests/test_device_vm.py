@@ -132,6 +132,40 @@ def test_scripted_bench_variants_on_the_device_vm(tmp_path, program, n4, buffer)
     assert stats == (4 * n4, 0), stats
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("buffer", [64, 4096, 1000])
+def test_notes_run_on_the_device_vm_up_to_the_run_that_ends_them(tmp_path, buffer):
+    """Round 5, tests/a2s/vmnotes.a2s: voices whose programs run out, sleep, call local functions, divide by registers,
+    draw from the engine's RNG, hang around attached - a song's notes.  The device VM takes each for the stretch of its
+    future that needs none of that (the look-ahead of a2amd_vm_adopt) and the walk hands it back to the engine in the
+    fragment that holds the first VM run that does (ENT.vm_exit, a2amd_walk.c): END, a2_VoiceFree, the CALL, the RAND
+    draw, SLEEP and the wake-up message are the engine's own, at the engine's own frame.  2 s against the CPU render."""
+    need_ref()
+    frames = 48000 * 2 // buffer * buffer
+    cpu, _, _ = render(tmp_path, "cpu", "vmnotes", "Main", frames, buffer, ["0.08"])
+    vm, stats, err = render(tmp_path, "vm", "vmnotes", "Main", frames, buffer, ["0.08"], preload=f"{WALK_SO} {UNITS_SO}")
+    assert cpu.any()
+    assert first_difference(cpu, vm, 2, buffer) is None, first_difference(cpu, vm, 2, buffer)
+    # 10 rounds of 7 notes + the sleeper's rounds: most of them must have been the device's for a while, and all but
+    # the notes still sounding when the render stops came back (none of these programs loops for ever)
+    assert stats and stats[0] >= 40 and stats[0] - 6 <= stats[1] <= stats[0], (stats, err[-400:])
+
+
+@pytest.mark.gpu
+def test_song_notes_are_taken_by_the_device_vm(tmp_path):
+    """tests/a2s/song.a2s (the plumbing-sized workload): its melodic notes and the kick - programs that run out - are
+    the device VM's between their first delay and their last VM run; hats and snares stay the engine's (their noise
+    oscillators draw from the engine's one RNG in walk order, a2amd_vm_adopt).  Audio = the CPU engine's."""
+    need_ref()
+    frames = 48000 * 4
+    cpu, _, _ = render(tmp_path, "cpu", "song", "Song", frames, 4096, [])
+    vm, stats, err = render(tmp_path, "vm", "song", "Song", frames, 4096, [], preload=f"{WALK_SO} {UNITS_SO}")
+    assert cpu.any()
+    assert first_difference(cpu, vm, 2, 4096) is None, first_difference(cpu, vm, 2, 4096)
+    # 4 s = 8 beats: 16 + 32 arpeggio notes ... per 16 ticks 32 Arp, 6 Bass, 3 Pad, 4 Kick of 69 notes
+    assert stats and stats[0] >= 60, (stats, err[-400:])
+
+
 # ---- CPU: analysis and host interpreter -------------------------------------------------------
 def lib():
     L = audiality2_amd.load_library()
@@ -321,22 +355,13 @@ def env_tables():
     return (ctypes.c_uint16 * (8 * 66))(*[v for row in t for v in row])
 
 
-@pytest.mark.parametrize("case", range(23))
-def test_host_interpreter_against_the_reference_vm(case):
-    """tests/golden/vm_traces.json.xz (made by tests/golden/make_vm_traces.py from oracle/ref_vmtrace.c: the COMPILED
-    REFERENCE's own VM running each looping voice of vmloops.a2s - and, cases 12 on, of envtrace.a2s: voices with env
-    units in every table mode, in front of and behind what they drive, with 'time' overrides, two on one voice, and
-    (case 22, 'Short') a table look-up that runs past its table's end into the engine's next table - for 600
-    fragments, every unit register write, every window and the root voice's windows logged).  The host copy of the
-    device VM's interpreter - the header the kernel is compiled from - takes over at the same moment (program text,
-    A2_vmstate, register wiring, env placement, engine clock, the engine's fragments as the root voice cut them) and
-    must produce the same windows and the same writes: register, value as the unit's callback transforms it
-    (a2amd_unit_write: wtosc / fm pitch + transpose + base pitch, filter12's 1/q, limiter's release and threshold; an env
-    segment's per-window value through its control wire), duration, start - in the same order, and end in the same VM
-    state.  No GPU involved."""
-    d = load_vm_traces()[case]
+def replay_trace(d, with_exit=False):
+    """One fixture of tests/golden/vm_traces.json.xz through the host copy of the interpreter: (records it made, the
+    reference's events in the same form, the VM state at the end, (has_exit, exit_when, writes of the stay), frames per
+    backend fragment)."""
     L = audiality2_amd.load_library()
     L.a2amd_vm_trace_host_env.restype = ctypes.c_int
+    L.a2amd_vm_trace_host_exit.restype = ctypes.c_int
     n = len(d["code"])
     code = (ctypes.c_uint32 * n)(*d["code"])
     st = VmState()
@@ -378,10 +403,15 @@ def test_host_interpreter_against_the_reference_vm(case):
     fb = (ctypes.c_uint8 * nfr)(*base)
     cap = 1 << 16
     recs = (ctypes.c_uint32 * (4 * cap))()
-    k = L.a2amd_vm_trace_host_env(code, ctypes.c_uint(n), ctypes.byref(st), (ctypes.c_int32 * 64)(*wu), (ctypes.c_uint8 * 64)(*wr),
-                                  (ctypes.c_int32 * len(kinds))(*kinds), len(kinds), ctypes.c_uint32(d["now"]),
-                                  ctypes.c_uint32(d["msdur"]), d["samplerate"], d["basepitch"], ff, fb, nfr, envs, len(d["envs"]),
-                                  env_tables(), recs, cap)
+    args = [code, ctypes.c_uint(n), ctypes.byref(st), (ctypes.c_int32 * 64)(*wu), (ctypes.c_uint8 * 64)(*wr),
+            (ctypes.c_int32 * len(kinds))(*kinds), len(kinds), ctypes.c_uint32(d["now"]),
+            ctypes.c_uint32(d["msdur"]), d["samplerate"], d["basepitch"], ff, fb, nfr, envs, len(d["envs"]),
+            env_tables(), recs, cap]
+    has_exit, exit_when, stay = ctypes.c_int32(0), ctypes.c_uint32(0), ctypes.c_int32(0)
+    if with_exit:
+        k = L.a2amd_vm_trace_host_exit(*args, ctypes.byref(has_exit), ctypes.byref(exit_when), ctypes.byref(stay))
+    else:
+        k = L.a2amd_vm_trace_host_env(*args)
     assert 0 < k < cap, k
     got = []
     for i in range(k):
@@ -420,11 +450,93 @@ def test_host_interpreter_against_the_reference_vm(case):
             v8 = i32((value << 8) & 0xffffffff)
             value = (abs(v8) // d["samplerate"]) * (1 if v8 >= 0 else -1) if reg == 0 else max(256, (value << 8) & 0xffffffff)
         want.append((frag, "w", bpos[pos], reg, value, dur, start & 255))
+    return got, want, st, (has_exit.value, exit_when.value, stay.value), frames
+
+
+@pytest.mark.parametrize("case", range(23))
+def test_host_interpreter_against_the_reference_vm(case):
+    """tests/golden/vm_traces.json.xz (made by tests/golden/make_vm_traces.py from oracle/ref_vmtrace.c: the COMPILED
+    REFERENCE's own VM running each looping voice of vmloops.a2s - and, cases 12 on, of envtrace.a2s: voices with env
+    units in every table mode, in front of and behind what they drive, with 'time' overrides, two on one voice, and
+    (case 22, 'Short') a table look-up that runs past its table's end into the engine's next table - for 600
+    fragments, every unit register write, every window and the root voice's windows logged).  The host copy of the
+    device VM's interpreter - the header the kernel is compiled from - takes over at the same moment (program text,
+    A2_vmstate, register wiring, env placement, engine clock, the engine's fragments as the root voice cut them) and
+    must produce the same windows and the same writes: register, value as the unit's callback transforms it
+    (a2amd_unit_write: wtosc / fm pitch + transpose + base pitch, filter12's 1/q, limiter's release and threshold; an env
+    segment's per-window value through its control wire), duration, start - in the same order, and end in the same VM
+    state.  No GPU involved."""
+    d = load_vm_traces()[case]
+    got, want, st, _, _ = replay_trace(d)
     assert len(want) > 20
     first = next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), None)
     assert first is None and len(got) == len(want), (first, got[first:first + 3] if first is not None else len(got),
                                                      want[first:first + 3] if first is not None else len(want))
     assert (st.waketime, st.state, st.pc) == (d["end_state"]["waketime"], d["end_state"]["state"], d["end_state"]["pc"])
+
+
+# what ends each stay of tests/a2s/vmnotes.a2s' voices, and how many frames of the trace it lasts at least / at most
+# (ms of the program text in front of the VM run that is the engine's; the trace starts inside the first delay)
+STAYS = {"Note": ("END", 25 + 40.5, 25 + 40.5 + 33), "Pluck": ("END", 9 * 11.3, 9 * 11.3 + 27), "Tail": ("END", 5 * 14.7, 6 * 14.7),
+         "Div": ("END", 12 * 9.9, 12 * 9.9 + 12), "Call": ("CALL", 20, 40), "Rnd": ("RAND", 4 * 13, 5 * 13),
+         "Sleeper": ("SLEEP", 8 * 12.1, 8 * 12.1 + 20), "Hang": ("END", 4 * 21, 4 * 21 + 9)}
+
+
+@pytest.mark.parametrize("case", range(23, 32))
+def test_host_interpreter_stops_where_the_engine_has_to_take_over(case):
+    """Round 5 (the rest of SURVEY 8 f4): programs that END, SLEEP, CALL, draw from the engine's RNG, divide by registers
+    (tests/a2s/vmnotes.a2s), traced from the compiled reference's VM like the looping ones - the voices that run out
+    until they are gone.  a2amd_vm_trace_host_exit() makes the look-ahead a2amd_vm_adopt makes for such a voice and
+    stops the interpreter in front of the first VM run that is the engine's: up to there it reproduces the reference's
+    windows and writes record for record (register divisors included), the exit lies in the frame the program text
+    says, the state handed back is the one the engine's VM had when it started that run - for a voice that runs out,
+    the run that ended it: the trace's last window ends exactly there."""
+    d = load_vm_traces()[case]
+    got, want, st, (has_exit, exit_when, stay), frames = replay_trace(d, with_exit=True)
+    assert has_exit == 1
+    why, lo_ms, hi_ms = STAYS[d["program"]]
+    xf = ((exit_when - d["now"]) & 0xffffffff) >> 8            # frames into the trace
+    assert lo_ms * 48 - 64 <= xf <= hi_ms * 48 + 1, (d["program"], xf, lo_ms * 48, hi_ms * 48)
+    # where that is on the backend's fragment grid
+    frag, acc = 0, 0
+    while acc + frames[frag] <= xf:
+        acc += frames[frag]
+        frag += 1
+    off = xf - acc
+
+    def before(ev):
+        return ev[0] < frag or (ev[0] == frag and ev[1] == "p" and ev[2] < off)
+    # ours: everything in front of the exit; behind it the voice only gets default windows (and the rest of the exit's fragment)
+    ours = [e for e in got if before(e) or (e[0] == frag and e[1] == "w" and got.index(e) < next(
+        (i for i, g in enumerate(got) if g[0] == frag and g[1] == "p" and g[2] >= off), len(got)))]
+    assert not [e for e in got if e[1] == "w" and e not in ours], "a write behind the exit"
+    # the reference's: its events up to the window that ends at the exit (what follows belongs to the run that is the engine's)
+    cut = len(want)
+    for i, e in enumerate(want):
+        if e[0] > frag or (e[0] == frag and e[1] == "p" and e[2] >= off):
+            cut = i
+            break
+    if off:     # (the window [0, off) of the exit's fragment is part of the stay; writes behind it are the exit run's)
+        k = next((i for i, e in enumerate(want) if e[0] == frag and e[1] == "p" and e[2] + e[3] == off), None)
+        assert k is not None, (frag, off, [e for e in want if e[0] == frag])
+        cut = k + 1
+    else:
+        cut = next((i for i, e in enumerate(want) if e[0] >= frag), len(want))
+    ref = want[:cut]
+    first = next((i for i, (a, b) in enumerate(zip(ours, ref)) if a != b), None)
+    assert first is None and len(ours) == len(ref), (first, ours[first:first + 3] if first is not None else len(ours),
+                                                     ref[first:first + 3] if first is not None else len(ref))
+    assert len([e for e in ref if e[1] == "w"]) == stay and stay >= 1
+    assert st.waketime == exit_when and st.state == 1       # (A2_WAITING: asleep in the delay in front of that run)
+    if "gone" in d and why == "END":
+        # the voice ran out: the engine ended it in the VM run at 'exit_when' - the last window it got ends there
+        last = [e for e in d["events"] if e[0] == "p"][-1]
+        assert d["fragments"] == d["gone"] + 1
+        lastfrag_start = 64 * d["gone"]
+        if last[1] == d["gone"]:
+            assert lastfrag_start + last[2] + last[3] == xf, (last, xf)
+        else:       # (it ended in the first frame of the fragment: no window there)
+            assert xf == lastfrag_start, (last, xf)
 
 
 def test_host_interpreter_cutoff_goes_through_the_coefficient_table():

@@ -86,8 +86,10 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--period", type=int, default=2)
     ap.add_argument("--what", default="pitch")
+    ap.add_argument("--names", default="quiet,scripted,scripted2,scripted3,quiet2",
+                    help="the batches to run, in order (quiet*: no records, scripted*: with)")
     args = ap.parse_args()
-    res = measure(args.voices, args.chain, args.batch, args.period, args.what)
+    res = measure(args.voices, args.chain, args.batch, args.period, args.what, names=tuple(args.names.split(",")))
     print(json.dumps({"voices": args.voices, "chain": args.chain, "fragments_per_batch": args.batch, "what": args.what,
                       "voices_with_records_per_fragment": 1.0 / args.period, **res}))
 
