@@ -255,13 +255,17 @@ int a2d_launch_leaf_osc2pan(const A2DParams *dparams, const A2DParams &hp, const
 int a2d_launch_leaf_recs(const A2DParams *dparams, const A2DParams &hp, int nosc, int filt, const int *dlist,
 		int nlist, int vpw, void *stream, int skip_empty = 0);
 // Round 5 (a2amd_win.hip): the same voices in two passes.  The control pass (lane = voice) walks the
-// records of fragments [fa, fb) and leaves closed-form window entries of A2D_WIN_WORDS words: the first
-// window of fragment f for list position i in its slot wslot[(f - fa) * nlist + i], further windows of
-// that fragment in the pool wext from index widx[(f - fa) * nlist + i] on (pool indices from the counter
-// wtop[0], at most wcap; wtop[1] != 0: the pool was too small).  The render pass (lane = frame) evaluates them.
+// records of fragments [fa, fb) and leaves closed-form window entries: the first window of fragment f for
+// list position i in its slot wslot[((f - fa) * nlist + i) * A2D_WIN_SLOTWORDS(nosc, filt)], further windows
+// of that fragment in the pool wext (A2D_WIN_WORDS apart) from index widx[(f - fa) * nlist + i] on (pool
+// indices from the counter wtop[0], at most wcap; wtop[1] != 0: the pool was too small); wrc[i]: where a
+// voice's walk through its records stands between two slabs of a batch.  The render pass (lane = frame)
+// evaluates them.
 #define A2D_WIN_WORDS 24
+#define A2D_WIN_SLOTWORDS(nosc, filt) ((filt) ? ((nosc) == 1 ? 20 : 24) : ((nosc) == 1 ? 12 : 20))
 int a2d_launch_win_ctl(const A2DParams *dparams, const A2DParams &hp, int nosc, int filt, const int *dlist, int nlist,
-		int skip_empty, int fa, int fb, int *wslot, int *wext, unsigned *widx, unsigned *wtop, unsigned wcap, void *stream);
+		int skip_empty, int fa, int fb, int *wslot, int *wext, unsigned *widx, unsigned *wtop, unsigned wcap, int *wrc,
+		void *stream);
 int a2d_launch_win_render(const A2DParams &hp, int nosc, int filt, const int *dlist, int nlist, int fa, int fb,
 		const int *wslot, const int *wext, const unsigned *widx, void *stream);
 // ... all four kinds in one launch: lists[k] / counts[k] for (nosc, filt) = (1,0) (2,0) (1,1) (2,1)

@@ -102,7 +102,12 @@ void a2amd_close(a2amd_ctx *c)
 		hipEventDestroy(c->grp_ev);
 	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
 	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
-	hipFree(c->d_win.d); hipFree(c->d_wext.d); hipFree(c->d_widx.d); hipFree(c->d_wtop);
+	hipFree(c->d_win.d); hipFree(c->d_wext.d); hipFree(c->d_wrc.d); hipFree(c->d_widx.d); hipFree(c->d_wtop);
+	if(c->win_stream)
+		hipStreamDestroy(c->win_stream);
+	for(int k = 0; k < 5; ++k)
+		if(c->win_ev[k])
+			hipEventDestroy(c->win_ev[k]);
 	hipFree(c->d_waves.d); hipFree(c->d_wavepool.d); hipFree(c->d_wavecoef.d); hipFree(c->d_busmem.d);
 	vm_close(c);
 	hipFree(c->capture.d); hipFree(c->capture.d_fragpos);
@@ -501,6 +506,7 @@ int a2amd_unit_init(a2amd_ctx *c, uint64_t key, int kind, unsigned flags, int ni
 	  case A2AMD_FILTER12:
 		if(nin != nout || nin < 1 || nin > 2)
 			return c->fail(A2AMD_EINVAL, "filter12 %d->%d", nin, nout);
+		vm_start_f1tab(c);	// (its cutoff may one day be written by the device VM)
 		break;
 	  case A2AMD_XINSERT:
 		if(nin != nout || nin < 1)

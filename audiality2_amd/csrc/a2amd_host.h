@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <map>
 #include <vector>
+#include <future>
 
 #include "../../include/a2amd.h"
 #include "../../include/a2amd_vm.h"
@@ -264,7 +265,10 @@ struct VmHost {
 	uint32_t msdur = 0;
 	uint64_t batch_time = 0;	// walk_time when the batch being recorded began
 	uint64_t replayed = 0;		// frames the kept batch has been re-run over (a2amd_replay / KEEP)
-	std::vector<int32_t> f1tab;	// [32][65536], built on first need
+	std::vector<int32_t> f1tab;	// [32][65536]: made on a thread of its own from the moment the context opens (two
+					// million libm sines, tens of ms: not on the engine thread in the middle of a fragment)
+	std::future<std::vector<int32_t>> f1_future;
+	uint32_t f1_future_sum = 0;	// (of the pitch table that thread works from)
 	uint32_t f1tab_sum = 0;		// (of the pitch table it was made from)
 	bool f1tab_up = false;
 	// the device's states as the last batch left them, fetched when the engine wants voices back:
@@ -472,9 +476,11 @@ struct a2amd_ctx {
 	// the window kernels (a2amd_win.hip): a slab's slots (one per fragment and voice), the pool of further
 	// windows, where each voice's begin per fragment, the pool counter + overflow flag
 	std::vector<int> moving;	// voices with moving_until set
-	DevBuf<int> d_win, d_wext;
+	DevBuf<int> d_win, d_wext, d_wrc;
 	DevBuf<unsigned> d_widx;
-	unsigned *d_wtop = nullptr;
+	unsigned *d_wtop = nullptr;	// [2 sets]{ pool counter, overflow flag }
+	hipStream_t win_stream = nullptr;	// the control passes' stream (slabs: issue_windows, a2amd_sched.cpp)
+	hipEvent_t win_ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };	// control pass of set 0 / 1 done, render pass of set 0 / 1 done, fork
 
 	a2amd_stats stats;
 	VmHost vm;
@@ -583,6 +589,7 @@ int vm_issue(a2amd_ctx *c);			// issue_kernels(): the VM kernel's two passes
 int vm_take_back(a2amd_ctx *c, int vi, bool inclusive, a2amd_vm_state *out, a2amd_vm_env *envs_out = nullptr);	// the voice is the host's again
 void vm_end_batch(a2amd_ctx *c);
 void vm_close(a2amd_ctx *c);
+void vm_start_f1tab(a2amd_ctx *c);		// the cutoff -> coefficient table, made on a thread of its own
 int vm_blob_room(a2amd_ctx *c);			// records the VM's region of the blob should hold
 
 } // namespace a2h

@@ -513,6 +513,9 @@ int upload(a2amd_ctx *c)
 				continue;
 			}
 			++i;
+			// (a voice slot that was recycled while it stood in the list stands in it twice)
+			if(v.moving_run == c->serial_base)
+				continue;
 			if(no_moving || !v.recs.empty() || v.vm >= 0 || c->lists_dirty || v.mode_mix || !v.resolved ||
 					!(v.cls == CLS_OSCPAN || v.cls == CLS_OSC2PAN || v.cls == CLS_OSCFILTPAN))
 				continue;
@@ -1008,53 +1011,117 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 	if(!nj)
 		return 0;
 	static const size_t budget = (size_t)(getenv("A2AMD_WIN_MB") ? atoi(getenv("A2AMD_WIN_MB")) : 1024) * (1u << 20) /
-			(A2D_WIN_WORDS * sizeof(int));
+			(A2D_WIN_WORDS * sizeof(int)) / 2;
+	// Slabs: the control pass (lane = voice: a few hundred wavefronts, each as long as its voices' walk) of slab
+	// k + 1 runs on a stream of its own beside the render pass of slab k - two sets of slots and pools.  A batch
+	// of 16 fragments or more is cut into four slabs (A2AMD_WIN_SLABS), a shorter one is one slab.
+	// (measured, 16 384 scripted voices x 64 fragments: 0.50 ms as one slab, 0.76 as four - the control pass is as
+	// long as ONE wavefront's walk, and a wavefront that shares its SIMD with seven render wavefronts walks at a
+	// fraction of its pace - so slabs are what the memory bound asks for, not the default)
+	static const int want_slabs = getenv("A2AMD_WIN_SLABS") ? std::max(1, atoi(getenv("A2AMD_WIN_SLABS"))) : 1;
 	const int nfrags = c->nfrags;
-	int per = nfrags;
-	if(nvoices * (size_t)nfrags > budget)
-		per = (int)std::min<size_t>((size_t)nfrags, std::max<size_t>(1, budget / nvoices));
+	int per = nfrags >= 16 ? (nfrags + want_slabs - 1) / want_slabs : nfrags;
+	if(nvoices * (size_t)per > budget)
+		per = (int)std::max<size_t>(1, budget / nvoices);
+	const int nslabs = (nfrags + per - 1) / per;
+	const bool two = nslabs > 1;
 	const size_t nslots = nvoices * (size_t)per, cap = std::max<size_t>(nrec, 1);
+	size_t slotwords = 0;		// of a slab: every list's slots at its class's size
+	for(int j = 0; j < nj; ++j)
+		slotwords += (size_t)jobs[j].n * (size_t)per * A2D_WIN_SLOTWORDS(jobs[j].nosc, jobs[j].filt);
 	if(cap >= ((size_t)1 << 32))
 		return c->fail(A2AMD_EUNSUPPORTED, "a batch of %zu records", cap);
-	if(nslots > c->d_win.cap || cap > c->d_wext.cap || nslots > c->d_widx.cap || !c->d_wtop) {
+	const size_t sets = two ? 2 : 1;
+	if(sets * slotwords > c->d_win.cap || sets * cap > c->d_wext.cap || sets * nslots > c->d_widx.cap || nvoices > c->d_wrc.cap ||
+			!c->d_wtop || (two && !c->win_stream)) {
 		if(c->capturing)
 			return c->fail(A2AMD_ESTATE, "window pool too small inside a graph capture");
-		if(int r = grow(c, c->d_win, nslots, A2D_WIN_WORDS, false)) return r;
-		if(int r = grow(c, c->d_wext, cap, A2D_WIN_WORDS, false)) return r;
-		if(int r = grow(c, c->d_widx, nslots, 1, false)) return r;
+		if(int r = grow(c, c->d_win, sets * slotwords, 1, false)) return r;
+		if(int r = grow(c, c->d_wext, sets * cap, A2D_WIN_WORDS, false)) return r;
+		if(int r = grow(c, c->d_widx, sets * nslots, 1, false)) return r;
+		if(int r = grow(c, c->d_wrc, nvoices, 1, false)) return r;
 		if(!c->d_wtop)
-			HIPCHK(c, hipMalloc((void **)&c->d_wtop, 2 * sizeof(unsigned)));
+			HIPCHK(c, hipMalloc((void **)&c->d_wtop, 4 * sizeof(unsigned)));
+		if(two && !c->win_stream) {
+			HIPCHK(c, hipStreamCreateWithFlags(&c->win_stream, hipStreamNonBlocking));
+			for(int k = 0; k < 5; ++k)
+				HIPCHK(c, hipEventCreateWithFlags(&c->win_ev[k], hipEventDisableTiming));
+		}
 	}
-	for(int fa = 0; fa < nfrags; fa += per) {
-		const int fb = std::min(nfrags, fa + per);
-		HIPCHK(c, hipMemsetAsync(c->d_wtop, 0, 2 * sizeof(unsigned), c->stream));
-		size_t at = 0;
+	// (the sets are laid out by the CURRENT capacities: a graph captured earlier was dropped when they grew)
+	const size_t half_win = c->d_win.cap / 2, half_ext = c->d_wext.cap / 2, half_idx = c->d_widx.cap / 2;
+	hipStream_t sc = two ? c->win_stream : c->stream;		// the control passes' stream
+	if(two) {
+		// everything issued so far (uploads, the device VM's records, the quiet kernels) comes first
+		HIPCHK(c, hipEventRecord(c->win_ev[4], c->stream));
+		HIPCHK(c, hipStreamWaitEvent(sc, c->win_ev[4], 0));
+	}
+	static const bool wtiming = getenv("A2AMD_WIN_TIMING") != nullptr;
+	static hipEvent_t tev[3] = { nullptr, nullptr, nullptr };
+	int k = 0;
+	for(int fa = 0; fa < nfrags; fa += per, ++k) {
+		const int fb = std::min(nfrags, fa + per), set = two ? (k & 1) : 0;
+		int *const wslot = c->d_win.d + (size_t)set * half_win;
+		int *const wext = c->d_wext.d + (size_t)set * half_ext * A2D_WIN_WORDS;
+		unsigned *const widx = c->d_widx.d + (size_t)set * half_idx;
+		unsigned *const wtop = c->d_wtop + 2 * set;
+		if(two && k >= 2)	// (the render pass that read this set has to be done with it)
+			HIPCHK(c, hipStreamWaitEvent(sc, c->win_ev[2 + set], 0));
+		if(wtiming && !two && !c->capturing) {
+			for(int q = 0; q < 3; ++q)
+				if(!tev[q])
+					HIPCHK(c, hipEventCreate(&tev[q]));
+			HIPCHK(c, hipEventRecord(tev[0], c->stream));
+		}
+		HIPCHK(c, hipMemsetAsync(wtop, 0, 2 * sizeof(unsigned), sc));
+		size_t at = 0, atw = 0, atv = 0;
 		for(int j = 0; j < nj; ++j) {
 			const Job &b = jobs[j];
 			if(a2d_launch_win_ctl(c->d_params, c->hparams, b.nosc, b.filt, b.list, b.n, b.skip, fa, fb,
-					c->d_win.d + at * A2D_WIN_WORDS, c->d_wext.d, c->d_widx.d + at, c->d_wtop,
-					(unsigned)std::min<size_t>(c->d_wext.cap, 0xffffffffu), c->stream))
+					wslot + atw, wext, widx + at, wtop,
+					(unsigned)std::min<size_t>(two ? half_ext : c->d_wext.cap, 0xffffffffu), c->d_wrc.d + atv, sc))
 				return c->fail(A2AMD_EHIP, "window control launch failed: %s", hipGetErrorString(hipGetLastError()));
 			at += (size_t)b.n * (size_t)(fb - fa);
+			atw += (size_t)b.n * (size_t)(fb - fa) * A2D_WIN_SLOTWORDS(b.nosc, b.filt);
+			atv += (size_t)b.n;
 			++c->stats.launches;
 		}
-		at = 0;
+		if(two) {
+			HIPCHK(c, hipEventRecord(c->win_ev[set], sc));
+			HIPCHK(c, hipStreamWaitEvent(c->stream, c->win_ev[set], 0));
+		}
+		if(wtiming && !two && !c->capturing)
+			HIPCHK(c, hipEventRecord(tev[1], c->stream));
+		at = atw = 0;
 		for(int j = 0; j < nj; ++j) {
 			const Job &b = jobs[j];
-			if(a2d_launch_win_render(c->hparams, b.nosc, b.filt, b.list, b.n, fa, fb, c->d_win.d + at * A2D_WIN_WORDS,
-					c->d_wext.d, c->d_widx.d + at, c->stream))
+			if(a2d_launch_win_render(c->hparams, b.nosc, b.filt, b.list, b.n, fa, fb, wslot + atw,
+					wext, widx + at, c->stream))
 				return c->fail(A2AMD_EHIP, "window render launch failed: %s", hipGetErrorString(hipGetLastError()));
 			at += (size_t)b.n * (size_t)(fb - fa);
+			atw += (size_t)b.n * (size_t)(fb - fa) * A2D_WIN_SLOTWORDS(b.nosc, b.filt);
 			++c->stats.launches;
+		}
+		if(two)
+			HIPCHK(c, hipEventRecord(c->win_ev[2 + set], c->stream));
+		if(wtiming && !two && !c->capturing) {
+			// (A2AMD_WIN_TIMING=1: the two passes' times per slab on stderr - a measurement aid that waits for the GPU)
+			float t_ctl = 0, t_ren = 0;
+			HIPCHK(c, hipEventRecord(tev[2], c->stream));
+			HIPCHK(c, hipEventSynchronize(tev[2]));
+			hipEventElapsedTime(&t_ctl, tev[0], tev[1]);
+			hipEventElapsedTime(&t_ren, tev[1], tev[2]);
+			fprintf(stderr, "a2amd windows: fragments [%d, %d), %zu voices in %d list(s), %zu records: control pass %.1f us, render pass %.1f us\n",
+					fa, fb, nvoices, nj, nrec, t_ctl * 1e3, t_ren * 1e3);
 		}
 	}
 	static const bool check = getenv("A2AMD_WIN_CHECK") != nullptr;
 	if(check && !c->capturing) {
-		unsigned top[2] = { 0, 0 };
+		unsigned top[4] = { 0, 0, 0, 0 };
 		HIPCHK(c, hipMemcpyAsync(top, c->d_wtop, sizeof(top), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
-		if(top[1])
-			return c->fail(A2AMD_ESTATE, "window pool overflow (%u of %zu entries)", top[0], c->d_wext.cap);
+		if(top[1] || (two && top[3]))
+			return c->fail(A2AMD_ESTATE, "window pool overflow (%u / %u of %zu entries)", top[0], top[2], c->d_wext.cap);
 	}
 	return 0;
 }

@@ -165,6 +165,9 @@ typedef struct HOSTSTATE
 	unsigned	win_pos;	/* ... up to the start of the open root window */
 	unsigned	acc_pos;	/* frames of the buffer rendered so far (in acc) */
 	unsigned	acc_cap;
+	/* round 5: the first half of a long buffer is on the GPU while the engine walks the second (flush_part) */
+	unsigned	split_frames;	/* this buffer: hand the batch over once this many frames are recorded (0: whole) */
+	unsigned	part_at, part_frames;	/* the part in flight: where its audio goes in acc, how many frames */
 	int32_t		*acc[A2AMD_MAXCHANNELS];	/* the buffer's master bus, as rendered */
 	int32_t		*rinj[A2AMD_MAXCHANNELS];	/* what WRITE clients of the root xinsert produced */
 	int		rinj_used;
@@ -1142,13 +1145,72 @@ static int render_batch(HOSTSTATE *hs, int32_t **outp, unsigned cap)
 	return a2amd_render(hs->ctx, A2AMD_RENDER_ROOT | A2AMD_RENDER_READBACK, outp, cap);
 }
 
+/* the part of the buffer that was handed over early (flush_part): its audio into its place */
+static void collect_part(HOSTSTATE *hs)
+{
+	int32_t *outp[A2AMD_MAXCHANNELS];
+	int c, n;
+	if(!hs->part_frames)
+		return;
+	for(c = 0; c < A2AMD_MAXCHANNELS; ++c)
+		outp[c] = hs->acc[c] ? hs->acc[c] + hs->part_at : NULL;
+	if(!hs->failed && (n = a2amd_collect(hs->ctx, outp, hs->part_frames)) != (int)hs->part_frames)
+		fail(hs, "a2amd_collect", n);
+	if(hs->failed)
+		for(c = 0; c < hs->cfg->channels; ++c)
+			memset(hs->acc[c] + hs->part_at, 0, hs->part_frames * sizeof(int32_t));
+	hs->part_frames = 0;
+}
+
+static void flush_batch(HOSTSTATE *hs);
+
+/* Round 5: a long buffer (a2play's 4 096 frames) is not rendered in ONE round trip behind the engine's walk
+ * of all of it - the GPU idle while the engine walks, the engine idle while the GPU renders - but in two: what
+ * has been recorded by the middle of the buffer is launched without waiting (A2AMD_RENDER_ASYNC), the engine
+ * walks the second half beside it, and the buffer's end renders the rest and collects both.  Only where nothing
+ * has to come back in between: one context, no sink / insert clients waiting for their windows. */
+static void flush_part(HOSTSTATE *hs)
+{
+	int n;
+	if(!hs->batch_frags)
+		return;
+	if(hs->failed || hs->ndev != 1 || hs->ninserts || hs->npend || hs->nzombies || hs->part_frames)
+	{
+		flush_batch(hs);
+		return;
+	}
+	n = a2amd_render(hs->ctx, A2AMD_RENDER_ALL | A2AMD_RENDER_ASYNC, NULL, 0);
+	if(n == A2AMD_EUNSUPPORTED)
+	{
+		/* (READ clients attached somewhere: their taps have to come back with the audio) */
+		hs->split_frames = 0;
+		flush_batch(hs);
+		return;
+	}
+	if(n != (int)(hs->rec_pos - hs->acc_pos))
+		fail(hs, "a2amd_render", n);
+	hs->part_at = hs->acc_pos;
+	hs->part_frames = hs->failed ? 0 : hs->rec_pos - hs->acc_pos;
+	if(hs->failed)
+	{
+		int c;
+		for(c = 0; c < hs->cfg->channels; ++c)
+			memset(hs->acc[c] + hs->acc_pos, 0, (hs->rec_pos - hs->acc_pos) * sizeof(int32_t));
+	}
+	hs->acc_pos = hs->rec_pos;
+	hs->batch_frags = 0;
+}
+
 /* render what has been recorded of the buffer so far */
 static void flush_batch(HOSTSTATE *hs)
 {
 	int32_t *outp[A2AMD_MAXCHANNELS];
 	int c, n;
 	if(!hs->batch_frags)
+	{
+		collect_part(hs);
 		return;
+	}
 	for(c = 0; c < A2AMD_MAXCHANNELS; ++c)
 		outp[c] = hs->acc[c] ? hs->acc[c] + hs->acc_pos : NULL;
 	if(!hs->failed)
@@ -1162,6 +1224,7 @@ static void flush_batch(HOSTSTATE *hs)
 			memset(hs->acc[c] + hs->acc_pos, 0, (hs->rec_pos - hs->acc_pos) * sizeof(int32_t));
 	hs->acc_pos = hs->rec_pos;
 	hs->batch_frags = 0;
+	collect_part(hs);	/* (rendered before this batch: its copy is done) */
 	if(hs->npend || hs->nzombies)
 		deliver_pending(hs);
 }
@@ -1211,6 +1274,14 @@ static void amd_drv_process(A2P_audiodriver *drv, unsigned frames)
 	hs->rec_pos = hs->win_pos = hs->acc_pos = 0;
 	hs->batch_frags = 0;
 	hs->rinj_used = 0;
+	hs->part_frames = 0;
+	{
+		/* (A2AMD_SPLIT=0: the whole buffer in one round trip, as rounds 2-4 did; n: from n frames on) */
+		static int split_min = -1;
+		if(split_min < 0)
+			split_min = getenv("A2AMD_SPLIT") ? atoi(getenv("A2AMD_SPLIT")) : 1024;
+		hs->split_frames = split_min > 0 && frames >= (unsigned)split_min && hs->ndev == 1 ? (frames / 2 + 63) / 64 * 64 : 0;
+	}
 	if(!grow_acc(hs, frames))
 		hs->decided = 1;	/* (out of memory: this buffer the old way) */
 	if(timing_on)
@@ -1537,6 +1608,8 @@ static void amd_inline_process(A2P_unit *u, unsigned offset, unsigned frames)
 		}
 		if(hs->batching && hs->batch_frags == hs->max_batch)
 			flush_batch(hs);
+		else if(hs->batching && hs->split_frames && !hs->part_frames && hs->acc_pos == 0 && hs->rec_pos >= hs->split_frames)
+			flush_part(hs);
 		{
 			int d;
 			for(d = 0; d < hs->ndev; ++d)

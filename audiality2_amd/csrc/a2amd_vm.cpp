@@ -82,30 +82,60 @@ Consts consts_of(a2amd_ctx *c)
 // result is X(n) >> ((7 - oct) & 31) with X a function of the 16 fraction bits n alone, so 32 x
 // 65536 entries cover every pitch - made here with the reference's own float / double / libm
 // expression (a2amd_host.h: f12_coeff), which is why the device never evaluates a sine
-void build_f1tab(a2amd_ctx *c)
+static uint32_t ptab_sum(const uint32_t *ptab)
 {
-	VmHost &m = c->vm;
 	uint32_t sum = 0;
 	for(int i = 0; i < 128; ++i)
-		sum = sum * 31u + c->ptab[i];
-	if(!m.f1tab.empty() && m.f1tab_sum == sum)
-		return;
-	m.f1tab.resize((size_t)32 * 65536);
+		sum = sum * 31u + ptab[i];
+	return sum;
+}
+
+static std::vector<int32_t> make_f1tab(const uint32_t *ptab, int samplerate)
+{
+	std::vector<int32_t> t((size_t)32 * 65536);
 	for(unsigned sh = 0; sh < 32; ++sh) {
 		// a pitch whose a2_P2I shift count is sh: oct = 7 - sh (any oct with (7 - oct) & 31 == sh)
 		const int oct = 7 - (int)sh;
 		for(unsigned n = 0; n < 65536; ++n) {
 			const int pitch = (int)(((unsigned)oct << 16) | n);
 			// (f12_coeff takes the ramper value: the pitch is value >> 8)
-			float f = a2h::p2i(c->ptab, pitch) * (261.626f / 16777216.0f);
+			float f = a2h::p2i(ptab, pitch) * (261.626f / 16777216.0f);
 			int v;
-			if(f > (c->cfg.samplerate >> 2))
+			if(f > (samplerate >> 2))
 				v = 362 << 16;
 			else
-				v = (int)(512.0f * 65536.0f * sin(M_PI * f / c->cfg.samplerate));
-			m.f1tab[(size_t)sh * 65536 + n] = v;
+				v = (int)(512.0f * 65536.0f * sin(M_PI * f / samplerate));
+			t[(size_t)sh * 65536 + n] = v;
 		}
 	}
+	return t;
+}
+
+// (a2amd_open / a2amd_set_pitch_table: the table is on its way long before the first filter voice is adopted)
+void start_f1tab(a2amd_ctx *c)
+{
+	VmHost &m = c->vm;
+	static const bool off = getenv("A2AMD_NO_VM") != nullptr;
+	if(off)
+		return;
+	struct Args { uint32_t ptab[128]; int sr; };
+	Args a;
+	memcpy(a.ptab, c->ptab, sizeof(a.ptab));
+	a.sr = c->cfg.samplerate;
+	m.f1_future_sum = ptab_sum(c->ptab);
+	m.f1_future = std::async(std::launch::async, [a]() { return make_f1tab(a.ptab, a.sr); });
+}
+
+void build_f1tab(a2amd_ctx *c)
+{
+	VmHost &m = c->vm;
+	const uint32_t sum = ptab_sum(c->ptab);
+	if(!m.f1tab.empty() && m.f1tab_sum == sum)
+		return;
+	if(m.f1_future.valid() && m.f1_future_sum == sum)
+		m.f1tab = m.f1_future.get();
+	else
+		m.f1tab = make_f1tab(c->ptab, c->cfg.samplerate);
 	m.f1tab_sum = sum;
 	m.f1tab_up = false;
 }
@@ -504,6 +534,16 @@ int vm_take_back(a2amd_ctx *c, int vi, bool inclusive, a2amd_vm_state *out, a2am
 	--m.stats.live;
 	++m.stats.recalled;
 	return A2AMD_OK;
+}
+
+// the first filter12 / dcblock unit of a context, a new pitch table: the coefficient table the device VM will
+// want (a2vm::f1_of_pitch) starts being made, on a thread of its own
+void vm_start_f1tab(a2amd_ctx *c)
+{
+	VmHost &m = c->vm;
+	if((m.f1_future.valid() && m.f1_future_sum == ptab_sum(c->ptab)) || (!m.f1tab.empty() && m.f1tab_sum == ptab_sum(c->ptab)))
+		return;
+	start_f1tab(c);
 }
 
 int vm_blob_room(a2amd_ctx *c)

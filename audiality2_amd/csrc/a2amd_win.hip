@@ -15,7 +15,7 @@
 //                           batch's fragments and carries the voice's whole control state -
 //                           rampers, pitch -> increment (a2_P2I), mip level, phase, wave,
 //                           mode, liveness - in vector registers; for every window of the
-//                           chain it writes one closed-form ENTRY (A2D_WIN_WORDS words): where
+//                           chain it writes one closed-form ENTRY (12 to 24 words): where
 //                           each oscillator's taps start and how they step, amplitude, volume
 //                           and pan values and per-frame deltas, the filter's cutoff
 //                           coefficient and q with their steps.  64 voices per wavefront
@@ -43,18 +43,24 @@
 #include "a2amd_dsp.h"
 #include "a2amd_taps.h"
 
-// Layout (round 5, second cut): one SLOT of A2D_WIN_WORDS words per (fragment, list position) -
-// wslot[(f - fa) * nlist + i] - holds the fragment's first window (the only one, for most voices in
-// most fragments); further windows of the same fragment ("extras": a script's sub-fragment
-// windows) go to the voice's run of the pool wext, in order, widx[(f - fa) * nlist + i] naming
-// the first.  So what a render wavefront needs for its voices in a fragment is ONE contiguous
-// block it can ask for ahead of time, and what 64 control lanes write per fragment is one too.
+// Layout: one SLOT per (fragment, list position) - wslot[((f - fa) * nlist + i) * SW] - holds the
+// fragment's first window (the only one, for most voices in most fragments); further windows of the
+// same fragment ("extras": a script's sub-fragment windows) go to the voice's run of the pool wext, in
+// order (A2D_WIN_WORDS apart whatever the class: one pool for all), widx[(f - fa) * nlist + i] naming the first.  What 64 control lanes write per fragment is one
+// contiguous block, and a render wavefront reads its voices' slots of a fragment the same way: LANE =
+// VOICE, a few 16-byte loads each, asked for a fragment ahead - the words then come out of the vector
+// registers with v_readlane when the voice's turn comes (what the quiet kernels do with voice state).
+// (The first cuts fetched entries through the scalar cache: 1.5 million 96-byte entries per batch
+// is not what that cache is for - the render pass ran at a third of this.)
 //
-// slot / entry words (A2D_WIN_WORDS = 24)
+// slot / entry words: head, panmix (4), oscillators (6 each), then - filter classes - filter12 (7);
+// SW words per class, a multiple of 4
 enum { WE_HEAD = 0,	// off | len << 6 | clamp << 13 | fresh << 14 | mode0 << 15 | mode1 << 17 | extras << 19
-	WE_F0, WE_DF, WE_QV, WE_QD, WE_LP, WE_BP, WE_HP,	// filter12: coefficient + step, q + step, mix levels
 	WE_VOL, WE_DVOL, WE_PAN, WE_DPAN,			// panmix: values at the window's first frame, per-frame deltas
-	WE_OSC = 12 };						// 6 words per oscillator:
+	WE_OSC = 5 };						// 6 words per oscillator (below)
+enum { WF_F0 = 0, WF_DF, WF_QV, WF_QD, WF_LP, WF_BP, WF_HP };	// filter12, from word 5 + 6 * NOSC: coefficient + step, q + step, mix levels
+#define WIN_NW(NOSC)       (5 + 6 * (NOSC))			/* words the oscillator / pan stages read */
+#define WIN_SW(NOSC, FILT) ((FILT) ? ((NOSC) == 1 ? 20 : 24) : ((NOSC) == 1 ? 12 : 20))
 enum { WO_A = 0, WO_B, WO_C, WO_DPH, WO_AK, WO_DA };		//   taps:  level offset in the pool, phase lo / hi, increment
 								//   noise: seed, held sample, phase lo, increment; then amplitude + delta
 enum { WM_SILENT = 0, WM_TAPS, WM_NOISE };
@@ -304,12 +310,31 @@ DEV void osc_write_v(const A2DWave *waves, OscV &o, int reg, int v, int start, i
 
 struct FiltV { Ramp q; int lp, bp, hp, f1, f1next, ramp; };
 
+// What the control wavefront leaves per fragment, in LDS: its 64 voices' slots as they go to memory, up to
+// WIN_EXL extras per voice, where each voice's extras begin in the pool and how many were staged.  A second
+// wavefront of the workgroup carries it out (win_ctl_writer): on gfx9 stores count in vmcnt like loads, and a walk
+// that has to wait for a record it asked for an iteration ago would wait for its own stores' round trips with it -
+// two microseconds per trip through the loop, four fifths of the first cut's control pass.
+#define WIN_EXL 2
+struct WinStage {
+	int slot[2][64 * A2D_WIN_WORDS];		// [buffer][lane * SW + word]
+	int ext[2][64][WIN_EXL][A2D_WIN_WORDS];
+	unsigned e0[2][64];
+	int nst[2][64];
+};
+
+// the two wavefronts meet (LDS writes done; nothing waits for global stores here)
+DEV void win_meet()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template<int NOSC, int FILT>
 DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int idx, int skip_empty,
 		int fa, int fb, int *__restrict__ wslot, int *__restrict__ wext, unsigned *__restrict__ widx,
-		unsigned *__restrict__ wtop, unsigned wcap,
+		unsigned *__restrict__ wtop, unsigned wcap, int *__restrict__ wrc,
 		const A2DVoice *__restrict__ voices, int *ustate, int *vactive, const A2DWave *__restrict__ waves,
-		const PTab &ptab, const uint8_t *ffr)
+		const PTab &ptab, const uint8_t *ffr, WinStage &st)
 {
 	const A2DParams &p = *pp;
 	const int lane = threadIdx.x & 63;
@@ -364,9 +389,10 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 		vol = ramp_load(wp + PW_VOL);
 		pan = ramp_load(wp + PW_PAN);
 		active = vactive[slot];
-		// (a later slab of the batch: the records of the fragments before it have been carried out)
-		while(rc < re && (int)A2D_RFRAG(recs[rc].head) < fa)
-			++rc;
+		// (a later slab of the batch: the records of the fragments before it have been carried out - the slab
+		// before left its place in the voice's run)
+		if(fa > 0)
+			rc = min(re, max(rc, wrc[idx]));
 	} else {
 #pragma unroll
 		for(int o = 0; o < NOSC; ++o) {
@@ -419,7 +445,9 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 	int pending_fresh = 0;
 	for(int f = fa; f < fb; ++f) {
 		const int n = (int)ffr[f];
-		int *const myslot = wslot + ((size_t)(f - fa) * nlist + (listed ? idx : 0)) * A2D_WIN_WORDS;
+		const int sb = (f - fa) & 1;
+		int *const myslot = st.slot[sb] + lane * WIN_SW(NOSC, FILT);		// (LDS: win_ctl_writer carries it out)
+		int nstaged = 0;
 		const unsigned e0 = e;
 		unsigned head0 = 0;
 		int nwin = 0;
@@ -445,10 +473,11 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 				if(active) {
 					// one window of the chain: frames [off, off + len) of the fragment
 					const int off = (int)(dur & 0xffffu), len = (int)(dur >> 16);
-					int W[A2D_WIN_WORDS];
+					constexpr int SW = WIN_SW(NOSC, FILT), FW = WIN_NW(NOSC);
+					int W[SW];
 					unsigned head = (unsigned)(off & 63) | ((unsigned)(len & 127) << 6);
 #pragma unroll
-					for(int k = 0; k < A2D_WIN_WORDS; ++k)
+					for(int k = 0; k < SW; ++k)
 						W[k] = 0;
 #pragma unroll
 					for(int o = 0; o < NOSC; ++o) {
@@ -463,17 +492,17 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 						// f12_process's head, filter12.c:86-96 (the host / the device VM ran the cutoff
 						// ramper and f12_pitch2coeff: R_F1SET / R_F1RAMP)
 						ramp_prepare_v(fs.q, len);
-						W[WE_F0] = fs.f1;
+						W[FW + WF_F0] = fs.f1;
 						if(fs.ramp) {
 							const int f0 = fs.f1;
 							fs.f1 = fs.f1next;
-							W[WE_DF] = len > 0 ? wadd(wsub(fs.f1, f0), len >> 1) / len : 0;
+							W[FW + WF_DF] = len > 0 ? wadd(wsub(fs.f1, f0), len >> 1) / len : 0;
 							fs.ramp = 0;
 						}
-						W[WE_QV] = fs.q.value;
-						W[WE_QD] = fs.q.delta;
+						W[FW + WF_QV] = fs.q.value;
+						W[FW + WF_QD] = fs.q.delta;
 						ramp_run(fs.q, len);
-						W[WE_LP] = fs.lp; W[WE_BP] = fs.bp; W[WE_HP] = fs.hp;
+						W[FW + WF_LP] = fs.lp; W[FW + WF_BP] = fs.bp; W[FW + WF_HP] = fs.hp;
 						if(pending_fresh) {
 							head |= WH_FRESH;
 							pending_fresh = 0;
@@ -495,12 +524,15 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 					if(!nwin) {
 						head0 = head;
 						dst = myslot;
-					} else if(e < elim)
-						dst = wext + (size_t)e++ * A2D_WIN_WORDS;
+					} else if(e < elim) {
+						// (the first WIN_EXL extras of a fragment are staged too; a busier fragment stores the rest itself)
+						dst = nstaged < WIN_EXL && nstaged == nwin - 1 ? st.ext[sb][lane][nstaged++] : wext + (size_t)e * A2D_WIN_WORDS;
+						++e;
+					}
 					++nwin;
 					if(dst) {
 #pragma unroll
-						for(int k = 0; k < A2D_WIN_WORDS / 4; ++k) {
+						for(int k = 0; k < SW / 4; ++k) {
 							const Int4 q = { W[4 * k], W[4 * k + 1], W[4 * k + 2], W[4 * k + 3] };
 							((Int4 *)dst)[k] = q;
 						}
@@ -581,7 +613,7 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 			} else
 				op = 0;
 		}
-		if(listed) {
+		{
 			// a voice born without a window behind its birth in this slab: its filter still starts from
 			// rest - the slab's last slot carries the flag, with or without frames
 			if(FILT && pending_fresh && f == fb - 1) {
@@ -589,8 +621,10 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 				pending_fresh = 0;
 			}
 			myslot[WE_HEAD] = (int)(head0 | ((unsigned)(nwin > 1 ? min(nwin - 1, (int)(e - e0)) : 0) << 19));
-			widx[(size_t)(f - fa) * nlist + idx] = e0;
+			st.e0[sb][lane] = e0;
+			st.nst[sb][lane] = nstaged;
 		}
+		win_meet();	// (the writer takes buffer sb from here; this wavefront goes on into the other one)
 	}
 
 	if(live) {
@@ -615,53 +649,160 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 		ramp_store(wp + PW_VOL, vol);
 		ramp_store(wp + PW_PAN, pan);
 		vactive[slot] = active;
+		wrc[idx] = rc;
+	}
+}
+
+// The control wavefront's companion: after every fragment it copies what that wavefront staged - the 64 slots (one
+// contiguous block in memory), the staged extras, the index of each voice's first extra - to memory, while the
+// control wavefront walks the next fragment into the other buffer.
+template<int NOSC, int FILT>
+DEV void win_ctl_writer(int nlist, int first, int fa, int fb, int *__restrict__ wslot, int *__restrict__ wext,
+		unsigned *__restrict__ widx, const WinStage &st)
+{
+	constexpr int SW = WIN_SW(NOSC, FILT);
+	const int lane = threadIdx.x & 63;
+	const int nv = max(0, min(64, nlist - first));
+	for(int f = fa; f < fb; ++f) {
+		const int sb = (f - fa) & 1;
+		win_meet();
+		int *const dst = wslot + ((size_t)(f - fa) * nlist + first) * SW;
+		// (16 bytes per lane and trip: SW / 4 of them per slot)
+		for(int i = lane; i < nv * (SW / 4); i += 64)
+			((Int4 *)dst)[i] = ((const Int4 *)st.slot[sb])[i];
+		if(lane < nv) {
+			const unsigned e0 = st.e0[sb][lane];
+			const int n = st.nst[sb][lane];
+			widx[(size_t)(f - fa) * nlist + first + lane] = e0;
+			for(int k = 0; k < n; ++k) {
+				Int4 *o = (Int4 *)(wext + ((size_t)e0 + k) * A2D_WIN_WORDS);
+				const Int4 *in = (const Int4 *)st.ext[sb][lane][k];
+#pragma unroll
+				for(int q = 0; q < SW / 4; ++q)
+					o[q] = in[q];
+			}
+		}
 	}
 }
 
 template<int NOSC, int FILT>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(128)
 void k_win_ctl(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int skip_empty,
 		int fa, int fb, int *__restrict__ wslot, int *__restrict__ wext, unsigned *__restrict__ widx,
-		unsigned *__restrict__ wtop, unsigned wcap,
+		unsigned *__restrict__ wtop, unsigned wcap, int *__restrict__ wrc,
 		const A2DVoice *__restrict__ voices, int *ustate, int *vactive, const A2DWave *__restrict__ waves,
 		const uint32_t *__restrict__ ptab)
 {
 	// the pitch table and the batch's fragment lengths: read in every window, from LDS
 	__shared__ PTab s_ptab;
 	__shared__ uint8_t s_ffr[A2D_MAXBATCH];
-	for(int k = (int)threadIdx.x; k < 128; k += 64)
+	__shared__ WinStage s_stage;
+	for(int k = (int)threadIdx.x; k < 128; k += 128)
 		s_ptab[k] = ptab[k];
-	for(int k = (int)threadIdx.x; k < A2D_MAXBATCH; k += 64)
+	for(int k = (int)threadIdx.x; k < A2D_MAXBATCH; k += 128)
 		s_ffr[k] = pp->fragframes[k];
 	__syncthreads();
-	win_ctl_body<NOSC, FILT>(pp, list, nlist, (int)(blockIdx.x * 64 + threadIdx.x), skip_empty, fa, fb, wslot, wext, widx, wtop, wcap,
-			voices, ustate, vactive, waves, s_ptab, s_ffr);
+	if(rfl((int)(threadIdx.x >> 6)) == 0)
+		win_ctl_body<NOSC, FILT>(pp, list, nlist, (int)(blockIdx.x * 64 + threadIdx.x), skip_empty, fa, fb, wslot, wext, widx, wtop, wcap,
+				wrc, voices, ustate, vactive, waves, s_ptab, s_ffr, s_stage);
+	else
+		win_ctl_writer<NOSC, FILT>(nlist, (int)blockIdx.x * 64, fa, fb, wslot, wext, widx, s_stage);
 }
 
 // ---------------------------------------------------------------------------
 // the render passes: lane = frame
 // ---------------------------------------------------------------------------
 #define WIN_FCH 4		// fragments of a chunk
-#define WIN_WPB 4		// wavefronts per workgroup of k_win_render
+#define WIN_WPB 8		// wavefronts per workgroup of k_win_render: their bus sums meet in LDS before the atomics
 
-// an entry in scalar registers
-struct WinE { Int8 q[A2D_WIN_WORDS / 8]; };
-DEV WinE win_load(const int *base, size_t e)
+// An entry's words as wave-uniform values.  LaneAcc: the entry sits in lane v of NW vector registers (the
+// lane = voice preload) and a word comes out with v_readlane; ScalAcc: already in scalar registers.
+template<int NW>
+struct LaneAcc {
+	const int (&S)[NW];
+	int v;
+	DEV int operator()(int w) const { return rdl(S[w], v); }
+};
+template<int NW>
+struct ScalAcc {
+	int w[NW];
+	DEV int operator()(int k) const { return w[k]; }
+};
+
+// lane 'lane' (one voice each) takes the first NW words of its entry at p (16-byte loads)
+template<int NW>
+DEV void lane_load(const int *p, bool on, int (&S)[NW])
 {
-	WinE E;
 #pragma unroll
-	for(int k = 0; k < A2D_WIN_WORDS / 8; ++k)
-		E.q[k] = sload8(base + e * A2D_WIN_WORDS + 8 * k);
+	for(int k = 0; k < NW; ++k)
+		S[k] = 0;
+	if(on) {
+#pragma unroll
+		for(int q = 0; q < (NW + 3) / 4; ++q) {
+			const Int4 x = ((const Int4 *)p)[q];
+#pragma unroll
+			for(int k = 0; k < 4; ++k)
+				if(4 * q + k < NW)
+					S[4 * q + k] = x[k];
+		}
+	}
+}
+
+// an entry every lane reads (a fragment's third window and beyond: rare), into scalar registers
+template<int NW>
+DEV ScalAcc<NW> bcast_load(const int *p)
+{
+	ScalAcc<NW> E;
+#pragma unroll
+	for(int q = 0; q < (NW + 3) / 4; ++q) {
+		const Int4 x = ((const Int4 *)p)[q];
+#pragma unroll
+		for(int k = 0; k < 4; ++k)
+			if(4 * q + k < NW)
+				E.w[4 * q + k] = rfl(x[k]);
+	}
 	return E;
 }
-DEV int win_word(const WinE &E, int k) { return E.q[k >> 3][k & 7]; }
 
-// the oscillators of one window: what they leave in the voice's scratch buffer for this lane's frame
+// The oscillators of one window in two halves: win_taps_issue() works out where this lane's frame reads the
+// wave and ISSUES the coefficient loads, win_oscs_finish() interpolates - the render loops issue for the next
+// entry before they finish this one, so a wavefront always has a window's loads in flight behind its arithmetic.
 // (fl = frame within the window; 'in' = the lane holds one)
 template<int NOSC>
-DEV int win_oscs(const WinE &E, const CoefRsrc rs, int fl, bool in)
+struct WinTaps { Coef4 k1[NOSC], k2[NOSC]; unsigned t1[NOSC], t2[NOSC]; unsigned head; int ak[NOSC], da[NOSC]; };
+
+template<int NOSC, class EA>
+DEV void win_taps_issue(const EA &E, const CoefRsrc rs, int lane, WinTaps<NOSC> &T)
 {
-	const unsigned head = (unsigned)win_word(E, WE_HEAD);
+	const unsigned head = (unsigned)E(WE_HEAD);
+	const int fl = lane - WH_OFF(head);
+	const bool in = (unsigned)fl < (unsigned)WH_LEN(head);
+	T.head = head;
+#pragma unroll
+	for(int o = 0; o < NOSC; ++o) {
+		const int b = WE_OSC + 6 * o;
+		T.t1[o] = T.t2[o] = 0;
+		T.ak[o] = T.da[o] = 0;
+		if(WH_MODE(head, o) == WM_TAPS) {
+			const unsigned phlo = (unsigned)E(b + WO_B), phhi = (unsigned)E(b + WO_C), dph = (unsigned)E(b + WO_DPH);
+			const int cb = coef_base((unsigned)E(b + WO_A));
+			T.ak[o] = E(b + WO_AK);
+			T.da[o] = E(b + WO_DA);
+			if(in) {
+				const uint64_t ph = (uint64_t)phlo | ((uint64_t)phhi << 32);
+				T.t1[o] = tap_phase(ph, (unsigned)fl * dph);
+				T.t2[o] = T.t1[o] + ((dph >> 16) >> 1);
+				T.k1[o] = coef_at(rs, cb, T.t1[o]);
+				T.k2[o] = coef_at(rs, cb, T.t2[o]);
+			}
+		}
+	}
+}
+
+template<int NOSC, class EA>
+DEV int win_oscs_finish(const EA &E, const WinTaps<NOSC> &T, int fl, bool in)
+{
+	const unsigned head = T.head;
 	int x = 0;
 #pragma unroll
 	for(int o = 0; o < NOSC; ++o) {
@@ -669,33 +810,30 @@ DEV int win_oscs(const WinE &E, const CoefRsrc rs, int fl, bool in)
 		const int b = WE_OSC + 6 * o;
 		if(m == WM_TAPS) {
 			if(in) {
-				const uint64_t ph = (uint64_t)(unsigned)win_word(E, b + WO_B) | ((uint64_t)(unsigned)win_word(E, b + WO_C) << 32);
-				const unsigned dph = (unsigned)win_word(E, b + WO_DPH);
-				const unsigned t1 = tap_phase(ph, (unsigned)fl * dph), t2 = t1 + ((dph >> 16) >> 1);
-				const int cb = coef_base((unsigned)win_word(E, b + WO_A));
-				const Coef4 k1 = coef_at(rs, cb, t1), k2 = coef_at(rs, cb, t2);
-				const int ak = wadd(win_word(E, b + WO_AK), wmul(win_word(E, b + WO_DA), fl));
-				x = wadd(x, mul64s(hermite_c(k1, t1) + hermite_c(k2, t2), ak, 17));
+				const int h = hermite_c(T.k1[o], T.t1[o]) + hermite_c(T.k2[o], T.t2[o]);
+				// (an amplitude at rest - most windows - is one scalar for the window)
+				const int ak = T.da[o] ? wadd(T.ak[o], wmul(T.da[o], fl)) : T.ak[o];
+				x = wadd(x, mul64s(h, ak, 17));
 			}
 		} else if(m == WM_NOISE) {
 			// wtosc_noise, wtosc.c:129-152: which draw of the LCG a frame holds is a prefix count over
 			// the window's frames, the draws themselves a uniform loop from the window's seed
-			const unsigned dph = (unsigned)win_word(E, b + WO_DPH);
-			const unsigned phk = (unsigned)win_word(E, b + WO_C) + (unsigned)(in ? fl : 0) * dph;
+			const unsigned dph = (unsigned)E(b + WO_DPH);
+			const unsigned phk = (unsigned)E(b + WO_C) + (unsigned)(in ? fl : 0) * dph;
 			const bool draw = in && ((dph >= (1u << 23)) || (((phk + dph) ^ phk) >> 23));
 			const unsigned long long dm = __ballot(draw);
 			const int me = (int)(threadIdx.x & 63);
 			const unsigned long long below = (me >= 63) ? ~0ull : ((2ull << me) - 1ull);
 			const int mine = __popcll(dm & below), total = __popcll(dm);
-			int held = win_word(E, b + WO_B), myval = held;
-			unsigned st = (unsigned)win_word(E, b + WO_A);
+			int held = E(b + WO_B), myval = held;
+			unsigned st = (unsigned)E(b + WO_A);
 			for(int j = 1; j <= total; ++j) {
 				held = noise_next(st) - 32767;
 				if(j == mine)
 					myval = held;
 			}
 			if(in) {
-				const int ak = wadd(win_word(E, b + WO_AK), wmul(win_word(E, b + WO_DA), fl));
+				const int ak = wadd(E(b + WO_AK), wmul(E(b + WO_DA), fl));
 				x = wadd(x, wmul(myval, ak >> 10) >> 6);
 			}
 		}
@@ -703,15 +841,29 @@ DEV int win_oscs(const WinE &E, const CoefRsrc rs, int fl, bool in)
 	return x;
 }
 
-// panmix_process12 (panmix.c:78-125) of one window for input y
-DEV void win_pan(const WinE &E, int y, int fl, bool in, int &acc0, int &acc1)
+// panmix_process12 (panmix.c:78-125) of one window for input y; the window's words as scalars
+DEV void win_pan(unsigned head, int vol, int dvol, int pan, int dpan, int y, int fl, bool in, int &acc0, int &acc1)
 {
-	if(in) {
-		const int vk = wadd(win_word(E, WE_VOL), wmul(win_word(E, WE_DVOL), fl));
-		const int pk = wadd(win_word(E, WE_PAN), wmul(win_word(E, WE_DPAN), fl));
+	const bool clamp = (head & WH_CLAMP) != 0;
+	if(!(dvol | dpan)) {
+		// volume and pan at rest - most windows: the two gains are the window's, worked out on the scalar unit
+		const int vp = mul64s(pan, vol, 24);
+		int v0 = wsub(vol, vp), v1 = wadd(vol, vp);
+		if(clamp) {
+			const int lim = wshl(vol, 1);
+			if(v0 > lim) v0 = lim;
+			if(v1 > lim) v1 = lim;
+		}
+		if(in) {
+			acc0 = wadd(acc0, mul64s(y, v0, 24));
+			acc1 = wadd(acc1, mul64s(y, v1, 24));
+		}
+	} else if(in) {
+		const int vk = wadd(vol, wmul(dvol, fl));
+		const int pk = wadd(pan, wmul(dpan, fl));
 		const int vp = mul64s(pk, vk, 24);
 		int v0 = wsub(vk, vp), v1 = wadd(vk, vp);
-		if((unsigned)win_word(E, WE_HEAD) & WH_CLAMP) {
+		if(clamp) {
 			const int lim = wshl(vk, 1);
 			if(v0 > lim) v0 = lim;
 			if(v1 > lim) v1 = lim;
@@ -733,75 +885,166 @@ DEV void bus_add(int *busmem, int off, int nch, int f, int lane, int dbg, int &a
 	a0 = a1 = 0;
 }
 
+// one entry, start to finish (not pipelined), oscillators + pan stage
+template<int NOSC, class EA>
+DEV void win_entry_now(const EA &E, const CoefRsrc rs, int lane, int &a0, int &a1)
+{
+	WinTaps<NOSC> T;
+	win_taps_issue<NOSC>(E, rs, lane, T);
+	const int fl = lane - WH_OFF(T.head);
+	const bool in = (unsigned)fl < (unsigned)WH_LEN(T.head);
+	const int x = win_oscs_finish<NOSC>(E, T, fl, in);
+	win_pan(T.head, E(WE_VOL), E(WE_DVOL), E(WE_PAN), E(WE_DPAN), x, fl, in, a0, a1);
+}
+
+// The voices whose entries sit one per lane in S (lane k = voice v0 + k of the wavefront's run, n of them), one
+// after the other: the coefficient loads of voice k + 1 are issued before voice k's arithmetic.  mask: which
+// lanes hold an entry at all.  on_bus(k): the wavefront moves to voice k (bus bookkeeping).
+template<int NOSC, int NW, class BUS>
+DEV void win_run(const int (&S)[NW], unsigned long long mask, const CoefRsrc rs, int lane, int &a0, int &a1, BUS on_bus)
+{
+	if(!mask)
+		return;
+	int k = (int)__builtin_ctzll(mask);
+	mask &= mask - 1;
+	WinTaps<NOSC> T0;
+	{
+		const LaneAcc<NW> E = { S, k };
+		win_taps_issue<NOSC>(E, rs, lane, T0);
+	}
+	for(;;) {
+		const int kn = mask ? (int)__builtin_ctzll(mask) : -1;
+		WinTaps<NOSC> T1;
+		if(kn >= 0) {
+			const LaneAcc<NW> En = { S, kn };
+			win_taps_issue<NOSC>(En, rs, lane, T1);
+		}
+		on_bus(k);
+		{
+			const LaneAcc<NW> E = { S, k };
+			const int fl = lane - WH_OFF(T0.head);
+			const bool in = (unsigned)fl < (unsigned)WH_LEN(T0.head);
+			const int x = win_oscs_finish<NOSC>(E, T0, fl, in);
+			win_pan(T0.head, E(WE_VOL), E(WE_DVOL), E(WE_PAN), E(WE_DPAN), x, fl, in, a0, a1);
+		}
+		if(kn < 0)
+			break;
+		mask &= mask - 1;
+		k = kn;
+		T0 = T1;
+	}
+}
+
 template<int NOSC>
 __global__ __launch_bounds__(64 * WIN_WPB)
 void k_win_render(const int *__restrict__ list, int nlist, int vpw, int fa, int fb, const int *__restrict__ wslot,
 		const int *__restrict__ wext, const unsigned *__restrict__ widx, const A2DVoice *__restrict__ voices,
 		const int *__restrict__ wavecoef, int *__restrict__ busmem, int dbg)
 {
+	constexpr int NW = WIN_NW(NOSC), SW = WIN_SW(NOSC, 0);
+	// what the workgroup's wavefronts are left with at the end of a fragment: summed here before it goes to the bus
+	// (sixteen thousand voices playing straight into one bus are as many atomic adds on the same 512 bytes per
+	// fragment; neighbours in the list share their bus: it is sorted) - two buffers, one barrier per fragment
+	__shared__ int part[2][WIN_WPB][2][64];
+	__shared__ int part_off[2][WIN_WPB], part_nch[2][WIN_WPB];
 	const int wv = rfl((int)(threadIdx.x >> 6));
 	const int lane = threadIdx.x & 63;
-	const int gw = (int)blockIdx.x * WIN_WPB + wv;
+	// a workgroup = WIN_WPB neighbouring voice groups x one chunk of fragments
 	const int ngroups = (nlist + vpw - 1) / vpw;
-	const int group = gw % ngroups, chunk = gw / ngroups;
+	const int gblocks = (ngroups + WIN_WPB - 1) / WIN_WPB;
+	const int chunk = (int)blockIdx.x / gblocks, group = ((int)blockIdx.x % gblocks) * WIN_WPB + wv;
 	const int f0 = fa + chunk * WIN_FCH;
-	if(f0 >= fb)
-		return;
-	const int nf = min(WIN_FCH, fb - f0);
-	const int first = group * vpw, nv = min(vpw, nlist - first);
+	const int nf = max(0, min(WIN_FCH, fb - f0));
+	const int first = group * vpw, nv = group < ngroups ? min(vpw, nlist - first) : 0;
 	const CoefRsrc rs = coef_rsrc(wavecoef);
-	// lane v keeps voice v's output bus
+	const bool mine = lane < nv;
+	// lane v keeps voice v: its output bus, and per fragment its slot and its first extra
 	int l_off = -1, l_nch = 2;
-	if(lane < nv) {
+	if(mine) {
 		const A2DVoice &vc = voices[list[first + lane]];
 		l_off = vc.out_off;
 		l_nch = vc.out_nch;
 	}
+	int S[NW], Sn[NW], X[NW];
+	unsigned wi = 0, win = 0;
+	lane_load<NW>(wslot + ((size_t)(f0 - fa) * nlist + first + lane) * SW, mine && nf > 0, S);
+	if(mine && nf > 0)
+		wi = widx[(size_t)(f0 - fa) * nlist + first + lane];
 	for(int j = 0; j < nf; ++j) {
 		const int f = f0 + j;
-		// the slots of the wavefront's voices in this fragment: one contiguous block
-		const int *const sbase = wslot + ((size_t)(f - fa) * nlist + first) * A2D_WIN_WORDS;
-		const unsigned l_wi = lane < nv ? widx[(size_t)(f - fa) * nlist + first + lane] : 0u;
+		// the first extras of this fragment (behind the slots just arrived) and the slots of the next one:
+		// on their way while the slots are rendered
+		const int nx = mine ? WH_EXTRAS((unsigned)S[WE_HEAD]) : 0;
+		lane_load<NW>(wext + (size_t)wi * A2D_WIN_WORDS, nx > 0, X);
+		if(j + 1 < nf) {
+			lane_load<NW>(wslot + ((size_t)(f + 1 - fa) * nlist + first + lane) * SW, mine, Sn);
+			if(mine)
+				win = widx[(size_t)(f + 1 - fa) * nlist + first + lane];
+		}
 		int a0 = 0, a1 = 0;
 		int cur_off = rdl(l_off, 0), cur_nch = rdl(l_nch, 0);
-		WinE cur = win_load(sbase, 0);
-		for(int v = 0; v < nv; ++v) {
-			// (the next voice's slot is on its way while this one is rendered)
-			const WinE nxt = win_load(sbase, (size_t)min(v + 1, nv - 1));
-			const int voff = rdl(l_off, v);
+		auto on_bus = [&](int k) {
+			const int voff = rdl(l_off, k);
 			if(voff != cur_off) {
 				bus_add(busmem, cur_off, cur_nch, f, lane, dbg, a0, a1);
 				cur_off = voff;
-				cur_nch = rdl(l_nch, v);
+				cur_nch = rdl(l_nch, k);
 			}
-			const unsigned head = (unsigned)win_word(cur, WE_HEAD);
-			{
-				const int fl = lane - WH_OFF(head);
-				const bool in = (unsigned)fl < (unsigned)WH_LEN(head);
-				const int x = win_oscs<NOSC>(cur, rs, fl, in);
-				win_pan(cur, x, fl, in, a0, a1);
+		};
+		win_run<NOSC, NW>(S, __ballot(mine && WH_LEN((unsigned)S[WE_HEAD]) != 0), rs, lane, a0, a1, on_bus);
+		const unsigned long long xm = __ballot(nx > 0);
+		win_run<NOSC, NW>(X, xm, rs, lane, a0, a1, on_bus);
+		// a fragment's third window and beyond
+		unsigned long long more = __ballot(nx > 1);
+		while(more) {
+			const int k = (int)__builtin_ctzll(more);
+			more &= more - 1;
+			on_bus(k);
+			const int n = rdl(nx, k);
+			const unsigned e0 = (unsigned)rdl((int)wi, k);
+			for(int q = 1; q < n; ++q) {
+				const ScalAcc<NW> E = bcast_load<NW>(wext + ((size_t)e0 + q) * A2D_WIN_WORDS);
+				win_entry_now<NOSC>(E, rs, lane, a0, a1);
 			}
-			const int nx = WH_EXTRAS(head);
-			if(nx) {
-				const unsigned e0 = (unsigned)rdl((int)l_wi, v);
-				for(int k = 0; k < nx; ++k) {
-					const WinE E = win_load(wext, (size_t)e0 + k);
-					const unsigned h = (unsigned)win_word(E, WE_HEAD);
-					const int fl = lane - WH_OFF(h);
-					const bool in = (unsigned)fl < (unsigned)WH_LEN(h);
-					const int x = win_oscs<NOSC>(E, rs, fl, in);
-					win_pan(E, x, fl, in, a0, a1);
+		}
+		// the wavefronts' sums of this fragment meet: wavefront r adds up row r (channel r) of its neighbours on the same bus
+		{
+			const int pb = j & 1;
+			part[pb][wv][0][lane] = a0;
+			part[pb][wv][1][lane] = a1;
+			if(lane == 0) {
+				part_off[pb][wv] = nv ? cur_off : -1;
+				part_nch[pb][wv] = cur_nch;
+			}
+			__syncthreads();
+			if(wv < 2) {
+				int sum = 0, off = -1, nch = 2;
+				for(int w = 0; w <= WIN_WPB; ++w) {
+					const int woff = w < WIN_WPB ? part_off[pb][w] : -2;
+					if(woff != off) {
+						if(off >= 0 && sum && !(dbg & 1))
+							atomicAdd(busmem + off + ((size_t)f * nch + wv) * A2D_FRAG + lane, sum);
+						sum = 0;
+						off = woff;
+						nch = w < WIN_WPB ? part_nch[pb][w] : 2;
+					}
+					if(w < WIN_WPB && woff >= 0)
+						sum = wadd(sum, part[pb][w][wv][lane]);
 				}
 			}
-			cur = nxt;
 		}
-		bus_add(busmem, cur_off, cur_nch, f, lane, dbg, a0, a1);
+		if(j + 1 < nf) {
+#pragma unroll
+			for(int k = 0; k < NW; ++k)
+				S[k] = Sn[k];
+			wi = win;
+		}
 	}
 }
 
 // ---- with filter12: a workgroup owns its voices for the whole slab -----------------------------
 #define WINF_PITCH 65
-#define WINF_MAXW  16		// wavefronts per workgroup (one filters)
+#define WINF_MAXW  8		// wavefronts per workgroup (one filters)
 
 // f12_process, filter12.c:97-118, over the frames [off, off + len) of a voice's row, in place
 DEV void winf_filter(int *row, int off, int len, int f0v, int df, int qv, int qd, int lp, int bp, int hp, int &d1, int &d2)
@@ -832,12 +1075,16 @@ DEV void winf_filter(int *row, int off, int len, int f0v, int df, int qv, int qd
 		step(row[off + k], off + k);
 }
 
+// the pan stage's words of an entry (head + panmix), kept from the step that rendered its oscillators
+struct PanW { int w[5]; };
+
 template<int NOSC>
 __global__ __launch_bounds__(64 * WINF_MAXW)
 void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, int fb, const int *__restrict__ wslot,
 		const int *__restrict__ wext, const unsigned *__restrict__ widx, const A2DVoice *__restrict__ voices, int *ustate,
 		const int *__restrict__ wavecoef, int *__restrict__ busmem, int dbg)
 {
+	constexpr int NW = WIN_NW(NOSC), SW = WIN_SW(NOSC, 1), FW = WIN_NW(NOSC);
 	extern __shared__ int winf_lds[];
 	const int nw = (int)(blockDim.x >> 6);		// >= 2
 	const int wv = rfl((int)(threadIdx.x >> 6));
@@ -852,26 +1099,49 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 
 	// the filter wavefront: lane = voice, d1 / d2 in registers over the slab
 	int d1 = 0, d2 = 0, ufilt = -1;
-	Int4 fq0 = { 0, 0, 0, 0 }, fq1 = fq0;		// the voice's slot of the fragment to be filtered next: words 0..7
+	int fhd = 0, fw[7];				// the voice's slot of the fragment to be filtered next: head, filter words
 	unsigned fwi = 0;
+#pragma unroll
+	for(int k = 0; k < 7; ++k)
+		fw[k] = 0;
+	auto fload = [&](int g) {
+		const int *S = wslot + ((size_t)g * nlist + first + lane) * SW;
+		fhd = S[WE_HEAD];
+#pragma unroll
+		for(int k = 0; k < 7; ++k)
+			fw[k] = S[FW + k];
+		fwi = widx[(size_t)g * nlist + first + lane];
+	};
 	if(wv == 0 && lane < nv) {
 		ufilt = voices[list[first + lane]].unit[NOSC];
 		d1 = ustate[(size_t)ufilt * A2D_USTATE + FW_D1A];
 		d2 = ustate[(size_t)ufilt * A2D_USTATE + FW_D2A];
-		const Int4 *S = (const Int4 *)(wslot + ((size_t)first + lane) * A2D_WIN_WORDS);
-		fq0 = S[0];
-		fq1 = S[1];
-		fwi = widx[first + lane];
+		fload(0);
 	}
-	// the others: a contiguous share of the voices each (neighbours in the list share their bus)
+	// the others: a contiguous share of the voices each (neighbours in the list share their bus), one per lane
 	const int nworkers = nw - 1;
 	const int per = (nv + nworkers - 1) / nworkers;
 	const int lo = min(nv, (wv - 1) * per), hi = wv ? min(nv, lo + per) : 0;
+	const bool mine = wv && lo + lane < hi;
 	int l_off = -1, l_nch = 2;
-	if(wv && lo + lane < hi) {
+	if(mine) {
 		const A2DVoice &vc = voices[list[first + lo + lane]];
 		l_off = vc.out_off;
 		l_nch = vc.out_nch;
+	}
+	// a worker's voices, lane = voice: the slot (and first extra) of the fragment whose oscillators it renders in
+	// this step, of the next one (on their way), and the pan words of the two fragments before
+	int S[NW], Sn[NW], X[NW];
+	unsigned wi = 0, win = 0;
+	PanW P1, P2, PX1, PX2;		// slots / first extras of fragments s - 1 and s - 2
+	unsigned wi1 = 0, wi2 = 0;
+#pragma unroll
+	for(int k = 0; k < 5; ++k)
+		P1.w[k] = P2.w[k] = PX1.w[k] = PX2.w[k] = 0;
+	if(wv) {
+		lane_load<NW>(wslot + ((size_t)first + lo + lane) * SW, mine && nfr > 0, S);
+		if(mine && nfr > 0)
+			wi = widx[first + lo + lane];
 	}
 
 	for(int s = 0; s < nfr + 3; ++s) {
@@ -879,26 +1149,24 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 			const int g = s - 1;		// fragment (of the slab) to filter
 			if(g >= 0 && g < nfr && lane < nv) {
 				int *const row = tiles + (g % 3) * vpg * WINF_PITCH + lane * WINF_PITCH;
-				const Int4 q0 = fq0, q1 = fq1;
-				const unsigned e0 = fwi;
-				if(g + 1 < nfr) {	// (the next fragment's, on their way while this one is filtered)
-					const Int4 *S = (const Int4 *)(wslot + ((size_t)(g + 1) * nlist + first + lane) * A2D_WIN_WORDS);
-					fq0 = S[0];
-					fq1 = S[1];
-					fwi = widx[(size_t)(g + 1) * nlist + first + lane];
-				}
-				const unsigned head = (unsigned)q0.x;
+				const unsigned head = (unsigned)fhd, e0 = fwi;
+				int q[7];
+#pragma unroll
+				for(int k = 0; k < 7; ++k)
+					q[k] = fw[k];
+				if(g + 1 < nfr)		// (the next fragment's, on their way while this one is filtered)
+					fload(g + 1);
 				if(head & WH_FRESH)
 					d1 = d2 = 0;
-				winf_filter(row, WH_OFF(head), WH_LEN(head), q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, d1, d2);
+				winf_filter(row, WH_OFF(head), WH_LEN(head), q[WF_F0], q[WF_DF], q[WF_QV], q[WF_QD], q[WF_LP], q[WF_BP], q[WF_HP], d1, d2);
 				const int nx = WH_EXTRAS(head);
 				for(int k = 0; k < nx; ++k) {
-					const Int4 *E = (const Int4 *)(wext + ((size_t)e0 + k) * A2D_WIN_WORDS);
-					const Int4 x0 = E[0], x1 = E[1];
-					const unsigned h = (unsigned)x0.x;
+					const int *E = wext + ((size_t)e0 + k) * A2D_WIN_WORDS;
+					const unsigned h = (unsigned)E[WE_HEAD];
 					if(h & WH_FRESH)
 						d1 = d2 = 0;
-					winf_filter(row, WH_OFF(h), WH_LEN(h), x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, d1, d2);
+					winf_filter(row, WH_OFF(h), WH_LEN(h), E[FW + WF_F0], E[FW + WF_DF], E[FW + WF_QV], E[FW + WF_QD],
+							E[FW + WF_LP], E[FW + WF_BP], E[FW + WF_HP], d1, d2);
 				}
 			}
 		} else {
@@ -922,86 +1190,130 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 					}
 				}
 			}
-			// oscillators of fragment s into its tile
-			if(s < nfr && lo < hi) {
-				int *const tile = tiles + (s % 3) * vpg * WINF_PITCH;
-				const int *const sbase = wslot + ((size_t)s * nlist + first) * A2D_WIN_WORDS;
-				const unsigned l_wi = lo + lane < hi ? widx[(size_t)s * nlist + first + lo + lane] : 0u;
-				WinE cur = win_load(sbase, (size_t)lo);
-				for(int v = lo; v < hi; ++v) {
-					const WinE nxt = win_load(sbase, (size_t)min(v + 1, hi - 1));
-					const unsigned head = (unsigned)win_word(cur, WE_HEAD);
-					{
-						const int fl = lane - WH_OFF(head);
-						const bool in = (unsigned)fl < (unsigned)WH_LEN(head);
-						const int x = win_oscs<NOSC>(cur, rs, fl, in);
-						if(in)
-							tile[v * WINF_PITCH + lane] = x;
-					}
-					const int nx = WH_EXTRAS(head);
-					if(nx) {
-						const unsigned e0 = (unsigned)rdl((int)l_wi, v - lo);
-						for(int k = 0; k < nx; ++k) {
-							const WinE E = win_load(wext, (size_t)e0 + k);
-							const unsigned h = (unsigned)win_word(E, WE_HEAD);
-							const int fl = lane - WH_OFF(h);
-							const bool in = (unsigned)fl < (unsigned)WH_LEN(h);
-							const int x = win_oscs<NOSC>(E, rs, fl, in);
-							if(in)
-								tile[v * WINF_PITCH + lane] = x;
-						}
-					}
-					cur = nxt;
-				}
+			// what this step needs from memory: the first extras of fragment s, the slots of fragment s + 1
+			const int nx = (mine && s < nfr) ? WH_EXTRAS((unsigned)S[WE_HEAD]) : 0;
+			lane_load<NW>(wext + (size_t)wi * A2D_WIN_WORDS, nx > 0, X);
+			if(s + 1 < nfr) {
+				lane_load<NW>(wslot + ((size_t)(s + 1) * nlist + first + lo + lane) * SW, mine, Sn);
+				if(mine)
+					win = widx[(size_t)(s + 1) * nlist + first + lo + lane];
 			}
-			// pan stage of fragment s - 2 out of its tile
+			// pan stage of fragment s - 2 out of its tile (its words were kept two steps ago)
 			if(s >= 2 && s - 2 < nfr) {
 				const int g = s - 2, pb = g & 1;
 				const int *const tile = tiles + (g % 3) * vpg * WINF_PITCH;
-				int a0 = 0, a1 = 0, cur_off = -1, cur_nch = 2;
-				if(lo < hi) {
-					const int *const sbase = wslot + ((size_t)g * nlist + first) * A2D_WIN_WORDS;
-					const unsigned l_wi = lo + lane < hi ? widx[(size_t)g * nlist + first + lo + lane] : 0u;
-					cur_off = rdl(l_off, 0);
-					cur_nch = rdl(l_nch, 0);
-					WinE cur = win_load(sbase, (size_t)lo);
-					for(int v = lo; v < hi; ++v) {
-						const WinE nxt = win_load(sbase, (size_t)min(v + 1, hi - 1));
-						const int voff = rdl(l_off, v - lo);
-						if(voff != cur_off) {
-							bus_add(busmem, cur_off, cur_nch, fa + g, lane, dbg, a0, a1);
-							cur_off = voff;
-							cur_nch = rdl(l_nch, v - lo);
+				int a0 = 0, a1 = 0, cur_off = rdl(l_off, 0), cur_nch = rdl(l_nch, 0);
+				auto pan_of = [&](const PanW &P, int k) {
+					const unsigned h = (unsigned)rdl(P.w[WE_HEAD], k);
+					const int fl = lane - WH_OFF(h);
+					const bool in = (unsigned)fl < (unsigned)WH_LEN(h);
+					const int y = in ? tile[(lo + k) * WINF_PITCH + lane] : 0;
+					win_pan(h, rdl(P.w[WE_VOL], k), rdl(P.w[WE_DVOL], k), rdl(P.w[WE_PAN], k), rdl(P.w[WE_DPAN], k), y, fl, in, a0, a1);
+				};
+				for(int k = 0; k < hi - lo; ++k) {
+					const int voff = rdl(l_off, k);
+					if(voff != cur_off) {
+						bus_add(busmem, cur_off, cur_nch, fa + g, lane, dbg, a0, a1);
+						cur_off = voff;
+						cur_nch = rdl(l_nch, k);
+					}
+					const unsigned h = (unsigned)rdl(P2.w[WE_HEAD], k);
+					if(WH_LEN(h))
+						pan_of(P2, k);
+					const int n = WH_EXTRAS(h);
+					if(n) {
+						pan_of(PX2, k);
+						const unsigned e0 = (unsigned)rdl((int)wi2, k);
+						for(int q = 1; q < n; ++q) {
+							const ScalAcc<5> E = bcast_load<5>(wext + ((size_t)e0 + q) * A2D_WIN_WORDS);
+							const unsigned hq = (unsigned)E(WE_HEAD);
+							const int fl = lane - WH_OFF(hq);
+							const bool in = (unsigned)fl < (unsigned)WH_LEN(hq);
+							const int y = in ? tile[(lo + k) * WINF_PITCH + lane] : 0;
+							win_pan(hq, E(WE_VOL), E(WE_DVOL), E(WE_PAN), E(WE_DPAN), y, fl, in, a0, a1);
 						}
-						const unsigned head = (unsigned)win_word(cur, WE_HEAD);
-						{
-							const int fl = lane - WH_OFF(head);
-							const bool in = (unsigned)fl < (unsigned)WH_LEN(head);
-							const int y = in ? tile[v * WINF_PITCH + lane] : 0;
-							win_pan(cur, y, fl, in, a0, a1);
-						}
-						const int nx = WH_EXTRAS(head);
-						if(nx) {
-							const unsigned e0 = (unsigned)rdl((int)l_wi, v - lo);
-							for(int k = 0; k < nx; ++k) {
-								const WinE E = win_load(wext, (size_t)e0 + k);
-								const unsigned h = (unsigned)win_word(E, WE_HEAD);
-								const int fl = lane - WH_OFF(h);
-								const bool in = (unsigned)fl < (unsigned)WH_LEN(h);
-								const int y = in ? tile[v * WINF_PITCH + lane] : 0;
-								win_pan(E, y, fl, in, a0, a1);
-							}
-						}
-						cur = nxt;
 					}
 				}
 				part[((pb * nw + wv) * 2 + 0) * 64 + lane] = a0;
 				part[((pb * nw + wv) * 2 + 1) * 64 + lane] = a1;
 				if(lane == 0) {
-					part_off[pb * nw + wv] = cur_off;
+					part_off[pb * nw + wv] = hi > lo ? cur_off : -1;
 					part_nch[pb * nw + wv] = cur_nch;
 				}
 			}
+			// oscillators of fragment s into its tile: the slots, then the first extras (whose loads have had
+			// the pan stage's time to arrive), the rest one by one
+			if(s < nfr) {
+				int *const tile = tiles + (s % 3) * vpg * WINF_PITCH;
+				auto oscs = [&](const int (&R)[NW], unsigned long long mask) {
+					if(!mask)
+						return;
+					int k = (int)__builtin_ctzll(mask);
+					mask &= mask - 1;
+					WinTaps<NOSC> T0;
+					{
+						const LaneAcc<NW> E = { R, k };
+						win_taps_issue<NOSC>(E, rs, lane, T0);
+					}
+					for(;;) {
+						const int kn = mask ? (int)__builtin_ctzll(mask) : -1;
+						WinTaps<NOSC> T1;
+						if(kn >= 0) {
+							const LaneAcc<NW> En = { R, kn };
+							win_taps_issue<NOSC>(En, rs, lane, T1);
+						}
+						{
+							const LaneAcc<NW> E = { R, k };
+							const int fl = lane - WH_OFF(T0.head);
+							const bool in = (unsigned)fl < (unsigned)WH_LEN(T0.head);
+							const int x = win_oscs_finish<NOSC>(E, T0, fl, in);
+							if(in)
+								tile[(lo + k) * WINF_PITCH + lane] = x;
+						}
+						if(kn < 0)
+							break;
+						mask &= mask - 1;
+						k = kn;
+						T0 = T1;
+					}
+				};
+				oscs(S, __ballot(mine && WH_LEN((unsigned)S[WE_HEAD]) != 0));
+				oscs(X, __ballot(nx > 0));
+				unsigned long long more = __ballot(nx > 1);
+				while(more) {
+					const int k = (int)__builtin_ctzll(more);
+					more &= more - 1;
+					const int n = rdl(nx, k);
+					const unsigned e0 = (unsigned)rdl((int)wi, k);
+					for(int q = 1; q < n; ++q) {
+						const ScalAcc<NW> E = bcast_load<NW>(wext + ((size_t)e0 + q) * A2D_WIN_WORDS);
+						WinTaps<NOSC> T;
+						win_taps_issue<NOSC>(E, rs, lane, T);
+						const int fl = lane - WH_OFF(T.head);
+						const bool in = (unsigned)fl < (unsigned)WH_LEN(T.head);
+						const int x = win_oscs_finish<NOSC>(E, T, fl, in);
+						if(in)
+							tile[(lo + k) * WINF_PITCH + lane] = x;
+					}
+				}
+			}
+			// the steps move on: this fragment's pan words are kept for the step after next
+			P2 = P1;
+			PX2 = PX1;
+			wi2 = wi1;
+#pragma unroll
+			for(int k = 0; k < 5; ++k) {
+				P1.w[k] = s < nfr ? S[k] : 0;
+				PX1.w[k] = s < nfr ? X[k] : 0;
+			}
+			wi1 = wi;
+			if(s + 1 < nfr) {
+#pragma unroll
+				for(int k = 0; k < NW; ++k)
+					S[k] = Sn[k];
+				wi = win;
+			} else
+				S[WE_HEAD] = 0;
 		}
 		__syncthreads();
 	}
@@ -1015,13 +1327,13 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 // launchers
 // ---------------------------------------------------------------------------
 int a2d_launch_win_ctl(const A2DParams *dparams, const A2DParams &hp, int nosc, int filt, const int *dlist, int nlist,
-		int skip_empty, int fa, int fb, int *wslot, int *wext, unsigned *widx, unsigned *wtop, unsigned wcap, void *stream)
+		int skip_empty, int fa, int fb, int *wslot, int *wext, unsigned *widx, unsigned *wtop, unsigned wcap, int *wrc, void *stream)
 {
 	if(nlist <= 0 || fb <= fa)
 		return 0;
 	const int nblocks = (nlist + 63) / 64;
-#define CTL_LAUNCH(N, F) hipLaunchKernelGGL((k_win_ctl<N, F>), dim3(nblocks), dim3(64), 0, (hipStream_t)stream, dparams, dlist, \
-		nlist, skip_empty, fa, fb, wslot, wext, widx, wtop, wcap, hp.voices, hp.ustate, hp.vactive, hp.waves, hp.ptab)
+#define CTL_LAUNCH(N, F) hipLaunchKernelGGL((k_win_ctl<N, F>), dim3(nblocks), dim3(128), 0, (hipStream_t)stream, dparams, dlist, \
+		nlist, skip_empty, fa, fb, wslot, wext, widx, wtop, wcap, wrc, hp.voices, hp.ustate, hp.vactive, hp.waves, hp.ptab)
 	if(nosc == 1 && !filt)
 		CTL_LAUNCH(1, 0);
 	else if(nosc == 2 && !filt)
@@ -1040,14 +1352,13 @@ int a2d_launch_win_render(const A2DParams &hp, int nosc, int filt, const int *dl
 	if(nlist <= 0 || fb <= fa)
 		return 0;
 	if(!filt) {
-		// voices per wavefront: about 8 192 wavefronts in the launch, up to 32 voices to an atomic
+		// voices per wavefront (one per lane at most): about 8 192 wavefronts in the launch
 		const int nchunks = (fb - fa + WIN_FCH - 1) / WIN_FCH;
 		static const int force = getenv("A2AMD_WVPW") ? atoi(getenv("A2AMD_WVPW")) : 0;
-		int vpw = force > 0 ? force : (int)std::min<long long>(std::max<long long>(((long long)nlist * nchunks + 8191) / 8192, 1), 32);
+		int vpw = force > 0 ? force : (int)std::min<long long>(std::max<long long>(((long long)nlist * nchunks + 8191) / 8192, 1), 64);
 		vpw = std::min(std::max(vpw, 1), 64);
 		const int ngroups = (nlist + vpw - 1) / vpw;
-		const int nwaves = ngroups * nchunks;
-		const int nblocks = (nwaves + WIN_WPB - 1) / WIN_WPB;
+		const int nblocks = nchunks * ((ngroups + WIN_WPB - 1) / WIN_WPB);
 		if(nosc == 1)
 			hipLaunchKernelGGL((k_win_render<1>), dim3(nblocks), dim3(64 * WIN_WPB), 0, (hipStream_t)stream, dlist, nlist, vpw,
 					fa, fb, wslot, wext, widx, hp.voices, hp.wavecoef, hp.busmem, hp.debug);
@@ -1062,7 +1373,7 @@ int a2d_launch_win_render(const A2DParams &hp, int nosc, int filt, const int *dl
 		vpg = std::min(std::max(vpg, 1), 48);	// (48 rows x 3 tiles + the bus sums: within 64 KB of LDS)
 		// wavefronts: the filter's + one per ~4 voices
 		static const int forcew = getenv("A2AMD_WFWAVES") ? atoi(getenv("A2AMD_WFWAVES")) : 0;
-		int nw = forcew > 1 ? forcew : 1 + std::min(std::max((vpg + 3) / 4, 1), WINF_MAXW - 1);
+		int nw = forcew > 1 ? forcew : 1 + std::min(std::max((vpg + 3) / 4, 1), WINF_MAXW - 1);	// (up to 7 voices per worker)
 		nw = std::min(std::max(nw, 2), WINF_MAXW);
 		const int nblocks = (nlist + vpg - 1) / vpg;
 		const size_t dyn = (size_t)(3 * vpg * WINF_PITCH + 2 * nw * 2 * 64 + 2 * nw * 2) * sizeof(int);

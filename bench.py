@@ -272,7 +272,7 @@ def engine_result(p, timeout=600):
     return res
 
 
-def engine_in_loop(cases=None, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fragments=1024):
+def engine_in_loop(cases=None, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fragments=1024, dropin_env=None):
     """a2_Run() with the reference engine in the loop, drop-in vs the engine's own CPU units:
     voice-samples/s, time per 64-frame fragment (p50 / p99 over the a2_Run() calls), and the
     FNV-1a hash of the first `hash_fragments` fragments after the warm-up from both runs.
@@ -332,7 +332,7 @@ def engine_in_loop(cases=None, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fr
                      "cpu_tail_hash": c["tail_hashes"][0] if tail is not None else None}
                 for mode, walk in modes:
                     g = engine_run(program, voices, nruns[mode], buf, True, hf, walk=walk,
-                                   env_extra={"A2REF_HASH_AT": str(tail)} if tail is not None else None)
+                                   env_extra=dict(dropin_env or {}, **({"A2REF_HASH_AT": str(tail)} if tail is not None else {})))
                     if "error" in g:
                         e[mode] = {"error": g["error"]}
                         all_equal = False
@@ -971,6 +971,18 @@ def main():
                 "kernel": "k_leaf_oscfiltpan", "avg_launch_ms": leaf4, "all_kernels_ms_per_step": all4}}
         r4.be.close()
     dist.destroy_process_group()
+    if rank == 0 and not args.no_engine and args.config == 3 and not custom:
+        # The north star's claim - 256k voices in realtime on 8 GPUs - as the ENGINE sees it: ONE engine state whose
+        # voice tree the drop-in spreads over this run's N GPUs (A2AMD_DEVICES=N: top-level subtrees per GPU, the
+        # root-bus partials exchanged per batch, root chain on device 0), a2_Run(4096) throughput and a2_Run(64)
+        # p50 / p99 against the 1.333 ms budget, audio hash-compared with the engine's own CPU units.
+        # (the other ranks have finished their timed work; their processes end while this runs)
+        eil = engine_in_loop(cases=[("configs[4] shape over %d GPU(s), one engine state" % world, "FilterTree", 32768 * world)],
+                             dropin_env={"A2AMD_DEVICES": str(world)})
+        line["engine_in_loop"] = eil
+        rt = eil.get("max_realtime_voices_one_engine_state", {})
+        line["max_realtime_voices"] = {"n_gpus": world, "units": rt.get("units"), "units+walk": rt.get("units+walk"),
+                                       "what": rt.get("what")}
     if rank == 0 and not args.no_cpu_baseline:
         # (one rank's share of the job on this box's host cores; the other ranks are done)
         line["cpu_baseline"] = cpu_baseline(cfg["voices"], cfg["chain"], cfg["groups"])
