@@ -105,6 +105,12 @@ void a2amd_close(a2amd_ctx *c)
 	hipFree(c->d_win.d); hipFree(c->d_wext.d); hipFree(c->d_wrc.d); hipFree(c->d_widx.d); hipFree(c->d_wtop);
 	if(c->win_stream)
 		hipStreamDestroy(c->win_stream);
+	for(int k = 0; k < 7; ++k)
+		if(c->win_fork[k])
+			hipStreamDestroy(c->win_fork[k]);
+	for(int k = 0; k < 8; ++k)
+		if(c->win_fev[k])
+			hipEventDestroy(c->win_fev[k]);
 	for(int k = 0; k < 5; ++k)
 		if(c->win_ev[k])
 			hipEventDestroy(c->win_ev[k]);

@@ -479,6 +479,8 @@ struct a2amd_ctx {
 	DevBuf<int> d_win, d_wext, d_wrc;
 	DevBuf<unsigned> d_widx;
 	unsigned *d_wtop = nullptr;	// [2 sets]{ pool counter, overflow flag }
+	hipStream_t win_fork[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };	// a stream per list of a batch with several (issue_windows)
+	hipEvent_t win_fev[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };	// [list] done, [7] fork
 	hipStream_t win_stream = nullptr;	// the control passes' stream (slabs: issue_windows, a2amd_sched.cpp)
 	hipEvent_t win_ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };	// control pass of set 0 / 1 done, render pass of set 0 / 1 done, fork
 

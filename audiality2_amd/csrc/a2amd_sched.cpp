@@ -1058,6 +1058,44 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 	}
 	static const bool wtiming = getenv("A2AMD_WIN_TIMING") != nullptr;
 	static hipEvent_t tev[3] = { nullptr, nullptr, nullptr };
+	// Several lists, one slab (a song: a few dozen voices of four classes): each list's control pass and render
+	// pass are kernels of a few wavefronts that take as long as one voice's walk / one filter chain - on one stream
+	// they would run back to back; here every list gets a stream of its own between a fork and a join (the render
+	// passes only ever ADD to the buses).  A2AMD_WIN_FORK=0: one stream.
+	static const bool fork_ok = !(getenv("A2AMD_WIN_FORK") && !atoi(getenv("A2AMD_WIN_FORK")));
+	if(nj > 1 && nslabs == 1 && fork_ok && !wtiming) {
+		if(!c->win_fork[0]) {
+			if(c->capturing)
+				return c->fail(A2AMD_ESTATE, "window streams missing inside a graph capture");
+			for(int j = 0; j < 7; ++j) {
+				HIPCHK(c, hipStreamCreateWithFlags(&c->win_fork[j], hipStreamNonBlocking));
+				HIPCHK(c, hipEventCreateWithFlags(&c->win_fev[j], hipEventDisableTiming));
+			}
+			HIPCHK(c, hipEventCreateWithFlags(&c->win_fev[7], hipEventDisableTiming));
+		}
+		HIPCHK(c, hipMemsetAsync(c->d_wtop, 0, 2 * sizeof(unsigned), c->stream));
+		HIPCHK(c, hipEventRecord(c->win_fev[7], c->stream));
+		size_t at = 0, atw = 0, atv = 0;
+		for(int j = 0; j < nj; ++j) {
+			const Job &b = jobs[j];
+			hipStream_t sj = c->win_fork[j];
+			HIPCHK(c, hipStreamWaitEvent(sj, c->win_fev[7], 0));
+			if(a2d_launch_win_ctl(c->d_params, c->hparams, b.nosc, b.filt, b.list, b.n, b.skip, 0, nfrags,
+					c->d_win.d + atw, c->d_wext.d, c->d_widx.d + at, c->d_wtop,
+					(unsigned)std::min<size_t>(c->d_wext.cap, 0xffffffffu), c->d_wrc.d + atv, sj))
+				return c->fail(A2AMD_EHIP, "window control launch failed: %s", hipGetErrorString(hipGetLastError()));
+			if(a2d_launch_win_render(c->hparams, b.nosc, b.filt, b.list, b.n, 0, nfrags, c->d_win.d + atw,
+					c->d_wext.d, c->d_widx.d + at, sj))
+				return c->fail(A2AMD_EHIP, "window render launch failed: %s", hipGetErrorString(hipGetLastError()));
+			HIPCHK(c, hipEventRecord(c->win_fev[j], sj));
+			HIPCHK(c, hipStreamWaitEvent(c->stream, c->win_fev[j], 0));
+			at += (size_t)b.n * (size_t)nfrags;
+			atw += (size_t)b.n * (size_t)nfrags * A2D_WIN_SLOTWORDS(b.nosc, b.filt);
+			atv += (size_t)b.n;
+			c->stats.launches += 2;
+		}
+		return 0;
+	}
 	int k = 0;
 	for(int fa = 0; fa < nfrags; fa += per, ++k) {
 		const int fb = std::min(nfrags, fa + per), set = two ? (k & 1) : 0;
@@ -1251,7 +1289,17 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			// Round 5: the record stream resolved by a lane = voice control pass, the windows rendered
 			// from closed-form entries (a2amd_win.hip).  A2AMD_WIN=0: k_leaf_recs, the kernels of rounds
 			// 2-4 that interpret the records on the scalar unit of the rendering wavefront (A/B).
-			static const int use_win = getenv("A2AMD_WIN") ? atoi(getenv("A2AMD_WIN")) : 1;
+			// Which one: the window kernels' two passes are each as long as ONE voice's walk through the batch (the
+			// control pass) / one filter chain (the render pass) whatever the voice count - 0.4 to 1 ms per 64 fragments -
+			// where k_leaf_recs, one wavefront per voice, takes 0.3 ms for a song's few dozen voices and 0.4 - 0.7 ms for a
+			// thousand; from a few thousand voices on it is k_leaf_recs that queues up (16 384: 1.1 - 3.9 ms against
+			// 0.5 - 1.8).  A2AMD_WIN=0 / 1 forces (the parity tests run both), A2AMD_WIN_MIN moves the threshold.
+			const char *wenv = getenv("A2AMD_WIN");
+			static const int win_min = getenv("A2AMD_WIN_MIN") ? atoi(getenv("A2AMD_WIN_MIN")) : 2048;
+			int nwinv = total;
+			for(int k = 0; k < 3; ++k)
+				nwinv += c->vm.list.empty() ? 0 : c->vm.n_cls[k];
+			const bool use_win = wenv ? atoi(wenv) != 0 : nwinv >= win_min;
 			if(use_win) {
 				if(int r = issue_windows(c, lists, counts))
 					return r;

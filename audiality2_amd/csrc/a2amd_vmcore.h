@@ -306,11 +306,13 @@ VMFN void rt_apply(const Tracker &rt, A2DVmVoice &v, const Consts &K, E &e, int 
 // Returns TRAP_NONE when the VM has rescheduled itself, a TRAP_* where the engine's would have
 // aborted (which a2amd_vm_analyze() has ruled out for every adopted voice).
 template<class E>
-VMFN int run(A2DVmVoice &v, const uint32_t *code, const Consts &K, E &e, int frag)
+VMFN int run(A2DVmVoice &v, const uint32_t *code, const Consts &K, E &e, int frag, Tracker *rtmem = nullptr)
 {
 	int32_t *r = v.r;
 	unsigned inscount = A2AMD_VM_INSLIMIT;
-	Tracker rt;
+	// (the tracker's register list is indexed at run time: the kernel hands in a place in LDS for it)
+	Tracker rtlocal;
+	Tracker &rt = rtmem ? *rtmem : rtlocal;
 	rt.mask = rt.position = 0;
 	if(v.state == A2AMD_VM_WAITING)
 		v.state = A2AMD_VM_RUNNING;
@@ -534,7 +536,8 @@ VMFN int run(A2DVmVoice &v, const uint32_t *code, const Consts &K, E &e, int fra
 // fragment's only event (the default window, a2amd_unit_process).  FF: frames of fragment f.
 // Returns the engine time at the end of fragment f1 - 1; v.fault is set where a trap stopped the VM.
 template<class E, class FF>
-VMFN uint32_t run_batch(A2DVmVoice &v, const uint32_t *code, const Consts &K, E &e, uint32_t now, int f0, int f1, FF frames_of)
+VMFN uint32_t run_batch(A2DVmVoice &v, const uint32_t *code, const Consts &K, E &e, uint32_t now, int f0, int f1, FF frames_of,
+		Tracker *rtmem = nullptr)
 {
 	uint32_t fs = now;
 	for(int f = f0; f < f1; ++f) {
@@ -557,7 +560,7 @@ VMFN uint32_t run_batch(A2DVmVoice &v, const uint32_t *code, const Consts &K, E 
 					res = frames;
 					break;
 				}
-				const int trap = run(v, code, K, e, f);
+				const int trap = run(v, code, K, e, f, rtmem);
 				if(trap) {
 					v.fault = trap;
 					res = frames;

@@ -323,7 +323,8 @@ struct WinStage {
 	int nst[2][64];
 };
 
-// the two wavefronts meet (LDS writes done; nothing waits for global stores here)
+// the wavefronts of a workgroup meet: LDS writes done - and nothing else waited for (__syncthreads() also waits for
+// the wavefront's outstanding global stores and atomics)
 DEV void win_meet()
 {
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1016,20 +1017,27 @@ void k_win_render(const int *__restrict__ list, int nlist, int vpw, int fa, int 
 				part_off[pb][wv] = nv ? cur_off : -1;
 				part_nch[pb][wv] = cur_nch;
 			}
-			__syncthreads();
+			win_meet();
 			if(wv < 2) {
+				// (every wavefront's row asked for at once, then added up bus by bus)
+				const int po = lane < WIN_WPB ? part_off[pb][lane] : -2, pn = lane < WIN_WPB ? part_nch[pb][lane] : 2;
+				int pv[WIN_WPB];
+#pragma unroll
+				for(int w = 0; w < WIN_WPB; ++w)
+					pv[w] = part[pb][w][wv][lane];
 				int sum = 0, off = -1, nch = 2;
+#pragma unroll
 				for(int w = 0; w <= WIN_WPB; ++w) {
-					const int woff = w < WIN_WPB ? part_off[pb][w] : -2;
+					const int woff = w < WIN_WPB ? rdl(po, w < WIN_WPB ? w : 0) : -2;
 					if(woff != off) {
 						if(off >= 0 && sum && !(dbg & 1))
 							atomicAdd(busmem + off + ((size_t)f * nch + wv) * A2D_FRAG + lane, sum);
 						sum = 0;
 						off = woff;
-						nch = w < WIN_WPB ? part_nch[pb][w] : 2;
+						nch = w < WIN_WPB ? rdl(pn, w < WIN_WPB ? w : 0) : 2;
 					}
 					if(w < WIN_WPB && woff >= 0)
-						sum = wadd(sum, part[pb][w][wv][lane]);
+						sum = wadd(sum, pv[w]);
 				}
 			}
 		}
@@ -1079,7 +1087,7 @@ DEV void winf_filter(int *row, int off, int len, int f0v, int df, int qv, int qd
 struct PanW { int w[5]; };
 
 template<int NOSC>
-__global__ __launch_bounds__(64 * WINF_MAXW)
+__global__ __launch_bounds__(64 * WINF_MAXW) __attribute__((amdgpu_waves_per_eu(NOSC == 1 ? 4 : 2, NOSC == 1 ? 4 : 2)))
 void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, int fb, const int *__restrict__ wslot,
 		const int *__restrict__ wext, const unsigned *__restrict__ widx, const A2DVoice *__restrict__ voices, int *ustate,
 		const int *__restrict__ wavecoef, int *__restrict__ busmem, int dbg)
@@ -1170,23 +1178,30 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 				}
 			}
 		} else {
-			// (the last worker first: the bus sums of the fragment panned in the step before)
+			// (the last worker first: the bus sums of the fragment panned in the step before - every wavefront's row
+			// asked for at once, then added up bus by bus: one after the other they were 5 400 cycles of LDS round trips a step)
 			if(wv == nw - 1 && s >= 3) {
 				const int pb = (s - 3) & 1, g = s - 3;
+				const int po = lane < nw ? part_off[pb * nw + lane] : -2, pn = lane < nw ? part_nch[pb * nw + lane] : 2;
 #pragma unroll
 				for(int ch = 0; ch < 2; ++ch) {
+					int pv[WINF_MAXW];
+#pragma unroll
+					for(int w = 1; w < WINF_MAXW; ++w)
+						pv[w] = w < nw ? part[((pb * nw + w) * 2 + ch) * 64 + lane] : 0;
 					int sum = 0, off = -1, nch = 2;
-					for(int w = 1; w <= nw; ++w) {
-						const int woff = w < nw ? part_off[pb * nw + w] : -2;
+#pragma unroll
+					for(int w = 1; w <= WINF_MAXW; ++w) {
+						const int woff = w < nw ? rdl(po, w < WINF_MAXW ? w : 0) : -2;
 						if(woff != off) {
 							if(off >= 0 && sum && !(dbg & 1))
 								atomicAdd(busmem + off + ((size_t)(fa + g) * nch + ch) * A2D_FRAG + lane, sum);
 							sum = 0;
 							off = woff;
-							nch = w < nw ? part_nch[pb * nw + w] : 2;
+							nch = w < nw ? rdl(pn, w < WINF_MAXW ? w : 0) : 2;
 						}
-						if(w < nw && woff >= 0)
-							sum = wadd(sum, part[((pb * nw + w) * 2 + ch) * 64 + lane]);
+						if(w < WINF_MAXW && w < nw && woff >= 0)
+							sum = wadd(sum, pv[w]);
 					}
 				}
 			}
@@ -1315,7 +1330,7 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 			} else
 				S[WE_HEAD] = 0;
 		}
-		__syncthreads();
+		win_meet();
 	}
 	if(wv == 0 && lane < nv) {
 		ustate[(size_t)ufilt * A2D_USTATE + FW_D1A] = d1;

@@ -15,6 +15,13 @@ ORACLE_SO = os.path.join(ROOT, "oracle", "liba2oracle.so")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Voices that carry records are rendered by the window kernels (a2amd_win.hip) from a few thousand voices on and by
+    # the records kernels (k_leaf_recs) below that (a2amd_sched.cpp).  The test scenes are small: left alone, the suite
+    # would hardly ever reach the window kernels.  So the whole suite - in-process and through the engine - runs with the
+    # window kernels forced, and the tests named for k_leaf_recs' shapes, the trace replays at one batch size and the
+    # scripted engine cases run the records kernels as well (A2AMD_WIN=0); test_window_and_records_kernels_agree_at_size
+    # puts both through the same scene at the size where the library switches by itself.
+    os.environ.setdefault("A2AMD_WIN", "1")
 
 
 def fnv1a_fragments(pcm, frag=64):

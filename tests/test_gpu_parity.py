@@ -27,11 +27,16 @@ def first_diff(a, b):
     return int(d[0][i]), int(d[1][i]), int(a[d[0][i], d[1][i]]), int(b[d[0][i], d[1][i]])
 
 
-@pytest.mark.parametrize("batch", [1, 7, 64])
+@pytest.mark.parametrize("batch", [1, 7, 64, "64-records-kernels"])
 @pytest.mark.parametrize("name", CASES)
-def test_reference_traces_on_gpu(oracle_lib, name, batch):
+def test_reference_traces_on_gpu(oracle_lib, monkeypatch, name, batch):
     """The reference's own call traces (its five benchmark songs and our test scripts),
-    rendered on the GPU in batches of 1, 7 and 64 fragments, hash-equal to the audio the reference produced."""
+    rendered on the GPU in batches of 1, 7 and 64 fragments, hash-equal to the audio the reference produced - with the
+    window kernels (a2amd_win.hip; forced for the suite, conftest.py) and, at 64, with the records kernels (k_leaf_recs:
+    what a scene of fewer than a few thousand voices gets by default)."""
+    if batch == "64-records-kernels":
+        monkeypatch.setenv("A2AMD_WIN", "0")
+        batch = 64
     if name in ("k2intro", "k2intro44", "k2epilogue", "k2loader", "k2trance", "pulsetronic") and batch == 1:
         pytest.skip("covered by the batched run; one launch set per fragment is slow over 4500 fragments")
     tr = Trace(os.path.join(GOLDEN, f"{name}.trace.xz"))
@@ -387,6 +392,7 @@ def test_wavetable_leaf_kernel_executes_records(oracle_lib, monkeypatch, chain, 
     records-executing leaf kernel, not the general one; the 2 x wtosc->filter12->panmix
     voice (the usual subtractive note) always is; with one, a few and 64 voices per
     wavefront."""
+    monkeypatch.setenv("A2AMD_WIN", "0")        # (the kernels this test is about: k_leaf_recs)
     monkeypatch.setenv("A2AMD_RVPW", str(rvpw))
     gpu = make_gpu(max_batch=16)
     got = _wt_script(gpu, chain, groups=groups)
@@ -406,6 +412,7 @@ def test_records_kernel_filter_with_lane_per_voice(oracle_lib, monkeypatch, chai
     the pan stage reads them back.  Forced on here (A2AMD_VFILT=1) at sizes the oracle follows: the same
     random script of writes, ramps, cutoff sets and sweeps, q ramps, mix changes, births and deaths, with 1,
     3, 4 and 16 voices per wavefront (a pool that fills up in mid-voice turns the wavefront round early)."""
+    monkeypatch.setenv("A2AMD_WIN", "0")        # (the kernels this test is about: k_leaf_recs)
     monkeypatch.setenv("A2AMD_VFILT", "1")
     monkeypatch.setenv("A2AMD_RVPW", str(rvpw))
     gpu = make_gpu(max_batch=16)
@@ -420,6 +427,7 @@ def test_records_kernel_filter_with_lane_per_voice(oracle_lib, monkeypatch, chai
 
 def test_records_kernel_filter_lane_per_voice_matches_scalar_filter_at_size(monkeypatch):
     """... and A/B against the scalar recurrence on the same script at 6 000 voices, 64-fragment batches."""
+    monkeypatch.setenv("A2AMD_WIN", "0")        # (the kernels this test is about: k_leaf_recs)
     outs = []
     for vf in ("0", "1"):
         monkeypatch.setenv("A2AMD_VFILT", vf)
@@ -455,6 +463,7 @@ def test_private_sample_waves_as_coefficients_and_as_samples(oracle_lib, monkeyp
 def test_wavetable_records_kernel_matches_general_kernel(monkeypatch):
     """... and A/B against the general kernel on the same script at a size the
     oracle would take long over (A2AMD_NO_FAST=64 sends the records to k_voices)."""
+    monkeypatch.setenv("A2AMD_WIN", "0")        # (the kernels this test is about: k_leaf_recs)
     outs = []
     for no in ("0", "64"):
         monkeypatch.setenv("A2AMD_NO_FAST", no)
@@ -462,6 +471,27 @@ def test_wavetable_records_kernel_matches_general_kernel(monkeypatch):
         outs.append(_wt_script(gpu, "osc2-pan", nvoices=6000, batches=2, bfrags=64, groups=8))
         gpu.close()
     assert outs[0].any() and first_diff(outs[0], outs[1]) is None
+
+
+@pytest.mark.parametrize("chain,groups", [("osc-pan", 0), ("osc2-pan", 8), ("osc-filter-pan", 4), ("osc2-filter-pan", 0)])
+def test_window_and_records_kernels_agree_at_size(monkeypatch, chain, groups):
+    """Round 5: the window kernels (a2amd_win.hip: control pass lane = voice, render pass lane = frame) against the
+    records kernels (k_leaf_recs) on the same random script - writes, ramps, sub-fragment windows, births, deaths - at
+    the size where the library switches from the one to the other by itself, in one slab and cut into slabs (the
+    record cursor carried between them), with one stream and with a stream per list."""
+    outs = {}
+    for tag, env in (("records", {"A2AMD_WIN": "0"}), ("windows", {"A2AMD_WIN": "1"}),
+                     ("slabs", {"A2AMD_WIN": "1", "A2AMD_WIN_SLABS": "3"}), ("auto", {})):
+        for k in ("A2AMD_WIN", "A2AMD_WIN_SLABS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        gpu = make_gpu(max_batch=64)
+        outs[tag] = _wt_script(gpu, chain, nvoices=5000, batches=2, bfrags=64, groups=groups)
+        gpu.close()
+    assert outs["records"].any()
+    for tag in ("windows", "slabs", "auto"):
+        assert first_diff(outs[tag], outs["records"]) is None, tag
 
 
 def test_wave_drop_and_pool_reuse(oracle_lib):

@@ -1,9 +1,6 @@
 cd $GRAFT_REPO_ROOT
-run() { echo "== $*"; env "$@" A2AMD_WIN_TIMING=1 python tools/scripted_timing.py --chain osc-filter-pan --names scripted,scripted2,quiet2 2>&1 | grep "a2amd windows" | tail -2 | sed 's/.*records: //'; }
-run A2AMD_WFVPG=16 A2AMD_WFWAVES=8
-run A2AMD_WFVPG=16 A2AMD_WFWAVES=5
-run A2AMD_WFVPG=32 A2AMD_WFWAVES=8
-run A2AMD_WFVPG=32 A2AMD_WFWAVES=5
-run A2AMD_WFVPG=48 A2AMD_WFWAVES=8
-run A2AMD_WFVPG=8 A2AMD_WFWAVES=5
-run A2AMD_WFVPG=8 A2AMD_WFWAVES=3
+echo "== song (units only)"; python tests/measure/song_timing.py --seconds 500 2>&1 | tail -3 | cut -c1-500
+echo "== song A2AMD_WIN=0 (round 4's kernels)"; A2AMD_WIN=0 A2AMD_SPLIT=0 python tests/measure/song_timing.py --seconds 500 2>&1 | tail -2 | cut -c1-400
+echo "== song A2AMD_SPLIT=0"; A2AMD_SPLIT=0 python tests/measure/song_timing.py --seconds 500 2>&1 | tail -2 | cut -c1-400
+echo "== song A2AMD_WIN_FORK=0"; A2AMD_WIN_FORK=0 python tests/measure/song_timing.py --seconds 500 2>&1 | tail -2 | cut -c1-400
+for ch in osc-pan osc-filter-pan osc2-filter-pan; do echo "== $ch"; A2AMD_WIN_TIMING=1 python tools/scripted_timing.py --chain $ch --names scripted,scripted2,quiet2 2>&1 | grep "a2amd windows" | tail -2 | sed 's/.*records: //'; done
