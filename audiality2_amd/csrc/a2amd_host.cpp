@@ -103,6 +103,10 @@ void a2amd_close(a2amd_ctx *c)
 	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
 	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
 	hipFree(c->d_win.d); hipFree(c->d_wext.d); hipFree(c->d_wrc.d); hipFree(c->d_widx.d); hipFree(c->d_wtop);
+	if(c->h_wtop)
+		hipHostFree(c->h_wtop);
+	if(c->wtop_ev)
+		hipEventDestroy(c->wtop_ev);
 	if(c->win_stream)
 		hipStreamDestroy(c->win_stream);
 	for(int k = 0; k < 7; ++k)

@@ -476,9 +476,13 @@ struct a2amd_ctx {
 	// the window kernels (a2amd_win.hip): a slab's slots (one per fragment and voice), the pool of further
 	// windows, where each voice's begin per fragment, the pool counter + overflow flag
 	std::vector<int> moving;	// voices with moving_until set
+	size_t n_moving_listed = 0;	// ... of which this batch's upload() gave the stand-in record run
 	DevBuf<int> d_win, d_wext, d_wrc;
 	DevBuf<unsigned> d_widx;
 	unsigned *d_wtop = nullptr;	// [2 sets]{ pool counter, overflow flag }
+	unsigned *h_wtop = nullptr;	// ... copied back behind every batch (pinned), looked at before the next
+	hipEvent_t wtop_ev = nullptr;
+	bool wtop_pending = false;
 	hipStream_t win_fork[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };	// a stream per list of a batch with several (issue_windows)
 	hipEvent_t win_fev[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };	// [list] done, [7] fork
 	hipStream_t win_stream = nullptr;	// the control passes' stream (slabs: issue_windows, a2amd_sched.cpp)

@@ -499,6 +499,7 @@ int upload(a2amd_ctx *c)
 	// rampers in closed form.  They are given ONE shared stand-in record that belongs to no fragment - a run the
 	// quiet kernels skip and the control pass never consumes: default windows throughout.
 	static const bool no_moving = getenv("A2AMD_NO_MOVING") != nullptr;
+	c->n_moving_listed = 0;
 	if(!c->moving.empty()) {
 		int nop_at = -1;
 		const uint64_t t0 = c->vm.batch_time;	// walk_time when this batch began
@@ -533,6 +534,7 @@ int upload(a2amd_ctx *c)
 			now[nnow++] = vi;
 			v.moving_run = c->serial_base;
 			v.listed_recs = true;
+			++c->n_moving_listed;
 		}
 	}
 	now.resize(nnow);
@@ -998,7 +1000,9 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 			jobs[nj++] = Job{ nosc[k], filt[k], counts[k], 0, lists[k] };
 			nvoices += (size_t)counts[k];
 		}
-	size_t nrec = c->up_recs.size();
+	// (the control pass takes room in the pool by the length of a voice's record run: every gliding voice's run is
+	// the ONE shared stand-in record)
+	size_t nrec = c->up_recs.size() + c->n_moving_listed;
 	if(!c->vm.list.empty()) {
 		const int *l = c->vm.d_list.d + c->vm.list.size();
 		for(int k = 0; k < 3; l += c->vm.n_cls[k++])
@@ -1010,6 +1014,12 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 	}
 	if(!nj)
 		return 0;
+	if(c->wtop_pending && hipEventQuery(c->wtop_ev) == hipSuccess) {
+		c->wtop_pending = false;
+		if(c->h_wtop[1] || c->h_wtop[3])
+			return c->fail(A2AMD_ESTATE, "window pool overflow in an earlier batch (%u / %u entries taken of %zu): voices lost windows",
+					c->h_wtop[0], c->h_wtop[2], c->d_wext.cap);
+	}
 	static const size_t budget = (size_t)(getenv("A2AMD_WIN_MB") ? atoi(getenv("A2AMD_WIN_MB")) : 1024) * (1u << 20) /
 			(A2D_WIN_WORDS * sizeof(int)) / 2;
 	// Slabs: the control pass (lane = voice: a few hundred wavefronts, each as long as its voices' walk) of slab
@@ -1040,8 +1050,10 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 		if(int r = grow(c, c->d_wext, sets * cap, A2D_WIN_WORDS, false)) return r;
 		if(int r = grow(c, c->d_widx, sets * nslots, 1, false)) return r;
 		if(int r = grow(c, c->d_wrc, nvoices, 1, false)) return r;
-		if(!c->d_wtop)
+		if(!c->d_wtop) {
 			HIPCHK(c, hipMalloc((void **)&c->d_wtop, 4 * sizeof(unsigned)));
+			HIPCHK(c, hipMemsetAsync(c->d_wtop, 0, 4 * sizeof(unsigned), c->stream));
+		}
 		if(two && !c->win_stream) {
 			HIPCHK(c, hipStreamCreateWithFlags(&c->win_stream, hipStreamNonBlocking));
 			for(int k = 0; k < 5; ++k)
@@ -1063,6 +1075,7 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 	// they would run back to back; here every list gets a stream of its own between a fork and a join (the render
 	// passes only ever ADD to the buses).  A2AMD_WIN_FORK=0: one stream.
 	static const bool fork_ok = !(getenv("A2AMD_WIN_FORK") && !atoi(getenv("A2AMD_WIN_FORK")));
+	bool forked = false;
 	if(nj > 1 && nslabs == 1 && fork_ok && !wtiming) {
 		if(!c->win_fork[0]) {
 			if(c->capturing)
@@ -1094,10 +1107,10 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 			atv += (size_t)b.n;
 			c->stats.launches += 2;
 		}
-		return 0;
+		forked = true;
 	}
 	int k = 0;
-	for(int fa = 0; fa < nfrags; fa += per, ++k) {
+	for(int fa = 0; fa < nfrags && !forked; fa += per, ++k) {
 		const int fb = std::min(nfrags, fa + per), set = two ? (k & 1) : 0;
 		int *const wslot = c->d_win.d + (size_t)set * half_win;
 		int *const wext = c->d_wext.d + (size_t)set * half_ext * A2D_WIN_WORDS;
@@ -1152,6 +1165,19 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 			fprintf(stderr, "a2amd windows: fragments [%d, %d), %zu voices in %d list(s), %zu records: control pass %.1f us, render pass %.1f us\n",
 					fa, fb, nvoices, nj, nrec, t_ctl * 1e3, t_ren * 1e3);
 		}
+	}
+	// The pool's overflow flag (a bound the host got wrong: voices would lose windows) is never left unread: it is
+	// copied back behind the batch and looked at before the next one's windows are issued - a batch late, but loud
+	// (A2AMD_WIN_CHECK=1, the test suite's setting: at once, with a wait).
+	if(!c->capturing) {
+		if(!c->h_wtop) {
+			HIPCHK(c, hipHostMalloc((void **)&c->h_wtop, 4 * sizeof(unsigned), hipHostMallocDefault));
+			memset(c->h_wtop, 0, 4 * sizeof(unsigned));
+			HIPCHK(c, hipEventCreateWithFlags(&c->wtop_ev, hipEventDisableTiming));
+		}
+		HIPCHK(c, hipMemcpyAsync(c->h_wtop, c->d_wtop, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipEventRecord(c->wtop_ev, c->stream));
+		c->wtop_pending = true;
 	}
 	static const bool check = getenv("A2AMD_WIN_CHECK") != nullptr;
 	if(check && !c->capturing) {

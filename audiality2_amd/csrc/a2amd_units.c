@@ -1279,7 +1279,7 @@ static void amd_drv_process(A2P_audiodriver *drv, unsigned frames)
 		/* (A2AMD_SPLIT=0: the whole buffer in one round trip, as rounds 2-4 did; n: from n frames on) */
 		static int split_min = -1;
 		if(split_min < 0)
-			split_min = getenv("A2AMD_SPLIT") ? atoi(getenv("A2AMD_SPLIT")) : 1024;
+			split_min = getenv("A2AMD_SPLIT") ? atoi(getenv("A2AMD_SPLIT")) : 0;
 		hs->split_frames = split_min > 0 && frames >= (unsigned)split_min && hs->ndev == 1 ? (frames / 2 + 63) / 64 * 64 : 0;
 	}
 	if(!grow_acc(hs, frames))

@@ -40,13 +40,23 @@ void k_vm_count(A2DVmParams vp)
 	__shared__ VmSlot s_v[VM_TPB];
 	int n = 0, fault = 0;
 	if(i < vp.n) {
+#ifdef VM_SCRATCH	// (A/B: round 4's private copy)
+		A2DVmVoice vpriv;
+		A2DVmVoice &v = vpriv;
+#else
 		A2DVmVoice &v = s_v[threadIdx.x].v;
+#endif
 		v = vp.vmv[vp.list[i]];
 		const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab, vp.envlut };
 		CountE e = { 0 };
 		const uint8_t *ff = vp.fragframes, *fb = vp.fragbase;
 		run_batch(v, vp.code + v.code, K, e, vp.now, 0, vp.nfrags, [ff, fb](int f) { return (unsigned)ff[f] | ((unsigned)fb[f] << 8); },
-				&s_v[threadIdx.x].rt);
+#ifdef VM_SCRATCH
+				nullptr
+#else
+				&s_v[threadIdx.x].rt
+#endif
+				);
 		n = e.n;
 		fault = v.fault != 0;
 	}
@@ -80,7 +90,12 @@ void k_vm_emit(A2DVmParams vp)
 		return;
 	__shared__ VmSlot s_v[VM_TPB];
 	const int slot = vp.list[i];
+#ifdef VM_SCRATCH
+	A2DVmVoice vpriv;
+	A2DVmVoice &v = vpriv;
+#else
 	A2DVmVoice &v = s_v[threadIdx.x].v;
+#endif
 	v = vp.vmv[slot];
 	const A2DRun place = vp.vmrun[i];
 	const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab, vp.envlut };
@@ -89,7 +104,12 @@ void k_vm_emit(A2DVmParams vp)
 		StoreE e = { vp.recs + vp.rec_base + place.first, 0 };
 		const uint8_t *ff = vp.fragframes, *fb = vp.fragbase;
 		run_batch(v, vp.code + v.code, K, e, vp.now, 0, vp.nfrags, [ff, fb](int f) { return (unsigned)ff[f] | ((unsigned)fb[f] << 8); },
-				&s_v[threadIdx.x].rt);
+#ifdef VM_SCRATCH
+				nullptr
+#else
+				&s_v[threadIdx.x].rt
+#endif
+				);
 		if(e.n) {
 			run.first = (int)(vp.rec_base + (unsigned)place.first);
 			run.count = e.n;

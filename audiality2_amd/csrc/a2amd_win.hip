@@ -444,6 +444,11 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 			rq1 = *(const Int4 *)(recs + rc + 1);
 	}
 	int pending_fresh = 0;
+#ifdef WIN_PROF
+	const long long cp_in = __builtin_readcyclecounter();
+	long long cp_meet = 0;
+	int cp_trips = 0;
+#endif
 	for(int f = fa; f < fb; ++f) {
 		const int n = (int)ffr[f];
 		const int sb = (f - fa) & 1;
@@ -467,6 +472,9 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 				op = R_NOP;
 		}
 		while(__ballot(op != 0)) {
+#ifdef WIN_PROF
+			++cp_trips;
+#endif
 			const int value = r.y;
 			const unsigned dur = (unsigned)r.z, start = (unsigned)r.w;
 			const int u = (int)A2D_RUNIT((unsigned)r.x), reg = (int)A2D_RREG((unsigned)r.x);
@@ -625,8 +633,19 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 			st.e0[sb][lane] = e0;
 			st.nst[sb][lane] = nstaged;
 		}
+#ifdef WIN_PROF
+		const long long cp_m0 = __builtin_readcyclecounter();
+#endif
 		win_meet();	// (the writer takes buffer sb from here; this wavefront goes on into the other one)
+#ifdef WIN_PROF
+		cp_meet += __builtin_readcyclecounter() - cp_m0;
+#endif
 	}
+#ifdef WIN_PROF
+	if(blockIdx.x % 61 == 5 && lane == 0)
+		printf("k_win_ctl<%d,%d> block %d: %d fragments, %d trips through the op switch: %lld cycles (of which %lld at the meeting point)\n",
+				NOSC, FILT, (int)blockIdx.x, fb - fa, cp_trips, (long long)__builtin_readcyclecounter() - cp_in, cp_meet);
+#endif
 
 	if(live) {
 #pragma unroll
@@ -1052,22 +1071,30 @@ void k_win_render(const int *__restrict__ list, int nlist, int vpw, int fa, int 
 
 // ---- with filter12: a workgroup owns its voices for the whole slab -----------------------------
 #define WINF_PITCH 65
-#define WINF_MAXW  8		// wavefronts per workgroup (one filters)
+#define WINF_MAXW(NOSC) ((NOSC) == 1 ? 16 : 8)	// wavefronts per workgroup, one of which filters (two oscillators: the
+							// kernel needs more than the 128 registers sixteen would leave it)
 
-// f12_process, filter12.c:97-118, over the frames [off, off + len) of a voice's row, in place
-DEV void winf_filter(int *row, int off, int len, int f0v, int df, int qv, int qd, int lp, int bp, int hp, int &d1, int &d2)
+// f12_process, filter12.c:97-118, over the frames [off, off + len) of a voice's row, in place.  Two things most
+// windows do not need are decided for the whole wavefront (its lanes are its voices): LP - plain low passes, the
+// band / high pass products drop out of the output sum; REST - cutoff and q at rest, their per-frame steps and
+// the shifts of the values drop out of the loop.
+template<bool LP, bool REST>
+DEV void winf_filter_t(int *row, int off, int len, int f0v, int df, int qv, int qd, int lp, int bp, int hp, int &d1, int &d2)
 {
+	const int fq0 = f0v >> 12, qq0 = qv >> 12;
 	auto step = [&](int xin, int at) {
-		const int fq = f0v >> 12, qq = qv >> 12;
+		const int fq = REST ? fq0 : f0v >> 12, qq = REST ? qq0 : qv >> 12;
 		const int d1s = d1 >> 4;
 		const int l = wadd(d2, wmul(fq, d1s) >> 8);
 		const int h = wsub(wsub(xin >> 5, l), wmul(qq, d1s) >> 8);
 		const int b = wadd(wmul(fq, h >> 4) >> 8, d1);
-		row[at] = wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp)) >> 3;
+		row[at] = (LP ? wmul(l, lp) : wadd(wadd(wmul(l, lp), wmul(b, bp)), wmul(h, hp))) >> 3;
 		d1 = b;
 		d2 = l;
-		f0v = wadd(f0v, df);
-		qv = wadd(qv, qd);
+		if(!REST) {
+			f0v = wadd(f0v, df);
+			qv = wadd(qv, qd);
+		}
 	};
 	int k = 0;
 	for(; k + 4 <= len; k += 4) {
@@ -1083,11 +1110,24 @@ DEV void winf_filter(int *row, int off, int len, int f0v, int df, int qv, int qd
 		step(row[off + k], off + k);
 }
 
+DEV void winf_filter(int *row, int off, int len, int f0v, int df, int qv, int qd, int lp, int bp, int hp, int &d1, int &d2)
+{
+	const bool lponly = __all((bp | hp) == 0), rest = __all((df | qd) == 0);
+	if(lponly && rest)
+		winf_filter_t<true, true>(row, off, len, f0v, df, qv, qd, lp, bp, hp, d1, d2);
+	else if(lponly)
+		winf_filter_t<true, false>(row, off, len, f0v, df, qv, qd, lp, bp, hp, d1, d2);
+	else if(rest)
+		winf_filter_t<false, true>(row, off, len, f0v, df, qv, qd, lp, bp, hp, d1, d2);
+	else
+		winf_filter_t<false, false>(row, off, len, f0v, df, qv, qd, lp, bp, hp, d1, d2);
+}
+
 // the pan stage's words of an entry (head + panmix), kept from the step that rendered its oscillators
 struct PanW { int w[5]; };
 
 template<int NOSC>
-__global__ __launch_bounds__(64 * WINF_MAXW) __attribute__((amdgpu_waves_per_eu(NOSC == 1 ? 4 : 2, NOSC == 1 ? 4 : 2)))
+__global__ __launch_bounds__(64 * WINF_MAXW(NOSC)) __attribute__((amdgpu_waves_per_eu(NOSC == 1 ? 4 : 2, NOSC == 1 ? 4 : 2)))
 void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, int fb, const int *__restrict__ wslot,
 		const int *__restrict__ wext, const unsigned *__restrict__ widx, const A2DVoice *__restrict__ voices, int *ustate,
 		const int *__restrict__ wavecoef, int *__restrict__ busmem, int dbg)
@@ -1185,22 +1225,22 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 				const int po = lane < nw ? part_off[pb * nw + lane] : -2, pn = lane < nw ? part_nch[pb * nw + lane] : 2;
 #pragma unroll
 				for(int ch = 0; ch < 2; ++ch) {
-					int pv[WINF_MAXW];
+					int pv[WINF_MAXW(NOSC)];
 #pragma unroll
-					for(int w = 1; w < WINF_MAXW; ++w)
+					for(int w = 1; w < WINF_MAXW(NOSC); ++w)
 						pv[w] = w < nw ? part[((pb * nw + w) * 2 + ch) * 64 + lane] : 0;
 					int sum = 0, off = -1, nch = 2;
 #pragma unroll
-					for(int w = 1; w <= WINF_MAXW; ++w) {
-						const int woff = w < nw ? rdl(po, w < WINF_MAXW ? w : 0) : -2;
+					for(int w = 1; w <= WINF_MAXW(NOSC); ++w) {
+						const int woff = w < nw ? rdl(po, w < WINF_MAXW(NOSC) ? w : 0) : -2;
 						if(woff != off) {
 							if(off >= 0 && sum && !(dbg & 1))
 								atomicAdd(busmem + off + ((size_t)(fa + g) * nch + ch) * A2D_FRAG + lane, sum);
 							sum = 0;
 							off = woff;
-							nch = w < nw ? rdl(pn, w < WINF_MAXW ? w : 0) : 2;
+							nch = w < nw ? rdl(pn, w < WINF_MAXW(NOSC) ? w : 0) : 2;
 						}
-						if(w < WINF_MAXW && w < nw && woff >= 0)
+						if(w < WINF_MAXW(NOSC) && w < nw && woff >= 0)
 							sum = wadd(sum, pv[w]);
 					}
 				}
@@ -1384,12 +1424,16 @@ int a2d_launch_win_render(const A2DParams &hp, int nosc, int filt, const int *dl
 		// voices per workgroup = lanes of its filter wavefront: spread out until every CU has a couple of
 		// workgroups (a workgroup takes as long as its filter chain whatever its voice count), then fill up
 		static const int force = getenv("A2AMD_WFVPG") ? atoi(getenv("A2AMD_WFVPG")) : 0;
+		const int maxw = WINF_MAXW(nosc);
 		int vpg = force > 0 ? force : std::min(std::max((nlist + 511) / 512, 1), 48);
-		vpg = std::min(std::max(vpg, 1), 48);	// (48 rows x 3 tiles + the bus sums: within 64 KB of LDS)
+		vpg = std::min(std::max(vpg, 1), 64);
 		// wavefronts: the filter's + one per ~4 voices
 		static const int forcew = getenv("A2AMD_WFWAVES") ? atoi(getenv("A2AMD_WFWAVES")) : 0;
-		int nw = forcew > 1 ? forcew : 1 + std::min(std::max((vpg + 3) / 4, 1), WINF_MAXW - 1);	// (up to 7 voices per worker)
-		nw = std::min(std::max(nw, 2), WINF_MAXW);
+		int nw = forcew > 1 ? forcew : 1 + std::min(std::max((vpg + 3) / 4, 1), 7);
+		nw = std::min(std::max(nw, 2), maxw);
+		// (three tiles of vpg rows + the wavefronts' bus sums: within 64 KB of LDS)
+		while(vpg > 1 && (size_t)(3 * vpg * WINF_PITCH + 2 * nw * 2 * 64 + 2 * nw * 2) * sizeof(int) > 65536)
+			--vpg;
 		const int nblocks = (nlist + vpg - 1) / vpg;
 		const size_t dyn = (size_t)(3 * vpg * WINF_PITCH + 2 * nw * 2 * 64 + 2 * nw * 2) * sizeof(int);
 		if(nosc == 1)

@@ -22,6 +22,9 @@ def pytest_configure(config):
     # scripted engine cases run the records kernels as well (A2AMD_WIN=0); test_window_and_records_kernels_agree_at_size
     # puts both through the same scene at the size where the library switches by itself.
     os.environ.setdefault("A2AMD_WIN", "1")
+    # ... and with the window pool's overflow flag read back after every batch (a bound the host got wrong fails the
+    # render at once instead of a batch later)
+    os.environ.setdefault("A2AMD_WIN_CHECK", "1")
 
 
 def fnv1a_fragments(pcm, frag=64):
