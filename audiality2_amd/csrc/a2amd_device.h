@@ -215,6 +215,17 @@ struct A2DParams {
 
 // a2amd_vm.hip: the count pass (emit = 0) or the emit pass of the VM kernel
 int a2d_launch_vm(const A2DVmParams &vp, int emit, void *stream);
+// k_vm_pool: the window pool entries k_vm_win would take for the batch described by vp (vp.list: VM slots, any
+// classes) - one per window that begins inside a fragment - added to *out
+int a2d_launch_vm_pool(const A2DVmParams &vp, unsigned *out, void *stream);
+#define A2D_WIN_STAGED 2	/* further windows of a fragment a control lane keeps in LDS (WIN_EXL, a2amd_winctl.h) */
+// k_vm_win (a2amd_vmwin.hip): the VM voices of one window class (vp.list: their VM slots in the order of the
+// class's voice list, vp.n) run through fragments [fa, fb) and write the window entries themselves - no records.
+// now_fa: engine time of fragment fa's first frame, batch_end: of the batch's end; runs[voice].count says
+// afterwards whose the voice is this batch (0: the quiet kernels').  Returns -1 for a class without a kernel.
+int a2d_launch_vm_win(const A2DVmParams &vp, const A2DParams &hp, int nosc, int filt, int fa, int fb, uint32_t now_fa,
+		uint32_t batch_end, int *wslot, int *wext, int *wscr, unsigned *widx, unsigned *wtop, unsigned wcap, void *stream);
+#define A2D_VMW_ROW (64 - 1 - A2D_WIN_STAGED)	/* entries of wscr per voice of the list (A2D_WIN_WORDS each) */
 
 // launchers implemented in a2amd_kernels.hip (stream = hipStream_t)
 // dparams / dlist are device pointers; 'vpw' voices of the list per wavefront

@@ -102,7 +102,7 @@ void a2amd_close(a2amd_ctx *c)
 		hipEventDestroy(c->grp_ev);
 	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
 	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
-	hipFree(c->d_win.d); hipFree(c->d_wext.d); hipFree(c->d_wrc.d); hipFree(c->d_widx.d); hipFree(c->d_wtop);
+	hipFree(c->d_win.d); hipFree(c->d_wext.d); hipFree(c->d_wscr.d); hipFree(c->d_wrc.d); hipFree(c->d_widx.d); hipFree(c->d_wtop);
 	if(c->h_wtop)
 		hipHostFree(c->h_wtop);
 	if(c->wtop_ev)

@@ -258,6 +258,28 @@ struct VmHost {
 	std::vector<int> list;		// slots the kernel runs (active on the device), and ...
 	std::vector<int> cls_lists;	// ... their voices by launch class, for the records kernels: [osc1 | osc2 | filt1]
 	int n_cls[3] = { 0, 0, 0 };
+	// d_list: [list | cls_lists | the classes' VM slots in cls_lists' order (k_vm_win) | the VM slots of no class]
+	int n_other = 0;
+	bool fused = false;		// this batch: the class voices run in k_vm_win (vm_issue decides, issue_windows launches)
+	uint32_t batch_now = 0;		// engine time of this batch's first frame
+	bool total_pending = false;	// faults of a fused batch: read a batch later (h_total[1], total_ev)
+	hipEvent_t total_ev = nullptr;
+	size_t pool_used = 0;		// window pool entries the last fused batch took (sizes the next one's pool)
+	uint64_t fused_batches = 0, vm_batches = 0;
+	bool fused_off = false;		// the pool overflowed under k_vm_win (a prediction that did not hold): records from then on
+	// The pool room of a fused batch is PREDICTED: behind every batch k_vm_pool runs the class voices through the
+	// batch the host expects next - same voices, same fragments, starting where this one ends - on a stream of its
+	// own; a batch that is what was predicted runs fused with exactly that room, any other through records.
+	uint64_t list_serial = 0;	// counts the rebuilds of the lists
+	hipStream_t pred_stream = nullptr;
+	hipEvent_t pred_after = nullptr, pred_ev = nullptr;
+	unsigned *d_pred = nullptr, *h_pred = nullptr;
+	bool pred_valid = false;
+	uint64_t pred_serial = 0;
+	uint32_t pred_now = 0;
+	uint32_t pred_span = 0;		// frames
+	size_t pred_entries = 0;	// ... of the batch being issued (fused)
+	uint64_t pred_why[7] = { 0, 0, 0, 0, 0, 0, 0 };	// batches by what kept them from being fused (0: nothing)
 	bool list_dirty = false;
 	std::vector<std::pair<int, A2DVmVoice>> to_upload;	// (slot, state) going up with this batch
 	uint32_t t0 = 0;		// engine time of the context's frame 0 (walk_time = 0)
@@ -477,7 +499,7 @@ struct a2amd_ctx {
 	// windows, where each voice's begin per fragment, the pool counter + overflow flag
 	std::vector<int> moving;	// voices with moving_until set
 	size_t n_moving_listed = 0;	// ... of which this batch's upload() gave the stand-in record run
-	DevBuf<int> d_win, d_wext, d_wrc;
+	DevBuf<int> d_win, d_wext, d_wrc, d_wscr;	// (d_wscr: k_vm_win's rows of parked windows, A2D_VMW_ROW per voice)
 	DevBuf<unsigned> d_widx;
 	unsigned *d_wtop = nullptr;	// [2 sets]{ pool counter, overflow flag }
 	unsigned *h_wtop = nullptr;	// ... copied back behind every batch (pinned), looked at before the next
@@ -591,7 +613,10 @@ int dist_reduce_root(a2amd_ctx *c);
 // a2amd_vm.cpp
 int vm_prepare_batch(a2amd_ctx *c);		// upload(): pending adoptions, program text, states
 int vm_build_lists(a2amd_ctx *c);		// ... and the kernel's list, the records kernels' class lists
-int vm_issue(a2amd_ctx *c);			// issue_kernels(): the VM kernel's two passes
+int vm_issue(a2amd_ctx *c, bool fused);		// issue_kernels(): the VM kernel's two passes (fused: of the voices k_vm_win does not run)
+void vm_class_params(a2amd_ctx *c, int k, A2DVmParams *vp);	// k_vm_win's parameters for a window class
+int vm_fused_done(a2amd_ctx *c);		// ... and its fault count on its way back
+int vm_predict(a2amd_ctx *c);			// k_vm_pool for the batch after this one (issue_kernels, behind the window kernels)
 int vm_take_back(a2amd_ctx *c, int vi, bool inclusive, a2amd_vm_state *out, a2amd_vm_env *envs_out = nullptr);	// the voice is the host's again
 void vm_end_batch(a2amd_ctx *c);
 void vm_close(a2amd_ctx *c);

@@ -990,35 +990,48 @@ bool depth_has_mutes(const a2amd_ctx *c, int d)
 // a batch whose slots would not fit A2AMD_WIN_MB (1 024) is cut into slabs of fragments.
 static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *counts)
 {
-	struct Job { int nosc, filt, n, skip; const int *list; };
+	struct Job { int nosc, filt, n, skip; const int *list; int vmk; };	// vmk >= 0: a class of VM voices run by k_vm_win
 	static const int nosc[4] = { 1, 2, 1, 2 }, filt[4] = { 0, 0, 1, 1 };
 	Job jobs[7];
 	int nj = 0;
 	size_t nvoices = 0;
 	for(int k = 0; k < 4; ++k)
 		if(counts[k]) {
-			jobs[nj++] = Job{ nosc[k], filt[k], counts[k], 0, lists[k] };
+			jobs[nj++] = Job{ nosc[k], filt[k], counts[k], 0, lists[k], -1 };
 			nvoices += (size_t)counts[k];
 		}
 	// (the control pass takes room in the pool by the length of a voice's record run: every gliding voice's run is
 	// the ONE shared stand-in record)
 	size_t nrec = c->up_recs.size() + c->n_moving_listed;
+	size_t nfusedv = 0;
 	if(!c->vm.list.empty()) {
 		const int *l = c->vm.d_list.d + c->vm.list.size();
 		for(int k = 0; k < 3; l += c->vm.n_cls[k++])
 			if(c->vm.n_cls[k]) {
-				jobs[nj++] = Job{ nosc[k], filt[k], c->vm.n_cls[k], 1, l };
+				jobs[nj++] = Job{ nosc[k], filt[k], c->vm.n_cls[k], 1, l, c->vm.fused ? k : -1 };
 				nvoices += (size_t)c->vm.n_cls[k];
+				if(c->vm.fused)
+					nfusedv += (size_t)c->vm.n_cls[k];
 			}
 		nrec += c->vm.last_total;
+	}
+	// (k_vm_win takes pool room as its voices' VMs make further windows: how much was counted ahead, by k_vm_pool
+	// behind the last batch - vm_issue, a2amd_vm.cpp - for exactly this batch)
+	if(nfusedv) {
+		nrec += c->vm.pred_entries + 64;
+		++c->vm.fused_batches;
 	}
 	if(!nj)
 		return 0;
 	if(c->wtop_pending && hipEventQuery(c->wtop_ev) == hipSuccess) {
 		c->wtop_pending = false;
-		if(c->h_wtop[1] || c->h_wtop[3])
+		c->vm.pool_used = std::max(c->h_wtop[0], c->h_wtop[2]);
+		if(c->h_wtop[1] || c->h_wtop[3]) {
+			// (a bound that did not hold - the control pass's record count, k_vm_pool's prediction: never)
+			c->vm.fused_off = true;
 			return c->fail(A2AMD_ESTATE, "window pool overflow in an earlier batch (%u / %u entries taken of %zu): voices lost windows",
 					c->h_wtop[0], c->h_wtop[2], c->d_wext.cap);
+		}
 	}
 	static const size_t budget = (size_t)(getenv("A2AMD_WIN_MB") ? atoi(getenv("A2AMD_WIN_MB")) : 1024) * (1u << 20) /
 			(A2D_WIN_WORDS * sizeof(int)) / 2;
@@ -1043,6 +1056,7 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 		return c->fail(A2AMD_EUNSUPPORTED, "a batch of %zu records", cap);
 	const size_t sets = two ? 2 : 1;
 	if(sets * slotwords > c->d_win.cap || sets * cap > c->d_wext.cap || sets * nslots > c->d_widx.cap || nvoices > c->d_wrc.cap ||
+			nfusedv * A2D_VMW_ROW > c->d_wscr.cap ||
 			!c->d_wtop || (two && !c->win_stream)) {
 		if(c->capturing)
 			return c->fail(A2AMD_ESTATE, "window pool too small inside a graph capture");
@@ -1050,6 +1064,7 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 		if(int r = grow(c, c->d_wext, sets * cap, A2D_WIN_WORDS, false)) return r;
 		if(int r = grow(c, c->d_widx, sets * nslots, 1, false)) return r;
 		if(int r = grow(c, c->d_wrc, nvoices, 1, false)) return r;
+		if(int r = grow(c, c->d_wscr, nfusedv * A2D_VMW_ROW, A2D_WIN_WORDS, false)) return r;
 		if(!c->d_wtop) {
 			HIPCHK(c, hipMalloc((void **)&c->d_wtop, 4 * sizeof(unsigned)));
 			HIPCHK(c, hipMemsetAsync(c->d_wtop, 0, 4 * sizeof(unsigned), c->stream));
@@ -1068,6 +1083,34 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 		HIPCHK(c, hipEventRecord(c->win_ev[4], c->stream));
 		HIPCHK(c, hipStreamWaitEvent(sc, c->win_ev[4], 0));
 	}
+	// a list's control pass over fragments [fa, fb): k_win_ctl over its records, or - VM voices of a fused batch - k_vm_win
+	uint32_t frames_to[A2D_MAXBATCH + 1];
+	frames_to[0] = 0;
+	for(int f = 0; f < nfrags; ++f)
+		frames_to[f + 1] = frames_to[f] + (uint32_t)c->fragframes[f];
+	auto control = [&](const Job &b, int fa, int fb, int *wslot, int *wext, unsigned *widx, unsigned *wtop, unsigned wcap, int *wrc,
+			hipStream_t st) -> int {
+		int r;
+		if(b.vmk >= 0) {
+			A2DVmParams vp;
+			vm_class_params(c, b.vmk, &vp);
+			size_t before = 0;	// (voices of the classes in front of this one: their rows of d_wscr)
+			for(int q = 0; q < b.vmk; ++q)
+				before += (size_t)c->vm.n_cls[q];
+			int *const wscr = c->d_wscr.d + before * A2D_VMW_ROW * A2D_WIN_WORDS;
+			r = a2d_launch_vm_win(vp, c->hparams, b.nosc, b.filt, fa, fb, vp.now + (frames_to[fa] << 8), vp.now + (frames_to[nfrags] << 8),
+					wslot, wext, wscr, widx, wtop, wcap, st);
+		} else
+			r = a2d_launch_win_ctl(c->d_params, c->hparams, b.nosc, b.filt, b.list, b.n, b.skip, fa, fb, wslot, wext, widx, wtop, wcap, wrc, st);
+		// (A2AMD_WIN_SYNC=1, debugging: wait for every launch and say so - the last line names the kernel that faulted)
+		static const bool dbgsync = getenv("A2AMD_WIN_SYNC") != nullptr;
+		if(dbgsync && !r && !c->capturing) {
+			const hipError_t e = hipStreamSynchronize(st);
+			fprintf(stderr, "a2amd windows: control pass <%d,%d> %s of %d voices, fragments [%d, %d): %s\n", b.nosc, b.filt,
+					b.vmk >= 0 ? "k_vm_win" : "k_win_ctl", b.n, fa, fb, hipGetErrorString(e));
+		}
+		return r;
+	};
 	static const bool wtiming = getenv("A2AMD_WIN_TIMING") != nullptr;
 	static hipEvent_t tev[3] = { nullptr, nullptr, nullptr };
 	// Several lists, one slab (a song: a few dozen voices of four classes): each list's control pass and render
@@ -1093,8 +1136,7 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 			const Job &b = jobs[j];
 			hipStream_t sj = c->win_fork[j];
 			HIPCHK(c, hipStreamWaitEvent(sj, c->win_fev[7], 0));
-			if(a2d_launch_win_ctl(c->d_params, c->hparams, b.nosc, b.filt, b.list, b.n, b.skip, 0, nfrags,
-					c->d_win.d + atw, c->d_wext.d, c->d_widx.d + at, c->d_wtop,
+			if(control(b, 0, nfrags, c->d_win.d + atw, c->d_wext.d, c->d_widx.d + at, c->d_wtop,
 					(unsigned)std::min<size_t>(c->d_wext.cap, 0xffffffffu), c->d_wrc.d + atv, sj))
 				return c->fail(A2AMD_EHIP, "window control launch failed: %s", hipGetErrorString(hipGetLastError()));
 			if(a2d_launch_win_render(c->hparams, b.nosc, b.filt, b.list, b.n, 0, nfrags, c->d_win.d + atw,
@@ -1128,8 +1170,7 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 		size_t at = 0, atw = 0, atv = 0;
 		for(int j = 0; j < nj; ++j) {
 			const Job &b = jobs[j];
-			if(a2d_launch_win_ctl(c->d_params, c->hparams, b.nosc, b.filt, b.list, b.n, b.skip, fa, fb,
-					wslot + atw, wext, widx + at, wtop,
+			if(control(b, fa, fb, wslot + atw, wext, widx + at, wtop,
 					(unsigned)std::min<size_t>(two ? half_ext : c->d_wext.cap, 0xffffffffu), c->d_wrc.d + atv, sc))
 				return c->fail(A2AMD_EHIP, "window control launch failed: %s", hipGetErrorString(hipGetLastError()));
 			at += (size_t)b.n * (size_t)(fb - fa);
@@ -1179,13 +1220,19 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 		HIPCHK(c, hipEventRecord(c->wtop_ev, c->stream));
 		c->wtop_pending = true;
 	}
+	if(c->vm.fused)
+		if(int r = vm_fused_done(c))
+			return r;
 	static const bool check = getenv("A2AMD_WIN_CHECK") != nullptr;
 	if(check && !c->capturing) {
 		unsigned top[4] = { 0, 0, 0, 0 };
 		HIPCHK(c, hipMemcpyAsync(top, c->d_wtop, sizeof(top), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
-		if(top[1] || (two && top[3]))
+		if(top[1] || (two && top[3])) {
+			if(c->vm.fused)
+				c->vm.fused_off = true;
 			return c->fail(A2AMD_ESTATE, "window pool overflow (%u / %u of %zu entries)", top[0], top[2], c->d_wext.cap);
+		}
 	}
 	return 0;
 }
@@ -1220,8 +1267,41 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			HIPCHK(c, hipEventRecord(e0, c->stream));
 		// the scripted voices the device runs itself: their VMs first - the records of this batch,
 		// runs[] pointing at them (a2amd_vm.cpp / a2amd_vm.hip) - then the kernels as for host records
-		if(int r = vm_issue(c))
+		// The voices that carry records this batch: the 2 x wtosc-filter12-panmix leaves, with and without
+		// records, and - of the classes that have quiet kernels of their own - this batch's voices with records.
+		// Round 5: the record stream resolved by a lane = voice control pass, the windows rendered
+		// from closed-form entries (a2amd_win.hip).  A2AMD_WIN=0: k_leaf_recs, the kernels of rounds
+		// 2-4 that interpret the records on the scalar unit of the rendering wavefront (A/B).
+		// Which one: the window kernels' two passes are each as long as ONE voice's walk through the batch (the
+		// control pass) / one filter chain (the render pass) whatever the voice count - 0.4 to 1 ms per 64 fragments -
+		// where k_leaf_recs, one wavefront per voice, takes 0.3 ms for a song's few dozen voices and 0.4 - 0.7 ms for a
+		// thousand; from a few thousand voices on it is k_leaf_recs that queues up (16 384: 1.1 - 3.9 ms against
+		// 0.5 - 1.8).  A2AMD_WIN=0 / 1 forces (the parity tests run both), A2AMD_WIN_MIN moves the threshold.
+		const int *rlists[4] = { c->d_dyn, c->d_dyn + c->n_dyn_osc1, c->d_dyn + c->n_dyn_osc1 + c->n_dyn_osc2,
+				c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf + c->n_fm_leaf + c->n_leaf };
+		const int rcounts[4] = { c->n_dyn_osc1, c->n_dyn_osc2, c->n_dyn_filt, c->n_o2f_leaf };
+		const int rtotal = rcounts[0] + rcounts[1] + rcounts[2] + rcounts[3];
+		bool use_win;
+		{
+			const char *wenv = getenv("A2AMD_WIN");
+			static const int win_min = getenv("A2AMD_WIN_MIN") ? atoi(getenv("A2AMD_WIN_MIN")) : 2048;
+			int nwinv = rtotal;
+			for(int k = 0; k < 3; ++k)
+				nwinv += c->vm.list.empty() ? 0 : c->vm.n_cls[k];
+			use_win = wenv ? atoi(wenv) != 0 : nwinv >= win_min;
+		}
+		// (A2AMD_VMWIN=0: the device VM's voices through records - k_vm_count / k_vm_emit - whatever renders them)
+		static const bool vmwin_ok = !(getenv("A2AMD_VMWIN") && !atoi(getenv("A2AMD_VMWIN")));
+		if(int r = vm_issue(c, use_win && vmwin_ok && !c->vm.fused_off))
 			return r;
+		// ... the window kernels first: k_vm_win says in runs[] which of the VM's voices are the quiet kernels' this batch
+		if(use_win) {
+			if(int r = issue_windows(c, rlists, rcounts))
+				return r;
+			if(vmwin_ok)
+				if(int r = vm_predict(c))
+					return r;
+		}
 		if(c->n_fast_leaf) {
 			int vpw, ysplit;
 			pick_fast_shape(c->n_fast_leaf, c->nfrags, &vpw, &ysplit);
@@ -1305,31 +1385,11 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 				++c->stats.launches;
 				return 0;
 			};
-			// the 2 x wtosc-filter12-panmix leaves, with and without records, and - of the classes that
-			// have quiet kernels of their own - this batch's voices with records
-			const int *lists[4] = { c->d_dyn, c->d_dyn + c->n_dyn_osc1, c->d_dyn + c->n_dyn_osc1 + c->n_dyn_osc2,
-					c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf + c->n_fm_leaf + c->n_leaf };
-			const int counts[4] = { c->n_dyn_osc1, c->n_dyn_osc2, c->n_dyn_filt, c->n_o2f_leaf };
-			const int total = counts[0] + counts[1] + counts[2] + counts[3];
+			const int *const *lists = rlists;
+			const int *counts = rcounts;
+			const int total = rtotal;
 			const int kinds = (counts[0] != 0) + (counts[1] != 0) + (counts[2] != 0) + (counts[3] != 0);
-			// Round 5: the record stream resolved by a lane = voice control pass, the windows rendered
-			// from closed-form entries (a2amd_win.hip).  A2AMD_WIN=0: k_leaf_recs, the kernels of rounds
-			// 2-4 that interpret the records on the scalar unit of the rendering wavefront (A/B).
-			// Which one: the window kernels' two passes are each as long as ONE voice's walk through the batch (the
-			// control pass) / one filter chain (the render pass) whatever the voice count - 0.4 to 1 ms per 64 fragments -
-			// where k_leaf_recs, one wavefront per voice, takes 0.3 ms for a song's few dozen voices and 0.4 - 0.7 ms for a
-			// thousand; from a few thousand voices on it is k_leaf_recs that queues up (16 384: 1.1 - 3.9 ms against
-			// 0.5 - 1.8).  A2AMD_WIN=0 / 1 forces (the parity tests run both), A2AMD_WIN_MIN moves the threshold.
-			const char *wenv = getenv("A2AMD_WIN");
-			static const int win_min = getenv("A2AMD_WIN_MIN") ? atoi(getenv("A2AMD_WIN_MIN")) : 2048;
-			int nwinv = total;
-			for(int k = 0; k < 3; ++k)
-				nwinv += c->vm.list.empty() ? 0 : c->vm.n_cls[k];
-			const bool use_win = wenv ? atoi(wenv) != 0 : nwinv >= win_min;
-			if(use_win) {
-				if(int r = issue_windows(c, lists, counts))
-					return r;
-			} else {
+			if(!use_win) {
 			if(kinds > 1 && total <= 4096 && !getenv("A2AMD_RVPW")) {
 				// few voices of several kinds (a song): one launch - on one stream the per-kind
 				// launches would run back to back, each as long as one voice's walk through the batch

@@ -46,7 +46,7 @@ unsigned ins_size(unsigned op)		// a2_InsSize, src/compiler.c:111-131
 }
 
 // records of the host interpreter go where the recorder's go: the voice's list, fragment order
-struct HostE {
+struct HostE : a2vm::PlainE {
 	a2amd_ctx *c;
 	int vi;
 	void rec(int frag, int op, int unit, int reg, int value, unsigned dur, unsigned start)
@@ -345,7 +345,7 @@ static void vm_lookahead(const A2DVmVoice &d0, const uint32_t *code, const Const
 		int *records, int *runs_out)
 {
 	A2DVmVoice d = d0;
-	CountE e = { 0 };
+	CountE e = { {}, 0 };
 	int runs = 0;
 	*exit_when = d.waketime;
 	for(; runs < VM_MAXRUNS; ++runs) {
@@ -451,7 +451,7 @@ int vm_take_back(a2amd_ctx *c, int vi, bool inclusive, a2amd_vm_state *out, a2am
 	if(f0 < f1) {
 		const HVmProg &p = m.progs[h.prog];
 		const Consts K = consts_of(c);
-		HostE e = { c, vi };
+		HostE e = { {}, c, vi };
 		uint64_t frames_before = 0;
 		for(int f = 0; f < f0; ++f)
 			frames_before += c->fragframes[f];
@@ -573,7 +573,7 @@ int vm_prepare_batch(a2amd_ctx *c)
 			continue;
 		const HVmProg &p = m.progs[h.prog];
 		const Consts K = consts_of(c);
-		HostE e = { c, h.voice };
+		HostE e = { {}, c, h.voice };
 		uint64_t frames_before = 0;
 		for(int f = 0; f <= h.adopt_frag && f < c->nfrags; ++f)
 			frames_before += c->fragframes[f];
@@ -642,7 +642,9 @@ int vm_build_lists(a2amd_ctx *c)
 	if(m.list_dirty) {
 		use_device(c);
 		m.list.clear();
-		std::vector<int> cls[3];
+		++m.list_serial;
+		std::vector<std::pair<int, int>> cls[3];	// (voice slot, VM slot)
+		std::vector<int> other;
 		for(size_t s = 0; s < m.vms.size(); ++s) {
 			const HVm &h = m.vms[s];
 			if(!h.live || h.pending || h.fresh)
@@ -655,17 +657,25 @@ int vm_build_lists(a2amd_ctx *c)
 			const HVoice &v = c->voices[m.vms[s].voice];
 			const int k = v.cls == CLS_OSCPAN ? 0 : v.cls == CLS_OSC2PAN ? 1 : v.cls == CLS_OSCFILTPAN ? 2 : -1;
 			if(k >= 0)
-				cls[k].push_back(m.vms[s].voice);
+				cls[k].push_back(std::make_pair(m.vms[s].voice, s));
+			else
+				other.push_back(s);
 		}
 		m.cls_lists.clear();
+		std::vector<int> cls_vm;
 		for(int k = 0; k < 3; ++k) {
-			auto by_bus = [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; };
+			auto by_bus = [&](const std::pair<int, int> &a, const std::pair<int, int> &b) {
+				return c->voices[a.first].out_off < c->voices[b.first].out_off; };
 			if(!std::is_sorted(cls[k].begin(), cls[k].end(), by_bus))	// (slots follow the walk: usually grouped already)
 				std::stable_sort(cls[k].begin(), cls[k].end(), by_bus);
 			m.n_cls[k] = (int)cls[k].size();
-			m.cls_lists.insert(m.cls_lists.end(), cls[k].begin(), cls[k].end());
+			for(const auto &pr : cls[k]) {
+				m.cls_lists.push_back(pr.first);
+				cls_vm.push_back(pr.second);
+			}
 		}
-		const size_t n = m.list.size() + m.cls_lists.size();
+		m.n_other = (int)other.size();
+		const size_t n = m.list.size() + 2 * m.cls_lists.size() + other.size();
 		if(int r = grow(c, m.d_list, n + 64, 1, false))
 			return r;
 		if(int r = grow(c, m.d_vmrun, m.list.size() + 64, 1, false))
@@ -673,6 +683,8 @@ int vm_build_lists(a2amd_ctx *c)
 		if(n) {
 			std::vector<int> all = m.list;
 			all.insert(all.end(), m.cls_lists.begin(), m.cls_lists.end());
+			all.insert(all.end(), cls_vm.begin(), cls_vm.end());
+			all.insert(all.end(), other.begin(), other.end());
 			HIPCHK(c, hipMemcpyAsync(m.d_list.d, all.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
 			HIPCHK(c, hipStreamSynchronize(c->stream));
 		}
@@ -684,19 +696,10 @@ int vm_build_lists(a2amd_ctx *c)
 // issue_kernels(): count pass, the host reads the total (and grows the blob's VM region when the
 // records do not fit), emit pass.  The leaf kernels that follow find runs[voice] and the records
 // where host records would be.
-int vm_issue(a2amd_ctx *c)
+// what the VM kernels are told beside their voice list: the whole list, this batch's time and fragments
+static void fill_params(a2amd_ctx *c, A2DVmParams &vp)
 {
 	VmHost &m = c->vm;
-	if(m.list.empty())
-		return 0;
-	if(c->capturing)
-		return c->fail(A2AMD_ESTATE, "device VM voices in a captured batch");
-	use_device(c);
-	if(!m.d_total) {
-		HIPCHK(c, hipMalloc((void **)&m.d_total, 2 * sizeof(uint32_t)));
-		HIPCHK(c, hipHostMalloc((void **)&m.h_total, 2 * sizeof(uint32_t), hipHostMallocDefault));
-	}
-	A2DVmParams vp;
 	memset(&vp, 0, sizeof(vp));
 	vp.vmv = m.d_vmv.d;
 	vp.list = m.d_list.d;
@@ -718,7 +721,151 @@ int vm_issue(a2amd_ctx *c)
 		vp.fragframes[f] = (uint8_t)c->fragframes[f];
 		vp.fragbase[f] = c->fragbase[f];
 	}
+}
+
+// k_vm_win's parameters for window class k (0: wtosc-panmix, 1: 2 x wtosc-panmix, 2: wtosc-filter12-panmix) of a
+// fused batch (vm_issue has run: the batch's time is the one it used)
+void vm_class_params(a2amd_ctx *c, int k, A2DVmParams *vp)
+{
+	VmHost &m = c->vm;
+	fill_params(c, *vp);
+	vp->now = m.batch_now;
+	const int *l = m.d_list.d + m.list.size() + m.cls_lists.size();
+	for(int q = 0; q < k; ++q)
+		l += m.n_cls[q];
+	vp->list = l;
+	vp->n = m.n_cls[k];
+}
+
+// Behind a batch's window kernels: what k_vm_win would take from the pool for the NEXT batch if that one has this
+// one's fragments, begins where this one ends and finds the lists as they are - all of which vm_issue checks before
+// it believes the number.  On a stream of its own: nothing of this batch waits for it.
+int vm_predict(a2amd_ctx *c)
+{
+	VmHost &m = c->vm;
+	m.pred_valid = false;
+	const int ncls = m.n_cls[0] + m.n_cls[1] + m.n_cls[2];
+	if(m.list.empty() || !ncls || c->capturing || m.fused_off)
+		return 0;
+	if(!m.pred_stream) {
+		HIPCHK(c, hipStreamCreateWithFlags(&m.pred_stream, hipStreamNonBlocking));
+		HIPCHK(c, hipEventCreateWithFlags(&m.pred_after, hipEventDisableTiming));
+		HIPCHK(c, hipEventCreateWithFlags(&m.pred_ev, hipEventDisableTiming));
+		HIPCHK(c, hipMalloc((void **)&m.d_pred, 2 * sizeof(unsigned)));
+		HIPCHK(c, hipHostMalloc((void **)&m.h_pred, 2 * sizeof(unsigned), hipHostMallocDefault));
+	}
+	A2DVmParams vp;
+	fill_params(c, vp);
+	uint32_t frames = 0;
+	for(int f = 0; f < c->nfrags; ++f)
+		frames += c->fragframes[f];
+	if((frames + A2D_FRAG - 1) / A2D_FRAG > A2D_MAXBATCH)
+		return 0;
+	vp.now = m.batch_now + (frames << 8);
+	vp.nfrags = 0;
+	for(uint32_t at = 0; at < frames; at += A2D_FRAG) {	// (the stretch this batch covered, uncut)
+		vp.fragframes[vp.nfrags] = (uint8_t)std::min<uint32_t>(A2D_FRAG, frames - at);
+		vp.fragbase[vp.nfrags++] = 0;
+	}
+	vp.list = m.d_list.d + m.list.size() + m.cls_lists.size();	// the three classes' VM slots, one after the other
+	vp.n = ncls;
+	HIPCHK(c, hipEventRecord(m.pred_after, c->stream));
+	HIPCHK(c, hipStreamWaitEvent(m.pred_stream, m.pred_after, 0));
+	HIPCHK(c, hipMemsetAsync(m.d_pred, 0, 2 * sizeof(unsigned), m.pred_stream));
+	if(a2d_launch_vm_pool(vp, m.d_pred, m.pred_stream))
+		return c->fail(A2AMD_EHIP, "VM pool launch failed: %s", hipGetErrorString(hipGetLastError()));
+	HIPCHK(c, hipMemcpyAsync(m.h_pred, m.d_pred, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, m.pred_stream));
+	HIPCHK(c, hipEventRecord(m.pred_ev, m.pred_stream));
+	m.pred_valid = true;
+	m.pred_serial = m.list_serial;
+	m.pred_now = vp.now;
+	m.pred_span = frames;
+	++c->stats.launches;
+	return 0;
+}
+
+// faults of a fused batch's voices (k_vm_win counts them in d_total[1]): copied back behind the batch, looked at
+// before the next one (vm_issue)
+int vm_fused_done(a2amd_ctx *c)
+{
+	VmHost &m = c->vm;
+	if(!m.total_ev)
+		HIPCHK(c, hipEventCreateWithFlags(&m.total_ev, hipEventDisableTiming));
+	HIPCHK(c, hipMemcpyAsync(m.h_total, m.d_total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipEventRecord(m.total_ev, c->stream));
+	m.total_pending = true;
+	return 0;
+}
+
+// fused (the window kernels render this batch's record voices, issue_kernels decides): the voices of the three
+// window classes are not run here - k_vm_win, launched by issue_windows() with vm_params(), runs their VMs and
+// writes their window entries itself; count / emit then cover only the voices of other chains.
+int vm_issue(a2amd_ctx *c, bool fused)
+{
+	VmHost &m = c->vm;
+	m.fused = false;
+	if(m.list.empty())
+		return 0;
+	if(c->capturing)
+		return c->fail(A2AMD_ESTATE, "device VM voices in a captured batch");
+	use_device(c);
+	if(!m.d_total) {
+		HIPCHK(c, hipMalloc((void **)&m.d_total, 2 * sizeof(uint32_t)));
+		HIPCHK(c, hipHostMalloc((void **)&m.h_total, 2 * sizeof(uint32_t), hipHostMallocDefault));
+	}
+	if(m.total_pending) {
+		HIPCHK(c, hipEventSynchronize(m.total_ev));	// (behind the batch before this one: long done)
+		m.total_pending = false;
+		if(m.h_total[1])
+			return c->fail(A2AMD_ESTATE, "device VM: %u voice(s) faulted in an earlier batch (the analysis let a program through "
+					"that it should not have)", m.h_total[1]);
+	}
+	A2DVmParams vp;
+	fill_params(c, vp);
+	m.batch_now = vp.now;
+	++m.vm_batches;
+	// fused only if this batch is the one k_vm_pool was run for behind the last one: its count is the pool's bound
+	m.fused = false;
+	if(fused && m.n_cls[0] + m.n_cls[1] + m.n_cls[2] > 0) {
+		// ... the same voices, beginning at the time predicted, covering the stretch predicted, in the fragments predicted
+		// (64 frames each from the first) or pieces of them
+		int why = !m.pred_valid ? 1 : m.pred_serial != m.list_serial ? 2 : m.pred_now != vp.now ? 3 : 0;
+		if(!why) {
+			uint32_t at = 0;
+			for(int f = 0; f < c->nfrags && !why; ++f) {
+				if(at / A2D_FRAG != (at + c->fragframes[f] - 1) / A2D_FRAG)
+					why = 5;	// (a fragment across a predicted boundary)
+				at += c->fragframes[f];
+			}
+			if(!why && at != m.pred_span)
+				why = 4;
+		}
+		++m.pred_why[why];
+		static const int trace = getenv("A2AMD_HOSTTIMING") ? atoi(getenv("A2AMD_HOSTTIMING")) : 0;
+		if(trace >= 2 && why >= 4)
+			fprintf(stderr, "a2amd device VM: batch of %d fragments not fused: %s (predicted: %u frames)\n", c->nfrags,
+					why == 4 ? "another length" : "a fragment across a 64-frame boundary", m.pred_span);
+		if(!why) {
+			HIPCHK(c, hipEventSynchronize(m.pred_ev));	// (launched beside the last batch's render pass: done)
+			m.pred_entries = m.h_pred[0];
+			m.fused = true;
+		}
+	}
+	m.pred_valid = false;
+	if(m.fused) {
+		vp.list = m.d_list.d + m.list.size() + 2 * m.cls_lists.size();
+		vp.n = m.n_other;
+	}
 	HIPCHK(c, hipMemsetAsync(m.d_total, 0, 2 * sizeof(uint32_t), c->stream));
+	uint64_t batch_frames = 0;
+	for(int f = 0; f < c->nfrags; ++f)
+		batch_frames += c->fragframes[f];
+	if(vp.n == 0) {		// (every voice is k_vm_win's)
+		m.last_total = 0;
+		m.stats.vm_voice_batches += m.list.size();
+		m.replayed += batch_frames;
+		return 0;
+	}
 	if(a2d_launch_vm(vp, 0, c->stream))
 		return c->fail(A2AMD_EHIP, "VM count launch failed: %s", hipGetErrorString(hipGetLastError()));
 	HIPCHK(c, hipMemcpyAsync(m.h_total, m.d_total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -797,6 +944,12 @@ void vm_end_batch(a2amd_ctx *c)
 void vm_close(a2amd_ctx *c)
 {
 	VmHost &m = c->vm;
+	if(c->hosttiming && m.vm_batches)
+		fprintf(stderr, "a2amd device VM: %llu batches with device VM voices, %llu of them through k_vm_win (the others: %llu not "
+				"predicted, %llu other voices, %llu another time, %llu / %llu / %llu other fragments)\n",
+				(unsigned long long)m.vm_batches, (unsigned long long)m.fused_batches, (unsigned long long)m.pred_why[1],
+				(unsigned long long)m.pred_why[2], (unsigned long long)m.pred_why[3], (unsigned long long)m.pred_why[4],
+				(unsigned long long)m.pred_why[5], (unsigned long long)m.pred_why[6]);
 	hipFree(m.d_vmv.d);
 	hipFree(m.d_code.d);
 	hipFree(m.d_list.d);
@@ -804,6 +957,16 @@ void vm_close(a2amd_ctx *c)
 	hipFree(m.d_f1tab);
 	hipFree(m.d_envlut);
 	hipFree(m.d_total);
+	if(m.total_ev)
+		hipEventDestroy(m.total_ev);
+	if(m.pred_stream) {
+		hipStreamSynchronize(m.pred_stream);
+		hipStreamDestroy(m.pred_stream);
+		hipEventDestroy(m.pred_after);
+		hipEventDestroy(m.pred_ev);
+		hipFree(m.d_pred);
+		hipHostFree(m.h_pred);
+	}
 	if(m.h_total)
 		hipHostFree(m.h_total);
 	if(m.h_stage)
@@ -1221,7 +1384,7 @@ static int trace_impl(const uint32_t *code, unsigned nwords, a2amd_vm_state *st,
 		K.f1tab = f1.data();
 	}
 	std::vector<A2DRec> buf((size_t)cap + 8);
-	struct BoundedE {
+	struct BoundedE : a2vm::PlainE {
 		A2DRec *out;
 		int n, cap;
 		void rec(int frag, int op, int unit, int reg, int value, unsigned dur, unsigned start)
@@ -1235,7 +1398,7 @@ static int trace_impl(const uint32_t *code, unsigned nwords, a2amd_vm_state *st,
 			++n;
 		}
 		int count() const { return n; }
-	} e = { buf.data(), 0, (int)cap };
+	} e = { {}, buf.data(), 0, (int)cap };
 	if(has_exit) {
 		// the stretch the device VM would be given (a2amd_vm_adopt, vm_lookahead): the interpreter stops in front of
 		// the first VM run that is the engine's

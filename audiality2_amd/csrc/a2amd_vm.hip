@@ -48,7 +48,7 @@ void k_vm_count(A2DVmParams vp)
 #endif
 		v = vp.vmv[vp.list[i]];
 		const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab, vp.envlut };
-		CountE e = { 0 };
+		CountE e = { {}, 0 };
 		const uint8_t *ff = vp.fragframes, *fb = vp.fragbase;
 		run_batch(v, vp.code + v.code, K, e, vp.now, 0, vp.nfrags, [ff, fb](int f) { return (unsigned)ff[f] | ((unsigned)fb[f] << 8); },
 #ifdef VM_SCRATCH
@@ -101,7 +101,7 @@ void k_vm_emit(A2DVmParams vp)
 	const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab, vp.envlut };
 	A2DRun run = { 0, 0 };
 	if((unsigned)place.first + (unsigned)place.count <= vp.rec_cap) {
-		StoreE e = { vp.recs + vp.rec_base + place.first, 0 };
+		StoreE e = { {}, vp.recs + vp.rec_base + place.first, 0 };
 		const uint8_t *ff = vp.fragframes, *fb = vp.fragbase;
 		run_batch(v, vp.code + v.code, K, e, vp.now, 0, vp.nfrags, [ff, fb](int f) { return (unsigned)ff[f] | ((unsigned)fb[f] << 8); },
 #ifdef VM_SCRATCH
@@ -118,6 +118,43 @@ void k_vm_emit(A2DVmParams vp)
 	}
 	// (no room - the host checked: never - leaves the voice where it was, silent on the VM's side)
 	vp.runs[v.voice] = run;
+}
+
+// The pool room k_vm_win will need for the batch AFTER this one: every voice run, on a copy, through the stretch of
+// time the host expects that batch to cover, in fragments of 64 frames - PoolE counts the windows that begin inside
+// one.  A window begins where the voice's VM wakes up (run_batch), whatever the fragments are: the count is a bound
+// for any batch over the same stretch whose fragments are these or pieces of these (the engine cuts a fragment
+// where a group's own VM wakes up, core.c:1852-1878), which vm_issue checks (a2amd_vm.cpp).  out[0] += entries.
+// (Launched beside the render pass, read when the next batch is issued.)
+__global__ __launch_bounds__(VM_TPB)
+void k_vm_pool(A2DVmParams vp, unsigned *out)
+{
+	const int i = (int)(blockIdx.x * VM_TPB + threadIdx.x), lane = (int)(threadIdx.x & 63);
+	__shared__ VmSlot s_v[VM_TPB];
+	int n = 0;
+	if(i < vp.n) {
+		A2DVmVoice &v = s_v[threadIdx.x].v;
+		v = vp.vmv[vp.list[i]];
+		const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab, vp.envlut };
+		PoolE e = { {}, 0, 0, 0 };
+		const uint8_t *ff = vp.fragframes, *fb = vp.fragbase;
+		run_batch(v, vp.code + v.code, K, e, vp.now, 0, vp.nfrags, [ff, fb](int f) { return (unsigned)ff[f] | ((unsigned)fb[f] << 8); },
+				&s_v[threadIdx.x].rt);
+		n = e.pool;
+	}
+#pragma unroll
+	for(int d = 32; d > 0; d >>= 1)
+		n += __shfl_xor(n, d, 64);
+	if(lane == 0 && n)
+		atomicAdd(out, (unsigned)n);
+}
+
+int a2d_launch_vm_pool(const A2DVmParams &vp, unsigned *out, void *stream)
+{
+	if(vp.n <= 0)
+		return 0;
+	hipLaunchKernelGGL(k_vm_pool, dim3((vp.n + VM_TPB - 1) / VM_TPB), dim3(VM_TPB), 0, (hipStream_t)stream, vp, out);
+	return (int)hipGetLastError();
 }
 
 int a2d_launch_vm(const A2DVmParams &vp, int emit, void *stream)

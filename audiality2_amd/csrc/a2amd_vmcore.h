@@ -35,7 +35,10 @@ struct Consts {
 };
 
 enum { TRAP_NONE = 0, TRAP_OVERLOAD, TRAP_OPCODE, TRAP_DIVISOR, TRAP_PC,
-	TRAP_TARGET };	// a write through a VM register wired to something the device VM does not write (A2D_VM_TRAPWRITE)
+	TRAP_TARGET,	// a write through a VM register wired to something the device VM does not write (A2D_VM_TRAPWRITE)
+	TRAP_RECORDS };	// more records between two drains than a lane of k_vm_win holds (a2amd_vmwin.hip)
+// (not a trap: a run that gives way to its caller - an emitter with a bounded queue, E::fused - and is entered again)
+enum { RUN_YIELD = -1 };
 // (env keeps its own copy of the state's msdur, env.c:236: the same expression)
 VMFN uint32_t en_msdur(const Consts &K) { return K.msdur; }
 
@@ -313,12 +316,19 @@ VMFN int run(A2DVmVoice &v, const uint32_t *code, const Consts &K, E &e, int fra
 	// (the tracker's register list is indexed at run time: the kernel hands in a place in LDS for it)
 	Tracker rtlocal;
 	Tracker &rt = rtmem ? *rtmem : rtlocal;
-	rt.mask = rt.position = 0;
+	if(e.resuming())	// (a run that gave way, below: its tracker - in rtmem - and its instruction count go on)
+		inscount = e.resume();
+	else
+		rt.mask = rt.position = 0;
 	if(v.state == A2AMD_VM_WAITING)
 		v.state = A2AMD_VM_RUNNING;
 	for(;;) {
 		if(v.fault)
 			return v.fault;
+		if(e.crowded()) {
+			e.yield(inscount);
+			return RUN_YIELD;
+		}
 		if(v.pc >= v.ncode)
 			return TRAP_PC;
 		const uint32_t w = code[v.pc];
@@ -549,7 +559,8 @@ VMFN uint32_t run_batch(A2DVmVoice &v, const uint32_t *code, const Consts &K, E 
 		int s = 0;
 		while(s < frames) {
 			const uint32_t t = fs + ((uint32_t)s << 8);
-			int res;
+			int res = 0;
+			bool gave_way = false;
 			for(;;) {
 				const int nextvm = (int)(v.waketime - t);	// a2_TSDiff
 				if(nextvm > 255) {
@@ -561,11 +572,19 @@ VMFN uint32_t run_batch(A2DVmVoice &v, const uint32_t *code, const Consts &K, E 
 					break;
 				}
 				const int trap = run(v, code, K, e, f, rtmem);
+				if(trap == RUN_YIELD) {		// (k_vm_win: the records so far are carried out, then the run goes on)
+					gave_way = true;
+					break;
+				}
 				if(trap) {
 					v.fault = trap;
 					res = frames;
 					break;
 				}
+			}
+			if(gave_way) {
+				e.drain(f);
+				continue;
 			}
 			if(res > frames - s)
 				res = frames - s;
@@ -597,26 +616,56 @@ VMFN uint32_t run_batch(A2DVmVoice &v, const uint32_t *code, const Consts &K, E 
 							}
 						}
 				}
-			if(!(s == 0 && res == frames && e.count() == before && !nlate))
+			// (the fragment's default window - nothing else in it - is no record; an emitter that is the
+			// records' reader as well gets every window)
+			if(E::fused || !(s == 0 && res == frames && e.count() == before && !nlate))
 				e.rec(f, R_SEG, 0, 0, 0, (unsigned)s | ((unsigned)res << 16), 0);
 			for(int k = 0; k < nlate; ++k) {
 				const A2DVmEnv &en = v.env[late_slot[k]];
 				write_unit(v, K, e, f, en.target, en.out, (unsigned)(base + s), (unsigned)res << 8);
 			}
 			s += res;
+			e.drain(f);
 		}
+		e.end_fragment(f);
 		fs += (uint32_t)frames << 8;
 	}
 	return fs;
 }
 
-struct CountE {
+// (what an emitter without a queue of its own says to run() / run_batch())
+struct PlainE {
+	static constexpr bool fused = false;
+	VMFN bool resuming() const { return false; }
+	VMFN unsigned resume() { return 0; }
+	VMFN bool crowded() const { return false; }
+	VMFN void yield(unsigned) {}
+	VMFN void drain(int) {}
+	VMFN void end_fragment(int) {}
+};
+
+// What k_vm_win (a2amd_vmwin.hip) takes from the window pool for a voice: one entry per window of a fragment beyond
+// its first.  Run ahead of the batch it is about (k_vm_pool, a2amd_vm.hip), on a copy of the voice.
+struct PoolE : PlainE {
+	static constexpr bool fused = true;	// (every window is a record: run_batch)
+	int nseg, total, pool;
+	VMFN void rec(int, int op, int, int, int, unsigned, unsigned) { ++total; nseg += op == R_SEG; }
+	VMFN int count() const { return total; }
+	VMFN void end_fragment(int)
+	{
+		if(nseg > 1)
+			pool += nseg - 1;
+		nseg = 0;
+	}
+};
+
+struct CountE : PlainE {
 	int n;
 	VMFN void rec(int, int, int, int, int, unsigned, unsigned) { ++n; }
 	VMFN int count() const { return n; }
 };
 
-struct StoreE {
+struct StoreE : PlainE {
 	A2DRec *out;
 	int n;
 	VMFN void rec(int frag, int op, int unit, int reg, int value, unsigned dur, unsigned start)

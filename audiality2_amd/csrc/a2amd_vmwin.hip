@@ -1,0 +1,343 @@
+// a2amd_vmwin.hip - the device VM driving the window kernels' control state directly (round 5).
+//
+// k_vm_count / k_vm_emit (a2amd_vm.hip) make RECORDS of what a scripted voice's VM does - some eighty
+// per voice and 64-fragment batch for a script that writes every 3 ms - which k_win_ctl (a2amd_win.hip)
+// then reads back one by one: the interpreter runs twice (the count pass sizes the record array, the
+// host waits for its total), 22 MB of records per batch of 16 384 voices are written and read, and two
+// lane = voice walks of the batch follow each other, each as long as one wavefront's serial trip.
+// For the voices the window kernels render anyway - the chains wtosc [wtosc] [filter12] panmix - this
+// kernel is both at once:
+//
+//   k_vm_win<NOSC, FILT>   lane = VOICE.  The lane runs its voice's VM through the batch's fragments
+//                          (run_batch, a2amd_vmcore.h - a2_VoiceProcess, core.c:1847-1880) and applies
+//                          what the VM does - control writes, cutoff coefficients, windows - to the
+//                          voice's control state (CtlVoice, a2amd_winctl.h) in the same lane, writing
+//                          the closed-form window entries k_win_render reads.  What the emitter makes is
+//                          still "records", in the order the engine makes its calls - but they live in
+//                          a queue of a few per lane in LDS and are carried out at the end of every
+//                          window (one copy of the code that carries them out, shared with k_win_ctl).
+//
+// No count pass, no host round trip in the middle of the batch, no record array.  A voice the VM leaves
+// alone for the whole batch (asleep beyond its end, stopped in front of the engine's run) is not taken:
+// runs[voice].count says which (1: ours, 0: the quiet kernels'), written before those are launched.
+//
+// Further windows of a fragment ("extras") need room in the launch's pool: a control pass takes one per
+// record up front (it knows the count); here the writer wavefront takes what a fragment's staged extras
+// need, one atomic per wavefront and fragment that has any, off the control wavefront's path.  A lane
+// with more than WIN_EXL extras in one fragment (a VM that wakes more often than every 20 frames) parks
+// the others in a row of its own in memory (wscr: 62 entries per lane, a fragment has no more windows
+// than frames) and moves them to the pool when the fragment is done and their number known.  So the
+// pool holds exactly one entry per further window - at most one per VM run that begins inside a
+// fragment - which is what the host sized it by (k_vm_pool, a2amd_vm.hip: counted ahead of the batch).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <algorithm>
+#include "a2amd_device.h"
+#include "a2amd_vmcore.h"
+#include "a2amd_winctl.h"
+
+using namespace a2vm;
+
+// records a lane keeps between two drains, and from how many on a VM run gives way to a drain: ONE instruction
+// makes at most one record per control register of the chain and two for a cutoff (SETALL / RAMPALL over
+// 2 x 4 wtosc + 5 filter12 + 2 panmix registers: 16), so VMW_GIVEWAY + 17 <= VMW_RING never overflows; the
+// queue says so if it ever does (TRAP_RECORDS: the voice stops and the host reports the fault)
+#define VMW_RING    24
+#define VMW_GIVEWAY 6
+#define VMW_ROW     (64 - 1 - WIN_EXL)	/* further windows of a fragment beyond the staged ones: a lane's row of wscr */
+
+struct VmwSlot { A2DVmVoice v; Tracker rt; int32_t pad[((sizeof(A2DVmVoice) + sizeof(Tracker)) / 4) % 2 ? 0 : 1]; };
+static_assert((sizeof(VmwSlot) / 4) % 2 == 1, "an odd stride in words");
+
+struct VmwStage {
+	WinStage w;
+	int own[2][64];		// the lane took the fragment's room in the pool itself (e0 says where)
+	Int4 ring[VMW_RING][64];
+};
+
+template<int NOSC, int FILT>
+struct WinE {
+	static constexpr bool fused = true;
+	CtlVoice<NOSC, FILT> &cv;
+	A2DVmVoice &v;
+	VmwStage &st;
+	const A2DWave *waves;
+	const PTab &ptab;
+	int *ustate;
+	int *wext;
+	int *wrow;		// this lane's row of wscr
+	unsigned *wtop;
+	unsigned wcap;
+	int lane, fa, fb;
+	int n, total;		// records queued / made so far
+	bool again;
+	unsigned left;
+	// the fragment under way
+	int nwin, nstaged, own;
+	unsigned head0, block;
+
+	VMFN void rec(int frag, int op, int unit, int reg, int value, unsigned dur, unsigned start)
+	{
+		const Int4 q = { (int)A2D_HEAD(frag, op, unit, reg), value, (int)dur, (int)start };
+		if(n < VMW_RING)
+			st.ring[n][lane] = q;
+		else
+			v.fault = TRAP_RECORDS;
+		++n;
+		++total;
+	}
+	VMFN int count() const { return total; }
+	VMFN bool resuming() const { return again; }
+	VMFN unsigned resume() { again = false; return left; }
+	VMFN bool crowded() const { return n > VMW_GIVEWAY; }
+	VMFN void yield(unsigned inscount) { left = inscount; again = true; }
+
+	DEV void begin_fragment()
+	{
+		nwin = nstaged = own = 0;
+		head0 = block = 0;
+	}
+
+	// carries out what the VM has done since the last time, in order
+	DEV void drain(int f)
+	{
+		constexpr int SW = WIN_SW(NOSC, FILT);
+		const int sb = (f - fa) & 1;
+		const int m = n < VMW_RING ? n : VMW_RING;
+		for(int k = 0; k < m; ++k) {
+			const Int4 r = st.ring[k][lane];
+			const int op = (int)A2D_ROP((unsigned)r.x);
+			if(op == R_SEG) {
+				if(!cv.active)
+					continue;
+				const unsigned dur = (unsigned)r.z;
+				int W[SW];
+				const unsigned head = ctl_window(cv, waves, ptab, (int)(dur & 0xffffu), (int)(dur >> 16), W);
+				int *dst = nullptr;
+				if(!nwin) {
+					head0 = head;
+					dst = st.w.slot[sb] + lane * SW;
+				} else if(nstaged < WIN_EXL)
+					dst = st.w.ext[sb][lane][nstaged++];
+				else if(nwin - 1 - WIN_EXL < VMW_ROW) {
+					own = 1;	// (parked: end_fragment moves them)
+					dst = wrow + (size_t)(nwin - 1 - WIN_EXL) * A2D_WIN_WORDS;
+				}
+				++nwin;
+				if(dst) {
+#pragma unroll
+					for(int j = 0; j < SW / 4; ++j) {
+						const Int4 q = { W[4 * j], W[4 * j + 1], W[4 * j + 2], W[4 * j + 3] };
+						((Int4 *)dst)[j] = q;
+					}
+				}
+			} else
+				ctl_apply(cv, waves, ptab, ustate, op, (int)A2D_RUNIT((unsigned)r.x), (int)A2D_RREG((unsigned)r.x), r.y,
+						(unsigned)r.z, (unsigned)r.w);
+		}
+		n = 0;
+	}
+
+	// the fragment's slot gets its head word, the writer wavefront the fragment
+	DEV void end_fragment(int f)
+	{
+		const int sb = (f - fa) & 1;
+		if(FILT && cv.pending_fresh && f == fb - 1) {
+			head0 |= WH_FRESH;
+			cv.pending_fresh = 0;
+		}
+		int extras = nwin > 1 ? min(nwin - 1, WIN_EXL + VMW_ROW) : 0;
+		if(own) {
+			// the fragment's further windows, now that their number is known: room in the pool, the staged ones and
+			// the parked ones moved there
+			constexpr int SW = WIN_SW(NOSC, FILT);
+			block = atomicAdd(wtop, (unsigned)extras);
+			if(block + (unsigned)extras > wcap) {
+				atomicOr(wtop + 1, 1u);	// (no room - the host counted them ahead: never; they are lost, the flag says so)
+				extras = 0;
+			} else
+				for(int q = 0; q < extras; ++q) {
+					const Int4 *in = q < WIN_EXL ? (const Int4 *)st.w.ext[sb][lane][q] :
+							(const Int4 *)(wrow + (size_t)(q - WIN_EXL) * A2D_WIN_WORDS);
+					Int4 *o = (Int4 *)(wext + ((size_t)block + q) * A2D_WIN_WORDS);
+#pragma unroll
+					for(int j = 0; j < SW / 4; ++j)
+						o[j] = in[j];
+				}
+		}
+		st.w.slot[sb][lane * WIN_SW(NOSC, FILT) + WE_HEAD] = (int)(head0 | ((unsigned)extras << 19));
+		st.w.e0[sb][lane] = block;
+		st.w.nst[sb][lane] = own ? 0 : nstaged;
+		st.own[sb][lane] = own;
+		win_meet();
+		begin_fragment();
+	}
+};
+
+// The writer: what win_ctl_writer does, and the pool room of the fragment's staged extras - a prefix sum over the
+// lanes and one atomic - before they go out.  A wavefront that finds the pool full (the host sized it: never)
+// takes the extras out of its voices' head words again, and the flag says so.
+template<int NOSC, int FILT>
+DEV void vmw_writer(int nlist, int first, int fa, int fb, int *__restrict__ wslot, int *__restrict__ wext,
+		unsigned *__restrict__ widx, unsigned *__restrict__ wtop, unsigned wcap, VmwStage &st)
+{
+	constexpr int SW = WIN_SW(NOSC, FILT);
+	const int lane = threadIdx.x & 63;
+	const int nv = max(0, min(64, nlist - first));
+	for(int f = fa; f < fb; ++f) {
+		const int sb = (f - fa) & 1;
+		win_meet();
+		const int own = lane < nv ? st.own[sb][lane] : 0;
+		int n = lane < nv ? st.w.nst[sb][lane] : 0;
+		unsigned e0 = st.w.e0[sb][lane];
+		if(__ballot(n != 0)) {
+			int pre = n;
+#pragma unroll
+			for(int d = 1; d < 64; d <<= 1) {
+				const int t = __shfl_up(pre, d, 64);
+				if(lane >= d)
+					pre += t;
+			}
+			const int total = __shfl(pre, 63, 64);
+			unsigned base = 0;
+			if(lane == 0)
+				base = atomicAdd(wtop, (unsigned)total);
+			base = (unsigned)__shfl((int)base, 0, 64);
+			if(base + (unsigned)total > wcap) {
+				if(lane == 0)
+					atomicOr(wtop + 1, 1u);
+				if(n) {
+					int *h = st.w.slot[sb] + lane * SW + WE_HEAD;
+					*h = (int)((unsigned)*h & ~(127u << 19));
+				}
+				n = 0;
+			} else if(!own)
+				e0 = base + (unsigned)(pre - n);
+		}
+		int *const dst = wslot + ((size_t)(f - fa) * nlist + first) * SW;
+		for(int i = lane; i < nv * (SW / 4); i += 64)
+			((Int4 *)dst)[i] = ((const Int4 *)st.w.slot[sb])[i];
+		if(lane < nv) {
+			widx[(size_t)(f - fa) * nlist + first + lane] = e0;
+			for(int k = 0; k < n; ++k) {
+				Int4 *o = (Int4 *)(wext + ((size_t)e0 + k) * A2D_WIN_WORDS);
+				const Int4 *in = (const Int4 *)st.w.ext[sb][lane][k];
+#pragma unroll
+				for(int q = 0; q < SW / 4; ++q)
+					o[q] = in[q];
+			}
+		}
+	}
+}
+
+// Is the voice the VM's this batch?  Not if nothing will happen to it: the VM asleep beyond the batch's end (no
+// run: a run needs waketime - t <= 255 at a window start t < end, run_batch), stopped by a fault or in front of
+// the run that is the engine's, and no env unit or cutoff ramp under way that makes records without the VM.
+DEV bool vmw_idle(const A2DVmVoice &v, uint32_t batch_end)
+{
+	if(v.nenv | v.ncut) {
+		for(int k = 0; k < v.nenv && k < A2D_VM_MAXENV; ++k)
+			if(v.env[k].active)
+				return false;
+		for(int k = 0; k < (int)v.ncut && k < A2D_VM_MAXCUT; ++k)
+			if(v.cut[k][3])		// (the ramper's timer: still on its way)
+				return false;
+	}
+	if(v.fault || (v.has_exit && v.waketime == v.exit_when))
+		return true;
+	return (int32_t)(v.waketime - batch_end) >= 0;
+}
+
+template<int NOSC, int FILT>
+__global__ __launch_bounds__(128)
+void k_vm_win(A2DVmParams vp, int fa, int fb, uint32_t now_fa, uint32_t batch_end,
+		int *__restrict__ wslot, int *__restrict__ wext, int *__restrict__ wscr, unsigned *__restrict__ widx, unsigned *__restrict__ wtop, unsigned wcap,
+		const A2DVoice *__restrict__ voices, int *ustate, int *vactive, const A2DWave *__restrict__ waves,
+		const uint32_t *__restrict__ ptab)
+{
+	__shared__ PTab s_ptab;
+	__shared__ VmwSlot s_v[64];
+	__shared__ VmwStage s_stage;
+	__shared__ int s_anylive;
+	for(int k = (int)threadIdx.x; k < 128; k += 128)
+		s_ptab[k] = ptab[k];
+	const int wave = rfl((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+	const int first = (int)blockIdx.x * 64, idx = first + lane;
+	constexpr int SW = WIN_SW(NOSC, FILT);
+	bool live = false;
+	int slot = 0;
+	if(wave == 0) {
+		// (a lane without a voice of ours leaves an empty slot every fragment: its head words never change)
+		s_stage.w.slot[0][lane * SW + WE_HEAD] = 0;
+		s_stage.w.slot[1][lane * SW + WE_HEAD] = 0;
+		s_stage.w.e0[0][lane] = s_stage.w.e0[1][lane] = 0;
+		s_stage.w.nst[0][lane] = s_stage.w.nst[1][lane] = 0;
+		s_stage.own[0][lane] = s_stage.own[1][lane] = 0;
+		if(idx < vp.n) {
+			slot = vp.list[idx];
+			A2DVmVoice &v = s_v[lane].v;
+			v = vp.vmv[slot];
+			// (a later slab of the batch: the first one decided)
+			live = fa > 0 ? vp.runs[v.voice].count != 0 : !vmw_idle(v, batch_end);
+			if(fa == 0) {
+				const A2DRun run = { 0, live ? 1 : 0 };
+				vp.runs[v.voice] = run;
+			}
+		}
+		const unsigned long long any = __ballot(live);
+		if(lane == 0)
+			s_anylive = any != 0;
+	}
+	__syncthreads();
+	if(wave != 0) {
+		vmw_writer<NOSC, FILT>(vp.n, first, fa, fb, wslot, wext, widx, wtop, wcap, s_stage);
+		return;
+	}
+	if(!s_anylive) {
+		// (none of the 64 is ours this batch: the writer still carries out their - empty - slots, the render pass
+		// reads every slot of the list)
+		for(int f = fa; f < fb; ++f)
+			win_meet();
+		return;
+	}
+	if(live) {
+		A2DVmVoice &v = s_v[lane].v;
+		CtlVoice<NOSC, FILT> cv;
+		ctl_clear(cv);
+		const A2DVoice &vc = voices[v.voice];
+#pragma unroll
+		for(int o = 0; o <= NOSC + FILT; ++o)
+			cv.uu[o] = vc.unit[o];
+		ctl_load(cv, ustate, vactive, v.voice);
+		const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab, vp.envlut };
+		WinE<NOSC, FILT> e = { cv, v, s_stage, waves, s_ptab, ustate, wext, wscr + (size_t)idx * VMW_ROW * A2D_WIN_WORDS, wtop, wcap,
+				lane, fa, fb, 0, 0, false, 0u, 0, 0, 0, 0u, 0u };
+		const uint8_t *ff = vp.fragframes, *fbs = vp.fragbase;
+		run_batch(v, vp.code + v.code, K, e, now_fa, fa, fb, [ff, fbs](int f) { return (unsigned)ff[f] | ((unsigned)fbs[f] << 8); },
+				&s_v[lane].rt);
+		ctl_store(cv, ustate, vactive, v.voice);
+		vp.vmv[slot] = v;
+		if(v.fault)
+			atomicAdd(vp.total + 1, 1u);
+	}
+}
+
+int a2d_launch_vm_win(const A2DVmParams &vp, const A2DParams &hp, int nosc, int filt, int fa, int fb, uint32_t now_fa,
+		uint32_t batch_end, int *wslot, int *wext, int *wscr, unsigned *widx, unsigned *wtop, unsigned wcap, void *stream)
+{
+	if(vp.n <= 0 || fb <= fa)
+		return 0;
+	const int nblocks = (vp.n + 63) / 64;
+#define VMW_LAUNCH(N, F) hipLaunchKernelGGL((k_vm_win<N, F>), dim3(nblocks), dim3(128), 0, (hipStream_t)stream, vp, fa, fb, now_fa, \
+		batch_end, wslot, wext, wscr, widx, wtop, wcap, hp.voices, hp.ustate, hp.vactive, hp.waves, hp.ptab)
+	if(nosc == 1 && !filt)
+		VMW_LAUNCH(1, 0);
+	else if(nosc == 2 && !filt)
+		VMW_LAUNCH(2, 0);
+	else if(nosc == 1 && filt)
+		VMW_LAUNCH(1, 1);
+	else
+		return -1;
+#undef VMW_LAUNCH
+	return (int)hipGetLastError();
+}

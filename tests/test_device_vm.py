@@ -152,6 +152,48 @@ def test_notes_run_on_the_device_vm_up_to_the_run_that_ends_them(tmp_path, buffe
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("vmwin", ["1", "0"])
+@pytest.mark.parametrize("buffer", [64, 4096, 1000])
+def test_voices_that_wake_many_times_per_fragment(tmp_path, buffer, vmwin):
+    """tests/a2s/vmfast.a2s: VMs that wake every 0.1 to 0.4 ms - up to a dozen windows of the chain per 64-frame
+    fragment, bursts of sixty - on all three window classes.  With k_vm_win (A2AMD_VMWIN=1, the default with the window
+    kernels) a fragment's further windows beyond the two staged in LDS go to a block of the pool the lane takes for
+    that fragment itself (a2amd_vmwin.hip); through records (A2AMD_VMWIN=0) k_win_ctl places them by its up-front
+    bound.  Both against the CPU engine's render, sample for sample."""
+    need_ref()
+    frames = 48000 // buffer * buffer
+    cpu, _, _ = render(tmp_path, "cpu", "vmfast", "Main", frames, buffer, ["0.05"])
+    vm, stats, err = render(tmp_path, "vm", "vmfast", "Main", frames, buffer, ["0.05"], preload=f"{WALK_SO} {UNITS_SO}",
+                            env_extra={"A2AMD_VMWIN": vmwin, "A2AMD_HOSTTIMING": "1"})
+    assert cpu.any()
+    assert first_difference(cpu, vm, 2, buffer) is None, first_difference(cpu, vm, 2, buffer)
+    assert stats and stats[0] >= 40, (stats, err[-400:])
+    # (the test is about k_vm_win: most batches must have been its - every batch whose voices and fragments are the
+    # ones the batch before predicted, a2amd_vm.cpp vm_predict)
+    m = re.search(r"(\d+) batches with device VM voices, (\d+) of them through k_vm_win", err)
+    assert m, err[-600:]
+    if vmwin == "1":
+        assert int(m.group(2)) >= int(m.group(1)) // 4 > 0, m.group(0)
+    else:
+        assert int(m.group(2)) == 0, m.group(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("script,args", [("vmloops", ["0.08"]), ("vmnotes", ["0.08"]), ("envloops", ["0.08"])])
+def test_device_vm_voices_through_records_are_the_same_audio(tmp_path, script, args):
+    """A2AMD_VMWIN=0: the window-class voices of the device VM through k_vm_count / k_vm_emit and k_win_ctl - the path
+    the suite's other tests leave to voices of other chains since k_vm_win - against the CPU engine."""
+    need_ref()
+    buffer = 1000
+    frames = 48000 * 2 // buffer * buffer
+    cpu, _, _ = render(tmp_path, "cpu", script, "Main", frames, buffer, args)
+    vm, stats, err = render(tmp_path, "vm", script, "Main", frames, buffer, args, preload=f"{WALK_SO} {UNITS_SO}",
+                            env_extra={"A2AMD_VMWIN": "0"})
+    assert first_difference(cpu, vm, 2, buffer) is None, first_difference(cpu, vm, 2, buffer)
+    assert stats and stats[0] >= 12, (stats, err[-400:])
+
+
+@pytest.mark.gpu
 def test_song_notes_are_taken_by_the_device_vm(tmp_path):
     """tests/a2s/song.a2s (the plumbing-sized workload): its melodic notes and the kick - programs that run out - are
     the device VM's between their first delay and their last VM run; hats and snares stay the engine's (their noise
