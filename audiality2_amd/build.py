@@ -52,7 +52,7 @@ def build_lib(force=False):
     srcs = [os.path.join(csrc, f) for f in ("a2amd_host.cpp", "a2amd_sched.cpp", "a2amd_render.cpp", "a2amd_dist.cpp",
                                             "a2amd_vm.cpp", "a2amd_kernels.hip", "a2amd_fast.hip", "a2amd_vm.hip", "a2amd_wavecap.hip", "a2amd_win.hip", "a2amd_vmwin.hip")]
     deps = srcs + [os.path.join(csrc, "a2amd_host.h"), os.path.join(csrc, "a2amd_device.h"), os.path.join(csrc, "a2amd_dsp.h"),
-                   os.path.join(csrc, "a2amd_fm.h"), os.path.join(csrc, "a2amd_vmcore.h"), os.path.join(csrc, "a2amd_taps.h"), os.path.join(csrc, "a2amd_winctl.h"), os.path.join(ROOT, "include", "a2amd.h"),
+                   os.path.join(csrc, "a2amd_fm.h"), os.path.join(csrc, "a2amd_vmcore.h"), os.path.join(csrc, "a2amd_taps.h"), os.path.join(csrc, "a2amd_winctl.h"), os.path.join(csrc, "a2amd_vmdev.h"), os.path.join(ROOT, "include", "a2amd.h"),
                    os.path.join(ROOT, "include", "a2amd_vm.h")]
     out = os.path.join(HERE, "liba2amd.so")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]

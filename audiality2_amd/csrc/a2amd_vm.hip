@@ -20,43 +20,29 @@
 #include <hip/hip_runtime.h>
 #include "a2amd_device.h"
 #include "a2amd_vmcore.h"
+#include "a2amd_vmdev.h"
 
 using namespace a2vm;
 
 #define VM_TPB 64		// one wavefront per workgroup: voices diverge, a short block retires early
-
-// A voice's working copy lives in LDS, one per lane: the interpreter indexes the register file, the control
-// map, the env units and the cutoff rampers with run-time values, and a struct indexed like that in "registers"
-// is a struct in scratch memory (round 4: 476 bytes of private segment per lane, every VM register access a
-// trip to the vector cache).  One word of padding makes a lane's stride odd: the same word of 64 voices lies in
-// 32 different banks.
-struct VmSlot { A2DVmVoice v; Tracker rt; int32_t pad[((sizeof(A2DVmVoice) + sizeof(Tracker)) / 4) % 2 ? 0 : 1]; };
-static_assert((sizeof(VmSlot) / 4) % 2 == 1, "an odd stride in words");
 
 __global__ __launch_bounds__(VM_TPB)
 void k_vm_count(A2DVmParams vp)
 {
 	const int i = (int)(blockIdx.x * VM_TPB + threadIdx.x), lane = (int)(threadIdx.x & 63);
 	__shared__ VmSlot s_v[VM_TPB];
+	__shared__ uint32_t s_code[VM_CODEWORDS];
 	int n = 0, fault = 0;
-	if(i < vp.n) {
-#ifdef VM_SCRATCH	// (A/B: round 4's private copy)
-		A2DVmVoice vpriv;
-		A2DVmVoice &v = vpriv;
-#else
-		A2DVmVoice &v = s_v[threadIdx.x].v;
-#endif
+	A2DVmVoice &v = s_v[threadIdx.x].v;
+	if(i < vp.n)
 		v = vp.vmv[vp.list[i]];
+	const uint32_t *code = vm_stage_code(vp.code, v, i < vp.n, s_code);
+	if(i < vp.n) {
 		const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab, vp.envlut };
 		CountE e = { {}, 0 };
 		const uint8_t *ff = vp.fragframes, *fb = vp.fragbase;
-		run_batch(v, vp.code + v.code, K, e, vp.now, 0, vp.nfrags, [ff, fb](int f) { return (unsigned)ff[f] | ((unsigned)fb[f] << 8); },
-#ifdef VM_SCRATCH
-				nullptr
-#else
-				&s_v[threadIdx.x].rt
-#endif
-				);
+		run_batch(v, code, K, e, vp.now, 0, vp.nfrags, [ff, fb](int f) { return (unsigned)ff[f] | ((unsigned)fb[f] << 8); },
+				&s_v[threadIdx.x].rt);
 		n = e.n;
 		fault = v.fault != 0;
 	}
@@ -86,30 +72,24 @@ __global__ __launch_bounds__(VM_TPB)
 void k_vm_emit(A2DVmParams vp)
 {
 	const int i = (int)(blockIdx.x * VM_TPB + threadIdx.x);
-	if(i >= vp.n)
-		return;
 	__shared__ VmSlot s_v[VM_TPB];
-	const int slot = vp.list[i];
-#ifdef VM_SCRATCH
-	A2DVmVoice vpriv;
-	A2DVmVoice &v = vpriv;
-#else
+	__shared__ uint32_t s_code[VM_CODEWORDS];
+	const bool has = i < vp.n;
+	const int slot = has ? vp.list[i] : 0;
 	A2DVmVoice &v = s_v[threadIdx.x].v;
-#endif
-	v = vp.vmv[slot];
+	if(has)
+		v = vp.vmv[slot];
+	const uint32_t *code = vm_stage_code(vp.code, v, has, s_code);
+	if(!has)
+		return;
 	const A2DRun place = vp.vmrun[i];
 	const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab, vp.envlut };
 	A2DRun run = { 0, 0 };
 	if((unsigned)place.first + (unsigned)place.count <= vp.rec_cap) {
 		StoreE e = { {}, vp.recs + vp.rec_base + place.first, 0 };
 		const uint8_t *ff = vp.fragframes, *fb = vp.fragbase;
-		run_batch(v, vp.code + v.code, K, e, vp.now, 0, vp.nfrags, [ff, fb](int f) { return (unsigned)ff[f] | ((unsigned)fb[f] << 8); },
-#ifdef VM_SCRATCH
-				nullptr
-#else
-				&s_v[threadIdx.x].rt
-#endif
-				);
+		run_batch(v, code, K, e, vp.now, 0, vp.nfrags, [ff, fb](int f) { return (unsigned)ff[f] | ((unsigned)fb[f] << 8); },
+				&s_v[threadIdx.x].rt);
 		if(e.n) {
 			run.first = (int)(vp.rec_base + (unsigned)place.first);
 			run.count = e.n;
@@ -131,14 +111,17 @@ void k_vm_pool(A2DVmParams vp, unsigned *out)
 {
 	const int i = (int)(blockIdx.x * VM_TPB + threadIdx.x), lane = (int)(threadIdx.x & 63);
 	__shared__ VmSlot s_v[VM_TPB];
+	__shared__ uint32_t s_code[VM_CODEWORDS];
 	int n = 0;
-	if(i < vp.n) {
-		A2DVmVoice &v = s_v[threadIdx.x].v;
+	A2DVmVoice &v = s_v[threadIdx.x].v;
+	if(i < vp.n)
 		v = vp.vmv[vp.list[i]];
+	const uint32_t *code = vm_stage_code(vp.code, v, i < vp.n, s_code);
+	if(i < vp.n) {
 		const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab, vp.envlut };
 		PoolE e = { {}, 0, 0, 0 };
 		const uint8_t *ff = vp.fragframes, *fb = vp.fragbase;
-		run_batch(v, vp.code + v.code, K, e, vp.now, 0, vp.nfrags, [ff, fb](int f) { return (unsigned)ff[f] | ((unsigned)fb[f] << 8); },
+		run_batch(v, code, K, e, vp.now, 0, vp.nfrags, [ff, fb](int f) { return (unsigned)ff[f] | ((unsigned)fb[f] << 8); },
 				&s_v[threadIdx.x].rt);
 		n = e.pool;
 	}

@@ -335,8 +335,9 @@ VMFN int run(A2DVmVoice &v, const uint32_t *code, const Consts &K, E &e, int fra
 		const unsigned op = A2AMD_VM_OPCODE(w), a1 = A2AMD_VM_A1(w) & 63u, a2 = A2AMD_VM_A2(w);
 		// (two-word instructions keep a3 in the next word; read where it exists)
 		const int32_t a3 = (v.pc + 1u < v.ncode) ? (int32_t)code[v.pc + 1] : 0;
-		unsigned dt = 0;
+		unsigned dt = 0, cdur = 0;
 		bool timing = false;
+		int ctl = 0;		// 1: a write through register a1's wire, 2: through all the tracker holds
 		if(!--inscount)
 			return TRAP_OVERLOAD;
 		switch(op) {
@@ -492,42 +493,52 @@ VMFN int run(A2DVmVoice &v, const uint32_t *code, const Consts &K, E &e, int fra
 		  case A2AMD_OP_XORR: r[a1] = (!r[a1] != !r[a2 & 63u]) << 16; rt_mark(rt, a1); break;
 		  case A2AMD_OP_NOTR: r[a1] = (!r[a2 & 63u]) << 16; rt_mark(rt, a1); break;
 
-		  // unit control, core.c:1459-1489
+		  // unit control, core.c:1459-1489 (carried out behind the switch)
 		  case A2AMD_OP_SET:
-			control(v, K, e, frag, a1, v.waketime, 0);
-			rt_unmark(rt, a1);
+			ctl = 1;
 			break;
 		  case A2AMD_OP_SETALL:		// a2_RTSetAll, core.c:1109-1116
-			rt_apply(rt, v, K, e, frag, v.waketime, 0);
-			rt.mask = rt.position = 0;
+			ctl = 2;
 			break;
 		  case A2AMD_OP_RAMP:
-			control(v, K, e, frag, a1, v.waketime, ms2t(K.msdur, a3));
-			rt_unmark(rt, a1);
+			ctl = 1;
+			cdur = ms2t(K.msdur, a3);
 			++v.pc;
 			break;
 		  case A2AMD_OP_RAMPR:
-			control(v, K, e, frag, a1, v.waketime, ms2t(K.msdur, r[a2 & 63u]));
-			rt_unmark(rt, a1);
+			ctl = 1;
+			cdur = ms2t(K.msdur, r[a2 & 63u]);
 			break;
 		  case A2AMD_OP_RAMPALL:
-			rt_apply(rt, v, K, e, frag, v.waketime, ms2t(K.msdur, a3));
-			rt.mask = rt.position = 0;
+			ctl = 2;
+			cdur = ms2t(K.msdur, a3);
 			++v.pc;
 			break;
 		  case A2AMD_OP_RAMPALLR:
-			rt_apply(rt, v, K, e, frag, v.waketime, ms2t(K.msdur, r[a1]));
-			rt.mask = rt.position = 0;
+			ctl = 2;
+			cdur = ms2t(K.msdur, r[a1]);
 			break;
 
 		  default:
 			return TRAP_OPCODE;
 		}
 		++v.pc;
+		// The writes through the control wires - one register (SET / RAMP*), all the tracker holds (SETALL / RAMPALL*:
+		// a2_RTApply + reset, core.c:1101-1116), or what a timing instruction finds in the tracker ("timing:",
+		// core.c:1719-1733) - in ONE place: control() with everything behind it (the units' write callbacks, the
+		// recorder) is most of the interpreter's text, and seven copies of it were more than the instruction cache holds.
+		if(ctl | (int)timing) {
+			const bool one = ctl == 1;
+			const unsigned nreg = one ? 1u : rt.position, dur = timing ? dt : cdur;
+			for(unsigned i = 0; i < nreg; ++i)
+				control(v, K, e, frag, one ? a1 : (unsigned)rt.regs[i], v.waketime, dur);
+			if(one)
+				rt_unmark(rt, a1);
+			else if(!timing)
+				rt.mask = rt.position = 0;
+		}
 		if(!timing)
 			continue;
-		// "timing:", core.c:1719-1733
-		rt_apply(rt, v, K, e, frag, v.waketime, dt);
 		if(v.fault)
 			return v.fault;
 		if(!dt)
@@ -561,6 +572,7 @@ VMFN uint32_t run_batch(A2DVmVoice &v, const uint32_t *code, const Consts &K, E 
 			const uint32_t t = fs + ((uint32_t)s << 8);
 			int res = 0;
 			bool gave_way = false;
+			e.mark(0);
 			for(;;) {
 				const int nextvm = (int)(v.waketime - t);	// a2_TSDiff
 				if(nextvm > 255) {
@@ -582,49 +594,51 @@ VMFN uint32_t run_batch(A2DVmVoice &v, const uint32_t *code, const Consts &K, E 
 					break;
 				}
 			}
-			if(gave_way) {
-				e.drain(f);
-				continue;
-			}
-			if(res > frames - s)
-				res = frames - s;
-			// The units get the window in chain order (core.c:1875-1876).  What the recorder keeps of that:
-			// a running env segment's write through its control wire (env.c:116-134) - into the records
-			// before the window if the target unit comes behind the env in the chain, behind it if the
-			// target has already rendered the window (push_rec, a2amd_sched.cpp) - and a ramping cutoff's
-			// coefficient for the window (the head of f12_process, filter12.c:86-96).
-			int nlate = 0, late_slot[A2D_VM_MAXENV];
-			if(v.nenv | v.ncut)
-				for(int p = 0; p <= A2D_MAXCHAIN; ++p) {
-					for(int k = 0; k < v.nenv && k < A2D_VM_MAXENV; ++k) {
-						A2DVmEnv &en = v.env[k];
-						if(en.k != p || !en.active)
-							continue;
-						env_lut(K, en, res);
-						const bool cutoff = v.kind[(en.target >> 4) & 7] == A2D_FILTER12 && (en.target & 15u) == 0;
-						if((int)(en.target >> 4) >= p || cutoff)	// (a cutoff write is host state, not a record)
-							write_unit(v, K, e, f, en.target, en.out, (unsigned)(base + s), (unsigned)res << 8);
-						else
-							late_slot[nlate++] = k;
-					}
-					for(int k = 0; k < (int)v.ncut && k < A2D_VM_MAXCUT; ++k)
-						if(v.cutpos[k] == p) {
-							rp_prepare(v.cut[k], res);
-							if(v.cut[k][2]) {
-								rp_run(v.cut[k], res);
-								e.rec(f, R_F1RAMP, v.cutpos[k], 0, f1_of_pitch(K, v.cut[k][0] >> 8), 0, 0);
-							}
+			e.mark(1);
+			// (a run that gave way - k_vm_win: the records so far are carried out below, then the run goes on - has not
+			// got to its window yet)
+			if(!gave_way) {
+				if(res > frames - s)
+					res = frames - s;
+				// The units get the window in chain order (core.c:1875-1876).  What the recorder keeps of that:
+				// a running env segment's write through its control wire (env.c:116-134) - into the records
+				// before the window if the target unit comes behind the env in the chain, behind it if the
+				// target has already rendered the window (push_rec, a2amd_sched.cpp) - and a ramping cutoff's
+				// coefficient for the window (the head of f12_process, filter12.c:86-96).
+				int nlate = 0, late_slot[A2D_VM_MAXENV];
+				if(v.nenv | v.ncut)
+					for(int p = 0; p <= A2D_MAXCHAIN; ++p) {
+						for(int k = 0; k < v.nenv && k < A2D_VM_MAXENV; ++k) {
+							A2DVmEnv &en = v.env[k];
+							if(en.k != p || !en.active)
+								continue;
+							env_lut(K, en, res);
+							const bool cutoff = v.kind[(en.target >> 4) & 7] == A2D_FILTER12 && (en.target & 15u) == 0;
+							if((int)(en.target >> 4) >= p || cutoff)	// (a cutoff write is host state, not a record)
+								write_unit(v, K, e, f, en.target, en.out, (unsigned)(base + s), (unsigned)res << 8);
+							else
+								late_slot[nlate++] = k;
 						}
+						for(int k = 0; k < (int)v.ncut && k < A2D_VM_MAXCUT; ++k)
+							if(v.cutpos[k] == p) {
+								rp_prepare(v.cut[k], res);
+								if(v.cut[k][2]) {
+									rp_run(v.cut[k], res);
+									e.rec(f, R_F1RAMP, v.cutpos[k], 0, f1_of_pitch(K, v.cut[k][0] >> 8), 0, 0);
+								}
+							}
+					}
+				// (the fragment's default window - nothing else in it - is no record; an emitter that is the
+				// records' reader as well gets every window)
+				if(E::fused || !(s == 0 && res == frames && e.count() == before && !nlate))
+					e.rec(f, R_SEG, 0, 0, 0, (unsigned)s | ((unsigned)res << 16), 0);
+				for(int k = 0; k < nlate; ++k) {
+					const A2DVmEnv &en = v.env[late_slot[k]];
+					write_unit(v, K, e, f, en.target, en.out, (unsigned)(base + s), (unsigned)res << 8);
 				}
-			// (the fragment's default window - nothing else in it - is no record; an emitter that is the
-			// records' reader as well gets every window)
-			if(E::fused || !(s == 0 && res == frames && e.count() == before && !nlate))
-				e.rec(f, R_SEG, 0, 0, 0, (unsigned)s | ((unsigned)res << 16), 0);
-			for(int k = 0; k < nlate; ++k) {
-				const A2DVmEnv &en = v.env[late_slot[k]];
-				write_unit(v, K, e, f, en.target, en.out, (unsigned)(base + s), (unsigned)res << 8);
+				s += res;
 			}
-			s += res;
+			e.mark(2);
 			e.drain(f);
 		}
 		e.end_fragment(f);
@@ -642,6 +656,7 @@ struct PlainE {
 	VMFN void yield(unsigned) {}
 	VMFN void drain(int) {}
 	VMFN void end_fragment(int) {}
+	VMFN void mark(int) {}		// (measurement builds: where run_batch is)
 };
 
 // What k_vm_win (a2amd_vmwin.hip) takes from the window pool for a voice: one entry per window of a fragment beyond

@@ -34,6 +34,7 @@
 #include <algorithm>
 #include "a2amd_device.h"
 #include "a2amd_vmcore.h"
+#include "a2amd_vmdev.h"
 #include "a2amd_winctl.h"
 
 using namespace a2vm;
@@ -46,8 +47,6 @@ using namespace a2vm;
 #define VMW_GIVEWAY 6
 #define VMW_ROW     (64 - 1 - WIN_EXL)	/* further windows of a fragment beyond the staged ones: a lane's row of wscr */
 
-struct VmwSlot { A2DVmVoice v; Tracker rt; int32_t pad[((sizeof(A2DVmVoice) + sizeof(Tracker)) / 4) % 2 ? 0 : 1]; };
-static_assert((sizeof(VmwSlot) / 4) % 2 == 1, "an odd stride in words");
 
 struct VmwStage {
 	WinStage w;
@@ -75,6 +74,19 @@ struct WinE {
 	// the fragment under way
 	int nwin, nstaged, own;
 	unsigned head0, block;
+#ifdef WIN_PROF
+	long long t_drain = 0, t_meet = 0, t_end = 0, t_mark = 0, t_seg[3] = { 0, 0, 0 };
+	int n_drain = 0, n_recs = 0;
+	DEV void mark(int k)
+	{
+		const long long t = __builtin_readcyclecounter();
+		if(k)
+			t_seg[k] += t - t_mark;
+		t_mark = t;
+	}
+#else
+	VMFN void mark(int) {}
+#endif
 
 	VMFN void rec(int frag, int op, int unit, int reg, int value, unsigned dur, unsigned start)
 	{
@@ -104,6 +116,11 @@ struct WinE {
 		constexpr int SW = WIN_SW(NOSC, FILT);
 		const int sb = (f - fa) & 1;
 		const int m = n < VMW_RING ? n : VMW_RING;
+#ifdef WIN_PROF
+		const long long t0 = __builtin_readcyclecounter();
+		++n_drain;
+		n_recs += m;
+#endif
 		for(int k = 0; k < m; ++k) {
 			const Int4 r = st.ring[k][lane];
 			const int op = (int)A2D_ROP((unsigned)r.x);
@@ -136,12 +153,18 @@ struct WinE {
 						(unsigned)r.z, (unsigned)r.w);
 		}
 		n = 0;
+#ifdef WIN_PROF
+		t_drain += __builtin_readcyclecounter() - t0;
+#endif
 	}
 
 	// the fragment's slot gets its head word, the writer wavefront the fragment
 	DEV void end_fragment(int f)
 	{
 		const int sb = (f - fa) & 1;
+#ifdef WIN_PROF
+		const long long t0 = __builtin_readcyclecounter();
+#endif
 		if(FILT && cv.pending_fresh && f == fb - 1) {
 			head0 |= WH_FRESH;
 			cv.pending_fresh = 0;
@@ -169,7 +192,14 @@ struct WinE {
 		st.w.e0[sb][lane] = block;
 		st.w.nst[sb][lane] = own ? 0 : nstaged;
 		st.own[sb][lane] = own;
+#ifdef WIN_PROF
+		const long long t1 = __builtin_readcyclecounter();
+#endif
 		win_meet();
+#ifdef WIN_PROF
+		t_meet += __builtin_readcyclecounter() - t1;
+		t_end += t1 - t0;
+#endif
 		begin_fragment();
 	}
 };
@@ -256,8 +286,9 @@ void k_vm_win(A2DVmParams vp, int fa, int fb, uint32_t now_fa, uint32_t batch_en
 		const uint32_t *__restrict__ ptab)
 {
 	__shared__ PTab s_ptab;
-	__shared__ VmwSlot s_v[64];
+	__shared__ VmSlot s_v[64];
 	__shared__ VmwStage s_stage;
+	__shared__ uint32_t s_code[VM_CODEWORDS];
 	__shared__ int s_anylive;
 	for(int k = (int)threadIdx.x; k < 128; k += 128)
 		s_ptab[k] = ptab[k];
@@ -266,6 +297,7 @@ void k_vm_win(A2DVmParams vp, int fa, int fb, uint32_t now_fa, uint32_t batch_en
 	constexpr int SW = WIN_SW(NOSC, FILT);
 	bool live = false;
 	int slot = 0;
+	const uint32_t *code = nullptr;
 	if(wave == 0) {
 		// (a lane without a voice of ours leaves an empty slot every fragment: its head words never change)
 		s_stage.w.slot[0][lane * SW + WE_HEAD] = 0;
@@ -287,6 +319,7 @@ void k_vm_win(A2DVmParams vp, int fa, int fb, uint32_t now_fa, uint32_t batch_en
 		const unsigned long long any = __ballot(live);
 		if(lane == 0)
 			s_anylive = any != 0;
+		code = vm_stage_code(vp.code, s_v[lane].v, live, s_code);
 	}
 	__syncthreads();
 	if(wave != 0) {
@@ -309,12 +342,23 @@ void k_vm_win(A2DVmParams vp, int fa, int fb, uint32_t now_fa, uint32_t batch_en
 		for(int o = 0; o <= NOSC + FILT; ++o)
 			cv.uu[o] = vc.unit[o];
 		ctl_load(cv, ustate, vactive, v.voice);
+#ifdef WIN_PROF
+		const long long t_in = __builtin_readcyclecounter();
+#endif
 		const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab, vp.envlut };
 		WinE<NOSC, FILT> e = { cv, v, s_stage, waves, s_ptab, ustate, wext, wscr + (size_t)idx * VMW_ROW * A2D_WIN_WORDS, wtop, wcap,
 				lane, fa, fb, 0, 0, false, 0u, 0, 0, 0, 0u, 0u };
 		const uint8_t *ff = vp.fragframes, *fbs = vp.fragbase;
-		run_batch(v, vp.code + v.code, K, e, now_fa, fa, fb, [ff, fbs](int f) { return (unsigned)ff[f] | ((unsigned)fbs[f] << 8); },
+		run_batch(v, code, K, e, now_fa, fa, fb, [ff, fbs](int f) { return (unsigned)ff[f] | ((unsigned)fbs[f] << 8); },
 				&s_v[lane].rt);
+#ifdef WIN_PROF
+		if(blockIdx.x % 61 == 5 && lane == 7)
+			printf("k_vm_win<%d,%d> block %d lane 7: %d fragments, %lld cycles: %lld in %d drains of %d records, %lld at the end of "
+					"fragments + %lld meeting the writer\n", NOSC, FILT, (int)blockIdx.x, fb - fa,
+					(long long)__builtin_readcyclecounter() - t_in, e.t_drain, e.n_drain, e.n_recs, e.t_end, e.t_meet);
+		if(blockIdx.x % 61 == 5 && lane == 7)
+			printf("    ... %lld in the VM's runs, %lld in the windows' env / cutoff / SEG part\n", e.t_seg[1], e.t_seg[2]);
+#endif
 		ctl_store(cv, ustate, vactive, v.voice);
 		vp.vmv[slot] = v;
 		if(v.fault)
