@@ -87,6 +87,17 @@ typedef struct UPTR
 	A2_unit		*u[3];
 } UPTR;
 
+#define BLKN 256
+#define SUM_STREAK 8
+#define HOLD_MIN 32	/* fragments */
+typedef struct BLK
+{
+	uint32_t	wake;		/* the earliest wake time in the block (timed) */
+	uint32_t	lo, hi;		/* its voices' bytes in the map of context dev: within [lo, hi]; all of that range if
+					 * hi - lo == BLKN - 1, else the bytes LIST.blk_slots names */
+	uint8_t		ok, timed, dev;
+} BLK;
+
 typedef struct LIST
 {
 	A2_voice	**head;		/* the list: &parent->sub (key) */
@@ -109,6 +120,14 @@ typedef struct LIST
 	unsigned	reached;	/* the fragment (a2amd_walkview.frag_serial) in which the walk last passed it asleep */
 	uint32_t	sum_dev, sum_lo, sum_cnt;	/* their bytes in the default map: one range of one context ... */
 	int		sum_range;	/* ... or not (then entry by entry) */
+	/* A list that never sleeps as a whole - a pad's 16 384 voices and ONE sequencer voice in the same group -
+	 * in blocks of BLKN entries: a block whose voices all slept unseen, none of them a group, their bytes one
+	 * range of one context's map, is one test and one memset the next time (while the list is taken from memory
+	 * and none of the block's voices has been handed to the engine). */
+	struct BLK	*blk;
+	unsigned	blk_cap;
+	uint32_t	*blk_slots;	/* [entry]: its byte in the map, for the blocks (blk_cap * BLKN of them) */
+	unsigned	streak;		/* walks in a row in which every voice of the list slept unseen */
 } LIST;
 
 typedef struct WSTATE
@@ -128,7 +147,7 @@ typedef struct WSTATE
 	unsigned	n_held;		/* lists held */
 	uint32_t	*scratch;	/* slots of a list, per context */
 	unsigned	scratch_cap;
-	unsigned long long skipped, unread, visited;
+	unsigned long long skipped, unread, visited, in_blocks, summaries, holds, slow_walks, blocks_made;
 	/* (code, pc) pairs the device VM has turned down for good: not offered again */
 	struct { const unsigned *code; unsigned pc; } vm_no[64];
 	unsigned	vm_no_pos;
@@ -147,7 +166,7 @@ static WSTATE **wstates;
 static unsigned n_wstates, cap_wstates;
 static pthread_mutex_t wmtx = PTHREAD_MUTEX_INITIALIZER;
 static __thread WSTATE *last_ws;
-static int walk_off = -1, walk_stats, walk_cut, walk_nocache, walk_nohold, walk_novm, walk_globalepoch;
+static int walk_off = -1, walk_stats, walk_cut, walk_nocache, walk_nohold, walk_novm, walk_globalepoch, walk_noblocks, walk_nohold_min;
 
 static inline int wstate_closed(const WSTATE *w)
 {
@@ -212,6 +231,8 @@ static WSTATE *wstate_of(A2_state *st)
 				free(w->lists[k]->e);
 				free(w->lists[k]->up);
 				free(w->lists[k]->gidx);
+				free(w->lists[k]->blk);
+				free(w->lists[k]->blk_slots);
 				free(w->lists[k]);
 			}
 		free(w->lists);
@@ -275,6 +296,11 @@ static void report(void)
 					"reading the voice%s); %llu voices handed to the device VM, %llu taken back\n", (void *)wstates[i]->st,
 					wstates[i]->skipped, wstates[i]->visited, wstates[i]->unread,
 					wstates[i]->hooks_broken ? "; HOOKS BROKEN" : "", wstates[i]->adopted, wstates[i]->recalled);
+	for(i = 0; i < n_wstates; ++i)
+		if(wstates[i]->in_blocks || wstates[i]->summaries)
+			fprintf(stderr, "a2amd walk: state %p: %llu of the skipped in blocks of %d, %llu list summaries made, %llu lists held, "
+					"%llu walks voice by voice, %llu block summaries made\n", (void *)wstates[i]->st, wstates[i]->in_blocks, BLKN, wstates[i]->summaries,
+					wstates[i]->holds, wstates[i]->slow_walks, wstates[i]->blocks_made);
 }
 
 static void bind_engine(void)
@@ -309,6 +335,8 @@ static void bind_engine(void)
 	walk_globalepoch = getenv("A2AMD_WALK_GLOBALEPOCH") != NULL;	/* (A/B: rounds 3-4's one epoch per state) */
 	/* A/B: sleeping lists are marked fragment by fragment instead of being put on hold */
 	walk_nohold = getenv("A2AMD_WALK_NOHOLD") != NULL;
+	walk_noblocks = getenv("A2AMD_WALK_NOBLOCKS") != NULL;
+	walk_nohold_min = walk_noblocks;	/* (A/B: every voice of a list that does not sleep as a whole, one by one) */
 	/* test hook: voices are handed to the engine's loop run by run even in a state the drop-in
 	 * does not serve (the engine's own CPU units): exercises the cut / relink / voice death
 	 * logic without a GPU; no visit is ever skipped there */
@@ -593,6 +621,7 @@ static int hold_list(WSTATE *w, LIST *sl, int on)
 	{
 		sl->held_gen = w->hold_gen;
 		++w->n_held;
+		++w->holds;
 	}
 	else if(sl->held_gen == w->hold_gen)
 	{
@@ -603,11 +632,14 @@ static int hold_list(WSTATE *w, LIST *sl, int on)
 }
 
 /* the default window for every voice of a sleeping list (list_sleeps) and of the lists below it */
-static void mark_list(WSTATE *w, LIST *sl)
+static void mark_list(WSTATE *w, LIST *sl, unsigned now)
 {
 	unsigned k, g;
 	sl->reached = *w->view.frag_serial;
-	if(sl->held_gen != w->hold_gen && hold_list(w, sl, 1))
+	/* (a hold is made and released voice by voice: for a list that will wake within HOLD_MIN fragments - a pad
+	 * with a sequencer voice in its group - the map's bytes, one memset per fragment, are the cheaper way) */
+	if(sl->held_gen != w->hold_gen && ((sl->sum_timed && sl->sum_range && !walk_nohold_min &&
+			(a2_TSDiff(sl->sum_wake, now) >> 8) < HOLD_MIN * A2_MAXFRAG) || hold_list(w, sl, 1)))
 	{
 		/* (no hold to be had: fragment by fragment, then) */
 		if(sl->sum_range)
@@ -623,16 +655,16 @@ static void mark_list(WSTATE *w, LIST *sl)
 			mark_default(w, &sl->e[sl->gidx[g]]);
 	}
 	for(g = 0; g < sl->ng; ++g)
-		mark_list(w, sl->e[sl->gidx[g]].sub);
+		mark_list(w, sl->e[sl->gidx[g]].sub, now);
 }
 
 /* ... for one voice that sleeps unseen (entry_sleeps), its subvoices included */
-static inline void mark_entry(WSTATE *w, const ENT *e)
+static inline void mark_entry(WSTATE *w, const ENT *e, unsigned now)
 {
 	mark_default(w, e);
 	if(e->flags & E_GROUP)
 	{
-		mark_list(w, e->sub);
+		mark_list(w, e->sub, now);
 		w->skipped += e->sub->sum_voices;
 		w->unread += e->sub->sum_voices;
 	}
@@ -774,6 +806,9 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 	LIST *l;
 	unsigned k = 0, now;
 	int deflt, cached, all_unread;
+	unsigned acc_at = 0;		/* the block summary under way (BLK) */
+	int acc_ok = 0, acc_timed = 0, acc_best = 0;
+	uint32_t acc_lo = 0, acc_hi = 0, acc_dev = 0, acc_wake = 0;
 	if(walk_off < 0)
 		bind_engine();
 	if(!engine_walk)
@@ -791,15 +826,35 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 	l->quiet_visit = 0;
 	if(cached && deflt && list_sleeps(w, l, now, frames))
 	{
-		mark_list(w, l);
+		mark_list(w, l, now);
 		w->skipped += l->sum_voices;
 		w->unread += l->sum_voices;
 		return;
 	}
+	if(!cached)
+		++w->slow_walks;
 	/* voice by voice, then: none of them stays on hold */
 	if(l->held_gen == w->hold_gen && w->hold_gen)
 		hold_list(w, l, 0);
 	all_unread = cached && deflt;
+	/* the blocks' summaries hold while the list is taken from memory */
+	if(!(cached && deflt) && l->blk)
+		memset(l->blk, 0, l->blk_cap * sizeof(BLK));
+	if(cached && deflt && !walk_noblocks && l->n >= 2 * BLKN && l->blk_cap < l->n / BLKN)
+	{
+		BLK *nb = (BLK *)realloc(l->blk, (l->n / BLKN + 16) * sizeof(BLK));
+		uint32_t *ns = nb ? (uint32_t *)realloc(l->blk_slots, (size_t)(l->n / BLKN + 16) * BLKN * sizeof(uint32_t)) : NULL;
+		if(nb)
+			l->blk = nb;
+		if(ns)
+			l->blk_slots = ns;
+		if(nb && ns)
+		{
+			memset(nb + l->blk_cap, 0, (l->n / BLKN + 16 - l->blk_cap) * sizeof(BLK));
+			l->blk = nb;
+			l->blk_cap = l->n / BLKN + 16;
+		}
+	}
 	for(;;)
 	{
 		A2_voice *v, *last, *rest, *p;
@@ -809,14 +864,85 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 		{
 			if(k >= l->n)
 				break;
+			if(deflt && !(k % BLKN) && k / BLKN < l->blk_cap && k + BLKN <= l->n)
+			{
+				const BLK *b = &l->blk[k / BLKN];
+				if(b->ok && !(b->timed && (a2_TSDiff(b->wake, now) >> 8) < (int)frames) &&
+						b->hi < w->view.map_cap[b->dev])
+				{
+					uint8_t *const map = w->view.map[b->dev];
+					if(b->hi - b->lo == BLKN - 1)
+						memset(map + b->lo, 1, BLKN);
+					else
+					{
+						const uint32_t *sl = l->blk_slots + k;
+						unsigned q;
+						for(q = 0; q < BLKN; ++q)
+							map[sl[q]] = 1;
+					}
+					k += BLKN;
+					w->skipped += BLKN;
+					w->unread += BLKN;
+					w->in_blocks += BLKN;
+					continue;
+				}
+				/* (a new summary of this block is under way: every voice of it that sleeps unseen adds to it) */
+				acc_at = k;
+				acc_ok = 1;
+				acc_timed = 0;
+				acc_best = 0x7fffffff;
+				acc_lo = 0xffffffffu;
+				acc_hi = 0;
+				acc_dev = 0xffffffffu;
+			}
 			if(entry_sleeps_unread(w, &l->e[k], now, frames, deflt))
 			{
-				mark_entry(w, &l->e[k]);
+				const ENT *e = &l->e[k];
+				mark_entry(w, e, now);
+				if(acc_ok && k - acc_at < BLKN)
+				{
+					const uint32_t slot = e->slotdev & 0x0fffffffu, dev = e->slotdev >> 28;
+					if((e->flags & E_GROUP) || e->stamp == STAMP_NOUNITS || (acc_dev != 0xffffffffu && dev != acc_dev))
+						acc_ok = 0;
+					else
+					{
+						int d;
+						acc_dev = dev;
+						l->blk_slots[k] = slot;
+						if(slot < acc_lo)
+							acc_lo = slot;
+						if(slot > acc_hi)
+							acc_hi = slot;
+						if(!(e->flags & E_VM) || (e->flags & E_VMEXIT))
+						{
+							const uint32_t t = (e->flags & E_VM) ? e->vm_exit : e->wake;
+							d = a2_TSDiff(t, now);
+							acc_timed = 1;
+							if(d < acc_best)
+							{
+								acc_best = d;
+								acc_wake = t;
+							}
+						}
+						if(k - acc_at == BLKN - 1 && acc_at / BLKN < l->blk_cap)
+						{
+							++w->blocks_made;
+							BLK *b = &l->blk[acc_at / BLKN];
+							b->wake = acc_wake;
+							b->timed = (uint8_t)acc_timed;
+							b->lo = acc_lo;
+							b->hi = acc_hi;
+							b->dev = (uint8_t)acc_dev;
+							b->ok = 1;
+						}
+					}
+				}
 				++k;
 				++w->skipped;
 				++w->unread;
 				continue;
 			}
+			acc_ok = 0;
 			/* (head: the link that points at this voice - an address, not a load) */
 			v = l->e[k].v;
 			if(k)
@@ -832,7 +958,7 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 				realign(l, k, v);
 			if(voice_sleeps(w, l, k, v, now, frames, deflt))
 			{
-				mark_entry(w, &l->e[k]);
+				mark_entry(w, &l->e[k], now);
 				head = &v->next;
 				++k;
 				++w->skipped;
@@ -851,6 +977,7 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 		 * voices behind it that need a visit as well - cut out of the list for the call */
 		all_unread = 0;
 		l->sum_ok = 0;
+		acc_ok = 0;
 		last = v;
 		if(k < l->n && l->e[k].v == v)
 			hint_visit(v, &l->up[k]);
@@ -879,6 +1006,8 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 				if(sl)
 					sl->quiet_visit = w->visits + 1;
 			}
+		for(kk = k / BLKN; kk < l->blk_cap && kk <= (k + run) / BLKN; ++kk)
+			l->blk[kk].ok = 0;	/* (what is remembered of these voices is about to change) */
 		recall_run(w, l, k, v, run);
 		rest = last->next;
 		last->next = NULL;
@@ -894,7 +1023,11 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 		w->cur_visit = visit0;
 		w->visited += run;
 		if(w->epoch != epoch0 || l->epoch != w->epoch)
+		{
 			cached = 0;		/* voices were born or died in THIS list: the rest of it is read */
+			if(l->blk)		/* (... and what stands where in it may move) */
+				memset(l->blk, 0, l->blk_cap * sizeof(BLK));
+		}
 		/* what is left of them (voices that ended were freed: a2_VoiceFree, core.c:1892) goes back in
 		 * front of the rest; and what to do with each while it sleeps */
 		for(p = *head; p; p = p->next)
@@ -962,6 +1095,12 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 		}
 		*head = rest;
 	}
+	/* (a long list taken in blocks costs a few dozen tests per walk; its summary - every entry read - is worth making
+	 * once it has slept through SUM_STREAK walks in a row, not every time a sequencer voice in it dozes off) */
+	if(!(cached && all_unread))
+		l->streak = 0;
+	else if(l->blk && l->n >= 2 * BLKN && ++l->streak < SUM_STREAK)
+		return;
 	if(cached && all_unread && l->n)
 	{
 		/* every voice of the list slept, unseen: next time one test will do (until a voice of the
@@ -1045,6 +1184,7 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 		l->sum_cnt = l->sum_range ? cnt : 0;
 		l->sum_epoch = w->epoch;
 		l->sum_ok = 1;
+		++w->summaries;
 	}
 	if(!cached)
 	{

@@ -194,6 +194,25 @@ def test_device_vm_voices_through_records_are_the_same_audio(tmp_path, script, a
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("blocks", [True, False])
+@pytest.mark.parametrize("buffer", [64, 1000])
+def test_births_and_deaths_beside_a_thousand_sleeping_voices(tmp_path, buffer, blocks):
+    """tests/a2s/bench.a2s OscFilterPanChurn (the bench line's "churn" cell at 1 024 voices): a pad's voices and ONE
+    sequencer voice in the same group - 200 births and deaths per second in the sequencer's own list.  The pad's list
+    never sleeps as a whole (the sequencer stands in it); the walk takes it in blocks of 256 voices that slept unseen
+    (a2amd_walk.c BLK; A2AMD_WALK_NOBLOCKS=1: voice by voice).  1.5 s against the CPU engine, sample for sample."""
+    need_ref()
+    frames = 72000 // buffer * buffer
+    cpu, _, _ = render(tmp_path, "cpu", "bench", "OscFilterPanChurn", frames, buffer, ["256", "0.002"])
+    vm, stats, err = render(tmp_path, "vm", "bench", "OscFilterPanChurn", frames, buffer, ["256", "0.002"],
+                            preload=f"{WALK_SO} {UNITS_SO}", env_extra={} if blocks else {"A2AMD_WALK_NOBLOCKS": "1"})
+    assert cpu.any()
+    assert first_difference(cpu, vm, 2, buffer) is None, first_difference(cpu, vm, 2, buffer)
+    m = re.search(r"(\d+) voice visits skipped, (\d+) made", err)
+    assert m and int(m.group(1)) > 50 * int(m.group(2)), err[-400:]
+
+
+@pytest.mark.gpu
 def test_song_notes_are_taken_by_the_device_vm(tmp_path):
     """tests/a2s/song.a2s (the plumbing-sized workload): its melodic notes and the kick - programs that run out - are
     the device VM's between their first delay and their last VM run; hats and snares stay the engine's (their noise

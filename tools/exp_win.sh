@@ -1,6 +1,7 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp
-pre="$R/build_variants/liba2amd_prof.so $R/audiality2_amd/liba2amd_walk.so $R/audiality2_amd/liba2amd_units.so"
-for prog in OscPanScripted; do
-  LD_PRELOAD="$pre" A2REF_BUFFER=4096 $R/oracle/_ref/ref_bench $R/tests/a2s/bench.a2s $prog 16384 1024 1 2>&1 | grep -A1 "k_vm_win" | tail -8 | cut -c1-300
+pre="$R/audiality2_amd/liba2amd_walk.so $R/audiality2_amd/liba2amd_units.so"
+for buf in 4096 64; do
+LD_PRELOAD="$pre" A2REF_BUFFER=$buf A2AMD_WALK_STATS=1 A2AMD_HOSTTIMING=1 $R/oracle/_ref/ref_bench $R/tests/a2s/bench.a2s OscFilterPanChurn 16384 8192 1 2>&1 | grep -v "uploads by" | tail -5 | cut -c1-400
 done
+cd $R && timeout 1500 python -m pytest tests/test_device_vm.py tests/test_dropin.py -m gpu -x -q 2>&1 | tail -3

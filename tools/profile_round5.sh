@@ -47,5 +47,25 @@ timeout 300 python tools/scripted_timing.py --chain osc-pan --voices 16384 --bat
 # 4. the song (BASELINE configs[0]'s command shape), with and without the walk + device VM
 timeout 900 python tests/measure/song_timing.py --seconds 500 2>&1 | tail -2 > $OUT/song_timing.jsonl
 A2AMD_SPLIT=0 timeout 900 python tests/measure/song_timing.py --seconds 500 2>&1 | tail -2 | sed 's/^{/{"env": "A2AMD_SPLIT=0", /' >> $OUT/song_timing.jsonl
+
+# 5. the scripted engine cells (BASELINE variants 2b / 3b: unmodified engine + walk + drop-in units, a2_Run(4096)) with the
+#    device VM's voices through k_vm_win and through records (A2AMD_VMWIN=0), each with its kernel trace
+pre="$REPO/audiality2_amd/liba2amd_walk.so $REPO/audiality2_amd/liba2amd_units.so"
+: > $OUT/engine_cells_vmwin_ab.txt
+cd /tmp
+for vw in 1 0; do
+  for prog in OscPanScripted OscFilterPanScripted; do
+    echo "== $prog, 16 384 voices, a2_Run(4096), A2AMD_VMWIN=$vw" >> $OUT/engine_cells_vmwin_ab.txt
+    LD_PRELOAD="$pre" A2AMD_VMWIN=$vw A2REF_BUFFER=4096 A2AMD_HOSTTIMING=1 $REPO/oracle/_ref/ref_bench $REPO/tests/a2s/bench.a2s $prog 16384 8192 1 2>&1 |
+        grep -v "uploads by first" | tail -4 >> $OUT/engine_cells_vmwin_ab.txt
+    rm -rf /tmp/prof_e; LD_PRELOAD="$pre" A2AMD_VMWIN=$vw A2REF_BUFFER=4096 rocprofv3 --kernel-trace -d /tmp/prof_e -o p -- \
+        $REPO/oracle/_ref/ref_bench $REPO/tests/a2s/bench.a2s $prog 16384 8192 1 > /dev/null 2>&1
+    python $REPO/tools/rocpd_kernels.py /tmp/prof_e "$prog vmwin=$vw" >> $OUT/engine_cells_vmwin_ab.txt
+  done
+done
+
+# 6. the N > 1 bench path on one rank (what the driver's 2 / 4 / 8 GPU runs execute, minus the other ranks)
+cd /tmp
+A2AMD_BENCH_FORCE_DIST=1 $B --no-cpu-baseline > $OUT/bench_n_gt_1_path_one_rank.json 2> $OUT/bench_n_gt_1.err
 ls -la $OUT
 cat $OUT/bench_default.json | cut -c1-3000
