@@ -135,7 +135,7 @@ typedef struct HOSTSTATE
 	/* ... and in the state that asked for the wave: captures waiting for the engine thread to build the wave's
 	 * device copy from them, at the wave's first use (a2_RenderWave may be called from the API thread of a
 	 * realtime state: the backend context belongs to the engine thread) */
-	struct PENDCAP { A2P_wave *w; a2amd_capture *cap; } *pendcaps;
+	struct PENDCAP { A2P_wave *w; int handle; a2amd_capture *cap; } *pendcaps;	/* (handle: the wave's, by which w is looked up again before it is trusted) */
 	int		npendcaps, cap_pendcaps;
 	pthread_mutex_t	pendcaps_mtx;
 	int		pendcaps_mtx_ok;
@@ -775,7 +775,9 @@ static void sweep_waves(HOSTSTATE *hs)
 		/* a rendered wave that was released before anybody played it: its capture goes with it */
 		pthread_mutex_lock(&hs->pendcaps_mtx);
 		for(i = 0; i < hs->npendcaps; )
-			if(!hs->pendcaps[i].w->size[0])
+			/* (by handle, not through the remembered pointer: a state that sat out the cycle in which the released
+			 * wave lingered would read freed memory - and find a later wave at the same address) */
+			if(a2_GetWave(hs->cfg->interface, hs->pendcaps[i].handle) != hs->pendcaps[i].w || !hs->pendcaps[i].w->size[0])
 			{
 				a2amd_capture_free(hs->pendcaps[i].cap);
 				hs->pendcaps[i] = hs->pendcaps[--hs->npendcaps];
@@ -1782,7 +1784,7 @@ static int wave_id_of(HOSTSTATE *hs, int dev, A2P_wave *w)
 		a2amd_capture *cap = NULL;
 		pthread_mutex_lock(&hs->pendcaps_mtx);
 		for(i = 0; i < hs->npendcaps; ++i)
-			if(hs->pendcaps[i].w == w)
+			if(hs->pendcaps[i].w == w && a2_GetWave(hs->cfg->interface, hs->pendcaps[i].handle) == w)
 			{
 				cap = hs->pendcaps[i].cap;
 				hs->pendcaps[i] = hs->pendcaps[--hs->npendcaps];
@@ -2845,6 +2847,7 @@ int a2_RenderWave(void *iface, int wt, unsigned period, int flags, unsigned samp
 			if(hs->npendcaps < hs->cap_pendcaps)
 			{
 				hs->pendcaps[hs->npendcaps].w = w;
+				hs->pendcaps[hs->npendcaps].handle = wh;
 				hs->pendcaps[hs->npendcaps++].cap = rc.cap;
 				kept = 1;
 			}

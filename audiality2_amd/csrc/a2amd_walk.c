@@ -148,8 +148,9 @@ typedef struct WSTATE
 	uint32_t	*scratch;	/* slots of a list, per context */
 	unsigned	scratch_cap;
 	unsigned long long skipped, unread, visited, in_blocks, summaries, holds, slow_walks, blocks_made;
-	/* (code, pc) pairs the device VM has turned down for good: not offered again */
-	struct { const unsigned *code; unsigned pc; } vm_no[64];
+	/* (code, pc) pairs the device VM has turned down for good: not offered again.  (The text's size and a sum of its
+	 * words go with the address: a program compiled later may stand where a released one stood.) */
+	struct { const unsigned *code; unsigned pc, size, sum; } vm_no[64];
 	unsigned	vm_no_pos;
 	unsigned long long adopted, recalled;
 } WSTATE;
@@ -768,6 +769,14 @@ static void recall_run(WSTATE *w, LIST *l, unsigned k, A2_voice *v, unsigned run
  * here on?  A leaf voice waiting in a delay, no events, no call stack, nobody outside the tree who
  * could send it anything (no API handle) - and a program that a2amd_vm_analyze() can prove to stay
  * inside the subset from p->s.pc on.  Returns 1 when the voice was handed over. */
+static unsigned text_sum(const unsigned *code, unsigned size)
+{
+	unsigned k, h = 2166136261u;
+	for(k = 0; k < size; ++k)
+		h = (h ^ code[k]) * 16777619u;
+	return h;
+}
+
 static int offer_to_vm(WSTATE *w, A2_state *st, A2_voice *p, int *has_exit, uint32_t *exit_when)
 {
 	void *wr_unit[A2_REGISTERS], *wr_fn[A2_REGISTERS];
@@ -780,8 +789,12 @@ static int offer_to_vm(WSTATE *w, A2_state *st, A2_voice *p, int *has_exit, uint
 		return 0;
 	fn = &p->program->funcs[p->s.func];
 	for(r = 0; r < 64; ++r)
-		if(w->vm_no[r].code == fn->code && w->vm_no[r].pc == p->s.pc)
-			return 0;
+		if(w->vm_no[r].code == fn->code && w->vm_no[r].pc == p->s.pc && w->vm_no[r].size == fn->size)
+		{
+			if(w->vm_no[r].sum == text_sum(fn->code, fn->size))
+				return 0;
+			w->vm_no[r].code = NULL;	/* (another program at that address) */
+		}
 	for(r = 0; r < A2_REGISTERS; ++r)
 	{
 		wr_unit[r] = r < p->ncregs ? (void *)p->cregs[r].unit : NULL;
@@ -792,6 +805,8 @@ static int offer_to_vm(WSTATE *w, A2_state *st, A2_voice *p, int *has_exit, uint
 	if(rc == -1)
 	{
 		w->vm_no[w->vm_no_pos & 63].code = fn->code;
+		w->vm_no[w->vm_no_pos & 63].size = fn->size;
+		w->vm_no[w->vm_no_pos & 63].sum = text_sum(fn->code, fn->size);
 		w->vm_no[w->vm_no_pos++ & 63].pc = p->s.pc;
 	}
 	if(!rc)
