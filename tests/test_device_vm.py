@@ -416,7 +416,7 @@ def env_tables():
     return (ctypes.c_uint16 * (8 * 66))(*[v for row in t for v in row])
 
 
-def replay_trace(d, with_exit=False):
+def replay_trace(d, with_exit=False, layout=None):
     """One fixture of tests/golden/vm_traces.json.xz through the host copy of the interpreter: (records it made, the
     reference's events in the same form, the VM state at the end, (has_exit, exit_when, writes of the stay), frames per
     backend fragment)."""
@@ -459,6 +459,9 @@ def replay_trace(d, with_exit=False):
         else:
             pending.append(e)
     assert not pending and sum(frames) == 64 * d["fragments"]
+    if layout is not None:      # (other fragments over the same stretch of time: only the records are of interest then)
+        assert sum(layout) == sum(frames)
+        frames, base = list(layout), [0] * len(layout)
     nfr = len(frames)
     ff = (ctypes.c_uint8 * nfr)(*frames)
     fb = (ctypes.c_uint8 * nfr)(*base)
@@ -474,6 +477,12 @@ def replay_trace(d, with_exit=False):
     else:
         k = L.a2amd_vm_trace_host_env(*args)
     assert 0 < k < cap, k
+    if layout is not None:
+        segs = [0] * nfr
+        for i in range(k):
+            if (recs[4 * i] >> 16) & 0xff == R_SEG:
+                segs[recs[4 * i] & 0xffff] += 1
+        return segs
     got = []
     for i in range(k):
         head, value, dur, start = recs[4 * i], ctypes.c_int32(recs[4 * i + 1]).value, recs[4 * i + 2], recs[4 * i + 3]
@@ -512,6 +521,45 @@ def replay_trace(d, with_exit=False):
             value = (abs(v8) // d["samplerate"]) * (1 if v8 >= 0 else -1) if reg == 0 else max(256, (value << 8) & 0xffffffff)
         want.append((frag, "w", bpos[pos], reg, value, dur, start & 255))
     return got, want, st, (has_exit.value, exit_when.value, stay.value), frames
+
+
+@pytest.mark.parametrize("case", [0, 3, 7, 11, 14, 19, 24, 27])
+def test_windows_inside_fragments_are_bounded_by_their_count_over_uncut_fragments(case):
+    """What k_vm_pool's prediction rests on (a2amd_vm.hip): a window of a voice begins inside a fragment only
+    where its VM wakes up, so the number of such windows over a stretch of time cut into 64-frame fragments bounds the
+    number over the same stretch in any fragments that are those or pieces of them (the engine cuts a fragment where a
+    group's VM wakes up).  The host copy of the interpreter over the trace fixtures' programs, 300 fragments, uncut
+    against random cuts: a fragment's further windows = its R_SEG records - 1 (a fragment with one window has none)."""
+    d = load_vm_traces()[case]
+    nfr = min(d["fragments"], 300)
+    d = dict(d, fragments=nfr, events=[e for e in d["events"]])
+    # (the fixture's own fragments up to nfr engine fragments: replay_trace checks their sum)
+    total, keep = 0, []
+    for e in d["events"]:
+        keep.append(e)
+        if e[0] == "r":
+            total += e[3]
+            if total == 64 * nfr:
+                break
+    d["events"] = keep
+    uncut = replay_trace(d, with_exit=case >= 23, layout=[64] * nfr)
+    bound = sum(max(0, n - 1) for n in uncut)
+    assert bound > 0
+    rng = np.random.default_rng(case)
+    for _ in range(6):
+        lay = []
+        for _f in range(nfr):
+            if rng.random() < 0.4:
+                c = int(rng.integers(1, 64))
+                lay += [c, 64 - c] if rng.random() < 0.7 else [c // 2 or 1, c - (c // 2 or 1) or 1, 64 - c][:3]
+            else:
+                lay.append(64)
+        lay = [x for x in lay if x > 0]
+        # (repair the rare piece arithmetic that does not add up to whole fragments)
+        if sum(lay) != 64 * nfr:
+            continue
+        segs = replay_trace(d, with_exit=case >= 23, layout=lay)
+        assert sum(max(0, n - 1) for n in segs) <= bound, (sum(max(0, n - 1) for n in segs), bound)
 
 
 @pytest.mark.parametrize("case", range(23))
