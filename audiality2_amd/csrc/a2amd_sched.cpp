@@ -482,11 +482,31 @@ int upload(a2amd_ctx *c)
 		now.resize(c->with_recs.size());
 	}
 	size_t nsc_used = 0, nnow = 0;
+	static const bool keep_bus_windows = getenv("A2AMD_BUS_WINDOWS") != nullptr;	// (A/B: round 4's routing)
 	for(int vi : c->with_recs) {
 		HVoice &v = c->voices[vi];
 		if(v.recs.empty()) {
 			v.listed_recs = false;
 			continue;
+		}
+		// A group voice with the stateless chain inline -> panmix -> xinsert whose records are windows only - its own VM
+		// woke inside a fragment (a sequencer that spawns notes), or its parent's did - and whose volume and pan are at
+		// rest: the windows change nothing (a2_PrepareRamper with no ramp under way sets the same gains for every window,
+		// a2_dsp.h:128-133; inline, panmix and xinsert keep no state from frame to frame), so it stays with the bus
+		// kernel of its depth instead of going to the general kernel - one wavefront that is as long as the batch.
+		if(!keep_bus_windows && v.inline_pos >= 0 && v.vm < 0 && v.moving_until <= c->vm.batch_time && !(c->no_fast & 4) &&
+				v.resolved && is_driver_chain(c, v)) {
+			bool only_windows = true;
+			for(const A2DRec &r : v.recs)
+				if(A2D_ROP(r.head) != R_SEG) {
+					only_windows = false;
+					break;
+				}
+			if(only_windows) {
+				v.recs.clear();
+				v.listed_recs = false;
+				continue;
+			}
 		}
 		A2DRun r = { (int)recs.size(), (int)v.recs.size() };
 		recs.insert(recs.end(), v.recs.begin(), v.recs.end());
@@ -606,10 +626,17 @@ int upload(a2amd_ctx *c)
 			}
 		}
 		auto by_bus = [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; };
-		std::stable_sort(fast_leaf.begin(), fast_leaf.end(), by_bus);
-		std::stable_sort(gen_leaf.begin(), gen_leaf.end(), by_bus);
-		std::stable_sort(filt_leaf.begin(), filt_leaf.end(), by_bus);
-		std::stable_sort(osc2_leaf.begin(), osc2_leaf.end(), by_bus);
+		// (slots follow the order of birth, births the walk: a class is usually grouped by bus already - one pass
+		// says so, where a sort of 16 384 voices by a key two loads away was most of a rebuild; a scene with a note
+		// born or ended in most batches rebuilds in most batches)
+		auto sort_by_bus = [&](std::vector<int> &l) {
+			if(!std::is_sorted(l.begin(), l.end(), by_bus))
+				std::stable_sort(l.begin(), l.end(), by_bus);
+		};
+		sort_by_bus(fast_leaf);
+		sort_by_bus(gen_leaf);
+		sort_by_bus(filt_leaf);
+		sort_by_bus(osc2_leaf);
 		c->list_all = fast_leaf;
 		c->n_fast_leaf = (int)fast_leaf.size();
 		c->list_all.insert(c->list_all.end(), osc2_leaf.begin(), osc2_leaf.end());
@@ -631,7 +658,7 @@ int upload(a2amd_ctx *c)
 		}
 		c->list_all.insert(c->list_all.end(), gen_leaf.begin(), gen_leaf.end());
 		c->n_leaf = (int)gen_leaf.size();
-		std::stable_sort(o2f_leaf.begin(), o2f_leaf.end(), by_bus);
+		sort_by_bus(o2f_leaf);
 		c->list_all.insert(c->list_all.end(), o2f_leaf.begin(), o2f_leaf.end());
 		c->n_o2f_leaf = (int)o2f_leaf.size();
 		c->depth_ranges.assign(maxdepth + 1, DepthRange());

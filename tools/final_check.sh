@@ -2,7 +2,7 @@
 # last check of a round on the GPU box: the whole GPU suite, smoke(), then the reference's songs replayed (soak_long/)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -12 > gpurun_out/gpu_suite.txt
+timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -12 > gpurun_out/gpu_suite.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 >> gpurun_out/gpu_suite.txt
 cat gpurun_out/gpu_suite.txt
 if [ -d soak_long ]; then
