@@ -766,6 +766,7 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 					c->lists_dirty = true;
 				if(!was || !is)
 					c->voices[u.voice].mode_mix = true;
+				c->voices[u.voice].cls_stale = true;
 				c->voices[u.voice].plain = 0;
 			}
 			if(u.mode == A2D_OSC_NOISE && nmode != A2D_OSC_NOISE)
@@ -830,8 +831,10 @@ int a2amd_unit_write(a2amd_ctx *c, int ui, int reg, int value, unsigned start, u
 			const int frames = (int)((int64_t)value * c->cfg.samplerate / 65536000);
 			// (a tap that stops or starts being at least a fragment long moves the
 			// voice between the frame-parallel delay kernel and the general one)
-			if(fbd_tap_ok(frames) != fbd_tap_ok(u.fbd_taps[reg]))
+			if(fbd_tap_ok(frames) != fbd_tap_ok(u.fbd_taps[reg])) {
 				c->lists_dirty = true;
+				c->voices[u.voice].cls_stale = true;
+			}
 			u.fbd_taps[reg] = frames;
 		}
 		break;
@@ -1389,6 +1392,7 @@ int a2amd_unit_clients(a2amd_ctx *c, int ui, unsigned mode)
 	c->n_clients += (int)(mode != 0) - (int)(u.xio_mode != 0);
 	u.xio_mode = mode;
 	c->lists_dirty = true;		// a driver chain with clients is served by the general kernel
+	c->voices[u.voice].cls_stale = true;
 	return A2AMD_OK;
 }
 

@@ -171,6 +171,7 @@ struct HVoice {
 					// the window (a2amd_voice_process takes its short path), 2 not so
 	bool fancy_recs = false;	// this batch's records hold something k_leaf_recs does not execute
 	bool mode_mix = false;		// an oscillator played something else than a mip-mapped wave at some
+	bool cls_stale = true;	// what the launch class is made of has changed since upload() last classified the voice (or it never has)
 					// point of the batch being recorded (its records go to the general kernel)
 	int nunits = 0;
 	int win_off = -1, win_frames = 0;

@@ -164,6 +164,7 @@ void resolve_out(a2amd_ctx *c, HVoice &v)
 		}
 	}
 	v.resolved = true;
+	v.cls_stale = true;
 	c->voices_dirty = true;
 	c->dirty_voices.push_back((int)(&v - c->voices.data()));
 	c->lists_dirty = true;
@@ -586,6 +587,7 @@ int upload(a2amd_ctx *c)
 	// The fast kernels skip a voice whose runs[] entry is non-zero; those voices
 	// form the dynamic part (this batch's exceptions) and go to the general kernel.
 	if(c->lists_dirty) {
+		static const bool cls_check = getenv("A2AMD_CLS_CHECK") != nullptr;
 		bool owners_ok = !getenv("A2AMD_NO_SELFCLEAN"), root_driver = false;
 		std::vector<int> fast_leaf, osc2_leaf, filt_leaf, fm_leaf, gen_leaf, o2f_leaf;
 		std::map<int, std::pair<std::vector<int>, std::vector<int>>> bydepth;
@@ -599,10 +601,17 @@ int upload(a2amd_ctx *c)
 				v.cls = -1;
 				continue;
 			}
+			// (what a voice's class is made of - its units' kinds, wiring and modes, its place in the tree, clients on its
+			// xinsert, delay taps, mode_mix - changes at a handful of places, each of which says so: cls_stale.  A rebuild -
+			// one per batch in which a note is born or ends - classifies only those voices; A2AMD_CLS_CHECK=1, the test
+			// suite's setting, classifies all and fails if a remembered class is not what comes out)
+			const bool classify = v.cls_stale || v.cls < 0 || cls_check;
+			const int was_cls = v.cls;
 			if(v.inline_pos >= 0) {
 				auto &d = bydepth[v.depth];
-				v.cls = !(c->no_fast & 4) && is_driver_chain(c, v) ? CLS_BUSDRIVER :
-						!(c->no_fast & 32) && v.depth > 0 && is_fbdchain(c, v) ? CLS_FBDCHAIN : CLS_BUSGENERIC;
+				if(classify)
+					v.cls = !(c->no_fast & 4) && is_driver_chain(c, v) ? CLS_BUSDRIVER :
+							!(c->no_fast & 32) && v.depth > 0 && is_fbdchain(c, v) ? CLS_FBDCHAIN : CLS_BUSGENERIC;
 				// (the master bus at offset 0 is the root's alone)
 				if(v.cls == CLS_BUSGENERIC || (v.out_off == 0) != (v.depth == 0))
 					owners_ok = false;
@@ -611,19 +620,24 @@ int upload(a2amd_ctx *c)
 				(v.cls == CLS_BUSDRIVER ? d.first : v.cls == CLS_FBDCHAIN ? fbd_bydepth[v.depth] : d.second).push_back((int)vi);
 				maxdepth = std::max(maxdepth, v.depth);
 			} else {
-				v.cls = !(c->no_fast & 1) && is_oscpan_chain(c, v) ? CLS_OSCPAN :
-						!(c->no_fast & 8) && is_osc2pan_chain(c, v) ? CLS_OSC2PAN :
-						!(c->no_fast & 2) && is_oscfiltpan_chain(c, v) ? CLS_OSCFILTPAN :
-						// (no quiet kernel of its own: k_leaf_recs renders it, records or not - unless an
-						// oscillator leaves the mip-mapped waves somewhere in this batch)
-						!(c->no_fast & 128) && !v.mode_mix && is_osc2filtpan_chain(c, v) ? CLS_OSC2FILTPAN :
-						!(c->no_fast & 16) && is_fmpan_chain(c, v) ? CLS_FMPAN : CLS_GENERIC;
+				if(classify)
+					v.cls = !(c->no_fast & 1) && is_oscpan_chain(c, v) ? CLS_OSCPAN :
+							!(c->no_fast & 8) && is_osc2pan_chain(c, v) ? CLS_OSC2PAN :
+							!(c->no_fast & 2) && is_oscfiltpan_chain(c, v) ? CLS_OSCFILTPAN :
+							// (no quiet kernel of its own: k_leaf_recs renders it, records or not - unless an
+							// oscillator leaves the mip-mapped waves somewhere in this batch)
+							!(c->no_fast & 128) && !v.mode_mix && is_osc2filtpan_chain(c, v) ? CLS_OSC2FILTPAN :
+							!(c->no_fast & 16) && is_fmpan_chain(c, v) ? CLS_FMPAN : CLS_GENERIC;
 				if(v.out_off == 0)
 					owners_ok = false;	// adds straight into the master bus
 				(v.cls == CLS_OSCPAN ? fast_leaf : v.cls == CLS_OSC2PAN ? osc2_leaf :
 				 v.cls == CLS_OSCFILTPAN ? filt_leaf : v.cls == CLS_FMPAN ? fm_leaf :
 				 v.cls == CLS_OSC2FILTPAN ? o2f_leaf : gen_leaf).push_back((int)vi);
 			}
+			if(cls_check && !v.cls_stale && was_cls >= 0 && was_cls != v.cls)
+				return c->fail(A2AMD_ESTATE, "voice %zu: remembered launch class %d, classified %d (a change nobody reported)",
+						vi, was_cls, v.cls);
+			v.cls_stale = false;
 		}
 		auto by_bus = [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; };
 		// (slots follow the order of birth, births the walk: a class is usually grouped by bus already - one pass
@@ -953,8 +967,10 @@ void end_batch(a2amd_ctx *c)
 		} else {
 			v.touched = -1;
 			v.listed_recs = false;
-			if(v.mode_mix)
+			if(v.mode_mix) {
 				c->lists_dirty = true;	// (it may have its leaf class back)
+				v.cls_stale = true;
+			}
 			v.mode_mix = false;
 			v.fancy_recs = false;
 		}

@@ -270,7 +270,10 @@ DEV bool vmw_idle(const A2DVmVoice &v, uint32_t batch_end)
 			if(v.env[k].active)
 				return false;
 		for(int k = 0; k < (int)v.ncut && k < A2D_VM_MAXCUT; ++k)
-			if(v.cut[k][3])		// (the ramper's timer: still on its way)
+			// (the ramper's timer: still on its way - or just arrived: the window after a ramp's last one sets value =
+			// target and delta = 0, rp_prepare, without a record; a write that found the old delta would start from
+			// somewhere else, rp_set)
+			if(v.cut[k][3] | v.cut[k][2])
 				return false;
 	}
 	if(v.fault || (v.has_exit && v.waketime == v.exit_when))

@@ -25,6 +25,8 @@ def pytest_configure(config):
     # ... and with the window pool's overflow flag read back after every batch (a bound the host got wrong fails the
     # render at once instead of a batch later)
     os.environ.setdefault("A2AMD_WIN_CHECK", "1")
+    # ... and every rebuild of the launch lists classifies every voice and compares with the class it remembered (upload())
+    os.environ.setdefault("A2AMD_CLS_CHECK", "1")
 
 
 def fnv1a_fragments(pcm, frag=64):

@@ -28,7 +28,8 @@ def engine_config(seed):
 # part of the instruction set, fuzz_scripts.loop_programs - taken by the device VM, sent messages, killed, detached)
 # (3779: found by the end-of-round-4 soak - an env unit's re-targeted unity ramp overshoots 1.0 and the engine's table
 # look-up reads on into the next table of its array, env.c:127-133; the drop-in's tables are laid out the same way)
-@pytest.mark.parametrize("seed", list(range(24)) + list(range(1000, 1012)) + list(range(2000, 2024)) + list(range(3000, 3016)) + [3779])
+@pytest.mark.parametrize("seed", list(range(24)) + list(range(1000, 1012)) + list(range(2000, 2024)) + list(range(3000, 3016)) +
+                         [3779, 2635])    # (3779: round 4's env table finding; 2635: round 5, a cutoff ramp that ends while k_vm_win leaves the voice alone)
 def test_random_script_matches_reference(tmp_path, seed):
     if not (os.path.exists(REF_RENDER) and os.path.exists(UNITS_SO)):
         pytest.skip("oracle/_ref (compiled reference) or liba2amd_units.so not built")
