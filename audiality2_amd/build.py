@@ -27,16 +27,31 @@ def source_hash(sources, cmd=()):
     return h.hexdigest()[:32]
 
 
-def stamped_hash(lib):
+def stamped_hash(lib, mark=MARK):
     """the stamp a built library carries (None: no library, or one from before the stamps)"""
     if not os.path.exists(lib):
         return None
     with open(lib, "rb") as f:
         blob = f.read()
-    i = blob.find(MARK)
+    i = blob.find(mark)
     if i < 0:
         return None
-    return blob[i + len(MARK):i + len(MARK) + 32].decode("ascii", "replace")
+    return blob[i + len(mark):i + len(mark) + 32].decode("ascii", "replace")
+
+
+ENGMARK = b"A2AMD_ENGHASH:"
+
+
+def engine_hash(engine):
+    """Hash of the engine headers liba2amd_walk.so is compiled against (it reads A2_voice / A2_state members by
+    name, i.e. by THAT version's offsets): everything under the engine's include/ and src/ that is a header or the
+    template of one, plus liba2amd_units.so's own source hash (the walk links it)."""
+    files = []
+    for d in ("include", "src", os.path.join("src", "units"), os.path.join("src", "drivers")):
+        p = os.path.join(engine, d)
+        if os.path.isdir(p):
+            files += [os.path.join(p, f) for f in sorted(os.listdir(p)) if f.endswith((".h", ".h.cmake", ".h.in"))]
+    return source_hash(files, (stamped_hash(os.path.join(HERE, "liba2amd_units.so")) or "",))
 
 
 def _stale(target, want):
@@ -96,10 +111,14 @@ def build_walk(force=False, engine=None):
                                f"sources {want}) and the engine's source tree ({engine}) is not here to rebuild it")
         return out if os.path.exists(out) else None
     inc = os.path.join(HERE, "_engine_include")
-    if force or _stale(out, want):
+    # where the engine's tree is, the library must also have been compiled against THESE headers (another engine
+    # version = another A2_voice layout: a silent mismatch otherwise); boxes without the tree keep the stamp of our
+    # own sources only, above
+    weng = engine_hash(engine)
+    if force or _stale(out, want) or stamped_hash(out, ENGMARK) != weng:
         subprocess.run(["cmake", f"-DENGINE={engine}", f"-DOUT={inc}", "-P", os.path.join(HERE, "csrc", "engine_header.cmake")],
                        check=True, stdout=subprocess.DEVNULL)
-        subprocess.run(["gcc"] + flags + [_define(want), "-I" + inc] +
+        subprocess.run(["gcc"] + flags + [_define(want), '-DA2AMD_ENGHASH="%s"' % weng, "-I" + inc] +
                        ["-I" + os.path.join(engine, d) for d in ("include", "src", "src/units", "src/drivers")] +
                        ["-o", out, src, "-L" + HERE, "-la2amd_units", "-la2amd", "-ldl", "-lpthread", "-Wl,-rpath,$ORIGIN"],
                        check=True)

@@ -1066,7 +1066,10 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 	}
 	if(!nj)
 		return 0;
-	if(c->wtop_pending && hipEventQuery(c->wtop_ev) == hipSuccess) {
+	if(c->wtop_pending) {
+		// (the copy sits behind the batch before this one: done, or nearly - waited for rather than polled, because this
+		// batch's memset and copy overwrite d_wtop / h_wtop and an overflow flag not read here would be lost)
+		HIPCHK(c, hipEventSynchronize(c->wtop_ev));
 		c->wtop_pending = false;
 		c->vm.pool_used = std::max(c->h_wtop[0], c->h_wtop[2]);
 		if(c->h_wtop[1] || c->h_wtop[3]) {

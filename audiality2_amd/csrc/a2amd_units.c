@@ -223,6 +223,11 @@ typedef struct XTRA
 	int		vm;
 	unsigned	vm_seen;
 	int		vm_seen_valid;
+	/* head: the backend looked ahead through the voice's program and found the stay not worth it (too short, no
+	 * writes): not asked again before frag_serial vm_retry - the look-ahead is up to thousands of VM runs on the
+	 * engine thread, and a voice that loops on delays would otherwise pay it at every wake-up.  Doubles per refusal. */
+	unsigned	vm_retry;
+	uint8_t		vm_backoff;
 	/* head: the voice's env units (a2_env_unitdesc below) and how many forwarded units stand in front of each;
 	 * nenv > 2: too many for the device VM */
 	A2P_unit	*env[2];
@@ -2631,6 +2636,8 @@ int a2amd_units_vm_adopt(const void *head_unit, const uint32_t *code, unsigned n
 	/* (a voice just given back is not offered again in the same fragment) */
 	if(x->vm_seen_valid && x->vm_seen == hs->frag_serial)
 		return -2;
+	if(x->vm_backoff && (int)(hs->frag_serial - x->vm_retry) < 0)
+		return -2;
 	if(x->nenv > A2AMD_VM_MAXENV)
 		return -1;
 	for(k = 0; k < x->nenv; ++k)
@@ -2702,8 +2709,16 @@ int a2amd_units_vm_adopt(const void *head_unit, const uint32_t *code, unsigned n
 			trace = getenv("A2AMD_VM_TRACE") != NULL;
 		if(trace)
 			fprintf(stderr, "a2amd units: voice not taken by the device VM: %s\n", a2amd_last_error(XCTX(x)));
+		if(rc != A2AMD_EUNSUPPORTED)
+		{
+			/* "not now": 8, 16 ... 4 096 fragments until the next look */
+			if(x->vm_backoff < 10)
+				++x->vm_backoff;
+			x->vm_retry = hs->frag_serial + (4u << x->vm_backoff);
+		}
 		return rc == A2AMD_EUNSUPPORTED ? -1 : -2;
 	}
+	x->vm_backoff = 0;
 	/* from here on it stands like a sleeping voice: default windows through the map / holds */
 	head->Process = amd_quick_process;
 	set_stamp(hs, x, 1);

@@ -804,21 +804,26 @@ int vm_issue(a2amd_ctx *c, bool fused)
 {
 	VmHost &m = c->vm;
 	m.fused = false;
-	if(m.list.empty())
+	// (the faults of the last fused batch are looked at whether or not a voice is left: all of them may have been
+	// recalled since)
+	if(m.total_pending) {
+		use_device(c);
+		HIPCHK(c, hipEventSynchronize(m.total_ev));	// (behind the batch before this one: long done)
+		m.total_pending = false;
+		if(m.h_total[1])
+			return c->fail(A2AMD_ESTATE, "device VM: %u voice(s) faulted in an earlier batch (the analysis let a program through "
+					"that it should not have)", m.h_total[1]);
+	}
+	if(m.list.empty()) {
+		m.last_total = 0;
 		return 0;
+	}
 	if(c->capturing)
 		return c->fail(A2AMD_ESTATE, "device VM voices in a captured batch");
 	use_device(c);
 	if(!m.d_total) {
 		HIPCHK(c, hipMalloc((void **)&m.d_total, 2 * sizeof(uint32_t)));
 		HIPCHK(c, hipHostMalloc((void **)&m.h_total, 2 * sizeof(uint32_t), hipHostMallocDefault));
-	}
-	if(m.total_pending) {
-		HIPCHK(c, hipEventSynchronize(m.total_ev));	// (behind the batch before this one: long done)
-		m.total_pending = false;
-		if(m.h_total[1])
-			return c->fail(A2AMD_ESTATE, "device VM: %u voice(s) faulted in an earlier batch (the analysis let a program through "
-					"that it should not have)", m.h_total[1]);
 	}
 	A2DVmParams vp;
 	fill_params(c, vp);

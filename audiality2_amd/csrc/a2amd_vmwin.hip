@@ -43,8 +43,15 @@ using namespace a2vm;
 // makes at most one record per control register of the chain and two for a cutoff (SETALL / RAMPALL over
 // 2 x 4 wtosc + 5 filter12 + 2 panmix registers: 16), so VMW_GIVEWAY + 17 <= VMW_RING never overflows; the
 // queue says so if it ever does (TRAP_RECORDS: the voice stops and the host reports the fault)
-#define VMW_RING    24
+#define VMW_RING    32
 #define VMW_GIVEWAY 6
+// (round 6, advisor) ... and behind a run, before the drain, run_batch adds the env units' writes, a cutoff's coefficient
+// step per filter, the window itself and the late env writes.  Worst case of the largest class (2 x wtosc, filter12,
+// panmix): VMW_GIVEWAY + (2 x 4 + 5 + 2 registers = 15, + 1 for a cutoff's second record) + 2 x A2D_VM_MAXENV +
+// A2D_VM_MAXCUT + 1 (R_SEG) = 29: the ring has room to spare, and a class that outgrows it does not compile
+#define VMW_MAXREGS (2 * 4 + 5 + 2)
+static_assert(VMW_GIVEWAY + VMW_MAXREGS + 1 + 2 * A2D_VM_MAXENV + A2D_VM_MAXCUT + 1 + 2 <= VMW_RING,
+		"k_vm_win's record ring must hold one instruction's records + what run_batch queues behind a run");
 #define VMW_ROW     (64 - 1 - WIN_EXL)	/* further windows of a fragment beyond the staged ones: a lane's row of wscr */
 
 

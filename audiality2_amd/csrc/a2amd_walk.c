@@ -1214,3 +1214,9 @@ void a2_ProcessVoices(A2_state *st, A2_voice **head, unsigned offset, unsigned f
 #define A2AMD_SRCHASH "unstamped"
 #endif
 const char *a2amd_walk_source_stamp(void) { return "A2AMD_SRCHASH:" A2AMD_SRCHASH; }
+/* ... and of the ENGINE headers it was compiled against (this file reads A2_voice / A2_state members: a library made
+ * for another engine version has another layout).  Checked wherever that engine's tree is (build.py). */
+#ifndef A2AMD_ENGHASH
+#define A2AMD_ENGHASH "unstamped"
+#endif
+const char *a2amd_walk_engine_stamp(void) { return "A2AMD_ENGHASH:" A2AMD_ENGHASH; }

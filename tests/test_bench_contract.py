@@ -36,7 +36,8 @@ def test_bench_prints_one_contract_line():
     assert d["parity"]["golden_steps_compared"] == 10 and d["parity"]["timed_steps_covered_by_golden"] == 6
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["kernel"] == "k_leaf_osc2pan"
+    # (the line carries 6 significant digits - bench._r - so frac and achieved / peak agree to that, not to 1e-9)
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5 * rf["frac"] and rf["kernel"] == "k_leaf_osc2pan"
     assert d["roofline_valu"]["bound"] == "valu-issue"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["realtime"]["fragment_ms_p99"] > 0
