@@ -254,6 +254,9 @@ int a2d_launch_build_coef(const int16_t *pool, int *coef, unsigned lo, unsigned 
 int a2d_launch_capture(const int32_t *bus, int32_t *dst, const uint32_t *fragpos, int nfrags, int nch, void *stream);
 int a2d_launch_wave_from_pcm(const int32_t *pcm, int16_t *pool, const uint32_t *off, const uint32_t *size, int levels, int looped,
 		int pre, int post, void *stream);
+int a2d_osc2filtpan_max_vpg(void);
+int a2d_launch_leaf_osc2filtpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
+		int vpg, void *stream);
 int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
 		int vpw, void *stream);
 // runs[idx[i]] = val[i] for the few voices whose record run changed this batch
@@ -280,8 +283,9 @@ int a2d_launch_win_ctl(const A2DParams *dparams, const A2DParams &hp, int nosc, 
 int a2d_launch_win_render(const A2DParams &hp, int nosc, int filt, const int *dlist, int nlist, int fa, int fb,
 		const int *wslot, const int *wext, const unsigned *widx, void *stream);
 // ... all four kinds in one launch: lists[k] / counts[k] for (nosc, filt) = (1,0) (2,0) (1,1) (2,1)
+// skip_mask bit k: list k may hold voices without records this batch - their quiet kernel renders those (skip_empty)
 int a2d_launch_leaf_recs_all(const A2DParams *dparams, const A2DParams &hp, const int *const *lists, const int *counts,
-		int vpw, void *stream);
+		int vpw, void *stream, int skip_mask = 0);
 // fm -> panmix leaf voices of ONE unit kind (a2amd_unitkind A2AMD_FM1..FM4R)
 int a2d_launch_leaf_fmpan(const A2DParams *dparams, const A2DParams &hp, int kind, const int *dlist, int nlist,
 		int vpw, void *stream);

@@ -1935,7 +1935,7 @@ __global__ __launch_bounds__(64 * RECS_WPB)
 void k_leaf_recs_all(const A2DParams *__restrict__ pp, RecsSegs segs, int vpw,
 		const A2DVoice *__restrict__ voices, int *ustate, int *vactive,
 		const int16_t *__restrict__ wavepool, const A2DWave *__restrict__ waves,
-		const uint32_t *__restrict__ ptab, int *__restrict__ busmem)
+		const uint32_t *__restrict__ ptab, int *__restrict__ busmem, int skip_mask)
 {
 	__shared__ RecsPart part[2];
 	__shared__ int part_off[2][RECS_WPB], part_nch[2][RECS_WPB];
@@ -1953,7 +1953,7 @@ void k_leaf_recs_all(const A2DParams *__restrict__ pp, RecsSegs segs, int vpw,
 	}
 	const int gw = b * wpb + (int)(threadIdx.x >> 6);
 #define RECS_BODY(K, N, F) case K: recs_body<N, F>(pp, segs.list[K], segs.count[K], vpw, gw, voices, ustate, vactive, \
-		wavepool, waves, ptab, busmem, part, part_off, part_nch); break
+		wavepool, waves, ptab, busmem, part, part_off, part_nch, (skip_mask >> K) & 1); break
 	switch(rfl(kind)) {
 	  RECS_BODY(0, 1, 0);
 	  RECS_BODY(1, 2, 0);
@@ -1979,7 +1979,7 @@ static int recs_wpb(int nwaves)
 }
 
 int a2d_launch_leaf_recs_all(const A2DParams *dparams, const A2DParams &hp, const int *const *lists, const int *counts,
-		int vpw, void *stream)
+		int vpw, void *stream, int skip_mask)
 {
 	RecsSegs segs;
 	int nblocks = 0, nwaves = 0;
@@ -1997,7 +1997,7 @@ int a2d_launch_leaf_recs_all(const A2DParams *dparams, const A2DParams &hp, cons
 	// (dynamic LDS: the filter kinds' window rows and pool, RECS_VFILT)
 	// (plumbing-sized launches keep the scalar recurrence: no rows, no pool)
 	hipLaunchKernelGGL(k_leaf_recs_all, dim3(nblocks), dim3(64 * wpb), 0, (hipStream_t)stream, dparams, segs, vpw,
-			hp.voices, hp.ustate, hp.vactive, hp.wavepool, hp.waves, hp.ptab, hp.busmem);
+			hp.voices, hp.ustate, hp.vactive, hp.wavepool, hp.waves, hp.ptab, hp.busmem, skip_mask);
 	return (int)hipGetLastError();
 }
 
@@ -2202,12 +2202,36 @@ DEV void filt_barrier()
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 __device__ unsigned g_filt_turn[4096];	// FILT_ROT == 2: workgroups arriving on a CU take turns (k_leaf_oscfiltpan)
-__global__ __launch_bounds__(64 * FILT_WAVES) __attribute__((amdgpu_waves_per_eu(FILT_WPE, FILT_WPE)))
-void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpg,
+// Round 6: the body is shared by two kernels - NOSC = 1, k_leaf_oscfiltpan (wtosc -> filter12 -> panmix, configs[2]),
+// and NOSC = 2, k_leaf_osc2filtpan: wtosc; wtosc (adding); filter12; panmix, the usual subtractive note (every lead of the
+// reference's benchmark/k2*.a2s), which rounds 2-5 rendered through the records / window kernels whether or not it
+// carried records.  The second oscillator adds into the voice's scratch before the filter reads it
+// (wtosc.c:200-236 with A2_PROCADD: out[s] += v * a >> 17, a wrapping int32 add; filter12.c:98: in >> 5 of the SUM), so a
+// row of the tile holds (xa + xb) >> 5: twice the taps per row, the filter and pan stages as they were.  An oscillator
+// wavefront's all-settled loop holds 4 tap pairs x 3 registers per voice instead of 2, hence fewer voices per wavefront
+// (FILT2_FASTV) and per workgroup (a2d_launch_leaf_osc2filtpan).  Everything added for NOSC = 2 is behind
+// if constexpr(NOSC == 2).  (With a plain if the discarded branches still disturbed the register allocation of the
+// one-oscillator kernel: 98 scratch accesses instead of 73.  As it stands k_leaf_oscfiltpan is round 5's code up to
+// register numbering and the grouping of a few prologue loads - not bit-identical (tools/isa_mix.py hash
+// 39e9eb94cc881251 -> 97b9066429681ca1), the same 21 858 instructions, the same 73 scratch accesses in the same
+// loops, 154 of 160 mnemonic counts equal and the other six off by one: profiles/r06_oscfiltpan_spill_sites.txt.
+// What configs[2] takes on it is measured)
+#ifndef FILT2_FASTV
+// most voices an oscillator wavefront of the two-oscillator kernel takes through its all-settled loop.  3: four tap
+// pairs x 3 registers per voice in flight across the barrier (FILT_AHEAD) - with 4 voices the loop holds 27 - 29
+// scratch reloads per trip (profiles/r06_oscfiltpan_spill_sites.txt) and MEASURED 3.5x slower than with 3
+// (16 384 voices x 256 fragments: 48 voices per workgroup = 4 per wavefront 3.83 ms, 32 = 2 - 3 per wavefront 1.09 ms,
+// 64 = 5 - 6 per wavefront, general loop, 1.50 ms; profiles/r06_osc2filtpan_shapes.txt)
+#define FILT2_FASTV 3
+#endif
+template<int NOSC>
+DEV void oscfiltpan_body(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpg,
 		const A2DVoice *__restrict__ voices, int *ustate, const int16_t *__restrict__ wavepool,
 		const A2DWave *__restrict__ waves, const uint32_t *__restrict__ ptab, int *__restrict__ busmem,
 		const int *__restrict__ wavecoef)
 {
+	constexpr int FASTV = NOSC == 1 ? FILT_FASTV : FILT2_FASTV;
+	constexpr int UF = NOSC, UP = NOSC + 1;		// chain positions of filter12 and panmix
 	extern __shared__ __attribute__((aligned(16))) int tiles[];	// 3 x [vpg][FILT_PITCH]
 	const A2DParams &p = *pp;
 	const int wv = rfl((int)(threadIdx.x >> 6));	// (wave-uniform, and known to the compiler as such)
@@ -2276,7 +2300,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		if(lane < nv)
 			mine = p.runs[list[first + lane]].count == 0;
 		if(mine) {
-			u1 = voices[list[first + lane]].unit[1];
+			u1 = voices[list[first + lane]].unit[UF];
 			const int *w1 = ustate + (size_t)u1 * A2D_USTATE;
 #pragma unroll
 			for(int k = 0; k < 4; ++k)
@@ -2452,7 +2476,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 	{
 		bool plain = true;
 		if(lane < nv && p.runs[list[first + lane]].count == 0) {
-			const int *w1 = ustate + (size_t)voices[list[first + lane]].unit[1] * A2D_USTATE;
+			const int *w1 = ustate + (size_t)voices[list[first + lane]].unit[UF] * A2D_USTATE;
 			plain = w1[FW_BP] == 0 && w1[FW_HP] == 0;
 		}
 		lpraw = __all(plain);
@@ -2464,14 +2488,25 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 #pragma unroll
 	for(int k = 0; k < DV_NWORDS; ++k)
 		dv[k] = 0;
+	// NOSC == 2: the adding oscillator's state words (the SV_ words up to the amplitude ramper) and what is
+	// derived from them once per launch (the DV_ words DV_MM .. DV_DOFF); DV_SETTLED speaks for both
+	int sw[NOSC == 2 ? SV_VOL : 1], dw[NOSC == 2 ? DV_V0 : 1], u1b = 0;
+	if constexpr(NOSC == 2) {
+#pragma unroll
+		for(int k = 0; k < SV_VOL; ++k)
+			sw[k] = 0;
+#pragma unroll
+		for(int k = 0; k < DV_V0; ++k)
+			dw[k] = 0;
+	}
 	if(lane < mv)
 		mine = p.runs[list[first + vb + lane]].count == 0;
 	const unsigned long long mine_mask = __ballot(mine);
 	if(mine) {
 		const A2DVoice &vc = voices[list[first + vb + lane]];
 		u0 = vc.unit[0];
-		u2 = vc.unit[2];
-		my_lp = ustate[(size_t)vc.unit[1] * A2D_USTATE + FW_LP];
+		u2 = vc.unit[UP];
+		my_lp = ustate[(size_t)vc.unit[UF] * A2D_USTATE + FW_LP];
 		my_off = vc.out_off;
 		my_nch = vc.out_nch;
 		const int *w0 = ustate + (size_t)u0 * A2D_USTATE;
@@ -2490,6 +2525,20 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 				  sv[SV_VOL + 3] | sv[SV_VOL + 2] | sv[SV_PAN + 3] | sv[SV_PAN + 2]) &&
 				sv[SV_P] == sv[SV_P + 1] && sv[SV_A] == sv[SV_A + 1] &&
 				sv[SV_VOL] == sv[SV_VOL + 1] && sv[SV_PAN] == sv[SV_PAN + 1];
+		if constexpr(NOSC == 2) {
+			u1b = vc.unit[1];
+			const int *wb = ustate + (size_t)u1b * A2D_USTATE;
+			sw[SV_MODE] = wb[OW_MODE]; sw[SV_WAVE] = wb[OW_WAVE]; sw[SV_DPHASE] = wb[OW_DPHASE];
+			sw[SV_PHLO] = wb[OW_PHASE_LO]; sw[SV_PHHI] = wb[OW_PHASE_HI]; sw[SV_PRAMP] = wb[OW_PRAMPING];
+#pragma unroll
+			for(int k = 0; k < 4; ++k) {
+				sw[SV_P + k] = wb[OW_P + k];
+				sw[SV_A + k] = wb[OW_A + k];
+			}
+			settled = settled && sw[SV_MODE] == A2D_OSC_MIPWAVE && sw[SV_DPHASE] && !sw[SV_PRAMP] &&
+					!(sw[SV_P + 3] | sw[SV_P + 2] | sw[SV_A + 3] | sw[SV_A + 2]) &&
+					sw[SV_P] == sw[SV_P + 1] && sw[SV_A] == sw[SV_A + 1];
+		}
 		if(settled) {
 			const A2DWave *w = waves + sv[SV_WAVE];
 			const unsigned period = w->period, dphase = (unsigned)sv[SV_DPHASE];
@@ -2502,6 +2551,19 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 			dv[DV_DPH] = (int)dph;
 			dv[DV_SIZEM] = (int)w->size[mm];
 			dv[DV_DOFF] = (int)w->off[mm];
+			if constexpr(NOSC == 2) {
+				const A2DWave *w2 = waves + sw[SV_WAVE];
+				const unsigned period2 = w2->period, dphase2 = (unsigned)sw[SV_DPHASE];
+				unsigned dph2 = ((dphase2 + 255) >> 8) * period2, mm2 = 0;
+				for(; (dph2 > (A2D_MAXPHINC << 8)) && (mm2 < A2D_MIPS - 1); ++mm2)
+					dph2 >>= 1;
+				dph2 = (unsigned)(((uint64_t)dphase2 * period2) >> mm2);
+				settled = settled && w2->size[0] && (w2->flags & 0x100u) && dph2 <= (A2D_MAXPHINC << 16);
+				dw[DV_MM] = (int)mm2;
+				dw[DV_DPH] = (int)dph2;
+				dw[DV_SIZEM] = (int)w2->size[mm2];
+				dw[DV_DOFF] = (int)w2->off[mm2];
+			}
 			const int vol = sv[SV_VOL], pan = sv[SV_PAN];
 			const int vp = mul64s(pan, vol, 24);
 			int v0 = wsub(vol, vp), v1 = wadd(vol, vp);
@@ -2527,6 +2589,11 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 	}
 	uint64_t lastph = 0;	// ... and at the start of the last fragment rendered (for the end state)
 	uint64_t endph = 0;	// (the all-settled loop: the unwrapped phase after the last fragment)
+	uint64_t curph2 = 0, lastph2 = 0, endph2 = 0;	// NOSC == 2: the same three for the adding oscillator
+	if(NOSC == 2 && mine && dv[DV_SETTLED]) {
+		const uint64_t phase = (uint64_t)(unsigned)sw[SV_PHLO] | ((uint64_t)(unsigned)sw[SV_PHHI] << 32);
+		curph2 = (phase >> (unsigned)dw[DV_MM]) % ((uint64_t)(unsigned)dw[DV_SIZEM] << 24);
+	}
 
 	// ---- The common case, a path of its own: every voice of this wavefront is ours, settled and
 	// mixes into the same stereo bus.  What the stages need per voice is then wave-uniform and constant
@@ -2536,7 +2603,7 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 	// phases advance in the scalar unit; lane * dph is kept per voice.  37 vector instructions per
 	// voice and fragment instead of 75.  (One barrier per step like the general loop and the
 	// filter wavefront: the wavefronts of a workgroup choose their loop independently.)
-	const bool fast = FILT_FASTV > 0 && !flusher && mv > 0 && mv <= FILT_FASTV && mine_mask == ((1ull << mv) - 1ull) &&
+	const bool fast = FASTV > 0 && !flusher && mv > 0 && mv <= FASTV && mine_mask == ((1ull << mv) - 1ull) &&
 			__all(lane >= mv || (dv[DV_SETTLED] && my_nch == 2 && my_off >= 0 && my_off == rdl(my_off, 0)));
 	// (one copy of the loop per number of voices, 1 .. FILT_FASTV: no guards inside)
 	auto fast_loop = [&](auto nvc, auto wgc) __attribute__((always_inline)) {
@@ -2545,6 +2612,10 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		unsigned s_dph[NV], s_size[NV], ldph[NV];
 		int s_cb[NV], g_amp[NV], g_v0[NV], g_v1[NV], g_lp[NV];
 		uint64_t s_ph[NV];
+		constexpr int NB = NOSC == 2 ? NV : 1;		// the adding oscillator's copies of the same
+		unsigned t_dph[NB], t_size[NB], ldph2[NB];
+		int t_cb[NB], g_amp2[NB];
+		uint64_t t_ph[NB];
 		const int bus = rdl(my_off, 0);
 #pragma unroll
 		for(int k = 0; k < NV; ++k) {
@@ -2561,6 +2632,16 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 			s_ph[k] = (uint64_t)(unsigned)rdl((int)(unsigned)curph, k) |
 					((uint64_t)(unsigned)rdl((int)(unsigned)(curph >> 32), k) << 32);
 			ldph[k] = lane_dph(lane, s_dph[k]);
+			if constexpr(NOSC == 2) {
+				t_dph[k] = (unsigned)rdl(dw[DV_DPH], k);
+				t_size[k] = (unsigned)rdl(dw[DV_SIZEM], k);
+				t_cb[k] = coef_base((unsigned)rdl(dw[DV_DOFF], k));
+				g_amp2[k] = rdl(sw[SV_A], k);
+				asm("" : "+v"(g_amp2[k]));
+				t_ph[k] = (uint64_t)(unsigned)rdl((int)(unsigned)curph2, k) |
+						((uint64_t)(unsigned)rdl((int)(unsigned)(curph2 >> 32), k) << 32);
+				ldph2[k] = lane_dph(lane, t_dph[k]);
+			}
 		}
 		// The coefficient entries of the fragment the phases stand at, all voices' loads in flight together.
 		// FILT_AHEAD (round 4): asked for at the END of the step before.  The wavefronts of a workgroup march
@@ -2570,6 +2651,8 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		// LDS only: filt_barrier).  configs[2]: 0.581 -> 0.546 ms per 256 fragments, configs[4] 8.74 -> 8.19.
 		Coef4 ka[NV], kb[NV];
 		unsigned pa[NV], pb[NV];
+		Coef4 kc[NB], kd[NB];
+		unsigned pc[NB], pd[NB];
 		auto ask = [&]() __attribute__((always_inline)) {
 #pragma unroll
 			for(int k = 0; k < NV; ++k) {
@@ -2577,6 +2660,12 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 				pb[k] = pa[k] + (s_dph[k] >> 17);
 				ka[k] = coef_at(crs, s_cb[k], pa[k]);
 				kb[k] = coef_at(crs, s_cb[k], pb[k]);
+				if constexpr(NOSC == 2) {
+					pc[k] = tap_phase(t_ph[k], ldph2[k]);
+					pd[k] = pc[k] + (t_dph[k] >> 17);
+					kc[k] = coef_at(crs, t_cb[k], pc[k]);
+					kd[k] = coef_at(crs, t_cb[k], pd[k]);
+				}
 			}
 		};
 #if FILT_AHEAD
@@ -2635,8 +2724,13 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 				int *tile = tiles + (fa % 3) * tsize + vb * FILT_PITCH;
 				int x[NV];
 #pragma unroll
-				for(int k = 0; k < NV; ++k)
+				for(int k = 0; k < NV; ++k) {
+					if constexpr(NOSC == 2)	// (the adding oscillator: a wrapping add in the voice's scratch, then in >> 5)
+						x[k] = wadd(mul64s(hermite_c(ka[k], pa[k]) + hermite_c(kb[k], pb[k]), g_amp[k], 17),
+								mul64s(hermite_c(kc[k], pc[k]) + hermite_c(kd[k], pd[k]), g_amp2[k], 17)) >> 5;
+					else
 					x[k] = mul64s(hermite_c(ka[k], pa[k]) + hermite_c(kb[k], pb[k]), g_amp[k], 17) >> 5;	// (x5: filt_step)
+				}
 				if(n == A2D_FRAG) {
 #pragma unroll
 					for(int k = 0; k < NV; ++k)
@@ -2659,6 +2753,17 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 						ph = ((uint64_t)hi << 24) | (ph & 0xffffffu);
 					}
 					s_ph[k] = ph;
+					if constexpr(NOSC == 2) {
+						uint64_t ph2 = t_ph[k] + (uint64_t)t_dph[k] * (unsigned)n;
+						unsigned hi2 = (unsigned)(ph2 >> 24);
+						if(hi2 >= t_size[k] && wrap) {
+							hi2 -= t_size[k];
+							if(hi2 >= t_size[k])
+								hi2 %= t_size[k];
+							ph2 = ((uint64_t)hi2 << 24) | (ph2 & 0xffffffu);
+						}
+						t_ph[k] = ph2;
+					}
 				}
 			}
 #if FILT_AHEAD
@@ -2687,12 +2792,15 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 #endif
 #pragma unroll
 		for(int k = 0; k < NV; ++k)
-			if(lane == k)
+			if(lane == k) {
 				endph = s_ph[k];
+				if constexpr(NOSC == 2)
+					endph2 = t_ph[k];
+			}
 	};
 	if(fast) {
 		switch(mv) {
-#define FAST_CASE(N) case N: if(N <= FILT_FASTV) { if(wgbus) fast_loop(std::integral_constant<int, N>{}, std::true_type{}); \
+#define FAST_CASE(N) case N: if(N <= FASTV) { if(wgbus) fast_loop(std::integral_constant<int, N>{}, std::true_type{}); \
 			else fast_loop(std::integral_constant<int, N>{}, std::false_type{}); } break;
 		FAST_CASE(1) FAST_CASE(2) FAST_CASE(3) FAST_CASE(4) FAST_CASE(5) FAST_CASE(6) FAST_CASE(7) FAST_CASE(8)
 #undef FAST_CASE
@@ -2704,6 +2812,12 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 			int *w0 = ustate + (size_t)u0 * A2D_USTATE;
 			w0[OW_PHASE_LO] = (int)(unsigned)ph;
 			w0[OW_PHASE_HI] = (int)(unsigned)(ph >> 32);
+			if constexpr(NOSC == 2) {
+				const uint64_t ph2 = endph2 << (unsigned)dw[DV_MM];
+				int *wb = ustate + (size_t)u1b * A2D_USTATE;
+				wb[OW_PHASE_LO] = (int)(unsigned)ph2;
+				wb[OW_PHASE_HI] = (int)(unsigned)(ph2 >> 32);
+			}
 		}
 		return;
 	}
@@ -2723,7 +2837,8 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 		unsigned pqph[FILT_BATCH], pqph2[FILT_BATCH];
 		int pnb = 0;
 		if(fa < nfrags) {
-			while(pnb < FILT_BATCH && pnb < mv && ((mine_mask >> pnb) & 1ull) && rdl(dv[DV_SETTLED], pnb))
+			// (NOSC == 2: no batched prefix - this loop is the two-oscillator kernel's slow path, voice by voice)
+			while(NOSC == 1 && pnb < FILT_BATCH && pnb < mv && ((mine_mask >> pnb) & 1ull) && rdl(dv[DV_SETTLED], pnb))
 				++pnb;
 			const unsigned cur_lo = (unsigned)curph, cur_hi = (unsigned)(curph >> 32);
 			// (branch free: an unused slot fetches voice 0's entries again - with branches
@@ -2862,6 +2977,48 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 					WRL(sv[SV_A], o.a.value); WRL(sv[SV_A + 1], o.a.target);
 					WRL(sv[SV_A + 2], o.a.delta); WRL(sv[SV_A + 3], o.a.timer);
 				}
+				if constexpr(NOSC == 2) {
+					// the adding oscillator, the same two ways (wtosc.c:200-236 with A2_PROCADD: out[s] += ...)
+					int xb;
+					if(rdl(dv[DV_SETTLED], v)) {
+						const unsigned dph = (unsigned)rdl(dw[DV_DPH], v), doff = (unsigned)rdl(dw[DV_DOFF], v);
+						const int amp = rdl(sw[SV_A], v);
+						const uint64_t ph = (uint64_t)(unsigned)rdl((int)(unsigned)curph2, v) |
+								((uint64_t)(unsigned)rdl((int)(unsigned)(curph2 >> 32), v) << 32);
+						unsigned ph16 = tap_phase(ph, (unsigned)lane * dph);
+						const unsigned ph16b = ph16 + (dph >> 17);
+						const int cb = coef_base(doff);
+						int sm = hermite_c(coef_at(crs, cb, ph16), ph16) + hermite_c(coef_at(crs, cb, ph16b), ph16b);
+						xb = mul64s(sm, amp, 17);
+					} else {
+						OscS o;
+						o.mode = rdl(sw[SV_MODE], v);
+						o.wave = rdl(sw[SV_WAVE], v);
+						o.dphase = (unsigned)rdl(sw[SV_DPHASE], v);
+						o.phase = (uint64_t)(unsigned)rdl(sw[SV_PHLO], v) |
+								((uint64_t)(unsigned)rdl(sw[SV_PHHI], v) << 32);
+						o.p_ramping = rdl(sw[SV_PRAMP], v);
+						o.p.value = rdl(sw[SV_P], v); o.p.target = rdl(sw[SV_P + 1], v);
+						o.p.delta = rdl(sw[SV_P + 2], v); o.p.timer = rdl(sw[SV_P + 3], v);
+						o.a.value = rdl(sw[SV_A], v); o.a.target = rdl(sw[SV_A + 1], v);
+						o.a.delta = rdl(sw[SV_A + 2], v); o.a.timer = rdl(sw[SV_A + 3], v);
+						o.noise = 0;	// (a noise oscillator's every window carries a record: never here)
+						o.seed = 0;
+						xb = osc_fragment_s(g, o, n, lane);
+						const bool me = lane == v;
+						WRL(sw[SV_MODE], o.mode);
+						WRL(sw[SV_WAVE], o.wave);
+						WRL(sw[SV_DPHASE], (int)o.dphase);
+						WRL(sw[SV_PHLO], (int)(unsigned)o.phase);
+						WRL(sw[SV_PHHI], (int)(unsigned)(o.phase >> 32));
+						WRL(sw[SV_PRAMP], o.p_ramping);
+						WRL(sw[SV_P], o.p.value); WRL(sw[SV_P + 1], o.p.target);
+						WRL(sw[SV_P + 2], o.p.delta); WRL(sw[SV_P + 3], o.p.timer);
+						WRL(sw[SV_A], o.a.value); WRL(sw[SV_A + 1], o.a.target);
+						WRL(sw[SV_A + 2], o.a.delta); WRL(sw[SV_A + 3], o.a.timer);
+					}
+					x = wadd(x, xb);
+				}
 				tile[v * FILT_PITCH + lane] = (lane < n) ? x >> 5 : 0;
 			}
 			// every settled voice moves on by n frames (all lanes at once)
@@ -2877,6 +3034,19 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 					ph = ((uint64_t)hi << 24) | (ph & 0xffffffu);
 				}
 				curph = ph;
+				if constexpr(NOSC == 2) {
+					lastph2 = curph2;
+					uint64_t ph2 = curph2 + (uint64_t)(unsigned)dw[DV_DPH] * (unsigned)n;
+					const unsigned size2 = (unsigned)dw[DV_SIZEM];
+					unsigned hi2 = (unsigned)(ph2 >> 24);
+					if(hi2 >= size2) {
+						hi2 -= size2;
+						if(hi2 >= size2)
+							hi2 = (size2 & (size2 - 1)) ? hi2 % size2 : (hi2 & (size2 - 1));
+						ph2 = ((uint64_t)hi2 << 24) | (ph2 & 0xffffffu);
+					}
+					curph2 = ph2;
+				}
 			}
 		}
 #ifdef FILT_PROF
@@ -2917,7 +3087,42 @@ void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__
 			w2[PW_VOL + k] = sv[SV_VOL + k];
 			w2[PW_PAN + k] = sv[SV_PAN + k];
 		}
+		if constexpr(NOSC == 2) {
+			if(dv[DV_SETTLED]) {
+				const uint64_t ph = (lastph2 + (uint64_t)(unsigned)dw[DV_DPH] * (unsigned)FILT_FRAMES(nfrags - 1)) <<
+						(unsigned)dw[DV_MM];
+				sw[SV_PHLO] = (int)(unsigned)ph;
+				sw[SV_PHHI] = (int)(unsigned)(ph >> 32);
+			}
+			int *wb = ustate + (size_t)u1b * A2D_USTATE;
+			wb[OW_MODE] = sw[SV_MODE]; wb[OW_WAVE] = sw[SV_WAVE]; wb[OW_DPHASE] = sw[SV_DPHASE];
+			wb[OW_PHASE_LO] = sw[SV_PHLO]; wb[OW_PHASE_HI] = sw[SV_PHHI]; wb[OW_PRAMPING] = sw[SV_PRAMP];
+#pragma unroll
+			for(int k = 0; k < 4; ++k) {
+				wb[OW_P + k] = sw[SV_P + k];
+				wb[OW_A + k] = sw[SV_A + k];
+			}
+		}
 	}
+}
+
+__global__ __launch_bounds__(64 * FILT_WAVES) __attribute__((amdgpu_waves_per_eu(FILT_WPE, FILT_WPE)))
+void k_leaf_oscfiltpan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpg,
+		const A2DVoice *__restrict__ voices, int *ustate, const int16_t *__restrict__ wavepool,
+		const A2DWave *__restrict__ waves, const uint32_t *__restrict__ ptab, int *__restrict__ busmem,
+		const int *__restrict__ wavecoef)
+{
+	oscfiltpan_body<1>(pp, list, nlist, vpg, voices, ustate, wavepool, waves, ptab, busmem, wavecoef);
+}
+
+// wtosc; wtosc (adding); filter12; panmix 1->2: the subtractive note without records (round 6)
+__global__ __launch_bounds__(64 * FILT_WAVES) __attribute__((amdgpu_waves_per_eu(FILT_WPE, FILT_WPE)))
+void k_leaf_osc2filtpan(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpg,
+		const A2DVoice *__restrict__ voices, int *ustate, const int16_t *__restrict__ wavepool,
+		const A2DWave *__restrict__ waves, const uint32_t *__restrict__ ptab, int *__restrict__ busmem,
+		const int *__restrict__ wavecoef)
+{
+	oscfiltpan_body<2>(pp, list, nlist, vpg, voices, ustate, wavepool, waves, ptab, busmem, wavecoef);
 }
 
 // ---------------------------------------------------------------------------
@@ -3213,6 +3418,28 @@ int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, co
 	int nblocks = (nlist + vpg - 1) / vpg;
 	size_t lds = (size_t)3 * vpg * FILT_PITCH * sizeof(int);
 	hipLaunchKernelGGL(k_leaf_oscfiltpan, dim3(nblocks), dim3(64 * FILT_WAVES), lds, (hipStream_t)stream,
+			dparams, dlist, nlist, vpg, hp.voices, hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem, hp.wavecoef);
+	return (int)hipGetLastError();
+}
+
+// voices per workgroup at which every oscillator wavefront of k_leaf_osc2filtpan stays in its all-settled loop:
+// FILT_WAVES - 1 filter wavefront - the FILT_WAVES / 4 - 1 wavefronts that share its SIMD and take no voices
+int a2d_osc2filtpan_max_vpg(void)
+{
+	const int nfull = FILT_WAVES - 1 - (FILT_WAVES / 4 - 1);
+	const int v = nfull * FILT2_FASTV;
+	return v > FILT_MAXV ? FILT_MAXV : v;
+}
+
+int a2d_launch_leaf_osc2filtpan(const A2DParams *dparams, const A2DParams &hp, const int *dlist, int nlist,
+		int vpg, void *stream)
+{
+	if(nlist <= 0)
+		return 0;
+	vpg = vpg < 1 ? 1 : (vpg > FILT_MAXV ? FILT_MAXV : vpg);
+	int nblocks = (nlist + vpg - 1) / vpg;
+	size_t lds = (size_t)3 * vpg * FILT_PITCH * sizeof(int);
+	hipLaunchKernelGGL(k_leaf_osc2filtpan, dim3(nblocks), dim3(64 * FILT_WAVES), lds, (hipStream_t)stream,
 			dparams, dlist, nlist, vpg, hp.voices, hp.ustate, hp.wavepool, hp.waves, hp.ptab, hp.busmem, hp.wavecoef);
 	return (int)hipGetLastError();
 }

@@ -201,6 +201,7 @@ struct HVoice {
 	uint64_t moving_until = 0;
 	bool listed_moving = false;	// in a2amd_ctx::moving
 	long long moving_run = -1;	// serial_base of the batch in which upload() gave it the stand-in record run
+	long long dynf2_run = -1;	// ... in which it was put on the records kernels' list of 2 x wtosc-filter12-panmix voices
 };
 
 struct DepthRange { int fast_first = 0, fast_count = 0, fbd_first = 0, fbd_count = 0, gen_first = 0, gen_count = 0,
@@ -258,6 +259,8 @@ struct VmHost {
 	int n_fresh = 0;		// ... of which upload() has sent this many up (they join the list when the batch ends)
 	std::vector<int> list;		// slots the kernel runs (active on the device), and ...
 	std::vector<int> cls_lists;	// ... their voices by launch class, for the records kernels: [osc1 | osc2 | filt1]
+	std::vector<int> o2f_voices;	// ... and the 2 x wtosc-filter12-panmix voices among the others (their records come from
+					// k_vm_emit: every batch they stand on the records kernels' list of that class, skip_empty)
 	int n_cls[3] = { 0, 0, 0 };
 	// d_list: [list | cls_lists | the classes' VM slots in cls_lists' order (k_vm_win) | the VM slots of no class]
 	int n_other = 0;
@@ -345,6 +348,7 @@ struct a2amd_ctx {
 	long long serial_base = 0;		// fragments rendered before this batch
 	int n_leaf_dyn = 0, static_len = 0;
 	int n_dyn_osc1 = 0, n_dyn_osc2 = 0, n_dyn_filt = 0;	// ... of n_leaf_dyn, first in the list: k_leaf_recs renders them
+	int n_dyn_filt2 = 0, n_dyn_rest = 0;	// ... 2 x wtosc-filter12-panmix (round 6: a quiet kernel of its own) / the general kernel's
 	int n_o2f_leaf = 0;			// 2 x wtosc-filter12-panmix leaves (list_all, behind the general leaves)
 	int n_started_live = 0;			// voices the engine is walking
 	int walked_started = 0;			// ... of which it has walked this many in the open fragment

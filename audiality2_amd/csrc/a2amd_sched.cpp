@@ -539,7 +539,7 @@ int upload(a2amd_ctx *c)
 			if(v.moving_run == c->serial_base)
 				continue;
 			if(no_moving || !v.recs.empty() || v.vm >= 0 || c->lists_dirty || v.mode_mix || !v.resolved ||
-					!(v.cls == CLS_OSCPAN || v.cls == CLS_OSC2PAN || v.cls == CLS_OSCFILTPAN))
+					!(v.cls == CLS_OSCPAN || v.cls == CLS_OSC2PAN || v.cls == CLS_OSCFILTPAN || v.cls == CLS_OSC2FILTPAN))
 				continue;
 			if(nop_at < 0) {
 				nop_at = (int)recs.size();
@@ -714,7 +714,7 @@ int upload(a2amd_ctx *c)
 					fprintf(stderr, "REC %lld v%d f%u op%u u%u r%u val %d dur %u start %u\n", c->serial_base, vi,
 							A2D_RFRAG(r.head), A2D_ROP(r.head), A2D_RUNIT(r.head), A2D_RREG(r.head), r.value, r.dur, r.start);
 			// (fm-panmix voices execute their own records in k_leaf_fmpan)
-			if(v.cls == CLS_OSCPAN || v.cls == CLS_OSCFILTPAN || v.cls == CLS_OSC2PAN)
+			if(v.cls == CLS_OSCPAN || v.cls == CLS_OSCFILTPAN || v.cls == CLS_OSC2PAN || v.cls == CLS_OSC2FILTPAN)
 				dyn_leaf.push_back(vi);
 			else if((v.cls == CLS_BUSDRIVER || v.cls == CLS_FBDCHAIN) && v.depth < (int)dyn_bus.size()) {
 				dyn_bus[v.depth].push_back(vi);
@@ -730,27 +730,46 @@ int upload(a2amd_ctx *c)
 		// mip-mapped waves throughout the batch) go first, by class; the rest -
 		// filter voices, a wave of another kind somewhere in the batch - to the
 		// general kernel.
-		std::vector<int> dyn_o1, dyn_o2, dyn_f1, dyn_rest;
+		std::vector<int> dyn_o1, dyn_o2, dyn_f1, dyn_f2, dyn_rest;
 		const bool no_recs_kernel = (c->no_fast & 64) != 0;
 		for(int vi : dyn_leaf) {
-			const HVoice &v = c->voices[vi];
+			HVoice &v = c->voices[vi];
 			// (close_fragment's R_NOP is the one other record k_leaf_recs takes - as nothing)
 			const bool ok = !no_recs_kernel && !v.mode_mix && !v.fancy_recs;
-			(!ok ? dyn_rest : v.cls == CLS_OSCPAN ? dyn_o1 : v.cls == CLS_OSC2PAN ? dyn_o2 : dyn_f1).push_back(vi);
+			if(ok && v.cls == CLS_OSC2FILTPAN)
+				v.dynf2_run = c->serial_base;
+			(!ok ? dyn_rest : v.cls == CLS_OSCPAN ? dyn_o1 : v.cls == CLS_OSC2PAN ? dyn_o2 :
+			 v.cls == CLS_OSCFILTPAN ? dyn_f1 : dyn_f2).push_back(vi);
+		}
+		// Round 6: 2 x wtosc-filter12-panmix has a quiet kernel of its own (k_leaf_osc2filtpan) and rounds 2-5's "the records
+		// kernels render every voice of the class" is over: like the other three classes, a voice is the quiet kernel's
+		// in a batch in which its run is empty and the records / window kernels' otherwise.  Whose records the DEVICE VM
+		// writes (k_vm_emit, after this list is made) the host cannot tell which it will be: the class's adopted voices
+		// stand on the list in every batch, and the list is taken with skip_empty - the one rule "runs[v].count == 0 <=>
+		// the quiet kernel's" decides for every voice, whoever wrote its records.
+		for(int vi : c->vm.o2f_voices) {
+			HVoice &v = c->voices[vi];
+			if(v.dynf2_run == c->serial_base || v.cls != CLS_OSC2FILTPAN || !(v.live || v.dying) || v.vm < 0)
+				continue;
+			v.dynf2_run = c->serial_base;
+			dyn_f2.push_back(vi);
 		}
 		// (the walk order usually has them grouped by bus already)
 		auto by_bus_dyn = [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; };
-		for(std::vector<int> *l : { &dyn_o1, &dyn_o2, &dyn_f1, &dyn_rest })
+		for(std::vector<int> *l : { &dyn_o1, &dyn_o2, &dyn_f1, &dyn_f2, &dyn_rest })
 			if(!std::is_sorted(l->begin(), l->end(), by_bus_dyn))
 				std::stable_sort(l->begin(), l->end(), by_bus_dyn);
 		std::vector<int> dyn = dyn_o1;
 		dyn.insert(dyn.end(), dyn_o2.begin(), dyn_o2.end());
 		dyn.insert(dyn.end(), dyn_f1.begin(), dyn_f1.end());
+		dyn.insert(dyn.end(), dyn_f2.begin(), dyn_f2.end());
 		dyn.insert(dyn.end(), dyn_rest.begin(), dyn_rest.end());
 		c->n_dyn_osc1 = (int)dyn_o1.size();
 		c->n_dyn_osc2 = (int)dyn_o2.size();
 		c->n_dyn_filt = (int)dyn_f1.size();
-		c->n_leaf_dyn = (int)dyn_leaf.size();
+		c->n_dyn_filt2 = (int)dyn_f2.size();
+		c->n_dyn_rest = (int)dyn_rest.size();
+		c->n_leaf_dyn = (int)dyn.size();	// (with the device VM's voices of the fourth class, which dyn_leaf does not hold)
 		for(size_t d = 0; d < dyn_bus.size(); ++d) {
 			c->depth_ranges[d].dyn_first = (int)dyn.size();
 			c->depth_ranges[d].dyn_count = (int)dyn_bus[d].size();
@@ -1040,7 +1059,7 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 	size_t nvoices = 0;
 	for(int k = 0; k < 4; ++k)
 		if(counts[k]) {
-			jobs[nj++] = Job{ nosc[k], filt[k], counts[k], 0, lists[k], -1 };
+			jobs[nj++] = Job{ nosc[k], filt[k], counts[k], k == 3, lists[k], -1 };	// (k == 3: see upload(), dyn_f2)
 			nvoices += (size_t)counts[k];
 		}
 	// (the control pass takes room in the pool by the length of a voice's record run: every gliding voice's run is
@@ -1324,8 +1343,10 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		// thousand; from a few thousand voices on it is k_leaf_recs that queues up (16 384: 1.1 - 3.9 ms against
 		// 0.5 - 1.8).  A2AMD_WIN=0 / 1 forces (the parity tests run both), A2AMD_WIN_MIN moves the threshold.
 		const int *rlists[4] = { c->d_dyn, c->d_dyn + c->n_dyn_osc1, c->d_dyn + c->n_dyn_osc1 + c->n_dyn_osc2,
-				c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf + c->n_fm_leaf + c->n_leaf };
-		const int rcounts[4] = { c->n_dyn_osc1, c->n_dyn_osc2, c->n_dyn_filt, c->n_o2f_leaf };
+				c->d_dyn + c->n_dyn_osc1 + c->n_dyn_osc2 + c->n_dyn_filt };
+		// (the fourth list: this batch's record-carrying 2 x wtosc-filter12-panmix voices and the device VM's voices of that
+		// class, taken with skip_empty - upload())
+		const int rcounts[4] = { c->n_dyn_osc1, c->n_dyn_osc2, c->n_dyn_filt, c->n_dyn_filt2 };
 		const int rtotal = rcounts[0] + rcounts[1] + rcounts[2] + rcounts[3];
 		bool use_win;
 		{
@@ -1385,6 +1406,22 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 				return c->fail(A2AMD_EHIP, "filter leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}
+		if(c->n_o2f_leaf) {
+			// 2 x wtosc-filter12-panmix without records (round 6).  A workgroup (16 wavefronts, 128 registers: one per CU)
+			// takes as long as its filter wavefront's chain whatever its voice count, as long as every oscillator
+			// wavefront stays in its all-settled loop (a2d_osc2filtpan_max_vpg voices): the voices are dealt over the
+			// fewest whole rounds of 256 workgroups that allows (16 384 voices: 2 rounds of 32 - measured 1.09 ms per 256
+			// fragments against 3.83 with 48 and 1.50 with 64 voices per workgroup)
+			const int nf = c->n_o2f_leaf;
+			static const int env_vpg = getenv("A2AMD_F2VPW") ? atoi(getenv("A2AMD_F2VPW")) : 0;
+			const int maxv = a2d_osc2filtpan_max_vpg();
+			const int rounds = std::max(1, (nf + 256 * maxv - 1) / (256 * maxv));
+			const int vpg = env_vpg ? env_vpg : std::min(std::max((nf + 256 * rounds - 1) / (256 * rounds), 1), maxv);
+			if(a2d_launch_leaf_osc2filtpan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf +
+					c->n_filt_leaf + c->n_fm_leaf + c->n_leaf, nf, vpg, c->stream))
+				return c->fail(A2AMD_EHIP, "2-osc filter leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+			++c->stats.launches;
+		}
 		int fm_kinds = 0;
 		for(int k = 0; k < 8; ++k)
 			fm_kinds += c->fm_kind_count[k] != 0;
@@ -1422,11 +1459,11 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		{
 			// (a wavefront walks its voices one after the other, fragment by fragment: as many
 			// wavefronts as the chip holds before a wavefront gets a second voice)
-			auto recs = [&](int nosc, int filt, const int *list, int n) -> int {
+			auto recs = [&](int nosc, int filt, const int *list, int n, int skip_empty) -> int {
 				if(!n)
 					return 0;
 				int vpw = getenv("A2AMD_RVPW") ? atoi(getenv("A2AMD_RVPW")) : (n + 8191) / 8192;
-				if(a2d_launch_leaf_recs(c->d_params, c->hparams, nosc, filt, list, n, vpw, c->stream))
+				if(a2d_launch_leaf_recs(c->d_params, c->hparams, nosc, filt, list, n, vpw, c->stream, skip_empty))
 					return c->fail(A2AMD_EHIP, "leaf records launch failed: %s", hipGetErrorString(hipGetLastError()));
 				++c->stats.launches;
 				return 0;
@@ -1439,13 +1476,13 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			if(kinds > 1 && total <= 4096 && !getenv("A2AMD_RVPW")) {
 				// few voices of several kinds (a song): one launch - on one stream the per-kind
 				// launches would run back to back, each as long as one voice's walk through the batch
-				if(a2d_launch_leaf_recs_all(c->d_params, c->hparams, lists, counts, 1, c->stream))
+				if(a2d_launch_leaf_recs_all(c->d_params, c->hparams, lists, counts, 1, c->stream, 8))
 					return c->fail(A2AMD_EHIP, "leaf records launch failed: %s", hipGetErrorString(hipGetLastError()));
 				++c->stats.launches;
 			} else {
 				static const int nosc[4] = { 1, 2, 1, 2 }, filt[4] = { 0, 0, 1, 1 };
 				for(int k = 0; k < 4; ++k)
-					if(int r = recs(nosc[k], filt[k], lists[k], counts[k]))
+					if(int r = recs(nosc[k], filt[k], lists[k], counts[k], k == 3))
 						return r;
 			}
 			// ... and the voices whose records the device VM has just written, by class (those it
@@ -1465,9 +1502,10 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			}
 			}
 		}
-		if(c->n_leaf_dyn - c->n_dyn_osc1 - c->n_dyn_osc2 - c->n_dyn_filt > 0) {
-			const int n = c->n_leaf_dyn - c->n_dyn_osc1 - c->n_dyn_osc2 - c->n_dyn_filt;
-			if(a2d_launch_voices(c->d_params, c->d_dyn + c->n_dyn_osc1 + c->n_dyn_osc2 + c->n_dyn_filt, n, pick_vpw(n), c->stream))
+		if(c->n_dyn_rest > 0) {
+			const int n = c->n_dyn_rest;
+			if(a2d_launch_voices(c->d_params, c->d_dyn + c->n_dyn_osc1 + c->n_dyn_osc2 + c->n_dyn_filt + c->n_dyn_filt2, n,
+					pick_vpw(n), c->stream))
 				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 			++c->stats.launches;
 		}

@@ -645,6 +645,7 @@ int vm_build_lists(a2amd_ctx *c)
 		++m.list_serial;
 		std::vector<std::pair<int, int>> cls[3];	// (voice slot, VM slot)
 		std::vector<int> other;
+		m.o2f_voices.clear();
 		for(size_t s = 0; s < m.vms.size(); ++s) {
 			const HVm &h = m.vms[s];
 			if(!h.live || h.pending || h.fresh)
@@ -658,8 +659,11 @@ int vm_build_lists(a2amd_ctx *c)
 			const int k = v.cls == CLS_OSCPAN ? 0 : v.cls == CLS_OSC2PAN ? 1 : v.cls == CLS_OSCFILTPAN ? 2 : -1;
 			if(k >= 0)
 				cls[k].push_back(std::make_pair(m.vms[s].voice, s));
-			else
+			else {
 				other.push_back(s);
+				if(v.cls == CLS_OSC2FILTPAN)
+					m.o2f_voices.push_back(m.vms[s].voice);
+			}
 		}
 		m.cls_lists.clear();
 		std::vector<int> cls_vm;

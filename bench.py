@@ -51,6 +51,7 @@ BYTES_PER_VOICE_FRAGMENT = {
     "osc-pan": 504.0,               # (152 + 96 B state) x 2 + 8 B bus share
     "osc-filter-pan": 792.0,        # + filter12's 144 B x 2
     "osc2-pan": 504.0 + 2 * 152.0,  # + the second oscillator
+    "osc2-filter-pan": 792.0 + 2 * 152.0,   # filter12's voice + the second oscillator (round 6: k_leaf_osc2filtpan)
     **{f"{k}-pan": (64.0 * n + 96.0) * 2 + 8.0 for k, n in
        (("fm1", 1), ("fm2", 2), ("fm3", 3), ("fm4", 4), ("fm3p", 3), ("fm4p", 4), ("fm2r", 2), ("fm4r", 4))},
 }
@@ -58,7 +59,8 @@ FBDELAY_BYTES_PER_FRAGMENT = 24.0 * 64 + 240.0      # 6 x 4 B per s
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s
 # integer VALU issue: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz (MI355X_MICROARCH.md)
 VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
-LEAF_KERNEL = {"osc-pan": "k_leaf_oscpan", "osc-filter-pan": "k_leaf_oscfiltpan", "osc2-pan": "k_leaf_osc2pan"}
+LEAF_KERNEL = {"osc-pan": "k_leaf_oscpan", "osc-filter-pan": "k_leaf_oscfiltpan", "osc2-pan": "k_leaf_osc2pan",
+               "osc2-filter-pan": "k_leaf_osc2filtpan"}
 
 CONFIGS = {   # BASELINE.json configs[i]
     1: dict(voices=1024, chain="osc-pan", groups=0,
@@ -85,6 +87,11 @@ CONFIGS[5] = dict(voices=65536, chain="osc-pan", groups=0, private=(2048, 65536,
                   label="65536 voices wtosc->panmix over 2048 private looped sample waves of 65536 samples (period 256), "
                         "pitches +-2.5 octaves, 48 kHz, fragment=64, stereo (SURVEY 8d: the private-wave case; not a "
                         "BASELINE config)")
+# Round 6: the subtractive note - wtosc; wtosc; filter12; panmix, the shape of every lead of the reference's benchmark/k2*.a2s -
+# at configs[2]'s size, sustained and settled: what its quiet kernel (k_leaf_osc2filtpan) renders.  Not a BASELINE config.
+CONFIGS[6] = dict(voices=16384, chain="osc2-filter-pan", groups=0,
+                  label="16384 voices 2xwtosc->filter12->panmix under the root (the subtractive note; configs[2]'s size), "
+                        "48 kHz, fragment=64, stereo (not a BASELINE config)")
 UP, SUB, ROOTP, RB, KEEP, ASYNC = 4, 1, 2, 8, 16, 32
 
 

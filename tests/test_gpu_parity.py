@@ -985,6 +985,89 @@ def test_filter_leaf_paths_mixed_buses_filter_shapes_and_short_fragments(oracle_
     assert first_diff(outs[0], outs[1]) is None
 
 
+@pytest.mark.parametrize("f2vpw", [1, 8, 32, 36, 48, 64])
+def test_osc2_filter_leaf_launch_shapes_at_bench_batch_match_oracle(oracle_lib, monkeypatch, f2vpw):
+    """Round 6: k_leaf_osc2filtpan, the quiet kernel of wtosc; wtosc (adding); filter12; panmix (rounds 2-5 rendered
+    that voice through the records / window kernels whether or not it carried records), at the batch length bench.py
+    times, 2 x 256 fragments against the oracle, over the shapes the launcher may pick - 1 voice per workgroup ... 36
+    (every oscillator wavefront in its all-settled loop, FILT2_FASTV = 3 voices each) - and two it does not, 48 and 64
+    (wavefronts with 4 - 6 voices: past FILT2_FASTV, the general loop renders settled voices too)."""
+    monkeypatch.setenv("A2AMD_F2VPW", str(f2vpw))
+
+    def build(be):
+        sc = synth.Scene(be)
+        sc.root()
+        sc.add_voices(900, chain="osc2-filter-pan", total=4096)
+        return sc
+    gpu = make_gpu(max_batch=256)
+    got = _async_steps(gpu, build(gpu), 2, 256)
+    gpu.close()
+    want = _oracle_fragments(oracle_lib, build, 512)
+    assert want.any()
+    assert first_diff(got, want) is None
+
+
+@pytest.mark.parametrize("f2vpw", [4, 36, 64])
+@pytest.mark.parametrize("no_moving", ["1", ""])
+def test_osc2_filter_leaf_paths_mixed_buses_filter_shapes_and_short_fragments(oracle_lib, monkeypatch, f2vpw, no_moving):
+    """k_leaf_osc2filtpan's paths side by side (the one-oscillator kernel's test above, with the second oscillator):
+    wavefronts whose voices are all settled next to wavefronts with a voice whose FIRST oscillator, SECOND oscillator,
+    q or pan is on its way somewhere (the general loop: the oscillator through osc_fragment_s, exact for any state);
+    workgroups on one bus / straddling buses; pure low pass / band and high pass mixed in; full fragments, short
+    ones, single frames.  no_moving = 1 (A2AMD_NO_MOVING): gliding voices stay this kernel's; otherwise they get the
+    stand-in record and the window kernels take them for as long as they glide (and the quiet kernel skips them)."""
+    monkeypatch.setenv("A2AMD_F2VPW", str(f2vpw))
+    if no_moving:
+        monkeypatch.setenv("A2AMD_NO_MOVING", no_moving)
+    outs = []
+    for be in (make_gpu(max_batch=32), make_oracle(oracle_lib)):
+        sc = synth.Scene(be)
+        sc.root()
+        groups = [sc.add_bus_group() for _ in range(3)]
+        for g, n in zip(groups, (37, 100, 203)):
+            sc.add_voices(n, chain="osc2-filter-pan", group=g, total=1024)
+        sc.add_voices(150, chain="osc2-filter-pan", total=1024)
+        leaves = [u for g in groups for u in g["leaves"]] + sc.leaves
+        for k, units in enumerate(leaves):
+            osca, oscb, filt, pan = units
+            if 128 <= k < 200 and k % 3 == 0:        # band / high pass mixed in: the full output expression
+                be.unit_write(filt, 3, synth.fix(0.4))
+                be.unit_write(filt, 4, synth.fix(-0.3))
+            if k % 53 == 7:                          # q on its way somewhere for 40 ms
+                be.unit_write(filt, 1, synth.fix(9.0), 0, 40 << 8)
+            if k % 61 == 11:                         # amplitude ramp on the first oscillator
+                be.unit_write(osca, 2, synth.fix(0.001), 0, 25 << 8)
+            if k % 59 == 5:                          # pitch glide on the second: across a mip level for some
+                be.unit_write(oscb, 1, synth.fix(((k % 61) - 30) / 12.0 + 1.3), 0, 30 << 8)
+            if k % 47 == 9:                          # amplitude ramp on the second only
+                be.unit_write(oscb, 2, synth.fix(0.0007), 0, 33 << 8)
+            if k % 43 == 3:                          # pan sweep past the clamp
+                be.unit_write(pan, 1, synth.fix(1.4), 0, 20 << 8)
+        a = sc.run(40, batch=32, frames=64)
+        b = sc.run(7, batch=32, frames=23)
+        c = sc.run(3, batch=32, frames=1)
+        d = sc.run(36, batch=32, frames=64)
+        outs.append(np.concatenate([a, b, c, d], axis=1))
+        be.close()
+    assert outs[1].any()
+    assert first_diff(outs[0], outs[1]) is None
+
+
+def test_subtractive_note_at_full_size_matches_oracle_golden():
+    """16 384 x wtosc; wtosc; filter12; panmix (round 5's review: the shape of every benchmark/k2*.a2s lead, "a quiet
+    kernel of its own") at FULL size, 2 steps of 256 fragments, against the per-fragment hashes the CPU oracle
+    rendered in the build container (tests/golden/make_bench_golden.py)."""
+    import bench
+    want = np.load(bench.golden_path(16384, "osc2-filter-pan", 0))
+    gpu = make_gpu(max_batch=256)
+    sc = bench.build_scene(gpu, 16384, "osc2-filter-pan", 0)
+    got = fnv1a_fragments(_async_steps(gpu, sc, 2, 256))
+    gpu.close()
+    assert len(want) >= len(got)
+    bad = np.nonzero(got != want[:len(got)])[0]
+    assert not len(bad), f"{len(bad)} fragments differ, first {bad[:8]}"
+
+
 @pytest.mark.parametrize("config", [1, 2, 3])
 def test_baseline_configs_at_full_size_match_oracle_golden(config):
     """BASELINE configs[1..3] at FULL size (1 024 / 16 384 / 65 536 voices, 512
