@@ -7,7 +7,12 @@
 #pragma once
 #include <stdint.h>
 
-#define A2D_MAXCHAIN   8      // units per voice (A2AMD_MAXCHAIN)
+#define A2D_MAXCHAIN   16     // units per voice (A2AMD_MAXCHAIN).  Round 6: 8 -> 16, what a record's 4-bit chain position
+			      // (A2D_RUNIT) addresses; the reference's unit list has no cap (core.c:163-300)
+#define A2D_CHAIN_INLINE 8    // ... of which the voice record (A2DVoice: one 64-byte line that every kernel reads per voice) holds
+			      // the first 8; units 8 - 15 of a longer chain stand in a side array only the general kernel reads
+			      // (A2DVoiceExt).  (First cut: unit[16] in the record itself, 96 bytes - k_leaf_oscfiltpan 0.5539 against
+			      // 0.5505 ms, k_leaf_osc2pan 2.198 against 2.186 ms, same box, interleaved x 3: profiles/r06_maxchain_ab.txt)
 #define A2D_MAXBATCH 256
 #define A2D_USTATE    24      // int32 words of device state per unit
 #define A2D_MAXCH      8
@@ -88,11 +93,14 @@ struct A2DWave {
 // one voice = one unit chain (host owned)
 struct A2DVoice {
 	int32_t nunits;
-	int32_t unit[A2D_MAXCHAIN];	// indices into udesc[] / ustate[]
+	int32_t unit[A2D_CHAIN_INLINE];	// indices into udesc[] / ustate[]; the chain's further units: A2DVoiceExt
 	int32_t out_off, out_nch;	// bus the wired outputs add into (int32 offset into busmem)
 	int32_t own_off, own_nch;	// bus our 'inline' unit collects children in, or -1
 	int32_t pad[3];
 };
+
+static_assert(sizeof(A2DVoice) == 64, "the voice record is one 64-byte line");
+struct A2DVoiceExt { int32_t unit[A2D_MAXCHAIN - A2D_CHAIN_INLINE]; };	// [voice slot], where a context has a chain > 8 units
 
 // command record, 16 bytes
 struct A2DRec {
@@ -192,6 +200,7 @@ enum { XW_SLOT = 0, XW_MODE = 1 };
 
 struct A2DParams {
 	const A2DVoice *voices;
+	const A2DVoiceExt *vext;	// units 8 - 15 of the chains that have them, or null (no such chain in the context)
 	const uint32_t *udesc;
 	int32_t        *ustate;		// [unit][A2D_USTATE]
 	int32_t        *vactive;	// [voice slot]
@@ -219,12 +228,26 @@ int a2d_launch_vm(const A2DVmParams &vp, int emit, void *stream);
 // classes) - one per window that begins inside a fragment - added to *out
 int a2d_launch_vm_pool(const A2DVmParams &vp, unsigned *out, void *stream);
 #define A2D_WIN_STAGED 2	/* further windows of a fragment a control lane keeps in LDS (WIN_EXL, a2amd_winctl.h) */
+// Where k_vm_win leaves the state it has stepped - the voices' VM state, their units' control words, which of them are
+// the quiet kernels' this batch (runs[]), the fault count.  Normally the live arrays; a SPECULATIVE pass (round 6,
+// vm_speculate: the next batch's VM + control work done behind this batch, while the engine thread walks) leaves it in
+// shadow arrays of the same shape, and k_vm_commit moves it over when the batch turns out to be the one predicted.
+struct A2DVmwOut {
+	A2DVmVoice *vmv;	// [vm slot]
+	int        *ustate;	// [unit][A2D_USTATE]
+	int        *vactive;	// [voice slot]
+	A2DRun     *runs;	// [voice slot]
+	uint32_t   *total;	// [1] += voices that faulted
+};
+// a speculative pass's results into the live state: the voices of window class (nosc, filt) in vp.list (vm slots)
+int a2d_launch_vm_commit(const A2DVmParams &vp, const A2DParams &hp, int nosc, int filt, const A2DVmwOut &from, void *stream);
 // k_vm_win (a2amd_vmwin.hip): the VM voices of one window class (vp.list: their VM slots in the order of the
 // class's voice list, vp.n) run through fragments [fa, fb) and write the window entries themselves - no records.
 // now_fa: engine time of fragment fa's first frame, batch_end: of the batch's end; runs[voice].count says
 // afterwards whose the voice is this batch (0: the quiet kernels').  Returns -1 for a class without a kernel.
 int a2d_launch_vm_win(const A2DVmParams &vp, const A2DParams &hp, int nosc, int filt, int fa, int fb, uint32_t now_fa,
-		uint32_t batch_end, int *wslot, int *wext, int *wscr, unsigned *widx, unsigned *wtop, unsigned wcap, void *stream);
+		uint32_t batch_end, int *wslot, int *wext, int *wscr, unsigned *widx, unsigned *wtop, unsigned wcap, void *stream,
+		const A2DVmwOut *out = nullptr);	// (out: null = the live arrays)
 #define A2D_VMW_ROW (64 - 1 - A2D_WIN_STAGED)	/* entries of wscr per voice of the list (A2D_WIN_WORDS each) */
 
 // launchers implemented in a2amd_kernels.hip (stream = hipStream_t)

@@ -2216,13 +2216,22 @@ __device__ unsigned g_filt_turn[4096];	// FILT_ROT == 2: workgroups arriving on 
 // 39e9eb94cc881251 -> 97b9066429681ca1), the same 21 858 instructions, the same 73 scratch accesses in the same
 // loops, 154 of 160 mnemonic counts equal and the other six off by one: profiles/r06_oscfiltpan_spill_sites.txt.
 // What configs[2] takes on it is measured)
+// Voices an oscillator wavefront of the two-oscillator kernel takes through its all-settled loop: the LAUNCHER deals at
+// most FILT2_LAUNCHV = 3 (a2d_osc2filtpan_max_vpg) - four tap pairs x 3 registers per voice in flight across the barrier
+// (FILT_AHEAD): the 4-voice loop holds 27 - 29 scratch reloads and as many vmcnt(0) stalls per trip
+// (profiles/r06_oscfiltpan_spill_sites.txt) and MEASURED 3.5x slower (16 384 voices x 256 fragments: 48 voices per
+// workgroup = 4 per wavefront 3.83 ms, 32 = 2 - 3 per wavefront 1.09 ms, 64 = 5 - 6 per wavefront, general loop, 1.50 ms;
+// profiles/r06_osc2filtpan_shapes.txt).  The KERNEL is nevertheless built with the 4-voice loop in it (FILT2_FASTV 4;
+// a shape forced by A2AMD_F2VPW reaches it, the parity tests do): built WITHOUT it (FILT2_FASTV 3) the same 32-voice
+// shape takes 1.34 ms instead of 1.08 - same box, interleaved, three runs each, and once more on another box
+// (profiles/r06_fastv_build_ab.txt) - although the 2- and 3-voice loops and the filter wavefront's loop it executes
+// are the same code in both builds (same instruction counts and event order: tools/r06 notes in DESIGN 6).  Where the
+// code sits is what is left; NOT understood, and kept because it is measured.
 #ifndef FILT2_FASTV
-// most voices an oscillator wavefront of the two-oscillator kernel takes through its all-settled loop.  3: four tap
-// pairs x 3 registers per voice in flight across the barrier (FILT_AHEAD) - with 4 voices the loop holds 27 - 29
-// scratch reloads per trip (profiles/r06_oscfiltpan_spill_sites.txt) and MEASURED 3.5x slower than with 3
-// (16 384 voices x 256 fragments: 48 voices per workgroup = 4 per wavefront 3.83 ms, 32 = 2 - 3 per wavefront 1.09 ms,
-// 64 = 5 - 6 per wavefront, general loop, 1.50 ms; profiles/r06_osc2filtpan_shapes.txt)
-#define FILT2_FASTV 3
+#define FILT2_FASTV 4
+#endif
+#ifndef FILT2_LAUNCHV
+#define FILT2_LAUNCHV 3
 #endif
 template<int NOSC>
 DEV void oscfiltpan_body(const A2DParams *__restrict__ pp, const int *__restrict__ list, int nlist, int vpg,
@@ -3427,7 +3436,7 @@ int a2d_launch_leaf_oscfiltpan(const A2DParams *dparams, const A2DParams &hp, co
 int a2d_osc2filtpan_max_vpg(void)
 {
 	const int nfull = FILT_WAVES - 1 - (FILT_WAVES / 4 - 1);
-	const int v = nfull * FILT2_FASTV;
+	const int v = nfull * (FILT2_LAUNCHV < FILT2_FASTV ? FILT2_LAUNCHV : FILT2_FASTV);
 	return v > FILT_MAXV ? FILT_MAXV : v;
 }
 

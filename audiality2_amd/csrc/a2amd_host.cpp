@@ -95,12 +95,18 @@ void a2amd_close(a2amd_ctx *c)
 		return;
 	use_device(c);
 	hipStreamSynchronize(c->stream);
+	// (round 6) ... and the device VM's speculative pass: launched behind the LAST batch on a non-blocking stream of its
+	// own, waited for by nobody if no batch follows, and reading voices / unit state / runs - which are freed below,
+	// before vm_close() gets to its stream (hipFree does not wait for it: a memory access fault at exit, intermittent,
+	// in every short render with device VM voices)
+	if(c->vm.pred_stream)
+		hipStreamSynchronize(c->vm.pred_stream);
 	drop_graphs(c);
 	if(c->comm && g_rccl.CommDestroy)
 		g_rccl.CommDestroy(c->comm);
 	if(c->grp_ev)
 		hipEventDestroy(c->grp_ev);
-	hipFree(c->d_voices.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
+	hipFree(c->d_voices.d); hipFree(c->d_vext.d); hipFree(c->d_udesc.d); hipFree(c->d_ustate.d); hipFree(c->d_ustage.d);
 	hipFree(c->d_vactive.d); hipFree(c->d_runs.d); hipFree(c->d_recs.d);
 	hipFree(c->d_win.d); hipFree(c->d_wext.d); hipFree(c->d_wscr.d); hipFree(c->d_wrc.d); hipFree(c->d_widx.d); hipFree(c->d_wtop);
 	if(c->h_wtop)

@@ -284,6 +284,49 @@ struct VmHost {
 	uint32_t pred_span = 0;		// frames
 	size_t pred_entries = 0;	// ... of the batch being issued (fused)
 	uint64_t pred_why[7] = { 0, 0, 0, 0, 0, 0, 0 };	// batches by what kept them from being fused (0: nothing)
+	// Round 6: the prediction does the WORK.  k_vm_win is one wavefront's serial trip per 64 voices - 0.5 - 0.64 ms per
+	// 64 fragments whatever the voice count - and stood in front of every scripted batch's render pass while the
+	// engine thread waited.  vm_speculate (in vm_predict's place when the batch is whole 64-frame fragments) runs the
+	// class voices' VMs AND their control state through the batch expected next, behind this batch's leaf kernels,
+	// on pred_stream: window entries into a slot set and pool of its own (d_swin ...), the stepped state into shadow
+	// arrays (A2DVmwOut).  A batch that is exactly the one predicted (vm_issue: same lists, same time, same fragments;
+	// no overflow, no fault) takes it: k_vm_commit moves the shadows over, the render pass reads the speculative
+	// slots, k_vm_win is not launched.  Any other batch ignores it - nothing live was touched - and still has the
+	// pool bound k_vm_pool would have given it (the pass's own counter, h_spec[0]).  A2AMD_VMSPEC=0: off.
+	// (two sets of slots and pool: the pass for batch N + 1 runs beside the render pass of batch N, which may be reading
+	// the set the pass for N wrote; spec_set = the one the last pass wrote)
+	DevBuf<int> d_swin[2], d_swext[2], d_swscr;
+	DevBuf<unsigned> d_swidx[2];
+	int spec_set = 0;
+	bool spec_launched_now = false;		// vm_speculate has run for the batch being issued (issue_kernels asks once)
+	unsigned *d_swtop = nullptr;		// [2]: entries taken, overflow flag
+	DevBuf<A2DVmVoice> d_vmv_sh;
+	DevBuf<int> d_ustate_sh, d_vactive_sh;	// (d_ustate_sh.cap in units, like d_ustate's)
+	DevBuf<A2DRun> d_runs_sh;
+	uint32_t *d_stotal = nullptr;		// [2]: (unused), voices that faulted
+	unsigned *h_spec = nullptr;		// pinned: d_swtop[0..1], d_stotal[0..1]
+	bool spec_valid = false;		// a pass was launched for the prediction pred_* describe
+	bool spec_use = false;			// this batch: taken (vm_issue decides, issue_windows commits + renders)
+	int spec_nfrags = 0, spec_cls[3] = { 0, 0, 0 };
+	uint8_t spec_ff[A2D_MAXBATCH], spec_fb[A2D_MAXBATCH];	// the fragments the pass was run for (frames, offset in the engine's)
+	uint32_t cut_hint[16];			// a2amd_vm_expect_cuts: engine times at which the root's VM wakes next
+	int n_cut_hint = 0;
+	size_t spec_cap = 0;			// pool entries the pass had room for
+	size_t spec_demand = 0;			// ... and what the last pass that was looked at asked for (true also when it overflowed)
+	uint64_t spec_launched = 0, spec_taken = 0, spec_overflows = 0;
+	// why a batch was not followed by a pass (0 switched off / no class voices / capturing, 1 a fragment that is not a
+	// whole one, 2 the slots would not fit the budget) and why a pass was not taken (0 the batch was not the one
+	// predicted - vm_issue's own reasons, 1 other fragments or class counts, 2 the pool overflowed, 3 a voice faulted)
+	uint64_t spec_skip[4] = { 0, 0, 0, 0 }, spec_miss[4] = { 0, 0, 0, 0 };	// (spec_skip[3]: the lists had only just changed)
+	// A pass in flight reads its slot list (a pointer into d_list, fixed at launch), the VM voices, the code pool: whoever
+	// REWRITES those in place - vm_build_lists when the membership changed, vm_prepare_batch when adopted voices go up -
+	// waits for it first (vm_wait_spec).  A stale pass whose later kernels started behind such a rewrite read voice slots
+	// where VM slots had been and indexed d_vmv past its end: a memory access fault, intermittent, in every scene whose
+	// voices come and go (vmloops.a2s).  So that the wait stays rare, no pass is launched until the lists have stood
+	// for two batches (rebuilt_at): a song whose notes change every buffer launches none.
+	uint64_t spec_waits = 0;
+	uint64_t rebuilt_at = 0;	// vm_batches when the lists were last rebuilt (a steady batch takes upload()'s quiet path and
+				// never comes by vm_build_lists: stability is counted in batches issued, not in calls there)
 	bool list_dirty = false;
 	std::vector<std::pair<int, A2DVmVoice>> to_upload;	// (slot, state) going up with this batch
 	uint32_t t0 = 0;		// engine time of the context's frame 0 (walk_time = 0)
@@ -389,6 +432,8 @@ struct a2amd_ctx {
 
 	// host mirrors of host-owned device tables
 	std::vector<A2DVoice> mvoices;
+	std::vector<A2DVoiceExt> mvext;		// units 8 - 15, once a chain of the context has them (long_chains)
+	bool long_chains = false;
 	std::vector<uint32_t> mudesc;
 	std::vector<A2DWave> mwaves;
 	bool voices_dirty = true, udesc_dirty = true, waves_dirty = true, lists_dirty = true, ptab_dirty = true;
@@ -427,6 +472,7 @@ struct a2amd_ctx {
 	std::vector<int> free_wave_slots, deferred_wave_slots;
 
 	DevBuf<A2DVoice> d_voices;
+	DevBuf<A2DVoiceExt> d_vext;
 	DevBuf<uint32_t> d_udesc;
 	DevBuf<int32_t> d_ustate;	// cap in units
 	DevBuf<int32_t> d_ustage;	// staging copy for time-sliced kernels
@@ -558,6 +604,13 @@ int grow(a2amd_ctx *c, DevBuf<T> &b, size_t need, size_t elem_mult, bool keep)
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 	if(b.d) {
 		HIPCHK(c, hipStreamSynchronize(c->stream));
+		// (round 6) ... and the device VM's speculative pass, on a non-blocking stream of its own, may still be READING
+		// the old array through a pointer it was launched with - voices, unit state, VM voices, code, lists - long after
+		// the batch it was launched behind is done: a pass that is not taken is not waited for anywhere else.  (Found as a
+		// memory access fault in vmloops.a2s at a2_Run(4096) - notes being born while a stale pass ran - that went away
+		// when every launch was waited for, A2AMD_WIN_SYNC=1.)  Arrays grow rarely: the wait costs nothing in a steady scene.
+		if(c->vm.pred_stream)
+			HIPCHK(c, hipStreamSynchronize(c->vm.pred_stream));
 		HIPCHK(c, hipFree(b.d));
 	}
 	b.d = nd;
@@ -622,6 +675,10 @@ int vm_issue(a2amd_ctx *c, bool fused);		// issue_kernels(): the VM kernel's two
 void vm_class_params(a2amd_ctx *c, int k, A2DVmParams *vp);	// k_vm_win's parameters for a window class
 int vm_fused_done(a2amd_ctx *c);		// ... and its fault count on its way back
 int vm_predict(a2amd_ctx *c);			// k_vm_pool for the batch after this one (issue_kernels, behind the window kernels)
+bool vm_spec_wanted(a2amd_ctx *c);		// round 6: may a speculative pass follow the batch being issued?
+// ... and over which fragments: the span of this batch again, cut where the root's VM is expected to wake (cut_hint)
+bool vm_spec_plan(a2amd_ctx *c, int *nfrags, uint8_t *ff, uint8_t *fb);
+int vm_speculate(a2amd_ctx *c);			// ... k_vm_win for the batch after this one, into shadows (behind the leaf kernels)
 int vm_take_back(a2amd_ctx *c, int vi, bool inclusive, a2amd_vm_state *out, a2amd_vm_env *envs_out = nullptr);	// the voice is the host's again
 void vm_end_batch(a2amd_ctx *c);
 void vm_close(a2amd_ctx *c);

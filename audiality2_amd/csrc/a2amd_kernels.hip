@@ -976,7 +976,31 @@ DEV void flush_otile(Ctx &c, int out_off, int out_nch)
 	}
 }
 
-DEV void process_window(Ctx &c, const A2DVoice &v, int offset, int frames)
+// a voice record with the whole chain in it (this kernel renders chains of up to A2D_MAXCHAIN units)
+struct VoiceFull {
+	int32_t nunits;
+	int32_t unit[A2D_MAXCHAIN];
+	int32_t out_off, out_nch, own_off, own_nch;
+};
+DEV VoiceFull load_voice(const A2DParams &p, int slot)
+{
+	const A2DVoice b = p.voices[slot];
+	VoiceFull v;
+	v.nunits = b.nunits;
+#pragma unroll
+	for(int k = 0; k < A2D_MAXCHAIN; ++k)
+		v.unit[k] = k < A2D_CHAIN_INLINE ? b.unit[k] : 0;
+	if(b.nunits > A2D_CHAIN_INLINE && p.vext) {
+		const A2DVoiceExt e = p.vext[slot];
+#pragma unroll
+		for(int k = A2D_CHAIN_INLINE; k < A2D_MAXCHAIN; ++k)
+			v.unit[k] = e.unit[k - A2D_CHAIN_INLINE];
+	}
+	v.out_off = b.out_off; v.out_nch = b.out_nch; v.own_off = b.own_off; v.own_nch = b.own_nch;
+	return v;
+}
+
+DEV void process_window(Ctx &c, const VoiceFull &v, int offset, int frames)
 {
 	for(int u = 0; u < v.nunits; ++u) {
 		uint32_t desc = c.p->udesc[v.unit[u]];
@@ -1046,7 +1070,7 @@ void k_voices(const A2DParams *__restrict__ pp, const int *__restrict__ list, in
 		c.frag = f;
 		for(int vi = first; vi < last; ++vi) {
 			const int slot = list[vi];
-			const A2DVoice v = p.voices[slot];
+			const VoiceFull v = load_voice(p, slot);
 			const A2DRun run = p.runs[slot];
 			if(v.out_off != cur_off) {
 				flush_otile(c, cur_off, cur_nch);

@@ -3,6 +3,7 @@
 // the launch shapes, hipGraphs of quiet batches, and the end of a batch.  (Split out of
 // a2amd_host.cpp in round 3; the design notes are at the top of that file.)
 #include "a2amd_host.h"
+#include <functional>
 
 namespace a2h {
 
@@ -178,8 +179,18 @@ void sync_voice_mirror(a2amd_ctx *c, int vi)
 	A2DVoice &m = c->mvoices[vi];
 	memset(&m, 0, sizeof(m));
 	m.nunits = v.nunits;
-	for(int i = 0; i < v.nunits; ++i)
+	for(int i = 0; i < v.nunits && i < A2D_CHAIN_INLINE; ++i)
 		m.unit[i] = v.unit[i];
+	if(v.nunits > A2D_CHAIN_INLINE)
+		c->long_chains = true;
+	if(c->long_chains) {
+		if(c->mvext.size() <= (size_t)vi)
+			c->mvext.resize(vi + 1);
+		A2DVoiceExt &e = c->mvext[vi];
+		memset(&e, 0, sizeof(e));
+		for(int i = A2D_CHAIN_INLINE; i < v.nunits; ++i)
+			e.unit[i - A2D_CHAIN_INLINE] = v.unit[i];
+	}
 	m.out_off = v.out_off;
 	m.out_nch = v.out_nch;
 	m.own_off = v.own_off;
@@ -445,6 +456,18 @@ int upload(a2amd_ctx *c)
 		if(hi >= lo)
 			HIPCHK(c, hipMemcpyAsync(c->d_voices.d + lo, c->mvoices.data() + lo,
 					(size_t)(hi - lo + 1) * sizeof(A2DVoice), hipMemcpyHostToDevice, c->stream));
+		if(c->long_chains) {
+			// (the first chain of more than 8 units: the side array comes into being, whole; from then on it follows the
+			// voice table's dirty span)
+			const bool fresh = c->d_vext.cap < c->d_voices.cap;
+			if(int r = grow(c, c->d_vext, c->d_voices.cap, 1, true)) return r;
+			if(c->mvext.size() < nv)
+				c->mvext.resize(nv);
+			const int elo = fresh ? 0 : lo, ehi = fresh ? (int)nv - 1 : hi;
+			if(ehi >= elo)
+				HIPCHK(c, hipMemcpyAsync(c->d_vext.d + elo, c->mvext.data() + elo,
+						(size_t)(ehi - elo + 1) * sizeof(A2DVoiceExt), hipMemcpyHostToDevice, c->stream));
+		}
 		c->voices_dirty = false;
 	}
 	if(c->udesc_dirty && nu) {
@@ -785,6 +808,7 @@ int upload(a2amd_ctx *c)
 	A2DParams p;
 	memset(&p, 0, sizeof(p));
 	p.voices = c->d_voices.d;
+	p.vext = c->long_chains ? c->d_vext.d : nullptr;
 	p.udesc = c->d_udesc.d;
 	p.ustate = c->d_ustate.d;
 	p.vactive = c->d_vactive.d;
@@ -1050,16 +1074,21 @@ bool depth_has_mutes(const a2amd_ctx *c, int d)
 // of the batch the control pass of every list, then the render pass of every list.  A slot per fragment
 // and voice, a pool of further windows sized by the bound the control pass allocates by (one per record);
 // a batch whose slots would not fit A2AMD_WIN_MB (1 024) is cut into slabs of fragments.
-static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *counts)
+static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *counts, const std::function<int()> &mid)
 {
-	struct Job { int nosc, filt, n, skip; const int *list; int vmk; };	// vmk >= 0: a class of VM voices run by k_vm_win
+	const int sset = c->vm.spec_set;	// (the speculative slot set a taken pass wrote: mid() may launch the next pass)
+	// vmk >= 0: a class of VM voices run by k_vm_win; spec: ... that a speculative pass has already run for this batch
+	// (vm_issue took it): its entries stand in the pass's own slot set and pool, at (sat, satw) - no control pass, no
+	// room in this batch's slot memory, k_vm_commit in k_vm_win's place
+	struct Job { int nosc, filt, n, skip; const int *list; int vmk; bool spec; size_t sat, satw; };
 	static const int nosc[4] = { 1, 2, 1, 2 }, filt[4] = { 0, 0, 1, 1 };
 	Job jobs[7];
 	int nj = 0;
-	size_t nvoices = 0;
+	size_t nvoices = 0;		// ... of the jobs that take slots here
+	const bool spec = c->vm.fused && c->vm.spec_use;
 	for(int k = 0; k < 4; ++k)
 		if(counts[k]) {
-			jobs[nj++] = Job{ nosc[k], filt[k], counts[k], k == 3, lists[k], -1 };	// (k == 3: see upload(), dyn_f2)
+			jobs[nj++] = Job{ nosc[k], filt[k], counts[k], k == 3, lists[k], -1, false, 0, 0 };	// (k == 3: see upload(), dyn_f2)
 			nvoices += (size_t)counts[k];
 		}
 	// (the control pass takes room in the pool by the length of a voice's record run: every gliding voice's run is
@@ -1068,21 +1097,25 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 	size_t nfusedv = 0;
 	if(!c->vm.list.empty()) {
 		const int *l = c->vm.d_list.d + c->vm.list.size();
+		size_t sat = 0, satw = 0;	// (the speculative pass's layout: the three classes one after the other, vm_speculate)
 		for(int k = 0; k < 3; l += c->vm.n_cls[k++])
 			if(c->vm.n_cls[k]) {
-				jobs[nj++] = Job{ nosc[k], filt[k], c->vm.n_cls[k], 1, l, c->vm.fused ? k : -1 };
-				nvoices += (size_t)c->vm.n_cls[k];
-				if(c->vm.fused)
+				jobs[nj++] = Job{ nosc[k], filt[k], c->vm.n_cls[k], 1, l, c->vm.fused ? k : -1, spec, sat, satw };
+				if(!spec)
+					nvoices += (size_t)c->vm.n_cls[k];
+				if(c->vm.fused && !spec)
 					nfusedv += (size_t)c->vm.n_cls[k];
+				sat += (size_t)c->vm.n_cls[k] * (size_t)c->nfrags;
+				satw += (size_t)c->vm.n_cls[k] * (size_t)c->nfrags * A2D_WIN_SLOTWORDS(nosc[k], filt[k]);
 			}
 		nrec += c->vm.last_total;
 	}
 	// (k_vm_win takes pool room as its voices' VMs make further windows: how much was counted ahead, by k_vm_pool
 	// behind the last batch - vm_issue, a2amd_vm.cpp - for exactly this batch)
-	if(nfusedv) {
+	if(nfusedv)
 		nrec += c->vm.pred_entries + 64;
+	if(nfusedv || spec)
 		++c->vm.fused_batches;
-	}
 	if(!nj)
 		return 0;
 	if(c->wtop_pending) {
@@ -1108,15 +1141,18 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 	// fraction of its pace - so slabs are what the memory bound asks for, not the default)
 	static const int want_slabs = getenv("A2AMD_WIN_SLABS") ? std::max(1, atoi(getenv("A2AMD_WIN_SLABS"))) : 1;
 	const int nfrags = c->nfrags;
-	int per = nfrags >= 16 ? (nfrags + want_slabs - 1) / want_slabs : nfrags;
-	if(nvoices * (size_t)per > budget)
+	// (a taken speculative pass covers the batch in one piece: with it, the lists that do take slots here are not cut
+	// into slabs for the asking - A2AMD_WIN_SLABS - only where the memory bound demands it)
+	int per = nfrags >= 16 && !spec ? (nfrags + want_slabs - 1) / want_slabs : nfrags;
+	if(nvoices && nvoices * (size_t)per > budget)
 		per = (int)std::max<size_t>(1, budget / nvoices);
 	const int nslabs = (nfrags + per - 1) / per;
 	const bool two = nslabs > 1;
 	const size_t nslots = nvoices * (size_t)per, cap = std::max<size_t>(nrec, 1);
 	size_t slotwords = 0;		// of a slab: every list's slots at its class's size
 	for(int j = 0; j < nj; ++j)
-		slotwords += (size_t)jobs[j].n * (size_t)per * A2D_WIN_SLOTWORDS(jobs[j].nosc, jobs[j].filt);
+		if(!jobs[j].spec)
+			slotwords += (size_t)jobs[j].n * (size_t)per * A2D_WIN_SLOTWORDS(jobs[j].nosc, jobs[j].filt);
 	if(cap >= ((size_t)1 << 32))
 		return c->fail(A2AMD_EUNSUPPORTED, "a batch of %zu records", cap);
 	const size_t sets = two ? 2 : 1;
@@ -1156,7 +1192,16 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 	auto control = [&](const Job &b, int fa, int fb, int *wslot, int *wext, unsigned *widx, unsigned *wtop, unsigned wcap, int *wrc,
 			hipStream_t st) -> int {
 		int r;
-		if(b.vmk >= 0) {
+		if(b.spec) {
+			// the speculative pass has done this job's control work: its results become the state (once: the first slab)
+			if(fa != 0)
+				return 0;
+			A2DVmParams vp;
+			vm_class_params(c, b.vmk, &vp);
+			VmHost &m = c->vm;
+			const A2DVmwOut from = { m.d_vmv_sh.d, m.d_ustate_sh.d, m.d_vactive_sh.d, m.d_runs_sh.d, m.d_stotal };
+			r = a2d_launch_vm_commit(vp, c->hparams, b.nosc, b.filt, from, st);
+		} else if(b.vmk >= 0) {
 			A2DVmParams vp;
 			vm_class_params(c, b.vmk, &vp);
 			size_t before = 0;	// (voices of the classes in front of this one: their rows of d_wscr)
@@ -1172,7 +1217,8 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 		if(dbgsync && !r && !c->capturing) {
 			const hipError_t e = hipStreamSynchronize(st);
 			fprintf(stderr, "a2amd windows: control pass <%d,%d> %s of %d voices, fragments [%d, %d): %s\n", b.nosc, b.filt,
-					b.vmk >= 0 ? "k_vm_win" : "k_win_ctl", b.n, fa, fb, hipGetErrorString(e));
+					b.spec ? "k_vm_commit (speculative pass taken)" : b.vmk >= 0 ? "k_vm_win" : "k_win_ctl", b.n, fa, fb,
+					hipGetErrorString(e));
 		}
 		return r;
 	};
@@ -1204,14 +1250,18 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 			if(control(b, 0, nfrags, c->d_win.d + atw, c->d_wext.d, c->d_widx.d + at, c->d_wtop,
 					(unsigned)std::min<size_t>(c->d_wext.cap, 0xffffffffu), c->d_wrc.d + atv, sj))
 				return c->fail(A2AMD_EHIP, "window control launch failed: %s", hipGetErrorString(hipGetLastError()));
-			if(a2d_launch_win_render(c->hparams, b.nosc, b.filt, b.list, b.n, 0, nfrags, c->d_win.d + atw,
-					c->d_wext.d, c->d_widx.d + at, sj))
+			if(b.spec ? a2d_launch_win_render(c->hparams, b.nosc, b.filt, b.list, b.n, 0, nfrags, c->vm.d_swin[sset].d + b.satw,
+						c->vm.d_swext[sset].d, c->vm.d_swidx[sset].d + b.sat, sj) :
+					a2d_launch_win_render(c->hparams, b.nosc, b.filt, b.list, b.n, 0, nfrags, c->d_win.d + atw,
+						c->d_wext.d, c->d_widx.d + at, sj))
 				return c->fail(A2AMD_EHIP, "window render launch failed: %s", hipGetErrorString(hipGetLastError()));
 			HIPCHK(c, hipEventRecord(c->win_fev[j], sj));
 			HIPCHK(c, hipStreamWaitEvent(c->stream, c->win_fev[j], 0));
-			at += (size_t)b.n * (size_t)nfrags;
-			atw += (size_t)b.n * (size_t)nfrags * A2D_WIN_SLOTWORDS(b.nosc, b.filt);
-			atv += (size_t)b.n;
+			if(!b.spec) {
+				at += (size_t)b.n * (size_t)nfrags;
+				atw += (size_t)b.n * (size_t)nfrags * A2D_WIN_SLOTWORDS(b.nosc, b.filt);
+				atv += (size_t)b.n;
+			}
 			c->stats.launches += 2;
 		}
 		forked = true;
@@ -1238,6 +1288,8 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 			if(control(b, fa, fb, wslot + atw, wext, widx + at, wtop,
 					(unsigned)std::min<size_t>(two ? half_ext : c->d_wext.cap, 0xffffffffu), c->d_wrc.d + atv, sc))
 				return c->fail(A2AMD_EHIP, "window control launch failed: %s", hipGetErrorString(hipGetLastError()));
+			if(b.spec)
+				continue;	// (no slots of this batch's: the speculative pass's own)
 			at += (size_t)b.n * (size_t)(fb - fa);
 			atw += (size_t)b.n * (size_t)(fb - fa) * A2D_WIN_SLOTWORDS(b.nosc, b.filt);
 			atv += (size_t)b.n;
@@ -1249,9 +1301,23 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 		}
 		if(wtiming && !two && !c->capturing)
 			HIPCHK(c, hipEventRecord(tev[1], c->stream));
+		// (one slab, one stream: the batch's other leaf kernels and the speculative pass for the next batch go here, the
+		// render passes behind them - issue_kernels)
+		if(nslabs == 1 && !wtiming)
+			if(int r = mid())
+				return r;
 		at = atw = 0;
 		for(int j = 0; j < nj; ++j) {
 			const Job &b = jobs[j];
+			if(b.spec) {
+				// (the whole batch at once, behind the first slab's control passes - the commit among them)
+				if(fa == 0 && a2d_launch_win_render(c->hparams, b.nosc, b.filt, b.list, b.n, 0, nfrags, c->vm.d_swin[sset].d + b.satw,
+						c->vm.d_swext[sset].d, c->vm.d_swidx[sset].d + b.sat, c->stream))
+					return c->fail(A2AMD_EHIP, "window render launch failed: %s", hipGetErrorString(hipGetLastError()));
+				if(fa == 0)
+					++c->stats.launches;
+				continue;
+			}
 			if(a2d_launch_win_render(c->hparams, b.nosc, b.filt, b.list, b.n, fa, fb, wslot + atw,
 					wext, widx + at, c->stream))
 				return c->fail(A2AMD_EHIP, "window render launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1361,156 +1427,191 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 		static const bool vmwin_ok = !(getenv("A2AMD_VMWIN") && !atoi(getenv("A2AMD_VMWIN")));
 		if(int r = vm_issue(c, use_win && vmwin_ok && !c->vm.fused_off))
 			return r;
+		// The batch's other leaf kernels - the quiet kernels of the classes, the records kernels where the window kernels
+		// are not in use, the general kernel - as a block that runs once: normally behind the window kernels, and
+		// (round 6) from INSIDE issue_windows, between its control passes and its render passes, when a speculative VM
+		// pass is to follow: that pass may start as soon as the control passes (k_vm_win / k_vm_commit: the stepped state
+		// of the VM voices that are live this batch) and the quiet kernels (the phases of those that are idle) are done,
+		// and then has the render pass - the long one - beside it, not in front of it.  All of these kernels only ever
+		// ADD to the buses, and runs[] is written by the control passes: their order among themselves is free.
+		bool leaves_done = false;
+		auto leaves = [&]() -> int {
+			if(leaves_done)
+				return 0;
+			leaves_done = true;
+			if(c->n_fast_leaf) {
+				int vpw, ysplit;
+				pick_fast_shape(c->n_fast_leaf, c->nfrags, &vpw, &ysplit);
+				// e1 right behind the main kernel when it is the only leaf kernel
+				// of the batch: "leaf" time is then that kernel alone
+				const bool solo = !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn && !c->n_o2f_leaf;
+				if(a2d_launch_leaf_oscpan(c->d_params, c->hparams, c->d_list.d, c->n_fast_leaf,
+						vpw, ysplit, c->d_ustage.d, c->stream, solo ? (void *)e1 : nullptr, &pend.c[pend.n]))
+					return c->fail(A2AMD_EHIP, "fast leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+				if(pend.c[pend.n].nlist)
+					++pend.n;
+				++c->stats.launches;
+			}
+			if(c->n_osc2_leaf) {
+				int vpw, ysplit;
+				// (its own chunk length; 16 time slices: 2.19 ms against 2.25 with 32 at configs[3], round 3)
+				pick_fast_shape(c->n_osc2_leaf, c->nfrags * A2D_FAST_FCH / A2D_OSC2_FCH, &vpw, &ysplit, 16);
+				if(a2d_launch_leaf_osc2pan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf, c->n_osc2_leaf,
+						vpw, ysplit, c->d_ustage.d, c->stream, &pend.c[pend.n]))
+					return c->fail(A2AMD_EHIP, "2-osc leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+				if(pend.c[pend.n].nlist)
+					++pend.n;
+				++c->stats.launches;
+			}
+			if(c->n_filt_leaf) {
+				// voices per workgroup = lanes of its filter wavefront: all 64 once there
+				// are enough voices for a workgroup on every CU (one 16-wavefront workgroup
+				// per CU), else spread out (a workgroup takes as long as its filter chain,
+				// whatever its voice count)
+				const int nf = c->n_filt_leaf;
+				int vpw = getenv("A2AMD_FVPW") ? atoi(getenv("A2AMD_FVPW")) :
+						std::min(std::max((nf + 255) / 256, 1), 64);
+				if(a2d_launch_leaf_oscfiltpan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf,
+						c->n_filt_leaf, vpw, c->stream))
+					return c->fail(A2AMD_EHIP, "filter leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+				++c->stats.launches;
+			}
+			if(c->n_o2f_leaf) {
+				// 2 x wtosc-filter12-panmix without records (round 6).  A workgroup (16 wavefronts, 128 registers: one per CU)
+				// takes as long as its filter wavefront's chain whatever its voice count, as long as every oscillator
+				// wavefront stays in its all-settled loop (a2d_osc2filtpan_max_vpg voices): the voices are dealt over the
+				// fewest whole rounds of 256 workgroups that allows (16 384 voices: 2 rounds of 32 - measured 1.09 ms per 256
+				// fragments against 3.83 with 48 and 1.50 with 64 voices per workgroup)
+				const int nf = c->n_o2f_leaf;
+				static const int env_vpg = getenv("A2AMD_F2VPW") ? atoi(getenv("A2AMD_F2VPW")) : 0;
+				const int maxv = a2d_osc2filtpan_max_vpg();
+				const int rounds = std::max(1, (nf + 256 * maxv - 1) / (256 * maxv));
+				const int vpg = env_vpg ? env_vpg : std::min(std::max((nf + 256 * rounds - 1) / (256 * rounds), 1), maxv);
+				if(a2d_launch_leaf_osc2filtpan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf +
+						c->n_filt_leaf + c->n_fm_leaf + c->n_leaf, nf, vpg, c->stream))
+					return c->fail(A2AMD_EHIP, "2-osc filter leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+				++c->stats.launches;
+			}
+			int fm_kinds = 0;
+			for(int k = 0; k < 8; ++k)
+				fm_kinds += c->fm_kind_count[k] != 0;
+			if(fm_kinds > 1 && c->n_fm_leaf <= 16384 && !getenv("A2AMD_FMVPW")) {
+				// several kinds, few voices: one launch for all of them (the
+				// per-kind launches below would run back to back, each as long
+				// as a voice's serial chain)
+				if(a2d_launch_leaf_fmpan_all(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf +
+						c->n_filt_leaf, c->fm_kind_count, (c->n_fm_leaf + 1023) / 1024, c->stream))
+					return c->fail(A2AMD_EHIP, "fm leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+				++c->stats.launches;
+			} else
+			for(int k = 0, at = c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf; k < 8; at += c->fm_kind_count[k++]) {
+				const int n = c->fm_kind_count[k];
+				if(!n)
+					continue;
+				// A voice is a serial recurrence: a launch takes as long as its longest
+				// lane, so few voices are spread over many wavefronts (idle lanes of a
+				// wavefront shadow its voices, see fmpan_body) until there is one
+				// wavefront per SIMD (1 024), then the lanes fill up
+				// (profiles/r01_fm_vpw_sweep.txt).
+				int vpw = getenv("A2AMD_FMVPW") ? atoi(getenv("A2AMD_FMVPW")) : (n + 1023) / 1024;
+				vpw = std::min(std::max(vpw, 1), 64);
+				if(a2d_launch_leaf_fmpan(c->d_params, c->hparams, A2AMD_FM1 + k, c->d_list.d + at, n, vpw, c->stream))
+					return c->fail(A2AMD_EHIP, "fm leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+				++c->stats.launches;
+			}
+			if(c->n_leaf) {
+				if(a2d_launch_voices(c->d_params, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf +
+						c->n_fm_leaf, c->n_leaf,
+						pick_vpw(c->n_leaf), c->stream))
+					return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+				++c->stats.launches;
+			}
+			{
+				// (a wavefront walks its voices one after the other, fragment by fragment: as many
+				// wavefronts as the chip holds before a wavefront gets a second voice)
+				auto recs = [&](int nosc, int filt, const int *list, int n, int skip_empty) -> int {
+					if(!n)
+						return 0;
+					int vpw = getenv("A2AMD_RVPW") ? atoi(getenv("A2AMD_RVPW")) : (n + 8191) / 8192;
+					if(a2d_launch_leaf_recs(c->d_params, c->hparams, nosc, filt, list, n, vpw, c->stream, skip_empty))
+						return c->fail(A2AMD_EHIP, "leaf records launch failed: %s", hipGetErrorString(hipGetLastError()));
+					++c->stats.launches;
+					return 0;
+				};
+				const int *const *lists = rlists;
+				const int *counts = rcounts;
+				const int total = rtotal;
+				const int kinds = (counts[0] != 0) + (counts[1] != 0) + (counts[2] != 0) + (counts[3] != 0);
+				if(!use_win) {
+				if(kinds > 1 && total <= 4096 && !getenv("A2AMD_RVPW")) {
+					// few voices of several kinds (a song): one launch - on one stream the per-kind
+					// launches would run back to back, each as long as one voice's walk through the batch
+					if(a2d_launch_leaf_recs_all(c->d_params, c->hparams, lists, counts, 1, c->stream, 8))
+						return c->fail(A2AMD_EHIP, "leaf records launch failed: %s", hipGetErrorString(hipGetLastError()));
+					++c->stats.launches;
+				} else {
+					static const int nosc[4] = { 1, 2, 1, 2 }, filt[4] = { 0, 0, 1, 1 };
+					for(int k = 0; k < 4; ++k)
+						if(int r = recs(nosc[k], filt[k], lists[k], counts[k], k == 3))
+							return r;
+				}
+				// ... and the voices whose records the device VM has just written, by class (those it
+				// left without records this batch were rendered by their quiet kernels above)
+				if(!c->vm.list.empty()) {
+					static const int nosc[3] = { 1, 2, 1 }, filt[3] = { 0, 0, 1 };
+					const int *l = c->vm.d_list.d + c->vm.list.size();
+					for(int k = 0; k < 3; l += c->vm.n_cls[k++]) {
+						const int n = c->vm.n_cls[k];
+						if(!n)
+							continue;
+						int vpw = getenv("A2AMD_RVPW") ? atoi(getenv("A2AMD_RVPW")) : (n + 8191) / 8192;
+						if(a2d_launch_leaf_recs(c->d_params, c->hparams, nosc[k], filt[k], l, n, vpw, c->stream, 1))
+							return c->fail(A2AMD_EHIP, "leaf records launch failed: %s", hipGetErrorString(hipGetLastError()));
+						++c->stats.launches;
+					}
+				}
+				}
+			}
+			if(c->n_dyn_rest > 0) {
+				const int n = c->n_dyn_rest;
+				if(a2d_launch_voices(c->d_params, c->d_dyn + c->n_dyn_osc1 + c->n_dyn_osc2 + c->n_dyn_filt + c->n_dyn_filt2, n,
+						pick_vpw(n), c->stream))
+					return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
+				++c->stats.launches;
+			}
+			return 0;
+		};
+		static const bool spec_early = !(getenv("A2AMD_VMSPEC_EARLY") && !atoi(getenv("A2AMD_VMSPEC_EARLY")));
+		const std::function<int()> mid = [&]() -> int {
+			if(!spec_early || !vmwin_ok || !vm_spec_wanted(c))
+				return 0;	// (no pass to follow: the old order)
+			if(int r = leaves())
+				return r;
+			// (a time-sliced quiet kernel leaves its voices' end state in the staging array until a commit that rides
+			// along with a later launch: the pass reads the unit state of the class voices that were idle this batch)
+			flush_commits();
+			return vm_speculate(c);
+		};
 		// ... the window kernels first: k_vm_win says in runs[] which of the VM's voices are the quiet kernels' this batch
 		if(use_win) {
-			if(int r = issue_windows(c, rlists, rcounts))
+			if(int r = issue_windows(c, rlists, rcounts, mid))
 				return r;
 			if(vmwin_ok)
 				if(int r = vm_predict(c))
 					return r;
 		}
-		if(c->n_fast_leaf) {
-			int vpw, ysplit;
-			pick_fast_shape(c->n_fast_leaf, c->nfrags, &vpw, &ysplit);
-			// e1 right behind the main kernel when it is the only leaf kernel
-			// of the batch: "leaf" time is then that kernel alone
-			const bool solo = !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn && !c->n_o2f_leaf;
-			if(a2d_launch_leaf_oscpan(c->d_params, c->hparams, c->d_list.d, c->n_fast_leaf,
-					vpw, ysplit, c->d_ustage.d, c->stream, solo ? (void *)e1 : nullptr, &pend.c[pend.n]))
-				return c->fail(A2AMD_EHIP, "fast leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
-			if(pend.c[pend.n].nlist)
-				++pend.n;
-			++c->stats.launches;
-		}
-		if(c->n_osc2_leaf) {
-			int vpw, ysplit;
-			// (its own chunk length; 16 time slices: 2.19 ms against 2.25 with 32 at configs[3], round 3)
-			pick_fast_shape(c->n_osc2_leaf, c->nfrags * A2D_FAST_FCH / A2D_OSC2_FCH, &vpw, &ysplit, 16);
-			if(a2d_launch_leaf_osc2pan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf, c->n_osc2_leaf,
-					vpw, ysplit, c->d_ustage.d, c->stream, &pend.c[pend.n]))
-				return c->fail(A2AMD_EHIP, "2-osc leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
-			if(pend.c[pend.n].nlist)
-				++pend.n;
-			++c->stats.launches;
-		}
-		if(c->n_filt_leaf) {
-			// voices per workgroup = lanes of its filter wavefront: all 64 once there
-			// are enough voices for a workgroup on every CU (one 16-wavefront workgroup
-			// per CU), else spread out (a workgroup takes as long as its filter chain,
-			// whatever its voice count)
-			const int nf = c->n_filt_leaf;
-			int vpw = getenv("A2AMD_FVPW") ? atoi(getenv("A2AMD_FVPW")) :
-					std::min(std::max((nf + 255) / 256, 1), 64);
-			if(a2d_launch_leaf_oscfiltpan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf,
-					c->n_filt_leaf, vpw, c->stream))
-				return c->fail(A2AMD_EHIP, "filter leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
-			++c->stats.launches;
-		}
-		if(c->n_o2f_leaf) {
-			// 2 x wtosc-filter12-panmix without records (round 6).  A workgroup (16 wavefronts, 128 registers: one per CU)
-			// takes as long as its filter wavefront's chain whatever its voice count, as long as every oscillator
-			// wavefront stays in its all-settled loop (a2d_osc2filtpan_max_vpg voices): the voices are dealt over the
-			// fewest whole rounds of 256 workgroups that allows (16 384 voices: 2 rounds of 32 - measured 1.09 ms per 256
-			// fragments against 3.83 with 48 and 1.50 with 64 voices per workgroup)
-			const int nf = c->n_o2f_leaf;
-			static const int env_vpg = getenv("A2AMD_F2VPW") ? atoi(getenv("A2AMD_F2VPW")) : 0;
-			const int maxv = a2d_osc2filtpan_max_vpg();
-			const int rounds = std::max(1, (nf + 256 * maxv - 1) / (256 * maxv));
-			const int vpg = env_vpg ? env_vpg : std::min(std::max((nf + 256 * rounds - 1) / (256 * rounds), 1), maxv);
-			if(a2d_launch_leaf_osc2filtpan(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf +
-					c->n_filt_leaf + c->n_fm_leaf + c->n_leaf, nf, vpg, c->stream))
-				return c->fail(A2AMD_EHIP, "2-osc filter leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
-			++c->stats.launches;
-		}
-		int fm_kinds = 0;
-		for(int k = 0; k < 8; ++k)
-			fm_kinds += c->fm_kind_count[k] != 0;
-		if(fm_kinds > 1 && c->n_fm_leaf <= 16384 && !getenv("A2AMD_FMVPW")) {
-			// several kinds, few voices: one launch for all of them (the
-			// per-kind launches below would run back to back, each as long
-			// as a voice's serial chain)
-			if(a2d_launch_leaf_fmpan_all(c->d_params, c->hparams, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf +
-					c->n_filt_leaf, c->fm_kind_count, (c->n_fm_leaf + 1023) / 1024, c->stream))
-				return c->fail(A2AMD_EHIP, "fm leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
-			++c->stats.launches;
-		} else
-		for(int k = 0, at = c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf; k < 8; at += c->fm_kind_count[k++]) {
-			const int n = c->fm_kind_count[k];
-			if(!n)
-				continue;
-			// A voice is a serial recurrence: a launch takes as long as its longest
-			// lane, so few voices are spread over many wavefronts (idle lanes of a
-			// wavefront shadow its voices, see fmpan_body) until there is one
-			// wavefront per SIMD (1 024), then the lanes fill up
-			// (profiles/r01_fm_vpw_sweep.txt).
-			int vpw = getenv("A2AMD_FMVPW") ? atoi(getenv("A2AMD_FMVPW")) : (n + 1023) / 1024;
-			vpw = std::min(std::max(vpw, 1), 64);
-			if(a2d_launch_leaf_fmpan(c->d_params, c->hparams, A2AMD_FM1 + k, c->d_list.d + at, n, vpw, c->stream))
-				return c->fail(A2AMD_EHIP, "fm leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
-			++c->stats.launches;
-		}
-		if(c->n_leaf) {
-			if(a2d_launch_voices(c->d_params, c->d_list.d + c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf +
-					c->n_fm_leaf, c->n_leaf,
-					pick_vpw(c->n_leaf), c->stream))
-				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
-			++c->stats.launches;
-		}
-		{
-			// (a wavefront walks its voices one after the other, fragment by fragment: as many
-			// wavefronts as the chip holds before a wavefront gets a second voice)
-			auto recs = [&](int nosc, int filt, const int *list, int n, int skip_empty) -> int {
-				if(!n)
-					return 0;
-				int vpw = getenv("A2AMD_RVPW") ? atoi(getenv("A2AMD_RVPW")) : (n + 8191) / 8192;
-				if(a2d_launch_leaf_recs(c->d_params, c->hparams, nosc, filt, list, n, vpw, c->stream, skip_empty))
-					return c->fail(A2AMD_EHIP, "leaf records launch failed: %s", hipGetErrorString(hipGetLastError()));
-				++c->stats.launches;
-				return 0;
-			};
-			const int *const *lists = rlists;
-			const int *counts = rcounts;
-			const int total = rtotal;
-			const int kinds = (counts[0] != 0) + (counts[1] != 0) + (counts[2] != 0) + (counts[3] != 0);
-			if(!use_win) {
-			if(kinds > 1 && total <= 4096 && !getenv("A2AMD_RVPW")) {
-				// few voices of several kinds (a song): one launch - on one stream the per-kind
-				// launches would run back to back, each as long as one voice's walk through the batch
-				if(a2d_launch_leaf_recs_all(c->d_params, c->hparams, lists, counts, 1, c->stream, 8))
-					return c->fail(A2AMD_EHIP, "leaf records launch failed: %s", hipGetErrorString(hipGetLastError()));
-				++c->stats.launches;
-			} else {
-				static const int nosc[4] = { 1, 2, 1, 2 }, filt[4] = { 0, 0, 1, 1 };
-				for(int k = 0; k < 4; ++k)
-					if(int r = recs(nosc[k], filt[k], lists[k], counts[k], k == 3))
-						return r;
-			}
-			// ... and the voices whose records the device VM has just written, by class (those it
-			// left without records this batch were rendered by their quiet kernels above)
-			if(!c->vm.list.empty()) {
-				static const int nosc[3] = { 1, 2, 1 }, filt[3] = { 0, 0, 1 };
-				const int *l = c->vm.d_list.d + c->vm.list.size();
-				for(int k = 0; k < 3; l += c->vm.n_cls[k++]) {
-					const int n = c->vm.n_cls[k];
-					if(!n)
-						continue;
-					int vpw = getenv("A2AMD_RVPW") ? atoi(getenv("A2AMD_RVPW")) : (n + 8191) / 8192;
-					if(a2d_launch_leaf_recs(c->d_params, c->hparams, nosc[k], filt[k], l, n, vpw, c->stream, 1))
-						return c->fail(A2AMD_EHIP, "leaf records launch failed: %s", hipGetErrorString(hipGetLastError()));
-					++c->stats.launches;
-				}
-			}
-			}
-		}
-		if(c->n_dyn_rest > 0) {
-			const int n = c->n_dyn_rest;
-			if(a2d_launch_voices(c->d_params, c->d_dyn + c->n_dyn_osc1 + c->n_dyn_osc2 + c->n_dyn_filt + c->n_dyn_filt2, n,
-					pick_vpw(n), c->stream))
-				return c->fail(A2AMD_EHIP, "leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
-			++c->stats.launches;
-		}
+		if(int r = leaves())
+			return r;
 		if(e1 && !(c->n_fast_leaf && !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn && !c->n_o2f_leaf))
 			HIPCHK(c, hipEventRecord(e1, c->stream));
+		// Round 6: behind the leaf kernels (the quiet ones have moved the phases of the VM voices that were idle this
+		// batch), on a stream of its own beside the bus kernels, the readback and the engine thread's next walk:
+		// the class voices' VM + control pass for the batch expected next (vm_speculate, a2amd_vm.cpp)
+		if(use_win && vmwin_ok && !c->vm.spec_launched_now && vm_spec_wanted(c)) {
+			flush_commits();	// (see mid(): the pass reads what the quiet kernels have staged)
+			if(int r = vm_speculate(c))
+				return r;
+		}
 		}	// (fresh start)
 		// the voices that own a bus, deepest first.  With A2AMD_RENDER_TAPS the walk stops behind a
 		// depth that holds a muted xinsert (insert clients: a2amd_unit_insertable): the host serves

@@ -110,6 +110,11 @@ typedef struct HOSTSTATE
 	int		walker;		/* liba2amd_walk.so walks this state: no prefetch hints of our own */
 	unsigned	serial;		/* a number of its own for every engine state ever opened (a2amd_walkview) */
 	unsigned	frag_serial;	/* root windows opened so far (a2amd_walkview) */
+	/* Round 6: the root voice's last wake time (root_vms, below, is its VM state inside its A2_voice) and the distance
+	 * of its last two wake-ups: what hint_cuts() announces to the backend - where the engine will cut the next buffer's
+	 * fragments (a2amd_vm_expect_cuts, include/a2amd_vm.h) */
+	unsigned	root_wake, root_period;
+	int		root_wake_valid;
 	unsigned	vm_live;	/* voices of this state the device VM runs (a2amd_units_vm_adopt) */
 	int		no_vm;		/* A2AMD_NO_VM=1: no voice is handed to the device VM (A/B measurements) */
 	/* Engine states (master states and a2_Render's substates) come and go; their records are
@@ -1122,10 +1127,33 @@ static void deliver_inserts(HOSTSTATE *hs, int depth, int dev)
 	}
 }
 
+/* Before a render: when the root's VM wakes next - where the engine will cut the NEXT buffer's fragments
+ * (a2_VoiceProcess, core.c:1852-1878).  An attached root that has reached END (A2_ENDING) wakes every 1 000 000 ticks
+ * (OP_END, core.c:1191-1217); one that waits in a delay of its own loop, at the distance of its last two wake-ups - a
+ * guess, and a wrong one costs the backend nothing but a speculative pass it does not take. */
+static void hint_cuts(HOSTSTATE *hs)
+{
+	uint32_t when[16];
+	int n = 0, d;
+	const A2P_vmstate *r = hs->root_vms;
+	if(r && (r->state == 3 /* A2_ENDING */ || r->state == 1 /* A2_WAITING */))
+	{
+		const unsigned period = r->state == 3 ? 1000000u : hs->root_period;
+		unsigned w = r->waketime;
+		when[n++] = w;
+		while(period >= (64u << 8) && n < 16)
+			when[n++] = (w += period);
+	}
+	for(d = 0; d < hs->ndev; ++d)
+		if(!hs->failed)
+			a2amd_vm_expect_cuts(hs->ctxs[d], when, n);
+}
+
 /* the batch recorded so far -> audio (outp[channel], at most cap frames) */
 static int render_batch(HOSTSTATE *hs, int32_t **outp, unsigned cap)
 {
 	int n;
+	hint_cuts(hs);
 	if(!hs->ninserts)
 		return a2amd_render_group(hs->ctxs, hs->ndev, A2AMD_RENDER_ALL, outp, cap);
 	hs->ninserts = 0;
@@ -1186,6 +1214,7 @@ static void flush_part(HOSTSTATE *hs)
 		flush_batch(hs);
 		return;
 	}
+	hint_cuts(hs);
 	n = a2amd_render(hs->ctx, A2AMD_RENDER_ALL | A2AMD_RENDER_ASYNC, NULL, 0);
 	if(n == A2AMD_EUNSUPPORTED)
 	{
@@ -1629,6 +1658,26 @@ static void amd_inline_process(A2P_unit *u, unsigned offset, unsigned frames)
 				if(!hs->map[d])
 					hs->map_cap[d] = 0;
 			}
+		}
+		if(x->is_root && x->vms)
+		{
+			if(!hs->root_wake_valid || x->vms->waketime != hs->root_wake)
+			{
+				hs->root_period = hs->root_wake_valid ? x->vms->waketime - hs->root_wake : 0;
+				hs->root_wake = x->vms->waketime;
+				hs->root_wake_valid = 1;
+			}
+		}
+		{
+			/* A2AMD_ROOTTRACE=1 (debugging aid): a window of the root voice that is not a whole fragment - the engine cut
+			 * it (a2_VoiceProcess, core.c:1852-1878) where the root's own VM wakes up or an event for it falls due */
+			static int rt = -1;
+			if(rt < 0)
+				rt = getenv("A2AMD_ROOTTRACE") != NULL;
+			if(rt && (frames != 64 || offset))
+				fprintf(stderr, "a2amd units: root window (%u, %u) at frame %u of the buffer: root VM state %d pc %d waketime %u\n",
+						offset, frames, hs->rec_pos, x->vms ? (int)x->vms->state : -1, x->vms ? (int)x->vms->pc : -1,
+						x->vms ? x->vms->waketime : 0u);
 		}
 		++hs->batch_frags;
 		++hs->frag_serial;

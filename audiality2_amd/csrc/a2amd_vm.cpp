@@ -559,6 +559,18 @@ int vm_blob_room(a2amd_ctx *c)
 
 // upload(): the voices adopted during this batch are carried to its end by the host interpreter
 // and sent up; the kernel's list and the records kernels' class lists follow the membership
+// a speculative pass that may still be running reads what the caller is about to rewrite (VmHost::spec_waits)
+static int vm_wait_spec(a2amd_ctx *c)
+{
+	VmHost &m = c->vm;
+	if(m.pred_stream && (m.spec_valid || m.pred_valid)) {
+		use_device(c);
+		HIPCHK(c, hipStreamSynchronize(m.pred_stream));
+		++m.spec_waits;
+	}
+	return 0;
+}
+
 int vm_prepare_batch(a2amd_ctx *c)
 {
 	VmHost &m = c->vm;
@@ -566,6 +578,8 @@ int vm_prepare_batch(a2amd_ctx *c)
 			(m.envlut_up || m.envlut.empty()))
 		return 0;
 	use_device(c);
+	if(int r = vm_wait_spec(c))
+		return r;
 	const std::vector<int> pend = m.pending;
 	for(int slot : pend) {
 		HVm &h = m.vms[slot];
@@ -641,6 +655,9 @@ int vm_build_lists(a2amd_ctx *c)
 	VmHost &m = c->vm;
 	if(m.list_dirty) {
 		use_device(c);
+		if(int r = vm_wait_spec(c))
+			return r;
+		m.rebuilt_at = m.vm_batches;
 		m.list.clear();
 		++m.list_serial;
 		std::vector<std::pair<int, int>> cls[3];	// (voice slot, VM slot)
@@ -747,7 +764,11 @@ void vm_class_params(a2amd_ctx *c, int k, A2DVmParams *vp)
 int vm_predict(a2amd_ctx *c)
 {
 	VmHost &m = c->vm;
-	m.pred_valid = false;
+	// (round 6: vm_speculate predicts by doing - and it may already have, from inside issue_windows: its flags are not
+	// this function's to clear)
+	if(m.spec_launched_now || vm_spec_wanted(c))
+		return 0;
+	m.pred_valid = m.spec_valid = false;
 	const int ncls = m.n_cls[0] + m.n_cls[1] + m.n_cls[2];
 	if(m.list.empty() || !ncls || c->capturing || m.fused_off)
 		return 0;
@@ -788,6 +809,202 @@ int vm_predict(a2amd_ctx *c)
 	return 0;
 }
 
+// The fragments of the batch expected next: this batch's span again (it has to be whole engine fragments or pieces of
+// them - the test vm_issue makes of a prediction), beginning where this one ends, each 64-frame fragment cut where
+// the root's VM is expected to wake inside it (a2amd_vm_expect_cuts; a2_VoiceProcess, core.c:1852-1878: from a fragment
+// start F the engine processes (W - F) >> 8 frames up to the wake-up at W if W - F > 255 ticks, else it runs the VM
+// first and the fragment stays whole).  The pass writes a slot per (fragment, voice), and "the next batch has these
+// fragments" is something vm_issue checks word for word.
+bool vm_spec_plan(a2amd_ctx *c, int *nfrags, uint8_t *ff, uint8_t *fb)
+{
+	VmHost &m = c->vm;
+	uint32_t frames = 0;
+	for(int f = 0; f < c->nfrags; ++f) {
+		if(!c->fragframes[f] || frames / A2D_FRAG != (frames + c->fragframes[f] - 1) / A2D_FRAG)
+			return false;
+		frames += c->fragframes[f];
+	}
+	if(!frames || frames % A2D_FRAG)
+		return false;
+	const uint32_t next_now = m.batch_now + (frames << 8);
+	int n = 0;
+	for(uint32_t k = 0; k < frames / A2D_FRAG; ++k) {
+		const uint32_t F = next_now + ((k * A2D_FRAG) << 8);
+		int cut = 0, ncuts = 0;
+		for(int h = 0; h < m.n_cut_hint; ++h) {
+			const int32_t d = (int32_t)(m.cut_hint[h] - F);
+			if(d > 255 && d < (A2D_FRAG << 8)) {
+				cut = d >> 8;
+				++ncuts;
+			}
+		}
+		if(ncuts > 1 || n + 2 > A2D_MAXBATCH)
+			return false;	// (two wake-ups inside one fragment, a list that does not fit: no prediction)
+		if(ncuts) {
+			ff[n] = (uint8_t)cut; fb[n++] = 0;
+			ff[n] = (uint8_t)(A2D_FRAG - cut); fb[n++] = (uint8_t)cut;
+		} else {
+			ff[n] = A2D_FRAG; fb[n++] = 0;
+		}
+	}
+	*nfrags = n;
+	return true;
+}
+
+// May the batch being issued be followed by a speculative pass (VmHost, round 6)?
+static int vm_spec_why_not(a2amd_ctx *c, int *nfrags, uint8_t *ff, uint8_t *fb)
+{
+	VmHost &m = c->vm;
+	static const bool on = !(getenv("A2AMD_VMSPEC") && !atoi(getenv("A2AMD_VMSPEC")));
+	const int ncls = m.n_cls[0] + m.n_cls[1] + m.n_cls[2];
+	if(!on || m.list.empty() || !ncls || c->capturing || m.fused_off || c->nfrags < 1 || c->nfrags > A2D_MAXBATCH)
+		return 1;
+	// Short batches are left alone: k_vm_win over ONE fragment is a few tens of microseconds, and the commit plus a
+	// pass that shares the chip with the batch's own kernels cost more than that (measured, 16 384 scripted voices,
+	// a2_Run(64): 140 -> 164 us per call with the pass, 130 -> 137 with filter12; a2_Run(1024) = 16 fragments: 335 -> 295,
+	// 496 -> 421; a2_Run(4096): 1 108 -> 904, 1 713 -> 1 360 - profiles/r06_vm_speculation_ab.txt).  A2AMD_VMSPEC_MIN moves it.
+	static const int min_frags = getenv("A2AMD_VMSPEC_MIN") ? atoi(getenv("A2AMD_VMSPEC_MIN")) : 8;
+	if(c->nfrags < min_frags)
+		return 1;
+	if(m.vm_batches - m.rebuilt_at < 2)	// (the lists have only just changed: VmHost::rebuilt_at)
+		return 4;
+	if(!vm_spec_plan(c, nfrags, ff, fb))
+		return 2;
+	// (the slots of the three classes for the whole batch in one piece: within the window kernels' own budget)
+	static const size_t budget = (size_t)(getenv("A2AMD_WIN_MB") ? atoi(getenv("A2AMD_WIN_MB")) : 1024) * (1u << 20) / sizeof(int);
+	static const int nosc[3] = { 1, 2, 1 }, filt[3] = { 0, 0, 1 };
+	size_t words = 0;
+	for(int k = 0; k < 3; ++k)
+		words += (size_t)m.n_cls[k] * (size_t)*nfrags * A2D_WIN_SLOTWORDS(nosc[k], filt[k]);
+	return words <= budget ? 0 : 3;
+}
+
+bool vm_spec_wanted(a2amd_ctx *c)
+{
+	int n;
+	uint8_t ff[A2D_MAXBATCH], fb[A2D_MAXBATCH];
+	return !vm_spec_why_not(c, &n, ff, fb);
+}
+
+
+// ... launched behind the batch's leaf kernels (issue_kernels): the quiet kernels have moved the phases of the class
+// voices that were idle in this batch, k_vm_win / the window control pass everything else the pass reads.
+int vm_speculate(a2amd_ctx *c)
+{
+	VmHost &m = c->vm;
+	// (not wanted: vm_predict has made this batch's prediction - k_vm_pool's count - and it stands.  The first cut of
+	// this function cleared pred_valid before it looked: no batch was fused any more when the pass was off or the
+	// fragments were not whole, and the audio - through records - was still right; the statistics line gave it away)
+	if(m.spec_launched_now)		// (once per batch: issue_windows may have called already, issue_kernels asks again)
+		return 0;
+	m.spec_launched_now = true;
+	int nfrags = 0;
+	if(const int why = vm_spec_why_not(c, &nfrags, m.spec_ff, m.spec_fb)) {
+		const int ncls0 = m.n_cls[0] + m.n_cls[1] + m.n_cls[2];
+		if(!m.list.empty() && ncls0)
+			++m.spec_skip[why - 1];
+		static const int trace = getenv("A2AMD_HOSTTIMING") ? atoi(getenv("A2AMD_HOSTTIMING")) : 0;
+		if(trace >= 2 && why == 2 && !m.list.empty() && ncls0)
+			fprintf(stderr, "a2amd device VM: no speculative pass behind a batch of %d fragments: its span is not whole engine "
+					"fragments, or two wake-ups of the root are expected inside one\n", c->nfrags);
+		return 0;
+	}
+	m.pred_valid = m.spec_valid = false;
+	use_device(c);
+	static const int nosc[3] = { 1, 2, 1 }, filt[3] = { 0, 0, 1 };
+	const int ncls = m.n_cls[0] + m.n_cls[1] + m.n_cls[2];
+	if(!m.pred_stream) {
+		HIPCHK(c, hipStreamCreateWithFlags(&m.pred_stream, hipStreamNonBlocking));
+		HIPCHK(c, hipEventCreateWithFlags(&m.pred_after, hipEventDisableTiming));
+		HIPCHK(c, hipEventCreateWithFlags(&m.pred_ev, hipEventDisableTiming));
+		HIPCHK(c, hipMalloc((void **)&m.d_pred, 2 * sizeof(unsigned)));
+		HIPCHK(c, hipHostMalloc((void **)&m.h_pred, 2 * sizeof(unsigned), hipHostMallocDefault));
+	}
+	if(!m.d_swtop) {
+		HIPCHK(c, hipMalloc((void **)&m.d_swtop, 2 * sizeof(unsigned)));
+		HIPCHK(c, hipMalloc((void **)&m.d_stotal, 2 * sizeof(uint32_t)));
+		HIPCHK(c, hipHostMalloc((void **)&m.h_spec, 4 * sizeof(unsigned), hipHostMallocDefault));
+	}
+	size_t slotwords = 0;
+	for(int k = 0; k < 3; ++k)
+		slotwords += (size_t)m.n_cls[k] * (size_t)nfrags * A2D_WIN_SLOTWORDS(nosc[k], filt[k]);
+	// pool room: what the last fused / speculative batch took, doubled, and never less than a window per voice and
+	// eight fragments; a pass that finds it too small says so (h_spec[1]), is not taken, and the next gets twice that
+	size_t want_cap = std::max<size_t>(2 * std::max(m.spec_demand, m.pool_used) + 4096, (size_t)ncls * (size_t)((nfrags + 7) / 8) + 4096);
+	if(m.spec_overflows)
+		want_cap = std::max(want_cap, 2 * m.spec_cap);
+	want_cap = std::min<size_t>(want_cap, 0xfffffff0u);
+	m.spec_overflows = 0;
+	const int set = m.spec_set ^ 1;		// (the other one may be under the render pass of the batch being issued)
+	if(slotwords > m.d_swin[set].cap || want_cap > m.d_swext[set].cap || (size_t)ncls * nfrags > m.d_swidx[set].cap ||
+			(size_t)ncls * A2D_VMW_ROW > m.d_swscr.cap || m.d_vmv.cap > m.d_vmv_sh.cap || c->d_ustate.cap > m.d_ustate_sh.cap ||
+			c->d_vactive.cap > m.d_vactive_sh.cap || c->d_runs.cap > m.d_runs_sh.cap) {
+		// (the last pass may still be reading / writing them)
+		HIPCHK(c, hipStreamSynchronize(m.pred_stream));
+		if(int r = grow(c, m.d_swin[set], slotwords, 1, false)) return r;
+		if(int r = grow(c, m.d_swext[set], want_cap, A2D_WIN_WORDS, false)) return r;
+		if(int r = grow(c, m.d_swidx[set], (size_t)ncls * nfrags, 1, false)) return r;
+		if(int r = grow(c, m.d_swscr, (size_t)ncls * A2D_VMW_ROW, A2D_WIN_WORDS, false)) return r;
+		if(int r = grow(c, m.d_vmv_sh, m.d_vmv.cap, 1, false)) return r;
+		if(int r = grow(c, m.d_ustate_sh, c->d_ustate.cap, A2D_USTATE, false)) return r;	// (cap in units, like d_ustate's)
+		if(int r = grow(c, m.d_vactive_sh, c->d_vactive.cap, 1, false)) return r;
+		if(int r = grow(c, m.d_runs_sh, c->d_runs.cap, 1, false)) return r;
+	}
+	m.spec_cap = std::min<size_t>(m.d_swext[set].cap, 0xfffffff0u);
+	A2DVmParams vp;
+	fill_params(c, vp);
+	uint32_t frames = 0;
+	for(int f = 0; f < c->nfrags; ++f)
+		frames += c->fragframes[f];
+	vp.now = m.batch_now + (frames << 8);		// (the same span again, beginning where this batch ends ...)
+	vp.nfrags = nfrags;				// (... in the fragments vm_spec_plan expects)
+	for(int f = 0; f < nfrags; ++f) {
+		vp.fragframes[f] = m.spec_ff[f];
+		vp.fragbase[f] = m.spec_fb[f];
+	}
+	const A2DVmwOut out = { m.d_vmv_sh.d, m.d_ustate_sh.d, m.d_vactive_sh.d, m.d_runs_sh.d, m.d_stotal };
+	HIPCHK(c, hipEventRecord(m.pred_after, c->stream));
+	HIPCHK(c, hipStreamWaitEvent(m.pred_stream, m.pred_after, 0));
+	HIPCHK(c, hipMemsetAsync(m.d_swtop, 0, 2 * sizeof(unsigned), m.pred_stream));
+	HIPCHK(c, hipMemsetAsync(m.d_stotal, 0, 2 * sizeof(uint32_t), m.pred_stream));
+	const int *l = m.d_list.d + m.list.size() + m.cls_lists.size();
+	size_t at = 0, atw = 0, atv = 0;
+	for(int k = 0; k < 3; l += m.n_cls[k], ++k) {
+		m.spec_cls[k] = m.n_cls[k];
+		if(!m.n_cls[k])
+			continue;
+		vp.list = l;
+		vp.n = m.n_cls[k];
+		if(a2d_launch_vm_win(vp, c->hparams, nosc[k], filt[k], 0, nfrags, vp.now, vp.now + (frames << 8), m.d_swin[set].d + atw,
+				m.d_swext[set].d, m.d_swscr.d + atv * A2D_VMW_ROW * A2D_WIN_WORDS, m.d_swidx[set].d + at, m.d_swtop,
+				(unsigned)m.spec_cap, m.pred_stream, &out))
+			return c->fail(A2AMD_EHIP, "speculative VM pass launch failed: %s", hipGetErrorString(hipGetLastError()));
+		// (A2AMD_WIN_SYNC=1, debugging: wait for the pass and say so - the last line names the kernel that faulted)
+		static const bool dbgsync = getenv("A2AMD_WIN_SYNC") != nullptr;
+		if(dbgsync) {
+			const hipError_t e = hipStreamSynchronize(m.pred_stream);
+			fprintf(stderr, "a2amd device VM: speculative pass <%d,%d> of %d voices over %d fragments into set %d (slots at %zu words, "
+					"index at %zu, rows at %zu; pool room %zu): %s\n", nosc[k], filt[k], m.n_cls[k], nfrags, set, atw, at, atv,
+					m.spec_cap, hipGetErrorString(e));
+		}
+		at += (size_t)m.n_cls[k] * (size_t)nfrags;
+		atw += (size_t)m.n_cls[k] * (size_t)nfrags * A2D_WIN_SLOTWORDS(nosc[k], filt[k]);
+		atv += (size_t)m.n_cls[k];
+		++c->stats.launches;
+	}
+	HIPCHK(c, hipMemcpyAsync(m.h_spec, m.d_swtop, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, m.pred_stream));
+	HIPCHK(c, hipMemcpyAsync(m.h_spec + 2, m.d_stotal, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, m.pred_stream));
+	HIPCHK(c, hipEventRecord(m.pred_ev, m.pred_stream));
+	m.pred_valid = m.spec_valid = true;
+	m.pred_serial = m.list_serial;
+	m.pred_now = vp.now;
+	m.pred_span = frames;
+	m.spec_nfrags = nfrags;
+	m.spec_set = set;
+	++m.spec_launched;
+	return 0;
+}
+
 // faults of a fused batch's voices (k_vm_win counts them in d_total[1]): copied back behind the batch, looked at
 // before the next one (vm_issue)
 int vm_fused_done(a2amd_ctx *c)
@@ -808,6 +1025,8 @@ int vm_issue(a2amd_ctx *c, bool fused)
 {
 	VmHost &m = c->vm;
 	m.fused = false;
+	m.spec_use = false;
+	m.spec_launched_now = false;
 	// (the faults of the last fused batch are looked at whether or not a voice is left: all of them may have been
 	// recalled since)
 	if(m.total_pending) {
@@ -820,6 +1039,7 @@ int vm_issue(a2amd_ctx *c, bool fused)
 	}
 	if(m.list.empty()) {
 		m.last_total = 0;
+		m.pred_valid = m.spec_valid = false;
 		return 0;
 	}
 	if(c->capturing)
@@ -851,16 +1071,36 @@ int vm_issue(a2amd_ctx *c, bool fused)
 		}
 		++m.pred_why[why];
 		static const int trace = getenv("A2AMD_HOSTTIMING") ? atoi(getenv("A2AMD_HOSTTIMING")) : 0;
+		if(why && m.spec_valid)
+			++m.spec_miss[0];
 		if(trace >= 2 && why >= 4)
 			fprintf(stderr, "a2amd device VM: batch of %d fragments not fused: %s (predicted: %u frames)\n", c->nfrags,
 					why == 4 ? "another length" : "a fragment across a 64-frame boundary", m.pred_span);
 		if(!why) {
 			HIPCHK(c, hipEventSynchronize(m.pred_ev));	// (launched beside the last batch's render pass: done)
-			m.pred_entries = m.h_pred[0];
+			m.pred_entries = m.spec_valid ? m.h_spec[0] : m.h_pred[0];
 			m.fused = true;
+			if(m.spec_valid) {
+				// the speculative pass is taken if this batch is EXACTLY the one it was run for - the same class
+				// lists (the serial says so), the same number of whole fragments - and it neither ran out of pool
+				// room nor met a fault (the fused pass that runs instead then reports it)
+				bool exact = c->nfrags == m.spec_nfrags;
+				for(int f = 0; f < c->nfrags && exact; ++f)
+					exact = c->fragframes[f] == m.spec_ff[f] && c->fragbase[f] == m.spec_fb[f];
+				for(int k = 0; k < 3; ++k)
+					exact = exact && m.spec_cls[k] == m.n_cls[k];
+				m.spec_demand = m.h_spec[0];
+				if(m.h_spec[1])
+					++m.spec_overflows;
+				m.spec_use = exact && !m.h_spec[1] && !m.h_spec[3];
+				if(m.spec_use)
+					++m.spec_taken;
+				else
+					++m.spec_miss[!exact ? 1 : m.h_spec[1] ? 2 : 3];
+			}
 		}
 	}
-	m.pred_valid = false;
+	m.pred_valid = m.spec_valid = false;
 	if(m.fused) {
 		vp.list = m.d_list.d + m.list.size() + 2 * m.cls_lists.size();
 		vp.n = m.n_other;
@@ -959,6 +1199,32 @@ void vm_close(a2amd_ctx *c)
 				(unsigned long long)m.vm_batches, (unsigned long long)m.fused_batches, (unsigned long long)m.pred_why[1],
 				(unsigned long long)m.pred_why[2], (unsigned long long)m.pred_why[3], (unsigned long long)m.pred_why[4],
 				(unsigned long long)m.pred_why[5], (unsigned long long)m.pred_why[6]);
+	if(c->hosttiming && m.spec_launched)
+		fprintf(stderr, "a2amd device VM: %llu speculative passes (k_vm_win for the batch expected next, into shadows), %llu of them taken "
+				"(k_vm_commit + render pass in k_vm_win's place); pool room %zu entries, last demand %zu; not taken: %llu not the "
+				"batch predicted, %llu other fragments / classes, %llu pool overflow, %llu faults; batches without a pass: %llu off / "
+				"short, %llu no plan (span not whole fragments), %llu over the slot budget, %llu lists just changed; %llu waits for a "
+				"pass in flight before a rewrite\n",
+				(unsigned long long)m.spec_launched, (unsigned long long)m.spec_taken, m.spec_cap, m.spec_demand,
+				(unsigned long long)m.spec_miss[0], (unsigned long long)m.spec_miss[1], (unsigned long long)m.spec_miss[2],
+				(unsigned long long)m.spec_miss[3], (unsigned long long)m.spec_skip[0], (unsigned long long)m.spec_skip[1],
+				(unsigned long long)m.spec_skip[2], (unsigned long long)m.spec_skip[3], (unsigned long long)m.spec_waits);
+	if(m.pred_stream)
+		hipStreamSynchronize(m.pred_stream);	// (a pass still running reads the arrays freed below)
+	for(int k = 0; k < 2; ++k) {
+		hipFree(m.d_swin[k].d);
+		hipFree(m.d_swext[k].d);
+		hipFree(m.d_swidx[k].d);
+	}
+	hipFree(m.d_swscr.d);
+	hipFree(m.d_swtop);
+	hipFree(m.d_vmv_sh.d);
+	hipFree(m.d_ustate_sh.d);
+	hipFree(m.d_vactive_sh.d);
+	hipFree(m.d_runs_sh.d);
+	hipFree(m.d_stotal);
+	if(m.h_spec)
+		hipHostFree(m.h_spec);
 	hipFree(m.d_vmv.d);
 	hipFree(m.d_code.d);
 	hipFree(m.d_list.d);
@@ -1235,6 +1501,18 @@ int a2amd_vm_adopt(a2amd_ctx *c, int head, int prog, const a2amd_vm_state *st, c
 	++m.stats.live;
 	++m.stats.adopted;
 	return A2AMD_OK;
+}
+
+// (include/a2amd_vm.h: where the next batch's fragments will be cut - for vm_spec_plan)
+int a2amd_vm_expect_cuts(a2amd_ctx *c, const uint32_t *when, int n)
+{
+	if(!c || n < 0 || (n && !when))
+		return A2AMD_EINVAL;
+	VmHost &m = c->vm;
+	m.n_cut_hint = std::min(n, 16);
+	for(int k = 0; k < m.n_cut_hint; ++k)
+		m.cut_hint[k] = when[k];
+	return 0;
 }
 
 int a2amd_vm_exit_time(a2amd_ctx *c, int head, uint32_t *when)

@@ -293,8 +293,11 @@ __global__ __launch_bounds__(128)
 void k_vm_win(A2DVmParams vp, int fa, int fb, uint32_t now_fa, uint32_t batch_end,
 		int *__restrict__ wslot, int *__restrict__ wext, int *__restrict__ wscr, unsigned *__restrict__ widx, unsigned *__restrict__ wtop, unsigned wcap,
 		const A2DVoice *__restrict__ voices, int *ustate, int *vactive, const A2DWave *__restrict__ waves,
-		const uint32_t *__restrict__ ptab)
+		const uint32_t *__restrict__ ptab, A2DVmwOut out)
 {
+	// (out: where the stepped state goes - the arrays it was read from, or a speculative pass's shadows; everything
+	// between the loads at the top and the stores at the bottom lives in registers and LDS.  ctl_apply's one direct
+	// write to ustate is a filter12's R_INIT, and the VM makes no births.)
 	__shared__ PTab s_ptab;
 	__shared__ VmSlot s_v[64];
 	__shared__ VmwStage s_stage;
@@ -323,7 +326,7 @@ void k_vm_win(A2DVmParams vp, int fa, int fb, uint32_t now_fa, uint32_t batch_en
 			live = fa > 0 ? vp.runs[v.voice].count != 0 : !vmw_idle(v, batch_end);
 			if(fa == 0) {
 				const A2DRun run = { 0, live ? 1 : 0 };
-				vp.runs[v.voice] = run;
+				out.runs[v.voice] = run;
 			}
 		}
 		const unsigned long long any = __ballot(live);
@@ -369,21 +372,71 @@ void k_vm_win(A2DVmParams vp, int fa, int fb, uint32_t now_fa, uint32_t batch_en
 		if(blockIdx.x % 61 == 5 && lane == 7)
 			printf("    ... %lld in the VM's runs, %lld in the windows' env / cutoff / SEG part\n", e.t_seg[1], e.t_seg[2]);
 #endif
-		ctl_store(cv, ustate, vactive, v.voice);
-		vp.vmv[slot] = v;
+		ctl_store(cv, out.ustate, out.vactive, v.voice);
+		out.vmv[slot] = v;
 		if(v.fault)
-			atomicAdd(vp.total + 1, 1u);
+			atomicAdd(out.total + 1, 1u);
 	}
 }
 
+// A speculative pass's results become the state (round 6, vm_speculate / vm_issue): for every voice of the class,
+// whose it is this batch (runs[]); for the ones the pass ran, the VM voice and exactly the unit words ctl_store
+// writes - NOT whole unit blocks: filter12's d1 / d2 live in the same block and belong to the render pass, which
+// has moved them since the shadow was written.
+template<int NOSC, int FILT>
+__global__ __launch_bounds__(64)
+void k_vm_commit(A2DVmParams vp, A2DVmwOut from, const A2DVoice *__restrict__ voices, int *ustate, int *vactive)
+{
+	const int idx = (int)(blockIdx.x * 64 + threadIdx.x);
+	if(idx >= vp.n)
+		return;
+	const int slot = vp.list[idx];
+	const int voice = vp.vmv[slot].voice;
+	const A2DRun run = from.runs[voice];
+	vp.runs[voice] = run;
+	if(!run.count)
+		return;		// (idle in that batch: the pass did not touch it)
+	vp.vmv[slot] = from.vmv[slot];
+	CtlVoice<NOSC, FILT> cv;
+	ctl_clear(cv);
+	const A2DVoice &vc = voices[voice];
+#pragma unroll
+	for(int o = 0; o <= NOSC + FILT; ++o)
+		cv.uu[o] = vc.unit[o];
+	ctl_load(cv, from.ustate, from.vactive, voice);
+	ctl_store(cv, ustate, vactive, voice);
+}
+
+int a2d_launch_vm_commit(const A2DVmParams &vp, const A2DParams &hp, int nosc, int filt, const A2DVmwOut &from, void *stream)
+{
+	if(vp.n <= 0)
+		return 0;
+	const int nblocks = (vp.n + 63) / 64;
+#define VMC_LAUNCH(N, F) hipLaunchKernelGGL((k_vm_commit<N, F>), dim3(nblocks), dim3(64), 0, (hipStream_t)stream, vp, from, \
+		hp.voices, hp.ustate, hp.vactive)
+	if(nosc == 1 && !filt)
+		VMC_LAUNCH(1, 0);
+	else if(nosc == 2 && !filt)
+		VMC_LAUNCH(2, 0);
+	else if(nosc == 1 && filt)
+		VMC_LAUNCH(1, 1);
+	else
+		return -1;
+#undef VMC_LAUNCH
+	return (int)hipGetLastError();
+}
+
 int a2d_launch_vm_win(const A2DVmParams &vp, const A2DParams &hp, int nosc, int filt, int fa, int fb, uint32_t now_fa,
-		uint32_t batch_end, int *wslot, int *wext, int *wscr, unsigned *widx, unsigned *wtop, unsigned wcap, void *stream)
+		uint32_t batch_end, int *wslot, int *wext, int *wscr, unsigned *widx, unsigned *wtop, unsigned wcap, void *stream,
+		const A2DVmwOut *outp)
 {
 	if(vp.n <= 0 || fb <= fa)
 		return 0;
 	const int nblocks = (vp.n + 63) / 64;
+	const A2DVmwOut live = { vp.vmv, hp.ustate, hp.vactive, vp.runs, vp.total };
+	const A2DVmwOut out = outp ? *outp : live;
 #define VMW_LAUNCH(N, F) hipLaunchKernelGGL((k_vm_win<N, F>), dim3(nblocks), dim3(128), 0, (hipStream_t)stream, vp, fa, fb, now_fa, \
-		batch_end, wslot, wext, wscr, widx, wtop, wcap, hp.voices, hp.ustate, hp.vactive, hp.waves, hp.ptab)
+		batch_end, wslot, wext, wscr, widx, wtop, wcap, hp.voices, hp.ustate, hp.vactive, hp.waves, hp.ptab, out)
 	if(nosc == 1 && !filt)
 		VMW_LAUNCH(1, 0);
 	else if(nosc == 2 && !filt)

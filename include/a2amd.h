@@ -53,7 +53,7 @@ extern "C" {
 #define A2AMD_MIPLEVELS    10   /* A2_MIPLEVELS, include/a2_waves.h:33 */
 #define A2AMD_WAVEPRE       1   /* A2_WAVEPRE,  include/a2_waves.h:60 */
 #define A2AMD_WAVEPOST    131   /* A2_WAVEPOST, include/a2_waves.h:63-64 */
-#define A2AMD_MAXCHAIN      8   /* max units in one voice's chain (ours) */
+#define A2AMD_MAXCHAIN     16   /* max units in one voice's chain (ours; 8 until round 6.  The reference's list has no cap) */
 
 typedef struct a2amd_ctx a2amd_ctx;
 

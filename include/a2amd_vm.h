@@ -12,18 +12,39 @@
  *   control   SET SETALL RAMP RAMPR RAMPALL RAMPALLR             core.c:1459-1489
  *             (a2_VoiceControl, core.c:143-149, through the register tracker, core.c:1064-1116)
  *
- * and - proven from the voice's current pc by a2amd_vm_analyze() - never reaches END / SLEEP /
- * RETURN / CALL, spawning, messages, RAND (the engine-global RNG), a register divisor, or a loop
- * without a delay of at least one 256th of a frame in it (A2_OVERLOAD, core.c:1190): such a voice can
- * neither end nor fault nor touch anything outside its own registers and its own units' control
- * registers, so nothing the engine does depends on WHEN its VM runs.  The engine hands the voice
+ *             DIVR MODR QUANTR (register divisors, since round 5: a zero divisor ends the stay, below)
+ *
+ * That subset is what the device EXECUTES.  Which voices it is given (rounds 5-6):
+ *
+ *  - a voice whose program a2amd_vm_analyze() can vouch for as a whole from its current pc - it never reaches
+ *    END / SLEEP / RETURN / CALL, spawning, messages, RAND (the engine-global RNG), a zero divisor, or a loop
+ *    without a delay of at least one 256th of a frame in it (A2_OVERLOAD, core.c:1190) - is the device's for
+ *    good (round 4's rule);
+ *  - any OTHER voice that waits in a delay is taken FOR A STRETCH: a2amd_vm_adopt() runs the host's copy of
+ *    the interpreter ahead on a copy of the state (its future runs depend on nothing but its own registers:
+ *    an event recalls it, env units and cutoff rampers do not read back) up to the first VM run that would
+ *    meet an instruction outside the subset.  That run is the ENGINE'S: its wake time is the voice's exit time
+ *    (a2amd_vm_exit_time), the walk recalls the voice in the fragment that holds it, and the engine's own VM
+ *    executes END (with a2_VoiceFree, the parent's wake-up, the detach logic), the CALL, the RAND draw, the
+ *    SLEEP, the message - at the engine's own frame.  The device never executes those; it is told when to stop.
+ *    A stay shorter than 2 048 frames or without a single write is not worth the hand-over (A2AMD_ESTATE: "not
+ *    now" - the units back off for 8 ... 4 096 fragments before they ask again, round 6); a voice whose very
+ *    next run is the engine's is refused from that pc (A2AMD_EUNSUPPORTED).
+ *
+ * Never taken: voices with a noise oscillator (the draws of the engine's one LCG interleave with every other noise
+ * voice's and with RAND in WALK order, wtosc.c:135, core.c:1400), with subvoices, with a call stack (inside a
+ * function or a message handler), with an API handle, with events queued.
+ *
+ * Either way nothing the engine does depends on WHEN an adopted voice's VM runs.  The engine hands the voice
  * over (a2amd_vm_adopt: program text, A2_vmstate, which VM register feeds which unit register),
  * stops visiting it (INTEGRATION.md option C: a2amd_walk.c treats it as asleep), and the device
  * runs the VM between the unit windows: a kernel with one lane per voice interprets the ENGINE'S
- * OWN bytecode and writes, per batch, the same command records the host would have recorded from
- * the engine's write / Process calls (R_WRITE, R_SEG, R_F1SET, R_F1RAMP; a2amd_device.h), which
+ * OWN bytecode.  For the three window-kernel classes (wtosc [wtosc] [filter12] panmix) it carries the writes out on
+ * the voice's control state in the same lane and writes the window entries the render pass reads (k_vm_win,
+ * a2amd_vmwin.hip); for every other chain it writes, per batch, the same command records the host would have
+ * recorded from the engine's write / Process calls (R_WRITE, R_SEG, R_F1SET, R_F1RAMP; a2amd_device.h), which
  * the leaf kernels execute as before.  When the engine needs the voice back - an event in its
- * queue, a window that is not the backend's fragment, a kill - a2amd_vm_recall() returns the
+ * queue, a window that is not the backend's fragment, a kill, its exit time - a2amd_vm_recall() returns the
  * A2_vmstate the engine's own VM would have reached by the start of the open fragment.
  *
  * Plain C types only.  The instruction encoding and the opcode numbers are the engine's
@@ -164,6 +185,16 @@ int a2amd_vm_adopt(a2amd_ctx *ctx, int head_unit, int prog, const a2amd_vm_state
  * fragment that holds that time, before the engine processes it there - or 0 for a voice taken for
  * good (or not taken). */
 int a2amd_vm_exit_time(a2amd_ctx *ctx, int head_unit, uint32_t *when);
+
+/* Round 6: where the NEXT batch's fragments will be cut.  The engine cuts the root voice's 64-frame window where the
+ * root's own VM wakes up (a2_VoiceProcess, core.c:1852-1878: at a window start 'now' it processes (waketime - now) >> 8
+ * frames if that difference exceeds 255 ticks) - and an attached root that has reached END wakes every 1 000 000 ticks
+ * for ever (OP_END, core.c:1191-1217: about one cut per 4 096-frame buffer at 48 kHz).  Whoever sees the root's
+ * A2_vmstate (the drop-in units) says before every a2amd_render() when the root will wake next: 'when' = up to 16
+ * engine times (24:8 ticks), ascending.  The backend uses them for nothing but its SPECULATIVE pass (the device VM's
+ * work for the batch expected next, done ahead - a2amd_vm.cpp vm_speculate): a batch whose fragments are not the ones
+ * predicted simply does not take it.  Never required; n = 0 forgets the last announcement. */
+int a2amd_vm_expect_cuts(a2amd_ctx *ctx, const uint32_t *when, int n);
 
 /* 1 while the voice 'head_unit' belongs to is run by the device VM. */
 int a2amd_vm_adopted(a2amd_ctx *ctx, int head_unit);

@@ -990,8 +990,9 @@ def test_osc2_filter_leaf_launch_shapes_at_bench_batch_match_oracle(oracle_lib, 
     """Round 6: k_leaf_osc2filtpan, the quiet kernel of wtosc; wtosc (adding); filter12; panmix (rounds 2-5 rendered
     that voice through the records / window kernels whether or not it carried records), at the batch length bench.py
     times, 2 x 256 fragments against the oracle, over the shapes the launcher may pick - 1 voice per workgroup ... 36
-    (every oscillator wavefront in its all-settled loop, FILT2_FASTV = 3 voices each) - and two it does not, 48 and 64
-    (wavefronts with 4 - 6 voices: past FILT2_FASTV, the general loop renders settled voices too)."""
+    (every oscillator wavefront in its all-settled loop with at most FILT2_LAUNCHV = 3 voices) - and two it does not:
+    48 (4 voices per wavefront: the all-settled loop's 4-voice instantiation, in the kernel but too slow to be dealt)
+    and 64 (5 - 6 voices: past FILT2_FASTV, the general loop renders settled voices too)."""
     monkeypatch.setenv("A2AMD_F2VPW", str(f2vpw))
 
     def build(be):
@@ -1066,6 +1067,57 @@ def test_subtractive_note_at_full_size_matches_oracle_golden():
     assert len(want) >= len(got)
     bad = np.nonzero(got != want[:len(got)])[0]
     assert not len(bad), f"{len(bad)} fragments differ, first {bad[:8]}"
+
+
+@pytest.mark.parametrize("nfilt", [8, 13])
+def test_long_chains_match_oracle(oracle_lib, nfilt):
+    """Round 6: a voice's chain may hold 16 units (8 before; the reference's list has no cap, core.c:163-300 - 16 is what a
+    command record's 4-bit chain position addresses).  wtosc; wtosc (adding); nfilt x filter12 in series (each in place:
+    the voice's scratch, as the engine wires a 1 -> 1 unit); panmix = 11 and 16 units, 60 voices, control writes to the
+    LAST filter and the pan between batches (records whose unit field is 9 - 15), against the oracle; a 17th unit is
+    refused loudly."""
+    from audiality2_amd.synth import K_WTOSC, K_FILTER12, K_PANMIX, PROCADD, fix
+    outs = []
+    for be in (make_gpu(max_batch=16), make_oracle(oracle_lib)):
+        sc = synth.Scene(be)
+        sc.root()
+        voices = []
+        for k in range(60):
+            key = sc._key()
+            units = [be.unit_init(key, K_WTOSC, 0, 0, 1, 0), be.unit_init(key, K_WTOSC, PROCADD, 0, 1, 0)]
+            units += [be.unit_init(key, K_FILTER12, 0, 1, 1, 0) for _ in range(nfilt)]
+            units.append(be.unit_init(key, K_PANMIX, PROCADD, 1, 2, 1))
+            p = fix(((k % 31) - 15) / 12.0)
+            for j, o in enumerate(units[:2]):
+                be.unit_write(o, 0, sc.wave_ids[(5 * k + j) % len(sc.wave_ids)])
+                be.unit_write(o, 1, p + (fix(0.02) if j else 0))
+                be.unit_write(o, 2, fix(0.02))
+            for j, f in enumerate(units[2:-1]):
+                be.unit_write(f, 0, p + fix(3.0 + 0.1 * j))      # cutoff, well above the note: eight low passes in a row
+                be.unit_write(f, 1, fix(1.0))
+            be.unit_write(units[-1], 1, fix(((k % 9) - 4) / 4.0))
+            voices.append(units)
+            sc.leaves.append(units)
+        parts = [sc.run(16, batch=16)]
+        for k, units in enumerate(voices):
+            if k % 3 == 0:
+                be.unit_write(units[-2], 0, fix(2.0), 0, 20 << 8)           # the last filter's cutoff, ramping
+            if k % 4 == 1:
+                be.unit_write(units[-1], 1, fix(-0.5), 0, 15 << 8)          # the pan: chain position nfilt + 2
+            if k % 5 == 2:
+                be.unit_write(units[-2], 1, fix(4.0), 0, 10 << 8)           # the last filter's q
+        parts.append(sc.run(32, batch=16))
+        outs.append(np.concatenate(parts, axis=1))
+        if be is not None and len(outs) == 1:
+            # (one more unit than the record format addresses)
+            key = sc._key()
+            for _ in range(16):
+                be.unit_init(key, K_FILTER12, 0, 1, 1, 0)
+            with pytest.raises(Exception):
+                be.unit_init(key, K_PANMIX, PROCADD, 1, 2, 1)
+        be.close()
+    assert outs[1].any()
+    assert first_diff(outs[0], outs[1]) is None
 
 
 @pytest.mark.parametrize("config", [1, 2, 3])

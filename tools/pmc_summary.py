@@ -37,6 +37,24 @@ def main():
                 except ValueError:
                     continue
                 per[(k, c)][(fn, row.get("Dispatch_Id"))] += v
+    # the kernel trace of the same run (--kernel-trace): total time per kernel, so that whoever reads the summary can
+    # pick the DOMINANT kernel of a workload by time instead of guessing it from the workload's name (round 5's review)
+    dur = collections.defaultdict(float)
+    calls = collections.Counter()
+    for fn in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
+        with open(fn, newline="") as f:
+            for row in csv.DictReader(f):
+                # (rocprofv3's kernel_trace.csv: Start_Timestamp / End_Timestamp, ns; other spellings tolerated - a trace
+                # that cannot be read leaves the summary without times and pmc_to_json.py says so: "kernel_chosen")
+                lo = {k.lower(): v for k, v in row.items() if k}
+                try:
+                    dt = float(lo.get("end_timestamp", lo.get("end", lo["endns"] if "endns" in lo else ""))) - \
+                        float(lo.get("start_timestamp", lo.get("start", lo["startns"] if "startns" in lo else "")))
+                except (KeyError, ValueError):
+                    continue
+                k = short(row.get("Kernel_Name", ""))
+                dur[k] += dt
+                calls[k] += 1
     out = {}
     for (k, c), d in sorted(per.items()):
         vals = sorted(d.values())
@@ -52,6 +70,11 @@ def main():
             hbm = (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0
             d["hbm_bytes_per_launch"] = hbm
             print(f"{label:>28s} {k:24s} {'-> HBM bytes/launch':24s} {hbm:16.6g}")
+    for k, d in out.items():
+        if k in dur:
+            d["trace_ns_total"] = dur[k]
+            d["trace_launches"] = calls[k]
+            print(f"{label:>28s} {k:24s} {'-> ns in this run':24s} {dur[k]:16.6g} over {calls[k]} launches")
     print("JSON " + json.dumps({label: out}))
 
 

@@ -2,10 +2,12 @@
 """Fold the "JSON {...}" lines tools/pmc_summary.py printed (one per counter pass)
 into the per-workload table bench.py reads (profiles/rNN_pmc.json).
 
-    python tools/pmc_to_json.py gpurun_out/round2/pmc_summary.txt > profiles/r02_pmc.json
+    python tools/pmc_to_json.py gpurun_out/round6/pmc_summary.txt tools/profile_round6.sh > profiles/r06_pmc.json
 
-Keys are "chain/voices/groups/fragments-per-step"; per key the dominant leaf
-kernel's HBM traffic per launch ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950
+(second argument: the script that made the summary - it is named in every entry's "source".)
+Keys are "chain/voices/groups/fragments-per-step"; per key the DOMINANT kernel - the one
+with the most time in the kernel trace of the counter runs (round 6; rounds 2-5 guessed it
+from the chain's name, which labelled every scripted workload k_leaf_fmpan) - with its HBM traffic per launch ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950
 correction of MI355X_MICROARCH.md) and its wave-level instruction counts per
 voice-fragment, plus the same for every other kernel of the step under "kernels".
 """
@@ -30,20 +32,31 @@ def code_shas():
 
 def main():
     shas = code_shas()
+    script = sys.argv[2] if len(sys.argv) > 2 else "an unnamed script"
     merged = {}
     for line in open(sys.argv[1]):
         if not line.startswith("JSON "):
             continue
         for label, kernels in json.loads(line[5:]).items():
             for k, d in kernels.items():
+                # (counters: one pass each; the trace time of a kernel: the longest of the passes' totals)
+                t = max(merged.get(label, {}).get(k, {}).get("trace_ns_total", 0.0), d.get("trace_ns_total", 0.0))
                 merged.setdefault(label, {}).setdefault(k, {}).update(d)
+                if t:
+                    merged[label][k]["trace_ns_total"] = t
     out = {}
     for label, kernels in merged.items():
         chain, voices, groups, B = label.split("/")
         voices, groups, B = int(voices), int(groups), int(B)
-        leaf = LEAF.get(chain, "k_leaf_oscpan" if chain.startswith("osc-pan") else "k_leaf_fmpan")
-        e = {"kernel": leaf, "source": f"rocprofv3 --pmc passes of bench.py --config shape {label} (tools/profile_round4.sh), "
-                                       "median launch", "kernels": {}}
+        timed = {k: d.get("trace_ns_total", 0.0) for k, d in kernels.items()}
+        if any(timed.values()):
+            leaf = max(timed, key=timed.get)
+            how = "by time in the counter runs' kernel trace"
+        else:       # (a summary from before round 6: no trace times in it)
+            leaf = LEAF.get(chain, "k_leaf_oscpan" if chain.startswith("osc-pan") else "k_leaf_fmpan")
+            how = "by the chain's name (no trace times in the summary)"
+        e = {"kernel": leaf, "kernel_chosen": how,
+             "source": f"rocprofv3 --pmc passes of workload {label} ({script}), median launch", "kernels": {}}
         for k, d in kernels.items():
             kd = dict(d)
             if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
