@@ -314,13 +314,32 @@ DEV ScalAcc<NW> bcast_load(const int *p)
 template<int NOSC>
 struct WinTaps { Coef4 k1[NOSC], k2[NOSC]; unsigned t1[NOSC], t2[NOSC]; unsigned head; int ak[NOSC], da[NOSC]; };
 
-template<int NOSC, class EA>
+// PLAIN (-1: look at the head, 0 / 1: the caller knows - the pipelined loops of win_run take a fragment's plain entries
+// and its others apart, so that neither loop branches on the kind between an entry's loads and the next one's: a
+// branch there cost more than the plain path saved - the wait at the join is for ALL loads in flight)
+template<int NOSC, class EA, int PLAIN = -1>
 DEV void win_taps_issue(const EA &E, const CoefRsrc rs, int lane, WinTaps<NOSC> &T)
 {
 	const unsigned head = (unsigned)E(WE_HEAD);
+	T.head = head;
+	if(PLAIN < 0 ? (head & WH_PLAIN) != 0 : PLAIN != 0) {
+		// the whole fragment, taps, everything at rest (a2amd_winctl.h): every lane holds a frame
+#pragma unroll
+		for(int o = 0; o < NOSC; ++o) {
+			const int b = WE_OSC + 6 * o;
+			const unsigned phlo = (unsigned)E(b + WO_B), phhi = (unsigned)E(b + WO_C), dph = (unsigned)E(b + WO_DPH);
+			const int cb = coef_base((unsigned)E(b + WO_A));
+			T.ak[o] = E(b + WO_AK);
+			T.da[o] = 0;
+			T.t1[o] = tap_phase((uint64_t)phlo | ((uint64_t)phhi << 32), (unsigned)lane * dph);
+			T.t2[o] = T.t1[o] + ((dph >> 16) >> 1);
+			T.k1[o] = coef_at(rs, cb, T.t1[o]);
+			T.k2[o] = coef_at(rs, cb, T.t2[o]);
+		}
+		return;
+	}
 	const int fl = lane - WH_OFF(head);
 	const bool in = (unsigned)fl < (unsigned)WH_LEN(head);
-	T.head = head;
 #pragma unroll
 	for(int o = 0; o < NOSC; ++o) {
 		const int b = WE_OSC + 6 * o;
@@ -428,23 +447,39 @@ DEV void bus_add(int *busmem, int off, int nch, int f, int lane, int dbg, int &a
 	a0 = a1 = 0;
 }
 
-// one entry, start to finish (not pipelined), oscillators + pan stage
-template<int NOSC, class EA>
-DEV void win_entry_now(const EA &E, const CoefRsrc rs, int lane, int &a0, int &a1)
+// the second half of an entry whose taps have been issued: interpolation, amplitude, pan stage into the bus sums
+template<int NOSC, class EA, int PLAIN = -1>
+DEV void win_finish_pan(const EA &E, const WinTaps<NOSC> &T, int lane, int &a0, int &a1)
 {
-	WinTaps<NOSC> T;
-	win_taps_issue<NOSC>(E, rs, lane, T);
+	if(PLAIN < 0 ? (T.head & WH_PLAIN) != 0 : PLAIN != 0) {
+		int x = 0;
+#pragma unroll
+		for(int o = 0; o < NOSC; ++o)
+			x = wadd(x, mul64s(hermite_c(T.k1[o], T.t1[o]) + hermite_c(T.k2[o], T.t2[o]), T.ak[o], 17));
+		a0 = wadd(a0, mul64s(x, E(WE_VOL), 24));	// (WE_VOL / WE_PAN: the two gains, WH_PLAIN)
+		a1 = wadd(a1, mul64s(x, E(WE_PAN), 24));
+		return;
+	}
 	const int fl = lane - WH_OFF(T.head);
 	const bool in = (unsigned)fl < (unsigned)WH_LEN(T.head);
 	const int x = win_oscs_finish<NOSC>(E, T, fl, in);
 	win_pan(T.head, E(WE_VOL), E(WE_DVOL), E(WE_PAN), E(WE_DPAN), x, fl, in, a0, a1);
 }
 
+// one entry, start to finish (not pipelined), oscillators + pan stage
+template<int NOSC, class EA>
+DEV void win_entry_now(const EA &E, const CoefRsrc rs, int lane, int &a0, int &a1)
+{
+	WinTaps<NOSC> T;
+	win_taps_issue<NOSC>(E, rs, lane, T);
+	win_finish_pan<NOSC>(E, T, lane, a0, a1);
+}
+
 // The voices whose entries sit one per lane in S (lane k = voice v0 + k of the wavefront's run, n of them), one
 // after the other: the coefficient loads of voice k + 1 are issued before voice k's arithmetic.  mask: which
 // lanes hold an entry at all.  on_bus(k): the wavefront moves to voice k (bus bookkeeping).
-template<int NOSC, int NW, class BUS>
-DEV void win_run(const int (&S)[NW], unsigned long long mask, const CoefRsrc rs, int lane, int &a0, int &a1, BUS on_bus)
+template<int NOSC, int NW, int PLAIN, class BUS>
+DEV void win_run_kind(const int (&S)[NW], unsigned long long mask, const CoefRsrc rs, int lane, int &a0, int &a1, BUS on_bus)
 {
 	if(!mask)
 		return;
@@ -453,22 +488,19 @@ DEV void win_run(const int (&S)[NW], unsigned long long mask, const CoefRsrc rs,
 	WinTaps<NOSC> T0;
 	{
 		const LaneAcc<NW> E = { S, k };
-		win_taps_issue<NOSC>(E, rs, lane, T0);
+		win_taps_issue<NOSC, LaneAcc<NW>, PLAIN>(E, rs, lane, T0);
 	}
 	for(;;) {
 		const int kn = mask ? (int)__builtin_ctzll(mask) : -1;
 		WinTaps<NOSC> T1;
 		if(kn >= 0) {
 			const LaneAcc<NW> En = { S, kn };
-			win_taps_issue<NOSC>(En, rs, lane, T1);
+			win_taps_issue<NOSC, LaneAcc<NW>, PLAIN>(En, rs, lane, T1);
 		}
 		on_bus(k);
 		{
 			const LaneAcc<NW> E = { S, k };
-			const int fl = lane - WH_OFF(T0.head);
-			const bool in = (unsigned)fl < (unsigned)WH_LEN(T0.head);
-			const int x = win_oscs_finish<NOSC>(E, T0, fl, in);
-			win_pan(T0.head, E(WE_VOL), E(WE_DVOL), E(WE_PAN), E(WE_DPAN), x, fl, in, a0, a1);
+			win_finish_pan<NOSC, LaneAcc<NW>, PLAIN>(E, T0, lane, a0, a1);
 		}
 		if(kn < 0)
 			break;
@@ -476,6 +508,15 @@ DEV void win_run(const int (&S)[NW], unsigned long long mask, const CoefRsrc rs,
 		k = kn;
 		T0 = T1;
 	}
+}
+
+// ... a fragment's plain entries (WH_PLAIN, a2amd_winctl.h) first, in a loop that knows they are, then the others
+template<int NOSC, int NW, class BUS>
+DEV void win_run(const int (&S)[NW], unsigned long long mask, const CoefRsrc rs, int lane, int &a0, int &a1, BUS on_bus)
+{
+	const unsigned long long plain = mask & __ballot(((unsigned)S[WE_HEAD] & WH_PLAIN) != 0);
+	win_run_kind<NOSC, NW, 1>(S, plain, rs, lane, a0, a1, on_bus);
+	win_run_kind<NOSC, NW, 0>(S, mask & ~plain, rs, lane, a0, a1, on_bus);
 }
 
 template<int NOSC>
@@ -642,6 +683,11 @@ DEV void winf_filter_t(int *row, int off, int len, int f0v, int df, int qv, int 
 DEV void winf_filter(int *row, int off, int len, int f0v, int df, int qv, int qd, int lp, int bp, int hp, int &d1, int &d2)
 {
 	const bool lponly = WINF_SPEC && __all((bp | hp) == 0), rest = WINF_SPEC && __all((df | qd) == 0);
+	// (Round 6, tried and dropped: a blocked loop for the case that every lane's window is the whole fragment - 8 or 4 frames
+	// at a time, the next block on its way from the LDS, as k_leaf_oscfiltpan's filt_row - measured SLOWER on one box
+	// against this loop: 16 384 x 64, wtosc-filter12-panmix scripted 0.896 -> 0.948 ms, gliding 0.633 -> 0.686; two
+	// oscillators 1.472 -> 1.624, 1.049 -> 1.141 (profiles/r06_window_kernels_ab.txt).  The kernel sits at its 128
+	// registers; the block buffers spilled.)
 	if(lponly && rest)
 		winf_filter_t<true, true>(row, off, len, f0v, df, qv, qd, lp, bp, hp, d1, d2);
 	else if(lponly)
@@ -837,14 +883,14 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 					WinTaps<NOSC> T0;
 					{
 						const LaneAcc<NW> E = { R, k };
-						win_taps_issue<NOSC>(E, rs, lane, T0);
+						win_taps_issue<NOSC, LaneAcc<NW>, 0>(E, rs, lane, T0);	// (a filter class entry is never WH_PLAIN)
 					}
 					for(;;) {
 						const int kn = mask ? (int)__builtin_ctzll(mask) : -1;
 						WinTaps<NOSC> T1;
 						if(kn >= 0) {
 							const LaneAcc<NW> En = { R, kn };
-							win_taps_issue<NOSC>(En, rs, lane, T1);
+							win_taps_issue<NOSC, LaneAcc<NW>, 0>(En, rs, lane, T1);
 						}
 						{
 							const LaneAcc<NW> E = { R, k };
@@ -872,7 +918,7 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 					for(int q = 1; q < n; ++q) {
 						const ScalAcc<NW> E = bcast_load<NW>(wext + ((size_t)e0 + q) * A2D_WIN_WORDS);
 						WinTaps<NOSC> T;
-						win_taps_issue<NOSC>(E, rs, lane, T);
+						win_taps_issue<NOSC, ScalAcc<NW>, 0>(E, rs, lane, T);
 						const int fl = lane - WH_OFF(T.head);
 						const bool in = (unsigned)fl < (unsigned)WH_LEN(T.head);
 						const int x = win_oscs_finish<NOSC>(E, T, fl, in);

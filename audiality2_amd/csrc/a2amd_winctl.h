@@ -36,6 +36,13 @@ enum { WM_SILENT = 0, WM_TAPS, WM_NOISE };
 #define WH_FRESH     (1u << 14)
 #define WH_MODE(h, o) (((h) >> (15 + 2 * (o))) & 3u)
 #define WH_EXTRAS(h) ((int)(((h) >> 19) & 127u))
+// Round 6: the window every voice has in most fragments - the whole fragment, every oscillator on taps with its
+// amplitude at rest, volume and pan at rest (classes without filter12) - is marked, and WE_VOL / WE_PAN hold the two
+// GAINS of panmix_process12 (panmix.c:84-95: v0 = vol - vp, v1 = vol + vp, vp = pan * vol >> 24, clamped where the
+// head says so) instead of volume and pan: the render pass takes such an entry through a straight line - no lane
+// predicate, no mode or ramp branches, no 64-bit products on the scalar unit (k_win_render: 96 vector + 114 scalar
+// instructions per window in the general path, a2amd_win.hip)
+#define WH_PLAIN     (1u << 26)
 
 // (a uniform address through the constant address space is a scalar load)
 typedef int Int4 __attribute__((ext_vector_type(4)));
@@ -419,6 +426,26 @@ DEV unsigned ctl_window(CtlVoice<NOSC, FILT> &s, const A2DWave *waves, const PTa
 	W[WE_PAN] = pan.value; W[WE_DPAN] = pan.delta;
 	ramp_run(vol, len);
 	ramp_run(pan, len);
+	if(!FILT && off == 0 && len == A2D_FRAG && !(W[WE_DVOL] | W[WE_DPAN])) {
+		bool plain = true;
+#pragma unroll
+		for(int o = 0; o < NOSC; ++o)
+			plain = plain && WH_MODE(head, o) == WM_TAPS && W[WE_OSC + 6 * o + WO_DA] == 0;
+		if(plain) {
+			// (win_pan's branch for volume and pan at rest, a2amd_win.hip: the same integer expressions)
+			const int v = W[WE_VOL], p = W[WE_PAN];
+			const int vp = mul64s(p, v, 24);
+			int v0 = wsub(v, vp), v1 = wadd(v, vp);
+			if(head & WH_CLAMP) {
+				const int lim = wshl(v, 1);
+				if(v0 > lim) v0 = lim;
+				if(v1 > lim) v1 = lim;
+			}
+			W[WE_VOL] = v0;
+			W[WE_PAN] = v1;
+			head |= WH_PLAIN;
+		}
+	}
 	W[WE_HEAD] = (int)head;
 	return head;
 }
