@@ -875,7 +875,10 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 			// the pan stage's time to arrive), the rest one by one
 			if(s < nfr) {
 				int *const tile = tiles + (s % 3) * vpg * WINF_PITCH;
-				auto oscs = [&](const int (&R)[NW], unsigned long long mask) {
+				// (as win_run: the entries whose oscillator part is plain - WH_PLAINOSC, a2amd_winctl.h - in a pipelined loop that
+				// knows they are, then the others; no branch on the kind between an entry's loads and the next one's)
+				auto oscs_kind = [&](const int (&R)[NW], unsigned long long mask, auto plain_c) {
+					constexpr int PL = decltype(plain_c)::value;
 					if(!mask)
 						return;
 					int k = (int)__builtin_ctzll(mask);
@@ -883,16 +886,22 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 					WinTaps<NOSC> T0;
 					{
 						const LaneAcc<NW> E = { R, k };
-						win_taps_issue<NOSC, LaneAcc<NW>, 0>(E, rs, lane, T0);	// (a filter class entry is never WH_PLAIN)
+						win_taps_issue<NOSC, LaneAcc<NW>, PL>(E, rs, lane, T0);
 					}
 					for(;;) {
 						const int kn = mask ? (int)__builtin_ctzll(mask) : -1;
 						WinTaps<NOSC> T1;
 						if(kn >= 0) {
 							const LaneAcc<NW> En = { R, kn };
-							win_taps_issue<NOSC, LaneAcc<NW>, 0>(En, rs, lane, T1);
+							win_taps_issue<NOSC, LaneAcc<NW>, PL>(En, rs, lane, T1);
 						}
-						{
+						if(PL) {
+							int x = 0;
+#pragma unroll
+							for(int o = 0; o < NOSC; ++o)
+								x = wadd(x, mul64s(hermite_c(T0.k1[o], T0.t1[o]) + hermite_c(T0.k2[o], T0.t2[o]), T0.ak[o], 17));
+							tile[(lo + k) * WINF_PITCH + lane] = x;
+						} else {
 							const LaneAcc<NW> E = { R, k };
 							const int fl = lane - WH_OFF(T0.head);
 							const bool in = (unsigned)fl < (unsigned)WH_LEN(T0.head);
@@ -906,6 +915,11 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 						k = kn;
 						T0 = T1;
 					}
+				};
+				auto oscs = [&](const int (&R)[NW], unsigned long long mask) {
+					const unsigned long long plain = mask & __ballot(((unsigned)R[WE_HEAD] & WH_PLAINOSC) != 0);
+					oscs_kind(R, plain, std::integral_constant<int, 1>{});
+					oscs_kind(R, mask & ~plain, std::integral_constant<int, 0>{});
 				};
 				oscs(S, __ballot(mine && WH_LEN((unsigned)S[WE_HEAD]) != 0));
 				oscs(X, __ballot(nx > 0));

@@ -43,6 +43,9 @@ enum { WM_SILENT = 0, WM_TAPS, WM_NOISE };
 // predicate, no mode or ramp branches, no 64-bit products on the scalar unit (k_win_render: 96 vector + 114 scalar
 // instructions per window in the general path, a2amd_win.hip)
 #define WH_PLAIN     (1u << 26)
+// ... and in the filter classes, whose pan stage is a step of its own and keeps volume and pan as they are: the
+// OSCILLATOR part of such a window is plain (whole fragment, taps, amplitudes at rest) - k_win_render_f's workers
+#define WH_PLAINOSC  (1u << 27)
 
 // (a uniform address through the constant address space is a scalar load)
 typedef int Int4 __attribute__((ext_vector_type(4)));
@@ -426,6 +429,14 @@ DEV unsigned ctl_window(CtlVoice<NOSC, FILT> &s, const A2DWave *waves, const PTa
 	W[WE_PAN] = pan.value; W[WE_DPAN] = pan.delta;
 	ramp_run(vol, len);
 	ramp_run(pan, len);
+	if(FILT && off == 0 && len == A2D_FRAG) {
+		bool plain = true;
+#pragma unroll
+		for(int o = 0; o < NOSC; ++o)
+			plain = plain && WH_MODE(head, o) == WM_TAPS && W[WE_OSC + 6 * o + WO_DA] == 0;
+		if(plain)
+			head |= WH_PLAINOSC;
+	}
 	if(!FILT && off == 0 && len == A2D_FRAG && !(W[WE_DVOL] | W[WE_DPAN])) {
 		bool plain = true;
 #pragma unroll
