@@ -391,6 +391,7 @@ struct a2amd_ctx {
 	long long serial_base = 0;		// fragments rendered before this batch
 	int n_leaf_dyn = 0, static_len = 0;
 	int n_dyn_osc1 = 0, n_dyn_osc2 = 0, n_dyn_filt = 0;	// ... of n_leaf_dyn, first in the list: k_leaf_recs renders them
+	bool o2f_quiet = true;			// this batch: the class's voices without records go to k_leaf_osc2filtpan (upload() decides)
 	int n_dyn_filt2 = 0, n_dyn_rest = 0;	// ... 2 x wtosc-filter12-panmix (round 6: a quiet kernel of its own) / the general kernel's
 	int n_o2f_leaf = 0;			// 2 x wtosc-filter12-panmix leaves (list_all, behind the general leaves)
 	int n_started_live = 0;			// voices the engine is walking

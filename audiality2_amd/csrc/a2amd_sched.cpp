@@ -777,6 +777,25 @@ int upload(a2amd_ctx *c)
 			v.dynf2_run = c->serial_base;
 			dyn_f2.push_back(vi);
 		}
+		// ... but not in a small scene.  A launch of k_leaf_osc2filtpan takes as long as its filter wavefront's chain
+		// through the batch whatever its voice count - and on the context's one stream it runs BEHIND the records kernel,
+		// which renders a song's few such voices inside the launch that renders the song's other record voices
+		// (measured: the 60-voice song, 500 s, 2.94 s in round 5 -> 3.53 s with the quiet kernel for its handful of notes,
+		// profiles/r06_song_timing.jsonl).  Below A2AMD_O2F_MIN voices of the class (default 512) every voice of it is the
+		// records / window kernels', as in rounds 2 - 5.
+		static const int o2f_min = getenv("A2AMD_O2F_MIN") ? atoi(getenv("A2AMD_O2F_MIN")) : 512;
+		c->o2f_quiet = c->n_o2f_leaf >= o2f_min;
+		if(!c->o2f_quiet && c->n_o2f_leaf) {
+			const int at = c->n_fast_leaf + c->n_osc2_leaf + c->n_filt_leaf + c->n_fm_leaf + c->n_leaf;
+			for(int k = 0; k < c->n_o2f_leaf; ++k) {
+				const int vi = c->list_all[at + k];
+				HVoice &v = c->voices[vi];
+				if(v.dynf2_run == c->serial_base || v.mode_mix)
+					continue;
+				v.dynf2_run = c->serial_base;
+				dyn_f2.push_back(vi);
+			}
+		}
 		// (the walk order usually has them grouped by bus already)
 		auto by_bus_dyn = [&](int a, int b) { return c->voices[a].out_off < c->voices[b].out_off; };
 		for(std::vector<int> *l : { &dyn_o1, &dyn_o2, &dyn_f1, &dyn_f2, &dyn_rest })
@@ -1088,7 +1107,7 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 	const bool spec = c->vm.fused && c->vm.spec_use;
 	for(int k = 0; k < 4; ++k)
 		if(counts[k]) {
-			jobs[nj++] = Job{ nosc[k], filt[k], counts[k], k == 3, lists[k], -1, false, 0, 0 };	// (k == 3: see upload(), dyn_f2)
+			jobs[nj++] = Job{ nosc[k], filt[k], counts[k], k == 3 && c->o2f_quiet, lists[k], -1, false, 0, 0 };	// (k == 3: see upload(), dyn_f2)
 			nvoices += (size_t)counts[k];
 		}
 	// (the control pass takes room in the pool by the length of a voice's record run: every gliding voice's run is
@@ -1476,7 +1495,7 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 					return c->fail(A2AMD_EHIP, "filter leaf launch failed: %s", hipGetErrorString(hipGetLastError()));
 				++c->stats.launches;
 			}
-			if(c->n_o2f_leaf) {
+			if(c->n_o2f_leaf && c->o2f_quiet) {
 				// 2 x wtosc-filter12-panmix without records (round 6).  A workgroup (16 wavefronts, 128 registers: one per CU)
 				// takes as long as its filter wavefront's chain whatever its voice count, as long as every oscillator
 				// wavefront stays in its all-settled loop (a2d_osc2filtpan_max_vpg voices): the voices are dealt over the
@@ -1546,13 +1565,13 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 				if(kinds > 1 && total <= 4096 && !getenv("A2AMD_RVPW")) {
 					// few voices of several kinds (a song): one launch - on one stream the per-kind
 					// launches would run back to back, each as long as one voice's walk through the batch
-					if(a2d_launch_leaf_recs_all(c->d_params, c->hparams, lists, counts, 1, c->stream, 8))
+					if(a2d_launch_leaf_recs_all(c->d_params, c->hparams, lists, counts, 1, c->stream, c->o2f_quiet ? 8 : 0))
 						return c->fail(A2AMD_EHIP, "leaf records launch failed: %s", hipGetErrorString(hipGetLastError()));
 					++c->stats.launches;
 				} else {
 					static const int nosc[4] = { 1, 2, 1, 2 }, filt[4] = { 0, 0, 1, 1 };
 					for(int k = 0; k < 4; ++k)
-						if(int r = recs(nosc[k], filt[k], lists[k], counts[k], k == 3))
+						if(int r = recs(nosc[k], filt[k], lists[k], counts[k], k == 3 && c->o2f_quiet))
 							return r;
 				}
 				// ... and the voices whose records the device VM has just written, by class (those it

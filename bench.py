@@ -425,7 +425,9 @@ def engine_in_loop(cases=None, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fr
             for mode, walk in modes:
                 # (without the walk's short cut a fragment costs ~40 ns per voice of engine walk: bound the run)
                 # ... and with it a fragment of a quiet scene costs microseconds: four times as many
-                nruns[mode] = (nfr if "Scripted" in program else 4 * nfr) if walk else \
+                # (round 6: the scripted cells as long as the others - the device VM adopts 16 384 voices over the first sixty
+                # batches or so, and a run of 1 024 fragments was over before the steady state began)
+                nruns[mode] = 4 * nfr if walk else \
                     max(hf, buf // 64, min(nfr, int(2.5e6 / (voices * 0.04))))
             # ... and where the SECOND hashed window lies: as far into the shortest of them as the one-thread CPU
             # render of the same scene gets in about a minute (1.5e9 voice-samples), on a 4 096-frame boundary
@@ -496,7 +498,7 @@ def engine_in_loop(cases=None, buffers=ENGINE_BUFFERS, hash_fragments=64, gpu_fr
 def pmc_entry(chain, voices, groups, B):
     """PMC-derived figures for this workload's dominant kernel (profiles/*.json, tools/pmc_summary.py)."""
     key = f"{chain}/{voices}/{groups}/{B}"
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -536,7 +538,7 @@ def kernel_code_sha(kernel):
 def valu_mix_entry(kernel):
     """The measured issue rate of the kernel's own instruction mix (tools/valu_mix.py)."""
     try:
-        for name in ("r04_valu_mix.json", "r03_valu_mix.json"):
+        for name in ("r06_valu_mix.json", "r04_valu_mix.json", "r03_valu_mix.json"):
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 with open(path) as f:

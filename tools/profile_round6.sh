@@ -9,16 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 B="python $REPO/bench.py"
 pre="$REPO/audiality2_amd/liba2amd_walk.so $REPO/audiality2_amd/liba2amd_units.so"
 
-# 1. the bench line with the driver's flags (stdout = the contract line, side file = everything), and config 6
-( cd $REPO && $B --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; cp bench_details.json $OUT/bench_default_details.json )
-( cd $REPO && $B --config 6 --steps 7 --warmup 1 > $OUT/bench_cfg6.json 2> $OUT/bench_cfg6.err )
-
-# 2. the kernel trace of the same command (without the engine / CPU legs)
-rm -rf /tmp/prof_k; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-realtime --no-engine --no-extra > /tmp/prof_k.log 2>&1
-find /tmp/prof_k -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
-find /tmp/prof_k -name "*kernel_trace.csv" | head -1 | xargs -r head -1 > $OUT/kernel_trace_header.txt
-
-# 3. PMC passes (counters only, own runs; --kernel-trace for the per-kernel times pmc_to_json.py picks the dominant kernel by)
+# 1. PMC passes (counters only, own runs; --kernel-trace for the per-kernel times pmc_to_json.py picks the dominant kernel by)
 rm -f $OUT/pmc_summary.txt
 pmc() { # label, counters, command...
   local label=$1 ctr=$2; shift 2
@@ -38,6 +29,21 @@ for ctr in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VAL
     python $REPO/tools/pmc_summary.py /tmp/prof_p "vm-osc-pan/16384/0/64" >> $OUT/pmc_summary.txt )
 done
 ( cd $REPO && python tools/pmc_to_json.py $OUT/pmc_summary.txt tools/profile_round6.sh > $OUT/pmc.json 2>/dev/null )
+# ... and the measured issue rate of the headline kernels' own hot-loop instruction mixes (roofline_valu.peak)
+( cd $REPO && timeout 900 python tools/valu_mix.py > $OUT/valu_mix.json 2> $OUT/valu_mix.err )
+# (the bench line below quotes both: they are this round's, of the binaries it runs)
+cp $OUT/pmc.json $REPO/profiles/r06_pmc.json
+[ -s $OUT/valu_mix.json ] && cp $OUT/valu_mix.json $REPO/profiles/r06_valu_mix.json
+
+
+# 2. the bench line with the driver's flags (stdout = the contract line, side file = everything), and config 6
+( cd $REPO && $B --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; cp bench_details.json $OUT/bench_default_details.json )
+( cd $REPO && $B --config 6 --steps 7 --warmup 1 > $OUT/bench_cfg6.json 2> $OUT/bench_cfg6.err )
+
+# 3. the kernel trace of the same command (without the engine / CPU legs)
+rm -rf /tmp/prof_k; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-realtime --no-engine --no-extra > /tmp/prof_k.log 2>&1
+find /tmp/prof_k -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
+find /tmp/prof_k -name "*kernel_trace.csv" | head -1 | xargs -r head -1 > $OUT/kernel_trace_header.txt
 
 # 4. the scripted batches: kernel times per batch (window kernels), the quiet kernels beside them
 cd $REPO
