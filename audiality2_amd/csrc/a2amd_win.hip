@@ -314,7 +314,8 @@ DEV ScalAcc<NW> bcast_load(const int *p)
 template<int NOSC>
 struct WinTaps { Coef4 k1[NOSC], k2[NOSC]; unsigned t1[NOSC], t2[NOSC]; unsigned head; int ak[NOSC], da[NOSC]; };
 
-// PLAIN (-1: look at the head, 0 / 1: the caller knows - the pipelined loops of win_run take a fragment's plain entries
+// PLAIN (-1: look at the head; 0 / 1 / 2: the caller knows - 1 a plain window that is the whole fragment, 2 a plain window that
+// is cut: the frame index of the lanes outside clamped, their share dropped with a select - the pipelined loops of win_run take a fragment's plain entries
 // and its others apart, so that neither loop branches on the kind between an entry's loads and the next one's: a
 // branch there cost more than the plain path saved - the wait at the join is for ALL loads in flight)
 template<int NOSC, class EA, int PLAIN = -1>
@@ -323,7 +324,10 @@ DEV void win_taps_issue(const EA &E, const CoefRsrc rs, int lane, WinTaps<NOSC> 
 	const unsigned head = (unsigned)E(WE_HEAD);
 	T.head = head;
 	if(PLAIN < 0 ? (head & WH_PLAIN) != 0 : PLAIN != 0) {
-		// the whole fragment, taps, everything at rest (a2amd_winctl.h): every lane holds a frame
+		// taps, everything at rest (a2amd_winctl.h).  A lane outside the window (a cut one) reads where frame 0 reads -
+		// a valid address - and win_finish_pan drops what it made of it: no branch, no exec mask
+		const int flp = lane - WH_OFF(head);
+		const unsigned flc = PLAIN == 1 ? (unsigned)lane : (unsigned)flp < (unsigned)WH_LEN(head) ? (unsigned)flp : 0u;
 #pragma unroll
 		for(int o = 0; o < NOSC; ++o) {
 			const int b = WE_OSC + 6 * o;
@@ -331,7 +335,7 @@ DEV void win_taps_issue(const EA &E, const CoefRsrc rs, int lane, WinTaps<NOSC> 
 			const int cb = coef_base((unsigned)E(b + WO_A));
 			T.ak[o] = E(b + WO_AK);
 			T.da[o] = 0;
-			T.t1[o] = tap_phase((uint64_t)phlo | ((uint64_t)phhi << 32), (unsigned)lane * dph);
+			T.t1[o] = tap_phase((uint64_t)phlo | ((uint64_t)phhi << 32), flc * dph);
 			T.t2[o] = T.t1[o] + ((dph >> 16) >> 1);
 			T.k1[o] = coef_at(rs, cb, T.t1[o]);
 			T.k2[o] = coef_at(rs, cb, T.t2[o]);
@@ -456,6 +460,8 @@ DEV void win_finish_pan(const EA &E, const WinTaps<NOSC> &T, int lane, int &a0, 
 #pragma unroll
 		for(int o = 0; o < NOSC; ++o)
 			x = wadd(x, mul64s(hermite_c(T.k1[o], T.t1[o]) + hermite_c(T.k2[o], T.t2[o]), T.ak[o], 17));
+		if(PLAIN != 1)
+			x = (unsigned)(lane - WH_OFF(T.head)) < (unsigned)WH_LEN(T.head) ? x : 0;	// (lanes outside a cut window)
 		a0 = wadd(a0, mul64s(x, E(WE_VOL), 24));	// (WE_VOL / WE_PAN: the two gains, WH_PLAIN)
 		a1 = wadd(a1, mul64s(x, E(WE_PAN), 24));
 		return;
@@ -515,7 +521,10 @@ template<int NOSC, int NW, class BUS>
 DEV void win_run(const int (&S)[NW], unsigned long long mask, const CoefRsrc rs, int lane, int &a0, int &a1, BUS on_bus)
 {
 	const unsigned long long plain = mask & __ballot(((unsigned)S[WE_HEAD] & WH_PLAIN) != 0);
-	win_run_kind<NOSC, NW, 1>(S, plain, rs, lane, a0, a1, on_bus);
+	// (offset 0, length 64: the low 13 bits of the head)
+	const unsigned long long whole = plain & __ballot(((unsigned)S[WE_HEAD] & 0x1fffu) == ((unsigned)A2D_FRAG << 6));
+	win_run_kind<NOSC, NW, 1>(S, whole, rs, lane, a0, a1, on_bus);
+	win_run_kind<NOSC, NW, 2>(S, plain & ~whole, rs, lane, a0, a1, on_bus);
 	win_run_kind<NOSC, NW, 0>(S, mask & ~plain, rs, lane, a0, a1, on_bus);
 }
 

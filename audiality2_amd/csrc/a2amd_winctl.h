@@ -36,8 +36,8 @@ enum { WM_SILENT = 0, WM_TAPS, WM_NOISE };
 #define WH_FRESH     (1u << 14)
 #define WH_MODE(h, o) (((h) >> (15 + 2 * (o))) & 3u)
 #define WH_EXTRAS(h) ((int)(((h) >> 19) & 127u))
-// Round 6: the window every voice has in most fragments - the whole fragment, every oscillator on taps with its
-// amplitude at rest, volume and pan at rest (classes without filter12) - is marked, and WE_VOL / WE_PAN hold the two
+// Round 6: the window every voice has in most fragments - every oscillator on taps with its amplitude at rest, volume
+// and pan at rest (classes without filter12); whole fragments and cut windows alike - is marked, and WE_VOL / WE_PAN hold the two
 // GAINS of panmix_process12 (panmix.c:84-95: v0 = vol - vp, v1 = vol + vp, vp = pan * vol >> 24, clamped where the
 // head says so) instead of volume and pan: the render pass takes such an entry through a straight line - no lane
 // predicate, no mode or ramp branches, no 64-bit products on the scalar unit (k_win_render: 96 vector + 114 scalar
@@ -437,7 +437,10 @@ DEV unsigned ctl_window(CtlVoice<NOSC, FILT> &s, const A2DWave *waves, const PTa
 		if(plain)
 			head |= WH_PLAINOSC;
 	}
-	if(!FILT && off == 0 && len == A2D_FRAG && !(W[WE_DVOL] | W[WE_DPAN])) {
+	// (any window of the kind, cut ones too - a script's sub-fragment windows: the render pass clamps the frame index of
+	// the lanes outside and drops their share with a select, no branch; first cut: whole fragments only, and every second
+	// voice-fragment of a scripted batch took the general path)
+	if(!FILT && len > 0 && !(W[WE_DVOL] | W[WE_DPAN])) {
 		bool plain = true;
 #pragma unroll
 		for(int o = 0; o < NOSC; ++o)
