@@ -909,7 +909,10 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 #pragma unroll
 							for(int o = 0; o < NOSC; ++o)
 								x = wadd(x, mul64s(hermite_c(T0.k1[o], T0.t1[o]) + hermite_c(T0.k2[o], T0.t2[o]), T0.ak[o], 17));
-							tile[(lo + k) * WINF_PITCH + lane] = x;
+							// (PL == 2, a cut window: the lanes outside it write the row's padding cell - WINF_PITCH is 65 -
+							// instead of a store under an exec mask)
+							const int col = PL == 1 || (unsigned)(lane - WH_OFF(T0.head)) < (unsigned)WH_LEN(T0.head) ? lane : A2D_FRAG;
+							tile[(lo + k) * WINF_PITCH + col] = x;
 						} else {
 							const LaneAcc<NW> E = { R, k };
 							const int fl = lane - WH_OFF(T0.head);
@@ -927,7 +930,9 @@ void k_win_render_f(const int *__restrict__ list, int nlist, int vpg, int fa, in
 				};
 				auto oscs = [&](const int (&R)[NW], unsigned long long mask) {
 					const unsigned long long plain = mask & __ballot(((unsigned)R[WE_HEAD] & WH_PLAINOSC) != 0);
-					oscs_kind(R, plain, std::integral_constant<int, 1>{});
+					const unsigned long long whole = plain & __ballot(((unsigned)R[WE_HEAD] & 0x1fffu) == ((unsigned)A2D_FRAG << 6));
+					oscs_kind(R, whole, std::integral_constant<int, 1>{});
+					oscs_kind(R, plain & ~whole, std::integral_constant<int, 2>{});
 					oscs_kind(R, mask & ~plain, std::integral_constant<int, 0>{});
 				};
 				oscs(S, __ballot(mine && WH_LEN((unsigned)S[WE_HEAD]) != 0));

@@ -429,7 +429,7 @@ DEV unsigned ctl_window(CtlVoice<NOSC, FILT> &s, const A2DWave *waves, const PTa
 	W[WE_PAN] = pan.value; W[WE_DPAN] = pan.delta;
 	ramp_run(vol, len);
 	ramp_run(pan, len);
-	if(FILT && off == 0 && len == A2D_FRAG) {
+	if(FILT && len > 0) {	// (cut windows too: k_win_render_f's workers send the lanes outside to the row's padding cell)
 		bool plain = true;
 #pragma unroll
 		for(int o = 0; o < NOSC; ++o)
