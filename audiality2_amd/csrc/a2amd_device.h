@@ -128,6 +128,8 @@ struct A2DRun { int32_t first, count; };
 #define A2D_VM_TRAPWRITE 0xfeu		// cmap: wired to something the device VM cannot write - the voice leaves before it would
 #define A2D_VM_MAXCUT  2
 #define A2D_VM_MAXENV  2
+#define A2D_VM_MAXPOS  8		// chain positions the device VM's register map can name (cmap, A2DVmEnv::target: a nibble, of which 14 and
+				// 15 mean something else): a voice with a longer chain stays the engine thread's (a2amd_vm_adopt)
 #define A2D_VM_ENVPOS  14		// cmap chain position that stands for "the target register of env unit <register nibble>"
 #define A2D_ENV_LUTSHIFT 6		// A2ENV_LUTSHIFT, env.c:27
 #define A2D_ENV_LUTSIZE  (1 << A2D_ENV_LUTSHIFT)
@@ -238,6 +240,7 @@ struct A2DVmwOut {
 	int        *vactive;	// [voice slot]
 	A2DRun     *runs;	// [voice slot]
 	uint32_t   *total;	// [1] += voices that faulted
+	uint32_t   *idle;	// += voices of the list the VM leaves alone this batch (the quiet kernels'), or null
 };
 // a speculative pass's results into the live state: the voices of window class (nosc, filt) in vp.list (vm slots)
 int a2d_launch_vm_commit(const A2DVmParams &vp, const A2DParams &hp, int nosc, int filt, const A2DVmwOut &from, void *stream);
@@ -248,7 +251,8 @@ int a2d_launch_vm_commit(const A2DVmParams &vp, const A2DParams &hp, int nosc, i
 int a2d_launch_vm_win(const A2DVmParams &vp, const A2DParams &hp, int nosc, int filt, int fa, int fb, uint32_t now_fa,
 		uint32_t batch_end, int *wslot, int *wext, int *wscr, unsigned *widx, unsigned *wtop, unsigned wcap, void *stream,
 		const A2DVmwOut *out = nullptr);	// (out: null = the live arrays)
-#define A2D_VMW_ROW (64 - 1 - A2D_WIN_STAGED)	/* entries of wscr per voice of the list (A2D_WIN_WORDS each) */
+#define A2D_VMW_ROW (64 - 1 - 1)	/* entries of wscr per voice of the list (A2D_WIN_WORDS each): a fragment's windows beyond
+				 * the first and the staged ones - one at least (WIN_EXLN, a2amd_winctl.h) */
 
 // launchers implemented in a2amd_kernels.hip (stream = hipStream_t)
 // dparams / dlist are device pointers; 'vpw' voices of the list per wavefront

@@ -277,6 +277,10 @@ struct VmHost {
 	uint64_t list_serial = 0;	// counts the rebuilds of the lists
 	hipStream_t pred_stream = nullptr;
 	hipEvent_t pred_after = nullptr, pred_ev = nullptr;
+	hipEvent_t spec_go = nullptr;		// on pred_stream, right in front of a speculative pass: the render pass waits for it
+	bool spec_go_pending = false;
+	uint32_t spec_idle[3] = { 0, 0, 0 };	// of the pass that was taken: voices of each class it left to the quiet kernels
+	uint64_t quiet_skipped = 0;		// quiet-kernel launches not made because of that (issue_kernels)
 	unsigned *d_pred = nullptr, *h_pred = nullptr;
 	bool pred_valid = false;
 	uint64_t pred_serial = 0;

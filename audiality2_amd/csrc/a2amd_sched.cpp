@@ -1218,7 +1218,7 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 			A2DVmParams vp;
 			vm_class_params(c, b.vmk, &vp);
 			VmHost &m = c->vm;
-			const A2DVmwOut from = { m.d_vmv_sh.d, m.d_ustate_sh.d, m.d_vactive_sh.d, m.d_runs_sh.d, m.d_stotal };
+			const A2DVmwOut from = { m.d_vmv_sh.d, m.d_ustate_sh.d, m.d_vactive_sh.d, m.d_runs_sh.d, m.d_stotal, nullptr };
 			r = a2d_launch_vm_commit(vp, c->hparams, b.nosc, b.filt, from, st);
 		} else if(b.vmk >= 0) {
 			A2DVmParams vp;
@@ -1322,9 +1322,14 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 			HIPCHK(c, hipEventRecord(tev[1], c->stream));
 		// (one slab, one stream: the batch's other leaf kernels and the speculative pass for the next batch go here, the
 		// render passes behind them - issue_kernels)
-		if(nslabs == 1 && !wtiming)
+		if(nslabs == 1 && !wtiming) {
 			if(int r = mid())
 				return r;
+			if(c->vm.spec_go_pending) {	// (the pass first, then the render pass: vm_speculate)
+				HIPCHK(c, hipStreamWaitEvent(c->stream, c->vm.spec_go, 0));
+				c->vm.spec_go_pending = false;
+			}
+		}
 		at = atw = 0;
 		for(int j = 0; j < nj; ++j) {
 			const Job &b = jobs[j];
@@ -1458,7 +1463,27 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 			if(leaves_done)
 				return 0;
 			leaves_done = true;
-			if(c->n_fast_leaf) {
+			// A class whose quiet voices are ALL the device VM's, none of them left alone this batch - the speculative pass
+			// that was taken for it counted (A2DVmwOut::idle) - has nothing for its quiet kernel to do, and a launch that
+			// finds that out voice by voice is 10 us (k_leaf_oscpan + commit) to 80 us (k_leaf_oscfiltpan: sixteen
+			// wavefronts per workgroup through the batch's fragments, barriers and all) in front of the next pass
+			// (profiles/r06_timeline_before.txt).  The launch classes contain the VM's (every live voice of the class is in
+			// the list, classify above): equal counts are equal sets.
+			// Not for the filter class: there the 80 us happen to keep the order that is best for it - the render pass onto
+			// the CUs first, the next pass behind it (vm_speculate) - and without them the two start together: 16 384 voices,
+			// a2_Run(4096) 1 398 -> 1 416 us per buffer, a2_Run(1024) 399 -> 416; with the pass held back behind the render
+			// pass instead 1 370 and 408 (profiles/r06_go_skip_ab.txt).  A2AMD_VMSKIP: bit 0 the classes without filter12,
+			// bit 1 the one with.
+			static const int vmskip = getenv("A2AMD_VMSKIP") ? atoi(getenv("A2AMD_VMSKIP")) : 1;
+			auto none_quiet = [&](int k, int nleaf) {
+				return (vmskip & (k == 2 ? 2 : 1)) && c->vm.spec_use && !c->vm.list.empty() && c->vm.n_cls[k] == nleaf && c->vm.spec_idle[k] == 0;
+			};
+			if(c->n_fast_leaf && none_quiet(0, c->n_fast_leaf)) {
+				const bool solo = !c->n_osc2_leaf && !c->n_filt_leaf && !c->n_fm_leaf && !c->n_leaf && !c->n_leaf_dyn && !c->n_o2f_leaf;
+				if(solo && e1)
+					HIPCHK(c, hipEventRecord(e1, c->stream));
+				++c->vm.quiet_skipped;
+			} else if(c->n_fast_leaf) {
 				int vpw, ysplit;
 				pick_fast_shape(c->n_fast_leaf, c->nfrags, &vpw, &ysplit);
 				// e1 right behind the main kernel when it is the only leaf kernel
@@ -1471,7 +1496,9 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 					++pend.n;
 				++c->stats.launches;
 			}
-			if(c->n_osc2_leaf) {
+			if(c->n_osc2_leaf && none_quiet(1, c->n_osc2_leaf))
+				++c->vm.quiet_skipped;
+			else if(c->n_osc2_leaf) {
 				int vpw, ysplit;
 				// (its own chunk length; 16 time slices: 2.19 ms against 2.25 with 32 at configs[3], round 3)
 				pick_fast_shape(c->n_osc2_leaf, c->nfrags * A2D_FAST_FCH / A2D_OSC2_FCH, &vpw, &ysplit, 16);
@@ -1482,7 +1509,9 @@ int issue_kernels(a2amd_ctx *c, unsigned phases, hipEvent_t e0, hipEvent_t e1, h
 					++pend.n;
 				++c->stats.launches;
 			}
-			if(c->n_filt_leaf) {
+			if(c->n_filt_leaf && none_quiet(2, c->n_filt_leaf))
+				++c->vm.quiet_skipped;
+			else if(c->n_filt_leaf) {
 				// voices per workgroup = lanes of its filter wavefront: all 64 once there
 				// are enough voices for a workgroup on every CU (one 16-wavefront workgroup
 				// per CU), else spread out (a workgroup takes as long as its filter chain,

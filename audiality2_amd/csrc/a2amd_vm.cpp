@@ -922,8 +922,8 @@ int vm_speculate(a2amd_ctx *c)
 	}
 	if(!m.d_swtop) {
 		HIPCHK(c, hipMalloc((void **)&m.d_swtop, 2 * sizeof(unsigned)));
-		HIPCHK(c, hipMalloc((void **)&m.d_stotal, 2 * sizeof(uint32_t)));
-		HIPCHK(c, hipHostMalloc((void **)&m.h_spec, 4 * sizeof(unsigned), hipHostMallocDefault));
+		HIPCHK(c, hipMalloc((void **)&m.d_stotal, 6 * sizeof(uint32_t)));	// ([0..1] as d_total, [2 + class] idle voices)
+		HIPCHK(c, hipHostMalloc((void **)&m.h_spec, 8 * sizeof(unsigned), hipHostMallocDefault));
 	}
 	size_t slotwords = 0;
 	for(int k = 0; k < 3; ++k)
@@ -962,11 +962,29 @@ int vm_speculate(a2amd_ctx *c)
 		vp.fragframes[f] = m.spec_ff[f];
 		vp.fragbase[f] = m.spec_fb[f];
 	}
-	const A2DVmwOut out = { m.d_vmv_sh.d, m.d_ustate_sh.d, m.d_vactive_sh.d, m.d_runs_sh.d, m.d_stotal };
+	// (the counters first: they are this stream's own - the last pass's copies to the host are in front of them - and
+	// the pass is then the very next thing behind the wait)
+	HIPCHK(c, hipMemsetAsync(m.d_swtop, 0, 2 * sizeof(unsigned), m.pred_stream));
+	HIPCHK(c, hipMemsetAsync(m.d_stotal, 0, 6 * sizeof(uint32_t), m.pred_stream));
 	HIPCHK(c, hipEventRecord(m.pred_after, c->stream));
 	HIPCHK(c, hipStreamWaitEvent(m.pred_stream, m.pred_after, 0));
-	HIPCHK(c, hipMemsetAsync(m.d_swtop, 0, 2 * sizeof(unsigned), m.pred_stream));
-	HIPCHK(c, hipMemsetAsync(m.d_stotal, 0, 2 * sizeof(uint32_t), m.pred_stream));
+	// The pass goes onto the chip BEFORE the render pass of the batch being issued (issue_windows waits for spec_go):
+	// it is one long wavefront per 64 voices that wants a corner of every CU for half a millisecond, the render pass
+	// fills whatever is free.  The other way round - the two become ready at the same moment, behind the leaf
+	// kernels, and the render pass's queue won by microseconds - k_win_render_f's workgroups held every CU until
+	// they were done and the pass ran BEHIND them - which, for the filter class, is as good as it gets: two workgroups
+	// of k_win_render_f (8 wavefronts of 128 registers) ARE a CU's register file, with the pass's wavefront there only
+	// one fits, and "pass and half the render pass, then the other half" measured 1 475 us per buffer against 1 360 for
+	// "render pass, then pass".  Without filter voices the pass shares the CUs with k_win_render, and whether it got
+	// onto them first was a race that went one way in one process and the other way in the next: 575 or 745 us per
+	// buffer of OscPanScripted, bimodal over runs (profiles/r06_timeline_before.txt, r06_go_ab.txt).
+	static const bool go = !(getenv("A2AMD_VMSPEC_GO") && !atoi(getenv("A2AMD_VMSPEC_GO")));
+	if(go && !m.n_cls[2]) {
+		if(!m.spec_go)
+			HIPCHK(c, hipEventCreateWithFlags(&m.spec_go, hipEventDisableTiming));
+		HIPCHK(c, hipEventRecord(m.spec_go, m.pred_stream));
+		m.spec_go_pending = true;
+	}
 	const int *l = m.d_list.d + m.list.size() + m.cls_lists.size();
 	size_t at = 0, atw = 0, atv = 0;
 	for(int k = 0; k < 3; l += m.n_cls[k], ++k) {
@@ -975,6 +993,7 @@ int vm_speculate(a2amd_ctx *c)
 			continue;
 		vp.list = l;
 		vp.n = m.n_cls[k];
+		const A2DVmwOut out = { m.d_vmv_sh.d, m.d_ustate_sh.d, m.d_vactive_sh.d, m.d_runs_sh.d, m.d_stotal, m.d_stotal + 2 + k };
 		if(a2d_launch_vm_win(vp, c->hparams, nosc[k], filt[k], 0, nfrags, vp.now, vp.now + (frames << 8), m.d_swin[set].d + atw,
 				m.d_swext[set].d, m.d_swscr.d + atv * A2D_VMW_ROW * A2D_WIN_WORDS, m.d_swidx[set].d + at, m.d_swtop,
 				(unsigned)m.spec_cap, m.pred_stream, &out))
@@ -993,7 +1012,7 @@ int vm_speculate(a2amd_ctx *c)
 		++c->stats.launches;
 	}
 	HIPCHK(c, hipMemcpyAsync(m.h_spec, m.d_swtop, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, m.pred_stream));
-	HIPCHK(c, hipMemcpyAsync(m.h_spec + 2, m.d_stotal, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, m.pred_stream));
+	HIPCHK(c, hipMemcpyAsync(m.h_spec + 2, m.d_stotal, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, m.pred_stream));
 	HIPCHK(c, hipEventRecord(m.pred_ev, m.pred_stream));
 	m.pred_valid = m.spec_valid = true;
 	m.pred_serial = m.list_serial;
@@ -1027,6 +1046,7 @@ int vm_issue(a2amd_ctx *c, bool fused)
 	m.fused = false;
 	m.spec_use = false;
 	m.spec_launched_now = false;
+	m.spec_go_pending = false;
 	// (the faults of the last fused batch are looked at whether or not a voice is left: all of them may have been
 	// recalled since)
 	if(m.total_pending) {
@@ -1093,8 +1113,11 @@ int vm_issue(a2amd_ctx *c, bool fused)
 				if(m.h_spec[1])
 					++m.spec_overflows;
 				m.spec_use = exact && !m.h_spec[1] && !m.h_spec[3];
-				if(m.spec_use)
+				if(m.spec_use) {
 					++m.spec_taken;
+					for(int k = 0; k < 3; ++k)
+						m.spec_idle[k] = m.h_spec[4 + k];
+				}
 				else
 					++m.spec_miss[!exact ? 1 : m.h_spec[1] ? 2 : 3];
 			}
@@ -1204,11 +1227,12 @@ void vm_close(a2amd_ctx *c)
 				"(k_vm_commit + render pass in k_vm_win's place); pool room %zu entries, last demand %zu; not taken: %llu not the "
 				"batch predicted, %llu other fragments / classes, %llu pool overflow, %llu faults; batches without a pass: %llu off / "
 				"short, %llu no plan (span not whole fragments), %llu over the slot budget, %llu lists just changed; %llu waits for a "
-				"pass in flight before a rewrite\n",
+				"pass in flight before a rewrite; %llu quiet-kernel launches not made (every voice of the class the VM's)\n",
 				(unsigned long long)m.spec_launched, (unsigned long long)m.spec_taken, m.spec_cap, m.spec_demand,
 				(unsigned long long)m.spec_miss[0], (unsigned long long)m.spec_miss[1], (unsigned long long)m.spec_miss[2],
 				(unsigned long long)m.spec_miss[3], (unsigned long long)m.spec_skip[0], (unsigned long long)m.spec_skip[1],
-				(unsigned long long)m.spec_skip[2], (unsigned long long)m.spec_skip[3], (unsigned long long)m.spec_waits);
+				(unsigned long long)m.spec_skip[2], (unsigned long long)m.spec_skip[3], (unsigned long long)m.spec_waits,
+				(unsigned long long)m.quiet_skipped);
 	if(m.pred_stream)
 		hipStreamSynchronize(m.pred_stream);	// (a pass still running reads the arrays freed below)
 	for(int k = 0; k < 2; ++k) {
@@ -1239,6 +1263,8 @@ void vm_close(a2amd_ctx *c)
 		hipStreamDestroy(m.pred_stream);
 		hipEventDestroy(m.pred_after);
 		hipEventDestroy(m.pred_ev);
+		if(m.spec_go)
+			hipEventDestroy(m.spec_go);
 		hipFree(m.d_pred);
 		hipHostFree(m.h_pred);
 	}
@@ -1303,6 +1329,11 @@ int a2amd_vm_adopt(a2amd_ctx *c, int head, int prog, const a2amd_vm_state *st, c
 		return c->fail(A2AMD_ESTATE, "vm_adopt outside a fragment");
 	if(v.inline_pos >= 0)
 		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: voice %d owns a bus", vi);
+	// (round 6 lifted the backend's chains to A2D_MAXCHAIN = 16 units; the VM's register map still names a chain position
+	// in a nibble that has 14 and 15 taken - A2D_VM_ENVPOS, A2D_VM_NOWRITE - and run_batch looks kinds up by pos & 7)
+	if(v.nunits > A2D_VM_MAXPOS)
+		return c->fail(A2AMD_EUNSUPPORTED, "vm_adopt: voice %d has a chain of %d units (the device VM takes up to %d)", vi,
+				v.nunits, A2D_VM_MAXPOS);
 	// (not now - which says nothing about the program: A2AMD_ESTATE)
 	const bool marked = c->defmap_used && (size_t)vi < c->defmap.size() && c->defmap[vi];
 	if(!v.live || v.dying || !v.resolved || !v.started || (v.walked != c->serial_base + c->cur_frag && !marked))
@@ -1587,7 +1618,7 @@ static int trace_impl(const uint32_t *code, unsigned nwords, a2amd_vm_state *st,
 		int32_t basepitch, const uint8_t *fragframes, const uint8_t *fragbase, unsigned nfrags, a2amd_vm_env *envs, int nenv,
 		const uint16_t *envluts, uint32_t *recs, unsigned cap, int32_t *has_exit, uint32_t *exit_when, int32_t *stay_records)
 {
-	if(!code || !st || !wr_unit || !wr_reg || !kinds || !fragframes || !recs || nkinds < 1 || nkinds > A2D_MAXCHAIN)
+	if(!code || !st || !wr_unit || !wr_reg || !kinds || !fragframes || !recs || nkinds < 1 || nkinds > A2D_VM_MAXPOS)
 		return A2AMD_EINVAL;
 	if(nenv < 0 || nenv > A2AMD_VM_MAXENV || (nenv && (!envs || !envluts)))
 		return A2AMD_EINVAL;

@@ -258,7 +258,7 @@ VMFN void control(A2DVmVoice &v, const Consts &K, E &e, int frag, unsigned reg, 
 template<class E>
 VMFN void write_unit(A2DVmVoice &v, const Consts &K, E &e, int frag, unsigned m, int value, unsigned start, unsigned dur)
 {
-	const int pos = (int)(m >> 4), ureg = (int)(m & 15u), kind = v.kind[pos & 7];
+	const int pos = (int)(m >> 4), ureg = (int)(m & 15u), kind = v.kind[pos & (A2D_VM_MAXPOS - 1)];
 	const int transpose = v.r[A2AMD_VM_R_TRANSPOSE];
 	start &= 255u;
 	switch(kind) {
@@ -606,28 +606,44 @@ VMFN uint32_t run_batch(A2DVmVoice &v, const uint32_t *code, const Consts &K, E 
 				// target has already rendered the window (push_rec, a2amd_sched.cpp) - and a ramping cutoff's
 				// coefficient for the window (the head of f12_process, filter12.c:86-96).
 				int nlate = 0, late_slot[A2D_VM_MAXENV];
-				if(v.nenv | v.ncut)
-					for(int p = 0; p <= A2D_MAXCHAIN; ++p) {
-						for(int k = 0; k < v.nenv && k < A2D_VM_MAXENV; ++k) {
-							A2DVmEnv &en = v.env[k];
-							if(en.k != p || !en.active)
-								continue;
-							env_lut(K, en, res);
-							const bool cutoff = v.kind[(en.target >> 4) & 7] == A2D_FILTER12 && (en.target & 15u) == 0;
-							if((int)(en.target >> 4) >= p || cutoff)	// (a cutoff write is host state, not a record)
-								write_unit(v, K, e, f, en.target, en.out, (unsigned)(base + s), (unsigned)res << 8);
-							else
-								late_slot[nlate++] = k;
-						}
-						for(int k = 0; k < (int)v.ncut && k < A2D_VM_MAXCUT; ++k)
-							if(v.cutpos[k] == p) {
-								rp_prepare(v.cut[k], res);
-								if(v.cut[k][2]) {
-									rp_run(v.cut[k], res);
-									e.rec(f, R_F1RAMP, v.cutpos[k], 0, f1_of_pitch(K, v.cut[k][0] >> 8), 0, 0);
-								}
-							}
+				// (round 6: only the chain positions that HOLD an env unit or a cutoff ramper are visited, in order - the
+				// same visits in the same order as the walk over all 0 .. A2D_MAXCHAIN positions it replaces, which with chains of
+				// up to 16 units was seventeen trips through these two loops per window, each re-reading the voice from LDS:
+				// 3 800 cycles per window, a third of k_vm_win for the filter class, whose every voice has a cutoff
+				// ramper - moving or not (-DWIN_PROF: profiles/r06_vm_win_cycles.txt).  Activity is looked at when a
+				// position is visited, as before: an env's write may start or stop a later one.)
+				unsigned pmask = 0;
+				if(v.nenv | v.ncut) {
+					for(int k = 0; k < v.nenv && k < A2D_VM_MAXENV; ++k)
+						if((unsigned)v.env[k].k <= A2D_VM_MAXPOS)
+							pmask |= 1u << v.env[k].k;
+					for(int k = 0; k < (int)v.ncut && k < A2D_VM_MAXCUT; ++k)
+						if(v.cutpos[k] <= A2D_VM_MAXPOS)
+							pmask |= 1u << v.cutpos[k];
+				}
+				while(pmask) {
+					const int p = __builtin_ctz(pmask);
+					pmask &= pmask - 1;
+					for(int k = 0; k < v.nenv && k < A2D_VM_MAXENV; ++k) {
+						A2DVmEnv &en = v.env[k];
+						if(en.k != p || !en.active)
+							continue;
+						env_lut(K, en, res);
+						const bool cutoff = v.kind[(en.target >> 4) & (A2D_VM_MAXPOS - 1)] == A2D_FILTER12 && (en.target & 15u) == 0;
+						if((int)(en.target >> 4) >= p || cutoff)	// (a cutoff write is host state, not a record)
+							write_unit(v, K, e, f, en.target, en.out, (unsigned)(base + s), (unsigned)res << 8);
+						else
+							late_slot[nlate++] = k;
 					}
+					for(int k = 0; k < (int)v.ncut && k < A2D_VM_MAXCUT; ++k)
+						if(v.cutpos[k] == p) {
+							rp_prepare(v.cut[k], res);
+							if(v.cut[k][2]) {
+								rp_run(v.cut[k], res);
+								e.rec(f, R_F1RAMP, v.cutpos[k], 0, f1_of_pitch(K, v.cut[k][0] >> 8), 0, 0);
+							}
+						}
+				}
 				// (the fragment's default window - nothing else in it - is no record; an emitter that is the
 				// records' reader as well gets every window)
 				if(E::fused || !(s == 0 && res == frames && e.count() == before && !nlate))

@@ -21,7 +21,8 @@ static_assert((sizeof(VmSlot) / 4) % 2 == 1, "an odd stride in words");
 // wavefront of many different or very long programs - keep reading memory.  Returns the lane's text.
 #define VM_CODEWORDS 2048
 #define VM_NPROGS    8
-__device__ inline const uint32_t *vm_stage_code(const uint32_t *pool, const A2DVmVoice &v, bool has, uint32_t *s_code)
+__device__ inline const uint32_t *vm_stage_code(const uint32_t *pool, const A2DVmVoice &v, bool has, uint32_t *s_code,
+		unsigned room = VM_CODEWORDS)
 {
 	const int lane = (int)(threadIdx.x & 63);
 	const uint32_t *mine = pool + v.code;
@@ -31,7 +32,7 @@ __device__ inline const uint32_t *vm_stage_code(const uint32_t *pool, const A2DV
 		const int leader = __ffsll((long long)todo) - 1;
 		const uint32_t base = (uint32_t)__shfl((int)v.code, leader, 64), n = (uint32_t)__shfl((int)v.ncode, leader, 64);
 		const unsigned long long same = __ballot(has && v.code == base && v.ncode == n);
-		if(used + n <= VM_CODEWORDS) {
+		if(used + n <= room) {
 			for(uint32_t q = (uint32_t)lane; q < n; q += 64)
 				s_code[used + q] = pool[base + q];
 			if(has && v.code == base && v.ncode == n)

@@ -43,22 +43,25 @@ using namespace a2vm;
 // makes at most one record per control register of the chain and two for a cutoff (SETALL / RAMPALL over
 // 2 x 4 wtosc + 5 filter12 + 2 panmix registers: 16), so VMW_GIVEWAY + 17 <= VMW_RING never overflows; the
 // queue says so if it ever does (TRAP_RECORDS: the voice stops and the host reports the fault)
-#define VMW_RING    32
 #define VMW_GIVEWAY 6
 // (round 6, advisor) ... and behind a run, before the drain, run_batch adds the env units' writes, a cutoff's coefficient
 // step per filter, the window itself and the late env writes.  Worst case of the largest class (2 x wtosc, filter12,
 // panmix): VMW_GIVEWAY + (2 x 4 + 5 + 2 registers = 15, + 1 for a cutoff's second record) + 2 x A2D_VM_MAXENV +
 // A2D_VM_MAXCUT + 1 (R_SEG) = 29: the ring has room to spare, and a class that outgrows it does not compile
-#define VMW_MAXREGS (2 * 4 + 5 + 2)
-static_assert(VMW_GIVEWAY + VMW_MAXREGS + 1 + 2 * A2D_VM_MAXENV + A2D_VM_MAXCUT + 1 + 2 <= VMW_RING,
-		"k_vm_win's record ring must hold one instruction's records + what run_batch queues behind a run");
-#define VMW_ROW     (64 - 1 - WIN_EXL)	/* further windows of a fragment beyond the staged ones: a lane's row of wscr */
+// (... and sized by class: the ring of the one-oscillator class without a filter is 22 records, not 32 - LDS that
+// decides whether the render pass of the batch before fits the CU beside this kernel, WinStage)
+#define VMW_REGS(NOSC, FILT) (4 * (NOSC) + 5 * (FILT) + 2)
+#define VMW_RING(NOSC, FILT) (VMW_GIVEWAY + VMW_REGS(NOSC, FILT) + 1 + 2 * A2D_VM_MAXENV + A2D_VM_MAXCUT + 1 + 2)
+#define VMW_ROW(FILT) (64 - 1 - WIN_EXLN(FILT))	/* a fragment's windows beyond the staged ones: in the lane's row of wscr */
+static_assert(VMW_ROW(1) <= A2D_VMW_ROW && VMW_ROW(0) <= A2D_VMW_ROW, "the host sizes the rows of wscr by A2D_VMW_ROW");
+#define VMW_CODEWORDS 1024		/* program text staged in LDS (a2amd_vmdev.h): 4 KB here */
 
-
+template<int NOSC, int FILT>
 struct VmwStage {
-	WinStage w;
+	static constexpr int RING = VMW_RING(NOSC, FILT);
+	WinStage<NOSC, FILT> w;
 	int own[2][64];		// the lane took the fragment's room in the pool itself (e0 says where)
-	Int4 ring[VMW_RING][64];
+	Int4 ring[RING][64];
 };
 
 template<int NOSC, int FILT>
@@ -66,7 +69,7 @@ struct WinE {
 	static constexpr bool fused = true;
 	CtlVoice<NOSC, FILT> &cv;
 	A2DVmVoice &v;
-	VmwStage &st;
+	VmwStage<NOSC, FILT> &st;
 	const A2DWave *waves;
 	const PTab &ptab;
 	int *ustate;
@@ -98,7 +101,7 @@ struct WinE {
 	VMFN void rec(int frag, int op, int unit, int reg, int value, unsigned dur, unsigned start)
 	{
 		const Int4 q = { (int)A2D_HEAD(frag, op, unit, reg), value, (int)dur, (int)start };
-		if(n < VMW_RING)
+		if(n < VmwStage<NOSC, FILT>::RING)
 			st.ring[n][lane] = q;
 		else
 			v.fault = TRAP_RECORDS;
@@ -122,7 +125,7 @@ struct WinE {
 	{
 		constexpr int SW = WIN_SW(NOSC, FILT);
 		const int sb = (f - fa) & 1;
-		const int m = n < VMW_RING ? n : VMW_RING;
+		const int m = n < VmwStage<NOSC, FILT>::RING ? n : VmwStage<NOSC, FILT>::RING;
 #ifdef WIN_PROF
 		const long long t0 = __builtin_readcyclecounter();
 		++n_drain;
@@ -141,11 +144,11 @@ struct WinE {
 				if(!nwin) {
 					head0 = head;
 					dst = st.w.slot[sb] + lane * SW;
-				} else if(nstaged < WIN_EXL)
+				} else if(nstaged < WIN_EXLN(FILT))
 					dst = st.w.ext[sb][lane][nstaged++];
-				else if(nwin - 1 - WIN_EXL < VMW_ROW) {
+				else if(nwin - 1 - WIN_EXLN(FILT) < VMW_ROW(FILT)) {
 					own = 1;	// (parked: end_fragment moves them)
-					dst = wrow + (size_t)(nwin - 1 - WIN_EXL) * A2D_WIN_WORDS;
+					dst = wrow + (size_t)(nwin - 1 - WIN_EXLN(FILT)) * A2D_WIN_WORDS;
 				}
 				++nwin;
 				if(dst) {
@@ -176,7 +179,7 @@ struct WinE {
 			head0 |= WH_FRESH;
 			cv.pending_fresh = 0;
 		}
-		int extras = nwin > 1 ? min(nwin - 1, WIN_EXL + VMW_ROW) : 0;
+		int extras = nwin > 1 ? min(nwin - 1, WIN_EXLN(FILT) + VMW_ROW(FILT)) : 0;
 		if(own) {
 			// the fragment's further windows, now that their number is known: room in the pool, the staged ones and
 			// the parked ones moved there
@@ -187,8 +190,8 @@ struct WinE {
 				extras = 0;
 			} else
 				for(int q = 0; q < extras; ++q) {
-					const Int4 *in = q < WIN_EXL ? (const Int4 *)st.w.ext[sb][lane][q] :
-							(const Int4 *)(wrow + (size_t)(q - WIN_EXL) * A2D_WIN_WORDS);
+					const Int4 *in = q < WIN_EXLN(FILT) ? (const Int4 *)st.w.ext[sb][lane][q] :
+							(const Int4 *)(wrow + (size_t)(q - WIN_EXLN(FILT)) * A2D_WIN_WORDS);
 					Int4 *o = (Int4 *)(wext + ((size_t)block + q) * A2D_WIN_WORDS);
 #pragma unroll
 					for(int j = 0; j < SW / 4; ++j)
@@ -216,7 +219,7 @@ struct WinE {
 // takes the extras out of its voices' head words again, and the flag says so.
 template<int NOSC, int FILT>
 DEV void vmw_writer(int nlist, int first, int fa, int fb, int *__restrict__ wslot, int *__restrict__ wext,
-		unsigned *__restrict__ widx, unsigned *__restrict__ wtop, unsigned wcap, VmwStage &st)
+		unsigned *__restrict__ widx, unsigned *__restrict__ wtop, unsigned wcap, VmwStage<NOSC, FILT> &st)
 {
 	constexpr int SW = WIN_SW(NOSC, FILT);
 	const int lane = threadIdx.x & 63;
@@ -300,8 +303,8 @@ void k_vm_win(A2DVmParams vp, int fa, int fb, uint32_t now_fa, uint32_t batch_en
 	// write to ustate is a filter12's R_INIT, and the VM makes no births.)
 	__shared__ PTab s_ptab;
 	__shared__ VmSlot s_v[64];
-	__shared__ VmwStage s_stage;
-	__shared__ uint32_t s_code[VM_CODEWORDS];
+	__shared__ VmwStage<NOSC, FILT> s_stage;
+	__shared__ uint32_t s_code[VMW_CODEWORDS];
 	__shared__ int s_anylive;
 	for(int k = (int)threadIdx.x; k < 128; k += 128)
 		s_ptab[k] = ptab[k];
@@ -332,7 +335,14 @@ void k_vm_win(A2DVmParams vp, int fa, int fb, uint32_t now_fa, uint32_t batch_en
 		const unsigned long long any = __ballot(live);
 		if(lane == 0)
 			s_anylive = any != 0;
-		code = vm_stage_code(vp.code, s_v[lane].v, live, s_code);
+		if(out.idle && fa == 0) {
+			// (a speculative pass tells the host how many of the class it left to the quiet kernels: none - every voice of a
+			// scripted scene, every batch - and the quiet kernel of the class need not be launched to find that out)
+			const unsigned long long idl = __ballot(idx < vp.n && !live);
+			if(lane == 0 && idl)
+				atomicAdd(out.idle, (uint32_t)__popcll(idl));
+		}
+		code = vm_stage_code(vp.code, s_v[lane].v, live, s_code, VMW_CODEWORDS);
 	}
 	__syncthreads();
 	if(wave != 0) {
@@ -359,7 +369,7 @@ void k_vm_win(A2DVmParams vp, int fa, int fb, uint32_t now_fa, uint32_t batch_en
 		const long long t_in = __builtin_readcyclecounter();
 #endif
 		const Consts K = { vp.msdur, vp.samplerate, vp.basepitch, vp.ptab, vp.f1tab, vp.envlut };
-		WinE<NOSC, FILT> e = { cv, v, s_stage, waves, s_ptab, ustate, wext, wscr + (size_t)idx * VMW_ROW * A2D_WIN_WORDS, wtop, wcap,
+		WinE<NOSC, FILT> e = { cv, v, s_stage, waves, s_ptab, ustate, wext, wscr + (size_t)idx * A2D_VMW_ROW * A2D_WIN_WORDS, wtop, wcap,
 				lane, fa, fb, 0, 0, false, 0u, 0, 0, 0, 0u, 0u };
 		const uint8_t *ff = vp.fragframes, *fbs = vp.fragbase;
 		run_batch(v, code, K, e, now_fa, fa, fb, [ff, fbs](int f) { return (unsigned)ff[f] | ((unsigned)fbs[f] << 8); },
@@ -433,7 +443,7 @@ int a2d_launch_vm_win(const A2DVmParams &vp, const A2DParams &hp, int nosc, int 
 	if(vp.n <= 0 || fb <= fa)
 		return 0;
 	const int nblocks = (vp.n + 63) / 64;
-	const A2DVmwOut live = { vp.vmv, hp.ustate, hp.vactive, vp.runs, vp.total };
+	const A2DVmwOut live = { vp.vmv, hp.ustate, hp.vactive, vp.runs, vp.total, nullptr };
 	const A2DVmwOut out = outp ? *outp : live;
 #define VMW_LAUNCH(N, F) hipLaunchKernelGGL((k_vm_win<N, F>), dim3(nblocks), dim3(128), 0, (hipStream_t)stream, vp, fa, fb, now_fa, \
 		batch_end, wslot, wext, wscr, widx, wtop, wcap, hp.voices, hp.ustate, hp.vactive, hp.waves, hp.ptab, out)

@@ -51,7 +51,7 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 		int fa, int fb, int *__restrict__ wslot, int *__restrict__ wext, unsigned *__restrict__ widx,
 		unsigned *__restrict__ wtop, unsigned wcap, int *__restrict__ wrc,
 		const A2DVoice *__restrict__ voices, int *ustate, int *vactive, const A2DWave *__restrict__ waves,
-		const PTab &ptab, const uint8_t *ffr, WinStage &st)
+		const PTab &ptab, const uint8_t *ffr, WinStage<NOSC, FILT> &st)
 {
 	const A2DParams &p = *pp;
 	const int lane = threadIdx.x & 63;
@@ -163,8 +163,8 @@ DEV void win_ctl_body(const A2DParams *__restrict__ pp, const int *__restrict__ 
 						head0 = head;
 						dst = myslot;
 					} else if(e < elim) {
-						// (the first WIN_EXL extras of a fragment are staged too; a busier fragment stores the rest itself)
-						dst = nstaged < WIN_EXL && nstaged == nwin - 1 ? st.ext[sb][lane][nstaged++] : wext + (size_t)e * A2D_WIN_WORDS;
+						// (the first WIN_EXLN extras of a fragment are staged too; a busier fragment stores the rest itself)
+						dst = nstaged < WIN_EXLN(FILT) && nstaged == nwin - 1 ? st.ext[sb][lane][nstaged++] : wext + (size_t)e * A2D_WIN_WORDS;
 						++e;
 					}
 					++nwin;
@@ -239,7 +239,7 @@ void k_win_ctl(const A2DParams *__restrict__ pp, const int *__restrict__ list, i
 	// the pitch table and the batch's fragment lengths: read in every window, from LDS
 	__shared__ PTab s_ptab;
 	__shared__ uint8_t s_ffr[A2D_MAXBATCH];
-	__shared__ WinStage s_stage;
+	__shared__ WinStage<NOSC, FILT> s_stage;
 	for(int k = (int)threadIdx.x; k < 128; k += 128)
 		s_ptab[k] = ptab[k];
 	for(int k = (int)threadIdx.x; k < A2D_MAXBATCH; k += 128)

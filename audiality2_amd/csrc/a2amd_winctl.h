@@ -534,10 +534,15 @@ DEV void ctl_apply(CtlVoice<NOSC, FILT> &s, const A2DWave *waves, const PTab &pt
 // wavefront of the workgroup carries it out (win_ctl_writer): on gfx9 stores count in vmcnt like loads, and a walk
 // that has to wait for a record it asked for an iteration ago would wait for its own stores' round trips with it -
 // two microseconds per trip through the loop, four fifths of the first cut's control pass.
-#define WIN_EXL A2D_WIN_STAGED
+// (round 6: sized by class - SW words per entry, and ONE staged extra for the filter classes.  k_vm_win's 113 KB of LDS
+// beside two 32.5 KB workgroups of k_win_render_f did not fit a CU's 160 KB by 3 KB: every second workgroup of the
+// render pass waited for the speculative VM pass next to it to END - profiles/r06_timeline_before.txt, README there.)
+#define WIN_EXLN(FILT) ((FILT) ? 1 : A2D_WIN_STAGED)
+template<int NOSC, int FILT>
 struct WinStage {
-	int slot[2][64 * A2D_WIN_WORDS];		// [buffer][lane * SW + word]
-	int ext[2][64][WIN_EXL][A2D_WIN_WORDS];
+	static constexpr int SW = WIN_SW(NOSC, FILT), EXL = WIN_EXLN(FILT);
+	int slot[2][64 * SW];				// [buffer][lane * SW + word]
+	int ext[2][64][EXL][SW];
 	unsigned e0[2][64];
 	int nst[2][64];
 };
@@ -554,7 +559,7 @@ DEV void win_meet()
 // control wavefront walks the next fragment into the other buffer.
 template<int NOSC, int FILT>
 DEV void win_ctl_writer(int nlist, int first, int fa, int fb, int *__restrict__ wslot, int *__restrict__ wext,
-		unsigned *__restrict__ widx, const WinStage &st)
+		unsigned *__restrict__ widx, const WinStage<NOSC, FILT> &st)
 {
 	constexpr int SW = WIN_SW(NOSC, FILT);
 	const int lane = threadIdx.x & 63;

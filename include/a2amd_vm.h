@@ -33,7 +33,9 @@
  *
  * Never taken: voices with a noise oscillator (the draws of the engine's one LCG interleave with every other noise
  * voice's and with RAND in WALK order, wtosc.c:135, core.c:1400), with subvoices, with a call stack (inside a
- * function or a message handler), with an API handle, with events queued.
+ * function or a message handler), with an API handle, with events queued; voices that own a bus (an inline unit) or
+ * whose chain is longer than 8 units (the register map names a chain position in three bits; the backend itself
+ * renders chains of up to A2AMD_MAXCHAIN = 16).
  *
  * Either way nothing the engine does depends on WHEN an adopted voice's VM runs.  The engine hands the voice
  * over (a2amd_vm_adopt: program text, A2_vmstate, which VM register feeds which unit register),
