@@ -303,12 +303,12 @@ struct VmHost {
 	DevBuf<unsigned> d_swidx[2];
 	int spec_set = 0;
 	bool spec_launched_now = false;		// vm_speculate has run for the batch being issued (issue_kernels asks once)
-	unsigned *d_swtop = nullptr;		// [2]: entries taken, overflow flag
+	unsigned *d_swtop = nullptr;		// [2]: entries taken, overflow flag (the first words of one block of 8: d_stotal follows)
 	DevBuf<A2DVmVoice> d_vmv_sh;
 	DevBuf<int> d_ustate_sh, d_vactive_sh;	// (d_ustate_sh.cap in units, like d_ustate's)
 	DevBuf<A2DRun> d_runs_sh;
-	uint32_t *d_stotal = nullptr;		// [2]: (unused), voices that faulted
-	unsigned *h_spec = nullptr;		// pinned: d_swtop[0..1], d_stotal[0..1]
+	uint32_t *d_stotal = nullptr;		// = d_swtop + 2, [6]: (unused), voices that faulted, [2 + class] voices the pass left alone
+	unsigned *h_spec = nullptr;		// pinned: the block of 8 as the pass left it
 	bool spec_valid = false;		// a pass was launched for the prediction pred_* describe
 	bool spec_use = false;			// this batch: taken (vm_issue decides, issue_windows commits + renders)
 	int spec_nfrags = 0, spec_cls[3] = { 0, 0, 0 };

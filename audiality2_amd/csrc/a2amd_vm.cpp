@@ -921,8 +921,10 @@ int vm_speculate(a2amd_ctx *c)
 		HIPCHK(c, hipHostMalloc((void **)&m.h_pred, 2 * sizeof(unsigned), hipHostMallocDefault));
 	}
 	if(!m.d_swtop) {
-		HIPCHK(c, hipMalloc((void **)&m.d_swtop, 2 * sizeof(unsigned)));
-		HIPCHK(c, hipMalloc((void **)&m.d_stotal, 6 * sizeof(uint32_t)));	// ([0..1] as d_total, [2 + class] idle voices)
+		// (one block - one memset in front of a pass, one copy behind it: every call on the pass's stream is some 8 us
+		// of the engine thread between the commit and the pass, and the pass is what the next buffer waits for)
+		HIPCHK(c, hipMalloc((void **)&m.d_swtop, 8 * sizeof(unsigned)));
+		m.d_stotal = m.d_swtop + 2;		// ([0..1] as d_total, [2 + class] idle voices)
 		HIPCHK(c, hipHostMalloc((void **)&m.h_spec, 8 * sizeof(unsigned), hipHostMallocDefault));
 	}
 	size_t slotwords = 0;
@@ -964,8 +966,7 @@ int vm_speculate(a2amd_ctx *c)
 	}
 	// (the counters first: they are this stream's own - the last pass's copies to the host are in front of them - and
 	// the pass is then the very next thing behind the wait)
-	HIPCHK(c, hipMemsetAsync(m.d_swtop, 0, 2 * sizeof(unsigned), m.pred_stream));
-	HIPCHK(c, hipMemsetAsync(m.d_stotal, 0, 6 * sizeof(uint32_t), m.pred_stream));
+	HIPCHK(c, hipMemsetAsync(m.d_swtop, 0, 8 * sizeof(unsigned), m.pred_stream));
 	HIPCHK(c, hipEventRecord(m.pred_after, c->stream));
 	HIPCHK(c, hipStreamWaitEvent(m.pred_stream, m.pred_after, 0));
 	// The pass goes onto the chip BEFORE the render pass of the batch being issued (issue_windows waits for spec_go):
@@ -1011,8 +1012,7 @@ int vm_speculate(a2amd_ctx *c)
 		atv += (size_t)m.n_cls[k];
 		++c->stats.launches;
 	}
-	HIPCHK(c, hipMemcpyAsync(m.h_spec, m.d_swtop, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, m.pred_stream));
-	HIPCHK(c, hipMemcpyAsync(m.h_spec + 2, m.d_stotal, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, m.pred_stream));
+	HIPCHK(c, hipMemcpyAsync(m.h_spec, m.d_swtop, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, m.pred_stream));
 	HIPCHK(c, hipEventRecord(m.pred_ev, m.pred_stream));
 	m.pred_valid = m.spec_valid = true;
 	m.pred_serial = m.list_serial;
@@ -1246,7 +1246,6 @@ void vm_close(a2amd_ctx *c)
 	hipFree(m.d_ustate_sh.d);
 	hipFree(m.d_vactive_sh.d);
 	hipFree(m.d_runs_sh.d);
-	hipFree(m.d_stotal);
 	if(m.h_spec)
 		hipHostFree(m.h_spec);
 	hipFree(m.d_vmv.d);

@@ -41,15 +41,14 @@ using namespace a2vm;
 
 // records a lane keeps between two drains, and from how many on a VM run gives way to a drain: ONE instruction
 // makes at most one record per control register of the chain and two for a cutoff (SETALL / RAMPALL over
-// 2 x 4 wtosc + 5 filter12 + 2 panmix registers: 16), so VMW_GIVEWAY + 17 <= VMW_RING never overflows; the
-// queue says so if it ever does (TRAP_RECORDS: the voice stops and the host reports the fault)
+// 2 x 4 wtosc + 5 filter12 + 2 panmix registers: 16 for the widest class), so the ring - VMW_RING, below - never
+// overflows; the queue says so if it ever does (TRAP_RECORDS: the voice stops and the host reports the fault)
 #define VMW_GIVEWAY 6
 // (round 6, advisor) ... and behind a run, before the drain, run_batch adds the env units' writes, a cutoff's coefficient
 // step per filter, the window itself and the late env writes.  Worst case of the largest class (2 x wtosc, filter12,
 // panmix): VMW_GIVEWAY + (2 x 4 + 5 + 2 registers = 15, + 1 for a cutoff's second record) + 2 x A2D_VM_MAXENV +
-// A2D_VM_MAXCUT + 1 (R_SEG) = 29: the ring has room to spare, and a class that outgrows it does not compile
-// (... and sized by class: the ring of the one-oscillator class without a filter is 22 records, not 32 - LDS that
-// decides whether the render pass of the batch before fits the CU beside this kernel, WinStage)
+// A2D_VM_MAXCUT + 1 (R_SEG) = 29.  The ring is that sum for the class, two to spare: 22 records for one oscillator
+// without a filter, 26 for two, 27 with a filter (it was 32 for all: LDS the other kernels of a batch can use, WinStage)
 #define VMW_REGS(NOSC, FILT) (4 * (NOSC) + 5 * (FILT) + 2)
 #define VMW_RING(NOSC, FILT) (VMW_GIVEWAY + VMW_REGS(NOSC, FILT) + 1 + 2 * A2D_VM_MAXENV + A2D_VM_MAXCUT + 1 + 2)
 #define VMW_ROW(FILT) (64 - 1 - WIN_EXLN(FILT))	/* a fragment's windows beyond the staged ones: in the lane's row of wscr */

@@ -534,9 +534,10 @@ DEV void ctl_apply(CtlVoice<NOSC, FILT> &s, const A2DWave *waves, const PTab &pt
 // wavefront of the workgroup carries it out (win_ctl_writer): on gfx9 stores count in vmcnt like loads, and a walk
 // that has to wait for a record it asked for an iteration ago would wait for its own stores' round trips with it -
 // two microseconds per trip through the loop, four fifths of the first cut's control pass.
-// (round 6: sized by class - SW words per entry, and ONE staged extra for the filter classes.  k_vm_win's 113 KB of LDS
-// beside two 32.5 KB workgroups of k_win_render_f did not fit a CU's 160 KB by 3 KB: every second workgroup of the
-// render pass waited for the speculative VM pass next to it to END - profiles/r06_timeline_before.txt, README there.)
+// (round 6: sized by class - SW words per entry, and ONE staged extra for the filter classes: k_vm_win's stage was
+// 113 KB whatever the class, which beside two 32.5 KB workgroups of k_win_render_f is 3 KB more than a CU has.  For
+// THAT pair it is the register file that decides in the end - DESIGN 2c - but 83 / 100 / 90 KB leave the other
+// kernels of a batch the room the widest class never needed.)
 #define WIN_EXLN(FILT) ((FILT) ? 1 : A2D_WIN_STAGED)
 template<int NOSC, int FILT>
 struct WinStage {

@@ -26,7 +26,10 @@ for ctr in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VAL
   # the device VM's kernels: the scripted engine cell (k_vm_win in the speculative pass, k_vm_commit, k_win_render)
   ( cd $REPO/tests/a2s; rm -rf /tmp/prof_p; LD_PRELOAD="$pre" A2REF_BUFFER=4096 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/prof_p -- \
       $REPO/oracle/_ref/ref_bench bench.a2s OscPanScripted 16384 6144 1 > /tmp/prof_p.log 2>&1
-    python $REPO/tools/pmc_summary.py /tmp/prof_p "vm-osc-pan/16384/0/64" >> $OUT/pmc_summary.txt )
+    python $REPO/tools/pmc_summary.py /tmp/prof_p "vm-osc-pan/16384/0/64" >> $OUT/pmc_summary.txt
+    rm -rf /tmp/prof_p; LD_PRELOAD="$pre" A2REF_BUFFER=4096 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/prof_p -- \
+      $REPO/oracle/_ref/ref_bench bench.a2s OscFilterPanScripted 16384 6144 1 > /tmp/prof_p.log 2>&1
+    python $REPO/tools/pmc_summary.py /tmp/prof_p "vm-osc-filter-pan/16384/0/64" >> $OUT/pmc_summary.txt )
 done
 ( cd $REPO && python tools/pmc_to_json.py $OUT/pmc_summary.txt tools/profile_round6.sh > $OUT/pmc.json 2>/dev/null )
 # ... and the measured issue rate of the headline kernels' own hot-loop instruction mixes (roofline_valu.peak)
