@@ -212,6 +212,23 @@ def test_speculative_vm_pass_is_the_same_audio(tmp_path, program, buffer, spec):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("buffer", [64, 4096])
+def test_device_vm_leaves_chains_it_cannot_name_to_the_engine(tmp_path, buffer):
+    """tests/a2s/vmlong.a2s: two looping voices with ten-unit chains that write their ninth and tenth unit, two with
+    the plain wtosc-panmix chain.  The backend renders all four (chains of up to 16 units, round 6); the device VM's
+    register map names a chain position in three bits (A2D_VM_MAXPOS), so it takes the short ones and refuses the long
+    ones at adoption - it used to be handed nothing longer than 8 because the backend took nothing longer.  The audio
+    is the CPU engine's either way."""
+    need_ref()
+    frames = 48000 * 2 // buffer * buffer
+    cpu, _, _ = render(tmp_path, "cpu", "vmlong", "Main", frames, buffer, ["0.08"])
+    vm, stats, err = render(tmp_path, "vm", "vmlong", "Main", frames, buffer, ["0.08"], preload=f"{WALK_SO} {UNITS_SO}")
+    assert cpu.any()
+    assert first_difference(cpu, vm, 2, buffer) is None, first_difference(cpu, vm, 2, buffer)
+    assert stats and stats[0] == 2, (stats, err[-600:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("script,args", [("vmloops", ["0.08"]), ("vmnotes", ["0.08"]), ("envloops", ["0.08"])])
 def test_device_vm_voices_through_records_are_the_same_audio(tmp_path, script, args):
     """A2AMD_VMWIN=0: the window-class voices of the device VM through k_vm_count / k_vm_emit and k_win_ctl - the path
