@@ -1137,6 +1137,12 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 		++c->vm.fused_batches;
 	if(!nj)
 		return 0;
+	// (a batch whose every list took a speculative pass takes nothing from THIS pool and has no control pass of its own:
+	// its counter is neither cleared nor read back - two calls in front of the commit, two behind the render pass, of a
+	// buffer whose time is the engine thread's as much as the GPU's)
+	bool plain_jobs = false;
+	for(int j = 0; j < nj; ++j)
+		plain_jobs = plain_jobs || !jobs[j].spec;
 	if(c->wtop_pending) {
 		// (the copy sits behind the batch before this one: done, or nearly - waited for rather than polled, because this
 		// batch's memset and copy overwrite d_wtop / h_wtop and an overflow flag not read here would be lost)
@@ -1259,7 +1265,8 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 			}
 			HIPCHK(c, hipEventCreateWithFlags(&c->win_fev[7], hipEventDisableTiming));
 		}
-		HIPCHK(c, hipMemsetAsync(c->d_wtop, 0, 2 * sizeof(unsigned), c->stream));
+		if(plain_jobs)
+			HIPCHK(c, hipMemsetAsync(c->d_wtop, 0, 2 * sizeof(unsigned), c->stream));
 		HIPCHK(c, hipEventRecord(c->win_fev[7], c->stream));
 		size_t at = 0, atw = 0, atv = 0;
 		for(int j = 0; j < nj; ++j) {
@@ -1300,7 +1307,8 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 					HIPCHK(c, hipEventCreate(&tev[q]));
 			HIPCHK(c, hipEventRecord(tev[0], c->stream));
 		}
-		HIPCHK(c, hipMemsetAsync(wtop, 0, 2 * sizeof(unsigned), sc));
+		if(plain_jobs)
+			HIPCHK(c, hipMemsetAsync(wtop, 0, 2 * sizeof(unsigned), sc));
 		size_t at = 0, atw = 0, atv = 0;
 		for(int j = 0; j < nj; ++j) {
 			const Job &b = jobs[j];
@@ -1365,7 +1373,7 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 	// The pool's overflow flag (a bound the host got wrong: voices would lose windows) is never left unread: it is
 	// copied back behind the batch and looked at before the next one's windows are issued - a batch late, but loud
 	// (A2AMD_WIN_CHECK=1, the test suite's setting: at once, with a wait).
-	if(!c->capturing) {
+	if(!c->capturing && plain_jobs) {
 		if(!c->h_wtop) {
 			HIPCHK(c, hipHostMalloc((void **)&c->h_wtop, 4 * sizeof(unsigned), hipHostMallocDefault));
 			memset(c->h_wtop, 0, 4 * sizeof(unsigned));
@@ -1375,11 +1383,11 @@ static int issue_windows(a2amd_ctx *c, const int *const *lists, const int *count
 		HIPCHK(c, hipEventRecord(c->wtop_ev, c->stream));
 		c->wtop_pending = true;
 	}
-	if(c->vm.fused)
+	if(c->vm.fused && !c->vm.spec_use)	// (a pass that met a fault is not taken: vm_issue)
 		if(int r = vm_fused_done(c))
 			return r;
 	static const bool check = getenv("A2AMD_WIN_CHECK") != nullptr;
-	if(check && !c->capturing) {
+	if(check && !c->capturing && plain_jobs) {
 		unsigned top[4] = { 0, 0, 0, 0 };
 		HIPCHK(c, hipMemcpyAsync(top, c->d_wtop, sizeof(top), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -1128,7 +1128,10 @@ int vm_issue(a2amd_ctx *c, bool fused)
 		vp.list = m.d_list.d + m.list.size() + 2 * m.cls_lists.size();
 		vp.n = m.n_other;
 	}
-	HIPCHK(c, hipMemsetAsync(m.d_total, 0, 2 * sizeof(uint32_t), c->stream));
+	// (the count of records and faults: k_vm_count / k_vm_emit and a k_vm_win of this batch's own add to it - a batch
+	// whose class voices took a speculative pass and that has no others runs none of them)
+	if(!(m.spec_use && vp.n == 0))
+		HIPCHK(c, hipMemsetAsync(m.d_total, 0, 2 * sizeof(uint32_t), c->stream));
 	uint64_t batch_frames = 0;
 	for(int f = 0; f < c->nfrags; ++f)
 		batch_frames += c->fragframes[f];

@@ -210,9 +210,14 @@ def test_speculative_vm_pass_is_the_same_audio(tmp_path, program, buffer, spec):
         # ... and a pass that was taken has counted the voices it left to the quiet kernels - none, in these scenes - so
         # the quiet kernel of the class is not launched to find that out (issue_kernels; by default not for the filter
         # class, whose 80 us of k_leaf_oscfiltpan keep an order of kernels that is worth more: DESIGN 2c)
+        # (a 64-frame buffer is one fragment, in which most of these voices - they wake every 3 ms - are left alone:
+        # their quiet kernel has work to do, and whether any batch had none is not this test's to say)
         q = re.search(r"(\d+) quiet-kernel launches not made", err)
         assert q, err[-800:]
-        assert (int(q.group(1)) > 0) == (program == "OscPanScripted"), (program, q.group(0))
+        if buffer >= 1024:
+            assert (int(q.group(1)) > 0) == (program == "OscPanScripted"), (program, q.group(0))
+        elif program != "OscPanScripted":
+            assert int(q.group(1)) == 0, q.group(0)
     # (a 1 000-frame buffer ends in a 40-frame fragment: such a batch is not followed by a pass - but a buffer the drop-in
     # delivers in two pieces may leave a batch of whole fragments, and a pass behind that is as right as any: no claim)
 
