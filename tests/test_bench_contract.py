@@ -72,7 +72,7 @@ def test_bench_refuses_without_gpu():
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
 
 
-@pytest.mark.parametrize("name", ["r06_bench_default_details.json", "r05_bench_default.json", "r05_bench_n_gt_1_path_one_rank.json",
+@pytest.mark.parametrize("name", ["r06_bench_default_details.json", "r06_bench_default_final_library_details.json", "r05_bench_default.json", "r05_bench_n_gt_1_path_one_rank.json",
                                   "r04_bench_cfg5_private_waves.json", "r04_bench_cfg4_all_on_one_gpu.json"])
 def test_contract_line_of_a_full_run_stays_short(name):
     """Round 5's driver record had parsed: null - the line had grown to 24 KB and the driver keeps 8 KB of stdout.
