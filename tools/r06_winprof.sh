@@ -1,5 +1,9 @@
 #!/bin/bash
-# round 6: cycle counters inside k_vm_win (-DWIN_PROF build in build_variants/winprof): where a lane's time goes
+# round 6: cycle counters inside k_vm_win: where a lane's time goes.  Needs a -DWIN_PROF build of the library next to
+# copies of the other two (the variant is not kept in the tree):
+#   mkdir -p build_variants/winprof && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DWIN_PROF \
+#     '-DA2AMD_SRCHASH="winprof"' -o build_variants/winprof/liba2amd.so audiality2_amd/csrc/*.cpp audiality2_amd/csrc/*.hip \
+#     && cp audiality2_amd/liba2amd_units.so audiality2_amd/liba2amd_walk.so build_variants/winprof/
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 V=$PWD/build_variants/winprof
 pre="$V/liba2amd_walk.so $V/liba2amd_units.so"
